@@ -1,0 +1,182 @@
+"""ctypes binding for the simulator C API in sims/common/sim_c_api.h.
+
+The same wrapper drives a simulator built against the MI355X HIP backend
+(``lib<sim>_hip.so``) and one built against the reference CPU backend
+(``oracle/_ref/lib<sim>_ref.so``); only tests/, ``__graft_entry__.smoke`` and
+bench.py's ``cpu_baseline`` leg are allowed to load the latter.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+REPO_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIP_BUILD_DIR = os.path.join(REPO_ROOT, "madrona_amd", "_build")
+REF_BUILD_DIR = os.path.join(REPO_ROOT, "oracle", "_ref")
+
+SIM_DTYPES = {
+    0: np.uint8, 1: np.int8, 2: np.int16, 3: np.int32, 4: np.int64,
+    5: np.float16, 6: np.float32,
+}
+
+
+class SimCreateArgs(C.Structure):
+    _fields_ = [
+        ("num_worlds", C.c_uint32),
+        ("seed", C.c_uint32),
+        ("gpu_id", C.c_int32),
+        ("num_workers", C.c_uint32),
+        ("world_base", C.c_uint32),
+        ("flags", C.c_uint32),
+    ]
+
+
+class SimTensorInfo(C.Structure):
+    _fields_ = [
+        ("name", C.c_char_p),
+        ("dtype", C.c_int32),
+        ("ndim", C.c_int32),
+        ("dims", C.c_int64 * 4),
+        ("on_device", C.c_int32),
+    ]
+
+
+class SimColumnInfo(C.Structure):
+    _fields_ = [
+        ("name", C.c_char_p),
+        ("elem_bytes", C.c_uint32),
+        ("is_float", C.c_int32),
+    ]
+
+
+def hip_lib_path(sim: str) -> str:
+    return os.path.join(HIP_BUILD_DIR, f"lib{sim}_hip.so")
+
+
+def ref_lib_path(sim: str, speed: bool = False) -> str:
+    suffix = "_ref_speed.so" if speed else "_ref.so"
+    return os.path.join(REF_BUILD_DIR, f"lib{sim}{suffix}")
+
+
+def _bind(lib: C.CDLL) -> None:
+    lib.sim_create.restype = C.c_void_p
+    lib.sim_create.argtypes = [C.POINTER(SimCreateArgs)]
+    lib.sim_destroy.argtypes = [C.c_void_p]
+    lib.sim_backend.restype = C.c_char_p
+    lib.sim_backend.argtypes = [C.c_void_p]
+    lib.sim_step.argtypes = [C.c_void_p, C.c_uint32]
+    lib.sim_num_tensors.restype = C.c_uint32
+    lib.sim_num_tensors.argtypes = [C.c_void_p]
+    lib.sim_tensor_info.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(SimTensorInfo)]
+    lib.sim_tensor_ptr.restype = C.c_void_p
+    lib.sim_tensor_ptr.argtypes = [C.c_void_p, C.c_uint32]
+    lib.sim_tensor_read.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64]
+    lib.sim_tensor_write.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64]
+    lib.sim_num_columns.restype = C.c_uint32
+    lib.sim_num_columns.argtypes = [C.c_void_p]
+    lib.sim_column_info.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(SimColumnInfo)]
+    lib.sim_column_dump.restype = C.c_int64
+    lib.sim_column_dump.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64,
+                                    C.POINTER(C.c_int32)]
+    lib.sim_hip_exec.restype = C.c_void_p
+    lib.sim_hip_exec.argtypes = [C.c_void_p]
+
+
+class Simulator:
+    """One simulator instance behind the C API (either backend)."""
+
+    def __init__(self, lib_path: str, num_worlds: int, seed: int = 5,
+                 gpu_id: int = 0, num_workers: int = 1, world_base: int = 0,
+                 flags: int = 0):
+        if not os.path.exists(lib_path):
+            raise FileNotFoundError(
+                f"{lib_path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        mode = C.RTLD_GLOBAL if lib_path.endswith("_hip.so") else C.RTLD_LOCAL
+        self.lib = C.CDLL(lib_path, mode=mode)
+        _bind(self.lib)
+        self.num_worlds = num_worlds
+        args = SimCreateArgs(num_worlds, seed, gpu_id, num_workers, world_base, flags)
+        self.handle = self.lib.sim_create(C.byref(args))
+        if not self.handle:
+            raise RuntimeError(f"sim_create failed for {lib_path}")
+        self.backend = self.lib.sim_backend(self.handle).decode()
+        self._tensor_info: Dict[str, Tuple[int, np.dtype, Tuple[int, ...], bool]] = {}
+        for i in range(self.lib.sim_num_tensors(self.handle)):
+            info = SimTensorInfo()
+            self.lib.sim_tensor_info(self.handle, i, C.byref(info))
+            dims = tuple(int(info.dims[k]) for k in range(info.ndim))
+            self._tensor_info[info.name.decode()] = (
+                i, np.dtype(SIM_DTYPES[info.dtype]), dims, bool(info.on_device))
+        self._columns: List[Tuple[str, int, bool]] = []
+        for i in range(self.lib.sim_num_columns(self.handle)):
+            ci = SimColumnInfo()
+            self.lib.sim_column_info(self.handle, i, C.byref(ci))
+            self._columns.append((ci.name.decode(), int(ci.elem_bytes), bool(ci.is_float)))
+
+    # -- lifecycle ---------------------------------------------------------
+    def close(self) -> None:
+        if self.handle:
+            self.lib.sim_destroy(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def step(self, n: int = 1) -> None:
+        self.lib.sim_step(self.handle, n)
+
+    # -- tensors -----------------------------------------------------------
+    @property
+    def tensor_names(self) -> List[str]:
+        return list(self._tensor_info.keys())
+
+    def tensor_meta(self, name: str):
+        return self._tensor_info[name]
+
+    def tensor_ptr(self, name: str) -> int:
+        return int(self.lib.sim_tensor_ptr(self.handle, self._tensor_info[name][0]))
+
+    def read_tensor(self, name: str) -> np.ndarray:
+        idx, dtype, dims, _ = self._tensor_info[name]
+        out = np.empty(dims, dtype=dtype)
+        rc = self.lib.sim_tensor_read(self.handle, idx, out.ctypes.data, out.nbytes)
+        if rc != 0:
+            raise RuntimeError(f"sim_tensor_read({name}) -> {rc}")
+        return out
+
+    def write_tensor(self, name: str, value: np.ndarray) -> None:
+        idx, dtype, dims, _ = self._tensor_info[name]
+        arr = np.ascontiguousarray(value, dtype=dtype).reshape(dims)
+        rc = self.lib.sim_tensor_write(self.handle, idx, arr.ctypes.data, arr.nbytes)
+        if rc != 0:
+            raise RuntimeError(f"sim_tensor_write({name}) -> {rc}")
+
+    # -- parity dumps ------------------------------------------------------
+    @property
+    def columns(self) -> List[Tuple[str, int, bool]]:
+        return list(self._columns)
+
+    def dump_column(self, idx: int, max_rows_per_world: int = 256):
+        name, elem_bytes, is_float = self._columns[idx]
+        cap = self.num_worlds * max_rows_per_world * elem_bytes
+        buf = np.empty(cap, dtype=np.uint8)
+        counts = np.zeros(self.num_worlds, dtype=np.int32)
+        n = self.lib.sim_column_dump(
+            self.handle, idx, buf.ctypes.data, buf.nbytes,
+            counts.ctypes.data_as(C.POINTER(C.c_int32)))
+        if n < 0:
+            raise RuntimeError(f"sim_column_dump({name}) -> {n}")
+        return buf[: n * elem_bytes].reshape(n, elem_bytes).copy(), counts
+
+    def dump_all(self, max_rows_per_world: int = 256):
+        return {self._columns[i][0]: self.dump_column(i, max_rows_per_world)
+                for i in range(len(self._columns))}
+
+    def hip_exec(self) -> int:
+        return int(self.lib.sim_hip_exec(self.handle) or 0)

@@ -1,0 +1,314 @@
+// Shared implementation of sims/common/sim_c_api.h.
+//
+// A simulator's mgr.cpp defines `struct SimTraits` (types, tensor list, dump
+// list) and then includes this file.  Compiled twice:
+//   -DSIM_BACKEND_REF_CPU  -> reference madrona::TaskGraphExecutor (the oracle;
+//                             reference include/madrona/mw_cpu.hpp:73-110)
+//   otherwise              -> madrona::MWCudaExecutor as provided by
+//                             madrona_amd's <madrona/mw_gpu.hpp> (HIP backend;
+//                             mirrors reference include/madrona/mw_gpu.hpp:98-164)
+// The Manager code below is deliberately written the way the reference's
+// simulators write theirs (StateConfig{...}, buildLaunchGraphAllTaskGraphs,
+// run, getExported) so it doubles as the "links unchanged" check.
+#pragma once
+
+#include "sim_c_api.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#ifdef SIM_BACKEND_REF_CPU
+#include <madrona/mw_cpu.hpp>
+#else
+#include <madrona/mw_gpu.hpp>
+#include <mwhip.h>
+#endif
+
+namespace simmgr {
+
+struct TensorDesc {
+    std::string name;
+    int32_t dtype;
+    std::vector<int64_t> dims;
+    uint32_t slot;
+};
+
+static inline uint64_t dtypeBytes(int32_t dtype)
+{
+    switch (dtype) {
+    case SIM_U8: case SIM_I8: return 1;
+    case SIM_I16: case SIM_F16: return 2;
+    case SIM_I32: case SIM_F32: return 4;
+    case SIM_I64: return 8;
+    default: return 0;
+    }
+}
+
+#ifdef SIM_BACKEND_REF_CPU
+using DumpFn = std::pair<void *, uint32_t> (*)(madrona::StateManager &,
+                                                uint32_t world);
+#endif
+
+struct ColumnDesc {
+    std::string name;
+    uint32_t elemBytes;
+    int32_t isFloat;
+#ifdef SIM_BACKEND_REF_CPU
+    DumpFn fn;
+#else
+    uint32_t archetypeID;
+    uint32_t componentID;
+#endif
+};
+
+struct ColumnList {
+    std::vector<ColumnDesc> cols;
+
+    template <typename ArchetypeT, typename ComponentT>
+    void add(const char *name, bool is_float)
+    {
+        ColumnDesc d;
+        d.name = name;
+        d.elemBytes = (uint32_t)sizeof(ComponentT);
+        d.isFloat = is_float ? 1 : 0;
+#ifdef SIM_BACKEND_REF_CPU
+        d.fn = [](madrona::StateManager &mgr, uint32_t world)
+                -> std::pair<void *, uint32_t> {
+            if constexpr (std::is_same_v<ComponentT, madrona::Entity>) {
+                auto *ptr = mgr.getWorldEntities<ArchetypeT>(world);
+                auto n = mgr.numRows<ArchetypeT>(world);
+                return { (void *)ptr, (uint32_t)n };
+            } else {
+                auto [ptr, n] = mgr.getWorldComponentsAndCount<
+                    ArchetypeT, ComponentT>(world);
+                return { (void *)ptr, n };
+            }
+        };
+#else
+        d.archetypeID = madrona::TypeTracker::typeID<ArchetypeT>();
+        d.componentID = madrona::TypeTracker::typeID<ComponentT>();
+#endif
+        cols.push_back(std::move(d));
+    }
+};
+
+}
+
+struct SimHandle {
+    using Traits = SimTraits;
+    using Sim = typename Traits::Sim;
+    using Engine = typename Traits::Engine;
+    using Config = typename Sim::Config;
+    using WorldInit = typename Sim::WorldInit;
+
+    uint32_t numWorlds;
+    std::vector<simmgr::TensorDesc> tensors;
+    simmgr::ColumnList columns;
+
+#ifdef SIM_BACKEND_REF_CPU
+    using Exec = madrona::TaskGraphExecutor<Engine, Sim, Config, WorldInit>;
+    Exec *exec;
+#else
+    madrona::MWCudaExecutor *exec;
+    madrona::MWCudaLaunchGraph *stepGraph;
+#endif
+};
+
+extern "C" {
+
+SimHandle *sim_create(const SimCreateArgs *args)
+{
+    using Traits = SimTraits;
+    using Sim = typename Traits::Sim;
+    using Config = typename Sim::Config;
+    using WorldInit = typename Sim::WorldInit;
+
+    SimHandle *h = new SimHandle {};
+    h->numWorlds = args->num_worlds;
+
+    Config cfg = Traits::makeConfig(*args);
+    std::vector<WorldInit> inits(args->num_worlds);
+    Traits::makeInits(*args, inits.data());
+
+#ifdef SIM_BACKEND_REF_CPU
+    h->exec = new SimHandle::Exec(
+        madrona::ThreadPoolExecutor::Config {
+            .numWorlds = args->num_worlds,
+            .numExportedBuffers = Traits::numExports,
+            .numWorkers = args->num_workers,
+        },
+        cfg, inits.data(), Traits::numTaskGraphs);
+#else
+    auto ctx = madrona::MWCudaExecutor::initCUDA(args->gpu_id);
+
+    h->exec = new madrona::MWCudaExecutor({
+        .worldInitPtr = inits.data(),
+        .numWorldInitBytes = (uint32_t)sizeof(WorldInit),
+        .userConfigPtr = (void *)&cfg,
+        .numUserConfigBytes = (uint32_t)sizeof(Config),
+        .numWorldDataBytes = (uint32_t)sizeof(Sim),
+        .worldDataAlignment = (uint32_t)alignof(Sim),
+        .numWorlds = args->num_worlds,
+        .numTaskGraphs = Traits::numTaskGraphs,
+        .numExportedBuffers = Traits::numExports,
+    }, {
+        {}, {}, madrona::CompileConfig::OptMode::LTO,
+    }, ctx);
+
+    h->stepGraph = new madrona::MWCudaLaunchGraph(
+        h->exec->buildLaunchGraphAllTaskGraphs());
+#endif
+
+    Traits::describeTensors(h->tensors, args->num_worlds);
+    Traits::describeColumns(h->columns);
+
+    return h;
+}
+
+void sim_destroy(SimHandle *h)
+{
+    if (!h) return;
+#ifndef SIM_BACKEND_REF_CPU
+    delete h->stepGraph;
+#endif
+    delete h->exec;
+    delete h;
+}
+
+const char *sim_backend(SimHandle *)
+{
+#ifdef SIM_BACKEND_REF_CPU
+    return "ref_cpu";
+#else
+    return "hip";
+#endif
+}
+
+void sim_step(SimHandle *h, uint32_t num_steps)
+{
+    for (uint32_t i = 0; i < num_steps; i++) {
+#ifdef SIM_BACKEND_REF_CPU
+        h->exec->run();
+#else
+        h->exec->run(*h->stepGraph);
+#endif
+    }
+}
+
+uint32_t sim_num_tensors(SimHandle *h)
+{
+    return (uint32_t)h->tensors.size();
+}
+
+int sim_tensor_info(SimHandle *h, uint32_t idx, SimTensorInfo *out)
+{
+    if (idx >= h->tensors.size()) return -1;
+    const auto &t = h->tensors[idx];
+    out->name = t.name.c_str();
+    out->dtype = t.dtype;
+    out->ndim = (int32_t)t.dims.size();
+    for (int i = 0; i < 4; i++) {
+        out->dims[i] = i < (int)t.dims.size() ? t.dims[i] : 1;
+    }
+#ifdef SIM_BACKEND_REF_CPU
+    out->on_device = 0;
+#else
+    out->on_device = 1;
+#endif
+    return 0;
+}
+
+void *sim_tensor_ptr(SimHandle *h, uint32_t idx)
+{
+    if (idx >= h->tensors.size()) return nullptr;
+    return h->exec->getExported(h->tensors[idx].slot);
+}
+
+static uint64_t simTensorBytes(const simmgr::TensorDesc &t)
+{
+    uint64_t n = simmgr::dtypeBytes(t.dtype);
+    for (int64_t d : t.dims) n *= (uint64_t)d;
+    return n;
+}
+
+int sim_tensor_read(SimHandle *h, uint32_t idx, void *dst, uint64_t num_bytes)
+{
+    if (idx >= h->tensors.size()) return -1;
+    if (num_bytes > simTensorBytes(h->tensors[idx])) return -2;
+    void *src = sim_tensor_ptr(h, idx);
+#ifdef SIM_BACKEND_REF_CPU
+    memcpy(dst, src, num_bytes);
+    return 0;
+#else
+    return mwhip_memcpy_d2h(dst, src, num_bytes);
+#endif
+}
+
+int sim_tensor_write(SimHandle *h, uint32_t idx, const void *src,
+                     uint64_t num_bytes)
+{
+    if (idx >= h->tensors.size()) return -1;
+    if (num_bytes > simTensorBytes(h->tensors[idx])) return -2;
+    void *dst = sim_tensor_ptr(h, idx);
+#ifdef SIM_BACKEND_REF_CPU
+    memcpy(dst, src, num_bytes);
+    return 0;
+#else
+    return mwhip_memcpy_h2d(dst, src, num_bytes);
+#endif
+}
+
+uint32_t sim_num_columns(SimHandle *h)
+{
+    return (uint32_t)h->columns.cols.size();
+}
+
+int sim_column_info(SimHandle *h, uint32_t idx, SimColumnInfo *out)
+{
+    if (idx >= h->columns.cols.size()) return -1;
+    const auto &c = h->columns.cols[idx];
+    out->name = c.name.c_str();
+    out->elem_bytes = c.elemBytes;
+    out->is_float = c.isFloat;
+    return 0;
+}
+
+int64_t sim_column_dump(SimHandle *h, uint32_t idx, void *dst,
+                        uint64_t dst_bytes, int32_t *world_counts)
+{
+    if (idx >= h->columns.cols.size()) return -1;
+    const auto &c = h->columns.cols[idx];
+#ifdef SIM_BACKEND_REF_CPU
+    madrona::StateManager &mgr = *h->exec->getWorldContext(0).getStateManager();
+    uint64_t off = 0;
+    int64_t total = 0;
+    for (uint32_t w = 0; w < h->numWorlds; w++) {
+        auto [ptr, n] = c.fn(mgr, w);
+        uint64_t nb = (uint64_t)n * c.elemBytes;
+        if (off + nb > dst_bytes) return -2;
+        memcpy((char *)dst + off, ptr, nb);
+        off += nb;
+        total += n;
+        world_counts[w] = (int32_t)n;
+    }
+    return total;
+#else
+    return mwhip_dump_column(h->exec->handle(), c.archetypeID, c.componentID,
+                             dst, dst_bytes, world_counts);
+#endif
+}
+
+void *sim_hip_exec(SimHandle *h)
+{
+#ifdef SIM_BACKEND_REF_CPU
+    (void)h;
+    return nullptr;
+#else
+    return (void *)h->exec->handle();
+#endif
+}
+
+}

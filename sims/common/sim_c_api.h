@@ -1,0 +1,70 @@
+/* C API every synthetic simulator in sims/ exposes, identically, from
+ *   (a) oracle/_ref/lib<sim>_ref.so   -- linked against the REFERENCE CPU backend
+ *       (madrona::TaskGraphExecutor, reference include/madrona/mw_cpu.hpp:73-110)
+ *   (b) madrona_amd/_build/lib<sim>_hip.so -- linked against libmadrona_hip.so
+ *       (madrona::MWHipExecutor, the MI355X backend).
+ * Tests / bench.py load both with ctypes and diff what they return.
+ */
+#pragma once
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct SimHandle SimHandle;
+
+typedef struct SimCreateArgs {
+    uint32_t num_worlds;
+    uint32_t seed;
+    int32_t gpu_id;          /* HIP backend only */
+    uint32_t num_workers;    /* reference CPU backend only; 1 => bit-exact ids */
+    uint32_t world_base;     /* global index of local world 0 (multi-GPU sharding) */
+    uint32_t flags;          /* simulator specific */
+} SimCreateArgs;
+
+/* dtype codes follow madrona::py::TensorElementType
+ * (reference include/madrona/py/utils.hpp:58-66) */
+enum { SIM_U8 = 0, SIM_I8 = 1, SIM_I16 = 2, SIM_I32 = 3, SIM_I64 = 4,
+       SIM_F16 = 5, SIM_F32 = 6 };
+
+typedef struct SimTensorInfo {
+    const char *name;
+    int32_t dtype;
+    int32_t ndim;
+    int64_t dims[4];
+    int32_t on_device;   /* 1: ptr is a device pointer */
+} SimTensorInfo;
+
+typedef struct SimColumnInfo {
+    const char *name;        /* "Archetype.Component" */
+    uint32_t elem_bytes;
+    int32_t is_float;        /* 1: compare with fp tolerance, 0: bit exact */
+} SimColumnInfo;
+
+SimHandle *sim_create(const SimCreateArgs *args);
+void sim_destroy(SimHandle *h);
+const char *sim_backend(SimHandle *h);     /* "ref_cpu" | "hip" */
+void sim_step(SimHandle *h, uint32_t num_steps);
+
+uint32_t sim_num_tensors(SimHandle *h);
+int sim_tensor_info(SimHandle *h, uint32_t slot, SimTensorInfo *out);
+void *sim_tensor_ptr(SimHandle *h, uint32_t slot);
+/* copy tensor `slot` to / from host memory regardless of backend */
+int sim_tensor_read(SimHandle *h, uint32_t slot, void *dst, uint64_t num_bytes);
+int sim_tensor_write(SimHandle *h, uint32_t slot, const void *src, uint64_t num_bytes);
+
+/* Parity dumps: column idx of the registered dump list
+ * copied to host, rows grouped by world in world order; world_counts[w] rows
+ * for world w.  Returns total rows, or -1 on error / -2 if dst is too small. */
+uint32_t sim_num_columns(SimHandle *h);
+int sim_column_info(SimHandle *h, uint32_t idx, SimColumnInfo *out);
+int64_t sim_column_dump(SimHandle *h, uint32_t idx, void *dst, uint64_t dst_bytes,
+                        int32_t *world_counts);
+
+/* HIP backend only (NULL/0 on the reference): opaque mwhip_exec* for profiling */
+void *sim_hip_exec(SimHandle *h);
+
+#ifdef __cplusplus
+}
+#endif
