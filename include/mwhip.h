@@ -1,0 +1,206 @@
+/* mwhip.h -- C ABI of libmadrona_hip.so, the MI355X (gfx950) many-world ECS
+ * task-graph backend.
+ *
+ * The reference has no FFI for this path: its boundary is the C++ class
+ * madrona::MWCudaExecutor (reference include/madrona/mw_gpu.hpp:98-164) plus
+ * device code that it JIT-compiles with NVRTC.  This header is the C-ABI that
+ * a maintainer would bind instead; madrona_amd/include/madrona/mw_gpu.hpp is a
+ * header-only C++ shim over it with the reference's class/method names, so
+ * existing simulators compile unchanged.  Every entry point cites the
+ * reference interface it replaces.
+ *
+ * Conventions: plain pointers and sizes only; functions returning int return
+ * 0 on success and a negative code on error (the reference aborts through
+ * FATAL()/REQ_CUDA(); the C++ shim restores that behaviour by aborting on a
+ * non-zero code).  One executor drives one GPU from one host thread.
+ */
+#ifndef MWHIP_H
+#define MWHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MWHIP_ABI_VERSION 1u
+
+typedef struct mwhip_exec mwhip_exec; /* opaque; == MWCudaExecutor::Impl */
+
+/* == madrona::StateConfig (reference include/madrona/mw_gpu.hpp:25-51), POD,
+ * plus the gpu id that MWCudaExecutor::initCUDA(gpu_id) (:104) selected. */
+typedef struct mwhip_state_config {
+    const void *world_init_ptr;     /* host: num_worlds * num_world_init_bytes */
+    uint32_t num_world_init_bytes;
+    const void *user_config_ptr;    /* host */
+    uint32_t num_user_config_bytes;
+    uint32_t num_world_data_bytes;
+    uint32_t world_data_alignment;
+    uint32_t num_worlds;
+    uint32_t num_task_graphs;
+    uint32_t num_exported_buffers;
+    int32_t gpu_id;
+} mwhip_state_config;
+
+/* What the simulator's offline-compiled HIP translation unit hands to the
+ * executor.  Replaces CompileConfig::userSources + the three entry kernels
+ * instantiated by MADRONA_BUILD_MWGPU_ENTRY (reference
+ * src/mw/device/include/madrona/mw_gpu_entry.hpp:12-91).  registerTypes and
+ * setupTasks run on the HOST here (they only describe types and graph
+ * topology); world constructors run on the device. */
+typedef struct mwhip_user_entry {
+    uint32_t abi_version;
+    /* calls WorldT::registerTypes(ECSRegistry&, cfg) -> mwhip_register_* */
+    void (*register_types)(mwhip_exec *exec, const void *user_cfg_host);
+    /* calls WorldT::setupTasks(TaskGraphManager&, cfg) -> mwhip_tg_add_node */
+    void (*setup_tasks)(mwhip_exec *exec, const void *user_cfg_host);
+    /* host stub of __global__ void(ecs_state*, const void *cfg_dev,
+     *   const void *inits_dev, int32_t num_worlds): placement-new of
+     *   WorldT(ctx, cfg, init[w]) for one world per thread
+     *   (== entryKernels::initWorlds, mw_gpu_entry.hpp:37-56) */
+    const void *init_worlds_kernel;
+    /* stores the device ecs_state pointer into the user module's
+     * __device__ global (== GPUImplConsts::get().stateManagerAddr) */
+    void (*bind_device_state)(void *ecs_state_dev);
+} mwhip_user_entry;
+
+/* MWCudaExecutor::MWCudaExecutor(state_cfg, compile_cfg, cu_ctx)
+ * (reference src/mw/cuda_exec.cpp:2333-2420): allocates the ECS, runs
+ * registerTypes, constructs all worlds on the device, runs setupTasks. */
+int mwhip_create(const mwhip_state_config *cfg, const mwhip_user_entry *entry,
+                 mwhip_exec **out);
+/* MWCudaExecutor::~MWCudaExecutor (cuda_exec.cpp:2484-2530) */
+void mwhip_destroy(mwhip_exec *exec);
+/* last error text for this thread ("" if none) */
+const char *mwhip_last_error(void);
+
+/* ---- ECS registry: StateManager::register* ------------------------------
+ * reference src/mw/device/state.cpp:154-378, device state.inl:7-158 */
+int mwhip_register_component(mwhip_exec *exec, uint32_t component_id,
+                             uint32_t alignment, uint32_t num_bytes);
+/* bundle ids carry bit 31 (reference state.hpp:197); nested bundles are
+ * flattened in place */
+int mwhip_register_bundle(mwhip_exec *exec, uint32_t bundle_id,
+                          const uint32_t *component_ids, uint32_t num_components);
+int mwhip_register_archetype(mwhip_exec *exec, uint32_t archetype_id,
+                             const uint32_t *component_ids,
+                             const uint32_t *component_flags, /* may be NULL */
+                             uint32_t num_components, uint32_t archetype_flags,
+                             uint32_t max_num_entities_per_world);
+/* registerSingleton<T>: archetype with one row per world, entity ids assigned
+ * in world order (reference device state.inl:136-151, CPU state.inl:163-179) */
+int mwhip_register_singleton(mwhip_exec *exec, uint32_t archetype_id,
+                             uint32_t component_id);
+/* ECSRegistry::exportColumn (registry.inl:47-51): returns the device address
+ * of the column, stable for the executor's lifetime, also stored in `slot` */
+void *mwhip_export_column(mwhip_exec *exec, uint32_t archetype_id,
+                          uint32_t component_id, int32_t slot);
+/* StateManager::makeQuery (device/state.cpp:380-440): appends
+ * [archetype, col idx per component]* to the query table; returns its offset */
+int mwhip_make_query(mwhip_exec *exec, const uint32_t *component_ids,
+                     uint32_t num_components, uint32_t *offset_out,
+                     uint32_t *num_matching_out);
+/* address of the device-resident ecs_state (valid after mwhip_create's
+ * register phase) and of per-world user data */
+void *mwhip_device_state(mwhip_exec *exec);
+void *mwhip_world_data(mwhip_exec *exec, uint32_t world_idx);
+uint32_t mwhip_num_worlds(const mwhip_exec *exec);
+uint32_t mwhip_num_task_graphs(const mwhip_exec *exec);
+
+/* ---- task graph: TaskGraph::Builder -------------------------------------
+ * reference src/mw/device/taskgraph_utils.cpp:30-146 + taskgraph.inl:59-111 */
+enum mwhip_node_kind {
+    MWHIP_NODE_KERNEL = 0,        /* user/system kernel: ParallelFor, custom node */
+    MWHIP_NODE_SORT_ARCHETYPE = 1,/* SortArchetypeNode<A,C> (sort_archetype.cpp) */
+    MWHIP_NODE_CLEAR_TMP = 2,     /* ClearTmpNode<A> (taskgraph_utils.cpp:171-190) */
+    MWHIP_NODE_RESET_TMP_ALLOC = 3,/* ResetTmpAllocNode (:216-230) */
+    MWHIP_NODE_RECYCLE = 4        /* RecycleEntitiesNode (:192-214); no-op here */
+};
+
+enum mwhip_count_mode {
+    MWHIP_COUNT_QUERY_ROWS = 0,   /* one invocation per row of the query's tables */
+    MWHIP_COUNT_FIXED = 1,        /* fixed_count invocations */
+    MWHIP_COUNT_PER_WORLD = 2     /* one invocation per world */
+};
+
+typedef struct mwhip_node_desc {
+    uint32_t kind;
+    const char *name;             /* for profiles; copied */
+    /* MWHIP_NODE_KERNEL: host stub of
+     *   __global__ void(ecs_state*, void *node_data_dev, uint32_t a0, uint32_t a1) */
+    const void *kernel;
+    int32_t node_data_id;         /* from mwhip_tg_add_node_data, or -1 */
+    uint32_t arg0, arg1;
+    uint32_t count_mode;
+    uint32_t fixed_count;
+    uint32_t threads_per_invocation;
+    uint32_t query_offset;        /* MWHIP_COUNT_QUERY_ROWS */
+    uint32_t num_matching;
+    uint32_t bytes_per_row;       /* algorithmic bytes for rooflines */
+    /* SORT / CLEAR_TMP */
+    uint32_t archetype_id;
+    uint32_t component_id;
+} mwhip_node_desc;
+
+/* TaskGraph::Builder::constructNodeData (taskgraph.inl:43-57): copies a node
+ * data block (<= 256 B) to the device; several nodes may share one block.
+ * Returns the data id >= 0 or a negative error. */
+int32_t mwhip_tg_add_node_data(mwhip_exec *exec, uint32_t taskgraph_id,
+                               const void *data, uint32_t num_bytes);
+/* device address of a node data block (TaskGraph::getNodeData) */
+void *mwhip_tg_node_data(mwhip_exec *exec, uint32_t taskgraph_id, int32_t data_id);
+/* TaskGraph::Builder::registerNode (taskgraph_utils.cpp:30-72).  Nodes are
+ * ordered with the reference's own "first unqueued node whose dependencies
+ * are queued" rule (taskgraph_utils.cpp:74-146).  Returns node id >= 0. */
+int32_t mwhip_tg_add_node(mwhip_exec *exec, uint32_t taskgraph_id,
+                          const mwhip_node_desc *desc, const int32_t *deps,
+                          uint32_t num_deps);
+
+/* ---- execution ----------------------------------------------------------*/
+/* MWCudaExecutor::buildLaunchGraph(Span<const uint32_t>, stat_name)
+ * (cuda_exec.cpp:2174-2292): captures one hipGraph running the given task
+ * graphs back to back.  graph_out is a handle owned by the executor. */
+int mwhip_build_launch_graph(mwhip_exec *exec, const uint32_t *taskgraph_ids,
+                             uint32_t num_taskgraphs, const char *stat_name,
+                             uint64_t *graph_out);
+void mwhip_free_launch_graph(mwhip_exec *exec, uint64_t graph);
+/* MWCudaExecutor::run (cuda_exec.cpp:2756-2794): synchronous */
+int mwhip_run(mwhip_exec *exec, uint64_t graph);
+/* MWCudaExecutor::runAsync (:2796-2800) */
+int mwhip_run_async(mwhip_exec *exec, uint64_t graph, void *hip_stream);
+/* the executor's private stream (cu::makeStream, cuda_exec.cpp:2342) */
+void *mwhip_stream(mwhip_exec *exec);
+/* MWCudaExecutor::getExported (cuda_exec.cpp:2802-2805) */
+void *mwhip_get_exported(const mwhip_exec *exec, uint32_t slot);
+
+/* ---- introspection for parity dumps / measurement (new) ----------------- */
+int32_t mwhip_num_rows(mwhip_exec *exec, uint32_t archetype_id);
+/* Copies column `component_id` of `archetype_id`, rows grouped by world in
+ * world order (== concatenating the reference CPU backend's per-world
+ * tables, state.inl:368-377); world_counts[num_worlds] receives rows/world.
+ * Returns total rows, -1 on error, -2 if dst is too small. */
+int64_t mwhip_dump_column(mwhip_exec *exec, uint32_t archetype_id,
+                          uint32_t component_id, void *dst, uint64_t dst_bytes,
+                          int32_t *world_counts);
+int mwhip_memcpy_d2h(void *dst_host, const void *src_dev, uint64_t num_bytes);
+int mwhip_memcpy_h2d(void *dst_dev, const void *src_host, uint64_t num_bytes);
+
+/* Per-kernel timing with HIP events on the executor's stream (replaces the
+ * reference's device tracing, mw_gpu/tracing.hpp).  Runs the launch graph's
+ * kernels eagerly `reps` times with an event pair around every kernel. */
+typedef struct mwhip_kernel_stat {
+    const char *name;       /* node name + kernel role, owned by the executor */
+    uint32_t node_kind;
+    uint32_t archetype_id;
+    double avg_us;          /* mean duration of this kernel per step */
+    double algo_bytes;      /* mean algorithmic bytes per launch */
+    double rows;            /* mean rows / invocations processed per launch */
+} mwhip_kernel_stat;
+int32_t mwhip_profile(mwhip_exec *exec, uint64_t graph, uint32_t reps,
+                      mwhip_kernel_stat *out, uint32_t max_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MWHIP_H */

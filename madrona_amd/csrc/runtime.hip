@@ -1,0 +1,1713 @@
+// libmadrona_hip.so -- host runtime of the MI355X many-world ECS backend.
+// Implements the C ABI declared in include/mwhip.h.
+//
+// Replaces, for the hot path only, the reference's GPU executor host side
+// (src/mw/cuda_exec.cpp: state allocation :1721-1948, graph build :2174-2292,
+// run :2756-2794) and the device-side registry / task-graph builder
+// (src/mw/device/state.cpp:154-440, taskgraph_utils.cpp:30-146).  There is no
+// runtime compiler, no megakernel and no host<->device mailbox: registration
+// and graph construction are host code, every node is its own kernel, and a
+// step is one hipGraph replay on the executor's private stream.
+#include "runtime_internal.hpp"
+
+#include <cinttypes>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <unordered_map>
+
+using namespace madrona;
+using namespace madrona::mwhip;
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static thread_local std::string g_lastError;
+
+static int fail(int code, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_lastError = buf;
+    if (getenv("MADRONA_MWHIP_VERBOSE") != nullptr) {
+        fprintf(stderr, "[mwhip] error %d: %s\n", code, buf);
+    }
+    return code;
+}
+
+#define HIPCHK(expr) \
+    do { \
+        hipError_t hipchk_res_ = (expr); \
+        if (hipchk_res_ != hipSuccess) { \
+            return fail(-10, "%s -> %s (%s:%d)", #expr, \
+                hipGetErrorString(hipchk_res_), __FILE__, __LINE__); \
+        } \
+    } while (0)
+
+static uint32_t envU32(const char *name, uint32_t fallback)
+{
+    const char *v = getenv(name);
+    if (v == nullptr || *v == '\0') return fallback;
+    return (uint32_t)strtoul(v, nullptr, 10);
+}
+
+// ---------------------------------------------------------------------------
+// small device kernels owned by the runtime
+// ---------------------------------------------------------------------------
+namespace {
+
+enum MiscOpKind : uint32_t { kOpClearTmp = 0, kOpResetTmpAlloc = 1 };
+
+struct MiscOp {
+    uint32_t kind;
+    uint32_t archetype;
+};
+
+// ClearTmpNode / ResetTmpAllocNode (reference taskgraph_utils.cpp:171-230):
+// a handful of scalar stores; consecutive ones share one launch.
+__global__ void miscOpsKernel(EcsState *S, const MiscOp *ops, uint32_t num_ops)
+{
+    uint32_t i = threadIdx.x;
+    if (i >= num_ops) return;
+
+    MiscOp op = ops[i];
+    if (op.kind == kOpClearTmp) {
+        TableHdr &tbl = S->tables[op.archetype];
+        if (tbl.numRows != 0) {
+            tbl.needsSort = 1u;
+        }
+        tbl.numRows = 0;
+    } else if (op.kind == kOpResetTmpAlloc) {
+        S->tmpOffset = 0ull;
+    }
+}
+
+// Holds the stream until the host flips a flag in pinned memory, so that a
+// whole step's kernels + timing events can be queued behind it and then run
+// back to back on the device (per-kernel event deltas would otherwise mostly
+// measure the host's launch rate).
+__global__ void gateKernel(int32_t *host_flag)
+{
+    if (threadIdx.x != 0) return;
+    for (uint32_t spins = 0; spins < (1u << 22); spins++) {
+        if (__hip_atomic_load(host_flag, __ATOMIC_RELAXED,
+                              __HIP_MEMORY_SCOPE_SYSTEM) != 0) {
+            break;
+        }
+        __builtin_amdgcn_s_sleep(32);
+    }
+}
+
+// End-of-graph health record written straight into pinned host memory.
+__global__ void statsKernel(EcsState *S, int32_t *host_out)
+{
+    uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a < S->numArchetypeSlots) {
+        host_out[2 + a] = S->tables[a].registered ? S->tables[a].numRows : -1;
+    }
+    if (a == 0) {
+        host_out[0] = (int32_t)S->errorFlags;
+        host_out[1] = S->numIds;
+    }
+}
+
+}
+
+// ---------------------------------------------------------------------------
+// executor
+// ---------------------------------------------------------------------------
+struct ComponentRec {
+    bool registered = false;
+    uint32_t alignment = 0;
+    uint32_t bytes = 0;
+};
+
+struct ArchetypeRec {
+    bool registered = false;
+    uint32_t id = 0;
+    std::vector<uint32_t> comps;        // flattened user components
+    uint32_t flags = 0;
+    uint32_t maxPerWorld = 0;
+    bool singleton = false;
+    int32_t singletonOrdinal = -1;
+    uint32_t capacity = 0;
+    uint32_t numColumns = 0;
+    uint32_t rowBytes = 0;
+    std::vector<void *> primary;
+    std::vector<void *> alt;
+    std::vector<uint32_t> colBytes;
+    std::vector<uint32_t> colFlags;
+    std::vector<uint32_t> colComponent;
+    int32_t *worldOffsets = nullptr;
+    int32_t *worldCounts = nullptr;
+    // sort scratch (allocated on first use)
+    SortState *sortState = nullptr;
+    uint32_t *keysA = nullptr, *keysB = nullptr;
+    int32_t *idxA = nullptr, *idxB = nullptr;
+    unsigned long long *lookback = nullptr;
+};
+
+struct QueryRec {
+    std::vector<uint32_t> comps;
+    uint32_t offset;
+    uint32_t numMatching;
+};
+
+struct NodeRec {
+    mwhip_node_desc desc;
+    std::string name;
+    std::vector<int32_t> deps;
+};
+
+struct TaskGraphRec {
+    std::vector<NodeRec> nodes;
+    std::vector<void *> dataDev;
+    std::vector<int32_t> sorted;
+    bool built = false;
+};
+
+struct LaunchGraph {
+    std::vector<KernelLaunch> launches;
+    std::vector<std::unique_ptr<SortBatch>> sortBatches;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graphExec = nullptr;
+    std::string statName;
+    std::vector<std::string> statNames;     // backing store for mwhip_kernel_stat::name
+};
+
+struct mwhip_exec {
+    mwhip_state_config cfg {};
+    mwhip_user_entry entry {};
+    hipStream_t stream = nullptr;
+
+    std::vector<ComponentRec> components;
+    std::vector<ArchetypeRec> archetypes;
+    std::unordered_map<uint32_t, std::vector<uint32_t>> bundles;
+    std::vector<QueryRec> queries;
+    std::vector<uint32_t> queryDataHost;
+    uint32_t queryCapacity = 1u << 16;      // reference state.hpp:207
+    uint32_t numSingletons = 0;
+    bool registrationOpen = false;
+    bool stateBuilt = false;
+
+    std::vector<void *> exported;
+
+    EcsState hostState {};
+    EcsState *stateDev = nullptr;
+    std::vector<TableHdr> tablesHost;
+    uint32_t singletonIdEnd = 0;            // rounded up to a block of 64
+
+    void *userCfgDev = nullptr;
+    void *worldInitsDev = nullptr;
+
+    std::vector<TaskGraphRec> taskGraphs;
+    std::unordered_map<uint64_t, std::unique_ptr<LaunchGraph>> launchGraphs;
+    uint64_t nextGraphHandle = 1;
+
+    int32_t *statsHost = nullptr;           // pinned, device-visible
+    std::vector<void *> allocations;
+    bool checkAfterRun = true;
+    bool sortBatching = true;
+};
+
+static int devAlloc(mwhip_exec *exec, void **out, size_t bytes, bool zero = true)
+{
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (bytes == 0) bytes = 256;
+    HIPCHK(hipMalloc(out, bytes));
+    exec->allocations.push_back(*out);
+    if (zero) {
+        HIPCHK(hipMemset(*out, 0, bytes));
+    }
+    return 0;
+}
+
+template <typename T>
+static int devAllocT(mwhip_exec *exec, T **out, size_t count, bool zero = true)
+{
+    return devAlloc(exec, (void **)out, count * sizeof(T), zero);
+}
+
+// ---------------------------------------------------------------------------
+// registry
+// ---------------------------------------------------------------------------
+extern "C" const char *mwhip_last_error(void)
+{
+    return g_lastError.c_str();
+}
+
+extern "C" int mwhip_register_component(mwhip_exec *exec, uint32_t id,
+                                        uint32_t alignment, uint32_t num_bytes)
+{
+    if (!exec->registrationOpen) {
+        return fail(-1, "registerComponent outside registerTypes");
+    }
+    if (id >= kMaxComponents) {
+        return fail(-2, "component id %u exceeds the limit of %u", id,
+                    kMaxComponents);
+    }
+    if (exec->components.size() <= id) {
+        exec->components.resize(id + 1);
+    }
+    exec->components[id] = ComponentRec { true, alignment, num_bytes };
+    return 0;
+}
+
+static int flattenComponents(mwhip_exec *exec, const uint32_t *ids, uint32_t n,
+                             std::vector<uint32_t> &out)
+{
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t id = ids[i];
+        if ((id & kBundleMask) != 0u) {
+            auto it = exec->bundles.find(id);
+            if (it == exec->bundles.end()) {
+                return fail(-3, "bundle 0x%x used before registerBundle", id);
+            }
+            out.insert(out.end(), it->second.begin(), it->second.end());
+        } else {
+            if (id >= exec->components.size() ||
+                    !exec->components[id].registered) {
+                return fail(-3, "component %u used before registerComponent",
+                            id);
+            }
+            out.push_back(id);
+        }
+    }
+    return 0;
+}
+
+extern "C" int mwhip_register_bundle(mwhip_exec *exec, uint32_t bundle_id,
+                                     const uint32_t *component_ids,
+                                     uint32_t num_components)
+{
+    if (!exec->registrationOpen) {
+        return fail(-1, "registerBundle outside registerTypes");
+    }
+    std::vector<uint32_t> flat;
+    int rc = flattenComponents(exec, component_ids, num_components, flat);
+    if (rc != 0) return rc;
+    exec->bundles[bundle_id | kBundleMask] = std::move(flat);
+    return 0;
+}
+
+static uint32_t defaultRowsPerWorld()
+{
+    return envU32("MADRONA_MWHIP_ROWS_PER_WORLD", 64);
+}
+
+extern "C" int mwhip_register_archetype(mwhip_exec *exec, uint32_t id,
+                                        const uint32_t *component_ids,
+                                        const uint32_t *component_flags,
+                                        uint32_t num_components,
+                                        uint32_t archetype_flags,
+                                        uint32_t max_per_world)
+{
+    (void)component_flags;
+    if (!exec->registrationOpen) {
+        return fail(-1, "registerArchetype outside registerTypes");
+    }
+    if (id >= kMaxArchetypes) {
+        return fail(-2, "archetype id %u exceeds the limit of %u", id,
+                    kMaxArchetypes);
+    }
+    if (exec->archetypes.size() <= id) {
+        exec->archetypes.resize(id + 1);
+    }
+
+    ArchetypeRec &arch = exec->archetypes[id];
+    if (arch.registered) {
+        return 0;   // idempotent, like the reference's CPU registry
+    }
+
+    arch = ArchetypeRec {};
+    arch.id = id;
+    arch.flags = archetype_flags;
+    arch.maxPerWorld = max_per_world;
+    int rc = flattenComponents(exec, component_ids, num_components, arch.comps);
+    if (rc != 0) return rc;
+
+    arch.numColumns = 2u + (uint32_t)arch.comps.size();
+    if (arch.numColumns > kMaxColumns) {
+        return fail(-2, "archetype %u has %u columns (limit %u)", id,
+                    arch.numColumns, kMaxColumns);
+    }
+
+    const uint64_t W = exec->cfg.num_worlds;
+    // Rows of one world that were destroyed and re-created coexist until the
+    // next compaction, hence the 2x head room over the declared maximum.
+    uint64_t rows_per_world = max_per_world == 1 ? 1 :
+        (max_per_world > 0 ? 2ull * max_per_world : defaultRowsPerWorld());
+    uint64_t capacity = std::max<uint64_t>(W * rows_per_world, 64);
+    if (capacity > 0x7FFFFFF0ull) {
+        return fail(-2, "archetype %u capacity overflow", id);
+    }
+    arch.capacity = (uint32_t)capacity;
+
+    // column 0 = Entity, column 1 = WorldID, then user components
+    // (reference src/mw/device/state.cpp:269-341)
+    arch.colBytes.push_back((uint32_t)sizeof(Entity));
+    arch.colComponent.push_back(0);
+    arch.colBytes.push_back((uint32_t)sizeof(WorldID));
+    arch.colComponent.push_back(1);
+    for (uint32_t c : arch.comps) {
+        arch.colBytes.push_back(exec->components[c].bytes);
+        arch.colComponent.push_back(c);
+    }
+
+    arch.rowBytes = 0;
+    arch.primary.resize(arch.numColumns);
+    arch.alt.resize(arch.numColumns);
+    arch.colFlags.assign(arch.numColumns, 0u);
+    for (uint32_t c = 0; c < arch.numColumns; c++) {
+        arch.rowBytes += arch.colBytes[c];
+        size_t bytes = (size_t)arch.capacity * arch.colBytes[c] + 16;
+        rc = devAlloc(exec, &arch.primary[c], bytes);
+        if (rc != 0) return rc;
+        rc = devAlloc(exec, &arch.alt[c], bytes);
+        if (rc != 0) return rc;
+    }
+
+    rc = devAllocT(exec, &arch.worldOffsets, W);
+    if (rc != 0) return rc;
+    rc = devAllocT(exec, &arch.worldCounts, W);
+    if (rc != 0) return rc;
+
+    arch.registered = true;
+    return 0;
+}
+
+extern "C" int mwhip_register_singleton(mwhip_exec *exec, uint32_t archetype_id,
+                                        uint32_t component_id)
+{
+    (void)component_id;
+    if (archetype_id >= exec->archetypes.size() ||
+            !exec->archetypes[archetype_id].registered) {
+        return fail(-3, "singleton archetype %u not registered", archetype_id);
+    }
+    ArchetypeRec &arch = exec->archetypes[archetype_id];
+    if (!arch.singleton) {
+        arch.singleton = true;
+        arch.singletonOrdinal = (int32_t)exec->numSingletons++;
+    }
+    return 0;
+}
+
+static int findColumn(const ArchetypeRec &arch, uint32_t component_id)
+{
+    if (component_id == 0) return 0;
+    if (component_id == 1) return 1;
+    for (size_t i = 0; i < arch.comps.size(); i++) {
+        if (arch.comps[i] == component_id) {
+            return (int)i + 2;
+        }
+    }
+    return -1;
+}
+
+extern "C" void *mwhip_export_column(mwhip_exec *exec, uint32_t archetype_id,
+                                     uint32_t component_id, int32_t slot)
+{
+    if (archetype_id >= exec->archetypes.size() ||
+            !exec->archetypes[archetype_id].registered) {
+        fail(-3, "exportColumn: archetype %u not registered", archetype_id);
+        return nullptr;
+    }
+    ArchetypeRec &arch = exec->archetypes[archetype_id];
+    int col = findColumn(arch, component_id);
+    if (col < 0) {
+        fail(-3, "exportColumn: archetype %u has no component %u",
+             archetype_id, component_id);
+        return nullptr;
+    }
+    if (slot < 0 || (uint32_t)slot >= exec->exported.size()) {
+        fail(-3, "exportColumn: slot %d out of range (numExportedBuffers=%zu)",
+             slot, exec->exported.size());
+        return nullptr;
+    }
+
+    // exported columns keep their address across sorts
+    arch.colFlags[col] |= kColumnPinned;
+    exec->exported[slot] = arch.primary[col];
+    return arch.primary[col];
+}
+
+extern "C" int mwhip_make_query(mwhip_exec *exec, const uint32_t *component_ids,
+                                uint32_t num_components, uint32_t *offset_out,
+                                uint32_t *num_matching_out)
+{
+    std::vector<uint32_t> comps(component_ids, component_ids + num_components);
+    for (const QueryRec &q : exec->queries) {
+        if (q.comps == comps) {
+            *offset_out = q.offset;
+            *num_matching_out = q.numMatching;
+            return 0;
+        }
+    }
+
+    // same record layout and archetype order as the reference's makeQuery
+    // (src/mw/device/state.cpp:380-440)
+    QueryRec rec;
+    rec.comps = comps;
+    rec.offset = (uint32_t)exec->queryDataHost.size();
+    rec.numMatching = 0;
+
+    for (uint32_t a = 0; a < exec->archetypes.size(); a++) {
+        const ArchetypeRec &arch = exec->archetypes[a];
+        if (!arch.registered) continue;
+
+        bool has_all = true;
+        for (uint32_t c : comps) {
+            if (c == 0) continue;   // Entity is in every table
+            if (findColumn(arch, c) < 0) {
+                has_all = false;
+                break;
+            }
+        }
+        if (!has_all) continue;
+
+        rec.numMatching += 1;
+        exec->queryDataHost.push_back(a);
+        for (uint32_t c : comps) {
+            exec->queryDataHost.push_back((uint32_t)findColumn(arch, c));
+        }
+    }
+
+    if (exec->queryDataHost.size() > exec->queryCapacity) {
+        return fail(-2, "query table overflow");
+    }
+
+    if (exec->stateBuilt && exec->queryDataHost.size() > rec.offset) {
+        HIPCHK(hipMemcpy(exec->hostState.queryData + rec.offset,
+            exec->queryDataHost.data() + rec.offset,
+            (exec->queryDataHost.size() - rec.offset) * sizeof(uint32_t),
+            hipMemcpyHostToDevice));
+    }
+
+    *offset_out = rec.offset;
+    *num_matching_out = rec.numMatching;
+    exec->queries.push_back(std::move(rec));
+    return 0;
+}
+
+extern "C" void *mwhip_device_state(mwhip_exec *exec) { return exec->stateDev; }
+
+extern "C" void *mwhip_world_data(mwhip_exec *exec, uint32_t world_idx)
+{
+    return exec->hostState.worldData +
+        (uint64_t)world_idx * exec->hostState.worldDataStride;
+}
+
+extern "C" uint32_t mwhip_num_worlds(const mwhip_exec *exec)
+{
+    return exec->cfg.num_worlds;
+}
+
+extern "C" uint32_t mwhip_num_task_graphs(const mwhip_exec *exec)
+{
+    return exec->cfg.num_task_graphs;
+}
+
+extern "C" void *mwhip_stream(mwhip_exec *exec) { return exec->stream; }
+
+extern "C" void *mwhip_get_exported(const mwhip_exec *exec, uint32_t slot)
+{
+    return slot < exec->exported.size() ? exec->exported[slot] : nullptr;
+}
+
+// ---------------------------------------------------------------------------
+// state construction
+// ---------------------------------------------------------------------------
+static int buildDeviceState(mwhip_exec *exec)
+{
+    const uint32_t W = exec->cfg.num_worlds;
+    EcsState &hs = exec->hostState;
+
+    hs.numArchetypeSlots = (uint32_t)exec->archetypes.size();
+    hs.numComponentSlots = (uint32_t)exec->components.size();
+    hs.numWorlds = (int32_t)W;
+
+    // ---- table headers + dense (archetype, component) -> column lookup -----
+    exec->tablesHost.assign(std::max<uint32_t>(hs.numArchetypeSlots, 1u),
+                            TableHdr {});
+    std::vector<uint16_t> lookup(
+        (size_t)std::max<uint32_t>(hs.numArchetypeSlots, 1u) *
+            std::max<uint32_t>(hs.numComponentSlots, 1u), kNoColumn);
+
+    for (uint32_t a = 0; a < hs.numArchetypeSlots; a++) {
+        const ArchetypeRec &arch = exec->archetypes[a];
+        TableHdr &hdr = exec->tablesHost[a];
+        if (!arch.registered) continue;
+
+        for (uint32_t c = 0; c < arch.numColumns; c++) {
+            hdr.columns[c] = arch.primary[c];
+            hdr.columnsAlt[c] = arch.alt[c];
+            hdr.columnBytes[c] = arch.colBytes[c];
+            hdr.columnFlags[c] = arch.colFlags[c];
+            lookup[(size_t)a * hs.numComponentSlots + arch.colComponent[c]] =
+                (uint16_t)c;
+        }
+        hdr.numColumns = (int32_t)arch.numColumns;
+        hdr.numRows = arch.singleton ? (int32_t)W : 0;
+        hdr.capacity = (int32_t)arch.capacity;
+        hdr.needsSort = 0;
+        hdr.worldOffsets = arch.worldOffsets;
+        hdr.worldCounts = arch.worldCounts;
+        hdr.maxPerWorld = arch.maxPerWorld;
+        hdr.registered = 1;
+        hdr.rowBytes = arch.rowBytes;
+    }
+
+    int rc = devAllocT(exec, &hs.tables, exec->tablesHost.size());
+    if (rc != 0) return rc;
+    rc = devAllocT(exec, &hs.colLookup, lookup.size());
+    if (rc != 0) return rc;
+    HIPCHK(hipMemcpy(hs.colLookup, lookup.data(),
+        lookup.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+
+    rc = devAllocT(exec, &hs.queryData, exec->queryCapacity);
+    if (rc != 0) return rc;
+
+    // ---- entity store ---------------------------------------------------------
+    const uint64_t singleton_ids = (uint64_t)exec->numSingletons * W;
+    exec->singletonIdEnd =
+        (uint32_t)((singleton_ids + kIdsPerBlock - 1) / kIdsPerBlock *
+                   kIdsPerBlock);
+    const uint32_t blocks_per_world =
+        envU32("MADRONA_MWHIP_ID_BLOCKS_PER_WORLD", 4);
+    uint64_t entity_capacity = (uint64_t)exec->singletonIdEnd +
+        (uint64_t)W * blocks_per_world * kIdsPerBlock + kIdsPerBlock;
+    if (entity_capacity > 0x7FFFFFF0ull) {
+        return fail(-2, "entity store overflow");
+    }
+    hs.entityCapacity = (int32_t)entity_capacity;
+    rc = devAllocT(exec, &hs.entities, entity_capacity);
+    if (rc != 0) return rc;
+    rc = devAllocT(exec, &hs.worldCaches, W);
+    if (rc != 0) return rc;
+    rc = devAllocT(exec, &hs.initBlockBase, W);
+    if (rc != 0) return rc;
+
+    // ---- per-world user data + scratch allocator --------------------------------
+    uint32_t align = std::max<uint32_t>(exec->cfg.world_data_alignment, 16u);
+    hs.worldDataStride =
+        (exec->cfg.num_world_data_bytes + align - 1) / align * align;
+    rc = devAlloc(exec, (void **)&hs.worldData,
+                  (size_t)hs.worldDataStride * W);
+    if (rc != 0) return rc;
+
+    hs.tmpCapacity =
+        (unsigned long long)envU32("MADRONA_MWHIP_TMP_MB", 64) << 20;
+    rc = devAlloc(exec, (void **)&hs.tmpBase, hs.tmpCapacity, false);
+    if (rc != 0) return rc;
+    hs.tmpOffset = 0;
+
+    hs.idFreeHead = 0xFFFFFFFFull;      // {gen 0, head sentinel}
+    hs.numIds = (int32_t)exec->singletonIdEnd;
+    hs.initMode = 0;
+    hs.errorFlags = 0;
+    hs.hostExec = nullptr;
+
+    // ---- singletons: one row per world, ids in (singleton, world) order -------
+    // (reference CPU state.inl:163-179: k-th created singleton entity gets id k)
+    std::vector<Entity> ents(W);
+    std::vector<int32_t> iota(W), ones(W, 1);
+    std::vector<EntitySlot> slots(W);
+    for (uint32_t a = 0; a < hs.numArchetypeSlots; a++) {
+        const ArchetypeRec &arch = exec->archetypes[a];
+        if (!arch.registered || !arch.singleton) continue;
+
+        const uint32_t base = (uint32_t)arch.singletonOrdinal * W;
+        for (uint32_t w = 0; w < W; w++) {
+            ents[w] = Entity { 0, (int32_t)(base + w) };
+            iota[w] = (int32_t)w;
+            slots[w].loc.archetype = a;
+            slots[w].loc.row = (int32_t)w;
+            slots[w].gen = 0;
+        }
+        HIPCHK(hipMemcpy(arch.primary[0], ents.data(), W * sizeof(Entity),
+                         hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(arch.primary[1], iota.data(), W * sizeof(int32_t),
+                         hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(arch.worldOffsets, iota.data(), W * sizeof(int32_t),
+                         hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(arch.worldCounts, ones.data(), W * sizeof(int32_t),
+                         hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(hs.entities + base, slots.data(),
+                         W * sizeof(EntitySlot), hipMemcpyHostToDevice));
+    }
+
+    HIPCHK(hipMemcpy(hs.tables, exec->tablesHost.data(),
+        exec->tablesHost.size() * sizeof(TableHdr), hipMemcpyHostToDevice));
+    if (!exec->queryDataHost.empty()) {
+        HIPCHK(hipMemcpy(hs.queryData, exec->queryDataHost.data(),
+            exec->queryDataHost.size() * sizeof(uint32_t),
+            hipMemcpyHostToDevice));
+    }
+
+    rc = devAllocT(exec, &exec->stateDev, 1);
+    if (rc != 0) return rc;
+    HIPCHK(hipMemcpy(exec->stateDev, &hs, sizeof(EcsState),
+                     hipMemcpyHostToDevice));
+
+    // [0] error flags, [1] id high-water mark, [2..] rows per archetype,
+    // [2 + kMaxArchetypes] profiling gate flag
+    HIPCHK(hipHostMalloc((void **)&exec->statsHost,
+        (3 + kMaxArchetypes) * sizeof(int32_t), hipHostMallocMapped));
+    memset(exec->statsHost, 0, (3 + kMaxArchetypes) * sizeof(int32_t));
+
+    exec->stateBuilt = true;
+    return 0;
+}
+
+template <typename T>
+static int pokeState(mwhip_exec *exec, T EcsState::*field, const T &value)
+{
+    exec->hostState.*field = value;
+    char *dst = (char *)exec->stateDev +
+        ((char *)&(exec->hostState.*field) - (char *)&exec->hostState);
+    HIPCHK(hipMemcpy(dst, &value, sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+static int fetchError(mwhip_exec *exec, uint32_t *flags)
+{
+    HIPCHK(hipMemcpy(flags, (char *)exec->stateDev +
+        offsetof(EcsState, errorFlags), sizeof(uint32_t),
+        hipMemcpyDeviceToHost));
+    return 0;
+}
+
+static const char *describeError(uint32_t flags)
+{
+    if (flags & kErrTableOverflow) {
+        return "an archetype table ran out of rows (raise "
+               "max_num_entities_per_world or MADRONA_MWHIP_ROWS_PER_WORLD)";
+    }
+    if (flags & kErrEntityOverflow) {
+        return "the entity id store is full (raise "
+               "MADRONA_MWHIP_ID_BLOCKS_PER_WORLD)";
+    }
+    if (flags & kErrTmpOverflow) {
+        return "Context::tmpAlloc scratch exhausted (raise MADRONA_MWHIP_TMP_MB)";
+    }
+    if (flags & kErrSortLookback) {
+        return "sort look-back timed out";
+    }
+    if (flags & kErrInitBlocks) {
+        return "world constructors are not deterministic";
+    }
+    return "unknown device error";
+}
+
+// ---------------------------------------------------------------------------
+// launches
+// ---------------------------------------------------------------------------
+static int launchOne(mwhip_exec *exec, KernelLaunch &k, hipStream_t stream)
+{
+    void *args[8];
+    k.argPointers(args);
+    HIPCHK(hipLaunchKernel(k.fn, k.grid, k.block, args, 0, stream));
+    (void)exec;
+    return 0;
+}
+
+static int ensureSortScratch(mwhip_exec *exec, ArchetypeRec &arch)
+{
+    if (arch.sortState != nullptr) return 0;
+
+    int rc = devAllocT(exec, &arch.sortState, 1);
+    if (rc != 0) return rc;
+    rc = devAllocT(exec, &arch.keysA, arch.capacity, false);
+    if (rc != 0) return rc;
+    rc = devAllocT(exec, &arch.keysB, arch.capacity, false);
+    if (rc != 0) return rc;
+    rc = devAllocT(exec, &arch.idxA, arch.capacity, false);
+    if (rc != 0) return rc;
+    rc = devAllocT(exec, &arch.idxB, arch.capacity, false);
+    if (rc != 0) return rc;
+    size_t tiles = (arch.capacity + sortTileSize() - 1) / sortTileSize();
+    rc = devAllocT(exec, &arch.lookback, tiles * 256);
+    return rc;
+}
+
+static int makeSortBatch(mwhip_exec *exec,
+                         const std::vector<std::pair<uint32_t, uint32_t>> &specs,
+                         std::unique_ptr<SortBatch> &out)
+{
+    out.reset(new SortBatch {});
+    out->stateDev = exec->stateDev;
+
+    std::vector<SortSite> sites;
+    std::vector<GatherColumn> cols;
+
+    for (auto [archetype_id, component_id] : specs) {
+        if (archetype_id >= exec->archetypes.size() ||
+                !exec->archetypes[archetype_id].registered) {
+            return fail(-3, "sort node on unregistered archetype %u",
+                        archetype_id);
+        }
+        ArchetypeRec &arch = exec->archetypes[archetype_id];
+        int key_col = findColumn(arch, component_id);
+        if (key_col < 0) {
+            return fail(-3, "sort node: archetype %u has no component %u",
+                        archetype_id, component_id);
+        }
+        if (arch.colBytes[key_col] != 4) {
+            return fail(-3, "sort key component %u is not 4 bytes",
+                        component_id);
+        }
+
+        int rc = ensureSortScratch(exec, arch);
+        if (rc != 0) return rc;
+
+        const bool world_sort = component_id == 1;
+
+        SortSiteHost host_site {};
+        host_site.archetype = archetype_id;
+        host_site.keyColumn = (uint32_t)key_col;
+        host_site.worldSort = world_sort;
+        host_site.numPasses = sortNumPasses(world_sort, exec->cfg.num_worlds);
+        host_site.capacity = arch.capacity;
+        host_site.rowBytes = arch.rowBytes;
+        host_site.stateDev = arch.sortState;
+        out->sites.push_back(host_site);
+
+        SortSite site {};
+        site.archetype = archetype_id;
+        site.keyColumn = (uint32_t)key_col;
+        site.numPasses = host_site.numPasses;
+        site.worldSort = world_sort ? 1u : 0u;
+        site.keysA = arch.keysA;
+        site.keysB = arch.keysB;
+        site.idxA = arch.idxA;
+        site.idxB = arch.idxB;
+        site.lookback = arch.lookback;
+        site.state = arch.sortState;
+        sites.push_back(site);
+
+        for (uint32_t c = 0; c < arch.numColumns; c++) {
+            uint32_t bytes = arch.colBytes[c];
+            GatherColumn gc {};
+            gc.site = (uint32_t)sites.size() - 1;
+            gc.column = c;
+            gc.wordBytes = bytes % 16 == 0 ? 16 : (bytes % 8 == 0 ? 8 :
+                (bytes % 4 == 0 ? 4 : 1));
+            gc.wordsPerRow = bytes / gc.wordBytes;
+            gc.invMagic = gc.wordsPerRow <= 1 ? 0ull :
+                (~0ull / gc.wordsPerRow) + 1ull;
+            cols.push_back(gc);
+        }
+    }
+
+    int rc = devAllocT(exec, &out->sitesDev, sites.size());
+    if (rc != 0) return rc;
+    HIPCHK(hipMemcpy(out->sitesDev, sites.data(),
+        sites.size() * sizeof(SortSite), hipMemcpyHostToDevice));
+    rc = devAllocT(exec, &out->gatherColumnsDev, cols.size());
+    if (rc != 0) return rc;
+    HIPCHK(hipMemcpy(out->gatherColumnsDev, cols.data(),
+        cols.size() * sizeof(GatherColumn), hipMemcpyHostToDevice));
+    out->numGatherColumns = (uint32_t)cols.size();
+    return 0;
+}
+
+static void pickGrid(mwhip_exec *exec, KernelLaunch &k, uint64_t max_invocations,
+                     uint32_t threads_per_invocation)
+{
+    (void)exec;
+    uint64_t threads = max_invocations * std::max(threads_per_invocation, 1u);
+    // small tables: 64-thread workgroups so the work spreads over more CUs;
+    // big tables: 256-thread workgroups, capped, with grid-stride loops
+    uint32_t block = threads >= 256ull * 512ull ? 256u : 64u;
+    uint64_t blocks = (threads + block - 1) / block;
+    blocks = std::min<uint64_t>(std::max<uint64_t>(blocks, 1), 2048);
+    k.block = dim3(block, 1, 1);
+    k.grid = dim3((uint32_t)blocks, 1, 1);
+}
+
+static uint64_t queryCapacityRows(mwhip_exec *exec, uint32_t offset,
+                                  uint32_t num_matching, uint32_t num_components_hint)
+{
+    (void)num_components_hint;
+    // find the query record to learn its component count
+    for (const QueryRec &q : exec->queries) {
+        if (q.offset == offset) {
+            uint64_t rows = 0;
+            const uint32_t *p = exec->queryDataHost.data() + offset;
+            for (uint32_t i = 0; i < num_matching; i++) {
+                rows += exec->archetypes[p[0]].capacity;
+                p += 1 + q.comps.size();
+            }
+            return rows;
+        }
+    }
+    return 0;
+}
+
+static int buildLaunchList(mwhip_exec *exec, const std::vector<uint32_t> &tg_ids,
+                           LaunchGraph &lg)
+{
+    for (uint32_t tg_id : tg_ids) {
+        if (tg_id >= exec->taskGraphs.size()) {
+            return fail(-3, "task graph %u does not exist", tg_id);
+        }
+        TaskGraphRec &tg = exec->taskGraphs[tg_id];
+        const std::vector<int32_t> &order = tg.sorted;
+
+        std::vector<MiscOp> pending_misc;
+        auto flushMisc = [&]() -> int {
+            if (pending_misc.empty()) return 0;
+            MiscOp *ops_dev;
+            int rc = devAllocT(exec, &ops_dev, pending_misc.size());
+            if (rc != 0) return rc;
+            HIPCHK(hipMemcpy(ops_dev, pending_misc.data(),
+                pending_misc.size() * sizeof(MiscOp), hipMemcpyHostToDevice));
+            KernelLaunch k;
+            k.fn = (const void *)&miscOpsKernel;
+            k.grid = dim3(1, 1, 1);
+            k.block = dim3(64, 1, 1);
+            k.setArgs(exec->stateDev, (const MiscOp *)ops_dev,
+                      (uint32_t)pending_misc.size());
+            k.name = "misc";
+            k.role = "clear/reset";
+            k.kind = MWHIP_NODE_CLEAR_TMP;
+            lg.launches.push_back(k);
+            pending_misc.clear();
+            return 0;
+        };
+
+        for (size_t oi = 0; oi < order.size(); oi++) {
+            NodeRec &node = tg.nodes[order[oi]];
+            const mwhip_node_desc &d = node.desc;
+
+            switch (d.kind) {
+            case MWHIP_NODE_KERNEL: {
+                int rc = flushMisc();
+                if (rc != 0) return rc;
+
+                KernelLaunch k;
+                k.fn = d.kernel;
+                void *data_dev = d.node_data_id >= 0 ?
+                    tg.dataDev[d.node_data_id] : nullptr;
+                k.setArgs(exec->stateDev, data_dev, d.arg0, d.arg1);
+                k.name = node.name;
+                k.role = "";
+                k.kind = d.kind;
+                k.bytesPerRow = d.bytes_per_row;
+                k.countMode = d.count_mode;
+                k.fixedCount = d.fixed_count;
+                k.queryOffset = d.query_offset;
+                k.numMatching = d.num_matching;
+
+                uint64_t max_inv = 0;
+                if (d.count_mode == MWHIP_COUNT_QUERY_ROWS) {
+                    max_inv = queryCapacityRows(exec, d.query_offset,
+                                                d.num_matching, 0);
+                    if (d.num_matching == 0) max_inv = 1;
+                } else if (d.count_mode == MWHIP_COUNT_PER_WORLD) {
+                    max_inv = exec->cfg.num_worlds;
+                } else {
+                    max_inv = d.fixed_count == 0xFFFFFFFFu ?
+                        (256ull * 1024ull) : std::max(d.fixed_count, 1u);
+                }
+                pickGrid(exec, k, max_inv, d.threads_per_invocation);
+                lg.launches.push_back(k);
+            } break;
+            case MWHIP_NODE_SORT_ARCHETYPE: {
+                int rc = flushMisc();
+                if (rc != 0) return rc;
+
+                // Batch this sort with the sort nodes that directly follow it.
+                // ResetTmpAlloc / Recycle nodes in between commute with the
+                // sort (it uses neither) and are replayed after the batch.
+                std::vector<std::pair<uint32_t, uint32_t>> specs;
+                specs.emplace_back(d.archetype_id, d.component_id);
+                std::string name = node.name;
+                size_t oj = oi + 1;
+                if (exec->sortBatching) {
+                    for (; oj < order.size(); oj++) {
+                        const mwhip_node_desc &nd = tg.nodes[order[oj]].desc;
+                        if (nd.kind == MWHIP_NODE_RESET_TMP_ALLOC) {
+                            pending_misc.push_back({ kOpResetTmpAlloc, 0 });
+                            continue;
+                        }
+                        if (nd.kind == MWHIP_NODE_RECYCLE) {
+                            continue;
+                        }
+                        if (nd.kind != MWHIP_NODE_SORT_ARCHETYPE) {
+                            break;
+                        }
+                        bool dup = false;
+                        for (auto &s : specs) {
+                            if (s.first == nd.archetype_id) dup = true;
+                        }
+                        if (dup) break;
+                        specs.emplace_back(nd.archetype_id, nd.component_id);
+                    }
+                    // collapse duplicate deferred resets
+                    if (pending_misc.size() > 1) pending_misc.resize(1);
+                }
+
+                std::unique_ptr<SortBatch> batch;
+                rc = makeSortBatch(exec, specs, batch);
+                if (rc != 0) return rc;
+
+                size_t first = lg.launches.size();
+                buildSortLaunches(*batch, lg.launches);
+                for (size_t i = first; i < lg.launches.size(); i++) {
+                    lg.launches[i].name = name;
+                    lg.launches[i].archetype = specs[0].first;
+                }
+                lg.sortBatches.push_back(std::move(batch));
+                oi = oj - 1;
+            } break;
+            case MWHIP_NODE_CLEAR_TMP:
+                pending_misc.push_back({ kOpClearTmp, d.archetype_id });
+                break;
+            case MWHIP_NODE_RESET_TMP_ALLOC:
+                pending_misc.push_back({ kOpResetTmpAlloc, 0 });
+                break;
+            case MWHIP_NODE_RECYCLE:
+                break;
+            default:
+                return fail(-3, "unknown node kind %u", d.kind);
+            }
+
+            if (pending_misc.size() >= 64) {
+                int rc = flushMisc();
+                if (rc != 0) return rc;
+            }
+        }
+
+        int rc = flushMisc();
+        if (rc != 0) return rc;
+    }
+
+    if (exec->checkAfterRun) {
+        KernelLaunch k;
+        k.fn = (const void *)&statsKernel;
+        k.grid = dim3(1, 1, 1);
+        k.block = dim3(256, 1, 1);
+        int32_t *host_out = nullptr;
+        HIPCHK(hipHostGetDevicePointer((void **)&host_out, exec->statsHost, 0));
+        k.setArgs(exec->stateDev, host_out);
+        k.name = "stats";
+        k.role = "health";
+        k.kind = MWHIP_NODE_RECYCLE;
+        lg.launches.push_back(k);
+    }
+
+    return 0;
+}
+
+static int sortAllArchetypes(mwhip_exec *exec)
+{
+    // World-sort every non-singleton table once after world construction so
+    // rows are world-major (world constructors run in parallel and append in
+    // arrival order; the stable sort keeps each world's creation order).
+    std::vector<std::pair<uint32_t, uint32_t>> specs;
+    for (uint32_t a = 0; a < exec->archetypes.size(); a++) {
+        const ArchetypeRec &arch = exec->archetypes[a];
+        if (arch.registered && !arch.singleton) {
+            specs.emplace_back(a, 1u);
+        }
+    }
+    if (specs.empty()) return 0;
+
+    std::unique_ptr<SortBatch> batch;
+    int rc = makeSortBatch(exec, specs, batch);
+    if (rc != 0) return rc;
+
+    std::vector<KernelLaunch> launches;
+    buildSortLaunches(*batch, launches);
+    for (KernelLaunch &k : launches) {
+        rc = launchOne(exec, k, exec->stream);
+        if (rc != 0) return rc;
+    }
+    HIPCHK(hipStreamSynchronize(exec->stream));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// world construction (two passes, deterministic id blocks)
+// ---------------------------------------------------------------------------
+static int launchInitWorlds(mwhip_exec *exec)
+{
+    const int32_t W = (int32_t)exec->cfg.num_worlds;
+    EcsState *state = exec->stateDev;
+    const void *cfg = exec->userCfgDev;
+    const void *inits = exec->worldInitsDev;
+    void *args[] = { &state, &cfg, &inits, (void *)&W };
+    HIPCHK(hipLaunchKernel(exec->entry.init_worlds_kernel,
+        dim3((uint32_t)((W + 63) / 64), 1, 1), dim3(64, 1, 1), args, 0,
+        exec->stream));
+    HIPCHK(hipStreamSynchronize(exec->stream));
+    return 0;
+}
+
+static int resetForInitPass(mwhip_exec *exec)
+{
+    const uint32_t W = exec->cfg.num_worlds;
+    EcsState &hs = exec->hostState;
+
+    HIPCHK(hipMemcpy(hs.tables, exec->tablesHost.data(),
+        exec->tablesHost.size() * sizeof(TableHdr), hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(hs.worldCaches, 0, W * sizeof(IdCache)));
+    std::vector<IdCache> caches(W);
+    for (IdCache &c : caches) {
+        c.freeHead = kIdSentinel;
+        c.numFree = 0;
+        c.overflowHead = kIdSentinel;
+        c.numOverflow = 0;
+        c.lock = 0;
+        c.initBlocksUsed = 0;
+    }
+    HIPCHK(hipMemcpy(hs.worldCaches, caches.data(), W * sizeof(IdCache),
+                     hipMemcpyHostToDevice));
+
+    HIPCHK(hipMemset(hs.entities + exec->singletonIdEnd, 0,
+        (size_t)(hs.entityCapacity - (int32_t)exec->singletonIdEnd) *
+            sizeof(EntitySlot)));
+    HIPCHK(hipMemset(hs.worldData, 0, (size_t)hs.worldDataStride * W));
+
+    // singleton user data back to zero
+    for (const ArchetypeRec &arch : exec->archetypes) {
+        if (arch.registered && arch.singleton) {
+            HIPCHK(hipMemset(arch.primary[2], 0,
+                             (size_t)arch.capacity * arch.colBytes[2]));
+        }
+    }
+
+    int rc = pokeState(exec, &EcsState::numIds, (int32_t)exec->singletonIdEnd);
+    if (rc != 0) return rc;
+    rc = pokeState(exec, &EcsState::tmpOffset, 0ull);
+    if (rc != 0) return rc;
+    rc = pokeState(exec, &EcsState::idFreeHead, 0xFFFFFFFFull);
+    if (rc != 0) return rc;
+    return pokeState(exec, &EcsState::errorFlags, 0u);
+}
+
+static int constructWorlds(mwhip_exec *exec)
+{
+    const uint32_t W = exec->cfg.num_worlds;
+    EcsState &hs = exec->hostState;
+
+    // pass 1: run the constructors to learn how many id blocks each world
+    // takes from the global store
+    int rc = resetForInitPass(exec);
+    if (rc != 0) return rc;
+    rc = pokeState(exec, &EcsState::initMode, 1u);
+    if (rc != 0) return rc;
+    rc = launchInitWorlds(exec);
+    if (rc != 0) return rc;
+
+    uint32_t err = 0;
+    rc = fetchError(exec, &err);
+    if (rc != 0) return rc;
+    if (err != 0) {
+        return fail(-4, "world construction failed: %s", describeError(err));
+    }
+
+    std::vector<IdCache> caches(W);
+    HIPCHK(hipMemcpy(caches.data(), hs.worldCaches, W * sizeof(IdCache),
+                     hipMemcpyDeviceToHost));
+
+    // pass 2: replay with world-major block bases, i.e. the order in which the
+    // reference CPU backend's sequential constructor loop
+    // (include/madrona/mw_cpu.inl:42-46) would have grabbed them
+    std::vector<int32_t> bases(W);
+    int64_t next = exec->singletonIdEnd;
+    for (uint32_t w = 0; w < W; w++) {
+        bases[w] = (int32_t)next;
+        next += (int64_t)caches[w].initBlocksUsed * kIdsPerBlock;
+    }
+    if (next > hs.entityCapacity) {
+        return fail(-4, "world construction failed: %s",
+                    describeError(kErrEntityOverflow));
+    }
+
+    rc = resetForInitPass(exec);
+    if (rc != 0) return rc;
+    HIPCHK(hipMemcpy(hs.initBlockBase, bases.data(), W * sizeof(int32_t),
+                     hipMemcpyHostToDevice));
+    rc = pokeState(exec, &EcsState::numIds, (int32_t)next);
+    if (rc != 0) return rc;
+    rc = pokeState(exec, &EcsState::initMode, 2u);
+    if (rc != 0) return rc;
+    rc = launchInitWorlds(exec);
+    if (rc != 0) return rc;
+
+    std::vector<IdCache> caches2(W);
+    HIPCHK(hipMemcpy(caches2.data(), hs.worldCaches, W * sizeof(IdCache),
+                     hipMemcpyDeviceToHost));
+    for (uint32_t w = 0; w < W; w++) {
+        if (caches2[w].initBlocksUsed != caches[w].initBlocksUsed) {
+            return fail(-4, "world %u constructor is not deterministic "
+                "(%d id blocks, then %d)", w, caches[w].initBlocksUsed,
+                caches2[w].initBlocksUsed);
+        }
+    }
+
+    rc = fetchError(exec, &err);
+    if (rc != 0) return rc;
+    if (err != 0) {
+        return fail(-4, "world construction failed: %s", describeError(err));
+    }
+
+    return pokeState(exec, &EcsState::initMode, 0u);
+}
+
+// ---------------------------------------------------------------------------
+// create / destroy
+// ---------------------------------------------------------------------------
+extern "C" int mwhip_create(const mwhip_state_config *cfg,
+                            const mwhip_user_entry *entry, mwhip_exec **out)
+{
+    *out = nullptr;
+    if (entry == nullptr || entry->abi_version != MWHIP_ABI_VERSION) {
+        return fail(-1, "user entry ABI mismatch");
+    }
+    if (cfg->num_worlds == 0) {
+        return fail(-1, "numWorlds must be > 0");
+    }
+
+    int device_count = 0;
+    hipError_t res = hipGetDeviceCount(&device_count);
+    if (res != hipSuccess || device_count == 0) {
+        return fail(-11, "no HIP device available (the MI355X backend has no "
+                    "CPU fallback)");
+    }
+    HIPCHK(hipSetDevice(cfg->gpu_id));
+
+    g_lastError.clear();
+    std::unique_ptr<mwhip_exec> exec(new mwhip_exec {});
+    exec->cfg = *cfg;
+    exec->entry = *entry;
+    exec->exported.assign(cfg->num_exported_buffers, nullptr);
+    exec->taskGraphs.resize(cfg->num_task_graphs);
+    exec->checkAfterRun = envU32("MADRONA_MWHIP_CHECK", 1) != 0;
+    exec->sortBatching = envU32("MADRONA_MWHIP_SORT_BATCH", 1) != 0;
+    HIPCHK(hipStreamCreateWithFlags(&exec->stream, hipStreamNonBlocking));
+
+    // ---- registerTypes (host) -------------------------------------------------
+    exec->registrationOpen = true;
+    entry->register_types(exec.get(), cfg->user_config_ptr);
+    exec->registrationOpen = false;
+    int rc = buildDeviceState(exec.get());
+    if (rc != 0) return rc;
+    entry->bind_device_state(exec->stateDev);
+
+    // ---- world constructors (device) -----------------------------------------
+    rc = devAlloc(exec.get(), &exec->userCfgDev,
+                  std::max<uint32_t>(cfg->num_user_config_bytes, 16u));
+    if (rc != 0) return rc;
+    if (cfg->num_user_config_bytes > 0) {
+        HIPCHK(hipMemcpy(exec->userCfgDev, cfg->user_config_ptr,
+            cfg->num_user_config_bytes, hipMemcpyHostToDevice));
+    }
+    size_t init_bytes = (size_t)cfg->num_world_init_bytes * cfg->num_worlds;
+    rc = devAlloc(exec.get(), &exec->worldInitsDev,
+                  std::max<size_t>(init_bytes, 16));
+    if (rc != 0) return rc;
+    if (init_bytes > 0 && cfg->world_init_ptr != nullptr) {
+        HIPCHK(hipMemcpy(exec->worldInitsDev, cfg->world_init_ptr, init_bytes,
+                         hipMemcpyHostToDevice));
+    }
+
+    rc = constructWorlds(exec.get());
+    if (rc != 0) return rc;
+    rc = sortAllArchetypes(exec.get());
+    if (rc != 0) return rc;
+
+    // ---- setupTasks (host) ----------------------------------------------------
+    g_lastError.clear();
+    entry->setup_tasks(exec.get(), cfg->user_config_ptr);
+
+    *out = exec.release();
+    return 0;
+}
+
+extern "C" void mwhip_destroy(mwhip_exec *exec)
+{
+    if (exec == nullptr) return;
+    (void)hipSetDevice(exec->cfg.gpu_id);
+    (void)hipStreamSynchronize(exec->stream);
+    for (auto &kv : exec->launchGraphs) {
+        if (kv.second->graphExec) (void)hipGraphExecDestroy(kv.second->graphExec);
+        if (kv.second->graph) (void)hipGraphDestroy(kv.second->graph);
+    }
+    for (void *p : exec->allocations) {
+        (void)hipFree(p);
+    }
+    if (exec->statsHost) (void)hipHostFree(exec->statsHost);
+    (void)hipStreamDestroy(exec->stream);
+    delete exec;
+}
+
+// ---------------------------------------------------------------------------
+// task graph
+// ---------------------------------------------------------------------------
+extern "C" int32_t mwhip_tg_add_node_data(mwhip_exec *exec, uint32_t tg_id,
+                                          const void *data, uint32_t num_bytes)
+{
+    if (tg_id >= exec->taskGraphs.size()) {
+        return fail(-3, "task graph %u out of range (numTaskGraphs=%zu)", tg_id,
+                    exec->taskGraphs.size());
+    }
+    if (num_bytes > 256) {
+        return fail(-2, "node data larger than 256 bytes");
+    }
+    void *dev = nullptr;
+    int rc = devAlloc(exec, &dev, 256);
+    if (rc != 0) return rc;
+    if (num_bytes > 0) {
+        HIPCHK(hipMemcpy(dev, data, num_bytes, hipMemcpyHostToDevice));
+    }
+    TaskGraphRec &tg = exec->taskGraphs[tg_id];
+    tg.dataDev.push_back(dev);
+    return (int32_t)tg.dataDev.size() - 1;
+}
+
+extern "C" void *mwhip_tg_node_data(mwhip_exec *exec, uint32_t tg_id,
+                                    int32_t data_id)
+{
+    if (tg_id >= exec->taskGraphs.size()) return nullptr;
+    TaskGraphRec &tg = exec->taskGraphs[tg_id];
+    if (data_id < 0 || (size_t)data_id >= tg.dataDev.size()) return nullptr;
+    return tg.dataDev[data_id];
+}
+
+extern "C" int32_t mwhip_tg_add_node(mwhip_exec *exec, uint32_t tg_id,
+                                     const mwhip_node_desc *desc,
+                                     const int32_t *deps, uint32_t num_deps)
+{
+    if (tg_id >= exec->taskGraphs.size()) {
+        return fail(-3, "task graph %u out of range (numTaskGraphs=%zu)", tg_id,
+                    exec->taskGraphs.size());
+    }
+    TaskGraphRec &tg = exec->taskGraphs[tg_id];
+
+    NodeRec node;
+    node.desc = *desc;
+    node.name = desc->name != nullptr ? desc->name : "node";
+    node.desc.name = nullptr;
+    for (uint32_t i = 0; i < num_deps; i++) {
+        if (deps[i] < 0 || (size_t)deps[i] >= tg.nodes.size()) {
+            return fail(-3, "node '%s' depends on unknown node %d",
+                        node.name.c_str(), deps[i]);
+        }
+        node.deps.push_back(deps[i]);
+    }
+    if (desc->kind == MWHIP_NODE_KERNEL && desc->kernel == nullptr) {
+        return fail(-3, "node '%s' has no kernel", node.name.c_str());
+    }
+
+    tg.nodes.push_back(std::move(node));
+    tg.built = false;
+    return (int32_t)tg.nodes.size() - 1;
+}
+
+// Same ordering rule as the reference builder (taskgraph_utils.cpp:74-146,
+// identical on CPU: src/core/taskgraph.cpp:53-117): repeatedly take the first
+// not-yet-queued node; queue it if all of its dependencies are queued.
+static int topoSort(TaskGraphRec &tg)
+{
+    const size_t n = tg.nodes.size();
+    tg.sorted.clear();
+    if (n == 0) {
+        tg.built = true;
+        return 0;
+    }
+
+    std::vector<bool> queued(n, false);
+    size_t remaining = n;
+    size_t guard = 0;
+    while (remaining > 0) {
+        bool progressed = false;
+        for (size_t i = 0; i < n; i++) {
+            if (queued[i]) continue;
+            bool ready = true;
+            for (int32_t dep : tg.nodes[i].deps) {
+                if (!queued[dep]) {
+                    ready = false;
+                    break;
+                }
+            }
+            if (ready) {
+                queued[i] = true;
+                tg.sorted.push_back((int32_t)i);
+                remaining--;
+                progressed = true;
+                break;
+            }
+        }
+        if (!progressed || ++guard > n * n + 1) {
+            return fail(-3, "task graph has a dependency cycle");
+        }
+    }
+    tg.built = true;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// launch graphs
+// ---------------------------------------------------------------------------
+extern "C" int mwhip_build_launch_graph(mwhip_exec *exec,
+                                        const uint32_t *taskgraph_ids,
+                                        uint32_t num_taskgraphs,
+                                        const char *stat_name,
+                                        uint64_t *graph_out)
+{
+    HIPCHK(hipSetDevice(exec->cfg.gpu_id));
+
+    std::vector<uint32_t> ids(taskgraph_ids, taskgraph_ids + num_taskgraphs);
+    for (uint32_t id : ids) {
+        if (id >= exec->taskGraphs.size()) {
+            return fail(-3, "task graph %u does not exist", id);
+        }
+        if (!exec->taskGraphs[id].built) {
+            int rc = topoSort(exec->taskGraphs[id]);
+            if (rc != 0) return rc;
+        }
+    }
+
+    std::unique_ptr<LaunchGraph> lg(new LaunchGraph {});
+    lg->statName = stat_name != nullptr ? stat_name : "";
+    int rc = buildLaunchList(exec, ids, *lg);
+    if (rc != 0) return rc;
+
+    HIPCHK(hipStreamBeginCapture(exec->stream, hipStreamCaptureModeThreadLocal));
+    for (KernelLaunch &k : lg->launches) {
+        rc = launchOne(exec, k, exec->stream);
+        if (rc != 0) {
+            hipGraph_t dead = nullptr;
+            (void)hipStreamEndCapture(exec->stream, &dead);
+            if (dead) (void)hipGraphDestroy(dead);
+            return rc;
+        }
+    }
+    HIPCHK(hipStreamEndCapture(exec->stream, &lg->graph));
+    HIPCHK(hipGraphInstantiate(&lg->graphExec, lg->graph, nullptr, nullptr, 0));
+
+    uint64_t handle = exec->nextGraphHandle++;
+    exec->launchGraphs[handle] = std::move(lg);
+    *graph_out = handle;
+    return 0;
+}
+
+extern "C" void mwhip_free_launch_graph(mwhip_exec *exec, uint64_t graph)
+{
+    auto it = exec->launchGraphs.find(graph);
+    if (it == exec->launchGraphs.end()) return;
+    (void)hipStreamSynchronize(exec->stream);
+    if (it->second->graphExec) (void)hipGraphExecDestroy(it->second->graphExec);
+    if (it->second->graph) (void)hipGraphDestroy(it->second->graph);
+    exec->launchGraphs.erase(it);
+}
+
+static int checkHealth(mwhip_exec *exec)
+{
+    if (!exec->checkAfterRun) return 0;
+    uint32_t flags = (uint32_t)exec->statsHost[0];
+    if (flags != 0) {
+        return fail(-5, "device error 0x%x: %s", flags, describeError(flags));
+    }
+    return 0;
+}
+
+extern "C" int mwhip_run(mwhip_exec *exec, uint64_t graph)
+{
+    auto it = exec->launchGraphs.find(graph);
+    if (it == exec->launchGraphs.end()) {
+        return fail(-3, "unknown launch graph");
+    }
+    HIPCHK(hipGraphLaunch(it->second->graphExec, exec->stream));
+    HIPCHK(hipStreamSynchronize(exec->stream));
+    return checkHealth(exec);
+}
+
+extern "C" int mwhip_run_async(mwhip_exec *exec, uint64_t graph, void *hip_stream)
+{
+    auto it = exec->launchGraphs.find(graph);
+    if (it == exec->launchGraphs.end()) {
+        return fail(-3, "unknown launch graph");
+    }
+    // health of the *previous* completed replay
+    int rc = checkHealth(exec);
+    if (rc != 0) return rc;
+    HIPCHK(hipGraphLaunch(it->second->graphExec, (hipStream_t)hip_stream));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// introspection
+// ---------------------------------------------------------------------------
+extern "C" int32_t mwhip_num_rows(mwhip_exec *exec, uint32_t archetype_id)
+{
+    if (archetype_id >= exec->archetypes.size() ||
+            !exec->archetypes[archetype_id].registered) {
+        return -1;
+    }
+    TableHdr hdr;
+    if (hipMemcpy(&hdr, exec->hostState.tables + archetype_id, sizeof(TableHdr),
+                  hipMemcpyDeviceToHost) != hipSuccess) {
+        return -1;
+    }
+    return hdr.numRows;
+}
+
+extern "C" int64_t mwhip_dump_column(mwhip_exec *exec, uint32_t archetype_id,
+                                     uint32_t component_id, void *dst,
+                                     uint64_t dst_bytes, int32_t *world_counts)
+{
+    if (archetype_id >= exec->archetypes.size() ||
+            !exec->archetypes[archetype_id].registered) {
+        fail(-3, "dump: archetype %u not registered", archetype_id);
+        return -1;
+    }
+    (void)hipSetDevice(exec->cfg.gpu_id);
+    (void)hipStreamSynchronize(exec->stream);
+
+    const ArchetypeRec &arch = exec->archetypes[archetype_id];
+    int col = findColumn(arch, component_id);
+    if (col < 0) {
+        fail(-3, "dump: archetype %u has no component %u", archetype_id,
+             component_id);
+        return -1;
+    }
+
+    // the live header knows which of the ping-pong buffers is current
+    TableHdr hdr;
+    if (hipMemcpy(&hdr, exec->hostState.tables + archetype_id, sizeof(TableHdr),
+                  hipMemcpyDeviceToHost) != hipSuccess) {
+        return -1;
+    }
+
+    const uint32_t W = exec->cfg.num_worlds;
+    std::vector<int32_t> offsets(W), counts(W);
+    if (hipMemcpy(offsets.data(), hdr.worldOffsets, W * sizeof(int32_t),
+                  hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(counts.data(), hdr.worldCounts, W * sizeof(int32_t),
+                  hipMemcpyDeviceToHost) != hipSuccess) {
+        return -1;
+    }
+
+    const uint32_t elem = arch.colBytes[col];
+    int64_t total = 0;
+    bool contiguous = true;
+    for (uint32_t w = 0; w < W; w++) {
+        if (counts[w] < 0 || offsets[w] < 0) {
+            fail(-3, "dump: table %u is not sorted by world", archetype_id);
+            return -1;
+        }
+        if (counts[w] > 0 && offsets[w] != total) contiguous = false;
+        total += counts[w];
+        world_counts[w] = counts[w];
+    }
+    if ((uint64_t)total * elem > dst_bytes) {
+        return -2;
+    }
+
+    if (contiguous) {
+        if (total > 0 && hipMemcpy(dst, hdr.columns[col], (size_t)total * elem,
+                hipMemcpyDeviceToHost) != hipSuccess) {
+            return -1;
+        }
+    } else {
+        char *out = (char *)dst;
+        for (uint32_t w = 0; w < W; w++) {
+            size_t nb = (size_t)counts[w] * elem;
+            if (nb == 0) continue;
+            if (hipMemcpy(out, (char *)hdr.columns[col] +
+                    (size_t)offsets[w] * elem, nb,
+                    hipMemcpyDeviceToHost) != hipSuccess) {
+                return -1;
+            }
+            out += nb;
+        }
+    }
+    return total;
+}
+
+extern "C" int mwhip_memcpy_d2h(void *dst_host, const void *src_dev,
+                                uint64_t num_bytes)
+{
+    HIPCHK(hipMemcpy(dst_host, src_dev, num_bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int mwhip_memcpy_h2d(void *dst_dev, const void *src_host,
+                                uint64_t num_bytes)
+{
+    HIPCHK(hipMemcpy(dst_dev, src_host, num_bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// per-kernel timing + algorithmic bytes
+// ---------------------------------------------------------------------------
+static int readRowCounts(mwhip_exec *exec, std::vector<int32_t> &rows)
+{
+    std::vector<TableHdr> hdrs(exec->tablesHost.size());
+    HIPCHK(hipMemcpy(hdrs.data(), exec->hostState.tables,
+        hdrs.size() * sizeof(TableHdr), hipMemcpyDeviceToHost));
+    rows.resize(hdrs.size());
+    for (size_t i = 0; i < hdrs.size(); i++) rows[i] = hdrs[i].numRows;
+    return 0;
+}
+
+extern "C" int32_t mwhip_profile(mwhip_exec *exec, uint64_t graph, uint32_t reps,
+                                 mwhip_kernel_stat *out, uint32_t max_out)
+{
+    auto it = exec->launchGraphs.find(graph);
+    if (it == exec->launchGraphs.end()) {
+        return fail(-3, "unknown launch graph");
+    }
+    LaunchGraph &lg = *it->second;
+    const size_t n = lg.launches.size();
+    if (reps == 0) reps = 1;
+
+    HIPCHK(hipSetDevice(exec->cfg.gpu_id));
+    HIPCHK(hipStreamSynchronize(exec->stream));
+
+    std::vector<hipEvent_t> ev(n + 1);
+    for (auto &e : ev) HIPCHK(hipEventCreate(&e));
+
+    std::vector<double> total_us(n, 0.0), total_rows(n, 0.0),
+        total_bytes(n, 0.0);
+
+    // snapshot sort statistics to turn them into per-launch averages
+    struct SiteSnap { SortState before, after; };
+    std::vector<std::vector<SiteSnap>> snaps(lg.sortBatches.size());
+    for (size_t b = 0; b < lg.sortBatches.size(); b++) {
+        snaps[b].resize(lg.sortBatches[b]->sites.size());
+        for (size_t s = 0; s < snaps[b].size(); s++) {
+            HIPCHK(hipMemcpy(&snaps[b][s].before,
+                lg.sortBatches[b]->sites[s].stateDev, sizeof(SortState),
+                hipMemcpyDeviceToHost));
+        }
+    }
+
+    for (uint32_t r = 0; r < reps; r++) {
+        std::vector<int32_t> rows;
+        int rc = readRowCounts(exec, rows);
+        if (rc != 0) return rc;
+
+        // queue everything behind the gate, then open it
+        volatile int32_t *gate_host = exec->statsHost + 2 + kMaxArchetypes;
+        *gate_host = 0;
+        __sync_synchronize();
+        {
+            int32_t *gate_dev = nullptr;
+            HIPCHK(hipHostGetDevicePointer((void **)&gate_dev,
+                (void *)(exec->statsHost + 2 + kMaxArchetypes), 0));
+            void *gargs[] = { &gate_dev };
+            HIPCHK(hipLaunchKernel((const void *)&gateKernel, dim3(1), dim3(64),
+                                   gargs, 0, exec->stream));
+        }
+        for (size_t i = 0; i < n; i++) {
+            HIPCHK(hipEventRecord(ev[i], exec->stream));
+            rc = launchOne(exec, lg.launches[i], exec->stream);
+            if (rc != 0) {
+                *gate_host = 1;
+                return rc;
+            }
+        }
+        HIPCHK(hipEventRecord(ev[n], exec->stream));
+        *gate_host = 1;
+        __sync_synchronize();
+        HIPCHK(hipStreamSynchronize(exec->stream));
+        rc = checkHealth(exec);
+        if (rc != 0) return rc;
+
+        for (size_t i = 0; i < n; i++) {
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+            total_us[i] += (double)ms * 1000.0;
+
+            const KernelLaunch &k = lg.launches[i];
+            if (k.kind == MWHIP_NODE_KERNEL &&
+                    k.countMode == MWHIP_COUNT_QUERY_ROWS) {
+                // rows at the start of the step (steady-state approximation)
+                double nrows = 0;
+                for (const QueryRec &q : exec->queries) {
+                    if (q.offset != k.queryOffset) continue;
+                    const uint32_t *p =
+                        exec->queryDataHost.data() + q.offset;
+                    for (uint32_t m = 0; m < q.numMatching; m++) {
+                        nrows += rows[p[0]];
+                        p += 1 + q.comps.size();
+                    }
+                    break;
+                }
+                total_rows[i] += nrows;
+                total_bytes[i] += nrows * k.bytesPerRow;
+            }
+        }
+    }
+
+    // sort kernels: bytes from the measured rows in / out of each site
+    for (size_t b = 0; b < lg.sortBatches.size(); b++) {
+        const SortBatch &batch = *lg.sortBatches[b];
+        double hist = 0, pass0 = 0, passn = 0, gather = 0, fin = 0, rows_in = 0;
+        for (size_t s = 0; s < batch.sites.size(); s++) {
+            HIPCHK(hipMemcpy(&snaps[b][s].after, batch.sites[s].stateDev,
+                sizeof(SortState), hipMemcpyDeviceToHost));
+            double n_in = (double)(snaps[b][s].after.statRowsIn -
+                                   snaps[b][s].before.statRowsIn) / reps;
+            double n_out = (double)(snaps[b][s].after.statRowsOut -
+                                    snaps[b][s].before.statRowsOut) / reps;
+            double runs = (double)(snaps[b][s].after.statRuns -
+                                   snaps[b][s].before.statRuns) / reps;
+            rows_in += n_in;
+            hist += 4.0 * n_in + 8.0 * exec->cfg.num_worlds * runs;
+            pass0 += 4.0 * n_in + 8.0 * n_in;
+            passn += 16.0 * n_in;
+            gather += 4.0 * n_out + 2.0 * batch.sites[s].rowBytes * n_out +
+                4.0 * n_out;
+            fin += 8.0 * exec->cfg.num_worlds * runs;
+        }
+        uint32_t pass_idx = 0;
+        for (size_t i = 0; i < n; i++) {
+            const KernelLaunch &k = lg.launches[i];
+            if (k.sortBatch != &batch) continue;
+            double bytes = 0;
+            switch (k.sortRole) {
+            case SortRole::Histogram: bytes = hist; pass_idx = 0; break;
+            case SortRole::Onesweep:
+                bytes = pass_idx == 0 ? pass0 : passn;
+                pass_idx++;
+                break;
+            case SortRole::Gather: bytes = gather; break;
+            case SortRole::Finalize: bytes = fin; break;
+            default: break;
+            }
+            total_bytes[i] = bytes * reps;
+            total_rows[i] = rows_in * reps;
+        }
+    }
+
+    for (auto &e : ev) (void)hipEventDestroy(e);
+
+    lg.statNames.resize(n);
+    uint32_t count = (uint32_t)std::min<size_t>(n, max_out);
+    for (uint32_t i = 0; i < count; i++) {
+        const KernelLaunch &k = lg.launches[i];
+        lg.statNames[i] = k.name;
+        if (k.role[0] != '\0') {
+            lg.statNames[i] += ":";
+            lg.statNames[i] += k.role;
+        }
+        out[i].name = lg.statNames[i].c_str();
+        out[i].node_kind = k.kind;
+        out[i].archetype_id = k.archetype;
+        out[i].avg_us = total_us[i] / reps;
+        out[i].algo_bytes = total_bytes[i] / reps;
+        out[i].rows = total_rows[i] / reps;
+    }
+    return (int32_t)n;
+}

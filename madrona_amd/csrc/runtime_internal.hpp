@@ -1,0 +1,129 @@
+// Internal declarations shared by the translation units of libmadrona_hip.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <madrona/ecs.hpp>
+#include <madrona/mwhip/ecs_state.hpp>
+#include <mwhip.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace madrona {
+namespace mwhip {
+
+// ---- sort ----------------------------------------------------------------------
+
+// Device-resident, per sort site (one per sorted archetype+key).
+struct SortState {
+    uint32_t bins[4 * 256];         // digit histograms of up to 4 passes
+    uint32_t tileCounter[4];        // onesweep tile tickets per pass
+    uint32_t numValid;              // rows whose key != 0xFFFFFFFF
+    uint32_t epoch;                 // tags look-back granules; never reset
+    uint32_t finalizeArrivals;
+    uint32_t pad_;
+    unsigned long long statRowsIn;  // cumulative, for measurement
+    unsigned long long statRowsOut;
+    unsigned long long statRuns;
+};
+
+struct SortSite {
+    uint32_t archetype;
+    uint32_t keyColumn;
+    int32_t numPasses;
+    uint32_t worldSort;
+    uint32_t *keysA;
+    uint32_t *keysB;
+    int32_t *idxA;
+    int32_t *idxB;
+    unsigned long long *lookback;   // [numTiles][256] granules
+    SortState *state;
+};
+
+struct GatherColumn {
+    uint32_t site;
+    uint32_t column;
+    uint32_t wordBytes;             // 16 / 8 / 4 / 1
+    uint32_t wordsPerRow;
+    unsigned long long invMagic;    // floor(2^64 / wordsPerRow) + 1
+};
+
+struct SortSiteHost {
+    uint32_t archetype;
+    uint32_t keyColumn;
+    int numPasses;
+    bool worldSort;
+    uint32_t capacity;
+    uint32_t rowBytes;
+    SortState *stateDev;
+};
+
+enum class SortRole : uint32_t { None, Histogram, Onesweep, Gather, Finalize };
+
+struct SortBatch {
+    std::vector<SortSiteHost> sites;
+    EcsState *stateDev = nullptr;
+    SortSite *sitesDev = nullptr;
+    GatherColumn *gatherColumnsDev = nullptr;
+    uint32_t numGatherColumns = 0;
+};
+
+// ---- launches ------------------------------------------------------------------
+
+struct KernelLaunch {
+    const void *fn = nullptr;
+    dim3 grid { 1, 1, 1 };
+    dim3 block { 1, 1, 1 };
+    alignas(16) unsigned char argStorage[64] {};
+    uint32_t argOffsets[8] {};
+    uint32_t numArgs = 0;
+
+    std::string name;               // node name
+    const char *role = "";          // kernel role inside the node
+    uint32_t kind = MWHIP_NODE_KERNEL;
+    uint32_t archetype = 0xFFFFFFFFu;
+    uint32_t bytesPerRow = 0;
+    uint32_t countMode = 0;
+    uint32_t fixedCount = 0;
+    uint32_t queryOffset = 0;
+    uint32_t numMatching = 0;
+    const SortBatch *sortBatch = nullptr;
+    SortRole sortRole = SortRole::None;
+
+    template <typename T>
+    void pushArg(const T &v)
+    {
+        uint32_t off = numArgs == 0 ? 0 : argOffsets[numArgs];
+        off = (off + (uint32_t)alignof(T) - 1) & ~((uint32_t)alignof(T) - 1);
+        memcpy(argStorage + off, &v, sizeof(T));
+        argOffsets[numArgs] = off;
+        numArgs += 1;
+        argOffsets[numArgs] = off + (uint32_t)sizeof(T);
+    }
+
+    template <typename... Ts>
+    void setArgs(const Ts &...vs)
+    {
+        numArgs = 0;
+        argOffsets[0] = 0;
+        (pushArg(vs), ...);
+    }
+
+    void argPointers(void **out)
+    {
+        for (uint32_t i = 0; i < numArgs; i++) {
+            out[i] = argStorage + argOffsets[i];
+        }
+    }
+};
+
+int sortNumPasses(bool world_sort, uint32_t num_worlds);
+uint32_t sortTileSize();
+void buildSortLaunches(const SortBatch &batch, std::vector<KernelLaunch> &out);
+
+}
+}

@@ -1,0 +1,665 @@
+// SortArchetypeNode / CompactArchetypeNode for gfx950 (MI355X, CDNA4).
+//
+// Contract (reference src/mw/device/sort_archetype.cpp):
+// stable ascending sort of an archetype's global table by a 4-byte key column
+// (the WorldID column for the "compaction" sort), every other column permuted
+// with the same permutation, rows whose WorldID is -1 (destroyed) dropped,
+// entity_store[e.id].loc.row updated, worldOffsets[]/worldCounts[] rebuilt.
+//
+// This is NOT the reference's CUB-derived pipeline (~20 megakernel nodes, 512
+// key tiles, every payload column moved twice).  Design for CDNA4:
+//   kernel 1  sortHistogram   per-tile LDS histograms of all P digits at once,
+//                             count of surviving rows, offsets/counts cleared
+//   kernel 2..P+1 sortOnesweep  one LSD pass each: 2048-key tiles (8 keys per
+//                             lane, 4 wave64s), wave-ballot digit matching +
+//                             mbcnt ranking, keys/indices staged through LDS
+//                             so the global scatter is digit-contiguous,
+//                             decoupled look-back through 8-byte
+//                             {epoch tag, status|count} granules stored and
+//                             polled with relaxed agent-scope atomics (no
+//                             fences needed: the data is the flag), tiles
+//                             ordered by an atomic ticket so a spinning tile's
+//                             predecessors are always resident
+//   kernel P+2 sortGather     ONE fused out-of-place gather over all columns
+//                             (grid.y = column) into the ping-pong twin of each
+//                             column, vectorised to 16/8/4-byte words so stores
+//                             are fully coalesced; entity Loc remap and world
+//                             boundary detection fused in
+//   kernel P+3 sortFinalize   empty-world fix-up, copy-back of pinned
+//                             (exported) columns, and -- by the last block to
+//                             finish -- column pointer swap, new row count,
+//                             self-cleaning of bins/counters for the next run
+// Every kernel takes an array of sort "sites" and picks sites[blockIdx.y /
+// column map], so consecutive sort nodes of a task graph run as ONE chain.
+//
+// Algorithmic HBM bytes per sort: 4N (histogram) + P*16N
+// (key+index read & write per pass, first pass reads keys only) + 4N' (index
+// read) + 2*B_row*N' (every column read once, written once).
+#include "runtime_internal.hpp"
+
+namespace madrona {
+namespace mwhip {
+
+namespace {
+
+constexpr int kSortThreads = 256;
+constexpr int kSortWaves = kSortThreads / 64;
+constexpr int kSortItems = 8;
+constexpr int kSortTile = kSortThreads * kSortItems;   // 2048 keys
+constexpr int kRadixBits = 8;
+constexpr int kRadixDigits = 1 << kRadixBits;
+
+constexpr unsigned long long kStatusAggregate = 1ull << 30;
+constexpr unsigned long long kStatusInclusive = 2ull << 30;
+constexpr unsigned long long kCountMask = (1ull << 30) - 1ull;
+
+__device__ inline uint32_t sortKey(const SortSite &site, uint32_t raw)
+{
+    // World sort: keys are world ids in [0, W) or 0xFFFFFFFF for destroyed
+    // rows; only the low 8*P bits are sorted, and the all-ones pattern still
+    // sorts after every live world because W <= 2^(8P) - 1.
+    (void)site;
+    return raw;
+}
+
+__device__ inline unsigned long long ballot64(bool pred)
+{
+    return __ballot(pred);
+}
+
+__device__ inline uint32_t laneId()
+{
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+// Exclusive scan of one value per thread across a 256-thread block.
+// scratch: kSortWaves uint32 in LDS.
+__device__ inline uint32_t blockExclusiveScan256(uint32_t v, uint32_t *scratch,
+                                                 uint32_t *total_out)
+{
+    const uint32_t lane = laneId();
+    const uint32_t wave = threadIdx.x >> 6;
+
+    uint32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t up = __shfl_up(incl, d, 64);
+        if ((int)lane >= d) incl += up;
+    }
+
+    if (lane == 63) {
+        scratch[wave] = incl;
+    }
+    __syncthreads();
+
+    uint32_t wave_base = 0;
+    uint32_t total = 0;
+#pragma unroll
+    for (int w = 0; w < kSortWaves; w++) {
+        uint32_t s = scratch[w];
+        if (w < (int)wave) wave_base += s;
+        total += s;
+    }
+    __syncthreads();
+
+    if (total_out != nullptr) *total_out = total;
+    return wave_base + incl - v;
+}
+
+// ---------------------------------------------------------------------------
+// kernel 1: histogram of every pass's digit + survivors + clear offsets
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(kSortThreads)
+sortHistogram(EcsState *S, const SortSite *sites)
+{
+    const SortSite &site = sites[blockIdx.y];
+    TableHdr &tbl = S->tables[site.archetype];
+
+    if (site.worldSort && tbl.needsSort == 0u) {
+        return;
+    }
+
+    const int32_t n = tbl.numRows;
+    const int32_t num_passes = site.numPasses;
+    const uint32_t *keys = (const uint32_t *)tbl.columns[site.keyColumn];
+    SortState *state = site.state;
+
+    __shared__ uint32_t lds_hist[4][kRadixDigits];
+    __shared__ uint32_t lds_valid;
+
+    for (int i = threadIdx.x; i < 4 * kRadixDigits; i += kSortThreads) {
+        (&lds_hist[0][0])[i] = 0;
+    }
+    if (threadIdx.x == 0) lds_valid = 0;
+    __syncthreads();
+
+    uint32_t my_valid = 0;
+    const int32_t stride = (int32_t)(gridDim.x * kSortThreads);
+    for (int32_t i = (int32_t)(blockIdx.x * kSortThreads + threadIdx.x); i < n;
+         i += stride) {
+        uint32_t key = sortKey(site, keys[i]);
+        my_valid += (key != 0xFFFFFFFFu) ? 1u : 0u;
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            if (p < num_passes) {
+                atomicAdd(&lds_hist[p][(key >> (p * kRadixBits)) & 0xFFu], 1u);
+            }
+        }
+    }
+
+    // wave-reduce the survivor count, one LDS atomic per wave
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        my_valid += __shfl_down(my_valid, d, 64);
+    }
+    if (laneId() == 0 && my_valid != 0) {
+        atomicAdd(&lds_valid, my_valid);
+    }
+    __syncthreads();
+
+    for (int i = threadIdx.x; i < num_passes * kRadixDigits; i += kSortThreads) {
+        uint32_t c = (&lds_hist[0][0])[i];
+        if (c != 0) {
+            atomicAdd(&state->bins[i], c);
+        }
+    }
+    if (threadIdx.x == 0 && lds_valid != 0) {
+        atomicAdd(&state->numValid, lds_valid);
+    }
+
+    if (site.worldSort) {
+        // sentinel: "no row of this world seen"; fixed up in sortFinalize
+        for (int32_t w = (int32_t)(blockIdx.x * kSortThreads + threadIdx.x);
+             w < S->numWorlds; w += stride) {
+            tbl.worldOffsets[w] = -1;
+            tbl.worldCounts[w] = -1;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// kernel 2: one LSD radix pass (one-sweep, decoupled look-back)
+// ---------------------------------------------------------------------------
+struct alignas(16) OnesweepLDS {
+    uint32_t waveHist[kSortWaves][kRadixDigits]; // per-wave digit counts -> offsets
+    uint32_t digitStart[kRadixDigits];           // tile-local exclusive digit offsets
+    int32_t globalBase[kRadixDigits];            // dst index of local position 0 of digit
+    uint32_t stageKeys[kSortTile];
+    int32_t stageIdx[kSortTile];
+    uint32_t scanScratch[kSortWaves];
+    uint32_t tile;
+};
+
+__global__ void __launch_bounds__(kSortThreads)
+sortOnesweep(EcsState *S, const SortSite *sites, uint32_t pass)
+{
+    const SortSite &site = sites[blockIdx.y];
+    TableHdr &tbl = S->tables[site.archetype];
+
+    if ((int32_t)pass >= site.numPasses) {
+        return;
+    }
+    if (site.worldSort && tbl.needsSort == 0u) {
+        return;
+    }
+
+    const int32_t n = tbl.numRows;
+    SortState *state = site.state;
+
+    __shared__ OnesweepLDS lds;
+
+    // ticket: tile order == start order, so predecessors are always resident
+    if (threadIdx.x == 0) {
+        lds.tile = atomicAdd(&state->tileCounter[pass], 1u);
+    }
+    for (int i = threadIdx.x; i < kSortWaves * kRadixDigits; i += kSortThreads) {
+        (&lds.waveHist[0][0])[i] = 0;
+    }
+    __syncthreads();
+
+    const uint32_t tile = lds.tile;
+    const int32_t tile_base = (int32_t)(tile * (uint32_t)kSortTile);
+    if (tile_base >= n) {
+        return;
+    }
+    const int32_t tile_count = min(kSortTile, n - tile_base);
+
+    const uint32_t *keys_in;
+    const int32_t *idx_in;
+    if (pass == 0) {
+        keys_in = (const uint32_t *)tbl.columns[site.keyColumn];
+        idx_in = nullptr;
+    } else {
+        keys_in = (pass & 1u) ? site.keysA : site.keysB;
+        idx_in = (pass & 1u) ? site.idxA : site.idxB;
+    }
+    uint32_t *keys_out = (pass & 1u) ? site.keysB : site.keysA;
+    int32_t *idx_out = (pass & 1u) ? site.idxB : site.idxA;
+
+    const uint32_t shift = pass * kRadixBits;
+    const uint32_t lane = laneId();
+    const uint32_t wave = threadIdx.x >> 6;
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+
+    // ---- load (wave-striped: wave w owns a contiguous 512-key run, item j of
+    // lane l is key j*64+l of the run, which keeps the sort stable) ----------
+    uint32_t key[kSortItems];
+    int32_t idx[kSortItems];
+    uint32_t rank[kSortItems];
+
+    const int32_t wave_base = (int32_t)(wave * 64u * kSortItems);
+#pragma unroll
+    for (int j = 0; j < kSortItems; j++) {
+        int32_t local = wave_base + j * 64 + (int32_t)lane;
+        bool valid = local < tile_count;
+        int32_t gi = tile_base + local;
+        key[j] = valid ? sortKey(site, keys_in[gi]) : 0xFFFFFFFFu;
+        idx[j] = valid ? (idx_in != nullptr ? idx_in[gi] : gi) : -1;
+    }
+
+    // ---- rank within the wave: ballot-match the 8 digit bits ---------------
+#pragma unroll
+    for (int j = 0; j < kSortItems; j++) {
+        int32_t local = wave_base + j * 64 + (int32_t)lane;
+        bool valid = local < tile_count;
+        uint32_t digit = (key[j] >> shift) & 0xFFu;
+
+        unsigned long long match = ballot64(valid);
+#pragma unroll
+        for (int b = 0; b < kRadixBits; b++) {
+            bool bit = ((digit >> b) & 1u) != 0u;
+            unsigned long long vote = ballot64(bit && valid);
+            match &= bit ? vote : ~vote;
+        }
+
+        uint32_t before = (uint32_t)__popcll(match & lane_lt);
+        uint32_t count = (uint32_t)__popcll(match);
+
+        uint32_t prev = 0;
+        if (valid) {
+            prev = lds.waveHist[wave][digit];
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (valid && before == 0) {
+            lds.waveHist[wave][digit] = prev + count;
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        rank[j] = prev + before;
+    }
+    __syncthreads();
+
+    // ---- per-digit: wave offsets, tile totals, tile-local digit starts -----
+    const uint32_t d = threadIdx.x;     // 256 threads <-> 256 digits
+    uint32_t digit_total = 0;
+#pragma unroll
+    for (int w = 0; w < kSortWaves; w++) {
+        uint32_t c = lds.waveHist[w][d];
+        lds.waveHist[w][d] = digit_total;
+        digit_total += c;
+    }
+
+    // global start of this digit = exclusive scan of the pass's histogram
+    uint32_t bin_count = state->bins[pass * kRadixDigits + d];
+    uint32_t bin_start = blockExclusiveScan256(bin_count, lds.scanScratch, nullptr);
+    uint32_t digit_start =
+        blockExclusiveScan256(digit_total, lds.scanScratch, nullptr);
+    lds.digitStart[d] = digit_start;
+
+    // ---- decoupled look-back over predecessor tiles for digit d ------------
+    const uint32_t tag = state->epoch * 8u + pass + 1u;
+    unsigned long long *granules = site.lookback;
+    const size_t my_slot = (size_t)tile * kRadixDigits + d;
+
+    uint32_t exclusive = 0;
+    if (tile == 0) {
+        __hip_atomic_store(&granules[my_slot],
+            ((unsigned long long)tag << 32) | kStatusInclusive | digit_total,
+            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        __hip_atomic_store(&granules[my_slot],
+            ((unsigned long long)tag << 32) | kStatusAggregate | digit_total,
+            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+        int32_t look = (int32_t)tile - 1;
+        uint32_t spins = 0;
+        while (true) {
+            unsigned long long g = __hip_atomic_load(
+                &granules[(size_t)look * kRadixDigits + d],
+                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((uint32_t)(g >> 32) != tag) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 26)) {
+                    raiseError(S, kErrSortLookback);
+                    break;
+                }
+                continue;
+            }
+            exclusive += (uint32_t)(g & kCountMask);
+            if ((g & kStatusInclusive) != 0ull) {
+                break;
+            }
+            look -= 1;
+        }
+
+        __hip_atomic_store(&granules[my_slot],
+            ((unsigned long long)tag << 32) | kStatusInclusive |
+                (unsigned long long)(exclusive + digit_total),
+            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+
+    lds.globalBase[d] =
+        (int32_t)(bin_start + exclusive) - (int32_t)digit_start;
+    __syncthreads();
+
+    // ---- stage keys + indices in LDS at their tile-local sorted position ---
+#pragma unroll
+    for (int j = 0; j < kSortItems; j++) {
+        int32_t local = wave_base + j * 64 + (int32_t)lane;
+        if (local < tile_count) {
+            uint32_t digit = (key[j] >> shift) & 0xFFu;
+            uint32_t pos = lds.digitStart[digit] + lds.waveHist[wave][digit] +
+                rank[j];
+            lds.stageKeys[pos] = key[j];
+            lds.stageIdx[pos] = idx[j];
+        }
+    }
+    __syncthreads();
+
+    // ---- digit-contiguous global scatter -----------------------------------
+#pragma unroll
+    for (int j = 0; j < kSortItems; j++) {
+        int32_t pos = j * kSortThreads + (int32_t)threadIdx.x;
+        if (pos < tile_count) {
+            uint32_t k = lds.stageKeys[pos];
+            uint32_t digit = (k >> shift) & 0xFFu;
+            int32_t dst = lds.globalBase[digit] + pos;
+            keys_out[dst] = k;
+            idx_out[dst] = lds.stageIdx[pos];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// kernel 3: fused gather of every column + entity remap + world boundaries
+// ---------------------------------------------------------------------------
+template <typename WordT>
+__device__ inline void gatherWords(const WordT *__restrict__ src,
+                                   WordT *__restrict__ dst,
+                                   const int32_t *__restrict__ perm,
+                                   int32_t num_rows, uint32_t words_per_row,
+                                   unsigned long long inv_magic)
+{
+    const long long total = (long long)num_rows * words_per_row;
+    const long long stride = (long long)gridDim.x * kSortThreads;
+    long long j = (long long)blockIdx.x * kSortThreads + threadIdx.x;
+
+    if (words_per_row == 1) {
+        for (; j < total; j += stride) {
+            dst[j] = src[perm[j]];
+        }
+    } else {
+        for (; j < total; j += stride) {
+            // row = j / words_per_row via a 64-bit reciprocal (exact for j < 2^32)
+            uint32_t row = (uint32_t)__umul64hi((unsigned long long)j, inv_magic);
+            uint32_t off = (uint32_t)(j - (long long)row * words_per_row);
+            dst[j] = src[(long long)perm[row] * words_per_row + off];
+        }
+    }
+}
+
+struct alignas(16) Word16 { uint32_t v[4]; };
+struct alignas(8) Word8 { uint32_t v[2]; };
+
+__global__ void __launch_bounds__(kSortThreads)
+sortGather(EcsState *S, const SortSite *sites, const GatherColumn *columns)
+{
+    const GatherColumn gc = columns[blockIdx.y];
+    const SortSite &site = sites[gc.site];
+    TableHdr &tbl = S->tables[site.archetype];
+
+    if (site.worldSort && tbl.needsSort == 0u) {
+        return;
+    }
+
+    SortState *state = site.state;
+    const int32_t n = tbl.numRows;
+    const int32_t n_out = site.worldSort ? (int32_t)state->numValid : n;
+
+    const bool final_in_b = ((site.numPasses - 1) & 1) != 0;
+    const int32_t *perm = final_in_b ? site.idxB : site.idxA;
+
+    const uint32_t col = gc.column;
+    const void *src = tbl.columns[col];
+    void *dst = tbl.columnsAlt[col];
+
+    if (col == 0) {
+        // Entity column: 8-byte handles; update the entity store's row
+        const Entity *esrc = (const Entity *)src;
+        Entity *edst = (Entity *)dst;
+        const int32_t stride = (int32_t)(gridDim.x * kSortThreads);
+        for (int32_t i = (int32_t)(blockIdx.x * kSortThreads + threadIdx.x);
+             i < n_out; i += stride) {
+            Entity e = esrc[perm[i]];
+            edst[i] = e;
+            if (e.id >= 0) {
+                S->entities[e.id].loc.row = i;
+            }
+        }
+        return;
+    }
+
+    if (col == 1 && site.worldSort) {
+        // WorldID column doubles as the place where per-world ranges are
+        // detected from the sorted keys (contiguous, already in cache).
+        const uint32_t *sorted = final_in_b ? site.keysB : site.keysA;
+        int32_t *wdst = (int32_t *)dst;
+        const int32_t stride = (int32_t)(gridDim.x * kSortThreads);
+        for (int32_t i = (int32_t)(blockIdx.x * kSortThreads + threadIdx.x);
+             i < n_out; i += stride) {
+            uint32_t k = sorted[i];
+            wdst[i] = (int32_t)k;
+            uint32_t kp = i > 0 ? sorted[i - 1] : 0xFFFFFFFFu;
+            if (i == 0 || k != kp) {
+                tbl.worldOffsets[k] = i;
+                if (i > 0) {
+                    tbl.worldCounts[kp] = i;        // end index for now
+                }
+            }
+            if (i == n_out - 1) {
+                tbl.worldCounts[k] = n_out;
+            }
+        }
+        return;
+    }
+
+    switch (gc.wordBytes) {
+    case 16:
+        gatherWords<Word16>((const Word16 *)src, (Word16 *)dst, perm, n_out,
+                            gc.wordsPerRow, gc.invMagic);
+        break;
+    case 8:
+        gatherWords<Word8>((const Word8 *)src, (Word8 *)dst, perm, n_out,
+                           gc.wordsPerRow, gc.invMagic);
+        break;
+    case 4:
+        gatherWords<uint32_t>((const uint32_t *)src, (uint32_t *)dst, perm,
+                              n_out, gc.wordsPerRow, gc.invMagic);
+        break;
+    default:
+        gatherWords<uint8_t>((const uint8_t *)src, (uint8_t *)dst, perm,
+                             n_out, gc.wordsPerRow, gc.invMagic);
+        break;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// kernel 4: finalize
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(kSortThreads)
+sortFinalize(EcsState *S, const SortSite *sites)
+{
+    const SortSite &site = sites[blockIdx.y];
+    TableHdr &tbl = S->tables[site.archetype];
+
+    if (site.worldSort && tbl.needsSort == 0u) {
+        return;
+    }
+
+    SortState *state = site.state;
+    const int32_t n = tbl.numRows;
+    const int32_t n_out = site.worldSort ? (int32_t)state->numValid : n;
+    const int32_t stride = (int32_t)(gridDim.x * kSortThreads);
+    const int32_t tid = (int32_t)(blockIdx.x * kSortThreads + threadIdx.x);
+
+    if (site.worldSort) {
+        for (int32_t w = tid; w < S->numWorlds; w += stride) {
+            int32_t off = tbl.worldOffsets[w];
+            if (off == -1) {
+                tbl.worldOffsets[w] = n_out;
+                tbl.worldCounts[w] = 0;
+            } else {
+                tbl.worldCounts[w] = tbl.worldCounts[w] - off;
+            }
+        }
+    }
+
+    // exported columns must keep their address: copy the gathered data back
+    for (int32_t c = 0; c < tbl.numColumns; c++) {
+        if ((tbl.columnFlags[c] & kColumnPinned) == 0u) continue;
+        const uint32_t *src = (const uint32_t *)tbl.columnsAlt[c];
+        uint32_t *dst = (uint32_t *)tbl.columns[c];
+        // column allocations are padded to 16 B, copy whole dwords
+        long long words = ((long long)n_out * tbl.columnBytes[c] + 3) / 4;
+        for (long long j = tid; j < words; j += stride) {
+            dst[j] = src[j];
+        }
+    }
+
+    // last block to arrive publishes the new table and resets the sort state
+    __shared__ bool is_last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        uint32_t done = atomicAdd(&state->finalizeArrivals, 1u);
+        is_last = (done == gridDim.x - 1);
+    }
+    __syncthreads();
+
+    if (!is_last) {
+        return;
+    }
+
+    for (int32_t c = threadIdx.x; c < tbl.numColumns; c += kSortThreads) {
+        if ((tbl.columnFlags[c] & kColumnPinned) == 0u) {
+            void *tmp = tbl.columns[c];
+            tbl.columns[c] = tbl.columnsAlt[c];
+            tbl.columnsAlt[c] = tmp;
+        }
+    }
+    for (int i = threadIdx.x; i < 4 * kRadixDigits; i += kSortThreads) {
+        state->bins[i] = 0;
+    }
+    if (threadIdx.x == 0) {
+        state->statRowsIn += (unsigned long long)n;
+        state->statRowsOut += (unsigned long long)n_out;
+        state->statRuns += 1ull;
+
+        tbl.numRows = n_out;
+        tbl.needsSort = 0u;
+        state->numValid = 0;
+        state->finalizeArrivals = 0;
+        for (int p = 0; p < 4; p++) state->tileCounter[p] = 0;
+        state->epoch += 1u;
+    }
+}
+
+}
+
+// ---------------------------------------------------------------------------
+// Host side: expand a batch of sort sites into kernel launches
+// ---------------------------------------------------------------------------
+int sortNumPasses(bool world_sort, uint32_t num_worlds)
+{
+    if (!world_sort) {
+        return 4;
+    }
+    // bits needed so that W live world ids and the all-ones "destroyed" key
+    // stay distinct after truncation (reference sort_archetype.cpp:1432-1438)
+    uint32_t bits = 32u - (uint32_t)__builtin_clz(num_worlds + 1u);
+    return (int)((bits + kRadixBits - 1) / kRadixBits);
+}
+
+uint32_t sortTileSize() { return (uint32_t)kSortTile; }
+
+void buildSortLaunches(const SortBatch &batch, std::vector<KernelLaunch> &out)
+{
+    const uint32_t num_sites = (uint32_t)batch.sites.size();
+
+    uint32_t max_capacity = 0;
+    int max_passes = 0;
+    for (const SortSiteHost &s : batch.sites) {
+        max_capacity = std::max(max_capacity, s.capacity);
+        max_passes = std::max(max_passes, s.numPasses);
+    }
+
+    const uint32_t tiles = (max_capacity + kSortTile - 1) / kSortTile;
+    const uint32_t stream_blocks = std::min<uint32_t>(
+        std::max<uint32_t>((max_capacity + kSortThreads * 4 - 1) /
+                           (kSortThreads * 4), 1u), 1024u);
+
+    {
+        KernelLaunch k;
+        k.fn = (const void *)&sortHistogram;
+        k.grid = dim3(stream_blocks, num_sites, 1);
+        k.block = dim3(kSortThreads, 1, 1);
+        k.setArgs(batch.stateDev, batch.sitesDev);
+        k.role = "sort.histogram";
+        k.kind = MWHIP_NODE_SORT_ARCHETYPE;
+        k.sortBatch = &batch;
+        k.sortRole = SortRole::Histogram;
+        out.push_back(k);
+    }
+
+    for (int p = 0; p < max_passes; p++) {
+        KernelLaunch k;
+        k.fn = (const void *)&sortOnesweep;
+        k.grid = dim3(std::max(tiles, 1u), num_sites, 1);
+        k.block = dim3(kSortThreads, 1, 1);
+        k.setArgs(batch.stateDev, batch.sitesDev, (uint32_t)p);
+        k.role = "sort.onesweep";
+        k.kind = MWHIP_NODE_SORT_ARCHETYPE;
+        k.sortBatch = &batch;
+        k.sortRole = SortRole::Onesweep;
+        out.push_back(k);
+    }
+
+    {
+        KernelLaunch k;
+        k.fn = (const void *)&sortGather;
+        k.grid = dim3(stream_blocks, (uint32_t)batch.numGatherColumns, 1);
+        k.block = dim3(kSortThreads, 1, 1);
+        k.setArgs(batch.stateDev, batch.sitesDev, batch.gatherColumnsDev);
+        k.role = "sort.gather";
+        k.kind = MWHIP_NODE_SORT_ARCHETYPE;
+        k.sortBatch = &batch;
+        k.sortRole = SortRole::Gather;
+        out.push_back(k);
+    }
+
+    {
+        KernelLaunch k;
+        k.fn = (const void *)&sortFinalize;
+        k.grid = dim3(std::min<uint32_t>(stream_blocks, 256u), num_sites, 1);
+        k.block = dim3(kSortThreads, 1, 1);
+        k.setArgs(batch.stateDev, batch.sitesDev);
+        k.role = "sort.finalize";
+        k.kind = MWHIP_NODE_SORT_ARCHETYPE;
+        k.sortBatch = &batch;
+        k.sortRole = SortRole::Finalize;
+        out.push_back(k);
+    }
+}
+
+}
+}

@@ -1,0 +1,330 @@
+// Device-resident ECS state of the MI355X backend + the device-side entity /
+// row allocation primitives.  Shared between libmadrona_hip.so (runtime, sort
+// kernels) and the header overlay compiled into the simulator's HIP TU.
+//
+// Layout decisions:
+//  * ONE global SoA table per archetype for all worlds, column 0 = Entity,
+//    column 1 = WorldID, then user components -- the contract of the
+//    reference GPU backend (src/mw/device/state.cpp:163-341,
+//    device/include/madrona/table.hpp:18-40).
+//  * every column has a ping-pong twin (columnsAlt): the sort node gathers
+//    out-of-place and swaps pointers instead of staging + copying back
+//    (SURVEY.md Appendix C / D4).
+//  * entity ids are handed out from per-world caches of 64-id blocks that
+//    mirror the reference CPU backend's IDMap (include/madrona/impl/
+//    id_map_impl.inl:69-260) so that entity ids are bit-identical to the CPU
+//    oracle, instead of the reference GPU backend's global fetch_add
+//    (device/state.cpp:442-527) which makes ids scheduling dependent.
+#pragma once
+
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define MWHIP_HD __host__ __device__
+#define MWHIP_DEV __device__
+#else
+#define MWHIP_HD
+#define MWHIP_DEV
+#endif
+
+namespace madrona {
+
+struct Entity;
+struct Loc;
+
+namespace mwhip {
+
+inline constexpr uint32_t kMaxColumns = 128;       // reference table.hpp:21
+inline constexpr uint32_t kMaxArchetypes = 256;    // reference state.hpp:204
+inline constexpr uint32_t kMaxComponents = 1024;   // reference state.hpp:203
+inline constexpr int32_t kIdsPerBlock = 64;        // reference id_map.hpp:134
+inline constexpr int32_t kIdSentinel = -1;         // 0xFFFF'FFFF_i32
+inline constexpr uint16_t kNoColumn = 0xFFFF;
+inline constexpr uint32_t kBundleMask = 0x80000000u;
+
+enum ColumnFlags : uint32_t {
+    kColumnPinned = 1u << 0,    // exported: address must stay fixed across sorts
+};
+
+enum ErrorFlags : uint32_t {
+    kErrTableOverflow = 1u << 0,
+    kErrEntityOverflow = 1u << 1,
+    kErrTmpOverflow = 1u << 2,
+    kErrInitBlocks = 1u << 3,
+    kErrSortLookback = 1u << 4,
+};
+
+struct TableHdr {
+    void *columns[kMaxColumns];
+    void *columnsAlt[kMaxColumns];
+    uint32_t columnBytes[kMaxColumns];
+    uint32_t columnFlags[kMaxColumns];
+    int32_t numColumns;
+    int32_t numRows;            // appended to with agent-scope atomics
+    int32_t capacity;           // rows mapped in every column
+    uint32_t needsSort;
+    int32_t *worldOffsets;      // [numWorlds]
+    int32_t *worldCounts;       // [numWorlds]
+    uint32_t maxPerWorld;
+    uint32_t registered;
+    uint32_t rowBytes;          // sum of columnBytes
+    uint32_t pad_;
+};
+
+// == IDMap::Node with V = Loc (reference impl/id_map.hpp:41-53): a live slot
+// stores the entity's Loc, a free slot stores the free-list links.
+struct EntitySlot {
+    union {
+        struct { uint32_t archetype; int32_t row; } loc;
+        struct { int32_t subNext; int32_t globalNext; } freeNode;
+    };
+    uint32_t gen;
+};
+
+// == IDMap::Cache (reference impl/id_map.hpp:24-36), one per world, plus a
+// lock for the (rare) case of several threads of one world creating /
+// destroying entities inside the same ParallelFor node.
+struct IdCache {
+    int32_t freeHead;
+    int32_t numFree;
+    int32_t overflowHead;
+    int32_t numOverflow;
+    uint32_t lock;
+    int32_t initBlocksUsed;   // blocks taken from the global store during world init
+    uint32_t pad_[2];
+};
+
+struct EcsState {
+    TableHdr *tables;               // [numArchetypeSlots]
+    uint16_t *colLookup;            // [numArchetypeSlots * numComponentSlots]
+    uint32_t *queryData;
+    EntitySlot *entities;
+    IdCache *worldCaches;           // [numWorlds]
+    int32_t *initBlockBase;         // [numWorlds] first id of world's init blocks (pass 2)
+    char *worldData;
+    char *tmpBase;
+
+    unsigned long long tmpCapacity;
+    unsigned long long tmpOffset;   // bump pointer
+    unsigned long long idFreeHead;  // {gen:32 | head:32} global list of returned blocks
+
+    uint32_t numArchetypeSlots;
+    uint32_t numComponentSlots;
+    uint32_t worldDataStride;
+    int32_t numWorlds;
+    int32_t entityCapacity;
+    int32_t numIds;                 // high-water mark of the id store (multiple of 64)
+    uint32_t initMode;              // 0 run, 1 init pass (count), 2 init pass (assign)
+    uint32_t errorFlags;
+
+    void *hostExec;                 // host mirror only: owning mwhip_exec*
+    uint64_t reserved_[3];
+};
+
+#if defined(__HIPCC__)
+
+MWHIP_DEV inline int32_t atomicAddI32(int32_t *p, int32_t v)
+{
+    return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_AGENT);
+}
+
+MWHIP_DEV inline void raiseError(EcsState *S, uint32_t flag)
+{
+    __hip_atomic_fetch_or(&S->errorFlags, flag, __ATOMIC_RELAXED,
+                          __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- per-world id cache ----------------------------------------------------
+// The lock protects the cache when several lanes of the same world allocate
+// concurrently.  Written in the "try, do, release inside one loop iteration"
+// form so divergent lanes of one wavefront cannot dead-lock each other.
+template <typename Fn>
+MWHIP_DEV inline void withWorldCache(EcsState *S, int32_t world, Fn &&fn)
+{
+    IdCache *cache = &S->worldCaches[world];
+    bool done = false;
+    while (!done) {
+        if (__hip_atomic_exchange(&cache->lock, 1u, __ATOMIC_ACQUIRE,
+                                  __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            fn(*cache);
+            __hip_atomic_store(&cache->lock, 0u, __ATOMIC_RELEASE,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            done = true;
+        } else {
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+}
+
+// Pops the head of a cached free list; mirrors `assignCachedID`
+// (reference id_map_impl.inl:73-101) including the contiguous-run encoding in
+// freeNode.globalNext.
+MWHIP_DEV inline int32_t popCachedId(EcsState *S, int32_t *head, uint32_t *gen_out)
+{
+    int32_t new_id = *head;
+    EntitySlot &node = S->entities[new_id];
+    int32_t num_contiguous = node.freeNode.globalNext;
+
+    if (num_contiguous == 1) {
+        *head = node.freeNode.subNext;
+    } else {
+        int32_t next_free = new_id + 1;
+        EntitySlot &next_node = S->entities[next_free];
+        next_node.freeNode.subNext = node.freeNode.subNext;
+        next_node.freeNode.globalNext = num_contiguous - 1;
+        next_node.gen = 0;
+        *head = next_free;
+    }
+
+    *gen_out = node.gen;
+    return new_id;
+}
+
+// Takes a fresh block of 64 ids from the end of the id store
+// (== store_.expand(ids_per_cache_), reference id_map_impl.inl:158-182).
+// During world construction the block order is made deterministic (world
+// major, like the CPU backend's sequential constructor loop): pass 1 counts
+// blocks per world, pass 2 replays with prefix-summed bases.
+MWHIP_DEV inline int32_t expandIdStore(EcsState *S, int32_t world, IdCache &cache)
+{
+    int32_t block_start;
+    if (S->initMode == 2u) {
+        block_start = S->initBlockBase[world] +
+            cache.initBlocksUsed * kIdsPerBlock;
+        cache.initBlocksUsed += 1;
+    } else {
+        if (S->initMode == 1u) {
+            cache.initBlocksUsed += 1;
+        }
+        block_start = atomicAddI32(&S->numIds, kIdsPerBlock);
+    }
+
+    if (block_start + kIdsPerBlock > S->entityCapacity) {
+        raiseError(S, kErrEntityOverflow);
+        block_start = 0;
+    }
+    return block_start;
+}
+
+MWHIP_DEV inline int32_t acquireIdLocked(EcsState *S, int32_t world, IdCache &cache,
+                                        uint32_t *gen_out)
+{
+    if (cache.numOverflow > 0) {
+        cache.numOverflow -= 1;
+        return popCachedId(S, &cache.overflowHead, gen_out);
+    }
+
+    if (cache.numFree > 0) {
+        cache.numFree -= 1;
+        return popCachedId(S, &cache.freeHead, gen_out);
+    }
+
+    // refill from the global list of returned blocks (id_map_impl.inl:118-156)
+    unsigned long long cur = __hip_atomic_load(&S->idFreeHead, __ATOMIC_ACQUIRE,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+    int32_t free_ids = kIdSentinel;
+    while (true) {
+        int32_t head = (int32_t)(uint32_t)(cur & 0xFFFFFFFFull);
+        if (head == kIdSentinel) {
+            break;
+        }
+        uint32_t gen = (uint32_t)(cur >> 32);
+        int32_t next = __hip_atomic_load(&S->entities[head].freeNode.globalNext,
+            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long desired =
+            ((unsigned long long)(gen + 1u) << 32) | (uint32_t)next;
+        if (__hip_atomic_compare_exchange_strong(&S->idFreeHead, &cur, desired,
+                __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) {
+            free_ids = head;
+            break;
+        }
+    }
+
+    if (free_ids != kIdSentinel) {
+        S->entities[free_ids].freeNode.globalNext = 1;
+        cache.freeHead = free_ids;
+        cache.numFree = kIdsPerBlock - 1;
+        return popCachedId(S, &cache.freeHead, gen_out);
+    }
+
+    int32_t first_id = expandIdStore(S, world, cache);
+    S->entities[first_id].gen = 0;
+
+    int32_t free_start = first_id + 1;
+    EntitySlot &next_free = S->entities[free_start];
+    next_free.freeNode.subNext = kIdSentinel;
+    next_free.freeNode.globalNext = kIdsPerBlock - 1;
+    next_free.gen = 0;
+
+    cache.freeHead = free_start;
+    cache.numFree = kIdsPerBlock - 1;
+
+    *gen_out = 0;
+    return first_id;
+}
+
+// mirrors IDMap::releaseID (reference id_map_impl.inl:186-224)
+MWHIP_DEV inline void releaseIdLocked(EcsState *S, IdCache &cache, int32_t id)
+{
+    EntitySlot &node = S->entities[id];
+    node.gen = node.gen + 1;
+    node.freeNode.globalNext = 1;
+
+    if (cache.numFree < kIdsPerBlock) {
+        node.freeNode.subNext = cache.freeHead;
+        cache.freeHead = id;
+        cache.numFree += 1;
+        return;
+    }
+
+    if (cache.numOverflow < kIdsPerBlock) {
+        node.freeNode.subNext = cache.overflowHead;
+        cache.overflowHead = id;
+        cache.numOverflow += 1;
+    }
+
+    if (cache.numOverflow == kIdsPerBlock) {
+        int32_t new_head = cache.overflowHead;
+        unsigned long long cur = __hip_atomic_load(&S->idFreeHead,
+            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (true) {
+            __hip_atomic_store(&S->entities[new_head].freeNode.globalNext,
+                (int32_t)(uint32_t)(cur & 0xFFFFFFFFull), __ATOMIC_RELAXED,
+                __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long desired =
+                ((unsigned long long)((uint32_t)(cur >> 32) + 1u) << 32) |
+                (uint32_t)new_head;
+            if (__hip_atomic_compare_exchange_strong(&S->idFreeHead, &cur,
+                    desired, __ATOMIC_RELEASE, __ATOMIC_RELAXED,
+                    __HIP_MEMORY_SCOPE_AGENT)) {
+                break;
+            }
+        }
+        cache.overflowHead = kIdSentinel;
+        cache.numOverflow = 0;
+    }
+}
+
+// ---- rows --------------------------------------------------------------------
+// Appends one row to the archetype's global table.  Rows of one world that are
+// created by one thread keep their creation order under the stable world sort,
+// which is what makes per-world row order equal to the CPU backend's.
+MWHIP_DEV inline int32_t appendRow(EcsState *S, TableHdr &tbl)
+{
+    int32_t row = atomicAddI32(&tbl.numRows, 1);
+    if (row >= tbl.capacity) {
+        raiseError(S, kErrTableOverflow);
+        // keep writes in bounds; the host aborts after the step
+        atomicAddI32(&tbl.numRows, -1);
+        row = tbl.capacity - 1;
+    }
+    tbl.needsSort = 1u;
+    return row;
+}
+
+#endif // __HIPCC__
+
+}
+}

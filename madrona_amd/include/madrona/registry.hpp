@@ -1,0 +1,93 @@
+// ECSRegistry: what the simulator's registerTypes receives.
+// API contract: reference include/madrona/registry.hpp:19-76.
+#pragma once
+
+#include <madrona/state.hpp>
+
+namespace madrona {
+
+class ECSRegistry {
+public:
+    // export_ptrs is kept for signature compatibility with the reference; the
+    // exported addresses live in the executor (mwhip_get_exported).
+    MADRONA_HOST_API inline ECSRegistry(StateManager *state_mgr, void **export_ptrs)
+        : state_mgr_(state_mgr), export_ptrs_(export_ptrs)
+    {}
+
+    template <typename ComponentT>
+    MADRONA_HOST_API void registerComponent(uint32_t num_bytes = 0)
+    {
+        state_mgr_->registerComponent<ComponentT>(num_bytes);
+    }
+
+    template <typename ArchetypeT>
+    MADRONA_HOST_API void registerArchetype()
+    {
+        state_mgr_->registerArchetype<ArchetypeT>(
+            ComponentMetadataSelector<> {}, ArchetypeFlags::None, 0);
+    }
+
+    template <typename ArchetypeT, typename... MetadataComponentTs>
+    MADRONA_HOST_API void registerArchetype(
+        ComponentMetadataSelector<MetadataComponentTs...> component_metadatas,
+        ArchetypeFlags archetype_flags,
+        CountT max_num_entities_per_world = 0)
+    {
+        state_mgr_->registerArchetype<ArchetypeT>(component_metadatas,
+            archetype_flags, max_num_entities_per_world);
+    }
+
+    template <typename BundleT>
+    MADRONA_HOST_API void registerBundle()
+    {
+        state_mgr_->registerBundle<BundleT>();
+    }
+
+    template <typename AliasT, typename BundleT>
+    MADRONA_HOST_API void registerBundleAlias()
+    {
+        state_mgr_->registerBundleAlias<AliasT, BundleT>();
+    }
+
+    template <typename SingletonT>
+    MADRONA_HOST_API void registerSingleton()
+    {
+        state_mgr_->registerSingleton<SingletonT>();
+    }
+
+    template <typename ArchetypeT, typename ComponentT>
+    MADRONA_HOST_API void exportColumn(int32_t slot)
+    {
+        void *ptr = state_mgr_->exportColumn<ArchetypeT, ComponentT>(slot);
+        if (export_ptrs_ != nullptr) {
+            export_ptrs_[slot] = ptr;
+        }
+    }
+
+    template <typename SingletonT>
+    MADRONA_HOST_API void exportSingleton(int32_t slot)
+    {
+        void *ptr = state_mgr_->exportSingleton<SingletonT>(slot);
+        if (export_ptrs_ != nullptr) {
+            export_ptrs_[slot] = ptr;
+        }
+    }
+
+    template <typename ArchetypeT, typename ComponentT, EnumType EnumT>
+    MADRONA_HOST_API void exportColumn(EnumT slot)
+    {
+        exportColumn<ArchetypeT, ComponentT>((int32_t)slot);
+    }
+
+    template <typename SingletonT, EnumType EnumT>
+    MADRONA_HOST_API void exportSingleton(EnumT slot)
+    {
+        exportSingleton<SingletonT>((int32_t)slot);
+    }
+
+private:
+    StateManager *state_mgr_;
+    void **export_ptrs_;
+};
+
+}

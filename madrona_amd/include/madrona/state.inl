@@ -1,0 +1,523 @@
+#pragma once
+
+namespace madrona {
+
+// ===========================================================================
+// Host: registration -> C ABI
+// ===========================================================================
+
+template <typename ComponentT>
+MADRONA_HOST_API ComponentID StateManager::registerComponent(uint32_t num_bytes)
+{
+    TypeTracker::touchDeviceSymbol<ComponentT>();
+#if MADRONA_ON_HOST
+    TypeTracker::registerType<ComponentT>(&next_component_id_);
+    uint32_t id = TypeTracker::typeID<ComponentT>();
+
+    uint32_t size = num_bytes == 0 ? (uint32_t)sizeof(ComponentT) : num_bytes;
+    mwhip::check(mwhip_register_component(exec(), id,
+        (uint32_t)alignof(ComponentT), size), "registerComponent");
+
+    return ComponentID { id };
+#else
+    MADRONA_DEVICE_STUB();
+#endif
+}
+
+namespace mwhip {
+
+template <typename ComponentT, typename... FlagComponentTs>
+inline ComponentFlags lookupComponentFlags(
+    const ComponentMetadataSelector<FlagComponentTs...> &sel)
+{
+    ComponentFlags result = ComponentFlags::None;
+    if constexpr (sizeof...(FlagComponentTs) > 0) {
+        const bool matches[] = { std::is_same_v<ComponentT, FlagComponentTs>... };
+        for (size_t i = 0; i < sizeof...(FlagComponentTs); i++) {
+            if (matches[i]) {
+                result = sel.flags[i];
+                break;
+            }
+        }
+    }
+    return result;
+}
+
+template <typename> struct ArchetypeUnpack;
+template <typename... Cs>
+struct ArchetypeUnpack<Archetype<Cs...>> {
+    static constexpr uint32_t count = sizeof...(Cs);
+
+    static void ids(uint32_t *out)
+    {
+        uint32_t tmp[] = { TypeTracker::typeID<Cs>()..., 0u };
+        for (uint32_t i = 0; i < count; i++) out[i] = tmp[i];
+    }
+
+    template <typename... Ms>
+    static void flags(const ComponentMetadataSelector<Ms...> &sel, uint32_t *out)
+    {
+        uint32_t tmp[] = { (uint32_t)lookupComponentFlags<Cs>(sel)..., 0u };
+        for (uint32_t i = 0; i < count; i++) out[i] = tmp[i];
+    }
+};
+
+template <typename> struct BundleUnpack;
+template <typename... Cs>
+struct BundleUnpack<Bundle<Cs...>> {
+    static constexpr uint32_t count = sizeof...(Cs);
+
+    static void ids(uint32_t *out)
+    {
+        uint32_t tmp[] = { TypeTracker::typeID<Cs>()..., 0u };
+        for (uint32_t i = 0; i < count; i++) out[i] = tmp[i];
+    }
+};
+
+}
+
+template <typename ArchetypeT, typename... MetadataComponentTs>
+MADRONA_HOST_API ArchetypeID StateManager::registerArchetype(
+    ComponentMetadataSelector<MetadataComponentTs...> component_metadatas,
+    ArchetypeFlags archetype_flags,
+    CountT max_num_entities_per_world)
+{
+    TypeTracker::touchDeviceSymbol<ArchetypeT>();
+#if MADRONA_ON_HOST
+    TypeTracker::registerType<ArchetypeT>(&next_archetype_id_);
+    uint32_t id = TypeTracker::typeID<ArchetypeT>();
+
+    using Unpack = mwhip::ArchetypeUnpack<typename ArchetypeT::Base>;
+    uint32_t component_ids[Unpack::count + 1];
+    uint32_t component_flags[Unpack::count + 1];
+    Unpack::ids(component_ids);
+    Unpack::flags(component_metadatas, component_flags);
+
+    for (uint32_t i = 0; i < Unpack::count; i++) {
+        if (component_ids[i] == TypeTracker::unassignedTypeID) {
+            fprintf(stderr, "madrona_amd: archetype %u uses an unregistered "
+                    "component (position %u)\n", id, i);
+            abort();
+        }
+    }
+
+    mwhip::check(mwhip_register_archetype(exec(), id, component_ids,
+        component_flags, Unpack::count, (uint32_t)archetype_flags,
+        (uint32_t)max_num_entities_per_world), "registerArchetype");
+
+    return ArchetypeID { id };
+#else
+    MADRONA_DEVICE_STUB();
+#endif
+}
+
+template <typename SingletonT>
+MADRONA_HOST_API void StateManager::registerSingleton()
+{
+#if MADRONA_ON_HOST
+    using ArchetypeT = SingletonArchetype<SingletonT>;
+
+    registerComponent<SingletonT>();
+    registerArchetype<ArchetypeT>(
+        ComponentMetadataSelector<> {}, ArchetypeFlags::None, 1);
+
+    mwhip::check(mwhip_register_singleton(exec(),
+        TypeTracker::typeID<ArchetypeT>(),
+        TypeTracker::typeID<SingletonT>()), "registerSingleton");
+#else
+    MADRONA_DEVICE_STUB();
+#endif
+}
+
+template <typename BundleT>
+MADRONA_HOST_API void StateManager::registerBundle()
+{
+    TypeTracker::touchDeviceSymbol<BundleT>();
+#if MADRONA_ON_HOST
+    TypeTracker::registerType<BundleT>(&next_bundle_id_);
+    uint32_t id = TypeTracker::typeID<BundleT>();
+
+    using Unpack = mwhip::BundleUnpack<typename BundleT::Base>;
+    uint32_t component_ids[Unpack::count + 1];
+    Unpack::ids(component_ids);
+
+    mwhip::check(mwhip_register_bundle(exec(), id, component_ids,
+        Unpack::count), "registerBundle");
+#else
+    MADRONA_DEVICE_STUB();
+#endif
+}
+
+template <typename AliasT, typename BundleT>
+MADRONA_HOST_API void StateManager::registerBundleAlias()
+{
+    TypeTracker::touchDeviceSymbol<AliasT>();
+#if MADRONA_ON_HOST
+    uint32_t bundle_id = TypeTracker::typeID<BundleT>();
+    assert(bundle_id != TypeTracker::unassignedTypeID);
+
+    // the alias shares the bundle's id (reference device state.inl:124-131)
+    TypeTracker::registerType<AliasT>(&bundle_id);
+#else
+    MADRONA_DEVICE_STUB();
+#endif
+}
+
+template <typename ArchetypeT, typename ComponentT>
+MADRONA_HOST_API ComponentT *StateManager::exportColumn(int32_t slot)
+{
+#if MADRONA_ON_HOST
+    return (ComponentT *)mwhip_export_column(exec(),
+        TypeTracker::typeID<ArchetypeT>(), TypeTracker::typeID<ComponentT>(),
+        slot);
+#else
+    MADRONA_DEVICE_STUB();
+#endif
+}
+
+template <typename SingletonT>
+MADRONA_HOST_API SingletonT *StateManager::exportSingleton(int32_t slot)
+{
+#if MADRONA_ON_HOST
+    return exportColumn<SingletonArchetype<SingletonT>, SingletonT>(slot);
+#else
+    MADRONA_DEVICE_STUB();
+#endif
+}
+
+template <typename... ComponentTs>
+MADRONA_HOST_API Query<ComponentTs...> StateManager::query()
+{
+#if MADRONA_ON_HOST
+    uint32_t component_ids[] = {
+        TypeTracker::typeID<std::remove_const_t<ComponentTs>>()...
+    };
+
+    QueryRef ref {};
+    mwhip::check(mwhip_make_query(exec(), component_ids,
+        (uint32_t)sizeof...(ComponentTs), &ref.offset,
+        &ref.numMatchingArchetypes), "makeQuery");
+    ref.numComponents = (uint32_t)sizeof...(ComponentTs);
+    ref.numReferences = 1;
+
+    return Query<ComponentTs...>(ref);
+#else
+    MADRONA_DEVICE_STUB();
+#endif
+}
+
+// ===========================================================================
+// Device: accessors
+// ===========================================================================
+
+MADRONA_HD Loc StateManager::getLoc(Entity e) const
+{
+    if (e.id < 0) {
+        return Loc::none();
+    }
+
+    const mwhip::EntitySlot &slot = entities[e.id];
+    if (slot.gen != e.gen) {
+        return Loc::none();
+    }
+
+    return Loc { slot.loc.archetype, slot.loc.row };
+}
+
+template <typename ComponentT>
+MADRONA_HD ComponentT &StateManager::getUnsafe(Loc loc)
+{
+    uint32_t component_id = TypeTracker::typeID<ComponentT>();
+    uint16_t col_idx =
+        colLookup[loc.archetype * numComponentSlots + component_id];
+    return ((ComponentT *)tables[loc.archetype].columns[col_idx])[loc.row];
+}
+
+template <typename ComponentT>
+MADRONA_HD ComponentT &StateManager::getUnsafe(Entity e)
+{
+    const mwhip::EntitySlot &slot = entities[e.id];
+    return getUnsafe<ComponentT>(Loc { slot.loc.archetype, slot.loc.row });
+}
+
+template <typename ComponentT>
+MADRONA_HD ResultRef<ComponentT> StateManager::get(Loc loc)
+{
+    uint32_t component_id = TypeTracker::typeID<ComponentT>();
+    uint16_t col_idx =
+        colLookup[loc.archetype * numComponentSlots + component_id];
+    if (col_idx == mwhip::kNoColumn) {
+        return ResultRef<ComponentT>(nullptr);
+    }
+
+    return ResultRef<ComponentT>(
+        (ComponentT *)tables[loc.archetype].columns[col_idx] + loc.row);
+}
+
+template <typename ComponentT>
+MADRONA_HD ResultRef<ComponentT> StateManager::get(Entity e)
+{
+    Loc loc = getLoc(e);
+    if (!loc.valid()) {
+        return ResultRef<ComponentT>(nullptr);
+    }
+
+    return get<ComponentT>(loc);
+}
+
+template <typename ComponentT>
+MADRONA_HD ComponentT &StateManager::getDirect(int32_t column_idx, Loc loc)
+{
+    return ((ComponentT *)tables[loc.archetype].columns[column_idx])[loc.row];
+}
+
+template <typename SingletonT>
+MADRONA_HD SingletonT *StateManager::getSingletonColumn()
+{
+    // a singleton archetype has exactly one user column, column 2
+    uint32_t archetype_id =
+        TypeTracker::typeID<SingletonArchetype<SingletonT>>();
+    return (SingletonT *)tables[archetype_id].columns[user_component_offset_];
+}
+
+template <typename SingletonT>
+MADRONA_HD SingletonT &StateManager::getSingleton(WorldID world_id)
+{
+    return getSingletonColumn<SingletonT>()[world_id.idx];
+}
+
+MADRONA_HD inline Entity StateManager::makeEntityNow(WorldID world_id, uint32_t archetype_id)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    mwhip::TableHdr &tbl = tables[archetype_id];
+    int32_t row = mwhip::appendRow(this, tbl);
+
+    uint32_t gen = 0;
+    int32_t id = 0;
+    mwhip::withWorldCache(this, world_id.idx, [&](mwhip::IdCache &cache) {
+        id = mwhip::acquireIdLocked(this, world_id.idx, cache, &gen);
+    });
+
+    mwhip::EntitySlot &slot = entities[id];
+    slot.loc.archetype = archetype_id;
+    slot.loc.row = row;
+
+    Entity e { gen, id };
+    ((Entity *)tbl.columns[0])[row] = e;
+    ((WorldID *)tbl.columns[1])[row] = world_id;
+
+    return e;
+#else
+    (void)0;
+    mwhip::hostOnlyAbort("makeEntity"); return Entity::none();
+#endif
+}
+
+MADRONA_HD inline Loc StateManager::makeTemporary(WorldID world_id, uint32_t archetype_id)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    mwhip::TableHdr &tbl = tables[archetype_id];
+    int32_t row = mwhip::appendRow(this, tbl);
+
+    // sentinel so the sort node does not try to remap an entity slot
+    ((Entity *)tbl.columns[0])[row] = Entity::none();
+    ((WorldID *)tbl.columns[1])[row] = world_id;
+
+    return Loc { archetype_id, row };
+#else
+    (void)0;
+    mwhip::hostOnlyAbort("makeTemporary"); return Loc::none();
+#endif
+}
+
+// Mirrors the CPU backend (src/core/state.cpp:188-203): stale handles are
+// ignored, the row keeps its slot until the next compaction, the id goes back
+// to the *calling* world's cache.  The row is tagged the way both backends'
+// ParallelFor skip tests expect: Entity::none() (CPU state.inl:484) and
+// WorldID -1 (GPU taskgraph.inl:208), which is also the sort key that drops it.
+MADRONA_HD inline void StateManager::destroyEntityNow(WorldID caller_world, Entity e)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    Loc loc = getLoc(e);
+    if (!loc.valid()) {
+        return;
+    }
+
+    mwhip::TableHdr &tbl = tables[loc.archetype];
+    ((Entity *)tbl.columns[0])[loc.row] = Entity::none();
+    ((WorldID *)tbl.columns[1])[loc.row] = WorldID { -1 };
+    tbl.needsSort = 1u;
+
+    mwhip::withWorldCache(this, caller_world.idx, [&](mwhip::IdCache &cache) {
+        mwhip::releaseIdLocked(this, cache, e.id);
+    });
+#else
+    (void)0;
+    mwhip::hostOnlyAbort("destroyEntity");
+#endif
+}
+
+MADRONA_HD inline void StateManager::clearTemporaries(uint32_t archetype_id)
+{
+    mwhip::TableHdr &tbl = tables[archetype_id];
+    if (tbl.numRows != 0) {
+        tbl.needsSort = 1u;
+    }
+    tbl.numRows = 0;
+}
+
+MADRONA_HD int32_t StateManager::getArchetypeColumnIndex(uint32_t archetype_id,
+                                              uint32_t component_id)
+{
+    return (int32_t)colLookup[archetype_id * numComponentSlots + component_id];
+}
+
+MADRONA_HD void *StateManager::getArchetypeColumn(uint32_t archetype_id, int32_t column_idx)
+{
+    return tables[archetype_id].columns[column_idx];
+}
+
+MADRONA_HD void *StateManager::getArchetypeComponent(uint32_t archetype_id,
+                                          uint32_t component_id)
+{
+    return getArchetypeColumn(archetype_id,
+        getArchetypeColumnIndex(archetype_id, component_id));
+}
+
+template <typename ArchetypeT, typename ComponentT>
+MADRONA_HD ComponentT *StateManager::getArchetypeComponent()
+{
+    return (ComponentT *)getArchetypeComponent(
+        TypeTracker::typeID<ArchetypeT>(), TypeTracker::typeID<ComponentT>());
+}
+
+MADRONA_HD int32_t *StateManager::getArchetypeWorldOffsets(uint32_t archetype_id)
+{
+    return tables[archetype_id].worldOffsets;
+}
+
+MADRONA_HD int32_t *StateManager::getArchetypeWorldCounts(uint32_t archetype_id)
+{
+    return tables[archetype_id].worldCounts;
+}
+
+template <typename ArchetypeT>
+MADRONA_HD int32_t *StateManager::getArchetypeWorldOffsets()
+{
+    return getArchetypeWorldOffsets(TypeTracker::typeID<ArchetypeT>());
+}
+
+template <typename ArchetypeT>
+MADRONA_HD int32_t *StateManager::getArchetypeWorldCounts()
+{
+    return getArchetypeWorldCounts(TypeTracker::typeID<ArchetypeT>());
+}
+
+template <typename ArchetypeT, typename ComponentT>
+MADRONA_HD std::pair<ComponentT *, uint32_t> StateManager::getWorldComponentsAndCount(
+    uint32_t world_id)
+{
+    uint32_t archetype_id = TypeTracker::typeID<ArchetypeT>();
+    ComponentT *col = getArchetypeComponent<ArchetypeT, ComponentT>();
+    mwhip::TableHdr &tbl = tables[archetype_id];
+    return { col + tbl.worldOffsets[world_id],
+             (uint32_t)tbl.worldCounts[world_id] };
+}
+
+template <typename ArchetypeT>
+MADRONA_HD Entity *StateManager::getWorldEntities(uint32_t world_id)
+{
+    mwhip::TableHdr &tbl = tables[TypeTracker::typeID<ArchetypeT>()];
+    return (Entity *)tbl.columns[0] + tbl.worldOffsets[world_id];
+}
+
+template <typename ArchetypeT>
+MADRONA_HD uint32_t StateManager::getArchetypeNumRows()
+{
+    return (uint32_t)tables[TypeTracker::typeID<ArchetypeT>()].numRows;
+}
+
+MADRONA_HD int32_t StateManager::numArchetypeRows(uint32_t archetype_id) const
+{
+    return tables[archetype_id].numRows;
+}
+
+MADRONA_HD int32_t StateManager::getArchetypeNumColumns(uint32_t archetype_id)
+{
+    return tables[archetype_id].numColumns;
+}
+
+MADRONA_HD uint32_t StateManager::getArchetypeColumnBytesPerRow(uint32_t archetype_id,
+                                                     int32_t column_idx)
+{
+    return tables[archetype_id].columnBytes[column_idx];
+}
+
+MADRONA_HD bool StateManager::archetypeNeedsSort(uint32_t archetype_id) const
+{
+    return tables[archetype_id].needsSort != 0;
+}
+
+MADRONA_HD void StateManager::archetypeSetNeedsSort(uint32_t archetype_id)
+{
+    tables[archetype_id].needsSort = 1u;
+}
+
+namespace mwhip {
+
+template <typename Fn, int32_t... Indices>
+MADRONA_HD inline void iterateQueryImpl(
+    EcsState *S, int32_t world_id, const QueryRef *query_ref, Fn &&fn,
+    std::integer_sequence<int32_t, Indices...>)
+{
+    const uint32_t *query_values = &S->queryData[query_ref->offset];
+    const int32_t num_archetypes = (int32_t)query_ref->numMatchingArchetypes;
+
+    for (int32_t i = 0; i < num_archetypes; i++) {
+        uint32_t archetype_idx = query_values[0];
+        query_values += 1;
+
+        TableHdr &tbl = S->tables[archetype_idx];
+        int32_t world_offset = tbl.worldOffsets[world_id];
+        int32_t world_count = tbl.worldCounts[world_id];
+
+        for (int32_t r = 0; r < world_count; r++) {
+            fn(world_offset + r, tbl.columns[query_values[Indices]]...);
+        }
+
+        query_values += sizeof...(Indices);
+    }
+}
+
+}
+
+template <int32_t num_components, typename Fn>
+MADRONA_HD void StateManager::iterateQuery(uint32_t world_id, const QueryRef *query_ref,
+                                Fn &&fn)
+{
+    mwhip::iterateQueryImpl(this, (int32_t)world_id, query_ref,
+        std::forward<Fn>(fn),
+        std::make_integer_sequence<int32_t, num_components>());
+}
+
+// 256-byte aligned bump allocation from the executor's scratch region
+// (reference mwGPU::TmpAllocator, device/memory.cpp:123-178).
+MADRONA_HD void *StateManager::tmpAlloc(uint64_t num_bytes)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    num_bytes = utils::roundUpPow2(num_bytes, (uint64_t)256);
+    unsigned long long off = __hip_atomic_fetch_add(&tmpOffset,
+        (unsigned long long)num_bytes, __ATOMIC_RELAXED,
+        __HIP_MEMORY_SCOPE_AGENT);
+    if (off + num_bytes > tmpCapacity) {
+        mwhip::raiseError(this, mwhip::kErrTmpOverflow);
+        return tmpBase;
+    }
+    return tmpBase + off;
+#else
+    (void)0;
+    mwhip::hostOnlyAbort("tmpAlloc"); return nullptr;
+#endif
+}
+
+}

@@ -1,0 +1,473 @@
+#pragma once
+
+namespace madrona {
+
+namespace mwhip {
+
+// ---- algorithmic bytes of a system from its signature -----
+// const T & / T by value = read once, T & = read + write; + 4 B WorldID/row.
+template <typename ArgT>
+constexpr uint32_t systemArgBytes()
+{
+    using BaseT = std::remove_cv_t<std::remove_reference_t<ArgT>>;
+    if constexpr (std::is_lvalue_reference_v<ArgT> &&
+                  !std::is_const_v<std::remove_reference_t<ArgT>>) {
+        return 2u * (uint32_t)sizeof(BaseT);
+    } else {
+        return (uint32_t)sizeof(BaseT);
+    }
+}
+
+template <typename FnT> struct SystemTraits {
+    static constexpr uint32_t bytesPerRow = 0;
+};
+
+template <typename CtxT, typename... ArgTs>
+struct SystemTraits<void (*)(CtxT &, ArgTs...)> {
+    static constexpr uint32_t bytesPerRow =
+        4u + (0u + ... + systemArgBytes<ArgTs>());
+};
+
+// Pulls "ns::fnName" out of __PRETTY_FUNCTION__ of a function templated on
+// <auto Fn> (host only, used to label kernels in profiles).
+template <auto Fn>
+inline std::string systemName()
+{
+    std::string pretty = __PRETTY_FUNCTION__;
+    size_t start = pretty.find("Fn = ");
+    if (start == std::string::npos) {
+        return "system";
+    }
+    start += 5;
+    if (pretty[start] == '&') start++;
+    size_t end = pretty.find_first_of("];,", start);
+    return pretty.substr(start, end - start);
+}
+
+#if defined(__HIPCC__)
+
+template <typename ContextT, auto Fn, typename... ComponentTs, size_t... Is>
+MADRONA_DEVICE inline void invokeSystemRow(ContextT &ctx, void *const *cols,
+                                           int32_t row,
+                                           std::index_sequence<Is...>)
+{
+    Fn(ctx, ((ComponentTs *)cols[Is])[row]...);
+}
+
+// One thread per matching row; rows of each matched archetype are walked with
+// a grid-stride loop whose bound is the table's device-resident row count.
+// Adjacent lanes touch adjacent rows of every SoA column (coalesced).
+template <typename ContextT, auto Fn, typename... ComponentTs>
+__global__ void __launch_bounds__(256)
+parallelForKernel(EcsState *S, void *, uint32_t query_offset,
+                  uint32_t num_matching)
+{
+    constexpr size_t N = sizeof...(ComponentTs);
+
+    StateManager *state_mgr = static_cast<StateManager *>(S);
+    const uint32_t *query_values = S->queryData + query_offset;
+
+    const int32_t tid = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
+    const int32_t stride = (int32_t)(gridDim.x * blockDim.x);
+
+    for (uint32_t a = 0; a < num_matching; a++) {
+        TableHdr &tbl = S->tables[query_values[0]];
+        const int32_t num_rows = tbl.numRows;
+        const WorldID *world_col = (const WorldID *)tbl.columns[1];
+
+        void *cols[N > 0 ? N : 1];
+MADRONA_UNROLL
+        for (size_t c = 0; c < N; c++) {
+            cols[c] = tbl.columns[query_values[1 + c]];
+        }
+
+        for (int32_t row = tid; row < num_rows; row += stride) {
+            WorldID world_id = world_col[row];
+            // destroyed but not yet compacted away
+            if (world_id.idx == -1) {
+                continue;
+            }
+
+            ContextT ctx =
+                TaskGraph::makeContext<ContextT>(state_mgr, world_id);
+            invokeSystemRow<ContextT, Fn, ComponentTs...>(
+                ctx, cols, row, std::make_index_sequence<N>());
+        }
+
+        query_values += 1 + N;
+    }
+}
+
+// N-items-per-invocation convention of CustomParallelForNode
+// (reference device taskgraph.inl:229-266): Fn(WorldID *, Cs *..., count).
+template <auto Fn, int32_t items_per_invocation, typename... ComponentTs,
+          size_t... Is>
+MADRONA_DEVICE inline void invokeSystemBatch(WorldID *worlds, void *const *cols,
+                                             int32_t row, int32_t count,
+                                             std::index_sequence<Is...>)
+{
+    Fn(worlds + row, ((ComponentTs *)cols[Is] + row)..., count);
+}
+
+template <auto Fn, int32_t threads_per_invocation,
+          int32_t items_per_invocation, typename... ComponentTs>
+__global__ void __launch_bounds__(256)
+parallelForBatchKernel(EcsState *S, void *, uint32_t query_offset,
+                       uint32_t num_matching)
+{
+    constexpr size_t N = sizeof...(ComponentTs);
+    const uint32_t *query_values = S->queryData + query_offset;
+
+    // every lane of a threads_per_invocation group makes the same call; the
+    // user function differentiates lanes itself (threadIdx.x % group size)
+    const int32_t tid = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
+    const int32_t group = tid / threads_per_invocation;
+    const int32_t num_groups =
+        (int32_t)(gridDim.x * blockDim.x) / threads_per_invocation;
+
+    for (uint32_t a = 0; a < num_matching; a++) {
+        TableHdr &tbl = S->tables[query_values[0]];
+        const int32_t num_rows = tbl.numRows;
+
+        void *cols[N > 0 ? N : 1];
+MADRONA_UNROLL
+        for (size_t c = 0; c < N; c++) {
+            cols[c] = tbl.columns[query_values[1 + c]];
+        }
+
+        for (int32_t base = group * items_per_invocation; base < num_rows;
+             base += num_groups * items_per_invocation) {
+            int32_t count = num_rows - base;
+            if (count > items_per_invocation) count = items_per_invocation;
+            invokeSystemBatch<Fn, items_per_invocation, ComponentTs...>(
+                (WorldID *)tbl.columns[1], cols, base, count,
+                std::make_index_sequence<N>());
+        }
+
+        query_values += 1 + N;
+    }
+}
+
+// Custom node: (node->*fn)(invocation_idx) for invocation_idx < count, where
+// count is fixed or NodeT::numInvocations() evaluated on the device.
+template <typename NodeT, auto fn, bool dynamic_count>
+__global__ void __launch_bounds__(256)
+customNodeKernel(EcsState *, void *node_data, uint32_t fixed_count, uint32_t)
+{
+    NodeT *node = (NodeT *)node_data;
+
+    uint32_t count = fixed_count;
+    if constexpr (dynamic_count) {
+        count = node->numInvocations();
+    }
+
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = tid; i < count; i += stride) {
+        std::invoke(fn, node, (int32_t)i);
+    }
+}
+
+#endif // __HIPCC__
+
+}
+
+// ---------------------------------------------------------------------------
+// Builder (host API: device copies are stubs, see MADRONA_HOST_API)
+// ---------------------------------------------------------------------------
+
+TaskGraph::Builder::Builder(mwhip_exec *exec, StateManager *state_mgr,
+                            uint32_t taskgraph_id)
+    : exec_(exec), state_mgr_(state_mgr), taskgraph_id_(taskgraph_id)
+{}
+
+template <typename NodeT, typename... Args>
+MADRONA_HOST_API TaskGraph::TypedDataID<NodeT>
+TaskGraph::Builder::constructNodeData(Args &&...args)
+{
+    static_assert(sizeof(NodeT) <= maxNodeDataBytes);
+    static_assert(alignof(NodeT) <= alignof(NodeData));
+    static_assert(std::is_trivially_copyable_v<NodeT>,
+        "node data is copied to the device byte for byte");
+
+#if MADRONA_ON_HOST
+    int32_t data_idx = (int32_t)node_datas_.size();
+    node_datas_.emplace_back(new NodeData {});
+    node_data_bytes_.push_back((uint32_t)sizeof(NodeT));
+    new (node_datas_.back()->userData) NodeT(std::forward<Args>(args)...);
+
+    return TypedDataID<NodeT> { DataID { data_idx } };
+#else
+    MADRONA_DEVICE_STUB();
+#endif
+}
+
+template <typename NodeT>
+MADRONA_HOST_API NodeT &TaskGraph::Builder::getDataRef(
+    TypedDataID<NodeT> data_id)
+{
+#if MADRONA_ON_HOST
+    return *(NodeT *)node_datas_[data_id.id]->userData;
+#else
+    MADRONA_DEVICE_STUB();
+#endif
+}
+
+TaskGraph::NodeID TaskGraph::Builder::addRuntimeNode(
+    const mwhip_node_desc &desc, int32_t staged_data_idx,
+    Span<const NodeID> dependencies)
+{
+    StagedNode staged;
+    staged.desc = desc;
+    staged.name = desc.name != nullptr ? desc.name : "node";
+    staged.dataIdx = staged_data_idx;
+    for (NodeID dep : dependencies) {
+        staged.deps.push_back(dep.id);
+    }
+
+    staged_.push_back(std::move(staged));
+    return NodeID { (int32_t)staged_.size() - 1 };
+}
+
+template <auto fn, typename NodeT>
+MADRONA_HOST_API TaskGraph::NodeID TaskGraph::Builder::addNodeFn(
+    TypedDataID<NodeT> data,
+    Span<const NodeID> dependencies,
+    Optional<NodeID>,
+    uint32_t fixed_num_invocations,
+    uint32_t num_threads_per_invocation)
+{
+    // a __host__ lambda may name a __global__ function; defining it here also
+    // instantiates the kernel in the device compilation pass
+    [[maybe_unused]] auto kernel_stub = [] __host__ () -> const void * {
+        return (const void *)&mwhip::customNodeKernel<NodeT, fn, false>;
+    };
+
+#if MADRONA_ON_HOST
+    mwhip_node_desc desc {};
+    desc.kind = MWHIP_NODE_KERNEL;
+    std::string name = "custom:" + mwhip::systemName<fn>();
+    desc.name = name.c_str();
+    desc.kernel = kernel_stub();
+    desc.count_mode = MWHIP_COUNT_FIXED;
+    desc.fixed_count = fixed_num_invocations;
+    desc.arg0 = fixed_num_invocations;
+    desc.threads_per_invocation = num_threads_per_invocation;
+
+    return addRuntimeNode(desc, data.id, dependencies);
+#else
+    MADRONA_DEVICE_STUB();
+#endif
+}
+
+template <typename NodeT, int32_t count, typename... Args>
+MADRONA_HOST_API TaskGraph::NodeID TaskGraph::Builder::addOneOffNode(
+    Span<const NodeID> dependencies, Args &&...args)
+{
+    auto data_id = constructNodeData<NodeT>(std::forward<Args>(args)...);
+    return addNodeFn<&NodeT::run>(data_id, dependencies,
+                                  Optional<NodeID>::none(), count);
+}
+
+template <typename NodeT, typename... Args>
+MADRONA_HOST_API TaskGraph::NodeID TaskGraph::Builder::addDynamicCountNode(
+    Span<const NodeID> dependencies,
+    uint32_t num_threads_per_invocation,
+    Args &&...args)
+{
+    [[maybe_unused]] auto kernel_stub = [] __host__ () -> const void * {
+        return (const void *)&mwhip::customNodeKernel<NodeT, &NodeT::run, true>;
+    };
+
+#if MADRONA_ON_HOST
+    auto data_id = constructNodeData<NodeT>(std::forward<Args>(args)...);
+
+    mwhip_node_desc desc {};
+    desc.kind = MWHIP_NODE_KERNEL;
+    std::string name = "dynamic:" + mwhip::systemName<&NodeT::run>();
+    desc.name = name.c_str();
+    desc.kernel = kernel_stub();
+    // the count is only known on the device: launch a full grid
+    desc.count_mode = MWHIP_COUNT_FIXED;
+    desc.fixed_count = 0xFFFFFFFFu;
+    desc.threads_per_invocation = num_threads_per_invocation;
+
+    return addRuntimeNode(desc, data_id.id, dependencies);
+#else
+    MADRONA_DEVICE_STUB();
+#endif
+}
+
+template <typename NodeT>
+MADRONA_HOST_API TaskGraph::NodeID TaskGraph::Builder::addToGraph(
+    Span<const NodeID> dependencies)
+{
+    return NodeT::addToGraph(*this, dependencies);
+}
+
+void TaskGraph::Builder::flush()
+{
+    std::vector<int32_t> data_ids(node_datas_.size(), -1);
+    for (size_t i = 0; i < node_datas_.size(); i++) {
+        data_ids[i] = mwhip_tg_add_node_data(exec_, taskgraph_id_,
+            node_datas_[i]->userData, node_data_bytes_[i]);
+        mwhip::check(data_ids[i], "tg_add_node_data");
+    }
+
+    for (StagedNode &staged : staged_) {
+        staged.desc.name = staged.name.c_str();
+        staged.desc.node_data_id =
+            staged.dataIdx >= 0 ? data_ids[staged.dataIdx] : -1;
+        int32_t id = mwhip_tg_add_node(exec_, taskgraph_id_, &staged.desc,
+            staged.deps.data(), (uint32_t)staged.deps.size());
+        mwhip::check(id, "tg_add_node");
+    }
+
+    staged_.clear();
+}
+
+// ---------------------------------------------------------------------------
+// TaskGraphManager
+// ---------------------------------------------------------------------------
+
+TaskGraphManager::TaskGraphManager(mwhip_exec *exec, StateManager *state_mgr,
+                                   uint32_t num_taskgraphs)
+    : exec_(exec), state_mgr_(state_mgr), builders_(num_taskgraphs)
+{}
+
+MADRONA_HOST_API TaskGraphBuilder &TaskGraphManager::init(uint32_t taskgraph_id)
+{
+#if MADRONA_ON_HOST
+    builders_[taskgraph_id].reset(
+        new TaskGraphBuilder(exec_, state_mgr_, taskgraph_id));
+    return *builders_[taskgraph_id];
+#else
+    MADRONA_DEVICE_STUB();
+#endif
+}
+
+void TaskGraphManager::constructGraphs()
+{
+    for (auto &builder : builders_) {
+        if (builder) {
+            builder->flush();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Built-in nodes
+// ---------------------------------------------------------------------------
+
+template <typename ContextT, auto Fn,
+          int32_t threads_per_invocation,
+          int32_t items_per_invocation,
+          typename... ComponentTs>
+MADRONA_HOST_API TaskGraph::NodeID
+CustomParallelForNode<ContextT, Fn, threads_per_invocation,
+                      items_per_invocation, ComponentTs...>::addToGraph(
+    TaskGraph::Builder &builder,
+    Span<const TaskGraph::NodeID> dependencies)
+{
+    [[maybe_unused]] auto kernel_stub = [] __host__ () -> const void * {
+        if constexpr (items_per_invocation == 1) {
+            static_assert(threads_per_invocation == 1,
+                "1 item per invocation runs one thread per row");
+            return (const void *)&mwhip::parallelForKernel<
+                ContextT, Fn, ComponentTs...>;
+        } else {
+            return (const void *)&mwhip::parallelForBatchKernel<
+                Fn, threads_per_invocation, items_per_invocation,
+                ComponentTs...>;
+        }
+    };
+
+#if MADRONA_ON_HOST
+    auto query = builder.stateManager().template query<ComponentTs...>();
+    const QueryRef *ref = query.getSharedRef();
+
+    mwhip_node_desc desc {};
+    desc.kind = MWHIP_NODE_KERNEL;
+    std::string name = mwhip::systemName<Fn>();
+    desc.name = name.c_str();
+    desc.kernel = kernel_stub();
+    desc.node_data_id = -1;
+    desc.arg0 = ref->offset;
+    desc.arg1 = ref->numMatchingArchetypes;
+    desc.count_mode = MWHIP_COUNT_QUERY_ROWS;
+    desc.query_offset = ref->offset;
+    desc.num_matching = ref->numMatchingArchetypes;
+    desc.threads_per_invocation = (uint32_t)threads_per_invocation;
+
+    if constexpr (items_per_invocation == 1) {
+        desc.bytes_per_row = mwhip::SystemTraits<decltype(Fn)>::bytesPerRow;
+    } else {
+        desc.bytes_per_row = 4u + (0u + ... + (uint32_t)sizeof(ComponentTs));
+    }
+
+    return builder.addRuntimeNode(desc, -1, dependencies);
+#else
+    MADRONA_DEVICE_STUB();
+#endif
+}
+
+namespace mwhip {
+
+MADRONA_HOST_API inline TaskGraph::NodeID addSimpleNode(
+    TaskGraph::Builder &builder, Span<const TaskGraph::NodeID> dependencies,
+    uint32_t kind, const char *name, uint32_t archetype_id,
+    uint32_t component_id)
+{
+#if MADRONA_ON_HOST
+    mwhip_node_desc desc {};
+    desc.kind = kind;
+    desc.name = name;
+    desc.node_data_id = -1;
+    desc.archetype_id = archetype_id;
+    desc.component_id = component_id;
+    return builder.addRuntimeNode(desc, -1, dependencies);
+#else
+    MADRONA_DEVICE_STUB();
+#endif
+}
+
+}
+
+MADRONA_HOST_API TaskGraph::NodeID ClearTmpNodeBase::addToGraph(
+    TaskGraph::Builder &builder,
+    Span<const TaskGraph::NodeID> dependencies,
+    uint32_t archetype_id)
+{
+    return mwhip::addSimpleNode(builder, dependencies, MWHIP_NODE_CLEAR_TMP,
+                                "ClearTmp", archetype_id, 0);
+}
+
+MADRONA_HOST_API TaskGraph::NodeID RecycleEntitiesNode::addToGraph(
+    TaskGraph::Builder &builder,
+    Span<const TaskGraph::NodeID> dependencies)
+{
+    return mwhip::addSimpleNode(builder, dependencies, MWHIP_NODE_RECYCLE,
+                                "RecycleEntities", 0, 0);
+}
+
+MADRONA_HOST_API TaskGraph::NodeID ResetTmpAllocNode::addToGraph(
+    TaskGraph::Builder &builder,
+    Span<const TaskGraph::NodeID> dependencies)
+{
+    return mwhip::addSimpleNode(builder, dependencies,
+                                MWHIP_NODE_RESET_TMP_ALLOC, "ResetTmpAlloc",
+                                0, 0);
+}
+
+MADRONA_HOST_API TaskGraph::NodeID SortArchetypeNodeBase::addToGraph(
+    TaskGraph::Builder &builder,
+    Span<const TaskGraph::NodeID> dependencies,
+    uint32_t archetype_id,
+    int32_t component_id)
+{
+    return mwhip::addSimpleNode(builder, dependencies,
+                                MWHIP_NODE_SORT_ARCHETYPE, "SortArchetype",
+                                archetype_id, (uint32_t)component_id);
+}
+
+}

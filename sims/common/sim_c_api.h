@@ -12,6 +12,8 @@
 extern "C" {
 #endif
 
+#define SIM_API __attribute__((visibility("default")))
+
 typedef struct SimHandle SimHandle;
 
 typedef struct SimCreateArgs {
@@ -42,28 +44,28 @@ typedef struct SimColumnInfo {
     int32_t is_float;        /* 1: compare with fp tolerance, 0: bit exact */
 } SimColumnInfo;
 
-SimHandle *sim_create(const SimCreateArgs *args);
-void sim_destroy(SimHandle *h);
-const char *sim_backend(SimHandle *h);     /* "ref_cpu" | "hip" */
-void sim_step(SimHandle *h, uint32_t num_steps);
+SIM_API SimHandle *sim_create(const SimCreateArgs *args);
+SIM_API void sim_destroy(SimHandle *h);
+SIM_API const char *sim_backend(SimHandle *h);     /* "ref_cpu" | "hip" */
+SIM_API void sim_step(SimHandle *h, uint32_t num_steps);
 
-uint32_t sim_num_tensors(SimHandle *h);
-int sim_tensor_info(SimHandle *h, uint32_t slot, SimTensorInfo *out);
-void *sim_tensor_ptr(SimHandle *h, uint32_t slot);
+SIM_API uint32_t sim_num_tensors(SimHandle *h);
+SIM_API int sim_tensor_info(SimHandle *h, uint32_t slot, SimTensorInfo *out);
+SIM_API void *sim_tensor_ptr(SimHandle *h, uint32_t slot);
 /* copy tensor `slot` to / from host memory regardless of backend */
-int sim_tensor_read(SimHandle *h, uint32_t slot, void *dst, uint64_t num_bytes);
-int sim_tensor_write(SimHandle *h, uint32_t slot, const void *src, uint64_t num_bytes);
+SIM_API int sim_tensor_read(SimHandle *h, uint32_t slot, void *dst, uint64_t num_bytes);
+SIM_API int sim_tensor_write(SimHandle *h, uint32_t slot, const void *src, uint64_t num_bytes);
 
 /* Parity dumps: column idx of the registered dump list
  * copied to host, rows grouped by world in world order; world_counts[w] rows
  * for world w.  Returns total rows, or -1 on error / -2 if dst is too small. */
-uint32_t sim_num_columns(SimHandle *h);
-int sim_column_info(SimHandle *h, uint32_t idx, SimColumnInfo *out);
-int64_t sim_column_dump(SimHandle *h, uint32_t idx, void *dst, uint64_t dst_bytes,
+SIM_API uint32_t sim_num_columns(SimHandle *h);
+SIM_API int sim_column_info(SimHandle *h, uint32_t idx, SimColumnInfo *out);
+SIM_API int64_t sim_column_dump(SimHandle *h, uint32_t idx, void *dst, uint64_t dst_bytes,
                         int32_t *world_counts);
 
 /* HIP backend only (NULL/0 on the reference): opaque mwhip_exec* for profiling */
-void *sim_hip_exec(SimHandle *h);
+SIM_API void *sim_hip_exec(SimHandle *h);
 
 #ifdef __cplusplus
 }
