@@ -32,7 +32,7 @@ struct ObjectInstance : Bundle<
     ObjectID
 > {};
 
-inline void registerTypes(ECSRegistry &registry)
+MADRONA_HOST_API inline void registerTypes(ECSRegistry &registry)
 {
     registry.registerComponent<Position>();
     registry.registerComponent<Rotation>();

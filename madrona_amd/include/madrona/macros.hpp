@@ -6,9 +6,11 @@
 #include <hip/hip_runtime.h>
 #define MADRONA_HD __host__ __device__
 #define MADRONA_DEVICE __device__
+#define MADRONA_HOST_LAMBDA __host__
 #else
 #define MADRONA_HD
 #define MADRONA_DEVICE
+#define MADRONA_HOST_LAMBDA
 #endif
 
 // Host-API functions (registry, task-graph builder) are called from the

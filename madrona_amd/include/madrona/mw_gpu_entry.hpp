@@ -108,7 +108,7 @@ struct MWHipEntry {
 #define MADRONA_BUILD_MWGPU_ENTRY(ContextT, WorldT, ConfigT, InitT) \
     extern "C" MADRONA_EXPORT const mwhip_user_entry *madronaMWHipUserEntry() \
     { \
-        [[maybe_unused]] auto get_entry = [] __host__ () { \
+        [[maybe_unused]] auto get_entry = [] MADRONA_HOST_LAMBDA () { \
             return ::madrona::mwGPU::MWHipEntry< \
                 ContextT, WorldT, ConfigT, InitT>::get(); \
         }; \

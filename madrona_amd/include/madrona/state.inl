@@ -114,6 +114,8 @@ MADRONA_HOST_API ArchetypeID StateManager::registerArchetype(
 template <typename SingletonT>
 MADRONA_HOST_API void StateManager::registerSingleton()
 {
+    TypeTracker::touchDeviceSymbol<SingletonT>();
+    TypeTracker::touchDeviceSymbol<SingletonArchetype<SingletonT>>();
 #if MADRONA_ON_HOST
     using ArchetypeT = SingletonArchetype<SingletonT>;
 

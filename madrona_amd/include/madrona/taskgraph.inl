@@ -239,9 +239,13 @@ MADRONA_HOST_API TaskGraph::NodeID TaskGraph::Builder::addNodeFn(
 {
     // a __host__ lambda may name a __global__ function; defining it here also
     // instantiates the kernel in the device compilation pass
+#if defined(__HIPCC__)
     [[maybe_unused]] auto kernel_stub = [] __host__ () -> const void * {
         return (const void *)&mwhip::customNodeKernel<NodeT, fn, false>;
     };
+#else
+    auto kernel_stub = []() -> const void * { return nullptr; };
+#endif
 
 #if MADRONA_ON_HOST
     mwhip_node_desc desc {};
@@ -275,9 +279,13 @@ MADRONA_HOST_API TaskGraph::NodeID TaskGraph::Builder::addDynamicCountNode(
     uint32_t num_threads_per_invocation,
     Args &&...args)
 {
+#if defined(__HIPCC__)
     [[maybe_unused]] auto kernel_stub = [] __host__ () -> const void * {
         return (const void *)&mwhip::customNodeKernel<NodeT, &NodeT::run, true>;
     };
+#else
+    auto kernel_stub = []() -> const void * { return nullptr; };
+#endif
 
 #if MADRONA_ON_HOST
     auto data_id = constructNodeData<NodeT>(std::forward<Args>(args)...);
@@ -369,6 +377,7 @@ CustomParallelForNode<ContextT, Fn, threads_per_invocation,
     TaskGraph::Builder &builder,
     Span<const TaskGraph::NodeID> dependencies)
 {
+#if defined(__HIPCC__)
     [[maybe_unused]] auto kernel_stub = [] __host__ () -> const void * {
         if constexpr (items_per_invocation == 1) {
             static_assert(threads_per_invocation == 1,
@@ -381,6 +390,9 @@ CustomParallelForNode<ContextT, Fn, threads_per_invocation,
                 ComponentTs...>;
         }
     };
+#else
+    auto kernel_stub = []() -> const void * { return nullptr; };
+#endif
 
 #if MADRONA_ON_HOST
     auto query = builder.stateManager().template query<ComponentTs...>();
