@@ -98,9 +98,10 @@ void *mwhip_export_column(mwhip_exec *exec, uint32_t archetype_id,
                           uint32_t component_id, int32_t slot);
 /* StateManager::makeQuery (device/state.cpp:380-440): appends
  * [archetype, col idx per component]* to the query table; returns its offset */
+#define MWHIP_QUERY_ALL_SINGLETON 1u  /* every matched archetype has 1 row/world */
 int mwhip_make_query(mwhip_exec *exec, const uint32_t *component_ids,
                      uint32_t num_components, uint32_t *offset_out,
-                     uint32_t *num_matching_out);
+                     uint32_t *num_matching_out, uint32_t *flags_out);
 /* address of the device-resident ecs_state (valid after mwhip_create's
  * register phase) and of per-world user data */
 void *mwhip_device_state(mwhip_exec *exec);

@@ -155,6 +155,7 @@ struct QueryRec {
     std::vector<uint32_t> comps;
     uint32_t offset;
     uint32_t numMatching;
+    uint32_t flags;
 };
 
 struct NodeRec {
@@ -437,13 +438,14 @@ extern "C" void *mwhip_export_column(mwhip_exec *exec, uint32_t archetype_id,
 
 extern "C" int mwhip_make_query(mwhip_exec *exec, const uint32_t *component_ids,
                                 uint32_t num_components, uint32_t *offset_out,
-                                uint32_t *num_matching_out)
+                                uint32_t *num_matching_out, uint32_t *flags_out)
 {
     std::vector<uint32_t> comps(component_ids, component_ids + num_components);
     for (const QueryRec &q : exec->queries) {
         if (q.comps == comps) {
             *offset_out = q.offset;
             *num_matching_out = q.numMatching;
+            if (flags_out) *flags_out = q.flags;
             return 0;
         }
     }
@@ -454,6 +456,7 @@ extern "C" int mwhip_make_query(mwhip_exec *exec, const uint32_t *component_ids,
     rec.comps = comps;
     rec.offset = (uint32_t)exec->queryDataHost.size();
     rec.numMatching = 0;
+    bool all_singleton = true;
 
     for (uint32_t a = 0; a < exec->archetypes.size(); a++) {
         const ArchetypeRec &arch = exec->archetypes[a];
@@ -470,6 +473,7 @@ extern "C" int mwhip_make_query(mwhip_exec *exec, const uint32_t *component_ids,
         if (!has_all) continue;
 
         rec.numMatching += 1;
+        all_singleton = all_singleton && arch.singleton;
         exec->queryDataHost.push_back(a);
         for (uint32_t c : comps) {
             exec->queryDataHost.push_back((uint32_t)findColumn(arch, c));
@@ -487,8 +491,11 @@ extern "C" int mwhip_make_query(mwhip_exec *exec, const uint32_t *component_ids,
             hipMemcpyHostToDevice));
     }
 
+    rec.flags = (rec.numMatching > 0 && all_singleton) ?
+        MWHIP_QUERY_ALL_SINGLETON : 0u;
     *offset_out = rec.offset;
     *num_matching_out = rec.numMatching;
+    if (flags_out) *flags_out = rec.flags;
     exec->queries.push_back(std::move(rec));
     return 0;
 }
@@ -536,6 +543,7 @@ static int buildDeviceState(mwhip_exec *exec)
     std::vector<uint16_t> lookup(
         (size_t)std::max<uint32_t>(hs.numArchetypeSlots, 1u) *
             std::max<uint32_t>(hs.numComponentSlots, 1u), kNoColumn);
+    std::vector<void *> col_ptrs(lookup.size(), nullptr);
 
     for (uint32_t a = 0; a < hs.numArchetypeSlots; a++) {
         const ArchetypeRec &arch = exec->archetypes[a];
@@ -547,8 +555,11 @@ static int buildDeviceState(mwhip_exec *exec)
             hdr.columnsAlt[c] = arch.alt[c];
             hdr.columnBytes[c] = arch.colBytes[c];
             hdr.columnFlags[c] = arch.colFlags[c];
+            hdr.columnComponent[c] = (uint16_t)arch.colComponent[c];
             lookup[(size_t)a * hs.numComponentSlots + arch.colComponent[c]] =
                 (uint16_t)c;
+            col_ptrs[(size_t)a * hs.numComponentSlots + arch.colComponent[c]] =
+                arch.primary[c];
         }
         hdr.numColumns = (int32_t)arch.numColumns;
         hdr.numRows = arch.singleton ? (int32_t)W : 0;
@@ -567,6 +578,10 @@ static int buildDeviceState(mwhip_exec *exec)
     if (rc != 0) return rc;
     HIPCHK(hipMemcpy(hs.colLookup, lookup.data(),
         lookup.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    rc = devAllocT(exec, &hs.colPtr, col_ptrs.size());
+    if (rc != 0) return rc;
+    HIPCHK(hipMemcpy(hs.colPtr, col_ptrs.data(),
+        col_ptrs.size() * sizeof(void *), hipMemcpyHostToDevice));
 
     rc = devAllocT(exec, &hs.queryData, exec->queryCapacity);
     if (rc != 0) return rc;

@@ -553,8 +553,11 @@ sortFinalize(EcsState *S, const SortSite *sites)
     for (int32_t c = threadIdx.x; c < tbl.numColumns; c += kSortThreads) {
         if ((tbl.columnFlags[c] & kColumnPinned) == 0u) {
             void *tmp = tbl.columns[c];
-            tbl.columns[c] = tbl.columnsAlt[c];
+            void *cur = tbl.columnsAlt[c];
+            tbl.columns[c] = cur;
             tbl.columnsAlt[c] = tmp;
+            S->colPtr[site.archetype * S->numComponentSlots +
+                      tbl.columnComponent[c]] = cur;
         }
     }
     for (int i = threadIdx.x; i < 4 * kRadixDigits; i += kSortThreads) {
@@ -650,7 +653,9 @@ void buildSortLaunches(const SortBatch &batch, std::vector<KernelLaunch> &out)
     {
         KernelLaunch k;
         k.fn = (const void *)&sortFinalize;
-        k.grid = dim3(std::min<uint32_t>(stream_blocks, 256u), num_sites, 1);
+        // W-sized fix-up + (rare) pinned-column copy-back: keep the grid small,
+        // every block pays a device-scope fence for the last-block hand-off
+        k.grid = dim3(std::min<uint32_t>(stream_blocks, 16u), num_sites, 1);
         k.block = dim3(kSortThreads, 1, 1);
         k.setArgs(batch.stateDev, batch.sitesDev);
         k.role = "sort.finalize";

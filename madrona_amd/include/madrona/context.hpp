@@ -15,12 +15,16 @@ namespace madrona {
 struct WorkerInit {
     WorldID worldID;
     StateManager *stateMgr;
+    // true when the running node has exactly one thread per world
+    bool exclusiveWorld = false;
 };
 
 class Context {
 public:
     MADRONA_HD inline Context(WorldBase *world_data, const WorkerInit &init)
-        : data_(world_data), state_mgr_(init.stateMgr), world_id_(init.worldID)
+        : data_(world_data), state_mgr_(init.stateMgr), world_id_(init.worldID),
+          exclusive_world_(init.exclusiveWorld),
+          cached_id_(-1), cached_gen_(0), cached_loc_ { 0, 0 }
     {}
 
     template <typename ArchetypeT>
@@ -31,7 +35,15 @@ public:
 
     MADRONA_HD inline Entity makeEntity(uint32_t archetype_id)
     {
-        return state_mgr_->makeEntityNow(world_id_, archetype_id);
+        Loc loc;
+        Entity e = state_mgr_->makeEntityNow(world_id_, archetype_id,
+                                             exclusive_world_, &loc);
+        // the usual next step is a run of ctx.get<T>(e) = ...: remember where
+        // the entity lives so those skip the entity-store round trip
+        cached_id_ = e.id;
+        cached_gen_ = e.gen;
+        cached_loc_ = loc;
+        return e;
     }
 
     template <typename ArchetypeT>
@@ -47,7 +59,10 @@ public:
 
     MADRONA_HD inline void destroyEntity(Entity e)
     {
-        state_mgr_->destroyEntityNow(world_id_, e);
+        if (e.id == cached_id_) {
+            cached_id_ = -1;
+        }
+        state_mgr_->destroyEntityNow(world_id_, e, exclusive_world_);
     }
 
     MADRONA_HD inline Loc loc(Entity e) const
@@ -58,7 +73,7 @@ public:
     template <typename ComponentT>
     MADRONA_HD inline ComponentT &get(Entity e)
     {
-        return state_mgr_->getUnsafe<ComponentT>(e);
+        return state_mgr_->getUnsafe<ComponentT>(locCached(e));
     }
 
     template <typename ComponentT>
@@ -123,8 +138,32 @@ protected:
     WorldBase *data_;
 
 private:
+    // One-entry (entity -> Loc) cache, held in registers.  Systems typically
+    // touch several components of the same entity back to back; each hit
+    // removes one dependent memory round trip (~0.3-0.5 us when the thread is
+    // alone in its wavefront, as in per-world reset systems).  Rows only move
+    // in the sort node, i.e. between kernels, so an entry cannot go stale
+    // while a Context is alive except through destroyEntity (handled above).
+    MADRONA_HD inline Loc locCached(Entity e)
+    {
+        if (e.id == cached_id_ && e.gen == cached_gen_) {
+            return cached_loc_;
+        }
+
+        const mwhip::EntitySlot &slot = state_mgr_->entities[e.id];
+        Loc loc { slot.loc.archetype, slot.loc.row };
+        cached_id_ = e.id;
+        cached_gen_ = e.gen;
+        cached_loc_ = loc;
+        return loc;
+    }
+
     StateManager *state_mgr_;
     WorldID world_id_;
+    bool exclusive_world_;
+    int32_t cached_id_;
+    uint32_t cached_gen_;
+    Loc cached_loc_;
 };
 
 }

@@ -36,8 +36,8 @@ initWorlds(mwhip::EcsState *S, const void *cfg, const void *user_inits,
 
     StateManager *state_mgr = static_cast<StateManager *>(S);
     WorldBase *world = TaskGraph::getWorld(state_mgr, world_idx);
-    ContextT ctx = TaskGraph::makeContext<ContextT>(state_mgr,
-                                                    WorldID { world_idx });
+    ContextT ctx = TaskGraph::makeContext<ContextT>(
+        state_mgr, WorldID { world_idx }, /* exclusive_world = */ true);
 
     new (world) WorldT(ctx, *(const ConfigT *)cfg,
                        ((const InitT *)user_inits)[world_idx]);

@@ -60,6 +60,7 @@ struct TableHdr {
     void *columnsAlt[kMaxColumns];
     uint32_t columnBytes[kMaxColumns];
     uint32_t columnFlags[kMaxColumns];
+    uint16_t columnComponent[kMaxColumns];  // component id stored in each column
     int32_t numColumns;
     int32_t numRows;            // appended to with agent-scope atomics
     int32_t capacity;           // rows mapped in every column
@@ -98,6 +99,11 @@ struct IdCache {
 struct EcsState {
     TableHdr *tables;               // [numArchetypeSlots]
     uint16_t *colLookup;            // [numArchetypeSlots * numComponentSlots]
+    // [numArchetypeSlots * numComponentSlots] current base address of the
+    // column holding that component (nullptr if absent): Context::get needs
+    // one dependent load after the entity slot instead of two.  Kept in sync
+    // by sortFinalize when it swaps ping-pong buffers.
+    void **colPtr;
     uint32_t *queryData;
     EntitySlot *entities;
     IdCache *worldCaches;           // [numWorlds]
@@ -119,7 +125,7 @@ struct EcsState {
     uint32_t errorFlags;
 
     void *hostExec;                 // host mirror only: owning mwhip_exec*
-    uint64_t reserved_[3];
+    uint64_t reserved_[2];
 };
 
 #if defined(__HIPCC__)

@@ -14,12 +14,13 @@ struct QueryRef {
     uint32_t numMatchingArchetypes;
     uint32_t numComponents;
     uint32_t numReferences;
+    uint32_t flags;             // MWHIP_QUERY_*
 };
 
 template <typename... ComponentTs>
 class Query {
 public:
-    MADRONA_HD Query() : ref_ { 0, 0xFFFFFFFFu, 0, 0 } {}
+    MADRONA_HD Query() : ref_ { 0, 0xFFFFFFFFu, 0, 0, 0 } {}
     MADRONA_HD Query(QueryRef ref) : ref_(ref) {}
 
     MADRONA_HD inline uint32_t numMatchingArchetypes() const

@@ -198,7 +198,7 @@ MADRONA_HOST_API Query<ComponentTs...> StateManager::query()
     QueryRef ref {};
     mwhip::check(mwhip_make_query(exec(), component_ids,
         (uint32_t)sizeof...(ComponentTs), &ref.offset,
-        &ref.numMatchingArchetypes), "makeQuery");
+        &ref.numMatchingArchetypes, &ref.flags), "makeQuery");
     ref.numComponents = (uint32_t)sizeof...(ComponentTs);
     ref.numReferences = 1;
 
@@ -230,9 +230,8 @@ template <typename ComponentT>
 MADRONA_HD ComponentT &StateManager::getUnsafe(Loc loc)
 {
     uint32_t component_id = TypeTracker::typeID<ComponentT>();
-    uint16_t col_idx =
-        colLookup[loc.archetype * numComponentSlots + component_id];
-    return ((ComponentT *)tables[loc.archetype].columns[col_idx])[loc.row];
+    return ((ComponentT *)colPtr[loc.archetype * numComponentSlots +
+                                 component_id])[loc.row];
 }
 
 template <typename ComponentT>
@@ -246,14 +245,13 @@ template <typename ComponentT>
 MADRONA_HD ResultRef<ComponentT> StateManager::get(Loc loc)
 {
     uint32_t component_id = TypeTracker::typeID<ComponentT>();
-    uint16_t col_idx =
-        colLookup[loc.archetype * numComponentSlots + component_id];
-    if (col_idx == mwhip::kNoColumn) {
+    ComponentT *col = (ComponentT *)colPtr[
+        loc.archetype * numComponentSlots + component_id];
+    if (col == nullptr) {
         return ResultRef<ComponentT>(nullptr);
     }
 
-    return ResultRef<ComponentT>(
-        (ComponentT *)tables[loc.archetype].columns[col_idx] + loc.row);
+    return ResultRef<ComponentT>(col + loc.row);
 }
 
 template <typename ComponentT>
@@ -288,7 +286,7 @@ MADRONA_HD SingletonT &StateManager::getSingleton(WorldID world_id)
     return getSingletonColumn<SingletonT>()[world_id.idx];
 }
 
-MADRONA_HD inline Entity StateManager::makeEntityNow(WorldID world_id, uint32_t archetype_id)
+MADRONA_HD inline Entity StateManager::makeEntityNow(WorldID world_id, uint32_t archetype_id, bool exclusive, Loc *loc_out)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     mwhip::TableHdr &tbl = tables[archetype_id];
@@ -296,9 +294,15 @@ MADRONA_HD inline Entity StateManager::makeEntityNow(WorldID world_id, uint32_t 
 
     uint32_t gen = 0;
     int32_t id = 0;
-    mwhip::withWorldCache(this, world_id.idx, [&](mwhip::IdCache &cache) {
-        id = mwhip::acquireIdLocked(this, world_id.idx, cache, &gen);
-    });
+    if (exclusive) {
+        // one thread per world in this node: nobody else touches the cache
+        id = mwhip::acquireIdLocked(this, world_id.idx,
+                                    worldCaches[world_id.idx], &gen);
+    } else {
+        mwhip::withWorldCache(this, world_id.idx, [&](mwhip::IdCache &cache) {
+            id = mwhip::acquireIdLocked(this, world_id.idx, cache, &gen);
+        });
+    }
 
     mwhip::EntitySlot &slot = entities[id];
     slot.loc.archetype = archetype_id;
@@ -308,6 +312,9 @@ MADRONA_HD inline Entity StateManager::makeEntityNow(WorldID world_id, uint32_t 
     ((Entity *)tbl.columns[0])[row] = e;
     ((WorldID *)tbl.columns[1])[row] = world_id;
 
+    if (loc_out != nullptr) {
+        *loc_out = Loc { archetype_id, row };
+    }
     return e;
 #else
     (void)0;
@@ -337,7 +344,7 @@ MADRONA_HD inline Loc StateManager::makeTemporary(WorldID world_id, uint32_t arc
 // to the *calling* world's cache.  The row is tagged the way both backends'
 // ParallelFor skip tests expect: Entity::none() (CPU state.inl:484) and
 // WorldID -1 (GPU taskgraph.inl:208), which is also the sort key that drops it.
-MADRONA_HD inline void StateManager::destroyEntityNow(WorldID caller_world, Entity e)
+MADRONA_HD inline void StateManager::destroyEntityNow(WorldID caller_world, Entity e, bool exclusive)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     Loc loc = getLoc(e);
@@ -350,9 +357,14 @@ MADRONA_HD inline void StateManager::destroyEntityNow(WorldID caller_world, Enti
     ((WorldID *)tbl.columns[1])[loc.row] = WorldID { -1 };
     tbl.needsSort = 1u;
 
-    mwhip::withWorldCache(this, caller_world.idx, [&](mwhip::IdCache &cache) {
-        mwhip::releaseIdLocked(this, cache, e.id);
-    });
+    if (exclusive) {
+        mwhip::releaseIdLocked(this, worldCaches[caller_world.idx], e.id);
+    } else {
+        mwhip::withWorldCache(this, caller_world.idx,
+                              [&](mwhip::IdCache &cache) {
+            mwhip::releaseIdLocked(this, cache, e.id);
+        });
+    }
 #else
     (void)0;
     mwhip::hostOnlyAbort("destroyEntity");

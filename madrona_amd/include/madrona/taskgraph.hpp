@@ -153,11 +153,12 @@ public:
 
     template <typename ContextT>
     MADRONA_HD static inline ContextT makeContext(StateManager *state_mgr,
-                                                      WorldID world_id)
+                                                  WorldID world_id,
+                                                  bool exclusive_world = false)
     {
         using WorldDataT = typename WorldTypeExtract<ContextT>::type;
         return ContextT((WorldDataT *)getWorld(state_mgr, world_id.idx),
-                        WorkerInit { world_id, state_mgr });
+                        WorkerInit { world_id, state_mgr, exclusive_world });
     }
 
     template <typename ContextT>

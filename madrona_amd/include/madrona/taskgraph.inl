@@ -60,9 +60,13 @@ MADRONA_DEVICE inline void invokeSystemRow(ContextT &ctx, void *const *cols,
 template <typename ContextT, auto Fn, typename... ComponentTs>
 __global__ void __launch_bounds__(256)
 parallelForKernel(EcsState *S, void *, uint32_t query_offset,
-                  uint32_t num_matching)
+                  uint32_t num_matching_and_flags)
 {
     constexpr size_t N = sizeof...(ComponentTs);
+
+    // bit 31: every matched archetype is a singleton => one thread per world
+    const uint32_t num_matching = num_matching_and_flags & 0x7FFFFFFFu;
+    const bool exclusive_world = (num_matching_and_flags >> 31) != 0u;
 
     StateManager *state_mgr = static_cast<StateManager *>(S);
     const uint32_t *query_values = S->queryData + query_offset;
@@ -88,8 +92,8 @@ MADRONA_UNROLL
                 continue;
             }
 
-            ContextT ctx =
-                TaskGraph::makeContext<ContextT>(state_mgr, world_id);
+            ContextT ctx = TaskGraph::makeContext<ContextT>(
+                state_mgr, world_id, exclusive_world);
             invokeSystemRow<ContextT, Fn, ComponentTs...>(
                 ctx, cols, row, std::make_index_sequence<N>());
         }
@@ -405,7 +409,8 @@ CustomParallelForNode<ContextT, Fn, threads_per_invocation,
     desc.kernel = kernel_stub();
     desc.node_data_id = -1;
     desc.arg0 = ref->offset;
-    desc.arg1 = ref->numMatchingArchetypes;
+    desc.arg1 = ref->numMatchingArchetypes |
+        ((ref->flags & MWHIP_QUERY_ALL_SINGLETON) != 0u ? 0x80000000u : 0u);
     desc.count_mode = MWHIP_COUNT_QUERY_ROWS;
     desc.query_offset = ref->offset;
     desc.num_matching = ref->numMatchingArchetypes;

@@ -83,6 +83,29 @@ def _bind(lib: C.CDLL) -> None:
                                     C.POINTER(C.c_int32)]
     lib.sim_hip_exec.restype = C.c_void_p
     lib.sim_hip_exec.argtypes = [C.c_void_p]
+    lib.sim_hip_step_graph.restype = C.c_uint64
+    lib.sim_hip_step_graph.argtypes = [C.c_void_p]
+
+
+class KernelStat(C.Structure):
+    _fields_ = [
+        ("name", C.c_char_p),
+        ("node_kind", C.c_uint32),
+        ("archetype_id", C.c_uint32),
+        ("avg_us", C.c_double),
+        ("algo_bytes", C.c_double),
+        ("rows", C.c_double),
+    ]
+
+
+def runtime_lib() -> C.CDLL:
+    """libmadrona_hip.so (the C ABI of include/mwhip.h)."""
+    lib = C.CDLL(os.path.join(HIP_BUILD_DIR, "libmadrona_hip.so"), mode=C.RTLD_GLOBAL)
+    lib.mwhip_profile.restype = C.c_int32
+    lib.mwhip_profile.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32,
+                                  C.POINTER(KernelStat), C.c_uint32]
+    lib.mwhip_last_error.restype = C.c_char_p
+    return lib
 
 
 class Simulator:
@@ -180,3 +203,17 @@ class Simulator:
 
     def hip_exec(self) -> int:
         return int(self.lib.sim_hip_exec(self.handle) or 0)
+
+    def profile(self, reps: int = 20):
+        """Per-kernel timing of one step (HIP events on the executor's stream,
+        kernels queued back to back behind a gate).  Advances the simulation by
+        `reps` steps.  Returns a list of dicts."""
+        rt = runtime_lib()
+        stats = (KernelStat * 512)()
+        n = rt.mwhip_profile(self.hip_exec(), self.lib.sim_hip_step_graph(self.handle),
+                             reps, stats, 512)
+        if n < 0:
+            raise RuntimeError(f"mwhip_profile -> {n}: {rt.mwhip_last_error().decode()}")
+        return [dict(name=stats[i].name.decode(), kind=int(stats[i].node_kind),
+                     avg_us=float(stats[i].avg_us), algo_bytes=float(stats[i].algo_bytes),
+                     rows=float(stats[i].rows)) for i in range(n)]

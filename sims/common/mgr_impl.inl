@@ -301,6 +301,16 @@ int64_t sim_column_dump(SimHandle *h, uint32_t idx, void *dst,
 #endif
 }
 
+uint64_t sim_hip_step_graph(SimHandle *h)
+{
+#ifdef SIM_BACKEND_REF_CPU
+    (void)h;
+    return 0;
+#else
+    return h->stepGraph->handle();
+#endif
+}
+
 void *sim_hip_exec(SimHandle *h)
 {
 #ifdef SIM_BACKEND_REF_CPU

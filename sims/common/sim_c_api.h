@@ -66,6 +66,8 @@ SIM_API int64_t sim_column_dump(SimHandle *h, uint32_t idx, void *dst, uint64_t 
 
 /* HIP backend only (NULL/0 on the reference): opaque mwhip_exec* for profiling */
 SIM_API void *sim_hip_exec(SimHandle *h);
+/* launch-graph handle of the per-step graph inside that executor (0 on the reference) */
+SIM_API uint64_t sim_hip_step_graph(SimHandle *h);
 
 #ifdef __cplusplus
 }
