@@ -1,0 +1,151 @@
+#include "sim.hpp"
+
+#ifdef MADRONA_GPU_MODE
+#include <madrona/mw_gpu_entry.hpp>
+#endif
+
+using namespace madrona;
+
+namespace sortstress {
+
+void Sim::registerTypes(ECSRegistry &registry, const Config &)
+{
+    registry.registerComponent<Tag8>();
+    registry.registerComponent<Half>();
+    registry.registerComponent<Key>();
+    registry.registerComponent<Pair>();
+    registry.registerComponent<Vec3>();
+    registry.registerComponent<Quad>();
+    registry.registerComponent<Blob20>();
+    registry.registerComponent<Wide>();
+    registry.registerSingleton<Churn>();
+
+    registry.registerArchetype<Item>();
+    registry.registerArchetype<Scratch>();
+
+    registry.exportSingleton<Churn>((uint32_t)ExportID::Churn);
+}
+
+static inline void fillItem(Engine &ctx, Entity e, RNG &rng)
+{
+    uint32_t bits = (uint32_t)rng.sampleI32(0, 0x7FFFFFFF);
+
+    ctx.get<Tag8>(e).v = (uint8_t)(bits & 0xFF);
+    ctx.get<Half>(e).v = (uint16_t)(bits >> 8);
+    ctx.get<Key>(e).v = bits;
+    ctx.get<Pair>(e).v = ((uint64_t)bits << 32) | (uint64_t)(uint32_t)e.id;
+
+    Vec3 &v3 = ctx.get<Vec3>(e);
+    for (int i = 0; i < 3; i++) v3.v[i] = rng.sampleUniform();
+
+    Quad &q = ctx.get<Quad>(e);
+    for (int i = 0; i < 4; i++) q.v[i] = (float)i + v3.v[0];
+
+    Blob20 &b = ctx.get<Blob20>(e);
+    for (int i = 0; i < 5; i++) b.v[i] = bits * (uint32_t)(i + 1);
+
+    Wide &w = ctx.get<Wide>(e);
+    for (int i = 0; i < 60; i++) w.v[i] = (float)(bits & 0xFFFF) + (float)i;
+}
+
+inline void churnSystem(Engine &ctx, Churn &churn)
+{
+    Sim &sim = ctx.data();
+    RNG &rng = sim.rng;
+
+    int32_t num_destroy = rng.sampleI32(0, consts::maxChurn + 1);
+    for (int32_t i = 0; i < num_destroy && sim.numItems > 0; i++) {
+        int32_t victim = rng.sampleI32(0, sim.numItems);
+        ctx.destroyEntity(sim.items[victim]);
+        sim.items[victim] = sim.items[sim.numItems - 1];
+        sim.numItems -= 1;
+    }
+
+    int32_t num_create = rng.sampleI32(0, consts::maxChurn + 1);
+    for (int32_t i = 0; i < num_create && sim.numItems < consts::maxItems; i++) {
+        Entity e = ctx.makeEntity<Item>();
+        fillItem(ctx, e, rng);
+        sim.items[sim.numItems++] = e;
+    }
+
+    int32_t num_scratch = rng.sampleI32(0, consts::maxScratch + 1);
+    for (int32_t i = 0; i < num_scratch; i++) {
+        Loc loc = ctx.makeTemporary<Scratch>();
+        ctx.get<Key>(loc).v = churn.step * 1000u + (uint32_t)i;
+        Vec3 &v = ctx.get<Vec3>(loc);
+        v.v[0] = rng.sampleUniform();
+        v.v[1] = (float)i;
+        v.v[2] = (float)churn.step;
+    }
+
+    churn.step += 1;
+    churn.numItems = (uint32_t)sim.numItems;
+}
+
+inline void touchSystem(Engine &, Entity e, Key &key, Vec3 &v3, Wide &wide)
+{
+    key.v = key.v * 1664525u + 1013904223u + (uint32_t)e.id;
+    v3.v[1] = v3.v[1] * 0.5f + 0.25f;
+    wide.v[(key.v >> 8) % 60] += 1.f;
+}
+
+inline void scratchSystem(Engine &ctx, Key &key, Vec3 &v3)
+{
+    v3.v[2] = v3.v[2] + (float)ctx.worldID().idx + (float)(key.v & 7u);
+}
+
+void Sim::setupTasks(TaskGraphManager &taskgraph_mgr, const Config &)
+{
+    TaskGraphBuilder &builder = taskgraph_mgr.init(0);
+
+    auto clear_tmp = builder.addToGraph<ClearTmpNode<Scratch>>({});
+
+    auto churn_sys = builder.addToGraph<ParallelForNode<Engine,
+        churnSystem, Churn>>({clear_tmp});
+
+    auto compact = builder.addToGraph<CompactArchetypeNode<Item>>({churn_sys});
+
+#ifdef MADRONA_GPU_MODE
+    // as the reference's XPBD graph does for Contact temporaries
+    // (src/physics/xpbd.cpp:1107-1113): group temporaries by world
+    auto sort_tmp = builder.addToGraph<
+        SortArchetypeNode<Scratch, WorldID>>({compact});
+    auto post_sort = builder.addToGraph<ResetTmpAllocNode>({sort_tmp});
+#else
+    auto post_sort = compact;
+#endif
+
+    auto touch_sys = builder.addToGraph<ParallelForNode<Engine,
+        touchSystem, Entity, Key, Vec3, Wide>>({post_sort});
+
+    auto scratch_sys = builder.addToGraph<ParallelForNode<Engine,
+        scratchSystem, Key, Vec3>>({touch_sys});
+
+    (void)scratch_sys;
+}
+
+Sim::Sim(Engine &ctx, const Config &cfg, const WorldInit &)
+    : WorldBase(ctx)
+{
+    uint32_t global_world = cfg.worldBase + (uint32_t)ctx.worldID().idx;
+    rng = RNG(rand::split_i(rand::initKey(cfg.seed), global_world));
+    numItems = 0;
+
+    Churn &churn = ctx.singleton<Churn>();
+    churn.step = 0;
+    churn.numItems = 0;
+
+    // ragged start: world w begins with (w * 7) % maxItems items, some worlds empty
+    int32_t initial = (int32_t)((global_world * 7u) % (uint32_t)consts::maxItems);
+    for (int32_t i = 0; i < initial; i++) {
+        Entity e = ctx.makeEntity<Item>();
+        fillItem(ctx, e, rng);
+        items[numItems++] = e;
+    }
+}
+
+#ifdef MADRONA_GPU_MODE
+MADRONA_BUILD_MWGPU_ENTRY(Engine, Sim, Sim::Config, Sim::WorldInit);
+#endif
+
+}

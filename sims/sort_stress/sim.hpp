@@ -1,0 +1,78 @@
+// Sort/compaction stress simulator (test workload, not a BASELINE config):
+// per-world random create/destroy churn over an archetype whose columns cover
+// every gather width of the sort node (1, 2, 4, 8, 12, 16, 20, 240 bytes), plus
+// a temporary archetype (makeTemporary / ClearTmpNode / world sort).  Compiled
+// unchanged against the reference CPU backend (oracle) and the HIP backend.
+#pragma once
+
+#include <madrona/taskgraph_builder.hpp>
+#include <madrona/custom_context.hpp>
+#include <madrona/rand.hpp>
+
+namespace sortstress {
+
+using madrona::Entity;
+using madrona::RandKey;
+using madrona::RNG;
+
+namespace consts {
+inline constexpr int32_t maxItems = 40;
+inline constexpr int32_t maxChurn = 6;
+inline constexpr int32_t maxScratch = 12;
+}
+
+enum class ExportID : uint32_t {
+    Churn,
+    NumExports,
+};
+
+struct Tag8 { uint8_t v; };
+struct Half { uint16_t v; };
+struct Key { uint32_t v; };
+struct Pair { uint64_t v; };
+struct Vec3 { float v[3]; };
+struct Quad { float v[4]; };
+struct Blob20 { uint32_t v[5]; };
+struct Wide { float v[60]; };
+
+struct Churn {
+    uint32_t step;
+    uint32_t numItems;
+};
+
+struct Item : public madrona::Archetype<
+    Tag8, Half, Key, Pair, Vec3, Quad, Blob20, Wide
+> {};
+
+struct Scratch : public madrona::Archetype<
+    Key, Vec3
+> {};
+
+class Engine;
+
+struct Sim : public madrona::WorldBase {
+    struct Config {
+        uint32_t seed;
+        uint32_t worldBase;
+    };
+
+    struct WorldInit {};
+
+    static void registerTypes(madrona::ECSRegistry &registry,
+                              const Config &cfg);
+    static void setupTasks(madrona::TaskGraphManager &taskgraph_mgr,
+                           const Config &cfg);
+
+    Sim(Engine &ctx, const Config &cfg, const WorldInit &init);
+
+    RNG rng;
+    int32_t numItems;
+    Entity items[consts::maxItems];
+};
+
+class Engine : public madrona::CustomContext<Engine, Sim> {
+public:
+    using CustomContext::CustomContext;
+};
+
+}
