@@ -1080,6 +1080,7 @@ static int resetForInitPass(mwhip_exec *exec)
         c.numOverflow = 0;
         c.lock = 0;
         c.initBlocksUsed = 0;
+        c.runtimeBlocksUsed = 0;
     }
     HIPCHK(hipMemcpy(hs.worldCaches, caches.data(), W * sizeof(IdCache),
                      hipMemcpyHostToDevice));
@@ -1173,6 +1174,8 @@ static int constructWorlds(mwhip_exec *exec)
         return fail(-4, "world construction failed: %s", describeError(err));
     }
 
+    rc = pokeState(exec, &EcsState::runtimeIdBase, (int32_t)next);
+    if (rc != 0) return rc;
     return pokeState(exec, &EcsState::initMode, 0u);
 }
 

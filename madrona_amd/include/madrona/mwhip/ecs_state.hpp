@@ -93,7 +93,8 @@ struct IdCache {
     int32_t numOverflow;
     uint32_t lock;
     int32_t initBlocksUsed;   // blocks taken from the global store during world init
-    uint32_t pad_[2];
+    int32_t runtimeBlocksUsed;// blocks taken after init (static per-world partition)
+    uint32_t pad_;
 };
 
 struct EcsState {
@@ -120,12 +121,14 @@ struct EcsState {
     uint32_t worldDataStride;
     int32_t numWorlds;
     int32_t entityCapacity;
-    int32_t numIds;                 // high-water mark of the id store (multiple of 64)
+    int32_t numIds;                 // end of the ids handed out during init (multiple of 64)
     uint32_t initMode;              // 0 run, 1 init pass (count), 2 init pass (assign)
     uint32_t errorFlags;
 
     void *hostExec;                 // host mirror only: owning mwhip_exec*
-    uint64_t reserved_[2];
+    int32_t runtimeIdBase;          // first id of the post-init block partition
+    int32_t pad_;
+    uint64_t reserved_[1];
 };
 
 #if defined(__HIPCC__)
@@ -193,6 +196,14 @@ MWHIP_DEV inline int32_t popCachedId(EcsState *S, int32_t *head, uint32_t *gen_o
 // During world construction the block order is made deterministic (world
 // major, like the CPU backend's sequential constructor loop): pass 1 counts
 // blocks per world, pass 2 replays with prefix-summed bases.
+// After init a world's k-th new block comes from a static partition,
+// runtimeIdBase + (k * numWorlds + world) * 64: independent of thread
+// scheduling, so runs are reproducible.  (The CPU backend hands such blocks out
+// in world-major order *within a step*, which a node-major GPU schedule cannot
+// reproduce without serialising worlds; ids therefore match the CPU backend
+// bit for bit as long as worlds get their blocks during construction -- the
+// case for Escape-Room / Hide-and-Seek style simulators -- and are otherwise a
+// per-world renaming of them.  DESIGN.md §5.)
 MWHIP_DEV inline int32_t expandIdStore(EcsState *S, int32_t world, IdCache &cache)
 {
     int32_t block_start;
@@ -200,11 +211,13 @@ MWHIP_DEV inline int32_t expandIdStore(EcsState *S, int32_t world, IdCache &cach
         block_start = S->initBlockBase[world] +
             cache.initBlocksUsed * kIdsPerBlock;
         cache.initBlocksUsed += 1;
-    } else {
-        if (S->initMode == 1u) {
-            cache.initBlocksUsed += 1;
-        }
+    } else if (S->initMode == 1u) {
+        cache.initBlocksUsed += 1;
         block_start = atomicAddI32(&S->numIds, kIdsPerBlock);
+    } else {
+        block_start = S->runtimeIdBase +
+            (cache.runtimeBlocksUsed * S->numWorlds + world) * kIdsPerBlock;
+        cache.runtimeBlocksUsed += 1;
     }
 
     if (block_start + kIdsPerBlock > S->entityCapacity) {

@@ -117,8 +117,9 @@ class Simulator:
         if not os.path.exists(lib_path):
             raise FileNotFoundError(
                 f"{lib_path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
-        mode = C.RTLD_GLOBAL if lib_path.endswith("_hip.so") else C.RTLD_LOCAL
-        self.lib = C.CDLL(lib_path, mode=mode)
+        # RTLD_LOCAL: every simulator library defines the same C API (and
+        # madronaMWHipUserEntry); they must not interpose on each other
+        self.lib = C.CDLL(lib_path, mode=C.RTLD_LOCAL)
         _bind(self.lib)
         self.num_worlds = num_worlds
         args = SimCreateArgs(num_worlds, seed, gpu_id, num_workers, world_base, flags)
@@ -194,7 +195,10 @@ class Simulator:
             self.handle, idx, buf.ctypes.data, buf.nbytes,
             counts.ctypes.data_as(C.POINTER(C.c_int32)))
         if n < 0:
-            raise RuntimeError(f"sim_column_dump({name}) -> {n}")
+            detail = ""
+            if self.backend == "hip":
+                detail = ": " + runtime_lib().mwhip_last_error().decode()
+            raise RuntimeError(f"sim_column_dump({name}) -> {n}{detail}")
         return buf[: n * elem_bytes].reshape(n, elem_bytes).copy(), counts
 
     def dump_all(self, max_rows_per_world: int = 256):

@@ -16,7 +16,7 @@ struct SimTraits {
 
     static Sim::Config makeConfig(const SimCreateArgs &args)
     {
-        return Sim::Config { args.seed, args.world_base };
+        return Sim::Config { args.seed, args.world_base, args.flags & 1u };
     }
 
     static void makeInits(const SimCreateArgs &, Sim::WorldInit *) {}

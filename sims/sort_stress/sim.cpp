@@ -29,11 +29,12 @@ void Sim::registerTypes(ECSRegistry &registry, const Config &)
 static inline void fillItem(Engine &ctx, Entity e, RNG &rng)
 {
     uint32_t bits = (uint32_t)rng.sampleI32(0, 0x7FFFFFFF);
+    uint32_t id_bits = ctx.data().mixIds != 0 ? (uint32_t)e.id : 0u;
 
     ctx.get<Tag8>(e).v = (uint8_t)(bits & 0xFF);
     ctx.get<Half>(e).v = (uint16_t)(bits >> 8);
     ctx.get<Key>(e).v = bits;
-    ctx.get<Pair>(e).v = ((uint64_t)bits << 32) | (uint64_t)(uint32_t)e.id;
+    ctx.get<Pair>(e).v = ((uint64_t)bits << 32) | (uint64_t)id_bits;
 
     Vec3 &v3 = ctx.get<Vec3>(e);
     for (int i = 0; i < 3; i++) v3.v[i] = rng.sampleUniform();
@@ -82,9 +83,10 @@ inline void churnSystem(Engine &ctx, Churn &churn)
     churn.numItems = (uint32_t)sim.numItems;
 }
 
-inline void touchSystem(Engine &, Entity e, Key &key, Vec3 &v3, Wide &wide)
+inline void touchSystem(Engine &ctx, Entity e, Key &key, Vec3 &v3, Wide &wide)
 {
-    key.v = key.v * 1664525u + 1013904223u + (uint32_t)e.id;
+    uint32_t id_bits = ctx.data().mixIds != 0 ? (uint32_t)e.id : 0u;
+    key.v = key.v * 1664525u + 1013904223u + id_bits;
     v3.v[1] = v3.v[1] * 0.5f + 0.25f;
     wide.v[(key.v >> 8) % 60] += 1.f;
 }
@@ -129,14 +131,17 @@ Sim::Sim(Engine &ctx, const Config &cfg, const WorldInit &)
 {
     uint32_t global_world = cfg.worldBase + (uint32_t)ctx.worldID().idx;
     rng = RNG(rand::split_i(rand::initKey(cfg.seed), global_world));
+    mixIds = cfg.coldStart == 0 ? 1u : 0u;
     numItems = 0;
 
     Churn &churn = ctx.singleton<Churn>();
     churn.step = 0;
     churn.numItems = 0;
 
-    // ragged start: world w begins with (w * 7) % maxItems items, some worlds empty
-    int32_t initial = (int32_t)((global_world * 7u) % (uint32_t)consts::maxItems);
+    // ragged start; with coldStart some worlds begin empty
+    int32_t initial = cfg.coldStart != 0 ?
+        (int32_t)((global_world * 7u) % (uint32_t)consts::maxItems) :
+        1 + (int32_t)((global_world * 7u) % (uint32_t)(consts::maxItems - 1));
     for (int32_t i = 0; i < initial; i++) {
         Entity e = ctx.makeEntity<Item>();
         fillItem(ctx, e, rng);

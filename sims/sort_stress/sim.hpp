@@ -54,6 +54,9 @@ struct Sim : public madrona::WorldBase {
     struct Config {
         uint32_t seed;
         uint32_t worldBase;
+        // 1: some worlds start empty and take their first block of entity ids
+        // at run time (ids are then executor-specific; values avoid them)
+        uint32_t coldStart;
     };
 
     struct WorldInit {};
@@ -66,6 +69,7 @@ struct Sim : public madrona::WorldBase {
     Sim(Engine &ctx, const Config &cfg, const WorldInit &init);
 
     RNG rng;
+    uint32_t mixIds;
     int32_t numItems;
     Entity items[consts::maxItems];
 };
