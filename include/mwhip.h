@@ -125,12 +125,31 @@ enum mwhip_count_mode {
     MWHIP_COUNT_PER_WORLD = 2     /* one invocation per world */
 };
 
+/* Query resolution passed BY VALUE in the kernel-argument segment of
+ * ParallelFor kernels: the matched tables' header addresses and the column
+ * index of every component, so a kernel starts with one round trip (row count +
+ * column pointers) instead of walking ecs_state -> query table -> table.
+ * Queries matching more archetypes / components than fit set num_inline = 0
+ * and the kernel walks the query table (mwhip_make_query) instead. */
+#define MWHIP_PFOR_MAX_INLINE 4
+#define MWHIP_PFOR_MAX_COMPONENTS 24
+typedef struct mwhip_pfor_args {
+    uint32_t num_matching;
+    uint32_t num_inline;
+    void *tables[MWHIP_PFOR_MAX_INLINE];            /* device table headers */
+    uint16_t columns[MWHIP_PFOR_MAX_INLINE][MWHIP_PFOR_MAX_COMPONENTS];
+} mwhip_pfor_args;
+
 typedef struct mwhip_node_desc {
     uint32_t kind;
     const char *name;             /* for profiles; copied */
     /* MWHIP_NODE_KERNEL: host stub of
-     *   __global__ void(ecs_state*, void *node_data_dev, uint32_t a0, uint32_t a1) */
+     *   __global__ void(ecs_state*, void *node_data_dev, uint32_t a0, uint32_t a1)
+     * or, when wants_pfor_args != 0 (count_mode MWHIP_COUNT_QUERY_ROWS),
+     *   __global__ void(ecs_state*, void *node_data_dev, uint32_t a0, uint32_t a1,
+     *                   mwhip_pfor_args query) */
     const void *kernel;
+    uint32_t wants_pfor_args;
     int32_t node_data_id;         /* from mwhip_tg_add_node_data, or -1 */
     uint32_t arg0, arg1;
     uint32_t count_mode;

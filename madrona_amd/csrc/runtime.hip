@@ -10,6 +10,8 @@
 // step is one hipGraph replay on the executor's private stream.
 #include "runtime_internal.hpp"
 
+#include <hip/hip_ext.h>
+
 #include <cinttypes>
 #include <cstdarg>
 #include <cstdio>
@@ -909,6 +911,30 @@ static int buildLaunchList(mwhip_exec *exec, const std::vector<uint32_t> &tg_ids
                 void *data_dev = d.node_data_id >= 0 ?
                     tg.dataDev[d.node_data_id] : nullptr;
                 k.setArgs(exec->stateDev, data_dev, d.arg0, d.arg1);
+                if (d.wants_pfor_args != 0 &&
+                        d.count_mode == MWHIP_COUNT_QUERY_ROWS) {
+                    mwhip_pfor_args pa {};
+                    pa.num_matching = d.num_matching;
+                    pa.num_inline = 0;
+                    for (const QueryRec &q : exec->queries) {
+                        if (q.offset != d.query_offset) continue;
+                        if (q.numMatching <= MWHIP_PFOR_MAX_INLINE &&
+                                q.comps.size() <= MWHIP_PFOR_MAX_COMPONENTS) {
+                            const uint32_t *p =
+                                exec->queryDataHost.data() + q.offset;
+                            for (uint32_t m = 0; m < q.numMatching; m++) {
+                                pa.tables[m] = exec->hostState.tables + p[0];
+                                for (size_t c = 0; c < q.comps.size(); c++) {
+                                    pa.columns[m][c] = (uint16_t)p[1 + c];
+                                }
+                                p += 1 + q.comps.size();
+                            }
+                            pa.num_inline = q.numMatching;
+                        }
+                        break;
+                    }
+                    k.pushArg(pa);
+                }
                 k.name = node.name;
                 k.role = "";
                 k.kind = d.kind;
@@ -1592,8 +1618,14 @@ extern "C" int32_t mwhip_profile(mwhip_exec *exec, uint64_t graph, uint32_t reps
     HIPCHK(hipSetDevice(exec->cfg.gpu_id));
     HIPCHK(hipStreamSynchronize(exec->stream));
 
-    std::vector<hipEvent_t> ev(n + 1);
-    for (auto &e : ev) HIPCHK(hipEventCreate(&e));
+    // start/stop events attached to each dispatch: their difference is the
+    // kernel's own begin/end timestamp pair (what rocprofv3 reports), without
+    // the cost of separate event packets between kernels
+    std::vector<hipEvent_t> ev_start(n), ev_stop(n);
+    for (size_t i = 0; i < n; i++) {
+        HIPCHK(hipEventCreate(&ev_start[i]));
+        HIPCHK(hipEventCreate(&ev_stop[i]));
+    }
 
     std::vector<double> total_us(n, 0.0), total_rows(n, 0.0),
         total_bytes(n, 0.0);
@@ -1628,14 +1660,17 @@ extern "C" int32_t mwhip_profile(mwhip_exec *exec, uint64_t graph, uint32_t reps
                                    gargs, 0, exec->stream));
         }
         for (size_t i = 0; i < n; i++) {
-            HIPCHK(hipEventRecord(ev[i], exec->stream));
-            rc = launchOne(exec, lg.launches[i], exec->stream);
-            if (rc != 0) {
+            KernelLaunch &k = lg.launches[i];
+            void *kargs[8];
+            k.argPointers(kargs);
+            hipError_t lres = hipExtLaunchKernel(k.fn, k.grid, k.block, kargs, 0,
+                exec->stream, ev_start[i], ev_stop[i], 0);
+            if (lres != hipSuccess) {
                 *gate_host = 1;
-                return rc;
+                return fail(-10, "hipExtLaunchKernel -> %s",
+                            hipGetErrorString(lres));
             }
         }
-        HIPCHK(hipEventRecord(ev[n], exec->stream));
         *gate_host = 1;
         __sync_synchronize();
         HIPCHK(hipStreamSynchronize(exec->stream));
@@ -1644,7 +1679,7 @@ extern "C" int32_t mwhip_profile(mwhip_exec *exec, uint64_t graph, uint32_t reps
 
         for (size_t i = 0; i < n; i++) {
             float ms = 0.f;
-            HIPCHK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+            HIPCHK(hipEventElapsedTime(&ms, ev_start[i], ev_stop[i]));
             total_us[i] += (double)ms * 1000.0;
 
             const KernelLaunch &k = lg.launches[i];
@@ -1709,7 +1744,10 @@ extern "C" int32_t mwhip_profile(mwhip_exec *exec, uint64_t graph, uint32_t reps
         }
     }
 
-    for (auto &e : ev) (void)hipEventDestroy(e);
+    for (size_t i = 0; i < n; i++) {
+        (void)hipEventDestroy(ev_start[i]);
+        (void)hipEventDestroy(ev_stop[i]);
+    }
 
     lg.statNames.resize(n);
     uint32_t count = (uint32_t)std::min<size_t>(n, max_out);

@@ -78,7 +78,7 @@ struct KernelLaunch {
     const void *fn = nullptr;
     dim3 grid { 1, 1, 1 };
     dim3 block { 1, 1, 1 };
-    alignas(16) unsigned char argStorage[64] {};
+    alignas(16) unsigned char argStorage[320] {};
     uint32_t argOffsets[8] {};
     uint32_t numArgs = 0;
 

@@ -57,10 +57,50 @@ MADRONA_DEVICE inline void invokeSystemRow(ContextT &ctx, void *const *cols,
 // One thread per matching row; rows of each matched archetype are walked with
 // a grid-stride loop whose bound is the table's device-resident row count.
 // Adjacent lanes touch adjacent rows of every SoA column (coalesced).
+//
+// The query resolution (table headers + column indices) arrives by value in
+// the kernel-argument segment, so the dependent chain at kernel start is
+// [row count + column pointers] -> [component data]: two round trips, not the
+// five of ecs_state -> query table -> table -> column -> data.  These kernels
+// are launch/latency bound at Escape-Room sizes (a few 1e4 rows).
+template <typename ContextT, auto Fn, typename... ComponentTs>
+MADRONA_DEVICE inline void parallelForTable(StateManager *state_mgr,
+                                            TableHdr &tbl,
+                                            const uint16_t *col_indices,
+                                            bool exclusive_world)
+{
+    constexpr size_t N = sizeof...(ComponentTs);
+
+    const int32_t num_rows = tbl.numRows;
+    const WorldID *world_col = (const WorldID *)tbl.columns[1];
+
+    void *cols[N > 0 ? N : 1];
+MADRONA_UNROLL
+    for (size_t c = 0; c < N; c++) {
+        cols[c] = tbl.columns[col_indices[c]];
+    }
+
+    const int32_t tid = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
+    const int32_t stride = (int32_t)(gridDim.x * blockDim.x);
+
+    for (int32_t row = tid; row < num_rows; row += stride) {
+        WorldID world_id = world_col[row];
+        // destroyed but not yet compacted away
+        if (world_id.idx == -1) {
+            continue;
+        }
+
+        ContextT ctx = TaskGraph::makeContext<ContextT>(
+            state_mgr, world_id, exclusive_world);
+        invokeSystemRow<ContextT, Fn, ComponentTs...>(
+            ctx, cols, row, std::make_index_sequence<N>());
+    }
+}
+
 template <typename ContextT, auto Fn, typename... ComponentTs>
 __global__ void __launch_bounds__(256)
 parallelForKernel(EcsState *S, void *, uint32_t query_offset,
-                  uint32_t num_matching_and_flags)
+                  uint32_t num_matching_and_flags, mwhip_pfor_args query)
 {
     constexpr size_t N = sizeof...(ComponentTs);
 
@@ -69,35 +109,29 @@ parallelForKernel(EcsState *S, void *, uint32_t query_offset,
     const bool exclusive_world = (num_matching_and_flags >> 31) != 0u;
 
     StateManager *state_mgr = static_cast<StateManager *>(S);
+
+    if (query.num_inline == num_matching) {
+MADRONA_UNROLL
+        for (uint32_t a = 0; a < MWHIP_PFOR_MAX_INLINE; a++) {
+            if (a < num_matching) {
+                parallelForTable<ContextT, Fn, ComponentTs...>(
+                    state_mgr, *(TableHdr *)query.tables[a], query.columns[a],
+                    exclusive_world);
+            }
+        }
+        return;
+    }
+
+    // general path: walk the query table
     const uint32_t *query_values = S->queryData + query_offset;
-
-    const int32_t tid = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
-    const int32_t stride = (int32_t)(gridDim.x * blockDim.x);
-
     for (uint32_t a = 0; a < num_matching; a++) {
-        TableHdr &tbl = S->tables[query_values[0]];
-        const int32_t num_rows = tbl.numRows;
-        const WorldID *world_col = (const WorldID *)tbl.columns[1];
-
-        void *cols[N > 0 ? N : 1];
+        uint16_t col_indices[N > 0 ? N : 1];
 MADRONA_UNROLL
         for (size_t c = 0; c < N; c++) {
-            cols[c] = tbl.columns[query_values[1 + c]];
+            col_indices[c] = (uint16_t)query_values[1 + c];
         }
-
-        for (int32_t row = tid; row < num_rows; row += stride) {
-            WorldID world_id = world_col[row];
-            // destroyed but not yet compacted away
-            if (world_id.idx == -1) {
-                continue;
-            }
-
-            ContextT ctx = TaskGraph::makeContext<ContextT>(
-                state_mgr, world_id, exclusive_world);
-            invokeSystemRow<ContextT, Fn, ComponentTs...>(
-                ctx, cols, row, std::make_index_sequence<N>());
-        }
-
+        parallelForTable<ContextT, Fn, ComponentTs...>(
+            state_mgr, S->tables[query_values[0]], col_indices, exclusive_world);
         query_values += 1 + N;
     }
 }
@@ -412,6 +446,7 @@ CustomParallelForNode<ContextT, Fn, threads_per_invocation,
     desc.arg1 = ref->numMatchingArchetypes |
         ((ref->flags & MWHIP_QUERY_ALL_SINGLETON) != 0u ? 0x80000000u : 0u);
     desc.count_mode = MWHIP_COUNT_QUERY_ROWS;
+    desc.wants_pfor_args = items_per_invocation == 1 ? 1u : 0u;
     desc.query_offset = ref->offset;
     desc.num_matching = ref->numMatchingArchetypes;
     desc.threads_per_invocation = (uint32_t)threads_per_invocation;
