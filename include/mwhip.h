@@ -102,6 +102,27 @@ void *mwhip_export_column(mwhip_exec *exec, uint32_t archetype_id,
 int mwhip_make_query(mwhip_exec *exec, const uint32_t *component_ids,
                      uint32_t num_components, uint32_t *offset_out,
                      uint32_t *num_matching_out, uint32_t *flags_out);
+/* Executor-owned device scratch (freed by mwhip_destroy). */
+void *mwhip_alloc_device(mwhip_exec *exec, uint64_t num_bytes, int zero);
+/* Device memory that outlives any executor (asset tables uploaded before the
+ * executor exists: PhysicsLoader, reference src/physics/physics_loader.cpp).
+ * gpu_id selects the device; return nullptr / nonzero on failure. */
+void *mwhip_raw_alloc(int gpu_id, uint64_t num_bytes);
+void mwhip_raw_free(int gpu_id, void *device_ptr);
+int mwhip_raw_copy_h2d(int gpu_id, void *dst_device, const void *src_host,
+                       uint64_t num_bytes);
+int mwhip_raw_copy_d2h(int gpu_id, void *dst_host, const void *src_device,
+                       uint64_t num_bytes);
+/* Small table of module-private device pointers inside ecs_state
+ * (ecs_state::moduleData[slot], slot < 4); e.g. the physics module's scratch. */
+int mwhip_set_module_data(mwhip_exec *exec, uint32_t slot, void *device_ptr);
+/* rows every column of the archetype's table can hold */
+uint32_t mwhip_archetype_capacity(mwhip_exec *exec, uint32_t archetype_id);
+/* device address of the archetype's table header (mwhip::TableHdr) */
+void *mwhip_table_header(mwhip_exec *exec, uint32_t archetype_id);
+/* copies `count` words of the query table starting at `offset` */
+int mwhip_get_query_data(mwhip_exec *exec, uint32_t offset, uint32_t count,
+                         uint32_t *out);
 /* address of the device-resident ecs_state (valid after mwhip_create's
  * register phase) and of per-world user data */
 void *mwhip_device_state(mwhip_exec *exec);
@@ -116,8 +137,24 @@ enum mwhip_node_kind {
     MWHIP_NODE_SORT_ARCHETYPE = 1,/* SortArchetypeNode<A,C> (sort_archetype.cpp) */
     MWHIP_NODE_CLEAR_TMP = 2,     /* ClearTmpNode<A> (taskgraph_utils.cpp:171-190) */
     MWHIP_NODE_RESET_TMP_ALLOC = 3,/* ResetTmpAllocNode (:216-230) */
-    MWHIP_NODE_RECYCLE = 4        /* RecycleEntitiesNode (:192-214); no-op here */
+    MWHIP_NODE_RECYCLE = 4,       /* RecycleEntitiesNode (:192-214); no-op here */
+    /* In-place exclusive prefix sum over up to 8 device arrays treated as one
+     * sequence (node_data = mwhip_scan_params).  Building block of the
+     * deterministic "count -> scan -> fill" emission of temporaries that
+     * replaces arrival-order atomics. */
+    MWHIP_NODE_EXCLUSIVE_SCAN = 5
 };
+
+#define MWHIP_SCAN_MAX_SEGMENTS 8
+typedef struct mwhip_scan_params {
+    uint32_t num_segments;
+    uint32_t capacity;              /* total_out is clamped to this; overflow raises
+                                     * the table-overflow device error */
+    uint32_t *data[MWHIP_SCAN_MAX_SEGMENTS];         /* device, scanned in place */
+    const int32_t *lengths[MWHIP_SCAN_MAX_SEGMENTS]; /* device-resident lengths */
+    int32_t *total_out;             /* device; e.g. a table's row count */
+    uint32_t *needs_sort_out;       /* optional device flag set to 1 if total > 0 */
+} mwhip_scan_params;
 
 enum mwhip_count_mode {
     MWHIP_COUNT_QUERY_ROWS = 0,   /* one invocation per row of the query's tables */

@@ -88,6 +88,170 @@ __global__ void miscOpsKernel(EcsState *S, const MiscOp *ops, uint32_t num_ops)
     }
 }
 
+// ---- exclusive scan over a few device arrays (MWHIP_NODE_EXCLUSIVE_SCAN) ----
+// Single pass, chained through 8-byte {epoch tag | status | value} granules
+// like the sort's look-back (relaxed agent-scope atomics, ticketed tiles).
+constexpr int kScanThreads = 256;
+constexpr int kScanItems = 8;
+constexpr int kScanTile = kScanThreads * kScanItems;
+
+struct ScanState {
+    uint32_t ticket;
+    uint32_t epoch;
+    uint32_t arrivals;
+    uint32_t pad;
+};
+
+struct ScanNode {
+    mwhip_scan_params params;
+    ScanState *state;
+    unsigned long long *granules;
+    uint32_t maxTiles;
+};
+
+__global__ void __launch_bounds__(kScanThreads)
+exclusiveScanKernel(EcsState *S, const ScanNode *node_ptr)
+{
+    const ScanNode &node = *node_ptr;
+    const mwhip_scan_params &p = node.params;
+
+    __shared__ uint32_t lds_tile;
+    __shared__ uint32_t lds_wave[kScanThreads / 64];
+    __shared__ uint32_t lds_prefix;
+
+    // segment layout: tiles never straddle segments
+    int32_t seg_len[MWHIP_SCAN_MAX_SEGMENTS];
+    uint32_t seg_tile_start[MWHIP_SCAN_MAX_SEGMENTS + 1];
+    uint32_t total_tiles = 0;
+    for (uint32_t s = 0; s < MWHIP_SCAN_MAX_SEGMENTS; s++) {
+        int32_t len = s < p.num_segments ? *p.lengths[s] : 0;
+        seg_len[s] = len > 0 ? len : 0;
+        seg_tile_start[s] = total_tiles;
+        total_tiles += (uint32_t)((seg_len[s] + kScanTile - 1) / kScanTile);
+    }
+    seg_tile_start[MWHIP_SCAN_MAX_SEGMENTS] = total_tiles;
+
+    if (threadIdx.x == 0) {
+        lds_tile = atomicAdd(&node.state->ticket, 1u);
+    }
+    __syncthreads();
+    const uint32_t tile = lds_tile;
+    const uint32_t epoch = node.state->epoch;
+    const uint32_t tag = epoch + 1u;
+
+    if (tile < total_tiles) {
+        uint32_t seg = 0;
+        while (seg + 1 < MWHIP_SCAN_MAX_SEGMENTS && tile >= seg_tile_start[seg + 1]) {
+            seg++;
+        }
+        const int32_t base = (int32_t)(tile - seg_tile_start[seg]) * kScanTile;
+        uint32_t *data = p.data[seg];
+        const int32_t len = seg_len[seg];
+
+        // blocked arrangement: thread t owns items [t*8, t*8+8) of the tile
+        uint32_t v[kScanItems];
+        uint32_t thread_sum = 0;
+#pragma unroll
+        for (int j = 0; j < kScanItems; j++) {
+            int32_t i = base + (int32_t)threadIdx.x * kScanItems + j;
+            v[j] = i < len ? data[i] : 0u;
+            thread_sum += v[j];
+        }
+
+        // block exclusive scan of thread sums
+        const uint32_t lane = threadIdx.x & 63u;
+        const uint32_t wave = threadIdx.x >> 6;
+        uint32_t incl = thread_sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t up = __shfl_up(incl, d, 64);
+            if ((int)lane >= d) incl += up;
+        }
+        if (lane == 63) lds_wave[wave] = incl;
+        __syncthreads();
+        uint32_t wave_base = 0, tile_total = 0;
+#pragma unroll
+        for (int w = 0; w < kScanThreads / 64; w++) {
+            uint32_t ws = lds_wave[w];
+            if (w < (int)wave) wave_base += ws;
+            tile_total += ws;
+        }
+
+        // look back for the sum of all earlier tiles
+        if (threadIdx.x == 0) {
+            unsigned long long *g = node.granules;
+            uint32_t exclusive = 0;
+            if (tile == 0) {
+                __hip_atomic_store(&g[0], ((unsigned long long)tag << 32) |
+                    (2ull << 30) | tile_total, __ATOMIC_RELAXED,
+                    __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                __hip_atomic_store(&g[tile], ((unsigned long long)tag << 32) |
+                    (1ull << 30) | tile_total, __ATOMIC_RELAXED,
+                    __HIP_MEMORY_SCOPE_AGENT);
+                int32_t look = (int32_t)tile - 1;
+                uint32_t spins = 0;
+                while (true) {
+                    unsigned long long x = __hip_atomic_load(&g[look],
+                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((uint32_t)(x >> 32) != tag) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > (1u << 26)) {
+                            raiseError(S, kErrSortLookback);
+                            break;
+                        }
+                        continue;
+                    }
+                    exclusive += (uint32_t)(x & ((1ull << 30) - 1ull));
+                    if ((x >> 30) & 2ull) break;
+                    look -= 1;
+                }
+                __hip_atomic_store(&g[tile], ((unsigned long long)tag << 32) |
+                    (2ull << 30) | (unsigned long long)(exclusive + tile_total),
+                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            lds_prefix = exclusive;
+
+            if (tile == total_tiles - 1) {
+                uint32_t total = exclusive + tile_total;
+                if (total > p.capacity) {
+                    raiseError(S, kErrTableOverflow);
+                    total = p.capacity;
+                }
+                *p.total_out = (int32_t)total;
+                if (p.needs_sort_out != nullptr && total > 0) {
+                    *p.needs_sort_out = 1u;
+                }
+            }
+        }
+        __syncthreads();
+
+        uint32_t running = lds_prefix + wave_base + incl - thread_sum;
+#pragma unroll
+        for (int j = 0; j < kScanItems; j++) {
+            int32_t i = base + (int32_t)threadIdx.x * kScanItems + j;
+            if (i < len) {
+                data[i] = running;
+            }
+            running += v[j];
+        }
+    } else if (total_tiles == 0 && tile == 0 && threadIdx.x == 0) {
+        *p.total_out = 0;
+    }
+
+    // last block resets the ticket and advances the epoch for the next launch
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        uint32_t done = atomicAdd(&node.state->arrivals, 1u);
+        if (done == gridDim.x - 1) {
+            node.state->arrivals = 0;
+            node.state->ticket = 0;
+            node.state->epoch = epoch + 1u;
+        }
+    }
+}
+
 // Holds the stream until the host flips a flag in pinned memory, so that a
 // whole step's kernels + timing events can be queued behind it and then run
 // back to back on the device (per-kernel event deltas would otherwise mostly
@@ -502,6 +666,99 @@ extern "C" int mwhip_make_query(mwhip_exec *exec, const uint32_t *component_ids,
     return 0;
 }
 
+extern "C" void *mwhip_raw_alloc(int gpu_id, uint64_t num_bytes)
+{
+    void *ptr = nullptr;
+    if (hipSetDevice(gpu_id) != hipSuccess ||
+            hipMalloc(&ptr, num_bytes == 0 ? 16 : num_bytes) != hipSuccess) {
+        fail(-2, "raw_alloc of %llu bytes on gpu %d failed",
+             (unsigned long long)num_bytes, gpu_id);
+        return nullptr;
+    }
+    return ptr;
+}
+
+extern "C" void mwhip_raw_free(int gpu_id, void *device_ptr)
+{
+    if (device_ptr != nullptr && hipSetDevice(gpu_id) == hipSuccess) {
+        (void)hipFree(device_ptr);
+    }
+}
+
+extern "C" int mwhip_raw_copy_h2d(int gpu_id, void *dst_device,
+                                  const void *src_host, uint64_t num_bytes)
+{
+    HIPCHK(hipSetDevice(gpu_id));
+    if (num_bytes != 0) {
+        HIPCHK(hipMemcpy(dst_device, src_host, num_bytes,
+                         hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+extern "C" int mwhip_raw_copy_d2h(int gpu_id, void *dst_host,
+                                  const void *src_device, uint64_t num_bytes)
+{
+    HIPCHK(hipSetDevice(gpu_id));
+    if (num_bytes != 0) {
+        HIPCHK(hipMemcpy(dst_host, src_device, num_bytes,
+                         hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
+extern "C" void *mwhip_alloc_device(mwhip_exec *exec, uint64_t num_bytes, int zero)
+{
+    void *ptr = nullptr;
+    if (devAlloc(exec, &ptr, num_bytes, zero != 0) != 0) {
+        return nullptr;
+    }
+    return ptr;
+}
+
+extern "C" int mwhip_set_module_data(mwhip_exec *exec, uint32_t slot,
+                                     void *device_ptr)
+{
+    if (slot >= 4) {
+        return fail(-3, "module data slot %u out of range", slot);
+    }
+    exec->hostState.moduleData[slot] = device_ptr;
+    if (exec->stateBuilt) {
+        HIPCHK(hipMemcpy((char *)exec->stateDev +
+            offsetof(EcsState, moduleData) + slot * sizeof(void *), &device_ptr,
+            sizeof(void *), hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+extern "C" uint32_t mwhip_archetype_capacity(mwhip_exec *exec,
+                                             uint32_t archetype_id)
+{
+    if (archetype_id >= exec->archetypes.size() ||
+            !exec->archetypes[archetype_id].registered) {
+        return 0;
+    }
+    return exec->archetypes[archetype_id].capacity;
+}
+
+extern "C" void *mwhip_table_header(mwhip_exec *exec, uint32_t archetype_id)
+{
+    if (!exec->stateBuilt || archetype_id >= exec->archetypes.size()) {
+        return nullptr;
+    }
+    return exec->hostState.tables + archetype_id;
+}
+
+extern "C" int mwhip_get_query_data(mwhip_exec *exec, uint32_t offset,
+                                    uint32_t count, uint32_t *out)
+{
+    if ((size_t)offset + count > exec->queryDataHost.size()) {
+        return fail(-3, "query data range out of bounds");
+    }
+    memcpy(out, exec->queryDataHost.data() + offset, count * sizeof(uint32_t));
+    return 0;
+}
+
 extern "C" void *mwhip_device_state(mwhip_exec *exec) { return exec->stateDev; }
 
 extern "C" void *mwhip_world_data(mwhip_exec *exec, uint32_t world_idx)
@@ -622,6 +879,12 @@ static int buildDeviceState(mwhip_exec *exec)
     if (rc != 0) return rc;
     hs.tmpOffset = 0;
 
+    hs.persistCapacity = (unsigned long long)W *
+        envU32("MADRONA_MWHIP_PERSIST_KB_PER_WORLD", 16) * 1024ull + (1ull << 20);
+    rc = devAlloc(exec, (void **)&hs.persistBase, hs.persistCapacity, false);
+    if (rc != 0) return rc;
+    hs.persistOffset = 0;
+
     hs.idFreeHead = 0xFFFFFFFFull;      // {gen 0, head sentinel}
     hs.numIds = (int32_t)exec->singletonIdEnd;
     hs.initMode = 0;
@@ -713,6 +976,14 @@ static const char *describeError(uint32_t flags)
     }
     if (flags & kErrSortLookback) {
         return "sort look-back timed out";
+    }
+    if (flags & kErrPersistOverflow) {
+        return "persistent world-constructor allocations exhausted (raise "
+               "MADRONA_MWHIP_PERSIST_KB_PER_WORLD)";
+    }
+    if (flags & kErrPhysics) {
+        return "physics capacity exceeded (BVH leaves / traversal stack / "
+               "hull scratch)";
     }
     if (flags & kErrInitBlocks) {
         return "world constructors are not deterministic";
@@ -1006,6 +1277,46 @@ static int buildLaunchList(mwhip_exec *exec, const std::vector<uint32_t> &tg_ids
                 lg.sortBatches.push_back(std::move(batch));
                 oi = oj - 1;
             } break;
+            case MWHIP_NODE_EXCLUSIVE_SCAN: {
+                int rc = flushMisc();
+                if (rc != 0) return rc;
+                if (d.node_data_id < 0) {
+                    return fail(-3, "scan node '%s' without parameters",
+                                node.name.c_str());
+                }
+
+                // node data holds mwhip_scan_params; wrap it with the scan's
+                // own state (ticket / epoch / granules)
+                mwhip_scan_params params;
+                HIPCHK(hipMemcpy(&params, tg.dataDev[d.node_data_id],
+                                 sizeof(params), hipMemcpyDeviceToHost));
+                uint32_t max_tiles = d.fixed_count == 0 ? 1u :
+                    (d.fixed_count + kScanTile - 1) / kScanTile +
+                    MWHIP_SCAN_MAX_SEGMENTS;
+
+                ScanNode host_node {};
+                host_node.params = params;
+                host_node.maxTiles = max_tiles;
+                rc = devAllocT(exec, &host_node.state, 1);
+                if (rc != 0) return rc;
+                rc = devAllocT(exec, &host_node.granules, max_tiles);
+                if (rc != 0) return rc;
+                ScanNode *node_dev;
+                rc = devAllocT(exec, &node_dev, 1);
+                if (rc != 0) return rc;
+                HIPCHK(hipMemcpy(node_dev, &host_node, sizeof(ScanNode),
+                                 hipMemcpyHostToDevice));
+
+                KernelLaunch k;
+                k.fn = (const void *)&exclusiveScanKernel;
+                k.grid = dim3(max_tiles, 1, 1);
+                k.block = dim3(kScanThreads, 1, 1);
+                k.setArgs(exec->stateDev, (const ScanNode *)node_dev);
+                k.name = node.name;
+                k.role = "scan";
+                k.kind = d.kind;
+                lg.launches.push_back(k);
+            } break;
             case MWHIP_NODE_CLEAR_TMP:
                 pending_misc.push_back({ kOpClearTmp, d.archetype_id });
                 break;
@@ -1127,6 +1438,8 @@ static int resetForInitPass(mwhip_exec *exec)
     int rc = pokeState(exec, &EcsState::numIds, (int32_t)exec->singletonIdEnd);
     if (rc != 0) return rc;
     rc = pokeState(exec, &EcsState::tmpOffset, 0ull);
+    if (rc != 0) return rc;
+    rc = pokeState(exec, &EcsState::persistOffset, 0ull);
     if (rc != 0) return rc;
     rc = pokeState(exec, &EcsState::idFreeHead, 0xFFFFFFFFull);
     if (rc != 0) return rc;

@@ -1,0 +1,164 @@
+// Per-world broadphase: a 4-wide BVH over the world's rigid bodies.
+//
+// API contract: reference include/madrona/broadphase.hpp:14-115 +
+// broadphase.inl (LeafID, BVH: reserveLeaf, getLeafAABB, findIntersecting,
+// findLeafIntersecting, updateLeafPosition, expandLeaf, refitLeaf,
+// rebuildOnUpdate, updateTree, clearLeaves).  Behaviour follows
+// src/physics/broadphase.cpp: a top-down midpoint-split build that only runs
+// after PhysicsSystem::reset (:47-285), leaf AABBs inflated by motion
+// (:440-497) and a leaf-to-root refit that only ever grows boxes (:550-647).
+//
+// One BVH per world, stored as a singleton component; its arrays come from the
+// executor's persistent region (rawAlloc).  Refit uses integer atomics on the
+// float bit patterns (order independent => deterministic).
+#pragma once
+
+#include <madrona/components.hpp>
+#include <madrona/context.hpp>
+#include <madrona/math.hpp>
+#include <madrona/memory.hpp>
+
+namespace madrona::phys {
+
+struct ObjectManager;
+
+}
+
+namespace madrona::phys::broadphase {
+
+struct LeafID {
+    int32_t id;
+};
+
+class BVH {
+public:
+    MADRONA_HD inline BVH(const ObjectManager *obj_mgr,
+                          CountT max_leaves,
+                          float leaf_velocity_expansion,
+                          float leaf_accel_expansion);
+
+    MADRONA_HD inline LeafID reserveLeaf(Entity e, base::ObjectID obj_id);
+    MADRONA_HD inline math::AABB getLeafAABB(LeafID leaf_id) const
+    {
+        return leaf_aabbs_[leaf_id.id];
+    }
+
+    template <typename Fn>
+    MADRONA_HD inline void findIntersecting(const math::AABB &aabb,
+                                            Fn &&fn) const;
+
+    template <typename Fn>
+    MADRONA_HD inline void findLeafIntersecting(LeafID leaf_id, Fn &&fn) const
+    {
+        findIntersecting(leaf_aabbs_[leaf_id.id], std::forward<Fn>(fn));
+    }
+
+    MADRONA_HD inline void updateLeafPosition(LeafID leaf_id,
+                                              const math::Vector3 &pos,
+                                              const math::Quat &rot,
+                                              const math::Diag3x3 &scale,
+                                              const math::Vector3 &linear_vel,
+                                              const math::AABB &obj_aabb);
+
+    MADRONA_HD inline math::AABB expandLeaf(LeafID leaf_id,
+                                            const math::Vector3 &linear_vel);
+
+    MADRONA_HD inline void refitLeaf(LeafID leaf_id,
+                                     const math::AABB &leaf_aabb);
+
+    MADRONA_HD inline void rebuildOnUpdate() { force_rebuild_ = true; }
+    MADRONA_HD inline void updateTree();
+
+    MADRONA_HD inline void clearLeaves() { num_leaves_ = 0; }
+
+    MADRONA_HD inline int32_t numLeaves() const { return num_leaves_; }
+
+private:
+    static constexpr int32_t sentinel_ = -1;
+    static constexpr uint32_t leaf_bit_ = 0x80000000u;
+
+    // SoA over the 4 children so one node's child boxes load as 6 x 16 B
+    struct Node {
+        float minX[4];
+        float minY[4];
+        float minZ[4];
+        float maxX[4];
+        float maxY[4];
+        float maxZ[4];
+        int32_t children[4];
+        int32_t parentID;
+
+        MADRONA_HD inline bool isLeaf(CountT c) const
+        {
+            return ((uint32_t)children[c] & leaf_bit_) != 0;
+        }
+
+        MADRONA_HD inline int32_t leafIDX(CountT c) const
+        {
+            return (int32_t)((uint32_t)children[c] & ~leaf_bit_);
+        }
+
+        MADRONA_HD inline void setLeaf(CountT c, int32_t idx)
+        {
+            children[c] = (int32_t)(leaf_bit_ | (uint32_t)idx);
+        }
+
+        MADRONA_HD inline bool hasChild(CountT c) const
+        {
+            return children[c] != sentinel_;
+        }
+
+        MADRONA_HD inline void setBounds(CountT c, const math::AABB &aabb)
+        {
+            minX[c] = aabb.pMin.x; minY[c] = aabb.pMin.y; minZ[c] = aabb.pMin.z;
+            maxX[c] = aabb.pMax.x; maxY[c] = aabb.pMax.y; maxZ[c] = aabb.pMax.z;
+        }
+
+        MADRONA_HD inline math::AABB bounds(CountT c) const
+        {
+            return math::AABB { { minX[c], minY[c], minZ[c] },
+                                { maxX[c], maxY[c], maxZ[c] } };
+        }
+    };
+
+    struct LeafTransform {
+        math::Vector3 pos;
+        math::Quat rot;
+        math::Diag3x3 scale;
+    };
+
+    MADRONA_HD static inline CountT numInternalNodes(CountT num_leaves)
+    {
+        CountT third = utils::divideRoundUp(num_leaves - 1, CountT(3));
+        return (third > 1 ? third : 1) + num_leaves;
+    }
+
+    MADRONA_HD inline math::Vector3 leafCenter(int32_t sorted_idx) const
+    {
+        math::AABB aabb = leaf_aabbs_[sorted_leaves_[sorted_idx]];
+        return (aabb.pMin + aabb.pMax) / 2.f;
+    }
+
+    MADRONA_HD inline int32_t midpointSplit(int32_t base, int32_t num_elems);
+    MADRONA_HD inline void rebuild();
+
+    Node *nodes_;
+    CountT num_nodes_;
+    CountT num_allocated_nodes_;
+    Entity *leaf_entities_;
+    const ObjectManager *obj_mgr_;
+    base::ObjectID *leaf_obj_ids_;
+    math::AABB *leaf_aabbs_;
+    LeafTransform *leaf_transforms_;
+    uint32_t *leaf_parents_;
+    int32_t *sorted_leaves_;
+    int32_t num_leaves_;
+    int32_t num_allocated_leaves_;
+    float leaf_velocity_expansion_;
+    float leaf_accel_expansion_;
+    bool force_rebuild_;
+};
+
+}
+
+#include "broadphase.inl"

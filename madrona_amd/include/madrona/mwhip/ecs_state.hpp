@@ -53,6 +53,8 @@ enum ErrorFlags : uint32_t {
     kErrTmpOverflow = 1u << 2,
     kErrInitBlocks = 1u << 3,
     kErrSortLookback = 1u << 4,
+    kErrPersistOverflow = 1u << 5,
+    kErrPhysics = 1u << 6,
 };
 
 struct TableHdr {
@@ -111,9 +113,14 @@ struct EcsState {
     int32_t *initBlockBase;         // [numWorlds] first id of world's init blocks (pass 2)
     char *worldData;
     char *tmpBase;
+    // never-freed allocations made by world constructors (e.g. the physics
+    // BVH arrays; reference: device malloc heap, src/mw/cuda_exec.cpp:267-285)
+    char *persistBase;
 
     unsigned long long tmpCapacity;
     unsigned long long tmpOffset;   // bump pointer
+    unsigned long long persistCapacity;
+    unsigned long long persistOffset;
     unsigned long long idFreeHead;  // {gen:32 | head:32} global list of returned blocks
 
     uint32_t numArchetypeSlots;
@@ -128,7 +135,7 @@ struct EcsState {
     void *hostExec;                 // host mirror only: owning mwhip_exec*
     int32_t runtimeIdBase;          // first id of the post-init block partition
     int32_t pad_;
-    uint64_t reserved_[1];
+    void *moduleData[4];            // module-private device pointers (physics scratch, ...)
 };
 
 #if defined(__HIPCC__)
@@ -324,6 +331,19 @@ MWHIP_DEV inline void releaseIdLocked(EcsState *S, IdCache &cache, int32_t id)
         cache.overflowHead = kIdSentinel;
         cache.numOverflow = 0;
     }
+}
+
+// 16-byte aligned persistent allocation (world constructors only).
+MWHIP_DEV inline void *persistAlloc(EcsState *S, unsigned long long num_bytes)
+{
+    num_bytes = (num_bytes + 15ull) & ~15ull;
+    unsigned long long off = __hip_atomic_fetch_add(&S->persistOffset, num_bytes,
+        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (off + num_bytes > S->persistCapacity) {
+        raiseError(S, kErrPersistOverflow);
+        return S->persistBase;
+    }
+    return S->persistBase + off;
 }
 
 // ---- rows --------------------------------------------------------------------

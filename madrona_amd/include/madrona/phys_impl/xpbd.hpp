@@ -1,0 +1,777 @@
+// XPBD rigid-body solver math (Mueller et al., "Detailed Rigid Body Simulation
+// with Extended Position Based Dynamics"): substep integration, positional
+// contact + static friction, joints, velocity update, restitution and dynamic
+// friction.  Pure functions over plain values (host + device) so they can be
+// checked on the CPU; the ECS-facing kernels are in physics.inl.
+//
+// Numerics follow the reference solver step for step (src/physics/xpbd.cpp:
+// integration :100-185, positional updates :206-275, contacts :304-550, joints
+// :552-718, velocities :738-779, restitution / friction :781-1039) so that
+// fp32 state equals the CPU oracle's under -ffp-contract=off.
+#pragma once
+
+#include <madrona/math.hpp>
+#include <madrona/physics.hpp>
+
+namespace madrona::phys::xpbd {
+
+using math::Vector3;
+using math::Vector4;
+using math::Quat;
+
+struct XPBDContactState {
+    float lambdaN[4];
+};
+
+struct SubstepPrevState {
+    math::Vector3 prevPosition;
+    math::Quat prevRotation;
+};
+
+struct PreSolvePositional {
+    math::Vector3 x;
+    math::Quat q;
+};
+
+struct PreSolveVelocity {
+    math::Vector3 v;
+    math::Vector3 omega;
+};
+
+struct Contact : Archetype<ContactConstraint, XPBDContactState> {};
+struct Joint : Archetype<JointConstraint> {};
+
+struct XPBDRigidBodyState : Bundle<
+    SubstepPrevState,
+    PreSolvePositional,
+    PreSolveVelocity
+> {};
+
+namespace XPBDCols {
+    constexpr inline CountT SubstepPrevState = RGDCols::SolverBase;
+    constexpr inline CountT PreSolvePositional = RGDCols::SolverBase + 1;
+    constexpr inline CountT PreSolveVelocity = RGDCols::SolverBase + 2;
+}
+
+// Everything the solver reads / writes for one body, gathered once.
+struct BodyState {
+    Vector3 x;
+    Quat q;
+    float invMass;
+    Vector3 invInertia;
+};
+
+MADRONA_HD inline Vector3 multDiag(Vector3 diag, Vector3 v)
+{
+    return Vector3 { diag.x * v.x, diag.y * v.y, diag.z * v.z };
+}
+
+// ---------------------------------------------------------------------------
+// integration
+// ---------------------------------------------------------------------------
+struct SubstepResult {
+    Vector3 x;
+    Quat q;
+    Vector3 v;
+    Vector3 omega;
+};
+
+// semi-implicit Euler with the gyroscopic term in the body frame
+MADRONA_HD inline SubstepResult integrateBody(Vector3 x, Quat q, Vector3 v,
+                                              Vector3 omega, float inv_m,
+                                              Vector3 inv_I, Vector3 ext_force,
+                                              Vector3 ext_torque, Vector3 gravity,
+                                              float h, bool apply_gravity)
+{
+    if (apply_gravity) {
+        v += h * gravity;
+    }
+
+    v += h * inv_m * ext_force;
+    x += h * v;
+
+    Vector3 I {
+        (inv_I.x == 0) ? 0.0f : 1.0f / inv_I.x,
+        (inv_I.y == 0) ? 0.0f : 1.0f / inv_I.y,
+        (inv_I.z == 0) ? 0.0f : 1.0f / inv_I.z,
+    };
+
+    Quat to_local = q.inv();
+
+    Vector3 tau_ext_local = to_local.rotateVec(ext_torque);
+    Vector3 omega_local = to_local.rotateVec(omega);
+
+    Vector3 I_omega_local = multDiag(I, omega_local);
+
+    omega_local += h * multDiag(inv_I,
+        tau_ext_local - (cross(omega_local, I_omega_local)));
+
+    omega = q.rotateVec(omega_local);
+
+    Quat apply_omega = Quat::fromAngularVec(0.5f * h * omega);
+    q += apply_omega * q;
+    q = q.normalize();
+
+    return SubstepResult { x, q, v, omega };
+}
+
+// ---------------------------------------------------------------------------
+// positional constraints
+// ---------------------------------------------------------------------------
+MADRONA_HD inline float generalizedInverseMass(Vector3 torque_axis,
+                                               Vector3 rot_axis, float inv_m)
+{
+    return inv_m + dot(torque_axis, rot_axis);
+}
+
+MADRONA_HD inline float computePositionalLambda(
+    Vector3 torque_axis1, Vector3 torque_axis2,
+    Vector3 rot_axis1, Vector3 rot_axis2,
+    float inv_m1, float inv_m2, float c, float alpha_tilde)
+{
+    float w1 = generalizedInverseMass(torque_axis1, rot_axis1, inv_m1);
+    float w2 = generalizedInverseMass(torque_axis2, rot_axis2, inv_m2);
+    return -c / (w1 + w2 + alpha_tilde);
+}
+
+MADRONA_HD inline void applyPositionalImpulse(
+    Vector3 &x1, Vector3 &x2, Quat &q1, Quat &q2,
+    Vector3 rot_axis_local1, Vector3 rot_axis_local2,
+    float inv_m1, float inv_m2, Vector3 n, float delta_lambda)
+{
+    x1 += delta_lambda * inv_m1 * n;
+    x2 -= delta_lambda * inv_m2 * n;
+
+    float half_lambda = 0.5f * delta_lambda;
+
+    Vector3 q1_update_angular = q1.rotateVec(half_lambda * rot_axis_local1);
+    Vector3 q2_update_angular = q2.rotateVec(half_lambda * rot_axis_local2);
+
+    q1 += Quat::fromAngularVec(q1_update_angular) * q1;
+    q2 -= Quat::fromAngularVec(q2_update_angular) * q2;
+
+    q1 = q1.normalize();
+    q2 = q2.normalize();
+}
+
+// distance constraint of magnitude c along n_world at body-local anchors r1, r2
+MADRONA_HD inline float applyPositionalUpdate(
+    Vector3 &x1, Vector3 &x2, Quat &q1, Quat &q2,
+    Vector3 r1, Vector3 r2, float inv_m1, float inv_m2,
+    Vector3 inv_I1, Vector3 inv_I2, Vector3 n_world,
+    float c, float alpha_tilde)
+{
+    Vector3 n_local1 = q1.inv().rotateVec(n_world);
+    Vector3 n_local2 = q2.inv().rotateVec(n_world);
+
+    Vector3 torque_axis_local1 = cross(r1, n_local1);
+    Vector3 torque_axis_local2 = cross(r2, n_local2);
+
+    Vector3 rot_axis_local1 = multDiag(inv_I1, torque_axis_local1);
+    Vector3 rot_axis_local2 = multDiag(inv_I2, torque_axis_local2);
+
+    float lambda = computePositionalLambda(
+        torque_axis_local1, torque_axis_local2,
+        rot_axis_local1, rot_axis_local2,
+        inv_m1, inv_m2, c, alpha_tilde);
+
+    applyPositionalImpulse(x1, x2, q1, q2, rot_axis_local1, rot_axis_local2,
+                           inv_m1, inv_m2, n_world, lambda);
+
+    return lambda;
+}
+
+struct AngularUpdate {
+    Quat q1;
+    Quat q2;
+};
+
+MADRONA_HD inline AngularUpdate computeAngularUpdate(
+    Quat q1, Quat q2, Vector3 inv_I1, Vector3 inv_I2,
+    Vector3 n1, Vector3 n2, float theta, float alpha_tilde)
+{
+    Vector3 local_rot_axis1 = multDiag(inv_I1, n1);
+    Vector3 local_rot_axis2 = multDiag(inv_I2, n2);
+
+    float w1 = dot(n1, local_rot_axis1);
+    float w2 = dot(n2, local_rot_axis2);
+
+    float delta_lambda = -theta / (w1 + w2 + alpha_tilde);
+    float half_lambda = 0.5f * delta_lambda;
+
+    return AngularUpdate {
+        Quat::fromAngularVec(q1.rotateVec(half_lambda * local_rot_axis1)),
+        Quat::fromAngularVec(q2.rotateVec(half_lambda * local_rot_axis2)),
+    };
+}
+
+MADRONA_HD inline void applyAngularUpdate(Quat &q1, Quat &q2, AngularUpdate u)
+{
+    q1 = (q1 + u.q1 * q1).normalize();
+    q2 = (q2 - u.q2 * q2).normalize();
+}
+
+// ---------------------------------------------------------------------------
+// contacts
+// ---------------------------------------------------------------------------
+// non-penetration along n_world, then static friction on the tangential drift
+MADRONA_HD inline void solveContactPoint(
+    Vector3 &x1, Vector3 &x2, Quat &q1, Quat &q2,
+    SubstepPrevState prev1, SubstepPrevState prev2,
+    float inv_m1, float inv_m2, Vector3 inv_I1, Vector3 inv_I2,
+    Vector3 r1, Vector3 r2, Vector3 n_world, float avg_mu_s,
+    float *lambda_n_out, float *lambda_t_out)
+{
+    Vector3 p1 = q1.rotateVec(r1) + x1;
+    Vector3 p2 = q2.rotateVec(r2) + x2;
+
+    float d = dot(p1 - p2, n_world);
+    if (d <= 0) {
+        return;
+    }
+
+    float lambda_n = applyPositionalUpdate(
+        x1, x2, q1, q2, r1, r2, inv_m1, inv_m2, inv_I1, inv_I2, n_world, d, 0);
+    *lambda_n_out = lambda_n;
+
+    Vector3 p1_hat = prev1.prevRotation.rotateVec(r1) + prev1.prevPosition;
+    Vector3 p2_hat = prev2.prevRotation.rotateVec(r2) + prev2.prevPosition;
+
+    // re-evaluate after the normal correction so friction absorbs its drift
+    p1 = q1.rotateVec(r1) + x1;
+    p2 = q2.rotateVec(r2) + x2;
+
+    Vector3 delta_p = (p1 - p1_hat) - (p2 - p2_hat);
+    Vector3 delta_p_t = delta_p - dot(delta_p, n_world) * n_world;
+
+    float tangential_magnitude = delta_p_t.length();
+    if (tangential_magnitude > 0.f) {
+        Vector3 t_world = delta_p_t / tangential_magnitude;
+        Vector3 t_local1 = q1.inv().rotateVec(t_world);
+        Vector3 t_local2 = q2.inv().rotateVec(t_world);
+
+        Vector3 friction_torque_axis_local1 = cross(r1, t_local1);
+        Vector3 friction_torque_axis_local2 = cross(r2, t_local2);
+
+        Vector3 friction_rot_axis_local1 =
+            multDiag(inv_I1, friction_torque_axis_local1);
+        Vector3 friction_rot_axis_local2 =
+            multDiag(inv_I2, friction_torque_axis_local2);
+
+        float lambda_t = computePositionalLambda(
+            friction_torque_axis_local1, friction_torque_axis_local2,
+            friction_rot_axis_local1, friction_rot_axis_local2,
+            inv_m1, inv_m2, tangential_magnitude, 0);
+        float lambda_threshold = lambda_n * avg_mu_s;
+
+        if (lambda_t > lambda_threshold) {
+            *lambda_t_out = lambda_t;
+
+            applyPositionalImpulse(
+                x1, x2, q1, q2,
+                friction_rot_axis_local1, friction_rot_axis_local2,
+                inv_m1, inv_m2, t_world, lambda_t);
+        }
+    }
+}
+
+struct LocalContacts {
+    Vector3 r1;
+    Vector3 r2;
+};
+
+MADRONA_HD inline LocalContacts getLocalSpaceContacts(
+    const PreSolvePositional &presolve_pos1,
+    const PreSolvePositional &presolve_pos2,
+    Vector3 contact1, float penetration_depth, Vector3 contact_normal)
+{
+    Vector3 contact2 = contact1 - contact_normal * penetration_depth;
+
+    return LocalContacts {
+        presolve_pos1.q.inv().rotateVec(contact1 - presolve_pos1.x),
+        presolve_pos2.q.inv().rotateVec(contact2 - presolve_pos2.x),
+    };
+}
+
+// depth-weighted average of the manifold; true when all depths are zero
+MADRONA_HD inline bool getAvgContact(const ContactConstraint &contact,
+                                     Vector3 *avg_out, float *penetration_out)
+{
+    Vector3 avg_contact = Vector3::zero();
+
+    float max_penetration = -FLT_MAX;
+    float penetration_sum = 0.f;
+    for (CountT i = 0; i < contact.numPoints; i++) {
+        Vector4 pt = contact.points[i];
+        if (pt.w > max_penetration) {
+            max_penetration = pt.w;
+        }
+        penetration_sum += pt.w;
+    }
+
+    if (penetration_sum == 0.f) {
+        return true;
+    }
+
+    for (CountT i = 0; i < contact.numPoints; i++) {
+        Vector4 pt = contact.points[i];
+        avg_contact += pt.w / penetration_sum * pt.xyz();
+    }
+
+    *avg_out = avg_contact;
+    *penetration_out = max_penetration;
+    return false;
+}
+
+// ---------------------------------------------------------------------------
+// joints
+// ---------------------------------------------------------------------------
+MADRONA_HD inline void applyJointOrientationConstraint(
+    Quat &q1, Quat &q2, Quat attach_q1, Quat attach_q2,
+    Vector3 inv_I1, Vector3 inv_I2)
+{
+    Quat orientation1 = (q1 * attach_q1).normalize();
+    Quat orientation2 = (q2 * attach_q2).normalize();
+
+    Quat diff = orientation1 * orientation2.inv();
+
+    Vector3 delta_q = 2.f * Vector3 { diff.x, diff.y, diff.z };
+    float delta_q_magnitude = delta_q.length();
+
+    if (delta_q_magnitude > 0) {
+        delta_q /= delta_q_magnitude;
+        Vector3 delta_q_local1 = q1.inv().rotateVec(delta_q);
+        Vector3 delta_q_local2 = q2.inv().rotateVec(delta_q);
+
+        applyAngularUpdate(q1, q2, computeAngularUpdate(
+            q1, q2, inv_I1, inv_I2, delta_q_local1, delta_q_local2,
+            delta_q_magnitude, 0));
+    }
+}
+
+MADRONA_HD inline void applyJointAxisConstraint(
+    Quat &q1, Quat &q2, Vector3 axis1_local, Vector3 axis2_local,
+    Vector3 inv_I1, Vector3 inv_I2)
+{
+    Vector3 axis1 = q1.rotateVec(axis1_local);
+    Vector3 axis2 = q2.rotateVec(axis2_local);
+
+    Vector3 delta_q = cross(axis1, axis2);
+    float delta_q_magnitude = delta_q.length();
+
+    if (delta_q_magnitude > 0) {
+        delta_q /= delta_q_magnitude;
+        Vector3 delta_q_local1 = q1.inv().rotateVec(delta_q);
+        Vector3 delta_q_local2 = q2.inv().rotateVec(delta_q);
+
+        applyAngularUpdate(q1, q2, computeAngularUpdate(
+            q1, q2, inv_I1, inv_I2, delta_q_local1, delta_q_local2,
+            delta_q_magnitude, 0));
+    }
+}
+
+MADRONA_HD inline void solveJoint(const JointConstraint &joint,
+                                  Vector3 &x1, Vector3 &x2, Quat &q1, Quat &q2,
+                                  float inv_m1, float inv_m2,
+                                  Vector3 inv_I1, Vector3 inv_I2)
+{
+    Vector3 pos_correction;
+    if (joint.type == JointConstraint::Type::Fixed) {
+        JointConstraint::Fixed fixed_data = joint.fixed;
+
+        applyJointOrientationConstraint(
+            q1, q2, fixed_data.attachRot1, fixed_data.attachRot2,
+            inv_I1, inv_I2);
+
+        Vector3 r1_world = q1.rotateVec(joint.r1) + x1;
+        Vector3 r2_world = q2.rotateVec(joint.r2) + x2;
+        Vector3 delta_r = r2_world - r1_world;
+
+        Quat axes_rot = (q1 * fixed_data.attachRot1).normalize();
+
+        Vector3 a1 = axes_rot.rotateVec(math::fwd);
+        Vector3 b1 = axes_rot.rotateVec(math::right);
+        Vector3 c1 = cross(a1, b1);
+
+        // fixed separation along a1, none along the other two axes
+        pos_correction = Vector3::zero();
+        float a_separation = dot(delta_r, a1);
+        pos_correction -= (a_separation - fixed_data.separation) * a1;
+        float b_separation = dot(delta_r, b1);
+        pos_correction -= b_separation * b1;
+        float c_separation = dot(delta_r, c1);
+        pos_correction -= c_separation * c1;
+    } else {
+        JointConstraint::Hinge hinge_data = joint.hinge;
+
+        applyJointAxisConstraint(q1, q2, hinge_data.a1Local,
+                                 hinge_data.a2Local, inv_I1, inv_I2);
+
+        Vector3 r1_world = q1.rotateVec(joint.r1) + x1;
+        Vector3 r2_world = q2.rotateVec(joint.r2) + x2;
+
+        pos_correction = r2_world - r1_world;
+    }
+
+    float pos_correction_magnitude = pos_correction.length();
+    if (pos_correction_magnitude > 0.f) {
+        pos_correction /= pos_correction_magnitude;
+
+        applyPositionalUpdate(
+            x1, x2, q1, q2, joint.r1, joint.r2, inv_m1, inv_m2,
+            inv_I1, inv_I2, pos_correction, pos_correction_magnitude, 0);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// velocities
+// ---------------------------------------------------------------------------
+MADRONA_HD inline Velocity deriveVelocity(Vector3 x, Quat q,
+                                          const SubstepPrevState &prev_state,
+                                          float h)
+{
+    Vector3 x_prev = prev_state.prevPosition;
+    Quat q_prev = prev_state.prevRotation;
+
+    // identical rotations must give exactly zero angular velocity
+    Quat delta_q;
+    if (q.w != q_prev.w || q.x != q_prev.x ||
+            q.y != q_prev.y || q.z != q_prev.z) {
+        delta_q = q * q_prev.inv();
+    } else {
+        delta_q = Quat { 1, 0, 0, 0 };
+    }
+
+    Vector3 new_omega = 2.f / h * Vector3 { delta_q.x, delta_q.y, delta_q.z };
+
+    return Velocity {
+        (x - x_prev) / h,
+        delta_q.w > 0.f ? new_omega : -new_omega,
+    };
+}
+
+MADRONA_HD inline Vector3 computeRelativeVelocity(
+    Vector3 v1, Vector3 v2, Vector3 omega1, Vector3 omega2,
+    Vector3 dir1, Vector3 dir2)
+{
+    return (v1 + cross(omega1, dir1)) - (v2 + cross(omega2, dir2));
+}
+
+MADRONA_HD inline void applyFrictionVelocityUpdate(
+    Vector3 &v1, Vector3 &v2, Vector3 &omega1, Vector3 &omega2,
+    Quat q1, Quat q2, float inv_m1, float inv_m2,
+    Vector3 inv_I1, Vector3 inv_I2, Vector3 n, float mu_d, float h,
+    Vector3 r1_local, Vector3 r2_local, Vector3 r1_world, Vector3 r2_world,
+    float lambda)
+{
+    Vector3 v = computeRelativeVelocity(
+        v1, v2, omega1, omega2, r1_world, r2_world);
+
+    float vn = dot(n, v);
+    Vector3 vt = v - n * vn;
+
+    float vt_len = vt.length();
+    if (vt_len == 0.f) {
+        return;
+    }
+
+    Vector3 delta_world = vt / vt_len;
+
+    Vector3 delta_local1 = q1.inv().rotateVec(delta_world);
+    Vector3 delta_local2 = q2.inv().rotateVec(delta_world);
+
+    Vector3 friction_torque_axis_local1 = cross(r1_local, delta_local1);
+    Vector3 friction_torque_axis_local2 = cross(r2_local, delta_local2);
+
+    Vector3 friction_rot_axis_local1 =
+        multDiag(inv_I1, friction_torque_axis_local1);
+    Vector3 friction_rot_axis_local2 =
+        multDiag(inv_I2, friction_torque_axis_local2);
+
+    float w1 = generalizedInverseMass(
+        friction_torque_axis_local1, friction_rot_axis_local1, inv_m1);
+    float w2 = generalizedInverseMass(
+        friction_torque_axis_local2, friction_rot_axis_local2, inv_m2);
+
+    float inv_mass_scale = 1.f / (w1 + w2);
+
+    float dynamic_friction_magnitude =
+        mu_d * fabsf(lambda) * inv_mass_scale / h;
+
+    float corrected_magnitude = -fminf(dynamic_friction_magnitude, vt_len);
+
+    float impulse_magnitude = corrected_magnitude * inv_mass_scale;
+    if (impulse_magnitude == 0.f) {
+        return;
+    }
+
+    v1 += delta_world * impulse_magnitude * inv_m1;
+    v2 -= delta_world * impulse_magnitude * inv_m2;
+
+    omega1 += q1.rotateVec(impulse_magnitude * friction_rot_axis_local1);
+    omega2 -= q2.rotateVec(impulse_magnitude * friction_rot_axis_local2);
+}
+
+MADRONA_HD inline void applyRestitutionVelocityUpdate(
+    Vector3 &v1, Vector3 &v2, Vector3 &omega1, Vector3 &omega2,
+    Quat q1, Quat q2, float inv_m1, float inv_m2,
+    Vector3 inv_I1, Vector3 inv_I2, Vector3 n, float restitution_threshold,
+    Vector3 r1_world, Vector3 r2_world,
+    Vector3 restitution_torque_axis_local1,
+    Vector3 restitution_torque_axis_local2, float vn_bar)
+{
+    Vector3 v = computeRelativeVelocity(
+        v1, v2, omega1, omega2, r1_world, r2_world);
+
+    float vn = dot(n, v);
+
+    float e = 0.3f;     // fixed restitution coefficient, as in the reference
+    if (fabsf(vn_bar) <= restitution_threshold) {
+        e = 0.f;
+    }
+
+    float restitution_magnitude = fminf(-e * vn_bar, 0) - vn;
+
+    Vector3 restitution_rot_axis_local1 =
+        multDiag(inv_I1, restitution_torque_axis_local1);
+    Vector3 restitution_rot_axis_local2 =
+        multDiag(inv_I2, restitution_torque_axis_local2);
+
+    float w1 = generalizedInverseMass(
+        restitution_torque_axis_local1, restitution_rot_axis_local1, inv_m1);
+    float w2 = generalizedInverseMass(
+        restitution_torque_axis_local2, restitution_rot_axis_local2, inv_m2);
+
+    float inv_mass_scale = 1.f / (w1 + w2);
+
+    float impulse_magnitude = restitution_magnitude * inv_mass_scale;
+    if (impulse_magnitude == 0.f) {
+        return;
+    }
+
+    v1 += n * impulse_magnitude * inv_m1;
+    v2 -= n * impulse_magnitude * inv_m2;
+
+    omega1 += q1.rotateVec(impulse_magnitude * restitution_rot_axis_local1);
+    omega2 -= q2.rotateVec(impulse_magnitude * restitution_rot_axis_local2);
+}
+
+// ---------------------------------------------------------------------------
+// ECS-facing wrappers: gather body state through Loc, solve, scatter back
+// (reference xpbd.cpp handleContact :454-548, handleJointConstraint :607-718,
+// solveVelocitiesForContact :918-1036)
+// ---------------------------------------------------------------------------
+struct BodyConstants {
+    float invMass;
+    Vector3 invInertia;
+    RigidBodyFrictionData friction;
+};
+
+MADRONA_HD inline BodyConstants bodyConstants(Context &ctx,
+                                              const ObjectManager &obj_mgr,
+                                              Loc loc)
+{
+    base::ObjectID obj_id =
+        ctx.getDirect<base::ObjectID>(RGDCols::ObjectID, loc);
+    ResponseType resp_type =
+        ctx.getDirect<ResponseType>(RGDCols::ResponseType, loc);
+
+    RigidBodyMetadata metadata = obj_mgr.metadata[obj_id.idx];
+
+    BodyConstants c {
+        metadata.mass.invMass,
+        metadata.mass.invInertiaTensor,
+        metadata.friction,
+    };
+
+    if (resp_type == ResponseType::Static) {
+        c.invMass = 0.f;
+        c.invInertia = Vector3::zero();
+    }
+
+    return c;
+}
+
+MADRONA_HD inline void handleContact(Context &ctx,
+                                     const ObjectManager &obj_mgr,
+                                     const ContactConstraint &contact,
+                                     float *lambdas)
+{
+    base::Position *x1_ptr =
+        &ctx.getDirect<base::Position>(RGDCols::Position, contact.ref);
+    base::Position *x2_ptr =
+        &ctx.getDirect<base::Position>(RGDCols::Position, contact.alt);
+    base::Rotation *q1_ptr =
+        &ctx.getDirect<base::Rotation>(RGDCols::Rotation, contact.ref);
+    base::Rotation *q2_ptr =
+        &ctx.getDirect<base::Rotation>(RGDCols::Rotation, contact.alt);
+
+    SubstepPrevState prev1 = ctx.getDirect<SubstepPrevState>(
+        XPBDCols::SubstepPrevState, contact.ref);
+    SubstepPrevState prev2 = ctx.getDirect<SubstepPrevState>(
+        XPBDCols::SubstepPrevState, contact.alt);
+
+    PreSolvePositional presolve_pos1 = ctx.getDirect<PreSolvePositional>(
+        XPBDCols::PreSolvePositional, contact.ref);
+    PreSolvePositional presolve_pos2 = ctx.getDirect<PreSolvePositional>(
+        XPBDCols::PreSolvePositional, contact.alt);
+
+    BodyConstants c1 = bodyConstants(ctx, obj_mgr, contact.ref);
+    BodyConstants c2 = bodyConstants(ctx, obj_mgr, contact.alt);
+
+    Vector3 x1 = *x1_ptr;
+    Vector3 x2 = *x2_ptr;
+    Quat q1 = *q1_ptr;
+    Quat q2 = *q2_ptr;
+
+    float avg_mu_s = 0.5f * (c1.friction.muS + c2.friction.muS);
+
+    Vector3 avg_contact_pos;
+    float contact_pos_penetration;
+    if (getAvgContact(contact, &avg_contact_pos, &contact_pos_penetration)) {
+        return;
+    }
+
+    LocalContacts local = getLocalSpaceContacts(
+        presolve_pos1, presolve_pos2, avg_contact_pos,
+        contact_pos_penetration, contact.normal);
+
+    float lambda_n = 0.f;
+    float lambda_t = 0.f;
+
+    solveContactPoint(x1, x2, q1, q2, prev1, prev2,
+                      c1.invMass, c2.invMass, c1.invInertia, c2.invInertia,
+                      local.r1, local.r2, contact.normal, avg_mu_s,
+                      &lambda_n, &lambda_t);
+
+    lambdas[0] = lambda_n;
+
+    *x1_ptr = x1;
+    *x2_ptr = x2;
+    *q1_ptr = q1;
+    *q2_ptr = q2;
+}
+
+MADRONA_HD inline void handleJointConstraint(Context &ctx,
+                                             const ObjectManager &obj_mgr,
+                                             const JointConstraint &joint)
+{
+    Loc l1 = ctx.loc(joint.e1);
+    Loc l2 = ctx.loc(joint.e2);
+
+    Vector3 *x1_ptr = &ctx.getDirect<base::Position>(RGDCols::Position, l1);
+    Vector3 *x2_ptr = &ctx.getDirect<base::Position>(RGDCols::Position, l2);
+    Quat *q1_ptr = &ctx.getDirect<base::Rotation>(RGDCols::Rotation, l1);
+    Quat *q2_ptr = &ctx.getDirect<base::Rotation>(RGDCols::Rotation, l2);
+
+    Vector3 x1 = *x1_ptr;
+    Vector3 x2 = *x2_ptr;
+    Quat q1 = *q1_ptr;
+    Quat q2 = *q2_ptr;
+
+    BodyConstants c1 = bodyConstants(ctx, obj_mgr, l1);
+    BodyConstants c2 = bodyConstants(ctx, obj_mgr, l2);
+
+    solveJoint(joint, x1, x2, q1, q2, c1.invMass, c2.invMass,
+               c1.invInertia, c2.invInertia);
+
+    *x1_ptr = x1;
+    *x2_ptr = x2;
+    *q1_ptr = q1;
+    *q2_ptr = q2;
+}
+
+MADRONA_HD inline void solveVelocitiesForContact(
+    Context &ctx, const ObjectManager &obj_mgr,
+    const ContactConstraint &contact, const float *lambda_n,
+    float h, float restitution_threshold)
+{
+    Velocity *v1_out = &ctx.getDirect<Velocity>(RGDCols::Velocity, contact.ref);
+    Velocity *v2_out = &ctx.getDirect<Velocity>(RGDCols::Velocity, contact.alt);
+
+    Quat q1 = ctx.getDirect<base::Rotation>(RGDCols::Rotation, contact.ref);
+    Quat q2 = ctx.getDirect<base::Rotation>(RGDCols::Rotation, contact.alt);
+
+    PreSolvePositional presolve_pos1 = ctx.getDirect<PreSolvePositional>(
+        XPBDCols::PreSolvePositional, contact.ref);
+    PreSolvePositional presolve_pos2 = ctx.getDirect<PreSolvePositional>(
+        XPBDCols::PreSolvePositional, contact.alt);
+
+    PreSolveVelocity presolve_vel1 = ctx.getDirect<PreSolveVelocity>(
+        XPBDCols::PreSolveVelocity, contact.ref);
+    PreSolveVelocity presolve_vel2 = ctx.getDirect<PreSolveVelocity>(
+        XPBDCols::PreSolveVelocity, contact.alt);
+
+    BodyConstants c1 = bodyConstants(ctx, obj_mgr, contact.ref);
+    BodyConstants c2 = bodyConstants(ctx, obj_mgr, contact.alt);
+
+    Vector3 v1 = v1_out->linear;
+    Vector3 omega1 = v1_out->angular;
+    Vector3 v2 = v2_out->linear;
+    Vector3 omega2 = v2_out->angular;
+
+    float mu_d = 0.5f * (c1.friction.muD + c2.friction.muD);
+
+    {
+        Vector3 avg_contact_pos;
+        float contact_pos_penetration;
+        if (getAvgContact(contact, &avg_contact_pos,
+                          &contact_pos_penetration)) {
+            return;
+        }
+
+        LocalContacts local = getLocalSpaceContacts(
+            presolve_pos1, presolve_pos2, avg_contact_pos,
+            contact_pos_penetration, contact.normal);
+
+        Vector3 r1_presolve = presolve_pos1.q.rotateVec(local.r1);
+        Vector3 r2_presolve = presolve_pos2.q.rotateVec(local.r2);
+
+        Vector3 v_bar = computeRelativeVelocity(
+            presolve_vel1.v, presolve_vel2.v,
+            presolve_vel1.omega, presolve_vel2.omega,
+            r1_presolve, r2_presolve);
+
+        float vn_bar = dot(contact.normal, v_bar);
+
+        Vector3 r1_world = q1.rotateVec(local.r1);
+        Vector3 r2_world = q2.rotateVec(local.r2);
+
+        Vector3 restitution_torque_axis_local1 =
+            cross(local.r1, q1.inv().rotateVec(contact.normal));
+        Vector3 restitution_torque_axis_local2 =
+            cross(local.r2, q2.inv().rotateVec(contact.normal));
+
+        applyRestitutionVelocityUpdate(
+            v1, v2, omega1, omega2, q1, q2, c1.invMass, c2.invMass,
+            c1.invInertia, c2.invInertia, contact.normal,
+            restitution_threshold, r1_world, r2_world,
+            restitution_torque_axis_local1, restitution_torque_axis_local2,
+            vn_bar);
+    }
+
+    float penetration_sum = 0.f;
+    for (CountT i = 0; i < contact.numPoints; i++) {
+        penetration_sum += contact.points[i].w;
+    }
+
+    for (CountT i = 0; i < contact.numPoints; i++) {
+        LocalContacts local = getLocalSpaceContacts(
+            presolve_pos1, presolve_pos2, contact.points[i].xyz(),
+            contact.points[i].w, contact.normal);
+
+        Vector3 r1_world = q1.rotateVec(local.r1);
+        Vector3 r2_world = q2.rotateVec(local.r2);
+
+        applyFrictionVelocityUpdate(
+            v1, v2, omega1, omega2, q1, q2, c1.invMass, c2.invMass,
+            c1.invInertia, c2.invInertia, contact.normal, mu_d, h,
+            local.r1, local.r2, r1_world, r2_world,
+            lambda_n[0] * (contact.points[i].w / penetration_sum));
+    }
+
+    *v1_out = Velocity { v1, omega1 };
+    *v2_out = Velocity { v2, omega2 };
+}
+
+}

@@ -1,0 +1,1346 @@
+#pragma once
+
+#include <madrona/phys_impl/narrowphase.hpp>
+#include <madrona/phys_impl/xpbd.hpp>
+
+namespace madrona::phys {
+
+struct PhysicsSystemState {
+    float deltaT;
+    float h;
+    math::Vector3 g;
+    float gMagnitude;
+    float restitutionThreshold;
+    uint32_t contactArchetypeID;
+    uint32_t jointArchetypeID;
+};
+
+struct CandidateTemporary : Archetype<CandidateCollision> {};
+
+namespace xpbd {
+
+// The reference keeps its Query objects here (xpbd.cpp:21-24); this backend
+// resolves queries when the graph is built, the singleton is kept so that the
+// same number of singleton entities (hence the same entity ids) exist.
+struct SolverState {
+    uint32_t unused[8];
+};
+
+}
+
+// ---------------------------------------------------------------------------
+// Device-global scratch of the physics module (ecs_state::moduleData[0]),
+// allocated by setupPhysicsStepTasks.  Candidates and contacts are emitted in
+// the CPU backend's order -- (body archetype, row, traversal order) -- by
+// counting per creator row, scanning, and filling, instead of appending with
+// atomics in arrival order: XPBD is Gauss-Seidel over contacts
+// in table order, so the order is part of the result.
+// ---------------------------------------------------------------------------
+struct PhysicsScratch {
+    static constexpr uint32_t maxBodyArchetypes = MWHIP_SCAN_MAX_SEGMENTS;
+
+    uint32_t numBodyArchetypes;
+    uint32_t bodyArchetypes[maxBodyArchetypes];
+    uint32_t *bodyCounts[maxBodyArchetypes];    // per body row: #candidates -> offset
+
+    uint32_t candidateArchetype;
+    uint32_t contactArchetype;
+    uint32_t jointArchetype;
+
+    uint32_t *contactFlags;                     // per candidate row: 0/1 -> offset
+    ContactConstraint *contactStaging;          // per candidate row
+};
+
+namespace detail {
+
+#if MADRONA_ON_HOST
+// per-world row budget of the physics temporaries, overridable from the
+// environment (tables hold 2x the hint per world)
+inline CountT capacityHint(const char *env_name, CountT fallback)
+{
+    const char *v = getenv(env_name);
+    if (v != nullptr && atol(v) > 0) {
+        return (CountT)atol(v);
+    }
+    return fallback;
+}
+#endif
+
+MADRONA_HD inline PhysicsScratch *scratch(mwhip::EcsState *S)
+{
+    return (PhysicsScratch *)S->moduleData[0];
+}
+
+// Visits, in BVH traversal order, every (other body, #primitive pairs) that
+// body `e` must be tested against (reference findIntersectingEntry,
+// broadphase.cpp:930-993): each unordered pair once (lower entity id owns it),
+// static-static pairs skipped.
+template <typename Fn>
+MADRONA_HD inline void forEachCandidate(Context &ctx, Entity e,
+                                        broadphase::LeafID leaf_id, Loc a_loc,
+                                        Fn &&fn)
+{
+    broadphase::BVH &bvh = ctx.singleton<broadphase::BVH>();
+    const ObjectManager &obj_mgr = *ctx.singleton<ObjectData>().mgr;
+
+    bool a_is_static =
+        ctx.getDirect<ResponseType>(RGDCols::ResponseType, a_loc) ==
+        ResponseType::Static;
+    base::ObjectID a_obj =
+        ctx.getDirect<base::ObjectID>(RGDCols::ObjectID, a_loc);
+    CountT a_num_prims = (CountT)obj_mgr.rigidBodyPrimitiveCounts[a_obj.idx];
+
+    bvh.findLeafIntersecting(leaf_id, [&](Entity other) {
+        if (e.id < other.id) {
+            Loc b_loc = ctx.loc(other);
+
+            if (a_is_static &&
+                ctx.getDirect<ResponseType>(RGDCols::ResponseType, b_loc) ==
+                    ResponseType::Static) {
+                return;
+            }
+
+            base::ObjectID b_obj =
+                ctx.getDirect<base::ObjectID>(RGDCols::ObjectID, b_loc);
+            CountT b_num_prims =
+                (CountT)obj_mgr.rigidBodyPrimitiveCounts[b_obj.idx];
+
+            fn(b_loc, a_num_prims, b_num_prims);
+        }
+    });
+}
+
+}
+
+// ---------------------------------------------------------------------------
+// narrowphase: primitive-pair dispatch and contact generation (reference
+// narrowphase.cpp narrowphaseDispatch :1214-1514, generateContacts :1516-1680,
+// runNarrowphase :1682-1907, CPU flavour: one candidate per lane, hulls
+// transformed to world space up front)
+// ---------------------------------------------------------------------------
+namespace narrowphase {
+
+struct PrimitiveTransform {
+    Vector3 pos;
+    Quat rot;
+    Diag3x3 scale;
+};
+
+MADRONA_HD inline NarrowphaseResult noContact()
+{
+    NarrowphaseResult result {};
+    result.type = ContactType::None;
+    return result;
+}
+
+MADRONA_HD inline NarrowphaseResult sphereResult(SphereContact contact)
+{
+    NarrowphaseResult result {};
+    result.type = ContactType::Sphere;
+    result.sphere = contact;
+    return result;
+}
+
+MADRONA_HD inline NarrowphaseResult narrowphaseDispatch(
+    NarrowphaseTest test_type,
+    const PrimitiveTransform &a, const PrimitiveTransform &b,
+    const CollisionPrimitive *a_prim, const CollisionPrimitive *b_prim,
+    Vector3 *txfm_vertex_buffer, Plane *txfm_face_buffer,
+    CountT max_tmp_elems, bool *unsupported)
+{
+    switch (test_type) {
+    case NarrowphaseTest::SphereSphere: {
+        float a_radius = a.scale.d0 * a_prim->sphere.radius;
+        float b_radius = b.scale.d0 * b_prim->sphere.radius;
+
+        Vector3 to_b = b.pos - a.pos;
+        float dist = to_b.length();
+
+        if (dist > a_radius + b_radius) {
+            return noContact();
+        }
+
+        Vector3 normal = dist > 0.f ? to_b / dist : math::up;
+        float penetration = a_radius + b_radius - dist;
+
+        return sphereResult(SphereContact {
+            normal,
+            a.pos + a_radius * normal,
+            penetration,
+        });
+    }
+    case NarrowphaseTest::HullHull: {
+        const HalfEdgeMesh &a_he_mesh = a_prim->hull.halfEdgeMesh;
+        const HalfEdgeMesh &b_he_mesh = b_prim->hull.halfEdgeMesh;
+
+        if ((CountT)(a_he_mesh.numFaces + b_he_mesh.numFaces) > max_tmp_elems ||
+            (CountT)(a_he_mesh.numVertices + b_he_mesh.numVertices) >
+                max_tmp_elems) {
+            *unsupported = true;
+            return noContact();
+        }
+
+        HullState a_hull_state = makeHullState(a_he_mesh, a.pos, a.rot,
+            a.scale, txfm_vertex_buffer, txfm_face_buffer);
+
+        txfm_vertex_buffer += a_hull_state.mesh.numVertices;
+        txfm_face_buffer += a_hull_state.mesh.numFaces;
+
+        HullState b_hull_state = makeHullState(b_he_mesh, b.pos, b.rot,
+            b.scale, txfm_vertex_buffer, txfm_face_buffer);
+
+        const SATResult sat = doSAT(a_hull_state, b_hull_state);
+
+        NarrowphaseResult result {};
+        result.type = sat.type;
+        result.sat = sat.contact;
+        result.aVertices = a_hull_state.mesh.vertices;
+        result.bVertices = b_hull_state.mesh.vertices;
+        result.aHalfEdges = a_hull_state.mesh.halfEdges;
+        result.bHalfEdges = b_hull_state.mesh.halfEdges;
+        result.aFaceHedgeRoots = a_hull_state.mesh.faceBaseHalfEdges;
+        result.bFaceHedgeRoots = b_hull_state.mesh.faceBaseHalfEdges;
+        return result;
+    }
+    case NarrowphaseTest::SpherePlane: {
+        float sphere_radius = a.scale.d0 * a_prim->sphere.radius;
+
+        constexpr Vector3 base_normal = { 0, 0, 1 };
+        Vector3 plane_normal = b.rot.rotateVec(base_normal);
+
+        float d = plane_normal.dot(b.pos);
+        float t = plane_normal.dot(a.pos) - d;
+
+        float penetration = sphere_radius - t;
+        if (penetration < 0) {
+            return noContact();
+        }
+
+        return sphereResult(SphereContact {
+            plane_normal,
+            a.pos - t * plane_normal,
+            penetration,
+        });
+    }
+    case NarrowphaseTest::HullPlane: {
+        const HalfEdgeMesh &a_he_mesh = a_prim->hull.halfEdgeMesh;
+
+        if ((CountT)a_he_mesh.numFaces > max_tmp_elems ||
+            (CountT)a_he_mesh.numVertices > max_tmp_elems) {
+            *unsupported = true;
+            return noContact();
+        }
+
+        HullState a_hull_state = makeHullState(a_he_mesh, a.pos, a.rot,
+            a.scale, txfm_vertex_buffer, txfm_face_buffer);
+
+        constexpr Vector3 base_normal = { 0, 0, 1 };
+        Vector3 plane_normal = b.rot.rotateVec(base_normal);
+
+        Plane plane { plane_normal, dot(plane_normal, b.pos) };
+
+        const SATResult sat = doSATPlane(plane, a_hull_state);
+
+        NarrowphaseResult result {};
+        result.type = sat.type;
+        result.sat = sat.contact;
+        result.aVertices = a_hull_state.mesh.vertices;
+        result.aHalfEdges = a_hull_state.mesh.halfEdges;
+        result.aFaceHedgeRoots = a_hull_state.mesh.faceBaseHalfEdges;
+        return result;
+    }
+    case NarrowphaseTest::SphereHull:   // needs GJK: SURVEY.md §8f, not built yet
+    case NarrowphaseTest::PlanePlane:   // planes are static, never paired
+    default:
+        *unsupported = true;
+        return noContact();
+    }
+}
+
+MADRONA_HD inline void manifoldToContact(const Manifold &manifold,
+                                         Loc ref_loc, Loc other_loc,
+                                         ContactConstraint *out)
+{
+    out->ref = ref_loc;
+    out->alt = other_loc;
+    for (int i = 0; i < 4; i++) {
+        out->points[i] = Vector4::fromVec3W(manifold.contactPoints[i],
+                                            manifold.penetrationDepths[i]);
+    }
+    out->numPoints = manifold.numContactPoints;
+    out->normal = manifold.normal;
+}
+
+// returns true when a contact was produced
+MADRONA_HD inline bool generateContact(const NarrowphaseResult &result,
+                                       Loc a_loc, Loc b_loc,
+                                       void *tmp_storage_a, void *tmp_storage_b,
+                                       ContactConstraint *out)
+{
+    const Vector3 no_offset { 0, 0, 0 };
+    const Quat no_rot { 1, 0, 0, 0 };
+
+    switch (result.type) {
+    case ContactType::Sphere: {
+        out->ref = b_loc;
+        out->alt = a_loc;
+        out->points[0] =
+            Vector4::fromVec3W(result.sphere.pt, result.sphere.depth);
+        out->points[1] = Vector4::zero();
+        out->points[2] = Vector4::zero();
+        out->points[3] = Vector4::zero();
+        out->numPoints = 1;
+        out->normal = result.sphere.normal;
+        return true;
+    }
+    case ContactType::SATPlane: {
+        // the plane is always b and always the reference
+        Plane plane { result.sat.normal, result.sat.planeDOrSeparation };
+
+        Manifold manifold = createFacePlaneContact(
+            plane, (int32_t)result.sat.incidentFaceIdxOrEdgeIdxB,
+            result.aVertices, result.aHalfEdges, result.aFaceHedgeRoots,
+            (Vector3 *)tmp_storage_a, (float *)tmp_storage_b,
+            no_offset, no_rot);
+
+        // barely touching pairs can lose every clipped point to fp32
+        if (manifold.numContactPoints == 0) {
+            return false;
+        }
+        manifoldToContact(manifold, b_loc, a_loc, out);
+        return true;
+    }
+    case ContactType::SATFace: {
+        uint32_t ref_face_idx_and_ref_mask = result.sat.refFaceIdxOrEdgeIdxA;
+        uint32_t incident_face_idx = result.sat.incidentFaceIdxOrEdgeIdxB;
+
+        uint32_t ref_face_idx = ref_face_idx_and_ref_mask & 0x7FFFFFFFu;
+        bool a_is_ref = ref_face_idx == ref_face_idx_and_ref_mask;
+
+        Plane ref_plane { result.sat.normal, result.sat.planeDOrSeparation };
+
+        Manifold manifold = a_is_ref ?
+            createFaceContact(ref_plane, (int32_t)ref_face_idx,
+                (int32_t)incident_face_idx,
+                result.aVertices, result.bVertices,
+                result.aHalfEdges, result.bHalfEdges,
+                result.aFaceHedgeRoots, result.bFaceHedgeRoots,
+                tmp_storage_a, tmp_storage_b, no_offset, no_rot) :
+            createFaceContact(ref_plane, (int32_t)ref_face_idx,
+                (int32_t)incident_face_idx,
+                result.bVertices, result.aVertices,
+                result.bHalfEdges, result.aHalfEdges,
+                result.bFaceHedgeRoots, result.aFaceHedgeRoots,
+                tmp_storage_a, tmp_storage_b, no_offset, no_rot);
+
+        if (manifold.numContactPoints == 0) {
+            return false;
+        }
+        manifoldToContact(manifold, a_is_ref ? a_loc : b_loc,
+                          a_is_ref ? b_loc : a_loc, out);
+        return true;
+    }
+    case ContactType::SATEdge: {
+        Manifold manifold = createEdgeContact(
+            result.sat.normal, result.sat.planeDOrSeparation,
+            (int32_t)result.sat.refFaceIdxOrEdgeIdxA,
+            (int32_t)result.sat.incidentFaceIdxOrEdgeIdxB,
+            result.aVertices, result.bVertices,
+            result.aHalfEdges, result.bHalfEdges, no_offset, no_rot);
+
+        manifoldToContact(manifold, a_loc, b_loc, out);
+        return true;
+    }
+    case ContactType::None:
+    default:
+        return false;
+    }
+}
+
+// One primitive pair: order by primitive type, AABB reject, dispatch, contact.
+// tmp_vertices / tmp_faces: max_tmp_elems entries each; the face buffer's two
+// halves double as the clipping scratch once SAT is done with the planes.
+MADRONA_HD inline bool collidePrimitives(
+    const ObjectManager &obj_mgr,
+    Loc a_loc, Loc b_loc,
+    uint32_t a_prim_idx, uint32_t b_prim_idx,
+    PrimitiveTransform a_txfm, PrimitiveTransform b_txfm,
+    Vector3 *tmp_vertices, Plane *tmp_faces, CountT max_tmp_elems,
+    ContactConstraint *out, bool *unsupported)
+{
+    const CollisionPrimitive *a_prim = &obj_mgr.collisionPrimitives[a_prim_idx];
+    const CollisionPrimitive *b_prim = &obj_mgr.collisionPrimitives[b_prim_idx];
+
+    uint32_t raw_type_a = static_cast<uint32_t>(a_prim->type);
+    uint32_t raw_type_b = static_cast<uint32_t>(b_prim->type);
+
+    if (raw_type_a > raw_type_b) {
+        Loc tmp_loc = a_loc; a_loc = b_loc; b_loc = tmp_loc;
+        const CollisionPrimitive *tmp_prim = a_prim;
+        a_prim = b_prim; b_prim = tmp_prim;
+        uint32_t tmp_idx = a_prim_idx; a_prim_idx = b_prim_idx;
+        b_prim_idx = tmp_idx;
+        uint32_t tmp_type = raw_type_a; raw_type_a = raw_type_b;
+        raw_type_b = tmp_type;
+        PrimitiveTransform tmp_txfm = a_txfm; a_txfm = b_txfm;
+        b_txfm = tmp_txfm;
+    }
+
+    {
+        math::AABB a_obj_aabb = obj_mgr.primitiveAABBs[a_prim_idx];
+        math::AABB b_obj_aabb = obj_mgr.primitiveAABBs[b_prim_idx];
+
+        math::AABB a_world_aabb =
+            a_obj_aabb.applyTRS(a_txfm.pos, a_txfm.rot, a_txfm.scale);
+        math::AABB b_world_aabb =
+            b_obj_aabb.applyTRS(b_txfm.pos, b_txfm.rot, b_txfm.scale);
+
+        if (!a_world_aabb.intersects(b_world_aabb)) {
+            return false;
+        }
+    }
+
+    const NarrowphaseTest test_type { raw_type_a | raw_type_b };
+
+    NarrowphaseResult result = narrowphaseDispatch(
+        test_type, a_txfm, b_txfm, a_prim, b_prim,
+        tmp_vertices, tmp_faces, max_tmp_elems, unsupported);
+
+    return generateContact(result, a_loc, b_loc, tmp_faces,
+                           tmp_faces + max_tmp_elems / 2, out);
+}
+
+MADRONA_HD inline bool computeContact(Context &ctx,
+                                      const ObjectManager &obj_mgr,
+                                      const CandidateCollision &candidate,
+                                      Vector3 *tmp_vertices, Plane *tmp_faces,
+                                      CountT max_tmp_elems,
+                                      ContactConstraint *out)
+{
+    Loc a_loc = candidate.a;
+    Loc b_loc = candidate.b;
+
+    base::ObjectID a_obj =
+        ctx.getDirect<base::ObjectID>(RGDCols::ObjectID, a_loc);
+    base::ObjectID b_obj =
+        ctx.getDirect<base::ObjectID>(RGDCols::ObjectID, b_loc);
+
+    uint32_t a_prim_idx =
+        obj_mgr.rigidBodyPrimitiveOffsets[a_obj.idx] + candidate.aPrim;
+    uint32_t b_prim_idx =
+        obj_mgr.rigidBodyPrimitiveOffsets[b_obj.idx] + candidate.bPrim;
+
+    PrimitiveTransform a_txfm {
+        ctx.getDirect<base::Position>(RGDCols::Position, a_loc),
+        ctx.getDirect<base::Rotation>(RGDCols::Rotation, a_loc),
+        Diag3x3(ctx.getDirect<base::Scale>(RGDCols::Scale, a_loc)),
+    };
+    PrimitiveTransform b_txfm {
+        ctx.getDirect<base::Position>(RGDCols::Position, b_loc),
+        ctx.getDirect<base::Rotation>(RGDCols::Rotation, b_loc),
+        Diag3x3(ctx.getDirect<base::Scale>(RGDCols::Scale, b_loc)),
+    };
+
+    bool unsupported = false;
+    bool has_contact = collidePrimitives(obj_mgr, a_loc, b_loc,
+        a_prim_idx, b_prim_idx, a_txfm, b_txfm, tmp_vertices, tmp_faces,
+        max_tmp_elems, out, &unsupported);
+
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (unsupported) {
+        mwhip::raiseError(ctx.getStateManager(), mwhip::kErrPhysics);
+    }
+#endif
+
+    return has_contact;
+}
+
+}
+
+// ---------------------------------------------------------------------------
+// Systems that are plain ParallelFor nodes
+// ---------------------------------------------------------------------------
+namespace broadphase {
+
+inline void updateLeafPositionsEntry(Context &ctx,
+                                     const LeafID &leaf_id,
+                                     const base::Position &pos,
+                                     const base::Rotation &rot,
+                                     const base::Scale &scale,
+                                     const base::ObjectID &obj_id,
+                                     const Velocity &vel)
+{
+    BVH &bvh = ctx.singleton<BVH>();
+    ObjectManager &obj_mgr = *ctx.singleton<ObjectData>().mgr;
+    math::AABB obj_aabb = obj_mgr.rigidBodyAABBs[obj_id.idx];
+
+    bvh.updateLeafPosition(leaf_id, pos, rot, scale, vel.linear, obj_aabb);
+}
+
+inline void updateBVHEntry(Context &, BVH &bvh)
+{
+    bvh.updateTree();
+}
+
+inline void refitEntry(Context &ctx, LeafID leaf_id)
+{
+    BVH &bvh = ctx.singleton<BVH>();
+    bvh.refitLeaf(leaf_id, bvh.getLeafAABB(leaf_id));
+}
+
+}
+
+namespace xpbd {
+
+inline void substepRigidBodies(Context &ctx,
+                               base::Position &pos,
+                               base::Rotation &rot,
+                               const Velocity &vel,
+                               const base::ObjectID &obj_id,
+                               ResponseType response_type,
+                               ExternalForce &ext_force,
+                               ExternalTorque &ext_torque,
+                               SubstepPrevState &prev_state,
+                               PreSolvePositional &presolve_pos,
+                               PreSolveVelocity &presolve_vel)
+{
+    Vector3 x = pos;
+    Quat q = rot;
+
+    prev_state.prevPosition = x;
+    prev_state.prevRotation = q;
+
+    if (response_type == ResponseType::Static) {
+        presolve_pos.x = x;
+        presolve_pos.q = q;
+        presolve_vel.v = Vector3::zero();
+        presolve_vel.omega = Vector3::zero();
+        return;
+    }
+
+    const PhysicsSystemState &physics_sys =
+        ctx.singleton<PhysicsSystemState>();
+    const ObjectManager &obj_mgr = *ctx.singleton<ObjectData>().mgr;
+    const RigidBodyMetadata &metadata = obj_mgr.metadata[obj_id.idx];
+
+    SubstepResult next = integrateBody(
+        x, q, vel.linear, vel.angular, metadata.mass.invMass,
+        metadata.mass.invInertiaTensor, ext_force, ext_torque, physics_sys.g,
+        physics_sys.h, response_type == ResponseType::Dynamic);
+
+    pos = next.x;
+    rot = next.q;
+
+    presolve_pos.x = next.x;
+    presolve_pos.q = next.q;
+    presolve_vel.v = next.v;
+    presolve_vel.omega = next.omega;
+}
+
+inline void setVelocities(Context &ctx,
+                          const base::Position &pos,
+                          const base::Rotation &rot,
+                          const SubstepPrevState &prev_state,
+                          Velocity &vel)
+{
+    const PhysicsSystemState &physics_sys =
+        ctx.singleton<PhysicsSystemState>();
+    vel = deriveVelocity(pos, rot, prev_state, physics_sys.h);
+}
+
+}
+
+// ---------------------------------------------------------------------------
+// Custom kernels (device only)
+// ---------------------------------------------------------------------------
+#if defined(__HIPCC__)
+namespace kernels {
+
+using mwhip::EcsState;
+using mwhip::TableHdr;
+
+// broadphase, phase 1 and 3: per rigid-body row, count / write the candidate
+// pairs it owns.  fill == false: bodyCounts[a][row] = #candidates;
+// fill == true: write them at the scanned offset.
+template <bool fill>
+__global__ void __launch_bounds__(256)
+candidateKernel(EcsState *S, void *, uint32_t, uint32_t)
+{
+    StateManager *state_mgr = static_cast<StateManager *>(S);
+    PhysicsScratch *ps = detail::scratch(S);
+
+    const int32_t tid = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
+    const int32_t stride = (int32_t)(gridDim.x * blockDim.x);
+
+    TableHdr &cand_tbl = S->tables[ps->candidateArchetype];
+
+    for (uint32_t a = 0; a < ps->numBodyArchetypes; a++) {
+        const uint32_t archetype_id = ps->bodyArchetypes[a];
+        TableHdr &tbl = S->tables[archetype_id];
+        const int32_t num_rows = tbl.numRows;
+        const Entity *entities = (const Entity *)tbl.columns[0];
+        const WorldID *worlds = (const WorldID *)tbl.columns[1];
+        const broadphase::LeafID *leaves =
+            (const broadphase::LeafID *)tbl.columns[RGDCols::LeafID];
+        uint32_t *counts = ps->bodyCounts[a];
+
+        for (int32_t row = tid; row < num_rows; row += stride) {
+            WorldID world_id = worlds[row];
+            if (world_id.idx == -1) {
+                if constexpr (!fill) counts[row] = 0;
+                continue;
+            }
+
+            Context ctx = TaskGraph::makeContext<Context>(state_mgr, world_id);
+            Loc a_loc { archetype_id, row };
+
+            uint32_t n = 0;
+            uint32_t out = fill ? counts[row] : 0u;
+            detail::forEachCandidate(ctx, entities[row], leaves[row], a_loc,
+                [&](Loc b_loc, CountT a_num_prims, CountT b_num_prims) {
+                CountT total_checks = a_num_prims * b_num_prims;
+                if constexpr (fill) {
+                    for (CountT k = 0; k < total_checks; k++) {
+                        uint32_t dst = out + n + (uint32_t)k;
+                        if (dst >= (uint32_t)cand_tbl.capacity) {
+                            break;      // scan already raised the overflow flag
+                        }
+                        ((Entity *)cand_tbl.columns[0])[dst] = Entity::none();
+                        ((WorldID *)cand_tbl.columns[1])[dst] = world_id;
+                        CandidateCollision &candidate = ((CandidateCollision *)
+                            cand_tbl.columns[RGDCols::CandidateCollision])[dst];
+                        candidate.a = a_loc;
+                        candidate.b = b_loc;
+                        candidate.aPrim = (uint32_t)(k / b_num_prims);
+                        candidate.bPrim = (uint32_t)(k % b_num_prims);
+                    }
+                }
+                n += (uint32_t)total_checks;
+            });
+
+            if constexpr (!fill) counts[row] = n;
+        }
+    }
+}
+
+// narrowphase: one lane per candidate; result staged per candidate row
+__global__ void __launch_bounds__(256)
+narrowphaseKernel(EcsState *S, void *, uint32_t, uint32_t)
+{
+    using namespace narrowphase;
+
+    StateManager *state_mgr = static_cast<StateManager *>(S);
+    PhysicsScratch *ps = detail::scratch(S);
+
+    TableHdr &cand_tbl = S->tables[ps->candidateArchetype];
+    const int32_t num_rows = cand_tbl.numRows;
+    const WorldID *worlds = (const WorldID *)cand_tbl.columns[1];
+    const CandidateCollision *candidates = (const CandidateCollision *)
+        cand_tbl.columns[RGDCols::CandidateCollision];
+
+    constexpr int32_t max_elems = MADRONA_PHYS_MAX_HULL_ELEMS;
+    geo::Plane tmp_faces[max_elems];
+    math::Vector3 tmp_vertices[max_elems];
+
+    const int32_t tid = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
+    const int32_t stride = (int32_t)(gridDim.x * blockDim.x);
+
+    for (int32_t row = tid; row < num_rows; row += stride) {
+        Context ctx = TaskGraph::makeContext<Context>(state_mgr, worlds[row]);
+        const ObjectManager &obj_mgr = *ctx.singleton<ObjectData>().mgr;
+
+        ContactConstraint contact;
+        bool has_contact = computeContact(
+            ctx, obj_mgr, candidates[row], tmp_vertices, tmp_faces, max_elems,
+            &contact);
+
+        ps->contactFlags[row] = has_contact ? 1u : 0u;
+        if (has_contact) {
+            ps->contactStaging[row] = contact;
+        }
+    }
+}
+
+// moves staged contacts to the Contact table at their scanned offsets
+__global__ void __launch_bounds__(256)
+contactCompactKernel(EcsState *S, void *, uint32_t, uint32_t)
+{
+    PhysicsScratch *ps = detail::scratch(S);
+    TableHdr &cand_tbl = S->tables[ps->candidateArchetype];
+    TableHdr &contact_tbl = S->tables[ps->contactArchetype];
+
+    const int32_t num_rows = cand_tbl.numRows;
+    const int32_t num_contacts = contact_tbl.numRows;   // written by the scan
+    const WorldID *cand_worlds = (const WorldID *)cand_tbl.columns[1];
+
+    const int32_t tid = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
+    const int32_t stride = (int32_t)(gridDim.x * blockDim.x);
+
+    for (int32_t row = tid; row < num_rows; row += stride) {
+        // after the scan: flags[row] = offset; a contact exists iff the next
+        // offset (or the total) is larger
+        uint32_t off = ps->contactFlags[row];
+        uint32_t next = row + 1 < num_rows ?
+            ps->contactFlags[row + 1] : (uint32_t)num_contacts;
+        if (next == off || off >= (uint32_t)contact_tbl.capacity) {
+            continue;
+        }
+
+        ((Entity *)contact_tbl.columns[0])[off] = Entity::none();
+        ((WorldID *)contact_tbl.columns[1])[off] = cand_worlds[row];
+        ((ContactConstraint *)contact_tbl.columns[2])[off] =
+            ps->contactStaging[row];
+        xpbd::XPBDContactState zero {};
+        ((xpbd::XPBDContactState *)contact_tbl.columns[3])[off] = zero;
+    }
+}
+
+// XPBD position solve: one lane per world walks that world's contacts, then
+// its joints, in table order (Gauss-Seidel; reference xpbd.cpp:720-736)
+__global__ void __launch_bounds__(256)
+solvePositionsKernel(EcsState *S, void *, uint32_t, uint32_t)
+{
+    StateManager *state_mgr = static_cast<StateManager *>(S);
+    PhysicsScratch *ps = detail::scratch(S);
+
+    const int32_t world = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (world >= S->numWorlds) {
+        return;
+    }
+
+    Context ctx = TaskGraph::makeContext<Context>(state_mgr, WorldID { world });
+    ObjectManager &obj_mgr = *ctx.singleton<ObjectData>().mgr;
+
+    {
+        TableHdr &tbl = S->tables[ps->contactArchetype];
+        const int32_t begin = tbl.worldOffsets[world];
+        const int32_t end = begin + tbl.worldCounts[world];
+        ContactConstraint *contacts = (ContactConstraint *)tbl.columns[2];
+        xpbd::XPBDContactState *states =
+            (xpbd::XPBDContactState *)tbl.columns[3];
+        for (int32_t i = begin; i < end; i++) {
+            states[i].lambdaN[0] = 0.f;
+            states[i].lambdaN[1] = 0.f;
+            states[i].lambdaN[2] = 0.f;
+            states[i].lambdaN[3] = 0.f;
+            xpbd::handleContact(ctx, obj_mgr, contacts[i], states[i].lambdaN);
+        }
+    }
+
+    {
+        TableHdr &tbl = S->tables[ps->jointArchetype];
+        const int32_t begin = tbl.worldOffsets[world];
+        const int32_t end = begin + tbl.worldCounts[world];
+        const JointConstraint *joints = (const JointConstraint *)tbl.columns[2];
+        const Entity *joint_entities = (const Entity *)tbl.columns[0];
+        for (int32_t i = begin; i < end; i++) {
+            if (joint_entities[i].id < 0) {
+                continue;       // destroyed, not yet compacted
+            }
+            xpbd::handleJointConstraint(ctx, obj_mgr, joints[i]);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+solveVelocitiesKernel(EcsState *S, void *, uint32_t, uint32_t)
+{
+    StateManager *state_mgr = static_cast<StateManager *>(S);
+    PhysicsScratch *ps = detail::scratch(S);
+
+    const int32_t world = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (world >= S->numWorlds) {
+        return;
+    }
+
+    Context ctx = TaskGraph::makeContext<Context>(state_mgr, WorldID { world });
+    ObjectManager &obj_mgr = *ctx.singleton<ObjectData>().mgr;
+    const PhysicsSystemState &physics_sys =
+        ctx.singleton<PhysicsSystemState>();
+
+    TableHdr &tbl = S->tables[ps->contactArchetype];
+    const int32_t begin = tbl.worldOffsets[world];
+    const int32_t end = begin + tbl.worldCounts[world];
+    ContactConstraint *contacts = (ContactConstraint *)tbl.columns[2];
+    xpbd::XPBDContactState *states = (xpbd::XPBDContactState *)tbl.columns[3];
+    for (int32_t i = begin; i < end; i++) {
+        xpbd::solveVelocitiesForContact(ctx, obj_mgr, contacts[i],
+            states[i].lambdaN, physics_sys.h, physics_sys.restitutionThreshold);
+    }
+}
+
+}
+#endif // __HIPCC__
+
+}
+
+// ---------------------------------------------------------------------------
+// PhysicsSystem: the simulator-facing API (reference src/physics/physics.cpp)
+// ---------------------------------------------------------------------------
+namespace madrona::phys::PhysicsSystem {
+
+MADRONA_HD inline void init(Context &ctx,
+                            ObjectManager *obj_mgr,
+                            float delta_t,
+                            CountT num_substeps,
+                            math::Vector3 gravity,
+                            CountT max_dynamic_objects,
+                            Solver)
+{
+    broadphase::BVH &bvh = ctx.singleton<broadphase::BVH>();
+
+    // leaves are expanded by 2 * delta_t * velocity plus room for
+    // acceleration within the step
+    constexpr float max_inst_accel = 100.f;
+    new (&bvh) broadphase::BVH(
+        obj_mgr, max_dynamic_objects, 2.f * delta_t,
+        max_inst_accel * delta_t * delta_t);
+
+    float h = delta_t / (float)num_substeps;
+    float g_mag = gravity.length();
+
+    PhysicsSystemState &state = ctx.singleton<PhysicsSystemState>();
+    state.deltaT = delta_t;
+    state.h = h;
+    state.g = gravity;
+    state.gMagnitude = g_mag;
+    state.restitutionThreshold = 2.f * g_mag * h;
+    state.contactArchetypeID = TypeTracker::typeID<xpbd::Contact>();
+    state.jointArchetypeID = TypeTracker::typeID<xpbd::Joint>();
+
+    xpbd::SolverState &solver_state = ctx.singleton<xpbd::SolverState>();
+    for (int i = 0; i < 8; i++) {
+        solver_state.unused[i] = 0;
+    }
+
+    ctx.singleton<ObjectData>() = ObjectData { obj_mgr };
+}
+
+MADRONA_HD inline void reset(Context &ctx)
+{
+    broadphase::BVH &bvh = ctx.singleton<broadphase::BVH>();
+    bvh.rebuildOnUpdate();
+    bvh.clearLeaves();
+}
+
+MADRONA_HD inline broadphase::LeafID registerEntity(Context &ctx,
+                                                    Entity e,
+                                                    base::ObjectID obj_id)
+{
+    return ctx.singleton<broadphase::BVH>().reserveLeaf(e, obj_id);
+}
+
+template <typename Fn>
+MADRONA_HD inline void findEntitiesWithinAABB(Context &ctx,
+                                              math::AABB aabb,
+                                              Fn &&fn)
+{
+    ctx.singleton<broadphase::BVH>().findIntersecting(aabb, fn);
+}
+
+MADRONA_HD inline bool checkEntityAABBOverlap(Context &ctx,
+                                              math::AABB aabb,
+                                              Entity e)
+{
+    using namespace math;
+
+    const ObjectManager &obj_mgr = *ctx.singleton<ObjectData>().mgr;
+
+    base::ObjectID e_obj_id = ctx.get<base::ObjectID>(e);
+    Vector3 e_pos = ctx.get<base::Position>(e);
+    Quat e_rot = ctx.get<base::Rotation>(e);
+    Diag3x3 e_scale = ctx.get<base::Scale>(e);
+
+    uint32_t num_prims = obj_mgr.rigidBodyPrimitiveCounts[e_obj_id.idx];
+    uint32_t base_prim_offset = obj_mgr.rigidBodyPrimitiveOffsets[e_obj_id.idx];
+
+    for (uint32_t prim_offset = 0; prim_offset < num_prims; prim_offset++) {
+        uint32_t prim_idx = base_prim_offset + prim_offset;
+
+        const CollisionPrimitive &prim = obj_mgr.collisionPrimitives[prim_idx];
+        if (prim.type != CollisionPrimitive::Type::Hull) {
+            continue;
+        }
+
+        AABB prim_aabb = obj_mgr.primitiveAABBs[prim_idx];
+        AABB txfmed_aabb = prim_aabb.applyTRS(e_pos, e_rot, e_scale);
+
+        if (!txfmed_aabb.overlaps(aabb)) {
+            continue;
+        }
+
+        // exact extent of the transformed hull along the world axes
+        const Vector3 *vertices = prim.hull.halfEdgeMesh.vertices;
+        CountT num_verts = (CountT)prim.hull.halfEdgeMesh.numVertices;
+
+        const Vector3 axes[3] { right, fwd, up };
+        float min_hull_projs[3] { FLT_MAX, FLT_MAX, FLT_MAX };
+        float max_hull_projs[3] { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+
+        for (CountT vert_idx = 0; vert_idx < num_verts; vert_idx++) {
+            Vector3 v = e_rot.rotateVec(e_scale * vertices[vert_idx]) + e_pos;
+
+            for (CountT i = 0; i < 3; i++) {
+                float proj = dot(v, axes[i]);
+                if (proj < min_hull_projs[i]) {
+                    min_hull_projs[i] = proj;
+                }
+                if (proj > max_hull_projs[i]) {
+                    max_hull_projs[i] = proj;
+                }
+            }
+        }
+
+        bool axes_overlap = true;
+        for (CountT i = 0; i < 3; i++) {
+            bool proj_overlap = max_hull_projs[i] > aabb.pMin[i] &&
+                aabb.pMax[i] > min_hull_projs[i];
+            if (!proj_overlap) {
+                axes_overlap = false;
+            }
+        }
+
+        if (axes_overlap) {
+            return true;
+        }
+    }
+
+    return false;
+}
+
+MADRONA_HD inline Entity makeFixedJoint(Context &ctx,
+                                        Entity e1, Entity e2,
+                                        math::Quat attach_rot1,
+                                        math::Quat attach_rot2,
+                                        math::Vector3 r1, math::Vector3 r2,
+                                        float separation)
+{
+    const PhysicsSystemState &physics_sys =
+        ctx.singleton<PhysicsSystemState>();
+    Entity e = ctx.makeEntity(physics_sys.jointArchetypeID);
+
+    JointConstraint &joint = ctx.get<JointConstraint>(e);
+    joint.e1 = e1;
+    joint.e2 = e2;
+    joint.type = JointConstraint::Type::Fixed;
+    joint.fixed.attachRot1 = attach_rot1;
+    joint.fixed.attachRot2 = attach_rot2;
+    joint.fixed.separation = separation;
+    joint.r1 = r1;
+    joint.r2 = r2;
+
+    return e;
+}
+
+MADRONA_HD inline Entity makeHingeJoint(Context &ctx,
+                                        Entity e1, Entity e2,
+                                        math::Vector3 a1_local,
+                                        math::Vector3 a2_local,
+                                        math::Vector3 b1_local,
+                                        math::Vector3 b2_local,
+                                        math::Vector3 r1, math::Vector3 r2)
+{
+    const PhysicsSystemState &physics_sys =
+        ctx.singleton<PhysicsSystemState>();
+    Entity e = ctx.makeEntity(physics_sys.jointArchetypeID);
+
+    JointConstraint &joint = ctx.get<JointConstraint>(e);
+    joint.e1 = e1;
+    joint.e2 = e2;
+    joint.type = JointConstraint::Type::Hinge;
+    joint.hinge.a1Local = a1_local;
+    joint.hinge.a2Local = a2_local;
+    joint.hinge.b1Local = b1_local;
+    joint.hinge.b2Local = b2_local;
+    joint.r1 = r1;
+    joint.r2 = r2;
+
+    return e;
+}
+
+MADRONA_HOST_API inline void registerTypes(ECSRegistry &registry, Solver solver)
+{
+#if MADRONA_ON_HOST
+    if (solver != Solver::XPBD) {
+        FATAL("madrona_amd physics: only the XPBD solver is available");
+    }
+
+    // Same order as the reference (physics.cpp:308-341, xpbd.cpp:1046-1060):
+    // singleton registration order fixes singleton entity ids.
+    registry.registerComponent<ResponseType>();
+    registry.registerComponent<broadphase::LeafID>();
+    registry.registerComponent<Velocity>();
+    registry.registerComponent<ExternalForce>();
+    registry.registerComponent<ExternalTorque>();
+
+    registry.registerSingleton<broadphase::BVH>();
+
+    registry.registerComponent<CollisionEvent>();
+    registry.registerArchetype<CollisionEventTemporary>();
+
+    registry.registerComponent<CandidateCollision>();
+    registry.registerArchetype<CandidateTemporary>(
+        ComponentMetadataSelector<> {}, ArchetypeFlags::None,
+        detail::capacityHint("MADRONA_MWHIP_MAX_CANDIDATES_PER_WORLD", 128));
+
+    registry.registerComponent<JointConstraint>();
+    registry.registerComponent<ContactConstraint>();
+
+    registry.registerSingleton<PhysicsSystemState>();
+    registry.registerSingleton<ObjectData>();
+
+    registry.registerComponent<xpbd::SubstepPrevState>();
+    registry.registerComponent<xpbd::PreSolvePositional>();
+    registry.registerComponent<xpbd::PreSolveVelocity>();
+    registry.registerComponent<xpbd::XPBDContactState>();
+
+    registry.registerArchetype<xpbd::Joint>();
+    registry.registerArchetype<xpbd::Contact>(
+        ComponentMetadataSelector<> {}, ArchetypeFlags::None,
+        detail::capacityHint("MADRONA_MWHIP_MAX_CONTACTS_PER_WORLD", 64));
+
+    registry.registerSingleton<xpbd::SolverState>();
+
+    registry.registerBundle<xpbd::XPBDRigidBodyState>();
+    registry.registerBundleAlias<SolverBundleAlias, xpbd::XPBDRigidBodyState>();
+
+    registry.registerBundle<RigidBody>();
+#else
+    (void)registry; (void)solver;
+    MADRONA_DEVICE_STUB();
+#endif
+}
+
+MADRONA_HOST_API inline TaskGraphNodeID setupBroadphaseTasks(
+    TaskGraphBuilder &builder,
+    Span<const TaskGraphNodeID> deps)
+{
+    using namespace base;
+    using broadphase::LeafID;
+
+    auto update_leaves = builder.addToGraph<ParallelForNode<Context,
+        broadphase::updateLeafPositionsEntry,
+            LeafID, Position, Rotation, Scale, ObjectID, Velocity>>(deps);
+
+    auto bvh_update = builder.addToGraph<ParallelForNode<Context,
+        broadphase::updateBVHEntry, broadphase::BVH>>({update_leaves});
+
+    // the update may be a no-op, refit unconditionally
+    auto refit = builder.addToGraph<ParallelForNode<Context,
+        broadphase::refitEntry, LeafID>>({bvh_update});
+
+    return refit;
+}
+
+namespace detail {
+
+#if MADRONA_ON_HOST
+inline PhysicsScratch *scratchHost(TaskGraphBuilder &builder,
+                                   PhysicsScratch *host_copy_out)
+{
+    // one scratch block per executor, shared by every graph that has physics
+    static thread_local mwhip_exec *cached_exec = nullptr;
+    static thread_local PhysicsScratch *cached_dev = nullptr;
+    static thread_local PhysicsScratch cached_host {};
+
+    mwhip_exec *exec = builder.exec();
+    if (cached_exec == exec) {
+        *host_copy_out = cached_host;
+        return cached_dev;
+    }
+
+    StateManager &state_mgr = builder.stateManager();
+
+    PhysicsScratch ps {};
+
+    // body archetypes in query order == CPU iteration order
+    auto body_query = state_mgr.query<Entity, broadphase::LeafID>();
+    const QueryRef *ref = body_query.getSharedRef();
+    if (ref->numMatchingArchetypes > PhysicsScratch::maxBodyArchetypes) {
+        FATAL("madrona_amd physics: more than %u rigid body archetypes",
+              PhysicsScratch::maxBodyArchetypes);
+    }
+
+    uint32_t query_words[PhysicsScratch::maxBodyArchetypes * 3];
+    mwhip::check(mwhip_get_query_data(exec, ref->offset,
+        ref->numMatchingArchetypes * 3, query_words), "get_query_data");
+
+    ps.numBodyArchetypes = ref->numMatchingArchetypes;
+    for (uint32_t i = 0; i < ps.numBodyArchetypes; i++) {
+        uint32_t archetype_id = query_words[i * 3];
+        ps.bodyArchetypes[i] = archetype_id;
+        uint32_t capacity = mwhip_archetype_capacity(exec, archetype_id);
+        ps.bodyCounts[i] = (uint32_t *)mwhip_alloc_device(
+            exec, (uint64_t)capacity * sizeof(uint32_t), 1);
+    }
+
+    ps.candidateArchetype = TypeTracker::typeID<CandidateTemporary>();
+    ps.contactArchetype = TypeTracker::typeID<xpbd::Contact>();
+    ps.jointArchetype = TypeTracker::typeID<xpbd::Joint>();
+
+    uint32_t cand_capacity =
+        mwhip_archetype_capacity(exec, ps.candidateArchetype);
+    ps.contactFlags = (uint32_t *)mwhip_alloc_device(
+        exec, (uint64_t)cand_capacity * sizeof(uint32_t), 1);
+    ps.contactStaging = (ContactConstraint *)mwhip_alloc_device(
+        exec, (uint64_t)cand_capacity * sizeof(ContactConstraint), 0);
+
+    PhysicsScratch *dev = (PhysicsScratch *)mwhip_alloc_device(
+        exec, sizeof(PhysicsScratch), 0);
+    if (dev == nullptr || ps.contactStaging == nullptr) {
+        FATAL("madrona_amd physics: scratch allocation failed: %s",
+              mwhip_last_error());
+    }
+    mwhip::check(mwhip_memcpy_h2d(dev, &ps, sizeof(PhysicsScratch)),
+                 "memcpy_h2d");
+    mwhip::check(mwhip_set_module_data(exec, 0, dev), "set_module_data");
+
+    cached_exec = exec;
+    cached_dev = dev;
+    cached_host = ps;
+    *host_copy_out = ps;
+    return dev;
+}
+
+inline int32_t *numRowsAddr(mwhip_exec *exec, uint32_t archetype_id)
+{
+    char *hdr = (char *)mwhip_table_header(exec, archetype_id);
+    return (int32_t *)(hdr + offsetof(mwhip::TableHdr, numRows));
+}
+
+inline uint32_t *needsSortAddr(mwhip_exec *exec, uint32_t archetype_id)
+{
+    char *hdr = (char *)mwhip_table_header(exec, archetype_id);
+    return (uint32_t *)(hdr + offsetof(mwhip::TableHdr, needsSort));
+}
+
+inline TaskGraphNodeID addKernelNode(TaskGraphBuilder &builder,
+                                     const char *name, const void *kernel,
+                                     uint32_t count_mode, uint32_t fixed_count,
+                                     Span<const TaskGraphNodeID> deps)
+{
+    mwhip_node_desc desc {};
+    desc.kind = MWHIP_NODE_KERNEL;
+    desc.name = name;
+    desc.kernel = kernel;
+    desc.count_mode = count_mode;
+    desc.fixed_count = fixed_count;
+    desc.threads_per_invocation = 1;
+    return builder.addRuntimeNode(desc, -1, deps);
+}
+#endif
+
+// broadphase overlap: count -> scan -> fill (replaces the reference's
+// findIntersectingEntry ParallelFor, broadphase.cpp:930-993)
+MADRONA_HOST_API inline TaskGraphNodeID setupCandidateTasks(
+    TaskGraphBuilder &builder, Span<const TaskGraphNodeID> deps)
+{
+#if defined(__HIPCC__)
+    [[maybe_unused]] auto count_stub = [] __host__ () -> const void * {
+        return (const void *)&kernels::candidateKernel<false>;
+    };
+    [[maybe_unused]] auto fill_stub = [] __host__ () -> const void * {
+        return (const void *)&kernels::candidateKernel<true>;
+    };
+#else
+    auto count_stub = []() -> const void * { return nullptr; };
+    auto fill_stub = []() -> const void * { return nullptr; };
+#endif
+
+#if MADRONA_ON_HOST
+    mwhip_exec *exec = builder.exec();
+    PhysicsScratch ps;
+    scratchHost(builder, &ps);
+
+    uint64_t body_capacity = 0;
+    for (uint32_t i = 0; i < ps.numBodyArchetypes; i++) {
+        body_capacity += mwhip_archetype_capacity(exec, ps.bodyArchetypes[i]);
+    }
+
+    auto count = addKernelNode(builder, "physics:candidateCount", count_stub(),
+        MWHIP_COUNT_FIXED, (uint32_t)body_capacity, deps);
+
+    mwhip_scan_params scan {};
+    scan.num_segments = ps.numBodyArchetypes;
+    scan.capacity = mwhip_archetype_capacity(exec, ps.candidateArchetype);
+    for (uint32_t i = 0; i < ps.numBodyArchetypes; i++) {
+        scan.data[i] = ps.bodyCounts[i];
+        scan.lengths[i] = numRowsAddr(exec, ps.bodyArchetypes[i]);
+    }
+    scan.total_out = numRowsAddr(exec, ps.candidateArchetype);
+    scan.needs_sort_out = nullptr;
+
+    auto scan_data = builder.constructNodeData<mwhip_scan_params>(scan);
+    mwhip_node_desc scan_desc {};
+    scan_desc.kind = MWHIP_NODE_EXCLUSIVE_SCAN;
+    scan_desc.name = "physics:candidateScan";
+    scan_desc.fixed_count = (uint32_t)body_capacity;
+    auto scanned = builder.addRuntimeNode(scan_desc, scan_data.id, {count});
+
+    return addKernelNode(builder, "physics:candidateFill", fill_stub(),
+        MWHIP_COUNT_FIXED, (uint32_t)body_capacity, {scanned});
+#else
+    (void)builder; (void)deps;
+    MADRONA_DEVICE_STUB();
+#endif
+}
+
+// narrowphase: stage -> scan -> compact into the Contact table
+MADRONA_HOST_API inline TaskGraphNodeID setupNarrowphaseTasks(
+    TaskGraphBuilder &builder, Span<const TaskGraphNodeID> deps)
+{
+#if defined(__HIPCC__)
+    [[maybe_unused]] auto stage_stub = [] __host__ () -> const void * {
+        return (const void *)&kernels::narrowphaseKernel;
+    };
+    [[maybe_unused]] auto compact_stub = [] __host__ () -> const void * {
+        return (const void *)&kernels::contactCompactKernel;
+    };
+#else
+    auto stage_stub = []() -> const void * { return nullptr; };
+    auto compact_stub = []() -> const void * { return nullptr; };
+#endif
+
+#if MADRONA_ON_HOST
+    mwhip_exec *exec = builder.exec();
+    PhysicsScratch ps;
+    scratchHost(builder, &ps);
+
+    uint32_t cand_capacity =
+        mwhip_archetype_capacity(exec, ps.candidateArchetype);
+
+    auto stage = addKernelNode(builder, "physics:narrowphase", stage_stub(),
+        MWHIP_COUNT_FIXED, cand_capacity, deps);
+
+    mwhip_scan_params scan {};
+    scan.num_segments = 1;
+    scan.capacity = mwhip_archetype_capacity(exec, ps.contactArchetype);
+    scan.data[0] = ps.contactFlags;
+    scan.lengths[0] = numRowsAddr(exec, ps.candidateArchetype);
+    scan.total_out = numRowsAddr(exec, ps.contactArchetype);
+    scan.needs_sort_out = needsSortAddr(exec, ps.contactArchetype);
+
+    auto scan_data = builder.constructNodeData<mwhip_scan_params>(scan);
+    mwhip_node_desc scan_desc {};
+    scan_desc.kind = MWHIP_NODE_EXCLUSIVE_SCAN;
+    scan_desc.name = "physics:contactScan";
+    scan_desc.fixed_count = cand_capacity;
+    auto scanned = builder.addRuntimeNode(scan_desc, scan_data.id, {stage});
+
+    return addKernelNode(builder, "physics:contactCompact", compact_stub(),
+        MWHIP_COUNT_FIXED, cand_capacity, {scanned});
+#else
+    (void)builder; (void)deps;
+    MADRONA_DEVICE_STUB();
+#endif
+}
+
+MADRONA_HOST_API inline TaskGraphNodeID setupPostIntegrationTasks(
+    TaskGraphBuilder &builder, Span<const TaskGraphNodeID> deps)
+{
+    using namespace base;
+    using broadphase::LeafID;
+
+    auto update_leaves = builder.addToGraph<ParallelForNode<Context,
+        broadphase::updateLeafPositionsEntry,
+            LeafID, Position, Rotation, Scale, ObjectID, Velocity>>(deps);
+
+    return builder.addToGraph<ParallelForNode<Context,
+        broadphase::refitEntry, LeafID>>({update_leaves});
+}
+
+}
+
+MADRONA_HOST_API inline TaskGraphNodeID setupPhysicsStepTasks(
+    TaskGraphBuilder &builder,
+    Span<const TaskGraphNodeID> deps,
+    CountT num_substeps,
+    Solver)
+{
+    using namespace base;
+    using namespace xpbd;
+
+#if defined(__HIPCC__)
+    [[maybe_unused]] auto solve_pos_stub = [] __host__ () -> const void * {
+        return (const void *)&kernels::solvePositionsKernel;
+    };
+    [[maybe_unused]] auto solve_vel_stub = [] __host__ () -> const void * {
+        return (const void *)&kernels::solveVelocitiesKernel;
+    };
+#else
+    auto solve_pos_stub = []() -> const void * { return nullptr; };
+    auto solve_vel_stub = []() -> const void * { return nullptr; };
+#endif
+
+    auto cur_node = detail::setupCandidateTasks(builder, deps);
+
+    // joints are created / destroyed by the simulator between steps
+    cur_node = builder.addToGraph<
+        SortArchetypeNode<Joint, WorldID>>({cur_node});
+    cur_node = builder.addToGraph<ResetTmpAllocNode>({cur_node});
+
+    for (CountT i = 0; i < num_substeps; i++) {
+        auto rgb_update = builder.addToGraph<ParallelForNode<Context,
+            substepRigidBodies, Position, Rotation, Velocity, ObjectID,
+            ResponseType, ExternalForce, ExternalTorque,
+            SubstepPrevState, PreSolvePositional,
+            PreSolveVelocity>>({cur_node});
+
+        auto run_narrowphase =
+            detail::setupNarrowphaseTasks(builder, {rgb_update});
+
+        // groups contacts by world (stable, so each world keeps the CPU
+        // order) and produces the per-world ranges the solver walks
+        run_narrowphase = builder.addToGraph<
+            SortArchetypeNode<Contact, WorldID>>({run_narrowphase});
+        run_narrowphase = builder.addToGraph<ResetTmpAllocNode>(
+            {run_narrowphase});
+
+        TaskGraphNodeID solve_pos, vel_set, solve_vel;
+#if MADRONA_ON_HOST
+        solve_pos = detail::addKernelNode(builder, "physics:solvePositions",
+            solve_pos_stub(), MWHIP_COUNT_PER_WORLD, 0, {run_narrowphase});
+#endif
+
+        vel_set = builder.addToGraph<ParallelForNode<Context,
+            setVelocities, Position, Rotation,
+            SubstepPrevState, Velocity>>({solve_pos});
+
+#if MADRONA_ON_HOST
+        solve_vel = detail::addKernelNode(builder, "physics:solveVelocities",
+            solve_vel_stub(), MWHIP_COUNT_PER_WORLD, 0, {vel_set});
+#endif
+
+        auto clear_contacts = builder.addToGraph<
+            ClearTmpNode<Contact>>({solve_vel});
+
+        cur_node = builder.addToGraph<ResetTmpAllocNode>({clear_contacts});
+    }
+
+    auto clear_broadphase = builder.addToGraph<
+        ClearTmpNode<CandidateTemporary>>({cur_node});
+
+    return detail::setupPostIntegrationTasks(builder, {clear_broadphase});
+}
+
+MADRONA_HOST_API inline TaskGraphNodeID setupCleanupTasks(
+    TaskGraphBuilder &builder, Span<const TaskGraphNodeID> deps)
+{
+    return builder.addToGraph<ClearTmpNode<CollisionEventTemporary>>(deps);
+}
+
+MADRONA_HOST_API inline TaskGraphNodeID setupStandaloneBroadphaseOverlapTasks(
+    TaskGraphBuilder &builder,
+    Span<const TaskGraphNodeID> deps)
+{
+    return detail::setupCandidateTasks(builder, deps);
+}
+
+MADRONA_HOST_API inline TaskGraphNodeID setupStandaloneBroadphaseCleanupTasks(
+    TaskGraphBuilder &builder,
+    Span<const TaskGraphNodeID> deps)
+{
+    return builder.addToGraph<ClearTmpNode<CandidateTemporary>>(deps);
+}
+
+}

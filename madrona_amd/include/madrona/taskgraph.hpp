@@ -119,6 +119,7 @@ public:
 
         MADRONA_HD inline uint32_t getTaskgraphID() const { return taskgraph_id_; }
         MADRONA_HD inline StateManager &stateManager() { return *state_mgr_; }
+        MADRONA_HD inline mwhip_exec *exec() const { return exec_; }
 
         // Backend-facing: stage a fully described node.
         inline NodeID addRuntimeNode(const mwhip_node_desc &desc,

@@ -1,0 +1,810 @@
+#include "sim.hpp"
+
+#ifdef MADRONA_GPU_MODE
+#include <madrona/mw_gpu_entry.hpp>
+#endif
+
+using namespace madrona;
+using namespace madrona::math;
+using namespace madrona::phys;
+
+namespace escphys {
+
+// cos / sin of k * 2pi / 8 and of k * 2pi / 30 as literals: libm results differ
+// in the last ulp between glibc and the device math library, literals do not.
+static constexpr float kMoveSin[8] = {
+    0.f, 0.70710678f, 1.f, 0.70710678f, 0.f, -0.70710678f, -1.f, -0.70710678f,
+};
+static constexpr float kMoveCos[8] = {
+    1.f, 0.70710678f, 0.f, -0.70710678f, -1.f, -0.70710678f, 0.f, 0.70710678f,
+};
+
+static constexpr float kLidarCos[consts::numLidarSamples] = {
+    1.f, 0.9781476f, 0.91354546f, 0.80901699f, 0.66913061f, 0.5f,
+    0.30901699f, 0.10452846f, -0.10452846f, -0.30901699f, -0.5f,
+    -0.66913061f, -0.80901699f, -0.91354546f, -0.9781476f, -1.f,
+    -0.9781476f, -0.91354546f, -0.80901699f, -0.66913061f, -0.5f,
+    -0.30901699f, -0.10452846f, 0.10452846f, 0.30901699f, 0.5f,
+    0.66913061f, 0.80901699f, 0.91354546f, 0.9781476f,
+};
+static constexpr float kLidarSin[consts::numLidarSamples] = {
+    0.f, 0.20791169f, 0.40673664f, 0.58778525f, 0.74314483f, 0.8660254f,
+    0.95105652f, 0.9945219f, 0.9945219f, 0.95105652f, 0.8660254f,
+    0.74314483f, 0.58778525f, 0.40673664f, 0.20791169f, 0.f,
+    -0.20791169f, -0.40673664f, -0.58778525f, -0.74314483f, -0.8660254f,
+    -0.95105652f, -0.9945219f, -0.9945219f, -0.95105652f, -0.8660254f,
+    -0.74314483f, -0.58778525f, -0.40673664f, -0.20791169f,
+};
+
+void Sim::registerTypes(ECSRegistry &registry, const Config &)
+{
+    base::registerTypes(registry);
+    PhysicsSystem::registerTypes(registry);
+
+    registry.registerComponent<Action>();
+    registry.registerComponent<Reward>();
+    registry.registerComponent<Done>();
+    registry.registerComponent<SelfObservation>();
+    registry.registerComponent<PartnerObservation>();
+    registry.registerComponent<RoomEntityObservations>();
+    registry.registerComponent<DoorObservation>();
+    registry.registerComponent<Lidar>();
+    registry.registerComponent<StepsRemaining>();
+    registry.registerComponent<Progress>();
+    registry.registerComponent<OtherAgents>();
+    registry.registerComponent<GrabState>();
+    registry.registerComponent<EntityType>();
+    registry.registerComponent<OpenState>();
+    registry.registerComponent<DoorProperties>();
+    registry.registerComponent<ButtonState>();
+
+    registry.registerSingleton<WorldReset>();
+    registry.registerSingleton<LevelState>();
+
+    registry.registerArchetype<Agent>();
+    registry.registerArchetype<PhysicsEntity>();
+    registry.registerArchetype<DoorEntity>();
+    registry.registerArchetype<ButtonEntity>();
+
+    registry.exportSingleton<WorldReset>((uint32_t)ExportID::Reset);
+    registry.exportColumn<Agent, Action>((uint32_t)ExportID::Action);
+    registry.exportColumn<Agent, Reward>((uint32_t)ExportID::Reward);
+    registry.exportColumn<Agent, Done>((uint32_t)ExportID::Done);
+    registry.exportColumn<Agent, SelfObservation>(
+        (uint32_t)ExportID::SelfObservation);
+    registry.exportColumn<Agent, PartnerObservation>(
+        (uint32_t)ExportID::PartnerObservation);
+    registry.exportColumn<Agent, RoomEntityObservations>(
+        (uint32_t)ExportID::RoomEntityObservations);
+    registry.exportColumn<Agent, DoorObservation>(
+        (uint32_t)ExportID::DoorObservation);
+    registry.exportColumn<Agent, Lidar>((uint32_t)ExportID::Lidar);
+    registry.exportColumn<Agent, StepsRemaining>(
+        (uint32_t)ExportID::StepsRemaining);
+}
+
+// ---------------------------------------------------------------------------
+// level generation
+// ---------------------------------------------------------------------------
+static inline float randInRange(RNG &rng, float lo, float hi)
+{
+    return lo + rng.sampleUniform() * (hi - lo);
+}
+
+// Fills the RigidBody bundle and (re)registers the body with the broadphase.
+static inline void setupRigidBody(Engine &ctx, Entity e, Vector3 pos, Quat rot,
+                                  SimObject obj, EntityType type,
+                                  ResponseType response, Diag3x3 scale)
+{
+    ObjectID obj_id { (int32_t)obj };
+
+    ctx.get<Position>(e) = pos;
+    ctx.get<Rotation>(e) = rot;
+    ctx.get<Scale>(e) = scale;
+    ctx.get<ObjectID>(e) = obj_id;
+    ctx.get<ResponseType>(e) = response;
+    ctx.get<Velocity>(e) = Velocity { Vector3::zero(), Vector3::zero() };
+    ctx.get<ExternalForce>(e) = Vector3::zero();
+    ctx.get<ExternalTorque>(e) = Vector3::zero();
+    ctx.get<broadphase::LeafID>(e) =
+        PhysicsSystem::registerEntity(ctx, e, obj_id);
+    ctx.get<EntityType>(e) = type;
+}
+
+static inline void registerRigidBodyEntity(Engine &ctx, Entity e)
+{
+    ctx.get<broadphase::LeafID>(e) =
+        PhysicsSystem::registerEntity(ctx, e, ctx.get<ObjectID>(e));
+}
+
+static Entity makeWall(Engine &ctx, float x_min, float x_max, float y)
+{
+    Entity wall = ctx.makeEntity<PhysicsEntity>();
+    setupRigidBody(ctx, wall,
+        Vector3 { (x_min + x_max) * 0.5f, y, consts::wallHeight * 0.5f },
+        Quat { 1, 0, 0, 0 }, SimObject::Wall, EntityType::Wall,
+        ResponseType::Static,
+        Diag3x3 { x_max - x_min, consts::wallWidth, consts::wallHeight });
+    return wall;
+}
+
+static void generateLevel(Engine &ctx)
+{
+    Sim &sim = ctx.data();
+    LevelState &level = ctx.singleton<LevelState>();
+    RNG &rng = sim.rng;
+
+    const float half_width = consts::worldWidth / 2.f;
+
+    for (int32_t r = 0; r < consts::numRooms; r++) {
+        Room &room = level.rooms[r];
+        const float y_min = (float)r * consts::roomLength;
+        const float y_max = y_min + consts::roomLength;
+
+        for (int32_t b = 0; b < consts::numButtonsPerRoom; b++) {
+            Entity button = ctx.makeEntity<ButtonEntity>();
+            Vector3 pos {
+                randInRange(rng, -half_width + 2.f, half_width - 2.f),
+                randInRange(rng, y_min + 2.f, y_max - 3.f),
+                0.f,
+            };
+            ctx.get<Position>(button) = pos;
+            ctx.get<Rotation>(button) = Quat { 1, 0, 0, 0 };
+            ctx.get<Scale>(button) = Diag3x3 {
+                consts::buttonWidth, consts::buttonWidth, 0.2f,
+            };
+            ctx.get<ObjectID>(button) = ObjectID { (int32_t)SimObject::Button };
+            ctx.get<ButtonState>(button).isPressed = 0;
+            ctx.get<EntityType>(button) = EntityType::Button;
+            room.buttons[b] = button;
+        }
+
+        // wall with a door gap
+        float door_x = randInRange(rng, -half_width + 4.f, half_width - 4.f);
+        room.walls[0] = makeWall(ctx, -half_width,
+                                 door_x - consts::doorWidth * 0.5f, y_max);
+        room.walls[1] = makeWall(ctx, door_x + consts::doorWidth * 0.5f,
+                                 half_width, y_max);
+
+        Entity door = ctx.makeEntity<DoorEntity>();
+        setupRigidBody(ctx, door, Vector3 { door_x, y_max, 0.f },
+            Quat { 1, 0, 0, 0 }, SimObject::Door, EntityType::Door,
+            ResponseType::Static,
+            Diag3x3 { consts::doorWidth * 0.8f, consts::wallWidth,
+                      2.f * consts::wallHeight });
+        ctx.get<OpenState>(door).isOpen = 0;
+        DoorProperties &props = ctx.get<DoorProperties>(door);
+        for (int32_t b = 0; b < 4; b++) {
+            props.buttons[b] = b < consts::numButtonsPerRoom ?
+                room.buttons[b] : Entity::none();
+        }
+        props.numButtons = 1 + rng.sampleI32(0, consts::numButtonsPerRoom);
+        props.isPersistent = rng.sampleBool() ? 1 : 0;
+        room.door = door;
+
+        for (int32_t c = 0; c < consts::numCubesPerRoom; c++) {
+            Entity cube = ctx.makeEntity<PhysicsEntity>();
+            Vector3 pos {
+                randInRange(rng, -half_width + 1.5f, half_width - 1.5f),
+                randInRange(rng, y_min + 4.f, y_max - 2.5f),
+                consts::cubeSize * 0.5f,
+            };
+            setupRigidBody(ctx, cube, pos, Quat { 1, 0, 0, 0 },
+                SimObject::Cube, EntityType::Cube, ResponseType::Dynamic,
+                Diag3x3 { consts::cubeSize, consts::cubeSize,
+                          consts::cubeSize });
+            room.cubes[c] = cube;
+        }
+    }
+}
+
+static void resetPersistentEntities(Engine &ctx)
+{
+    Sim &sim = ctx.data();
+    RNG &rng = sim.rng;
+    const float half_width = consts::worldWidth / 2.f;
+
+    registerRigidBodyEntity(ctx, sim.floorPlane);
+    for (int32_t i = 0; i < consts::numBorderWalls; i++) {
+        registerRigidBodyEntity(ctx, sim.borders[i]);
+    }
+
+    for (int32_t i = 0; i < consts::numAgents; i++) {
+        Entity agent = sim.agents[i];
+        registerRigidBodyEntity(ctx, agent);
+
+        // agents start in their own half so they never spawn interpenetrating
+        float x_lo = i == 0 ? -half_width + 2.f : 1.5f;
+        float x_hi = i == 0 ? -1.5f : half_width - 2.f;
+        Vector3 pos {
+            randInRange(rng, x_lo, x_hi),
+            randInRange(rng, 1.5f, 3.f),
+            1.f,
+        };
+        // heading: rotation about z by one of the 8 move angles; half-angle
+        // terms from the tables via the half-angle identities (libm free)
+        int32_t heading = rng.sampleI32(0, 8);
+        float c = kMoveCos[heading];
+        float s = kMoveSin[heading];
+        float ch = sqrtf((1.f + c) * 0.5f);
+        float sh = sqrtf((1.f - c) * 0.5f);
+        if (s < 0.f) sh = -sh;
+        Quat rot = Quat { ch, 0.f, 0.f, sh }.normalize();
+
+        ctx.get<Position>(agent) = pos;
+        ctx.get<Rotation>(agent) = rot;
+        ctx.get<Velocity>(agent) = Velocity { Vector3::zero(), Vector3::zero() };
+        ctx.get<ExternalForce>(agent) = Vector3::zero();
+        ctx.get<ExternalTorque>(agent) = Vector3::zero();
+        ctx.get<Action>(agent) = Action { 0, 0, 0, 0 };
+        ctx.get<Progress>(agent).maxY = pos.y;
+        ctx.get<StepsRemaining>(agent).t = consts::episodeLen;
+        ctx.get<GrabState>(agent).constraintEntity = Entity::none();
+        ctx.get<Reward>(agent).v = 0.f;
+        ctx.get<Done>(agent).v = 0;
+    }
+}
+
+static void createPersistentEntities(Engine &ctx)
+{
+    Sim &sim = ctx.data();
+    const float half_width = consts::worldWidth / 2.f;
+    const float w = consts::wallWidth;
+
+    sim.floorPlane = ctx.makeEntity<PhysicsEntity>();
+    setupRigidBody(ctx, sim.floorPlane, Vector3 { 0, 0, 0 },
+        Quat { 1, 0, 0, 0 }, SimObject::Plane, EntityType::None,
+        ResponseType::Static, Diag3x3 { 1, 1, 1 });
+
+    // back, front, left, right
+    const Vector3 border_pos[consts::numBorderWalls] = {
+        { 0.f, -w * 0.5f, consts::wallHeight * 0.5f },
+        { 0.f, consts::worldLength + 1.5f * w, consts::wallHeight * 0.5f },
+        { -half_width - w * 0.5f, consts::worldLength * 0.5f,
+          consts::wallHeight * 0.5f },
+        { half_width + w * 0.5f, consts::worldLength * 0.5f,
+          consts::wallHeight * 0.5f },
+    };
+    const Diag3x3 border_scale[consts::numBorderWalls] = {
+        { consts::worldWidth + 2.f * w, w, consts::wallHeight },
+        { consts::worldWidth + 2.f * w, w, consts::wallHeight },
+        { w, consts::worldLength + 4.f * w, consts::wallHeight },
+        { w, consts::worldLength + 4.f * w, consts::wallHeight },
+    };
+    for (int32_t i = 0; i < consts::numBorderWalls; i++) {
+        sim.borders[i] = ctx.makeEntity<PhysicsEntity>();
+        setupRigidBody(ctx, sim.borders[i], border_pos[i],
+            Quat { 1, 0, 0, 0 }, SimObject::Wall, EntityType::Wall,
+            ResponseType::Static, border_scale[i]);
+    }
+
+    for (int32_t i = 0; i < consts::numAgents; i++) {
+        Entity agent = ctx.makeEntity<Agent>();
+        sim.agents[i] = agent;
+
+        setupRigidBody(ctx, agent, Vector3 { 0, 0, 1.f }, Quat { 1, 0, 0, 0 },
+            SimObject::Agent, EntityType::Agent, ResponseType::Dynamic,
+            Diag3x3 { 1.5f, 1.5f, 2.f });
+    }
+
+    for (int32_t i = 0; i < consts::numAgents; i++) {
+        OtherAgents &others = ctx.get<OtherAgents>(sim.agents[i]);
+        int32_t out = 0;
+        for (int32_t j = 0; j < consts::numAgents; j++) {
+            if (j != i) {
+                others.e[out++] = sim.agents[j];
+            }
+        }
+    }
+}
+
+static void initWorld(Engine &ctx)
+{
+    Sim &sim = ctx.data();
+
+    // every body re-registers with an emptied BVH (rebuilt on the next update)
+    PhysicsSystem::reset(ctx);
+
+    // a fresh RNG stream per (world, episode)
+    sim.rng = RNG(rand::split_i(sim.initRandKey, sim.curWorldEpisode++));
+
+    resetPersistentEntities(ctx);
+    generateLevel(ctx);
+}
+
+static void cleanupWorld(Engine &ctx)
+{
+    Sim &sim = ctx.data();
+    for (int32_t i = 0; i < consts::numAgents; i++) {
+        GrabState &grab = ctx.get<GrabState>(sim.agents[i]);
+        if (grab.constraintEntity != Entity::none()) {
+            ctx.destroyEntity(grab.constraintEntity);
+            grab.constraintEntity = Entity::none();
+        }
+    }
+
+    LevelState &level = ctx.singleton<LevelState>();
+    for (int32_t r = 0; r < consts::numRooms; r++) {
+        Room &room = level.rooms[r];
+        for (int32_t c = 0; c < consts::numCubesPerRoom; c++) {
+            ctx.destroyEntity(room.cubes[c]);
+        }
+        ctx.destroyEntity(room.walls[0]);
+        ctx.destroyEntity(room.walls[1]);
+        ctx.destroyEntity(room.door);
+        for (int32_t b = 0; b < consts::numButtonsPerRoom; b++) {
+            ctx.destroyEntity(room.buttons[b]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// systems
+// ---------------------------------------------------------------------------
+inline void movementSystem(Engine &,
+                           Action &action,
+                           Rotation &rot,
+                           ExternalForce &external_force,
+                           ExternalTorque &external_torque)
+{
+    constexpr float move_max = 1000.f;
+    constexpr float turn_max = 320.f;
+
+    Quat cur_rot = rot;
+
+    float move_amount = (float)action.moveAmount *
+        (move_max / (float)(consts::numMoveAmountBuckets - 1));
+
+    int32_t angle = action.moveAngle & (consts::numMoveAngleBuckets - 1);
+    float f_x = move_amount * kMoveSin[angle];
+    float f_y = move_amount * kMoveCos[angle];
+
+    constexpr float turn_delta_per_bucket =
+        turn_max / (float)(consts::numTurnBuckets / 2);
+    float t_z = turn_delta_per_bucket * (float)action.rotate;
+
+    external_force = cur_rot.rotateVec(Vector3 { f_x, f_y, 0.f });
+    external_torque = Vector3 { 0.f, 0.f, t_z };
+}
+
+// Grab / release the cube in front of each agent with a fixed joint.  One
+// invocation per world, agents in order: entity creation order inside a world
+// is then the same on every backend (parallel per-agent creation would make
+// joint ids depend on scheduling).
+inline void grabSystem(Engine &ctx, LevelState &)
+{
+    Sim &sim = ctx.data();
+
+    for (int32_t i = 0; i < consts::numAgents; i++) {
+        Entity e = sim.agents[i];
+        if (ctx.get<Action>(e).grab == 0) {
+            continue;
+        }
+
+        GrabState &grab = ctx.get<GrabState>(e);
+        if (grab.constraintEntity != Entity::none()) {
+            ctx.destroyEntity(grab.constraintEntity);
+            grab.constraintEntity = Entity::none();
+            continue;
+        }
+
+        Vector3 pos = ctx.get<Position>(e);
+        Quat rot = ctx.get<Rotation>(e);
+
+        Vector3 reach = pos + rot.rotateVec(Vector3 { 0.f, 1.75f, 0.f });
+        AABB reach_box {
+            reach - Vector3 { 1.f, 1.f, 1.f },
+            reach + Vector3 { 1.f, 1.f, 1.f },
+        };
+
+        Entity grab_entity = Entity::none();
+        PhysicsSystem::findEntitiesWithinAABB(ctx, reach_box,
+            [&](Entity other) {
+                if (grab_entity != Entity::none()) {
+                    return;
+                }
+                if (ctx.get<EntityType>(other) == EntityType::Cube) {
+                    grab_entity = other;
+                }
+            });
+
+        if (grab_entity == Entity::none()) {
+            continue;
+        }
+
+        Vector3 other_pos = ctx.get<Position>(grab_entity);
+        Quat other_rot = ctx.get<Rotation>(grab_entity);
+
+        Vector3 r1 = Vector3 { 0.f, 1.25f, 0.f };
+        Vector3 r2 = Vector3::zero();
+        Quat attach1 { 1, 0, 0, 0 };
+        Quat attach2 = (other_rot.inv() * rot).normalize();
+        float separation = (other_pos - pos).length() - 1.25f;
+
+        grab.constraintEntity = PhysicsSystem::makeFixedJoint(
+            ctx, e, grab_entity, attach1, attach2, r1, r2, separation);
+    }
+}
+
+// agents stop dead every step: removes the need for drag
+inline void agentZeroVelSystem(Engine &,
+                               Velocity &vel,
+                               Action &)
+{
+    vel.linear.x = 0.f;
+    vel.linear.y = 0.f;
+    vel.linear.z = fminf(vel.linear.z, 0.f);
+
+    vel.angular = Vector3::zero();
+}
+
+inline void buttonSystem(Engine &ctx,
+                         Position &pos,
+                         ButtonState &state)
+{
+    const Sim &sim = ctx.data();
+
+    bool pressed = false;
+    for (int32_t i = 0; i < consts::numAgents; i++) {
+        Vector3 agent_pos = ctx.get<Position>(sim.agents[i]);
+        float dx = fabsf(agent_pos.x - pos.x);
+        float dy = fabsf(agent_pos.y - pos.y);
+        if (dx < consts::buttonWidth && dy < consts::buttonWidth) {
+            pressed = true;
+        }
+    }
+
+    state.isPressed = pressed ? 1 : 0;
+}
+
+inline void doorOpenSystem(Engine &ctx,
+                           OpenState &open_state,
+                           const DoorProperties &props)
+{
+    bool all_pressed = true;
+    for (int32_t i = 0; i < props.numButtons; i++) {
+        Entity button = props.buttons[i];
+        all_pressed = all_pressed && ctx.get<ButtonState>(button).isPressed != 0;
+    }
+
+    if (all_pressed) {
+        open_state.isOpen = 1;
+    } else if (props.isPersistent == 0) {
+        open_state.isOpen = 0;
+    }
+}
+
+inline void setDoorPositionSystem(Engine &,
+                                  Position &pos,
+                                  OpenState &open_state)
+{
+    if (open_state.isOpen != 0) {
+        if (pos.z > -4.5f) {
+            pos.z += -consts::doorSpeed * consts::deltaT;
+        }
+    } else if (pos.z < 0.f) {
+        pos.z += consts::doorSpeed * consts::deltaT;
+    }
+
+    if (pos.z >= 0.f) {
+        pos.z = 0.f;
+    }
+}
+
+inline void rewardSystem(Engine &,
+                         Position &pos,
+                         Progress &progress,
+                         Reward &out_reward)
+{
+    float reward_pos = fminf(pos.y, consts::worldLength * 2.f);
+
+    float old_max_y = progress.maxY;
+    float new_progress = reward_pos - old_max_y;
+
+    float reward;
+    if (new_progress > 0.f) {
+        reward = new_progress * consts::rewardPerDist;
+        progress.maxY = reward_pos;
+    } else {
+        reward = consts::slackReward;
+    }
+
+    out_reward.v = reward;
+}
+
+inline void stepTrackerSystem(Engine &,
+                              StepsRemaining &steps_remaining,
+                              Done &done)
+{
+    int32_t num_remaining = (int32_t)--steps_remaining.t;
+    if (num_remaining == consts::episodeLen - 1) {
+        done.v = 0;
+    } else if (num_remaining == 0) {
+        done.v = 1;
+    }
+}
+
+inline void resetSystem(Engine &ctx, WorldReset &reset)
+{
+    Sim &sim = ctx.data();
+
+    int32_t should_reset = reset.reset;
+
+    for (int32_t i = 0; i < consts::numAgents; i++) {
+        if (ctx.get<Done>(sim.agents[i]).v != 0) {
+            should_reset = 1;
+        }
+    }
+
+    if (sim.autoResetDenom != 0) {
+        if (sim.resetRng.sampleI32(0, (int32_t)sim.autoResetDenom) == 0) {
+            should_reset = 1;
+        }
+    }
+
+    if (should_reset != 0) {
+        reset.reset = 0;
+        cleanupWorld(ctx);
+        initWorld(ctx);
+    }
+}
+
+inline void collectObservationsSystem(Engine &ctx,
+                                      Position &pos,
+                                      Rotation &rot,
+                                      const Progress &progress,
+                                      const GrabState &grab,
+                                      const OtherAgents &other_agents,
+                                      SelfObservation &self_obs,
+                                      PartnerObservation &partner_obs,
+                                      RoomEntityObservations &room_ent_obs,
+                                      DoorObservation &door_obs)
+{
+    const LevelState &level = ctx.singleton<LevelState>();
+
+    int32_t room_idx = (int32_t)(pos.y / consts::roomLength);
+    if (room_idx < 0) room_idx = 0;
+    if (room_idx > consts::numRooms - 1) room_idx = consts::numRooms - 1;
+    const Room &room = level.rooms[room_idx];
+
+    const float room_y_min = (float)room_idx * consts::roomLength;
+
+    self_obs.roomX = pos.x / (consts::worldWidth / 2.f);
+    self_obs.roomY = (pos.y - room_y_min) / consts::roomLength;
+    self_obs.globalX = pos.x / consts::worldWidth;
+    self_obs.globalY = pos.y / consts::worldLength;
+    self_obs.globalZ = pos.z / 10.f;
+    self_obs.maxY = progress.maxY / consts::worldLength;
+    self_obs.facing = rot.z;
+    self_obs.isGrabbing =
+        grab.constraintEntity != Entity::none() ? 1.f : 0.f;
+
+    Quat to_view = rot.inv();
+
+    {
+        Entity other = other_agents.e[0];
+        Vector3 other_pos = ctx.get<Position>(other);
+        Vector3 rel = to_view.rotateVec(other_pos - pos);
+        partner_obs.dx = rel.x / consts::worldLength;
+        partner_obs.dy = rel.y / consts::worldLength;
+        partner_obs.isGrabbing =
+            ctx.get<GrabState>(other).constraintEntity != Entity::none() ?
+                1.f : 0.f;
+    }
+
+    int32_t out = 0;
+    for (int32_t c = 0; c < consts::numCubesPerRoom; c++) {
+        Entity e = room.cubes[c];
+        Vector3 rel = to_view.rotateVec(ctx.get<Position>(e) - pos);
+        room_ent_obs.obs[out++] = EntityObservation {
+            rel.x / consts::worldLength, rel.y / consts::worldLength,
+            (float)ctx.get<EntityType>(e) / (float)EntityType::NumTypes,
+        };
+    }
+    for (int32_t b = 0; b < consts::numButtonsPerRoom; b++) {
+        Entity e = room.buttons[b];
+        Vector3 rel = to_view.rotateVec(ctx.get<Position>(e) - pos);
+        room_ent_obs.obs[out++] = EntityObservation {
+            rel.x / consts::worldLength, rel.y / consts::worldLength,
+            (float)ctx.get<EntityType>(e) / (float)EntityType::NumTypes,
+        };
+    }
+    room_ent_obs.obs[out] = EntityObservation { 0.f, 0.f, 0.f };
+
+    {
+        Entity door = room.door;
+        Vector3 rel = to_view.rotateVec(ctx.get<Position>(door) - pos);
+        door_obs.dx = rel.x / consts::worldLength;
+        door_obs.dy = rel.y / consts::worldLength;
+        door_obs.isOpen = ctx.get<OpenState>(door).isOpen != 0 ? 1.f : 0.f;
+    }
+}
+
+// Analytic stand-in for the BVH ray cast: distance along each of 30 view rays
+// to the arena walls and to the other agent (circle).
+inline void lidarSystem(Engine &ctx,
+                        Entity e,
+                        Lidar &lidar)
+{
+    Vector3 pos = ctx.get<Position>(e);
+    Quat rot = ctx.get<Rotation>(e);
+    Vector3 other_pos = ctx.get<Position>(ctx.get<OtherAgents>(e).e[0]);
+
+    const float x_lim = consts::worldWidth / 2.f;
+
+    for (int32_t i = 0; i < consts::numLidarSamples; i++) {
+        Vector3 dir = rot.rotateVec(
+            Vector3 { kLidarCos[i], kLidarSin[i], 0.f });
+
+        float t_hit = 200.f;
+        float hit_type = (float)EntityType::None;
+
+        // walls
+        if (dir.x > 1e-6f) {
+            float t = (x_lim - pos.x) / dir.x;
+            if (t < t_hit) { t_hit = t; hit_type = (float)EntityType::Wall; }
+        } else if (dir.x < -1e-6f) {
+            float t = (-x_lim - pos.x) / dir.x;
+            if (t < t_hit) { t_hit = t; hit_type = (float)EntityType::Wall; }
+        }
+        if (dir.y > 1e-6f) {
+            float t = (consts::worldLength - pos.y) / dir.y;
+            if (t < t_hit) { t_hit = t; hit_type = (float)EntityType::Wall; }
+        } else if (dir.y < -1e-6f) {
+            float t = (0.f - pos.y) / dir.y;
+            if (t < t_hit) { t_hit = t; hit_type = (float)EntityType::Wall; }
+        }
+
+        // other agent: |pos + t dir - c|^2 = r^2
+        Vector3 oc = pos - other_pos;
+        float b = 2.f * (oc.x * dir.x + oc.y * dir.y);
+        float c = oc.x * oc.x + oc.y * oc.y -
+            consts::agentRadius * consts::agentRadius;
+        float t1, t2;
+        if (solveQuadraticUnsafe(1.f, b, c, &t1, &t2)) {
+            if (t1 > 0.f && t1 < t_hit) {
+                t_hit = t1;
+                hit_type = (float)EntityType::Agent;
+            }
+        }
+
+        lidar.samples[i] = LidarSample {
+            t_hit / 200.f,
+            hit_type / (float)EntityType::NumTypes,
+        };
+    }
+}
+
+void Sim::setupTasks(TaskGraphManager &taskgraph_mgr, const Config &)
+{
+    TaskGraphBuilder &builder = taskgraph_mgr.init(0);
+
+    auto move_sys = builder.addToGraph<ParallelForNode<Engine,
+        movementSystem,
+            Action,
+            Rotation,
+            ExternalForce,
+            ExternalTorque
+        >>({});
+
+    auto broadphase_setup_sys =
+        PhysicsSystem::setupBroadphaseTasks(builder, {move_sys});
+
+    auto grab_sys = builder.addToGraph<ParallelForNode<Engine,
+        grabSystem,
+            LevelState
+        >>({broadphase_setup_sys});
+
+    auto substep_sys = PhysicsSystem::setupPhysicsStepTasks(builder,
+        {grab_sys}, consts::numPhysicsSubsteps);
+
+    auto agent_zero_vel = builder.addToGraph<ParallelForNode<Engine,
+        agentZeroVelSystem,
+            Velocity,
+            Action
+        >>({substep_sys});
+
+    auto phys_done =
+        PhysicsSystem::setupCleanupTasks(builder, {agent_zero_vel});
+
+    auto button_sys = builder.addToGraph<ParallelForNode<Engine,
+        buttonSystem,
+            Position,
+            ButtonState
+        >>({phys_done});
+
+    auto door_open_sys = builder.addToGraph<ParallelForNode<Engine,
+        doorOpenSystem,
+            OpenState,
+            DoorProperties
+        >>({button_sys});
+
+    auto set_door_pos_sys = builder.addToGraph<ParallelForNode<Engine,
+        setDoorPositionSystem,
+            Position,
+            OpenState
+        >>({door_open_sys});
+
+    auto reward_sys = builder.addToGraph<ParallelForNode<Engine,
+        rewardSystem,
+            Position,
+            Progress,
+            Reward
+        >>({set_door_pos_sys});
+
+    auto done_sys = builder.addToGraph<ParallelForNode<Engine,
+        stepTrackerSystem,
+            StepsRemaining,
+            Done
+        >>({reward_sys});
+
+    auto reset_sys = builder.addToGraph<ParallelForNode<Engine,
+        resetSystem,
+            WorldReset
+        >>({done_sys});
+
+#ifdef MADRONA_GPU_MODE
+    auto recycle_sys = builder.addToGraph<RecycleEntitiesNode>({reset_sys});
+    auto post_reset = recycle_sys;
+#else
+    auto post_reset = reset_sys;
+#endif
+
+    auto compact_cubes = builder.addToGraph<
+        CompactArchetypeNode<PhysicsEntity>>({post_reset});
+    auto compact_doors = builder.addToGraph<
+        CompactArchetypeNode<DoorEntity>>({compact_cubes});
+    auto compact_buttons = builder.addToGraph<
+        CompactArchetypeNode<ButtonEntity>>({compact_doors});
+
+    // a reset world needs its BVH before observations / the next step
+    auto post_reset_broadphase =
+        PhysicsSystem::setupBroadphaseTasks(builder, {compact_buttons});
+
+    auto collect_obs = builder.addToGraph<ParallelForNode<Engine,
+        collectObservationsSystem,
+            Position,
+            Rotation,
+            Progress,
+            GrabState,
+            OtherAgents,
+            SelfObservation,
+            PartnerObservation,
+            RoomEntityObservations,
+            DoorObservation
+        >>({post_reset_broadphase});
+
+    auto lidar = builder.addToGraph<ParallelForNode<Engine,
+        lidarSystem,
+            Entity,
+            Lidar
+        >>({collect_obs});
+
+    (void)lidar;
+}
+
+Sim::Sim(Engine &ctx, const Config &cfg, const WorldInit &)
+    : WorldBase(ctx)
+{
+    uint32_t global_world = cfg.worldBase + (uint32_t)ctx.worldID().idx;
+
+    initRandKey = rand::split_i(rand::initKey(cfg.seed), global_world);
+    resetRng = RNG(rand::split_i(initRandKey, 0x7E5E7u));
+    curWorldEpisode = 0;
+    autoResetDenom = cfg.autoResetDenom;
+
+    ctx.singleton<WorldReset>().reset = 0;
+
+    PhysicsSystem::init(ctx, cfg.rigidBodyObjMgr, consts::deltaT,
+        consts::numPhysicsSubsteps, -9.8f * math::up,
+        consts::maxRigidBodies);
+
+    createPersistentEntities(ctx);
+    initWorld(ctx);
+}
+
+#ifdef MADRONA_GPU_MODE
+MADRONA_BUILD_MWGPU_ENTRY(Engine, Sim, Sim::Config, Sim::WorldInit);
+#endif
+
+}
