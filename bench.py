@@ -39,7 +39,8 @@ def parse_args():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=2000)
     p.add_argument("--warmup", type=int, default=200)
-    p.add_argument("--worlds", type=int, default=4096, help="worlds per GPU")
+    p.add_argument("--worlds", type=int, default=0,
+                   help="worlds per GPU (default: 4096, or 8192 for escape_room_phys)")
     p.add_argument("--sim", default="escape_room")
     p.add_argument("--auto-reset-denom", type=int, default=200)
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -72,8 +73,20 @@ def cpu_baseline(sim, worlds, flags, seed, budget_s=12.0):
     }
 
 
+WORKLOADS = {
+    "escape_room": (4096, "Escape-Room-shaped ECS (physics off), {w} worlds per GPU "
+                          "(BASELINE.json configs[1]), 29 entity rows/world"),
+    "escape_room_phys": (8192, "Escape-Room + XPBD rigid body + LBVH broadphase, {w} "
+                               "worlds per GPU (BASELINE.json configs[2]), 28 rigid "
+                               "bodies + 6 buttons/world, 4 substeps, grab joints"),
+}
+
+
 def main():
     args = parse_args()
+    default_worlds, workload_fmt = WORKLOADS.get(args.sim, (4096, args.sim + ", {w} worlds"))
+    if args.worlds <= 0:
+        args.worlds = default_worlds
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -116,6 +129,8 @@ def main():
         torch.randint(0, 4, (W, 2), device="cuda", generator=gen),
         torch.randint(0, 8, (W, 2), device="cuda", generator=gen),
         torch.randint(-2, 3, (W, 2), device="cuda", generator=gen),
+        torch.randint(0, 2, (W, 2), device="cuda", generator=gen)
+        if args.sim == "escape_room_phys" else
         torch.zeros((W, 2), device="cuda", dtype=torch.int64),
     ], -1).to(torch.int32))
     torch.cuda.synchronize()
@@ -199,9 +214,8 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"Escape-Room-shaped ECS (physics off), {args.worlds} worlds "
-                            f"per GPU (BASELINE.json configs[1]), 29 entity rows/world, "
-                            f"auto-reset p=1/{args.auto_reset_denom} per world per step",
+                "workload": workload_fmt.format(w=args.worlds) +
+                            f", auto-reset p=1/{args.auto_reset_denom} per world per step",
                 "sim": args.sim,
                 "worlds_per_gpu": args.worlds,
                 "total_worlds": total_worlds,

@@ -116,6 +116,7 @@ int mwhip_raw_copy_d2h(int gpu_id, void *dst_host, const void *src_device,
 /* Small table of module-private device pointers inside ecs_state
  * (ecs_state::moduleData[slot], slot < 4); e.g. the physics module's scratch. */
 int mwhip_set_module_data(mwhip_exec *exec, uint32_t slot, void *device_ptr);
+void *mwhip_get_module_data(mwhip_exec *exec, uint32_t slot);
 /* rows every column of the archetype's table can hold */
 uint32_t mwhip_archetype_capacity(mwhip_exec *exec, uint32_t archetype_id);
 /* device address of the archetype's table header (mwhip::TableHdr) */

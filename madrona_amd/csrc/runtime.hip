@@ -731,6 +731,11 @@ extern "C" int mwhip_set_module_data(mwhip_exec *exec, uint32_t slot,
     return 0;
 }
 
+extern "C" void *mwhip_get_module_data(mwhip_exec *exec, uint32_t slot)
+{
+    return slot < 4 ? exec->hostState.moduleData[slot] : nullptr;
+}
+
 extern "C" uint32_t mwhip_archetype_capacity(mwhip_exec *exec,
                                              uint32_t archetype_id)
 {

@@ -53,18 +53,21 @@ struct PhysicsScratch {
 
 namespace detail {
 
-#if MADRONA_ON_HOST
 // per-world row budget of the physics temporaries, overridable from the
 // environment (tables hold 2x the hint per world)
-inline CountT capacityHint(const char *env_name, CountT fallback)
+MADRONA_HOST_API inline CountT capacityHint(const char *env_name,
+                                            CountT fallback)
 {
+#if MADRONA_ON_HOST
     const char *v = getenv(env_name);
     if (v != nullptr && atol(v) > 0) {
         return (CountT)atol(v);
     }
+#else
+    (void)env_name;
+#endif
     return fallback;
 }
-#endif
 
 MADRONA_HD inline PhysicsScratch *scratch(mwhip::EcsState *S)
 {
@@ -835,7 +838,13 @@ MADRONA_HD inline void findEntitiesWithinAABB(Context &ctx,
                                               math::AABB aabb,
                                               Fn &&fn)
 {
-    ctx.singleton<broadphase::BVH>().findIntersecting(aabb, fn);
+    // BVH boxes are conservative (expanded for motion): confirm against the
+    // body's actual hull extents (reference physics.inl:8-24)
+    ctx.singleton<broadphase::BVH>().findIntersecting(aabb, [&](Entity e) {
+        if (checkEntityAABBOverlap(ctx, aabb, e)) {
+            fn(e);
+        }
+    });
 }
 
 MADRONA_HD inline bool checkEntityAABBOverlap(Context &ctx,
@@ -964,9 +973,14 @@ MADRONA_HOST_API inline void registerTypes(ECSRegistry &registry, Solver solver)
     if (solver != Solver::XPBD) {
         FATAL("madrona_amd physics: only the XPBD solver is available");
     }
+#else
+    (void)solver;
+#endif
 
     // Same order as the reference (physics.cpp:308-341, xpbd.cpp:1046-1060):
-    // singleton registration order fixes singleton entity ids.
+    // singleton registration order fixes singleton entity ids.  (Not inside a
+    // host-only block: the device pass instantiates the per-type id symbols
+    // from these calls.)
     registry.registerComponent<ResponseType>();
     registry.registerComponent<broadphase::LeafID>();
     registry.registerComponent<Velocity>();
@@ -1005,10 +1019,6 @@ MADRONA_HOST_API inline void registerTypes(ECSRegistry &registry, Solver solver)
     registry.registerBundleAlias<SolverBundleAlias, xpbd::XPBDRigidBodyState>();
 
     registry.registerBundle<RigidBody>();
-#else
-    (void)registry; (void)solver;
-    MADRONA_DEVICE_STUB();
-#endif
 }
 
 MADRONA_HOST_API inline TaskGraphNodeID setupBroadphaseTasks(
@@ -1038,15 +1048,13 @@ namespace detail {
 inline PhysicsScratch *scratchHost(TaskGraphBuilder &builder,
                                    PhysicsScratch *host_copy_out)
 {
-    // one scratch block per executor, shared by every graph that has physics
-    static thread_local mwhip_exec *cached_exec = nullptr;
-    static thread_local PhysicsScratch *cached_dev = nullptr;
-    static thread_local PhysicsScratch cached_host {};
-
+    // one scratch block per executor (kept in the executor's module slot 0),
+    // shared by every graph that has physics
     mwhip_exec *exec = builder.exec();
-    if (cached_exec == exec) {
-        *host_copy_out = cached_host;
-        return cached_dev;
+    if (void *existing = mwhip_get_module_data(exec, 0)) {
+        mwhip::check(mwhip_memcpy_d2h(host_copy_out, existing,
+                                      sizeof(PhysicsScratch)), "memcpy_d2h");
+        return (PhysicsScratch *)existing;
     }
 
     StateManager &state_mgr = builder.stateManager();
@@ -1095,9 +1103,6 @@ inline PhysicsScratch *scratchHost(TaskGraphBuilder &builder,
                  "memcpy_h2d");
     mwhip::check(mwhip_set_module_data(exec, 0, dev), "set_module_data");
 
-    cached_exec = exec;
-    cached_dev = dev;
-    cached_host = ps;
     *host_copy_out = ps;
     return dev;
 }
@@ -1311,8 +1316,23 @@ MADRONA_HOST_API inline TaskGraphNodeID setupPhysicsStepTasks(
             solve_vel_stub(), MWHIP_COUNT_PER_WORLD, 0, {vel_set});
 #endif
 
-        auto clear_contacts = builder.addToGraph<
-            ClearTmpNode<Contact>>({solve_vel});
+        TaskGraphNodeID clear_contacts = solve_vel;
+        bool keep_contacts = false;
+#if MADRONA_ON_HOST
+        // debugging aid: leave the last substep's contacts in their table
+        keep_contacts = i == num_substeps - 1 &&
+            getenv("MADRONA_MWHIP_PHYS_KEEP_CONTACTS") != nullptr;
+        if (keep_contacts) {
+            fprintf(stderr, "physics debug: Contact archetype %u, "
+                    "ContactConstraint component %u\n",
+                    TypeTracker::typeID<Contact>(),
+                    TypeTracker::typeID<ContactConstraint>());
+        }
+#endif
+        if (!keep_contacts) {
+            clear_contacts = builder.addToGraph<
+                ClearTmpNode<Contact>>({solve_vel});
+        }
 
         cur_node = builder.addToGraph<ResetTmpAllocNode>({clear_contacts});
     }

@@ -24,25 +24,33 @@ CASES = {
     "cartpole_w64": ("cartpole", 64, 5, 0, [1, 10, 100, 400]),
     "escape_room_w16": ("escape_room", 16, 5, 20, [1, 5, 25, 60]),
     "sort_stress_w33": ("sort_stress", 33, 7, 0, [1, 3, 10, 40]),
+    # rigid-body physics on: BVH + narrowphase + XPBD + joints (grab action)
+    "escape_room_phys_w8": ("escape_room_phys", 8, 5, 30, [1, 5, 25, 60]),
 }
 
 
-def escape_actions(step, num_worlds):
+def escape_actions(step, num_worlds, grab=False):
     rng = np.random.default_rng(1000 + step)
     return np.stack([
         rng.integers(0, 4, (num_worlds, 2)), rng.integers(0, 8, (num_worlds, 2)),
-        rng.integers(-2, 3, (num_worlds, 2)), np.zeros((num_worlds, 2), int),
+        rng.integers(-2, 3, (num_worlds, 2)),
+        rng.integers(0, 2, (num_worlds, 2)) if grab else
+        np.zeros((num_worlds, 2), int),
     ], -1).astype(np.int32)
 
 
 def main():
+    only = sys.argv[1:]
     for name, (sim, worlds, seed, flags, checkpoints) in CASES.items():
+        if only and name not in only:
+            continue
         out = {}
         with Simulator(ref_lib_path(sim), worlds, seed=seed, num_workers=1,
                        flags=flags) as s:
             for step in range(1, max(checkpoints) + 1):
-                if sim == "escape_room":
-                    s.write_tensor("action", escape_actions(step, worlds))
+                if sim.startswith("escape_room"):
+                    s.write_tensor("action", escape_actions(
+                        step, worlds, grab=sim == "escape_room_phys"))
                 s.step(1)
                 if step in checkpoints:
                     for col, (rows, counts) in s.dump_all().items():

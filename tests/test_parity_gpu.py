@@ -29,13 +29,15 @@ def _need_ref(sim):
         pytest.skip("oracle/_ref missing on this box")
 
 
-def _escape_actions(seed):
+def _escape_actions(seed, grab=False):
     rng = np.random.default_rng(seed)
 
     def feed(ref, hip, step):
         W = ref.num_worlds
         a = np.stack([rng.integers(0, 4, (W, 2)), rng.integers(0, 8, (W, 2)),
-                      rng.integers(-2, 3, (W, 2)), np.zeros((W, 2), int)],
+                      rng.integers(-2, 3, (W, 2)),
+                      rng.integers(0, 2, (W, 2)) if grab else
+                      np.zeros((W, 2), int)],
                      -1).astype(np.int32)
         ref.write_tensor("action", a)
         hip.write_tensor("action", a)
@@ -79,6 +81,22 @@ def test_escape_room_external_reset_and_timeouts(built):
 
     probs, step = run_pair("escape_room", W, 230, flags=0, actions=actions,
                            check_init=False, check_every=5)
+    assert not probs, (step, probs[:3])
+
+
+@pytest.mark.parametrize("worlds,denom,steps", [(1, 0, 230), (16, 40, 150),
+                                                (256, 100, 80), (1024, 150, 30)])
+def test_escape_room_physics_lockstep(built, worlds, denom, steps):
+    """BASELINE config 3 shape: BVH build/refit, broadphase candidates,
+    SAT narrowphase (hull-hull, hull-plane), XPBD contacts + fixed joints
+    (grab action), resets re-registering every body.  fp32 state is compared
+    bit for bit (stricter than the 1e-5 relative bound): contact order is the
+    CPU backend's, so the Gauss-Seidel solve sees the same sequence."""
+    _need_ref("escape_room_phys")
+    probs, step = run_pair("escape_room_phys", worlds, steps, flags=denom,
+                           check_every=1 if worlds <= 16 else 10,
+                           actions=_escape_actions(worlds + 1, grab=True),
+                           check_init=False)
     assert not probs, (step, probs[:3])
 
 
@@ -131,15 +149,17 @@ def test_sort_three_pass_world_ids(built):
 
 
 # ---- 2. committed golden fixtures ------------------------------------------------
-@pytest.mark.parametrize("name", ["cartpole_w64", "escape_room_w16", "sort_stress_w33"])
+@pytest.mark.parametrize("name", ["cartpole_w64", "escape_room_w16",
+                                  "sort_stress_w33", "escape_room_phys_w8"])
 def test_hip_matches_golden(built, name):
     from golden.make_golden import CASES, escape_actions
     sim, worlds, seed, flags, checkpoints = CASES[name]
     gold = np.load(os.path.join(GOLDEN, f"{name}.npz"))
     with Simulator(hip_lib_path(sim), worlds, seed=seed, flags=flags) as s:
         for step in range(1, max(checkpoints) + 1):
-            if sim == "escape_room":
-                s.write_tensor("action", escape_actions(step, worlds))
+            if sim.startswith("escape_room"):
+                s.write_tensor("action", escape_actions(
+                    step, worlds, grab=sim == "escape_room_phys"))
             s.step(1)
             if step in checkpoints:
                 for col, (rows, counts) in s.dump_all().items():
@@ -177,6 +197,40 @@ def test_escape_room_full_size_properties(built):
             assert np.isfinite(obs).all()
             lidar = s.read_tensor("lidar")
             assert np.isfinite(lidar).all() and (lidar[..., 0] >= 0).all()
+
+
+def test_escape_room_physics_full_size_properties(built):
+    """BASELINE config 3 at its full size (8192 worlds): bodies stay finite and
+    on or above the (infinite) floor plane; body counts per world constant; ids
+    unique; two runs identical.  (Bodies may leave the arena: a grabbed cube
+    can be dragged over a wall, exactly as on the CPU backend.)"""
+    W = 8192
+    dumps = []
+    for _ in range(2):
+        with Simulator(hip_lib_path("escape_room_phys"), W, flags=120) as s:
+            rng = np.random.default_rng(9)
+            for _step in range(40):
+                a = np.stack([rng.integers(0, 4, (W, 2)),
+                              rng.integers(0, 8, (W, 2)),
+                              rng.integers(-2, 3, (W, 2)),
+                              rng.integers(0, 2, (W, 2))], -1).astype(np.int32)
+                s.write_tensor("action", a)
+                s.step(1)
+            dumps.append(s.dump_all())
+    dump = dumps[0]
+    assert not compare_columns(dump, dumps[1])
+    _check_entity_columns(dump, ["Agent", "PhysicsEntity", "DoorEntity",
+                                 "ButtonEntity"])
+    assert (dump["Agent.Entity"][1] == 2).all()
+    assert (dump["PhysicsEntity.Entity"][1] == 23).all()
+    assert (dump["DoorEntity.Entity"][1] == 3).all()
+    for arch in ("Agent", "PhysicsEntity"):
+        pos = dump[f"{arch}.Position"][0].view(np.float32)
+        assert np.isfinite(pos).all()
+        assert (pos[:, 2] > -0.1).all(), "a body fell through the floor"
+        assert (np.abs(pos[:, :2]) < 1e3).all()
+        vel = dump[f"{arch}.Velocity"][0].view(np.float32)
+        assert np.isfinite(vel).all()
 
 
 def test_partition_invariance_on_device(built):
