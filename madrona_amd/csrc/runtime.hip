@@ -1112,6 +1112,14 @@ static void pickGrid(mwhip_exec *exec, KernelLaunch &k, uint64_t max_invocations
                      uint32_t threads_per_invocation)
 {
     (void)exec;
+    if (threads_per_invocation >= 64) {
+        // wave- (or workgroup-) per-invocation kernels: one workgroup of that
+        // size per invocation, the hardware scheduler balances the rest
+        k.block = dim3(threads_per_invocation, 1, 1);
+        k.grid = dim3((uint32_t)std::min<uint64_t>(
+            std::max<uint64_t>(max_invocations, 1), 1u << 20), 1, 1);
+        return;
+    }
     uint64_t threads = max_invocations * std::max(threads_per_invocation, 1u);
     // small tables: 64-thread workgroups so the work spreads over more CUs;
     // big tables: 256-thread workgroups, capped, with grid-stride loops
@@ -2021,19 +2029,32 @@ extern "C" int32_t mwhip_profile(mwhip_exec *exec, uint64_t graph, uint32_t reps
         }
     }
 
-    // sort kernels: bytes from the measured rows in / out of each site
+    // sort kernels: bytes from the measured rows in / out of each site.  An
+    // archetype sorted by several nodes of the graph (e.g. the contact table,
+    // once per substep) has one SortState: split its counters evenly.
+    auto shareCount = [&](const void *state_dev) {
+        double count = 0;
+        for (const auto &other : lg.sortBatches) {
+            for (const auto &site : other->sites) {
+                if ((const void *)site.stateDev == state_dev) count += 1;
+            }
+        }
+        return count < 1 ? 1.0 : count;
+    };
     for (size_t b = 0; b < lg.sortBatches.size(); b++) {
         const SortBatch &batch = *lg.sortBatches[b];
         double hist = 0, pass0 = 0, passn = 0, gather = 0, fin = 0, rows_in = 0;
         for (size_t s = 0; s < batch.sites.size(); s++) {
             HIPCHK(hipMemcpy(&snaps[b][s].after, batch.sites[s].stateDev,
                 sizeof(SortState), hipMemcpyDeviceToHost));
+            const double share =
+                (double)reps * shareCount(batch.sites[s].stateDev);
             double n_in = (double)(snaps[b][s].after.statRowsIn -
-                                   snaps[b][s].before.statRowsIn) / reps;
+                                   snaps[b][s].before.statRowsIn) / share;
             double n_out = (double)(snaps[b][s].after.statRowsOut -
-                                    snaps[b][s].before.statRowsOut) / reps;
+                                    snaps[b][s].before.statRowsOut) / share;
             double runs = (double)(snaps[b][s].after.statRuns -
-                                   snaps[b][s].before.statRuns) / reps;
+                                   snaps[b][s].before.statRuns) / share;
             rows_in += n_in;
             hist += 4.0 * n_in + 8.0 * exec->cfg.num_worlds * runs;
             pass0 += 4.0 * n_in + 8.0 * n_in;

@@ -73,6 +73,29 @@ public:
 
     MADRONA_HD inline int32_t numLeaves() const { return num_leaves_; }
 
+    // Leaves in the order a full traversal (findIntersecting with an all-
+    // covering box) reports them.  Pruning only removes visits, so EVERY query
+    // reports its leaves as a subsequence of this order; together with the leaf
+    // boxes it lets a kernel enumerate a query's hits without walking the tree
+    // (phys_impl/world_step.inl).  Valid from the last rebuild on.
+    MADRONA_HD inline const int32_t *traversalOrder() const
+    {
+        return dfs_leaves_;
+    }
+
+    // the box the traversal tests for `leaf`: its slot in the parent node (grown
+    // by every refit since the last rebuild, so a superset of getLeafAABB())
+    MADRONA_HD inline math::AABB leafSlotBounds(int32_t leaf) const
+    {
+        uint32_t parent = leaf_parents_[leaf];
+        return nodes_[parent >> 2].bounds((CountT)(parent & 3u));
+    }
+
+    MADRONA_HD inline Entity leafEntity(int32_t leaf) const
+    {
+        return leaf_entities_[leaf];
+    }
+
 private:
     static constexpr int32_t sentinel_ = -1;
     static constexpr uint32_t leaf_bit_ = 0x80000000u;
@@ -152,6 +175,7 @@ private:
     LeafTransform *leaf_transforms_;
     uint32_t *leaf_parents_;
     int32_t *sorted_leaves_;
+    int32_t *dfs_leaves_;
     int32_t num_leaves_;
     int32_t num_allocated_leaves_;
     float leaf_velocity_expansion_;

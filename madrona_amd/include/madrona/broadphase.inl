@@ -18,6 +18,7 @@ BVH::BVH(const ObjectManager *obj_mgr,
           sizeof(LeafTransform) * max_leaves)),
       leaf_parents_((uint32_t *)rawAlloc(sizeof(uint32_t) * max_leaves)),
       sorted_leaves_((int32_t *)rawAlloc(sizeof(int32_t) * max_leaves)),
+      dfs_leaves_((int32_t *)rawAlloc(sizeof(int32_t) * max_leaves)),
       num_leaves_(0),
       num_allocated_leaves_((int32_t)max_leaves),
       leaf_velocity_expansion_(leaf_velocity_expansion),
@@ -368,6 +369,27 @@ void BVH::rebuild()
 
         parent.children[child_offset] = node_id;
         parent.setBounds(child_offset, combined);
+    }
+
+    // record the order an unpruned traversal visits the leaves in
+    {
+        int32_t visit[32];
+        visit[0] = 0;
+        CountT visit_size = 1;
+        int32_t rank = 0;
+        while (visit_size > 0 && num_leaves > 0) {
+            const Node &node = nodes_[visit[--visit_size]];
+            for (CountT c = 0; c < 4; c++) {
+                if (!node.hasChild(c)) {
+                    continue;
+                }
+                if (node.isLeaf(c)) {
+                    dfs_leaves_[rank++] = node.leafIDX(c);
+                } else {
+                    visit[visit_size++] = node.children[c];
+                }
+            }
+        }
     }
 }
 

@@ -9,10 +9,15 @@
 // clipping :659-700, manifold reduction to <= 4 points :771-905, face / plane /
 // edge contacts :907-1138, dispatch :1214-1514.
 //
-// One candidate pair is handled by ONE lane (hull-hull SAT is branchy and
-// short for the box-like hulls simulators use); scratch for the transformed
-// hulls lives in the lane's private memory and is bounded by
-// MADRONA_PHYS_MAX_HULL_ELEMS vertices + faces per pair.
+// Every routine is a template over the hull representation:
+//   * HullState  -- world-space vertices / planes stored in caller scratch (the
+//     reference's layout; used on the host and by the generic device path);
+//   * LazyHull   -- object-space mesh + transform, world-space vertices and
+//     planes recomputed on every access.  Same expressions, no fp contraction,
+//     hence the same bits as the stored form -- but no per-lane scratch memory,
+//     which on CDNA costs hundreds of cycles per access (phys_impl/
+//     world_step.inl uses this form, and splits the hull-hull SAT loops over
+//     the lanes of a wavefront).
 #pragma once
 
 #include <madrona/geo.hpp>
@@ -53,6 +58,68 @@ enum class NarrowphaseTest : uint32_t {
 struct HullState {
     HalfEdgeMesh mesh;      // world-space vertices and planes
     Vector3 center;
+
+    MADRONA_HD inline CountT numVertices() const { return (CountT)mesh.numVertices; }
+    MADRONA_HD inline CountT numFaces() const { return (CountT)mesh.numFaces; }
+    MADRONA_HD inline CountT numEdges() const { return (CountT)mesh.numEdges(); }
+    MADRONA_HD inline Vector3 vertex(CountT i) const { return mesh.vertices[i]; }
+    MADRONA_HD inline Plane plane(CountT i) const { return mesh.facePlanes[i]; }
+    MADRONA_HD inline HalfEdge hedge(CountT i) const { return mesh.halfEdges[i]; }
+    MADRONA_HD inline uint32_t faceBaseHedge(CountT f) const
+    {
+        return mesh.faceBaseHalfEdges[f];
+    }
+};
+
+// World-space view of an object-space mesh, evaluated on demand with the
+// expressions makeHullState stores.
+struct LazyHull {
+    const HalfEdgeMesh *mesh;
+    Mat3x3 vertexTxfm;
+    Mat3x3 normalTxfm;
+    Vector3 translation;
+    Vector3 center;
+
+    MADRONA_HD inline LazyHull(const HalfEdgeMesh &obj_mesh, Vector3 t, Quat r,
+                               Diag3x3 s)
+        : mesh(&obj_mesh), translation(t)
+    {
+        Mat3x3 unscaled_rot = Mat3x3::fromQuat(r);
+        vertexTxfm = unscaled_rot * s;
+        normalTxfm = unscaled_rot * s.inv();
+
+        center = Vector3::zero();
+        const CountT num_vertices = (CountT)obj_mesh.numVertices;
+        for (CountT i = 0; i < num_vertices; i++) {
+            center += vertex(i);
+        }
+        center /= (float)num_vertices;
+    }
+
+    MADRONA_HD inline CountT numVertices() const { return (CountT)mesh->numVertices; }
+    MADRONA_HD inline CountT numFaces() const { return (CountT)mesh->numFaces; }
+    MADRONA_HD inline CountT numEdges() const { return (CountT)mesh->numEdges(); }
+
+    MADRONA_HD inline Vector3 vertex(CountT i) const
+    {
+        return vertexTxfm * mesh->vertices[i] + translation;
+    }
+
+    MADRONA_HD inline Plane plane(CountT i) const
+    {
+        Plane obj_plane = mesh->facePlanes[i];
+        Vector3 plane_origin =
+            vertexTxfm * (obj_plane.normal * obj_plane.d) + translation;
+
+        Vector3 txfmed_normal = (normalTxfm * obj_plane.normal).normalize();
+        return Plane { txfmed_normal, dot(txfmed_normal, plane_origin) };
+    }
+
+    MADRONA_HD inline HalfEdge hedge(CountT i) const { return mesh->halfEdges[i]; }
+    MADRONA_HD inline uint32_t faceBaseHedge(CountT f) const
+    {
+        return mesh->faceBaseHalfEdges[f];
+    }
 };
 
 struct Manifold {
@@ -83,17 +150,6 @@ struct SATContact {
     uint32_t incidentFaceIdxOrEdgeIdxB;
 };
 
-struct NarrowphaseResult {
-    ContactType type;
-    SphereContact sphere;
-    SATContact sat;
-    const Vector3 *aVertices;
-    const Vector3 *bVertices;
-    const HalfEdge *aHalfEdges;
-    const HalfEdge *bHalfEdges;
-    const uint32_t *aFaceHedgeRoots;
-    const uint32_t *bFaceHedgeRoots;
-};
 
 // ---------------------------------------------------------------------------
 // hull setup
@@ -152,13 +208,14 @@ MADRONA_HD inline Vector3 planeIntersection(const Plane &plane,
 }
 
 // signed distance of the hull's deepest vertex
+template <typename HullT>
 MADRONA_HD inline float getHullDistanceFromPlane(const Plane &plane,
-                                                 const HullState &h)
+                                                 const HullT &h)
 {
     float min_dot_n = FLT_MAX;
-    const CountT num_verts = (CountT)h.mesh.numVertices;
+    const CountT num_verts = h.numVertices();
     for (CountT i = 0; i < num_verts; i++) {
-        float cur_dot = dot(h.mesh.vertices[i], plane.normal);
+        float cur_dot = dot(h.vertex(i), plane.normal);
         if (cur_dot < min_dot_n) {
             min_dot_n = cur_dot;
         }
@@ -176,17 +233,18 @@ struct FaceQuery {
 };
 
 // face of a that b is least behind; stops at the first separating face
-MADRONA_HD inline FaceQuery queryFaceDirections(const HullState &a,
-                                                const HullState &b)
+template <typename HullA, typename HullB>
+MADRONA_HD inline FaceQuery queryFaceDirections(const HullA &a,
+                                                const HullB &b)
 {
     FaceQuery best;
     best.separation = -FLT_MAX;
     best.faceIdx = -1;
     best.plane = Plane { Vector3::zero(), 0.f };
 
-    const CountT num_a_faces = (CountT)a.mesh.numFaces;
+    const CountT num_a_faces = a.numFaces();
     for (CountT face_idx = 0; face_idx < num_a_faces; face_idx++) {
-        Plane plane = a.mesh.facePlanes[face_idx];
+        Plane plane = a.plane(face_idx);
         float face_dist = getHullDistanceFromPlane(plane, b);
 
         if (face_dist > best.separation) {
@@ -218,12 +276,11 @@ MADRONA_HD inline bool isMinkowskiFace(const Vector3 &a, const Vector3 &b,
     return cba * dba < 0.0f && adc * bdc < 0.0f && cba * bdc > 0.0f;
 }
 
-MADRONA_HD inline Segment getEdgeSegment(const Vector3 *vertices,
-                                         const HalfEdge *hedges,
-                                         HalfEdge start)
+template <typename HullT>
+MADRONA_HD inline Segment getEdgeSegment(const HullT &h, HalfEdge start)
 {
-    return Segment { vertices[start.rootVertex],
-                     vertices[hedges[start.next].rootVertex] };
+    return Segment { h.vertex(start.rootVertex),
+                     h.vertex(h.hedge(start.next).rootVertex) };
 }
 
 struct EdgeTestResult {
@@ -231,13 +288,14 @@ struct EdgeTestResult {
     float separation;
 };
 
-MADRONA_HD inline EdgeTestResult edgeDistance(const HullState &a,
-                                              const HullState &b,
+template <typename HullA, typename HullB>
+MADRONA_HD inline EdgeTestResult edgeDistance(const HullA &a,
+                                              const HullB &b,
                                               HalfEdge hedge_a,
                                               HalfEdge hedge_b)
 {
-    Segment segment_a = getEdgeSegment(a.mesh.vertices, a.mesh.halfEdges, hedge_a);
-    Segment segment_b = getEdgeSegment(b.mesh.vertices, b.mesh.halfEdges, hedge_b);
+    Segment segment_a = getEdgeSegment(a, hedge_a);
+    Segment segment_b = getEdgeSegment(b, hedge_b);
 
     Vector3 dir_a = segment_a.p2 - segment_a.p1;
     Vector3 dir_b = segment_b.p2 - segment_b.p1;
@@ -268,8 +326,35 @@ struct EdgeQuery {
     int32_t edgeIdxB;
 };
 
-MADRONA_HD inline EdgeQuery queryEdgeDirections(const HullState &a,
-                                                const HullState &b)
+// One (edge of a, edge of b) pair: separation along the pair's axis, or
+// -FLT_MAX when the pair does not span a face of the Minkowski difference.
+template <typename HullA, typename HullB>
+MADRONA_HD inline EdgeTestResult testEdgePair(const HullA &a, const HullB &b,
+                                              int32_t he_idx_a,
+                                              int32_t he_idx_b)
+{
+    HalfEdge cur_hedge_a = a.hedge(he_idx_a);
+    HalfEdge twin_hedge_a = a.hedge(he_idx_a ^ 1);
+    Vector3 a_normal1 = a.plane(cur_hedge_a.face).normal;
+    Vector3 a_normal2 = a.plane(twin_hedge_a.face).normal;
+
+    HalfEdge cur_hedge_b = b.hedge(he_idx_b);
+    HalfEdge twin_hedge_b = b.hedge(he_idx_b ^ 1);
+    Vector3 b_normal1 = b.plane(cur_hedge_b.face).normal;
+    Vector3 b_normal2 = b.plane(twin_hedge_b.face).normal;
+
+    if (isMinkowskiFace(a_normal1, a_normal2, -b_normal1, -b_normal2)) {
+        return edgeDistance(a, b, cur_hedge_a, cur_hedge_b);
+    }
+
+    return EdgeTestResult { Vector3::zero(), -FLT_MAX };
+}
+
+// best over all edge pairs in (edge of a)-major order, first maximum wins;
+// stops at the first separating pair
+template <typename HullA, typename HullB>
+MADRONA_HD inline EdgeQuery queryEdgeDirections(const HullA &a,
+                                                const HullB &b)
 {
     EdgeQuery best;
     best.separation = -FLT_MAX;
@@ -277,43 +362,24 @@ MADRONA_HD inline EdgeQuery queryEdgeDirections(const HullState &a,
     best.edgeIdxA = 0;
     best.edgeIdxB = 0;
 
-    const CountT a_num_edges = (CountT)a.mesh.numEdges();
-    const CountT b_num_edges = (CountT)b.mesh.numEdges();
+    const CountT a_num_edges = a.numEdges();
+    const CountT b_num_edges = b.numEdges();
 
     for (CountT edge_idx_a = 0; edge_idx_a < a_num_edges; edge_idx_a++) {
-        int32_t he_idx_a = (int32_t)a.mesh.edgeToHalfEdge((uint32_t)edge_idx_a);
-        HalfEdge cur_hedge_a = a.mesh.halfEdges[he_idx_a];
-        HalfEdge twin_hedge_a = a.mesh.halfEdges[a.mesh.twinIDX((uint32_t)he_idx_a)];
-        Vector3 a_normal1 = a.mesh.facePlanes[cur_hedge_a.face].normal;
-        Vector3 a_normal2 = a.mesh.facePlanes[twin_hedge_a.face].normal;
+        int32_t he_idx_a = (int32_t)(edge_idx_a * 2);
 
         for (CountT edge_idx_b = 0; edge_idx_b < b_num_edges; edge_idx_b++) {
-            int32_t he_idx_b =
-                (int32_t)b.mesh.edgeToHalfEdge((uint32_t)edge_idx_b);
-            HalfEdge cur_hedge_b = b.mesh.halfEdges[he_idx_b];
-            HalfEdge twin_hedge_b =
-                b.mesh.halfEdges[b.mesh.twinIDX((uint32_t)he_idx_b)];
-            Vector3 b_normal1 = b.mesh.facePlanes[cur_hedge_b.face].normal;
-            Vector3 b_normal2 = b.mesh.facePlanes[twin_hedge_b.face].normal;
+            int32_t he_idx_b = (int32_t)(edge_idx_b * 2);
 
-            // only edge pairs that span a face of the Minkowski difference
-            // can be separating axes
-            float separation = -FLT_MAX;
-            Vector3 normal = Vector3::zero();
-            if (isMinkowskiFace(a_normal1, a_normal2, -b_normal1, -b_normal2)) {
-                EdgeTestResult edge_cmp =
-                    edgeDistance(a, b, cur_hedge_a, cur_hedge_b);
-                separation = edge_cmp.separation;
-                normal = edge_cmp.normal;
-            }
+            EdgeTestResult edge_cmp = testEdgePair(a, b, he_idx_a, he_idx_b);
 
-            if (separation > best.separation) {
-                best.separation = separation;
-                best.normal = normal;
+            if (edge_cmp.separation > best.separation) {
+                best.separation = edge_cmp.separation;
+                best.normal = edge_cmp.normal;
                 best.edgeIdxA = he_idx_a;
                 best.edgeIdxB = he_idx_b;
 
-                if (separation > 0) {
+                if (edge_cmp.separation > 0) {
                     return best;
                 }
             }
@@ -324,15 +390,16 @@ MADRONA_HD inline EdgeQuery queryEdgeDirections(const HullState &a,
 }
 
 // face of h most anti-parallel to ref_normal
-MADRONA_HD inline CountT findIncidentFace(const HullState &h,
+template <typename HullT>
+MADRONA_HD inline CountT findIncidentFace(const HullT &h,
                                           Vector3 ref_normal)
 {
     float min_dot = FLT_MAX;
     CountT minimizing_face = -1;
 
-    const CountT num_faces = (CountT)h.mesh.numFaces;
+    const CountT num_faces = h.numFaces();
     for (CountT face_idx = 0; face_idx < num_faces; face_idx++) {
-        float face_dot_ref = dot(h.mesh.facePlanes[face_idx].normal, ref_normal);
+        float face_dot_ref = dot(h.plane(face_idx).normal, ref_normal);
         if (face_dot_ref < min_dot) {
             min_dot = face_dot_ref;
             minimizing_face = face_idx;
@@ -347,7 +414,49 @@ struct SATResult {
     SATContact contact;
 };
 
-MADRONA_HD inline SATResult doSAT(const HullState &a, const HullState &b)
+// turns the three query results (all non-separating) into the contact feature
+template <typename HullA, typename HullB>
+MADRONA_HD inline SATResult chooseSATContact(const HullA &a, const HullB &b,
+                                             const FaceQuery &face_query_a,
+                                             const FaceQuery &face_query_b,
+                                             const EdgeQuery &edge_query)
+{
+    SATResult result;
+    result.contact = SATContact { Vector3::zero(), 0.f, 0u, 0u };
+
+    bool is_face_contact_a = face_query_a.separation > edge_query.separation;
+    bool is_face_contact_b = face_query_b.separation > edge_query.separation;
+
+    if (is_face_contact_a || is_face_contact_b) {
+        bool a_is_ref = face_query_a.separation >= face_query_b.separation;
+
+        Plane ref_plane = a_is_ref ? face_query_a.plane : face_query_b.plane;
+        CountT ref_face_idx =
+            a_is_ref ? face_query_a.faceIdx : face_query_b.faceIdx;
+
+        CountT incident_face_idx = a_is_ref ?
+            findIncidentFace(b, ref_plane.normal) :
+            findIncidentFace(a, ref_plane.normal);
+
+        result.type = ContactType::SATFace;
+        result.contact.normal = ref_plane.normal;
+        result.contact.planeDOrSeparation = ref_plane.d;
+        result.contact.refFaceIdxOrEdgeIdxA =
+            (uint32_t)ref_face_idx | (a_is_ref ? 0u : (1u << 31));
+        result.contact.incidentFaceIdxOrEdgeIdxB = (uint32_t)incident_face_idx;
+    } else {
+        result.type = ContactType::SATEdge;
+        result.contact.normal = edge_query.normal;
+        result.contact.planeDOrSeparation = edge_query.separation;
+        result.contact.refFaceIdxOrEdgeIdxA = (uint32_t)edge_query.edgeIdxA;
+        result.contact.incidentFaceIdxOrEdgeIdxB = (uint32_t)edge_query.edgeIdxB;
+    }
+
+    return result;
+}
+
+template <typename HullA, typename HullB>
+MADRONA_HD inline SATResult doSAT(const HullA &a, const HullB &b)
 {
     SATResult result;
     result.type = ContactType::None;
@@ -368,38 +477,11 @@ MADRONA_HD inline SATResult doSAT(const HullState &a, const HullState &b)
         return result;
     }
 
-    bool is_face_contact_a = face_query_a.separation > edge_query.separation;
-    bool is_face_contact_b = face_query_b.separation > edge_query.separation;
-
-    if (is_face_contact_a || is_face_contact_b) {
-        bool a_is_ref = face_query_a.separation >= face_query_b.separation;
-
-        Plane ref_plane = a_is_ref ? face_query_a.plane : face_query_b.plane;
-        CountT ref_face_idx =
-            a_is_ref ? face_query_a.faceIdx : face_query_b.faceIdx;
-        const HullState &incident_hull = a_is_ref ? b : a;
-
-        CountT incident_face_idx =
-            findIncidentFace(incident_hull, ref_plane.normal);
-
-        result.type = ContactType::SATFace;
-        result.contact.normal = ref_plane.normal;
-        result.contact.planeDOrSeparation = ref_plane.d;
-        result.contact.refFaceIdxOrEdgeIdxA =
-            (uint32_t)ref_face_idx | (a_is_ref ? 0u : (1u << 31));
-        result.contact.incidentFaceIdxOrEdgeIdxB = (uint32_t)incident_face_idx;
-    } else {
-        result.type = ContactType::SATEdge;
-        result.contact.normal = edge_query.normal;
-        result.contact.planeDOrSeparation = edge_query.separation;
-        result.contact.refFaceIdxOrEdgeIdxA = (uint32_t)edge_query.edgeIdxA;
-        result.contact.incidentFaceIdxOrEdgeIdxB = (uint32_t)edge_query.edgeIdxB;
-    }
-
-    return result;
+    return chooseSATContact(a, b, face_query_a, face_query_b, edge_query);
 }
 
-MADRONA_HD inline SATResult doSATPlane(const Plane &plane, const HullState &h)
+template <typename HullT>
+MADRONA_HD inline SATResult doSATPlane(const Plane &plane, const HullT &h)
 {
     SATResult result;
     result.type = ContactType::None;
@@ -562,15 +644,12 @@ MADRONA_HD inline Manifold buildFaceContactManifold(Vector3 contact_normal,
 
 // Clips the incident face against the side planes of the reference face and
 // keeps what lies below the reference plane, projected onto it.
+template <typename RefHull, typename OtherHull>
 MADRONA_HD inline Manifold createFaceContact(Plane ref_plane,
                                              int32_t ref_face_idx,
                                              int32_t incident_face_idx,
-                                             const Vector3 *ref_vertices,
-                                             const Vector3 *other_vertices,
-                                             const HalfEdge *ref_hedges,
-                                             const HalfEdge *other_hedges,
-                                             const uint32_t *ref_face_hedges,
-                                             const uint32_t *other_face_hedges,
+                                             const RefHull &ref,
+                                             const OtherHull &other,
                                              void *tmp_buf1, void *tmp_buf2,
                                              Vector3 world_offset,
                                              Quat to_world_frame)
@@ -580,26 +659,26 @@ MADRONA_HD inline Manifold createFaceContact(Plane ref_plane,
 
     CountT num_clipped_vertices = 0;
     {
-        uint32_t hedge_idx = other_face_hedges[incident_face_idx];
+        uint32_t hedge_idx = other.faceBaseHedge(incident_face_idx);
         const uint32_t start_hedge_idx = hedge_idx;
         do {
-            const HalfEdge &cur_hedge = other_hedges[hedge_idx];
+            const HalfEdge cur_hedge = other.hedge(hedge_idx);
             hedge_idx = cur_hedge.next;
             clipping_input[num_clipped_vertices++] =
-                other_vertices[cur_hedge.rootVertex];
+                other.vertex(cur_hedge.rootVertex);
         } while (hedge_idx != start_hedge_idx);
     }
 
     {
-        uint32_t hedge_idx = ref_face_hedges[ref_face_idx];
+        uint32_t hedge_idx = ref.faceBaseHedge(ref_face_idx);
         const uint32_t start_hedge_idx = hedge_idx;
 
-        const HalfEdge *cur_hedge = &ref_hedges[hedge_idx];
-        Vector3 cur_point = ref_vertices[cur_hedge->rootVertex];
+        HalfEdge cur_hedge = ref.hedge(hedge_idx);
+        Vector3 cur_point = ref.vertex(cur_hedge.rootVertex);
         do {
-            hedge_idx = cur_hedge->next;
-            cur_hedge = &ref_hedges[hedge_idx];
-            Vector3 next_point = ref_vertices[cur_hedge->rootVertex];
+            hedge_idx = cur_hedge.next;
+            cur_hedge = ref.hedge(hedge_idx);
+            Vector3 next_point = ref.vertex(cur_hedge.rootVertex);
 
             Vector3 edge = next_point - cur_point;
             Vector3 plane_normal = cross(edge, ref_plane.normal);
@@ -633,11 +712,10 @@ MADRONA_HD inline Manifold createFaceContact(Plane ref_plane,
         penetration_depths, num_below_plane, world_offset, to_world_frame);
 }
 
+template <typename HullT>
 MADRONA_HD inline Manifold createFacePlaneContact(Plane plane,
                                                   int32_t incident_face_idx,
-                                                  const Vector3 *vertices,
-                                                  const HalfEdge *hedges,
-                                                  const uint32_t *face_hedge_roots,
+                                                  const HullT &h,
                                                   Vector3 *contacts_tmp,
                                                   float *penetration_depths_tmp,
                                                   Vector3 world_offset,
@@ -645,12 +723,12 @@ MADRONA_HD inline Manifold createFacePlaneContact(Plane plane,
 {
     CountT num_incident_vertices = 0;
 
-    uint32_t hedge_idx = face_hedge_roots[incident_face_idx];
+    uint32_t hedge_idx = h.faceBaseHedge(incident_face_idx);
     const uint32_t start_hedge_idx = hedge_idx;
     do {
-        const HalfEdge &cur_hedge = hedges[hedge_idx];
+        const HalfEdge cur_hedge = h.hedge(hedge_idx);
         hedge_idx = cur_hedge.next;
-        Vector3 vertex = vertices[cur_hedge.rootVertex];
+        Vector3 vertex = h.vertex(cur_hedge.rootVertex);
 
         float d = getDistanceFromPlane(plane, vertex);
         if (d <= 0.0f) {
@@ -695,19 +773,18 @@ MADRONA_HD inline Segment shortestSegmentBetween(const Segment &seg1,
     return Segment { seg1.p1 + s * v1, seg2.p1 + t * v2 };
 }
 
+template <typename HullA, typename HullB>
 MADRONA_HD inline Manifold createEdgeContact(Vector3 normal,
                                              float separation,
                                              int32_t hedge_idx_a,
                                              int32_t hedge_idx_b,
-                                             const Vector3 *a_vertices,
-                                             const Vector3 *b_vertices,
-                                             const HalfEdge *a_hedges,
-                                             const HalfEdge *b_hedges,
+                                             const HullA &a,
+                                             const HullB &b,
                                              Vector3 world_offset,
                                              Quat to_world_frame)
 {
-    Segment seg_a = getEdgeSegment(a_vertices, a_hedges, a_hedges[hedge_idx_a]);
-    Segment seg_b = getEdgeSegment(b_vertices, b_hedges, b_hedges[hedge_idx_b]);
+    Segment seg_a = getEdgeSegment(a, a.hedge(hedge_idx_a));
+    Segment seg_b = getEdgeSegment(b, b.hedge(hedge_idx_b));
 
     Segment s = shortestSegmentBetween(seg_a, seg_b);
     Vector3 contact = s.p1;

@@ -1,0 +1,1305 @@
+// The fused rigid-body step: ONE kernel per simulation step, one wavefront per
+// world (included by physics.inl inside namespace madrona::phys::kernels).
+//
+// Worlds are independent, and everything the physics step does is per world:
+// find candidate pairs, then per substep integrate, collide, solve positions,
+// derive velocities, solve velocities.  The reference GPU backend runs those as
+// ~8 megakernel nodes per substep over globally compacted tables (atomically
+// appended, then radix sorted by world).  Here a 64-lane wavefront owns a world
+// for the whole step:
+//   * lanes = bodies / candidates / contacts of that world; phases are
+//     separated by workgroup-scope fences (a wave never leaves its CU), not by
+//     kernel boundaries -- no launches, no sorts, no scans in between;
+//   * candidates and contacts live in per-world segments of module-private
+//     arrays (fixed stride), written in the CPU backend's order with wave
+//     ballots + prefix sums, so XPBD's Gauss-Seidel sweep sees the CPU sequence;
+//   * the sequential sweep itself is parallelised exactly: contact i must wait
+//     only for earlier contacts that touch one of its non-static bodies, so
+//     contacts are assigned dependency levels and each level runs in parallel.
+//     Constraints of one level touch disjoint bodies, therefore commute bit for
+//     bit with the sequential order of the CPU solver (xpbd.cpp:720-736).
+//
+// Requirement: every rigid-body archetype is grouped by world when the physics
+// step starts (the simulator compacts after creating / destroying bodies, as
+// the reference's GPU simulators do); otherwise kErrPhysics is raised.
+
+using namespace narrowphase;
+
+#ifdef MADRONA_PHYS_NOINLINE_NARROWPHASE
+#define MADRONA_PHYS_NP_INLINE __attribute__((noinline))
+#else
+#define MADRONA_PHYS_NP_INLINE inline
+#endif
+
+namespace wave {
+
+__device__ inline uint32_t laneID()
+{
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+// phase boundary inside a wave: earlier global writes of any lane become
+// visible to later reads of every lane (same CU), and the compiler may not
+// move memory operations across it
+__device__ inline void phaseFence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__device__ inline uint32_t exclusiveScan(uint32_t v, uint32_t lane,
+                                         uint32_t *total)
+{
+    uint32_t incl = v;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        uint32_t up = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += up;
+    }
+    *total = __shfl(incl, 63, 64);
+    return incl - v;
+}
+
+__device__ inline uint32_t maxReduce(uint32_t v)
+{
+#pragma unroll
+    for (uint32_t d = 32; d > 0; d >>= 1) {
+        uint32_t o = __shfl_xor(v, d, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// arg-max over the wave where the LOWEST index wins among equal values -- the
+// result of a sequential "if (v > best)" scan in index order.  Every lane
+// returns the winner.  (Lane-local values are never NaN: they start at
+// -FLT_MAX and are only replaced through a strict >.)
+__device__ inline void argMaxFirst(float &v, uint32_t &idx)
+{
+#pragma unroll
+    for (uint32_t d = 32; d > 0; d >>= 1) {
+        float ov = __shfl_xor(v, d, 64);
+        uint32_t oi = __shfl_xor(idx, d, 64);
+        if (ov > v || (ov == v && oi < idx)) {
+            v = ov;
+            idx = oi;
+        }
+    }
+}
+
+__device__ inline uint32_t rankInBallot(uint64_t mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+        __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+}
+
+// ---------------------------------------------------------------------------
+// narrowphase on a wavefront
+// ---------------------------------------------------------------------------
+// Per-lane clipping scratch in LDS: lanePolyVerts points + depths per lane,
+// rows padded to an odd dword count so lanes fall into different banks.
+inline constexpr uint32_t lanePolyVerts = 8;
+inline constexpr uint32_t lanePolyDwords = lanePolyVerts * 4 + 1;
+// rows available per round; lanes that need one are served in rounds
+inline constexpr uint32_t lanePolyRows = 16;
+// clipping scratch of the wave-cooperative hull-hull path (2 polygons)
+inline constexpr uint32_t wavePolyVerts = 24;
+
+struct alignas(16) WaveScratch {
+    float lanePoly[lanePolyRows * lanePolyDwords];
+    math::Vector3 clip[2][wavePolyVerts];
+};
+
+// number of vertices of face `face_idx`
+template <typename HullT>
+__device__ inline uint32_t faceVertexCount(const HullT &h, uint32_t face_idx)
+{
+    uint32_t n = 0;
+    uint32_t hedge_idx = h.faceBaseHedge(face_idx);
+    const uint32_t start = hedge_idx;
+    do {
+        hedge_idx = h.hedge(hedge_idx).next;
+        n++;
+    } while (hedge_idx != start);
+    return n;
+}
+
+// SAT face query with the faces of `a` spread over the lanes (sequential
+// reference: narrowphase.hpp queryFaceDirections)
+template <typename HullA, typename HullB>
+__device__ inline FaceQuery queryFaceDirectionsWave(uint32_t lane,
+                                                    const HullA &a,
+                                                    const HullB &b)
+{
+    float best_sep = -FLT_MAX;
+    uint32_t best_face = 0xFFFFFFFFu;
+
+    const uint32_t num_a_faces = (uint32_t)a.numFaces();
+    for (uint32_t f = lane; f < num_a_faces; f += 64) {
+        float face_dist = getHullDistanceFromPlane(a.plane(f), b);
+        if (face_dist > best_sep) {
+            best_sep = face_dist;
+            best_face = f;
+        }
+    }
+    wave::argMaxFirst(best_sep, best_face);
+
+    FaceQuery best;
+    best.separation = best_sep;
+    if (best_face == 0xFFFFFFFFu) {
+        best.faceIdx = -1;
+        best.plane = Plane { Vector3::zero(), 0.f };
+    } else {
+        best.faceIdx = (CountT)best_face;
+        best.plane = a.plane(best_face);
+    }
+    return best;
+}
+
+// SAT edge query with the (edge of a, edge of b) pairs spread over the lanes
+// (sequential reference: narrowphase.hpp queryEdgeDirections)
+template <typename HullA, typename HullB>
+__device__ inline EdgeQuery queryEdgeDirectionsWave(uint32_t lane,
+                                                    const HullA &a,
+                                                    const HullB &b)
+{
+    float best_sep = -FLT_MAX;
+    uint32_t best_pair = 0xFFFFFFFFu;
+
+    const uint32_t b_num_edges = (uint32_t)b.numEdges();
+    const uint32_t num_pairs = (uint32_t)a.numEdges() * b_num_edges;
+    for (uint32_t p = lane; p < num_pairs; p += 64) {
+        int32_t he_idx_a = (int32_t)((p / b_num_edges) * 2);
+        int32_t he_idx_b = (int32_t)((p % b_num_edges) * 2);
+        EdgeTestResult r = testEdgePair(a, b, he_idx_a, he_idx_b);
+        if (r.separation > best_sep) {
+            best_sep = r.separation;
+            best_pair = p;
+        }
+    }
+    wave::argMaxFirst(best_sep, best_pair);
+
+    EdgeQuery best;
+    best.separation = best_sep;
+    if (best_pair == 0xFFFFFFFFu) {
+        best.normal = Vector3::zero();
+        best.edgeIdxA = 0;
+        best.edgeIdxB = 0;
+    } else {
+        best.edgeIdxA = (int32_t)((best_pair / b_num_edges) * 2);
+        best.edgeIdxB = (int32_t)((best_pair % b_num_edges) * 2);
+        best.normal =
+            testEdgePair(a, b, best.edgeIdxA, best.edgeIdxB).normal;
+    }
+    return best;
+}
+
+// Hull-hull pair handled by the whole wave (`pair` is wave-uniform).  Returns
+// false with *too_big set when the clipped polygon may not fit the LDS scratch.
+__device__ inline bool hullHullWave(uint32_t lane, const PairSetup &pair,
+                                    WaveScratch *scratch,
+                                    ContactConstraint *out, bool *too_big)
+{
+    LazyHull a(pair.aPrim->hull.halfEdgeMesh, pair.a.pos, pair.a.rot,
+               pair.a.scale);
+    LazyHull b(pair.bPrim->hull.halfEdgeMesh, pair.b.pos, pair.b.rot,
+               pair.b.scale);
+
+    FaceQuery face_query_a = queryFaceDirectionsWave(lane, a, b);
+    if (face_query_a.separation > 0.0f) {
+        return false;
+    }
+
+    FaceQuery face_query_b = queryFaceDirectionsWave(lane, b, a);
+    if (face_query_b.separation > 0.0f) {
+        return false;
+    }
+
+    EdgeQuery edge_query = queryEdgeDirectionsWave(lane, a, b);
+    if (edge_query.separation > 0.0f) {
+        return false;
+    }
+
+    // from here on every lane computes the same thing (cheap, and it keeps the
+    // wave converged); the clipping polygons live in LDS
+    const SATResult sat =
+        chooseSATContact(a, b, face_query_a, face_query_b, edge_query);
+
+    if (sat.type == ContactType::SATFace) {
+        uint32_t ref_face = sat.contact.refFaceIdxOrEdgeIdxA & 0x7FFFFFFFu;
+        bool a_is_ref = ref_face == sat.contact.refFaceIdxOrEdgeIdxA;
+        uint32_t inc_face = sat.contact.incidentFaceIdxOrEdgeIdxB;
+        uint32_t n_ref = a_is_ref ? faceVertexCount(a, ref_face) :
+                                    faceVertexCount(b, ref_face);
+        uint32_t n_inc = a_is_ref ? faceVertexCount(b, inc_face) :
+                                    faceVertexCount(a, inc_face);
+        if (n_ref + n_inc > wavePolyVerts) {
+            *too_big = true;
+            return false;
+        }
+    }
+
+    return satToContact(sat, a, b, pair.aLoc, pair.bLoc,
+                        scratch->clip[0], scratch->clip[1], out);
+}
+
+// Every other primitive pair: one lane, hull evaluated lazily, clipping
+// scratch in the lane's LDS row.
+__device__ inline bool collidePairLane(const PairSetup &pair, float *row,
+                                       ContactConstraint *out,
+                                       bool *too_big, bool *unsupported)
+{
+    switch (pair.test) {
+    case NarrowphaseTest::SphereSphere:
+        return sphereSphereContact(pair, out);
+    case NarrowphaseTest::SpherePlane:
+        return spherePlaneContact(pair, out);
+    case NarrowphaseTest::HullPlane: {
+        LazyHull a(pair.aPrim->hull.halfEdgeMesh, pair.a.pos, pair.a.rot,
+                   pair.a.scale);
+
+        // largest face bounds the contact polygon
+        const uint32_t num_faces = (uint32_t)a.numFaces();
+        if (a.mesh->numHalfEdges > lanePolyVerts * num_faces) {
+            // cannot rule out a face with more than lanePolyVerts vertices
+            bool fits = true;
+            for (uint32_t f = 0; f < num_faces; f++) {
+                fits = fits && faceVertexCount(a, f) <= lanePolyVerts;
+            }
+            if (!fits) {
+                *too_big = true;
+                return false;
+            }
+        }
+
+        return hullPlaneContact(a, pair.b, pair.aLoc, pair.bLoc,
+                                row, row + lanePolyVerts * 3, out);
+    }
+    case NarrowphaseTest::SphereHull:   // needs GJK, not built yet
+    case NarrowphaseTest::PlanePlane:
+    default:
+        *unsupported = true;
+        return false;
+    }
+}
+
+struct WorldBodies {
+    uint32_t numArchetypes;
+    uint32_t archetype[PhysicsScratch::maxBodyArchetypes];
+    int32_t rowBase[PhysicsScratch::maxBodyArchetypes];
+    int32_t bodyBase[PhysicsScratch::maxBodyArchetypes + 1];
+
+    __device__ inline int32_t count() const { return bodyBase[numArchetypes]; }
+
+    // k-th body of the world in the CPU backend's iteration order
+    __device__ inline Loc loc(int32_t k) const
+    {
+        uint32_t a = 0;
+        while (a + 1 < numArchetypes && k >= bodyBase[a + 1]) {
+            a++;
+        }
+        return Loc { archetype[a], rowBase[a] + (k - bodyBase[a]) };
+    }
+};
+
+// Dependency levels for a window of <= 64 constraints held one per lane.
+// key_a / key_b: the two bodies (0 = static / none, never conflicts).
+__device__ inline uint32_t constraintLevels(uint32_t lane, uint32_t n,
+                                            uint64_t key_a, uint64_t key_b)
+{
+    uint32_t level = 0;
+    for (uint32_t j = 0; j + 1 < n; j++) {
+        uint64_t ja = __shfl(key_a, j, 64);
+        uint64_t jb = __shfl(key_b, j, 64);
+        uint32_t jl = __shfl(level, j, 64);
+        bool conflict =
+            (ja != 0 && (ja == key_a || ja == key_b)) ||
+            (jb != 0 && (jb == key_a || jb == key_b));
+        if (lane > j && lane < n && conflict && jl + 1 > level) {
+            level = jl + 1;
+        }
+    }
+    return level;
+}
+
+__device__ inline uint64_t bodyKey(Context &ctx, Loc loc)
+{
+    if (ctx.getDirect<ResponseType>(RGDCols::ResponseType, loc) ==
+            ResponseType::Static) {
+        return 0;
+    }
+    return ((uint64_t)(loc.archetype + 1) << 32) | (uint64_t)(uint32_t)loc.row;
+}
+
+#ifndef MADRONA_PHYS_WAVES_PER_EU
+#define MADRONA_PHYS_WAVES_PER_EU 1
+#endif
+__global__ void __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(MADRONA_PHYS_WAVES_PER_EU)))
+physicsStepKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
+{
+    StateManager *state_mgr = static_cast<StateManager *>(S);
+    PhysicsScratch *ps = detail::scratch(S);
+    const PhysicsStepParams params = *(const PhysicsStepParams *)node_data;
+
+    const uint32_t lane = wave::laneID();
+    const int32_t waves_per_block = (int32_t)(blockDim.x / 64);
+    const int32_t wave_in_block = __builtin_amdgcn_readfirstlane(
+        (int32_t)(threadIdx.x / 64));
+    const int32_t num_worlds = S->numWorlds;
+
+    // generic fallback only (hulls whose faces outgrow the LDS scratch)
+    constexpr int32_t max_elems = MADRONA_PHYS_MAX_HULL_ELEMS;
+    geo::Plane tmp_faces[max_elems];
+    math::Vector3 tmp_vertices[max_elems];
+
+    __shared__ WaveScratch block_scratch[4];
+    WaveScratch *scratch = &block_scratch[wave_in_block];
+
+#ifdef MADRONA_PHYS_PROFILE
+    // per-phase cycle counters (debug builds): moduleData[1] -> uint64[8]
+    unsigned long long prof_t = __builtin_readcyclecounter();
+    unsigned long long prof_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+#define PHYS_PROF(slot) do { unsigned long long now_ = __builtin_readcyclecounter(); \
+        prof_acc[slot] += now_ - prof_t; prof_t = now_; } while (0)
+#else
+#define PHYS_PROF(slot) do {} while (0)
+#endif
+
+    const uint32_t cand_stride = ps->candidatesPerWorld;
+    const uint32_t contact_stride = ps->contactsPerWorld;
+
+    for (int32_t world = (int32_t)blockIdx.x * waves_per_block + wave_in_block;
+         world < num_worlds; world += (int32_t)gridDim.x * waves_per_block) {
+        Context ctx = TaskGraph::makeContext<Context>(
+            state_mgr, WorldID { world }, true);
+        const ObjectManager &obj_mgr = *ctx.singleton<ObjectData>().mgr;
+        const PhysicsSystemState physics_sys =
+            ctx.singleton<PhysicsSystemState>();
+
+        // ---- the world's bodies ---------------------------------------------
+        WorldBodies bodies;
+        bodies.numArchetypes = ps->numBodyArchetypes;
+        bodies.bodyBase[0] = 0;
+        bool unsorted = false;
+        for (uint32_t a = 0; a < bodies.numArchetypes; a++) {
+            const TableHdr &tbl = S->tables[ps->bodyArchetypes[a]];
+            bodies.archetype[a] = ps->bodyArchetypes[a];
+            bodies.rowBase[a] = tbl.worldOffsets[world];
+            bodies.bodyBase[a + 1] =
+                bodies.bodyBase[a] + tbl.worldCounts[world];
+            unsorted = unsorted || tbl.needsSort != 0;
+        }
+        if (unsorted) {
+            mwhip::raiseError(S, mwhip::kErrPhysics);
+            continue;
+        }
+        const int32_t num_bodies = bodies.count();
+        PHYS_PROF(0);
+
+        CandidateCollision *candidates =
+            ps->worldCandidates + (uint64_t)world * cand_stride;
+        ContactConstraint *contacts =
+            ps->worldContacts + (uint64_t)world * contact_stride;
+        float *lambdas = ps->worldLambdas + (uint64_t)world * contact_stride;
+
+        // ---- broadphase: candidate pairs in (body, traversal) order -----------
+        uint32_t num_candidates = 0;
+        for (int32_t chunk = 0; chunk < num_bodies; chunk += 64) {
+            const int32_t k = chunk + (int32_t)lane;
+            const bool active = k < num_bodies;
+
+            Loc a_loc = active ? bodies.loc(k) : Loc { 0, 0 };
+            Entity e = Entity::none();
+            broadphase::LeafID leaf_id { 0 };
+            uint32_t n = 0;
+            if (active) {
+                e = ctx.getDirect<Entity>(0, a_loc);
+                leaf_id = ctx.getDirect<broadphase::LeafID>(
+                    RGDCols::LeafID, a_loc);
+                detail::forEachCandidate(ctx, e, leaf_id, a_loc,
+                    [&](Loc, CountT a_num_prims, CountT b_num_prims) {
+                        n += (uint32_t)(a_num_prims * b_num_prims);
+                    });
+            }
+
+            uint32_t chunk_total;
+            uint32_t out = num_candidates +
+                wave::exclusiveScan(n, lane, &chunk_total);
+
+            if (active && n != 0 && out + n <= cand_stride) {
+                detail::forEachCandidate(ctx, e, leaf_id, a_loc,
+                    [&](Loc b_loc, CountT a_num_prims, CountT b_num_prims) {
+                        CountT total_checks = a_num_prims * b_num_prims;
+                        for (CountT c = 0; c < total_checks; c++) {
+                            CandidateCollision &candidate = candidates[out++];
+                            candidate.a = a_loc;
+                            candidate.b = b_loc;
+                            candidate.aPrim = (uint32_t)(c / b_num_prims);
+                            candidate.bPrim = (uint32_t)(c % b_num_prims);
+                        }
+                    });
+            }
+            num_candidates += chunk_total;
+        }
+        if (num_candidates > cand_stride) {
+            mwhip::raiseError(S, mwhip::kErrTableOverflow);
+            continue;
+        }
+        wave::phaseFence();
+        PHYS_PROF(1);
+
+        // ---- the world's joints (table sorted by world just before) -----------
+        const TableHdr &joint_tbl = S->tables[ps->jointArchetype];
+        const int32_t joint_begin = joint_tbl.worldOffsets[world];
+        const int32_t num_joints = joint_tbl.worldCounts[world];
+        const JointConstraint *joints =
+            (const JointConstraint *)joint_tbl.columns[2] + joint_begin;
+
+        for (int32_t substep = 0; substep < params.numSubsteps; substep++) {
+            // ---- integrate ------------------------------------------------------
+            for (int32_t k = (int32_t)lane; k < num_bodies; k += 64) {
+                Loc loc = bodies.loc(k);
+                xpbd::substepRigidBodies(ctx,
+                    ctx.getDirect<base::Position>(RGDCols::Position, loc),
+                    ctx.getDirect<base::Rotation>(RGDCols::Rotation, loc),
+                    ctx.getDirect<Velocity>(RGDCols::Velocity, loc),
+                    ctx.getDirect<base::ObjectID>(RGDCols::ObjectID, loc),
+                    ctx.getDirect<ResponseType>(RGDCols::ResponseType, loc),
+                    ctx.getDirect<ExternalForce>(RGDCols::ExternalForce, loc),
+                    ctx.getDirect<ExternalTorque>(RGDCols::ExternalTorque, loc),
+                    ctx.getDirect<xpbd::SubstepPrevState>(
+                        xpbd::XPBDCols::SubstepPrevState, loc),
+                    ctx.getDirect<xpbd::PreSolvePositional>(
+                        xpbd::XPBDCols::PreSolvePositional, loc),
+                    ctx.getDirect<xpbd::PreSolveVelocity>(
+                        xpbd::XPBDCols::PreSolveVelocity, loc));
+            }
+            wave::phaseFence();
+            PHYS_PROF(2);
+
+            // ---- narrowphase: contacts in candidate order ------------------------
+            uint32_t num_contacts = 0;
+            for (uint32_t chunk = 0; chunk < num_candidates; chunk += 64) {
+                const uint32_t c = chunk + lane;
+                ContactConstraint contact;
+                bool has_contact = false;
+                bool too_big = false;
+                bool unsupported = false;
+
+                // per lane: order the pair, reject by world AABBs, classify
+                uint32_t kind = 0;      // 1: this lane alone, 2: whole wave
+                PairSetup pair;
+                if (c < num_candidates) {
+                    pair = setupPair(ctx, obj_mgr, candidates[c]);
+                    if (pair.aabbOverlap) {
+                        kind = pair.test == NarrowphaseTest::HullHull ? 2 : 1;
+                    }
+                }
+
+                // lanes on their own, in rounds of lanePolyRows scratch rows
+                uint64_t solo = __builtin_amdgcn_ballot_w64(kind == 1);
+                const uint32_t solo_rank = wave::rankInBallot(solo);
+                const uint32_t solo_count = (uint32_t)__builtin_popcountll(solo);
+                for (uint32_t first = 0; first < solo_count;
+                     first += lanePolyRows) {
+                    if (kind == 1 && solo_rank >= first &&
+                            solo_rank < first + lanePolyRows) {
+                        has_contact = collidePairLane(pair,
+                            scratch->lanePoly +
+                                (solo_rank - first) * lanePolyDwords,
+                            &contact, &too_big, &unsupported);
+                    }
+                }
+
+                // hull-hull pairs: one after the other, SAT loops over the lanes
+                uint64_t hull_pairs = __builtin_amdgcn_ballot_w64(kind == 2);
+                while (hull_pairs != 0) {
+                    const uint32_t src = (uint32_t)__builtin_ctzll(hull_pairs);
+                    hull_pairs &= hull_pairs - 1;
+
+                    PairSetup shared_pair =
+                        setupPair(ctx, obj_mgr, candidates[chunk + src]);
+                    ContactConstraint shared_contact;
+                    bool shared_too_big = false;
+                    bool found = hullHullWave(lane, shared_pair, scratch,
+                        &shared_contact, &shared_too_big);
+                    if (lane == src) {
+                        contact = shared_contact;
+                        has_contact = found;
+                        too_big = shared_too_big;
+                    }
+                }
+
+                // rare: polygons larger than the LDS scratch -> generic path
+                // with the hulls stored in the lane's private memory
+                if (too_big) {
+                    has_contact = collidePairStored(pair, tmp_vertices,
+                        tmp_faces, max_elems, &contact, &unsupported);
+                }
+                if (unsupported) {
+                    mwhip::raiseError(S, mwhip::kErrPhysics);
+                }
+
+                uint64_t mask = __builtin_amdgcn_ballot_w64(has_contact);
+                uint32_t dst = num_contacts + wave::rankInBallot(mask);
+                if (has_contact && dst < contact_stride) {
+                    contacts[dst] = contact;
+                }
+                num_contacts += (uint32_t)__builtin_popcountll(mask);
+            }
+            if (num_contacts > contact_stride) {
+                mwhip::raiseError(S, mwhip::kErrTableOverflow);
+                num_contacts = contact_stride;
+            }
+            wave::phaseFence();
+            PHYS_PROF(3);
+
+            // ---- position solve: contacts, then joints, level by level ----------
+            for (uint32_t base = 0; base < num_contacts; base += 64) {
+                const uint32_t n = num_contacts - base < 64 ?
+                    num_contacts - base : 64;
+                const uint32_t i = base + lane;
+                uint64_t key_a = 0, key_b = 0;
+                if (lane < n) {
+                    key_a = bodyKey(ctx, contacts[i].ref);
+                    key_b = bodyKey(ctx, contacts[i].alt);
+                }
+                uint32_t level = constraintLevels(lane, n, key_a, key_b);
+                uint32_t max_level = wave::maxReduce(lane < n ? level : 0);
+
+                for (uint32_t l = 0; l <= max_level; l++) {
+                    if (lane < n && level == l) {
+                        float lambda_n[4] { 0.f, 0.f, 0.f, 0.f };
+                        xpbd::handleContact(ctx, obj_mgr, contacts[i], lambda_n);
+                        lambdas[i] = lambda_n[0];
+                    }
+                    wave::phaseFence();
+                }
+            }
+
+            for (int32_t base = 0; base < num_joints; base += 64) {
+                const uint32_t n = num_joints - base < 64 ?
+                    (uint32_t)(num_joints - base) : 64u;
+                const int32_t i = base + (int32_t)lane;
+                uint64_t key_a = 0, key_b = 0;
+                if (lane < n) {
+                    key_a = bodyKey(ctx, ctx.loc(joints[i].e1));
+                    key_b = bodyKey(ctx, ctx.loc(joints[i].e2));
+                }
+                uint32_t level = constraintLevels(lane, n, key_a, key_b);
+                uint32_t max_level = wave::maxReduce(lane < n ? level : 0);
+
+                for (uint32_t l = 0; l <= max_level; l++) {
+                    if (lane < n && level == l) {
+                        xpbd::handleJointConstraint(ctx, obj_mgr, joints[i]);
+                    }
+                    wave::phaseFence();
+                }
+            }
+
+            PHYS_PROF(4);
+            // ---- velocities -----------------------------------------------------
+            for (int32_t k = (int32_t)lane; k < num_bodies; k += 64) {
+                Loc loc = bodies.loc(k);
+                xpbd::setVelocities(ctx,
+                    ctx.getDirect<base::Position>(RGDCols::Position, loc),
+                    ctx.getDirect<base::Rotation>(RGDCols::Rotation, loc),
+                    ctx.getDirect<xpbd::SubstepPrevState>(
+                        xpbd::XPBDCols::SubstepPrevState, loc),
+                    ctx.getDirect<Velocity>(RGDCols::Velocity, loc));
+            }
+            wave::phaseFence();
+            PHYS_PROF(5);
+
+            for (uint32_t base = 0; base < num_contacts; base += 64) {
+                const uint32_t n = num_contacts - base < 64 ?
+                    num_contacts - base : 64;
+                const uint32_t i = base + lane;
+                uint64_t key_a = 0, key_b = 0;
+                if (lane < n) {
+                    key_a = bodyKey(ctx, contacts[i].ref);
+                    key_b = bodyKey(ctx, contacts[i].alt);
+                }
+                uint32_t level = constraintLevels(lane, n, key_a, key_b);
+                uint32_t max_level = wave::maxReduce(lane < n ? level : 0);
+
+                for (uint32_t l = 0; l <= max_level; l++) {
+                    if (lane < n && level == l) {
+                        float lambda_n[4] { lambdas[i], 0.f, 0.f, 0.f };
+                        xpbd::solveVelocitiesForContact(ctx, obj_mgr,
+                            contacts[i], lambda_n, physics_sys.h,
+                            physics_sys.restitutionThreshold);
+                    }
+                    wave::phaseFence();
+                }
+            }
+            PHYS_PROF(6);
+        }
+    }
+
+#ifdef MADRONA_PHYS_PROFILE
+    if (lane == 0 && S->moduleData[1] != nullptr) {
+        unsigned long long *dst = (unsigned long long *)S->moduleData[1];
+        for (int i = 0; i < 8; i++) {
+            atomicAdd(&dst[i], prof_acc[i]);
+        }
+    }
+#endif
+}
+// ===========================================================================
+// The same step with the world resident in LDS.
+//
+// The generic kernel above is bound by dependent HBM/L2 round trips (each
+// constraint chases Loc -> column pointer -> row for both bodies; measured:
+// ~870 K cycles per world-step, > 95 % of them waiting).  A world's rigid-body
+// state is a few KB, so this variant loads it once (coalesced, all lanes), runs
+// candidates + every substep against LDS, and stores positions / velocities /
+// solver state back once.  HBM traffic per world-step: one read and one write
+// of the body columns; everything else stays on the CU.
+//
+// Candidate pairs come from the BVH without walking it: the traversal reports a
+// leaf iff the query box overlaps the leaf's slot box (ancestor boxes are
+// supersets), in an order that does not depend on the query
+// (BVH::traversalOrder), so lane a tests its box against the slot boxes in
+// that order.
+//
+// MAXB bounds bodies per world (LDS capacity); the host picks the instantiation
+// and worlds that exceed it raise kErrPhysics.
+// ===========================================================================
+// candidate pair of the LDS step: body indices inside the world
+struct WaveCandidate {
+    uint16_t a;
+    uint16_t b;
+    uint16_t aPrim;
+    uint16_t bPrim;
+};
+
+template <int MAXB>
+struct WorldBlock {
+    static constexpr int maxBodies = MAXB;
+    // sized so that a 32-body block stays under 16 KB of LDS: four
+    // single-wave workgroups per CU, as many as the register file admits
+    static constexpr int maxCandidates = MAXB * 3;
+    static constexpr int maxContacts = MAXB + MAXB / 4;
+    static constexpr int maxJoints = 6;         // more: read from HBM
+    static constexpr int maxPrims = 8;          // more: hull data stays in HBM
+    static constexpr int arenaDwords = 192;     // object-space hull meshes
+
+    math::Vector3 pos[MAXB];
+    math::Quat rot[MAXB];
+    math::Diag3x3 scale[MAXB];
+    Velocity vel[MAXB];
+    math::Vector3 extForce[MAXB];
+    math::Vector3 extTorque[MAXB];
+    xpbd::SubstepPrevState prev[MAXB];
+    xpbd::PreSolvePositional prePos[MAXB];
+    xpbd::PreSolveVelocity preVel[MAXB];
+    xpbd::BodyConstants constants[MAXB];    // zeroed for static bodies
+    uint32_t resp[MAXB];
+    int32_t entityID[MAXB];
+    uint16_t primOffset[MAXB];
+    uint16_t primCount[MAXB];
+    uint16_t leafBody[MAXB];                // leaf id -> body index
+    uint16_t orderBody[MAXB];               // traversal rank -> body index
+    WaveCandidate candidates[maxCandidates];
+
+    // broadphase boxes are dead once the candidates exist: the contacts of the
+    // substeps reuse their storage
+    static constexpr size_t boxBytes = 2 * MAXB * sizeof(math::AABB);
+    static constexpr size_t contactBytes =
+        maxContacts * sizeof(ContactConstraint);
+    alignas(16) char shared[boxBytes > contactBytes ? boxBytes : contactBytes];
+    float lambdas[maxContacts];
+
+    JointConstraint joints[maxJoints];
+    uint16_t jointBodies[maxJoints][2];
+    PhysicsSystemState sys;
+    // the object manager's primitives (and as many hull meshes as fit) copied
+    // next to the CU; hull pointers inside `prims` are rebased onto `arena`
+    CollisionPrimitive prims[maxPrims];
+    math::AABB primAABBs[maxPrims];
+    const void *primMeshKey[maxPrims];      // HBM vertex array of each hull prim
+    alignas(16) uint32_t arena[arenaDwords];
+    WaveScratch scratch;
+
+    __device__ inline math::AABB *queryBox() { return (math::AABB *)shared; }
+    __device__ inline math::AABB *slotBox()
+    {
+        return (math::AABB *)shared + MAXB;
+    }
+    __device__ inline ContactConstraint *contacts()
+    {
+        return (ContactConstraint *)shared;
+    }
+};
+
+// Copies `count` dwords with all lanes.
+__device__ inline void waveCopyDwords(uint32_t lane, uint32_t *dst,
+                                      const uint32_t *src, uint32_t count)
+{
+    for (uint32_t i = lane; i < count; i += 64) {
+        dst[i] = src[i];
+    }
+}
+
+// Stages primitives [0, num_prims) of the object manager in LDS.  Returns an
+// ObjectManager whose primitive arrays point at the copies (or the original
+// when they do not fit).
+template <int MAXB>
+__device__ inline ObjectManager stagePrimitives(uint32_t lane,
+                                                WorldBlock<MAXB> *w,
+                                                const ObjectManager &obj_mgr,
+                                                uint32_t num_prims)
+{
+    using Block = WorldBlock<MAXB>;
+    if (num_prims > (uint32_t)Block::maxPrims) {
+        return obj_mgr;
+    }
+
+    waveCopyDwords(lane, (uint32_t *)w->prims,
+        (const uint32_t *)obj_mgr.collisionPrimitives,
+        num_prims * (uint32_t)(sizeof(CollisionPrimitive) / 4));
+    waveCopyDwords(lane, (uint32_t *)w->primAABBs,
+        (const uint32_t *)obj_mgr.primitiveAABBs,
+        num_prims * (uint32_t)(sizeof(math::AABB) / 4));
+    wave::phaseFence();
+    if (lane < num_prims) {
+        w->primMeshKey[lane] =
+            w->prims[lane].type == CollisionPrimitive::Type::Hull ?
+                (const void *)w->prims[lane].hull.halfEdgeMesh.vertices :
+                nullptr;
+    }
+    wave::phaseFence();
+
+    // every lane walks the (short) primitive list; meshes shared by several
+    // primitives are staged once
+    uint32_t arena_used = 0;
+    for (uint32_t p = 0; p < num_prims; p++) {
+        if (w->prims[p].type != CollisionPrimitive::Type::Hull) {
+            continue;
+        }
+
+        // still the HBM pointers: a primitive is only patched in its own turn
+        const geo::HalfEdgeMesh src = w->prims[p].hull.halfEdgeMesh;
+
+        bool shared = false;
+        for (uint32_t q = 0; q < p; q++) {
+            if (w->primMeshKey[q] == (const void *)src.vertices) {
+                if (lane == 0) {
+                    w->prims[p].hull.halfEdgeMesh =
+                        w->prims[q].hull.halfEdgeMesh;
+                }
+                shared = true;
+                break;
+            }
+        }
+        if (shared) {
+            wave::phaseFence();
+            continue;
+        }
+
+        const uint32_t hedge_dw = src.numHalfEdges * 3;
+        const uint32_t base_dw = src.numFaces;
+        const uint32_t plane_dw = src.numFaces * 4;
+        const uint32_t vert_dw = src.numVertices * 3;
+        const uint32_t need = hedge_dw + base_dw + plane_dw + vert_dw;
+        if (arena_used + need > (uint32_t)Block::arenaDwords) {
+            continue;       // stays in HBM
+        }
+
+        uint32_t *dst = w->arena + arena_used;
+        waveCopyDwords(lane, dst, (const uint32_t *)src.facePlanes, plane_dw);
+        waveCopyDwords(lane, dst + plane_dw,
+                       (const uint32_t *)src.halfEdges, hedge_dw);
+        waveCopyDwords(lane, dst + plane_dw + hedge_dw,
+                       (const uint32_t *)src.vertices, vert_dw);
+        waveCopyDwords(lane, dst + plane_dw + hedge_dw + vert_dw,
+                       src.faceBaseHalfEdges, base_dw);
+        if (lane == 0) {
+            geo::HalfEdgeMesh &staged = w->prims[p].hull.halfEdgeMesh;
+            staged.facePlanes = (geo::Plane *)dst;
+            staged.halfEdges = (geo::HalfEdge *)(dst + plane_dw);
+            staged.vertices = (math::Vector3 *)(dst + plane_dw + hedge_dw);
+            staged.faceBaseHalfEdges = dst + plane_dw + hedge_dw + vert_dw;
+        }
+        arena_used += need;
+        wave::phaseFence();
+    }
+    wave::phaseFence();
+
+    ObjectManager staged = obj_mgr;
+    staged.collisionPrimitives = w->prims;
+    staged.primitiveAABBs = w->primAABBs;
+    return staged;
+}
+
+template <int MAXB>
+struct LdsBodyStore {
+    WorldBlock<MAXB> *w;
+
+    __device__ inline math::Vector3 &position(Loc l) { return w->pos[l.row]; }
+    __device__ inline math::Quat &rotation(Loc l) { return w->rot[l.row]; }
+    __device__ inline Velocity &velocity(Loc l) { return w->vel[l.row]; }
+    __device__ inline xpbd::SubstepPrevState prevState(Loc l)
+    {
+        return w->prev[l.row];
+    }
+    __device__ inline xpbd::PreSolvePositional presolvePositional(Loc l)
+    {
+        return w->prePos[l.row];
+    }
+    __device__ inline xpbd::PreSolveVelocity presolveVelocity(Loc l)
+    {
+        return w->preVel[l.row];
+    }
+    __device__ inline xpbd::BodyConstants constants(Loc l)
+    {
+        return w->constants[l.row];
+    }
+};
+
+template <int MAXB>
+__device__ inline uint64_t ldsBodyKey(const WorldBlock<MAXB> *w, int32_t k)
+{
+    return w->resp[k] == (uint32_t)ResponseType::Static ? 0ull :
+        (uint64_t)(k + 1);
+}
+
+template <int MAXB>
+__device__ inline PairSetup ldsSetupPair(const WorldBlock<MAXB> *w,
+                                         const ObjectManager &obj_mgr,
+                                         const WaveCandidate &candidate)
+{
+    const int32_t ka = candidate.a;
+    const int32_t kb = candidate.b;
+
+    return setupPair(obj_mgr, Loc { 0, ka }, Loc { 0, kb },
+        (uint32_t)w->primOffset[ka] + candidate.aPrim,
+        (uint32_t)w->primOffset[kb] + candidate.bPrim,
+        PrimitiveTransform { w->pos[ka], w->rot[ka], w->scale[ka] },
+        PrimitiveTransform { w->pos[kb], w->rot[kb], w->scale[kb] });
+}
+
+#ifndef MADRONA_PHYS_LDS_WAVES_PER_EU
+#define MADRONA_PHYS_LDS_WAVES_PER_EU 1
+#endif
+template <int MAXB>
+__global__ void __launch_bounds__(64)
+__attribute__((amdgpu_waves_per_eu(MADRONA_PHYS_LDS_WAVES_PER_EU)))
+physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
+{
+    using Block = WorldBlock<MAXB>;
+
+    StateManager *state_mgr = static_cast<StateManager *>(S);
+    PhysicsScratch *ps = detail::scratch(S);
+    const PhysicsStepParams params = *(const PhysicsStepParams *)node_data;
+
+    const uint32_t lane = wave::laneID();
+    const int32_t num_worlds = S->numWorlds;
+
+    __shared__ Block block;
+    Block *w = &block;
+    LdsBodyStore<MAXB> store { w };
+
+    // generic fallback only (hulls whose faces outgrow the LDS scratch)
+    constexpr int32_t max_elems = MADRONA_PHYS_MAX_HULL_ELEMS;
+    geo::Plane tmp_faces[max_elems];
+    math::Vector3 tmp_vertices[max_elems];
+
+#ifdef MADRONA_PHYS_PROFILE
+    unsigned long long prof_t = __builtin_readcyclecounter();
+    unsigned long long prof_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+#endif
+
+    for (int32_t world = (int32_t)blockIdx.x; world < num_worlds;
+         world += (int32_t)gridDim.x) {
+        Context ctx = TaskGraph::makeContext<Context>(
+            state_mgr, WorldID { world }, true);
+        const ObjectManager &hbm_obj_mgr = *ctx.singleton<ObjectData>().mgr;
+        const broadphase::BVH &bvh = ctx.singleton<broadphase::BVH>();
+
+        // ---- the world's bodies ---------------------------------------------
+        WorldBodies bodies;
+        bodies.numArchetypes = ps->numBodyArchetypes;
+        bodies.bodyBase[0] = 0;
+        bool unsorted = false;
+        for (uint32_t a = 0; a < bodies.numArchetypes; a++) {
+            const TableHdr &tbl = S->tables[ps->bodyArchetypes[a]];
+            bodies.archetype[a] = ps->bodyArchetypes[a];
+            bodies.rowBase[a] = tbl.worldOffsets[world];
+            bodies.bodyBase[a + 1] =
+                bodies.bodyBase[a] + tbl.worldCounts[world];
+            unsorted = unsorted || tbl.needsSort != 0;
+        }
+        const int32_t num_bodies = bodies.count();
+        if (unsorted || num_bodies > MAXB || bvh.numLeaves() != num_bodies) {
+            mwhip::raiseError(S, mwhip::kErrPhysics);
+            continue;
+        }
+
+        // ---- load: HBM -> LDS ---------------------------------------------------
+        for (int32_t k = (int32_t)lane; k < num_bodies; k += 64) {
+            Loc loc = bodies.loc(k);
+            w->pos[k] = ctx.getDirect<base::Position>(RGDCols::Position, loc);
+            w->rot[k] = ctx.getDirect<base::Rotation>(RGDCols::Rotation, loc);
+            w->scale[k] = ctx.getDirect<base::Scale>(RGDCols::Scale, loc);
+            w->vel[k] = ctx.getDirect<Velocity>(RGDCols::Velocity, loc);
+            w->extForce[k] =
+                ctx.getDirect<ExternalForce>(RGDCols::ExternalForce, loc);
+            w->extTorque[k] =
+                ctx.getDirect<ExternalTorque>(RGDCols::ExternalTorque, loc);
+
+            ResponseType resp =
+                ctx.getDirect<ResponseType>(RGDCols::ResponseType, loc);
+            w->resp[k] = (uint32_t)resp;
+            w->entityID[k] = ctx.getDirect<Entity>(0, loc).id;
+
+            base::ObjectID obj_id =
+                ctx.getDirect<base::ObjectID>(RGDCols::ObjectID, loc);
+            const RigidBodyMetadata metadata =
+                hbm_obj_mgr.metadata[obj_id.idx];
+            w->constants[k] = xpbd::bodyConstants(metadata, resp);
+            w->primOffset[k] = (uint16_t)
+                hbm_obj_mgr.rigidBodyPrimitiveOffsets[obj_id.idx];
+            w->primCount[k] = (uint16_t)
+                hbm_obj_mgr.rigidBodyPrimitiveCounts[obj_id.idx];
+
+            int32_t leaf = ctx.getDirect<broadphase::LeafID>(
+                RGDCols::LeafID, loc).id;
+            w->queryBox()[k] = bvh.getLeafAABB(broadphase::LeafID { leaf });
+            w->slotBox()[k] = bvh.leafSlotBounds(leaf);
+            w->leafBody[leaf] = (uint16_t)k;
+        }
+        if (lane == 0) {
+            w->sys = ctx.singleton<PhysicsSystemState>();
+        }
+        wave::phaseFence();
+
+        // primitives referenced by this world's bodies
+        uint32_t prim_end = 0;
+        for (int32_t k = (int32_t)lane; k < num_bodies; k += 64) {
+            uint32_t end = (uint32_t)w->primOffset[k] + w->primCount[k];
+            prim_end = end > prim_end ? end : prim_end;
+        }
+        prim_end = wave::maxReduce(prim_end);
+#ifdef MADRONA_PHYS_NO_STAGE_PRIMS
+        const ObjectManager obj_mgr = hbm_obj_mgr;
+        (void)prim_end;
+#else
+        const ObjectManager obj_mgr =
+            stagePrimitives(lane, w, hbm_obj_mgr, prim_end);
+#endif
+
+        {
+            const int32_t *order = bvh.traversalOrder();
+            for (int32_t r = (int32_t)lane; r < num_bodies; r += 64) {
+                w->orderBody[r] = w->leafBody[order[r]];
+            }
+        }
+        wave::phaseFence();
+        PHYS_PROF(0);
+
+        // ---- broadphase: candidate pairs in (body, traversal) order -----------
+        uint32_t num_candidates = 0;
+        for (int32_t chunk = 0; chunk < num_bodies; chunk += 64) {
+            const int32_t k = chunk + (int32_t)lane;
+            const bool active = k < num_bodies;
+
+            auto forEachHit = [&](auto &&fn) {
+                const math::AABB query = w->queryBox()[k];
+                const int32_t my_id = w->entityID[k];
+                const bool my_static =
+                    w->resp[k] == (uint32_t)ResponseType::Static;
+                for (int32_t r = 0; r < num_bodies; r++) {
+                    const int32_t kb = w->orderBody[r];
+                    if (!query.overlaps(w->slotBox()[kb])) continue;
+                    if (!(my_id < w->entityID[kb])) continue;
+                    if (my_static &&
+                        w->resp[kb] == (uint32_t)ResponseType::Static) {
+                        continue;
+                    }
+                    fn(kb);
+                }
+            };
+
+            uint32_t n = 0;
+            if (active) {
+                const uint32_t a_prims = w->primCount[k];
+                forEachHit([&](int32_t kb) { n += a_prims * w->primCount[kb]; });
+            }
+
+            uint32_t chunk_total;
+            uint32_t out = num_candidates +
+                wave::exclusiveScan(n, lane, &chunk_total);
+
+            if (active && n != 0 && out + n <= (uint32_t)Block::maxCandidates) {
+                const uint32_t a_prims = w->primCount[k];
+                forEachHit([&](int32_t kb) {
+                    const uint32_t b_prims = w->primCount[kb];
+                    const uint32_t total_checks = a_prims * b_prims;
+                    for (uint32_t c = 0; c < total_checks; c++) {
+                        w->candidates[out++] = WaveCandidate {
+                            (uint16_t)k, (uint16_t)kb,
+                            (uint16_t)(c / b_prims), (uint16_t)(c % b_prims),
+                        };
+                    }
+                });
+            }
+            num_candidates += chunk_total;
+        }
+        if (num_candidates > (uint32_t)Block::maxCandidates) {
+            mwhip::raiseError(S, mwhip::kErrTableOverflow);
+            continue;
+        }
+        wave::phaseFence();
+        PHYS_PROF(1);
+
+        // ---- the world's joints (table sorted by world just before) -----------
+        const TableHdr &joint_tbl = S->tables[ps->jointArchetype];
+        const int32_t joint_begin = joint_tbl.worldOffsets[world];
+        const int32_t num_joints = joint_tbl.worldCounts[world];
+        const JointConstraint *joints =
+            (const JointConstraint *)joint_tbl.columns[2] + joint_begin;
+
+        // body index of a joint end point
+        auto jointBodyLoc = [&](Entity e) {
+            Loc loc = ctx.loc(e);
+            for (uint32_t a = 0; a < bodies.numArchetypes; a++) {
+                if (bodies.archetype[a] == loc.archetype) {
+                    return Loc { 0,
+                        bodies.bodyBase[a] + (loc.row - bodies.rowBase[a]) };
+                }
+            }
+            return Loc { 0, 0 };
+        };
+        const bool joints_staged = num_joints <= Block::maxJoints;
+        if (joints_staged) {
+            for (int32_t i = (int32_t)lane; i < num_joints; i += 64) {
+                w->joints[i] = joints[i];
+                w->jointBodies[i][0] =
+                    (uint16_t)jointBodyLoc(joints[i].e1).row;
+                w->jointBodies[i][1] =
+                    (uint16_t)jointBodyLoc(joints[i].e2).row;
+            }
+            wave::phaseFence();
+        }
+
+        for (int32_t substep = 0; substep < params.numSubsteps; substep++) {
+            // ---- integrate (xpbd.cpp substepRigidBodies) ------------------------
+            for (int32_t k = (int32_t)lane; k < num_bodies; k += 64) {
+                Vector3 x = w->pos[k];
+                Quat q = w->rot[k];
+
+                w->prev[k] = xpbd::SubstepPrevState { x, q };
+
+                if (w->resp[k] == (uint32_t)ResponseType::Static) {
+                    w->prePos[k] = xpbd::PreSolvePositional { x, q };
+                    w->preVel[k] = xpbd::PreSolveVelocity {
+                        Vector3::zero(), Vector3::zero() };
+                    continue;
+                }
+
+                xpbd::SubstepResult next = xpbd::integrateBody(
+                    x, q, w->vel[k].linear, w->vel[k].angular,
+                    w->constants[k].invMass, w->constants[k].invInertia,
+                    w->extForce[k],
+                    w->extTorque[k], w->sys.g, w->sys.h,
+                    w->resp[k] == (uint32_t)ResponseType::Dynamic);
+
+                w->pos[k] = next.x;
+                w->rot[k] = next.q;
+                w->prePos[k] = xpbd::PreSolvePositional { next.x, next.q };
+                w->preVel[k] = xpbd::PreSolveVelocity { next.v, next.omega };
+            }
+            wave::phaseFence();
+            PHYS_PROF(2);
+
+            // ---- narrowphase: contacts in candidate order ------------------------
+            uint32_t num_contacts = 0;
+            for (uint32_t chunk = 0; chunk < num_candidates; chunk += 64) {
+                const uint32_t c = chunk + lane;
+                ContactConstraint contact;
+                bool has_contact = false;
+                bool too_big = false;
+                bool unsupported = false;
+
+                uint32_t kind = 0;      // 1: this lane alone, 2: whole wave
+                PairSetup pair;
+                if (c < num_candidates) {
+                    pair = ldsSetupPair(w, obj_mgr, w->candidates[c]);
+                    if (pair.aabbOverlap) {
+                        kind = pair.test == NarrowphaseTest::HullHull ? 2 : 1;
+                    }
+                }
+
+                // lanes on their own, in rounds of lanePolyRows scratch rows
+                uint64_t solo = __builtin_amdgcn_ballot_w64(kind == 1);
+                const uint32_t solo_rank = wave::rankInBallot(solo);
+                const uint32_t solo_count = (uint32_t)__builtin_popcountll(solo);
+                for (uint32_t first = 0; first < solo_count;
+                     first += lanePolyRows) {
+                    if (kind == 1 && solo_rank >= first &&
+                            solo_rank < first + lanePolyRows) {
+                        has_contact = collidePairLane(pair,
+                            w->scratch.lanePoly +
+                                (solo_rank - first) * lanePolyDwords,
+                            &contact, &too_big, &unsupported);
+                    }
+                }
+
+                uint64_t hull_pairs = __builtin_amdgcn_ballot_w64(kind == 2);
+                while (hull_pairs != 0) {
+                    const uint32_t src = (uint32_t)__builtin_ctzll(hull_pairs);
+                    hull_pairs &= hull_pairs - 1;
+
+                    PairSetup shared_pair =
+                        ldsSetupPair(w, obj_mgr, w->candidates[chunk + src]);
+                    ContactConstraint shared_contact;
+                    bool shared_too_big = false;
+                    bool found = hullHullWave(lane, shared_pair, &w->scratch,
+                        &shared_contact, &shared_too_big);
+                    if (lane == src) {
+                        contact = shared_contact;
+                        has_contact = found;
+                        too_big = shared_too_big;
+                    }
+                }
+
+                if (too_big) {
+                    has_contact = collidePairStored(pair, tmp_vertices,
+                        tmp_faces, max_elems, &contact, &unsupported);
+                }
+                if (unsupported) {
+                    mwhip::raiseError(S, mwhip::kErrPhysics);
+                }
+
+                uint64_t mask = __builtin_amdgcn_ballot_w64(has_contact);
+                uint32_t dst = num_contacts + wave::rankInBallot(mask);
+                if (has_contact && dst < (uint32_t)Block::maxContacts) {
+                    w->contacts()[dst] = contact;
+                }
+                num_contacts += (uint32_t)__builtin_popcountll(mask);
+            }
+            if (num_contacts > (uint32_t)Block::maxContacts) {
+                mwhip::raiseError(S, mwhip::kErrTableOverflow);
+                num_contacts = (uint32_t)Block::maxContacts;
+            }
+            wave::phaseFence();
+            PHYS_PROF(3);
+
+            // ---- position solve: contacts, then joints, level by level ----------
+            for (uint32_t base = 0; base < num_contacts; base += 64) {
+                const uint32_t n = num_contacts - base < 64 ?
+                    num_contacts - base : 64;
+                const uint32_t i = base + lane;
+                uint64_t key_a = 0, key_b = 0;
+                if (lane < n) {
+                    key_a = ldsBodyKey(w, w->contacts()[i].ref.row);
+                    key_b = ldsBodyKey(w, w->contacts()[i].alt.row);
+                }
+                uint32_t level = constraintLevels(lane, n, key_a, key_b);
+                uint32_t max_level = wave::maxReduce(lane < n ? level : 0);
+
+                for (uint32_t l = 0; l <= max_level; l++) {
+                    if (lane < n && level == l) {
+                        float lambda_n[4] { 0.f, 0.f, 0.f, 0.f };
+                        xpbd::handleContact(store, w->contacts()[i], lambda_n);
+                        w->lambdas[i] = lambda_n[0];
+                    }
+                    wave::phaseFence();
+                }
+            }
+
+            for (int32_t base = 0; base < num_joints; base += 64) {
+                const uint32_t n = num_joints - base < 64 ?
+                    (uint32_t)(num_joints - base) : 64u;
+                const int32_t i = base + (int32_t)lane;
+                Loc l1 { 0, 0 }, l2 { 0, 0 };
+                uint64_t key_a = 0, key_b = 0;
+                if (lane < n) {
+                    if (joints_staged) {
+                        l1 = Loc { 0, (int32_t)w->jointBodies[i][0] };
+                        l2 = Loc { 0, (int32_t)w->jointBodies[i][1] };
+                    } else {
+                        l1 = jointBodyLoc(joints[i].e1);
+                        l2 = jointBodyLoc(joints[i].e2);
+                    }
+                    key_a = ldsBodyKey(w, l1.row);
+                    key_b = ldsBodyKey(w, l2.row);
+                }
+                uint32_t level = constraintLevels(lane, n, key_a, key_b);
+                uint32_t max_level = wave::maxReduce(lane < n ? level : 0);
+
+                for (uint32_t l = 0; l <= max_level; l++) {
+                    if (lane < n && level == l) {
+                        xpbd::handleJointConstraint(store, l1, l2,
+                            joints_staged ? w->joints[i] : joints[i]);
+                    }
+                    wave::phaseFence();
+                }
+            }
+
+            PHYS_PROF(4);
+            // ---- velocities -----------------------------------------------------
+            for (int32_t k = (int32_t)lane; k < num_bodies; k += 64) {
+                w->vel[k] = xpbd::deriveVelocity(w->pos[k], w->rot[k],
+                                                 w->prev[k], w->sys.h);
+            }
+            wave::phaseFence();
+            PHYS_PROF(5);
+
+            for (uint32_t base = 0; base < num_contacts; base += 64) {
+                const uint32_t n = num_contacts - base < 64 ?
+                    num_contacts - base : 64;
+                const uint32_t i = base + lane;
+                uint64_t key_a = 0, key_b = 0;
+                if (lane < n) {
+                    key_a = ldsBodyKey(w, w->contacts()[i].ref.row);
+                    key_b = ldsBodyKey(w, w->contacts()[i].alt.row);
+                }
+                uint32_t level = constraintLevels(lane, n, key_a, key_b);
+                uint32_t max_level = wave::maxReduce(lane < n ? level : 0);
+
+                for (uint32_t l = 0; l <= max_level; l++) {
+                    if (lane < n && level == l) {
+                        float lambda_n[4] { w->lambdas[i], 0.f, 0.f, 0.f };
+                        xpbd::solveVelocitiesForContact(store, w->contacts()[i],
+                            lambda_n, w->sys.h,
+                            w->sys.restitutionThreshold);
+                    }
+                    wave::phaseFence();
+                }
+            }
+        }
+
+        PHYS_PROF(6);
+        // ---- store: LDS -> HBM --------------------------------------------------
+        for (int32_t k = (int32_t)lane; k < num_bodies; k += 64) {
+            Loc loc = bodies.loc(k);
+            ctx.getDirect<base::Position>(RGDCols::Position, loc) = w->pos[k];
+            ctx.getDirect<base::Rotation>(RGDCols::Rotation, loc) = w->rot[k];
+            ctx.getDirect<Velocity>(RGDCols::Velocity, loc) = w->vel[k];
+            ctx.getDirect<xpbd::SubstepPrevState>(
+                xpbd::XPBDCols::SubstepPrevState, loc) = w->prev[k];
+            ctx.getDirect<xpbd::PreSolvePositional>(
+                xpbd::XPBDCols::PreSolvePositional, loc) = w->prePos[k];
+            ctx.getDirect<xpbd::PreSolveVelocity>(
+                xpbd::XPBDCols::PreSolveVelocity, loc) = w->preVel[k];
+        }
+        wave::phaseFence();
+        PHYS_PROF(7);
+    }
+
+#ifdef MADRONA_PHYS_PROFILE
+    if (lane == 0 && S->moduleData[1] != nullptr) {
+        unsigned long long *dst = (unsigned long long *)S->moduleData[1];
+        for (int i = 0; i < 8; i++) {
+            atomicAdd(&dst[i], prof_acc[i]);
+        }
+    }
+#endif
+}

@@ -557,9 +557,11 @@ MADRONA_HD inline void applyRestitutionVelocityUpdate(
 }
 
 // ---------------------------------------------------------------------------
-// ECS-facing wrappers: gather body state through Loc, solve, scatter back
+// Constraint solves against a body store: gather the two bodies, solve, scatter
 // (reference xpbd.cpp handleContact :454-548, handleJointConstraint :607-718,
-// solveVelocitiesForContact :918-1036)
+// solveVelocitiesForContact :918-1036).  The store decides where body state
+// lives: ECS columns in HBM (EcsBodyStore) or a world's LDS block
+// (phys_impl/world_step.inl); constraints name bodies by Loc either way.
 // ---------------------------------------------------------------------------
 struct BodyConstants {
     float invMass;
@@ -567,17 +569,9 @@ struct BodyConstants {
     RigidBodyFrictionData friction;
 };
 
-MADRONA_HD inline BodyConstants bodyConstants(Context &ctx,
-                                              const ObjectManager &obj_mgr,
-                                              Loc loc)
+MADRONA_HD inline BodyConstants bodyConstants(const RigidBodyMetadata &metadata,
+                                              ResponseType resp_type)
 {
-    base::ObjectID obj_id =
-        ctx.getDirect<base::ObjectID>(RGDCols::ObjectID, loc);
-    ResponseType resp_type =
-        ctx.getDirect<ResponseType>(RGDCols::ResponseType, loc);
-
-    RigidBodyMetadata metadata = obj_mgr.metadata[obj_id.idx];
-
     BodyConstants c {
         metadata.mass.invMass,
         metadata.mass.invInertiaTensor,
@@ -592,32 +586,69 @@ MADRONA_HD inline BodyConstants bodyConstants(Context &ctx,
     return c;
 }
 
-MADRONA_HD inline void handleContact(Context &ctx,
-                                     const ObjectManager &obj_mgr,
+struct EcsBodyStore {
+    Context &ctx;
+    const ObjectManager &objMgr;
+
+    MADRONA_HD inline Vector3 &position(Loc l)
+    {
+        return ctx.getDirect<base::Position>(RGDCols::Position, l);
+    }
+
+    MADRONA_HD inline Quat &rotation(Loc l)
+    {
+        return ctx.getDirect<base::Rotation>(RGDCols::Rotation, l);
+    }
+
+    MADRONA_HD inline Velocity &velocity(Loc l)
+    {
+        return ctx.getDirect<Velocity>(RGDCols::Velocity, l);
+    }
+
+    MADRONA_HD inline SubstepPrevState prevState(Loc l)
+    {
+        return ctx.getDirect<SubstepPrevState>(XPBDCols::SubstepPrevState, l);
+    }
+
+    MADRONA_HD inline PreSolvePositional presolvePositional(Loc l)
+    {
+        return ctx.getDirect<PreSolvePositional>(
+            XPBDCols::PreSolvePositional, l);
+    }
+
+    MADRONA_HD inline PreSolveVelocity presolveVelocity(Loc l)
+    {
+        return ctx.getDirect<PreSolveVelocity>(XPBDCols::PreSolveVelocity, l);
+    }
+
+    MADRONA_HD inline BodyConstants constants(Loc l)
+    {
+        base::ObjectID obj_id =
+            ctx.getDirect<base::ObjectID>(RGDCols::ObjectID, l);
+        ResponseType resp_type =
+            ctx.getDirect<ResponseType>(RGDCols::ResponseType, l);
+        return bodyConstants(objMgr.metadata[obj_id.idx], resp_type);
+    }
+};
+
+template <typename StoreT>
+MADRONA_HD inline void handleContact(StoreT &store,
                                      const ContactConstraint &contact,
                                      float *lambdas)
 {
-    base::Position *x1_ptr =
-        &ctx.getDirect<base::Position>(RGDCols::Position, contact.ref);
-    base::Position *x2_ptr =
-        &ctx.getDirect<base::Position>(RGDCols::Position, contact.alt);
-    base::Rotation *q1_ptr =
-        &ctx.getDirect<base::Rotation>(RGDCols::Rotation, contact.ref);
-    base::Rotation *q2_ptr =
-        &ctx.getDirect<base::Rotation>(RGDCols::Rotation, contact.alt);
+    Vector3 *x1_ptr = &store.position(contact.ref);
+    Vector3 *x2_ptr = &store.position(contact.alt);
+    Quat *q1_ptr = &store.rotation(contact.ref);
+    Quat *q2_ptr = &store.rotation(contact.alt);
 
-    SubstepPrevState prev1 = ctx.getDirect<SubstepPrevState>(
-        XPBDCols::SubstepPrevState, contact.ref);
-    SubstepPrevState prev2 = ctx.getDirect<SubstepPrevState>(
-        XPBDCols::SubstepPrevState, contact.alt);
+    SubstepPrevState prev1 = store.prevState(contact.ref);
+    SubstepPrevState prev2 = store.prevState(contact.alt);
 
-    PreSolvePositional presolve_pos1 = ctx.getDirect<PreSolvePositional>(
-        XPBDCols::PreSolvePositional, contact.ref);
-    PreSolvePositional presolve_pos2 = ctx.getDirect<PreSolvePositional>(
-        XPBDCols::PreSolvePositional, contact.alt);
+    PreSolvePositional presolve_pos1 = store.presolvePositional(contact.ref);
+    PreSolvePositional presolve_pos2 = store.presolvePositional(contact.alt);
 
-    BodyConstants c1 = bodyConstants(ctx, obj_mgr, contact.ref);
-    BodyConstants c2 = bodyConstants(ctx, obj_mgr, contact.alt);
+    BodyConstants c1 = store.constants(contact.ref);
+    BodyConstants c2 = store.constants(contact.alt);
 
     Vector3 x1 = *x1_ptr;
     Vector3 x2 = *x2_ptr;
@@ -652,25 +683,22 @@ MADRONA_HD inline void handleContact(Context &ctx,
     *q2_ptr = q2;
 }
 
-MADRONA_HD inline void handleJointConstraint(Context &ctx,
-                                             const ObjectManager &obj_mgr,
+template <typename StoreT>
+MADRONA_HD inline void handleJointConstraint(StoreT &store, Loc l1, Loc l2,
                                              const JointConstraint &joint)
 {
-    Loc l1 = ctx.loc(joint.e1);
-    Loc l2 = ctx.loc(joint.e2);
-
-    Vector3 *x1_ptr = &ctx.getDirect<base::Position>(RGDCols::Position, l1);
-    Vector3 *x2_ptr = &ctx.getDirect<base::Position>(RGDCols::Position, l2);
-    Quat *q1_ptr = &ctx.getDirect<base::Rotation>(RGDCols::Rotation, l1);
-    Quat *q2_ptr = &ctx.getDirect<base::Rotation>(RGDCols::Rotation, l2);
+    Vector3 *x1_ptr = &store.position(l1);
+    Vector3 *x2_ptr = &store.position(l2);
+    Quat *q1_ptr = &store.rotation(l1);
+    Quat *q2_ptr = &store.rotation(l2);
 
     Vector3 x1 = *x1_ptr;
     Vector3 x2 = *x2_ptr;
     Quat q1 = *q1_ptr;
     Quat q2 = *q2_ptr;
 
-    BodyConstants c1 = bodyConstants(ctx, obj_mgr, l1);
-    BodyConstants c2 = bodyConstants(ctx, obj_mgr, l2);
+    BodyConstants c1 = store.constants(l1);
+    BodyConstants c2 = store.constants(l2);
 
     solveJoint(joint, x1, x2, q1, q2, c1.invMass, c2.invMass,
                c1.invInertia, c2.invInertia);
@@ -681,29 +709,25 @@ MADRONA_HD inline void handleJointConstraint(Context &ctx,
     *q2_ptr = q2;
 }
 
+template <typename StoreT>
 MADRONA_HD inline void solveVelocitiesForContact(
-    Context &ctx, const ObjectManager &obj_mgr,
-    const ContactConstraint &contact, const float *lambda_n,
+    StoreT &store, const ContactConstraint &contact, const float *lambda_n,
     float h, float restitution_threshold)
 {
-    Velocity *v1_out = &ctx.getDirect<Velocity>(RGDCols::Velocity, contact.ref);
-    Velocity *v2_out = &ctx.getDirect<Velocity>(RGDCols::Velocity, contact.alt);
+    Velocity *v1_out = &store.velocity(contact.ref);
+    Velocity *v2_out = &store.velocity(contact.alt);
 
-    Quat q1 = ctx.getDirect<base::Rotation>(RGDCols::Rotation, contact.ref);
-    Quat q2 = ctx.getDirect<base::Rotation>(RGDCols::Rotation, contact.alt);
+    Quat q1 = store.rotation(contact.ref);
+    Quat q2 = store.rotation(contact.alt);
 
-    PreSolvePositional presolve_pos1 = ctx.getDirect<PreSolvePositional>(
-        XPBDCols::PreSolvePositional, contact.ref);
-    PreSolvePositional presolve_pos2 = ctx.getDirect<PreSolvePositional>(
-        XPBDCols::PreSolvePositional, contact.alt);
+    PreSolvePositional presolve_pos1 = store.presolvePositional(contact.ref);
+    PreSolvePositional presolve_pos2 = store.presolvePositional(contact.alt);
 
-    PreSolveVelocity presolve_vel1 = ctx.getDirect<PreSolveVelocity>(
-        XPBDCols::PreSolveVelocity, contact.ref);
-    PreSolveVelocity presolve_vel2 = ctx.getDirect<PreSolveVelocity>(
-        XPBDCols::PreSolveVelocity, contact.alt);
+    PreSolveVelocity presolve_vel1 = store.presolveVelocity(contact.ref);
+    PreSolveVelocity presolve_vel2 = store.presolveVelocity(contact.alt);
 
-    BodyConstants c1 = bodyConstants(ctx, obj_mgr, contact.ref);
-    BodyConstants c2 = bodyConstants(ctx, obj_mgr, contact.alt);
+    BodyConstants c1 = store.constants(contact.ref);
+    BodyConstants c2 = store.constants(contact.alt);
 
     Vector3 v1 = v1_out->linear;
     Vector3 omega1 = v1_out->angular;
@@ -772,6 +796,34 @@ MADRONA_HD inline void solveVelocitiesForContact(
 
     *v1_out = Velocity { v1, omega1 };
     *v2_out = Velocity { v2, omega2 };
+}
+
+// ECS-backed conveniences
+MADRONA_HD inline void handleContact(Context &ctx,
+                                     const ObjectManager &obj_mgr,
+                                     const ContactConstraint &contact,
+                                     float *lambdas)
+{
+    EcsBodyStore store { ctx, obj_mgr };
+    handleContact(store, contact, lambdas);
+}
+
+MADRONA_HD inline void handleJointConstraint(Context &ctx,
+                                             const ObjectManager &obj_mgr,
+                                             const JointConstraint &joint)
+{
+    EcsBodyStore store { ctx, obj_mgr };
+    handleJointConstraint(store, ctx.loc(joint.e1), ctx.loc(joint.e2), joint);
+}
+
+MADRONA_HD inline void solveVelocitiesForContact(
+    Context &ctx, const ObjectManager &obj_mgr,
+    const ContactConstraint &contact, const float *lambda_n,
+    float h, float restitution_threshold)
+{
+    EcsBodyStore store { ctx, obj_mgr };
+    solveVelocitiesForContact(store, contact, lambda_n, h,
+                              restitution_threshold);
 }
 
 }

@@ -47,8 +47,18 @@ struct PhysicsScratch {
     uint32_t contactArchetype;
     uint32_t jointArchetype;
 
-    uint32_t *contactFlags;                     // per candidate row: 0/1 -> offset
-    ContactConstraint *contactStaging;          // per candidate row
+    // fused per-world step (phys_impl/world_step.inl): fixed-stride per-world
+    // segments, world w owns [w * stride, (w + 1) * stride)
+    uint32_t candidatesPerWorld;
+    uint32_t contactsPerWorld;
+    CandidateCollision *worldCandidates;
+    ContactConstraint *worldContacts;
+    float *worldLambdas;
+};
+
+// node data of the fused per-world step kernel
+struct PhysicsStepParams {
+    int32_t numSubsteps;
 };
 
 namespace detail {
@@ -129,247 +139,24 @@ struct PrimitiveTransform {
     Diag3x3 scale;
 };
 
-MADRONA_HD inline NarrowphaseResult noContact()
-{
-    NarrowphaseResult result {};
-    result.type = ContactType::None;
-    return result;
-}
+// A candidate after primitive-type ordering (a's type <= b's type), ready for
+// the type-specific test.
+struct PairSetup {
+    Loc aLoc;
+    Loc bLoc;
+    const CollisionPrimitive *aPrim;
+    const CollisionPrimitive *bPrim;
+    PrimitiveTransform a;
+    PrimitiveTransform b;
+    NarrowphaseTest test;
+    bool aabbOverlap;       // false: the pair cannot touch
+};
 
-MADRONA_HD inline NarrowphaseResult sphereResult(SphereContact contact)
-{
-    NarrowphaseResult result {};
-    result.type = ContactType::Sphere;
-    result.sphere = contact;
-    return result;
-}
-
-MADRONA_HD inline NarrowphaseResult narrowphaseDispatch(
-    NarrowphaseTest test_type,
-    const PrimitiveTransform &a, const PrimitiveTransform &b,
-    const CollisionPrimitive *a_prim, const CollisionPrimitive *b_prim,
-    Vector3 *txfm_vertex_buffer, Plane *txfm_face_buffer,
-    CountT max_tmp_elems, bool *unsupported)
-{
-    switch (test_type) {
-    case NarrowphaseTest::SphereSphere: {
-        float a_radius = a.scale.d0 * a_prim->sphere.radius;
-        float b_radius = b.scale.d0 * b_prim->sphere.radius;
-
-        Vector3 to_b = b.pos - a.pos;
-        float dist = to_b.length();
-
-        if (dist > a_radius + b_radius) {
-            return noContact();
-        }
-
-        Vector3 normal = dist > 0.f ? to_b / dist : math::up;
-        float penetration = a_radius + b_radius - dist;
-
-        return sphereResult(SphereContact {
-            normal,
-            a.pos + a_radius * normal,
-            penetration,
-        });
-    }
-    case NarrowphaseTest::HullHull: {
-        const HalfEdgeMesh &a_he_mesh = a_prim->hull.halfEdgeMesh;
-        const HalfEdgeMesh &b_he_mesh = b_prim->hull.halfEdgeMesh;
-
-        if ((CountT)(a_he_mesh.numFaces + b_he_mesh.numFaces) > max_tmp_elems ||
-            (CountT)(a_he_mesh.numVertices + b_he_mesh.numVertices) >
-                max_tmp_elems) {
-            *unsupported = true;
-            return noContact();
-        }
-
-        HullState a_hull_state = makeHullState(a_he_mesh, a.pos, a.rot,
-            a.scale, txfm_vertex_buffer, txfm_face_buffer);
-
-        txfm_vertex_buffer += a_hull_state.mesh.numVertices;
-        txfm_face_buffer += a_hull_state.mesh.numFaces;
-
-        HullState b_hull_state = makeHullState(b_he_mesh, b.pos, b.rot,
-            b.scale, txfm_vertex_buffer, txfm_face_buffer);
-
-        const SATResult sat = doSAT(a_hull_state, b_hull_state);
-
-        NarrowphaseResult result {};
-        result.type = sat.type;
-        result.sat = sat.contact;
-        result.aVertices = a_hull_state.mesh.vertices;
-        result.bVertices = b_hull_state.mesh.vertices;
-        result.aHalfEdges = a_hull_state.mesh.halfEdges;
-        result.bHalfEdges = b_hull_state.mesh.halfEdges;
-        result.aFaceHedgeRoots = a_hull_state.mesh.faceBaseHalfEdges;
-        result.bFaceHedgeRoots = b_hull_state.mesh.faceBaseHalfEdges;
-        return result;
-    }
-    case NarrowphaseTest::SpherePlane: {
-        float sphere_radius = a.scale.d0 * a_prim->sphere.radius;
-
-        constexpr Vector3 base_normal = { 0, 0, 1 };
-        Vector3 plane_normal = b.rot.rotateVec(base_normal);
-
-        float d = plane_normal.dot(b.pos);
-        float t = plane_normal.dot(a.pos) - d;
-
-        float penetration = sphere_radius - t;
-        if (penetration < 0) {
-            return noContact();
-        }
-
-        return sphereResult(SphereContact {
-            plane_normal,
-            a.pos - t * plane_normal,
-            penetration,
-        });
-    }
-    case NarrowphaseTest::HullPlane: {
-        const HalfEdgeMesh &a_he_mesh = a_prim->hull.halfEdgeMesh;
-
-        if ((CountT)a_he_mesh.numFaces > max_tmp_elems ||
-            (CountT)a_he_mesh.numVertices > max_tmp_elems) {
-            *unsupported = true;
-            return noContact();
-        }
-
-        HullState a_hull_state = makeHullState(a_he_mesh, a.pos, a.rot,
-            a.scale, txfm_vertex_buffer, txfm_face_buffer);
-
-        constexpr Vector3 base_normal = { 0, 0, 1 };
-        Vector3 plane_normal = b.rot.rotateVec(base_normal);
-
-        Plane plane { plane_normal, dot(plane_normal, b.pos) };
-
-        const SATResult sat = doSATPlane(plane, a_hull_state);
-
-        NarrowphaseResult result {};
-        result.type = sat.type;
-        result.sat = sat.contact;
-        result.aVertices = a_hull_state.mesh.vertices;
-        result.aHalfEdges = a_hull_state.mesh.halfEdges;
-        result.aFaceHedgeRoots = a_hull_state.mesh.faceBaseHalfEdges;
-        return result;
-    }
-    case NarrowphaseTest::SphereHull:   // needs GJK: SURVEY.md §8f, not built yet
-    case NarrowphaseTest::PlanePlane:   // planes are static, never paired
-    default:
-        *unsupported = true;
-        return noContact();
-    }
-}
-
-MADRONA_HD inline void manifoldToContact(const Manifold &manifold,
-                                         Loc ref_loc, Loc other_loc,
-                                         ContactConstraint *out)
-{
-    out->ref = ref_loc;
-    out->alt = other_loc;
-    for (int i = 0; i < 4; i++) {
-        out->points[i] = Vector4::fromVec3W(manifold.contactPoints[i],
-                                            manifold.penetrationDepths[i]);
-    }
-    out->numPoints = manifold.numContactPoints;
-    out->normal = manifold.normal;
-}
-
-// returns true when a contact was produced
-MADRONA_HD inline bool generateContact(const NarrowphaseResult &result,
-                                       Loc a_loc, Loc b_loc,
-                                       void *tmp_storage_a, void *tmp_storage_b,
-                                       ContactConstraint *out)
-{
-    const Vector3 no_offset { 0, 0, 0 };
-    const Quat no_rot { 1, 0, 0, 0 };
-
-    switch (result.type) {
-    case ContactType::Sphere: {
-        out->ref = b_loc;
-        out->alt = a_loc;
-        out->points[0] =
-            Vector4::fromVec3W(result.sphere.pt, result.sphere.depth);
-        out->points[1] = Vector4::zero();
-        out->points[2] = Vector4::zero();
-        out->points[3] = Vector4::zero();
-        out->numPoints = 1;
-        out->normal = result.sphere.normal;
-        return true;
-    }
-    case ContactType::SATPlane: {
-        // the plane is always b and always the reference
-        Plane plane { result.sat.normal, result.sat.planeDOrSeparation };
-
-        Manifold manifold = createFacePlaneContact(
-            plane, (int32_t)result.sat.incidentFaceIdxOrEdgeIdxB,
-            result.aVertices, result.aHalfEdges, result.aFaceHedgeRoots,
-            (Vector3 *)tmp_storage_a, (float *)tmp_storage_b,
-            no_offset, no_rot);
-
-        // barely touching pairs can lose every clipped point to fp32
-        if (manifold.numContactPoints == 0) {
-            return false;
-        }
-        manifoldToContact(manifold, b_loc, a_loc, out);
-        return true;
-    }
-    case ContactType::SATFace: {
-        uint32_t ref_face_idx_and_ref_mask = result.sat.refFaceIdxOrEdgeIdxA;
-        uint32_t incident_face_idx = result.sat.incidentFaceIdxOrEdgeIdxB;
-
-        uint32_t ref_face_idx = ref_face_idx_and_ref_mask & 0x7FFFFFFFu;
-        bool a_is_ref = ref_face_idx == ref_face_idx_and_ref_mask;
-
-        Plane ref_plane { result.sat.normal, result.sat.planeDOrSeparation };
-
-        Manifold manifold = a_is_ref ?
-            createFaceContact(ref_plane, (int32_t)ref_face_idx,
-                (int32_t)incident_face_idx,
-                result.aVertices, result.bVertices,
-                result.aHalfEdges, result.bHalfEdges,
-                result.aFaceHedgeRoots, result.bFaceHedgeRoots,
-                tmp_storage_a, tmp_storage_b, no_offset, no_rot) :
-            createFaceContact(ref_plane, (int32_t)ref_face_idx,
-                (int32_t)incident_face_idx,
-                result.bVertices, result.aVertices,
-                result.bHalfEdges, result.aHalfEdges,
-                result.bFaceHedgeRoots, result.aFaceHedgeRoots,
-                tmp_storage_a, tmp_storage_b, no_offset, no_rot);
-
-        if (manifold.numContactPoints == 0) {
-            return false;
-        }
-        manifoldToContact(manifold, a_is_ref ? a_loc : b_loc,
-                          a_is_ref ? b_loc : a_loc, out);
-        return true;
-    }
-    case ContactType::SATEdge: {
-        Manifold manifold = createEdgeContact(
-            result.sat.normal, result.sat.planeDOrSeparation,
-            (int32_t)result.sat.refFaceIdxOrEdgeIdxA,
-            (int32_t)result.sat.incidentFaceIdxOrEdgeIdxB,
-            result.aVertices, result.bVertices,
-            result.aHalfEdges, result.bHalfEdges, no_offset, no_rot);
-
-        manifoldToContact(manifold, a_loc, b_loc, out);
-        return true;
-    }
-    case ContactType::None:
-    default:
-        return false;
-    }
-}
-
-// One primitive pair: order by primitive type, AABB reject, dispatch, contact.
-// tmp_vertices / tmp_faces: max_tmp_elems entries each; the face buffer's two
-// halves double as the clipping scratch once SAT is done with the planes.
-MADRONA_HD inline bool collidePrimitives(
-    const ObjectManager &obj_mgr,
-    Loc a_loc, Loc b_loc,
-    uint32_t a_prim_idx, uint32_t b_prim_idx,
-    PrimitiveTransform a_txfm, PrimitiveTransform b_txfm,
-    Vector3 *tmp_vertices, Plane *tmp_faces, CountT max_tmp_elems,
-    ContactConstraint *out, bool *unsupported)
+MADRONA_HD inline PairSetup setupPair(const ObjectManager &obj_mgr,
+                                      Loc a_loc, Loc b_loc,
+                                      uint32_t a_prim_idx, uint32_t b_prim_idx,
+                                      PrimitiveTransform a_txfm,
+                                      PrimitiveTransform b_txfm)
 {
     const CollisionPrimitive *a_prim = &obj_mgr.collisionPrimitives[a_prim_idx];
     const CollisionPrimitive *b_prim = &obj_mgr.collisionPrimitives[b_prim_idx];
@@ -389,36 +176,24 @@ MADRONA_HD inline bool collidePrimitives(
         b_txfm = tmp_txfm;
     }
 
-    {
-        math::AABB a_obj_aabb = obj_mgr.primitiveAABBs[a_prim_idx];
-        math::AABB b_obj_aabb = obj_mgr.primitiveAABBs[b_prim_idx];
+    math::AABB a_obj_aabb = obj_mgr.primitiveAABBs[a_prim_idx];
+    math::AABB b_obj_aabb = obj_mgr.primitiveAABBs[b_prim_idx];
 
-        math::AABB a_world_aabb =
-            a_obj_aabb.applyTRS(a_txfm.pos, a_txfm.rot, a_txfm.scale);
-        math::AABB b_world_aabb =
-            b_obj_aabb.applyTRS(b_txfm.pos, b_txfm.rot, b_txfm.scale);
+    math::AABB a_world_aabb =
+        a_obj_aabb.applyTRS(a_txfm.pos, a_txfm.rot, a_txfm.scale);
+    math::AABB b_world_aabb =
+        b_obj_aabb.applyTRS(b_txfm.pos, b_txfm.rot, b_txfm.scale);
 
-        if (!a_world_aabb.intersects(b_world_aabb)) {
-            return false;
-        }
-    }
-
-    const NarrowphaseTest test_type { raw_type_a | raw_type_b };
-
-    NarrowphaseResult result = narrowphaseDispatch(
-        test_type, a_txfm, b_txfm, a_prim, b_prim,
-        tmp_vertices, tmp_faces, max_tmp_elems, unsupported);
-
-    return generateContact(result, a_loc, b_loc, tmp_faces,
-                           tmp_faces + max_tmp_elems / 2, out);
+    return PairSetup {
+        a_loc, b_loc, a_prim, b_prim, a_txfm, b_txfm,
+        NarrowphaseTest { raw_type_a | raw_type_b },
+        a_world_aabb.intersects(b_world_aabb),
+    };
 }
 
-MADRONA_HD inline bool computeContact(Context &ctx,
+MADRONA_HD inline PairSetup setupPair(Context &ctx,
                                       const ObjectManager &obj_mgr,
-                                      const CandidateCollision &candidate,
-                                      Vector3 *tmp_vertices, Plane *tmp_faces,
-                                      CountT max_tmp_elems,
-                                      ContactConstraint *out)
+                                      const CandidateCollision &candidate)
 {
     Loc a_loc = candidate.a;
     Loc b_loc = candidate.b;
@@ -444,10 +219,243 @@ MADRONA_HD inline bool computeContact(Context &ctx,
         Diag3x3(ctx.getDirect<base::Scale>(RGDCols::Scale, b_loc)),
     };
 
+    return setupPair(obj_mgr, a_loc, b_loc, a_prim_idx, b_prim_idx,
+                     a_txfm, b_txfm);
+}
+
+MADRONA_HD inline void manifoldToContact(const Manifold &manifold,
+                                         Loc ref_loc, Loc other_loc,
+                                         ContactConstraint *out)
+{
+    out->ref = ref_loc;
+    out->alt = other_loc;
+    for (int i = 0; i < 4; i++) {
+        out->points[i] = Vector4::fromVec3W(manifold.contactPoints[i],
+                                            manifold.penetrationDepths[i]);
+    }
+    out->numPoints = manifold.numContactPoints;
+    out->normal = manifold.normal;
+}
+
+MADRONA_HD inline void sphereToContact(const SphereContact &sphere,
+                                       Loc a_loc, Loc b_loc,
+                                       ContactConstraint *out)
+{
+    out->ref = b_loc;
+    out->alt = a_loc;
+    out->points[0] = Vector4::fromVec3W(sphere.pt, sphere.depth);
+    out->points[1] = Vector4::zero();
+    out->points[2] = Vector4::zero();
+    out->points[3] = Vector4::zero();
+    out->numPoints = 1;
+    out->normal = sphere.normal;
+}
+
+// SAT feature -> manifold -> constraint (reference generateContacts,
+// narrowphase.cpp:1516-1680).  tmp_a / tmp_b: clipping scratch, each large
+// enough for the clipped incident polygon (Vector3s).
+template <typename HullA, typename HullB>
+MADRONA_HD inline bool satToContact(const SATResult &sat,
+                                    const HullA &a, const HullB &b,
+                                    Loc a_loc, Loc b_loc,
+                                    void *tmp_a, void *tmp_b,
+                                    ContactConstraint *out)
+{
+    const Vector3 no_offset { 0, 0, 0 };
+    const Quat no_rot { 1, 0, 0, 0 };
+
+    if (sat.type == ContactType::SATFace) {
+        uint32_t ref_face_idx_and_ref_mask = sat.contact.refFaceIdxOrEdgeIdxA;
+        uint32_t incident_face_idx = sat.contact.incidentFaceIdxOrEdgeIdxB;
+
+        uint32_t ref_face_idx = ref_face_idx_and_ref_mask & 0x7FFFFFFFu;
+        bool a_is_ref = ref_face_idx == ref_face_idx_and_ref_mask;
+
+        Plane ref_plane { sat.contact.normal, sat.contact.planeDOrSeparation };
+
+        Manifold manifold = a_is_ref ?
+            createFaceContact(ref_plane, (int32_t)ref_face_idx,
+                (int32_t)incident_face_idx, a, b, tmp_a, tmp_b,
+                no_offset, no_rot) :
+            createFaceContact(ref_plane, (int32_t)ref_face_idx,
+                (int32_t)incident_face_idx, b, a, tmp_a, tmp_b,
+                no_offset, no_rot);
+
+        // barely touching pairs can lose every clipped point to fp32
+        if (manifold.numContactPoints == 0) {
+            return false;
+        }
+        manifoldToContact(manifold, a_is_ref ? a_loc : b_loc,
+                          a_is_ref ? b_loc : a_loc, out);
+        return true;
+    } else if (sat.type == ContactType::SATEdge) {
+        Manifold manifold = createEdgeContact(
+            sat.contact.normal, sat.contact.planeDOrSeparation,
+            (int32_t)sat.contact.refFaceIdxOrEdgeIdxA,
+            (int32_t)sat.contact.incidentFaceIdxOrEdgeIdxB,
+            a, b, no_offset, no_rot);
+
+        manifoldToContact(manifold, a_loc, b_loc, out);
+        return true;
+    }
+
+    return false;
+}
+
+template <typename HullT>
+MADRONA_HD inline bool hullPlaneContact(const HullT &a_hull,
+                                        const PrimitiveTransform &plane_txfm,
+                                        Loc a_loc, Loc b_loc,
+                                        void *tmp_a, void *tmp_b,
+                                        ContactConstraint *out)
+{
+    constexpr Vector3 base_normal = { 0, 0, 1 };
+    Vector3 plane_normal = plane_txfm.rot.rotateVec(base_normal);
+
+    Plane plane { plane_normal, dot(plane_normal, plane_txfm.pos) };
+
+    const SATResult sat = doSATPlane(plane, a_hull);
+    if (sat.type != ContactType::SATPlane) {
+        return false;
+    }
+
+    // the plane is always b and always the reference
+    Manifold manifold = createFacePlaneContact(
+        Plane { sat.contact.normal, sat.contact.planeDOrSeparation },
+        (int32_t)sat.contact.incidentFaceIdxOrEdgeIdxB, a_hull,
+        (Vector3 *)tmp_a, (float *)tmp_b,
+        Vector3 { 0, 0, 0 }, Quat { 1, 0, 0, 0 });
+
+    if (manifold.numContactPoints == 0) {
+        return false;
+    }
+    manifoldToContact(manifold, b_loc, a_loc, out);
+    return true;
+}
+
+MADRONA_HD inline bool sphereSphereContact(const PairSetup &pair,
+                                           ContactConstraint *out)
+{
+    float a_radius = pair.a.scale.d0 * pair.aPrim->sphere.radius;
+    float b_radius = pair.b.scale.d0 * pair.bPrim->sphere.radius;
+
+    Vector3 to_b = pair.b.pos - pair.a.pos;
+    float dist = to_b.length();
+
+    if (dist > a_radius + b_radius) {
+        return false;
+    }
+
+    Vector3 normal = dist > 0.f ? to_b / dist : math::up;
+    float penetration = a_radius + b_radius - dist;
+
+    sphereToContact(SphereContact {
+        normal, pair.a.pos + a_radius * normal, penetration,
+    }, pair.aLoc, pair.bLoc, out);
+    return true;
+}
+
+MADRONA_HD inline bool spherePlaneContact(const PairSetup &pair,
+                                          ContactConstraint *out)
+{
+    float sphere_radius = pair.a.scale.d0 * pair.aPrim->sphere.radius;
+
+    constexpr Vector3 base_normal = { 0, 0, 1 };
+    Vector3 plane_normal = pair.b.rot.rotateVec(base_normal);
+
+    float d = plane_normal.dot(pair.b.pos);
+    float t = plane_normal.dot(pair.a.pos) - d;
+
+    float penetration = sphere_radius - t;
+    if (penetration < 0) {
+        return false;
+    }
+
+    sphereToContact(SphereContact {
+        plane_normal, pair.a.pos - t * plane_normal, penetration,
+    }, pair.aLoc, pair.bLoc, out);
+    return true;
+}
+
+// One primitive pair on one lane with the hulls transformed into caller
+// scratch (the reference's CPU flavour: runNarrowphase, narrowphase.cpp:
+// 1682-1907).  tmp_vertices / tmp_faces: max_tmp_elems entries each; the face
+// buffer's two halves double as the clipping scratch once SAT is done.
+MADRONA_HD inline bool collidePairStored(const PairSetup &pair,
+                                         Vector3 *tmp_vertices,
+                                         Plane *tmp_faces,
+                                         CountT max_tmp_elems,
+                                         ContactConstraint *out,
+                                         bool *unsupported)
+{
+    if (!pair.aabbOverlap) {
+        return false;
+    }
+
+    void *clip_a = tmp_faces;
+    void *clip_b = tmp_faces + max_tmp_elems / 2;
+
+    switch (pair.test) {
+    case NarrowphaseTest::SphereSphere:
+        return sphereSphereContact(pair, out);
+    case NarrowphaseTest::SpherePlane:
+        return spherePlaneContact(pair, out);
+    case NarrowphaseTest::HullHull: {
+        const HalfEdgeMesh &a_he_mesh = pair.aPrim->hull.halfEdgeMesh;
+        const HalfEdgeMesh &b_he_mesh = pair.bPrim->hull.halfEdgeMesh;
+
+        if ((CountT)(a_he_mesh.numFaces + b_he_mesh.numFaces) > max_tmp_elems ||
+            (CountT)(a_he_mesh.numVertices + b_he_mesh.numVertices) >
+                max_tmp_elems) {
+            *unsupported = true;
+            return false;
+        }
+
+        HullState a_hull = makeHullState(a_he_mesh, pair.a.pos, pair.a.rot,
+            pair.a.scale, tmp_vertices, tmp_faces);
+        HullState b_hull = makeHullState(b_he_mesh, pair.b.pos, pair.b.rot,
+            pair.b.scale, tmp_vertices + a_he_mesh.numVertices,
+            tmp_faces + a_he_mesh.numFaces);
+
+        const SATResult sat = doSAT(a_hull, b_hull);
+        return satToContact(sat, a_hull, b_hull, pair.aLoc, pair.bLoc,
+                            clip_a, clip_b, out);
+    }
+    case NarrowphaseTest::HullPlane: {
+        const HalfEdgeMesh &a_he_mesh = pair.aPrim->hull.halfEdgeMesh;
+
+        if ((CountT)a_he_mesh.numFaces > max_tmp_elems ||
+            (CountT)a_he_mesh.numVertices > max_tmp_elems) {
+            *unsupported = true;
+            return false;
+        }
+
+        HullState a_hull = makeHullState(a_he_mesh, pair.a.pos, pair.a.rot,
+            pair.a.scale, tmp_vertices, tmp_faces);
+
+        return hullPlaneContact(a_hull, pair.b, pair.aLoc, pair.bLoc,
+                                clip_a, clip_b, out);
+    }
+    case NarrowphaseTest::SphereHull:   // needs GJK: SURVEY.md §8f, not built yet
+    case NarrowphaseTest::PlanePlane:   // planes are static, never paired
+    default:
+        *unsupported = true;
+        return false;
+    }
+}
+
+MADRONA_HD inline bool computeContact(Context &ctx,
+                                      const ObjectManager &obj_mgr,
+                                      const CandidateCollision &candidate,
+                                      Vector3 *tmp_vertices, Plane *tmp_faces,
+                                      CountT max_tmp_elems,
+                                      ContactConstraint *out)
+{
+    PairSetup pair = setupPair(ctx, obj_mgr, candidate);
+
     bool unsupported = false;
-    bool has_contact = collidePrimitives(obj_mgr, a_loc, b_loc,
-        a_prim_idx, b_prim_idx, a_txfm, b_txfm, tmp_vertices, tmp_faces,
-        max_tmp_elems, out, &unsupported);
+    bool has_contact = collidePairStored(pair, tmp_vertices, tmp_faces,
+                                         max_tmp_elems, out, &unsupported);
 
 #if defined(__HIP_DEVICE_COMPILE__)
     if (unsupported) {
@@ -626,151 +634,7 @@ candidateKernel(EcsState *S, void *, uint32_t, uint32_t)
     }
 }
 
-// narrowphase: one lane per candidate; result staged per candidate row
-__global__ void __launch_bounds__(256)
-narrowphaseKernel(EcsState *S, void *, uint32_t, uint32_t)
-{
-    using namespace narrowphase;
-
-    StateManager *state_mgr = static_cast<StateManager *>(S);
-    PhysicsScratch *ps = detail::scratch(S);
-
-    TableHdr &cand_tbl = S->tables[ps->candidateArchetype];
-    const int32_t num_rows = cand_tbl.numRows;
-    const WorldID *worlds = (const WorldID *)cand_tbl.columns[1];
-    const CandidateCollision *candidates = (const CandidateCollision *)
-        cand_tbl.columns[RGDCols::CandidateCollision];
-
-    constexpr int32_t max_elems = MADRONA_PHYS_MAX_HULL_ELEMS;
-    geo::Plane tmp_faces[max_elems];
-    math::Vector3 tmp_vertices[max_elems];
-
-    const int32_t tid = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
-    const int32_t stride = (int32_t)(gridDim.x * blockDim.x);
-
-    for (int32_t row = tid; row < num_rows; row += stride) {
-        Context ctx = TaskGraph::makeContext<Context>(state_mgr, worlds[row]);
-        const ObjectManager &obj_mgr = *ctx.singleton<ObjectData>().mgr;
-
-        ContactConstraint contact;
-        bool has_contact = computeContact(
-            ctx, obj_mgr, candidates[row], tmp_vertices, tmp_faces, max_elems,
-            &contact);
-
-        ps->contactFlags[row] = has_contact ? 1u : 0u;
-        if (has_contact) {
-            ps->contactStaging[row] = contact;
-        }
-    }
-}
-
-// moves staged contacts to the Contact table at their scanned offsets
-__global__ void __launch_bounds__(256)
-contactCompactKernel(EcsState *S, void *, uint32_t, uint32_t)
-{
-    PhysicsScratch *ps = detail::scratch(S);
-    TableHdr &cand_tbl = S->tables[ps->candidateArchetype];
-    TableHdr &contact_tbl = S->tables[ps->contactArchetype];
-
-    const int32_t num_rows = cand_tbl.numRows;
-    const int32_t num_contacts = contact_tbl.numRows;   // written by the scan
-    const WorldID *cand_worlds = (const WorldID *)cand_tbl.columns[1];
-
-    const int32_t tid = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
-    const int32_t stride = (int32_t)(gridDim.x * blockDim.x);
-
-    for (int32_t row = tid; row < num_rows; row += stride) {
-        // after the scan: flags[row] = offset; a contact exists iff the next
-        // offset (or the total) is larger
-        uint32_t off = ps->contactFlags[row];
-        uint32_t next = row + 1 < num_rows ?
-            ps->contactFlags[row + 1] : (uint32_t)num_contacts;
-        if (next == off || off >= (uint32_t)contact_tbl.capacity) {
-            continue;
-        }
-
-        ((Entity *)contact_tbl.columns[0])[off] = Entity::none();
-        ((WorldID *)contact_tbl.columns[1])[off] = cand_worlds[row];
-        ((ContactConstraint *)contact_tbl.columns[2])[off] =
-            ps->contactStaging[row];
-        xpbd::XPBDContactState zero {};
-        ((xpbd::XPBDContactState *)contact_tbl.columns[3])[off] = zero;
-    }
-}
-
-// XPBD position solve: one lane per world walks that world's contacts, then
-// its joints, in table order (Gauss-Seidel; reference xpbd.cpp:720-736)
-__global__ void __launch_bounds__(256)
-solvePositionsKernel(EcsState *S, void *, uint32_t, uint32_t)
-{
-    StateManager *state_mgr = static_cast<StateManager *>(S);
-    PhysicsScratch *ps = detail::scratch(S);
-
-    const int32_t world = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (world >= S->numWorlds) {
-        return;
-    }
-
-    Context ctx = TaskGraph::makeContext<Context>(state_mgr, WorldID { world });
-    ObjectManager &obj_mgr = *ctx.singleton<ObjectData>().mgr;
-
-    {
-        TableHdr &tbl = S->tables[ps->contactArchetype];
-        const int32_t begin = tbl.worldOffsets[world];
-        const int32_t end = begin + tbl.worldCounts[world];
-        ContactConstraint *contacts = (ContactConstraint *)tbl.columns[2];
-        xpbd::XPBDContactState *states =
-            (xpbd::XPBDContactState *)tbl.columns[3];
-        for (int32_t i = begin; i < end; i++) {
-            states[i].lambdaN[0] = 0.f;
-            states[i].lambdaN[1] = 0.f;
-            states[i].lambdaN[2] = 0.f;
-            states[i].lambdaN[3] = 0.f;
-            xpbd::handleContact(ctx, obj_mgr, contacts[i], states[i].lambdaN);
-        }
-    }
-
-    {
-        TableHdr &tbl = S->tables[ps->jointArchetype];
-        const int32_t begin = tbl.worldOffsets[world];
-        const int32_t end = begin + tbl.worldCounts[world];
-        const JointConstraint *joints = (const JointConstraint *)tbl.columns[2];
-        const Entity *joint_entities = (const Entity *)tbl.columns[0];
-        for (int32_t i = begin; i < end; i++) {
-            if (joint_entities[i].id < 0) {
-                continue;       // destroyed, not yet compacted
-            }
-            xpbd::handleJointConstraint(ctx, obj_mgr, joints[i]);
-        }
-    }
-}
-
-__global__ void __launch_bounds__(256)
-solveVelocitiesKernel(EcsState *S, void *, uint32_t, uint32_t)
-{
-    StateManager *state_mgr = static_cast<StateManager *>(S);
-    PhysicsScratch *ps = detail::scratch(S);
-
-    const int32_t world = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (world >= S->numWorlds) {
-        return;
-    }
-
-    Context ctx = TaskGraph::makeContext<Context>(state_mgr, WorldID { world });
-    ObjectManager &obj_mgr = *ctx.singleton<ObjectData>().mgr;
-    const PhysicsSystemState &physics_sys =
-        ctx.singleton<PhysicsSystemState>();
-
-    TableHdr &tbl = S->tables[ps->contactArchetype];
-    const int32_t begin = tbl.worldOffsets[world];
-    const int32_t end = begin + tbl.worldCounts[world];
-    ContactConstraint *contacts = (ContactConstraint *)tbl.columns[2];
-    xpbd::XPBDContactState *states = (xpbd::XPBDContactState *)tbl.columns[3];
-    for (int32_t i = begin; i < end; i++) {
-        xpbd::solveVelocitiesForContact(ctx, obj_mgr, contacts[i],
-            states[i].lambdaN, physics_sys.h, physics_sys.restitutionThreshold);
-    }
-}
+#include <madrona/phys_impl/world_step.inl>
 
 }
 #endif // __HIPCC__
@@ -1086,16 +950,22 @@ inline PhysicsScratch *scratchHost(TaskGraphBuilder &builder,
     ps.contactArchetype = TypeTracker::typeID<xpbd::Contact>();
     ps.jointArchetype = TypeTracker::typeID<xpbd::Joint>();
 
-    uint32_t cand_capacity =
-        mwhip_archetype_capacity(exec, ps.candidateArchetype);
-    ps.contactFlags = (uint32_t *)mwhip_alloc_device(
-        exec, (uint64_t)cand_capacity * sizeof(uint32_t), 1);
-    ps.contactStaging = (ContactConstraint *)mwhip_alloc_device(
-        exec, (uint64_t)cand_capacity * sizeof(ContactConstraint), 0);
+    const uint64_t num_worlds = mwhip_num_worlds(exec);
+    ps.candidatesPerWorld = (uint32_t)phys::detail::capacityHint(
+        "MADRONA_MWHIP_MAX_CANDIDATES_PER_WORLD", 256);
+    ps.contactsPerWorld = (uint32_t)phys::detail::capacityHint(
+        "MADRONA_MWHIP_MAX_CONTACTS_PER_WORLD", 128);
+    ps.worldCandidates = (CandidateCollision *)mwhip_alloc_device(exec,
+        num_worlds * ps.candidatesPerWorld * sizeof(CandidateCollision), 0);
+    ps.worldContacts = (ContactConstraint *)mwhip_alloc_device(exec,
+        num_worlds * ps.contactsPerWorld * sizeof(ContactConstraint), 0);
+    ps.worldLambdas = (float *)mwhip_alloc_device(exec,
+        num_worlds * ps.contactsPerWorld * sizeof(float), 0);
 
     PhysicsScratch *dev = (PhysicsScratch *)mwhip_alloc_device(
         exec, sizeof(PhysicsScratch), 0);
-    if (dev == nullptr || ps.contactStaging == nullptr) {
+    if (dev == nullptr || ps.worldCandidates == nullptr ||
+            ps.worldContacts == nullptr || ps.worldLambdas == nullptr) {
         FATAL("madrona_amd physics: scratch allocation failed: %s",
               mwhip_last_error());
     }
@@ -1190,56 +1060,6 @@ MADRONA_HOST_API inline TaskGraphNodeID setupCandidateTasks(
 #endif
 }
 
-// narrowphase: stage -> scan -> compact into the Contact table
-MADRONA_HOST_API inline TaskGraphNodeID setupNarrowphaseTasks(
-    TaskGraphBuilder &builder, Span<const TaskGraphNodeID> deps)
-{
-#if defined(__HIPCC__)
-    [[maybe_unused]] auto stage_stub = [] __host__ () -> const void * {
-        return (const void *)&kernels::narrowphaseKernel;
-    };
-    [[maybe_unused]] auto compact_stub = [] __host__ () -> const void * {
-        return (const void *)&kernels::contactCompactKernel;
-    };
-#else
-    auto stage_stub = []() -> const void * { return nullptr; };
-    auto compact_stub = []() -> const void * { return nullptr; };
-#endif
-
-#if MADRONA_ON_HOST
-    mwhip_exec *exec = builder.exec();
-    PhysicsScratch ps;
-    scratchHost(builder, &ps);
-
-    uint32_t cand_capacity =
-        mwhip_archetype_capacity(exec, ps.candidateArchetype);
-
-    auto stage = addKernelNode(builder, "physics:narrowphase", stage_stub(),
-        MWHIP_COUNT_FIXED, cand_capacity, deps);
-
-    mwhip_scan_params scan {};
-    scan.num_segments = 1;
-    scan.capacity = mwhip_archetype_capacity(exec, ps.contactArchetype);
-    scan.data[0] = ps.contactFlags;
-    scan.lengths[0] = numRowsAddr(exec, ps.candidateArchetype);
-    scan.total_out = numRowsAddr(exec, ps.contactArchetype);
-    scan.needs_sort_out = needsSortAddr(exec, ps.contactArchetype);
-
-    auto scan_data = builder.constructNodeData<mwhip_scan_params>(scan);
-    mwhip_node_desc scan_desc {};
-    scan_desc.kind = MWHIP_NODE_EXCLUSIVE_SCAN;
-    scan_desc.name = "physics:contactScan";
-    scan_desc.fixed_count = cand_capacity;
-    auto scanned = builder.addRuntimeNode(scan_desc, scan_data.id, {stage});
-
-    return addKernelNode(builder, "physics:contactCompact", compact_stub(),
-        MWHIP_COUNT_FIXED, cand_capacity, {scanned});
-#else
-    (void)builder; (void)deps;
-    MADRONA_DEVICE_STUB();
-#endif
-}
-
 MADRONA_HOST_API inline TaskGraphNodeID setupPostIntegrationTasks(
     TaskGraphBuilder &builder, Span<const TaskGraphNodeID> deps)
 {
@@ -1262,85 +1082,67 @@ MADRONA_HOST_API inline TaskGraphNodeID setupPhysicsStepTasks(
     CountT num_substeps,
     Solver)
 {
-    using namespace base;
-    using namespace xpbd;
-
 #if defined(__HIPCC__)
-    [[maybe_unused]] auto solve_pos_stub = [] __host__ () -> const void * {
-        return (const void *)&kernels::solvePositionsKernel;
-    };
-    [[maybe_unused]] auto solve_vel_stub = [] __host__ () -> const void * {
-        return (const void *)&kernels::solveVelocitiesKernel;
+    [[maybe_unused]] auto step_stub = [] __host__ (int max_bodies)
+            -> const void * {
+        switch (max_bodies) {
+        case 32: return (const void *)&kernels::physicsStepLdsKernel<32>;
+        case 64: return (const void *)&kernels::physicsStepLdsKernel<64>;
+        case 128: return (const void *)&kernels::physicsStepLdsKernel<128>;
+        default: return (const void *)&kernels::physicsStepKernel;
+        }
     };
 #else
-    auto solve_pos_stub = []() -> const void * { return nullptr; };
-    auto solve_vel_stub = []() -> const void * { return nullptr; };
+    auto step_stub = [](int) -> const void * { return nullptr; };
 #endif
 
-    auto cur_node = detail::setupCandidateTasks(builder, deps);
-
-    // joints are created / destroyed by the simulator between steps
-    cur_node = builder.addToGraph<
-        SortArchetypeNode<Joint, WorldID>>({cur_node});
+    // joints are created / destroyed by the simulator between steps: group
+    // them by world (stable) so each world finds its range
+    auto cur_node = builder.addToGraph<
+        SortArchetypeNode<xpbd::Joint, WorldID>>(deps);
     cur_node = builder.addToGraph<ResetTmpAllocNode>({cur_node});
 
-    for (CountT i = 0; i < num_substeps; i++) {
-        auto rgb_update = builder.addToGraph<ParallelForNode<Context,
-            substepRigidBodies, Position, Rotation, Velocity, ObjectID,
-            ResponseType, ExternalForce, ExternalTorque,
-            SubstepPrevState, PreSolvePositional,
-            PreSolveVelocity>>({cur_node});
-
-        auto run_narrowphase =
-            detail::setupNarrowphaseTasks(builder, {rgb_update});
-
-        // groups contacts by world (stable, so each world keeps the CPU
-        // order) and produces the per-world ranges the solver walks
-        run_narrowphase = builder.addToGraph<
-            SortArchetypeNode<Contact, WorldID>>({run_narrowphase});
-        run_narrowphase = builder.addToGraph<ResetTmpAllocNode>(
-            {run_narrowphase});
-
-        TaskGraphNodeID solve_pos, vel_set, solve_vel;
 #if MADRONA_ON_HOST
-        solve_pos = detail::addKernelNode(builder, "physics:solvePositions",
-            solve_pos_stub(), MWHIP_COUNT_PER_WORLD, 0, {run_narrowphase});
-#endif
+    // candidates -> per substep (integrate, narrowphase, position solve,
+    // velocities, velocity solve): one wavefront per world, one launch
+    PhysicsScratch ps;
+    detail::scratchHost(builder, &ps);
 
-        vel_set = builder.addToGraph<ParallelForNode<Context,
-            setVelocities, Position, Rotation,
-            SubstepPrevState, Velocity>>({solve_pos});
+    auto params = builder.constructNodeData<PhysicsStepParams>(
+        PhysicsStepParams { (int32_t)num_substeps });
 
-#if MADRONA_ON_HOST
-        solve_vel = detail::addKernelNode(builder, "physics:solveVelocities",
-            solve_vel_stub(), MWHIP_COUNT_PER_WORLD, 0, {vel_set});
-#endif
-
-        TaskGraphNodeID clear_contacts = solve_vel;
-        bool keep_contacts = false;
-#if MADRONA_ON_HOST
-        // debugging aid: leave the last substep's contacts in their table
-        keep_contacts = i == num_substeps - 1 &&
-            getenv("MADRONA_MWHIP_PHYS_KEEP_CONTACTS") != nullptr;
-        if (keep_contacts) {
-            fprintf(stderr, "physics debug: Contact archetype %u, "
-                    "ContactConstraint component %u\n",
-                    TypeTracker::typeID<Contact>(),
-                    TypeTracker::typeID<ContactConstraint>());
+    // Worlds small enough to live in LDS take the LDS-resident kernel; the
+    // bound is twice the largest world at graph-build time, rounded up
+    // (MADRONA_MWHIP_PHYS_MAX_BODIES overrides; > 128 selects the generic
+    // kernel that works out of HBM).
+    mwhip_exec *exec = builder.exec();
+    int max_bodies = (int)phys::detail::capacityHint(
+        "MADRONA_MWHIP_PHYS_MAX_BODIES", 0);
+    if (max_bodies == 0) {
+        uint64_t total_rows = 0;
+        for (uint32_t i = 0; i < ps.numBodyArchetypes; i++) {
+            total_rows += (uint64_t)mwhip_num_rows(exec, ps.bodyArchetypes[i]);
         }
-#endif
-        if (!keep_contacts) {
-            clear_contacts = builder.addToGraph<
-                ClearTmpNode<Contact>>({solve_vel});
-        }
-
-        cur_node = builder.addToGraph<ResetTmpAllocNode>({clear_contacts});
+        uint64_t per_world = total_rows / mwhip_num_worlds(exec) + 1;
+        max_bodies = (int)(per_world + per_world / 2);
     }
+    max_bodies = max_bodies <= 32 ? 32 : max_bodies <= 64 ? 64 :
+                 max_bodies <= 128 ? 128 : 0;
 
-    auto clear_broadphase = builder.addToGraph<
-        ClearTmpNode<CandidateTemporary>>({cur_node});
+    mwhip_node_desc desc {};
+    desc.kind = MWHIP_NODE_KERNEL;
+    desc.name = max_bodies != 0 ? "physics:worldStep(LDS)" :
+                                  "physics:worldStep";
+    desc.kernel = step_stub(max_bodies);
+    desc.count_mode = MWHIP_COUNT_PER_WORLD;
+    desc.threads_per_invocation = 64;
+    desc.arg0 = max_bodies != 0 ? 1u : 0u;
+    cur_node = builder.addRuntimeNode(desc, params.id, {cur_node});
+#else
+    (void)num_substeps;
+#endif
 
-    return detail::setupPostIntegrationTasks(builder, {clear_broadphase});
+    return detail::setupPostIntegrationTasks(builder, {cur_node});
 }
 
 MADRONA_HOST_API inline TaskGraphNodeID setupCleanupTasks(

@@ -14,7 +14,8 @@ from typing import Dict, List, Tuple
 import numpy as np
 
 REPO_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HIP_BUILD_DIR = os.path.join(REPO_ROOT, "madrona_amd", "_build")
+HIP_BUILD_DIR = os.path.join(REPO_ROOT, "madrona_amd",
+                             os.environ.get("MADRONA_HIP_BUILD_DIR", "_build"))
 REF_BUILD_DIR = os.path.join(REPO_ROOT, "oracle", "_ref")
 
 SIM_DTYPES = {

@@ -1,0 +1,28 @@
+import sys, os, ctypes as C
+os.environ['MADRONA_HIP_BUILD_DIR'] = '_build_prof'
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from madrona_amd.simlib import Simulator, hip_lib_path, runtime_lib
+W = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+with Simulator(hip_lib_path('escape_room_phys'), W, seed=5, flags=200) as hip:
+    rt = runtime_lib()
+    rt.mwhip_alloc_device.restype = C.c_void_p
+    rt.mwhip_alloc_device.argtypes = [C.c_void_p, C.c_uint64, C.c_int]
+    rt.mwhip_set_module_data.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    rt.mwhip_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    rng = np.random.default_rng(0)
+    a = np.stack([rng.integers(0, 4, (W, 2)), rng.integers(0, 8, (W, 2)),
+                  rng.integers(-2, 3, (W, 2)), rng.integers(0, 2, (W, 2))], -1).astype(np.int32)
+    hip.write_tensor('action', a)
+    hip.step(50)
+    buf = rt.mwhip_alloc_device(hip.hip_exec(), 64, 1)
+    rt.mwhip_set_module_data(hip.hip_exec(), 1, buf)
+    N = 50
+    hip.step(N)
+    out = np.zeros(8, np.uint64)
+    rt.mwhip_memcpy_d2h(out.ctypes.data, buf, 64)
+    names = ['load', 'candidates', 'integrate', 'narrowphase', 'solvePos+joints', 'setVel', 'solveVel', 'store']
+    tot = out.sum()
+    for n, v in zip(names, out):
+        print(f'{n:18s} {v / N / W:10.0f} ticks/world/step  {100 * v / tot:5.1f}%')
+    print('total ticks/world/step', tot / N / W, '(s_memtime @100MHz => us =', tot / N / W / 100, ')')
