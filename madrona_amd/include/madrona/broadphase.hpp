@@ -96,12 +96,63 @@ public:
         return leaf_entities_[leaf];
     }
 
+    // ---- staged rebuild (physics.inl bvhUpdateKernel) -------------------------
+    // The top-down build is a long chain of dependent accesses to a few KB:
+    // run from HBM it is pure latency.  A kernel copies the leaf boxes next to
+    // the CU, runs rebuildStaged() on a *copy* of this object whose arrays point
+    // at that storage, and copies nodes / leaf parents / orders back.
+    static constexpr uint32_t nodeBytes = 116;
+
+    MADRONA_HD inline bool needsRebuild() const { return force_rebuild_; }
+    MADRONA_HD inline int32_t nodeCapacity() const
+    {
+        return (int32_t)num_allocated_nodes_;
+    }
+    MADRONA_HD inline void *rawNodes() const { return nodes_; }
+    MADRONA_HD inline math::AABB *rawLeafAABBs() const { return leaf_aabbs_; }
+    MADRONA_HD inline uint32_t *rawLeafParents() const { return leaf_parents_; }
+    MADRONA_HD inline int32_t *rawSortedLeaves() const { return sorted_leaves_; }
+    MADRONA_HD inline int32_t *rawTraversalOrder() const { return dfs_leaves_; }
+
+    MADRONA_HD inline int32_t numNodes() const { return (int32_t)num_nodes_; }
+
+    // a copy of this object whose tree arrays live somewhere else (LDS)
+    // leaf_centers (optional): centroid of every leaf box, precomputed
+    MADRONA_HD inline BVH rebased(void *nodes, math::AABB *leaf_aabbs,
+                                  uint32_t *leaf_parents,
+                                  int32_t *sorted_leaves,
+                                  int32_t *traversal_order,
+                                  math::Vector3 *leaf_centers = nullptr) const
+    {
+        BVH copy = *this;
+        copy.leaf_centers_ = leaf_centers;
+        copy.nodes_ = (Node *)nodes;
+        copy.leaf_aabbs_ = leaf_aabbs;
+        copy.leaf_parents_ = leaf_parents;
+        copy.sorted_leaves_ = sorted_leaves;
+        copy.dfs_leaves_ = traversal_order;
+        return copy;
+    }
+
+    // call on a rebased copy; returns the number of nodes the tree may reference
+    MADRONA_HD inline int32_t rebuildStaged()
+    {
+        rebuild();
+        return (int32_t)num_nodes_;
+    }
+
+    MADRONA_HD inline void finishRebuild(int32_t num_nodes)
+    {
+        num_nodes_ = num_nodes;
+        force_rebuild_ = false;
+    }
+
 private:
     static constexpr int32_t sentinel_ = -1;
     static constexpr uint32_t leaf_bit_ = 0x80000000u;
 
     // SoA over the 4 children so one node's child boxes load as 6 x 16 B
-    struct Node {
+    struct alignas(4) Node {
         float minX[4];
         float minY[4];
         float minZ[4];
@@ -144,6 +195,8 @@ private:
         }
     };
 
+    static_assert(sizeof(Node) == nodeBytes);
+
     struct LeafTransform {
         math::Vector3 pos;
         math::Quat rot;
@@ -158,6 +211,9 @@ private:
 
     MADRONA_HD inline math::Vector3 leafCenter(int32_t sorted_idx) const
     {
+        if (leaf_centers_ != nullptr) {
+            return leaf_centers_[sorted_leaves_[sorted_idx]];
+        }
         math::AABB aabb = leaf_aabbs_[sorted_leaves_[sorted_idx]];
         return (aabb.pMin + aabb.pMax) / 2.f;
     }
@@ -176,6 +232,7 @@ private:
     uint32_t *leaf_parents_;
     int32_t *sorted_leaves_;
     int32_t *dfs_leaves_;
+    math::Vector3 *leaf_centers_;   // only set on rebased copies
     int32_t num_leaves_;
     int32_t num_allocated_leaves_;
     float leaf_velocity_expansion_;

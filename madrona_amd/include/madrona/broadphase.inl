@@ -19,6 +19,7 @@ BVH::BVH(const ObjectManager *obj_mgr,
       leaf_parents_((uint32_t *)rawAlloc(sizeof(uint32_t) * max_leaves)),
       sorted_leaves_((int32_t *)rawAlloc(sizeof(int32_t) * max_leaves)),
       dfs_leaves_((int32_t *)rawAlloc(sizeof(int32_t) * max_leaves)),
+      leaf_centers_(nullptr),
       num_leaves_(0),
       num_allocated_leaves_((int32_t)max_leaves),
       leaf_velocity_expansion_(leaf_velocity_expansion),

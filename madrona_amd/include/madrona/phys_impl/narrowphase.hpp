@@ -80,8 +80,9 @@ struct LazyHull {
     Vector3 translation;
     Vector3 center;
 
+    // need_center: only the hull-hull edge test uses the centroid
     MADRONA_HD inline LazyHull(const HalfEdgeMesh &obj_mesh, Vector3 t, Quat r,
-                               Diag3x3 s)
+                               Diag3x3 s, bool need_center = true)
         : mesh(&obj_mesh), translation(t)
     {
         Mat3x3 unscaled_rot = Mat3x3::fromQuat(r);
@@ -89,6 +90,10 @@ struct LazyHull {
         normalTxfm = unscaled_rot * s.inv();
 
         center = Vector3::zero();
+        if (!need_center) {
+            return;
+        }
+
         const CountT num_vertices = (CountT)obj_mesh.numVertices;
         for (CountT i = 0; i < num_vertices; i++) {
             center += vertex(i);

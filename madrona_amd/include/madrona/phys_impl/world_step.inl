@@ -108,9 +108,14 @@ inline constexpr uint32_t lanePolyRows = 16;
 // clipping scratch of the wave-cooperative hull-hull path (2 polygons)
 inline constexpr uint32_t wavePolyVerts = 24;
 
+// world-space copies of the two hulls of a cooperative hull-hull test
+inline constexpr uint32_t waveHullElems = 16;   // vertices, faces per hull
+
 struct alignas(16) WaveScratch {
     float lanePoly[lanePolyRows * lanePolyDwords];
     math::Vector3 clip[2][wavePolyVerts];
+    math::Vector3 hullVerts[2][waveHullElems];
+    geo::Plane hullPlanes[2][waveHullElems];
 };
 
 // number of vertices of face `face_idx`
@@ -197,17 +202,74 @@ __device__ inline EdgeQuery queryEdgeDirectionsWave(uint32_t lane,
     return best;
 }
 
+// makeHullState with the vertices / planes spread over the lanes
+__device__ inline HullState makeHullStateWave(uint32_t lane,
+                                              const HalfEdgeMesh &mesh,
+                                              const PrimitiveTransform &txfm,
+                                              Vector3 *dst_vertices,
+                                              Plane *dst_planes)
+{
+    LazyHull lazy(mesh, txfm.pos, txfm.rot, txfm.scale, false);
+    if (lane < mesh.numVertices) {
+        dst_vertices[lane] = lazy.vertex(lane);
+    }
+    if (lane < mesh.numFaces) {
+        dst_planes[lane] = lazy.plane(lane);
+    }
+    wave::phaseFence();
+
+    // the centroid is a sequential sum (fp order): every lane adds it up
+    Vector3 center = Vector3::zero();
+    const CountT num_vertices = (CountT)mesh.numVertices;
+    for (CountT i = 0; i < num_vertices; i++) {
+        center += dst_vertices[i];
+    }
+    center /= (float)num_vertices;
+
+    HalfEdgeMesh world_mesh = mesh;
+    world_mesh.facePlanes = dst_planes;
+    world_mesh.vertices = dst_vertices;
+    return HullState { world_mesh, center };
+}
+
+template <typename HullA, typename HullB>
+__device__ inline bool hullHullWaveSAT(uint32_t lane, const PairSetup &pair,
+                                       const HullA &a, const HullB &b,
+                                       WaveScratch *scratch,
+                                       ContactConstraint *out, bool *too_big);
+
 // Hull-hull pair handled by the whole wave (`pair` is wave-uniform).  Returns
 // false with *too_big set when the clipped polygon may not fit the LDS scratch.
 __device__ inline bool hullHullWave(uint32_t lane, const PairSetup &pair,
                                     WaveScratch *scratch,
                                     ContactConstraint *out, bool *too_big)
 {
-    LazyHull a(pair.aPrim->hull.halfEdgeMesh, pair.a.pos, pair.a.rot,
-               pair.a.scale);
-    LazyHull b(pair.bPrim->hull.halfEdgeMesh, pair.b.pos, pair.b.rot,
-               pair.b.scale);
+    const HalfEdgeMesh &a_mesh = pair.aPrim->hull.halfEdgeMesh;
+    const HalfEdgeMesh &b_mesh = pair.bPrim->hull.halfEdgeMesh;
 
+    if (a_mesh.numVertices <= waveHullElems &&
+        a_mesh.numFaces <= waveHullElems &&
+        b_mesh.numVertices <= waveHullElems &&
+        b_mesh.numFaces <= waveHullElems) {
+        // small hulls: transform once into LDS
+        HullState a = makeHullStateWave(lane, a_mesh, pair.a,
+            scratch->hullVerts[0], scratch->hullPlanes[0]);
+        HullState b = makeHullStateWave(lane, b_mesh, pair.b,
+            scratch->hullVerts[1], scratch->hullPlanes[1]);
+        return hullHullWaveSAT(lane, pair, a, b, scratch, out, too_big);
+    }
+
+    LazyHull a(a_mesh, pair.a.pos, pair.a.rot, pair.a.scale);
+    LazyHull b(b_mesh, pair.b.pos, pair.b.rot, pair.b.scale);
+    return hullHullWaveSAT(lane, pair, a, b, scratch, out, too_big);
+}
+
+template <typename HullA, typename HullB>
+__device__ inline bool hullHullWaveSAT(uint32_t lane, const PairSetup &pair,
+                                       const HullA &a, const HullB &b,
+                                       WaveScratch *scratch,
+                                       ContactConstraint *out, bool *too_big)
+{
     FaceQuery face_query_a = queryFaceDirectionsWave(lane, a, b);
     if (face_query_a.separation > 0.0f) {
         return false;
@@ -259,7 +321,7 @@ __device__ inline bool collidePairLane(const PairSetup &pair, float *row,
         return spherePlaneContact(pair, out);
     case NarrowphaseTest::HullPlane: {
         LazyHull a(pair.aPrim->hull.halfEdgeMesh, pair.a.pos, pair.a.rot,
-                   pair.a.scale);
+                   pair.a.scale, false);
 
         // largest face bounds the contact polygon
         const uint32_t num_faces = (uint32_t)a.numFaces();
@@ -703,13 +765,14 @@ struct WorldBlock {
     int32_t entityID[MAXB];
     uint16_t primOffset[MAXB];
     uint16_t primCount[MAXB];
-    uint16_t leafBody[MAXB];                // leaf id -> body index
+    uint16_t leafRank[MAXB];                // leaf id -> traversal rank
     uint16_t orderBody[MAXB];               // traversal rank -> body index
     WaveCandidate candidates[maxCandidates];
 
     // broadphase boxes are dead once the candidates exist: the contacts of the
     // substeps reuse their storage
-    static constexpr size_t boxBytes = 2 * MAXB * sizeof(math::AABB);
+    static constexpr size_t boxBytes =
+        MAXB * (2 * sizeof(math::AABB) + sizeof(int32_t));
     static constexpr size_t contactBytes =
         maxContacts * sizeof(ContactConstraint);
     alignas(16) char shared[boxBytes > contactBytes ? boxBytes : contactBytes];
@@ -726,10 +789,16 @@ struct WorldBlock {
     alignas(16) uint32_t arena[arenaDwords];
     WaveScratch scratch;
 
+    // by body: the box a body queries the tree with; by traversal rank: the
+    // slot box the traversal tests and the entity id of that leaf's body
     __device__ inline math::AABB *queryBox() { return (math::AABB *)shared; }
-    __device__ inline math::AABB *slotBox()
+    __device__ inline math::AABB *rankSlotBox()
     {
         return (math::AABB *)shared + MAXB;
+    }
+    __device__ inline int32_t *rankEntity()
+    {
+        return (int32_t *)((math::AABB *)shared + 2 * MAXB);
     }
     __device__ inline ContactConstraint *contacts()
     {
@@ -942,6 +1011,14 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
         }
 
         // ---- load: HBM -> LDS ---------------------------------------------------
+        {
+            const int32_t *order = bvh.traversalOrder();
+            for (int32_t r = (int32_t)lane; r < num_bodies; r += 64) {
+                w->leafRank[order[r]] = (uint16_t)r;
+            }
+        }
+        wave::phaseFence();
+
         for (int32_t k = (int32_t)lane; k < num_bodies; k += 64) {
             Loc loc = bodies.loc(k);
             w->pos[k] = ctx.getDirect<base::Position>(RGDCols::Position, loc);
@@ -956,7 +1033,8 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
             ResponseType resp =
                 ctx.getDirect<ResponseType>(RGDCols::ResponseType, loc);
             w->resp[k] = (uint32_t)resp;
-            w->entityID[k] = ctx.getDirect<Entity>(0, loc).id;
+            const int32_t entity_id = ctx.getDirect<Entity>(0, loc).id;
+            w->entityID[k] = entity_id;
 
             base::ObjectID obj_id =
                 ctx.getDirect<base::ObjectID>(RGDCols::ObjectID, loc);
@@ -970,9 +1048,11 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
 
             int32_t leaf = ctx.getDirect<broadphase::LeafID>(
                 RGDCols::LeafID, loc).id;
+            const uint32_t rank = w->leafRank[leaf];
             w->queryBox()[k] = bvh.getLeafAABB(broadphase::LeafID { leaf });
-            w->slotBox()[k] = bvh.leafSlotBounds(leaf);
-            w->leafBody[leaf] = (uint16_t)k;
+            w->rankSlotBox()[rank] = bvh.leafSlotBounds(leaf);
+            w->rankEntity()[rank] = entity_id;
+            w->orderBody[rank] = (uint16_t)k;
         }
         if (lane == 0) {
             w->sys = ctx.singleton<PhysicsSystemState>();
@@ -994,42 +1074,49 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
             stagePrimitives(lane, w, hbm_obj_mgr, prim_end);
 #endif
 
-        {
-            const int32_t *order = bvh.traversalOrder();
-            for (int32_t r = (int32_t)lane; r < num_bodies; r += 64) {
-                w->orderBody[r] = w->leafBody[order[r]];
-            }
-        }
-        wave::phaseFence();
-        PHYS_PROF(0);
-
         // ---- broadphase: candidate pairs in (body, traversal) order -----------
+        // lane = body; one pass over the slot boxes in traversal order leaves a
+        // bit mask of hits, the pairs are written from the mask
         uint32_t num_candidates = 0;
         for (int32_t chunk = 0; chunk < num_bodies; chunk += 64) {
             const int32_t k = chunk + (int32_t)lane;
             const bool active = k < num_bodies;
 
-            auto forEachHit = [&](auto &&fn) {
+            constexpr int mask_words = (MAXB + 63) / 64;
+            uint64_t hits[mask_words];
+#pragma unroll
+            for (int m = 0; m < mask_words; m++) {
+                hits[m] = 0;
+            }
+
+            uint32_t n = 0;
+            if (active) {
                 const math::AABB query = w->queryBox()[k];
                 const int32_t my_id = w->entityID[k];
                 const bool my_static =
                     w->resp[k] == (uint32_t)ResponseType::Static;
-                for (int32_t r = 0; r < num_bodies; r++) {
-                    const int32_t kb = w->orderBody[r];
-                    if (!query.overlaps(w->slotBox()[kb])) continue;
-                    if (!(my_id < w->entityID[kb])) continue;
-                    if (my_static &&
-                        w->resp[kb] == (uint32_t)ResponseType::Static) {
-                        continue;
-                    }
-                    fn(kb);
-                }
-            };
-
-            uint32_t n = 0;
-            if (active) {
                 const uint32_t a_prims = w->primCount[k];
-                forEachHit([&](int32_t kb) { n += a_prims * w->primCount[kb]; });
+
+#pragma unroll
+                for (int m = 0; m < mask_words; m++) {
+                    const int32_t r_end = num_bodies - m * 64 < 64 ?
+                        num_bodies - m * 64 : 64;
+                    for (int32_t j = 0; j < r_end; j++) {
+                        const int32_t r = m * 64 + j;
+                        bool hit = query.overlaps(w->rankSlotBox()[r]) &&
+                            my_id < w->rankEntity()[r];
+                        if (hit) {
+                            const int32_t kb = w->orderBody[r];
+                            if (my_static && w->resp[kb] ==
+                                    (uint32_t)ResponseType::Static) {
+                                hit = false;
+                            } else {
+                                n += a_prims * w->primCount[kb];
+                            }
+                        }
+                        hits[m] |= (uint64_t)hit << j;
+                    }
+                }
             }
 
             uint32_t chunk_total;
@@ -1038,16 +1125,25 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
 
             if (active && n != 0 && out + n <= (uint32_t)Block::maxCandidates) {
                 const uint32_t a_prims = w->primCount[k];
-                forEachHit([&](int32_t kb) {
-                    const uint32_t b_prims = w->primCount[kb];
-                    const uint32_t total_checks = a_prims * b_prims;
-                    for (uint32_t c = 0; c < total_checks; c++) {
-                        w->candidates[out++] = WaveCandidate {
-                            (uint16_t)k, (uint16_t)kb,
-                            (uint16_t)(c / b_prims), (uint16_t)(c % b_prims),
-                        };
+#pragma unroll
+                for (int m = 0; m < mask_words; m++) {
+                    uint64_t pending = hits[m];
+                    while (pending != 0) {
+                        const int32_t r =
+                            m * 64 + (int32_t)__builtin_ctzll(pending);
+                        pending &= pending - 1;
+                        const int32_t kb = w->orderBody[r];
+                        const uint32_t b_prims = w->primCount[kb];
+                        const uint32_t total_checks = a_prims * b_prims;
+                        for (uint32_t c = 0; c < total_checks; c++) {
+                            w->candidates[out++] = WaveCandidate {
+                                (uint16_t)k, (uint16_t)kb,
+                                (uint16_t)(c / b_prims),
+                                (uint16_t)(c % b_prims),
+                            };
+                        }
                     }
-                });
+                }
             }
             num_candidates += chunk_total;
         }
@@ -1088,6 +1184,7 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
             wave::phaseFence();
         }
 
+        PHYS_PROF(7);
         for (int32_t substep = 0; substep < params.numSubsteps; substep++) {
             // ---- integrate (xpbd.cpp substepRigidBodies) ------------------------
             for (int32_t k = (int32_t)lane; k < num_bodies; k += 64) {
@@ -1135,6 +1232,7 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                         kind = pair.test == NarrowphaseTest::HullHull ? 2 : 1;
                     }
                 }
+                PHYS_PROF(0);
 
                 // lanes on their own, in rounds of lanePolyRows scratch rows
                 uint64_t solo = __builtin_amdgcn_ballot_w64(kind == 1);
@@ -1151,6 +1249,7 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                     }
                 }
 
+                PHYS_PROF(3);
                 uint64_t hull_pairs = __builtin_amdgcn_ballot_w64(kind == 2);
                 while (hull_pairs != 0) {
                     const uint32_t src = (uint32_t)__builtin_ctzll(hull_pairs);
@@ -1189,7 +1288,7 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                 num_contacts = (uint32_t)Block::maxContacts;
             }
             wave::phaseFence();
-            PHYS_PROF(3);
+            PHYS_PROF(5);
 
             // ---- position solve: contacts, then joints, level by level ----------
             for (uint32_t base = 0; base < num_contacts; base += 64) {
@@ -1250,7 +1349,7 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                                                  w->prev[k], w->sys.h);
             }
             wave::phaseFence();
-            PHYS_PROF(5);
+            PHYS_PROF(4);
 
             for (uint32_t base = 0; base < num_contacts; base += 64) {
                 const uint32_t n = num_contacts - base < 64 ?

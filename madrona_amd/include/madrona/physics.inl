@@ -636,6 +636,83 @@ candidateKernel(EcsState *S, void *, uint32_t, uint32_t)
 
 #include <madrona/phys_impl/world_step.inl>
 
+// BVH rebuild for the worlds that asked for one (a reset re-registered their
+// bodies): one wavefront per world, the build runs out of LDS on a rebased
+// copy of the tree (BVH::rebased) and the arrays go back to HBM once.  The
+// top-down build is a chain of a few thousand dependent accesses to a few KB;
+// from HBM that chain is pure latency (measured 230 us per step for ~40
+// rebuilding worlds with the reference's one-thread-per-world updateBVHEntry
+// ParallelFor, broadphase.cpp:1003-1004).
+__global__ void __launch_bounds__(64)
+bvhUpdateKernel(EcsState *S, void *, uint32_t, uint32_t)
+{
+    constexpr int32_t max_leaves = 64;
+    constexpr int32_t max_nodes = 21 + max_leaves;    // numInternalNodes(64)
+
+    struct Staging {
+        alignas(16) char nodes[max_nodes * broadphase::BVH::nodeBytes];
+        math::AABB leafAABBs[max_leaves];
+        math::Vector3 leafCenters[max_leaves];
+        uint32_t leafParents[max_leaves];
+        int32_t sortedLeaves[max_leaves];
+        int32_t traversalOrder[max_leaves];
+        int32_t numNodes;
+    };
+    __shared__ Staging staging;
+
+    StateManager *state_mgr = static_cast<StateManager *>(S);
+    const uint32_t lane = wave::laneID();
+    const int32_t num_worlds = S->numWorlds;
+
+    for (int32_t world = (int32_t)blockIdx.x; world < num_worlds;
+         world += (int32_t)gridDim.x) {
+        Context ctx = TaskGraph::makeContext<Context>(
+            state_mgr, WorldID { world }, true);
+        broadphase::BVH &bvh = ctx.singleton<broadphase::BVH>();
+
+        if (!bvh.needsRebuild()) {
+            continue;
+        }
+
+        const int32_t num_leaves = bvh.numLeaves();
+        if (num_leaves > max_leaves || bvh.nodeCapacity() > max_nodes) {
+            if (lane == 0) {
+                bvh.updateTree();       // too large to stage: build in place
+            }
+            continue;
+        }
+
+        for (int32_t i = (int32_t)lane; i < num_leaves; i += 64) {
+            math::AABB aabb = bvh.rawLeafAABBs()[i];
+            staging.leafAABBs[i] = aabb;
+            staging.leafCenters[i] = (aabb.pMin + aabb.pMax) / 2.f;
+            staging.sortedLeaves[i] = bvh.rawSortedLeaves()[i];
+        }
+        wave::phaseFence();
+
+        if (lane == 0) {
+            broadphase::BVH local = bvh.rebased(staging.nodes,
+                staging.leafAABBs, staging.leafParents, staging.sortedLeaves,
+                staging.traversalOrder, staging.leafCenters);
+            staging.numNodes = local.rebuildStaged();
+        }
+        wave::phaseFence();
+
+        const int32_t num_nodes = staging.numNodes;
+        waveCopyDwords(lane, (uint32_t *)bvh.rawNodes(),
+            (const uint32_t *)staging.nodes,
+            (uint32_t)num_nodes * (broadphase::BVH::nodeBytes / 4));
+        for (int32_t i = (int32_t)lane; i < num_leaves; i += 64) {
+            bvh.rawLeafParents()[i] = staging.leafParents[i];
+            bvh.rawSortedLeaves()[i] = staging.sortedLeaves[i];
+            bvh.rawTraversalOrder()[i] = staging.traversalOrder[i];
+        }
+        if (lane == 0) {
+            bvh.finishRebuild(num_nodes);
+        }
+        wave::phaseFence();
+    }
+}
 }
 #endif // __HIPCC__
 
@@ -887,24 +964,7 @@ MADRONA_HOST_API inline void registerTypes(ECSRegistry &registry, Solver solver)
 
 MADRONA_HOST_API inline TaskGraphNodeID setupBroadphaseTasks(
     TaskGraphBuilder &builder,
-    Span<const TaskGraphNodeID> deps)
-{
-    using namespace base;
-    using broadphase::LeafID;
-
-    auto update_leaves = builder.addToGraph<ParallelForNode<Context,
-        broadphase::updateLeafPositionsEntry,
-            LeafID, Position, Rotation, Scale, ObjectID, Velocity>>(deps);
-
-    auto bvh_update = builder.addToGraph<ParallelForNode<Context,
-        broadphase::updateBVHEntry, broadphase::BVH>>({update_leaves});
-
-    // the update may be a no-op, refit unconditionally
-    auto refit = builder.addToGraph<ParallelForNode<Context,
-        broadphase::refitEntry, LeafID>>({bvh_update});
-
-    return refit;
-}
+    Span<const TaskGraphNodeID> deps);
 
 namespace detail {
 
@@ -1074,6 +1134,43 @@ MADRONA_HOST_API inline TaskGraphNodeID setupPostIntegrationTasks(
         broadphase::refitEntry, LeafID>>({update_leaves});
 }
 
+}
+
+MADRONA_HOST_API inline TaskGraphNodeID setupBroadphaseTasks(
+    TaskGraphBuilder &builder,
+    Span<const TaskGraphNodeID> deps)
+{
+    using namespace base;
+    using broadphase::LeafID;
+
+#if defined(__HIPCC__)
+    [[maybe_unused]] auto bvh_stub = [] __host__ () -> const void * {
+        return (const void *)&kernels::bvhUpdateKernel;
+    };
+#else
+    auto bvh_stub = []() -> const void * { return nullptr; };
+#endif
+
+    auto update_leaves = builder.addToGraph<ParallelForNode<Context,
+        broadphase::updateLeafPositionsEntry,
+            LeafID, Position, Rotation, Scale, ObjectID, Velocity>>(deps);
+
+    TaskGraphNodeID bvh_update = update_leaves;
+#if MADRONA_ON_HOST
+    {
+        mwhip_node_desc desc {};
+        desc.kind = MWHIP_NODE_KERNEL;
+        desc.name = "physics:bvhUpdate";
+        desc.kernel = bvh_stub();
+        desc.count_mode = MWHIP_COUNT_PER_WORLD;
+        desc.threads_per_invocation = 64;
+        bvh_update = builder.addRuntimeNode(desc, -1, {update_leaves});
+    }
+#endif
+
+    // the update may be a no-op, refit unconditionally
+    return builder.addToGraph<ParallelForNode<Context,
+        broadphase::refitEntry, LeafID>>({bvh_update});
 }
 
 MADRONA_HOST_API inline TaskGraphNodeID setupPhysicsStepTasks(

@@ -21,7 +21,7 @@ with Simulator(hip_lib_path('escape_room_phys'), W, seed=5, flags=200) as hip:
     hip.step(N)
     out = np.zeros(8, np.uint64)
     rt.mwhip_memcpy_d2h(out.ctypes.data, buf, 64)
-    names = ['load', 'candidates', 'integrate', 'narrowphase', 'solvePos+joints', 'setVel', 'solveVel', 'store']
+    names = ['np.setup', 'load+cand', 'integrate', 'np.solo', 'solvePos+jnt+setVel', 'np.hull+compact', 'solveVel', 'store']
     tot = out.sum()
     for n, v in zip(names, out):
         print(f'{n:18s} {v / N / W:10.0f} ticks/world/step  {100 * v / tot:5.1f}%')
