@@ -204,8 +204,9 @@ def _replay_against_golden(path, lib_path):
     gold = np.load(path)
     with Simulator(lib_path, worlds, seed=seed, num_workers=1, flags=flags) as s:
         for step in range(1, max(checkpoints) + 1):
-            if sim == "escape_room":
-                s.write_tensor("action", escape_actions(step, worlds))
+            if sim.startswith("escape_room"):
+                s.write_tensor("action", escape_actions(
+                    step, worlds, grab=sim == "escape_room_phys"))
             s.step(1)
             if step in checkpoints:
                 for col, (rows, counts) in s.dump_all().items():
@@ -213,7 +214,8 @@ def _replay_against_golden(path, lib_path):
                     assert np.array_equal(rows, gold[f"s{step}/{col}/rows"]), (step, col)
 
 
-@pytest.mark.parametrize("name", ["cartpole_w64", "escape_room_w16", "sort_stress_w33"])
+@pytest.mark.parametrize("name", ["cartpole_w64", "escape_room_w16",
+                                  "sort_stress_w33", "escape_room_phys_w8"])
 def test_reference_backend_reproduces_golden(built, name):
     from golden.make_golden import CASES
     sim = CASES[name][0]
