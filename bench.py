@@ -73,6 +73,8 @@ def cpu_baseline(sim, worlds, flags, seed, budget_s=12.0):
     }
 
 
+PHYS_BODIES_PER_WORLD = 28      # 2 agents + 23 PhysicsEntity + 3 doors
+
 WORKLOADS = {
     "escape_room": (4096, "Escape-Room-shaped ECS (physics off), {w} worlds per GPU "
                           "(BASELINE.json configs[1]), 29 entity rows/world"),
@@ -164,6 +166,12 @@ def main():
     if rank == 0:
         stats = sim.profile(args.profile_reps)
         floor_us = min(k["avg_us"] for k in stats)     # empty-kernel interval
+        # rigid-body step: per body the fused kernel reads 156 B (transform,
+        # velocity, forces, ids, leaf + slot box) and writes 132 B (transform,
+        # velocity, solver state) -- DESIGN.md §10
+        for k in stats:
+            if k["name"].startswith("physics:worldStep"):
+                k["algo_bytes"] = float(args.worlds) * PHYS_BODIES_PER_WORLD * 288.0
         for k in stats:
             kernels.append({
                 "name": k["name"], "avg_us": round(k["avg_us"], 2),
@@ -175,7 +183,26 @@ def main():
         # the bandwidth-carrying kernel of the sort node (BASELINE metric names
         # "achieved HBM GB/s on sort node"): the fused column gather
         sort_k = [k for k in stats if "sort.gather" in k["name"]]
-        if sort_k:
+        phys_k = [k for k in stats if k["name"].startswith("physics:worldStep")]
+        if phys_k:
+            # config 3: the physics step is the dominant kernel (> 50 % of the
+            # step); it is bound by instruction issue at one wave per SIMD, not
+            # by HBM -- the fraction below says how far from the HBM roof it is
+            g = phys_k[0]
+            achieved = g["algo_bytes"] / (g["avg_us"] * 1e-6) / 1e9
+            roofline = {
+                "kernel": g["name"], "bound": "hbm",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None,
+                "avg_us": round(g["avg_us"], 2),
+                "algo_bytes_per_launch": int(g["algo_bytes"]),
+                "event_floor_us": round(floor_us, 2),
+                "note": "latency/issue-bound kernel (one wavefront per world, world "
+                        "resident in LDS): HBM traffic is one read + one write of the "
+                        "body columns per step; see DESIGN.md §10",
+            }
+        elif sort_k:
             g = max(sort_k, key=lambda k: k["algo_bytes"])
             achieved = g["algo_bytes"] / (g["avg_us"] * 1e-6) / 1e9
             roofline = {

@@ -953,8 +953,12 @@ __device__ inline PairSetup ldsSetupPair(const WorldBlock<MAXB> *w,
         PrimitiveTransform { w->pos[kb], w->rot[kb], w->scale[kb] });
 }
 
+// Two waves per SIMD: PMC shows the step parked on s_waitcnt 45 % of its wave
+// cycles at one wave per SIMD (SQ_WAIT_ANY / SQ_WAVE_CYCLES); capping the
+// kernel at 256 registers costs spills but lets a second world fill those
+// gaps (measured 1140 -> 868 us per step at 8192 worlds).
 #ifndef MADRONA_PHYS_LDS_WAVES_PER_EU
-#define MADRONA_PHYS_LDS_WAVES_PER_EU 1
+#define MADRONA_PHYS_LDS_WAVES_PER_EU 2
 #endif
 template <int MAXB>
 __global__ void __launch_bounds__(64)

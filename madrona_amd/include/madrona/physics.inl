@@ -1209,7 +1209,7 @@ MADRONA_HOST_API inline TaskGraphNodeID setupPhysicsStepTasks(
         PhysicsStepParams { (int32_t)num_substeps });
 
     // Worlds small enough to live in LDS take the LDS-resident kernel; the
-    // bound is twice the largest world at graph-build time, rounded up
+    // bound is the mean world at graph-build time + 1/8, rounded up
     // (MADRONA_MWHIP_PHYS_MAX_BODIES overrides; > 128 selects the generic
     // kernel that works out of HBM).
     mwhip_exec *exec = builder.exec();
@@ -1221,7 +1221,7 @@ MADRONA_HOST_API inline TaskGraphNodeID setupPhysicsStepTasks(
             total_rows += (uint64_t)mwhip_num_rows(exec, ps.bodyArchetypes[i]);
         }
         uint64_t per_world = total_rows / mwhip_num_worlds(exec) + 1;
-        max_bodies = (int)(per_world + per_world / 2);
+        max_bodies = (int)(per_world + per_world / 8);
     }
     max_bodies = max_bodies <= 32 ? 32 : max_bodies <= 64 ? 64 :
                  max_bodies <= 128 ? 128 : 0;
