@@ -44,6 +44,8 @@ def parse_args():
     p.add_argument("--sim", default="escape_room")
     p.add_argument("--auto-reset-denom", type=int, default=200)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-physics-line", action="store_true",
+                   help="skip the extra configs[2] measurement in the default run")
     p.add_argument("--profile-reps", type=int, default=30)
     return p.parse_args()
 
@@ -82,6 +84,48 @@ WORKLOADS = {
                                "worlds per GPU (BASELINE.json configs[2]), 28 rigid "
                                "bodies + 6 buttons/world, 4 substeps, grab joints"),
 }
+
+
+def physics_line(gpu_id, seed, denom, worlds=8192, steps=600, warmup=100):
+    """escape_room_phys at BASELINE configs[2] size: steps/s + the fused physics kernel."""
+    import torch
+    from madrona_amd.simlib import Simulator, hip_lib_path
+    from madrona_amd.tensor import to_torch
+
+    with Simulator(hip_lib_path("escape_room_phys"), worlds, seed=seed,
+                   gpu_id=gpu_id, flags=denom) as sim:
+        gen = torch.Generator(device="cuda")
+        gen.manual_seed(99)
+        action = to_torch(sim, "action", gpu_id)
+        action.copy_(torch.stack([
+            torch.randint(0, 4, (worlds, 2), device="cuda", generator=gen),
+            torch.randint(0, 8, (worlds, 2), device="cuda", generator=gen),
+            torch.randint(-2, 3, (worlds, 2), device="cuda", generator=gen),
+            torch.randint(0, 2, (worlds, 2), device="cuda", generator=gen),
+        ], -1).to(torch.int32))
+        torch.cuda.synchronize()
+        sim.step(warmup)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sim.step(steps)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        stats = sim.profile(10)
+    phys = [k for k in stats if k["name"].startswith("physics:worldStep")]
+    out = {
+        "workload": WORKLOADS["escape_room_phys"][1].format(w=worlds) +
+                    f", auto-reset p=1/{denom} per world per step",
+        "value": worlds * steps / dt, "unit": "steps/s",
+        "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
+    }
+    if phys:
+        algo = float(worlds) * PHYS_BODIES_PER_WORLD * 288.0
+        out["physics_kernel"] = {
+            "name": phys[0]["name"], "avg_us": round(phys[0]["avg_us"], 2),
+            "algo_bytes_per_launch": int(algo),
+            "GBps": round(algo / (phys[0]["avg_us"] * 1e-6) / 1e9, 1),
+        }
+    return out
 
 
 def main():
@@ -222,6 +266,14 @@ def main():
         cpu = cpu_baseline(args.sim, args.worlds, args.auto_reset_denom, seed)
 
     sharded.close()
+
+    # BASELINE configs[2] (physics on, 8192 worlds) next to the headline line,
+    # same timing discipline, shorter run
+    physics = None
+    if (rank == 0 and world_size == 1 and args.sim == "escape_room"
+            and not args.no_physics_line):
+        physics = physics_line(local_rank, seed, args.auto_reset_denom)
+
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
@@ -252,6 +304,7 @@ def main():
             },
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "physics_config3": physics,
             "kernels": kernels,
         }
         print(json.dumps(out))
