@@ -30,6 +30,50 @@ struct LeafID {
     int32_t id;
 };
 
+// LIFO of node indices for the traversals: the top 8 entries live in two
+// 64-bit registers (16 bits each), older ones spill to a private array.  A
+// plain int32_t stack[32] is indexed dynamically, which puts every push and pop
+// in scratch memory on CDNA (hundreds of cycles each).
+class NodeStack {
+public:
+    MADRONA_HD inline NodeStack() : lo_(0), hi_(0), num_reg_(0), num_spilled_(0) {}
+
+    MADRONA_HD inline bool empty() const
+    {
+        return num_reg_ == 0 && num_spilled_ == 0;
+    }
+
+    MADRONA_HD inline void push(int32_t node)
+    {
+        if (num_reg_ == 8) {
+            spilled_[num_spilled_++] = (uint16_t)(hi_ >> 48);
+            num_reg_ = 7;
+        }
+        hi_ = (hi_ << 16) | (lo_ >> 48);
+        lo_ = (lo_ << 16) | (uint64_t)(uint16_t)node;
+        num_reg_++;
+    }
+
+    MADRONA_HD inline int32_t pop()
+    {
+        if (num_reg_ == 0) {
+            return (int32_t)spilled_[--num_spilled_];
+        }
+        int32_t node = (int32_t)(lo_ & 0xFFFFu);
+        lo_ = (lo_ >> 16) | (hi_ << 48);
+        hi_ >>= 16;
+        num_reg_--;
+        return node;
+    }
+
+private:
+    uint64_t lo_;
+    uint64_t hi_;
+    int32_t num_reg_;
+    int32_t num_spilled_;
+    uint16_t spilled_[32];
+};
+
 class BVH {
 public:
     MADRONA_HD inline BVH(const ObjectManager *obj_mgr,
@@ -52,6 +96,15 @@ public:
     {
         findIntersecting(leaf_aabbs_[leaf_id.id], std::forward<Fn>(fn));
     }
+
+    // Closest hit of the ray o + t * d, 0 <= t <= t_max, against the collision
+    // primitives of every leaf (hulls and planes).  Returns Entity::none() on a
+    // miss.  Reference src/physics/broadphase.cpp:658-871.
+    MADRONA_HD inline Entity traceRay(math::Vector3 o,
+                                      math::Vector3 d,
+                                      float *out_hit_t,
+                                      math::Vector3 *out_hit_normal,
+                                      float t_max = float(INFINITY));
 
     MADRONA_HD inline void updateLeafPosition(LeafID leaf_id,
                                               const math::Vector3 &pos,
@@ -217,6 +270,14 @@ private:
         math::AABB aabb = leaf_aabbs_[sorted_leaves_[sorted_idx]];
         return (aabb.pMin + aabb.pMax) / 2.f;
     }
+
+    MADRONA_HD inline bool traceRayIntoLeaf(int32_t leaf_idx,
+                                            math::Vector3 world_ray_o,
+                                            math::Vector3 world_ray_d,
+                                            float t_min,
+                                            float t_max,
+                                            float *hit_t,
+                                            math::Vector3 *hit_normal);
 
     MADRONA_HD inline int32_t midpointSplit(int32_t base, int32_t num_elems);
     MADRONA_HD inline void rebuild();

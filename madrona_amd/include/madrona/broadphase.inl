@@ -6,6 +6,7 @@ BVH::BVH(const ObjectManager *obj_mgr,
          CountT max_leaves,
          float leaf_velocity_expansion,
          float leaf_accel_expansion)
+    // (node indices travel through 16-bit stack slots: max_leaves < ~49 K)
     : nodes_((Node *)rawAlloc(sizeof(Node) * numInternalNodes(max_leaves))),
       num_nodes_(0),
       num_allocated_nodes_(numInternalNodes(max_leaves)),
@@ -51,12 +52,11 @@ void BVH::findIntersecting(const math::AABB &aabb, Fn &&fn) const
 {
     // depth-first, children visited 0..3, deeper nodes pushed and popped LIFO:
     // the visit order defines the order candidates are emitted in
-    int32_t stack[32];
-    stack[0] = 0;
-    CountT stack_size = 1;
+    NodeStack stack;
+    stack.push(0);
 
-    while (stack_size > 0) {
-        const Node &node = nodes_[stack[--stack_size]];
+    while (!stack.empty()) {
+        const Node &node = nodes_[stack.pop()];
         for (CountT c = 0; c < 4; c++) {
             if (!node.hasChild(c)) {
                 continue;
@@ -69,7 +69,7 @@ void BVH::findIntersecting(const math::AABB &aabb, Fn &&fn) const
             if (node.isLeaf(c)) {
                 fn(leaf_entities_[node.leafIDX(c)]);
             } else {
-                stack[stack_size++] = node.children[c];
+                stack.push(node.children[c]);
             }
         }
     }

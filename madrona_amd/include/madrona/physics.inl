@@ -126,6 +126,216 @@ MADRONA_HD inline void forEachCandidate(Context &ctx, Entity e,
 }
 
 // ---------------------------------------------------------------------------
+// BVH ray casts (need the ObjectManager types, hence defined here)
+// ---------------------------------------------------------------------------
+namespace broadphase {
+
+namespace detail {
+
+// ray in the plane's frame: normal (0, 0, 1), d = 0
+MADRONA_HD inline bool traceRayIntoPlane(math::Vector3 ray_o,
+                                         math::Vector3 ray_d,
+                                         float t_min, float t_max,
+                                         float *hit_t,
+                                         math::Vector3 *hit_normal)
+{
+    float denom = ray_d.z;
+    if (denom == 0) {
+        return false;
+    }
+
+    float t = -ray_o.z / denom;
+    if (t < t_min || t > t_max) {
+        return false;
+    }
+
+    *hit_t = t;
+    *hit_normal = math::Vector3 { 0, 0, 1 };
+    return true;
+}
+
+// Clips the ray against the hull's half-spaces (Ericson, RTCD 5.3.8, with
+// outward normals); a ray that only meets back faces is a miss.
+MADRONA_HD inline bool traceRayIntoConvexPolyhedron(
+    const geo::HalfEdgeMesh &convex_mesh,
+    math::Vector3 ray_o, math::Vector3 ray_d,
+    float t_min, float t_max,
+    float *hit_t, math::Vector3 *hit_normal)
+{
+    float tfirst = t_min;
+    float tlast = t_max;
+
+    math::Vector3 closest_normal = math::Vector3::zero();
+
+    const CountT num_faces = (CountT)convex_mesh.numFaces;
+    for (CountT face_idx = 0; face_idx < num_faces; face_idx++) {
+        geo::Plane plane = convex_mesh.facePlanes[face_idx];
+
+        float denom = dot(plane.normal, ray_d);
+        float neg_dist = plane.d - dot(plane.normal, ray_o);
+
+        if (denom == 0.0f) {
+            // parallel to the face: outside its half-space means no hit at all
+            if (neg_dist < 0.0f) {
+                return false;
+            }
+        } else {
+            float t = neg_dist / denom;
+            if (denom < 0.0f) {
+                if (t >= tfirst) {      // entering
+                    tfirst = t;
+                    closest_normal = plane.normal;
+                }
+            } else {
+                if (t <= tlast) {       // leaving
+                    tlast = t;
+                }
+            }
+
+            if (tfirst > tlast) {
+                return false;
+            }
+        }
+    }
+
+    if (closest_normal.x == 0 && closest_normal.y == 0 &&
+            closest_normal.z == 0) {
+        return false;
+    }
+
+    *hit_t = tfirst;
+    *hit_normal = closest_normal;
+    return true;
+}
+
+}
+
+bool BVH::traceRayIntoLeaf(int32_t leaf_idx,
+                           math::Vector3 world_ray_o,
+                           math::Vector3 world_ray_d,
+                           float t_min,
+                           float t_max,
+                           float *hit_t,
+                           math::Vector3 *hit_normal)
+{
+    using namespace math;
+
+    base::ObjectID obj_id = leaf_obj_ids_[leaf_idx];
+    LeafTransform leaf_txfm = leaf_transforms_[leaf_idx];
+
+    Quat rot_to_local = leaf_txfm.rot.inv();
+
+    Vector3 obj_ray_o = rot_to_local.rotateVec(world_ray_o - leaf_txfm.pos);
+    obj_ray_o.x /= leaf_txfm.scale.d0;
+    obj_ray_o.y /= leaf_txfm.scale.d1;
+    obj_ray_o.z /= leaf_txfm.scale.d2;
+
+    Vector3 obj_ray_d = leaf_txfm.rot.inv().rotateVec(world_ray_d);
+    obj_ray_d.x /= leaf_txfm.scale.d0;
+    obj_ray_d.y /= leaf_txfm.scale.d1;
+    obj_ray_d.z /= leaf_txfm.scale.d2;
+
+    Diag3x3 inv_obj_ray_d = Diag3x3::fromVec(1.f / obj_ray_d);
+
+    Vector3 obj_hit_normal = Vector3::zero();
+
+    CountT prim_offset = (CountT)obj_mgr_->rigidBodyPrimitiveOffsets[obj_id.idx];
+    CountT num_prims = (CountT)obj_mgr_->rigidBodyPrimitiveCounts[obj_id.idx];
+
+    bool hit_leaf = false;
+    for (CountT i = 0; i < num_prims; i++) {
+        CountT prim_idx = prim_offset + i;
+
+        AABB prim_aabb = obj_mgr_->primitiveAABBs[prim_idx];
+        if (!prim_aabb.rayIntersects(obj_ray_o, inv_obj_ray_d, 0.f, t_max)) {
+            continue;
+        }
+
+        const CollisionPrimitive *prim =
+            &obj_mgr_->collisionPrimitives[prim_idx];
+
+        bool hit_prim = false;
+        if (prim->type == CollisionPrimitive::Type::Hull) {
+            hit_prim = detail::traceRayIntoConvexPolyhedron(
+                prim->hull.halfEdgeMesh, obj_ray_o, obj_ray_d, t_min, t_max,
+                hit_t, &obj_hit_normal);
+        } else if (prim->type == CollisionPrimitive::Type::Plane) {
+            hit_prim = detail::traceRayIntoPlane(
+                obj_ray_o, obj_ray_d, t_min, t_max, hit_t, &obj_hit_normal);
+        }   // spheres cannot be ray cast (the reference asserts)
+
+        if (hit_prim) {
+            hit_leaf = true;
+            t_max = *hit_t;
+        }
+    }
+
+    if (!hit_leaf) {
+        return false;
+    }
+
+    *hit_normal = leaf_txfm.rot.rotateVec(obj_hit_normal);
+    return true;
+}
+
+Entity BVH::traceRay(math::Vector3 o,
+                     math::Vector3 d,
+                     float *out_hit_t,
+                     math::Vector3 *out_hit_normal,
+                     float t_max)
+{
+    using namespace math;
+
+    Diag3x3 inv_d = Diag3x3::fromVec(d).inv();
+
+    NodeStack stack;
+    stack.push(0);
+
+    Entity closest_hit_entity = Entity::none();
+    Vector3 closest_hit_normal = Vector3::zero();
+
+    while (!stack.empty()) {
+        const Node &node = nodes_[stack.pop()];
+        for (CountT c = 0; c < 4; c++) {
+            if (!node.hasChild(c)) {
+                continue;
+            }
+
+            if (!node.bounds(c).rayIntersects(o, inv_d, 0.f, t_max)) {
+                continue;
+            }
+
+            if (node.isLeaf(c)) {
+                int32_t leaf_idx = node.leafIDX(c);
+
+                float hit_t;
+                Vector3 leaf_hit_normal;
+                bool leaf_hit = traceRayIntoLeaf(
+                    leaf_idx, o, d, 0.f, t_max, &hit_t, &leaf_hit_normal);
+
+                if (leaf_hit) {
+                    t_max = hit_t;
+                    closest_hit_entity = leaf_entities_[leaf_idx];
+                    closest_hit_normal = leaf_hit_normal;
+                }
+            } else {
+                stack.push(node.children[c]);
+            }
+        }
+    }
+
+    if (closest_hit_entity == Entity::none()) {
+        return Entity::none();
+    }
+
+    *out_hit_t = t_max;
+    *out_hit_normal = closest_hit_normal;
+    return closest_hit_entity;
+}
+
+}
+
+// ---------------------------------------------------------------------------
 // narrowphase: primitive-pair dispatch and contact generation (reference
 // narrowphase.cpp narrowphaseDispatch :1214-1514, generateContacts :1516-1680,
 // runNarrowphase :1682-1907, CPU flavour: one candidate per lane, hulls

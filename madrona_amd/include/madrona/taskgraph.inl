@@ -63,7 +63,13 @@ MADRONA_DEVICE inline void invokeSystemRow(ContextT &ctx, void *const *cols,
 // [row count + column pointers] -> [component data]: two round trips, not the
 // five of ecs_state -> query table -> table -> column -> data.  These kernels
 // are launch/latency bound at Escape-Room sizes (a few 1e4 rows).
-template <typename ContextT, auto Fn, typename... ComponentTs>
+//
+// threads_per_invocation > 1 (CustomParallelForNode<..., T, 1, ...>): T
+// consecutive lanes make the same call for one row and tell themselves apart
+// with threadIdx.x % T, the reference's convention (device taskgraph.inl:
+// 190-226) -- e.g. one ray per lane in a lidar system.
+template <typename ContextT, auto Fn, int32_t threads_per_invocation,
+          typename... ComponentTs>
 MADRONA_DEVICE inline void parallelForTable(StateManager *state_mgr,
                                             TableHdr &tbl,
                                             const uint16_t *col_indices,
@@ -80,8 +86,10 @@ MADRONA_UNROLL
         cols[c] = tbl.columns[col_indices[c]];
     }
 
-    const int32_t tid = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
-    const int32_t stride = (int32_t)(gridDim.x * blockDim.x);
+    const int32_t tid = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x) /
+        threads_per_invocation;
+    const int32_t stride = (int32_t)(gridDim.x * blockDim.x) /
+        threads_per_invocation;
 
     for (int32_t row = tid; row < num_rows; row += stride) {
         WorldID world_id = world_col[row];
@@ -97,7 +105,8 @@ MADRONA_UNROLL
     }
 }
 
-template <typename ContextT, auto Fn, typename... ComponentTs>
+template <typename ContextT, auto Fn, int32_t threads_per_invocation,
+          typename... ComponentTs>
 __global__ void __launch_bounds__(256)
 parallelForKernel(EcsState *S, void *, uint32_t query_offset,
                   uint32_t num_matching_and_flags, mwhip_pfor_args query)
@@ -114,7 +123,8 @@ parallelForKernel(EcsState *S, void *, uint32_t query_offset,
 MADRONA_UNROLL
         for (uint32_t a = 0; a < MWHIP_PFOR_MAX_INLINE; a++) {
             if (a < num_matching) {
-                parallelForTable<ContextT, Fn, ComponentTs...>(
+                parallelForTable<ContextT, Fn, threads_per_invocation,
+                                 ComponentTs...>(
                     state_mgr, *(TableHdr *)query.tables[a], query.columns[a],
                     exclusive_world);
             }
@@ -130,7 +140,8 @@ MADRONA_UNROLL
         for (size_t c = 0; c < N; c++) {
             col_indices[c] = (uint16_t)query_values[1 + c];
         }
-        parallelForTable<ContextT, Fn, ComponentTs...>(
+        parallelForTable<ContextT, Fn, threads_per_invocation,
+                         ComponentTs...>(
             state_mgr, S->tables[query_values[0]], col_indices, exclusive_world);
         query_values += 1 + N;
     }
@@ -418,10 +429,11 @@ CustomParallelForNode<ContextT, Fn, threads_per_invocation,
 #if defined(__HIPCC__)
     [[maybe_unused]] auto kernel_stub = [] __host__ () -> const void * {
         if constexpr (items_per_invocation == 1) {
-            static_assert(threads_per_invocation == 1,
-                "1 item per invocation runs one thread per row");
+            static_assert(threads_per_invocation >= 1 &&
+                64 % threads_per_invocation == 0,
+                "threads per invocation must divide the wavefront");
             return (const void *)&mwhip::parallelForKernel<
-                ContextT, Fn, ComponentTs...>;
+                ContextT, Fn, threads_per_invocation, ComponentTs...>;
         } else {
             return (const void *)&mwhip::parallelForBatchKernel<
                 Fn, threads_per_invocation, items_per_invocation,

@@ -620,59 +620,51 @@ inline void collectObservationsSystem(Engine &ctx,
     }
 }
 
-// Analytic stand-in for the BVH ray cast: distance along each of 30 view rays
-// to the arena walls and to the other agent (circle).
+// 30 rays per agent through the world's BVH (hulls + floor plane): depth and
+// the type of what was hit, like the Escape Room's lidar.  On the GPU backends
+// the node runs 32 threads per agent, one ray each (the reference simulators'
+// convention: CustomParallelForNode<..., 32, 1, ...> + threadIdx.x % 32).
 inline void lidarSystem(Engine &ctx,
                         Entity e,
                         Lidar &lidar)
 {
     Vector3 pos = ctx.get<Position>(e);
     Quat rot = ctx.get<Rotation>(e);
-    Vector3 other_pos = ctx.get<Position>(ctx.get<OtherAgents>(e).e[0]);
+    broadphase::BVH &bvh = ctx.singleton<broadphase::BVH>();
 
-    const float x_lim = consts::worldWidth / 2.f;
+    // from inside the agent's own hull (only back faces are met: a miss)
+    Vector3 ray_o = pos + 0.5f * math::up;
 
-    for (int32_t i = 0; i < consts::numLidarSamples; i++) {
-        Vector3 dir = rot.rotateVec(
-            Vector3 { kLidarCos[i], kLidarSin[i], 0.f });
+    auto traceRay = [&](int32_t i) {
+        Vector3 ray_d = rot.rotateVec(
+            Vector3 { kLidarCos[i], kLidarSin[i], 0.f }).normalize();
 
-        float t_hit = 200.f;
-        float hit_type = (float)EntityType::None;
+        float hit_t;
+        Vector3 hit_normal;
+        Entity hit_entity =
+            bvh.traceRay(ray_o, ray_d, &hit_t, &hit_normal, 200.f);
 
-        // walls
-        if (dir.x > 1e-6f) {
-            float t = (x_lim - pos.x) / dir.x;
-            if (t < t_hit) { t_hit = t; hit_type = (float)EntityType::Wall; }
-        } else if (dir.x < -1e-6f) {
-            float t = (-x_lim - pos.x) / dir.x;
-            if (t < t_hit) { t_hit = t; hit_type = (float)EntityType::Wall; }
+        if (hit_entity == Entity::none()) {
+            lidar.samples[i] = LidarSample { 0.f, 0.f };
+        } else {
+            EntityType hit_type = ctx.get<EntityType>(hit_entity);
+            lidar.samples[i] = LidarSample {
+                hit_t / 200.f,
+                (float)hit_type / (float)EntityType::NumTypes,
+            };
         }
-        if (dir.y > 1e-6f) {
-            float t = (consts::worldLength - pos.y) / dir.y;
-            if (t < t_hit) { t_hit = t; hit_type = (float)EntityType::Wall; }
-        } else if (dir.y < -1e-6f) {
-            float t = (0.f - pos.y) / dir.y;
-            if (t < t_hit) { t_hit = t; hit_type = (float)EntityType::Wall; }
-        }
+    };
 
-        // other agent: |pos + t dir - c|^2 = r^2
-        Vector3 oc = pos - other_pos;
-        float b = 2.f * (oc.x * dir.x + oc.y * dir.y);
-        float c = oc.x * oc.x + oc.y * oc.y -
-            consts::agentRadius * consts::agentRadius;
-        float t1, t2;
-        if (solveQuadraticUnsafe(1.f, b, c, &t1, &t2)) {
-            if (t1 > 0.f && t1 < t_hit) {
-                t_hit = t1;
-                hit_type = (float)EntityType::Agent;
-            }
-        }
-
-        lidar.samples[i] = LidarSample {
-            t_hit / 200.f,
-            hit_type / (float)EntityType::NumTypes,
-        };
+#ifdef MADRONA_GPU_MODE
+    int32_t idx = (int32_t)(threadIdx.x % 32);
+    if (idx < consts::numLidarSamples) {
+        traceRay(idx);
     }
+#else
+    for (int32_t i = 0; i < consts::numLidarSamples; i++) {
+        traceRay(i);
+    }
+#endif
 }
 
 void Sim::setupTasks(TaskGraphManager &taskgraph_mgr, const Config &)
@@ -774,8 +766,13 @@ void Sim::setupTasks(TaskGraphManager &taskgraph_mgr, const Config &)
             DoorObservation
         >>({post_reset_broadphase});
 
+#ifdef MADRONA_GPU_MODE
+    auto lidar = builder.addToGraph<CustomParallelForNode<Engine,
+        lidarSystem, 32, 1,
+#else
     auto lidar = builder.addToGraph<ParallelForNode<Engine,
         lidarSystem,
+#endif
             Entity,
             Lidar
         >>({collect_obs});
