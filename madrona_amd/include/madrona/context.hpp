@@ -150,7 +150,8 @@ private:
             return cached_loc_;
         }
 
-        const mwhip::EntitySlot &slot = state_mgr_->entities[e.id];
+        const mwhip::EntitySlot &slot =
+            mwhip::entitiesOf(state_mgr_)[e.id];
         Loc loc { slot.loc.archetype, slot.loc.row };
         cached_id_ = e.id;
         cached_gen_ = e.gen;

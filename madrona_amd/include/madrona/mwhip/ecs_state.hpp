@@ -138,6 +138,54 @@ struct EcsState {
     void *moduleData[4];            // module-private device pointers (physics scratch, ...)
 };
 
+// Load through the constant address space: for data no kernel of the *user*
+// code object ever writes (the ecs_state header fields, the column-pointer
+// table -- rewritten only by the sort's finalize kernel, between user
+// kernels).  The compiler may then hoist / batch these loads across the
+// stores of a system instead of re-reading them after every store: a
+// per-world system chains dozens of `ctx.get<T>(e) = ...`, and each
+// dependent reload is a ~0.5 us round trip with one lane per wave.
+template <typename T>
+MWHIP_HD inline T loadInvariant(const T *p)
+{
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8);
+#if !defined(__HIP_DEVICE_COMPILE__)
+    return *p;
+#else
+    if constexpr (sizeof(T) == 8) {
+        unsigned long long v = *(const __attribute__((address_space(4)))
+            unsigned long long *)(unsigned long long)p;
+        return __builtin_bit_cast(T, v);
+    } else {
+        unsigned int v = *(const __attribute__((address_space(4)))
+            unsigned int *)(unsigned long long)p;
+        return __builtin_bit_cast(T, v);
+    }
+#endif
+}
+
+// header fields that never change once the executor is built
+MWHIP_HD inline TableHdr *tablesOf(const EcsState *S)
+{
+    return loadInvariant(&S->tables);
+}
+
+MWHIP_HD inline EntitySlot *entitiesOf(const EcsState *S)
+{
+    return loadInvariant(&S->entities);
+}
+
+MWHIP_HD inline IdCache *worldCachesOf(const EcsState *S)
+{
+    return loadInvariant(&S->worldCaches);
+}
+
+// a table's column base (swapped only by the sort's finalize kernel)
+MWHIP_HD inline void *columnOf(const TableHdr &tbl, int32_t column_idx)
+{
+    return loadInvariant(&tbl.columns[column_idx]);
+}
+
 #if defined(__HIPCC__)
 
 MWHIP_DEV inline int32_t atomicAddI32(int32_t *p, int32_t v)
@@ -159,7 +207,7 @@ MWHIP_DEV inline void raiseError(EcsState *S, uint32_t flag)
 template <typename Fn>
 MWHIP_DEV inline void withWorldCache(EcsState *S, int32_t world, Fn &&fn)
 {
-    IdCache *cache = &S->worldCaches[world];
+    IdCache *cache = &worldCachesOf(S)[world];
     bool done = false;
     while (!done) {
         if (__hip_atomic_exchange(&cache->lock, 1u, __ATOMIC_ACQUIRE,
@@ -180,14 +228,14 @@ MWHIP_DEV inline void withWorldCache(EcsState *S, int32_t world, Fn &&fn)
 MWHIP_DEV inline int32_t popCachedId(EcsState *S, int32_t *head, uint32_t *gen_out)
 {
     int32_t new_id = *head;
-    EntitySlot &node = S->entities[new_id];
+    EntitySlot &node = entitiesOf(S)[new_id];
     int32_t num_contiguous = node.freeNode.globalNext;
 
     if (num_contiguous == 1) {
         *head = node.freeNode.subNext;
     } else {
         int32_t next_free = new_id + 1;
-        EntitySlot &next_node = S->entities[next_free];
+        EntitySlot &next_node = entitiesOf(S)[next_free];
         next_node.freeNode.subNext = node.freeNode.subNext;
         next_node.freeNode.globalNext = num_contiguous - 1;
         next_node.gen = 0;
@@ -257,7 +305,7 @@ MWHIP_DEV inline int32_t acquireIdLocked(EcsState *S, int32_t world, IdCache &ca
             break;
         }
         uint32_t gen = (uint32_t)(cur >> 32);
-        int32_t next = __hip_atomic_load(&S->entities[head].freeNode.globalNext,
+        int32_t next = __hip_atomic_load(&entitiesOf(S)[head].freeNode.globalNext,
             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned long long desired =
             ((unsigned long long)(gen + 1u) << 32) | (uint32_t)next;
@@ -269,17 +317,17 @@ MWHIP_DEV inline int32_t acquireIdLocked(EcsState *S, int32_t world, IdCache &ca
     }
 
     if (free_ids != kIdSentinel) {
-        S->entities[free_ids].freeNode.globalNext = 1;
+        entitiesOf(S)[free_ids].freeNode.globalNext = 1;
         cache.freeHead = free_ids;
         cache.numFree = kIdsPerBlock - 1;
         return popCachedId(S, &cache.freeHead, gen_out);
     }
 
     int32_t first_id = expandIdStore(S, world, cache);
-    S->entities[first_id].gen = 0;
+    entitiesOf(S)[first_id].gen = 0;
 
     int32_t free_start = first_id + 1;
-    EntitySlot &next_free = S->entities[free_start];
+    EntitySlot &next_free = entitiesOf(S)[free_start];
     next_free.freeNode.subNext = kIdSentinel;
     next_free.freeNode.globalNext = kIdsPerBlock - 1;
     next_free.gen = 0;
@@ -294,7 +342,7 @@ MWHIP_DEV inline int32_t acquireIdLocked(EcsState *S, int32_t world, IdCache &ca
 // mirrors IDMap::releaseID (reference id_map_impl.inl:186-224)
 MWHIP_DEV inline void releaseIdLocked(EcsState *S, IdCache &cache, int32_t id)
 {
-    EntitySlot &node = S->entities[id];
+    EntitySlot &node = entitiesOf(S)[id];
     node.gen = node.gen + 1;
     node.freeNode.globalNext = 1;
 
@@ -316,7 +364,7 @@ MWHIP_DEV inline void releaseIdLocked(EcsState *S, IdCache &cache, int32_t id)
         unsigned long long cur = __hip_atomic_load(&S->idFreeHead,
             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         while (true) {
-            __hip_atomic_store(&S->entities[new_head].freeNode.globalNext,
+            __hip_atomic_store(&entitiesOf(S)[new_head].freeNode.globalNext,
                 (int32_t)(uint32_t)(cur & 0xFFFFFFFFull), __ATOMIC_RELAXED,
                 __HIP_MEMORY_SCOPE_AGENT);
             unsigned long long desired =

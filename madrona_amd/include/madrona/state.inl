@@ -218,7 +218,7 @@ MADRONA_HD Loc StateManager::getLoc(Entity e) const
         return Loc::none();
     }
 
-    const mwhip::EntitySlot &slot = entities[e.id];
+    const mwhip::EntitySlot &slot = mwhip::entitiesOf(this)[e.id];
     if (slot.gen != e.gen) {
         return Loc::none();
     }
@@ -230,14 +230,21 @@ template <typename ComponentT>
 MADRONA_HD ComponentT &StateManager::getUnsafe(Loc loc)
 {
     uint32_t component_id = TypeTracker::typeID<ComponentT>();
+#if defined(__HIP_DEVICE_COMPILE__)
+    void *const *col_ptrs = mwhip::loadInvariant(&colPtr);
+    uint32_t num_slots = mwhip::loadInvariant(&numComponentSlots);
+    return ((ComponentT *)mwhip::loadInvariant(
+        &col_ptrs[loc.archetype * num_slots + component_id]))[loc.row];
+#else
     return ((ComponentT *)colPtr[loc.archetype * numComponentSlots +
                                  component_id])[loc.row];
+#endif
 }
 
 template <typename ComponentT>
 MADRONA_HD ComponentT &StateManager::getUnsafe(Entity e)
 {
-    const mwhip::EntitySlot &slot = entities[e.id];
+    const mwhip::EntitySlot &slot = mwhip::entitiesOf(this)[e.id];
     return getUnsafe<ComponentT>(Loc { slot.loc.archetype, slot.loc.row });
 }
 
@@ -245,8 +252,15 @@ template <typename ComponentT>
 MADRONA_HD ResultRef<ComponentT> StateManager::get(Loc loc)
 {
     uint32_t component_id = TypeTracker::typeID<ComponentT>();
+#if defined(__HIP_DEVICE_COMPILE__)
+    void *const *col_ptrs = mwhip::loadInvariant(&colPtr);
+    uint32_t num_slots = mwhip::loadInvariant(&numComponentSlots);
+    ComponentT *col = (ComponentT *)mwhip::loadInvariant(
+        &col_ptrs[loc.archetype * num_slots + component_id]);
+#else
     ComponentT *col = (ComponentT *)colPtr[
         loc.archetype * numComponentSlots + component_id];
+#endif
     if (col == nullptr) {
         return ResultRef<ComponentT>(nullptr);
     }
@@ -268,7 +282,8 @@ MADRONA_HD ResultRef<ComponentT> StateManager::get(Entity e)
 template <typename ComponentT>
 MADRONA_HD ComponentT &StateManager::getDirect(int32_t column_idx, Loc loc)
 {
-    return ((ComponentT *)tables[loc.archetype].columns[column_idx])[loc.row];
+    return ((ComponentT *)mwhip::columnOf(
+        mwhip::tablesOf(this)[loc.archetype], column_idx))[loc.row];
 }
 
 template <typename SingletonT>
@@ -277,7 +292,8 @@ MADRONA_HD SingletonT *StateManager::getSingletonColumn()
     // a singleton archetype has exactly one user column, column 2
     uint32_t archetype_id =
         TypeTracker::typeID<SingletonArchetype<SingletonT>>();
-    return (SingletonT *)tables[archetype_id].columns[user_component_offset_];
+    return (SingletonT *)mwhip::columnOf(
+        mwhip::tablesOf(this)[archetype_id], user_component_offset_);
 }
 
 template <typename SingletonT>
@@ -289,7 +305,7 @@ MADRONA_HD SingletonT &StateManager::getSingleton(WorldID world_id)
 MADRONA_HD inline Entity StateManager::makeEntityNow(WorldID world_id, uint32_t archetype_id, bool exclusive, Loc *loc_out)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    mwhip::TableHdr &tbl = tables[archetype_id];
+    mwhip::TableHdr &tbl = mwhip::tablesOf(this)[archetype_id];
     int32_t row = mwhip::appendRow(this, tbl);
 
     uint32_t gen = 0;
@@ -297,20 +313,21 @@ MADRONA_HD inline Entity StateManager::makeEntityNow(WorldID world_id, uint32_t 
     if (exclusive) {
         // one thread per world in this node: nobody else touches the cache
         id = mwhip::acquireIdLocked(this, world_id.idx,
-                                    worldCaches[world_id.idx], &gen);
+                                    mwhip::worldCachesOf(this)[world_id.idx],
+                                    &gen);
     } else {
         mwhip::withWorldCache(this, world_id.idx, [&](mwhip::IdCache &cache) {
             id = mwhip::acquireIdLocked(this, world_id.idx, cache, &gen);
         });
     }
 
-    mwhip::EntitySlot &slot = entities[id];
+    mwhip::EntitySlot &slot = mwhip::entitiesOf(this)[id];
     slot.loc.archetype = archetype_id;
     slot.loc.row = row;
 
     Entity e { gen, id };
-    ((Entity *)tbl.columns[0])[row] = e;
-    ((WorldID *)tbl.columns[1])[row] = world_id;
+    ((Entity *)mwhip::columnOf(tbl, 0))[row] = e;
+    ((WorldID *)mwhip::columnOf(tbl, 1))[row] = world_id;
 
     if (loc_out != nullptr) {
         *loc_out = Loc { archetype_id, row };
@@ -352,13 +369,14 @@ MADRONA_HD inline void StateManager::destroyEntityNow(WorldID caller_world, Enti
         return;
     }
 
-    mwhip::TableHdr &tbl = tables[loc.archetype];
-    ((Entity *)tbl.columns[0])[loc.row] = Entity::none();
-    ((WorldID *)tbl.columns[1])[loc.row] = WorldID { -1 };
+    mwhip::TableHdr &tbl = mwhip::tablesOf(this)[loc.archetype];
+    ((Entity *)mwhip::columnOf(tbl, 0))[loc.row] = Entity::none();
+    ((WorldID *)mwhip::columnOf(tbl, 1))[loc.row] = WorldID { -1 };
     tbl.needsSort = 1u;
 
     if (exclusive) {
-        mwhip::releaseIdLocked(this, worldCaches[caller_world.idx], e.id);
+        mwhip::releaseIdLocked(this,
+            mwhip::worldCachesOf(this)[caller_world.idx], e.id);
     } else {
         mwhip::withWorldCache(this, caller_world.idx,
                               [&](mwhip::IdCache &cache) {

@@ -148,8 +148,9 @@ public:
     MADRONA_HD static inline WorldBase *getWorld(StateManager *state_mgr,
                                                      int32_t world_idx)
     {
-        return (WorldBase *)(state_mgr->worldData +
-            (uint64_t)world_idx * state_mgr->worldDataStride);
+        return (WorldBase *)(mwhip::loadInvariant(&state_mgr->worldData) +
+            (uint64_t)world_idx *
+                mwhip::loadInvariant(&state_mgr->worldDataStride));
     }
 
     template <typename ContextT>

@@ -27,8 +27,10 @@ struct HostTypeID {
 #if defined(__HIPCC__)
 // `used`: the symbol must exist in the code object for hipMemcpyToSymbol even
 // when no kernel happens to read this type's id.
+// __constant__: written once from the host before any kernel runs, so the
+// compiler may treat reads as invariant (scalar loads, hoisted above stores).
 template <typename T>
-__device__ __attribute__((used)) uint32_t deviceTypeID = 0xFFFFFFFFu;
+__constant__ __attribute__((used)) uint32_t deviceTypeID = 0xFFFFFFFFu;
 #endif
 
 }
