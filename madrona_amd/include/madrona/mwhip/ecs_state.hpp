@@ -229,20 +229,23 @@ MWHIP_DEV inline int32_t popCachedId(EcsState *S, int32_t *head, uint32_t *gen_o
 {
     int32_t new_id = *head;
     EntitySlot &node = entitiesOf(S)[new_id];
-    int32_t num_contiguous = node.freeNode.globalNext;
+    // the whole 12-byte slot in one round trip
+    const int32_t sub_next = node.freeNode.subNext;
+    const int32_t num_contiguous = node.freeNode.globalNext;
+    const uint32_t gen = node.gen;
 
     if (num_contiguous == 1) {
-        *head = node.freeNode.subNext;
+        *head = sub_next;
     } else {
         int32_t next_free = new_id + 1;
         EntitySlot &next_node = entitiesOf(S)[next_free];
-        next_node.freeNode.subNext = node.freeNode.subNext;
+        next_node.freeNode.subNext = sub_next;
         next_node.freeNode.globalNext = num_contiguous - 1;
         next_node.gen = 0;
         *head = next_free;
     }
 
-    *gen_out = node.gen;
+    *gen_out = gen;
     return new_id;
 }
 
@@ -285,13 +288,17 @@ MWHIP_DEV inline int32_t expandIdStore(EcsState *S, int32_t world, IdCache &cach
 MWHIP_DEV inline int32_t acquireIdLocked(EcsState *S, int32_t world, IdCache &cache,
                                         uint32_t *gen_out)
 {
-    if (cache.numOverflow > 0) {
-        cache.numOverflow -= 1;
+    // both counters in one round trip (they share the cache struct's line)
+    const int32_t num_overflow = cache.numOverflow;
+    const int32_t num_free = cache.numFree;
+
+    if (num_overflow > 0) {
+        cache.numOverflow = num_overflow - 1;
         return popCachedId(S, &cache.overflowHead, gen_out);
     }
 
-    if (cache.numFree > 0) {
-        cache.numFree -= 1;
+    if (num_free > 0) {
+        cache.numFree = num_free - 1;
         return popCachedId(S, &cache.freeHead, gen_out);
     }
 
@@ -398,17 +405,30 @@ MWHIP_DEV inline void *persistAlloc(EcsState *S, unsigned long long num_bytes)
 // Appends one row to the archetype's global table.  Rows of one world that are
 // created by one thread keep their creation order under the stable world sort,
 // which is what makes per-world row order equal to the CPU backend's.
-MWHIP_DEV inline int32_t appendRow(EcsState *S, TableHdr &tbl)
+// Split in two so that a caller can put independent memory work between the
+// atomic and the first use of its result (one lane per world: every dependent
+// round trip is exposed).
+MWHIP_DEV inline int32_t appendRowIssue(TableHdr &tbl)
 {
-    int32_t row = atomicAddI32(&tbl.numRows, 1);
-    if (row >= tbl.capacity) {
+    tbl.needsSort = 1u;
+    return atomicAddI32(&tbl.numRows, 1);
+}
+
+MWHIP_DEV inline int32_t appendRowCheck(EcsState *S, TableHdr &tbl, int32_t row)
+{
+    const int32_t capacity = loadInvariant(&tbl.capacity);
+    if (row >= capacity) {
         raiseError(S, kErrTableOverflow);
         // keep writes in bounds; the host aborts after the step
         atomicAddI32(&tbl.numRows, -1);
-        row = tbl.capacity - 1;
+        row = capacity - 1;
     }
-    tbl.needsSort = 1u;
     return row;
+}
+
+MWHIP_DEV inline int32_t appendRow(EcsState *S, TableHdr &tbl)
+{
+    return appendRowCheck(S, tbl, appendRowIssue(tbl));
 }
 
 #endif // __HIPCC__

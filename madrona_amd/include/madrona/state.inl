@@ -306,7 +306,9 @@ MADRONA_HD inline Entity StateManager::makeEntityNow(WorldID world_id, uint32_t 
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     mwhip::TableHdr &tbl = mwhip::tablesOf(this)[archetype_id];
-    int32_t row = mwhip::appendRow(this, tbl);
+    // the row counter's atomic and the id cache reads are independent: issue
+    // the atomic, take the id, then look at the row
+    int32_t row = mwhip::appendRowIssue(tbl);
 
     uint32_t gen = 0;
     int32_t id = 0;
@@ -320,6 +322,8 @@ MADRONA_HD inline Entity StateManager::makeEntityNow(WorldID world_id, uint32_t 
             id = mwhip::acquireIdLocked(this, world_id.idx, cache, &gen);
         });
     }
+
+    row = mwhip::appendRowCheck(this, tbl, row);
 
     mwhip::EntitySlot &slot = mwhip::entitiesOf(this)[id];
     slot.loc.archetype = archetype_id;
