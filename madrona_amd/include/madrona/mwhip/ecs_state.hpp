@@ -347,23 +347,32 @@ MWHIP_DEV inline int32_t acquireIdLocked(EcsState *S, int32_t world, IdCache &ca
 }
 
 // mirrors IDMap::releaseID (reference id_map_impl.inl:186-224)
-MWHIP_DEV inline void releaseIdLocked(EcsState *S, IdCache &cache, int32_t id)
+// cur_gen: the slot's generation (the caller has just validated the handle
+// against it, so it is not read again)
+MWHIP_DEV inline void releaseIdLocked(EcsState *S, IdCache &cache, int32_t id,
+                                      uint32_t cur_gen)
 {
     EntitySlot &node = entitiesOf(S)[id];
-    node.gen = node.gen + 1;
+    node.gen = cur_gen + 1;
     node.freeNode.globalNext = 1;
 
-    if (cache.numFree < kIdsPerBlock) {
-        node.freeNode.subNext = cache.freeHead;
+    // the cache's four words in one round trip
+    const int32_t num_free = cache.numFree;
+    const int32_t free_head = cache.freeHead;
+    const int32_t num_overflow = cache.numOverflow;
+    const int32_t overflow_head = cache.overflowHead;
+
+    if (num_free < kIdsPerBlock) {
+        node.freeNode.subNext = free_head;
         cache.freeHead = id;
-        cache.numFree += 1;
+        cache.numFree = num_free + 1;
         return;
     }
 
-    if (cache.numOverflow < kIdsPerBlock) {
-        node.freeNode.subNext = cache.overflowHead;
+    if (num_overflow < kIdsPerBlock) {
+        node.freeNode.subNext = overflow_head;
         cache.overflowHead = id;
-        cache.numOverflow += 1;
+        cache.numOverflow = num_overflow + 1;
     }
 
     if (cache.numOverflow == kIdsPerBlock) {

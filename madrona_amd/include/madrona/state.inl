@@ -368,8 +368,15 @@ MADRONA_HD inline Loc StateManager::makeTemporary(WorldID world_id, uint32_t arc
 MADRONA_HD inline void StateManager::destroyEntityNow(WorldID caller_world, Entity e, bool exclusive)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    Loc loc = getLoc(e);
-    if (!loc.valid()) {
+    if (e.id < 0) {
+        return;
+    }
+
+    // generation and location in one round trip
+    const mwhip::EntitySlot &slot = mwhip::entitiesOf(this)[e.id];
+    const uint32_t slot_gen = slot.gen;
+    Loc loc { slot.loc.archetype, slot.loc.row };
+    if (slot_gen != e.gen) {
         return;
     }
 
@@ -380,11 +387,11 @@ MADRONA_HD inline void StateManager::destroyEntityNow(WorldID caller_world, Enti
 
     if (exclusive) {
         mwhip::releaseIdLocked(this,
-            mwhip::worldCachesOf(this)[caller_world.idx], e.id);
+            mwhip::worldCachesOf(this)[caller_world.idx], e.id, slot_gen);
     } else {
         mwhip::withWorldCache(this, caller_world.idx,
                               [&](mwhip::IdCache &cache) {
-            mwhip::releaseIdLocked(this, cache, e.id);
+            mwhip::releaseIdLocked(this, cache, e.id, slot_gen);
         });
     }
 #else
