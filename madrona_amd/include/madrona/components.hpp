@@ -6,41 +6,31 @@
 #include <madrona/fwd.hpp>
 #include <madrona/taskgraph.hpp>
 
-namespace madrona {
-namespace base {
+namespace madrona::base {
 
-struct Position : math::Vector3 {
-    MADRONA_HD Position(math::Vector3 v) : Vector3(v) {}
-};
+// thin wrappers: distinct component types over the math types
+struct Position : math::Vector3 { MADRONA_HD Position(math::Vector3 v) : Vector3(v) {} };
+struct Rotation : math::Quat { MADRONA_HD Rotation(math::Quat q) : Quat(q) {} };
+struct Scale : math::Diag3x3 { MADRONA_HD Scale(math::Diag3x3 d) : Diag3x3(d) {} };
 
-struct Rotation : math::Quat {
-    MADRONA_HD Rotation(math::Quat q) : Quat(q) {}
-};
+// index into the asset tables (ObjectManager, render meshes)
+struct ObjectID { int32_t idx; };
 
-struct Scale : math::Diag3x3 {
-    MADRONA_HD Scale(math::Diag3x3 d) : Diag3x3(d) {}
-};
+struct ObjectInstance : Bundle<Position, Rotation, Scale, ObjectID> {};
 
-struct ObjectID {
-    int32_t idx;
-};
+namespace detail {
+template <typename... Ts>
+MADRONA_HOST_API inline void registerAll(ECSRegistry &registry)
+{
+    (registry.registerComponent<Ts>(), ...);
+}
+}
 
-struct ObjectInstance : Bundle<
-    Position,
-    Rotation,
-    Scale,
-    ObjectID
-> {};
-
+// component ids are handed out in this order, as in src/core/base.cpp
 MADRONA_HOST_API inline void registerTypes(ECSRegistry &registry)
 {
-    registry.registerComponent<Position>();
-    registry.registerComponent<Rotation>();
-    registry.registerComponent<Scale>();
-    registry.registerComponent<ObjectID>();
-
+    detail::registerAll<Position, Rotation, Scale, ObjectID>(registry);
     registry.registerBundle<ObjectInstance>();
 }
 
-}
 }

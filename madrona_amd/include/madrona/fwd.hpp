@@ -1,11 +1,7 @@
+// forward declarations shared by the API headers
 #pragma once
 
 namespace madrona {
-
-class StateManager;
-class ECSRegistry;
-class Context;
-class TaskGraphManager;
+class Context; class StateManager; class ECSRegistry; class TaskGraphManager;
 struct WorkerInit;
-
 }

@@ -27,103 +27,71 @@
 
 namespace madrona::phys {
 
+// ---- per-body components (members of the RigidBody bundle) ------------------
+enum class ResponseType : uint32_t { Dynamic, Kinematic, Static };
+
+struct Velocity { math::Vector3 linear, angular; };
+
+// forces / torques accumulated by the simulator for the next step
 struct ExternalForce : math::Vector3 {
     MADRONA_HD ExternalForce(math::Vector3 v) : Vector3(v) {}
 };
-
 struct ExternalTorque : math::Vector3 {
     MADRONA_HD ExternalTorque(math::Vector3 v) : Vector3(v) {}
 };
 
-enum class ResponseType : uint32_t {
-    Dynamic,
-    Kinematic,
-    Static,
-};
-
-struct Velocity {
-    math::Vector3 linear;
-    math::Vector3 angular;
-};
-
+// replaced by the solver's own per-body state when the bundle is registered
 struct SolverBundleAlias {};
 
-struct RigidBody : Bundle<
-    base::ObjectInstance,
-    ResponseType,
-    broadphase::LeafID,
-    Velocity,
-    ExternalForce,
-    ExternalTorque,
-    SolverBundleAlias
-> {};
+struct RigidBody : Bundle<base::ObjectInstance, ResponseType, broadphase::LeafID,
+                          Velocity, ExternalForce, ExternalTorque,
+                          SolverBundleAlias> {};
 
+// ---- what the broadphase / narrowphase / solver pass to each other -----------
 struct CandidateCollision {
-    Loc a;
-    Loc b;
-    uint32_t aPrim;
-    uint32_t bPrim;
+    Loc a, b;               // the two bodies
+    uint32_t aPrim, bPrim;  // primitive of each body to test
 };
 
 struct ContactConstraint {
-    Loc ref;
-    Loc alt;
-    math::Vector4 points[4];
+    Loc ref, alt;               // body owning the reference feature, the other
+    math::Vector4 points[4];    // xyz = world position, w = penetration depth
     int32_t numPoints;
     math::Vector3 normal;
 };
 
 struct JointConstraint {
-    enum class Type {
-        Fixed,
-        Hinge
-    };
+    enum class Type { Fixed, Hinge };
 
     struct Fixed {
-        math::Quat attachRot1;
-        math::Quat attachRot2;
+        math::Quat attachRot1, attachRot2;
         float separation;
     };
 
     struct Hinge {
-        math::Vector3 a1Local;
-        math::Vector3 a2Local;
-        math::Vector3 b1Local;
-        math::Vector3 b2Local;
+        math::Vector3 a1Local, a2Local, b1Local, b2Local;
     };
 
-    Entity e1;
-    Entity e2;
+    Entity e1, e2;
     Type type;
-
     union {
         Fixed fixed;
         Hinge hinge;
     };
-
-    math::Vector3 r1;
-    math::Vector3 r2;
+    math::Vector3 r1, r2;
 };
 
-struct CollisionEvent {
-    Entity a;
-    Entity b;
-};
-
+struct CollisionEvent { Entity a, b; };
 struct CollisionEventTemporary : Archetype<CollisionEvent> {};
 
-// Per object state
+// ---- collision assets: one entry per object id -------------------------------
 struct RigidBodyMassData {
     float invMass;
-    math::Vector3 invInertiaTensor;
-    math::Vector3 toCenterOfMass;
+    math::Vector3 invInertiaTensor, toCenterOfMass;
     math::Quat toInteriaFrame;
 };
 
-struct RigidBodyFrictionData {
-    float muS;
-    float muD;
-};
+struct RigidBodyFrictionData { float muS, muD; };
 
 struct RigidBodyMetadata {
     RigidBodyMassData mass;
@@ -131,20 +99,11 @@ struct RigidBodyMetadata {
 };
 
 struct CollisionPrimitive {
-    enum class Type : uint32_t {
-        Sphere = 1 << 0,
-        Hull = 1 << 1,
-        Plane = 1 << 2,
-    };
+    // values are OR-ed into the narrowphase test id
+    enum class Type : uint32_t { Sphere = 1 << 0, Hull = 1 << 1, Plane = 1 << 2 };
 
-    struct Sphere {
-        float radius;
-    };
-
-    struct Hull {
-        geo::HalfEdgeMesh halfEdgeMesh;
-    };
-
+    struct Sphere { float radius; };
+    struct Hull { geo::HalfEdgeMesh halfEdgeMesh; };
     struct Plane {};
 
     Type type;
@@ -155,19 +114,17 @@ struct CollisionPrimitive {
     };
 };
 
+// arrays indexed by primitive (first two) and by object id (the rest); filled by
+// PhysicsLoader, device resident
 struct ObjectManager {
     CollisionPrimitive *collisionPrimitives;
     math::AABB *primitiveAABBs;
-
     math::AABB *rigidBodyAABBs;
-    uint32_t *rigidBodyPrimitiveOffsets;
-    uint32_t *rigidBodyPrimitiveCounts;
+    uint32_t *rigidBodyPrimitiveOffsets, *rigidBodyPrimitiveCounts;
     RigidBodyMetadata *metadata;
 };
 
-struct ObjectData {
-    ObjectManager *mgr;
-};
+struct ObjectData { ObjectManager *mgr; };
 
 namespace PhysicsSystem {
 
@@ -176,68 +133,47 @@ enum class Solver : uint32_t {
     TGS,    // not available in this backend yet
 };
 
-MADRONA_HD inline void init(Context &ctx,
-                            ObjectManager *obj_mgr,
-                            float delta_t,
-                            CountT num_substeps,
-                            math::Vector3 gravity,
+// ---- world constructor / reset ---------------------------------------------------
+MADRONA_HD inline void init(Context &ctx, ObjectManager *obj_mgr, float delta_t,
+                            CountT num_substeps, math::Vector3 gravity,
                             CountT max_dynamic_objects,
                             Solver solver = Solver::XPBD);
-
 MADRONA_HD inline void reset(Context &ctx);
+MADRONA_HD inline broadphase::LeafID registerEntity(
+    Context &ctx, Entity e, base::ObjectID obj_id);
 
-MADRONA_HD inline broadphase::LeafID registerEntity(Context &ctx,
-                                                    Entity e,
-                                                    base::ObjectID obj_id);
-
+// ---- queries against the world's BVH ---------------------------------------------
 template <typename Fn>
-MADRONA_HD inline void findEntitiesWithinAABB(Context &ctx,
-                                              math::AABB aabb,
+MADRONA_HD inline void findEntitiesWithinAABB(Context &ctx, math::AABB aabb,
                                               Fn &&fn);
-
-MADRONA_HD inline bool checkEntityAABBOverlap(Context &ctx,
-                                              math::AABB aabb,
+MADRONA_HD inline bool checkEntityAABBOverlap(Context &ctx, math::AABB aabb,
                                               Entity e);
 
-MADRONA_HD inline Entity makeFixedJoint(Context &ctx,
-                                        Entity e1, Entity e2,
-                                        math::Quat attach_rot1,
-                                        math::Quat attach_rot2,
-                                        math::Vector3 r1, math::Vector3 r2,
-                                        float separation);
+// ---- joints (entities of the solver's joint archetype) ---------------------------
+MADRONA_HD inline Entity makeFixedJoint(
+    Context &ctx, Entity e1, Entity e2,
+    math::Quat attach_rot1, math::Quat attach_rot2,
+    math::Vector3 r1, math::Vector3 r2, float separation);
+MADRONA_HD inline Entity makeHingeJoint(
+    Context &ctx, Entity e1, Entity e2,
+    math::Vector3 a1_local, math::Vector3 a2_local,
+    math::Vector3 b1_local, math::Vector3 b2_local,
+    math::Vector3 r1, math::Vector3 r2);
 
-MADRONA_HD inline Entity makeHingeJoint(Context &ctx,
-                                        Entity e1, Entity e2,
-                                        math::Vector3 a1_local,
-                                        math::Vector3 a2_local,
-                                        math::Vector3 b1_local,
-                                        math::Vector3 b2_local,
-                                        math::Vector3 r1, math::Vector3 r2);
-
+// ---- registration and task graph (host) ------------------------------------------
 MADRONA_HOST_API inline void registerTypes(ECSRegistry &registry,
                                            Solver solver = Solver::XPBD);
-
 MADRONA_HOST_API inline TaskGraphNodeID setupBroadphaseTasks(
-    TaskGraphBuilder &builder,
-    Span<const TaskGraphNodeID> deps);
-
+    TaskGraphBuilder &builder, Span<const TaskGraphNodeID> deps);
 MADRONA_HOST_API inline TaskGraphNodeID setupPhysicsStepTasks(
-    TaskGraphBuilder &builder,
-    Span<const TaskGraphNodeID> deps,
-    CountT num_substeps,
-    Solver solver = Solver::XPBD);
-
+    TaskGraphBuilder &builder, Span<const TaskGraphNodeID> deps,
+    CountT num_substeps, Solver solver = Solver::XPBD);
 MADRONA_HOST_API inline TaskGraphNodeID setupCleanupTasks(
-    TaskGraphBuilder &builder,
-    Span<const TaskGraphNodeID> deps);
-
+    TaskGraphBuilder &builder, Span<const TaskGraphNodeID> deps);
 MADRONA_HOST_API inline TaskGraphNodeID setupStandaloneBroadphaseOverlapTasks(
-    TaskGraphBuilder &builder,
-    Span<const TaskGraphNodeID> deps);
-
+    TaskGraphBuilder &builder, Span<const TaskGraphNodeID> deps);
 MADRONA_HOST_API inline TaskGraphNodeID setupStandaloneBroadphaseCleanupTasks(
-    TaskGraphBuilder &builder,
-    Span<const TaskGraphNodeID> deps);
+    TaskGraphBuilder &builder, Span<const TaskGraphNodeID> deps);
 
 }
 
