@@ -1313,7 +1313,7 @@ MADRONA_HOST_API inline TaskGraphNodeID setupCandidateTasks(
         scan.lengths[i] = numRowsAddr(exec, ps.bodyArchetypes[i]);
     }
     scan.total_out = numRowsAddr(exec, ps.candidateArchetype);
-    scan.needs_sort_out = nullptr;
+    scan.needs_sort_out = needsSortAddr(exec, ps.candidateArchetype);
 
     auto scan_data = builder.constructNodeData<mwhip_scan_params>(scan);
     mwhip_node_desc scan_desc {};
