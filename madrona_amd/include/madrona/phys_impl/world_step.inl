@@ -340,7 +340,12 @@ __device__ inline bool collidePairLane(const PairSetup &pair, float *row,
         return hullPlaneContact(a, pair.b, pair.aLoc, pair.bLoc,
                                 row, row + lanePolyVerts * 3, out);
     }
-    case NarrowphaseTest::SphereHull:   // needs GJK, not built yet
+    case NarrowphaseTest::SphereHull: {
+        // hull in the sphere's frame, evaluated lazily (no centroid needed)
+        LazyHull b(pair.bPrim->hull.halfEdgeMesh, pair.b.pos - pair.a.pos,
+                   pair.b.rot, pair.b.scale, false);
+        return sphereHullContact(pair, b, out);
+    }
     case NarrowphaseTest::PlanePlane:
     default:
         *unsupported = true;

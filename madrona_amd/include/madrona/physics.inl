@@ -1,6 +1,7 @@
 #pragma once
 
 #include <madrona/phys_impl/narrowphase.hpp>
+#include <madrona/phys_impl/gjk.hpp>
 #include <madrona/phys_impl/xpbd.hpp>
 
 namespace madrona::phys {
@@ -587,6 +588,63 @@ MADRONA_HD inline bool spherePlaneContact(const PairSetup &pair,
     return true;
 }
 
+// Sphere (a) against hull (b).  `b_hull` is the hull in the frame centred on
+// the sphere (translation b.pos - a.pos), so the sphere sits at the origin
+// (reference narrowphaseDispatch, SphereHull case, narrowphase.cpp:1325-1409).
+template <typename HullT>
+MADRONA_HD inline bool sphereHullContact(const PairSetup &pair,
+                                         const HullT &b_hull,
+                                         ContactConstraint *out)
+{
+    float sphere_radius = pair.a.scale.d0 * pair.aPrim->sphere.radius;
+
+    Vector3 to_hull_closest_pt;
+    float hull_dist2 = gjk::hullClosestPointToOrigin(
+        b_hull, 1e-10f, &to_hull_closest_pt);
+
+    if (hull_dist2 > sphere_radius * sphere_radius) {
+        return false;
+    }
+
+    SphereContact contact;
+    if (hull_dist2 == 0.f) {
+        // centre inside the hull: least-penetration face
+        float max_sep = -FLT_MAX;
+        Vector3 sep_normal = Vector3::zero();
+        const CountT num_faces = b_hull.numFaces();
+        for (CountT i = 0; i < num_faces; i++) {
+            Plane plane = b_hull.plane(i);
+            float face_dist = -plane.d;
+
+            if (face_dist > max_sep) {
+                max_sep = face_dist;
+                sep_normal = plane.normal;
+            }
+        }
+
+        // GJK said inside, SAT says (barely) outside
+        if (max_sep > 0.f) {
+            return false;
+        }
+
+        contact.normal = sep_normal;
+        contact.pt = pair.a.pos + sep_normal * sphere_radius;
+        contact.depth = -max_sep;
+    } else {
+        float to_hull_len = sqrtf(hull_dist2);
+
+        float depth = sphere_radius - to_hull_len;
+        Vector3 normal = to_hull_closest_pt / to_hull_len;
+
+        contact.normal = -normal;
+        contact.pt = pair.a.pos + normal * sphere_radius;
+        contact.depth = depth;
+    }
+
+    sphereToContact(contact, pair.aLoc, pair.bLoc, out);
+    return true;
+}
+
 // One primitive pair on one lane with the hulls transformed into caller
 // scratch (the reference's CPU flavour: runNarrowphase, narrowphase.cpp:
 // 1682-1907).  tmp_vertices / tmp_faces: max_tmp_elems entries each; the face
@@ -646,7 +704,20 @@ MADRONA_HD inline bool collidePairStored(const PairSetup &pair,
         return hullPlaneContact(a_hull, pair.b, pair.aLoc, pair.bLoc,
                                 clip_a, clip_b, out);
     }
-    case NarrowphaseTest::SphereHull:   // needs GJK: SURVEY.md §8f, not built yet
+    case NarrowphaseTest::SphereHull: {
+        const HalfEdgeMesh &b_he_mesh = pair.bPrim->hull.halfEdgeMesh;
+
+        if ((CountT)b_he_mesh.numFaces > max_tmp_elems ||
+            (CountT)b_he_mesh.numVertices > max_tmp_elems) {
+            *unsupported = true;
+            return false;
+        }
+
+        HullState b_hull = makeHullState(b_he_mesh, pair.b.pos - pair.a.pos,
+            pair.b.rot, pair.b.scale, tmp_vertices, tmp_faces);
+
+        return sphereHullContact(pair, b_hull, out);
+    }
     case NarrowphaseTest::PlanePlane:   // planes are static, never paired
     default:
         *unsupported = true;

@@ -133,13 +133,16 @@ API void ref_collide_pair(const float *verts, uint32_t num_verts,
     mesh.numVertices = num_verts;
     mesh.numFaces = num_faces;
 
-    SourceCollisionPrimitive src_prims[2];
+    SourceCollisionPrimitive src_prims[3];
     src_prims[0].type = CollisionPrimitive::Type::Hull;
     src_prims[0].hullInput.hullIDX = 0;
     src_prims[1].type = CollisionPrimitive::Type::Plane;
-    SourceCollisionObject objs[2] = {
+    src_prims[2].type = CollisionPrimitive::Type::Sphere;
+    src_prims[2].sphere.radius = 0.7f;
+    SourceCollisionObject objs[3] = {
         { Span<const SourceCollisionPrimitive>(&src_prims[0], 1), 1.f, { 0.5f, 0.5f } },
         { Span<const SourceCollisionPrimitive>(&src_prims[1], 1), 0.f, { 0.5f, 0.5f } },
+        { Span<const SourceCollisionPrimitive>(&src_prims[2], 1), 1.f, { 0.5f, 0.5f } },
     };
 
     StackAlloc tmp_alloc;
@@ -147,11 +150,12 @@ API void ref_collide_pair(const float *verts, uint32_t num_verts,
     CountT num_bytes;
     void *buf = RigidBodyAssets::processRigidBodyAssets(
         Span<const imp::SourceMesh>(&mesh, 1),
-        Span<const SourceCollisionObject>(objs, 2),
+        Span<const SourceCollisionObject>(objs, 3),
         false, tmp_alloc, &assets, &num_bytes);
 
-    const CollisionPrimitive *a_prim = &assets.primitives[0];
-    const CollisionPrimitive *b_prim = &assets.primitives[b_is_plane ? 1 : 0];
+    // b_is_plane: 0 hull-hull, 1 hull-plane, 2 sphere (a) - hull (b)
+    const CollisionPrimitive *a_prim = &assets.primitives[b_is_plane == 2 ? 2 : 0];
+    const CollisionPrimitive *b_prim = &assets.primitives[b_is_plane == 1 ? 1 : 0];
 
     Vector3 a_pos { a_txfm[0], a_txfm[1], a_txfm[2] };
     Quat a_rot { a_txfm[3], a_txfm[4], a_txfm[5], a_txfm[6] };
@@ -164,8 +168,9 @@ API void ref_collide_pair(const float *verts, uint32_t num_verts,
     static thread_local Plane tmp_faces[max_tmp];
     static thread_local Vector3 tmp_vertices[max_tmp];
 
-    NarrowphaseTest test = b_is_plane ? NarrowphaseTest::HullPlane :
-                                        NarrowphaseTest::HullHull;
+    NarrowphaseTest test = b_is_plane == 1 ? NarrowphaseTest::HullPlane :
+        b_is_plane == 2 ? NarrowphaseTest::SphereHull :
+                          NarrowphaseTest::HullHull;
     NarrowphaseResult result = narrowphaseDispatch(
         test, a_pos, b_pos, a_rot, b_rot, a_scale, b_scale, a_prim, b_prim,
         max_tmp, max_tmp, tmp_vertices, tmp_faces);
@@ -177,6 +182,13 @@ API void ref_collide_pair(const float *verts, uint32_t num_verts,
     bool has = false;
     float ref_is_a = 0.f;
     switch (result.type) {
+    case ContactType::Sphere: {
+        has = true;
+        manifold.numContactPoints = 1;
+        manifold.normal = result.sphere.normal;
+        manifold.contactPoints[0] = result.sphere.pt;
+        manifold.penetrationDepths[0] = result.sphere.depth;
+    } break;
     case ContactType::SATPlane: {
         Plane plane { result.sat.normal, result.sat.planeDOrSeparation };
         manifold = createFacePlaneContact(plane,

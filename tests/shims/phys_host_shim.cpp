@@ -119,13 +119,16 @@ API void amd_collide_pair(const float *verts, uint32_t num_verts,
     mesh.numVertices = num_verts;
     mesh.numFaces = num_faces;
 
-    SourceCollisionPrimitive src_prims[2];
+    SourceCollisionPrimitive src_prims[3];
     src_prims[0].type = CollisionPrimitive::Type::Hull;
     src_prims[0].hullInput.hullIDX = 0;
     src_prims[1].type = CollisionPrimitive::Type::Plane;
-    SourceCollisionObject objs[2] = {
+    src_prims[2].type = CollisionPrimitive::Type::Sphere;
+    src_prims[2].sphere.radius = 0.7f;
+    SourceCollisionObject objs[3] = {
         { Span<const SourceCollisionPrimitive>(&src_prims[0], 1), 1.f, { 0.5f, 0.5f } },
         { Span<const SourceCollisionPrimitive>(&src_prims[1], 1), 0.f, { 0.5f, 0.5f } },
+        { Span<const SourceCollisionPrimitive>(&src_prims[2], 1), 1.f, { 0.5f, 0.5f } },
     };
 
     StackAlloc tmp_alloc;
@@ -133,14 +136,15 @@ API void amd_collide_pair(const float *verts, uint32_t num_verts,
     CountT num_bytes;
     void *buf = RigidBodyAssets::processRigidBodyAssets(
         Span<const imp::SourceMesh>(&mesh, 1),
-        Span<const SourceCollisionObject>(objs, 2),
+        Span<const SourceCollisionObject>(objs, 3),
         false, tmp_alloc, &assets, &num_bytes);
 
+    // b_is_plane: 0 hull-hull, 1 hull-plane, 2 sphere (a) - hull (b)
     PairSetup pair {};
     pair.aLoc = Loc { 1, 0 };
     pair.bLoc = Loc { 2, 0 };
-    pair.aPrim = &assets.primitives[0];
-    pair.bPrim = &assets.primitives[b_is_plane ? 1 : 0];
+    pair.aPrim = &assets.primitives[b_is_plane == 2 ? 2 : 0];
+    pair.bPrim = &assets.primitives[b_is_plane == 1 ? 1 : 0];
     pair.a = PrimitiveTransform {
         { a_txfm[0], a_txfm[1], a_txfm[2] },
         { a_txfm[3], a_txfm[4], a_txfm[5], a_txfm[6] },
@@ -149,8 +153,9 @@ API void amd_collide_pair(const float *verts, uint32_t num_verts,
         { b_txfm[0], b_txfm[1], b_txfm[2] },
         { b_txfm[3], b_txfm[4], b_txfm[5], b_txfm[6] },
         { b_txfm[7], b_txfm[8], b_txfm[9] } };
-    pair.test = b_is_plane ? NarrowphaseTest::HullPlane :
-                             NarrowphaseTest::HullHull;
+    pair.test = b_is_plane == 1 ? NarrowphaseTest::HullPlane :
+        b_is_plane == 2 ? NarrowphaseTest::SphereHull :
+                          NarrowphaseTest::HullHull;
     pair.aabbOverlap = true;
 
     constexpr int32_t max_tmp = 128;
@@ -163,7 +168,11 @@ API void amd_collide_pair(const float *verts, uint32_t num_verts,
     if (mode == 0) {
         has = collidePairStored(pair, tmp_vertices, tmp_faces, max_tmp,
                                 &contact, &unsupported);
-    } else if (b_is_plane) {
+    } else if (b_is_plane == 2) {
+        LazyHull b(pair.bPrim->hull.halfEdgeMesh, pair.b.pos - pair.a.pos,
+                   pair.b.rot, pair.b.scale, false);
+        has = sphereHullContact(pair, b, &contact);
+    } else if (b_is_plane == 1) {
         LazyHull a(pair.aPrim->hull.halfEdgeMesh, pair.a.pos, pair.a.rot,
                    pair.a.scale, false);
         has = hullPlaneContact(a, pair.b, pair.aLoc, pair.bLoc, tmp_faces,
@@ -182,7 +191,8 @@ API void amd_collide_pair(const float *verts, uint32_t num_verts,
     if (has) {
         out[0] = 1.f;
         // hull-plane: the plane (b) is the reference; report as the ref shim does
-        out[1] = b_is_plane ? 0.f : (contact.ref.archetype == 1 ? 1.f : 0.f);
+        out[1] = b_is_plane != 0 ? 0.f :
+            (contact.ref.archetype == 1 ? 1.f : 0.f);
         out[2] = (float)contact.numPoints;
         out[3] = contact.normal.x; out[4] = contact.normal.y;
         out[5] = contact.normal.z;

@@ -99,7 +99,7 @@ def _random_quat(rng, tilt):
 
 
 @pytest.mark.parametrize("mesh,plane", [("cube", 0), ("cube", 1), ("wedge", 0),
-                                        ("wedge", 1)])
+                                        ("wedge", 1), ("cube", 2), ("wedge", 2)])
 def test_narrowphase_matches_reference(libs, mesh, plane):
     amd, ref = libs
     verts, idx, counts = MESHES[mesh]
@@ -112,7 +112,15 @@ def test_narrowphase_matches_reference(libs, mesh, plane):
         a = np.concatenate([rng.uniform(-1, 1, 3) * [1.5, 1.5, 0.3] + [0, 0, 0.7],
                             _random_quat(rng, tilt),
                             rng.uniform(0.6, 1.8, 3)]).astype(np.float32)
-        if plane:
+        if plane == 2:
+            # a = sphere (uniform scale), b = hull; near, touching, inside, far
+            r = rng.uniform(0.5, 1.5)
+            a = np.concatenate([rng.uniform(-1, 1, 3) * [2.2, 2.2, 2.2],
+                                [1, 0, 0, 0], [r, r, r]]).astype(np.float32)
+            b = np.concatenate([rng.uniform(-1, 1, 3) * 0.3,
+                                _random_quat(rng, np.pi),
+                                rng.uniform(0.6, 2.5, 3)]).astype(np.float32)
+        elif plane:
             b = np.array([0, 0, rng.uniform(-0.1, 0.3), 1, 0, 0, 0, 1, 1, 1], np.float32)
         else:
             b = np.concatenate([rng.uniform(-1, 1, 3) * [1.5, 1.5, 0.6],
@@ -137,6 +145,8 @@ def test_narrowphase_matches_reference(libs, mesh, plane):
 
         if expect[0] == 0:
             kinds["none"] += 1
+        elif plane == 2:
+            kinds["sphere"] = kinds.get("sphere", 0) + 1
         elif plane:
             kinds["plane"] += 1
         elif expect[2] == 1:
@@ -145,7 +155,9 @@ def test_narrowphase_matches_reference(libs, mesh, plane):
             kinds["face_a" if expect[1] else "face_b"] += 1
 
     # the sweep must actually exercise the feature types
-    if plane:
+    if plane == 2:
+        assert kinds["sphere"] > 200 and kinds["none"] > 200, kinds
+    elif plane:
         assert kinds["plane"] > 150 and kinds["none"] > 50, kinds
     else:
         assert kinds["face_a"] > 50 and kinds["face_b"] > 50, kinds
