@@ -240,7 +240,15 @@ __device__ inline bool hullHullWaveSAT(uint32_t lane, const PairSetup &pair,
 
 // Hull-hull pair handled by the whole wave (`pair` is wave-uniform).  Returns
 // false with *too_big set when the clipped polygon may not fit the LDS scratch.
-__device__ inline bool hullHullWave(uint32_t lane, const PairSetup &pair,
+// (A template so that only the device pass instantiates it; optionally kept out
+// of line to confine its register footprint: MADRONA_PHYS_OUTLINE_HULLHULL.)
+template <int = 0>
+#ifdef MADRONA_PHYS_OUTLINE_HULLHULL
+__device__ __attribute__((noinline)) bool
+#else
+__device__ inline bool
+#endif
+hullHullWave(uint32_t lane, const PairSetup &pair,
                                     WaveScratch *scratch,
                                     ContactConstraint *out, bool *too_big)
 {

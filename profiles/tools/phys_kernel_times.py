@@ -1,7 +1,8 @@
-"""Scratch: per-kernel times of escape_room_phys at 8192 worlds."""
+"""Per-kernel times (dispatch-attached events) of escape_room_phys at N worlds:
+    python profiles/tools/phys_kernel_times.py [worlds]"""
 import sys, os, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from madrona_amd.simlib import Simulator, hip_lib_path
 from collections import defaultdict
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 8192

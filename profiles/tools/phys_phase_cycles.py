@@ -1,7 +1,13 @@
+"""Per-phase cycle counters of the fused physics step (needs a profile build:
+
+    make -C madrona_amd OUT=_build_prof EXTRA=-DMADRONA_PHYS_PROFILE=1 runtime \\
+         _build_prof/libescape_room_phys_hip.so
+
+the kernel then adds s_memtime deltas per phase to ecs_state::moduleData[1])."""
 import sys, os, ctypes as C
 os.environ['MADRONA_HIP_BUILD_DIR'] = '_build_prof'
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from madrona_amd.simlib import Simulator, hip_lib_path, runtime_lib
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 with Simulator(hip_lib_path('escape_room_phys'), W, seed=5, flags=200) as hip:
