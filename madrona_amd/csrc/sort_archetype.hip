@@ -394,13 +394,47 @@ __device__ inline void gatherWords(const WordT *__restrict__ src,
     const long long stride = (long long)gridDim.x * kSortThreads;
     long long j = (long long)blockIdx.x * kSortThreads + threadIdx.x;
 
+    // Four independent (index -> word) chains in flight per thread: at
+    // Escape-Room sizes a thread only has a handful of words, and without the
+    // explicit batching each one costs two dependent round trips in sequence.
+    constexpr int kBatch = 4;
+
     if (words_per_row == 1) {
+        for (; j + (kBatch - 1) * stride < total; j += kBatch * stride) {
+            int32_t p[kBatch];
+            WordT w[kBatch];
+#pragma unroll
+            for (int u = 0; u < kBatch; u++) p[u] = perm[j + u * stride];
+#pragma unroll
+            for (int u = 0; u < kBatch; u++) w[u] = src[p[u]];
+#pragma unroll
+            for (int u = 0; u < kBatch; u++) dst[j + u * stride] = w[u];
+        }
         for (; j < total; j += stride) {
             dst[j] = src[perm[j]];
         }
     } else {
+        // row = j / words_per_row via a 64-bit reciprocal (exact for j < 2^32)
+        for (; j + (kBatch - 1) * stride < total; j += kBatch * stride) {
+            uint32_t off[kBatch];
+            int32_t p[kBatch];
+            WordT w[kBatch];
+#pragma unroll
+            for (int u = 0; u < kBatch; u++) {
+                long long ju = j + u * stride;
+                uint32_t row =
+                    (uint32_t)__umul64hi((unsigned long long)ju, inv_magic);
+                off[u] = (uint32_t)(ju - (long long)row * words_per_row);
+                p[u] = perm[row];
+            }
+#pragma unroll
+            for (int u = 0; u < kBatch; u++) {
+                w[u] = src[(long long)p[u] * words_per_row + off[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < kBatch; u++) dst[j + u * stride] = w[u];
+        }
         for (; j < total; j += stride) {
-            // row = j / words_per_row via a 64-bit reciprocal (exact for j < 2^32)
             uint32_t row = (uint32_t)__umul64hi((unsigned long long)j, inv_magic);
             uint32_t off = (uint32_t)(j - (long long)row * words_per_row);
             dst[j] = src[(long long)perm[row] * words_per_row + off];
@@ -640,7 +674,15 @@ void buildSortLaunches(const SortBatch &batch, std::vector<KernelLaunch> &out)
     {
         KernelLaunch k;
         k.fn = (const void *)&sortGather;
-        k.grid = dim3(stream_blocks, (uint32_t)batch.numGatherColumns, 1);
+        // Small tables: about 4096 workgroups over all columns (two resident
+        // rounds on 256 CUs) with 4 words in flight per thread beat one
+        // workgroup per 1024 rows (measured at 4096 worlds: 13.8 -> 10.5 us);
+        // large tables keep the row-proportional grid.
+        const uint32_t gather_blocks = std::min<uint32_t>(stream_blocks,
+            std::max<uint32_t>(
+                4096u / std::max<uint32_t>(batch.numGatherColumns, 1u),
+                (max_capacity + kSortThreads * 8 - 1) / (kSortThreads * 8)));
+        k.grid = dim3(gather_blocks, (uint32_t)batch.numGatherColumns, 1);
         k.block = dim3(kSortThreads, 1, 1);
         k.setArgs(batch.stateDev, batch.sitesDev, batch.gatherColumnsDev);
         k.role = "sort.gather";
