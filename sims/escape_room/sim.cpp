@@ -119,11 +119,9 @@ static inline void setupRigidBody(Engine &ctx, Entity e, Vector3 pos, Quat rot,
     ctx.get<EntityType>(e) = type;
 }
 
-static void generateLevel(Engine &ctx)
+static void generateLevel(Engine &ctx, RNG &rng)
 {
-    Sim &sim = ctx.data();
     LevelState &level = ctx.singleton<LevelState>();
-    RNG &rng = sim.rng;
 
     const float half_width = consts::worldWidth / 2.f;
 
@@ -190,10 +188,9 @@ static void generateLevel(Engine &ctx)
     }
 }
 
-static void resetAgents(Engine &ctx)
+static void resetAgents(Engine &ctx, RNG &rng)
 {
     Sim &sim = ctx.data();
-    RNG &rng = sim.rng;
     const float half_width = consts::worldWidth / 2.f;
 
     for (int32_t i = 0; i < consts::numAgents; i++) {
@@ -264,10 +261,14 @@ static void initWorld(Engine &ctx)
     Sim &sim = ctx.data();
 
     // a fresh RNG stream per (world, episode)
-    sim.rng = RNG(rand::split_i(sim.initRandKey, sim.curWorldEpisode++));
+    // the stream lives in registers while the level is generated (the world
+    // object is in memory that every component store might alias)
+    RNG rng(rand::split_i(sim.initRandKey, sim.curWorldEpisode++));
 
-    resetAgents(ctx);
-    generateLevel(ctx);
+    resetAgents(ctx, rng);
+    generateLevel(ctx, rng);
+
+    sim.rng = rng;
 }
 
 static void cleanupWorld(Engine &ctx)

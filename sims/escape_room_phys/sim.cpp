@@ -128,11 +128,9 @@ static Entity makeWall(Engine &ctx, float x_min, float x_max, float y)
     return wall;
 }
 
-static void generateLevel(Engine &ctx)
+static void generateLevel(Engine &ctx, RNG &rng)
 {
-    Sim &sim = ctx.data();
     LevelState &level = ctx.singleton<LevelState>();
-    RNG &rng = sim.rng;
 
     const float half_width = consts::worldWidth / 2.f;
 
@@ -198,10 +196,9 @@ static void generateLevel(Engine &ctx)
     }
 }
 
-static void resetPersistentEntities(Engine &ctx)
+static void resetPersistentEntities(Engine &ctx, RNG &rng)
 {
     Sim &sim = ctx.data();
-    RNG &rng = sim.rng;
     const float half_width = consts::worldWidth / 2.f;
 
     registerRigidBodyEntity(ctx, sim.floorPlane);
@@ -306,10 +303,14 @@ static void initWorld(Engine &ctx)
     PhysicsSystem::reset(ctx);
 
     // a fresh RNG stream per (world, episode)
-    sim.rng = RNG(rand::split_i(sim.initRandKey, sim.curWorldEpisode++));
+    // the stream lives in registers while the level is generated (the world
+    // object is in memory that every component store might alias)
+    RNG rng(rand::split_i(sim.initRandKey, sim.curWorldEpisode++));
 
-    resetPersistentEntities(ctx);
-    generateLevel(ctx);
+    resetPersistentEntities(ctx, rng);
+    generateLevel(ctx, rng);
+
+    sim.rng = rng;
 }
 
 static void cleanupWorld(Engine &ctx)
