@@ -225,9 +225,11 @@ MWHIP_DEV inline void withWorldCache(EcsState *S, int32_t world, Fn &&fn)
 // Pops the head of a cached free list; mirrors `assignCachedID`
 // (reference id_map_impl.inl:73-101) including the contiguous-run encoding in
 // freeNode.globalNext.
-MWHIP_DEV inline int32_t popCachedId(EcsState *S, int32_t *head, uint32_t *gen_out)
+// head_value: the current *head when the caller has already read it
+MWHIP_DEV inline int32_t popCachedId(EcsState *S, int32_t *head, uint32_t *gen_out,
+                                    int32_t head_value)
 {
-    int32_t new_id = *head;
+    int32_t new_id = head_value;
     EntitySlot &node = entitiesOf(S)[new_id];
     // the whole 12-byte slot in one round trip
     const int32_t sub_next = node.freeNode.subNext;
@@ -288,18 +290,21 @@ MWHIP_DEV inline int32_t expandIdStore(EcsState *S, int32_t world, IdCache &cach
 MWHIP_DEV inline int32_t acquireIdLocked(EcsState *S, int32_t world, IdCache &cache,
                                         uint32_t *gen_out)
 {
-    // both counters in one round trip (they share the cache struct's line)
+    // counters and list heads in one round trip (they share the cache
+    // struct's line); the popped id's slot is then the only dependent read
     const int32_t num_overflow = cache.numOverflow;
     const int32_t num_free = cache.numFree;
+    const int32_t overflow_head = cache.overflowHead;
+    const int32_t free_head = cache.freeHead;
 
     if (num_overflow > 0) {
         cache.numOverflow = num_overflow - 1;
-        return popCachedId(S, &cache.overflowHead, gen_out);
+        return popCachedId(S, &cache.overflowHead, gen_out, overflow_head);
     }
 
     if (num_free > 0) {
         cache.numFree = num_free - 1;
-        return popCachedId(S, &cache.freeHead, gen_out);
+        return popCachedId(S, &cache.freeHead, gen_out, free_head);
     }
 
     // refill from the global list of returned blocks (id_map_impl.inl:118-156)
@@ -327,7 +332,7 @@ MWHIP_DEV inline int32_t acquireIdLocked(EcsState *S, int32_t world, IdCache &ca
         entitiesOf(S)[free_ids].freeNode.globalNext = 1;
         cache.freeHead = free_ids;
         cache.numFree = kIdsPerBlock - 1;
-        return popCachedId(S, &cache.freeHead, gen_out);
+        return popCachedId(S, &cache.freeHead, gen_out, free_ids);
     }
 
     int32_t first_id = expandIdStore(S, world, cache);
