@@ -295,7 +295,7 @@ private:
     int32_t *dfs_leaves_;
     math::Vector3 *leaf_centers_;   // only set on rebased copies
     int32_t num_leaves_;
-    int32_t num_allocated_leaves_;
+    [[maybe_unused]] int32_t num_allocated_leaves_;     // device bounds check
     float leaf_velocity_expansion_;
     float leaf_accel_expansion_;
     bool force_rebuild_;

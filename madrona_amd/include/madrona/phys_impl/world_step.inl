@@ -975,7 +975,7 @@ __device__ inline PairSetup ldsSetupPair(const WorldBlock<MAXB> *w,
 #endif
 template <int MAXB>
 __global__ void __launch_bounds__(64)
-__attribute__((amdgpu_waves_per_eu(MADRONA_PHYS_LDS_WAVES_PER_EU)))
+__attribute__((amdgpu_waves_per_eu(MAXB <= 64 ? MADRONA_PHYS_LDS_WAVES_PER_EU : 1)))
 physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
 {
     using Block = WorldBlock<MAXB>;

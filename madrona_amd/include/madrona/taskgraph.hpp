@@ -201,8 +201,9 @@ public:
     inline void constructGraphs();
 
 private:
-    mwhip_exec *exec_;
-    StateManager *state_mgr_;
+    // (only read in the host bodies of the MADRONA_HOST_API members)
+    [[maybe_unused]] mwhip_exec *exec_;
+    [[maybe_unused]] StateManager *state_mgr_;
     std::vector<std::unique_ptr<TaskGraphBuilder>> builders_;
 };
 
