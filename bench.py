@@ -47,6 +47,9 @@ def parse_args():
     p.add_argument("--no-physics-line", action="store_true",
                    help="skip the extra configs[2] measurement in the default run")
     p.add_argument("--profile-reps", type=int, default=30)
+    p.add_argument("--force-collective", action="store_true",
+                   help="run the RCCL observation all-gather even with one rank "
+                        "(exercises the multi-GPU code path on a 1-GPU box)")
     return p.parse_args()
 
 
@@ -130,6 +133,13 @@ def physics_line(gpu_id, seed, denom, worlds=8192, steps=600, warmup=100):
 
 def main():
     args = parse_args()
+
+    # stdout carries exactly one JSON line: anything libraries print while the
+    # benchmark runs (RCCL prints a version banner from C) goes to stderr
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     default_worlds, workload_fmt = WORKLOADS.get(args.sim, (4096, args.sim + ", {w} worlds"))
     if args.worlds <= 0:
         args.worlds = default_worlds
@@ -143,7 +153,7 @@ def main():
     if world_size != args.gpus:
         if world_size == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
-    distributed = world_size > 1
+    distributed = world_size > 1 or args.force_collective
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP backend has no CPU fallback")
@@ -307,7 +317,12 @@ def main():
             "physics_config3": physics,
             "kernels": kernels,
         }
-        print(json.dumps(out))
+        # flush what C libraries buffered for "stdout" while it pointed at stderr
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
