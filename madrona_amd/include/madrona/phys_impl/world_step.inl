@@ -775,6 +775,7 @@ struct WorldBlock {
     xpbd::PreSolveVelocity preVel[MAXB];
     xpbd::BodyConstants constants[MAXB];    // zeroed for static bodies
     uint32_t resp[MAXB];
+    Loc bodyLoc[MAXB];                      // where the body's row is (store phase)
     int32_t entityID[MAXB];
     uint16_t primOffset[MAXB];
     uint16_t primCount[MAXB];
@@ -1038,6 +1039,7 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
 
         for (int32_t k = (int32_t)lane; k < num_bodies; k += 64) {
             Loc loc = bodies.loc(k);
+            w->bodyLoc[k] = loc;
             w->pos[k] = ctx.getDirect<base::Position>(RGDCols::Position, loc);
             w->rot[k] = ctx.getDirect<base::Rotation>(RGDCols::Rotation, loc);
             w->scale[k] = ctx.getDirect<base::Scale>(RGDCols::Scale, loc);
@@ -1178,13 +1180,15 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
         const JointConstraint *joints =
             (const JointConstraint *)joint_tbl.columns[2] + joint_begin;
 
-        // body index of a joint end point
+        // body index of a joint end point (the per-archetype row ranges are not
+        // kept alive through the substeps: look the row up among the staged
+        // bodies -- a handful of LDS reads, once per joint)
         auto jointBodyLoc = [&](Entity e) {
             Loc loc = ctx.loc(e);
-            for (uint32_t a = 0; a < bodies.numArchetypes; a++) {
-                if (bodies.archetype[a] == loc.archetype) {
-                    return Loc { 0,
-                        bodies.bodyBase[a] + (loc.row - bodies.rowBase[a]) };
+            for (int32_t k = 0; k < num_bodies; k++) {
+                Loc body = w->bodyLoc[k];
+                if (body.archetype == loc.archetype && body.row == loc.row) {
+                    return Loc { 0, k };
                 }
             }
             return Loc { 0, 0 };
@@ -1395,7 +1399,7 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
         PHYS_PROF(6);
         // ---- store: LDS -> HBM --------------------------------------------------
         for (int32_t k = (int32_t)lane; k < num_bodies; k += 64) {
-            Loc loc = bodies.loc(k);
+            Loc loc = w->bodyLoc[k];
             ctx.getDirect<base::Position>(RGDCols::Position, loc) = w->pos[k];
             ctx.getDirect<base::Rotation>(RGDCols::Rotation, loc) = w->rot[k];
             ctx.getDirect<Velocity>(RGDCols::Velocity, loc) = w->vel[k];
