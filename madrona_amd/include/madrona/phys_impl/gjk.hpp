@@ -323,7 +323,15 @@ MADRONA_HD inline float hullClosestPointToOrigin(const HullT &hull,
 MADRONA_UNROLL
         for (CountT i = 0; i < 4; i++) {
             if (solve.lambdas[i] != 0.f) {
-                Y[nY] = Y[i];
+                // Y[nY] = Y[i] with constant indices only (a dynamically
+                // indexed private array would live in scratch on the GPU)
+                const Vector3 kept = Y[i];
+MADRONA_UNROLL
+                for (CountT j = 0; j < 4; j++) {
+                    if (j == nY) {
+                        Y[j] = kept;
+                    }
+                }
                 nY += 1;
             }
         }

@@ -558,11 +558,15 @@ MADRONA_HD inline Manifold buildFaceContactManifold(Vector3 contact_normal,
         manifold.penetrationDepths[i] = 0.f;
     }
 
+    // (loops over the manifold's four slots have constant bounds throughout:
+    // a dynamically indexed private array lives in scratch memory on the GPU)
     if (num_contacts <= 4) {
         manifold.numContactPoints = (int32_t)num_contacts;
-        for (CountT i = 0; i < num_contacts; i++) {
-            manifold.contactPoints[i] = contacts[i];
-            manifold.penetrationDepths[i] = penetration_depths[i];
+        for (int i = 0; i < 4; i++) {
+            if ((CountT)i < num_contacts) {
+                manifold.contactPoints[i] = contacts[i];
+                manifold.penetrationDepths[i] = penetration_depths[i];
+            }
         }
     } else {
         manifold.numContactPoints = 4;
@@ -638,9 +642,12 @@ MADRONA_HD inline Manifold buildFaceContactManifold(Vector3 contact_normal,
         }
     }
 
-    for (CountT i = 0; i < (CountT)manifold.numContactPoints; i++) {
-        manifold.contactPoints[i] =
-            to_world_frame.rotateVec(manifold.contactPoints[i]) + world_offset;
+    for (int i = 0; i < 4; i++) {
+        if (i < manifold.numContactPoints) {
+            manifold.contactPoints[i] =
+                to_world_frame.rotateVec(manifold.contactPoints[i]) +
+                world_offset;
+        }
     }
 
     manifold.normal = to_world_frame.rotateVec(contact_normal);

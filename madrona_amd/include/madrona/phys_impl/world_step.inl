@@ -759,7 +759,9 @@ struct WorldBlock {
     // sized so that a 32-body block stays under 16 KB of LDS: four
     // single-wave workgroups per CU, as many as the register file admits
     static constexpr int maxCandidates = MAXB * 3;
-    static constexpr int maxContacts = MAXB + MAXB / 4;
+    // (at least a wave's worth: the narrowphase stages one contact per lane)
+    static constexpr int maxContacts =
+        MAXB + MAXB / 4 > 64 ? MAXB + MAXB / 4 : 64;
     static constexpr int maxJoints = 6;         // more: read from HBM
     static constexpr int maxPrims = 8;          // more: hull data stays in HBM
     static constexpr int arenaDwords = 192;     // object-space hull meshes
@@ -1237,36 +1239,56 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
             PHYS_PROF(2);
 
             // ---- narrowphase: contacts in candidate order ------------------------
+            // A lane's contact is staged in LDS at slot (num_contacts + lane)
+            // and the chunk is compacted in place afterwards: nothing as wide
+            // as a ContactConstraint stays live in registers across the
+            // cooperative hull-hull tests.  A chunk is as wide as the free
+            // slots allow.
             uint32_t num_contacts = 0;
-            for (uint32_t chunk = 0; chunk < num_candidates; chunk += 64) {
-                const uint32_t c = chunk + lane;
-                ContactConstraint contact;
+            bool contacts_overflow = false;
+            for (uint32_t chunk = 0; chunk < num_candidates; ) {
+                const uint32_t free_slots =
+                    (uint32_t)Block::maxContacts - num_contacts;
+                if (free_slots == 0) {
+                    contacts_overflow = true;
+                    break;
+                }
+                uint32_t width = num_candidates - chunk;
+                width = width < 64 ? width : 64;
+                width = width < free_slots ? width : free_slots;
+
+                ContactConstraint *stage = w->contacts() + num_contacts;
                 bool has_contact = false;
                 bool too_big = false;
                 bool unsupported = false;
 
                 uint32_t kind = 0;      // 1: this lane alone, 2: whole wave
-                PairSetup pair;
-                if (c < num_candidates) {
-                    pair = ldsSetupPair(w, obj_mgr, w->candidates[c]);
-                    if (pair.aabbOverlap) {
-                        kind = pair.test == NarrowphaseTest::HullHull ? 2 : 1;
+                {
+                    PairSetup pair;
+                    if (lane < width) {
+                        pair = ldsSetupPair(w, obj_mgr,
+                                            w->candidates[chunk + lane]);
+                        if (pair.aabbOverlap) {
+                            kind = pair.test == NarrowphaseTest::HullHull ?
+                                2 : 1;
+                        }
                     }
-                }
-                PHYS_PROF(0);
+                    PHYS_PROF(0);
 
-                // lanes on their own, in rounds of lanePolyRows scratch rows
-                uint64_t solo = __builtin_amdgcn_ballot_w64(kind == 1);
-                const uint32_t solo_rank = wave::rankInBallot(solo);
-                const uint32_t solo_count = (uint32_t)__builtin_popcountll(solo);
-                for (uint32_t first = 0; first < solo_count;
-                     first += lanePolyRows) {
-                    if (kind == 1 && solo_rank >= first &&
-                            solo_rank < first + lanePolyRows) {
-                        has_contact = collidePairLane(pair,
-                            w->scratch.lanePoly +
-                                (solo_rank - first) * lanePolyDwords,
-                            &contact, &too_big, &unsupported);
+                    // lanes on their own, in rounds of lanePolyRows scratch rows
+                    uint64_t solo = __builtin_amdgcn_ballot_w64(kind == 1);
+                    const uint32_t solo_rank = wave::rankInBallot(solo);
+                    const uint32_t solo_count =
+                        (uint32_t)__builtin_popcountll(solo);
+                    for (uint32_t first = 0; first < solo_count;
+                         first += lanePolyRows) {
+                        if (kind == 1 && solo_rank >= first &&
+                                solo_rank < first + lanePolyRows) {
+                            has_contact = collidePairLane(pair,
+                                w->scratch.lanePoly +
+                                    (solo_rank - first) * lanePolyDwords,
+                                stage + lane, &too_big, &unsupported);
+                        }
                     }
                 }
 
@@ -1278,35 +1300,44 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
 
                     PairSetup shared_pair =
                         ldsSetupPair(w, obj_mgr, w->candidates[chunk + src]);
-                    ContactConstraint shared_contact;
                     bool shared_too_big = false;
+                    // every lane writes the same contact to src's slot
                     bool found = hullHullWave(lane, shared_pair, &w->scratch,
-                        &shared_contact, &shared_too_big);
+                        stage + src, &shared_too_big);
                     if (lane == src) {
-                        contact = shared_contact;
                         has_contact = found;
                         too_big = shared_too_big;
                     }
                 }
 
                 if (too_big) {
+                    PairSetup pair = ldsSetupPair(w, obj_mgr,
+                                                  w->candidates[chunk + lane]);
                     has_contact = collidePairStored(pair, tmp_vertices,
-                        tmp_faces, max_elems, &contact, &unsupported);
+                        tmp_faces, max_elems, stage + lane, &unsupported);
                 }
                 if (unsupported) {
                     mwhip::raiseError(S, mwhip::kErrPhysics);
                 }
+                wave::phaseFence();
 
+                // compact in place: all reads, then all writes
                 uint64_t mask = __builtin_amdgcn_ballot_w64(has_contact);
-                uint32_t dst = num_contacts + wave::rankInBallot(mask);
-                if (has_contact && dst < (uint32_t)Block::maxContacts) {
-                    w->contacts()[dst] = contact;
+                const uint32_t rank = wave::rankInBallot(mask);
+                const bool moves = has_contact && rank != lane;
+                ContactConstraint moved;
+                if (moves) {
+                    moved = stage[lane];
+                }
+                wave::phaseFence();
+                if (moves) {
+                    stage[rank] = moved;
                 }
                 num_contacts += (uint32_t)__builtin_popcountll(mask);
+                chunk += width;
             }
-            if (num_contacts > (uint32_t)Block::maxContacts) {
+            if (contacts_overflow) {
                 mwhip::raiseError(S, mwhip::kErrTableOverflow);
-                num_contacts = (uint32_t)Block::maxContacts;
             }
             wave::phaseFence();
             PHYS_PROF(5);

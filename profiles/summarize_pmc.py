@@ -3,8 +3,41 @@
 (rocprofv3 --kernel-trace --pmc ... -d DIR -o NAME)."""
 import re
 import sqlite3
+import subprocess
 import sys
 from collections import defaultdict
+
+
+_demangled = {}
+
+
+def short_name(kname):
+    """Readable kernel name: demangled, anonymous-namespace noise and the
+    argument list dropped."""
+    if kname not in _demangled:
+        name = kname
+        if name.startswith("_Z"):
+            try:
+                name = subprocess.run(["c++filt", name], capture_output=True,
+                                      text=True).stdout.strip() or name
+            except OSError:
+                pass
+        if name.startswith("_Z"):
+            # c++filt of this image does not know `TnDa` (auto non-type
+            # template parameter): pull the system name out by hand
+            m = re.search(r"parallelForKernelIN\d+(\w+?)\d+EngineE.*?XadL_ZNS\d_(\d+)", name)
+            if m:
+                n = int(m.group(2))
+                name = ("parallelForKernel<" + m.group(1) + "::" +
+                        name[m.end():m.end() + n] + ">(")
+        name = name.replace("(anonymous namespace)::", "")
+        name = re.sub(r"^void ", "", name)
+        # parallelForKernel<Ctx, &fn, ...>: keep the system's name
+        m = re.match(r".*parallelForKernel<[^,]+, &?\(?([\w:]+)", name)
+        if m:
+            name = "parallelForKernel<" + m.group(1) + ">"
+        _demangled[kname] = re.sub(r"\(.*", "", name)[:90]
+    return _demangled[kname]
 
 
 def main():
@@ -22,7 +55,7 @@ def main():
     for kname, cname, value in rows:
         if pattern and not re.search(pattern, kname):
             continue
-        short = re.sub(r"\(.*", "", kname)[:70]
+        short = short_name(kname)
         acc[short][cname][0] += value
         acc[short][cname][1] += 1
     for kname, counters in acc.items():
