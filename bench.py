@@ -78,7 +78,15 @@ def cpu_baseline(sim, worlds, flags, seed, budget_s=12.0):
     }
 
 
-PHYS_BODIES_PER_WORLD = 28      # 2 agents + 23 PhysicsEntity + 3 doors
+# rigid bodies per world: 2 agents + 23 PhysicsEntity + 3 doors; 5 agents + 11
+# movable + 13 static
+PHYS_BODIES = {"escape_room_phys": 28, "hideseek": 29}
+PHYS_BODIES_PER_WORLD = PHYS_BODIES["escape_room_phys"]
+AGENTS = {"escape_room": 2, "escape_room_phys": 2, "hideseek": 5}
+SIM_OBS_TENSORS = {
+    "hideseek": ["self_obs", "agent_obs", "box_obs", "ramp_obs", "lidar",
+                 "reward", "done"],
+}
 
 WORKLOADS = {
     "escape_room": (4096, "Escape-Room-shaped ECS (physics off), {w} worlds per GPU "
@@ -86,6 +94,10 @@ WORKLOADS = {
     "escape_room_phys": (8192, "Escape-Room + XPBD rigid body + LBVH broadphase, {w} "
                                "worlds per GPU (BASELINE.json configs[2]), 28 rigid "
                                "bodies + 6 buttons/world, 4 substeps, grab joints"),
+    "hideseek": (8192, "Hide-and-Seek-shaped: XPBD + LBVH, {w} worlds per GPU "
+                       "(BASELINE.json configs[3] is 8 x 8192), 29 rigid bodies/world "
+                       "(5 agents, 9 boxes, 2 wedge ramps, 12 walls, plane), lock "
+                       "action, line-of-sight rays, 30-ray lidar, 2.9 KB obs/world"),
 }
 
 
@@ -173,7 +185,8 @@ def main():
                          gpu_id=local_rank, world_base=world_base,
                          flags=args.auto_reset_denom)
 
-    sharded = ShardedSimulator(make_sim, shard, OBS_TENSORS if distributed else [])
+    obs_tensors = SIM_OBS_TENSORS.get(args.sim, OBS_TENSORS)
+    sharded = ShardedSimulator(make_sim, shard, obs_tensors if distributed else [])
     sim = sharded.sim
 
     # synthetic policy output, resident in HBM before the timed region
@@ -181,13 +194,14 @@ def main():
     gen.manual_seed(1234 + rank)
     action = to_torch(sim, "action", local_rank)
     W = args.worlds
+    A = AGENTS.get(args.sim, 2)
     action.copy_(torch.stack([
-        torch.randint(0, 4, (W, 2), device="cuda", generator=gen),
-        torch.randint(0, 8, (W, 2), device="cuda", generator=gen),
-        torch.randint(-2, 3, (W, 2), device="cuda", generator=gen),
-        torch.randint(0, 2, (W, 2), device="cuda", generator=gen)
-        if args.sim == "escape_room_phys" else
-        torch.zeros((W, 2), device="cuda", dtype=torch.int64),
+        torch.randint(0, 4, (W, A), device="cuda", generator=gen),
+        torch.randint(0, 8, (W, A), device="cuda", generator=gen),
+        torch.randint(-2, 3, (W, A), device="cuda", generator=gen),
+        torch.randint(0, 2, (W, A), device="cuda", generator=gen)
+        if args.sim != "escape_room" else
+        torch.zeros((W, A), device="cuda", dtype=torch.int64),
     ], -1).to(torch.int32))
     torch.cuda.synchronize()
 
@@ -225,7 +239,8 @@ def main():
         # velocity, solver state) -- DESIGN.md §10
         for k in stats:
             if k["name"].startswith("physics:worldStep"):
-                k["algo_bytes"] = float(args.worlds) * PHYS_BODIES_PER_WORLD * 288.0
+                k["algo_bytes"] = (float(args.worlds) * 288.0 *
+                                   PHYS_BODIES.get(args.sim, PHYS_BODIES_PER_WORLD))
         for k in stats:
             kernels.append({
                 "name": k["name"], "avg_us": round(k["avg_us"], 2),

@@ -197,6 +197,7 @@ public:
     MADRONA_HD inline void finishRebuild(int32_t num_nodes)
     {
         num_nodes_ = num_nodes;
+        num_tree_leaves_ = num_leaves_;
         force_rebuild_ = false;
     }
 
@@ -295,6 +296,7 @@ private:
     int32_t *dfs_leaves_;
     math::Vector3 *leaf_centers_;   // only set on rebased copies
     int32_t num_leaves_;
+    int32_t num_tree_leaves_;       // leaves the current tree was built over
     [[maybe_unused]] int32_t num_allocated_leaves_;     // device bounds check
     float leaf_velocity_expansion_;
     float leaf_accel_expansion_;

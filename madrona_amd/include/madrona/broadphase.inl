@@ -22,6 +22,7 @@ BVH::BVH(const ObjectManager *obj_mgr,
       dfs_leaves_((int32_t *)rawAlloc(sizeof(int32_t) * max_leaves)),
       leaf_centers_(nullptr),
       num_leaves_(0),
+      num_tree_leaves_(0),
       num_allocated_leaves_((int32_t)max_leaves),
       leaf_velocity_expansion_(leaf_velocity_expansion),
       leaf_accel_expansion_(leaf_accel_expansion),
@@ -275,6 +276,7 @@ int32_t BVH::midpointSplit(int32_t base, int32_t num_elems)
 void BVH::rebuild()
 {
     const int32_t num_leaves = num_leaves_;
+    num_tree_leaves_ = num_leaves;
     num_nodes_ = numInternalNodes(num_leaves);
 
     struct StackEntry {

@@ -400,10 +400,24 @@ __device__ inline uint32_t constraintLevels(uint32_t lane, uint32_t n,
     return level;
 }
 
+// A static body does not order the constraints that touch it as long as the
+// solver's writes to it are no-ops.  Positions are (x += 0), but the reference
+// renormalises the rotation in every positional update (xpbd.cpp
+// applyPositionalUpdate), so that only holds while the rotation is a fixed
+// point of normalize() -- e.g. not for a tilted body that was switched to
+// Static mid-flight; such a body orders its constraints like a dynamic one.
+__device__ inline bool staticBodyIsInert(math::Quat q)
+{
+    math::Quat n = q.normalize();
+    return n.w == q.w && n.x == q.x && n.y == q.y && n.z == q.z;
+}
+
 __device__ inline uint64_t bodyKey(Context &ctx, Loc loc)
 {
     if (ctx.getDirect<ResponseType>(RGDCols::ResponseType, loc) ==
-            ResponseType::Static) {
+            ResponseType::Static &&
+        staticBodyIsInert(
+            ctx.getDirect<base::Rotation>(RGDCols::Rotation, loc))) {
         return 0;
     }
     return ((uint64_t)(loc.archetype + 1) << 32) | (uint64_t)(uint32_t)loc.row;
@@ -950,8 +964,8 @@ struct LdsBodyStore {
 template <int MAXB>
 __device__ inline uint64_t ldsBodyKey(const WorldBlock<MAXB> *w, int32_t k)
 {
-    return w->resp[k] == (uint32_t)ResponseType::Static ? 0ull :
-        (uint64_t)(k + 1);
+    return (w->resp[k] == (uint32_t)ResponseType::Static &&
+            staticBodyIsInert(w->rot[k])) ? 0ull : (uint64_t)(k + 1);
 }
 
 template <int MAXB>

@@ -1,5 +1,6 @@
 #pragma once
 
+#include <vector>
 #include <madrona/phys_impl/narrowphase.hpp>
 #include <madrona/phys_impl/gjk.hpp>
 #include <madrona/phys_impl/xpbd.hpp>
@@ -289,38 +290,73 @@ Entity BVH::traceRay(math::Vector3 o,
 
     Diag3x3 inv_d = Diag3x3::fromVec(d).inv();
 
-    NodeStack stack;
-    stack.push(0);
-
     Entity closest_hit_entity = Entity::none();
     Vector3 closest_hit_normal = Vector3::zero();
 
-    while (!stack.empty()) {
-        const Node &node = nodes_[stack.pop()];
-        for (CountT c = 0; c < 4; c++) {
-            if (!node.hasChild(c)) {
-                continue;
+    auto visitLeaf = [&](int32_t leaf_idx) {
+        float hit_t;
+        Vector3 leaf_hit_normal;
+        bool leaf_hit = traceRayIntoLeaf(
+            leaf_idx, o, d, 0.f, t_max, &hit_t, &leaf_hit_normal);
+
+        if (leaf_hit) {
+            t_max = hit_t;
+            closest_hit_entity = leaf_entities_[leaf_idx];
+            closest_hit_normal = leaf_hit_normal;
+        }
+    };
+
+    if (!force_rebuild_) {
+        // Flat traversal.  The stack walk below meets the leaves in an order
+        // fixed by the tree (culling removes visits, it never reorders them),
+        // and a leaf is met iff the ray hits its slot box: every ancestor's
+        // box contains it (refits only grow boxes) and the slab test is
+        // monotone in the box, so the ancestors' tests cannot cull a leaf
+        // whose own slot passes.  Testing the slot boxes in the order recorded
+        // by rebuild() therefore performs the same leaf tests in the same
+        // order with the same t_max, without the dependent node -> child ->
+        // node chain and without a stack; the boxes of a group of leaves are
+        // fetched together.
+        const int32_t n = num_tree_leaves_;
+        constexpr int32_t group = 4;
+        for (int32_t base = 0; base < n; base += group) {
+            int32_t leaf[group];
+            AABB box[group];
+MADRONA_UNROLL
+            for (int32_t j = 0; j < group; j++) {
+                const int32_t r = base + j < n ? base + j : n - 1;
+                leaf[j] = dfs_leaves_[r];
+                box[j] = leafSlotBounds(leaf[j]);
             }
-
-            if (!node.bounds(c).rayIntersects(o, inv_d, 0.f, t_max)) {
-                continue;
-            }
-
-            if (node.isLeaf(c)) {
-                int32_t leaf_idx = node.leafIDX(c);
-
-                float hit_t;
-                Vector3 leaf_hit_normal;
-                bool leaf_hit = traceRayIntoLeaf(
-                    leaf_idx, o, d, 0.f, t_max, &hit_t, &leaf_hit_normal);
-
-                if (leaf_hit) {
-                    t_max = hit_t;
-                    closest_hit_entity = leaf_entities_[leaf_idx];
-                    closest_hit_normal = leaf_hit_normal;
+MADRONA_UNROLL
+            for (int32_t j = 0; j < group; j++) {
+                if (base + j < n &&
+                        box[j].rayIntersects(o, inv_d, 0.f, t_max)) {
+                    visitLeaf(leaf[j]);
                 }
-            } else {
-                stack.push(node.children[c]);
+            }
+        }
+    } else {
+        // a rebuild is pending: walk whatever tree is there, like the reference
+        NodeStack stack;
+        stack.push(0);
+
+        while (!stack.empty()) {
+            const Node &node = nodes_[stack.pop()];
+            for (CountT c = 0; c < 4; c++) {
+                if (!node.hasChild(c)) {
+                    continue;
+                }
+
+                if (!node.bounds(c).rayIntersects(o, inv_d, 0.f, t_max)) {
+                    continue;
+                }
+
+                if (node.isLeaf(c)) {
+                    visitLeaf(node.leafIDX(c));
+                } else {
+                    stack.push(node.children[c]);
+                }
             }
         }
     }
@@ -1490,19 +1526,36 @@ MADRONA_HOST_API inline TaskGraphNodeID setupPhysicsStepTasks(
         PhysicsStepParams { (int32_t)num_substeps });
 
     // Worlds small enough to live in LDS take the LDS-resident kernel; the
-    // bound is the mean world at graph-build time + 1/8, rounded up
+    // bound is the largest world at graph-build time + 1/16, rounded up
     // (MADRONA_MWHIP_PHYS_MAX_BODIES overrides; > 128 selects the generic
     // kernel that works out of HBM).
     mwhip_exec *exec = builder.exec();
     int max_bodies = (int)phys::detail::capacityHint(
         "MADRONA_MWHIP_PHYS_MAX_BODIES", 0);
     if (max_bodies == 0) {
-        uint64_t total_rows = 0;
+        // rows per world of every rigid-body archetype, as initialised
+        const uint32_t num_worlds = mwhip_num_worlds(exec);
+        std::vector<int32_t> per_world(num_worlds, 0);
+        std::vector<int32_t> counts(num_worlds);
+        std::vector<int32_t> world_ids;
         for (uint32_t i = 0; i < ps.numBodyArchetypes; i++) {
-            total_rows += (uint64_t)mwhip_num_rows(exec, ps.bodyArchetypes[i]);
+            int32_t rows = mwhip_num_rows(exec, ps.bodyArchetypes[i]);
+            world_ids.resize((size_t)(rows > 0 ? rows : 1));
+            int64_t n = mwhip_dump_column(exec, ps.bodyArchetypes[i],
+                TypeTracker::typeID<WorldID>(), world_ids.data(),
+                world_ids.size() * sizeof(int32_t), counts.data());
+            if (n < 0) {
+                FATAL("physics: cannot read the body tables");
+            }
+            for (uint32_t w = 0; w < num_worlds; w++) {
+                per_world[w] += counts[w];
+            }
         }
-        uint64_t per_world = total_rows / mwhip_num_worlds(exec) + 1;
-        max_bodies = (int)(per_world + per_world / 8);
+        int32_t largest = 1;
+        for (int32_t n : per_world) {
+            largest = n > largest ? n : largest;
+        }
+        max_bodies = largest + largest / 16;
     }
     max_bodies = max_bodies <= 32 ? 32 : max_bodies <= 64 ? 64 :
                  max_bodies <= 128 ? 128 : 0;

@@ -26,17 +26,30 @@ CASES = {
     "sort_stress_w33": ("sort_stress", 33, 7, 0, [1, 3, 10, 40]),
     # rigid-body physics on: BVH + narrowphase + XPBD + joints (grab action)
     "escape_room_phys_w8": ("escape_room_phys", 8, 5, 30, [1, 5, 25, 60]),
+    # Hide-and-Seek shape: 29 bodies/world, wedge hulls, lock/unlock, ray casts
+    "hideseek_w8": ("hideseek", 8, 5, 40, [1, 5, 25, 110]),
 }
 
+AGENTS = {"escape_room": 2, "escape_room_phys": 2, "hideseek": 5}
 
-def escape_actions(step, num_worlds, grab=False):
+
+def escape_actions(step, num_worlds, grab=False, agents=2):
     rng = np.random.default_rng(1000 + step)
+    shape = (num_worlds, agents)
     return np.stack([
-        rng.integers(0, 4, (num_worlds, 2)), rng.integers(0, 8, (num_worlds, 2)),
-        rng.integers(-2, 3, (num_worlds, 2)),
-        rng.integers(0, 2, (num_worlds, 2)) if grab else
-        np.zeros((num_worlds, 2), int),
+        rng.integers(0, 4, shape), rng.integers(0, 8, shape),
+        rng.integers(-2, 3, shape),
+        rng.integers(0, 2, shape) if grab else np.zeros(shape, int),
     ], -1).astype(np.int32)
+
+
+def actions_for(sim, step, num_worlds):
+    """The action tensor fed at `step`, or None for simulators without one
+    (move amount, move angle, turn, grab / lock)."""
+    if sim not in AGENTS:
+        return None
+    return escape_actions(step, num_worlds, grab=sim != "escape_room",
+                          agents=AGENTS[sim])
 
 
 def main():
@@ -48,9 +61,9 @@ def main():
         with Simulator(ref_lib_path(sim), worlds, seed=seed, num_workers=1,
                        flags=flags) as s:
             for step in range(1, max(checkpoints) + 1):
-                if sim.startswith("escape_room"):
-                    s.write_tensor("action", escape_actions(
-                        step, worlds, grab=sim == "escape_room_phys"))
+                actions = actions_for(sim, step, worlds)
+                if actions is not None:
+                    s.write_tensor("action", actions)
                 s.step(1)
                 if step in checkpoints:
                     for col, (rows, counts) in s.dump_all().items():

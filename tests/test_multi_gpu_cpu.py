@@ -25,19 +25,30 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world_size, port, total_worlds, steps, out_dir):
+CASES = {
+    # sim: (gathered tensors, total worlds, steps)
+    "cartpole": (["state", "reward", "done"], 64, 50),
+    # BASELINE config 4's shape: the observation columns of the Hide-and-Seek
+    # worlds (2.9 KB per world) packed into one all-gather per step
+    "hideseek": (["self_obs", "agent_obs", "box_obs", "ramp_obs", "lidar",
+                  "reward", "done"], 8, 12),
+}
+
+
+def _worker(rank, world_size, port, sim_name, out_dir):
     sys.path.insert(0, REPO)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world_size)
     try:
+        names, total_worlds, steps = CASES[sim_name]
         shard = shard_for(rank, world_size, total_worlds=total_worlds)
 
         def make_sim(num_worlds, world_base):
-            return Simulator(ref_lib_path("cartpole"), num_worlds, seed=5,
+            return Simulator(ref_lib_path(sim_name), num_worlds, seed=5,
                              num_workers=1, world_base=world_base)
 
-        sharded = ShardedSimulator(make_sim, shard, ["state", "reward", "done"])
+        sharded = ShardedSimulator(make_sim, shard, names)
         gathered = None
         for _ in range(steps):
             gathered = sharded.step(1)
@@ -58,18 +69,19 @@ def test_shard_arithmetic():
         shard_for(0, 3, total_worlds=64)
 
 
-def test_two_rank_allgather_is_partition_invariant(built, tmp_path):
-    if not os.path.exists(ref_lib_path("cartpole")):
+@pytest.mark.parametrize("sim_name", sorted(CASES))
+def test_two_rank_allgather_is_partition_invariant(built, tmp_path, sim_name):
+    if not os.path.exists(ref_lib_path(sim_name)):
         pytest.skip("oracle/_ref not built here (no /root/reference)")
-    total_worlds, steps = 64, 50
+    names, total_worlds, steps = CASES[sim_name]
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, total_worlds, steps, str(tmp_path)), nprocs=2,
+    mp.spawn(_worker, args=(2, port, sim_name, str(tmp_path)), nprocs=2,
              join=True)
     got = np.load(os.path.join(str(tmp_path), "gathered.npz"))
 
     # one process owning all worlds must produce the same tensors bit for bit
-    with Simulator(ref_lib_path("cartpole"), total_worlds, seed=5, num_workers=1) as s:
+    with Simulator(ref_lib_path(sim_name), total_worlds, seed=5, num_workers=1) as s:
         s.step(steps)
-        for name in ["state", "reward", "done"]:
+        for name in names:
             assert np.array_equal(got[name].view(np.uint8),
                                   s.read_tensor(name).view(np.uint8)), name

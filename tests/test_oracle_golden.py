@@ -198,15 +198,15 @@ def test_sort_restatement_is_stable_argsort(restate, n, worlds):
 
 # ---- reference simulators vs committed golden fixtures -------------------------
 def _replay_against_golden(path, lib_path):
-    from golden.make_golden import CASES, escape_actions
+    from golden.make_golden import CASES, actions_for
     name = os.path.basename(path)[:-4]
     sim, worlds, seed, flags, checkpoints = CASES[name]
     gold = np.load(path)
     with Simulator(lib_path, worlds, seed=seed, num_workers=1, flags=flags) as s:
         for step in range(1, max(checkpoints) + 1):
-            if sim.startswith("escape_room"):
-                s.write_tensor("action", escape_actions(
-                    step, worlds, grab=sim == "escape_room_phys"))
+            actions = actions_for(sim, step, worlds)
+            if actions is not None:
+                s.write_tensor("action", actions)
             s.step(1)
             if step in checkpoints:
                 for col, (rows, counts) in s.dump_all().items():
@@ -215,7 +215,8 @@ def _replay_against_golden(path, lib_path):
 
 
 @pytest.mark.parametrize("name", ["cartpole_w64", "escape_room_w16",
-                                  "sort_stress_w33", "escape_room_phys_w8"])
+                                  "sort_stress_w33", "escape_room_phys_w8",
+                                  "hideseek_w8"])
 def test_reference_backend_reproduces_golden(built, name):
     from golden.make_golden import CASES
     sim = CASES[name][0]

@@ -29,15 +29,16 @@ def _need_ref(sim):
         pytest.skip("oracle/_ref missing on this box")
 
 
-def _escape_actions(seed, grab=False):
+def _escape_actions(seed, grab=False, agents=2):
     rng = np.random.default_rng(seed)
 
     def feed(ref, hip, step):
         W = ref.num_worlds
-        a = np.stack([rng.integers(0, 4, (W, 2)), rng.integers(0, 8, (W, 2)),
-                      rng.integers(-2, 3, (W, 2)),
-                      rng.integers(0, 2, (W, 2)) if grab else
-                      np.zeros((W, 2), int)],
+        shape = (W, agents)
+        a = np.stack([rng.integers(0, 4, shape), rng.integers(0, 8, shape),
+                      rng.integers(-2, 3, shape),
+                      rng.integers(0, 2, shape) if grab else
+                      np.zeros(shape, int)],
                      -1).astype(np.int32)
         ref.write_tensor("action", a)
         hip.write_tensor("action", a)
@@ -108,6 +109,36 @@ def test_escape_room_physics_kernel_variants(built, monkeypatch, max_bodies):
     monkeypatch.setenv("MADRONA_MWHIP_PHYS_MAX_BODIES", str(max_bodies))
     probs, step = run_pair("escape_room_phys", 48, 60, flags=25,
                            check_every=5, actions=_escape_actions(7, grab=True),
+                           check_init=False)
+    assert not probs, (step, probs[:3])
+
+
+@pytest.mark.parametrize("worlds,denom,steps", [(1, 0, 260), (16, 40, 150),
+                                                (64, 0, 300), (256, 100, 60),
+                                                (1024, 200, 30), (4096, 150, 20)])
+def test_hideseek_lockstep(built, worlds, denom, steps):
+    """BASELINE config 4 shape: 29 rigid bodies per world in three archetypes
+    (5 agents, 9 boxes, 2 wedge-shaped ramps, 12 walls, plane) -> the 64-body
+    LDS instantiation of the fused step; hull-hull SAT between different hulls
+    (cube / wedge: triangle faces, non axis-aligned edge pairs), bodies that
+    switch between Dynamic and Static (lock action), line-of-sight rays and a
+    lidar through BVH::traceRay, resets that rebuild the BVH."""
+    _need_ref("hideseek")
+    probs, step = run_pair("hideseek", worlds, steps, flags=denom,
+                           check_every=1 if worlds <= 16 else 10,
+                           actions=_escape_actions(worlds + 3, grab=True,
+                                                   agents=5),
+                           check_init=False)
+    assert not probs, (step, probs[:3])
+
+
+@pytest.mark.parametrize("max_bodies", [32, 128, 1000])
+def test_hideseek_kernel_variants(built, monkeypatch, max_bodies):
+    """29 bodies also fit the 32-body block exactly; 128 and the HBM variant."""
+    _need_ref("hideseek")
+    monkeypatch.setenv("MADRONA_MWHIP_PHYS_MAX_BODIES", str(max_bodies))
+    probs, step = run_pair("hideseek", 48, 60, flags=25, check_every=5,
+                           actions=_escape_actions(9, grab=True, agents=5),
                            check_init=False)
     assert not probs, (step, probs[:3])
 
@@ -220,16 +251,17 @@ def test_sort_three_pass_world_ids(built):
 
 # ---- 2. committed golden fixtures ------------------------------------------------
 @pytest.mark.parametrize("name", ["cartpole_w64", "escape_room_w16",
-                                  "sort_stress_w33", "escape_room_phys_w8"])
+                                  "sort_stress_w33", "escape_room_phys_w8",
+                                  "hideseek_w8"])
 def test_hip_matches_golden(built, name):
-    from golden.make_golden import CASES, escape_actions
+    from golden.make_golden import CASES, actions_for
     sim, worlds, seed, flags, checkpoints = CASES[name]
     gold = np.load(os.path.join(GOLDEN, f"{name}.npz"))
     with Simulator(hip_lib_path(sim), worlds, seed=seed, flags=flags) as s:
         for step in range(1, max(checkpoints) + 1):
-            if sim.startswith("escape_room"):
-                s.write_tensor("action", escape_actions(
-                    step, worlds, grab=sim == "escape_room_phys"))
+            actions = actions_for(sim, step, worlds)
+            if actions is not None:
+                s.write_tensor("action", actions)
             s.step(1)
             if step in checkpoints:
                 for col, (rows, counts) in s.dump_all().items():
