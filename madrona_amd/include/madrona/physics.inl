@@ -315,24 +315,34 @@ Entity BVH::traceRay(math::Vector3 o,
         // whose own slot passes.  Testing the slot boxes in the order recorded
         // by rebuild() therefore performs the same leaf tests in the same
         // order with the same t_max, without the dependent node -> child ->
-        // node chain and without a stack; the boxes of a group of leaves are
-        // fetched together.
+        // node chain and without a stack.
+        //
+        // Two passes per window of 64 leaves: every slot box against the
+        // initial t_max (all rays of an agent read the same boxes: broadcast
+        // loads, no divergence) leaves a bit mask of candidate leaves; then
+        // each ray walks ITS OWN set bits, re-testing the box with the current
+        // t_max as the stack walk would.  A wave then takes as many leaf-test
+        // steps as its busiest ray has candidates (a handful), not one per
+        // leaf that any of its rays touches.
         const int32_t n = num_tree_leaves_;
-        constexpr int32_t group = 4;
-        for (int32_t base = 0; base < n; base += group) {
-            int32_t leaf[group];
-            AABB box[group];
-MADRONA_UNROLL
-            for (int32_t j = 0; j < group; j++) {
-                const int32_t r = base + j < n ? base + j : n - 1;
-                leaf[j] = dfs_leaves_[r];
-                box[j] = leafSlotBounds(leaf[j]);
+        for (int32_t base = 0; base < n; base += 64) {
+            const int32_t window = n - base < 64 ? n - base : 64;
+
+            uint64_t candidates = 0;
+            for (int32_t j = 0; j < window; j++) {
+                AABB box = leafSlotBounds(dfs_leaves_[base + j]);
+                const bool hit = box.rayIntersects(o, inv_d, 0.f, t_max);
+                candidates |= (uint64_t)hit << j;
             }
-MADRONA_UNROLL
-            for (int32_t j = 0; j < group; j++) {
-                if (base + j < n &&
-                        box[j].rayIntersects(o, inv_d, 0.f, t_max)) {
-                    visitLeaf(leaf[j]);
+
+            while (candidates != 0) {
+                const int32_t j = (int32_t)__builtin_ctzll(candidates);
+                candidates &= candidates - 1;
+
+                const int32_t leaf_idx = dfs_leaves_[base + j];
+                if (leafSlotBounds(leaf_idx).rayIntersects(o, inv_d, 0.f,
+                                                           t_max)) {
+                    visitLeaf(leaf_idx);
                 }
             }
         }
