@@ -188,9 +188,17 @@ public:
     }
 
     // call on a rebased copy; returns the number of nodes the tree may reference
-    MADRONA_HD inline int32_t rebuildStaged()
+    struct RebuildStackEntry {
+        int32_t nodeID;
+        int32_t parentID;
+        int32_t offset;
+        int32_t numObjs;
+    };
+    static constexpr int32_t rebuildStackSize = 64;
+
+    MADRONA_HD inline int32_t rebuildStaged(RebuildStackEntry *stack)
     {
-        rebuild();
+        rebuild(stack);
         return (int32_t)num_nodes_;
     }
 
@@ -282,6 +290,7 @@ private:
 
     MADRONA_HD inline int32_t midpointSplit(int32_t base, int32_t num_elems);
     MADRONA_HD inline void rebuild();
+    MADRONA_HD inline void rebuild(RebuildStackEntry *stack);
 
     Node *nodes_;
     CountT num_nodes_;

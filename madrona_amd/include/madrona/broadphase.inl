@@ -275,18 +275,21 @@ int32_t BVH::midpointSplit(int32_t base, int32_t num_elems)
 // merged bounds go into the first free child slot of its parent.
 void BVH::rebuild()
 {
+    RebuildStackEntry stack[rebuildStackSize];
+    rebuild(stack);
+}
+
+// `stack`: rebuildStackSize entries of working storage.  On the GPU a private
+// array of this size lives in scratch memory, where every push / pop is a
+// memory round trip; the staged rebuild passes LDS instead.
+void BVH::rebuild(RebuildStackEntry *stack)
+{
+    using StackEntry = RebuildStackEntry;
+
     const int32_t num_leaves = num_leaves_;
     num_tree_leaves_ = num_leaves;
     num_nodes_ = numInternalNodes(num_leaves);
 
-    struct StackEntry {
-        int32_t nodeID;
-        int32_t parentID;
-        int32_t offset;
-        int32_t numObjs;
-    };
-
-    StackEntry stack[64];
     stack[0] = StackEntry { sentinel_, sentinel_, 0, num_leaves };
     CountT stack_size = 1;
 
@@ -376,7 +379,10 @@ void BVH::rebuild()
 
     // record the order an unpruned traversal visits the leaves in
     {
-        int32_t visit[32];
+        // (the build stack is free again: reuse it)
+        static_assert(sizeof(RebuildStackEntry) * rebuildStackSize >=
+                      32 * sizeof(int32_t));
+        int32_t *visit = (int32_t *)stack;
         visit[0] = 0;
         CountT visit_size = 1;
         int32_t rank = 0;

@@ -983,6 +983,8 @@ bvhUpdateKernel(EcsState *S, void *, uint32_t, uint32_t)
         uint32_t leafParents[max_leaves];
         int32_t sortedLeaves[max_leaves];
         int32_t traversalOrder[max_leaves];
+        broadphase::BVH::RebuildStackEntry
+            buildStack[broadphase::BVH::rebuildStackSize];
         int32_t numNodes;
     };
     __shared__ Staging staging;
@@ -1021,7 +1023,7 @@ bvhUpdateKernel(EcsState *S, void *, uint32_t, uint32_t)
             broadphase::BVH local = bvh.rebased(staging.nodes,
                 staging.leafAABBs, staging.leafParents, staging.sortedLeaves,
                 staging.traversalOrder, staging.leafCenters);
-            staging.numNodes = local.rebuildStaged();
+            staging.numNodes = local.rebuildStaged(staging.buildStack);
         }
         wave::phaseFence();
 
