@@ -815,6 +815,30 @@ inline void updateLeafPositionsEntry(Context &ctx,
     bvh.updateLeafPosition(leaf_id, pos, rot, scale, vel.linear, obj_aabb);
 }
 
+// Leaf update + refit in one pass over the bodies (the reference runs them as
+// two ParallelFor nodes, broadphase.cpp:892-1052): the refit of a leaf only
+// needs that leaf's new box, and expands its ancestors with atomic min / max,
+// so it can follow the update in the same thread.  A world whose tree is about
+// to be rebuilt skips the refit: the rebuild derives every box from the leaf
+// boxes, after which a refit changes nothing.
+inline void updateLeafAndRefitEntry(Context &ctx,
+                                    const LeafID &leaf_id,
+                                    const base::Position &pos,
+                                    const base::Rotation &rot,
+                                    const base::Scale &scale,
+                                    const base::ObjectID &obj_id,
+                                    const Velocity &vel)
+{
+    BVH &bvh = ctx.singleton<BVH>();
+    ObjectManager &obj_mgr = *ctx.singleton<ObjectData>().mgr;
+    math::AABB obj_aabb = obj_mgr.rigidBodyAABBs[obj_id.idx];
+
+    bvh.updateLeafPosition(leaf_id, pos, rot, scale, vel.linear, obj_aabb);
+    if (!bvh.needsRebuild()) {
+        bvh.refitLeaf(leaf_id, bvh.getLeafAABB(leaf_id));
+    }
+}
+
 inline void updateBVHEntry(Context &, BVH &bvh)
 {
     bvh.updateTree();
@@ -1455,12 +1479,9 @@ MADRONA_HOST_API inline TaskGraphNodeID setupPostIntegrationTasks(
     using namespace base;
     using broadphase::LeafID;
 
-    auto update_leaves = builder.addToGraph<ParallelForNode<Context,
-        broadphase::updateLeafPositionsEntry,
-            LeafID, Position, Rotation, Scale, ObjectID, Velocity>>(deps);
-
     return builder.addToGraph<ParallelForNode<Context,
-        broadphase::refitEntry, LeafID>>({update_leaves});
+        broadphase::updateLeafAndRefitEntry,
+            LeafID, Position, Rotation, Scale, ObjectID, Velocity>>(deps);
 }
 
 }
@@ -1481,7 +1502,7 @@ MADRONA_HOST_API inline TaskGraphNodeID setupBroadphaseTasks(
 #endif
 
     auto update_leaves = builder.addToGraph<ParallelForNode<Context,
-        broadphase::updateLeafPositionsEntry,
+        broadphase::updateLeafAndRefitEntry,
             LeafID, Position, Rotation, Scale, ObjectID, Velocity>>(deps);
 
     TaskGraphNodeID bvh_update = update_leaves;
@@ -1497,9 +1518,8 @@ MADRONA_HOST_API inline TaskGraphNodeID setupBroadphaseTasks(
     }
 #endif
 
-    // the update may be a no-op, refit unconditionally
-    return builder.addToGraph<ParallelForNode<Context,
-        broadphase::refitEntry, LeafID>>({bvh_update});
+    // (no refit after the rebuild: rebuilt boxes already contain their leaves)
+    return bvh_update;
 }
 
 MADRONA_HOST_API inline TaskGraphNodeID setupPhysicsStepTasks(
