@@ -202,6 +202,14 @@ public:
         return (int32_t)num_nodes_;
     }
 
+#if defined(__HIPCC__)
+    // Wave-cooperative flavour of the staged rebuild: all 64 lanes call it on
+    // identical rebased copies (<= 64 leaves); builds the same tree, node for
+    // node, as rebuild().  Needs leaf_centers_.
+    __device__ inline int32_t rebuildStagedWave(uint32_t lane,
+                                                RebuildStackEntry *stack);
+#endif
+
     MADRONA_HD inline void finishRebuild(int32_t num_nodes)
     {
         num_nodes_ = num_nodes;
@@ -291,6 +299,10 @@ private:
     MADRONA_HD inline int32_t midpointSplit(int32_t base, int32_t num_elems);
     MADRONA_HD inline void rebuild();
     MADRONA_HD inline void rebuild(RebuildStackEntry *stack);
+#if defined(__HIPCC__)
+    __device__ inline int32_t midpointSplitWave(uint32_t lane, int32_t base,
+                                                int32_t num_elems);
+#endif
 
     Node *nodes_;
     CountT num_nodes_;

@@ -402,6 +402,288 @@ void BVH::rebuild(RebuildStackEntry *stack)
     }
 }
 
+#if defined(__HIPCC__)
+// ---------------------------------------------------------------------------
+// The rebuild on a wavefront.  Run by one lane, rebuild() is a chain of a few
+// thousand dependent LDS accesses (~100 us per world on MI355X); here the same
+// state machine advances with all lanes: a range's leaves sit one per lane for
+// the midpoint splits (bounds by butterfly reduction, the Hoare partition's
+// swaps computed from two ballots), the four children of a node are written by
+// four lanes, merged bounds by six (one per box component), stack entries move
+// as 16-byte records.  The tree, the leaf order and the traversal order are
+// those of rebuild(), exactly: every decision is an integer function of the
+// same float comparisons.
+// ---------------------------------------------------------------------------
+namespace detail {
+
+__device__ inline void waveFence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__device__ inline uint64_t lanesBelow(uint32_t lane)
+{
+    return (1ull << lane) - 1ull;
+}
+
+}
+
+// rebuild()'s midpointSplit: lanes [0, num_elems) hold the range's elements.
+// The sequential partition swaps the k-th element >= split_val from the left
+// with the k-th element < split_val from the right until the scans meet, i.e.
+// exactly the elements on the wrong side of the final boundary, paired in
+// that order.  dfs_leaves_ (unused until the end of the build) is the
+// exchange buffer.
+int32_t BVH::midpointSplitWave(uint32_t lane, int32_t base, int32_t num_elems)
+{
+    using math::Vector3;
+
+    const bool active = (int32_t)lane < num_elems;
+    int32_t leaf = 0;
+    Vector3 center { 0.f, 0.f, 0.f };
+    if (active) {
+        leaf = sorted_leaves_[base + (int32_t)lane];
+        center = leaf_centers_[leaf];
+    }
+
+    float lo[3], hi[3];
+MADRONA_UNROLL
+    for (int32_t a = 0; a < 3; a++) {
+        lo[a] = active ? center[a] : FLT_MAX;
+        hi[a] = active ? center[a] : -FLT_MAX;
+    }
+MADRONA_UNROLL
+    for (uint32_t d = 32; d > 0; d >>= 1) {
+MADRONA_UNROLL
+        for (int32_t a = 0; a < 3; a++) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], d, 64));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], d, 64));
+        }
+    }
+
+    Vector3 center_min { lo[0], lo[1], lo[2] };
+    Vector3 center_max { hi[0], hi[1], hi[2] };
+    Vector3 center_diff = center_max - center_min;
+    int32_t axis;
+    if (center_diff.x > center_diff.y && center_diff.x > center_diff.z) {
+        axis = 0;
+    } else if (center_diff.y > center_diff.x && center_diff.y > center_diff.z) {
+        axis = 1;
+    } else {
+        axis = 2;
+    }
+
+    float split_val = 0.5f * (center_min[axis] + center_max[axis]);
+
+    const float v = axis == 0 ? center.x : axis == 1 ? center.y : center.z;
+    const bool below = active && v < split_val;
+    const bool above = active && v >= split_val;
+    const uint64_t below_mask = __builtin_amdgcn_ballot_w64(below);
+    const uint64_t above_mask = __builtin_amdgcn_ballot_w64(above);
+
+    const int32_t boundary = (int32_t)__builtin_popcountll(below_mask);
+    const uint64_t left = boundary >= 64 ? ~0ull : ((1ull << boundary) - 1ull);
+    const uint64_t wrong_above = above_mask & left;      // move right
+    const uint64_t wrong_below = below_mask & ~left;     // move left
+
+    if (wrong_above != 0) {
+        int32_t *from_left = dfs_leaves_;
+        int32_t *from_right = dfs_leaves_ + 32;
+        const bool moves_right = ((wrong_above >> lane) & 1ull) != 0;
+        const bool moves_left = ((wrong_below >> lane) & 1ull) != 0;
+        uint32_t k = 0;
+        if (moves_right) {          // k-th from the left
+            k = (uint32_t)__builtin_popcountll(
+                wrong_above & detail::lanesBelow(lane));
+            from_left[k] = leaf;
+        } else if (moves_left) {    // k-th from the right
+            k = (uint32_t)__builtin_popcountll(
+                wrong_below & ~(detail::lanesBelow(lane) | (1ull << lane)));
+            from_right[k] = leaf;
+        }
+        detail::waveFence();
+        if (moves_right) {
+            sorted_leaves_[base + (int32_t)lane] = from_right[k];
+        } else if (moves_left) {
+            sorted_leaves_[base + (int32_t)lane] = from_left[k];
+        }
+        detail::waveFence();
+    }
+
+    if (boundary > 0 && boundary < num_elems) {
+        return boundary;
+    }
+    return num_elems / 2;
+}
+
+int32_t BVH::rebuildStagedWave(uint32_t lane, RebuildStackEntry *stack)
+{
+    const int32_t num_leaves = num_leaves_;
+    num_tree_leaves_ = num_leaves;
+    num_nodes_ = numInternalNodes(num_leaves);
+
+    if (lane == 0) {
+        stack[0] = RebuildStackEntry { sentinel_, sentinel_, 0, num_leaves };
+    }
+    detail::waveFence();
+
+    int32_t stack_size = 1;
+    int32_t cur_node_offset = 0;
+
+    while (stack_size > 0) {
+        const RebuildStackEntry entry = stack[stack_size - 1];
+        int32_t node_id;
+
+        if (entry.numObjs <= 4) {
+            node_id = cur_node_offset++;
+            Node &node = nodes_[node_id];
+            if (lane == 0) {
+                node.parentID = entry.parentID;
+            }
+            if (lane < 4) {
+                const int32_t i = (int32_t)lane;
+                if (i < entry.numObjs) {
+                    int32_t leaf_id = sorted_leaves_[entry.offset + i];
+                    leaf_parents_[leaf_id] =
+                        ((uint32_t)node_id << 2) | (uint32_t)i;
+                    node.setLeaf(i, leaf_id);
+                    node.setBounds(i, leaf_aabbs_[leaf_id]);
+                } else {
+                    node.children[i] = sentinel_;
+                    node.setBounds(i, math::AABB::invalid());
+                }
+            }
+            detail::waveFence();
+        } else if (entry.nodeID == sentinel_) {
+            node_id = cur_node_offset++;
+
+            Node &node = nodes_[node_id];
+            if (lane == 0) {
+                stack[stack_size - 1].nodeID = node_id;
+                node.parentID = entry.parentID;
+            }
+            if (lane < 4) {
+                node.children[lane] = sentinel_;
+            }
+
+            const int32_t offset = entry.offset;
+            const int32_t num_objs = entry.numObjs;
+
+            int32_t second_split = midpointSplitWave(lane, offset, num_objs);
+            int32_t num_h1 = second_split;
+            int32_t num_h2 = num_objs - second_split;
+
+            int32_t first_split = midpointSplitWave(lane, offset, num_h1);
+            int32_t third_split =
+                midpointSplitWave(lane, offset + second_split, num_h2);
+
+            // pushed in reverse so the quarters are built left to right
+            if (lane < 4) {
+                RebuildStackEntry pushed;
+                pushed.nodeID = sentinel_;
+                pushed.parentID = node_id;
+                if (lane == 0) {
+                    pushed.offset = offset + num_h1 + third_split;
+                    pushed.numObjs = num_h2 - third_split;
+                } else if (lane == 1) {
+                    pushed.offset = offset + num_h1;
+                    pushed.numObjs = third_split;
+                } else if (lane == 2) {
+                    pushed.offset = offset + first_split;
+                    pushed.numObjs = num_h1 - first_split;
+                } else {
+                    pushed.offset = offset;
+                    pushed.numObjs = first_split;
+                }
+                stack[stack_size + (int32_t)lane] = pushed;
+            }
+            stack_size += 4;
+            detail::waveFence();
+
+            continue;
+        } else {
+            node_id = entry.nodeID;
+        }
+
+        stack_size -= 1;
+
+        // (node.parentID is the entry's in every case)
+        if (entry.parentID == sentinel_) {
+            continue;
+        }
+
+        Node &node = nodes_[node_id];
+        Node &parent = nodes_[entry.parentID];
+
+        // first free child slot of the parent
+        const uint64_t free_slots = __builtin_amdgcn_ballot_w64(
+            lane < 4 && parent.children[lane < 4 ? lane : 0] == sentinel_);
+        const int32_t child_offset = (int32_t)__builtin_ctzll(free_slots);
+
+        // merged bounds of the node's children, one box component per lane
+        // (the Node is six float[4] arrays: minX minY minZ maxX maxY maxZ)
+        if (lane < 6) {
+            const float *component = (const float *)&node + lane * 4;
+            const bool is_min = lane < 3;
+            float merged = is_min ? FLT_MAX : -FLT_MAX;
+            for (int32_t i = 0; i < 4; i++) {
+                if (!node.hasChild(i)) {
+                    break;
+                }
+                merged = is_min ? fminf(merged, component[i]) :
+                                  fmaxf(merged, component[i]);
+            }
+            ((float *)&parent)[lane * 4 + (uint32_t)child_offset] = merged;
+        }
+        if (lane == 0) {
+            parent.children[child_offset] = node_id;
+        }
+        detail::waveFence();
+    }
+
+    // record the order an unpruned traversal visits the leaves in
+    {
+        int32_t *visit = (int32_t *)stack;
+        if (lane == 0) {
+            visit[0] = 0;
+        }
+        detail::waveFence();
+
+        int32_t visit_size = 1;
+        int32_t rank = 0;
+        while (visit_size > 0 && num_leaves > 0) {
+            const Node &node = nodes_[visit[--visit_size]];
+            const int32_t child =
+                lane < 4 ? node.children[lane] : sentinel_;
+            const bool has_child = child != sentinel_;
+            const bool is_leaf =
+                has_child && ((uint32_t)child & leaf_bit_) != 0;
+            const bool is_inner = has_child && !is_leaf;
+            const uint64_t leaf_mask = __builtin_amdgcn_ballot_w64(is_leaf);
+            const uint64_t inner_mask = __builtin_amdgcn_ballot_w64(is_inner);
+            // the node index was read before this iteration's pushes
+            detail::waveFence();
+            if (is_leaf) {
+                dfs_leaves_[rank + (int32_t)__builtin_popcountll(
+                    leaf_mask & detail::lanesBelow(lane))] =
+                        (int32_t)((uint32_t)child & ~leaf_bit_);
+            }
+            if (is_inner) {
+                visit[visit_size + (int32_t)__builtin_popcountll(
+                    inner_mask & detail::lanesBelow(lane))] = child;
+            }
+            rank += (int32_t)__builtin_popcountll(leaf_mask);
+            visit_size += (int32_t)__builtin_popcountll(inner_mask);
+            detail::waveFence();
+        }
+    }
+
+    return (int32_t)num_nodes_;
+}
+#endif
+
 void BVH::updateTree()
 {
     if (force_rebuild_) {

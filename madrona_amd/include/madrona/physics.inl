@@ -1043,15 +1043,21 @@ bvhUpdateKernel(EcsState *S, void *, uint32_t, uint32_t)
         }
         wave::phaseFence();
 
+        broadphase::BVH local = bvh.rebased(staging.nodes,
+            staging.leafAABBs, staging.leafParents, staging.sortedLeaves,
+            staging.traversalOrder, staging.leafCenters);
+#ifdef MADRONA_PHYS_SERIAL_BVH_REBUILD
         if (lane == 0) {
-            broadphase::BVH local = bvh.rebased(staging.nodes,
-                staging.leafAABBs, staging.leafParents, staging.sortedLeaves,
-                staging.traversalOrder, staging.leafCenters);
             staging.numNodes = local.rebuildStaged(staging.buildStack);
         }
         wave::phaseFence();
-
         const int32_t num_nodes = staging.numNodes;
+#else
+        const int32_t num_nodes =
+            local.rebuildStagedWave(lane, staging.buildStack);
+        wave::phaseFence();
+#endif
+
         waveCopyDwords(lane, (uint32_t *)bvh.rawNodes(),
             (const uint32_t *)staging.nodes,
             (uint32_t)num_nodes * (broadphase::BVH::nodeBytes / 4));
