@@ -116,6 +116,12 @@ public:
     MADRONA_HD inline math::AABB expandLeaf(LeafID leaf_id,
                                             const math::Vector3 &linear_vel);
 
+    MADRONA_HD inline void updateLeafAndRefit(LeafID leaf_id,
+                                              const math::Vector3 &pos,
+                                              const math::Quat &rot,
+                                              const math::Diag3x3 &scale,
+                                              const math::Vector3 &linear_vel,
+                                              const math::AABB &obj_aabb);
     MADRONA_HD inline void refitLeaf(LeafID leaf_id,
                                      const math::AABB &leaf_aabb);
 
@@ -297,6 +303,8 @@ private:
                                             math::Vector3 *hit_normal);
 
     MADRONA_HD inline int32_t midpointSplit(int32_t base, int32_t num_elems);
+    MADRONA_HD inline void growAncestors(int32_t child_idx,
+                                         const math::AABB &leaf_aabb);
     MADRONA_HD inline void rebuild();
     MADRONA_HD inline void rebuild(RebuildStackEntry *stack);
 #if defined(__HIPCC__)

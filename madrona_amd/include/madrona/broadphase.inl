@@ -217,6 +217,116 @@ void BVH::refitLeaf(LeafID leaf_id, const math::AABB &leaf_aabb)
     }
 }
 
+// updateLeafPosition + refitLeaf(leaf, its new box) in one call, ordered for
+// the memory pipeline: everything the refit's first level reads (the leaf's
+// parent slot) is fetched BEFORE this thread's first store -- on CDNA a load
+// issued after a store waits for the store's acknowledgement, and the plain
+// sequence (store leaf box, reload it, load the slot) pays that twice.  A tree
+// that is about to be rebuilt is not refitted (the rebuild derives every box
+// from the leaf boxes).
+void BVH::updateLeafAndRefit(LeafID leaf_id,
+                             const math::Vector3 &pos,
+                             const math::Quat &rot,
+                             const math::Diag3x3 &scale,
+                             const math::Vector3 &linear_vel,
+                             const math::AABB &obj_aabb)
+{
+    const int32_t leaf = leaf_id.id;
+    const bool refit = !force_rebuild_;
+
+    int32_t node_idx = 0;
+    int32_t sub_idx = 0;
+    math::AABB slot = math::AABB::invalid();
+    if (refit) {
+        uint32_t leaf_parent = leaf_parents_[leaf];
+        node_idx = (int32_t)(leaf_parent >> 2);
+        sub_idx = (int32_t)(leaf_parent & 3u);
+        slot = nodes_[node_idx].bounds(sub_idx);
+    }
+
+    math::AABB world_aabb = obj_aabb.applyTRS(pos, rot, scale);
+    math::AABB leaf_aabb = detail::expandAABBWithMotion(
+        world_aabb, linear_vel, leaf_velocity_expansion_, leaf_accel_expansion_);
+
+    leaf_aabbs_[leaf] = leaf_aabb;
+    leaf_transforms_[leaf] = LeafTransform { pos, rot, scale };
+    sorted_leaves_[leaf] = leaf;
+
+    if (!refit) {
+        return;
+    }
+
+    // the leaf's own slot is touched by this thread only: plain stores
+    Node &leaf_node = nodes_[node_idx];
+    bool grew = false;
+    if (leaf_aabb.pMin.x < slot.pMin.x) {
+        leaf_node.minX[sub_idx] = leaf_aabb.pMin.x;
+        grew = true;
+    }
+    if (leaf_aabb.pMin.y < slot.pMin.y) {
+        leaf_node.minY[sub_idx] = leaf_aabb.pMin.y;
+        grew = true;
+    }
+    if (leaf_aabb.pMin.z < slot.pMin.z) {
+        leaf_node.minZ[sub_idx] = leaf_aabb.pMin.z;
+        grew = true;
+    }
+    if (leaf_aabb.pMax.x > slot.pMax.x) {
+        leaf_node.maxX[sub_idx] = leaf_aabb.pMax.x;
+        grew = true;
+    }
+    if (leaf_aabb.pMax.y > slot.pMax.y) {
+        leaf_node.maxY[sub_idx] = leaf_aabb.pMax.y;
+        grew = true;
+    }
+    if (leaf_aabb.pMax.z > slot.pMax.z) {
+        leaf_node.maxZ[sub_idx] = leaf_aabb.pMax.z;
+        grew = true;
+    }
+    if (!grew) {
+        return;
+    }
+
+    growAncestors(node_idx, leaf_aabb);
+}
+
+// Upper levels of a refit: several leaves of a world grow them concurrently.
+void BVH::growAncestors(int32_t child_idx, const math::AABB &leaf_aabb)
+{
+    int32_t node_idx = nodes_[child_idx].parentID;
+
+    while (node_idx != sentinel_) {
+        Node &node = nodes_[node_idx];
+
+        int32_t child_offset = 0;
+        for (int32_t j = 0; j < 4; j++) {
+            if (node.children[j] == child_idx) {
+                child_offset = j;
+                break;
+            }
+        }
+
+        const int32_t c = child_offset;
+        float x_min_prev = detail::fetchMinF(&node.minX[c], leaf_aabb.pMin.x, true);
+        float y_min_prev = detail::fetchMinF(&node.minY[c], leaf_aabb.pMin.y, true);
+        float z_min_prev = detail::fetchMinF(&node.minZ[c], leaf_aabb.pMin.z, true);
+        float x_max_prev = detail::fetchMaxF(&node.maxX[c], leaf_aabb.pMax.x, true);
+        float y_max_prev = detail::fetchMaxF(&node.maxY[c], leaf_aabb.pMax.y, true);
+        float z_max_prev = detail::fetchMaxF(&node.maxZ[c], leaf_aabb.pMax.z, true);
+
+        const bool grew =
+            leaf_aabb.pMin.x < x_min_prev || leaf_aabb.pMin.y < y_min_prev ||
+            leaf_aabb.pMin.z < z_min_prev || leaf_aabb.pMax.x > x_max_prev ||
+            leaf_aabb.pMax.y > y_max_prev || leaf_aabb.pMax.z > z_max_prev;
+        if (!grew) {
+            break;
+        }
+
+        child_idx = node_idx;
+        node_idx = node.parentID;
+    }
+}
+
 // Partitions sorted_leaves_[base, base + num_elems) about the midpoint of the
 // centroid bounds on the widest axis; returns the size of the lower half.
 int32_t BVH::midpointSplit(int32_t base, int32_t num_elems)

@@ -833,10 +833,7 @@ inline void updateLeafAndRefitEntry(Context &ctx,
     ObjectManager &obj_mgr = *ctx.singleton<ObjectData>().mgr;
     math::AABB obj_aabb = obj_mgr.rigidBodyAABBs[obj_id.idx];
 
-    bvh.updateLeafPosition(leaf_id, pos, rot, scale, vel.linear, obj_aabb);
-    if (!bvh.needsRebuild()) {
-        bvh.refitLeaf(leaf_id, bvh.getLeafAABB(leaf_id));
-    }
+    bvh.updateLeafAndRefit(leaf_id, pos, rot, scale, vel.linear, obj_aabb);
 }
 
 inline void updateBVHEntry(Context &, BVH &bvh)
