@@ -73,11 +73,35 @@ template <typename ContextT, auto Fn, int32_t threads_per_invocation,
 MADRONA_DEVICE inline void parallelForTable(StateManager *state_mgr,
                                             TableHdr &tbl,
                                             const uint16_t *col_indices,
-                                            bool exclusive_world)
+                                            bool exclusive_world,
+                                            int32_t num_rows,
+                                            int32_t rows_before)
 {
     constexpr size_t N = sizeof...(ComponentTs);
 
-    const int32_t num_rows = tbl.numRows;
+    const int32_t tid = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x) /
+        threads_per_invocation;
+    const int32_t stride = (int32_t)(gridDim.x * blockDim.x) /
+        threads_per_invocation;
+
+    // The matched tables form ONE index space (rows_before = rows of the tables
+    // ahead of this one): a thread continues in this table where the previous
+    // one ended, so with fewer rows than threads every thread runs one row in
+    // total -- one dependent chain (row -> world -> components -> ...), not
+    // one per matched archetype.
+#ifdef MADRONA_PFOR_PER_TABLE
+    (void)rows_before;
+    int32_t first_row = tid;
+#else
+    int32_t first_row = tid - rows_before % stride;
+    if (first_row < 0) {
+        first_row += stride;
+    }
+#endif
+    if (first_row >= num_rows) {
+        return;
+    }
+
     const WorldID *world_col = (const WorldID *)tbl.columns[1];
 
     void *cols[N > 0 ? N : 1];
@@ -86,12 +110,7 @@ MADRONA_UNROLL
         cols[c] = tbl.columns[col_indices[c]];
     }
 
-    const int32_t tid = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x) /
-        threads_per_invocation;
-    const int32_t stride = (int32_t)(gridDim.x * blockDim.x) /
-        threads_per_invocation;
-
-    for (int32_t row = tid; row < num_rows; row += stride) {
+    for (int32_t row = first_row; row < num_rows; row += stride) {
         WorldID world_id = world_col[row];
         // destroyed but not yet compacted away
         if (world_id.idx == -1) {
@@ -120,13 +139,22 @@ parallelForKernel(EcsState *S, void *, uint32_t query_offset,
     StateManager *state_mgr = static_cast<StateManager *>(S);
 
     if (query.num_inline == num_matching) {
+        int32_t num_rows[MWHIP_PFOR_MAX_INLINE];
+MADRONA_UNROLL
+        for (uint32_t a = 0; a < MWHIP_PFOR_MAX_INLINE; a++) {
+            num_rows[a] = a < num_matching ?
+                ((const TableHdr *)query.tables[a])->numRows : 0;
+        }
+
+        int32_t rows_before = 0;
 MADRONA_UNROLL
         for (uint32_t a = 0; a < MWHIP_PFOR_MAX_INLINE; a++) {
             if (a < num_matching) {
                 parallelForTable<ContextT, Fn, threads_per_invocation,
                                  ComponentTs...>(
                     state_mgr, *(TableHdr *)query.tables[a], query.columns[a],
-                    exclusive_world);
+                    exclusive_world, num_rows[a], rows_before);
+                rows_before += num_rows[a];
             }
         }
         return;
@@ -140,9 +168,10 @@ MADRONA_UNROLL
         for (size_t c = 0; c < N; c++) {
             col_indices[c] = (uint16_t)query_values[1 + c];
         }
+        TableHdr &tbl = S->tables[query_values[0]];
         parallelForTable<ContextT, Fn, threads_per_invocation,
                          ComponentTs...>(
-            state_mgr, S->tables[query_values[0]], col_indices, exclusive_world);
+            state_mgr, tbl, col_indices, exclusive_world, tbl.numRows, 0);
         query_values += 1 + N;
     }
 }
