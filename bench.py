@@ -136,12 +136,13 @@ def physics_line(gpu_id, seed, denom, worlds=8192, steps=600, warmup=100):
             torch.randint(0, 2, (worlds, 2), device="cuda", generator=gen),
         ], -1).to(torch.int32))
         torch.cuda.synchronize()
-        sim.step(warmup)
+        sim.step_async(warmup)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        sim.step(steps)
+        sim.step_async(steps)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        sim.sync()
         stats = sim.profile(10)
     phys = [k for k in stats if k["name"].startswith("physics:worldStep")]
     out = {
@@ -188,6 +189,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP backend has no CPU fallback")
     torch.cuda.set_device(local_rank)
     if distributed:
+        # (--force-collective outside torchrun: a one-rank group on this host)
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from madrona_amd.distributed import ShardedSimulator, shard_for
@@ -236,6 +242,7 @@ def main():
         sharded.step(1)
     barrier()
     elapsed = time.perf_counter() - t0
+    sharded.sync()      # device-side error flags of the queued replays
 
     if distributed:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)

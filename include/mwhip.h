@@ -229,6 +229,11 @@ int mwhip_run(mwhip_exec *exec, uint64_t graph);
 int mwhip_run_async(mwhip_exec *exec, uint64_t graph, void *hip_stream);
 /* the executor's private stream (cu::makeStream, cuda_exec.cpp:2342) */
 void *mwhip_stream(mwhip_exec *exec);
+/* Waits for everything queued on the executor's private stream (replays started
+ * with mwhip_run_async on mwhip_stream()) and returns the health of the last
+ * replay like mwhip_run does (new: the reference leaves this to the caller's
+ * cudaStreamSynchronize). */
+int mwhip_synchronize(mwhip_exec *exec);
 /* MWCudaExecutor::getExported (cuda_exec.cpp:2802-2805) */
 void *mwhip_get_exported(const mwhip_exec *exec, uint32_t slot);
 

@@ -1813,6 +1813,12 @@ extern "C" int mwhip_run_async(mwhip_exec *exec, uint64_t graph, void *hip_strea
     return 0;
 }
 
+extern "C" int mwhip_synchronize(mwhip_exec *exec)
+{
+    HIPCHK(hipStreamSynchronize(exec->stream));
+    return checkHealth(exec);
+}
+
 // ---------------------------------------------------------------------------
 // introspection
 // ---------------------------------------------------------------------------

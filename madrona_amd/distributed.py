@@ -64,6 +64,8 @@ class ShardedSimulator:
         self._packed_local = None
         self._packed_global = None
         self._global: Dict[str, "torch.Tensor"] = {}
+        self._exec_stream = None    # torch view of the executor's stream
+        self._packed_event = None   # recorded after each pack
 
     def _setup(self):
         import torch
@@ -94,28 +96,52 @@ class ShardedSimulator:
 
     def step(self, n: int = 1):
         """Steps the local worlds, then gathers the observation tensors:
-        out[name] has shape [total_worlds, ...]."""
+        out[name] has shape [total_worlds, ...].  On the HIP backend everything
+        is queued in stream order: consume the result on the current torch
+        stream, or synchronize, before reading it on the host."""
         import torch
 
-        self.sim.step(n)
+        on_device = getattr(self.sim, "backend", "") == "hip"
+        if not on_device:
+            self.sim.step(n)
+        else:
+            # Stream-ordered, no host round trip per step: the executor replays
+            # on its own stream (MWCudaExecutor::runAsync); the pack of the
+            # previous step must have read the exported columns before this
+            # step may overwrite them, and this step's pack waits for the
+            # replay.  The collective only reads the packed copy, so it
+            # overlaps with the next step.
+            cur = torch.cuda.current_stream()
+            if self._exec_stream is None:
+                self._exec_stream = torch.cuda.ExternalStream(
+                    self.sim.stream(), device=cur.device)
+            if self._packed_event is not None:
+                self._exec_stream.wait_event(self._packed_event)
+            self.sim.step_async(n)
+            if self.obs_names:
+                cur.wait_stream(self._exec_stream)
+
         if not self.obs_names:
             return self._global
         if self._local_words is None:
             self._setup()
 
         torch.cat(self._local_words, dim=1, out=self._packed_local)
-        if self._packed_local.is_cuda:
-            # the executor steps on its own stream: the pack must have read the
-            # exported columns before the next step may overwrite them (the
-            # collective itself then overlaps with that step, it only reads the
-            # packed copy)
-            torch.cuda.current_stream(self._packed_local.device).synchronize()
+        if on_device:
+            if self._packed_event is None:
+                self._packed_event = torch.cuda.Event()
+            self._packed_event.record(torch.cuda.current_stream())
         if self.shard.world_size == 1:
             self._packed_global.copy_(self._packed_local)
         else:
             self._dist.all_gather_into_tensor(
                 self._packed_global, self._packed_local, group=self.group)
         return self._global
+
+    def sync(self):
+        """Waits for queued steps (HIP backend); raises on a device error flag."""
+        if getattr(self.sim, "backend", "") == "hip":
+            self.sim.sync()
 
     def close(self):
         self.sim.close()

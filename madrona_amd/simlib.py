@@ -99,13 +99,31 @@ class KernelStat(C.Structure):
     ]
 
 
+def _torch_runtime_first() -> None:
+    """PyTorch-ROCm bundles its own HIP / HSA runtime; a process that loads the
+    system runtime first (through our libraries) and torch afterwards ends up
+    with two HSA runtimes and torch reports "No HIP GPUs are available".
+    Loading torch's copy first makes our libraries bind to it (same SONAME)."""
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+
+
 def runtime_lib() -> C.CDLL:
     """libmadrona_hip.so (the C ABI of include/mwhip.h)."""
+    _torch_runtime_first()
     lib = C.CDLL(os.path.join(HIP_BUILD_DIR, "libmadrona_hip.so"), mode=C.RTLD_GLOBAL)
     lib.mwhip_profile.restype = C.c_int32
     lib.mwhip_profile.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32,
                                   C.POINTER(KernelStat), C.c_uint32]
     lib.mwhip_last_error.restype = C.c_char_p
+    lib.mwhip_stream.restype = C.c_void_p
+    lib.mwhip_stream.argtypes = [C.c_void_p]
+    lib.mwhip_run_async.restype = C.c_int
+    lib.mwhip_run_async.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+    lib.mwhip_synchronize.restype = C.c_int
+    lib.mwhip_synchronize.argtypes = [C.c_void_p]
     return lib
 
 
@@ -120,6 +138,8 @@ class Simulator:
                 f"{lib_path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
         # RTLD_LOCAL: every simulator library defines the same C API (and
         # madronaMWHipUserEntry); they must not interpose on each other
+        if lib_path.endswith("_hip.so"):
+            _torch_runtime_first()
         self.lib = C.CDLL(lib_path, mode=C.RTLD_LOCAL)
         _bind(self.lib)
         self.num_worlds = num_worlds
@@ -208,6 +228,34 @@ class Simulator:
 
     def hip_exec(self) -> int:
         return int(self.lib.sim_hip_exec(self.handle) or 0)
+
+    # ---- stream-ordered stepping (HIP backend) -----------------------------------
+    def stream(self) -> int:
+        """hipStream_t of the executor's private stream (mwhip_stream)."""
+        return int(runtime_lib().mwhip_stream(self.hip_exec()) or 0)
+
+    def step_async(self, n: int = 1) -> None:
+        """Queues n replays of the step graph on the executor's stream without
+        waiting for them (MWCudaExecutor::runAsync, reference mw_gpu.hpp:146):
+        work that consumes the exported tensors must be ordered after this
+        stream (events / sync()), as with any stream-ordered producer."""
+        rt = runtime_lib()
+        exec_ = self.hip_exec()
+        graph = self.lib.sim_hip_step_graph(self.handle)
+        stream = rt.mwhip_stream(exec_)
+        for _ in range(n):
+            rc = rt.mwhip_run_async(exec_, graph, stream)
+            if rc != 0:
+                raise RuntimeError(
+                    f"mwhip_run_async -> {rc}: {rt.mwhip_last_error().decode()}")
+
+    def sync(self) -> None:
+        """Waits for the queued replays; raises on a device-side error flag."""
+        rt = runtime_lib()
+        rc = rt.mwhip_synchronize(self.hip_exec())
+        if rc != 0:
+            raise RuntimeError(
+                f"mwhip_synchronize -> {rc}: {rt.mwhip_last_error().decode()}")
 
     def profile(self, reps: int = 20):
         """Per-kernel timing of one step (HIP events on the executor's stream,
