@@ -1,0 +1,212 @@
+#include "ball_pit/sim.hpp"
+
+#include <madrona/physics_loader.hpp>
+#include <madrona/physics_assets.hpp>
+#include <madrona/importer.hpp>
+#include <madrona/stack_alloc.hpp>
+
+struct SimTraits;
+#include "common/sim_c_api.h"
+
+#include <vector>
+#include <string>
+#include <memory>
+#include <array>
+
+namespace {
+
+using namespace madrona;
+using namespace madrona::phys;
+using ballpit::SimObject;
+
+// Two source hulls (no file importers here), scaled per instance: a unit cube
+// and a unit wedge (right-triangle cross-section: the slope rises from y = -0.5
+// to y = +0.5; 6 vertices, 3 quads + 2 triangles).
+struct CubeMesh {
+    math::Vector3 positions[8] = {
+        { -0.5f, -0.5f, -0.5f }, { 0.5f, -0.5f, -0.5f },
+        { 0.5f, 0.5f, -0.5f }, { -0.5f, 0.5f, -0.5f },
+        { -0.5f, -0.5f, 0.5f }, { 0.5f, -0.5f, 0.5f },
+        { 0.5f, 0.5f, 0.5f }, { -0.5f, 0.5f, 0.5f },
+    };
+    uint32_t indices[24] = {
+        0, 3, 2, 1,     // -z
+        4, 5, 6, 7,     // +z
+        0, 1, 5, 4,     // -y
+        2, 3, 7, 6,     // +y
+        0, 4, 7, 3,     // -x
+        1, 2, 6, 5,     // +x
+    };
+    uint32_t faceCounts[6] = { 4, 4, 4, 4, 4, 4 };
+};
+
+struct WedgeMesh {
+    math::Vector3 positions[6] = {
+        { -0.5f, -0.5f, -0.5f }, { 0.5f, -0.5f, -0.5f },
+        { 0.5f, 0.5f, -0.5f }, { -0.5f, 0.5f, -0.5f },
+        { -0.5f, 0.5f, 0.5f }, { 0.5f, 0.5f, 0.5f },
+    };
+    uint32_t indices[18] = {
+        0, 3, 2, 1,     // -z
+        2, 3, 4, 5,     // +y
+        0, 1, 5, 4,     // slope (-y, +z)
+        0, 4, 3,        // -x
+        1, 2, 5,        // +x
+    };
+    uint32_t faceCounts[5] = { 4, 4, 4, 3, 3 };
+};
+
+// Loaders stay alive for the life of the process: worlds keep pointing at the
+// ObjectManager they own.
+std::vector<std::unique_ptr<PhysicsLoader>> &loaders()
+{
+    static std::vector<std::unique_ptr<PhysicsLoader>> list;
+    return list;
+}
+
+ObjectManager *loadPhysicsObjects(const SimCreateArgs &args)
+{
+#ifdef SIM_BACKEND_REF_CPU
+    (void)args;
+    auto loader = std::make_unique<PhysicsLoader>(ExecMode::CPU, 10);
+#else
+    auto loader = std::make_unique<PhysicsLoader>(ExecMode::CUDA, 10,
+                                                  args.gpu_id);
+#endif
+
+    CubeMesh cube;
+    WedgeMesh wedge;
+    std::array<imp::SourceMesh, 2> hull_meshes {};
+    hull_meshes[0].positions = cube.positions;
+    hull_meshes[0].indices = cube.indices;
+    hull_meshes[0].faceCounts = cube.faceCounts;
+    hull_meshes[0].numVertices = 8;
+    hull_meshes[0].numFaces = 6;
+    hull_meshes[1].positions = wedge.positions;
+    hull_meshes[1].indices = wedge.indices;
+    hull_meshes[1].faceCounts = wedge.faceCounts;
+    hull_meshes[1].numVertices = 6;
+    hull_meshes[1].numFaces = 5;
+
+    std::array<SourceCollisionPrimitive, (size_t)SimObject::NumObjects> prims {};
+    std::array<SourceCollisionObject, (size_t)SimObject::NumObjects> objs {};
+
+    auto setup_hull = [&](SimObject obj, uint32_t hull_idx, float inv_mass,
+                          RigidBodyFrictionData friction) {
+        SourceCollisionPrimitive &prim = prims[(size_t)obj];
+        prim.type = CollisionPrimitive::Type::Hull;
+        prim.hullInput.hullIDX = hull_idx;
+
+        objs[(size_t)obj] = SourceCollisionObject {
+            Span<const SourceCollisionPrimitive>(&prim, 1),
+            inv_mass,
+            friction,
+        };
+    };
+
+    setup_hull(SimObject::Box, 0, 0.2f, { 0.5f, 0.75f });
+    setup_hull(SimObject::Wedge, 1, 0.15f, { 0.6f, 0.8f });
+    setup_hull(SimObject::Wall, 0, 0.f, { 0.5f, 0.5f });
+
+    {
+        SourceCollisionPrimitive &prim = prims[(size_t)SimObject::Sphere];
+        prim.type = CollisionPrimitive::Type::Sphere;
+        prim.sphere.radius = 1.f;
+        objs[(size_t)SimObject::Sphere] = SourceCollisionObject {
+            Span<const SourceCollisionPrimitive>(&prim, 1),
+            0.25f,
+            { 0.5f, 0.6f },
+        };
+    }
+
+    {
+        SourceCollisionPrimitive &prim = prims[(size_t)SimObject::Plane];
+        prim.type = CollisionPrimitive::Type::Plane;
+        objs[(size_t)SimObject::Plane] = SourceCollisionObject {
+            Span<const SourceCollisionPrimitive>(&prim, 1),
+            0.f,
+            { 0.5f, 0.5f },
+        };
+    }
+
+    StackAlloc tmp_alloc;
+    RigidBodyAssets rigid_body_assets;
+    CountT num_rigid_body_data_bytes;
+    void *rigid_body_data = RigidBodyAssets::processRigidBodyAssets(
+        Span<const imp::SourceMesh>(hull_meshes.data(),
+                                    (CountT)hull_meshes.size()),
+        Span<const SourceCollisionObject>(objs.data(), (CountT)objs.size()),
+        false, tmp_alloc, &rigid_body_assets, &num_rigid_body_data_bytes);
+
+    if (rigid_body_data == nullptr) {
+        FATAL("Invalid collision hull input");
+    }
+
+    loader->loadRigidBodies(rigid_body_assets);
+    free(rigid_body_data);
+
+    ObjectManager *mgr = &loader->getObjectManager();
+    loaders().push_back(std::move(loader));
+    return mgr;
+}
+
+}
+
+struct SimTraits {
+    using Sim = ballpit::Sim;
+    using Engine = ballpit::Engine;
+
+    static constexpr uint32_t numExports =
+        (uint32_t)ballpit::ExportID::NumExports;
+    static constexpr uint32_t numTaskGraphs = 1;
+
+    // flags: low 16 bits = autoResetDenom (0 disables random resets)
+    static Sim::Config makeConfig(const SimCreateArgs &args)
+    {
+        return Sim::Config {
+            args.seed, args.world_base, args.flags & 0xFFFFu,
+            loadPhysicsObjects(args),
+        };
+    }
+
+    static void makeInits(const SimCreateArgs &, Sim::WorldInit *) {}
+
+    template <typename T>
+    static void describeTensors(T &out, uint32_t num_worlds);
+    template <typename T>
+    static void describeColumns(T &cols);
+};
+
+#include "common/mgr_impl.inl"
+
+template <typename T>
+void SimTraits::describeTensors(T &out, uint32_t num_worlds)
+{
+    using ballpit::ExportID;
+    int64_t W = num_worlds;
+    out.push_back({ "reset", SIM_I32, { W, 1 }, (uint32_t)ExportID::Reset });
+    out.push_back({ "steps_remaining", SIM_I32, { W, 1 },
+                    (uint32_t)ExportID::StepsRemaining });
+}
+
+template <typename T>
+void SimTraits::describeColumns(T &cols)
+{
+    using namespace ballpit;
+    using madrona::Entity;
+    using madrona::phys::broadphase::LeafID;
+
+    cols.template add<MovableObject, Entity>("MovableObject.Entity", false);
+    cols.template add<MovableObject, Position>("MovableObject.Position", true);
+    cols.template add<MovableObject, Rotation>("MovableObject.Rotation", true);
+    cols.template add<MovableObject, Scale>("MovableObject.Scale", true);
+    cols.template add<MovableObject, Velocity>("MovableObject.Velocity", true);
+    cols.template add<MovableObject, ExternalForce>(
+        "MovableObject.ExternalForce", true);
+    cols.template add<MovableObject, LeafID>("MovableObject.LeafID", false);
+    cols.template add<MovableObject, KickIndex>("MovableObject.KickIndex", false);
+
+    cols.template add<StaticObject, Entity>("StaticObject.Entity", false);
+    cols.template add<StaticObject, Position>("StaticObject.Position", true);
+    cols.template add<StaticObject, LeafID>("StaticObject.LeafID", false);
+}

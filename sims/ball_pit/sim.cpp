@@ -1,0 +1,290 @@
+#include "sim.hpp"
+
+#ifdef MADRONA_GPU_MODE
+#include <madrona/mw_gpu_entry.hpp>
+#endif
+
+using namespace madrona;
+using namespace madrona::math;
+using namespace madrona::phys;
+
+namespace ballpit {
+
+// rotation about z by k * 90 degrees
+static constexpr float kQuarterW[4] = { 1.f, 0.70710678f, 0.f, 0.70710678f };
+static constexpr float kQuarterZ[4] = { 0.f, 0.70710678f, 1.f, -0.70710678f };
+
+void Sim::registerTypes(ECSRegistry &registry, const Config &)
+{
+    base::registerTypes(registry);
+    PhysicsSystem::registerTypes(registry);
+
+    registry.registerComponent<KickIndex>();
+
+    registry.registerSingleton<WorldReset>();
+    registry.registerSingleton<StepsRemaining>();
+    registry.registerSingleton<LevelState>();
+
+    registry.registerArchetype<MovableObject>();
+    registry.registerArchetype<StaticObject>();
+
+    registry.exportSingleton<WorldReset>((uint32_t)ExportID::Reset);
+    registry.exportSingleton<StepsRemaining>(
+        (uint32_t)ExportID::StepsRemaining);
+}
+
+static inline float randInRange(RNG &rng, float lo, float hi)
+{
+    return lo + rng.sampleUniform() * (hi - lo);
+}
+
+static inline void setupRigidBody(Engine &ctx, Entity e, Vector3 pos, Quat rot,
+                                  SimObject obj, ResponseType response,
+                                  Diag3x3 scale)
+{
+    ObjectID obj_id { (int32_t)obj };
+
+    ctx.get<Position>(e) = pos;
+    ctx.get<Rotation>(e) = rot;
+    ctx.get<Scale>(e) = scale;
+    ctx.get<ObjectID>(e) = obj_id;
+    ctx.get<ResponseType>(e) = response;
+    ctx.get<Velocity>(e) = Velocity { Vector3::zero(), Vector3::zero() };
+    ctx.get<ExternalForce>(e) = Vector3::zero();
+    ctx.get<ExternalTorque>(e) = Vector3::zero();
+    ctx.get<broadphase::LeafID>(e) =
+        PhysicsSystem::registerEntity(ctx, e, obj_id);
+}
+
+// The movable objects start on a 4 x 4 board of cells at staggered heights, so
+// they fall onto the floor and onto each other.
+static void generateLevel(Engine &ctx, RNG &rng)
+{
+    LevelState &level = ctx.singleton<LevelState>();
+
+    constexpr int32_t board = 4;
+    constexpr float cell = consts::pitSize / (float)board;
+
+    for (int32_t i = 0; i < consts::numMovable; i++) {
+        Entity e = ctx.makeEntity<MovableObject>();
+
+        int32_t slot = (i * 5 + 3) % (board * board);
+        Vector3 pos {
+            ((float)(slot % board) + 0.5f) * cell - consts::pitSize * 0.5f +
+                randInRange(rng, -0.4f, 0.4f),
+            ((float)(slot / board) + 0.5f) * cell - consts::pitSize * 0.5f +
+                randInRange(rng, -0.4f, 0.4f),
+            randInRange(rng, 1.f, 4.f),
+        };
+
+        if (i < consts::numSpheres) {
+            float r = randInRange(rng, 0.5f, 1.1f);
+            setupRigidBody(ctx, e, pos, Quat { 1, 0, 0, 0 }, SimObject::Sphere,
+                           ResponseType::Dynamic, Diag3x3 { r, r, r });
+        } else if (i < consts::numSpheres + consts::numBoxes) {
+            int32_t quarter = rng.sampleI32(0, 4);
+            setupRigidBody(ctx, e, pos,
+                Quat { kQuarterW[quarter], 0.f, 0.f, kQuarterZ[quarter] },
+                SimObject::Box, ResponseType::Dynamic,
+                Diag3x3 { randInRange(rng, 0.8f, 1.6f),
+                          randInRange(rng, 0.8f, 1.6f),
+                          randInRange(rng, 0.8f, 1.6f) });
+        } else {
+            int32_t quarter = rng.sampleI32(0, 4);
+            setupRigidBody(ctx, e, pos,
+                Quat { kQuarterW[quarter], 0.f, 0.f, kQuarterZ[quarter] },
+                SimObject::Wedge, ResponseType::Dynamic,
+                Diag3x3 { 1.5f, 2.f, 1.2f });
+        }
+
+        ctx.get<KickIndex>(e).idx = i;
+        level.movable[i] = e;
+    }
+}
+
+static void createPersistentEntities(Engine &ctx)
+{
+    Sim &sim = ctx.data();
+    const float half = consts::pitSize * 0.5f;
+    const float t = consts::wallThickness;
+
+    sim.floorPlane = ctx.makeEntity<StaticObject>();
+    setupRigidBody(ctx, sim.floorPlane, Vector3 { 0, 0, 0 },
+        Quat { 1, 0, 0, 0 }, SimObject::Plane, ResponseType::Static,
+        Diag3x3 { 1, 1, 1 });
+
+    const Vector3 wall_pos[consts::numWalls] = {
+        { 0.f, -half - t * 0.5f, consts::wallHeight * 0.5f },
+        { 0.f, half + t * 0.5f, consts::wallHeight * 0.5f },
+        { -half - t * 0.5f, 0.f, consts::wallHeight * 0.5f },
+        { half + t * 0.5f, 0.f, consts::wallHeight * 0.5f },
+    };
+    const Diag3x3 wall_scale[consts::numWalls] = {
+        { consts::pitSize + 2.f * t, t, consts::wallHeight },
+        { consts::pitSize + 2.f * t, t, consts::wallHeight },
+        { t, consts::pitSize + 2.f * t, consts::wallHeight },
+        { t, consts::pitSize + 2.f * t, consts::wallHeight },
+    };
+    for (int32_t i = 0; i < consts::numWalls; i++) {
+        sim.walls[i] = ctx.makeEntity<StaticObject>();
+        setupRigidBody(ctx, sim.walls[i], wall_pos[i], Quat { 1, 0, 0, 0 },
+            SimObject::Wall, ResponseType::Static, wall_scale[i]);
+    }
+}
+
+static void initWorld(Engine &ctx)
+{
+    Sim &sim = ctx.data();
+
+    PhysicsSystem::reset(ctx);
+
+    RNG rng(rand::split_i(sim.initRandKey, sim.curWorldEpisode++));
+
+    ctx.get<broadphase::LeafID>(sim.floorPlane) = PhysicsSystem::registerEntity(
+        ctx, sim.floorPlane, ctx.get<ObjectID>(sim.floorPlane));
+    for (int32_t i = 0; i < consts::numWalls; i++) {
+        ctx.get<broadphase::LeafID>(sim.walls[i]) =
+            PhysicsSystem::registerEntity(ctx, sim.walls[i],
+                                          ctx.get<ObjectID>(sim.walls[i]));
+    }
+
+    generateLevel(ctx, rng);
+
+    ctx.singleton<StepsRemaining>().t = consts::episodeLen;
+    sim.rng = rng;
+}
+
+static void cleanupWorld(Engine &ctx)
+{
+    LevelState &level = ctx.singleton<LevelState>();
+    for (int32_t i = 0; i < consts::numMovable; i++) {
+        ctx.destroyEntity(level.movable[i]);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// systems
+// ---------------------------------------------------------------------------
+// Every 8 steps one object per world (round robin) is kicked sideways and up.
+// One invocation per world: the world's RNG stream advances in a fixed order.
+inline void kickSystem(Engine &ctx, LevelState &level)
+{
+    Sim &sim = ctx.data();
+    int32_t t = ctx.singleton<StepsRemaining>().t;
+
+    for (int32_t i = 0; i < consts::numMovable; i++) {
+        ctx.get<ExternalForce>(level.movable[i]) = Vector3::zero();
+        ctx.get<ExternalTorque>(level.movable[i]) = Vector3::zero();
+    }
+
+    if (t % 8 != 0) {
+        return;
+    }
+
+    RNG rng = sim.rng;
+    int32_t target = (t / 8) % consts::numMovable;
+    Vector3 force {
+        randInRange(rng, -300.f, 300.f),
+        randInRange(rng, -300.f, 300.f),
+        randInRange(rng, 0.f, 250.f),
+    };
+    Vector3 torque {
+        randInRange(rng, -20.f, 20.f),
+        randInRange(rng, -20.f, 20.f),
+        randInRange(rng, -20.f, 20.f),
+    };
+    sim.rng = rng;
+
+    ctx.get<ExternalForce>(level.movable[target]) = force;
+    ctx.get<ExternalTorque>(level.movable[target]) = torque;
+}
+
+inline void resetSystem(Engine &ctx, WorldReset &reset)
+{
+    Sim &sim = ctx.data();
+
+    int32_t should_reset = reset.reset;
+
+    StepsRemaining &steps = ctx.singleton<StepsRemaining>();
+    steps.t -= 1;
+    if (steps.t <= 0) {
+        should_reset = 1;
+    }
+
+    if (sim.autoResetDenom != 0) {
+        if (sim.resetRng.sampleI32(0, (int32_t)sim.autoResetDenom) == 0) {
+            should_reset = 1;
+        }
+    }
+
+    if (should_reset != 0) {
+        reset.reset = 0;
+        cleanupWorld(ctx);
+        initWorld(ctx);
+    }
+}
+
+void Sim::setupTasks(TaskGraphManager &taskgraph_mgr, const Config &)
+{
+    TaskGraphBuilder &builder = taskgraph_mgr.init(0);
+
+    auto kick_sys = builder.addToGraph<ParallelForNode<Engine,
+        kickSystem,
+            LevelState
+        >>({});
+
+    auto broadphase_setup_sys =
+        PhysicsSystem::setupBroadphaseTasks(builder, {kick_sys});
+
+    auto substep_sys = PhysicsSystem::setupPhysicsStepTasks(builder,
+        {broadphase_setup_sys}, consts::numPhysicsSubsteps);
+
+    auto phys_done =
+        PhysicsSystem::setupCleanupTasks(builder, {substep_sys});
+
+    auto reset_sys = builder.addToGraph<ParallelForNode<Engine,
+        resetSystem,
+            WorldReset
+        >>({phys_done});
+
+#ifdef MADRONA_GPU_MODE
+    auto recycle_sys = builder.addToGraph<RecycleEntitiesNode>({reset_sys});
+    auto post_reset = recycle_sys;
+#else
+    auto post_reset = reset_sys;
+#endif
+
+    auto compact_movable = builder.addToGraph<
+        CompactArchetypeNode<MovableObject>>({post_reset});
+
+    auto post_reset_broadphase =
+        PhysicsSystem::setupBroadphaseTasks(builder, {compact_movable});
+
+    (void)post_reset_broadphase;
+}
+
+Sim::Sim(Engine &ctx, const Config &cfg, const WorldInit &)
+    : WorldBase(ctx)
+{
+    uint32_t global_world = cfg.worldBase + (uint32_t)ctx.worldID().idx;
+
+    initRandKey = rand::split_i(rand::initKey(cfg.seed), global_world);
+    resetRng = RNG(rand::split_i(initRandKey, 0x7E5E7u));
+    curWorldEpisode = 0;
+    autoResetDenom = cfg.autoResetDenom;
+
+    ctx.singleton<WorldReset>().reset = 0;
+
+    PhysicsSystem::init(ctx, cfg.rigidBodyObjMgr, consts::deltaT,
+        consts::numPhysicsSubsteps, -9.8f * math::up,
+        consts::maxRigidBodies);
+
+    createPersistentEntities(ctx);
+    initWorld(ctx);
+}
+
+#ifdef MADRONA_GPU_MODE
+MADRONA_BUILD_MWGPU_ENTRY(Engine, Sim, Sim::Config, Sim::WorldInit);
+#endif
+
+}

@@ -1,0 +1,123 @@
+// A pit of spheres, boxes and wedges: the sphere primitive paths of the
+// narrowphase (sphere-sphere, sphere-plane, sphere-hull through GJK) that no
+// ray-casting simulator can exercise (the reference's BVH::traceRay asserts on
+// spheres).  No agents: bodies are kicked by forces drawn from the world's RNG.
+// Per world: plane + 4 walls + 6 spheres + 5 boxes + 2 wedges = 18 bodies in
+// two archetypes.  Written only against the public Madrona API.
+#pragma once
+
+#include <madrona/taskgraph_builder.hpp>
+#include <madrona/custom_context.hpp>
+#include <madrona/components.hpp>
+#include <madrona/math.hpp>
+#include <madrona/rand.hpp>
+#include <madrona/physics.hpp>
+
+namespace ballpit {
+
+using madrona::Entity;
+using madrona::RandKey;
+using madrona::RNG;
+using madrona::base::Position;
+using madrona::base::Rotation;
+using madrona::base::Scale;
+using madrona::base::ObjectID;
+using madrona::math::Vector3;
+using madrona::math::Quat;
+using madrona::phys::Velocity;
+using madrona::phys::ResponseType;
+using madrona::phys::ExternalForce;
+using madrona::phys::ExternalTorque;
+using madrona::phys::RigidBody;
+
+namespace consts {
+inline constexpr int32_t numSpheres = 6;
+inline constexpr int32_t numBoxes = 5;
+inline constexpr int32_t numWedges = 2;
+inline constexpr int32_t numMovable = numSpheres + numBoxes + numWedges;
+inline constexpr int32_t numWalls = 4;
+inline constexpr int32_t episodeLen = 150;
+inline constexpr float pitSize = 10.f;
+inline constexpr float wallThickness = 0.5f;
+inline constexpr float wallHeight = 3.f;
+inline constexpr float deltaT = 0.04f;
+inline constexpr int32_t numPhysicsSubsteps = 4;
+inline constexpr int32_t maxRigidBodies = 24;
+}
+
+enum class ExportID : uint32_t {
+    Reset,
+    StepsRemaining,
+    NumExports,
+};
+
+enum class SimObject : int32_t {
+    Sphere,
+    Box,
+    Wedge,
+    Wall,
+    Plane,
+    NumObjects,
+};
+
+struct WorldReset {
+    int32_t reset;
+};
+
+struct StepsRemaining {
+    int32_t t;
+};
+
+struct LevelState {
+    Entity movable[consts::numMovable];
+};
+
+// which movable object this is (kick schedule)
+struct KickIndex {
+    int32_t idx;
+};
+
+struct MovableObject : public madrona::Archetype<
+    RigidBody,
+    KickIndex
+> {};
+
+struct StaticObject : public madrona::Archetype<
+    RigidBody
+> {};
+
+class Engine;
+
+struct Sim : public madrona::WorldBase {
+    struct Config {
+        uint32_t seed;
+        uint32_t worldBase;
+        uint32_t autoResetDenom;
+        madrona::phys::ObjectManager *rigidBodyObjMgr;
+    };
+
+    struct WorldInit {};
+
+    static void registerTypes(madrona::ECSRegistry &registry,
+                              const Config &cfg);
+
+    static void setupTasks(madrona::TaskGraphManager &taskgraph_mgr,
+                           const Config &cfg);
+
+    Sim(Engine &ctx, const Config &cfg, const WorldInit &init);
+
+    RandKey initRandKey;
+    RNG rng;
+    RNG resetRng;
+    uint32_t curWorldEpisode;
+    uint32_t autoResetDenom;
+    Entity floorPlane;
+    Entity walls[consts::numWalls];
+};
+
+class Engine : public madrona::CustomContext<Engine, Sim> {
+public:
+    using CustomContext::CustomContext;
+};
+
+}

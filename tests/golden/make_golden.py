@@ -28,6 +28,8 @@ CASES = {
     "escape_room_phys_w8": ("escape_room_phys", 8, 5, 30, [1, 5, 25, 60]),
     # Hide-and-Seek shape: 29 bodies/world, wedge hulls, lock/unlock, ray casts
     "hideseek_w8": ("hideseek", 8, 5, 40, [1, 5, 25, 110]),
+    # sphere primitives (GJK sphere-hull), random kicks, no actions
+    "ball_pit_w8": ("ball_pit", 8, 5, 50, [1, 10, 40, 120]),
 }
 
 AGENTS = {"escape_room": 2, "escape_room_phys": 2, "hideseek": 5}

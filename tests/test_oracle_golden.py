@@ -216,7 +216,7 @@ def _replay_against_golden(path, lib_path):
 
 @pytest.mark.parametrize("name", ["cartpole_w64", "escape_room_w16",
                                   "sort_stress_w33", "escape_room_phys_w8",
-                                  "hideseek_w8"])
+                                  "hideseek_w8", "ball_pit_w8"])
 def test_reference_backend_reproduces_golden(built, name):
     from golden.make_golden import CASES
     sim = CASES[name][0]

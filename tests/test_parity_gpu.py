@@ -143,6 +143,20 @@ def test_hideseek_kernel_variants(built, monkeypatch, max_bodies):
     assert not probs, (step, probs[:3])
 
 
+@pytest.mark.parametrize("worlds,denom,steps", [(1, 0, 320), (16, 30, 200),
+                                                (256, 60, 100), (2048, 150, 40)])
+def test_ball_pit_lockstep(built, worlds, denom, steps):
+    """Sphere primitives: sphere-sphere, sphere-plane and sphere-hull (GJK with
+    the signed-volume sub-solvers, then the SAT fallback for centres inside the
+    hull) on the device, next to box / wedge hulls, kicked around by random
+    forces -- a chaotic pile, so an ulp anywhere shows within a few steps."""
+    _need_ref("ball_pit")
+    probs, step = run_pair("ball_pit", worlds, steps, flags=denom,
+                           check_every=1 if worlds <= 16 else 10,
+                           check_init=False)
+    assert not probs, (step, probs[:3])
+
+
 def _candidate_pairs(dump, arch_names):
     """CandidateCollision rows -> (world, entity id a, entity id b, aPrim, bPrim).
     A Loc's row is world-local on the CPU backend and global on the GPU; both are
@@ -252,7 +266,7 @@ def test_sort_three_pass_world_ids(built):
 # ---- 2. committed golden fixtures ------------------------------------------------
 @pytest.mark.parametrize("name", ["cartpole_w64", "escape_room_w16",
                                   "sort_stress_w33", "escape_room_phys_w8",
-                                  "hideseek_w8"])
+                                  "hideseek_w8", "ball_pit_w8"])
 def test_hip_matches_golden(built, name):
     from golden.make_golden import CASES, actions_for
     sim, worlds, seed, flags, checkpoints = CASES[name]
