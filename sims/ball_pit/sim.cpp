@@ -81,6 +81,15 @@ static void generateLevel(Engine &ctx, RNG &rng)
             float r = randInRange(rng, 0.5f, 1.1f);
             setupRigidBody(ctx, e, pos, Quat { 1, 0, 0, 0 }, SimObject::Sphere,
                            ResponseType::Dynamic, Diag3x3 { r, r, r });
+        } else if (i == consts::numSpheres + consts::numBoxes - 1) {
+            // the compound object: every pair it is in yields one candidate
+            // per primitive
+            int32_t quarter = rng.sampleI32(0, 4);
+            float sc = randInRange(rng, 0.8f, 1.2f);
+            setupRigidBody(ctx, e, pos,
+                Quat { kQuarterW[quarter], 0.f, 0.f, kQuarterZ[quarter] },
+                SimObject::LBlock, ResponseType::Dynamic,
+                Diag3x3 { sc, sc, sc });
         } else if (i < consts::numSpheres + consts::numBoxes) {
             int32_t quarter = rng.sampleI32(0, 4);
             setupRigidBody(ctx, e, pos,

@@ -2,8 +2,8 @@
 // narrowphase (sphere-sphere, sphere-plane, sphere-hull through GJK) that no
 // ray-casting simulator can exercise (the reference's BVH::traceRay asserts on
 // spheres).  No agents: bodies are kicked by forces drawn from the world's RNG.
-// Per world: plane + 4 walls + 6 spheres + 5 boxes + 2 wedges = 18 bodies in
-// two archetypes.  Written only against the public Madrona API.
+// Per world: plane + 4 walls + 6 spheres + 4 boxes + 1 L-shaped block made of
+// two hull primitives + 2 wedges = 18 bodies in two archetypes.  Written only against the public Madrona API.
 #pragma once
 
 #include <madrona/taskgraph_builder.hpp>
@@ -57,6 +57,7 @@ enum class SimObject : int32_t {
     Wedge,
     Wall,
     Plane,
+    LBlock,     // two hull primitives in one object
     NumObjects,
 };
 

@@ -148,11 +148,25 @@ def test_hideseek_kernel_variants(built, monkeypatch, max_bodies):
 def test_ball_pit_lockstep(built, worlds, denom, steps):
     """Sphere primitives: sphere-sphere, sphere-plane and sphere-hull (GJK with
     the signed-volume sub-solvers, then the SAT fallback for centres inside the
-    hull) on the device, next to box / wedge hulls, kicked around by random
-    forces -- a chaotic pile, so an ulp anywhere shows within a few steps."""
+    hull) on the device, next to box / wedge hulls and an object made of two
+    hull primitives (one candidate per primitive pair; its hulls do not fit the
+    LDS arena next to the others and are read from HBM), kicked around by
+    random forces -- a chaotic pile, so an ulp anywhere shows within a few
+    steps."""
     _need_ref("ball_pit")
     probs, step = run_pair("ball_pit", worlds, steps, flags=denom,
                            check_every=1 if worlds <= 16 else 10,
+                           check_init=False)
+    assert not probs, (step, probs[:3])
+
+
+@pytest.mark.parametrize("max_bodies", [64, 128, 1000])
+def test_ball_pit_kernel_variants(built, monkeypatch, max_bodies):
+    """Spheres and the two-primitive object through the other instantiations of
+    the fused step (the > 128 variant reads primitives and hulls from HBM)."""
+    _need_ref("ball_pit")
+    monkeypatch.setenv("MADRONA_MWHIP_PHYS_MAX_BODIES", str(max_bodies))
+    probs, step = run_pair("ball_pit", 64, 80, flags=30, check_every=5,
                            check_init=False)
     assert not probs, (step, probs[:3])
 
