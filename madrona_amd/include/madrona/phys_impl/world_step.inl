@@ -331,22 +331,11 @@ __device__ inline bool collidePairLane(const PairSetup &pair, float *row,
         LazyHull a(pair.aPrim->hull.halfEdgeMesh, pair.a.pos, pair.a.rot,
                    pair.a.scale, false);
 
-        // largest face bounds the contact polygon
-        const uint32_t num_faces = (uint32_t)a.numFaces();
-        if (a.mesh->numHalfEdges > lanePolyVerts * num_faces) {
-            // cannot rule out a face with more than lanePolyVerts vertices
-            bool fits = true;
-            for (uint32_t f = 0; f < num_faces; f++) {
-                fits = fits && faceVertexCount(a, f) <= lanePolyVerts;
-            }
-            if (!fits) {
-                *too_big = true;
-                return false;
-            }
-        }
-
+        // the contact polygon is (part of) the face SAT picks: it must fit
+        // the lane's LDS row
         return hullPlaneContact(a, pair.b, pair.aLoc, pair.bLoc,
-                                row, row + lanePolyVerts * 3, out);
+                                row, row + lanePolyVerts * 3, out,
+                                (CountT)lanePolyVerts, too_big);
     }
     case NarrowphaseTest::SphereHull: {
         // hull in the sphere's frame, evaluated lazily (no centroid needed)

@@ -560,11 +560,16 @@ MADRONA_HD inline bool satToContact(const SATResult &sat,
 }
 
 template <typename HullT>
+// tmp_a / tmp_b hold one entry per vertex of the incident face; a caller with
+// less room than the largest face passes its capacity and gets *too_big when
+// the face SAT picked does not fit.
 MADRONA_HD inline bool hullPlaneContact(const HullT &a_hull,
                                         const PrimitiveTransform &plane_txfm,
                                         Loc a_loc, Loc b_loc,
                                         void *tmp_a, void *tmp_b,
-                                        ContactConstraint *out)
+                                        ContactConstraint *out,
+                                        CountT tmp_capacity = -1,
+                                        bool *too_big = nullptr)
 {
     constexpr Vector3 base_normal = { 0, 0, 1 };
     Vector3 plane_normal = plane_txfm.rot.rotateVec(base_normal);
@@ -574,6 +579,22 @@ MADRONA_HD inline bool hullPlaneContact(const HullT &a_hull,
     const SATResult sat = doSATPlane(plane, a_hull);
     if (sat.type != ContactType::SATPlane) {
         return false;
+    }
+
+    if (tmp_capacity >= 0) {
+        CountT num_face_vertices = 0;
+        uint32_t hedge_idx = a_hull.faceBaseHedge(
+            (CountT)sat.contact.incidentFaceIdxOrEdgeIdxB);
+        const uint32_t start_hedge_idx = hedge_idx;
+        do {
+            hedge_idx = a_hull.hedge(hedge_idx).next;
+            num_face_vertices++;
+        } while (hedge_idx != start_hedge_idx);
+
+        if (num_face_vertices > tmp_capacity) {
+            *too_big = true;
+            return false;
+        }
     }
 
     // the plane is always b and always the reference
@@ -693,8 +714,12 @@ MADRONA_HD inline bool sphereHullContact(const PairSetup &pair,
 
 // One primitive pair on one lane with the hulls transformed into caller
 // scratch (the reference's CPU flavour: runNarrowphase, narrowphase.cpp:
-// 1682-1907).  tmp_vertices / tmp_faces: max_tmp_elems entries each; the face
-// buffer's two halves double as the clipping scratch once SAT is done.
+// 1682-1907).  tmp_vertices / tmp_faces: max_tmp_elems entries each; the
+// clipping scratch is the UNUSED TAIL of each buffer.  (It used to overlay the
+// planes "once SAT is done" -- but the planes are read through Plane lvalues
+// and the polygons written through Vector3 lvalues, so type-based alias
+// analysis lets the compiler sink a plane load below the polygon stores; the
+// device build did, for faces large enough to reach the plane it still needed.)
 MADRONA_HD inline bool collidePairStored(const PairSetup &pair,
                                          Vector3 *tmp_vertices,
                                          Plane *tmp_faces,
@@ -706,8 +731,20 @@ MADRONA_HD inline bool collidePairStored(const PairSetup &pair,
         return false;
     }
 
-    void *clip_a = tmp_faces;
-    void *clip_b = tmp_faces + max_tmp_elems / 2;
+    // clip_a: Vector3s behind the hulls' vertices, clip_b: behind their
+    // planes; a clipped polygon has at most (vertices of both hulls) corners
+    auto clipScratch = [&](CountT used_vertices, CountT used_faces,
+                           void **clip_a, void **clip_b) {
+        const CountT need = used_vertices;
+        const CountT have_a = max_tmp_elems - used_vertices;
+        const CountT have_b = (CountT)(((size_t)(max_tmp_elems - used_faces) *
+            sizeof(Plane)) / sizeof(Vector3));
+        *clip_a = tmp_vertices + used_vertices;
+        *clip_b = tmp_faces + used_faces;
+        return have_a >= need && have_b >= need;
+    };
+    void *clip_a = nullptr;
+    void *clip_b = nullptr;
 
     switch (pair.test) {
     case NarrowphaseTest::SphereSphere:
@@ -721,6 +758,13 @@ MADRONA_HD inline bool collidePairStored(const PairSetup &pair,
         if ((CountT)(a_he_mesh.numFaces + b_he_mesh.numFaces) > max_tmp_elems ||
             (CountT)(a_he_mesh.numVertices + b_he_mesh.numVertices) >
                 max_tmp_elems) {
+            *unsupported = true;
+            return false;
+        }
+        if (!clipScratch(
+                (CountT)(a_he_mesh.numVertices + b_he_mesh.numVertices),
+                (CountT)(a_he_mesh.numFaces + b_he_mesh.numFaces),
+                &clip_a, &clip_b)) {
             *unsupported = true;
             return false;
         }
@@ -740,6 +784,11 @@ MADRONA_HD inline bool collidePairStored(const PairSetup &pair,
 
         if ((CountT)a_he_mesh.numFaces > max_tmp_elems ||
             (CountT)a_he_mesh.numVertices > max_tmp_elems) {
+            *unsupported = true;
+            return false;
+        }
+        if (!clipScratch((CountT)a_he_mesh.numVertices,
+                         (CountT)a_he_mesh.numFaces, &clip_a, &clip_b)) {
             *unsupported = true;
             return false;
         }

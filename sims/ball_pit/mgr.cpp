@@ -75,6 +75,44 @@ struct BoxMesh {
     {}
 };
 
+// A regular n-gon prism ("coin") of radius r and height h, axis along z.
+struct PrismMesh {
+    std::vector<math::Vector3> positions;
+    std::vector<uint32_t> indices;
+    std::vector<uint32_t> faceCounts;
+
+    PrismMesh(uint32_t n, float r, float h)
+    {
+        for (uint32_t ring = 0; ring < 2; ring++) {
+            for (uint32_t i = 0; i < n; i++) {
+                float angle = 6.2831853f * (float)i / (float)n;
+                positions.push_back(math::Vector3 {
+                    r * cosf(angle), r * sinf(angle),
+                    ring == 0 ? -0.5f * h : 0.5f * h,
+                });
+            }
+        }
+        // bottom cap (seen from below), top cap, then the sides
+        indices.push_back(0);
+        for (uint32_t i = n - 1; i >= 1; i--) {
+            indices.push_back(i);
+        }
+        faceCounts.push_back(n);
+        for (uint32_t i = 0; i < n; i++) {
+            indices.push_back(n + i);
+        }
+        faceCounts.push_back(n);
+        for (uint32_t i = 0; i < n; i++) {
+            uint32_t j = (i + 1) % n;
+            indices.push_back(i);
+            indices.push_back(j);
+            indices.push_back(n + j);
+            indices.push_back(n + i);
+            faceCounts.push_back(4);
+        }
+    }
+};
+
 // Loaders stay alive for the life of the process: worlds keep pointing at the
 // ObjectManager they own.
 std::vector<std::unique_ptr<PhysicsLoader>> &loaders()
@@ -98,7 +136,18 @@ ObjectManager *loadPhysicsObjects(const SimCreateArgs &args)
     // the L-shaped block: a bar along x and a post standing on one end
     BoxMesh bar({ -1.f, -0.3f, -0.3f }, { 1.f, 0.3f, 0.3f });
     BoxMesh post({ 0.4f, -0.3f, 0.3f }, { 1.f, 0.3f, 1.2f });
-    std::array<imp::SourceMesh, 4> hull_meshes {};
+    PrismMesh coin12(12, 0.9f, 0.5f);
+    PrismMesh coin16(16, 1.f, 0.5f);
+    std::array<imp::SourceMesh, 6> hull_meshes {};
+    auto set_prism = [&](uint32_t idx, PrismMesh &m) {
+        hull_meshes[idx].positions = m.positions.data();
+        hull_meshes[idx].indices = m.indices.data();
+        hull_meshes[idx].faceCounts = m.faceCounts.data();
+        hull_meshes[idx].numVertices = (uint32_t)m.positions.size();
+        hull_meshes[idx].numFaces = (uint32_t)m.faceCounts.size();
+    };
+    set_prism(4, coin12);
+    set_prism(5, coin16);
     hull_meshes[2].positions = bar.positions;
     hull_meshes[2].indices = bar.indices;
     hull_meshes[2].faceCounts = bar.faceCounts;
@@ -137,7 +186,8 @@ ObjectManager *loadPhysicsObjects(const SimCreateArgs &args)
     };
 
     setup_hull(SimObject::Box, 0, 0.2f, { 0.5f, 0.75f });
-    setup_hull(SimObject::Wedge, 1, 0.15f, { 0.6f, 0.8f });
+    setup_hull(SimObject::Coin12, 4, 0.3f, { 0.6f, 0.8f });
+    setup_hull(SimObject::Coin16, 5, 0.25f, { 0.6f, 0.8f });
     setup_hull(SimObject::Wall, 0, 0.f, { 0.5f, 0.5f });
 
     std::array<SourceCollisionPrimitive, 2> l_prims {};

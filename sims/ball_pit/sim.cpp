@@ -100,10 +100,19 @@ static void generateLevel(Engine &ctx, RNG &rng)
                           randInRange(rng, 0.8f, 1.6f) });
         } else {
             int32_t quarter = rng.sampleI32(0, 4);
+            // coins start flat, some of them above one another
+            const int32_t coin = i - consts::numSpheres - consts::numBoxes;
+            if (coin == 2) {
+                Vector3 below = ctx.get<Position>(level.movable[i - 1]);
+                pos.x = below.x + randInRange(rng, -0.2f, 0.2f);
+                pos.y = below.y + randInRange(rng, -0.2f, 0.2f);
+                pos.z = below.z + 0.8f;
+            }
+            float sc = randInRange(rng, 0.8f, 1.3f);
             setupRigidBody(ctx, e, pos,
                 Quat { kQuarterW[quarter], 0.f, 0.f, kQuarterZ[quarter] },
-                SimObject::Wedge, ResponseType::Dynamic,
-                Diag3x3 { 1.5f, 2.f, 1.2f });
+                coin == 0 ? SimObject::Coin12 : SimObject::Coin16,
+                ResponseType::Dynamic, Diag3x3 { sc, sc, 1.f });
         }
 
         ctx.get<KickIndex>(e).idx = i;

@@ -3,7 +3,9 @@
 // ray-casting simulator can exercise (the reference's BVH::traceRay asserts on
 // spheres).  No agents: bodies are kicked by forces drawn from the world's RNG.
 // Per world: plane + 4 walls + 6 spheres + 4 boxes + 1 L-shaped block made of
-// two hull primitives + 2 wedges = 18 bodies in two archetypes.  Written only against the public Madrona API.
+// two hull primitives + 3 "coins" (12- and 16-sided prisms: hulls and faces
+// larger than the fused kernel's LDS staging, so its fallback paths run) = 19
+// bodies in two archetypes.  Written only against the public Madrona API.
 #pragma once
 
 #include <madrona/taskgraph_builder.hpp>
@@ -33,8 +35,8 @@ using madrona::phys::RigidBody;
 namespace consts {
 inline constexpr int32_t numSpheres = 6;
 inline constexpr int32_t numBoxes = 5;
-inline constexpr int32_t numWedges = 2;
-inline constexpr int32_t numMovable = numSpheres + numBoxes + numWedges;
+inline constexpr int32_t numCoins = 3;
+inline constexpr int32_t numMovable = numSpheres + numBoxes + numCoins;
 inline constexpr int32_t numWalls = 4;
 inline constexpr int32_t episodeLen = 150;
 inline constexpr float pitSize = 10.f;
@@ -54,7 +56,8 @@ enum class ExportID : uint32_t {
 enum class SimObject : int32_t {
     Sphere,
     Box,
-    Wedge,
+    Coin12,     // 12-gon prism: more vertices than the wave path keeps in LDS
+    Coin16,     // 16-gon prism: its cap faces outgrow the clipping scratch
     Wall,
     Plane,
     LBlock,     // two hull primitives in one object

@@ -37,8 +37,26 @@ WEDGE_IDX = np.array([0, 2, 1, 3, 4, 5, 0, 1, 4, 3, 1, 2, 5, 4, 2, 0, 3, 5],
                      np.uint32)
 WEDGE_COUNTS = np.array([3, 3, 4, 4, 4], np.uint32)
 
+
+
+def _prism(n, r, h):
+    """Regular n-gon prism (sims/ball_pit's "coins"): two n-vertex caps."""
+    ang = 2 * np.pi * np.arange(n) / n
+    ring = np.stack([r * np.cos(ang), r * np.sin(ang)], 1)
+    verts = np.concatenate([np.c_[ring, np.full(n, -h / 2)],
+                            np.c_[ring, np.full(n, h / 2)]]).astype(np.float32)
+    idx = [0] + list(range(n - 1, 0, -1)) + [n + i for i in range(n)]
+    counts = [n, n]
+    for i in range(n):
+        j = (i + 1) % n
+        idx += [i, j, n + j, n + i]
+        counts.append(4)
+    return verts, np.array(idx, np.uint32), np.array(counts, np.uint32)
+
+
 MESHES = {"cube": (CUBE_VERTS, CUBE_IDX, CUBE_COUNTS),
-          "wedge": (WEDGE_VERTS, WEDGE_IDX, WEDGE_COUNTS)}
+          "wedge": (WEDGE_VERTS, WEDGE_IDX, WEDGE_COUNTS),
+          "coin16": _prism(16, 1.0, 0.5)}
 
 
 def _ptr(a, t):
@@ -65,7 +83,7 @@ def libs(built):
     return amd, ref
 
 
-@pytest.mark.parametrize("mesh", ["cube", "wedge"])
+@pytest.mark.parametrize("mesh", ["cube", "wedge", "coin16"])
 def test_asset_baker_matches_reference(libs, mesh):
     amd, ref = libs
     verts, idx, counts = MESHES[mesh]
@@ -99,7 +117,8 @@ def _random_quat(rng, tilt):
 
 
 @pytest.mark.parametrize("mesh,plane", [("cube", 0), ("cube", 1), ("wedge", 0),
-                                        ("wedge", 1), ("cube", 2), ("wedge", 2)])
+                                        ("wedge", 1), ("cube", 2), ("wedge", 2),
+                                        ("coin16", 0), ("coin16", 1), ("coin16", 2)])
 def test_narrowphase_matches_reference(libs, mesh, plane):
     amd, ref = libs
     verts, idx, counts = MESHES[mesh]
