@@ -56,6 +56,25 @@ struct WedgeMesh {
     uint32_t faceCounts[5] = { 4, 4, 4, 3, 3 };
 };
 
+// An axis-aligned box hull [lo, hi] (same face / winding layout as CubeMesh).
+struct BoxMesh {
+    math::Vector3 positions[8];
+    uint32_t indices[24] = {
+        0, 3, 2, 1,  4, 5, 6, 7,  0, 1, 5, 4,  2, 3, 7, 6,  0, 4, 7, 3,
+        1, 2, 6, 5,
+    };
+    uint32_t faceCounts[6] = { 4, 4, 4, 4, 4, 4 };
+
+    BoxMesh(math::Vector3 lo, math::Vector3 hi)
+        : positions {
+              { lo.x, lo.y, lo.z }, { hi.x, lo.y, lo.z },
+              { hi.x, hi.y, lo.z }, { lo.x, hi.y, lo.z },
+              { lo.x, lo.y, hi.z }, { hi.x, lo.y, hi.z },
+              { hi.x, hi.y, hi.z }, { lo.x, hi.y, hi.z },
+          }
+    {}
+};
+
 // Loaders stay alive for the life of the process: worlds keep pointing at the
 // ObjectManager they own.
 std::vector<std::unique_ptr<PhysicsLoader>> &loaders()
@@ -76,7 +95,20 @@ ObjectManager *loadPhysicsObjects(const SimCreateArgs &args)
 
     CubeMesh cube;
     WedgeMesh wedge;
-    std::array<imp::SourceMesh, 2> hull_meshes {};
+    // the L-shaped block: a bar along x and a post standing on one end
+    BoxMesh bar({ -1.f, -0.3f, -0.5f }, { 1.f, 0.3f, 0.1f });
+    BoxMesh post({ 0.4f, -0.3f, 0.1f }, { 1.f, 0.3f, 0.9f });
+    std::array<imp::SourceMesh, 4> hull_meshes {};
+    hull_meshes[2].positions = bar.positions;
+    hull_meshes[2].indices = bar.indices;
+    hull_meshes[2].faceCounts = bar.faceCounts;
+    hull_meshes[2].numVertices = 8;
+    hull_meshes[2].numFaces = 6;
+    hull_meshes[3].positions = post.positions;
+    hull_meshes[3].indices = post.indices;
+    hull_meshes[3].faceCounts = post.faceCounts;
+    hull_meshes[3].numVertices = 8;
+    hull_meshes[3].numFaces = 6;
     hull_meshes[0].positions = cube.positions;
     hull_meshes[0].indices = cube.indices;
     hull_meshes[0].faceCounts = cube.faceCounts;
@@ -109,6 +141,17 @@ ObjectManager *loadPhysicsObjects(const SimCreateArgs &args)
     setup_hull(SimObject::Ramp, 1, 0.05f, { 0.6f, 0.8f });
     setup_hull(SimObject::Wall, 0, 0.f, { 0.5f, 0.5f });
     setup_hull(SimObject::Agent, 0, 1.f, { 0.5f, 0.5f });
+
+    std::array<SourceCollisionPrimitive, 2> l_prims {};
+    for (uint32_t i = 0; i < 2; i++) {
+        l_prims[i].type = CollisionPrimitive::Type::Hull;
+        l_prims[i].hullInput.hullIDX = 2 + i;
+    }
+    objs[(size_t)SimObject::LBlock] = SourceCollisionObject {
+        Span<const SourceCollisionPrimitive>(l_prims.data(), 2),
+        0.08f,
+        { 0.5f, 0.75f },
+    };
 
     {
         SourceCollisionPrimitive &prim = prims[(size_t)SimObject::Plane];

@@ -180,12 +180,20 @@ static void generateLevel(Engine &ctx, RNG &rng)
         }
         int32_t quarter = is_long ? rng.sampleI32(0, 2) : 0;
 
-        setupRigidBody(ctx, box, pos,
-            Quat { kQuarterW[quarter], 0.f, 0.f, kQuarterZ[quarter] },
-            is_long ? SimObject::LongBox : SimObject::Box, EntityType::Box,
-            ResponseType::Dynamic,
-            is_long ? Diag3x3 { 3.f, 1.2f, 1.5f } :
-                      Diag3x3 { 1.5f, 1.5f, 1.5f });
+        if (i == consts::numBoxes - 1) {
+            // the last "box" is an L-shaped compound of two hulls
+            setupRigidBody(ctx, box, pos,
+                Quat { kQuarterW[quarter], 0.f, 0.f, kQuarterZ[quarter] },
+                SimObject::LBlock, EntityType::Box, ResponseType::Dynamic,
+                Diag3x3 { 1.4f, 1.4f, 1.4f });
+        } else {
+            setupRigidBody(ctx, box, pos,
+                Quat { kQuarterW[quarter], 0.f, 0.f, kQuarterZ[quarter] },
+                is_long ? SimObject::LongBox : SimObject::Box, EntityType::Box,
+                ResponseType::Dynamic,
+                is_long ? Diag3x3 { 3.f, 1.2f, 1.5f } :
+                          Diag3x3 { 1.5f, 1.5f, 1.5f });
+        }
         ctx.get<LockState>(box) = LockState { 0, 0 };
         level.boxes[i] = box;
     }

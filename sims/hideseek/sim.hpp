@@ -80,6 +80,7 @@ enum class SimObject : int32_t {
     Wall,
     Agent,
     Plane,
+    LBlock,     // a box made of two hull primitives (rays meet both)
     NumObjects,
 };
 
