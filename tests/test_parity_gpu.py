@@ -297,6 +297,24 @@ def test_hip_matches_golden(built, name):
                     assert np.array_equal(rows, gold[f"s{step}/{col}/rows"]), (step, col)
 
 
+# ---- 2b. lock step at BASELINE's full sizes -------------------------------------
+@pytest.mark.parametrize("sim,worlds,steps,agents", [
+    ("escape_room", 4096, 300, 2),          # BASELINE configs[1]
+    ("escape_room_phys", 8192, 120, 2),     # configs[2]
+    ("hideseek", 8192, 120, 5),             # configs[3], one GPU's share
+])
+def test_full_size_lockstep(built, sim, worlds, steps, agents):
+    """The bench workloads themselves, every dumped column bit for bit against
+    the reference CPU backend on all host cores (size-independent properties
+    further down cover what a comparison cannot: id uniqueness etc.)."""
+    _need_ref(sim)
+    probs, step = run_pair(sim, worlds, steps, flags=200, check_every=20,
+                           actions=_escape_actions(77, grab=sim != "escape_room",
+                                                   agents=agents),
+                           check_init=False, ref_workers=0)
+    assert not probs, (step, probs[:3])
+
+
 # ---- 3. full-size properties -----------------------------------------------------
 def _check_entity_columns(dump, archetypes):
     """ids unique across archetypes, none destroyed, worlds contiguous."""
