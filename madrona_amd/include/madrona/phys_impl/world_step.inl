@@ -25,12 +25,6 @@
 
 using namespace narrowphase;
 
-#ifdef MADRONA_PHYS_NOINLINE_NARROWPHASE
-#define MADRONA_PHYS_NP_INLINE __attribute__((noinline))
-#else
-#define MADRONA_PHYS_NP_INLINE inline
-#endif
-
 namespace wave {
 
 __device__ inline uint32_t laneID()
@@ -240,14 +234,10 @@ __device__ inline bool hullHullWaveSAT(uint32_t lane, const PairSetup &pair,
 
 // Hull-hull pair handled by the whole wave (`pair` is wave-uniform).  Returns
 // false with *too_big set when the clipped polygon may not fit the LDS scratch.
-// (A template so that only the device pass instantiates it; optionally kept out
-// of line to confine its register footprint: MADRONA_PHYS_OUTLINE_HULLHULL.)
+// (A template so that only the device pass instantiates it.  Keeping it out of
+// line to confine its register footprint was measured: 1166 -> 1637 us.)
 template <int = 0>
-#ifdef MADRONA_PHYS_OUTLINE_HULLHULL
-__device__ __attribute__((noinline)) bool
-#else
 __device__ inline bool
-#endif
 hullHullWave(uint32_t lane, const PairSetup &pair,
                                     WaveScratch *scratch,
                                     ContactConstraint *out, bool *too_big)
@@ -1090,13 +1080,8 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
             prim_end = end > prim_end ? end : prim_end;
         }
         prim_end = wave::maxReduce(prim_end);
-#ifdef MADRONA_PHYS_NO_STAGE_PRIMS
-        const ObjectManager obj_mgr = hbm_obj_mgr;
-        (void)prim_end;
-#else
         const ObjectManager obj_mgr =
             stagePrimitives(lane, w, hbm_obj_mgr, prim_end);
-#endif
 
         // ---- broadphase: candidate pairs in (body, traversal) order -----------
         // lane = body; one pass over the slot boxes in traversal order leaves a
