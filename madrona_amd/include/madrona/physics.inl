@@ -328,11 +328,34 @@ Entity BVH::traceRay(math::Vector3 o,
         for (int32_t base = 0; base < n; base += 64) {
             const int32_t window = n - base < 64 ? n - base : 64;
 
+            // (boxes fetched a group at a time: leaf index -> parent slot ->
+            // box is three dependent round trips, paid once per group)
             uint64_t candidates = 0;
-            for (int32_t j = 0; j < window; j++) {
-                AABB box = leafSlotBounds(dfs_leaves_[base + j]);
-                const bool hit = box.rayIntersects(o, inv_d, 0.f, t_max);
-                candidates |= (uint64_t)hit << j;
+            constexpr int32_t group = 8;
+            for (int32_t g = 0; g < window; g += group) {
+                int32_t leaf[group];
+MADRONA_UNROLL
+                for (int32_t k = 0; k < group; k++) {
+                    const int32_t j = g + k < window ? g + k : window - 1;
+                    leaf[k] = dfs_leaves_[base + j];
+                }
+                uint32_t parent[group];
+MADRONA_UNROLL
+                for (int32_t k = 0; k < group; k++) {
+                    parent[k] = leaf_parents_[leaf[k]];
+                }
+                AABB box[group];
+MADRONA_UNROLL
+                for (int32_t k = 0; k < group; k++) {
+                    box[k] = nodes_[parent[k] >> 2].bounds(
+                        (CountT)(parent[k] & 3u));
+                }
+MADRONA_UNROLL
+                for (int32_t k = 0; k < group; k++) {
+                    const bool hit = g + k < window &&
+                        box[k].rayIntersects(o, inv_d, 0.f, t_max);
+                    candidates |= (uint64_t)hit << ((g + k) & 63);
+                }
             }
 
             while (candidates != 0) {
