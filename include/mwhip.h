@@ -117,8 +117,11 @@ int mwhip_raw_copy_d2h(int gpu_id, void *dst_host, const void *src_device,
  * (ecs_state::moduleData[slot], slot < 4); e.g. the physics module's scratch. */
 int mwhip_set_module_data(mwhip_exec *exec, uint32_t slot, void *device_ptr);
 void *mwhip_get_module_data(mwhip_exec *exec, uint32_t slot);
-/* rows every column of the archetype's table can hold */
+/* rows every column of the archetype's table can ever hold (the address space
+ * reserved for it; memory is mapped behind it as the table grows) */
 uint32_t mwhip_archetype_capacity(mwhip_exec *exec, uint32_t archetype_id);
+/* how many times a table has been grown so far (tests / monitoring) */
+uint32_t mwhip_num_table_growths(mwhip_exec *exec);
 /* device address of the archetype's table header (mwhip::TableHdr) */
 void *mwhip_table_header(mwhip_exec *exec, uint32_t archetype_id);
 /* copies `count` words of the query table starting at `offset` */

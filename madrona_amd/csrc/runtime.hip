@@ -292,6 +292,21 @@ struct ComponentRec {
     uint32_t bytes = 0;
 };
 
+// Growable device memory: address space reserved up front
+// (hipMemAddressReserve), backed 2 MiB at a time (hipMemCreate / hipMemMap), so
+// a table can grow without any pointer into it changing -- the reference's GPU
+// backend does the same through its host allocator thread (memory.cpp:20-178,
+// cuda_exec.cpp:1603-1719).  One handle per 2 MiB chunk: the granule on which
+// map + set-access behaved on this ROCm (larger or mixed chunk sizes returned
+// hipErrorInvalidValue from hipMemSetAccess).
+struct VmRange {
+    char *base = nullptr;
+    size_t reserved = 0;
+    size_t mapped = 0;
+    std::vector<hipMemGenericAllocationHandle_t> chunks;
+};
+static constexpr size_t kVmChunk = (size_t)2 << 20;
+
 struct ArchetypeRec {
     bool registered = false;
     uint32_t id = 0;
@@ -300,11 +315,15 @@ struct ArchetypeRec {
     uint32_t maxPerWorld = 0;
     bool singleton = false;
     int32_t singletonOrdinal = -1;
-    uint32_t capacity = 0;
+    uint32_t capacity = 0;              // rows backed by memory right now
+    uint32_t reservedCapacity = 0;      // rows the address space allows
     uint32_t numColumns = 0;
     uint32_t rowBytes = 0;
     std::vector<void *> primary;
     std::vector<void *> alt;
+    // growable archetypes: the ranges behind primary / alt / sort buffers
+    std::vector<VmRange *> primaryVm, altVm;
+    VmRange *sortVm[4] = { nullptr, nullptr, nullptr, nullptr };
     std::vector<uint32_t> colBytes;
     std::vector<uint32_t> colFlags;
     std::vector<uint32_t> colComponent;
@@ -344,6 +363,7 @@ struct LaunchGraph {
     hipGraphExec_t graphExec = nullptr;
     std::string statName;
     std::vector<std::string> statNames;     // backing store for mwhip_kernel_stat::name
+    std::vector<uint32_t> taskGraphIds;     // to rebuild after a table grew
 };
 
 struct mwhip_exec {
@@ -377,6 +397,9 @@ struct mwhip_exec {
 
     int32_t *statsHost = nullptr;           // pinned, device-visible
     std::vector<void *> allocations;
+    std::vector<std::unique_ptr<VmRange>> vmRanges;
+    uint32_t tableGrowth = 1;               // reserved / initial rows
+    uint32_t numGrowths = 0;
     bool checkAfterRun = true;
     bool sortBatching = true;
 };
@@ -397,6 +420,66 @@ template <typename T>
 static int devAllocT(mwhip_exec *exec, T **out, size_t count, bool zero = true)
 {
     return devAlloc(exec, (void **)out, count * sizeof(T), zero);
+}
+
+static int vmEnsure(mwhip_exec *exec, VmRange &r, size_t bytes, bool zero)
+{
+    bytes = (bytes + kVmChunk - 1) / kVmChunk * kVmChunk;
+    if (bytes > r.reserved) {
+        return fail(-4, "growable range: %zu bytes requested, %zu reserved",
+                    bytes, r.reserved);
+    }
+
+    hipMemAllocationProp prop {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = exec->cfg.gpu_id;
+    hipMemAccessDesc access {};
+    access.location = prop.location;
+    access.flags = hipMemAccessFlagsProtReadWrite;
+
+    while (r.mapped < bytes) {
+        hipMemGenericAllocationHandle_t chunk;
+        HIPCHK(hipMemCreate(&chunk, kVmChunk, &prop, 0));
+        HIPCHK(hipMemMap(r.base + r.mapped, kVmChunk, 0, chunk, 0));
+        HIPCHK(hipMemSetAccess(r.base + r.mapped, kVmChunk, &access, 1));
+        if (zero) {
+            HIPCHK(hipMemset(r.base + r.mapped, 0, kVmChunk));
+        }
+        r.chunks.push_back(chunk);
+        r.mapped += kVmChunk;
+    }
+    return 0;
+}
+
+static int vmAlloc(mwhip_exec *exec, void **out, VmRange **range_out,
+                   size_t reserve_bytes, size_t map_bytes, bool zero)
+{
+    std::unique_ptr<VmRange> r(new VmRange {});
+    r->reserved = (reserve_bytes + kVmChunk - 1) / kVmChunk * kVmChunk;
+    void *base = nullptr;
+    HIPCHK(hipMemAddressReserve(&base, r->reserved, kVmChunk, nullptr, 0));
+    r->base = (char *)base;
+    exec->vmRanges.push_back(std::move(r));
+    VmRange *range = exec->vmRanges.back().get();
+
+    int rc = vmEnsure(exec, *range, map_bytes, zero);
+    if (rc != 0) return rc;
+    *out = range->base;
+    *range_out = range;
+    return 0;
+}
+
+static void vmFreeAll(mwhip_exec *exec)
+{
+    for (auto &r : exec->vmRanges) {
+        for (size_t i = 0; i < r->chunks.size(); i++) {
+            (void)hipMemUnmap(r->base + i * kVmChunk, kVmChunk);
+            (void)hipMemRelease(r->chunks[i]);
+        }
+        (void)hipMemAddressFree(r->base, r->reserved);
+    }
+    exec->vmRanges.clear();
 }
 
 // ---------------------------------------------------------------------------
@@ -512,7 +595,21 @@ extern "C" int mwhip_register_archetype(mwhip_exec *exec, uint32_t id,
     if (capacity > 0x7FFFFFF0ull) {
         return fail(-2, "archetype %u capacity overflow", id);
     }
+    // Tables whose row count is not pinned to one per world can grow: address
+    // space for tableGrowth x the initial rows (MADRONA_MWHIP_TABLE_GROWTH,
+    // default 4; 1 = plain allocations), see growTables().
+    uint64_t reserved = capacity;
+    if (max_per_world != 1 && exec->tableGrowth > 1) {
+        reserved = std::min<uint64_t>(capacity * exec->tableGrowth, 0x7FFFFFF0ull);
+        // (test hook) start smaller than the rows the simulator declared
+        if (const char *div = getenv("MADRONA_MWHIP_INITIAL_CAPACITY_DIV")) {
+            uint64_t d = strtoull(div, nullptr, 10);
+            if (d > 1) capacity = std::max<uint64_t>(capacity / d, 64);
+        }
+    }
     arch.capacity = (uint32_t)capacity;
+    arch.reservedCapacity = (uint32_t)reserved;
+    const bool growable = reserved > capacity;
 
     // column 0 = Entity, column 1 = WorldID, then user components
     // (reference src/mw/device/state.cpp:269-341)
@@ -529,9 +626,22 @@ extern "C" int mwhip_register_archetype(mwhip_exec *exec, uint32_t id,
     arch.primary.resize(arch.numColumns);
     arch.alt.resize(arch.numColumns);
     arch.colFlags.assign(arch.numColumns, 0u);
+    arch.primaryVm.assign(arch.numColumns, nullptr);
+    arch.altVm.assign(arch.numColumns, nullptr);
     for (uint32_t c = 0; c < arch.numColumns; c++) {
         arch.rowBytes += arch.colBytes[c];
         size_t bytes = (size_t)arch.capacity * arch.colBytes[c] + 16;
+        if (growable) {
+            size_t max_bytes =
+                (size_t)arch.reservedCapacity * arch.colBytes[c] + 16;
+            rc = vmAlloc(exec, &arch.primary[c], &arch.primaryVm[c], max_bytes,
+                         bytes, true);
+            if (rc != 0) return rc;
+            rc = vmAlloc(exec, &arch.alt[c], &arch.altVm[c], max_bytes, bytes,
+                         true);
+            if (rc != 0) return rc;
+            continue;
+        }
         rc = devAlloc(exec, &arch.primary[c], bytes);
         if (rc != 0) return rc;
         rc = devAlloc(exec, &arch.alt[c], bytes);
@@ -743,7 +853,7 @@ extern "C" uint32_t mwhip_archetype_capacity(mwhip_exec *exec,
             !exec->archetypes[archetype_id].registered) {
         return 0;
     }
-    return exec->archetypes[archetype_id].capacity;
+    return exec->archetypes[archetype_id].reservedCapacity;
 }
 
 extern "C" void *mwhip_table_header(mwhip_exec *exec, uint32_t archetype_id)
@@ -1014,15 +1124,28 @@ static int ensureSortScratch(mwhip_exec *exec, ArchetypeRec &arch)
 
     int rc = devAllocT(exec, &arch.sortState, 1);
     if (rc != 0) return rc;
-    rc = devAllocT(exec, &arch.keysA, arch.capacity, false);
-    if (rc != 0) return rc;
-    rc = devAllocT(exec, &arch.keysB, arch.capacity, false);
-    if (rc != 0) return rc;
-    rc = devAllocT(exec, &arch.idxA, arch.capacity, false);
-    if (rc != 0) return rc;
-    rc = devAllocT(exec, &arch.idxB, arch.capacity, false);
-    if (rc != 0) return rc;
-    size_t tiles = (arch.capacity + sortTileSize() - 1) / sortTileSize();
+    if (arch.reservedCapacity > arch.capacity) {
+        void **bufs[4] = { (void **)&arch.keysA, (void **)&arch.keysB,
+                           (void **)&arch.idxA, (void **)&arch.idxB };
+        for (int i = 0; i < 4; i++) {
+            rc = vmAlloc(exec, bufs[i], &arch.sortVm[i],
+                         (size_t)arch.reservedCapacity * 4,
+                         (size_t)arch.capacity * 4, false);
+            if (rc != 0) return rc;
+        }
+    } else {
+        rc = devAllocT(exec, &arch.keysA, arch.capacity, false);
+        if (rc != 0) return rc;
+        rc = devAllocT(exec, &arch.keysB, arch.capacity, false);
+        if (rc != 0) return rc;
+        rc = devAllocT(exec, &arch.idxA, arch.capacity, false);
+        if (rc != 0) return rc;
+        rc = devAllocT(exec, &arch.idxB, arch.capacity, false);
+        if (rc != 0) return rc;
+    }
+    // (look-back slots for every tile the table can ever have)
+    size_t tiles =
+        (arch.reservedCapacity + sortTileSize() - 1) / sortTileSize();
     rc = devAllocT(exec, &arch.lookback, tiles * 256);
     return rc;
 }
@@ -1561,6 +1684,7 @@ extern "C" int mwhip_create(const mwhip_state_config *cfg,
     exec->taskGraphs.resize(cfg->num_task_graphs);
     exec->checkAfterRun = envU32("MADRONA_MWHIP_CHECK", 1) != 0;
     exec->sortBatching = envU32("MADRONA_MWHIP_SORT_BATCH", 1) != 0;
+    exec->tableGrowth = std::max(envU32("MADRONA_MWHIP_TABLE_GROWTH", 4), 1u);
     HIPCHK(hipStreamCreateWithFlags(&exec->stream, hipStreamNonBlocking));
 
     // ---- registerTypes (host) -------------------------------------------------
@@ -1613,6 +1737,7 @@ extern "C" void mwhip_destroy(mwhip_exec *exec)
     for (void *p : exec->allocations) {
         (void)hipFree(p);
     }
+    vmFreeAll(exec);
     if (exec->statsHost) (void)hipHostFree(exec->statsHost);
     (void)hipStreamDestroy(exec->stream);
     delete exec;
@@ -1726,6 +1851,112 @@ static int topoSort(TaskGraphRec &tg)
 // ---------------------------------------------------------------------------
 // launch graphs
 // ---------------------------------------------------------------------------
+// Launch list (grids sized from the tables' current capacities) + hipGraph.
+static int instantiateLaunchGraph(mwhip_exec *exec,
+                                  const std::vector<uint32_t> &ids,
+                                  const std::string &stat_name,
+                                  std::unique_ptr<LaunchGraph> &out)
+{
+    std::unique_ptr<LaunchGraph> lg(new LaunchGraph {});
+    lg->statName = stat_name;
+    lg->taskGraphIds = ids;
+    int rc = buildLaunchList(exec, ids, *lg);
+    if (rc != 0) return rc;
+
+    HIPCHK(hipStreamBeginCapture(exec->stream, hipStreamCaptureModeThreadLocal));
+    for (KernelLaunch &k : lg->launches) {
+        rc = launchOne(exec, k, exec->stream);
+        if (rc != 0) {
+            hipGraph_t dead = nullptr;
+            (void)hipStreamEndCapture(exec->stream, &dead);
+            if (dead) (void)hipGraphDestroy(dead);
+            return rc;
+        }
+    }
+    HIPCHK(hipStreamEndCapture(exec->stream, &lg->graph));
+    HIPCHK(hipGraphInstantiate(&lg->graphExec, lg->graph, nullptr, nullptr, 0));
+    out = std::move(lg);
+    return 0;
+}
+
+// Table growth, between replays (the stream is idle).  A table whose live rows
+// fill more than half of its backed capacity gets more memory mapped behind
+// every column (primary and ping-pong twin) and behind its sort buffers --
+// addresses do not change --, the capacity in its device header is raised, and
+// the launch graphs are rebuilt so that grids follow the new size.  Half,
+// because rows destroyed and re-created in one step coexist until the step's
+// compaction; a single step that outruns the head room still raises
+// kErrTableOverflow, as a fixed-capacity table does.
+// rows_of(a) = live rows of archetype a, or -1.
+template <typename RowsFn>
+static int growTables(mwhip_exec *exec, RowsFn &&rows_of)
+{
+    bool grew = false;
+    for (uint32_t a = 0; a < exec->archetypes.size(); a++) {
+        ArchetypeRec &arch = exec->archetypes[a];
+        if (!arch.registered || arch.reservedCapacity <= arch.capacity) {
+            continue;
+        }
+        int64_t rows = rows_of(a);
+        if (rows < 0 || 2 * rows <= (int64_t)arch.capacity) {
+            continue;
+        }
+
+        uint64_t new_capacity = std::max<uint64_t>(2ull * arch.capacity,
+                                                   3ull * (uint64_t)rows);
+        new_capacity = std::min<uint64_t>(new_capacity, arch.reservedCapacity);
+        if (!grew) {
+            HIPCHK(hipStreamSynchronize(exec->stream));
+        }
+
+        for (uint32_t c = 0; c < arch.numColumns; c++) {
+            size_t bytes = (size_t)new_capacity * arch.colBytes[c] + 16;
+            int rc = vmEnsure(exec, *arch.primaryVm[c], bytes, true);
+            if (rc != 0) return rc;
+            rc = vmEnsure(exec, *arch.altVm[c], bytes, true);
+            if (rc != 0) return rc;
+        }
+        for (VmRange *r : arch.sortVm) {
+            if (r != nullptr) {
+                int rc = vmEnsure(exec, *r, (size_t)new_capacity * 4, false);
+                if (rc != 0) return rc;
+            }
+        }
+
+        arch.capacity = (uint32_t)new_capacity;
+        exec->tablesHost[a].capacity = (int32_t)new_capacity;
+        int32_t cap = (int32_t)new_capacity;
+        HIPCHK(hipMemcpy((char *)(exec->hostState.tables + a) +
+                             offsetof(TableHdr, capacity),
+                         &cap, sizeof(cap), hipMemcpyHostToDevice));
+        exec->numGrowths++;
+        grew = true;
+    }
+
+    if (!grew) {
+        return 0;
+    }
+
+    for (auto &kv : exec->launchGraphs) {
+        std::unique_ptr<LaunchGraph> fresh;
+        int rc = instantiateLaunchGraph(exec, kv.second->taskGraphIds,
+                                        kv.second->statName, fresh);
+        if (rc != 0) return rc;
+        if (kv.second->graphExec) (void)hipGraphExecDestroy(kv.second->graphExec);
+        if (kv.second->graph) (void)hipGraphDestroy(kv.second->graph);
+        kv.second = std::move(fresh);
+    }
+    return 0;
+}
+
+// row counts the last completed replay reported (statsKernel)
+static int growTablesAfterReplay(mwhip_exec *exec)
+{
+    return growTables(exec, [exec](uint32_t a) -> int64_t {
+        return a < kMaxArchetypes ? exec->statsHost[2 + a] : -1;
+    });
+}
+
 extern "C" int mwhip_build_launch_graph(mwhip_exec *exec,
                                         const uint32_t *taskgraph_ids,
                                         uint32_t num_taskgraphs,
@@ -1745,23 +1976,22 @@ extern "C" int mwhip_build_launch_graph(mwhip_exec *exec,
         }
     }
 
-    std::unique_ptr<LaunchGraph> lg(new LaunchGraph {});
-    lg->statName = stat_name != nullptr ? stat_name : "";
-    int rc = buildLaunchList(exec, ids, *lg);
-    if (rc != 0) return rc;
-
-    HIPCHK(hipStreamBeginCapture(exec->stream, hipStreamCaptureModeThreadLocal));
-    for (KernelLaunch &k : lg->launches) {
-        rc = launchOne(exec, k, exec->stream);
-        if (rc != 0) {
-            hipGraph_t dead = nullptr;
-            (void)hipStreamEndCapture(exec->stream, &dead);
-            if (dead) (void)hipGraphDestroy(dead);
-            return rc;
-        }
+    // the worlds have been constructed: size the tables for what they hold
+    {
+        HIPCHK(hipStreamSynchronize(exec->stream));
+        std::vector<TableHdr> hdrs(exec->tablesHost.size());
+        HIPCHK(hipMemcpy(hdrs.data(), exec->hostState.tables,
+                         hdrs.size() * sizeof(TableHdr), hipMemcpyDeviceToHost));
+        int rc = growTables(exec, [&hdrs](uint32_t a) -> int64_t {
+            return a < hdrs.size() ? hdrs[a].numRows : -1;
+        });
+        if (rc != 0) return rc;
     }
-    HIPCHK(hipStreamEndCapture(exec->stream, &lg->graph));
-    HIPCHK(hipGraphInstantiate(&lg->graphExec, lg->graph, nullptr, nullptr, 0));
+
+    std::unique_ptr<LaunchGraph> lg;
+    int rc = instantiateLaunchGraph(exec, ids,
+                                    stat_name != nullptr ? stat_name : "", lg);
+    if (rc != 0) return rc;
 
     uint64_t handle = exec->nextGraphHandle++;
     exec->launchGraphs[handle] = std::move(lg);
@@ -1797,7 +2027,9 @@ extern "C" int mwhip_run(mwhip_exec *exec, uint64_t graph)
     }
     HIPCHK(hipGraphLaunch(it->second->graphExec, exec->stream));
     HIPCHK(hipStreamSynchronize(exec->stream));
-    return checkHealth(exec);
+    int rc = checkHealth(exec);
+    if (rc != 0) return rc;
+    return growTablesAfterReplay(exec);
 }
 
 extern "C" int mwhip_run_async(mwhip_exec *exec, uint64_t graph, void *hip_stream)
@@ -1806,17 +2038,28 @@ extern "C" int mwhip_run_async(mwhip_exec *exec, uint64_t graph, void *hip_strea
     if (it == exec->launchGraphs.end()) {
         return fail(-3, "unknown launch graph");
     }
-    // health of the *previous* completed replay
+    // health (and table sizes) as of the last completed replay
     int rc = checkHealth(exec);
     if (rc != 0) return rc;
+    rc = growTablesAfterReplay(exec);
+    if (rc != 0) return rc;
+    // (growing rebuilds the graphs: look the handle up again)
+    it = exec->launchGraphs.find(graph);
     HIPCHK(hipGraphLaunch(it->second->graphExec, (hipStream_t)hip_stream));
     return 0;
+}
+
+extern "C" uint32_t mwhip_num_table_growths(mwhip_exec *exec)
+{
+    return exec->numGrowths;
 }
 
 extern "C" int mwhip_synchronize(mwhip_exec *exec)
 {
     HIPCHK(hipStreamSynchronize(exec->stream));
-    return checkHealth(exec);
+    int rc = checkHealth(exec);
+    if (rc != 0) return rc;
+    return growTablesAfterReplay(exec);
 }
 
 // ---------------------------------------------------------------------------
