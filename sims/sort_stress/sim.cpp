@@ -55,6 +55,9 @@ inline void churnSystem(Engine &ctx, Churn &churn)
     RNG &rng = sim.rng;
 
     int32_t num_destroy = rng.sampleI32(0, consts::maxChurn + 1);
+    if (sim.rampUp != 0 && sim.numItems < consts::maxItems) {
+        num_destroy = 0;
+    }
     for (int32_t i = 0; i < num_destroy && sim.numItems > 0; i++) {
         int32_t victim = rng.sampleI32(0, sim.numItems);
         ctx.destroyEntity(sim.items[victim]);
@@ -132,6 +135,7 @@ Sim::Sim(Engine &ctx, const Config &cfg, const WorldInit &)
     uint32_t global_world = cfg.worldBase + (uint32_t)ctx.worldID().idx;
     rng = RNG(rand::split_i(rand::initKey(cfg.seed), global_world));
     mixIds = cfg.coldStart == 0 ? 1u : 0u;
+    rampUp = cfg.rampUp;
     numItems = 0;
 
     Churn &churn = ctx.singleton<Churn>();
@@ -142,6 +146,9 @@ Sim::Sim(Engine &ctx, const Config &cfg, const WorldInit &)
     int32_t initial = cfg.coldStart != 0 ?
         (int32_t)((global_world * 7u) % (uint32_t)consts::maxItems) :
         1 + (int32_t)((global_world * 7u) % (uint32_t)(consts::maxItems - 1));
+    if (cfg.rampUp != 0) {
+        initial = 1;
+    }
     for (int32_t i = 0; i < initial; i++) {
         Entity e = ctx.makeEntity<Item>();
         fillItem(ctx, e, rng);

@@ -57,6 +57,9 @@ struct Sim : public madrona::WorldBase {
         // 1: some worlds start empty and take their first block of entity ids
         // at run time (ids are then executor-specific; values avoid them)
         uint32_t coldStart;
+        // 1: every world starts with one item and only creates until it is
+        // full (a population that builds up at run time: table growth)
+        uint32_t rampUp;
     };
 
     struct WorldInit {};
@@ -70,6 +73,7 @@ struct Sim : public madrona::WorldBase {
 
     RNG rng;
     uint32_t mixIds;
+    uint32_t rampUp;
     int32_t numItems;
     Entity items[consts::maxItems];
 };

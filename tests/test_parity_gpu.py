@@ -489,6 +489,7 @@ def test_tables_grow_in_place(built, monkeypatch, sim, div):
         rt.mwhip_num_table_growths.restype = C.c_uint32
         rt.mwhip_num_table_growths.argtypes = [C.c_void_p]
         first_ptrs = {n: hip.tensor_ptr(n) for n in hip.tensor_names}
+        grown_at_start = rt.mwhip_num_table_growths(hip.hip_exec())
         feed = _escape_actions(3, grab=sim == "escape_room_phys") \
             if sim.startswith("escape_room") else None
         for s in range(1, steps + 1):
@@ -499,8 +500,34 @@ def test_tables_grow_in_place(built, monkeypatch, sim, div):
             if s % 10 == 0 or s == steps:
                 probs = compare_columns(ref.dump_all(), hip.dump_all())
                 assert not probs, (s, probs[:3])
-        assert rt.mwhip_num_table_growths(hip.hip_exec()) > 0, "nothing grew"
+        grown = rt.mwhip_num_table_growths(hip.hip_exec())
+        assert grown > 0 and grown >= grown_at_start, "nothing grew"
         assert first_ptrs == {n: hip.tensor_ptr(n) for n in hip.tensor_names}
         for name in ref.tensor_names:
             assert np.array_equal(ref.read_tensor(name).view(np.uint8),
                                   hip.read_tensor(name).view(np.uint8)), name
+
+
+def test_tables_grow_between_replays(built, monkeypatch):
+    """Growth while stepping (not only after construction): sort_stress in its
+    ramp-up mode -- every world starts with one item and creates up to six per
+    step until it holds 40 -- with tables mapped for a quarter of what the
+    simulator declared.  Everything stays bit-identical to the reference."""
+    import ctypes as C
+    from madrona_amd.simlib import runtime_lib
+    _need_ref("sort_stress")
+    monkeypatch.setenv("MADRONA_MWHIP_INITIAL_CAPACITY_DIV", "4")
+    W, steps = 300, 60
+    with Simulator(ref_lib_path("sort_stress"), W, seed=7, num_workers=1, flags=2) as r, \
+            Simulator(hip_lib_path("sort_stress"), W, seed=7, flags=2) as h:
+        rt = runtime_lib()
+        rt.mwhip_num_table_growths.restype = C.c_uint32
+        rt.mwhip_num_table_growths.argtypes = [C.c_void_p]
+        grown_at_start = rt.mwhip_num_table_growths(h.hip_exec())
+        for s in range(1, steps + 1):
+            r.step(1)
+            h.step(1)
+            if s % 5 == 0:
+                probs = compare_columns(r.dump_all(), h.dump_all())
+                assert not probs, (s, probs[:3])
+        assert rt.mwhip_num_table_growths(h.hip_exec()) >= grown_at_start + 2
