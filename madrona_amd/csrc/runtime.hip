@@ -2041,8 +2041,12 @@ extern "C" int mwhip_run_async(mwhip_exec *exec, uint64_t graph, void *hip_strea
     // health (and table sizes) as of the last completed replay
     int rc = checkHealth(exec);
     if (rc != 0) return rc;
-    rc = growTablesAfterReplay(exec);
-    if (rc != 0) return rc;
+    // (only on the executor's own stream: growing waits for that stream to
+    // drain; replays queued on a caller's stream grow at mwhip_synchronize)
+    if ((hipStream_t)hip_stream == exec->stream) {
+        rc = growTablesAfterReplay(exec);
+        if (rc != 0) return rc;
+    }
     // (growing rebuilds the graphs: look the handle up again)
     it = exec->launchGraphs.find(graph);
     HIPCHK(hipGraphLaunch(it->second->graphExec, (hipStream_t)hip_stream));
