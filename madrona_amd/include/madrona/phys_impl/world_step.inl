@@ -739,11 +739,12 @@ physicsStepKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
 // and worlds that exceed it raise kErrPhysics.
 // ===========================================================================
 // candidate pair of the LDS step: body indices inside the world
+// (4 bytes: MAXB <= 128 bodies, < 256 primitives per object)
 struct WaveCandidate {
-    uint16_t a;
-    uint16_t b;
-    uint16_t aPrim;
-    uint16_t bPrim;
+    uint8_t a;
+    uint8_t b;
+    uint8_t aPrim;
+    uint8_t bPrim;
 };
 
 template <int MAXB>
@@ -751,7 +752,9 @@ struct WorldBlock {
     static constexpr int maxBodies = MAXB;
     // sized so that a 32-body block stays under 16 KB of LDS: four
     // single-wave workgroups per CU, as many as the register file admits
-    static constexpr int maxCandidates = MAXB * 3;
+    // (a dense pile of n bodies has up to n (n - 1) / 2 candidate pairs: six
+    // per body covers a 19-body pile with every pair overlapping)
+    static constexpr int maxCandidates = MAXB * 6;
     // (at least a wave's worth: the narrowphase stages one contact per lane)
     static constexpr int maxContacts =
         MAXB + MAXB / 4 > 64 ? MAXB + MAXB / 4 : 64;
@@ -1146,9 +1149,9 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                         const uint32_t total_checks = a_prims * b_prims;
                         for (uint32_t c = 0; c < total_checks; c++) {
                             w->candidates[out++] = WaveCandidate {
-                                (uint16_t)k, (uint16_t)kb,
-                                (uint16_t)(c / b_prims),
-                                (uint16_t)(c % b_prims),
+                                (uint8_t)k, (uint8_t)kb,
+                                (uint8_t)(c / b_prims),
+                                (uint8_t)(c % b_prims),
                             };
                         }
                     }

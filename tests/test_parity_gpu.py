@@ -315,6 +315,24 @@ def test_full_size_lockstep(built, sim, worlds, steps, agents):
     assert not probs, (step, probs[:3])
 
 
+@pytest.mark.parametrize("seed", [11, 101])
+@pytest.mark.parametrize("sim,agents,steps,denom", [
+    ("escape_room", 2, 200, 60), ("escape_room_phys", 2, 120, 60),
+    ("hideseek", 5, 120, 80), ("ball_pit", 0, 150, 50), ("sort_stress", 0, 80, 0)])
+def test_lockstep_other_seeds(built, sim, agents, steps, denom, seed):
+    """Every simulator again, 1024 worlds, other world seeds and action streams
+    (this sweep is what found the candidate capacity of the LDS step kernel too
+    small for a dense pile: ball_pit, seed 11)."""
+    _need_ref(sim)
+    probs, step = run_pair(
+        sim, 777 if sim == "sort_stress" else 1024, steps, seed=seed,
+        flags=denom, check_every=20,
+        actions=_escape_actions(seed, grab=sim != "escape_room", agents=agents)
+        if agents else None,
+        check_init=False, ref_workers=0)
+    assert not probs, (step, probs[:3])
+
+
 # ---- 3. full-size properties -----------------------------------------------------
 def _check_entity_columns(dump, archetypes):
     """ids unique across archetypes, none destroyed, worlds contiguous."""
