@@ -252,6 +252,36 @@ int64_t mwhip_dump_column(mwhip_exec *exec, uint32_t archetype_id,
 int mwhip_memcpy_d2h(void *dst_host, const void *src_dev, uint64_t num_bytes);
 int mwhip_memcpy_h2d(void *dst_dev, const void *src_host, uint64_t num_bytes);
 
+/* Packs `num_columns` exported columns into one row-major record per row:
+ * dst[row] = column 0's words | column 1's words | ...  (4-byte words;
+ * words_per_row[c] of them from src_columns[c] + row * words_per_row[c]).  Queued
+ * on the executor's stream, i.e. ordered after the replays queued before it --
+ * the send buffer of the one observation all-gather per step of a multi-GPU run
+ * (the reference hands the column itself to ncclAllGather).
+ * Pointers are device pointers; the descriptor arrays are read before the call
+ * returns. */
+#define MWHIP_PACK_MAX_COLUMNS 16
+/* The same packing as the LAST node of a copy of launch graph `base_graph`
+ * (a foreign kernel between two replays costs ~35 us of lost launch
+ * pipelining on this runtime; inside the graph it costs its own ~4 us).
+ * Callers that overlap the collective with the next replay build two such
+ * graphs, one per send buffer, and alternate. */
+int mwhip_build_launch_graph_with_pack(mwhip_exec *exec, uint64_t base_graph,
+                                       uint32_t num_columns,
+                                       const void *const *src_columns,
+                                       const uint32_t *words_per_row,
+                                       uint32_t num_rows, void *dst,
+                                       uint64_t *graph_out);
+/* Makes `hip_stream` wait for every replay queued so far (mwhip_run_async on
+ * the executor's stream) without putting anything on the executor's stream: the
+ * last kernel of each replay bumps a counter in signal memory that the waiting
+ * stream polls (hipStreamWaitValue32). */
+int mwhip_stream_wait_replays(mwhip_exec *exec, void *hip_stream);
+int mwhip_pack_rows(mwhip_exec *exec, uint32_t num_columns,
+                    const void *const *src_columns,
+                    const uint32_t *words_per_row, uint32_t num_rows,
+                    void *dst);
+
 /* Per-kernel timing with HIP events on the executor's stream (replaces the
  * reference's device tracing, mw_gpu/tracing.hpp).  Runs the launch graph's
  * kernels eagerly `reps` times with an event pair around every kernel. */

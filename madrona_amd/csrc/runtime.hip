@@ -269,7 +269,39 @@ __global__ void gateKernel(int32_t *host_flag)
 }
 
 // End-of-graph health record written straight into pinned host memory.
-__global__ void statsKernel(EcsState *S, int32_t *host_out)
+struct PackArgs {
+    const uint32_t *src[MWHIP_PACK_MAX_COLUMNS];
+    uint32_t words[MWHIP_PACK_MAX_COLUMNS];     // per row, per column
+    uint32_t firstWord[MWHIP_PACK_MAX_COLUMNS]; // of the column inside a record
+    uint32_t numColumns;
+    uint32_t recordWords;
+    uint32_t numRows;
+};
+
+// One thread per output word (consecutive lanes -> consecutive words of a
+// record: coalesced stores; a column's words of one row are contiguous loads).
+__global__ void __launch_bounds__(256)
+packRowsKernel(PackArgs args, uint32_t *dst)
+{
+    const uint64_t total = (uint64_t)args.numRows * args.recordWords;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+         i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t row = (uint32_t)(i / args.recordWords);
+        const uint32_t w = (uint32_t)(i % args.recordWords);
+        uint32_t c = 0;
+#pragma unroll
+        for (uint32_t k = 1; k < MWHIP_PACK_MAX_COLUMNS; k++) {
+            if (k < args.numColumns && w >= args.firstWord[k]) {
+                c = k;
+            }
+        }
+        dst[i] = args.src[c][(uint64_t)row * args.words[c] +
+                             (w - args.firstWord[c])];
+    }
+}
+
+__global__ void statsKernel(EcsState *S, int32_t *host_out,
+                            uint32_t *replay_signal)
 {
     uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a < S->numArchetypeSlots) {
@@ -278,6 +310,9 @@ __global__ void statsKernel(EcsState *S, int32_t *host_out)
     if (a == 0) {
         host_out[0] = (int32_t)S->errorFlags;
         host_out[1] = S->numIds;
+        // this replay is complete (mwhip_stream_wait_replays polls this)
+        __hip_atomic_fetch_add(replay_signal, 1u, __ATOMIC_RELEASE,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -364,6 +399,10 @@ struct LaunchGraph {
     std::string statName;
     std::vector<std::string> statNames;     // backing store for mwhip_kernel_stat::name
     std::vector<uint32_t> taskGraphIds;     // to rebuild after a table grew
+    // optional last node: pack exported columns into a send buffer
+    bool hasPack = false;
+    PackArgs pack {};
+    void *packDst = nullptr;
 };
 
 struct mwhip_exec {
@@ -398,6 +437,8 @@ struct mwhip_exec {
     int32_t *statsHost = nullptr;           // pinned, device-visible
     std::vector<void *> allocations;
     std::vector<std::unique_ptr<VmRange>> vmRanges;
+    uint32_t *replaySignal = nullptr;       // device: replays completed
+    uint32_t replaysLaunched = 0;           // host: replays queued
     uint32_t tableGrowth = 1;               // reserved / initial rows
     uint32_t numGrowths = 0;
     bool checkAfterRun = true;
@@ -1054,6 +1095,15 @@ static int buildDeviceState(mwhip_exec *exec)
         (3 + kMaxArchetypes) * sizeof(int32_t), hipHostMallocMapped));
     memset(exec->statsHost, 0, (3 + kMaxArchetypes) * sizeof(int32_t));
 
+    // replay counter in signal memory (hipStreamWaitValue32 polls it)
+    if (hipExtMallocWithFlags((void **)&exec->replaySignal, 256,
+                              hipMallocSignalMemory) != hipSuccess) {
+        (void)hipGetLastError();
+        HIPCHK(hipMalloc((void **)&exec->replaySignal, 256));
+    }
+    exec->allocations.push_back(exec->replaySignal);
+    HIPCHK(hipMemset(exec->replaySignal, 0, 256));
+
     exec->stateBuilt = true;
     return 0;
 }
@@ -1482,7 +1532,7 @@ static int buildLaunchList(mwhip_exec *exec, const std::vector<uint32_t> &tg_ids
         k.block = dim3(256, 1, 1);
         int32_t *host_out = nullptr;
         HIPCHK(hipHostGetDevicePointer((void **)&host_out, exec->statsHost, 0));
-        k.setArgs(exec->stateDev, host_out);
+        k.setArgs(exec->stateDev, host_out, exec->replaySignal);
         k.name = "stats";
         k.role = "health";
         k.kind = MWHIP_NODE_RECYCLE;
@@ -1855,13 +1905,34 @@ static int topoSort(TaskGraphRec &tg)
 static int instantiateLaunchGraph(mwhip_exec *exec,
                                   const std::vector<uint32_t> &ids,
                                   const std::string &stat_name,
-                                  std::unique_ptr<LaunchGraph> &out)
+                                  std::unique_ptr<LaunchGraph> &out,
+                                  const LaunchGraph *pack_from = nullptr)
 {
     std::unique_ptr<LaunchGraph> lg(new LaunchGraph {});
     lg->statName = stat_name;
     lg->taskGraphIds = ids;
     int rc = buildLaunchList(exec, ids, *lg);
     if (rc != 0) return rc;
+
+    if (pack_from != nullptr && pack_from->hasPack) {
+        lg->hasPack = true;
+        lg->pack = pack_from->pack;
+        lg->packDst = pack_from->packDst;
+
+        KernelLaunch k;
+        k.fn = (const void *)&packRowsKernel;
+        const uint64_t total =
+            (uint64_t)lg->pack.numRows * lg->pack.recordWords;
+        k.grid = dim3((uint32_t)std::min<uint64_t>(
+            std::max<uint64_t>((total + 255) / 256, 1), 4096), 1, 1);
+        k.block = dim3(256, 1, 1);
+        k.setArgs(lg->pack, (uint32_t *)lg->packDst);
+        k.name = "pack";
+        k.role = "pack.rows";
+        k.kind = MWHIP_NODE_RECYCLE;
+        // before the health kernel that closes every replay
+        lg->launches.insert(lg->launches.end() - 1, k);
+    }
 
     HIPCHK(hipStreamBeginCapture(exec->stream, hipStreamCaptureModeThreadLocal));
     for (KernelLaunch &k : lg->launches) {
@@ -1940,7 +2011,8 @@ static int growTables(mwhip_exec *exec, RowsFn &&rows_of)
     for (auto &kv : exec->launchGraphs) {
         std::unique_ptr<LaunchGraph> fresh;
         int rc = instantiateLaunchGraph(exec, kv.second->taskGraphIds,
-                                        kv.second->statName, fresh);
+                                        kv.second->statName, fresh,
+                                        kv.second.get());
         if (rc != 0) return rc;
         if (kv.second->graphExec) (void)hipGraphExecDestroy(kv.second->graphExec);
         if (kv.second->graph) (void)hipGraphDestroy(kv.second->graph);
@@ -2026,6 +2098,7 @@ extern "C" int mwhip_run(mwhip_exec *exec, uint64_t graph)
         return fail(-3, "unknown launch graph");
     }
     HIPCHK(hipGraphLaunch(it->second->graphExec, exec->stream));
+    exec->replaysLaunched++;
     HIPCHK(hipStreamSynchronize(exec->stream));
     int rc = checkHealth(exec);
     if (rc != 0) return rc;
@@ -2050,6 +2123,98 @@ extern "C" int mwhip_run_async(mwhip_exec *exec, uint64_t graph, void *hip_strea
     // (growing rebuilds the graphs: look the handle up again)
     it = exec->launchGraphs.find(graph);
     HIPCHK(hipGraphLaunch(it->second->graphExec, (hipStream_t)hip_stream));
+    exec->replaysLaunched++;
+    return 0;
+}
+
+static int makePackArgs(uint32_t num_columns, const void *const *src_columns,
+                        const uint32_t *words_per_row, uint32_t num_rows,
+                        PackArgs *out)
+{
+    if (num_columns == 0 || num_columns > MWHIP_PACK_MAX_COLUMNS) {
+        return fail(-2, "pack_rows: %u columns (1..%u)", num_columns,
+                    (uint32_t)MWHIP_PACK_MAX_COLUMNS);
+    }
+    PackArgs args {};
+    args.numColumns = num_columns;
+    args.numRows = num_rows;
+    for (uint32_t c = 0; c < num_columns; c++) {
+        args.src[c] = (const uint32_t *)src_columns[c];
+        args.words[c] = words_per_row[c];
+        args.firstWord[c] = args.recordWords;
+        args.recordWords += words_per_row[c];
+    }
+    *out = args;
+    return 0;
+}
+
+extern "C" int mwhip_build_launch_graph_with_pack(
+    mwhip_exec *exec, uint64_t base_graph, uint32_t num_columns,
+    const void *const *src_columns, const uint32_t *words_per_row,
+    uint32_t num_rows, void *dst, uint64_t *graph_out)
+{
+    auto it = exec->launchGraphs.find(base_graph);
+    if (it == exec->launchGraphs.end()) {
+        return fail(-3, "unknown launch graph");
+    }
+    HIPCHK(hipSetDevice(exec->cfg.gpu_id));
+
+    LaunchGraph with_pack {};
+    with_pack.hasPack = true;
+    with_pack.packDst = dst;
+    int rc = makePackArgs(num_columns, src_columns, words_per_row, num_rows,
+                          &with_pack.pack);
+    if (rc != 0) return rc;
+
+    HIPCHK(hipStreamSynchronize(exec->stream));
+    std::unique_ptr<LaunchGraph> lg;
+    rc = instantiateLaunchGraph(exec, it->second->taskGraphIds,
+                                it->second->statName, lg, &with_pack);
+    if (rc != 0) return rc;
+
+    uint64_t handle = exec->nextGraphHandle++;
+    exec->launchGraphs[handle] = std::move(lg);
+    *graph_out = handle;
+    return 0;
+}
+
+// Another stream waits for every replay queued so far WITHOUT touching the
+// executor's stream: the last kernel of each replay bumps a counter in signal
+// memory and the waiting stream polls it (hipStreamWaitValue32).  An event
+// recorded between two graph launches would do, but costs ~20 us of launch
+// pipelining per step on this runtime; an event-record node inside the graph
+// does not order a later hipStreamWaitEvent (measured: the wait returns early).
+extern "C" int mwhip_stream_wait_replays(mwhip_exec *exec, void *hip_stream)
+{
+    if (exec->replaySignal == nullptr) {
+        return fail(-3, "no replay signal");
+    }
+    HIPCHK(hipStreamWaitValue32((hipStream_t)hip_stream, exec->replaySignal,
+                                exec->replaysLaunched, hipStreamWaitValueGte,
+                                0xFFFFFFFFu));
+    return 0;
+}
+
+extern "C" int mwhip_pack_rows(mwhip_exec *exec, uint32_t num_columns,
+                               const void *const *src_columns,
+                               const uint32_t *words_per_row, uint32_t num_rows,
+                               void *dst)
+{
+    PackArgs args {};
+    int rc = makePackArgs(num_columns, src_columns, words_per_row, num_rows,
+                          &args);
+    if (rc != 0) return rc;
+    if (args.recordWords == 0 || num_rows == 0) {
+        return 0;
+    }
+
+    const uint64_t total = (uint64_t)num_rows * args.recordWords;
+    const uint32_t blocks =
+        (uint32_t)std::min<uint64_t>((total + 255) / 256, 4096);
+    HIPCHK(hipSetDevice(exec->cfg.gpu_id));
+    hipLaunchKernelGGL(packRowsKernel, dim3(blocks), dim3(256), 0, exec->stream,
+                       args, (uint32_t *)dst);
+    HIPCHK(hipGetLastError());
     return 0;
 }
 
@@ -2253,6 +2418,10 @@ extern "C" int32_t mwhip_profile(mwhip_exec *exec, uint64_t graph, uint32_t reps
         *gate_host = 1;
         __sync_synchronize();
         HIPCHK(hipStreamSynchronize(exec->stream));
+        // (the health kernel ran once more: keep the host's replay count in
+        // step with the device's)
+        HIPCHK(hipMemcpy(&exec->replaysLaunched, exec->replaySignal,
+                         sizeof(uint32_t), hipMemcpyDeviceToHost));
         rc = checkHealth(exec);
         if (rc != 0) return rc;
 

@@ -65,7 +65,9 @@ class ShardedSimulator:
         self._packed_global = None
         self._global: Dict[str, "torch.Tensor"] = {}
         self._exec_stream = None    # torch view of the executor's stream
-        self._packed_event = None   # recorded after each pack
+        self._pack_graphs = None    # step graph + pack into buffer 0 / 1
+        self._slot = 0              # packed buffer of the next step
+        self._exchanged = [None, None]  # per buffer: its last collective done
 
     def _setup(self):
         import torch
@@ -86,8 +88,9 @@ class ShardedSimulator:
             offset += words.shape[1]
 
         device = self._local_words[0].device if self._local_words else "cpu"
-        self._packed_local = torch.empty((W, offset), dtype=torch.int32,
-                                         device=device)
+        self._packed_local = [
+            torch.empty((W, offset), dtype=torch.int32, device=device)
+            for _ in range(2)]
         self._packed_global = torch.empty((self.shard.total_worlds, offset),
                                           dtype=torch.int32, device=device)
         for name, dtype, tail, off, n in layout:
@@ -104,39 +107,64 @@ class ShardedSimulator:
         on_device = getattr(self.sim, "backend", "") == "hip"
         if not on_device:
             self.sim.step(n)
-        else:
-            # Stream-ordered, no host round trip per step: the executor replays
-            # on its own stream (MWCudaExecutor::runAsync); the pack of the
-            # previous step must have read the exported columns before this
-            # step may overwrite them, and this step's pack waits for the
-            # replay.  The collective only reads the packed copy, so it
-            # overlaps with the next step.
-            cur = torch.cuda.current_stream()
-            if self._exec_stream is None:
-                self._exec_stream = torch.cuda.ExternalStream(
-                    self.sim.stream(), device=cur.device)
-            if self._packed_event is not None:
-                self._exec_stream.wait_event(self._packed_event)
-            self.sim.step_async(n)
-            if self.obs_names:
-                cur.wait_stream(self._exec_stream)
+            if not self.obs_names:
+                return self._global
+            if self._local_words is None:
+                self._setup()
+            packed = self._packed_local[0]
+            torch.cat(self._local_words, dim=1, out=packed)
+            self._exchange(packed)
+            return self._global
+
+        # HIP backend: everything is stream-ordered, no host round trip.  The
+        # pack is part of the replay; only the collective (which reads the
+        # packed copy, not the exported columns) waits for the executor's
+        # stream, and it overlaps with the next replay.  Two packed buffers
+        # alternate: a buffer is packed again only after the collective that
+        # read it two steps ago has finished.
+        cur = torch.cuda.current_stream()
+        if self._exec_stream is None:
+            self._exec_stream = torch.cuda.ExternalStream(
+                self.sim.stream(), device=cur.device)
+        ext = self._exec_stream
 
         if not self.obs_names:
+            self.sim.step_async(n)
             return self._global
         if self._local_words is None:
             self._setup()
+        if self._pack_graphs is None:
+            # the pack is the last node of the step graph itself (one graph per
+            # packed buffer): a foreign kernel between two replays costs ~35 us
+            # of launch pipelining, and torch.cat of eight narrow tensors ~20
+            self._pack_graphs = [
+                self.sim.packed_step_graph(self.obs_names, buf.data_ptr())
+                for buf in self._packed_local]
 
-        torch.cat(self._local_words, dim=1, out=self._packed_local)
-        if on_device:
-            if self._packed_event is None:
-                self._packed_event = torch.cuda.Event()
-            self._packed_event.record(torch.cuda.current_stream())
+        if n > 1:
+            self.sim.step_async(n - 1)
+        slot = self._slot
+        self._slot ^= 1
+        packed = self._packed_local[slot]
+        if self._exchanged[slot] is not None:
+            ext.wait_event(self._exchanged[slot])
+        self.sim.step_async(1, graph=self._pack_graphs[slot])
+        # (not cur.wait_stream(ext): an event recorded between two graph
+        # launches costs ~20 us of launch pipelining; the replay's last kernel
+        # bumps a counter this stream polls instead)
+        self.sim.stream_wait_replays(cur.cuda_stream)
+        self._exchange(packed)
+        if self._exchanged[slot] is None:
+            self._exchanged[slot] = torch.cuda.Event()
+        self._exchanged[slot].record(cur)
+        return self._global
+
+    def _exchange(self, packed):
         if self.shard.world_size == 1:
-            self._packed_global.copy_(self._packed_local)
+            self._packed_global.copy_(packed)
         else:
             self._dist.all_gather_into_tensor(
-                self._packed_global, self._packed_local, group=self.group)
-        return self._global
+                self._packed_global, packed, group=self.group)
 
     def sync(self):
         """Waits for queued steps (HIP backend); raises on a device error flag."""

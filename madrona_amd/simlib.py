@@ -124,6 +124,15 @@ def runtime_lib() -> C.CDLL:
     lib.mwhip_run_async.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
     lib.mwhip_synchronize.restype = C.c_int
     lib.mwhip_synchronize.argtypes = [C.c_void_p]
+    lib.mwhip_build_launch_graph_with_pack.restype = C.c_int
+    lib.mwhip_build_launch_graph_with_pack.argtypes = [
+        C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_void_p),
+        C.POINTER(C.c_uint32), C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64)]
+    lib.mwhip_stream_wait_replays.restype = C.c_int
+    lib.mwhip_stream_wait_replays.argtypes = [C.c_void_p, C.c_void_p]
+    lib.mwhip_pack_rows.restype = C.c_int
+    lib.mwhip_pack_rows.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p),
+                                    C.POINTER(C.c_uint32), C.c_uint32, C.c_void_p]
     return lib
 
 
@@ -148,6 +157,7 @@ class Simulator:
         if not self.handle:
             raise RuntimeError(f"sim_create failed for {lib_path}")
         self.backend = self.lib.sim_backend(self.handle).decode()
+        self._async = None
         self._tensor_info: Dict[str, Tuple[int, np.dtype, Tuple[int, ...], bool]] = {}
         for i in range(self.lib.sim_num_tensors(self.handle)):
             info = SimTensorInfo()
@@ -234,20 +244,72 @@ class Simulator:
         """hipStream_t of the executor's private stream (mwhip_stream)."""
         return int(runtime_lib().mwhip_stream(self.hip_exec()) or 0)
 
-    def step_async(self, n: int = 1) -> None:
+    def _pack_descriptor(self, names: List[str]):
+        n = len(names)
+        ptrs = (C.c_void_p * n)(*[self.tensor_ptr(name) for name in names])
+        words = (C.c_uint32 * n)()
+        for i, name in enumerate(names):
+            _, dtype, dims, _ = self._tensor_info[name]
+            if np.dtype(dtype).itemsize != 4:
+                raise TypeError(f"{name}: only 4-byte element types are packed")
+            words[i] = int(np.prod(dims[1:])) if len(dims) > 1 else 1
+        return n, ptrs, words
+
+    def packed_step_graph(self, names: List[str], dst_ptr: int) -> int:
+        """A copy of the step graph whose last node packs the exported tensors
+        `names` into one [worlds, words] int32 record per world at device
+        address `dst_ptr` (mwhip_build_launch_graph_with_pack); replay it with
+        step_async(graph=...)."""
+        rt = runtime_lib()
+        n, ptrs, words = self._pack_descriptor(names)
+        out = C.c_uint64(0)
+        rc = rt.mwhip_build_launch_graph_with_pack(
+            self.hip_exec(), self.lib.sim_hip_step_graph(self.handle), n, ptrs,
+            words, self.num_worlds, dst_ptr, C.byref(out))
+        if rc != 0:
+            raise RuntimeError(f"mwhip_build_launch_graph_with_pack -> {rc}: "
+                               f"{rt.mwhip_last_error().decode()}")
+        return int(out.value)
+
+    def step_async(self, n: int = 1, graph: int = 0) -> None:
         """Queues n replays of the step graph on the executor's stream without
         waiting for them (MWCudaExecutor::runAsync, reference mw_gpu.hpp:146):
         work that consumes the exported tensors must be ordered after this
         stream (events / sync()), as with any stream-ordered producer."""
-        rt = runtime_lib()
-        exec_ = self.hip_exec()
-        graph = self.lib.sim_hip_step_graph(self.handle)
-        stream = rt.mwhip_stream(exec_)
+        if self._async is None:     # (looked up once: this is a per-step call)
+            rt = runtime_lib()
+            exec_ = self.hip_exec()
+            self._async = (rt, exec_, self.lib.sim_hip_step_graph(self.handle),
+                           rt.mwhip_stream(exec_))
+        rt, exec_, step_graph, stream = self._async
+        graph = graph or step_graph
         for _ in range(n):
             rc = rt.mwhip_run_async(exec_, graph, stream)
             if rc != 0:
                 raise RuntimeError(
                     f"mwhip_run_async -> {rc}: {rt.mwhip_last_error().decode()}")
+
+    def stream_wait_replays(self, hip_stream: int) -> None:
+        """Makes `hip_stream` (a hipStream_t) wait for every replay queued so
+        far, without putting anything on the executor's stream
+        (mwhip_stream_wait_replays)."""
+        rt = runtime_lib() if self._async is None else self._async[0]
+        rc = rt.mwhip_stream_wait_replays(self.hip_exec(), hip_stream)
+        if rc != 0:
+            raise RuntimeError(f"mwhip_stream_wait_replays -> {rc}: "
+                               f"{rt.mwhip_last_error().decode()}")
+
+    def pack_rows_async(self, names: List[str], dst_ptr: int) -> None:
+        """Queues, behind the replays queued so far, the packing of the exported
+        tensors `names` into one [worlds, words] int32 record per world at
+        device address `dst_ptr` (mwhip_pack_rows)."""
+        rt = runtime_lib()
+        n, ptrs, words = self._pack_descriptor(names)
+        rc = rt.mwhip_pack_rows(self.hip_exec(), n, ptrs, words,
+                                self.num_worlds, dst_ptr)
+        if rc != 0:
+            raise RuntimeError(
+                f"mwhip_pack_rows -> {rc}: {rt.mwhip_last_error().decode()}")
 
     def sync(self) -> None:
         """Waits for the queued replays; raises on a device-side error flag."""
