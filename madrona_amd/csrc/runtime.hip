@@ -1525,7 +1525,9 @@ static int buildLaunchList(mwhip_exec *exec, const std::vector<uint32_t> &tg_ids
         if (rc != 0) return rc;
     }
 
-    if (exec->checkAfterRun) {
+    // every replay ends with the health kernel: error flags and row counts to
+    // pinned host memory (table growth reads them), replay counter bumped
+    {
         KernelLaunch k;
         k.fn = (const void *)&statsKernel;
         k.grid = dim3(1, 1, 1);
