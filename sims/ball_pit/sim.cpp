@@ -118,6 +118,19 @@ static void generateLevel(Engine &ctx, RNG &rng)
         ctx.get<KickIndex>(e).idx = i;
         level.movable[i] = e;
     }
+
+    // movable[k] -- movable[k + 1], rigid at their initial distance
+    for (int32_t k = 0; k < consts::numJoints; k++) {
+        Entity a = level.movable[k];
+        Entity b = level.movable[k + 1];
+        Vector3 pa = ctx.get<Position>(a);
+        Vector3 pb = ctx.get<Position>(b);
+        Quat qa = ctx.get<Rotation>(a);
+        Quat qb = ctx.get<Rotation>(b);
+        level.joints[k] = PhysicsSystem::makeFixedJoint(ctx, a, b,
+            Quat { 1, 0, 0, 0 }, (qb.inv() * qa).normalize(),
+            Vector3::zero(), Vector3::zero(), (pb - pa).length());
+    }
 }
 
 static void createPersistentEntities(Engine &ctx)
@@ -175,6 +188,9 @@ static void initWorld(Engine &ctx)
 static void cleanupWorld(Engine &ctx)
 {
     LevelState &level = ctx.singleton<LevelState>();
+    for (int32_t k = 0; k < consts::numJoints; k++) {
+        ctx.destroyEntity(level.joints[k]);
+    }
     for (int32_t i = 0; i < consts::numMovable; i++) {
         ctx.destroyEntity(level.movable[i]);
     }

@@ -38,6 +38,7 @@ inline constexpr int32_t numBoxes = 5;
 inline constexpr int32_t numCoins = 3;
 inline constexpr int32_t numMovable = numSpheres + numBoxes + numCoins;
 inline constexpr int32_t numWalls = 4;
+inline constexpr int32_t numJoints = 8;
 inline constexpr int32_t episodeLen = 150;
 inline constexpr float pitSize = 10.f;
 inline constexpr float wallThickness = 0.5f;
@@ -74,6 +75,10 @@ struct StepsRemaining {
 
 struct LevelState {
     Entity movable[consts::numMovable];
+    // fixed joints tying consecutive objects into a chain (more joints per
+    // world than the step kernel stages next to the CU, and joints that share
+    // bodies: they must be solved in order)
+    Entity joints[consts::numJoints];
 };
 
 // which movable object this is (kick schedule)
