@@ -1088,7 +1088,16 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
 
         // ---- broadphase: candidate pairs in (body, traversal) order -----------
         // lane = body; one pass over the slot boxes in traversal order leaves a
-        // bit mask of hits, the pairs are written from the mask
+        // bit mask of hits, the pairs are written from the mask.  Slot boxes
+        // only grow between rebuilds, so a long-lived world with mobile bodies
+        // collects many more candidates than contacts: what does not fit the
+        // LDS list spills into the world's segment of the HBM candidate
+        // scratch (4-byte records).
+        WaveCandidate *spilled_candidates = (WaveCandidate *)(
+            ps->worldCandidates + (size_t)world * ps->candidatesPerWorld);
+        const uint32_t candidate_capacity = (uint32_t)Block::maxCandidates +
+            ps->candidatesPerWorld *
+                (uint32_t)(sizeof(CandidateCollision) / sizeof(WaveCandidate));
         uint32_t num_candidates = 0;
         for (int32_t chunk = 0; chunk < num_bodies; chunk += 64) {
             const int32_t k = chunk + (int32_t)lane;
@@ -1135,7 +1144,7 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
             uint32_t out = num_candidates +
                 wave::exclusiveScan(n, lane, &chunk_total);
 
-            if (active && n != 0 && out + n <= (uint32_t)Block::maxCandidates) {
+            if (active && n != 0 && out + n <= candidate_capacity) {
                 const uint32_t a_prims = w->primCount[k];
 #pragma unroll
                 for (int m = 0; m < mask_words; m++) {
@@ -1148,23 +1157,36 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                         const uint32_t b_prims = w->primCount[kb];
                         const uint32_t total_checks = a_prims * b_prims;
                         for (uint32_t c = 0; c < total_checks; c++) {
-                            w->candidates[out++] = WaveCandidate {
+                            const WaveCandidate candidate {
                                 (uint8_t)k, (uint8_t)kb,
                                 (uint8_t)(c / b_prims),
                                 (uint8_t)(c % b_prims),
                             };
+                            if (out < (uint32_t)Block::maxCandidates) {
+                                w->candidates[out] = candidate;
+                            } else {
+                                spilled_candidates[
+                                    out - (uint32_t)Block::maxCandidates] =
+                                        candidate;
+                            }
+                            out++;
                         }
                     }
                 }
             }
             num_candidates += chunk_total;
         }
-        if (num_candidates > (uint32_t)Block::maxCandidates) {
+        if (num_candidates > candidate_capacity) {
             mwhip::raiseError(S, mwhip::kErrTableOverflow);
             continue;
         }
         wave::phaseFence();
         PHYS_PROF(1);
+
+        auto candidateAt = [&](uint32_t c) {
+            return c < (uint32_t)Block::maxCandidates ? w->candidates[c] :
+                spilled_candidates[c - (uint32_t)Block::maxCandidates];
+        };
 
         // ---- the world's joints (table sorted by world just before) -----------
         const TableHdr &joint_tbl = S->tables[ps->jointArchetype];
@@ -1258,7 +1280,7 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                     PairSetup pair;
                     if (lane < width) {
                         pair = ldsSetupPair(w, obj_mgr,
-                                            w->candidates[chunk + lane]);
+                                            candidateAt(chunk + lane));
                         if (pair.aabbOverlap) {
                             kind = pair.test == NarrowphaseTest::HullHull ?
                                 2 : 1;
@@ -1290,7 +1312,7 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                     hull_pairs &= hull_pairs - 1;
 
                     PairSetup shared_pair =
-                        ldsSetupPair(w, obj_mgr, w->candidates[chunk + src]);
+                        ldsSetupPair(w, obj_mgr, candidateAt(chunk + src));
                     bool shared_too_big = false;
                     // every lane writes the same contact to src's slot
                     bool found = hullHullWave(lane, shared_pair, &w->scratch,
@@ -1303,7 +1325,7 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
 
                 if (too_big) {
                     PairSetup pair = ldsSetupPair(w, obj_mgr,
-                                                  w->candidates[chunk + lane]);
+                                                  candidateAt(chunk + lane));
                     has_contact = collidePairStored(pair, tmp_vertices,
                         tmp_faces, max_elems, stage + lane, &unsupported);
                 }

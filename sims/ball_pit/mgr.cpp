@@ -253,11 +253,13 @@ struct SimTraits {
         (uint32_t)ballpit::ExportID::NumExports;
     static constexpr uint32_t numTaskGraphs = 1;
 
-    // flags: low 16 bits = autoResetDenom (0 disables random resets)
+    // flags: low 16 bits = autoResetDenom (0 disables random resets), bits
+    // 16-23 = extra bodies per world (crowd mode)
     static Sim::Config makeConfig(const SimCreateArgs &args)
     {
         return Sim::Config {
             args.seed, args.world_base, args.flags & 0xFFFFu,
+            (args.flags >> 16) & 0xFFu,
             loadPhysicsObjects(args),
         };
     }

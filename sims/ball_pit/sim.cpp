@@ -119,6 +119,31 @@ static void generateLevel(Engine &ctx, RNG &rng)
         level.movable[i] = e;
     }
 
+    // crowd mode: a field of extra spheres and boxes around the pit
+    for (int32_t i = 0; i < ctx.data().numExtra; i++) {
+        Entity e = ctx.makeEntity<MovableObject>();
+
+        constexpr int32_t field = 13;
+        Vector3 pos {
+            ((float)(i % field) - 6.f) * 3.f + randInRange(rng, -0.5f, 0.5f),
+            ((float)(i / field) - 6.f) * 3.f + randInRange(rng, -0.5f, 0.5f),
+            randInRange(rng, 1.f, 3.f),
+        };
+        if (i % 2 == 0) {
+            float r = randInRange(rng, 0.5f, 1.f);
+            setupRigidBody(ctx, e, pos, Quat { 1, 0, 0, 0 }, SimObject::Sphere,
+                           ResponseType::Dynamic, Diag3x3 { r, r, r });
+        } else {
+            setupRigidBody(ctx, e, pos, Quat { 1, 0, 0, 0 }, SimObject::Box,
+                ResponseType::Dynamic,
+                Diag3x3 { randInRange(rng, 0.8f, 1.4f),
+                          randInRange(rng, 0.8f, 1.4f),
+                          randInRange(rng, 0.8f, 1.4f) });
+        }
+        ctx.get<KickIndex>(e).idx = consts::numMovable + i;
+        level.extra[i] = e;
+    }
+
     // movable[k] -- movable[k + 1], rigid at their initial distance
     for (int32_t k = 0; k < consts::numJoints; k++) {
         Entity a = level.movable[k];
@@ -193,6 +218,9 @@ static void cleanupWorld(Engine &ctx)
     }
     for (int32_t i = 0; i < consts::numMovable; i++) {
         ctx.destroyEntity(level.movable[i]);
+    }
+    for (int32_t i = 0; i < ctx.data().numExtra; i++) {
+        ctx.destroyEntity(level.extra[i]);
     }
 }
 
@@ -306,12 +334,14 @@ Sim::Sim(Engine &ctx, const Config &cfg, const WorldInit &)
     resetRng = RNG(rand::split_i(initRandKey, 0x7E5E7u));
     curWorldEpisode = 0;
     autoResetDenom = cfg.autoResetDenom;
+    numExtra = (int32_t)cfg.numExtra < consts::maxExtra ?
+        (int32_t)cfg.numExtra : consts::maxExtra;
 
     ctx.singleton<WorldReset>().reset = 0;
 
     PhysicsSystem::init(ctx, cfg.rigidBodyObjMgr, consts::deltaT,
         consts::numPhysicsSubsteps, -9.8f * math::up,
-        consts::maxRigidBodies);
+        consts::maxRigidBodies - consts::maxExtra + numExtra);
 
     createPersistentEntities(ctx);
     initWorld(ctx);

@@ -45,7 +45,11 @@ inline constexpr float wallThickness = 0.5f;
 inline constexpr float wallHeight = 3.f;
 inline constexpr float deltaT = 0.04f;
 inline constexpr int32_t numPhysicsSubsteps = 4;
-inline constexpr int32_t maxRigidBodies = 24;
+// crowd mode (Config::numExtra): extra spheres / boxes spread over a wider
+// field, up to this many -- worlds of more than 64 and more than 128 bodies,
+// i.e. the multi-chunk loops of the step kernels and the in-place BVH rebuild
+inline constexpr int32_t maxExtra = 150;
+inline constexpr int32_t maxRigidBodies = 24 + maxExtra;
 }
 
 enum class ExportID : uint32_t {
@@ -79,6 +83,7 @@ struct LevelState {
     // world than the step kernel stages next to the CU, and joints that share
     // bodies: they must be solved in order)
     Entity joints[consts::numJoints];
+    Entity extra[consts::maxExtra];
 };
 
 // which movable object this is (kick schedule)
@@ -102,6 +107,7 @@ struct Sim : public madrona::WorldBase {
         uint32_t seed;
         uint32_t worldBase;
         uint32_t autoResetDenom;
+        uint32_t numExtra;
         madrona::phys::ObjectManager *rigidBodyObjMgr;
     };
 
@@ -120,6 +126,7 @@ struct Sim : public madrona::WorldBase {
     RNG resetRng;
     uint32_t curWorldEpisode;
     uint32_t autoResetDenom;
+    int32_t numExtra;
     Entity floorPlane;
     Entity walls[consts::numWalls];
 };

@@ -171,6 +171,28 @@ def test_ball_pit_kernel_variants(built, monkeypatch, max_bodies):
     assert not probs, (step, probs[:3])
 
 
+@pytest.mark.parametrize("extra,kernel", [(60, "LDS<128>"), (140, "HBM")])
+def test_ball_pit_crowd(built, monkeypatch, extra, kernel):
+    """Worlds of 79 and 159 rigid bodies (ball_pit's crowd mode): more bodies
+    than lanes, so the body / candidate / contact loops of the step kernels run
+    several 64-wide chunks -- the 128-body LDS instantiation and the variant
+    that works out of HBM -- and the BVH (> 64 leaves) is rebuilt in place
+    instead of in the LDS staging of bvhUpdateKernel."""
+    _need_ref("ball_pit")
+    monkeypatch.setenv("MADRONA_MWHIP_ROWS_PER_WORLD", "400")
+    monkeypatch.setenv("MADRONA_MWHIP_PERSIST_KB_PER_WORLD", "96")
+    monkeypatch.setenv("MADRONA_MWHIP_MAX_CANDIDATES_PER_WORLD", "2048")
+    monkeypatch.setenv("MADRONA_MWHIP_MAX_CONTACTS_PER_WORLD", "1024")
+    # (resets only for the smaller crowd: a world that frees more than two
+    # blocks of entity ids at once spills them into the CPU backend's global
+    # free list, the id-renaming regime of DESIGN.md section 5 -- and body ids
+    # order the candidate pairs)
+    denom = 25 if extra <= 60 else 0
+    probs, step = run_pair("ball_pit", 24, 70, flags=(extra << 16) | denom,
+                           check_every=5, check_init=False)
+    assert not probs, (kernel, step, probs[:3])
+
+
 def _candidate_pairs(dump, arch_names):
     """CandidateCollision rows -> (world, entity id a, entity id b, aPrim, bPrim).
     A Loc's row is world-local on the CPU backend and global on the GPU; both are
