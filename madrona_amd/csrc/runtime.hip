@@ -1651,6 +1651,33 @@ static int constructWorlds(mwhip_exec *exec)
     uint32_t err = 0;
     rc = fetchError(exec, &err);
     if (rc != 0) return rc;
+    if (err == kErrPersistOverflow) {
+        // The constructors asked for more persistent memory (BVH arrays, ...)
+        // than MADRONA_MWHIP_PERSIST_KB_PER_WORLD provides.  persistAlloc kept
+        // counting, so the offset is what they need: size the region for it
+        // and run pass 1 again.
+        unsigned long long needed = 0;
+        HIPCHK(hipMemcpy(&needed, (char *)exec->stateDev +
+            offsetof(EcsState, persistOffset), sizeof(needed),
+            hipMemcpyDeviceToHost));
+        unsigned long long capacity = needed + needed / 8 + (1ull << 20);
+        char *region = nullptr;
+        rc = devAlloc(exec, (void **)&region, capacity, false);
+        if (rc != 0) return rc;
+        rc = pokeState(exec, &EcsState::persistBase, region);
+        if (rc != 0) return rc;
+        rc = pokeState(exec, &EcsState::persistCapacity, capacity);
+        if (rc != 0) return rc;
+
+        rc = resetForInitPass(exec);
+        if (rc != 0) return rc;
+        rc = pokeState(exec, &EcsState::initMode, 1u);
+        if (rc != 0) return rc;
+        rc = launchInitWorlds(exec);
+        if (rc != 0) return rc;
+        rc = fetchError(exec, &err);
+        if (rc != 0) return rc;
+    }
     if (err != 0) {
         return fail(-4, "world construction failed: %s", describeError(err));
     }
