@@ -1634,6 +1634,8 @@ static int resetForInitPass(mwhip_exec *exec)
     return pokeState(exec, &EcsState::errorFlags, 0u);
 }
 
+static int growTablesFromDevice(mwhip_exec *exec);
+
 static int constructWorlds(mwhip_exec *exec)
 {
     const uint32_t W = exec->cfg.num_worlds;
@@ -1668,6 +1670,27 @@ static int constructWorlds(mwhip_exec *exec)
         if (rc != 0) return rc;
         rc = pokeState(exec, &EcsState::persistCapacity, capacity);
         if (rc != 0) return rc;
+
+        rc = resetForInitPass(exec);
+        if (rc != 0) return rc;
+        rc = pokeState(exec, &EcsState::initMode, 1u);
+        if (rc != 0) return rc;
+        rc = launchInitWorlds(exec);
+        if (rc != 0) return rc;
+        rc = fetchError(exec, &err);
+        if (rc != 0) return rc;
+    }
+    // Constructors that create more rows than a table was given at
+    // registration: full tables grow (they live in reserved address space,
+    // growTables) and pass 1 runs again, until everything fits or the
+    // reservations are exhausted.
+    for (int attempt = 0; err == kErrTableOverflow && attempt < 6; attempt++) {
+        const uint32_t before = exec->numGrowths;
+        rc = growTablesFromDevice(exec);
+        if (rc != 0) return rc;
+        if (exec->numGrowths == before) {
+            break;      // nothing left to grow: report the overflow
+        }
 
         rc = resetForInitPass(exec);
         if (rc != 0) return rc;
@@ -2050,6 +2073,18 @@ static int growTables(mwhip_exec *exec, RowsFn &&rows_of)
     return 0;
 }
 
+// row counts read back from the device's table headers
+static int growTablesFromDevice(mwhip_exec *exec)
+{
+    HIPCHK(hipStreamSynchronize(exec->stream));
+    std::vector<TableHdr> hdrs(exec->tablesHost.size());
+    HIPCHK(hipMemcpy(hdrs.data(), exec->hostState.tables,
+                     hdrs.size() * sizeof(TableHdr), hipMemcpyDeviceToHost));
+    return growTables(exec, [&hdrs](uint32_t a) -> int64_t {
+        return a < hdrs.size() ? hdrs[a].numRows : -1;
+    });
+}
+
 // row counts the last completed replay reported (statsKernel)
 static int growTablesAfterReplay(mwhip_exec *exec)
 {
@@ -2079,13 +2114,7 @@ extern "C" int mwhip_build_launch_graph(mwhip_exec *exec,
 
     // the worlds have been constructed: size the tables for what they hold
     {
-        HIPCHK(hipStreamSynchronize(exec->stream));
-        std::vector<TableHdr> hdrs(exec->tablesHost.size());
-        HIPCHK(hipMemcpy(hdrs.data(), exec->hostState.tables,
-                         hdrs.size() * sizeof(TableHdr), hipMemcpyDeviceToHost));
-        int rc = growTables(exec, [&hdrs](uint32_t a) -> int64_t {
-            return a < hdrs.size() ? hdrs[a].numRows : -1;
-        });
+        int rc = growTablesFromDevice(exec);
         if (rc != 0) return rc;
     }
 

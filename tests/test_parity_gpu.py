@@ -178,10 +178,10 @@ def test_ball_pit_crowd(built, monkeypatch, extra, kernel):
     several 64-wide chunks -- the 128-body LDS instantiation and the variant
     that works out of HBM -- and the BVH (> 64 leaves) is rebuilt in place
     instead of in the LDS staging of bvhUpdateKernel.  (Their BVH arrays also
-    outgrow the default persistent region: the executor sizes it from what the
-    first constructor pass asked for.)"""
+    outgrow the default persistent region, and their constructors create more
+    rows than the default 64 per world: the executor sizes the region from what
+    the first constructor pass asked for, and grows the full tables.)"""
     _need_ref("ball_pit")
-    monkeypatch.setenv("MADRONA_MWHIP_ROWS_PER_WORLD", "400")
     monkeypatch.setenv("MADRONA_MWHIP_MAX_CANDIDATES_PER_WORLD", "2048")
     monkeypatch.setenv("MADRONA_MWHIP_MAX_CONTACTS_PER_WORLD", "1024")
     # (resets only for the smaller crowd: a world that frees more than two
@@ -507,8 +507,8 @@ def test_stream_ordered_stepping_matches_synchronous(built):
     sharded.close()
 
 
-@pytest.mark.parametrize("sim,div", [("escape_room", 2), ("escape_room_phys", 2),
-                                     ("sort_stress", 2)])
+@pytest.mark.parametrize("sim,div", [("escape_room", 2), ("escape_room", 7),
+                                     ("escape_room_phys", 2), ("sort_stress", 2)])
 def test_tables_grow_in_place(built, monkeypatch, sim, div):
     """Table growth: tables start with 1/div of the rows the
     simulator declared; the executor maps more memory behind their columns
@@ -520,8 +520,8 @@ def test_tables_grow_in_place(built, monkeypatch, sim, div):
     _need_ref(sim)
     monkeypatch.setenv("MADRONA_MWHIP_INITIAL_CAPACITY_DIV", str(div))
 
-    # (the world constructors must still fit: half of the declared rows is
-    # what a simulator that creates its maximum holds after construction)
+    # (div = 2: exactly what the constructors create; div = 7: less, so the
+    # tables already grow while the worlds are being constructed)
     worlds, steps = 200, 150
     kw = dict(flags=12) if sim.startswith("escape_room") else {}
     with Simulator(ref_lib_path(sim), worlds, seed=5, num_workers=1, **kw) as ref, \
