@@ -437,6 +437,7 @@ struct mwhip_exec {
     int32_t *statsHost = nullptr;           // pinned, device-visible
     std::vector<void *> allocations;
     std::vector<std::unique_ptr<VmRange>> vmRanges;
+    std::vector<uint32_t> rowsAtGraphBuild; // per archetype, see queryCapacityRows
     uint32_t *replaySignal = nullptr;       // device: replays completed
     uint32_t replaysLaunched = 0;           // host: replays queued
     uint32_t tableGrowth = 1;               // reserved / initial rows
@@ -1313,7 +1314,18 @@ static uint64_t queryCapacityRows(mwhip_exec *exec, uint32_t offset,
             uint64_t rows = 0;
             const uint32_t *p = exec->queryDataHost.data() + offset;
             for (uint32_t i = 0; i < num_matching; i++) {
-                rows += exec->archetypes[p[0]].capacity;
+                // Grids follow what the tables hold when the graph is built
+                // (x2 head room, at least 4096), not their capacity: the
+                // kernels stride over the device-resident row count, so a
+                // fuller table is still covered, and a table declared with 64
+                // rows per world but holding 4 does not launch 16x the
+                // workgroups it needs (a trivial system: 4.3 -> ~3 us).  Graphs
+                // are rebuilt when a table grows.
+                const ArchetypeRec &arch = exec->archetypes[p[0]];
+                uint64_t live = p[0] < exec->rowsAtGraphBuild.size() ?
+                    exec->rowsAtGraphBuild[p[0]] : arch.capacity;
+                rows += std::min<uint64_t>(arch.capacity,
+                    std::max<uint64_t>(2 * live, 4096));
                 p += 1 + q.comps.size();
             }
             return rows;
@@ -1963,6 +1975,21 @@ static int instantiateLaunchGraph(mwhip_exec *exec,
     std::unique_ptr<LaunchGraph> lg(new LaunchGraph {});
     lg->statName = stat_name;
     lg->taskGraphIds = ids;
+
+    if (envU32("MADRONA_MWHIP_GRIDS_FROM_ROWS", 1) != 0) {
+        HIPCHK(hipStreamSynchronize(exec->stream));
+        std::vector<TableHdr> hdrs(exec->tablesHost.size());
+        HIPCHK(hipMemcpy(hdrs.data(), exec->hostState.tables,
+                         hdrs.size() * sizeof(TableHdr), hipMemcpyDeviceToHost));
+        exec->rowsAtGraphBuild.assign(hdrs.size(), 0);
+        for (size_t a = 0; a < hdrs.size(); a++) {
+            exec->rowsAtGraphBuild[a] =
+                (uint32_t)std::max(hdrs[a].numRows, 0);
+        }
+    } else {
+        exec->rowsAtGraphBuild.clear();
+    }
+
     int rc = buildLaunchList(exec, ids, *lg);
     if (rc != 0) return rc;
 
