@@ -1324,8 +1324,11 @@ static uint64_t queryCapacityRows(mwhip_exec *exec, uint32_t offset,
                 const ArchetypeRec &arch = exec->archetypes[p[0]];
                 uint64_t live = p[0] < exec->rowsAtGraphBuild.size() ?
                     exec->rowsAtGraphBuild[p[0]] : arch.capacity;
-                rows += std::min<uint64_t>(arch.capacity,
-                    std::max<uint64_t>(2 * live, 4096));
+                // (tables that are empty at build time -- temporaries, joints
+                // -- say nothing about their steady state: capacity)
+                rows += live == 0 ? arch.capacity :
+                    std::min<uint64_t>(arch.capacity,
+                                       std::max<uint64_t>(2 * live, 4096));
                 p += 1 + q.comps.size();
             }
             return rows;
