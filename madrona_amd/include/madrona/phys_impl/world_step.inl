@@ -750,10 +750,10 @@ struct WaveCandidate {
 template <int MAXB>
 struct WorldBlock {
     static constexpr int maxBodies = MAXB;
-    // sized so that a 32-body block stays under 16 KB of LDS: four
-    // single-wave workgroups per CU, as many as the register file admits
-    // (a dense pile of n bodies has up to n (n - 1) / 2 candidate pairs: six
-    // per body covers a 19-body pile with every pair overlapping)
+    // sized so that a 32-body block stays under 20 KB of LDS: eight
+    // single-wave workgroups per CU, two per SIMD -- what the register cap of
+    // the kernel admits.  Six candidates per body in LDS (a dense pile of n
+    // bodies has up to n (n - 1) / 2 pairs); more spill to HBM.
     static constexpr int maxCandidates = MAXB * 6;
     // (at least a wave's worth: the narrowphase stages one contact per lane)
     static constexpr int maxContacts =
