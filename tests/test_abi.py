@@ -8,7 +8,8 @@ import pytest
 
 from madrona_amd.simlib import HIP_BUILD_DIR, REPO_ROOT, hip_lib_path
 
-SIMS = ["cartpole", "escape_room", "sort_stress"]
+SIMS = ["cartpole", "escape_room", "sort_stress", "escape_room_phys", "hideseek",
+        "ball_pit", "broadphase_only"]
 
 
 def declared_functions(header_path):
@@ -50,3 +51,13 @@ def test_error_reporting_without_creating_an_executor(built):
     lib = C.CDLL(os.path.join(HIP_BUILD_DIR, "libmadrona_hip.so"), mode=C.RTLD_GLOBAL)
     lib.mwhip_last_error.restype = C.c_char_p
     assert isinstance(lib.mwhip_last_error(), bytes)
+
+
+def test_physics_test_shims_are_built(built):
+    """The function-level physics test libraries (host flavour for the CPU
+    tests, device flavour for -m gpu) exist and export their entry points."""
+    C.CDLL(os.path.join(HIP_BUILD_DIR, "libmadrona_hip.so"), mode=C.RTLD_GLOBAL)
+    host = C.CDLL(os.path.join(HIP_BUILD_DIR, "libphys_host_test.so"))
+    assert hasattr(host, "amd_bake_objects") and hasattr(host, "amd_collide_pair")
+    dev = C.CDLL(os.path.join(HIP_BUILD_DIR, "libphys_device_test.so"))
+    assert hasattr(dev, "dev_collide_pairs")
