@@ -5,15 +5,17 @@ Metric (BASELINE.json): aggregate env steps/sec at N worlds + achieved HBM GB/s
 on the sort node.  A "step" is one replay of the simulator's task graph over
 all of the rank's worlds (one hipGraph launch on the executor's stream).
 
-N=1 workload = BASELINE.json configs[1]: Escape-Room-shaped ECS (physics off),
-4096 worlds on one MI355X (sims/escape_room, synthetic worlds, random actions
-resident in HBM, every world also resets itself with probability 1/200 per step
-so the compaction sorts run on live data every step).
-N>1: one process per GPU (torch.distributed / RCCL), 4096 worlds per GPU (weak
-scaling, worlds sharded by global index), one all-gather of the observation
-tensors per step over xGMI.
+N=1 workload = BASELINE.json configs[2], the configuration the north_star target
+is quoted on: Escape-Room + XPBD rigid bodies + BVH broadphase, 8192 worlds on
+one MI355X (sims/escape_room_phys; synthetic worlds, random actions resident in
+HBM, every world resets itself with probability 1/200 per step so that the
+compaction sorts and BVH rebuilds run on live data every step).  configs[1]
+(physics off, 4096 worlds) rides along as the secondary key `ecs_config2`.
+N>1 workload = BASELINE.json configs[3]: Hide-and-Seek-shaped worlds, 8192 per
+GPU (weak scaling, worlds sharded by global index), one packed all-gather of
+the observation tensors per step over RCCL/xGMI.
 
-    python bench.py --gpus 1 --steps 2000 --warmup 100
+    python bench.py --gpus 1 --steps 600 --warmup 100
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 \
         --master-addr 127.0.0.1 --master-port 29500 bench.py --gpus 8 ...
 
@@ -21,6 +23,7 @@ Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -29,23 +32,52 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+MIN_WINDOW_S = 0.5      # a timed window shorter than this is repeated over more steps
 
-OBS_TENSORS = ["self_obs", "partner_obs", "room_ent_obs", "door_obs", "lidar",
-               "reward", "done", "steps_remaining"]
+OBS_TENSORS = {
+    "escape_room": ["self_obs", "partner_obs", "room_ent_obs", "door_obs", "lidar",
+                    "reward", "done", "steps_remaining"],
+    "escape_room_phys": ["self_obs", "partner_obs", "room_ent_obs", "door_obs", "lidar",
+                         "reward", "done", "steps_remaining"],
+    "hideseek": ["self_obs", "agent_obs", "box_obs", "ramp_obs", "lidar",
+                 "reward", "done"],
+}
+
+# rigid bodies per world: 2 agents + 23 PhysicsEntity + 3 doors; 5 agents + 11
+# movable + 13 static
+PHYS_BODIES = {"escape_room_phys": 28, "hideseek": 29}
+# per body the fused step reads 156 B (transform, velocity, forces, ids, leaf +
+# slot box) and writes 132 B (transform, velocity, solver state) -- DESIGN.md §10
+PHYS_BYTES_PER_BODY = 288.0
+AGENTS = {"escape_room": 2, "escape_room_phys": 2, "hideseek": 5}
+
+WORKLOADS = {
+    "escape_room": (4096, "Escape-Room-shaped ECS (physics off), {w} worlds per GPU "
+                          "(BASELINE.json configs[1]), 29 entity rows/world"),
+    "escape_room_phys": (8192, "Escape-Room + XPBD rigid body + LBVH broadphase, {w} "
+                               "worlds per GPU (BASELINE.json configs[2]), 28 rigid "
+                               "bodies + 6 buttons/world, 4 substeps, grab joints"),
+    "hideseek": (8192, "Hide-and-Seek-shaped: XPBD + LBVH, {w} worlds per GPU "
+                       "(BASELINE.json configs[3] = 8 x 8192), 29 rigid bodies/world "
+                       "(5 agents, 9 boxes, 2 wedge ramps, 12 walls, plane), lock "
+                       "action, line-of-sight rays, 30-ray lidar, 2.9 KB obs/world"),
+}
 
 
 def parse_args():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=2000)
-    p.add_argument("--warmup", type=int, default=200)
+    p.add_argument("--steps", type=int, default=600)
+    p.add_argument("--warmup", type=int, default=100)
     p.add_argument("--worlds", type=int, default=0,
-                   help="worlds per GPU (default: 4096, or 8192 for escape_room_phys)")
-    p.add_argument("--sim", default="escape_room")
+                   help="worlds per GPU (default: the BASELINE size of the workload)")
+    p.add_argument("--sim", default="",
+                   help="default: escape_room_phys (configs[2]) on one GPU, "
+                        "hideseek (configs[3]) with --gpus N > 1")
     p.add_argument("--auto-reset-denom", type=int, default=200)
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--no-physics-line", action="store_true",
-                   help="skip the extra configs[2] measurement in the default run")
+    p.add_argument("--no-secondary", action="store_true",
+                   help="skip the configs[1] (physics off, 4096 worlds) measurement")
     p.add_argument("--profile-reps", type=int, default=30)
     p.add_argument("--force-collective", action="store_true",
                    help="run the RCCL observation all-gather even with one rank "
@@ -53,21 +85,34 @@ def parse_args():
     return p.parse_args()
 
 
-def recorded_traffic(sim, worlds, kernel_name):
-    """HBM bytes per launch of `kernel_name` measured with the PMC counters
-    (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; rocprofv3 cannot
-    run inside the bench): the recorded value for this exact workload from
-    profiles/r01_hbm_traffic.json, else None."""
-    path = os.path.join(REPO, "profiles", "r01_hbm_traffic.json")
-    try:
-        with open(path) as f:
-            entries = json.load(f)["entries"]
-    except (OSError, ValueError, KeyError):
-        return None
+def recorded_traffic():
+    """HBM bytes per launch measured with the PMC counters (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate passes; rocprofv3 cannot run inside the
+    bench): the newest profiles/rNN_hbm_traffic.json."""
+    import glob
+    entries = []
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_hbm_traffic.json"))):
+        try:
+            with open(path) as f:
+                for e in json.load(f)["entries"]:
+                    e["source"] = os.path.relpath(path, REPO)
+                    entries.append(e)
+        except (OSError, ValueError, KeyError):
+            pass
+    return entries
+
+
+def traffic_for(entries, sim, worlds, kernel_pattern):
+    """Sum of the newest recorded traffic of every kernel whose name contains
+    `kernel_pattern` for this workload, or None."""
+    latest = {}
     for e in entries:
-        if (e["sim"], e["worlds"], e["kernel"]) == (sim, worlds, kernel_name):
-            return e["traffic_bytes"]
-    return None
+        if (e["sim"], e["worlds"]) == (sim, worlds) and kernel_pattern in e["kernel"]:
+            latest[e["kernel"]] = e     # later files override earlier ones
+    if not latest:
+        return None, None
+    return (int(sum(e["traffic_bytes"] for e in latest.values())),
+            sorted({e["source"] for e in latest.values()})[-1])
 
 
 def cpu_baseline(sim, worlds, flags, seed, budget_s=12.0):
@@ -79,11 +124,11 @@ def cpu_baseline(sim, worlds, flags, seed, budget_s=12.0):
         return None
     cores = len(os.sched_getaffinity(0))
     with Simulator(path, worlds, seed=seed, num_workers=0, flags=flags) as s:
-        s.step(10)
+        s.step(5)
         t0 = time.perf_counter()
-        s.step(20)
-        per_step = (time.perf_counter() - t0) / 20
-        n = int(max(50, min(20000, budget_s / max(per_step, 1e-6))))
+        s.step(5)
+        per_step = (time.perf_counter() - t0) / 5
+        n = int(max(20, min(20000, budget_s / max(per_step, 1e-6))))
         t0 = time.perf_counter()
         s.step(n)
         dt = time.perf_counter() - t0
@@ -95,47 +140,125 @@ def cpu_baseline(sim, worlds, flags, seed, budget_s=12.0):
     }
 
 
-# rigid bodies per world: 2 agents + 23 PhysicsEntity + 3 doors; 5 agents + 11
-# movable + 13 static
-PHYS_BODIES = {"escape_room_phys": 28, "hideseek": 29}
-PHYS_BODIES_PER_WORLD = PHYS_BODIES["escape_room_phys"]
-AGENTS = {"escape_room": 2, "escape_room_phys": 2, "hideseek": 5}
-SIM_OBS_TENSORS = {
-    "hideseek": ["self_obs", "agent_obs", "box_obs", "ramp_obs", "lidar",
-                 "reward", "done"],
-}
-
-WORKLOADS = {
-    "escape_room": (4096, "Escape-Room-shaped ECS (physics off), {w} worlds per GPU "
-                          "(BASELINE.json configs[1]), 29 entity rows/world"),
-    "escape_room_phys": (8192, "Escape-Room + XPBD rigid body + LBVH broadphase, {w} "
-                               "worlds per GPU (BASELINE.json configs[2]), 28 rigid "
-                               "bodies + 6 buttons/world, 4 substeps, grab joints"),
-    "hideseek": (8192, "Hide-and-Seek-shaped: XPBD + LBVH, {w} worlds per GPU "
-                       "(BASELINE.json configs[3] is 8 x 8192), 29 rigid bodies/world "
-                       "(5 agents, 9 boxes, 2 wedge ramps, 12 walls, plane), lock "
-                       "action, line-of-sight rays, 30-ray lidar, 2.9 KB obs/world"),
-}
+def fill_actions(sim_name, sim, worlds, gpu_id, seed):
+    """Synthetic policy output, resident in HBM before any timed region."""
+    import torch
+    from madrona_amd.tensor import to_torch
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(seed)
+    action = to_torch(sim, "action", gpu_id)
+    A = AGENTS.get(sim_name, 2)
+    action.copy_(torch.stack([
+        torch.randint(0, 4, (worlds, A), device="cuda", generator=gen),
+        torch.randint(0, 8, (worlds, A), device="cuda", generator=gen),
+        torch.randint(-2, 3, (worlds, A), device="cuda", generator=gen),
+        torch.randint(0, 2, (worlds, A), device="cuda", generator=gen)
+        if sim_name != "escape_room" else
+        torch.zeros((worlds, A), device="cuda", dtype=torch.int64),
+    ], -1).to(torch.int32))
+    torch.cuda.synchronize()
 
 
-def physics_line(gpu_id, seed, denom, worlds=8192, steps=600, warmup=100):
-    """escape_room_phys at BASELINE configs[2] size: steps/s + the fused physics kernel."""
+def kernel_table(stats, sim_name, worlds):
+    """mwhip_profile output -> JSON rows.  ParallelFor bytes come from the
+    system's signature (`T&` = read + write): an upper bound on what it moves
+    (rows that return early move less), so no GB/s is derived from them."""
+    rows = []
+    for k in stats:
+        if k["name"].startswith("physics:worldStep"):
+            k["algo_bytes"] = (float(worlds) * PHYS_BYTES_PER_BODY *
+                               PHYS_BODIES.get(sim_name, 28))
+            k["exact"] = True
+        else:
+            k["exact"] = ":sort." in k["name"]
+        row = {"name": k["name"], "avg_us": round(k["avg_us"], 2),
+               "rows": round(k["rows"], 1)}
+        if k["exact"]:
+            row["algo_MB"] = round(k["algo_bytes"] / 1e6, 4)
+            row["GBps"] = (round(k["algo_bytes"] / (k["avg_us"] * 1e-6) / 1e9, 1)
+                           if k["avg_us"] > 0 else 0.0)
+        elif k["algo_bytes"] > 0:
+            row["algo_MB_signature_upper_bound"] = round(k["algo_bytes"] / 1e6, 4)
+        rows.append(row)
+    return rows
+
+
+def node_roofline(name, kernels, traffic, traffic_source, note):
+    """One roofline entry over a group of kernels: summed algorithmic bytes /
+    summed average durations (HIP events attached to the dispatches)."""
+    if not kernels:
+        return None
+    algo = sum(k["algo_bytes"] for k in kernels)
+    us = sum(k["avg_us"] for k in kernels)
+    achieved = algo / (us * 1e-6) / 1e9 if us > 0 else 0.0
+    return {
+        "kernel": name, "bound": "hbm",
+        "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4),
+        "traffic": traffic, "traffic_source": traffic_source,
+        "avg_us": round(us, 2), "launches": len(kernels),
+        "algo_bytes_per_launch": int(algo),
+        "note": note,
+    }
+
+
+def rooflines(stats, sim_name, worlds, ms_per_step):
+    """`roofline` = the kernel that dominates the step's time (contract), plus
+    `roofline.nodes`: the WHOLE sort node (every kernel of every sort chain in
+    the step), the fused physics step, and the step as a whole."""
+    entries = recorded_traffic()
+    sort_k = [k for k in stats if ":sort." in k["name"]]
+    phys_k = [k for k in stats if k["name"].startswith("physics:worldStep")]
+
+    nodes = {}
+    t, src = traffic_for(entries, sim_name, worlds, ":sort.")
+    nodes["sort_node"] = node_roofline(
+        "SortArchetype/CompactArchetype nodes (histogram + onesweep passes + gather "
+        "+ finalize of every sort chain in the step)", sort_k, t, src,
+        "BASELINE's 'achieved HBM GB/s on sort node': all kernels of the node, not "
+        "its best one; bytes = SURVEY 8d formula x rows the sorts measured")
+    t, src = traffic_for(entries, sim_name, worlds, "physics:worldStep")
+    nodes["physics_step"] = node_roofline(
+        "physics:worldStep (broadphase pairs + 4 x (integrate, narrowphase, XPBD "
+        "position + velocity solve) fused, one wavefront per world, world in LDS)",
+        phys_k, t, src,
+        "latency/issue-bound: HBM sees one read + one write of the body columns "
+        "per step (288 B/body); DESIGN.md §10")
+    # step level: every kernel's algorithmic bytes over the measured step time
+    step_bytes = sum(k["algo_bytes"] for k in stats)
+    t, src = traffic_for(entries, sim_name, worlds, "")
+    achieved = step_bytes / (ms_per_step * 1e-3) / 1e9
+    nodes["step"] = {
+        "kernel": "whole step (all launches of one replay)", "bound": "hbm",
+        "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4),
+        "traffic": t, "traffic_source": src,
+        "algo_bytes_per_step": int(step_bytes),
+        "note": "sum of algorithmic bytes (ParallelFor nodes at their signature "
+                "upper bound) / ms_per_step of the timed window",
+    }
+    nodes = {k: v for k, v in nodes.items() if v}
+
+    dominant = None
+    if phys_k and sum(k["avg_us"] for k in phys_k) >= sum(k["avg_us"] for k in sort_k):
+        dominant = dict(nodes["physics_step"])
+    elif sort_k:
+        dominant = dict(nodes["sort_node"])
+    if dominant is not None:
+        dominant["nodes"] = nodes
+        dominant["event_floor_us"] = round(min(k["avg_us"] for k in stats), 2)
+    return dominant
+
+
+def run_single(sim_name, worlds, gpu_id, seed, denom, steps, warmup, profile_reps):
+    """One-GPU measurement of `sim_name` outside the distributed harness (the
+    secondary configs[1] line).  Same timing discipline as the headline."""
     import torch
     from madrona_amd.simlib import Simulator, hip_lib_path
-    from madrona_amd.tensor import to_torch
 
-    with Simulator(hip_lib_path("escape_room_phys"), worlds, seed=seed,
-                   gpu_id=gpu_id, flags=denom) as sim:
-        gen = torch.Generator(device="cuda")
-        gen.manual_seed(99)
-        action = to_torch(sim, "action", gpu_id)
-        action.copy_(torch.stack([
-            torch.randint(0, 4, (worlds, 2), device="cuda", generator=gen),
-            torch.randint(0, 8, (worlds, 2), device="cuda", generator=gen),
-            torch.randint(-2, 3, (worlds, 2), device="cuda", generator=gen),
-            torch.randint(0, 2, (worlds, 2), device="cuda", generator=gen),
-        ], -1).to(torch.int32))
-        torch.cuda.synchronize()
+    with Simulator(hip_lib_path(sim_name), worlds, seed=seed, gpu_id=gpu_id,
+                   flags=denom) as sim:
+        fill_actions(sim_name, sim, worlds, gpu_id, 99)
         sim.step_async(warmup)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -143,22 +266,16 @@ def physics_line(gpu_id, seed, denom, worlds=8192, steps=600, warmup=100):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         sim.sync()
-        stats = sim.profile(10)
-    phys = [k for k in stats if k["name"].startswith("physics:worldStep")]
-    out = {
-        "workload": WORKLOADS["escape_room_phys"][1].format(w=worlds) +
+        stats = sim.profile(profile_reps)
+    ms = dt / steps * 1e3
+    return {
+        "workload": WORKLOADS[sim_name][1].format(w=worlds) +
                     f", auto-reset p=1/{denom} per world per step",
-        "value": worlds * steps / dt, "unit": "steps/s",
-        "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
+        "value": worlds * steps / dt, "unit": "steps/s", "ms_per_step": ms,
+        "steps": steps, "warmup": warmup,
+        "roofline": rooflines(stats, sim_name, worlds, ms),
+        "kernels": kernel_table(stats, sim_name, worlds),
     }
-    if phys:
-        algo = float(worlds) * PHYS_BODIES_PER_WORLD * 288.0
-        out["physics_kernel"] = {
-            "name": phys[0]["name"], "avg_us": round(phys[0]["avg_us"], 2),
-            "algo_bytes_per_launch": int(algo),
-            "GBps": round(algo / (phys[0]["avg_us"] * 1e-6) / 1e9, 1),
-        }
-    return out
 
 
 def main():
@@ -170,19 +287,21 @@ def main():
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
 
-    default_worlds, workload_fmt = WORKLOADS.get(args.sim, (4096, args.sim + ", {w} worlds"))
-    if args.worlds <= 0:
-        args.worlds = default_worlds
-    import numpy as np
-    import torch
-    import torch.distributed as dist
-
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world_size != args.gpus:
         if world_size == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    if not args.sim:
+        args.sim = "hideseek" if world_size > 1 else "escape_room_phys"
+    default_worlds, workload_fmt = WORKLOADS.get(args.sim, (4096, args.sim + ", {w} worlds"))
+    if args.worlds <= 0:
+        args.worlds = default_worlds
+
+    import torch
+    import torch.distributed as dist
+
     distributed = world_size > 1 or args.force_collective
 
     if not torch.cuda.is_available():
@@ -197,8 +316,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from madrona_amd.distributed import ShardedSimulator, shard_for
-    from madrona_amd.simlib import Simulator, hip_lib_path
-    from madrona_amd.tensor import to_torch
+    from madrona_amd.simlib import Simulator, hip_lib_path, runtime_lib
 
     shard = shard_for(rank, world_size, worlds_per_rank=args.worlds)
     seed = 5
@@ -208,111 +326,82 @@ def main():
                          gpu_id=local_rank, world_base=world_base,
                          flags=args.auto_reset_denom)
 
-    obs_tensors = SIM_OBS_TENSORS.get(args.sim, OBS_TENSORS)
+    obs_tensors = OBS_TENSORS.get(args.sim, OBS_TENSORS["escape_room"])
     sharded = ShardedSimulator(make_sim, shard, obs_tensors if distributed else [])
     sim = sharded.sim
-
-    # synthetic policy output, resident in HBM before the timed region
-    gen = torch.Generator(device="cuda")
-    gen.manual_seed(1234 + rank)
-    action = to_torch(sim, "action", local_rank)
-    W = args.worlds
-    A = AGENTS.get(args.sim, 2)
-    action.copy_(torch.stack([
-        torch.randint(0, 4, (W, A), device="cuda", generator=gen),
-        torch.randint(0, 8, (W, A), device="cuda", generator=gen),
-        torch.randint(-2, 3, (W, A), device="cuda", generator=gen),
-        torch.randint(0, 2, (W, A), device="cuda", generator=gen)
-        if args.sim != "escape_room" else
-        torch.zeros((W, A), device="cuda", dtype=torch.int64),
-    ], -1).to(torch.int32))
-    torch.cuda.synchronize()
+    fill_actions(args.sim, sim, args.worlds, local_rank, 1234 + rank)
+    rt = runtime_lib()
 
     def barrier():
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(steps, mark):
+        """barrier + sync, `steps` replays, barrier + sync; max over ranks."""
+        barrier()
+        if mark:
+            rt.mwhip_mark_window(sim.hip_exec(), 1)
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            sharded.step(1)
+        barrier()
+        local = time.perf_counter() - t0
+        if mark:
+            rt.mwhip_mark_window(sim.hip_exec(), 2)
+        sharded.sync()      # device-side error flags of the queued replays
+        per_rank = [local]
+        if distributed:
+            t = torch.tensor([local], device="cuda", dtype=torch.float64)
+            gathered = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+            dist.all_gather(gathered, t)
+            per_rank = [float(g.item()) for g in gathered]
+        return max(per_rank), per_rank
+
     for _ in range(args.warmup):
         sharded.step(1)
 
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        sharded.step(1)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    sharded.sync()      # device-side error flags of the queued replays
-
-    if distributed:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
+    # the contract's window: exactly --steps replays (the rocprofv3 summaries in
+    # profiles/ are trimmed to the marker kernels around it)
+    elapsed, per_rank = timed(args.steps, mark=True)
     total_worlds = shard.total_worlds
     value = total_worlds * args.steps / elapsed
+    ms_per_step = elapsed / args.steps * 1e3
+
+    # a window this short (the driver's --steps 20 is ~25 ms) says little:
+    # repeat over enough steps for MIN_WINDOW_S and report that next to it
+    long_window = None
+    if elapsed < MIN_WINDOW_S:
+        more = int(math.ceil(MIN_WINDOW_S / max(elapsed / args.steps, 1e-7)))
+        el2, _ = timed(more, mark=False)
+        long_window = {"steps": more, "seconds": round(el2, 4),
+                       "ms_per_step": el2 / more * 1e3,
+                       "value": total_worlds * more / el2}
+
+    # the collective on its own (packed observation record, RCCL all-gather)
+    allgather = None
+    if distributed and sharded._packed_global is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 20
+        barrier()
+        ev0.record()
+        for _ in range(reps):
+            sharded._exchange(sharded._packed_local[0])
+        ev1.record()
+        torch.cuda.synchronize()
+        nbytes = sharded._packed_global.numel() * 4
+        allgather = {"ms": ev0.elapsed_time(ev1) / reps, "gathered_bytes": nbytes,
+                     "per_rank_bytes": nbytes // max(world_size, 1)}
 
     # ---- per-kernel timing (HIP events on the executor's stream) + roofline ----
     roofline = None
     kernels = []
     if rank == 0:
         stats = sim.profile(args.profile_reps)
-        floor_us = min(k["avg_us"] for k in stats)     # empty-kernel interval
-        # rigid-body step: per body the fused kernel reads 156 B (transform,
-        # velocity, forces, ids, leaf + slot box) and writes 132 B (transform,
-        # velocity, solver state) -- DESIGN.md §10
-        for k in stats:
-            if k["name"].startswith("physics:worldStep"):
-                k["algo_bytes"] = (float(args.worlds) * 288.0 *
-                                   PHYS_BODIES.get(args.sim, PHYS_BODIES_PER_WORLD))
-        for k in stats:
-            kernels.append({
-                "name": k["name"], "avg_us": round(k["avg_us"], 2),
-                "algo_MB": round(k["algo_bytes"] / 1e6, 4),
-                "rows": round(k["rows"], 1),
-                "GBps": round(k["algo_bytes"] / (k["avg_us"] * 1e-6) / 1e9, 1)
-                        if k["avg_us"] > 0 else 0.0,
-            })
-        # the bandwidth-carrying kernel of the sort node (BASELINE metric names
-        # "achieved HBM GB/s on sort node"): the fused column gather
-        sort_k = [k for k in stats if "sort.gather" in k["name"]]
-        phys_k = [k for k in stats if k["name"].startswith("physics:worldStep")]
-        if phys_k:
-            # config 3: the physics step is the dominant kernel (> 50 % of the
-            # step); it is bound by instruction issue at one wave per SIMD, not
-            # by HBM -- the fraction below says how far from the HBM roof it is
-            g = phys_k[0]
-            achieved = g["algo_bytes"] / (g["avg_us"] * 1e-6) / 1e9
-            roofline = {
-                "kernel": g["name"], "bound": "hbm",
-                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": recorded_traffic(args.sim, args.worlds, g["name"]),
-                "traffic_source": "profiles/r01_hbm_traffic.json (rocprofv3 --pmc, "
-                                  "recorded; mostly register spills to scratch)",
-                "avg_us": round(g["avg_us"], 2),
-                "algo_bytes_per_launch": int(g["algo_bytes"]),
-                "event_floor_us": round(floor_us, 2),
-                "note": "latency/issue-bound kernel (one wavefront per world, world "
-                        "resident in LDS): HBM traffic is one read + one write of the "
-                        "body columns per step; see DESIGN.md §10",
-            }
-        elif sort_k:
-            g = max(sort_k, key=lambda k: k["algo_bytes"])
-            achieved = g["algo_bytes"] / (g["avg_us"] * 1e-6) / 1e9
-            roofline = {
-                "kernel": g["name"], "bound": "hbm",
-                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": recorded_traffic(args.sim, args.worlds, g["name"]),
-                "traffic_source": "profiles/r01_hbm_traffic.json (rocprofv3 --pmc, "
-                                  "recorded for this workload size)",
-                "avg_us": round(g["avg_us"], 2),
-                "algo_bytes_per_launch": int(g["algo_bytes"]),
-                "event_floor_us": round(floor_us, 2),
-                "note": "avg_us is the HIP-event interval around the launch (includes "
-                        "the event/launch floor shown); see profiles/ for rocprofv3",
-            }
+        roofline = rooflines(stats, args.sim, args.worlds,
+                             (long_window or {}).get("ms_per_step", ms_per_step))
+        kernels = kernel_table(stats, args.sim, args.worlds)
 
     cpu = None
     if rank == 0 and world_size == 1 and not args.no_cpu_baseline:
@@ -320,13 +409,14 @@ def main():
 
     sharded.close()
 
-    # BASELINE configs[2] (physics on, 8192 worlds) next to the headline line,
-    # same timing discipline, shorter run
-    physics = None
-    if (rank == 0 and world_size == 1 and args.sim == "escape_room"
-            and not args.no_physics_line):
-        physics = physics_line(local_rank, seed, args.auto_reset_denom)
+    # BASELINE configs[1] (physics off, 4096 worlds) next to the headline
+    secondary = None
+    if (rank == 0 and world_size == 1 and args.sim == "escape_room_phys"
+            and not args.no_secondary):
+        secondary = run_single("escape_room", 4096, local_rank, seed,
+                               args.auto_reset_denom, 3000, 200, args.profile_reps)
 
+    dist_world = dist.get_world_size() if distributed else 1
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
@@ -339,7 +429,7 @@ def main():
             "n_gpus": world_size,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": ms_per_step,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -351,13 +441,18 @@ def main():
                 "sim": args.sim,
                 "worlds_per_gpu": args.worlds,
                 "total_worlds": total_worlds,
+                "dist_world_size": dist_world,
                 "parallelism": f"worlds sharded over {world_size} GPU(s)"
-                               + (", RCCL all-gather of observations per step"
-                                  if distributed else ""),
+                               + (", one packed RCCL all-gather of the observation "
+                                  "tensors per step" if distributed else ""),
             },
+            "window_s": round(elapsed, 5),
+            "long_window": long_window,
+            "per_rank_ms_per_step": [round(t / args.steps * 1e3, 5) for t in per_rank],
+            "allgather": allgather,
             "roofline": roofline,
             "cpu_baseline": cpu,
-            "physics_config3": physics,
+            "ecs_config2": secondary,
             "kernels": kernels,
         }
         # flush what C libraries buffered for "stdout" while it pointed at stderr

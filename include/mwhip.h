@@ -83,6 +83,10 @@ int mwhip_register_component(mwhip_exec *exec, uint32_t component_id,
  * flattened in place */
 int mwhip_register_bundle(mwhip_exec *exec, uint32_t bundle_id,
                           const uint32_t *component_ids, uint32_t num_components);
+/* archetype_flags: the reference's ArchetypeFlags (ecs_flags.hpp) plus, in bit
+ * 31, "registered by registerSingleton": exactly one row per world, no head
+ * room, never grows. */
+#define MWHIP_ARCHETYPE_SINGLETON 0x80000000u
 int mwhip_register_archetype(mwhip_exec *exec, uint32_t archetype_id,
                              const uint32_t *component_ids,
                              const uint32_t *component_flags, /* may be NULL */
@@ -179,6 +183,14 @@ typedef struct mwhip_pfor_args {
     uint32_t num_inline;
     void *tables[MWHIP_PFOR_MAX_INLINE];            /* device table headers */
     uint16_t columns[MWHIP_PFOR_MAX_INLINE][MWHIP_PFOR_MAX_COMPONENTS];
+    /* Non-NULL for nodes whose system can append rows (makeEntity /
+     * makeTemporary reachable from the kernel): per-node device state through
+     * which the first workgroup to arrive fixes the row count of every matched
+     * table for the whole launch -- the reference evaluates numInvocations
+     * once per node (device taskgraph.inl:164-188), so rows created during a
+     * node are never visited by it.  The kernel is then launched with
+     * 4 * num_matching bytes of dynamic LDS. */
+    void *row_sync;
 } mwhip_pfor_args;
 
 typedef struct mwhip_node_desc {
@@ -249,6 +261,12 @@ int32_t mwhip_num_rows(mwhip_exec *exec, uint32_t archetype_id);
 int64_t mwhip_dump_column(mwhip_exec *exec, uint32_t archetype_id,
                           uint32_t component_id, void *dst, uint64_t dst_bytes,
                           int32_t *world_counts);
+/* The same column in TABLE order: every row below the table's row count
+ * (destroyed rows included), no grouping by world.  Returns rows, -1 on error,
+ * -2 if dst is too small. */
+int64_t mwhip_dump_column_raw(mwhip_exec *exec, uint32_t archetype_id,
+                              uint32_t component_id, void *dst,
+                              uint64_t dst_bytes);
 int mwhip_memcpy_d2h(void *dst_host, const void *src_dev, uint64_t num_bytes);
 int mwhip_memcpy_h2d(void *dst_dev, const void *src_host, uint64_t num_bytes);
 
@@ -281,6 +299,11 @@ int mwhip_pack_rows(mwhip_exec *exec, uint32_t num_columns,
                     const void *const *src_columns,
                     const uint32_t *words_per_row, uint32_t num_rows,
                     void *dst);
+
+/* Queues a one-wave marker kernel (benchWindowMarker) on the executor's stream:
+ * a pair of them brackets a measurement window in a rocprofv3 kernel trace
+ * (profiles/summarize_rocprof.py trims to it).  Measurement only. */
+int mwhip_mark_window(mwhip_exec *exec, uint32_t id);
 
 /* Per-kernel timing with HIP events on the executor's stream (replaces the
  * reference's device tracing, mw_gpu/tracing.hpp).  Runs the launch graph's

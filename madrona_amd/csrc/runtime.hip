@@ -268,6 +268,17 @@ __global__ void gateKernel(int32_t *host_flag)
     }
 }
 
+// Brackets a measurement window in a kernel trace: profiles/summarize_rocprof.py
+// keeps the dispatches between the first and the last launch of this kernel
+// (mwhip_mark_window), so the committed rocprofv3 averages cover exactly the
+// steps bench.py timed.
+__global__ void benchWindowMarker(uint32_t *signal, uint32_t id)
+{
+    if (threadIdx.x == 0 && signal != nullptr && id == 0xFFFFFFFFu) {
+        *signal = id;   // never taken: keeps the arguments alive
+    }
+}
+
 // End-of-graph health record written straight into pinned host memory.
 struct PackArgs {
     const uint32_t *src[MWHIP_PACK_MAX_COLUMNS];
@@ -444,6 +455,7 @@ struct mwhip_exec {
     uint32_t numGrowths = 0;
     bool checkAfterRun = true;
     bool sortBatching = true;
+    uint32_t rowSnapshotMode = 1;   // 0 never, 1 nodes that can append rows, 2 all
 };
 
 static int devAlloc(mwhip_exec *exec, void **out, size_t bytes, bool zero = true)
@@ -631,7 +643,11 @@ extern "C" int mwhip_register_archetype(mwhip_exec *exec, uint32_t id,
     const uint64_t W = exec->cfg.num_worlds;
     // Rows of one world that were destroyed and re-created coexist until the
     // next compaction, hence the 2x head room over the declared maximum.
-    uint64_t rows_per_world = max_per_world == 1 ? 1 :
+    // (Only singletons are pinned to exactly one row per world: an ordinary
+    // archetype declared with a maximum of 1 still needs two rows per world
+    // while its entity is destroyed and re-created inside one step.)
+    const bool pinned_rows = (archetype_flags & MWHIP_ARCHETYPE_SINGLETON) != 0u;
+    uint64_t rows_per_world = pinned_rows ? 1 :
         (max_per_world > 0 ? 2ull * max_per_world : defaultRowsPerWorld());
     uint64_t capacity = std::max<uint64_t>(W * rows_per_world, 64);
     if (capacity > 0x7FFFFFF0ull) {
@@ -641,7 +657,7 @@ extern "C" int mwhip_register_archetype(mwhip_exec *exec, uint32_t id,
     // space for tableGrowth x the initial rows (MADRONA_MWHIP_TABLE_GROWTH,
     // default 4; 1 = plain allocations), see growTables().
     uint64_t reserved = capacity;
-    if (max_per_world != 1 && exec->tableGrowth > 1) {
+    if (!pinned_rows && exec->tableGrowth > 1) {
         reserved = std::min<uint64_t>(capacity * exec->tableGrowth, 0x7FFFFFF0ull);
         // (test hook) start smaller than the rows the simulator declared
         if (const char *div = getenv("MADRONA_MWHIP_INITIAL_CAPACITY_DIV")) {
@@ -1164,7 +1180,7 @@ static int launchOne(mwhip_exec *exec, KernelLaunch &k, hipStream_t stream)
 {
     void *args[8];
     k.argPointers(args);
-    HIPCHK(hipLaunchKernel(k.fn, k.grid, k.block, args, 0, stream));
+    HIPCHK(hipLaunchKernel(k.fn, k.grid, k.block, args, k.dynamicLds, stream));
     (void)exec;
     return 0;
 }
@@ -1404,6 +1420,24 @@ static int buildLaunchList(mwhip_exec *exec, const std::vector<uint32_t> &tg_ids
                             pa.num_inline = q.numMatching;
                         }
                         break;
+                    }
+                    // A system that can append rows (its kernel carries the
+                    // static LDS marker of appendRowIssue; any other static
+                    // LDS errs on the safe side) must not visit rows created
+                    // during its own node: such nodes fix their row counts
+                    // once per launch.  MADRONA_MWHIP_ROW_SNAPSHOT=0 / 2
+                    // switches this off / on for every node (measurement).
+                    hipFuncAttributes attr {};
+                    HIPCHK(hipFuncGetAttributes(&attr, d.kernel));
+                    const uint32_t snap_mode = exec->rowSnapshotMode;
+                    if (d.num_matching > 0 && snap_mode != 0 &&
+                            (attr.sharedSizeBytes != 0 || snap_mode == 2)) {
+                        void *sync_dev = nullptr;
+                        int src = devAlloc(exec, &sync_dev,
+                            sizeof(PforRowSync) + 8ull * d.num_matching);
+                        if (src != 0) return src;
+                        pa.row_sync = sync_dev;
+                        k.dynamicLds = 4u * d.num_matching;
                     }
                     k.pushArg(pa);
                 }
@@ -1668,7 +1702,10 @@ static int constructWorlds(mwhip_exec *exec)
     uint32_t err = 0;
     rc = fetchError(exec, &err);
     if (rc != 0) return rc;
-    if (err == kErrPersistOverflow) {
+    // (both recoverable conditions may be raised by one pass: test bits, handle
+    // the persistent region first -- after its overflow every world aliases
+    // persistBase, which can produce secondary flags that the rerun clears)
+    if ((err & kErrPersistOverflow) != 0u) {
         // The constructors asked for more persistent memory (BVH arrays, ...)
         // than MADRONA_MWHIP_PERSIST_KB_PER_WORLD provides.  persistAlloc kept
         // counting, so the offset is what they need: size the region for it
@@ -1699,7 +1736,8 @@ static int constructWorlds(mwhip_exec *exec)
     // registration: full tables grow (they live in reserved address space,
     // growTables) and pass 1 runs again, until everything fits or the
     // reservations are exhausted.
-    for (int attempt = 0; err == kErrTableOverflow && attempt < 6; attempt++) {
+    for (int attempt = 0; (err & kErrTableOverflow) != 0u &&
+             (err & ~(uint32_t)kErrTableOverflow) == 0u && attempt < 6; attempt++) {
         const uint32_t before = exec->numGrowths;
         rc = growTablesFromDevice(exec);
         if (rc != 0) return rc;
@@ -1801,6 +1839,7 @@ extern "C" int mwhip_create(const mwhip_state_config *cfg,
     exec->taskGraphs.resize(cfg->num_task_graphs);
     exec->checkAfterRun = envU32("MADRONA_MWHIP_CHECK", 1) != 0;
     exec->sortBatching = envU32("MADRONA_MWHIP_SORT_BATCH", 1) != 0;
+    exec->rowSnapshotMode = envU32("MADRONA_MWHIP_ROW_SNAPSHOT", 1);
     exec->tableGrowth = std::max(envU32("MADRONA_MWHIP_TABLE_GROWTH", 4), 1u);
     HIPCHK(hipStreamCreateWithFlags(&exec->stream, hipStreamNonBlocking));
 
@@ -2306,6 +2345,15 @@ extern "C" int mwhip_pack_rows(mwhip_exec *exec, uint32_t num_columns,
     return 0;
 }
 
+extern "C" int mwhip_mark_window(mwhip_exec *exec, uint32_t id)
+{
+    HIPCHK(hipSetDevice(exec->cfg.gpu_id));
+    hipLaunchKernelGGL(benchWindowMarker, dim3(1), dim3(64), 0, exec->stream,
+                       (uint32_t *)nullptr, id);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 extern "C" uint32_t mwhip_num_table_growths(mwhip_exec *exec)
 {
     return exec->numGrowths;
@@ -2409,6 +2457,42 @@ extern "C" int64_t mwhip_dump_column(mwhip_exec *exec, uint32_t archetype_id,
     return total;
 }
 
+extern "C" int64_t mwhip_dump_column_raw(mwhip_exec *exec,
+                                         uint32_t archetype_id,
+                                         uint32_t component_id, void *dst,
+                                         uint64_t dst_bytes)
+{
+    if (archetype_id >= exec->archetypes.size() ||
+            !exec->archetypes[archetype_id].registered) {
+        fail(-3, "dump: archetype %u not registered", archetype_id);
+        return -1;
+    }
+    (void)hipSetDevice(exec->cfg.gpu_id);
+    (void)hipStreamSynchronize(exec->stream);
+
+    const ArchetypeRec &arch = exec->archetypes[archetype_id];
+    int col = findColumn(arch, component_id);
+    if (col < 0) {
+        fail(-3, "dump: archetype %u has no component %u", archetype_id,
+             component_id);
+        return -1;
+    }
+    TableHdr hdr;
+    if (hipMemcpy(&hdr, exec->hostState.tables + archetype_id, sizeof(TableHdr),
+                  hipMemcpyDeviceToHost) != hipSuccess) {
+        return -1;
+    }
+    const uint64_t bytes = (uint64_t)hdr.numRows * arch.colBytes[col];
+    if (bytes > dst_bytes) {
+        return -2;
+    }
+    if (bytes > 0 && hipMemcpy(dst, hdr.columns[col], bytes,
+                               hipMemcpyDeviceToHost) != hipSuccess) {
+        return -1;
+    }
+    return hdr.numRows;
+}
+
 extern "C" int mwhip_memcpy_d2h(void *dst_host, const void *src_dev,
                                 uint64_t num_bytes)
 {
@@ -2495,8 +2579,8 @@ extern "C" int32_t mwhip_profile(mwhip_exec *exec, uint64_t graph, uint32_t reps
             KernelLaunch &k = lg.launches[i];
             void *kargs[8];
             k.argPointers(kargs);
-            hipError_t lres = hipExtLaunchKernel(k.fn, k.grid, k.block, kargs, 0,
-                exec->stream, ev_start[i], ev_stop[i], 0);
+            hipError_t lres = hipExtLaunchKernel(k.fn, k.grid, k.block, kargs,
+                k.dynamicLds, exec->stream, ev_start[i], ev_stop[i], 0);
             if (lres != hipSuccess) {
                 *gate_host = 1;
                 return fail(-10, "hipExtLaunchKernel -> %s",

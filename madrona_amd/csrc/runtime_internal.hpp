@@ -81,6 +81,7 @@ struct KernelLaunch {
     alignas(16) unsigned char argStorage[320] {};
     uint32_t argOffsets[8] {};
     uint32_t numArgs = 0;
+    uint32_t dynamicLds = 0;        // bytes of dynamic LDS
 
     std::string name;               // node name
     const char *role = "";          // kernel role inside the node

@@ -603,7 +603,10 @@ sortFinalize(EcsState *S, const SortSite *sites)
         state->statRuns += 1ull;
 
         tbl.numRows = n_out;
-        tbl.needsSort = 0u;
+        // A sort by any other key scrambles the rows across worlds: the next
+        // world sort / compaction must not early-out, worldOffsets / worldCounts
+        // are stale until then (reference sort_archetype.cpp:1001-1007).
+        tbl.needsSort = site.worldSort ? 0u : 1u;
         state->numValid = 0;
         state->finalizeArrivals = 0;
         for (int p = 0; p < 4; p++) state->tileCounter[p] = 0;

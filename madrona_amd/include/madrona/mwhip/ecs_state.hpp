@@ -186,6 +186,14 @@ MWHIP_HD inline void *columnOf(const TableHdr &tbl, int32_t column_idx)
     return loadInvariant(&tbl.columns[column_idx]);
 }
 
+// Per-node state of the row-count snapshot (mwhip_pfor_args::row_sync):
+// a ticket counter that never resets (ticket / workgroups-per-launch = launch
+// epoch) and one {epoch : 32 | rows : 32} granule per matched table.
+struct PforRowSync {
+    unsigned long long ticket;
+    unsigned long long rows[1];     // [num_matching]
+};
+
 #if defined(__HIPCC__)
 
 MWHIP_DEV inline int32_t atomicAddI32(int32_t *p, int32_t v)
@@ -422,8 +430,21 @@ MWHIP_DEV inline void *persistAlloc(EcsState *S, unsigned long long num_bytes)
 // Split in two so that a caller can put independent memory work between the
 // atomic and the first use of its result (one lane per world: every dependent
 // round trip is exposed).
+// Any kernel that can reach a row append carries this word of static LDS.
+// The host reads the kernel's static LDS size (hipFuncGetAttributes) when it
+// builds the launch list: a ParallelFor kernel WITHOUT static LDS provably
+// cannot append rows and reads the live row counts directly; every other one
+// snapshots them once per launch (pforRowSnapshot, taskgraph.inl).  The test
+// errs on the safe side: LDS used for anything else also selects the snapshot.
+MWHIP_DEV inline void markRowAppender()
+{
+    __shared__ uint32_t mwhip_row_appender_marker;
+    *(volatile uint32_t *)&mwhip_row_appender_marker = 1u;
+}
+
 MWHIP_DEV inline int32_t appendRowIssue(TableHdr &tbl)
 {
+    markRowAppender();
     tbl.needsSort = 1u;
     return atomicAddI32(&tbl.numRows, 1);
 }

@@ -121,7 +121,8 @@ MADRONA_HOST_API void StateManager::registerSingleton()
 
     registerComponent<SingletonT>();
     registerArchetype<ArchetypeT>(
-        ComponentMetadataSelector<> {}, ArchetypeFlags::None, 1);
+        ComponentMetadataSelector<> {},
+        (ArchetypeFlags)MWHIP_ARCHETYPE_SINGLETON, 1);
 
     mwhip::check(mwhip_register_singleton(exec(),
         TypeTracker::typeID<ArchetypeT>(),

@@ -124,6 +124,49 @@ MADRONA_UNROLL
     }
 }
 
+// Row counts of the matched tables, fixed once per launch (nodes whose system
+// can append rows; mwhip_pfor_args::row_sync).  Thread 0 of every workgroup
+// takes a ticket; the first ticket of a launch reads the counts and publishes
+// them as {epoch, rows} granules, the others wait for granules of their epoch.
+// A workgroup only starts running the system -- only then can it append rows
+// -- after it has seen the published counts, so they are the counts from
+// before the node.  out: dynamic LDS, one word per matched table.
+template <typename TableOfFn>
+MADRONA_DEVICE inline void pforRowSnapshot(PforRowSync *sync,
+                                           uint32_t num_tables,
+                                           TableOfFn &&table_of,
+                                           int32_t *out)
+{
+    if (threadIdx.x == 0) {
+        const unsigned long long ticket = __hip_atomic_fetch_add(
+            &sync->ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long epoch =
+            (ticket / gridDim.x + 1ull) & 0xFFFFFFFFull;
+        if (ticket % gridDim.x == 0ull) {
+            for (uint32_t a = 0; a < num_tables; a++) {
+                int32_t n = __hip_atomic_load(&table_of(a)->numRows,
+                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&sync->rows[a],
+                    (epoch << 32) | (unsigned long long)(uint32_t)n,
+                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                out[a] = n;
+            }
+        } else {
+            for (uint32_t a = 0; a < num_tables; a++) {
+                unsigned long long g;
+                while (true) {
+                    g = __hip_atomic_load(&sync->rows[a], __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_AGENT);
+                    if ((g >> 32) == epoch) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                out[a] = (int32_t)(uint32_t)g;
+            }
+        }
+    }
+    __syncthreads();
+}
+
 template <typename ContextT, auto Fn, int32_t threads_per_invocation,
           typename... ComponentTs>
 __global__ void __launch_bounds__(256)
@@ -131,6 +174,7 @@ parallelForKernel(EcsState *S, void *, uint32_t query_offset,
                   uint32_t num_matching_and_flags, mwhip_pfor_args query)
 {
     constexpr size_t N = sizeof...(ComponentTs);
+    extern __shared__ int32_t pfor_snapshot_rows[];
 
     // bit 31: every matched archetype is a singleton => one thread per world
     const uint32_t num_matching = num_matching_and_flags & 0x7FFFFFFFu;
@@ -140,10 +184,16 @@ parallelForKernel(EcsState *S, void *, uint32_t query_offset,
 
     if (query.num_inline == num_matching) {
         int32_t num_rows[MWHIP_PFOR_MAX_INLINE];
+        if (query.row_sync != nullptr) {
+            pforRowSnapshot((PforRowSync *)query.row_sync, num_matching,
+                [&](uint32_t a) { return (TableHdr *)query.tables[a]; },
+                pfor_snapshot_rows);
+        }
 MADRONA_UNROLL
         for (uint32_t a = 0; a < MWHIP_PFOR_MAX_INLINE; a++) {
-            num_rows[a] = a < num_matching ?
-                ((const TableHdr *)query.tables[a])->numRows : 0;
+            num_rows[a] = a >= num_matching ? 0 :
+                (query.row_sync != nullptr ? pfor_snapshot_rows[a] :
+                 ((const TableHdr *)query.tables[a])->numRows);
         }
 
         int32_t rows_before = 0;
@@ -162,6 +212,12 @@ MADRONA_UNROLL
 
     // general path: walk the query table
     const uint32_t *query_values = S->queryData + query_offset;
+    if (query.row_sync != nullptr) {
+        pforRowSnapshot((PforRowSync *)query.row_sync, num_matching,
+            [&](uint32_t a) {
+                return &S->tables[query_values[a * (1 + N)]];
+            }, pfor_snapshot_rows);
+    }
     for (uint32_t a = 0; a < num_matching; a++) {
         uint16_t col_indices[N > 0 ? N : 1];
 MADRONA_UNROLL
@@ -171,7 +227,8 @@ MADRONA_UNROLL
         TableHdr &tbl = S->tables[query_values[0]];
         parallelForTable<ContextT, Fn, threads_per_invocation,
                          ComponentTs...>(
-            state_mgr, tbl, col_indices, exclusive_world, tbl.numRows, 0);
+            state_mgr, tbl, col_indices, exclusive_world,
+            query.row_sync != nullptr ? pfor_snapshot_rows[a] : tbl.numRows, 0);
         query_values += 1 + N;
     }
 }
@@ -191,10 +248,19 @@ template <auto Fn, int32_t threads_per_invocation,
           int32_t items_per_invocation, typename... ComponentTs>
 __global__ void __launch_bounds__(256)
 parallelForBatchKernel(EcsState *S, void *, uint32_t query_offset,
-                       uint32_t num_matching)
+                       uint32_t num_matching_and_flags, mwhip_pfor_args query)
 {
     constexpr size_t N = sizeof...(ComponentTs);
+    extern __shared__ int32_t pfor_snapshot_rows[];
+    const uint32_t num_matching = num_matching_and_flags & 0x7FFFFFFFu;
     const uint32_t *query_values = S->queryData + query_offset;
+
+    if (query.row_sync != nullptr) {
+        pforRowSnapshot((PforRowSync *)query.row_sync, num_matching,
+            [&](uint32_t a) {
+                return &S->tables[query_values[a * (1 + N)]];
+            }, pfor_snapshot_rows);
+    }
 
     // every lane of a threads_per_invocation group makes the same call; the
     // user function differentiates lanes itself (threadIdx.x % group size)
@@ -205,7 +271,8 @@ parallelForBatchKernel(EcsState *S, void *, uint32_t query_offset,
 
     for (uint32_t a = 0; a < num_matching; a++) {
         TableHdr &tbl = S->tables[query_values[0]];
-        const int32_t num_rows = tbl.numRows;
+        const int32_t num_rows = query.row_sync != nullptr ?
+            pfor_snapshot_rows[a] : tbl.numRows;
 
         void *cols[N > 0 ? N : 1];
 MADRONA_UNROLL
@@ -484,10 +551,14 @@ CustomParallelForNode<ContextT, Fn, threads_per_invocation,
     desc.kernel = kernel_stub();
     desc.node_data_id = -1;
     desc.arg0 = ref->offset;
+    // exclusive_world (lock-free id cache): one lane per world, i.e. only
+    // singleton archetypes AND one thread per invocation -- with several
+    // lanes per world create / destroy must take the world's lock
     desc.arg1 = ref->numMatchingArchetypes |
-        ((ref->flags & MWHIP_QUERY_ALL_SINGLETON) != 0u ? 0x80000000u : 0u);
+        (((ref->flags & MWHIP_QUERY_ALL_SINGLETON) != 0u &&
+          threads_per_invocation == 1) ? 0x80000000u : 0u);
     desc.count_mode = MWHIP_COUNT_QUERY_ROWS;
-    desc.wants_pfor_args = items_per_invocation == 1 ? 1u : 0u;
+    desc.wants_pfor_args = 1u;
     desc.query_offset = ref->offset;
     desc.num_matching = ref->numMatchingArchetypes;
     desc.threads_per_invocation = (uint32_t)threads_per_invocation;

@@ -82,6 +82,10 @@ def _bind(lib: C.CDLL) -> None:
     lib.sim_column_dump.restype = C.c_int64
     lib.sim_column_dump.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64,
                                     C.POINTER(C.c_int32)]
+    lib.sim_hip_run_taskgraph.restype = C.c_int
+    lib.sim_hip_run_taskgraph.argtypes = [C.c_void_p, C.c_uint32]
+    lib.sim_column_dump_raw.restype = C.c_int64
+    lib.sim_column_dump_raw.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64]
     lib.sim_hip_exec.restype = C.c_void_p
     lib.sim_hip_exec.argtypes = [C.c_void_p]
     lib.sim_hip_step_graph.restype = C.c_uint64
@@ -130,6 +134,8 @@ def runtime_lib() -> C.CDLL:
         C.POINTER(C.c_uint32), C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64)]
     lib.mwhip_stream_wait_replays.restype = C.c_int
     lib.mwhip_stream_wait_replays.argtypes = [C.c_void_p, C.c_void_p]
+    lib.mwhip_mark_window.restype = C.c_int
+    lib.mwhip_mark_window.argtypes = [C.c_void_p, C.c_uint32]
     lib.mwhip_pack_rows.restype = C.c_int
     lib.mwhip_pack_rows.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p),
                                     C.POINTER(C.c_uint32), C.c_uint32, C.c_void_p]
@@ -235,6 +241,21 @@ class Simulator:
     def dump_all(self, max_rows_per_world: int = 256):
         return {self._columns[i][0]: self.dump_column(i, max_rows_per_world)
                 for i in range(len(self._columns))}
+
+    def run_taskgraph(self, taskgraph_id: int) -> None:
+        """Replays ONE task graph of the simulator (HIP backend; test probes)."""
+        rc = self.lib.sim_hip_run_taskgraph(self.handle, taskgraph_id)
+        if rc != 0:
+            raise RuntimeError(f"sim_hip_run_taskgraph({taskgraph_id}) -> {rc}")
+
+    def dump_column_raw(self, idx: int, max_rows: int):
+        """Column `idx` in table order, destroyed rows included (HIP backend)."""
+        name, elem_bytes, _ = self._columns[idx]
+        buf = np.empty(max_rows * elem_bytes, dtype=np.uint8)
+        n = self.lib.sim_column_dump_raw(self.handle, idx, buf.ctypes.data, buf.nbytes)
+        if n < 0:
+            raise RuntimeError(f"sim_column_dump_raw({name}) -> {n}")
+        return buf[: n * elem_bytes].reshape(n, elem_bytes).copy()
 
     def hip_exec(self) -> int:
         return int(self.lib.sim_hip_exec(self.handle) or 0)

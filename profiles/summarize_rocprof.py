@@ -19,10 +19,19 @@ def short(name):
 def main():
     db_path, out_prefix = sys.argv[1], sys.argv[2]
     db = sqlite3.connect(db_path)
+    # bench.py brackets its timed window with benchWindowMarker dispatches
+    # (mwhip_mark_window): keep only what ran between the first two of them
+    marks = [r[0] for r in db.execute(
+        "select start from kernels where name like '%benchWindowMarker%' order by start")]
+    where, window = "", "whole trace (no window markers)"
+    if len(marks) >= 2:
+        where = f" where start > {marks[0]} and start < {marks[1]}"
+        window = (f"timed window only: {(marks[1] - marks[0]) / 1e6:.3f} ms between "
+                  f"the benchWindowMarker dispatches")
     rows = db.execute(
         "select name, count(*), sum(end-start), avg(end-start), min(end-start), "
         "max(end-start), max(grid_x), max(workgroup_x), max(vgpr_count), max(sgpr_count), "
-        "max(lds_size) from kernels group by name order by 3 desc").fetchall()
+        f"max(lds_size) from kernels{where} group by name order by 3 desc").fetchall()
     total = sum(r[2] for r in rows) or 1
     with open(out_prefix + ".csv", "w", newline="") as f:
         w = csv.writer(f)
@@ -32,6 +41,7 @@ def main():
             w.writerow([short(r[0]), r[1], int(r[2]), round(r[3], 1), int(r[4]), int(r[5]),
                         round(100 * r[2] / total, 2), r[6], r[7], r[8], r[9], r[10], r[0]])
     with open(out_prefix + ".txt", "w") as f:
+        f.write(f"# {window}\n")
         f.write(f"{'calls':>7} {'total_ms':>10} {'avg_us':>9} {'min_us':>8} {'max_us':>9} "
                 f"{'pct':>6}  kernel\n")
         for r in rows:

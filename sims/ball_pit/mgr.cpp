@@ -254,13 +254,16 @@ struct SimTraits {
     static constexpr uint32_t numTaskGraphs = 1;
 
     // flags: low 16 bits = autoResetDenom (0 disables random resets), bits
-    // 16-23 = extra bodies per world (crowd mode)
+    // 16-23 = extra bodies per world (crowd mode), bit 24 = every other joint
+    // is a hinge, bit 25 = checkEntityAABBOverlap steers the kicks
     static Sim::Config makeConfig(const SimCreateArgs &args)
     {
         return Sim::Config {
             args.seed, args.world_base, args.flags & 0xFFFFu,
             (args.flags >> 16) & 0xFFu,
             loadPhysicsObjects(args),
+            (args.flags >> 24) & 1u,
+            (args.flags >> 25) & 1u,
         };
     }
 

@@ -152,6 +152,17 @@ static void generateLevel(Engine &ctx, RNG &rng)
         Vector3 pb = ctx.get<Position>(b);
         Quat qa = ctx.get<Rotation>(a);
         Quat qb = ctx.get<Rotation>(b);
+        if (ctx.data().hingeMode != 0 && k % 2 == 1) {
+            // hinge about the x axis of `a` as both bodies see it now, pivot
+            // half way between the two centres
+            Quat a_to_b = (qb.inv() * qa).normalize();
+            Vector3 mid = (pa + pb) * 0.5f;
+            level.joints[k] = PhysicsSystem::makeHingeJoint(ctx, a, b,
+                Vector3 { 1, 0, 0 }, a_to_b.rotateVec(Vector3 { 1, 0, 0 }),
+                Vector3 { 0, 1, 0 }, a_to_b.rotateVec(Vector3 { 0, 1, 0 }),
+                qa.inv().rotateVec(mid - pa), qb.inv().rotateVec(mid - pb));
+            continue;
+        }
         level.joints[k] = PhysicsSystem::makeFixedJoint(ctx, a, b,
             Quat { 1, 0, 0, 0 }, (qb.inv() * qa).normalize(),
             Vector3::zero(), Vector3::zero(), (pb - pa).length());
@@ -257,6 +268,20 @@ inline void kickSystem(Engine &ctx, LevelState &level)
     };
     sim.rng = rng;
 
+    if (sim.overlapMode != 0) {
+        // PhysicsSystem::checkEntityAABBOverlap decides the kick's direction:
+        // objects whose hull reaches into the centre column are pushed down
+        // instead of up (spheres never overlap: the test only looks at hulls)
+        math::AABB column {
+            .pMin = Vector3 { -3.f, -3.f, 0.f },
+            .pMax = Vector3 { 3.f, 3.f, 8.f },
+        };
+        if (PhysicsSystem::checkEntityAABBOverlap(ctx, column,
+                                                  level.movable[target])) {
+            force.z = -force.z;
+        }
+    }
+
     ctx.get<ExternalForce>(level.movable[target]) = force;
     ctx.get<ExternalTorque>(level.movable[target]) = torque;
 }
@@ -336,6 +361,8 @@ Sim::Sim(Engine &ctx, const Config &cfg, const WorldInit &)
     autoResetDenom = cfg.autoResetDenom;
     numExtra = (int32_t)cfg.numExtra < consts::maxExtra ?
         (int32_t)cfg.numExtra : consts::maxExtra;
+    hingeMode = cfg.hingeMode;
+    overlapMode = cfg.overlapMode;
 
     ctx.singleton<WorldReset>().reset = 0;
 

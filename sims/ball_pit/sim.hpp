@@ -109,6 +109,10 @@ struct Sim : public madrona::WorldBase {
         uint32_t autoResetDenom;
         uint32_t numExtra;
         madrona::phys::ObjectManager *rigidBodyObjMgr;
+        // 1: every other joint of the chain is a hinge
+        uint32_t hingeMode;
+        // 1: PhysicsSystem::checkEntityAABBOverlap steers the kicks
+        uint32_t overlapMode;
     };
 
     struct WorldInit {};
@@ -127,6 +131,8 @@ struct Sim : public madrona::WorldBase {
     uint32_t curWorldEpisode;
     uint32_t autoResetDenom;
     int32_t numExtra;
+    uint32_t hingeMode;
+    uint32_t overlapMode;
     Entity floorPlane;
     Entity walls[consts::numWalls];
 };

@@ -97,6 +97,23 @@ struct ColumnList {
 
 }
 
+#ifndef SIM_BACKEND_REF_CPU
+namespace simmgr {
+// a step = every task graph back to back, unless the simulator says its other
+// task graphs are test probes (Traits::stepIsTaskGraph0)
+template <typename T>
+static madrona::MWCudaLaunchGraph *buildStepGraph(madrona::MWCudaExecutor &exec)
+{
+    if constexpr (requires { T::stepIsTaskGraph0; }) {
+        return new madrona::MWCudaLaunchGraph(exec.buildLaunchGraph(0u));
+    } else {
+        return new madrona::MWCudaLaunchGraph(
+            exec.buildLaunchGraphAllTaskGraphs());
+    }
+}
+}
+#endif
+
 struct SimHandle {
     using Traits = SimTraits;
     using Sim = typename Traits::Sim;
@@ -114,6 +131,7 @@ struct SimHandle {
 #else
     madrona::MWCudaExecutor *exec;
     madrona::MWCudaLaunchGraph *stepGraph;
+    std::vector<madrona::MWCudaLaunchGraph *> probeGraphs;
 #endif
 };
 
@@ -158,8 +176,7 @@ SimHandle *sim_create(const SimCreateArgs *args)
         {}, {}, madrona::CompileConfig::OptMode::LTO,
     }, ctx);
 
-    h->stepGraph = new madrona::MWCudaLaunchGraph(
-        h->exec->buildLaunchGraphAllTaskGraphs());
+    h->stepGraph = simmgr::buildStepGraph<Traits>(*h->exec);
 #endif
 
     Traits::describeTensors(h->tensors, args->num_worlds);
@@ -173,6 +190,7 @@ void sim_destroy(SimHandle *h)
     if (!h) return;
 #ifndef SIM_BACKEND_REF_CPU
     delete h->stepGraph;
+    for (auto *g : h->probeGraphs) delete g;
 #endif
     delete h->exec;
     delete h;
@@ -298,6 +316,39 @@ int64_t sim_column_dump(SimHandle *h, uint32_t idx, void *dst,
 #else
     return mwhip_dump_column(h->exec->handle(), c.archetypeID, c.componentID,
                              dst, dst_bytes, world_counts);
+#endif
+}
+
+int sim_hip_run_taskgraph(SimHandle *h, uint32_t taskgraph_id)
+{
+#ifdef SIM_BACKEND_REF_CPU
+    (void)h; (void)taskgraph_id;
+    return -1;
+#else
+    if (taskgraph_id >= SimTraits::numTaskGraphs) return -1;
+    if (h->probeGraphs.size() <= taskgraph_id) {
+        h->probeGraphs.resize(taskgraph_id + 1, nullptr);
+    }
+    if (h->probeGraphs[taskgraph_id] == nullptr) {
+        h->probeGraphs[taskgraph_id] = new madrona::MWCudaLaunchGraph(
+            h->exec->buildLaunchGraph(taskgraph_id));
+    }
+    h->exec->run(*h->probeGraphs[taskgraph_id]);
+    return 0;
+#endif
+}
+
+int64_t sim_column_dump_raw(SimHandle *h, uint32_t idx, void *dst,
+                            uint64_t dst_bytes)
+{
+#ifdef SIM_BACKEND_REF_CPU
+    (void)h; (void)idx; (void)dst; (void)dst_bytes;
+    return -1;
+#else
+    if (idx >= h->columns.cols.size()) return -1;
+    const auto &c = h->columns.cols[idx];
+    return mwhip_dump_column_raw(h->exec->handle(), c.archetypeID,
+                                 c.componentID, dst, dst_bytes);
 #endif
 }
 

@@ -64,6 +64,14 @@ SIM_API int sim_column_info(SimHandle *h, uint32_t idx, SimColumnInfo *out);
 SIM_API int64_t sim_column_dump(SimHandle *h, uint32_t idx, void *dst, uint64_t dst_bytes,
                         int32_t *world_counts);
 
+/* HIP backend only (-1 on the reference): replays ONE task graph of the
+ * simulator (a test probe: e.g. a lone sort node), and copies a column in TABLE
+ * order -- every row below the table's row count, destroyed ones included, no
+ * grouping by world -- to look at the table between nodes.  Returns rows. */
+SIM_API int sim_hip_run_taskgraph(SimHandle *h, uint32_t taskgraph_id);
+SIM_API int64_t sim_column_dump_raw(SimHandle *h, uint32_t idx, void *dst,
+                                    uint64_t dst_bytes);
+
 /* HIP backend only (NULL/0 on the reference): opaque mwhip_exec* for profiling */
 SIM_API void *sim_hip_exec(SimHandle *h);
 /* launch-graph handle of the per-step graph inside that executor (0 on the reference) */

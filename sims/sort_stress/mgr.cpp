@@ -12,7 +12,10 @@ struct SimTraits {
 
     static constexpr uint32_t numExports =
         (uint32_t)sortstress::ExportID::NumExports;
-    static constexpr uint32_t numTaskGraphs = 1;
+    static constexpr uint32_t numTaskGraphs =
+        (uint32_t)sortstress::TaskGraphID::NumTaskGraphs;
+    // sim_step replays task graph 0 only (the others are test probes)
+    static constexpr bool stepIsTaskGraph0 = true;
 
     static Sim::Config makeConfig(const SimCreateArgs &args)
     {
@@ -33,7 +36,7 @@ struct SimTraits {
 template <typename T>
 void SimTraits::describeTensors(T &out, uint32_t num_worlds)
 {
-    out.push_back({ "churn", SIM_I32, { (int64_t)num_worlds, 2 },
+    out.push_back({ "churn", SIM_I32, { (int64_t)num_worlds, 3 },
                     (uint32_t)sortstress::ExportID::Churn });
 }
 
@@ -53,6 +56,11 @@ void SimTraits::describeColumns(T &cols)
     cols.template add<Item, Quad>("Item.Quad", true);
     cols.template add<Item, Blob20>("Item.Blob20", false);
     cols.template add<Item, Wide>("Item.Wide", true);
+#ifndef SIM_BACKEND_REF_CPU
+    // (the global tables of the HIP backend carry the world id as column 1;
+    // the reference CPU backend keeps one table per world)
+    cols.template add<Item, WorldID>("Item.WorldID", false);
+#endif
     cols.template add<Scratch, Key>("Scratch.Key", false);
     cols.template add<Scratch, Vec3>("Scratch.Vec3", true);
 }

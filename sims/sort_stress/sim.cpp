@@ -99,9 +99,53 @@ inline void scratchSystem(Engine &ctx, Key &key, Vec3 &v3)
     v3.v[2] = v3.v[2] + (float)ctx.worldID().idx + (float)(key.v & 7u);
 }
 
+// The same per-row update twice: as an items_per_invocation = 4
+// CustomParallelForNode (Fn(WorldID *, Cs *..., count), reference device
+// taskgraph.inl:229-266 -- that node type only exists in the reference's
+// device headers) and, for the CPU oracle, as an ordinary ParallelForNode.
+static inline void scaleOne(Half &h, Pair &p)
+{
+    h.v = (uint16_t)(h.v * 3u + 1u);
+    p.v += (uint64_t)h.v << 8;
+}
+
+#ifdef MADRONA_GPU_MODE
+inline void scaleBatch(WorldID *worlds, Half *halves, Pair *pairs,
+                       int32_t count)
+{
+    for (int32_t i = 0; i < count; i++) {
+        if (worlds[i].idx != -1) {
+            scaleOne(halves[i], pairs[i]);
+        }
+    }
+}
+#else
+inline void scaleSystem(Engine &, Half &h, Pair &p)
+{
+    scaleOne(h, p);
+}
+#endif
+
+// Works in per-step scratch memory (Context::tmpAlloc; freed by
+// ResetTmpAllocNode): fills a buffer, reads it back in another order.
+inline void scratchSumSystem(Engine &ctx, Churn &churn)
+{
+    constexpr int32_t n = 24;
+    uint32_t *buf = (uint32_t *)ctx.tmpAlloc(sizeof(uint32_t) * n);
+    for (int32_t i = 0; i < n; i++) {
+        buf[i] = churn.step * 2654435761u + (uint32_t)i * 40503u +
+            churn.numItems;
+    }
+    uint32_t sum = 0;
+    for (int32_t i = n - 1; i >= 0; i--) {
+        sum = sum * 31u + buf[i];
+    }
+    churn.scratchSum = sum;
+}
+
 void Sim::setupTasks(TaskGraphManager &taskgraph_mgr, const Config &)
 {
-    TaskGraphBuilder &builder = taskgraph_mgr.init(0);
+    TaskGraphBuilder &builder = taskgraph_mgr.init(TaskGraphID::Step);
 
     auto clear_tmp = builder.addToGraph<ClearTmpNode<Scratch>>({});
 
@@ -126,7 +170,35 @@ void Sim::setupTasks(TaskGraphManager &taskgraph_mgr, const Config &)
     auto scratch_sys = builder.addToGraph<ParallelForNode<Engine,
         scratchSystem, Key, Vec3>>({touch_sys});
 
-    (void)scratch_sys;
+#ifdef MADRONA_GPU_MODE
+    auto scale_sys = builder.addToGraph<CustomParallelForNode<Engine,
+        scaleBatch, 1, 4, Half, Pair>>({scratch_sys});
+#else
+    auto scale_sys = builder.addToGraph<ParallelForNode<Engine,
+        scaleSystem, Half, Pair>>({scratch_sys});
+#endif
+
+    auto sum_sys = builder.addToGraph<ParallelForNode<Engine,
+        scratchSumSystem, Churn>>({scale_sys});
+    auto reset_tmp = builder.addToGraph<ResetTmpAllocNode>({sum_sys});
+    (void)reset_tmp;
+
+#ifdef MADRONA_GPU_MODE
+    {
+        TaskGraphBuilder &b = taskgraph_mgr.init(TaskGraphID::ChurnOnly);
+        auto clear = b.addToGraph<ClearTmpNode<Scratch>>({});
+        b.addToGraph<ParallelForNode<Engine, churnSystem, Churn>>({clear});
+    }
+    {
+        TaskGraphBuilder &b = taskgraph_mgr.init(TaskGraphID::SortByKey);
+        b.addToGraph<SortArchetypeNode<Item, Key>>({});
+    }
+    {
+        TaskGraphBuilder &b = taskgraph_mgr.init(TaskGraphID::CompactOnly);
+        auto c = b.addToGraph<CompactArchetypeNode<Item>>({});
+        b.addToGraph<SortArchetypeNode<Scratch, WorldID>>({c});
+    }
+#endif
 }
 
 Sim::Sim(Engine &ctx, const Config &cfg, const WorldInit &)
@@ -141,6 +213,7 @@ Sim::Sim(Engine &ctx, const Config &cfg, const WorldInit &)
     Churn &churn = ctx.singleton<Churn>();
     churn.step = 0;
     churn.numItems = 0;
+    churn.scratchSum = 0;
 
     // ragged start; with coldStart some worlds begin empty
     int32_t initial = cfg.coldStart != 0 ?

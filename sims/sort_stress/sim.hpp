@@ -38,6 +38,24 @@ struct Wide { float v[60]; };
 struct Churn {
     uint32_t step;
     uint32_t numItems;
+    // written by a system that works in Context::tmpAlloc scratch
+    uint32_t scratchSum;
+};
+
+// Task graphs.  Step = the graph every parity test replays.  The other three
+// exist on the HIP backend only and split a step so that a test can look at
+// the table between nodes: churn WITHOUT compaction (destroyed rows stay),
+// SortArchetypeNode<Item, Key> alone (a sort by a non-WorldID key: the
+// reference CPU backend's sortArchetype is not an oracle for it),
+// and the compaction that has to follow it.
+enum class TaskGraphID : uint32_t {
+    Step,
+#ifdef MADRONA_GPU_MODE
+    ChurnOnly,
+    SortByKey,
+    CompactOnly,
+#endif
+    NumTaskGraphs,
 };
 
 struct Item : public madrona::Archetype<

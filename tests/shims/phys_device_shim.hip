@@ -116,11 +116,72 @@ collideKernel(const ObjectManager *obj_mgr, const PairIn *pairs,
     }
 }
 
+// The reference's own known-answer tests for code on this path, evaluated by
+// the overlay's headers ON THE DEVICE: tests/math.cpp:23-48 (quaternions) and
+// tests/gjk.cpp:19-48 (simplex sub-solvers of the sphere-hull GJK).
+__global__ void katKernel(float *out)
+{
+    using math::Quat;
+    using math::Vector3;
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+
+    Quat q1 = Quat::angleAxis(0, { 0, 1, 0 });
+    Quat q2 = Quat::angleAxis(math::toRadians(45), { 0, 1, 0 });
+    Quat q3 = Quat::angleAxis(math::toRadians(45), { 1, 0, 0 });
+    Quat m1 = q2 * q3;
+    const Quat qs[4] = { q1, q2, q3, m1 };
+    for (int i = 0; i < 4; i++) {
+        out[4 * i + 0] = qs[i].w;
+        out[4 * i + 1] = qs[i].x;
+        out[4 * i + 2] = qs[i].y;
+        out[4 * i + 3] = qs[i].z;
+    }
+
+    {
+        Vector3 Y[4] {
+            { 0.814353108f, 0.195752025f, -0.698764443f },
+            { -0.784147143f, 0.126484752f, 0.701235533f },
+            { -0.784147143f, 0.126484752f, -0.698764443f },
+            { -0.784147143f, 0.126484752f, 0.701235533f },
+        };
+        gjk::SimplexSolve s3 = gjk::solveTriangle(Y[0], Y[1], Y[2]);
+        gjk::SimplexSolve s4 = gjk::solveTetrahedron(Y[0], Y[1], Y[2], Y[3]);
+        out[16] = s3.vLen2;
+        out[17] = s4.vLen2;
+    }
+    {
+        Vector3 Y[4] {
+            { 0.793287277f, 2.86326122f, -0.700307727f },
+            { -0.794485092f, -0.542466521f, 0.699692249f },
+            { 0.80550468f, -0.536717057f, -0.700307727f },
+            { -0.794485092f, -0.542466521f, -0.700307727f },
+        };
+        gjk::SimplexSolve s = gjk::solveTetrahedron(Y[0], Y[1], Y[2], Y[3]);
+        out[18] = s.v.x;
+        out[19] = s.v.y;
+        out[20] = s.v.z;
+        out[21] = s.vLen2;
+    }
+}
+
 }
 
 extern "C" {
 
 #define API __attribute__((visibility("default")))
+
+// out[22]: q1, q2, q3, q2*q3 (w x y z each), |v|^2 of the 3- and 4-simplex
+// solves with a duplicated point, v and |v|^2 of the simplex around the origin
+API int32_t dev_reference_kats(float *out)
+{
+    float *d_out = nullptr;
+    if (hipMalloc(&d_out, sizeof(float) * 22) != hipSuccess) return -2;
+    hipLaunchKernelGGL(katKernel, dim3(1), dim3(64), 0, 0, d_out);
+    int32_t rc = hipDeviceSynchronize() == hipSuccess ? 0 : -3;
+    (void)hipMemcpy(out, d_out, sizeof(float) * 22, hipMemcpyDeviceToHost);
+    (void)hipFree(d_out);
+    return rc;
+}
 
 // kind: 0 hull-hull, 1 hull-plane, 2 sphere (a) - hull (b); see modes above.
 // out: num_pairs x 28 floats, flags: num_pairs (bit 0: face too big for the

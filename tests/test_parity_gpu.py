@@ -252,6 +252,35 @@ def test_standalone_broadphase_candidates(built, worlds):
                 assert rp[0][0] == hp[0][1] and rp[1][0] == hp[1][1], (step, rw)
 
 
+def test_ball_pit_hinge_joints(built):
+    """Hinge joints (reference src/physics/xpbd.cpp:686-693 and the two
+    orientation constraints before it).  A hinged chain is not stable on the
+    reference itself (its positional correction pushes the anchors apart:
+    positions grow ~5x per step and the CPU backend stops making progress after
+    a dozen steps), so the pin is the first steps of that trajectory, bit for
+    bit, 20 substeps of the joint solve with contacts around it."""
+    _need_ref("ball_pit")
+    probs, step = run_pair("ball_pit", 96, 5, flags=1 << 24)
+    assert not probs, (step, probs[:3])
+
+
+def test_ball_pit_entity_aabb_overlap(built):
+    """PhysicsSystem::checkEntityAABBOverlap (reference src/physics/
+    physics.cpp:159-) decides the direction of every kick."""
+    _need_ref("ball_pit")
+    probs, step = run_pair("ball_pit", 128, 150, flags=(1 << 25) | 60,
+                           check_every=10)
+    assert not probs, (step, probs[:3])
+    # the test really steered something: the trajectory differs from the plain one
+    with Simulator(hip_lib_path("ball_pit"), 16, flags=1 << 25) as a, \
+            Simulator(hip_lib_path("ball_pit"), 16, flags=0) as b:
+        a.step(100)
+        b.step(100)
+        pa = a.dump_all()["MovableObject.Position"][0]
+        pb = b.dump_all()["MovableObject.Position"][0]
+        assert not np.array_equal(pa, pb)
+
+
 @pytest.mark.parametrize("worlds", [1, 2, 33, 255, 256, 300, 5000])
 def test_sort_stress_lockstep(built, worlds):
     """Ragged / empty worlds, every gather width (1..240 B columns),

@@ -100,3 +100,21 @@ def test_device_narrowphase_matches_reference(libs, mesh, kind, mode):
     else:
         assert checked == n
     assert hits > n // 20, "the configurations hardly ever touch"
+
+
+def test_reference_kats_on_device(built):
+    """The reference's known answers for this path (tests/math.cpp:23-48
+    quaternions, tests/gjk.cpp:19-48 GJK simplex solves), computed by the
+    overlay's math.hpp / phys_impl/gjk.hpp on the MI355X, with the reference's
+    own tolerances."""
+    dev = C.CDLL(DEV)
+    dev.dev_reference_kats.restype = C.c_int32
+    dev.dev_reference_kats.argtypes = [C.POINTER(C.c_float)]
+    out = (C.c_float * 22)()
+    assert dev.dev_reference_kats(out) == 0
+    o = np.array(out[:], dtype=np.float64)
+    want = [[1, 0, 0, 0], [0.9238795, 0, 0.3826834, 0], [0.9238795, 0.3826834, 0, 0],
+            [0.853553, 0.353553, 0.353553, -0.146447]]
+    assert np.abs(o[:16].reshape(4, 4) - np.array(want)).max() < 1e-4   # EXPECT_NEAR 1e-4
+    assert o[17] - o[16] <= 1e-5            # Solve4SimplexDuplicatePoint
+    assert (np.abs(o[18:21]) < 1e-5).all() and o[21] < 1e-5     # ...AroundOrigin
