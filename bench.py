@@ -159,11 +159,8 @@ def fill_actions(sim_name, sim, worlds, gpu_id, seed):
     torch.cuda.synchronize()
 
 
-def kernel_table(stats, sim_name, worlds):
-    """mwhip_profile output -> JSON rows.  ParallelFor bytes come from the
-    system's signature (`T&` = read + write): an upper bound on what it moves
-    (rows that return early move less), so no GB/s is derived from them."""
-    rows = []
+def annotate(stats, sim_name, worlds):
+    """Algorithmic bytes the executor cannot know: the fused physics step."""
     for k in stats:
         if k["name"].startswith("physics:worldStep"):
             k["algo_bytes"] = (float(worlds) * PHYS_BYTES_PER_BODY *
@@ -171,6 +168,15 @@ def kernel_table(stats, sim_name, worlds):
             k["exact"] = True
         else:
             k["exact"] = ":sort." in k["name"]
+    return stats
+
+
+def kernel_table(stats, sim_name, worlds):
+    """mwhip_profile output -> JSON rows.  ParallelFor bytes come from the
+    system's signature (`T&` = read + write): an upper bound on what it moves
+    (rows that return early move less), so no GB/s is derived from them."""
+    rows = []
+    for k in annotate(stats, sim_name, worlds):
         row = {"name": k["name"], "avg_us": round(k["avg_us"], 2),
                "rows": round(k["rows"], 1)}
         if k["exact"]:
@@ -207,6 +213,7 @@ def rooflines(stats, sim_name, worlds, ms_per_step):
     `roofline.nodes`: the WHOLE sort node (every kernel of every sort chain in
     the step), the fused physics step, and the step as a whole."""
     entries = recorded_traffic()
+    annotate(stats, sim_name, worlds)
     sort_k = [k for k in stats if ":sort." in k["name"]]
     phys_k = [k for k in stats if k["name"].startswith("physics:worldStep")]
 
@@ -226,7 +233,7 @@ def rooflines(stats, sim_name, worlds, ms_per_step):
         "per step (288 B/body); DESIGN.md §10")
     # step level: every kernel's algorithmic bytes over the measured step time
     step_bytes = sum(k["algo_bytes"] for k in stats)
-    t, src = traffic_for(entries, sim_name, worlds, "")
+    t, src = traffic_for(entries, sim_name, worlds, "step:all-kernels")
     achieved = step_bytes / (ms_per_step * 1e-3) / 1e9
     nodes["step"] = {
         "kernel": "whole step (all launches of one replay)", "bound": "hbm",
