@@ -12,8 +12,12 @@
 
 #include <hip/hip_ext.h>
 
+#include <atomic>
+#include <chrono>
 #include <cinttypes>
 #include <cstdarg>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
@@ -445,6 +449,13 @@ struct mwhip_exec {
     std::unordered_map<uint64_t, std::unique_ptr<LaunchGraph>> launchGraphs;
     uint64_t nextGraphHandle = 1;
 
+    // mwGPU::HostPrint: ring in pinned host memory + the thread that drains it
+    // while replays are in flight (replaces the reference's HostPrintCPU
+    // thread, src/mw/cuda_exec.cpp)
+    HostPrintRing *printRing = nullptr;
+    std::mutex printMutex;
+    std::thread printThread;
+    std::atomic<bool> printStop { false };
     int32_t *statsHost = nullptr;           // pinned, device-visible
     std::vector<void *> allocations;
     std::vector<std::unique_ptr<VmRange>> vmRanges;
@@ -1101,6 +1112,13 @@ static int buildDeviceState(mwhip_exec *exec)
             hipMemcpyHostToDevice));
     }
 
+    // device -> host message ring of mwGPU::HostPrint
+    HIPCHK(hipHostMalloc((void **)&exec->printRing, sizeof(HostPrintRing),
+                         hipHostMallocMapped));
+    memset((void *)exec->printRing, 0, sizeof(HostPrintRing));
+    HIPCHK(hipHostGetDevicePointer((void **)&hs.hostPrintRing,
+                                   exec->printRing, 0));
+
     rc = devAllocT(exec, &exec->stateDev, 1);
     if (rc != 0) return rc;
     HIPCHK(hipMemcpy(exec->stateDev, &hs, sizeof(EcsState),
@@ -1123,6 +1141,85 @@ static int buildDeviceState(mwhip_exec *exec)
 
     exec->stateBuilt = true;
     return 0;
+}
+
+// ---------------------------------------------------------------------------
+// mwGPU::HostPrint, host side: "{}" placeholders, one line per record
+// (reference HostPrintCPU, src/mw/cuda_exec.cpp: same placeholder syntax)
+// ---------------------------------------------------------------------------
+static void printRecord(const HostPrintRecord &rec)
+{
+    std::string out;
+    uint32_t next_arg = 0;
+    char num[64];
+    for (const char *p = rec.fmt; *p != '\0' &&
+             p < rec.fmt + HostPrintRecord::maxChars; p++) {
+        if (p[0] == '{' && p[1] == '}' && next_arg < rec.numArgs &&
+                next_arg < (uint32_t)HostPrintRecord::maxArgs) {
+            const uint64_t v = rec.args[next_arg];
+            switch (rec.types[next_arg]) {
+            case HostPrintRecord::I32:
+                snprintf(num, sizeof(num), "%d", (int32_t)(int64_t)v); break;
+            case HostPrintRecord::U32:
+                snprintf(num, sizeof(num), "%u", (uint32_t)v); break;
+            case HostPrintRecord::I64:
+                snprintf(num, sizeof(num), "%" PRId64, (int64_t)v); break;
+            case HostPrintRecord::U64:
+                snprintf(num, sizeof(num), "%" PRIu64, v); break;
+            case HostPrintRecord::Float: {
+                uint32_t bits = (uint32_t)v;
+                float f;
+                memcpy(&f, &bits, sizeof(f));
+                snprintf(num, sizeof(num), "%f", f);
+            } break;
+            default:
+                snprintf(num, sizeof(num), "%p", (void *)(uintptr_t)v); break;
+            }
+            out += num;
+            next_arg++;
+            p++;
+        } else {
+            out += *p;
+        }
+    }
+    printf("%s\n", out.c_str());
+}
+
+// Prints completed records in ticket order.  in_flight: writers may still be
+// running, stop at the first incomplete record; otherwise (the stream has been
+// waited for) an incomplete record below head is one its writer dropped
+// because the ring was full.
+static void drainHostPrints(mwhip_exec *exec, bool in_flight)
+{
+    HostPrintRing *ring = exec->printRing;
+    if (ring == nullptr) return;
+    std::lock_guard<std::mutex> guard(exec->printMutex);
+
+    const uint64_t head = __atomic_load_n(&ring->head, __ATOMIC_ACQUIRE);
+    uint64_t tail = ring->tail;
+    bool printed = false;
+    while (tail < head) {
+        HostPrintRecord &rec = ring->records[tail % HostPrintRing::numRecords];
+        const uint64_t seq = __atomic_load_n(&rec.seq, __ATOMIC_ACQUIRE);
+        if (seq == tail + 1) {
+            printRecord(rec);
+            printed = true;
+        } else if (in_flight) {
+            break;
+        }
+        tail += 1;
+        __atomic_store_n(&ring->tail, tail, __ATOMIC_RELEASE);
+    }
+    if (!in_flight) {
+        const uint64_t dropped =
+            __atomic_exchange_n(&ring->dropped, 0ull, __ATOMIC_RELAXED);
+        if (dropped != 0) {
+            printf("madrona_amd: HostPrint ring overflow, %" PRIu64
+                   " message(s) dropped\n", dropped);
+            printed = true;
+        }
+    }
+    if (printed) fflush(stdout);
 }
 
 template <typename T>
@@ -1877,7 +1974,18 @@ extern "C" int mwhip_create(const mwhip_state_config *cfg,
     g_lastError.clear();
     entry->setup_tasks(exec.get(), cfg->user_config_ptr);
 
-    *out = exec.release();
+    // messages of the world constructors; from here on a thread keeps the ring
+    // drained while replays are queued without being waited for
+    drainHostPrints(exec.get(), false);
+    mwhip_exec *raw = exec.release();
+    raw->printThread = std::thread([raw]() {
+        while (!raw->printStop.load()) {
+            drainHostPrints(raw, true);
+            std::this_thread::sleep_for(std::chrono::milliseconds(2));
+        }
+    });
+
+    *out = raw;
     return 0;
 }
 
@@ -1894,6 +2002,10 @@ extern "C" void mwhip_destroy(mwhip_exec *exec)
         (void)hipFree(p);
     }
     vmFreeAll(exec);
+    exec->printStop.store(true);
+    if (exec->printThread.joinable()) exec->printThread.join();
+    drainHostPrints(exec, false);
+    if (exec->printRing) (void)hipHostFree(exec->printRing);
     if (exec->statsHost) (void)hipHostFree(exec->statsHost);
     (void)hipStreamDestroy(exec->stream);
     delete exec;
@@ -2227,6 +2339,7 @@ extern "C" int mwhip_run(mwhip_exec *exec, uint64_t graph)
     HIPCHK(hipGraphLaunch(it->second->graphExec, exec->stream));
     exec->replaysLaunched++;
     HIPCHK(hipStreamSynchronize(exec->stream));
+    drainHostPrints(exec, false);
     int rc = checkHealth(exec);
     if (rc != 0) return rc;
     return growTablesAfterReplay(exec);
@@ -2362,6 +2475,7 @@ extern "C" uint32_t mwhip_num_table_growths(mwhip_exec *exec)
 extern "C" int mwhip_synchronize(mwhip_exec *exec)
 {
     HIPCHK(hipStreamSynchronize(exec->stream));
+    drainHostPrints(exec, false);
     int rc = checkHealth(exec);
     if (rc != 0) return rc;
     return growTablesAfterReplay(exec);

@@ -99,6 +99,30 @@ struct IdCache {
     uint32_t pad_;
 };
 
+// Device -> host message ring of mwGPU::HostPrint (madrona/mw_gpu/
+// host_print.hpp), in pinned host memory mapped into the device.
+struct HostPrintRecord {
+    static constexpr int32_t maxArgs = 12;
+    static constexpr int32_t maxChars = 120;
+    enum Type : uint8_t { I32, U32, I64, U64, Float, Ptr };
+
+    unsigned long long seq;         // 1 + ticket once the record is complete
+    unsigned long long args[maxArgs];
+    uint32_t numArgs;
+    uint8_t types[maxArgs];
+    char fmt[maxChars];
+};
+
+struct HostPrintRing {
+    static constexpr uint32_t numRecords = 1024;
+
+    unsigned long long head;        // next ticket (device, system-scope atomics)
+    unsigned long long tail;        // tickets below this have been printed (host)
+    unsigned long long dropped;
+    unsigned long long pad_;
+    HostPrintRecord records[numRecords];
+};
+
 struct EcsState {
     TableHdr *tables;               // [numArchetypeSlots]
     uint16_t *colLookup;            // [numArchetypeSlots * numComponentSlots]
@@ -136,6 +160,7 @@ struct EcsState {
     int32_t runtimeIdBase;          // first id of the post-init block partition
     int32_t pad_;
     void *moduleData[4];            // module-private device pointers (physics scratch, ...)
+    HostPrintRing *hostPrintRing;   // pinned host memory, or nullptr
 };
 
 // Load through the constant address space: for data no kernel of the *user*

@@ -6,6 +6,7 @@
 #include <madrona/types.hpp>
 
 #include <array>
+#include <cstddef>
 #include <initializer_list>
 #include <type_traits>
 

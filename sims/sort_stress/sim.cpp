@@ -2,6 +2,7 @@
 
 #ifdef MADRONA_GPU_MODE
 #include <madrona/mw_gpu_entry.hpp>
+#include <madrona/mw_gpu/host_print.hpp>
 #endif
 
 using namespace madrona;
@@ -84,6 +85,18 @@ inline void churnSystem(Engine &ctx, Churn &churn)
 
     churn.step += 1;
     churn.numItems = (uint32_t)sim.numItems;
+
+#ifdef MADRONA_GPU_MODE
+    // device-side printf through the executor's message ring (every argument
+    // type the channel carries); world 3 speaks once, at its third step
+    if (ctx.worldID().idx == 3 && churn.step == 3u) {
+        mwGPU::HostPrint::log(
+            "sort_stress: world {} step {} items {} mean {} key {} ptr {}",
+            ctx.worldID().idx, churn.step, (int64_t)sim.numItems,
+            (float)sim.numItems * 0.5f, (uint64_t)0x123456789ABCull,
+            (void *)&sim);
+    }
+#endif
 }
 
 inline void touchSystem(Engine &ctx, Entity e, Key &key, Vec3 &v3, Wide &wide)

@@ -42,8 +42,8 @@ def test_simulator_library_exports_c_api(built, sim):
     C.CDLL(os.path.join(HIP_BUILD_DIR, "libmadrona_hip.so"), mode=C.RTLD_GLOBAL)
     lib = C.CDLL(hip_lib_path(sim))
     for fn in ["sim_create", "sim_destroy", "sim_step", "sim_tensor_ptr",
-               "sim_column_dump", "sim_hip_exec", "sim_hip_step_graph",
-               "madronaMWHipUserEntry"]:
+               "sim_column_dump", "sim_column_dump_raw", "sim_hip_run_taskgraph",
+               "sim_hip_exec", "sim_hip_step_graph", "madronaMWHipUserEntry"]:
         assert hasattr(lib, fn), fn
 
 
@@ -60,4 +60,20 @@ def test_physics_test_shims_are_built(built):
     host = C.CDLL(os.path.join(HIP_BUILD_DIR, "libphys_host_test.so"))
     assert hasattr(host, "amd_bake_objects") and hasattr(host, "amd_collide_pair")
     dev = C.CDLL(os.path.join(HIP_BUILD_DIR, "libphys_device_test.so"))
-    assert hasattr(dev, "dev_collide_pairs")
+    assert hasattr(dev, "dev_collide_pairs") and hasattr(dev, "dev_reference_kats")
+
+
+def test_overlay_headers_of_the_boundary_exist(built):
+    """Every header SURVEY 8b says simulators / Managers / bindings include is
+    part of the overlay (their contents are compiled and exercised by
+    tests/test_api_conformance.py)."""
+    inc = os.path.join(REPO_ROOT, "madrona_amd", "include", "madrona")
+    for rel in ["sync.hpp", "memory.hpp", "dyn_array.hpp", "heap_array.hpp",
+                "inline_array.hpp", "mw_gpu/const.hpp", "mw_gpu/host_print.hpp",
+                "py/utils.hpp", "mw_gpu.hpp", "mw_gpu_entry.hpp", "taskgraph_builder.hpp",
+                "custom_context.hpp", "physics.hpp", "physics_loader.hpp"]:
+        assert os.path.exists(os.path.join(inc, rel)), rel
+    conf = C.CDLL(os.path.join(HIP_BUILD_DIR, "libapi_conformance.so"))
+    for fn in ["conf_containers", "conf_tensor_bytes", "conf_run",
+               "madronaMWHipUserEntry"]:
+        assert hasattr(conf, fn), fn
