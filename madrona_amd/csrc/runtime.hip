@@ -1369,7 +1369,23 @@ static int makeSortBatch(mwhip_exec *exec,
         site.state = arch.sortState;
         sites.push_back(site);
 
+        out->maxCapacity = std::max(out->maxCapacity, arch.capacity);
+        uint32_t site_columns = 0;
+        if (world_sort) {
+            // first in the list: its two binary-search chains per world overlap
+            // with the column traffic of the workgroups scheduled after it
+            GatherColumn ranges {};
+            ranges.site = (uint32_t)sites.size() - 1;
+            ranges.column = kWorldRangesColumn;
+            cols.push_back(ranges);
+            site_columns++;
+        }
         for (uint32_t c = 0; c < arch.numColumns; c++) {
+            if ((arch.colFlags[c] & kColumnPinned) != 0u) {
+                out->hasPinned = true;
+                sites.back().hasPinned = 1u;
+            }
+            site_columns++;
             uint32_t bytes = arch.colBytes[c];
             GatherColumn gc {};
             gc.site = (uint32_t)sites.size() - 1;
@@ -1381,6 +1397,7 @@ static int makeSortBatch(mwhip_exec *exec,
                 (~0ull / gc.wordsPerRow) + 1ull;
             cols.push_back(gc);
         }
+        sites.back().numGatherColumns = site_columns;
     }
 
     int rc = devAllocT(exec, &out->sitesDev, sites.size());
@@ -2752,6 +2769,7 @@ extern "C" int32_t mwhip_profile(mwhip_exec *exec, uint64_t graph, uint32_t reps
     for (size_t b = 0; b < lg.sortBatches.size(); b++) {
         const SortBatch &batch = *lg.sortBatches[b];
         double hist = 0, pass0 = 0, passn = 0, gather = 0, fin = 0, rows_in = 0;
+        double passes_small = 0;
         for (size_t s = 0; s < batch.sites.size(); s++) {
             HIPCHK(hipMemcpy(&snaps[b][s].after, batch.sites[s].stateDev,
                 sizeof(SortState), hipMemcpyDeviceToHost));
@@ -2764,12 +2782,16 @@ extern "C" int32_t mwhip_profile(mwhip_exec *exec, uint64_t graph, uint32_t reps
             double runs = (double)(snaps[b][s].after.statRuns -
                                    snaps[b][s].before.statRuns) / share;
             rows_in += n_in;
-            hist += 4.0 * n_in + 8.0 * exec->cfg.num_worlds * runs;
+            hist += 4.0 * n_in;
             pass0 += 4.0 * n_in + 8.0 * n_in;
             passn += 16.0 * n_in;
+            // index read + every column read and written once + Loc remap +
+            // the world's offset / count pair (world sorts)
             gather += 4.0 * n_out + 2.0 * batch.sites[s].rowBytes * n_out +
-                4.0 * n_out;
-            fin += 8.0 * exec->cfg.num_worlds * runs;
+                4.0 * n_out +
+                (batch.sites[s].worldSort ?
+                     8.0 * exec->cfg.num_worlds * runs : 0.0);
+            passes_small += (batch.sites[s].numPasses - 1) * 16.0 * n_in;
         }
         uint32_t pass_idx = 0;
         for (size_t i = 0; i < n; i++) {
@@ -2784,6 +2806,9 @@ extern "C" int32_t mwhip_profile(mwhip_exec *exec, uint64_t graph, uint32_t reps
                 break;
             case SortRole::Gather: bytes = gather; break;
             case SortRole::Finalize: bytes = fin; break;
+            case SortRole::Small:
+                bytes = hist + pass0 + passes_small + gather;
+                break;
             default: break;
             }
             total_bytes[i] = bytes * reps;

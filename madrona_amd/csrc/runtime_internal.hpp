@@ -25,7 +25,7 @@ struct SortState {
     uint32_t numValid;              // rows whose key != 0xFFFFFFFF
     uint32_t epoch;                 // tags look-back granules; never reset
     uint32_t finalizeArrivals;
-    uint32_t pad_;
+    uint32_t gatherArrivals;        // gather workgroups done (last one publishes)
     unsigned long long statRowsIn;  // cumulative, for measurement
     unsigned long long statRowsOut;
     unsigned long long statRuns;
@@ -36,6 +36,8 @@ struct SortSite {
     uint32_t keyColumn;
     int32_t numPasses;
     uint32_t worldSort;
+    uint32_t numGatherColumns;      // gather grid rows (blockIdx.y) of this site
+    uint32_t hasPinned;             // some column must keep its address
     uint32_t *keysA;
     uint32_t *keysB;
     int32_t *idxA;
@@ -44,9 +46,12 @@ struct SortSite {
     SortState *state;
 };
 
+// pseudo-column of a world-sort site: rebuild worldOffsets / worldCounts
+inline constexpr uint32_t kWorldRangesColumn = 0xFFFFFFFFu;
+
 struct GatherColumn {
     uint32_t site;
-    uint32_t column;
+    uint32_t column;                // or kWorldRangesColumn
     uint32_t wordBytes;             // 16 / 8 / 4 / 1
     uint32_t wordsPerRow;
     unsigned long long invMagic;    // floor(2^64 / wordsPerRow) + 1
@@ -62,7 +67,7 @@ struct SortSiteHost {
     SortState *stateDev;
 };
 
-enum class SortRole : uint32_t { None, Histogram, Onesweep, Gather, Finalize };
+enum class SortRole : uint32_t { None, Histogram, Onesweep, Gather, Finalize, Small };
 
 struct SortBatch {
     std::vector<SortSiteHost> sites;
@@ -70,6 +75,8 @@ struct SortBatch {
     SortSite *sitesDev = nullptr;
     GatherColumn *gatherColumnsDev = nullptr;
     uint32_t numGatherColumns = 0;
+    bool hasPinned = false;         // a sorted table has exported columns
+    uint32_t maxCapacity = 0;
 };
 
 // ---- launches ------------------------------------------------------------------
@@ -124,6 +131,7 @@ struct KernelLaunch {
 
 int sortNumPasses(bool world_sort, uint32_t num_worlds);
 uint32_t sortTileSize();
+uint32_t sortSmallRowLimit();
 void buildSortLaunches(const SortBatch &batch, std::vector<KernelLaunch> &out);
 
 }

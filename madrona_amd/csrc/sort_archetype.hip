@@ -42,6 +42,9 @@ namespace mwhip {
 
 namespace {
 
+// tables whose capacity is at most this take the single-launch path (sortSmall)
+constexpr uint32_t kSmallSortRows = 32768;
+
 constexpr int kSortThreads = 256;
 constexpr int kSortWaves = kSortThreads / 64;
 constexpr int kSortItems = 8;
@@ -167,14 +170,6 @@ sortHistogram(EcsState *S, const SortSite *sites)
         atomicAdd(&state->numValid, lds_valid);
     }
 
-    if (site.worldSort) {
-        // sentinel: "no row of this world seen"; fixed up in sortFinalize
-        for (int32_t w = (int32_t)(blockIdx.x * kSortThreads + threadIdx.x);
-             w < S->numWorlds; w += stride) {
-            tbl.worldOffsets[w] = -1;
-            tbl.worldCounts[w] = -1;
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------
@@ -388,11 +383,12 @@ __device__ inline void gatherWords(const WordT *__restrict__ src,
                                    WordT *__restrict__ dst,
                                    const int32_t *__restrict__ perm,
                                    int32_t num_rows, uint32_t words_per_row,
-                                   unsigned long long inv_magic)
+                                   unsigned long long inv_magic,
+                                   int32_t first, int32_t step)
 {
     const long long total = (long long)num_rows * words_per_row;
-    const long long stride = (long long)gridDim.x * kSortThreads;
-    long long j = (long long)blockIdx.x * kSortThreads + threadIdx.x;
+    const long long stride = step;
+    long long j = first;
 
     // Four independent (index -> word) chains in flight per thread: at
     // Escape-Room sizes a thread only has a handful of words, and without the
@@ -445,8 +441,86 @@ __device__ inline void gatherWords(const WordT *__restrict__ src,
 struct alignas(16) Word16 { uint32_t v[4]; };
 struct alignas(8) Word8 { uint32_t v[2]; };
 
+// first index in sorted[0, n) whose key is >= key
+__device__ inline int32_t lowerBound(const uint32_t *__restrict__ sorted,
+                                     int32_t n, uint32_t key)
+{
+    int32_t lo = 0, len = n;
+    while (len > 0) {
+        int32_t half = len >> 1;
+        bool right = sorted[lo + half] < key;
+        lo = right ? lo + half + 1 : lo;
+        len = right ? len - half - 1 : half;
+    }
+    return lo;
+}
+
+// worldOffsets[w] / worldCounts[w] straight from the sorted keys: two binary
+// searches per world (independent chains, ~log2 n cached loads each).  No
+// sentinel pass before and no fix-up pass after the gather, and worlds without
+// rows come out right by construction (count 0 at the position they would
+// occupy).  tid / stride enumerate the worlds.
+__device__ inline void writeWorldRanges(TableHdr &tbl,
+                                        const uint32_t *__restrict__ sorted,
+                                        int32_t n_out, int32_t num_worlds,
+                                        int32_t tid, int32_t stride)
+{
+    for (int32_t w = tid; w < num_worlds; w += stride) {
+        int32_t first = lowerBound(sorted, n_out, (uint32_t)w);
+        int32_t end = lowerBound(sorted, n_out, (uint32_t)w + 1u);
+        tbl.worldOffsets[w] = first;
+        tbl.worldCounts[w] = end - first;
+    }
+}
+
+// Makes the sorted table current: ping-pong swap of every column that is not
+// pinned, new row count, sort state cleaned for the next run.  Executed by ONE
+// workgroup once every gather workgroup of the site is done.
+__device__ inline void publishSite(EcsState *S, const SortSite &site,
+                                   TableHdr &tbl, int32_t n, int32_t n_out)
+{
+    SortState *state = site.state;
+    for (int32_t c = threadIdx.x; c < tbl.numColumns; c += blockDim.x) {
+        if ((tbl.columnFlags[c] & kColumnPinned) == 0u) {
+            void *tmp = tbl.columns[c];
+            void *cur = tbl.columnsAlt[c];
+            tbl.columns[c] = cur;
+            tbl.columnsAlt[c] = tmp;
+            S->colPtr[site.archetype * S->numComponentSlots +
+                      tbl.columnComponent[c]] = cur;
+        }
+    }
+    for (int i = threadIdx.x; i < 4 * kRadixDigits; i += blockDim.x) {
+        state->bins[i] = 0;
+    }
+    if (threadIdx.x == 0) {
+        state->statRowsIn += (unsigned long long)n;
+        state->statRowsOut += (unsigned long long)n_out;
+        state->statRuns += 1ull;
+
+        tbl.numRows = n_out;
+        // A sort by any other key scrambles the rows across worlds: the next
+        // world sort / compaction must not early-out, worldOffsets / worldCounts
+        // are stale until then (reference sort_archetype.cpp:1001-1007).
+        tbl.needsSort = site.worldSort ? 0u : 1u;
+        state->numValid = 0;
+        state->finalizeArrivals = 0;
+        state->gatherArrivals = 0;
+        for (int p = 0; p < 4; p++) state->tileCounter[p] = 0;
+        state->epoch += 1u;
+    }
+}
+
+// One column (blockIdx.y) of one site.  publish != 0: the batch has no pinned
+// column, so there is no copy-back to wait for and the last workgroup of a site
+// to finish publishes the table itself (no finalize launch).
+__device__ inline void gatherColumn(EcsState *S, const SortSite &site,
+                                    const GatherColumn &gc, TableHdr &tbl,
+                                    int32_t n_out, int32_t tid, int32_t stride);
+
 __global__ void __launch_bounds__(kSortThreads)
-sortGather(EcsState *S, const SortSite *sites, const GatherColumn *columns)
+sortGather(EcsState *S, const SortSite *sites, const GatherColumn *columns,
+           uint32_t publish)
 {
     const GatherColumn gc = columns[blockIdx.y];
     const SortSite &site = sites[gc.site];
@@ -460,10 +534,47 @@ sortGather(EcsState *S, const SortSite *sites, const GatherColumn *columns)
     const int32_t n = tbl.numRows;
     const int32_t n_out = site.worldSort ? (int32_t)state->numValid : n;
 
+    gatherColumn(S, site, gc, tbl, n_out,
+                 (int32_t)(blockIdx.x * kSortThreads + threadIdx.x),
+                 (int32_t)(gridDim.x * kSortThreads));
+
+    if (publish == 0u) {
+        return;
+    }
+
+    // last workgroup of this site (all of its columns + the world ranges)
+    __shared__ bool is_last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // (relaxed: the publisher swaps pointers and counters, it does not
+        // read what the other workgroups gathered; an agent-scope release per
+        // workgroup would write back its XCD's L2 every time)
+        uint32_t done = __hip_atomic_fetch_add(&state->gatherArrivals, 1u,
+            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = (done == gridDim.x * site.numGatherColumns - 1u);
+    }
+    __syncthreads();
+    if (is_last) {
+        publishSite(S, site, tbl, n, n_out);
+    }
+}
+
+// tid / stride: this thread's index among, and the number of, the threads
+// working on the column
+__device__ inline void gatherColumn(EcsState *S, const SortSite &site,
+                                    const GatherColumn &gc, TableHdr &tbl,
+                                    int32_t n_out, int32_t tid, int32_t stride)
+{
     const bool final_in_b = ((site.numPasses - 1) & 1) != 0;
     const int32_t *perm = final_in_b ? site.idxB : site.idxA;
 
     const uint32_t col = gc.column;
+    if (col == kWorldRangesColumn) {
+        writeWorldRanges(tbl, final_in_b ? site.keysB : site.keysA, n_out,
+                         S->numWorlds, tid, stride);
+        return;
+    }
+
     const void *src = tbl.columns[col];
     void *dst = tbl.columnsAlt[col];
 
@@ -471,9 +582,7 @@ sortGather(EcsState *S, const SortSite *sites, const GatherColumn *columns)
         // Entity column: 8-byte handles; update the entity store's row
         const Entity *esrc = (const Entity *)src;
         Entity *edst = (Entity *)dst;
-        const int32_t stride = (int32_t)(gridDim.x * kSortThreads);
-        for (int32_t i = (int32_t)(blockIdx.x * kSortThreads + threadIdx.x);
-             i < n_out; i += stride) {
+        for (int32_t i = tid; i < n_out; i += stride) {
             Entity e = esrc[perm[i]];
             edst[i] = e;
             if (e.id >= 0) {
@@ -484,25 +593,11 @@ sortGather(EcsState *S, const SortSite *sites, const GatherColumn *columns)
     }
 
     if (col == 1 && site.worldSort) {
-        // WorldID column doubles as the place where per-world ranges are
-        // detected from the sorted keys (contiguous, already in cache).
+        // the sorted keys ARE the new WorldID column: contiguous copy
         const uint32_t *sorted = final_in_b ? site.keysB : site.keysA;
         int32_t *wdst = (int32_t *)dst;
-        const int32_t stride = (int32_t)(gridDim.x * kSortThreads);
-        for (int32_t i = (int32_t)(blockIdx.x * kSortThreads + threadIdx.x);
-             i < n_out; i += stride) {
-            uint32_t k = sorted[i];
-            wdst[i] = (int32_t)k;
-            uint32_t kp = i > 0 ? sorted[i - 1] : 0xFFFFFFFFu;
-            if (i == 0 || k != kp) {
-                tbl.worldOffsets[k] = i;
-                if (i > 0) {
-                    tbl.worldCounts[kp] = i;        // end index for now
-                }
-            }
-            if (i == n_out - 1) {
-                tbl.worldCounts[k] = n_out;
-            }
+        for (int32_t i = tid; i < n_out; i += stride) {
+            wdst[i] = (int32_t)sorted[i];
         }
         return;
     }
@@ -510,19 +605,19 @@ sortGather(EcsState *S, const SortSite *sites, const GatherColumn *columns)
     switch (gc.wordBytes) {
     case 16:
         gatherWords<Word16>((const Word16 *)src, (Word16 *)dst, perm, n_out,
-                            gc.wordsPerRow, gc.invMagic);
+                            gc.wordsPerRow, gc.invMagic, tid, stride);
         break;
     case 8:
         gatherWords<Word8>((const Word8 *)src, (Word8 *)dst, perm, n_out,
-                           gc.wordsPerRow, gc.invMagic);
+                           gc.wordsPerRow, gc.invMagic, tid, stride);
         break;
     case 4:
         gatherWords<uint32_t>((const uint32_t *)src, (uint32_t *)dst, perm,
-                              n_out, gc.wordsPerRow, gc.invMagic);
+                              n_out, gc.wordsPerRow, gc.invMagic, tid, stride);
         break;
     default:
         gatherWords<uint8_t>((const uint8_t *)src, (uint8_t *)dst, perm,
-                             n_out, gc.wordsPerRow, gc.invMagic);
+                             n_out, gc.wordsPerRow, gc.invMagic, tid, stride);
         break;
     }
 }
@@ -545,18 +640,7 @@ sortFinalize(EcsState *S, const SortSite *sites)
     const int32_t n_out = site.worldSort ? (int32_t)state->numValid : n;
     const int32_t stride = (int32_t)(gridDim.x * kSortThreads);
     const int32_t tid = (int32_t)(blockIdx.x * kSortThreads + threadIdx.x);
-
-    if (site.worldSort) {
-        for (int32_t w = tid; w < S->numWorlds; w += stride) {
-            int32_t off = tbl.worldOffsets[w];
-            if (off == -1) {
-                tbl.worldOffsets[w] = n_out;
-                tbl.worldCounts[w] = 0;
-            } else {
-                tbl.worldCounts[w] = tbl.worldCounts[w] - off;
-            }
-        }
-    }
+    (void)state;
 
     // exported columns must keep their address: copy the gathered data back
     for (int32_t c = 0; c < tbl.numColumns; c++) {
@@ -580,38 +664,173 @@ sortFinalize(EcsState *S, const SortSite *sites)
     }
     __syncthreads();
 
-    if (!is_last) {
+    if (is_last) {
+        publishSite(S, site, tbl, n, n_out);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// small tables: the whole node in ONE launch
+// ---------------------------------------------------------------------------
+// A chain of histogram / passes / gather (/ finalize) costs its ~4 us launch
+// floor per kernel even when the table is empty or unchanged.  Tables that can
+// never hold more than kSmallSortRows rows (a physics joint table, ...) are
+// sorted by one 1024-thread workgroup per site instead: per pass an LDS
+// histogram, then 1024-key tiles ranked with the same wave-ballot matching as
+// the one-sweep kernel and scattered in tile order (stable); then the column
+// gather, the world ranges and the publication, separated by workgroup
+// barriers only.
+constexpr int kSmallThreads = 1024;
+constexpr int kSmallWaves = kSmallThreads / 64;
+
+struct SmallSortLDS {
+    uint32_t hist[kRadixDigits];
+    uint32_t binBase[kRadixDigits];
+    uint32_t waveBase[kSmallWaves][kRadixDigits];
+    uint32_t scan[4];
+    uint32_t valid;
+};
+
+__global__ void __launch_bounds__(kSmallThreads)
+sortSmall(EcsState *S, const SortSite *sites, const GatherColumn *columns,
+          uint32_t num_columns)
+{
+    const SortSite &site = sites[blockIdx.x];
+    TableHdr &tbl = S->tables[site.archetype];
+    if (site.worldSort && tbl.needsSort == 0u) {
         return;
     }
 
-    for (int32_t c = threadIdx.x; c < tbl.numColumns; c += kSortThreads) {
-        if ((tbl.columnFlags[c] & kColumnPinned) == 0u) {
-            void *tmp = tbl.columns[c];
-            void *cur = tbl.columnsAlt[c];
-            tbl.columns[c] = cur;
-            tbl.columnsAlt[c] = tmp;
-            S->colPtr[site.archetype * S->numComponentSlots +
-                      tbl.columnComponent[c]] = cur;
+    __shared__ SmallSortLDS lds;
+
+    const int32_t n = tbl.numRows;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = laneId();
+    const uint32_t wave = tid >> 6;
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+
+    if (tid == 0) lds.valid = 0;
+
+    for (int32_t pass = 0; pass < site.numPasses; pass++) {
+        const uint32_t *keys_in = pass == 0 ?
+            (const uint32_t *)tbl.columns[site.keyColumn] :
+            ((pass & 1) ? site.keysA : site.keysB);
+        const int32_t *idx_in = pass == 0 ? nullptr :
+            ((pass & 1) ? site.idxA : site.idxB);
+        uint32_t *keys_out = (pass & 1) ? site.keysB : site.keysA;
+        int32_t *idx_out = (pass & 1) ? site.idxB : site.idxA;
+        const uint32_t shift = (uint32_t)pass * kRadixBits;
+
+        if (tid < (uint32_t)kRadixDigits) lds.hist[tid] = 0;
+        __syncthreads();
+
+        uint32_t my_valid = 0;
+        for (int32_t i = (int32_t)tid; i < n; i += kSmallThreads) {
+            uint32_t key = keys_in[i];
+            my_valid += key != 0xFFFFFFFFu ? 1u : 0u;
+            atomicAdd(&lds.hist[(key >> shift) & 0xFFu], 1u);
+        }
+        if (pass == 0) {
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) {
+                my_valid += __shfl_down(my_valid, d, 64);
+            }
+            if (lane == 0 && my_valid != 0) atomicAdd(&lds.valid, my_valid);
+        }
+        __syncthreads();
+
+        // exclusive scan of the 256 bins by the first four waves
+        {
+            uint32_t v = tid < (uint32_t)kRadixDigits ? lds.hist[tid] : 0u;
+            uint32_t incl = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                uint32_t up = __shfl_up(incl, d, 64);
+                if ((int)lane >= d) incl += up;
+            }
+            if (wave < 4 && lane == 63) lds.scan[wave] = incl;
+            __syncthreads();
+            if (tid < (uint32_t)kRadixDigits) {
+                uint32_t base = 0;
+                for (uint32_t w = 0; w < wave; w++) base += lds.scan[w];
+                lds.binBase[tid] = base + incl - v;
+            }
+            __syncthreads();
+        }
+
+        for (int32_t tile = 0; tile < n; tile += kSmallThreads) {
+            for (uint32_t i = tid; i < (uint32_t)(kSmallWaves * kRadixDigits);
+                 i += kSmallThreads) {
+                (&lds.waveBase[0][0])[i] = 0;
+            }
+            __syncthreads();
+
+            const int32_t i = tile + (int32_t)tid;
+            const bool valid = i < n;
+            const uint32_t key = valid ? keys_in[i] : 0xFFFFFFFFu;
+            const int32_t src = valid ? (idx_in != nullptr ? idx_in[i] : i) : -1;
+            const uint32_t digit = (key >> shift) & 0xFFu;
+
+            unsigned long long match = ballot64(valid);
+#pragma unroll
+            for (int b = 0; b < kRadixBits; b++) {
+                bool bit = ((digit >> b) & 1u) != 0u;
+                unsigned long long vote = ballot64(bit && valid);
+                match &= bit ? vote : ~vote;
+            }
+            const uint32_t before = (uint32_t)__popcll(match & lane_lt);
+            if (valid && before == 0) {
+                lds.waveBase[wave][digit] = (uint32_t)__popcll(match);
+            }
+            __syncthreads();
+
+            // digit d: running base over the waves of this tile, then over tiles
+            if (tid < (uint32_t)kRadixDigits) {
+                uint32_t run = lds.binBase[tid];
+#pragma unroll
+                for (int w = 0; w < kSmallWaves; w++) {
+                    uint32_t c = lds.waveBase[w][tid];
+                    lds.waveBase[w][tid] = run;
+                    run += c;
+                }
+                lds.binBase[tid] = run;
+            }
+            __syncthreads();
+
+            if (valid) {
+                const uint32_t dst = lds.waveBase[wave][digit] + before;
+                keys_out[dst] = key;
+                idx_out[dst] = src;
+            }
+            __syncthreads();
         }
     }
-    for (int i = threadIdx.x; i < 4 * kRadixDigits; i += kSortThreads) {
-        state->bins[i] = 0;
-    }
-    if (threadIdx.x == 0) {
-        state->statRowsIn += (unsigned long long)n;
-        state->statRowsOut += (unsigned long long)n_out;
-        state->statRuns += 1ull;
+    __syncthreads();
 
-        tbl.numRows = n_out;
-        // A sort by any other key scrambles the rows across worlds: the next
-        // world sort / compaction must not early-out, worldOffsets / worldCounts
-        // are stale until then (reference sort_archetype.cpp:1001-1007).
-        tbl.needsSort = site.worldSort ? 0u : 1u;
-        state->numValid = 0;
-        state->finalizeArrivals = 0;
-        for (int p = 0; p < 4; p++) state->tileCounter[p] = 0;
-        state->epoch += 1u;
+    const int32_t n_out = site.worldSort ? (int32_t)lds.valid : n;
+
+    // gather: this site's columns one after the other (gridDim.x == 1 and
+    // blockDim.x == 1024 inside the helpers)
+    for (uint32_t c = 0; c < num_columns; c++) {
+        const GatherColumn gc = columns[c];
+        if (gc.site != blockIdx.x) continue;
+        gatherColumn(S, site, gc, tbl, n_out, (int32_t)tid, kSmallThreads);
     }
+    __syncthreads();
+
+    // pinned (exported) columns keep their address: copy the gathered rows back
+    for (int32_t c = 0; c < tbl.numColumns; c++) {
+        if ((tbl.columnFlags[c] & kColumnPinned) == 0u) continue;
+        const uint32_t *src = (const uint32_t *)tbl.columnsAlt[c];
+        uint32_t *dst = (uint32_t *)tbl.columns[c];
+        long long words = ((long long)n_out * tbl.columnBytes[c] + 3) / 4;
+        for (long long j = tid; j < words; j += kSmallThreads) {
+            dst[j] = src[j];
+        }
+    }
+    __syncthreads();
+
+    publishSite(S, site, tbl, n, n_out);
 }
 
 }
@@ -632,9 +851,27 @@ int sortNumPasses(bool world_sort, uint32_t num_worlds)
 
 uint32_t sortTileSize() { return (uint32_t)kSortTile; }
 
+uint32_t sortSmallRowLimit() { return kSmallSortRows; }
+
 void buildSortLaunches(const SortBatch &batch, std::vector<KernelLaunch> &out)
 {
     const uint32_t num_sites = (uint32_t)batch.sites.size();
+
+    // every table of the batch is small: the whole node in one launch
+    if (batch.maxCapacity <= kSmallSortRows) {
+        KernelLaunch k;
+        k.fn = (const void *)&sortSmall;
+        k.grid = dim3(num_sites, 1, 1);
+        k.block = dim3(kSmallThreads, 1, 1);
+        k.setArgs(batch.stateDev, batch.sitesDev, batch.gatherColumnsDev,
+                  batch.numGatherColumns);
+        k.role = "sort.small";
+        k.kind = MWHIP_NODE_SORT_ARCHETYPE;
+        k.sortBatch = &batch;
+        k.sortRole = SortRole::Small;
+        out.push_back(k);
+        return;
+    }
 
     uint32_t max_capacity = 0;
     int max_passes = 0;
@@ -687,7 +924,10 @@ void buildSortLaunches(const SortBatch &batch, std::vector<KernelLaunch> &out)
                 (max_capacity + kSortThreads * 8 - 1) / (kSortThreads * 8)));
         k.grid = dim3(gather_blocks, (uint32_t)batch.numGatherColumns, 1);
         k.block = dim3(kSortThreads, 1, 1);
-        k.setArgs(batch.stateDev, batch.sitesDev, batch.gatherColumnsDev);
+        // no exported column in the batch: the gather publishes the tables
+        // itself and the finalize launch is dropped
+        k.setArgs(batch.stateDev, batch.sitesDev, batch.gatherColumnsDev,
+                  batch.hasPinned ? 0u : 1u);
         k.role = "sort.gather";
         k.kind = MWHIP_NODE_SORT_ARCHETYPE;
         k.sortBatch = &batch;
@@ -695,7 +935,7 @@ void buildSortLaunches(const SortBatch &batch, std::vector<KernelLaunch> &out)
         out.push_back(k);
     }
 
-    {
+    if (batch.hasPinned) {
         KernelLaunch k;
         k.fn = (const void *)&sortFinalize;
         // W-sized fix-up + (rare) pinned-column copy-back: keep the grid small,

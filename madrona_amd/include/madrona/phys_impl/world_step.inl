@@ -997,7 +997,7 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
 
 #ifdef MADRONA_PHYS_PROFILE
     unsigned long long prof_t = __builtin_readcyclecounter();
-    unsigned long long prof_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    unsigned long long prof_acc[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 #endif
 
     for (int32_t world = (int32_t)blockIdx.x; world < num_worlds;
@@ -1075,6 +1075,7 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
             w->sys = ctx.singleton<PhysicsSystemState>();
         }
         wave::phaseFence();
+        PHYS_PROF(8);
 
         // primitives referenced by this world's bodies
         uint32_t prim_end = 0;
@@ -1085,6 +1086,7 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
         prim_end = wave::maxReduce(prim_end);
         const ObjectManager obj_mgr =
             stagePrimitives(lane, w, hbm_obj_mgr, prim_end);
+        PHYS_PROF(9);
 
         // ---- broadphase: candidate pairs in (body, traversal) order -----------
         // lane = body; one pass over the slot boxes in traversal order leaves a
@@ -1461,7 +1463,7 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
 #ifdef MADRONA_PHYS_PROFILE
     if (lane == 0 && S->moduleData[1] != nullptr) {
         unsigned long long *dst = (unsigned long long *)S->moduleData[1];
-        for (int i = 0; i < 8; i++) {
+        for (int i = 0; i < 12; i++) {
             atomicAdd(&dst[i], prof_acc[i]);
         }
     }

@@ -21,13 +21,13 @@ with Simulator(hip_lib_path('escape_room_phys'), W, seed=5, flags=200) as hip:
                   rng.integers(-2, 3, (W, 2)), rng.integers(0, 2, (W, 2))], -1).astype(np.int32)
     hip.write_tensor('action', a)
     hip.step(50)
-    buf = rt.mwhip_alloc_device(hip.hip_exec(), 64, 1)
+    buf = rt.mwhip_alloc_device(hip.hip_exec(), 96, 1)
     rt.mwhip_set_module_data(hip.hip_exec(), 1, buf)
     N = 50
     hip.step(N)
-    out = np.zeros(8, np.uint64)
-    rt.mwhip_memcpy_d2h(out.ctypes.data, buf, 64)
-    names = ['np.setup', 'load+cand', 'integrate', 'np.solo', 'solvePos+jnt+setVel', 'np.hull+compact', 'solveVel', 'store']
+    out = np.zeros(12, np.uint64)
+    rt.mwhip_memcpy_d2h(out.ctypes.data, buf, 96)
+    names = ['np.setup', 'candidates', 'integrate', 'np.solo', 'solvePos+jnt+setVel', 'np.hull+compact', 'solveVel', 'joints / store', 'load bodies', 'stage prims', '-', '-']
     tot = out.sum()
     for n, v in zip(names, out):
         print(f'{n:18s} {v / N / W:10.0f} ticks/world/step  {100 * v / tot:5.1f}%')
