@@ -364,6 +364,7 @@ struct ArchetypeRec {
     uint32_t flags = 0;
     uint32_t maxPerWorld = 0;
     bool singleton = false;
+    bool bigSort = false;           // outgrew the single-launch sort once
     int32_t singletonOrdinal = -1;
     uint32_t capacity = 0;              // rows backed by memory right now
     uint32_t reservedCapacity = 0;      // rows the address space allows
@@ -1112,6 +1113,17 @@ static int buildDeviceState(mwhip_exec *exec)
             hipMemcpyHostToDevice));
     }
 
+    // replay counter in signal memory (hipStreamWaitValue32 polls it; ParallelFor
+    // nodes derive their per-launch tag from it)
+    if (hipExtMallocWithFlags((void **)&exec->replaySignal, 256,
+                              hipMallocSignalMemory) != hipSuccess) {
+        (void)hipGetLastError();
+        HIPCHK(hipMalloc((void **)&exec->replaySignal, 256));
+    }
+    exec->allocations.push_back(exec->replaySignal);
+    HIPCHK(hipMemset(exec->replaySignal, 0, 256));
+    hs.replayCounter = exec->replaySignal;
+
     // device -> host message ring of mwGPU::HostPrint
     HIPCHK(hipHostMalloc((void **)&exec->printRing, sizeof(HostPrintRing),
                          hipHostMallocMapped));
@@ -1129,15 +1141,6 @@ static int buildDeviceState(mwhip_exec *exec)
     HIPCHK(hipHostMalloc((void **)&exec->statsHost,
         (3 + kMaxArchetypes) * sizeof(int32_t), hipHostMallocMapped));
     memset(exec->statsHost, 0, (3 + kMaxArchetypes) * sizeof(int32_t));
-
-    // replay counter in signal memory (hipStreamWaitValue32 polls it)
-    if (hipExtMallocWithFlags((void **)&exec->replaySignal, 256,
-                              hipMallocSignalMemory) != hipSuccess) {
-        (void)hipGetLastError();
-        HIPCHK(hipMalloc((void **)&exec->replaySignal, 256));
-    }
-    exec->allocations.push_back(exec->replaySignal);
-    HIPCHK(hipMemset(exec->replaySignal, 0, 256));
 
     exec->stateBuilt = true;
     return 0;
@@ -1323,6 +1326,7 @@ static int makeSortBatch(mwhip_exec *exec,
 
     std::vector<SortSite> sites;
     std::vector<GatherColumn> cols;
+    bool all_small = envU32("MADRONA_MWHIP_SORT_SMALL", 1) != 0;
 
     for (auto [archetype_id, component_id] : specs) {
         if (archetype_id >= exec->archetypes.size() ||
@@ -1370,6 +1374,16 @@ static int makeSortBatch(mwhip_exec *exec,
         sites.push_back(site);
 
         out->maxCapacity = std::max(out->maxCapacity, arch.capacity);
+        {
+            // small-table path while the table holds at most a quarter of the
+            // limit (checked again after every replay, sortsOutgrown())
+            uint64_t rows_now = archetype_id < exec->rowsAtGraphBuild.size() ?
+                exec->rowsAtGraphBuild[archetype_id] : arch.capacity;
+            if (arch.capacity <= sortSmallRowLimit()) rows_now = 0;
+            if (arch.bigSort || rows_now * 4 > sortSmallRowLimit()) {
+                all_small = false;
+            }
+        }
         uint32_t site_columns = 0;
         if (world_sort) {
             // first in the list: its two binary-search chains per world overlap
@@ -1399,6 +1413,7 @@ static int makeSortBatch(mwhip_exec *exec,
         }
         sites.back().numGatherColumns = site_columns;
     }
+    out->small = all_small;
 
     int rc = devAllocT(exec, &out->sitesDev, sites.size());
     if (rc != 0) return rc;
@@ -2283,12 +2298,51 @@ static int growTablesFromDevice(mwhip_exec *exec)
     });
 }
 
+// A table sorted by the single-launch path has grown past half of what that
+// path is meant for: its graphs are rebuilt with the chain (the single launch
+// stays correct at any size, it is just one workgroup).
+static int sortsOutgrown(mwhip_exec *exec)
+{
+    bool rebuild = false;
+    for (auto &kv : exec->launchGraphs) {
+        for (const auto &batch : kv.second->sortBatches) {
+            if (!batch->small) continue;
+            for (const SortSiteHost &site : batch->sites) {
+                int64_t rows = site.archetype < kMaxArchetypes ?
+                    exec->statsHost[2 + site.archetype] : 0;
+                if (rows * 2 > (int64_t)sortSmallRowLimit() &&
+                        !exec->archetypes[site.archetype].bigSort) {
+                    exec->archetypes[site.archetype].bigSort = true;
+                    rebuild = true;
+                }
+            }
+        }
+    }
+    if (!rebuild) {
+        return 0;
+    }
+    HIPCHK(hipStreamSynchronize(exec->stream));
+    for (auto &kv : exec->launchGraphs) {
+        std::unique_ptr<LaunchGraph> fresh;
+        int rc = instantiateLaunchGraph(exec, kv.second->taskGraphIds,
+                                        kv.second->statName, fresh,
+                                        kv.second.get());
+        if (rc != 0) return rc;
+        if (kv.second->graphExec) (void)hipGraphExecDestroy(kv.second->graphExec);
+        if (kv.second->graph) (void)hipGraphDestroy(kv.second->graph);
+        kv.second = std::move(fresh);
+    }
+    return 0;
+}
+
 // row counts the last completed replay reported (statsKernel)
 static int growTablesAfterReplay(mwhip_exec *exec)
 {
-    return growTables(exec, [exec](uint32_t a) -> int64_t {
+    int rc = growTables(exec, [exec](uint32_t a) -> int64_t {
         return a < kMaxArchetypes ? exec->statsHost[2 + a] : -1;
     });
+    if (rc != 0) return rc;
+    return sortsOutgrown(exec);
 }
 
 extern "C" int mwhip_build_launch_graph(mwhip_exec *exec,

@@ -19,13 +19,25 @@ namespace mwhip {
 // ---- sort ----------------------------------------------------------------------
 
 // Device-resident, per sort site (one per sorted archetype+key).
+// Life cycle of one run of the chain (no kernel needs to know when another
+// kernel's LAST workgroup is done -- one atomic per workgroup on one address
+// serialises at 11 ns unloaded, ~70 ns under memory load on MI355X,
+// profiles/tools/atomic_microbench.hip):
+//   histogram   workgroup 0 of a site records active / rowsIn / keyColumn
+//   last pass   workgroup 0 PUBLISHES the table (pointer swap, new row count):
+//               nothing reads the table until the chain ends, and the pass
+//               itself works from the key / index buffers
+//   gather      old buffers (now columnsAlt) -> current buffers; one workgroup
+//               cleans the state the passes have finished with
 struct SortState {
     uint32_t bins[4 * 256];         // digit histograms of up to 4 passes
-    uint32_t tileCounter[4];        // onesweep tile tickets per pass
     uint32_t numValid;              // rows whose key != 0xFFFFFFFF
     uint32_t epoch;                 // tags look-back granules; never reset
-    uint32_t finalizeArrivals;
-    uint32_t gatherArrivals;        // gather workgroups done (last one publishes)
+    uint32_t active;                // this run sorts (world sort: table was dirty)
+    int32_t rowsIn;                 // rows when the chain started
+    int32_t rowsOut;                // rows the sorted table has
+    uint32_t pad_;
+    const uint32_t *keyColumn;      // the key column when the chain started
     unsigned long long statRowsIn;  // cumulative, for measurement
     unsigned long long statRowsOut;
     unsigned long long statRuns;
@@ -77,6 +89,10 @@ struct SortBatch {
     uint32_t numGatherColumns = 0;
     bool hasPinned = false;         // a sorted table has exported columns
     uint32_t maxCapacity = 0;
+    // every table of the batch holds few rows: one launch (sortSmall) instead
+    // of the chain.  Decided from the rows the tables hold when the graph is
+    // built; the executor rebuilds its graphs when one outgrows it.
+    bool small = false;
 };
 
 // ---- launches ------------------------------------------------------------------

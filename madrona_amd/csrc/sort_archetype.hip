@@ -118,14 +118,23 @@ sortHistogram(EcsState *S, const SortSite *sites)
     const SortSite &site = sites[blockIdx.y];
     TableHdr &tbl = S->tables[site.archetype];
 
-    if (site.worldSort && tbl.needsSort == 0u) {
+    SortState *state = site.state;
+    const int32_t n = tbl.numRows;
+    const uint32_t *keys = (const uint32_t *)tbl.columns[site.keyColumn];
+
+    // nothing below this kernel looks at the table header again to decide
+    // whether (or what) to sort
+    const bool active = site.worldSort == 0u || tbl.needsSort != 0u;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        state->active = active ? 1u : 0u;
+        state->rowsIn = n;
+        state->keyColumn = keys;
+    }
+    if (!active) {
         return;
     }
 
-    const int32_t n = tbl.numRows;
     const int32_t num_passes = site.numPasses;
-    const uint32_t *keys = (const uint32_t *)tbl.columns[site.keyColumn];
-    SortState *state = site.state;
 
     __shared__ uint32_t lds_hist[4][kRadixDigits];
     __shared__ uint32_t lds_valid;
@@ -172,6 +181,54 @@ sortHistogram(EcsState *S, const SortSite *sites)
 
 }
 
+// Makes the sorted table current: ping-pong swap of every column that is not
+// pinned, new row count.  Executed by ONE workgroup, BEFORE the gather: between
+// the last key pass and the end of the chain nothing reads the table, and the
+// gather moves the rows from the old buffers (now columnsAlt) into the current
+// ones.  Pinned (exported) columns keep their address: they are gathered into
+// their twin and copied back by sortFinalize.
+__device__ inline void publishSite(EcsState *S, const SortSite &site,
+                                   TableHdr &tbl, int32_t n)
+{
+    SortState *state = site.state;
+    const int32_t n_out = site.worldSort ? (int32_t)state->numValid : n;
+    for (int32_t c = threadIdx.x; c < tbl.numColumns; c += blockDim.x) {
+        if ((tbl.columnFlags[c] & kColumnPinned) == 0u) {
+            void *old_buf = tbl.columns[c];
+            void *new_buf = tbl.columnsAlt[c];
+            tbl.columns[c] = new_buf;
+            tbl.columnsAlt[c] = old_buf;
+            S->colPtr[site.archetype * S->numComponentSlots +
+                      tbl.columnComponent[c]] = new_buf;
+        }
+    }
+    if (threadIdx.x == 0) {
+        state->rowsOut = n_out;
+        state->statRowsIn += (unsigned long long)n;
+        state->statRowsOut += (unsigned long long)n_out;
+        state->statRuns += 1ull;
+
+        tbl.numRows = n_out;
+        // A sort by any other key scrambles the rows across worlds: the next
+        // world sort / compaction must not early-out, worldOffsets / worldCounts
+        // are stale until then (reference sort_archetype.cpp:1001-1007).
+        tbl.needsSort = site.worldSort ? 0u : 1u;
+    }
+}
+
+// State the key passes are done with, cleaned for the next run (by one
+// workgroup of the gather, or at the end of sortSmall).
+__device__ inline void cleanSortState(SortState *state)
+{
+    for (int i = threadIdx.x; i < 4 * kRadixDigits; i += blockDim.x) {
+        state->bins[i] = 0;
+    }
+    if (threadIdx.x == 0) {
+        state->numValid = 0;
+        state->epoch += 1u;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // kernel 2: one LSD radix pass (one-sweep, decoupled look-back)
 // ---------------------------------------------------------------------------
@@ -182,7 +239,6 @@ struct alignas(16) OnesweepLDS {
     uint32_t stageKeys[kSortTile];
     int32_t stageIdx[kSortTile];
     uint32_t scanScratch[kSortWaves];
-    uint32_t tile;
 };
 
 __global__ void __launch_bounds__(kSortThreads)
@@ -194,35 +250,42 @@ sortOnesweep(EcsState *S, const SortSite *sites, uint32_t pass)
     if ((int32_t)pass >= site.numPasses) {
         return;
     }
-    if (site.worldSort && tbl.needsSort == 0u) {
+    SortState *state = site.state;
+    if (state->active == 0u) {
         return;
     }
 
-    const int32_t n = tbl.numRows;
-    SortState *state = site.state;
+    const int32_t n = state->rowsIn;
+
+    // The last pass no longer touches the table (it reads the key / index
+    // buffers of the pass before it, or the key column through the pointer the
+    // histogram kernel saved): its first workgroup publishes the sorted table
+    // -- ping-pong swap, new row count -- while the others still scatter.
+    if ((int32_t)pass == site.numPasses - 1 && blockIdx.x == 0) {
+        publishSite(S, site, tbl, n);
+    }
 
     __shared__ OnesweepLDS lds;
 
-    // ticket: tile order == start order, so predecessors are always resident
-    if (threadIdx.x == 0) {
-        lds.tile = atomicAdd(&state->tileCounter[pass], 1u);
+    // Tile = workgroup index: workgroups are dispatched in index order, so the
+    // predecessors a tile waits for in the look-back below are already running
+    // (or done).  No ticket counter: one atomic per tile on one address costs
+    // more than the rest of a small pass.
+    const uint32_t tile = blockIdx.x;
+    const int32_t tile_base = (int32_t)(tile * (uint32_t)kSortTile);
+    if (tile_base >= n) {
+        return;
     }
     for (int i = threadIdx.x; i < kSortWaves * kRadixDigits; i += kSortThreads) {
         (&lds.waveHist[0][0])[i] = 0;
     }
     __syncthreads();
-
-    const uint32_t tile = lds.tile;
-    const int32_t tile_base = (int32_t)(tile * (uint32_t)kSortTile);
-    if (tile_base >= n) {
-        return;
-    }
     const int32_t tile_count = min(kSortTile, n - tile_base);
 
     const uint32_t *keys_in;
     const int32_t *idx_in;
     if (pass == 0) {
-        keys_in = (const uint32_t *)tbl.columns[site.keyColumn];
+        keys_in = state->keyColumn;
         idx_in = nullptr;
     } else {
         keys_in = (pass & 1u) ? site.keysA : site.keysB;
@@ -473,89 +536,32 @@ __device__ inline void writeWorldRanges(TableHdr &tbl,
     }
 }
 
-// Makes the sorted table current: ping-pong swap of every column that is not
-// pinned, new row count, sort state cleaned for the next run.  Executed by ONE
-// workgroup once every gather workgroup of the site is done.
-__device__ inline void publishSite(EcsState *S, const SortSite &site,
-                                   TableHdr &tbl, int32_t n, int32_t n_out)
-{
-    SortState *state = site.state;
-    for (int32_t c = threadIdx.x; c < tbl.numColumns; c += blockDim.x) {
-        if ((tbl.columnFlags[c] & kColumnPinned) == 0u) {
-            void *tmp = tbl.columns[c];
-            void *cur = tbl.columnsAlt[c];
-            tbl.columns[c] = cur;
-            tbl.columnsAlt[c] = tmp;
-            S->colPtr[site.archetype * S->numComponentSlots +
-                      tbl.columnComponent[c]] = cur;
-        }
-    }
-    for (int i = threadIdx.x; i < 4 * kRadixDigits; i += blockDim.x) {
-        state->bins[i] = 0;
-    }
-    if (threadIdx.x == 0) {
-        state->statRowsIn += (unsigned long long)n;
-        state->statRowsOut += (unsigned long long)n_out;
-        state->statRuns += 1ull;
-
-        tbl.numRows = n_out;
-        // A sort by any other key scrambles the rows across worlds: the next
-        // world sort / compaction must not early-out, worldOffsets / worldCounts
-        // are stale until then (reference sort_archetype.cpp:1001-1007).
-        tbl.needsSort = site.worldSort ? 0u : 1u;
-        state->numValid = 0;
-        state->finalizeArrivals = 0;
-        state->gatherArrivals = 0;
-        for (int p = 0; p < 4; p++) state->tileCounter[p] = 0;
-        state->epoch += 1u;
-    }
-}
-
-// One column (blockIdx.y) of one site.  publish != 0: the batch has no pinned
-// column, so there is no copy-back to wait for and the last workgroup of a site
-// to finish publishes the table itself (no finalize launch).
+// One column (blockIdx.y) of one site: rows move from the buffers the table
+// had when the chain started into its current ones.
 __device__ inline void gatherColumn(EcsState *S, const SortSite &site,
                                     const GatherColumn &gc, TableHdr &tbl,
                                     int32_t n_out, int32_t tid, int32_t stride);
 
 __global__ void __launch_bounds__(kSortThreads)
-sortGather(EcsState *S, const SortSite *sites, const GatherColumn *columns,
-           uint32_t publish)
+sortGather(EcsState *S, const SortSite *sites, const GatherColumn *columns)
 {
     const GatherColumn gc = columns[blockIdx.y];
     const SortSite &site = sites[gc.site];
     TableHdr &tbl = S->tables[site.archetype];
 
-    if (site.worldSort && tbl.needsSort == 0u) {
+    SortState *state = site.state;
+    if (state->active == 0u) {
         return;
     }
-
-    SortState *state = site.state;
-    const int32_t n = tbl.numRows;
-    const int32_t n_out = site.worldSort ? (int32_t)state->numValid : n;
+    const int32_t n_out = state->rowsOut;
 
     gatherColumn(S, site, gc, tbl, n_out,
                  (int32_t)(blockIdx.x * kSortThreads + threadIdx.x),
                  (int32_t)(gridDim.x * kSortThreads));
 
-    if (publish == 0u) {
-        return;
-    }
-
-    // last workgroup of this site (all of its columns + the world ranges)
-    __shared__ bool is_last;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        // (relaxed: the publisher swaps pointers and counters, it does not
-        // read what the other workgroups gathered; an agent-scope release per
-        // workgroup would write back its XCD's L2 every time)
-        uint32_t done = __hip_atomic_fetch_add(&state->gatherArrivals, 1u,
-            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        is_last = (done == gridDim.x * site.numGatherColumns - 1u);
-    }
-    __syncthreads();
-    if (is_last) {
-        publishSite(S, site, tbl, n, n_out);
+    // (the passes are over: their histograms and counters are dead)
+    if (gc.column == 0u && blockIdx.x == 0) {
+        cleanSortState(state);
     }
 }
 
@@ -575,8 +581,11 @@ __device__ inline void gatherColumn(EcsState *S, const SortSite &site,
         return;
     }
 
-    const void *src = tbl.columns[col];
-    void *dst = tbl.columnsAlt[col];
+    // swapped already (publishSite): the rows still sit in what is now the
+    // twin; pinned columns were not swapped and go the other way
+    const bool pinned = (tbl.columnFlags[col] & kColumnPinned) != 0u;
+    const void *src = pinned ? tbl.columns[col] : tbl.columnsAlt[col];
+    void *dst = pinned ? tbl.columnsAlt[col] : tbl.columns[col];
 
     if (col == 0) {
         // Entity column: 8-byte handles; update the entity store's row
@@ -623,26 +632,24 @@ __device__ inline void gatherColumn(EcsState *S, const SortSite &site,
 }
 
 // ---------------------------------------------------------------------------
-// kernel 4: finalize
+// kernel 4 (only for batches with exported columns): copy-back
 // ---------------------------------------------------------------------------
+// An exported column must keep its address (PyTorch holds it): it was gathered
+// into its twin; the rows come back here.
 __global__ void __launch_bounds__(kSortThreads)
 sortFinalize(EcsState *S, const SortSite *sites)
 {
     const SortSite &site = sites[blockIdx.y];
     TableHdr &tbl = S->tables[site.archetype];
-
-    if (site.worldSort && tbl.needsSort == 0u) {
+    SortState *state = site.state;
+    if (state->active == 0u) {
         return;
     }
 
-    SortState *state = site.state;
-    const int32_t n = tbl.numRows;
-    const int32_t n_out = site.worldSort ? (int32_t)state->numValid : n;
+    const int32_t n_out = state->rowsOut;
     const int32_t stride = (int32_t)(gridDim.x * kSortThreads);
     const int32_t tid = (int32_t)(blockIdx.x * kSortThreads + threadIdx.x);
-    (void)state;
 
-    // exported columns must keep their address: copy the gathered data back
     for (int32_t c = 0; c < tbl.numColumns; c++) {
         if ((tbl.columnFlags[c] & kColumnPinned) == 0u) continue;
         const uint32_t *src = (const uint32_t *)tbl.columnsAlt[c];
@@ -652,20 +659,6 @@ sortFinalize(EcsState *S, const SortSite *sites)
         for (long long j = tid; j < words; j += stride) {
             dst[j] = src[j];
         }
-    }
-
-    // last block to arrive publishes the new table and resets the sort state
-    __shared__ bool is_last;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        uint32_t done = atomicAdd(&state->finalizeArrivals, 1u);
-        is_last = (done == gridDim.x - 1);
-    }
-    __syncthreads();
-
-    if (is_last) {
-        publishSite(S, site, tbl, n, n_out);
     }
 }
 
@@ -807,10 +800,17 @@ sortSmall(EcsState *S, const SortSite *sites, const GatherColumn *columns,
     }
     __syncthreads();
 
+    // same order as the chain: publish (swap), then gather old -> current
+    SortState *state = site.state;
+    if (tid == 0) {
+        state->numValid = lds.valid;
+    }
+    __syncthreads();
+    publishSite(S, site, tbl, n);
+    __syncthreads();
     const int32_t n_out = site.worldSort ? (int32_t)lds.valid : n;
 
-    // gather: this site's columns one after the other (gridDim.x == 1 and
-    // blockDim.x == 1024 inside the helpers)
+    // gather: this site's columns one after the other
     for (uint32_t c = 0; c < num_columns; c++) {
         const GatherColumn gc = columns[c];
         if (gc.site != blockIdx.x) continue;
@@ -828,9 +828,7 @@ sortSmall(EcsState *S, const SortSite *sites, const GatherColumn *columns,
             dst[j] = src[j];
         }
     }
-    __syncthreads();
-
-    publishSite(S, site, tbl, n, n_out);
+    cleanSortState(state);
 }
 
 }
@@ -858,7 +856,7 @@ void buildSortLaunches(const SortBatch &batch, std::vector<KernelLaunch> &out)
     const uint32_t num_sites = (uint32_t)batch.sites.size();
 
     // every table of the batch is small: the whole node in one launch
-    if (batch.maxCapacity <= kSmallSortRows) {
+    if (batch.small) {
         KernelLaunch k;
         k.fn = (const void *)&sortSmall;
         k.grid = dim3(num_sites, 1, 1);
@@ -888,7 +886,10 @@ void buildSortLaunches(const SortBatch &batch, std::vector<KernelLaunch> &out)
     {
         KernelLaunch k;
         k.fn = (const void *)&sortHistogram;
-        k.grid = dim3(stream_blocks, num_sites, 1);
+        // few, fat workgroups: every workgroup ends with one atomic per
+        // non-empty bin on the site's global histogram, and atomics on one
+        // address serialise (profiles/tools/atomic_microbench.hip)
+        k.grid = dim3(std::min<uint32_t>(stream_blocks, 64u), num_sites, 1);
         k.block = dim3(kSortThreads, 1, 1);
         k.setArgs(batch.stateDev, batch.sitesDev);
         k.role = "sort.histogram";
@@ -924,10 +925,7 @@ void buildSortLaunches(const SortBatch &batch, std::vector<KernelLaunch> &out)
                 (max_capacity + kSortThreads * 8 - 1) / (kSortThreads * 8)));
         k.grid = dim3(gather_blocks, (uint32_t)batch.numGatherColumns, 1);
         k.block = dim3(kSortThreads, 1, 1);
-        // no exported column in the batch: the gather publishes the tables
-        // itself and the finalize launch is dropped
-        k.setArgs(batch.stateDev, batch.sitesDev, batch.gatherColumnsDev,
-                  batch.hasPinned ? 0u : 1u);
+        k.setArgs(batch.stateDev, batch.sitesDev, batch.gatherColumnsDev);
         k.role = "sort.gather";
         k.kind = MWHIP_NODE_SORT_ARCHETYPE;
         k.sortBatch = &batch;

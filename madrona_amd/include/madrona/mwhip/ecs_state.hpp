@@ -161,6 +161,9 @@ struct EcsState {
     int32_t pad_;
     void *moduleData[4];            // module-private device pointers (physics scratch, ...)
     HostPrintRing *hostPrintRing;   // pinned host memory, or nullptr
+    // replays completed so far (bumped by the last kernel of every replay):
+    // with a node's position in the graph, a unique tag per launch
+    const uint32_t *replayCounter;
 };
 
 // Load through the constant address space: for data no kernel of the *user*
@@ -211,11 +214,11 @@ MWHIP_HD inline void *columnOf(const TableHdr &tbl, int32_t column_idx)
     return loadInvariant(&tbl.columns[column_idx]);
 }
 
-// Per-node state of the row-count snapshot (mwhip_pfor_args::row_sync):
-// a ticket counter that never resets (ticket / workgroups-per-launch = launch
-// epoch) and one {epoch : 32 | rows : 32} granule per matched table.
+// Per-node state of the row-count snapshot (mwhip_pfor_args::row_sync): one
+// {launch tag : 32 | rows : 32} granule per matched table, written by
+// workgroup 0 of the launch and polled by the others.
 struct PforRowSync {
-    unsigned long long ticket;
+    unsigned long long reserved;
     unsigned long long rows[1];     // [num_matching]
 };
 

@@ -759,27 +759,29 @@ struct WorldBlock {
     static constexpr int maxContacts =
         MAXB + MAXB / 4 > 64 ? MAXB + MAXB / 4 : 64;
     static constexpr int maxJoints = 6;         // more: read from HBM
-    static constexpr int maxPrims = 8;          // more: hull data stays in HBM
-    static constexpr int arenaDwords = 192;     // object-space hull meshes
+    static constexpr int maxPrims = (int)PrimImage::maxPrims;   // more: hull data stays in HBM
+    static constexpr int arenaDwords = (int)PrimImage::arenaDwords;   // object-space hull meshes
 
+    // ---- the world image: what a step reads from the ECS tables -----------
+    // The first imageBytes of this struct are exactly what physicsPackKernel
+    // leaves per world in HBM (same layout), so that the step kernel starts
+    // with ONE coalesced copy instead of a dozen dependent round trips
+    // (row ranges -> column pointers -> body columns -> object metadata ->
+    // leaf -> parent node slot), exposed at two waves per SIMD.
     math::Vector3 pos[MAXB];
     math::Quat rot[MAXB];
     math::Diag3x3 scale[MAXB];
     Velocity vel[MAXB];
     math::Vector3 extForce[MAXB];
     math::Vector3 extTorque[MAXB];
-    xpbd::SubstepPrevState prev[MAXB];
-    xpbd::PreSolvePositional prePos[MAXB];
-    xpbd::PreSolveVelocity preVel[MAXB];
     xpbd::BodyConstants constants[MAXB];    // zeroed for static bodies
     uint32_t resp[MAXB];
     Loc bodyLoc[MAXB];                      // where the body's row is (store phase)
     int32_t entityID[MAXB];
     uint16_t primOffset[MAXB];
     uint16_t primCount[MAXB];
-    uint16_t leafRank[MAXB];                // leaf id -> traversal rank
     uint16_t orderBody[MAXB];               // traversal rank -> body index
-    WaveCandidate candidates[maxCandidates];
+    uint16_t imagePad_[MAXB];               // (keeps `shared` 16-byte aligned)
 
     // broadphase boxes are dead once the candidates exist: the contacts of the
     // substeps reuse their storage
@@ -788,6 +790,13 @@ struct WorldBlock {
     static constexpr size_t contactBytes =
         maxContacts * sizeof(ContactConstraint);
     alignas(16) char shared[boxBytes > contactBytes ? boxBytes : contactBytes];
+    // ---- end of the image (imageBytes below) ------------------------------
+
+    xpbd::SubstepPrevState prev[MAXB];
+    xpbd::PreSolvePositional prePos[MAXB];
+    xpbd::PreSolveVelocity preVel[MAXB];
+    uint16_t leafRank[MAXB];                // leaf id -> traversal rank
+    WaveCandidate candidates[maxCandidates];
     float lambdas[maxContacts];
 
     JointConstraint joints[maxJoints];
@@ -816,6 +825,13 @@ struct WorldBlock {
     {
         return (ContactConstraint *)shared;
     }
+
+    // bytes of the world image (a multiple of 16)
+    __host__ __device__ static constexpr size_t imageBytes()
+    {
+        return (__builtin_offsetof(WorldBlock, shared) + boxBytes + 15) &
+            ~(size_t)15;
+    }
 };
 
 // Copies `count` dwords with all lanes.
@@ -839,6 +855,43 @@ __device__ inline ObjectManager stagePrimitives(uint32_t lane,
     using Block = WorldBlock<MAXB>;
     if (num_prims > (uint32_t)Block::maxPrims) {
         return obj_mgr;
+    }
+
+    // the loader's ready-made image covers these primitives: three coalesced
+    // copies and a pointer fix-up instead of the walk below
+    const PrimImage *image = obj_mgr.primImage;
+    if (image != nullptr) {
+        const uint32_t image_prims = image->numPrims;
+        if (image_prims >= num_prims && image_prims != 0) {
+            waveCopyDwords(lane, (uint32_t *)w->prims,
+                (const uint32_t *)image->prims,
+                image_prims * (uint32_t)(sizeof(CollisionPrimitive) / 4));
+            waveCopyDwords(lane, (uint32_t *)w->primAABBs,
+                (const uint32_t *)image->primAABBs,
+                image_prims * (uint32_t)(sizeof(math::AABB) / 4));
+            waveCopyDwords(lane, w->arena, image->arena, image->arenaUsed);
+            int32_t offsets[4] = { -1, -1, -1, -1 };
+            if (lane < image_prims) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    offsets[i] = image->meshOffset[lane][i];
+                }
+            }
+            wave::phaseFence();
+            if (lane < image_prims && offsets[0] >= 0) {
+                geo::HalfEdgeMesh &staged = w->prims[lane].hull.halfEdgeMesh;
+                staged.facePlanes = (geo::Plane *)(w->arena + offsets[0]);
+                staged.halfEdges = (geo::HalfEdge *)(w->arena + offsets[1]);
+                staged.vertices = (math::Vector3 *)(w->arena + offsets[2]);
+                staged.faceBaseHalfEdges = w->arena + offsets[3];
+            }
+            wave::phaseFence();
+
+            ObjectManager staged = obj_mgr;
+            staged.collisionPrimitives = w->prims;
+            staged.primitiveAABBs = w->primAABBs;
+            return staged;
+        }
     }
 
     waveCopyDwords(lane, (uint32_t *)w->prims,
@@ -965,6 +1018,114 @@ __device__ inline PairSetup ldsSetupPair(const WorldBlock<MAXB> *w,
         PrimitiveTransform { w->pos[kb], w->rot[kb], w->scale[kb] });
 }
 
+// The part of a step that reads the ECS tables: body k of the world -> slot k of
+// the block `dst` (in LDS when the step kernel loads for itself, in HBM when
+// physicsPackKernel prepares the world image).  leaf_rank: leaf id -> position
+// in the BVH's traversal order (LDS).
+template <int MAXB>
+__device__ inline void loadWorldBodies(uint32_t lane, WorldBlock<MAXB> *dst,
+                                       const uint16_t *leaf_rank, Context &ctx,
+                                       const WorldBodies &bodies,
+                                       const broadphase::BVH &bvh,
+                                       const ObjectManager &hbm_obj_mgr,
+                                       int32_t num_bodies)
+{
+    for (int32_t k = (int32_t)lane; k < num_bodies; k += 64) {
+        Loc loc = bodies.loc(k);
+        dst->bodyLoc[k] = loc;
+        dst->pos[k] = ctx.getDirect<base::Position>(RGDCols::Position, loc);
+        dst->rot[k] = ctx.getDirect<base::Rotation>(RGDCols::Rotation, loc);
+        dst->scale[k] = ctx.getDirect<base::Scale>(RGDCols::Scale, loc);
+        dst->vel[k] = ctx.getDirect<Velocity>(RGDCols::Velocity, loc);
+        dst->extForce[k] =
+            ctx.getDirect<ExternalForce>(RGDCols::ExternalForce, loc);
+        dst->extTorque[k] =
+            ctx.getDirect<ExternalTorque>(RGDCols::ExternalTorque, loc);
+
+        ResponseType resp =
+            ctx.getDirect<ResponseType>(RGDCols::ResponseType, loc);
+        dst->resp[k] = (uint32_t)resp;
+        const int32_t entity_id = ctx.getDirect<Entity>(0, loc).id;
+        dst->entityID[k] = entity_id;
+
+        base::ObjectID obj_id =
+            ctx.getDirect<base::ObjectID>(RGDCols::ObjectID, loc);
+        const RigidBodyMetadata metadata = hbm_obj_mgr.metadata[obj_id.idx];
+        dst->constants[k] = xpbd::bodyConstants(metadata, resp);
+        dst->primOffset[k] = (uint16_t)
+            hbm_obj_mgr.rigidBodyPrimitiveOffsets[obj_id.idx];
+        dst->primCount[k] = (uint16_t)
+            hbm_obj_mgr.rigidBodyPrimitiveCounts[obj_id.idx];
+
+        int32_t leaf = ctx.getDirect<broadphase::LeafID>(
+            RGDCols::LeafID, loc).id;
+        const uint32_t rank = leaf_rank[leaf];
+        dst->queryBox()[k] = bvh.getLeafAABB(broadphase::LeafID { leaf });
+        dst->rankSlotBox()[rank] = bvh.leafSlotBounds(leaf);
+        dst->rankEntity()[rank] = entity_id;
+        dst->orderBody[rank] = (uint16_t)k;
+    }
+}
+
+// World images for physicsStepLdsKernel<MAXB>: one wavefront per world runs the
+// table-reading part of the step and leaves the result in HBM in the layout of
+// the step's LDS block.  The chain of dependent loads is the same, but this
+// kernel needs a handful of registers and 64 B of LDS per wave: eight waves per
+// SIMD (the step kernel: two) and every world of an 8192-world launch resident
+// at once, so the chains of different worlds overlap instead of queueing.
+template <int MAXB>
+__global__ void __launch_bounds__(64)
+physicsPackKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
+{
+    using Block = WorldBlock<MAXB>;
+
+    StateManager *state_mgr = static_cast<StateManager *>(S);
+    PhysicsScratch *ps = detail::scratch(S);
+    const PhysicsStepParams params = *(const PhysicsStepParams *)node_data;
+
+    const uint32_t lane = wave::laneID();
+    const int32_t num_worlds = S->numWorlds;
+
+    __shared__ uint16_t leaf_rank[MAXB];
+
+    for (int32_t world = (int32_t)blockIdx.x; world < num_worlds;
+         world += (int32_t)gridDim.x) {
+        Context ctx = TaskGraph::makeContext<Context>(
+            state_mgr, WorldID { world }, true);
+        const ObjectManager &hbm_obj_mgr = *ctx.singleton<ObjectData>().mgr;
+        const broadphase::BVH &bvh = ctx.singleton<broadphase::BVH>();
+
+        WorldBodies bodies;
+        bodies.numArchetypes = ps->numBodyArchetypes;
+        bodies.bodyBase[0] = 0;
+        bool unsorted = false;
+        for (uint32_t a = 0; a < bodies.numArchetypes; a++) {
+            const TableHdr &tbl = S->tables[ps->bodyArchetypes[a]];
+            bodies.archetype[a] = ps->bodyArchetypes[a];
+            bodies.rowBase[a] = tbl.worldOffsets[world];
+            bodies.bodyBase[a + 1] =
+                bodies.bodyBase[a] + tbl.worldCounts[world];
+            unsorted = unsorted || tbl.needsSort != 0;
+        }
+        const int32_t num_bodies = bodies.count();
+        if (unsorted || num_bodies > MAXB || bvh.numLeaves() != num_bodies) {
+            continue;       // the step kernel raises the error
+        }
+
+        const int32_t *order = bvh.traversalOrder();
+        for (int32_t r = (int32_t)lane; r < num_bodies; r += 64) {
+            leaf_rank[order[r]] = (uint16_t)r;
+        }
+        wave::phaseFence();
+
+        Block *image = (Block *)((char *)params.worldImages +
+                                 (size_t)world * Block::imageBytes());
+        loadWorldBodies<MAXB>(lane, image, leaf_rank, ctx, bodies, bvh,
+                              hbm_obj_mgr, num_bodies);
+        wave::phaseFence();
+    }
+}
+
 // Two waves per SIMD: PMC shows the step parked on s_waitcnt 45 % of its wave
 // cycles at one wave per SIMD (SQ_WAIT_ANY / SQ_WAVE_CYCLES); capping the
 // kernel at 256 registers costs spills but lets a second world fill those
@@ -1027,49 +1188,26 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
         }
 
         // ---- load: HBM -> LDS ---------------------------------------------------
-        {
-            const int32_t *order = bvh.traversalOrder();
-            for (int32_t r = (int32_t)lane; r < num_bodies; r += 64) {
-                w->leafRank[order[r]] = (uint16_t)r;
+        const char *world_images = (const char *)params.worldImages;
+        if (world_images != nullptr) {
+            // packed by physicsPackKernel just before this launch
+            const uint4 *src = (const uint4 *)(
+                world_images + (size_t)world * Block::imageBytes());
+            uint4 *dst = (uint4 *)w;
+            constexpr uint32_t num_vec = (uint32_t)(Block::imageBytes() / 16);
+            for (uint32_t i = lane; i < num_vec; i += 64) {
+                dst[i] = src[i];
             }
-        }
-        wave::phaseFence();
-
-        for (int32_t k = (int32_t)lane; k < num_bodies; k += 64) {
-            Loc loc = bodies.loc(k);
-            w->bodyLoc[k] = loc;
-            w->pos[k] = ctx.getDirect<base::Position>(RGDCols::Position, loc);
-            w->rot[k] = ctx.getDirect<base::Rotation>(RGDCols::Rotation, loc);
-            w->scale[k] = ctx.getDirect<base::Scale>(RGDCols::Scale, loc);
-            w->vel[k] = ctx.getDirect<Velocity>(RGDCols::Velocity, loc);
-            w->extForce[k] =
-                ctx.getDirect<ExternalForce>(RGDCols::ExternalForce, loc);
-            w->extTorque[k] =
-                ctx.getDirect<ExternalTorque>(RGDCols::ExternalTorque, loc);
-
-            ResponseType resp =
-                ctx.getDirect<ResponseType>(RGDCols::ResponseType, loc);
-            w->resp[k] = (uint32_t)resp;
-            const int32_t entity_id = ctx.getDirect<Entity>(0, loc).id;
-            w->entityID[k] = entity_id;
-
-            base::ObjectID obj_id =
-                ctx.getDirect<base::ObjectID>(RGDCols::ObjectID, loc);
-            const RigidBodyMetadata metadata =
-                hbm_obj_mgr.metadata[obj_id.idx];
-            w->constants[k] = xpbd::bodyConstants(metadata, resp);
-            w->primOffset[k] = (uint16_t)
-                hbm_obj_mgr.rigidBodyPrimitiveOffsets[obj_id.idx];
-            w->primCount[k] = (uint16_t)
-                hbm_obj_mgr.rigidBodyPrimitiveCounts[obj_id.idx];
-
-            int32_t leaf = ctx.getDirect<broadphase::LeafID>(
-                RGDCols::LeafID, loc).id;
-            const uint32_t rank = w->leafRank[leaf];
-            w->queryBox()[k] = bvh.getLeafAABB(broadphase::LeafID { leaf });
-            w->rankSlotBox()[rank] = bvh.leafSlotBounds(leaf);
-            w->rankEntity()[rank] = entity_id;
-            w->orderBody[rank] = (uint16_t)k;
+        } else {
+            {
+                const int32_t *order = bvh.traversalOrder();
+                for (int32_t r = (int32_t)lane; r < num_bodies; r += 64) {
+                    w->leafRank[order[r]] = (uint16_t)r;
+                }
+            }
+            wave::phaseFence();
+            loadWorldBodies<MAXB>(lane, w, w->leafRank, ctx, bodies, bvh,
+                                  hbm_obj_mgr, num_bodies);
         }
         if (lane == 0) {
             w->sys = ctx.singleton<PhysicsSystemState>();

@@ -116,12 +116,35 @@ struct CollisionPrimitive {
 
 // arrays indexed by primitive (first two) and by object id (the rest); filled by
 // PhysicsLoader, device resident
+// What the LDS-resident step kernels keep next to the CU of the object
+// manager's geometry -- the first primitives and as many of their object-space
+// hull meshes as fit a small arena -- laid out once by PhysicsLoader, so that a
+// world stages it with one coalesced copy instead of walking the primitive
+// list (a dependent round trip per hull, per world, per step).
+struct PrimImage {
+    static constexpr uint32_t maxPrims = 8;
+    static constexpr uint32_t arenaDwords = 192;
+
+    uint32_t numPrims;                  // covers primitives [0, numPrims); 0: none
+    uint32_t arenaUsed;
+    uint32_t pad_[2];
+    CollisionPrimitive prims[maxPrims]; // hull pointers as in collisionPrimitives
+    math::AABB primAABBs[maxPrims];
+    // per hull primitive: dword offsets into `arena` of its face planes, half
+    // edges, vertices and face base half edges, or -1 (mesh stays in HBM)
+    int32_t meshOffset[maxPrims][4];
+    alignas(16) uint32_t arena[arenaDwords];
+};
+
 struct ObjectManager {
     CollisionPrimitive *collisionPrimitives;
     math::AABB *primitiveAABBs;
     math::AABB *rigidBodyAABBs;
     uint32_t *rigidBodyPrimitiveOffsets, *rigidBodyPrimitiveCounts;
     RigidBodyMetadata *metadata;
+    // (not in the reference's struct; nullptr when the manager was not filled
+    // by this backend's PhysicsLoader)
+    const PrimImage *primImage;
 };
 
 struct ObjectData { ObjectManager *mgr; };

@@ -61,6 +61,11 @@ struct PhysicsScratch {
 // node data of the fused per-world step kernel
 struct PhysicsStepParams {
     int32_t numSubsteps;
+    int32_t pad_;
+    // per-world images of the LDS step's block (physicsPackKernel writes them
+    // right before the step kernel reads them), or nullptr: the step kernel
+    // reads the tables itself
+    void *worldImages;
 };
 
 namespace detail {
@@ -1613,8 +1618,25 @@ MADRONA_HOST_API inline TaskGraphNodeID setupPhysicsStepTasks(
         default: return (const void *)&kernels::physicsStepKernel;
         }
     };
+    [[maybe_unused]] auto pack_stub = [] __host__ (int max_bodies)
+            -> const void * {
+        switch (max_bodies) {
+        case 32: return (const void *)&kernels::physicsPackKernel<32>;
+        case 64: return (const void *)&kernels::physicsPackKernel<64>;
+        default: return (const void *)&kernels::physicsPackKernel<128>;
+        }
+    };
+    [[maybe_unused]] auto image_bytes = [] __host__ (int max_bodies) -> size_t {
+        switch (max_bodies) {
+        case 32: return kernels::WorldBlock<32>::imageBytes();
+        case 64: return kernels::WorldBlock<64>::imageBytes();
+        default: return kernels::WorldBlock<128>::imageBytes();
+        }
+    };
 #else
     auto step_stub = [](int) -> const void * { return nullptr; };
+    auto pack_stub = [](int) -> const void * { return nullptr; };
+    auto image_bytes = [](int) -> size_t { return 0; };
 #endif
 
     // joints are created / destroyed by the simulator between steps: group
@@ -1629,8 +1651,6 @@ MADRONA_HOST_API inline TaskGraphNodeID setupPhysicsStepTasks(
     PhysicsScratch ps;
     detail::scratchHost(builder, &ps);
 
-    auto params = builder.constructNodeData<PhysicsStepParams>(
-        PhysicsStepParams { (int32_t)num_substeps });
 
     // Worlds small enough to live in LDS take the LDS-resident kernel; the
     // bound is the largest world at graph-build time + 1/16, rounded up
@@ -1666,6 +1686,32 @@ MADRONA_HOST_API inline TaskGraphNodeID setupPhysicsStepTasks(
     }
     max_bodies = max_bodies <= 32 ? 32 : max_bodies <= 64 ? 64 :
                  max_bodies <= 128 ? 128 : 0;
+
+    // The LDS kernels start from per-world images packed by a high-occupancy
+    // kernel right before them (MADRONA_MWHIP_PHYS_PACK=0: read the tables in
+    // the step kernel itself, as the generic kernel does).
+    void *world_images = nullptr;
+    if (max_bodies != 0 &&
+            phys::detail::capacityHint("MADRONA_MWHIP_PHYS_PACK", 1) != 0) {
+        world_images = mwhip_alloc_device(exec,
+            (uint64_t)mwhip_num_worlds(exec) * image_bytes(max_bodies), 1);
+        if (world_images == nullptr) {
+            FATAL("madrona_amd physics: world image allocation failed: %s",
+                  mwhip_last_error());
+        }
+    }
+    auto params = builder.constructNodeData<PhysicsStepParams>(
+        PhysicsStepParams { (int32_t)num_substeps, 0, world_images });
+
+    if (world_images != nullptr) {
+        mwhip_node_desc pack {};
+        pack.kind = MWHIP_NODE_KERNEL;
+        pack.name = "physics:packWorlds";
+        pack.kernel = pack_stub(max_bodies);
+        pack.count_mode = MWHIP_COUNT_PER_WORLD;
+        pack.threads_per_invocation = 64;
+        cur_node = builder.addRuntimeNode(pack, params.id, {cur_node});
+    }
 
     mwhip_node_desc desc {};
     desc.kind = MWHIP_NODE_KERNEL;

@@ -17,6 +17,7 @@
 
 #include <mwhip.h>
 
+#include <cstring>
 #include <memory>
 #include <vector>
 
@@ -49,7 +50,19 @@ private:
         CountT maxObjs;
         int gpuID;
         std::vector<void *> hullAllocs;
+
+        // host mirror of what the first PrimImage::maxPrims primitives need
+        // (device-side primitive records + their hull data), and the image
+        PrimImage *primImage;
+        struct HostPrim {
+            CollisionPrimitive devPrim;
+            math::AABB aabb;
+            std::vector<uint32_t> planes, halfEdges, vertices, faceBase;
+        };
+        std::vector<HostPrim> hostPrims;
     };
+
+    inline void rebuildPrimImage();
 
     template <typename T>
     inline T *allocDevice(CountT n)
@@ -93,6 +106,11 @@ PhysicsLoader::PhysicsLoader(ExecMode exec_mode, CountT max_objects, int gpu_id)
     impl_->rigidBodyPrimitiveCounts = allocDevice<uint32_t>(max_objects);
     impl_->metadatas = allocDevice<RigidBodyMetadata>(max_objects);
     impl_->mgr = allocDevice<ObjectManager>(1);
+    impl_->primImage = allocDevice<PrimImage>(1);
+    {
+        PrimImage empty {};
+        upload(impl_->primImage, &empty, sizeof(PrimImage));
+    }
 
     ObjectManager local {
         impl_->primitives,
@@ -101,6 +119,7 @@ PhysicsLoader::PhysicsLoader(ExecMode exec_mode, CountT max_objects, int gpu_id)
         impl_->rigidBodyPrimitiveOffsets,
         impl_->rigidBodyPrimitiveCounts,
         impl_->metadatas,
+        impl_->primImage,
     };
     upload(impl_->mgr, &local, sizeof(ObjectManager));
 }
@@ -121,6 +140,70 @@ PhysicsLoader::~PhysicsLoader()
     mwhip_raw_free(impl_->gpuID, impl_->rigidBodyPrimitiveCounts);
     mwhip_raw_free(impl_->gpuID, impl_->metadatas);
     mwhip_raw_free(impl_->gpuID, impl_->mgr);
+    mwhip_raw_free(impl_->gpuID, impl_->primImage);
+}
+
+// Same placement rules as the per-world staging it replaces
+// (phys_impl/world_step.inl stagePrimitives): primitives in index order, a mesh
+// shared by several primitives staged once, a mesh that does not fit the arena
+// left in HBM.
+void PhysicsLoader::rebuildPrimImage()
+{
+    PrimImage image {};
+    const size_t total = (size_t)impl_->curPrimOffset;
+    if (total == 0 || total > PrimImage::maxPrims ||
+            impl_->hostPrims.size() != total) {
+        upload(impl_->primImage, &image, sizeof(PrimImage));
+        return;
+    }
+
+    image.numPrims = (uint32_t)total;
+    uint32_t used = 0;
+    for (size_t p = 0; p < total; p++) {
+        const Impl::HostPrim &hp = impl_->hostPrims[p];
+        image.prims[p] = hp.devPrim;
+        image.primAABBs[p] = hp.aabb;
+        for (int i = 0; i < 4; i++) image.meshOffset[p][i] = -1;
+        if (hp.devPrim.type != CollisionPrimitive::Type::Hull) {
+            continue;
+        }
+
+        bool shared = false;
+        for (size_t q = 0; q < p; q++) {
+            const Impl::HostPrim &hq = impl_->hostPrims[q];
+            if (hq.devPrim.type == CollisionPrimitive::Type::Hull &&
+                    hq.devPrim.hull.halfEdgeMesh.vertices ==
+                        hp.devPrim.hull.halfEdgeMesh.vertices) {
+                for (int i = 0; i < 4; i++) {
+                    image.meshOffset[p][i] = image.meshOffset[q][i];
+                }
+                shared = true;
+                break;
+            }
+        }
+        if (shared) {
+            continue;
+        }
+
+        const uint32_t need = (uint32_t)(hp.planes.size() +
+            hp.halfEdges.size() + hp.vertices.size() + hp.faceBase.size());
+        if (used + need > PrimImage::arenaDwords) {
+            continue;       // stays in HBM
+        }
+        uint32_t at = used;
+        auto place = [&](const std::vector<uint32_t> &words, int slot) {
+            image.meshOffset[p][slot] = (int32_t)at;
+            memcpy(image.arena + at, words.data(), words.size() * 4);
+            at += (uint32_t)words.size();
+        };
+        place(hp.planes, 0);
+        place(hp.halfEdges, 1);
+        place(hp.vertices, 2);
+        place(hp.faceBase, 3);
+        used = at;
+    }
+    image.arenaUsed = used;
+    upload(impl_->primImage, &image, sizeof(PrimImage));
 }
 
 CountT PhysicsLoader::loadRigidBodies(const RigidBodyAssets &assets)
@@ -195,6 +278,27 @@ CountT PhysicsLoader::loadRigidBodies(const RigidBodyAssets &assets)
 
     upload(impl_->primitives + cur_prim_offset, prims.data(),
            sizeof(CollisionPrimitive) * assets.totalNumPrimitives);
+
+    // host mirror for the primitive image (only its first few entries matter)
+    for (uint32_t i = 0; i < assets.totalNumPrimitives; i++) {
+        if (impl_->hostPrims.size() >= PrimImage::maxPrims + 1) break;
+        Impl::HostPrim hp;
+        hp.devPrim = prims[i];
+        hp.aabb = assets.primitiveAABBs[i];
+        if (prims[i].type == CollisionPrimitive::Type::Hull) {
+            const geo::HalfEdgeMesh &src = assets.primitives[i].hull.halfEdgeMesh;
+            auto words = [](const void *ptr, size_t n) {
+                const uint32_t *w = (const uint32_t *)ptr;
+                return std::vector<uint32_t>(w, w + n);
+            };
+            hp.planes = words(src.facePlanes, (size_t)src.numFaces * 4);
+            hp.halfEdges = words(src.halfEdges, (size_t)src.numHalfEdges * 3);
+            hp.vertices = words(src.vertices, (size_t)src.numVertices * 3);
+            hp.faceBase = words(src.faceBaseHalfEdges, (size_t)src.numFaces);
+        }
+        impl_->hostPrims.push_back(std::move(hp));
+    }
+    rebuildPrimImage();
 
     return cur_obj_offset;
 }

@@ -125,29 +125,32 @@ MADRONA_UNROLL
 }
 
 // Row counts of the matched tables, fixed once per launch (nodes whose system
-// can append rows; mwhip_pfor_args::row_sync).  Thread 0 of every workgroup
-// takes a ticket; the first ticket of a launch reads the counts and publishes
-// them as {epoch, rows} granules, the others wait for granules of their epoch.
-// A workgroup only starts running the system -- only then can it append rows
-// -- after it has seen the published counts, so they are the counts from
-// before the node.  out: dynamic LDS, one word per matched table.
+// can append rows; mwhip_pfor_args::row_sync).  Workgroup 0 reads the counts
+// and publishes them as {tag, rows} granules; every other workgroup waits for
+// granules carrying this launch's tag -- replays completed so far + 1: a node
+// runs once per replay.  A workgroup only starts running the system -- only
+// then can it append rows -- after it has seen the published counts, so they
+// are the counts from before the node.  No atomics: a ticket per workgroup on
+// one address serialises (11 ns each unloaded on MI355X, profiles/tools/
+// atomic_microbench.hip); workgroups are dispatched in index order, so
+// workgroup 0 is never behind the ones waiting for it.
+// out: dynamic LDS, one word per matched table.
 template <typename TableOfFn>
-MADRONA_DEVICE inline void pforRowSnapshot(PforRowSync *sync,
+MADRONA_DEVICE inline void pforRowSnapshot(EcsState *S, PforRowSync *sync,
                                            uint32_t num_tables,
                                            TableOfFn &&table_of,
                                            int32_t *out)
 {
     if (threadIdx.x == 0) {
-        const unsigned long long ticket = __hip_atomic_fetch_add(
-            &sync->ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long epoch =
-            (ticket / gridDim.x + 1ull) & 0xFFFFFFFFull;
-        if (ticket % gridDim.x == 0ull) {
+        const unsigned long long tag = (unsigned long long)(
+            __hip_atomic_load(S->replayCounter, __ATOMIC_RELAXED,
+                              __HIP_MEMORY_SCOPE_AGENT) + 1u);
+        if (blockIdx.x == 0) {
             for (uint32_t a = 0; a < num_tables; a++) {
                 int32_t n = __hip_atomic_load(&table_of(a)->numRows,
                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&sync->rows[a],
-                    (epoch << 32) | (unsigned long long)(uint32_t)n,
+                    (tag << 32) | (unsigned long long)(uint32_t)n,
                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 out[a] = n;
             }
@@ -157,7 +160,7 @@ MADRONA_DEVICE inline void pforRowSnapshot(PforRowSync *sync,
                 while (true) {
                     g = __hip_atomic_load(&sync->rows[a], __ATOMIC_RELAXED,
                                           __HIP_MEMORY_SCOPE_AGENT);
-                    if ((g >> 32) == epoch) break;
+                    if ((g >> 32) == tag) break;
                     __builtin_amdgcn_s_sleep(1);
                 }
                 out[a] = (int32_t)(uint32_t)g;
@@ -185,7 +188,7 @@ parallelForKernel(EcsState *S, void *, uint32_t query_offset,
     if (query.num_inline == num_matching) {
         int32_t num_rows[MWHIP_PFOR_MAX_INLINE];
         if (query.row_sync != nullptr) {
-            pforRowSnapshot((PforRowSync *)query.row_sync, num_matching,
+            pforRowSnapshot(S, (PforRowSync *)query.row_sync, num_matching,
                 [&](uint32_t a) { return (TableHdr *)query.tables[a]; },
                 pfor_snapshot_rows);
         }
@@ -213,7 +216,7 @@ MADRONA_UNROLL
     // general path: walk the query table
     const uint32_t *query_values = S->queryData + query_offset;
     if (query.row_sync != nullptr) {
-        pforRowSnapshot((PforRowSync *)query.row_sync, num_matching,
+        pforRowSnapshot(S, (PforRowSync *)query.row_sync, num_matching,
             [&](uint32_t a) {
                 return &S->tables[query_values[a * (1 + N)]];
             }, pfor_snapshot_rows);
@@ -256,7 +259,7 @@ parallelForBatchKernel(EcsState *S, void *, uint32_t query_offset,
     const uint32_t *query_values = S->queryData + query_offset;
 
     if (query.row_sync != nullptr) {
-        pforRowSnapshot((PforRowSync *)query.row_sync, num_matching,
+        pforRowSnapshot(S, (PforRowSync *)query.row_sync, num_matching,
             [&](uint32_t a) {
                 return &S->tables[query_values[a * (1 + N)]];
             }, pfor_snapshot_rows);
