@@ -1687,12 +1687,15 @@ MADRONA_HOST_API inline TaskGraphNodeID setupPhysicsStepTasks(
     max_bodies = max_bodies <= 32 ? 32 : max_bodies <= 64 ? 64 :
                  max_bodies <= 128 ? 128 : 0;
 
-    // The LDS kernels start from per-world images packed by a high-occupancy
-    // kernel right before them (MADRONA_MWHIP_PHYS_PACK=0: read the tables in
-    // the step kernel itself, as the generic kernel does).
+    // MADRONA_MWHIP_PHYS_PACK=1: the LDS kernels start from per-world images
+    // packed by a high-occupancy kernel right before them instead of reading
+    // the tables themselves.  Off by default: measured on 8192 Escape-Room
+    // worlds the step kernel gets 15 us faster and the pack costs 32 us -- at
+    // two waves per SIMD the load chain mostly hides behind the other world's
+    // arithmetic (profiles/r02_physics_phases.txt).
     void *world_images = nullptr;
     if (max_bodies != 0 &&
-            phys::detail::capacityHint("MADRONA_MWHIP_PHYS_PACK", 1) != 0) {
+            phys::detail::capacityHint("MADRONA_MWHIP_PHYS_PACK", 0) != 0) {
         world_images = mwhip_alloc_device(exec,
             (uint64_t)mwhip_num_worlds(exec) * image_bytes(max_bodies), 1);
         if (world_images == nullptr) {
