@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MWHIP_ABI_VERSION 1u
+#define MWHIP_ABI_VERSION 2u
 
 typedef struct mwhip_exec mwhip_exec; /* opaque; == MWCudaExecutor::Impl */
 
@@ -41,6 +41,17 @@ typedef struct mwhip_state_config {
     uint32_t num_task_graphs;
     uint32_t num_exported_buffers;
     int32_t gpu_id;
+    /* == the parts of madrona::CudaBatchRenderConfig (mw_gpu.hpp:77-96) the
+     * render-prep ECS systems need (Optional<CudaBatchRenderConfig> of the
+     * MWCudaExecutor constructor, cuda_exec.cpp:2333): side of the square
+     * ray-caster outputs (0 = ray caster off), colour + depth or depth only,
+     * and one object-space root AABB (6 floats: min xyz, max xyz) per object id
+     * for the top-level BVH leaf boxes (host pointer, copied; may be NULL). */
+    uint32_t raycast_output_resolution;
+    uint32_t raycast_rgbd;
+    const float *object_root_aabbs;
+    uint32_t num_object_root_aabbs;
+    uint32_t pad_;
 } mwhip_state_config;
 
 /* What the simulator's offline-compiled HIP translation unit hands to the
@@ -136,6 +147,11 @@ int mwhip_get_query_data(mwhip_exec *exec, uint32_t offset, uint32_t count,
 void *mwhip_device_state(mwhip_exec *exec);
 void *mwhip_world_data(mwhip_exec *exec, uint32_t world_idx);
 uint32_t mwhip_num_worlds(const mwhip_exec *exec);
+/* the ray caster's output resolution / RGBD flag the executor was created with
+ * (registerTypes sizes the render-target components from them,
+ * reference src/render/ecs_system.cpp:385-404) */
+void mwhip_render_config(const mwhip_exec *exec, uint32_t *resolution_out,
+                         uint32_t *rgbd_out);
 uint32_t mwhip_num_task_graphs(const mwhip_exec *exec);
 
 /* ---- task graph: TaskGraph::Builder -------------------------------------

@@ -957,6 +957,14 @@ extern "C" uint32_t mwhip_num_worlds(const mwhip_exec *exec)
     return exec->cfg.num_worlds;
 }
 
+extern "C" void mwhip_render_config(const mwhip_exec *exec,
+                                    uint32_t *resolution_out,
+                                    uint32_t *rgbd_out)
+{
+    *resolution_out = exec->cfg.raycast_output_resolution;
+    *rgbd_out = exec->cfg.raycast_rgbd;
+}
+
 extern "C" uint32_t mwhip_num_task_graphs(const mwhip_exec *exec)
 {
     return exec->cfg.num_task_graphs;
@@ -1123,6 +1131,20 @@ static int buildDeviceState(mwhip_exec *exec)
     exec->allocations.push_back(exec->replaySignal);
     HIPCHK(hipMemset(exec->replaySignal, 0, 256));
     hs.replayCounter = exec->replaySignal;
+
+    // batch ray caster configuration (render-prep systems read it on the device)
+    hs.raycastOutputResolution = exec->cfg.raycast_output_resolution;
+    hs.raycastRGBD = exec->cfg.raycast_rgbd;
+    if (exec->cfg.object_root_aabbs != nullptr &&
+            exec->cfg.num_object_root_aabbs != 0) {
+        void *aabbs_dev = nullptr;
+        const size_t bytes = (size_t)exec->cfg.num_object_root_aabbs * 24;
+        rc = devAlloc(exec, &aabbs_dev, bytes, false);
+        if (rc != 0) return rc;
+        HIPCHK(hipMemcpy(aabbs_dev, exec->cfg.object_root_aabbs, bytes,
+                         hipMemcpyHostToDevice));
+        hs.moduleData[2] = aabbs_dev;
+    }
 
     // device -> host message ring of mwGPU::HostPrint
     HIPCHK(hipHostMalloc((void **)&exec->printRing, sizeof(HostPrintRing),

@@ -55,6 +55,25 @@ struct CompileConfig {
     OptMode optMode = OptMode::LTO;
 };
 
+// Batch ray caster configuration (reference mw_gpu.hpp:77-96).  The geometry
+// side (geoBVHData / materialData) is not built on this backend yet (SURVEY
+// 8f-1); what the render-prep systems need of it is one object-space root AABB
+// per object id.
+struct CudaBatchRenderConfig {
+    enum class RenderMode : uint32_t {
+        RGBD,
+        Depth,
+    };
+
+    RenderMode renderMode = RenderMode::RGBD;
+    // 6 floats per object id (min xyz, max xyz), host memory, may be empty
+    Span<const float> objectRootAABBs = {};
+    // the ray caster's outputs are renderResolution x renderResolution
+    uint32_t renderResolution = 0;
+    float nearPlane = 0.f;
+    float farPlane = 0.f;
+};
+
 // Opaque device context handle (the reference returns a CUcontext)
 struct MWHipContext {
     int32_t gpuID;
@@ -115,10 +134,20 @@ public:
 
     MWCudaExecutor(const StateConfig &state_cfg,
                    const CompileConfig &,
-                   CUcontext ctx)
+                   CUcontext ctx,
+                   Optional<CudaBatchRenderConfig> render_cfg =
+                       Optional<CudaBatchRenderConfig>::none())
         : exec_(nullptr), num_taskgraphs_(state_cfg.numTaskGraphs)
     {
         mwhip_state_config cfg {};
+        if (render_cfg.has_value()) {
+            cfg.raycast_output_resolution = render_cfg->renderResolution;
+            cfg.raycast_rgbd = render_cfg->renderMode ==
+                CudaBatchRenderConfig::RenderMode::RGBD ? 1u : 0u;
+            cfg.object_root_aabbs = render_cfg->objectRootAABBs.data();
+            cfg.num_object_root_aabbs =
+                (uint32_t)render_cfg->objectRootAABBs.size() / 6u;
+        }
         cfg.world_init_ptr = state_cfg.worldInitPtr;
         cfg.num_world_init_bytes = state_cfg.numWorldInitBytes;
         cfg.user_config_ptr = state_cfg.userConfigPtr;

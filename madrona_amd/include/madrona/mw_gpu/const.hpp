@@ -55,8 +55,12 @@ struct GPUImplConsts {
         c.tmpAllocatorAddr = mgr;
         c.numWorldDataBytes = mgr->worldDataStride;
         c.numWorlds = (uint32_t)mgr->numWorlds;
+        // (until the ray caster's BLAS exists: one object-space root AABB per
+        // object id, madrona/render/ecs.hpp)
         c.meshBVHsAddr = mgr->moduleData[2];
         c.bvhInternalData = mgr->moduleData[3];
+        c.raycastOutputResolution = mgr->raycastOutputResolution;
+        c.raycastRGBD = mgr->raycastRGBD;
 #endif
         return c;
     }

@@ -164,6 +164,9 @@ struct EcsState {
     // replays completed so far (bumped by the last kernel of every replay):
     // with a node's position in the graph, a unique tag per launch
     const uint32_t *replayCounter;
+    // batch ray caster (CudaBatchRenderConfig): 0 = off
+    uint32_t raycastOutputResolution;
+    uint32_t raycastRGBD;
 };
 
 // Load through the constant address space: for data no kernel of the *user*

@@ -85,6 +85,18 @@ public:
         exportSingleton<SingletonT>((int32_t)slot);
     }
 
+    // the ray caster configuration of the executor (reference: registerTypes
+    // reads it from GPUImplConsts on the device; here registration is host code)
+    MADRONA_HOST_API uint32_t raycastOutputResolution() const
+    {
+        return state_mgr_->renderConfig(0);
+    }
+
+    MADRONA_HOST_API bool raycastRGBD() const
+    {
+        return state_mgr_->renderConfig(1) != 0;
+    }
+
 private:
     StateManager *state_mgr_;
     void **export_ptrs_;

@@ -57,6 +57,8 @@ public:
     // ---- host: registration (reference device state.inl:7-158) -------------
     template <typename ComponentT>
     MADRONA_HOST_API ComponentID registerComponent(uint32_t num_bytes = 0);
+    // host: which = 0 ray caster resolution, 1 RGBD flag
+    MADRONA_HOST_API inline uint32_t renderConfig(int which) const;
 
     template <typename ArchetypeT, typename... MetadataComponentTs>
     MADRONA_HOST_API ArchetypeID registerArchetype(

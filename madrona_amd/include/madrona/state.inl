@@ -111,6 +111,18 @@ MADRONA_HOST_API ArchetypeID StateManager::registerArchetype(
 #endif
 }
 
+MADRONA_HOST_API inline uint32_t StateManager::renderConfig(int which) const
+{
+#if MADRONA_ON_HOST
+    uint32_t res = 0, rgbd = 0;
+    mwhip_render_config((const mwhip_exec *)hostExec, &res, &rgbd);
+    return which == 0 ? res : rgbd;
+#else
+    (void)which;
+    MADRONA_DEVICE_STUB();
+#endif
+}
+
 template <typename SingletonT>
 MADRONA_HOST_API void StateManager::registerSingleton()
 {

@@ -97,8 +97,30 @@ struct ColumnList {
 
 }
 
+namespace simmgr {
+// optional hook of a simulator's traits, run before every step
+template <typename T>
+static void preStep()
+{
+    if constexpr (requires { T::preStep(); }) {
+        T::preStep();
+    }
+}
+}
+
 #ifndef SIM_BACKEND_REF_CPU
 namespace simmgr {
+template <typename T>
+static madrona::Optional<madrona::CudaBatchRenderConfig> renderConfig(
+    const SimCreateArgs &args)
+{
+    if constexpr (requires { T::renderConfig(args); }) {
+        return T::renderConfig(args);
+    } else {
+        return madrona::Optional<madrona::CudaBatchRenderConfig>::none();
+    }
+}
+
 // a step = every task graph back to back, unless the simulator says its other
 // task graphs are test probes (Traits::stepIsTaskGraph0)
 template <typename T>
@@ -162,6 +184,11 @@ SimHandle *sim_create(const SimCreateArgs *args)
 #else
     auto ctx = madrona::MWCudaExecutor::initCUDA(args->gpu_id);
 
+    // (simulators with a batch renderer pass Optional<CudaBatchRenderConfig>,
+    // reference mw_gpu.hpp:106-110)
+    madrona::Optional<madrona::CudaBatchRenderConfig> render_cfg =
+        simmgr::renderConfig<Traits>(*args);
+
     h->exec = new madrona::MWCudaExecutor({
         .worldInitPtr = inits.data(),
         .numWorldInitBytes = (uint32_t)sizeof(WorldInit),
@@ -174,7 +201,7 @@ SimHandle *sim_create(const SimCreateArgs *args)
         .numExportedBuffers = Traits::numExports,
     }, {
         {}, {}, madrona::CompileConfig::OptMode::LTO,
-    }, ctx);
+    }, ctx, render_cfg);
 
     h->stepGraph = simmgr::buildStepGraph<Traits>(*h->exec);
 #endif
@@ -208,6 +235,7 @@ const char *sim_backend(SimHandle *)
 void sim_step(SimHandle *h, uint32_t num_steps)
 {
     for (uint32_t i = 0; i < num_steps; i++) {
+        simmgr::preStep<SimTraits>();
 #ifdef SIM_BACKEND_REF_CPU
         h->exec->run();
 #else

@@ -1,0 +1,180 @@
+#include "render_prep/sim.hpp"
+
+struct SimTraits;
+#include "common/sim_c_api.h"
+
+#include <cstring>
+#include <vector>
+
+#ifndef SIM_BACKEND_REF_CPU
+#include <madrona/mw_gpu.hpp>
+#endif
+
+#ifdef SIM_BACKEND_REF_CPU
+// the reference's private bridge struct, where it lies (oracle build only)
+#include "ecs_interop.hpp"
+#include <madrona/sync.hpp>
+#endif
+
+namespace {
+
+// flags: bit 0 = RenderingSystem::setupTasks(update_visual_properties = true),
+// bits 8-15 = ray caster output resolution (HIP backend; 0 = ray caster off)
+constexpr uint32_t kMaxRecordsPerWorld = 64;
+
+#ifdef SIM_BACKEND_REF_CPU
+// What the reference's Vulkan renderer would own: the buffers its CPU-mode
+// systems append instance / view records to (src/render/ecs_interop.hpp).
+struct CpuBridge {
+    madrona::render::RenderECSBridge bridge {};
+    std::vector<madrona::render::PerspectiveCameraData> views;
+    std::vector<madrona::render::InstanceData> instances;
+    std::vector<uint64_t> instanceKeys, viewKeys;
+    uint32_t totalViews = 0, totalInstances = 0;
+    madrona::AtomicU32 viewCounter { 0 };
+    madrona::AtomicU32 instanceCounter { 0 };
+};
+CpuBridge *g_bridge = nullptr;
+#endif
+
+// object-space root boxes of the four "models" (HIP backend, ray caster on)
+const float kRootAABBs[renderprep::consts::numObjects * 6] = {
+    -0.5f, -0.5f, -0.5f, 0.5f, 0.5f, 0.5f,
+    -1.f, -0.25f, 0.f, 1.f, 0.25f, 2.f,
+    -0.75f, -0.75f, -0.1f, 0.75f, 0.75f, 0.1f,
+    0.f, 0.f, 0.f, 1.5f, 1.f, 0.5f,
+};
+
+}
+
+struct SimTraits {
+    using Sim = renderprep::Sim;
+    using Engine = renderprep::Engine;
+
+    static constexpr uint32_t numExports =
+        (uint32_t)renderprep::ExportID::NumExports;
+    static constexpr uint32_t numTaskGraphs = 1;
+
+    static Sim::Config makeConfig(const SimCreateArgs &args)
+    {
+        const madrona::render::RenderECSBridge *bridge = nullptr;
+#ifdef SIM_BACKEND_REF_CPU
+        delete g_bridge;
+        g_bridge = new CpuBridge();
+        const size_t cap = (size_t)args.num_worlds * kMaxRecordsPerWorld;
+        g_bridge->views.resize(cap);
+        g_bridge->instances.resize(cap);
+        g_bridge->instanceKeys.resize(cap);
+        g_bridge->viewKeys.resize(cap);
+        auto &b = g_bridge->bridge;
+        b.views = g_bridge->views.data();
+        b.instances = g_bridge->instances.data();
+        b.totalNumViews = &g_bridge->totalViews;
+        b.totalNumInstances = &g_bridge->totalInstances;
+        b.totalNumViewsCPUInc = &g_bridge->viewCounter;
+        b.totalNumInstancesCPUInc = &g_bridge->instanceCounter;
+        b.instancesWorldIDs = g_bridge->instanceKeys.data();
+        b.viewsWorldIDs = g_bridge->viewKeys.data();
+        b.renderWidth = 64;
+        b.renderHeight = 64;
+        b.maxViewsPerworld = renderprep::consts::numViewers;
+        b.maxInstancesPerWorld = renderprep::consts::maxMovers;
+        b.isGPUBackend = false;
+        bridge = &b;
+#endif
+        return Sim::Config { args.seed, args.world_base, args.flags & 1u,
+                             bridge };
+    }
+
+    static void makeInits(const SimCreateArgs &, Sim::WorldInit *) {}
+
+#ifdef SIM_BACKEND_REF_CPU
+    // the renderer zeroes the append counters before every step
+    static void preStep()
+    {
+        g_bridge->viewCounter.store_relaxed(0);
+        g_bridge->instanceCounter.store_relaxed(0);
+    }
+#else
+    static madrona::Optional<madrona::CudaBatchRenderConfig> renderConfig(
+        const SimCreateArgs &args)
+    {
+        madrona::CudaBatchRenderConfig cfg {};
+        cfg.renderMode = madrona::CudaBatchRenderConfig::RenderMode::RGBD;
+        cfg.renderResolution = (args.flags >> 8) & 0xFFu;
+        cfg.objectRootAABBs = madrona::Span<const float>(
+            kRootAABBs, (madrona::CountT)(renderprep::consts::numObjects * 6));
+        return madrona::Optional<madrona::CudaBatchRenderConfig>::make(cfg);
+    }
+#endif
+
+    template <typename T>
+    static void describeTensors(T &out, uint32_t num_worlds);
+    template <typename T>
+    static void describeColumns(T &cols);
+};
+
+#include "common/mgr_impl.inl"
+
+template <typename T>
+void SimTraits::describeTensors(T &out, uint32_t num_worlds)
+{
+    out.push_back({ "roster", SIM_I32, { (int64_t)num_worlds, 2 },
+                    (uint32_t)renderprep::ExportID::Roster });
+}
+
+template <typename T>
+void SimTraits::describeColumns(T &cols)
+{
+    using namespace renderprep;
+    using namespace madrona::render;
+
+    // simulator side: identical rows in identical order on both backends
+    cols.template add<Mover, Position>("Mover.Position", true);
+    cols.template add<Mover, Rotation>("Mover.Rotation", true);
+    cols.template add<Mover, Renderable>("Mover.Renderable", false);
+    cols.template add<Mover, MaterialOverride>("Mover.MaterialOverride", false);
+    cols.template add<Mover, ColorOverride>("Mover.ColorOverride", false);
+    cols.template add<Viewer, Position>("Viewer.Position", true);
+    cols.template add<Lamp, Position>("Lamp.Position", true);
+    // render side.  The light table is filled the same way on both backends;
+    // Morton codes too, but the reference's CPU sort by Morton code is not a
+    // sort: compared per world as multisets.
+    cols.template add<LightArchetype, LightDesc>("Light.LightDesc", false);
+    cols.template add<RenderableArchetype, MortonCode>("Renderable.MortonCode", false);
+#ifndef SIM_BACKEND_REF_CPU
+    // GPU mode only: the render entities' rows ARE the renderer's records
+    cols.template add<RenderableArchetype, madrona::Entity>("Renderable.Entity", false);
+    cols.template add<RenderableArchetype, InstanceData>("Renderable.InstanceData", false);
+    cols.template add<RenderableArchetype, TLBVHNode>("Renderable.TLBVHNode", true);
+    cols.template add<RenderCameraArchetype, PerspectiveCameraData>("Camera.PerspectiveCameraData", false);
+    cols.template add<RenderCameraArchetype, RenderOutputIndex>("Camera.RenderOutputIndex", false);
+    cols.template add<RenderCameraArchetype, RenderOutputRef>("Camera.RenderOutputRef", false);
+#endif
+}
+
+// CPU mode: the records of the last step as the reference appended them to the
+// bridge (arrival order) + the (world << 32 | entity id) key of each.
+// kind 0 = instances (64 B each), 1 = views (48 B each).  Returns the count.
+extern "C" SIM_API int64_t render_prep_bridge_records(int32_t kind, void *dst,
+                                                      uint64_t *keys_dst,
+                                                      uint64_t max_records)
+{
+#ifdef SIM_BACKEND_REF_CPU
+    if (g_bridge == nullptr) return -1;
+    const uint64_t n = kind == 0 ? g_bridge->instanceCounter.load_relaxed() :
+                                   g_bridge->viewCounter.load_relaxed();
+    if (n > max_records) return -2;
+    if (kind == 0) {
+        memcpy(dst, g_bridge->instances.data(), n * 64);
+        memcpy(keys_dst, g_bridge->instanceKeys.data(), n * 8);
+    } else {
+        memcpy(dst, g_bridge->views.data(), n * 48);
+        memcpy(keys_dst, g_bridge->viewKeys.data(), n * 8);
+    }
+    return (int64_t)n;
+#else
+    (void)kind; (void)dst; (void)keys_dst; (void)max_records;
+    return -1;
+#endif
+}
