@@ -171,10 +171,16 @@ inline void exportCounts(Context &ctx, RenderingSystemState &state)
 MADRONA_HOST_API inline void registerTypes(ECSRegistry &registry,
                                            const RenderECSBridge *bridge)
 {
+    // (the body is compiled for the device too, although it only ever runs on
+    // the host: the device pass has to see every registerComponent<T> so that
+    // T's id variable exists in the simulator's code object)
 #if MADRONA_ON_HOST
     if (bridge != nullptr) {
         FATAL("RenderingSystem: no Vulkan bridge on this backend, pass nullptr");
     }
+#else
+    (void)bridge;
+#endif
 
     // render targets exist even with the ray caster off (4 bytes each); depth is
     // always produced, colour only in RGBD mode
@@ -214,11 +220,6 @@ MADRONA_HOST_API inline void registerTypes(ECSRegistry &registry,
     registry.registerArchetype<RenderableArchetype>();
 
     registry.registerSingleton<RenderingSystemState>();
-#else
-    (void)registry;
-    (void)bridge;
-    MADRONA_DEVICE_STUB();
-#endif
 }
 
 MADRONA_HOST_API inline TaskGraphNodeID setupTasks(
