@@ -86,6 +86,9 @@ __global__ void miscOpsKernel(EcsState *S, const MiscOp *ops, uint32_t num_ops)
         if (tbl.numRows != 0) {
             tbl.needsSort = 1u;
         }
+        if (tbl.numRows > tbl.peakRows) {
+            tbl.peakRows = tbl.numRows;
+        }
         tbl.numRows = 0;
     } else if (op.kind == kOpResetTmpAlloc) {
         S->tmpOffset = 0ull;
@@ -315,19 +318,34 @@ packRowsKernel(PackArgs args, uint32_t *dst)
     }
 }
 
+// layout of the pinned health record (int32 words)
+constexpr uint32_t kStatsRows = 2;                          // [kMaxArchetypes]
+constexpr uint32_t kStatsGate = 2 + kMaxArchetypes;         // profiling gate flag
+constexpr uint32_t kStatsPeaks = 3 + kMaxArchetypes;        // [kMaxArchetypes]
+constexpr uint32_t kStatsReplays = 3 + 2 * kMaxArchetypes;  // replays completed
+constexpr uint32_t kStatsWords = 4 + 2 * kMaxArchetypes;
+
 __global__ void statsKernel(EcsState *S, int32_t *host_out,
                             uint32_t *replay_signal)
 {
     uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a < S->numArchetypeSlots) {
-        host_out[2 + a] = S->tables[a].registered ? S->tables[a].numRows : -1;
+        TableHdr &tbl = S->tables[a];
+        host_out[kStatsRows + a] = tbl.registered ? tbl.numRows : -1;
+        // the step's high-water mark (what growth is sized by), then reset
+        host_out[kStatsPeaks + a] = tbl.registered ?
+            (tbl.peakRows > tbl.numRows ? tbl.peakRows : tbl.numRows) : -1;
+        tbl.peakRows = 0;
     }
     if (a == 0) {
         host_out[0] = (int32_t)S->errorFlags;
         host_out[1] = S->numIds;
-        // this replay is complete (mwhip_stream_wait_replays polls this)
-        __hip_atomic_fetch_add(replay_signal, 1u, __ATOMIC_RELEASE,
-                               __HIP_MEMORY_SCOPE_SYSTEM);
+        // this replay is complete (mwhip_stream_wait_replays polls this; the
+        // host reads the copy in pinned memory without waiting)
+        uint32_t done = __hip_atomic_fetch_add(replay_signal, 1u,
+            __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM) + 1u;
+        __hip_atomic_store((uint32_t *)&host_out[kStatsReplays], done,
+                           __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -365,6 +383,8 @@ struct ArchetypeRec {
     uint32_t maxPerWorld = 0;
     bool singleton = false;
     bool bigSort = false;           // outgrew the single-launch sort once
+    int64_t peakSeen = 0;           // largest per-step peak reported so far
+    uint32_t fillingUntil = 0;      // replay count until which the queue is kept short
     int32_t singletonOrdinal = -1;
     uint32_t capacity = 0;              // rows backed by memory right now
     uint32_t reservedCapacity = 0;      // rows the address space allows
@@ -453,6 +473,12 @@ struct mwhip_exec {
     // mwGPU::HostPrint: ring in pinned host memory + the thread that drains it
     // while replays are in flight (replaces the reference's HostPrintCPU
     // thread, src/mw/cuda_exec.cpp)
+    // device -> host requests for table memory (mwhip::GrowMailbox) and the
+    // lock that orders the service thread against growth between replays
+    hipStream_t serviceStream = nullptr;    // fills of freshly mapped memory
+    GrowMailbox *growMailbox = nullptr;
+    std::mutex growMutex;
+    bool headersStale = false;      // device headers / graphs lag the mapped rows
     HostPrintRing *printRing = nullptr;
     std::mutex printMutex;
     std::thread printThread;
@@ -510,10 +536,17 @@ static int vmEnsure(mwhip_exec *exec, VmRange &r, size_t bytes, bool zero)
         HIPCHK(hipMemMap(r.base + r.mapped, kVmChunk, 0, chunk, 0));
         HIPCHK(hipMemSetAccess(r.base + r.mapped, kVmChunk, &access, 1));
         if (zero) {
-            HIPCHK(hipMemset(r.base + r.mapped, 0, kVmChunk));
+            // on the executor's side stream: a synchronous hipMemset waits for
+            // the device to drain, and the service thread maps memory for
+            // kernels that are waiting for exactly that
+            HIPCHK(hipMemsetAsync(r.base + r.mapped, 0, kVmChunk,
+                                  exec->serviceStream));
         }
         r.chunks.push_back(chunk);
         r.mapped += kVmChunk;
+    }
+    if (zero) {
+        HIPCHK(hipStreamSynchronize(exec->serviceStream));
     }
     return 0;
 }
@@ -1146,6 +1179,18 @@ static int buildDeviceState(mwhip_exec *exec)
         hs.moduleData[2] = aabbs_dev;
     }
 
+    // device -> host requests for table memory
+    HIPCHK(hipHostMalloc((void **)&exec->growMailbox, sizeof(GrowMailbox),
+                         hipHostMallocMapped));
+    memset((void *)exec->growMailbox, 0, sizeof(GrowMailbox));
+    for (uint32_t a = 0; a < exec->archetypes.size() && a < kMaxArchetypes; a++) {
+        if (exec->archetypes[a].registered) {
+            exec->growMailbox->capacity[a] = (int32_t)exec->archetypes[a].capacity;
+        }
+    }
+    HIPCHK(hipHostGetDevicePointer((void **)&hs.growMailbox,
+                                   exec->growMailbox, 0));
+
     // device -> host message ring of mwGPU::HostPrint
     HIPCHK(hipHostMalloc((void **)&exec->printRing, sizeof(HostPrintRing),
                          hipHostMallocMapped));
@@ -1158,11 +1203,11 @@ static int buildDeviceState(mwhip_exec *exec)
     HIPCHK(hipMemcpy(exec->stateDev, &hs, sizeof(EcsState),
                      hipMemcpyHostToDevice));
 
-    // [0] error flags, [1] id high-water mark, [2..] rows per archetype,
-    // [2 + kMaxArchetypes] profiling gate flag
+    // [0] error flags, [1] id high-water mark, rows / per-step peak rows per
+    // archetype, profiling gate flag, replays completed (kStats* above)
     HIPCHK(hipHostMalloc((void **)&exec->statsHost,
-        (3 + kMaxArchetypes) * sizeof(int32_t), hipHostMallocMapped));
-    memset(exec->statsHost, 0, (3 + kMaxArchetypes) * sizeof(int32_t));
+        kStatsWords * sizeof(int32_t), hipHostMallocMapped));
+    memset(exec->statsHost, 0, kStatsWords * sizeof(int32_t));
 
     exec->stateBuilt = true;
     return 0;
@@ -1835,6 +1880,7 @@ static int resetForInitPass(mwhip_exec *exec)
 }
 
 static int growTablesFromDevice(mwhip_exec *exec);
+static void serviceGrowRequests(mwhip_exec *exec);
 
 static int constructWorlds(mwhip_exec *exec)
 {
@@ -1993,6 +2039,7 @@ extern "C" int mwhip_create(const mwhip_state_config *cfg,
     exec->rowSnapshotMode = envU32("MADRONA_MWHIP_ROW_SNAPSHOT", 1);
     exec->tableGrowth = std::max(envU32("MADRONA_MWHIP_TABLE_GROWTH", 4), 1u);
     HIPCHK(hipStreamCreateWithFlags(&exec->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&exec->serviceStream, hipStreamNonBlocking));
 
     // ---- registerTypes (host) -------------------------------------------------
     exec->registrationOpen = true;
@@ -2032,10 +2079,17 @@ extern "C" int mwhip_create(const mwhip_state_config *cfg,
     // drained while replays are queued without being waited for
     drainHostPrints(exec.get(), false);
     mwhip_exec *raw = exec.release();
+    __atomic_store_n(&raw->growMailbox->serviceEnabled, 1u, __ATOMIC_RELEASE);
     raw->printThread = std::thread([raw]() {
+        // table-memory requests are answered promptly (device threads wait for
+        // them), messages are printed at leisure
+        uint32_t tick = 0;
         while (!raw->printStop.load()) {
-            drainHostPrints(raw, true);
-            std::this_thread::sleep_for(std::chrono::milliseconds(2));
+            serviceGrowRequests(raw);
+            if (tick++ % 16u == 0u) {
+                drainHostPrints(raw, true);
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(150));
         }
     });
 
@@ -2060,8 +2114,10 @@ extern "C" void mwhip_destroy(mwhip_exec *exec)
     if (exec->printThread.joinable()) exec->printThread.join();
     drainHostPrints(exec, false);
     if (exec->printRing) (void)hipHostFree(exec->printRing);
+    if (exec->growMailbox) (void)hipHostFree(exec->growMailbox);
     if (exec->statsHost) (void)hipHostFree(exec->statsHost);
     (void)hipStreamDestroy(exec->stream);
+    (void)hipStreamDestroy(exec->serviceStream);
     delete exec;
 }
 
@@ -2246,10 +2302,92 @@ static int instantiateLaunchGraph(mwhip_exec *exec,
 // compaction; a single step that outruns the head room still raises
 // kErrTableOverflow, as a fixed-capacity table does.
 // rows_of(a) = live rows of archetype a, or -1.
+// Maps memory for `new_capacity` rows behind every column, twin and sort buffer
+// of archetype a (addresses do not change) and tells the device through the
+// mailbox.  The table's device header and the launch graphs are brought up to
+// date by refreshAfterGrowth(), with the stream idle.  Caller holds growMutex.
+static int mapTableRows(mwhip_exec *exec, uint32_t a, uint64_t new_capacity)
+{
+    ArchetypeRec &arch = exec->archetypes[a];
+    for (uint32_t c = 0; c < arch.numColumns; c++) {
+        size_t bytes = (size_t)new_capacity * arch.colBytes[c] + 16;
+        int rc = vmEnsure(exec, *arch.primaryVm[c], bytes, true);
+        if (rc != 0) return rc;
+        rc = vmEnsure(exec, *arch.altVm[c], bytes, true);
+        if (rc != 0) return rc;
+    }
+    for (VmRange *r : arch.sortVm) {
+        if (r != nullptr) {
+            int rc = vmEnsure(exec, *r, (size_t)new_capacity * 4, false);
+            if (rc != 0) return rc;
+        }
+    }
+    arch.capacity = (uint32_t)new_capacity;
+    exec->tablesHost[a].capacity = (int32_t)new_capacity;
+    if (exec->growMailbox != nullptr && a < kMaxArchetypes) {
+        __atomic_store_n(&exec->growMailbox->capacity[a], (int32_t)new_capacity,
+                         __ATOMIC_RELEASE);
+    }
+    exec->numGrowths++;
+    exec->headersStale = true;
+    if (getenv("MADRONA_MWHIP_DEBUG_GROWTH") != nullptr) {
+        fprintf(stderr, "madrona_amd: archetype %u now has %llu rows mapped\n",
+                a, (unsigned long long)new_capacity);
+    }
+    return 0;
+}
+
+// Service thread: answers the device's requests while a replay is running.
+static void serviceGrowRequests(mwhip_exec *exec)
+{
+    GrowMailbox *mb = exec->growMailbox;
+    if (mb == nullptr) return;
+    bool pending = false;
+    for (uint32_t a = 0; a < exec->archetypes.size() && a < kMaxArchetypes; a++) {
+        if (__atomic_load_n(&mb->requested[a], __ATOMIC_RELAXED) >
+                mb->capacity[a]) {
+            pending = true;
+            break;
+        }
+    }
+    if (!pending) return;
+
+    std::lock_guard<std::mutex> guard(exec->growMutex);
+    (void)hipSetDevice(exec->cfg.gpu_id);
+    for (uint32_t a = 0; a < exec->archetypes.size() && a < kMaxArchetypes; a++) {
+        ArchetypeRec &arch = exec->archetypes[a];
+        const int64_t wanted = __atomic_load_n(&mb->requested[a], __ATOMIC_RELAXED);
+        if (!arch.registered || wanted <= (int64_t)arch.capacity ||
+                arch.reservedCapacity <= arch.capacity) {
+            continue;
+        }
+        uint64_t new_capacity = std::max<uint64_t>(2ull * arch.capacity,
+                                                   2ull * (uint64_t)wanted);
+        new_capacity = std::min<uint64_t>(new_capacity, arch.reservedCapacity);
+        if (getenv("MADRONA_MWHIP_DEBUG_GROWTH") != nullptr) {
+            fprintf(stderr, "madrona_amd: on-demand growth of archetype %u: "
+                    "%u -> %llu rows (wanted %lld)\n", a, arch.capacity,
+                    (unsigned long long)new_capacity, (long long)wanted);
+        }
+        if (mapTableRows(exec, a, new_capacity) != 0) {
+            if (getenv("MADRONA_MWHIP_DEBUG_GROWTH") != nullptr) {
+                fprintf(stderr, "madrona_amd: mapping failed: %s\n",
+                        g_lastError.c_str());
+            }
+            // the waiting threads time out and raise the overflow flag
+            return;
+        }
+    }
+}
+
 template <typename RowsFn>
 static int growTables(mwhip_exec *exec, RowsFn &&rows_of)
 {
-    bool grew = false;
+    std::lock_guard<std::mutex> guard(exec->growMutex);
+    bool grew = exec->headersStale;
+    if (grew) {
+        HIPCHK(hipStreamSynchronize(exec->stream));
+    }
     for (uint32_t a = 0; a < exec->archetypes.size(); a++) {
         ArchetypeRec &arch = exec->archetypes[a];
         if (!arch.registered || arch.reservedCapacity <= arch.capacity) {
@@ -2266,34 +2404,26 @@ static int growTables(mwhip_exec *exec, RowsFn &&rows_of)
         if (!grew) {
             HIPCHK(hipStreamSynchronize(exec->stream));
         }
-
-        for (uint32_t c = 0; c < arch.numColumns; c++) {
-            size_t bytes = (size_t)new_capacity * arch.colBytes[c] + 16;
-            int rc = vmEnsure(exec, *arch.primaryVm[c], bytes, true);
-            if (rc != 0) return rc;
-            rc = vmEnsure(exec, *arch.altVm[c], bytes, true);
-            if (rc != 0) return rc;
-        }
-        for (VmRange *r : arch.sortVm) {
-            if (r != nullptr) {
-                int rc = vmEnsure(exec, *r, (size_t)new_capacity * 4, false);
-                if (rc != 0) return rc;
-            }
-        }
-
-        arch.capacity = (uint32_t)new_capacity;
-        exec->tablesHost[a].capacity = (int32_t)new_capacity;
-        int32_t cap = (int32_t)new_capacity;
-        HIPCHK(hipMemcpy((char *)(exec->hostState.tables + a) +
-                             offsetof(TableHdr, capacity),
-                         &cap, sizeof(cap), hipMemcpyHostToDevice));
-        exec->numGrowths++;
+        int rc = mapTableRows(exec, a, new_capacity);
+        if (rc != 0) return rc;
         grew = true;
     }
 
     if (!grew) {
         return 0;
     }
+
+    // device headers follow what is mapped (also after on-demand growth by the
+    // service thread), then the graphs are rebuilt for the new sizes
+    for (uint32_t a = 0; a < exec->archetypes.size(); a++) {
+        const ArchetypeRec &arch = exec->archetypes[a];
+        if (!arch.registered) continue;
+        int32_t cap = (int32_t)arch.capacity;
+        HIPCHK(hipMemcpy((char *)(exec->hostState.tables + a) +
+                             offsetof(TableHdr, capacity),
+                         &cap, sizeof(cap), hipMemcpyHostToDevice));
+    }
+    exec->headersStale = false;
 
     for (auto &kv : exec->launchGraphs) {
         std::unique_ptr<LaunchGraph> fresh;
@@ -2331,7 +2461,7 @@ static int sortsOutgrown(mwhip_exec *exec)
             if (!batch->small) continue;
             for (const SortSiteHost &site : batch->sites) {
                 int64_t rows = site.archetype < kMaxArchetypes ?
-                    exec->statsHost[2 + site.archetype] : 0;
+                    exec->statsHost[kStatsRows + site.archetype] : 0;
                 if (rows * 2 > (int64_t)sortSmallRowLimit() &&
                         !exec->archetypes[site.archetype].bigSort) {
                     exec->archetypes[site.archetype].bigSort = true;
@@ -2361,7 +2491,7 @@ static int sortsOutgrown(mwhip_exec *exec)
 static int growTablesAfterReplay(mwhip_exec *exec)
 {
     int rc = growTables(exec, [exec](uint32_t a) -> int64_t {
-        return a < kMaxArchetypes ? exec->statsHost[2 + a] : -1;
+        return a < kMaxArchetypes ? exec->statsHost[kStatsPeaks + a] : -1;
     });
     if (rc != 0) return rc;
     return sortsOutgrown(exec);
@@ -2447,6 +2577,45 @@ extern "C" int mwhip_run_async(mwhip_exec *exec, uint64_t graph, void *hip_strea
     // health (and table sizes) as of the last completed replay
     int rc = checkHealth(exec);
     if (rc != 0) return rc;
+
+    // Growth reacts to what COMPLETED replays reported: replays queued behind
+    // them run with the tables as they are.  While some table is filling up
+    // (its per-step peak above a quarter of what is mapped) at most two
+    // replays stay in flight, so that growth keeps ahead of it; otherwise the
+    // queue may run as deep as the caller likes.
+    if ((hipStream_t)hip_stream == exec->stream) {
+        const uint32_t done = __atomic_load_n(
+            (uint32_t *)&exec->statsHost[kStatsReplays], __ATOMIC_ACQUIRE);
+        const uint32_t in_flight = exec->replaysLaunched - done;
+        // (a table is "filling up" while its peak keeps setting records: a
+        // population in steady state -- resets that destroy and re-create the
+        // same number of rows -- does not throttle the queue)
+        bool filling = false;
+        for (uint32_t a = 0; a < exec->archetypes.size(); a++) {
+            ArchetypeRec &arch = exec->archetypes[a];
+            if (!arch.registered || arch.reservedCapacity <= arch.capacity) {
+                continue;
+            }
+            const int64_t peak = exec->statsHost[kStatsPeaks + a];
+            if (peak > arch.peakSeen) {
+                arch.peakSeen = peak;
+                if (4 * peak > (int64_t)arch.capacity) {
+                    arch.fillingUntil = exec->replaysLaunched + 4u;
+                }
+            }
+            if (exec->replaysLaunched < arch.fillingUntil) {
+                filling = true;
+            }
+        }
+        if (in_flight >= 2u) {
+            if (filling) {
+                HIPCHK(hipStreamSynchronize(exec->stream));
+                drainHostPrints(exec, false);
+                rc = checkHealth(exec);
+                if (rc != 0) return rc;
+            }
+        }
+    }
     // (only on the executor's own stream: growing waits for that stream to
     // drain; replays queued on a caller's stream grow at mwhip_synchronize)
     if ((hipStream_t)hip_stream == exec->stream) {
@@ -2771,13 +2940,13 @@ extern "C" int32_t mwhip_profile(mwhip_exec *exec, uint64_t graph, uint32_t reps
         if (rc != 0) return rc;
 
         // queue everything behind the gate, then open it
-        volatile int32_t *gate_host = exec->statsHost + 2 + kMaxArchetypes;
+        volatile int32_t *gate_host = exec->statsHost + kStatsGate;
         *gate_host = 0;
         __sync_synchronize();
         {
             int32_t *gate_dev = nullptr;
             HIPCHK(hipHostGetDevicePointer((void **)&gate_dev,
-                (void *)(exec->statsHost + 2 + kMaxArchetypes), 0));
+                (void *)(exec->statsHost + kStatsGate), 0));
             void *gargs[] = { &gate_dev };
             HIPCHK(hipLaunchKernel((const void *)&gateKernel, dim3(1), dim3(64),
                                    gargs, 0, exec->stream));

@@ -208,6 +208,9 @@ __device__ inline void publishSite(EcsState *S, const SortSite &site,
         state->statRowsOut += (unsigned long long)n_out;
         state->statRuns += 1ull;
 
+        if (n > tbl.peakRows) {
+            tbl.peakRows = n;
+        }
         tbl.numRows = n_out;
         // A sort by any other key scrambles the rows across worlds: the next
         // world sort / compaction must not early-out, worldOffsets / worldCounts
@@ -271,11 +274,12 @@ sortOnesweep(EcsState *S, const SortSite *sites, uint32_t pass)
     // predecessors a tile waits for in the look-back below are already running
     // (or done).  No ticket counter: one atomic per tile on one address costs
     // more than the rest of a small pass.
-    const uint32_t tile = blockIdx.x;
+    // (a table that grew during the replay -- on-demand growth -- has more
+    // tiles than the grid was sized for: workgroups take further rounds)
+    for (uint32_t tile = blockIdx.x;
+         (int32_t)(tile * (uint32_t)kSortTile) < n; tile += gridDim.x) {
     const int32_t tile_base = (int32_t)(tile * (uint32_t)kSortTile);
-    if (tile_base >= n) {
-        return;
-    }
+    __syncthreads();
     for (int i = threadIdx.x; i < kSortWaves * kRadixDigits; i += kSortThreads) {
         (&lds.waveHist[0][0])[i] = 0;
     }
@@ -436,6 +440,7 @@ sortOnesweep(EcsState *S, const SortSite *sites, uint32_t pass)
             idx_out[dst] = lds.stageIdx[pos];
         }
     }
+    }   // tile rounds
 }
 
 // ---------------------------------------------------------------------------

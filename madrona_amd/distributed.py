@@ -162,6 +162,23 @@ class ShardedSimulator:
     def _exchange(self, packed):
         if self.shard.world_size == 1:
             self._packed_global.copy_(packed)
+        elif packed.is_cuda and self._dist.get_backend(self.group) == "gloo":
+            # Device tensors over a host-side backend (two ranks sharing one
+            # GPU in tests: RCCL refuses duplicate devices): stage through
+            # pinned host memory.  Everything around the collective -- packed
+            # step graphs, stream ordering, double buffering -- is the code the
+            # RCCL path runs.
+            import torch
+            if getattr(self, "_stage", None) is None:
+                self._stage = (
+                    torch.empty(packed.shape, dtype=packed.dtype).pin_memory(),
+                    torch.empty(self._packed_global.shape,
+                                dtype=packed.dtype).pin_memory())
+            send, recv = self._stage
+            send.copy_(packed, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            self._dist.all_gather_into_tensor(recv, send, group=self.group)
+            self._packed_global.copy_(recv, non_blocking=True)
         else:
             self._dist.all_gather_into_tensor(
                 self._packed_global, packed, group=self.group)

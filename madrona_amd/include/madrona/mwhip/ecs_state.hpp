@@ -72,7 +72,11 @@ struct TableHdr {
     uint32_t maxPerWorld;
     uint32_t registered;
     uint32_t rowBytes;          // sum of columnBytes
-    uint32_t pad_;
+    // most rows the table held at any point of the running step (rows destroyed
+    // and re-created in one step coexist until its compaction): what table
+    // growth is sized by.  Raised where rows are dropped (sort, ClearTmp), read
+    // and reset by the end-of-replay health kernel.
+    int32_t peakRows;
 };
 
 // == IDMap::Node with V = Loc (reference impl/id_map.hpp:41-53): a live slot
@@ -123,6 +127,18 @@ struct HostPrintRing {
     HostPrintRecord records[numRecords];
 };
 
+// Device -> host requests for table memory, in pinned host memory.  A thread
+// that appends past what is mapped posts the rows it needs and waits for the
+// executor's service thread to map more behind the table's columns (addresses
+// do not change); the reference's device code asks its host thread the same
+// way (src/mw/device/memory.cpp:27-121, src/mw/cuda_exec.cpp:1603-1719).
+struct GrowMailbox {
+    int32_t capacity[kMaxArchetypes];   // rows mapped; written by the host
+    int32_t requested[kMaxArchetypes];  // rows wanted; raised by the device
+    uint32_t serviceEnabled;            // a host thread is answering
+    uint32_t pad_[3];
+};
+
 struct EcsState {
     TableHdr *tables;               // [numArchetypeSlots]
     uint16_t *colLookup;            // [numArchetypeSlots * numComponentSlots]
@@ -167,6 +183,7 @@ struct EcsState {
     // batch ray caster (CudaBatchRenderConfig): 0 = off
     uint32_t raycastOutputResolution;
     uint32_t raycastRGBD;
+    GrowMailbox *growMailbox;       // pinned host memory, or nullptr
 };
 
 // Load through the constant address space: for data no kernel of the *user*
@@ -480,10 +497,49 @@ MWHIP_DEV inline int32_t appendRowIssue(TableHdr &tbl)
     return atomicAddI32(&tbl.numRows, 1);
 }
 
+// Slow path of appendRowCheck: the row lies past what the table's header says
+// is mapped.  The header may be behind (it is refreshed between replays): ask
+// the mailbox, and if the row really is unmapped, request it and wait for the
+// service thread.  Bounded: without an answer in ~0.2 s the append fails like
+// on a fixed-capacity table.
+MWHIP_DEV inline bool waitForTableMemory(EcsState *S, TableHdr &tbl, int32_t row)
+{
+    GrowMailbox *mb = S->growMailbox;
+    if (mb == nullptr) {
+        return false;
+    }
+    const uint32_t arch = (uint32_t)(&tbl - tablesOf(S));
+    if (row < __hip_atomic_load(&mb->capacity[arch], __ATOMIC_ACQUIRE,
+                                __HIP_MEMORY_SCOPE_SYSTEM)) {
+        return true;
+    }
+    if (__hip_atomic_load(&mb->serviceEnabled, __ATOMIC_RELAXED,
+                          __HIP_MEMORY_SCOPE_SYSTEM) == 0u) {
+        return false;
+    }
+    // (the mailbox is host memory: only loads, stores, add, swap and CAS are
+    // atomic across the bus -- no fetch_max.  Waiters re-post instead: the
+    // largest request wins within a few rounds.)
+    for (uint32_t spins = 0; spins < 50000u; spins++) {
+        if ((spins & 15u) == 0u &&
+                __hip_atomic_load(&mb->requested[arch], __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_SYSTEM) < row + 1) {
+            __hip_atomic_store(&mb->requested[arch], row + 1, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        __builtin_amdgcn_s_sleep(127);
+        if (row < __hip_atomic_load(&mb->capacity[arch], __ATOMIC_ACQUIRE,
+                                    __HIP_MEMORY_SCOPE_SYSTEM)) {
+            return true;
+        }
+    }
+    return false;
+}
+
 MWHIP_DEV inline int32_t appendRowCheck(EcsState *S, TableHdr &tbl, int32_t row)
 {
     const int32_t capacity = loadInvariant(&tbl.capacity);
-    if (row >= capacity) {
+    if (row >= capacity && !waitForTableMemory(S, tbl, row)) {
         raiseError(S, kErrTableOverflow);
         // keep writes in bounds; the host aborts after the step
         atomicAddI32(&tbl.numRows, -1);

@@ -609,3 +609,33 @@ def test_tables_grow_between_replays(built, monkeypatch):
                 probs = compare_columns(r.dump_all(), h.dump_all())
                 assert not probs, (s, probs[:3])
         assert rt.mwhip_num_table_growths(h.hip_exec()) >= grown_at_start + 2
+
+
+def test_tables_grow_under_a_queue_of_replays(built, monkeypatch):
+    """Growth has to keep ahead of replays that are queued without being waited
+    for (MWCudaExecutor::runAsync): sort_stress ramping up from 1 to 40 items
+    per world with tables mapped for a sixteenth of what the simulator
+    declared, stepped through mwhip_run_async only.  The very first step
+    already outruns what is mapped: the appending threads post their request in
+    the mailbox and wait while the executor's service thread maps more memory
+    behind the columns of the running kernel (on-demand growth, reference
+    src/mw/device/memory.cpp:27-121); between replays tables are sized by the
+    per-step high-water mark.  Results stay bit-identical."""
+    import ctypes as C
+    from madrona_amd.simlib import runtime_lib
+    _need_ref("sort_stress")
+    monkeypatch.setenv("MADRONA_MWHIP_INITIAL_CAPACITY_DIV", "16")
+    W, steps = 300, 60
+    with Simulator(ref_lib_path("sort_stress"), W, seed=7, num_workers=1, flags=2) as r, \
+            Simulator(hip_lib_path("sort_stress"), W, seed=7, flags=2) as h:
+        rt = runtime_lib()
+        rt.mwhip_num_table_growths.restype = C.c_uint32
+        rt.mwhip_num_table_growths.argtypes = [C.c_void_p]
+        grown_at_start = rt.mwhip_num_table_growths(h.hip_exec())
+        for chunk in range(steps // 20):
+            r.step(20)
+            h.step_async(20)        # 20 replays queued back to back
+            h.sync()
+            probs = compare_columns(r.dump_all(), h.dump_all())
+            assert not probs, (chunk, probs[:3])
+        assert rt.mwhip_num_table_growths(h.hip_exec()) >= grown_at_start + 3
