@@ -2383,11 +2383,31 @@ static void serviceGrowRequests(mwhip_exec *exec)
 template <typename RowsFn>
 static int growTables(mwhip_exec *exec, RowsFn &&rows_of)
 {
+    // Anything to do?  If so the stream is drained BEFORE the lock is taken for
+    // the work: a replay in flight may be waiting for the service thread, which
+    // needs the same lock.
+    auto wants_growth = [&](uint32_t a) {
+        const ArchetypeRec &arch = exec->archetypes[a];
+        if (!arch.registered || arch.reservedCapacity <= arch.capacity) {
+            return false;
+        }
+        int64_t rows = rows_of(a);
+        return rows >= 0 && 2 * rows > (int64_t)arch.capacity;
+    };
+    {
+        std::lock_guard<std::mutex> peek(exec->growMutex);
+        bool needed = exec->headersStale;
+        for (uint32_t a = 0; a < exec->archetypes.size() && !needed; a++) {
+            needed = wants_growth(a);
+        }
+        if (!needed) {
+            return 0;
+        }
+    }
+    HIPCHK(hipStreamSynchronize(exec->stream));
+
     std::lock_guard<std::mutex> guard(exec->growMutex);
     bool grew = exec->headersStale;
-    if (grew) {
-        HIPCHK(hipStreamSynchronize(exec->stream));
-    }
     for (uint32_t a = 0; a < exec->archetypes.size(); a++) {
         ArchetypeRec &arch = exec->archetypes[a];
         if (!arch.registered || arch.reservedCapacity <= arch.capacity) {
@@ -2401,9 +2421,6 @@ static int growTables(mwhip_exec *exec, RowsFn &&rows_of)
         uint64_t new_capacity = std::max<uint64_t>(2ull * arch.capacity,
                                                    3ull * (uint64_t)rows);
         new_capacity = std::min<uint64_t>(new_capacity, arch.reservedCapacity);
-        if (!grew) {
-            HIPCHK(hipStreamSynchronize(exec->stream));
-        }
         int rc = mapTableRows(exec, a, new_capacity);
         if (rc != 0) return rc;
         grew = true;
@@ -2548,6 +2565,17 @@ static int checkHealth(mwhip_exec *exec)
     if (!exec->checkAfterRun) return 0;
     uint32_t flags = (uint32_t)exec->statsHost[0];
     if (flags != 0) {
+        if ((flags & kErrTableOverflow) != 0u && exec->growMailbox != nullptr &&
+                exec->growMailbox->failedRow != 0) {
+            const GrowMailbox &mb = *exec->growMailbox;
+            const ArchetypeRec *arch =
+                (size_t)mb.failedArchetype < exec->archetypes.size() ?
+                    &exec->archetypes[mb.failedArchetype] : nullptr;
+            return fail(-5, "device error 0x%x: %s [archetype %d: row %d with %d "
+                        "rows mapped, %u reserved]", flags, describeError(flags),
+                        mb.failedArchetype, mb.failedRow, mb.failedCapacity,
+                        arch != nullptr ? arch->reservedCapacity : 0u);
+        }
         return fail(-5, "device error 0x%x: %s", flags, describeError(flags));
     }
     return 0;

@@ -136,7 +136,10 @@ struct GrowMailbox {
     int32_t capacity[kMaxArchetypes];   // rows mapped; written by the host
     int32_t requested[kMaxArchetypes];  // rows wanted; raised by the device
     uint32_t serviceEnabled;            // a host thread is answering
-    uint32_t pad_[3];
+    // diagnostics of the first append that gave up: archetype, row, rows mapped
+    int32_t failedArchetype;
+    int32_t failedRow;
+    int32_t failedCapacity;
 };
 
 struct EcsState {
@@ -541,6 +544,19 @@ MWHIP_DEV inline int32_t appendRowCheck(EcsState *S, TableHdr &tbl, int32_t row)
     const int32_t capacity = loadInvariant(&tbl.capacity);
     if (row >= capacity && !waitForTableMemory(S, tbl, row)) {
         raiseError(S, kErrTableOverflow);
+        if (GrowMailbox *mb = S->growMailbox; mb != nullptr &&
+                __hip_atomic_load(&mb->failedRow, __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
+            const int32_t arch = (int32_t)(&tbl - tablesOf(S));
+            __hip_atomic_store(&mb->failedArchetype, arch, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&mb->failedCapacity,
+                __hip_atomic_load(&mb->capacity[arch], __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_SYSTEM),
+                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&mb->failedRow, row, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         // keep writes in bounds; the host aborts after the step
         atomicAddI32(&tbl.numRows, -1);
         row = capacity - 1;
