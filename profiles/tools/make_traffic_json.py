@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""HBM traffic per STEP of every kernel, from two rocprofv3 PMC passes of the
+same bench command (FETCH_SIZE, WRITE_SIZE; one counter per pass, kernel trace
+only -- MI355X_MICROARCH.md, HBM section) -> entries for
+profiles/rNN_hbm_traffic.json (bench.py copies them into roofline.*.traffic).
+
+    make_traffic_json.py SIM WORLDS fetch.db write.db >> entries
+
+bytes = 2 * FETCH_SIZE KiB (gfx950 reports half of the fetched bytes) +
+WRITE_SIZE KiB.  Launches per step = dispatches of the kernel / dispatches of
+the end-of-replay health kernel (one per replay)."""
+import json
+import re
+import sqlite3
+import sys
+from collections import defaultdict
+
+sys.path.insert(0, __file__.rsplit("/", 2)[0])
+from summarize_pmc import short_name  # noqa: E402
+
+# rocprof kernel (function) name -> the name bench.py's kernel table uses
+BENCH_NAMES = [
+    (r"sortHistogram", "SortArchetype:sort.histogram"),
+    (r"sortOnesweep", "SortArchetype:sort.onesweep"),
+    (r"sortGather", "SortArchetype:sort.gather"),
+    (r"sortFinalize", "SortArchetype:sort.finalize"),
+    (r"sortSmall", "SortArchetype:sort.small"),
+    (r"physicsStepLdsKernel|physicsStepKernel", "physics:worldStep(LDS)"),
+    (r"physicsPackKernel", "physics:packWorlds"),
+    (r"bvhUpdateKernel", "physics:bvhUpdate"),
+    (r"miscOpsKernel", "misc:clear/reset"),
+    (r"statsKernel", "stats:health"),
+]
+
+
+def per_kernel(db_path, counter):
+    db = sqlite3.connect(db_path)
+    cols = [r[1] for r in db.execute("pragma table_info(counters_collection)")]
+    name_col = "kernel_name" if "kernel_name" in cols else "name"
+    acc = defaultdict(lambda: [0.0, 0])
+    for kname, cname, value in db.execute(
+            f"select {name_col}, counter_name, value from counters_collection"):
+        if cname != counter:
+            continue
+        a = acc[short_name(kname)]
+        a[0] += value
+        a[1] += 1
+    return acc
+
+
+def bench_name(short):
+    for pat, name in BENCH_NAMES:
+        if re.search(pat, short):
+            return name
+    m = re.match(r"parallelForKernel<([\w:]+)>", short)
+    return m.group(1) if m else short
+
+
+def main():
+    sim, worlds, fetch_db, write_db = sys.argv[1], int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    fetch = per_kernel(fetch_db, "FETCH_SIZE")
+    write = per_kernel(write_db, "WRITE_SIZE")
+    steps = max(n for k, (_, n) in fetch.items() if "statsKernel" in k)
+    merged = defaultdict(lambda: [0.0, 0.0, 0])
+    for short, (total, n) in fetch.items():
+        merged[bench_name(short)][0] += total
+        merged[bench_name(short)][2] += n
+    for short, (total, _) in write.items():
+        merged[bench_name(short)][1] += total
+    entries = []
+    step_total = 0.0
+    for name, (f_kib, w_kib, n) in sorted(merged.items()):
+        if "benchWindowMarker" in name or "gateKernel" in name:
+            continue
+        per_step = (2.0 * f_kib + w_kib) * 1024.0 / steps
+        step_total += per_step
+        entries.append({"sim": sim, "worlds": worlds, "kernel": name,
+                        "fetch_size_kib_per_step": round(f_kib / steps, 1),
+                        "write_size_kib_per_step": round(w_kib / steps, 1),
+                        "launches_per_step": round(n / steps, 2),
+                        "traffic_bytes": int(per_step)})
+    entries.append({"sim": sim, "worlds": worlds, "kernel": "step:all-kernels",
+                    "launches_per_step": round(sum(e["launches_per_step"]
+                                                   for e in entries), 2),
+                    "traffic_bytes": int(step_total)})
+    print(json.dumps(entries))
+
+
+if __name__ == "__main__":
+    main()
