@@ -2635,7 +2635,9 @@ extern "C" int mwhip_run_async(mwhip_exec *exec, uint64_t graph, void *hip_strea
                 filling = true;
             }
         }
-        if (in_flight >= 2u) {
+        static const bool limit_queue =
+            envU32("MADRONA_MWHIP_LIMIT_QUEUE", 1) != 0;
+        if (in_flight >= 2u && limit_queue) {
             if (filling) {
                 HIPCHK(hipStreamSynchronize(exec->stream));
                 drainHostPrints(exec, false);
