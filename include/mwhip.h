@@ -52,7 +52,43 @@ typedef struct mwhip_state_config {
     const float *object_root_aabbs;
     uint32_t num_object_root_aabbs;
     uint32_t pad_;
+    /* triangle geometry + materials of the renderable objects (== the
+     * geoBVHData / materialData of CudaBatchRenderConfig, which the reference
+     * fills from Embree-built MeshBVHs): host memory, copied; the executor
+     * builds its own bottom-level BVHs.  NULL: no ray caster. */
+    const struct mwhip_render_geometry *render_geometry;
 } mwhip_state_config;
+
+typedef struct mwhip_render_geometry {
+    uint32_t num_objects;
+    uint32_t num_materials;
+    const float *vertices;              /* xyz per vertex, all objects */
+    const uint32_t *indices;            /* 3 per triangle, object-local vertex ids */
+    const uint32_t *object_vertex_offset;   /* [num_objects + 1] into vertices */
+    const uint32_t *object_triangle_offset; /* [num_objects + 1] into indices / 3 */
+    const int32_t *object_material;     /* [num_objects] material id, -1: none
+                                         * (white); NULL: none anywhere */
+    const float *material_color;        /* rgb per material */
+} mwhip_render_geometry;
+
+/* Which tables the batch ray caster reads and writes: set once by
+ * RenderingSystem::registerTypes (the type ids are assigned there).
+ * Replaces the pointers the reference's render BVH kernels find in their
+ * BVHParams (src/mw/device/bvh_raycast.cpp, src/mw/cuda_exec.cpp). */
+typedef struct mwhip_render_layout {
+    uint32_t renderable_archetype;      /* InstanceData, MortonCode, TLBVHNode */
+    uint32_t camera_archetype;          /* PerspectiveCameraData */
+    uint32_t light_archetype;           /* LightDesc */
+    uint32_t output_archetype;          /* RGBOutputBuffer, DepthOutputBuffer */
+    uint32_t instance_component;
+    uint32_t morton_component;
+    uint32_t tlbvh_component;
+    uint32_t camera_component;
+    uint32_t light_component;
+    uint32_t rgb_component;
+    uint32_t depth_component;
+    uint32_t pad_;
+} mwhip_render_layout;
 
 /* What the simulator's offline-compiled HIP translation unit hands to the
  * executor.  Replaces CompileConfig::userSources + the three entry kernels
@@ -152,6 +188,12 @@ uint32_t mwhip_num_worlds(const mwhip_exec *exec);
  * reference src/render/ecs_system.cpp:385-404) */
 void mwhip_render_config(const mwhip_exec *exec, uint32_t *resolution_out,
                          uint32_t *rgbd_out);
+int mwhip_set_render_layout(mwhip_exec *exec, const mwhip_render_layout *layout);
+/* MWCudaExecutor::buildRenderGraph (reference mw_gpu.hpp:140, cuda_exec.cpp:
+ * 2294-2331): a launch graph that builds every world's top-level BVH over its
+ * (Morton-sorted) instances and ray-casts every view into the render-target
+ * columns.  Run it after the step graph (mwhip_run / mwhip_run_async). */
+int mwhip_build_render_graph(mwhip_exec *exec, uint64_t *graph_out);
 uint32_t mwhip_num_task_graphs(const mwhip_exec *exec);
 
 /* ---- task graph: TaskGraph::Builder -------------------------------------

@@ -1,0 +1,76 @@
+// Batch ray caster: what runtime.hip and render_raycast.hip share.
+#pragma once
+
+#include "runtime_internal.hpp"
+
+#include <madrona/math.hpp>
+
+#include <vector>
+
+namespace madrona {
+namespace mwhip {
+
+// most instances a world may hold for the ray caster (LDS budget of the
+// one-wavefront TLAS build: 48 B per leaf)
+constexpr uint32_t kMaxTlasLeaves = 1024;
+// bottom-level nodes per object (traversal stack entries are 16 bit)
+constexpr uint32_t kMaxBlasNodes = 65536;
+
+// Binary BVH node of both levels: the boxes of BOTH children, so that a leaf is
+// only entered after its own box was hit.  child = index of an internal node of
+// the same tree, or 0x80000000 | leaf, or 0xFFFFFFFF: no such child (a tree
+// with one leaf).  Top level: leaf = instance index inside the world.  Bottom
+// level: leaf = first triangle (bits 0..27) | (triangles - 1) << 28.
+struct alignas(16) BvhNode {
+    math::AABB box[2];
+    uint32_t child[2];
+    uint32_t pad[2];
+};
+static_assert(sizeof(BvhNode) == 64);
+
+struct RenderGeometryDev {
+    uint32_t numObjects;
+    uint32_t numMaterials;
+    const BvhNode *nodes;
+    const math::Vector3 *triangleVertices;  // 3 per triangle, leaf order
+    const uint32_t *objectNodeOffset;       // [numObjects + 1]
+    const uint32_t *objectTriangleOffset;   // [numObjects + 1]
+    const int32_t *objectMaterial;          // [numObjects], -1: none (white)
+    const float *materialColor;             // rgb per material
+};
+
+struct RenderGeometryHost {
+    uint32_t numObjects = 0;
+    uint32_t numMaterials = 0;
+    std::vector<BvhNode> nodes;
+    std::vector<float> triangleVertices;
+    std::vector<uint32_t> objectNodeOffset;
+    std::vector<uint32_t> objectTriangleOffset;
+    std::vector<int32_t> objectMaterial;
+    std::vector<float> materialColor;
+    std::vector<float> objectRootBox;       // 6 per object: what TLBVHNode uses
+};
+
+struct RenderParams {
+    mwhip_render_layout layout;
+    uint32_t instanceColumn, mortonColumn, tlbvhColumn;
+    uint32_t cameraColumn, lightColumn, rgbColumn, depthColumn;
+    uint32_t resolution;
+    uint32_t rgbd;
+    uint32_t pad_;
+    BvhNode *tlasNodes;         // one slot per row of the renderable table
+    RenderGeometryDev geometry;
+};
+
+// host: one median-split BVH per object; -1 + mwhip_last_error on bad input
+int buildRenderGeometry(const mwhip_render_geometry &src, RenderGeometryHost &out,
+                        std::string &error);
+
+// the launches of one render pass: TLAS build (a wavefront per world), then the
+// ray caster (a 16 x 16 tile of one view per workgroup)
+void buildRenderLaunches(EcsState *state_dev, const RenderParams &params,
+                         uint32_t num_worlds, uint32_t view_capacity,
+                         std::vector<KernelLaunch> &out);
+
+}
+}

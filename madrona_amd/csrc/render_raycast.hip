@@ -1,0 +1,890 @@
+// Batch ray caster for gfx950 (BASELINE config 5): every view of
+// every world rendered to res x res RGBA8 + depth, into the render-target
+// columns of the ECS.
+//
+// What is reproduced from the reference (src/mw/device/bvh_raycast.cpp): the
+// image.  Ray generation (:58-88), the object-space ray per instance with its
+// t rescaling (:627-646, :747-766), Woop's watertight ray / triangle test with
+// the same fmaf placement and the double-precision edge fallback (:318-438,
+// :228-270), closest hit, material / override colour (:772-812), the light loop
+// with spot cut-off and optional shadow rays (:840-930), pixel encoding
+// (:816-835), depth 0 / black on a miss.  Results agree with a brute-force
+// restatement (oracle/restate/raycast.c) to float rounding: the only freedom a
+// ray caster has is the ORDER in which it visits instances, and that moves
+// t_max by an ulp per visited instance (t_max * t_scale / t_scale).
+//
+// What is not: the acceleration structures.  The reference builds 4-wide
+// quantised nodes with Embree on the host (BLAS) and a ~1000-line multi-kernel
+// LBVH + tree-rotation optimiser on the device (TLAS, bvh.cpp).  Here:
+//  * TLAS: instances arrive grouped by world and Morton-sorted inside a world
+//    with their world-space boxes (RenderingSystem, madrona/render/ecs.inl), so
+//    ONE wavefront per world builds a Karras radix tree over them in LDS --
+//    internal node i from the longest-common-prefix function of the codes,
+//    boxes bottom-up with LDS arrival counters -- and writes <= n - 1 binary
+//    nodes (the fp32 boxes of both children, 64 B) into the world's slice of a
+//    node array;
+//  * BLAS: a binary median-split BVH per object built once on the host, same
+//    node shape (leaves of <= 4 triangles, triangles stored contiguously by
+//    leaf);
+//  * trace kernel: a 16 x 16 pixel tile of one view per workgroup; the world's
+//    TLAS nodes, instances and lights are staged in LDS once per workgroup, the
+//    traversal stack (one for both levels) lives in LDS too (a dynamically
+//    indexed private array is a scratch array on CDNA).  Children are visited
+//    near to far.  Rays of a tile are coherent: a wave walks mostly the same
+//    nodes.
+#include "runtime_internal.hpp"
+#include "render_internal.hpp"
+
+#include <madrona/math.hpp>
+
+namespace madrona {
+namespace mwhip {
+
+namespace {
+
+using math::Vector3;
+using math::Quat;
+using math::Diag3x3;
+using math::AABB;
+
+// layouts of the ECS components involved (madrona/render/ecs.hpp)
+struct alignas(16) InstanceRec {
+    Vector3 position;
+    Quat rotation;
+    Diag3x3 scale;
+    int32_t matID;
+    int32_t objectID;
+    int32_t worldIDX;
+    uint32_t color;
+};
+static_assert(sizeof(InstanceRec) == 64);
+
+struct alignas(16) ViewRec {
+    Vector3 position;
+    Quat rotation;
+    float xScale;
+    float yScale;
+    float zNear;
+    int32_t worldIDX;
+    uint32_t pad;
+};
+static_assert(sizeof(ViewRec) == 48);
+
+struct LightRec {
+    bool directional;       // LightDesc::Type: Directional = true
+    bool castShadow;
+    Vector3 position;
+    Vector3 direction;
+    float cutoff;
+    float intensity;
+    bool active;
+};
+static_assert(sizeof(LightRec) == 40);
+
+struct alignas(16) LeafBox { AABB aabb; };
+static_assert(sizeof(LeafBox) == 32);
+
+constexpr uint32_t kLeafBit = 0x80000000u;
+constexpr uint32_t kNoChild = 0xFFFFFFFFu;
+
+__device__ inline uint32_t laneId()
+{
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+// ---------------------------------------------------------------------------
+// TLAS: Karras radix tree over a world's Morton-sorted instances
+// ---------------------------------------------------------------------------
+// longest common prefix of the keys of leaves i and j (ties broken by index),
+// -1 outside [0, n)
+__device__ inline int32_t lcp(const uint32_t *codes, int32_t n, int32_t i,
+                              int32_t j)
+{
+    if (j < 0 || j >= n) {
+        return -1;
+    }
+    const uint32_t a = codes[i], b = codes[j];
+    if (a != b) {
+        return __builtin_clz(a ^ b);
+    }
+    return 32 + __builtin_clz((uint32_t)i ^ (uint32_t)j);
+}
+
+__device__ inline AABB merge(const AABB &a, const AABB &b)
+{
+    return AABB {
+        { fminf(a.pMin.x, b.pMin.x), fminf(a.pMin.y, b.pMin.y),
+          fminf(a.pMin.z, b.pMin.z) },
+        { fmaxf(a.pMax.x, b.pMax.x), fmaxf(a.pMax.y, b.pMax.y),
+          fmaxf(a.pMax.z, b.pMax.z) },
+    };
+}
+
+
+struct TlasLDS {
+    uint32_t codes[kMaxTlasLeaves];
+    uint32_t left[kMaxTlasLeaves];      // children of internal node i
+    uint32_t right[kMaxTlasLeaves];
+    int32_t parent[2 * kMaxTlasLeaves]; // [0, n-1): internal, [n-1 ..): leaves
+    uint32_t arrivals[kMaxTlasLeaves];
+    AABB box[kMaxTlasLeaves];           // internal nodes
+};
+
+__global__ void __launch_bounds__(64)
+renderTlasBuild(EcsState *S, RenderParams params)
+{
+    const int32_t world = (int32_t)blockIdx.x;
+    const uint32_t lane = laneId();
+
+    const TableHdr &tbl = S->tables[params.layout.renderable_archetype];
+    const int32_t first = tbl.worldOffsets[world];
+    const int32_t n = tbl.worldCounts[world];
+    if (n <= 0) {
+        return;
+    }
+    if (n > (int32_t)kMaxTlasLeaves || tbl.needsSort != 0u) {
+        raiseError(S, kErrRender);
+        return;
+    }
+
+    const uint32_t *codes_hbm =
+        (const uint32_t *)tbl.columns[params.mortonColumn] + first;
+    const LeafBox *leaf_boxes =
+        (const LeafBox *)tbl.columns[params.tlbvhColumn] + first;
+    BvhNode *nodes = params.tlasNodes + first;
+
+    if (n == 1) {
+        if (lane == 0) {
+            BvhNode root {};
+            root.box[0] = leaf_boxes[0].aabb;
+            root.box[1] = root.box[0];
+            root.child[0] = kLeafBit | 0u;
+            root.child[1] = kNoChild;
+            nodes[0] = root;
+        }
+        return;
+    }
+
+    __shared__ TlasLDS lds;
+
+    for (int32_t i = (int32_t)lane; i < n; i += 64) {
+        lds.codes[i] = codes_hbm[i];
+        lds.arrivals[i] = 0;
+    }
+    if (lane == 0) {
+        lds.parent[0] = -1;
+    }
+    __syncthreads();
+
+    // ---- topology: one internal node per lane (Karras 2012, fig. 4) --------
+    for (int32_t i = (int32_t)lane; i < n - 1; i += 64) {
+        const int32_t d = (lcp(lds.codes, n, i, i + 1) -
+                           lcp(lds.codes, n, i, i - 1)) >= 0 ? 1 : -1;
+        const int32_t delta_min = lcp(lds.codes, n, i, i - d);
+
+        int32_t l_max = 2;
+        while (lcp(lds.codes, n, i, i + l_max * d) > delta_min) {
+            l_max *= 2;
+        }
+        int32_t l = 0;
+        for (int32_t t = l_max / 2; t >= 1; t /= 2) {
+            if (lcp(lds.codes, n, i, i + (l + t) * d) > delta_min) {
+                l += t;
+            }
+        }
+        const int32_t j = i + l * d;
+
+        const int32_t delta_node = lcp(lds.codes, n, i, j);
+        int32_t s = 0;
+        for (int32_t t = (l + 1) / 2; ; t = (t + 1) / 2) {
+            if (lcp(lds.codes, n, i, i + (s + t) * d) > delta_node) {
+                s += t;
+            }
+            if (t == 1) break;
+        }
+        const int32_t gamma = i + s * d + (d < 0 ? d : 0);
+
+        const int32_t lo = i < j ? i : j;
+        const int32_t hi = i < j ? j : i;
+        const bool left_leaf = lo == gamma;
+        const bool right_leaf = hi == gamma + 1;
+        lds.left[i] = left_leaf ? (kLeafBit | (uint32_t)gamma) : (uint32_t)gamma;
+        lds.right[i] = right_leaf ? (kLeafBit | (uint32_t)(gamma + 1)) :
+                                    (uint32_t)(gamma + 1);
+        lds.parent[left_leaf ? (n - 1 + gamma) : gamma] = i;
+        lds.parent[right_leaf ? (n - 1 + gamma + 1) : (gamma + 1)] = i;
+    }
+    __syncthreads();
+
+    // ---- boxes, bottom-up: the second child to arrive at a node merges --------
+    for (int32_t leaf = (int32_t)lane; leaf < n; leaf += 64) {
+        int32_t cur = lds.parent[n - 1 + leaf];
+        while (cur >= 0) {
+            if (__hip_atomic_fetch_add(&lds.arrivals[cur], 1u, __ATOMIC_ACQ_REL,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) {
+                break;      // the sibling subtree is not done yet
+            }
+            const uint32_t l = lds.left[cur], r = lds.right[cur];
+            const AABB lb = (l & kLeafBit) != 0u ?
+                leaf_boxes[l & ~kLeafBit].aabb : lds.box[l];
+            const AABB rb = (r & kLeafBit) != 0u ?
+                leaf_boxes[r & ~kLeafBit].aabb : lds.box[r];
+            lds.box[cur] = merge(lb, rb);
+            cur = lds.parent[cur];
+        }
+    }
+    __syncthreads();
+
+    for (int32_t i = (int32_t)lane; i < n - 1; i += 64) {
+        const uint32_t l = lds.left[i], r = lds.right[i];
+        BvhNode node {};
+        node.box[0] = (l & kLeafBit) != 0u ? leaf_boxes[l & ~kLeafBit].aabb :
+                                             lds.box[l];
+        node.box[1] = (r & kLeafBit) != 0u ? leaf_boxes[r & ~kLeafBit].aabb :
+                                             lds.box[r];
+        node.child[0] = l;
+        node.child[1] = r;
+        nodes[i] = node;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// tracing
+// ---------------------------------------------------------------------------
+struct RayIsect {
+    int32_t kx, ky, kz;
+    float Sx, Sy, Sz;
+};
+
+__device__ inline float comp(const Vector3 &v, int32_t k)
+{
+    return k == 0 ? v.x : (k == 1 ? v.y : v.z);
+}
+
+// Woop et al. 2013 shear constants (reference bvh_raycast.cpp:228-270)
+__device__ inline RayIsect rayIsectInfo(const Vector3 &d, const Vector3 &inv_d)
+{
+    const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    int32_t kz = (ax > ay && ax > az) ? 0 : (ay > az ? 1 : 2);
+    int32_t kx = kz + 1 == 3 ? 0 : kz + 1;
+    int32_t ky = kx + 1 == 3 ? 0 : kx + 1;
+    if (comp(d, kz) < 0.f) {
+        int32_t t = kx; kx = ky; ky = t;
+    }
+    RayIsect r;
+    r.kx = kx; r.ky = ky; r.kz = kz;
+    r.Sx = comp(d, kx) * comp(inv_d, kz);
+    r.Sy = comp(d, ky) * comp(inv_d, kz);
+    r.Sz = comp(inv_d, kz);
+    return r;
+}
+
+// watertight ray / triangle test, no back-face culling (reference
+// bvh_raycast.cpp:318-438: same fmaf placement, same fallback, same epsilons)
+__device__ inline bool rayTriangle(const Vector3 &ta, const Vector3 &tb,
+                                   const Vector3 &tc, const RayIsect &r,
+                                   const Vector3 &org, float t_max,
+                                   float *t_out, Vector3 *normal_out)
+{
+    const Vector3 A = ta - org, B = tb - org, C = tc - org;
+    const float a_kz = comp(A, r.kz), a_kx = comp(A, r.kx), a_ky = comp(A, r.ky);
+    const float b_kz = comp(B, r.kz), b_kx = comp(B, r.kx), b_ky = comp(B, r.ky);
+    const float c_kz = comp(C, r.kz), c_kx = comp(C, r.kx), c_ky = comp(C, r.ky);
+
+    const float Ax = fmaf(-r.Sx, a_kz, a_kx), Ay = fmaf(-r.Sy, a_kz, a_ky);
+    const float Bx = fmaf(-r.Sx, b_kz, b_kx), By = fmaf(-r.Sy, b_kz, b_ky);
+    const float Cx = fmaf(-r.Sx, c_kz, c_kx), Cy = fmaf(-r.Sy, c_kz, c_ky);
+
+    float U = fmaf(Cx, By, -Cy * Bx);
+    float V = fmaf(Ax, Cy, -Ay * Cx);
+    float W = fmaf(Bx, Ay, -By * Ax);
+
+    constexpr float eps_tol = 1e-7f;
+    if (U > -eps_tol && U < eps_tol) U = 0.f;
+    if (V > -eps_tol && V < eps_tol) V = 0.f;
+    if (W > -eps_tol && W < eps_tol) W = 0.f;
+
+    if ((U < 0.f || V < 0.f || W < 0.f) && (U > 0.f || V > 0.f || W > 0.f)) {
+        return false;
+    }
+
+    if (U == 0.f || V == 0.f || W == 0.f) {
+        U = (float)((double)Cx * (double)By - (double)Cy * (double)Bx);
+        V = (float)((double)Ax * (double)Cy - (double)Ay * (double)Cx);
+        W = (float)((double)Bx * (double)Ay - (double)By * (double)Ax);
+        if ((U < 0.f || V < 0.f || W < 0.f) &&
+                (U > 0.f || V > 0.f || W > 0.f)) {
+            return false;
+        }
+    }
+
+    const float det = U + V + W;
+    if (det == 0.f) {
+        return false;
+    }
+
+    const float Az = r.Sz * a_kz, Bz = r.Sz * b_kz, Cz = r.Sz * c_kz;
+    const float T = fmaf(U, Az, fmaf(V, Bz, W * Cz));
+
+    const uint32_t det_sign = __float_as_uint(det) & 0x80000000u;
+    const float xor_T = __uint_as_float(__float_as_uint(T) ^ det_sign);
+    const float abs_det = copysignf(det, 1.f);
+    if (xor_T < 0.f || xor_T > t_max * abs_det) {
+        return false;
+    }
+
+    const float rcp_det = 1.f / det;
+    *t_out = T * rcp_det;
+    *normal_out = math::cross(B - A, C - A).normalize();
+    return true;
+}
+
+// entry distance of the ray into a box over [0, t_max], or +inf on a miss
+__device__ inline float boxEntry(const AABB &b, const Vector3 &o,
+                                 const Vector3 &inv_d, float t_max)
+{
+    const float tx0 = (b.pMin.x - o.x) * inv_d.x, tx1 = (b.pMax.x - o.x) * inv_d.x;
+    const float ty0 = (b.pMin.y - o.y) * inv_d.y, ty1 = (b.pMax.y - o.y) * inv_d.y;
+    const float tz0 = (b.pMin.z - o.z) * inv_d.z, tz1 = (b.pMax.z - o.z) * inv_d.z;
+    // (fminf / fmaxf drop the NaN of 0 * inf: a ray inside a slab it runs
+    // parallel to is not rejected by that slab)
+    const float t_near = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)),
+                               fmaxf(fminf(tz0, tz1), 0.f));
+    const float t_far = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)),
+                              fminf(fmaxf(tz0, tz1), t_max));
+    // a little slack: the boxes are exact, the triangle test is watertight and
+    // may accept a hit an ulp outside the box
+    return t_near <= t_far * 1.00001f + 1e-6f ? t_near : INFINITY;
+}
+
+constexpr uint32_t kStackDepth = 48;
+
+struct TraceLDS {
+    static constexpr int maxInstances = 64;
+    static constexpr int maxLights = 8;
+
+    BvhNode nodes[maxInstances];
+    InstanceRec instances[maxInstances];
+    LightRec lights[maxLights];
+    // traversal stack (both levels), one column per thread
+    uint16_t stack[kStackDepth][256];
+};
+
+struct Hit {
+    bool hit;
+    float t;            // world-space distance along the normalised ray
+    int32_t instance;   // index inside the world
+    Vector3 normal;     // object space, geometric
+};
+
+struct WorldView {
+    const BvhNode *nodes;          // LDS or HBM
+    const InstanceRec *instances;   // LDS or HBM
+    int32_t numInstances;
+};
+
+// closest hit of the ray against one instance's triangles: the ray goes to
+// object space, t is rescaled on the way in and out (reference :627-646,
+// :747-766).  The stack above `sp` is free.
+__device__ inline void traceInstance(EcsState *S, const RenderGeometryDev &geo,
+                                     const InstanceRec &inst, int32_t inst_idx,
+                                     const Vector3 &world_o,
+                                     const Vector3 &world_d, float &t_max,
+                                     Hit &best, TraceLDS *lds, uint32_t sp_base,
+                                     uint32_t tid)
+{
+    if (inst.scale.d0 == 0.f && inst.scale.d1 == 0.f && inst.scale.d2 == 0.f) {
+        return;
+    }
+    const Diag3x3 inv_scale = inst.scale.inv();
+    const Quat inv_rot = inst.rotation.inv();
+    const Vector3 o = inv_scale * inv_rot.rotateVec(world_o - inst.position);
+    Vector3 d = inv_scale * inv_rot.rotateVec(world_d);
+    const float t_scale = d.length();
+    t_max *= t_scale;
+    d /= t_scale;
+    const Vector3 inv_d { 1.f / d.x, 1.f / d.y, 1.f / d.z };
+    const RayIsect isect = rayIsectInfo(d, inv_d);
+
+    const uint32_t obj = (uint32_t)inst.objectID < geo.numObjects ?
+        (uint32_t)inst.objectID : 0u;
+    const BvhNode *nodes = geo.nodes + geo.objectNodeOffset[obj];
+    const Vector3 *tris = geo.triangleVertices +
+                          3u * (size_t)geo.objectTriangleOffset[obj];
+
+    uint32_t sp = sp_base;
+    uint32_t cur = 0;
+    while (true) {
+        const BvhNode node = nodes[cur];
+        float entry[2];
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            entry[c] = node.child[c] == kNoChild ? INFINITY :
+                boxEntry(node.box[c], o, inv_d, t_max);
+        }
+        const int near = entry[1] < entry[0] ? 1 : 0;
+        uint32_t next = kNoChild;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int c = k == 0 ? near : 1 - near;
+            if (!(entry[c] <= t_max)) {
+                continue;
+            }
+            const uint32_t child = node.child[c];
+            if ((child & kLeafBit) != 0u) {
+                // leaf: bits 0..27 first triangle, 28..30 count - 1
+                const uint32_t first_tri = child & 0x0FFFFFFFu;
+                const uint32_t num_tris = ((child >> 28) & 7u) + 1u;
+                for (uint32_t t_idx = 0; t_idx < num_tris; t_idx++) {
+                    const Vector3 *tri = tris + 3u * (size_t)(first_tri + t_idx);
+                    float t;
+                    Vector3 nrm;
+                    if (rayTriangle(tri[0], tri[1], tri[2], isect, o, t_max, &t,
+                                    &nrm)) {
+                        t_max = t;
+                        best.hit = true;
+                        best.instance = inst_idx;
+                        best.normal = nrm;
+                    }
+                }
+            } else if (next == kNoChild) {
+                next = child;
+            } else if (sp < kStackDepth) {
+                lds->stack[sp++][tid] = (uint16_t)child;
+            } else {
+                raiseError(S, kErrRender);
+            }
+        }
+        if (next != kNoChild) {
+            cur = next;
+        } else {
+            if (sp == sp_base) break;
+            cur = lds->stack[--sp][tid];
+        }
+    }
+
+    t_max = t_max / t_scale;
+}
+
+__device__ inline Hit traceWorld(EcsState *S, const RenderGeometryDev &geo,
+                                 const WorldView &w, const Vector3 &o,
+                                 const Vector3 &d, float t_max, TraceLDS *lds,
+                                 uint32_t tid)
+{
+    Hit best;
+    best.hit = false;
+    best.t = 0.f;
+    best.instance = -1;
+    best.normal = Vector3 { 0.f, 0.f, 0.f };
+
+    if (w.numInstances <= 0) {
+        return best;
+    }
+    const Vector3 inv_d { 1.f / d.x, 1.f / d.y, 1.f / d.z };
+
+    uint32_t sp = 0;
+    uint32_t cur = 0;       // internal node index
+    while (true) {
+        const BvhNode node = w.nodes[cur];
+        float entry[2];
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            entry[c] = node.child[c] == kNoChild ? INFINITY :
+                boxEntry(node.box[c], o, inv_d, t_max);
+        }
+        const int near = entry[1] < entry[0] ? 1 : 0;
+        uint32_t next = kNoChild;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int c = k == 0 ? near : 1 - near;
+            if (!(entry[c] <= t_max)) {
+                continue;
+            }
+            const uint32_t child = node.child[c];
+            if ((child & kLeafBit) != 0u) {
+                const int32_t idx = (int32_t)(child & ~kLeafBit);
+                traceInstance(S, geo, w.instances[idx], idx, o, d, t_max, best,
+                              lds, sp, tid);
+            } else if (next == kNoChild) {
+                next = child;
+            } else if (sp < kStackDepth) {
+                lds->stack[sp++][tid] = (uint16_t)child;
+            } else {
+                raiseError(S, kErrRender);
+            }
+        }
+        if (next != kNoChild) {
+            cur = next;
+        } else {
+            if (sp == 0) break;
+            cur = lds->stack[--sp][tid];
+        }
+    }
+
+    best.t = t_max;
+    return best;
+}
+
+__device__ inline Vector3 hexToRgb(uint32_t hex)
+{
+    return Vector3 { (float)((hex >> 16) & 0xFFu) / 255.f,
+                     (float)((hex >> 8) & 0xFFu) / 255.f,
+                     (float)(hex & 0xFFu) / 255.f };
+}
+
+// one 16 x 16 tile of one view per workgroup
+__global__ void __launch_bounds__(256)
+renderRaycast(EcsState *S, RenderParams params)
+{
+    __shared__ TraceLDS lds;
+
+    const uint32_t res = params.resolution;
+    const uint32_t tiles_per_side = (res + 15u) / 16u;
+    const uint32_t tiles_per_view = tiles_per_side * tiles_per_side;
+    const uint32_t tid = threadIdx.x;
+
+    const TableHdr &cam_tbl = S->tables[params.layout.camera_archetype];
+    const TableHdr &inst_tbl = S->tables[params.layout.renderable_archetype];
+    const TableHdr &light_tbl = S->tables[params.layout.light_archetype];
+    const TableHdr &out_tbl = S->tables[params.layout.output_archetype];
+    const uint32_t num_views = (uint32_t)cam_tbl.numRows;
+    const uint32_t total_tiles = num_views * tiles_per_view;
+
+    const RenderGeometryDev geo = params.geometry;
+    uint8_t *rgb_out = (uint8_t *)out_tbl.columns[params.rgbColumn];
+    float *depth_out = (float *)out_tbl.columns[params.depthColumn];
+    const uint32_t pixels_per_view = res * res;
+
+    for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+        const uint32_t view_idx = tile / tiles_per_view;
+        const uint32_t tile_in_view = tile % tiles_per_view;
+        const ViewRec view =
+            ((const ViewRec *)cam_tbl.columns[params.cameraColumn])[view_idx];
+        const int32_t world = view.worldIDX;
+
+        const int32_t inst_first = inst_tbl.worldOffsets[world];
+        const int32_t num_inst = inst_tbl.worldCounts[world];
+        const int32_t light_first = light_tbl.worldOffsets[world];
+        int32_t num_lights = light_tbl.worldCounts[world];
+        num_lights = num_lights < TraceLDS::maxLights ? num_lights :
+                                                        TraceLDS::maxLights;
+
+        // ---- stage the world next to the CU ---------------------------------
+        __syncthreads();
+        const InstanceRec *inst_hbm =
+            (const InstanceRec *)inst_tbl.columns[params.instanceColumn] +
+            inst_first;
+        const BvhNode *nodes_hbm = params.tlasNodes + inst_first;
+        const bool staged = num_inst <= TraceLDS::maxInstances;
+        if (staged) {
+            const uint32_t inst_dw = (uint32_t)num_inst * 16u;
+            for (uint32_t i = tid; i < inst_dw; i += 256u) {
+                ((uint32_t *)lds.instances)[i] = ((const uint32_t *)inst_hbm)[i];
+            }
+            const uint32_t node_dw =
+                (uint32_t)(num_inst > 1 ? num_inst - 1 : num_inst) * 16u;
+            for (uint32_t i = tid; i < node_dw; i += 256u) {
+                ((uint32_t *)lds.nodes)[i] = ((const uint32_t *)nodes_hbm)[i];
+            }
+        }
+        {
+            const uint32_t light_dw = (uint32_t)num_lights * 10u;
+            const uint32_t *src = (const uint32_t *)((const LightRec *)
+                light_tbl.columns[params.lightColumn] + light_first);
+            for (uint32_t i = tid; i < light_dw; i += 256u) {
+                ((uint32_t *)lds.lights)[i] = src[i];
+            }
+        }
+        __syncthreads();
+
+        WorldView wv;
+        wv.nodes = staged ? lds.nodes : nodes_hbm;
+        wv.instances = staged ? lds.instances : inst_hbm;
+        wv.numInstances = num_inst;
+
+        const uint32_t px = (tile_in_view % tiles_per_side) * 16u + (tid & 15u);
+        const uint32_t py = (tile_in_view / tiles_per_side) * 16u + (tid >> 4);
+        if (px >= res || py >= res) {
+            continue;
+        }
+
+        // ---- primary ray (reference calculateOutRay, :58-88) -------------------
+        const Quat rot = view.rotation;
+        const Vector3 ray_start = view.position;
+        const Vector3 look_at = rot.inv().rotateVec(Vector3 { 0.f, 1.f, 0.f });
+        const float h = 1.f / (-view.yScale);
+        const float viewport = 2.f * h;
+        const Vector3 forward = look_at.normalize();
+        const Vector3 u = rot.inv().rotateVec(Vector3 { 1.f, 0.f, 0.f });
+        const Vector3 v = math::cross(forward, u).normalize();
+        const Vector3 horizontal = u * viewport;
+        const Vector3 vertical = v * viewport;
+        const Vector3 lower_left =
+            ray_start - horizontal / 2.f - vertical / 2.f + forward;
+        const float pixel_u = ((float)px + 0.5f) / (float)res;
+        const float pixel_v = ((float)py + 0.5f) / (float)res;
+        const Vector3 ray_dir = (lower_left + pixel_u * horizontal +
+                                 pixel_v * vertical - ray_start).normalize();
+
+        const Hit first = traceWorld(S, geo, wv, ray_start, ray_dir, 10000.f,
+                                     &lds, tid);
+
+        const uint32_t pixel = px + py * res;
+        float depth = 0.f;
+        Vector3 shaded { 0.f, 0.f, 0.f };
+        if (first.hit) {
+            depth = first.t;
+            if (params.rgbd != 0u) {
+                const InstanceRec &inst = wv.instances[first.instance];
+                // reference traceRay, :772-812 (one material per object here,
+                // untextured)
+                int32_t material = inst.matID;
+                if (material == -1) {
+                    material = (uint32_t)inst.objectID < geo.numObjects ?
+                        geo.objectMaterial[inst.objectID] : -1;
+                }
+                Vector3 color { 1.f, 1.f, 1.f };
+                if (inst.matID == -2) {
+                    color = hexToRgb(inst.color);
+                } else if (material >= 0 &&
+                           (uint32_t)material < geo.numMaterials) {
+                    color = Vector3 { geo.materialColor[3 * material],
+                                      geo.materialColor[3 * material + 1],
+                                      geo.materialColor[3 * material + 2] };
+                }
+                const Vector3 normal = inst.rotation.rotateVec(first.normal);
+                const Vector3 hit_pos = ray_start + first.t * ray_dir;
+
+                // ---- lights (reference computeFragment, :840-930) -------------
+                float light_contrib = 0.f;
+                for (int32_t i = 0; i < num_lights; i++) {
+                    const LightRec light = lds.lights[i];
+                    Vector3 light_dir = -light.direction;
+                    if (!light.directional) {
+                        light_dir = (light.position - hit_pos).normalize();
+                        if (light.cutoff != -1.f) {
+                            float c = (-light_dir).dot(light.direction);
+                            c /= light_dir.length() * light.direction.length();
+                            const float angle = acosf(c);
+                            if (fabsf(angle) > fabsf(light.cutoff)) {
+                                continue;
+                            }
+                        }
+                    }
+                    if (light.castShadow) {
+                        if (light_dir.dot(normal) > 0.f) {
+                            const Hit shadow = traceWorld(S, geo, wv, hit_pos,
+                                light_dir, 10000.f, &lds, tid);
+                            if (!shadow.hit) {
+                                light_contrib += fminf(fmaxf(
+                                    normal.dot(light_dir), 0.f), 1.f);
+                            }
+                        }
+                    } else {
+                        light_contrib += fminf(fmaxf(normal.dot(light_dir), 0.f),
+                                               1.f);
+                    }
+                }
+                shaded = fmaxf(0.2f, light_contrib) * color;
+                shaded.x = fminf(1.f, shaded.x);
+                shaded.y = fminf(1.f, shaded.y);
+                shaded.z = fminf(1.f, shaded.z);
+            }
+        }
+
+        depth_out[(size_t)view_idx * pixels_per_view + pixel] = depth;
+        if (params.rgbd != 0u) {
+            uint32_t *dst = (uint32_t *)rgb_out +
+                            (size_t)view_idx * pixels_per_view + pixel;
+            *dst = (uint32_t)(uint8_t)(shaded.x * 255.f) |
+                   ((uint32_t)(uint8_t)(shaded.y * 255.f) << 8) |
+                   ((uint32_t)(uint8_t)(shaded.z * 255.f) << 16) | (255u << 24);
+        }
+    }
+}
+
+}
+
+// ---------------------------------------------------------------------------
+// host: bottom-level BVHs, launches
+// ---------------------------------------------------------------------------
+namespace {
+
+struct BuildTri {
+    float v[9];
+    float c[3];
+};
+
+AABB boxOf(const std::vector<BuildTri> &tris, uint32_t first, uint32_t count)
+{
+    AABB b { { 3.4e38f, 3.4e38f, 3.4e38f }, { -3.4e38f, -3.4e38f, -3.4e38f } };
+    for (uint32_t i = first; i < first + count; i++) {
+        for (int k = 0; k < 3; k++) {
+            const float *p = tris[i].v + 3 * k;
+            b.pMin.x = std::min(b.pMin.x, p[0]); b.pMax.x = std::max(b.pMax.x, p[0]);
+            b.pMin.y = std::min(b.pMin.y, p[1]); b.pMax.y = std::max(b.pMax.y, p[1]);
+            b.pMin.z = std::min(b.pMin.z, p[2]); b.pMax.z = std::max(b.pMax.z, p[2]);
+        }
+    }
+    return b;
+}
+
+constexpr uint32_t kLeafTris = 4;
+
+// node `node_idx` covers triangles [first, first + count), count > kLeafTris:
+// median split along the widest axis of the centroids
+void buildBlas(std::vector<BuildTri> &tris, uint32_t first, uint32_t count,
+               std::vector<BvhNode> &nodes, uint32_t node_idx)
+{
+    float lo[3] = { 3.4e38f, 3.4e38f, 3.4e38f };
+    float hi[3] = { -3.4e38f, -3.4e38f, -3.4e38f };
+    for (uint32_t i = first; i < first + count; i++) {
+        for (int a = 0; a < 3; a++) {
+            lo[a] = std::min(lo[a], tris[i].c[a]);
+            hi[a] = std::max(hi[a], tris[i].c[a]);
+        }
+    }
+    int axis = 0;
+    if (hi[1] - lo[1] > hi[axis] - lo[axis]) axis = 1;
+    if (hi[2] - lo[2] > hi[axis] - lo[axis]) axis = 2;
+    const uint32_t half = count / 2;
+    std::nth_element(tris.begin() + first, tris.begin() + first + half,
+                     tris.begin() + first + count,
+                     [axis](const BuildTri &a, const BuildTri &b) {
+                         return a.c[axis] < b.c[axis];
+                     });
+
+    const uint32_t part_first[2] = { first, first + half };
+    const uint32_t part_count[2] = { half, count - half };
+    for (int c = 0; c < 2; c++) {
+        nodes[node_idx].box[c] = boxOf(tris, part_first[c], part_count[c]);
+        if (part_count[c] <= kLeafTris) {
+            nodes[node_idx].child[c] =
+                kLeafBit | ((part_count[c] - 1u) << 28) | part_first[c];
+        } else {
+            const uint32_t child = (uint32_t)nodes.size();
+            nodes.push_back(BvhNode {});
+            nodes[node_idx].child[c] = child;
+            buildBlas(tris, part_first[c], part_count[c], nodes, child);
+        }
+    }
+}
+
+}
+
+int buildRenderGeometry(const mwhip_render_geometry &src, RenderGeometryHost &out,
+                        std::string &error)
+{
+    out.numObjects = src.num_objects;
+    out.numMaterials = src.num_materials;
+    out.objectNodeOffset.assign(src.num_objects + 1, 0);
+    out.objectTriangleOffset.assign(src.num_objects + 1, 0);
+    out.objectRootBox.assign((size_t)src.num_objects * 6, 0.f);
+    out.objectMaterial.assign(src.num_objects, -1);
+    if (src.object_material != nullptr) {
+        out.objectMaterial.assign(src.object_material,
+                                  src.object_material + src.num_objects);
+    }
+    if (src.num_materials != 0) {
+        out.materialColor.assign(src.material_color,
+                                 src.material_color + 3 * (size_t)src.num_materials);
+    }
+
+    for (uint32_t obj = 0; obj < src.num_objects; obj++) {
+        const uint32_t tri_first = src.object_triangle_offset[obj];
+        const uint32_t tri_count = src.object_triangle_offset[obj + 1] - tri_first;
+        const uint32_t vert_first = src.object_vertex_offset[obj];
+        const uint32_t vert_count = src.object_vertex_offset[obj + 1] - vert_first;
+        const float *verts = src.vertices + 3 * (size_t)vert_first;
+
+        std::vector<BuildTri> tris(tri_count);
+        for (uint32_t t = 0; t < tri_count; t++) {
+            for (int k = 0; k < 3; k++) {
+                const uint32_t vi = src.indices[3 * (size_t)(tri_first + t) + k];
+                if (vi >= vert_count) {
+                    error = "render geometry: object " + std::to_string(obj) +
+                            " indexes vertex " + std::to_string(vi) + " of " +
+                            std::to_string(vert_count);
+                    return -1;
+                }
+                for (int a = 0; a < 3; a++) {
+                    tris[t].v[3 * k + a] = verts[3 * (size_t)vi + a];
+                }
+            }
+            for (int a = 0; a < 3; a++) {
+                tris[t].c[a] =
+                    (tris[t].v[a] + tris[t].v[3 + a] + tris[t].v[6 + a]) / 3.f;
+            }
+        }
+
+        std::vector<BvhNode> nodes(1);
+        nodes[0].child[0] = nodes[0].child[1] = kNoChild;
+        if (tri_count > kLeafTris) {
+            buildBlas(tris, 0, tri_count, nodes, 0);
+        } else if (tri_count > 0) {
+            nodes[0].box[0] = boxOf(tris, 0, tri_count);
+            nodes[0].child[0] = kLeafBit | ((tri_count - 1u) << 28);
+        }
+        if (nodes.size() > kMaxBlasNodes) {
+            error = "render geometry: object " + std::to_string(obj) + " needs " +
+                    std::to_string(nodes.size()) + " BVH nodes (limit " +
+                    std::to_string(kMaxBlasNodes) + ")";
+            return -1;
+        }
+
+        const uint32_t tri_base = (uint32_t)(out.triangleVertices.size() / 9);
+        if ((uint64_t)tri_base + tri_count > 0x0FFFFFFFull) {
+            error = "render geometry: more than 2^28 triangles";
+            return -1;
+        }
+        out.objectNodeOffset[obj] = (uint32_t)out.nodes.size();
+        out.objectTriangleOffset[obj] = tri_base;
+        out.nodes.insert(out.nodes.end(), nodes.begin(), nodes.end());
+        for (const BuildTri &t : tris) {
+            out.triangleVertices.insert(out.triangleVertices.end(), t.v, t.v + 9);
+        }
+        if (tri_count > 0) {
+            const AABB root = boxOf(tris, 0, tri_count);
+            float *rb = out.objectRootBox.data() + 6 * (size_t)obj;
+            rb[0] = root.pMin.x; rb[1] = root.pMin.y; rb[2] = root.pMin.z;
+            rb[3] = root.pMax.x; rb[4] = root.pMax.y; rb[5] = root.pMax.z;
+        }
+    }
+    out.objectNodeOffset[src.num_objects] = (uint32_t)out.nodes.size();
+    out.objectTriangleOffset[src.num_objects] =
+        (uint32_t)(out.triangleVertices.size() / 9);
+    return 0;
+}
+
+void buildRenderLaunches(EcsState *state_dev, const RenderParams &params,
+                         uint32_t num_worlds, uint32_t view_capacity,
+                         std::vector<KernelLaunch> &out)
+{
+    {
+        KernelLaunch k;
+        k.fn = (const void *)&renderTlasBuild;
+        k.grid = dim3(num_worlds, 1, 1);
+        k.block = dim3(64, 1, 1);
+        k.setArgs(state_dev, params);
+        k.name = "render";
+        k.role = "tlas.build";
+        out.push_back(k);
+    }
+    {
+        KernelLaunch k;
+        k.fn = (const void *)&renderRaycast;
+        const uint32_t tiles_per_side = (params.resolution + 15u) / 16u;
+        const uint64_t tiles =
+            (uint64_t)view_capacity * tiles_per_side * tiles_per_side;
+        k.grid = dim3((uint32_t)std::min<uint64_t>(std::max<uint64_t>(tiles, 1),
+                                                  1u << 20), 1, 1);
+        k.block = dim3(256, 1, 1);
+        k.setArgs(state_dev, params);
+        k.name = "render";
+        k.role = "raycast";
+        out.push_back(k);
+    }
+}
+
+}
+}

@@ -9,6 +9,7 @@
 // and graph construction are host code, every node is its own kernel, and a
 // step is one hipGraph replay on the executor's private stream.
 #include "runtime_internal.hpp"
+#include "render_internal.hpp"
 
 #include <hip/hip_ext.h>
 
@@ -325,11 +326,14 @@ constexpr uint32_t kStatsPeaks = 3 + kMaxArchetypes;        // [kMaxArchetypes]
 constexpr uint32_t kStatsReplays = 3 + 2 * kMaxArchetypes;  // replays completed
 constexpr uint32_t kStatsWords = 4 + 2 * kMaxArchetypes;
 
+// report_rows == 0 (render pass): error flags and the replay counter only -- the
+// step's row statistics and high-water marks stay as its own health kernel
+// reported them
 __global__ void statsKernel(EcsState *S, int32_t *host_out,
-                            uint32_t *replay_signal)
+                            uint32_t *replay_signal, uint32_t report_rows)
 {
     uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
-    if (a < S->numArchetypeSlots) {
+    if (a < S->numArchetypeSlots && report_rows != 0u) {
         TableHdr &tbl = S->tables[a];
         host_out[kStatsRows + a] = tbl.registered ? tbl.numRows : -1;
         // the step's high-water mark (what growth is sized by), then reset
@@ -439,6 +443,8 @@ struct LaunchGraph {
     bool hasPack = false;
     PackArgs pack {};
     void *packDst = nullptr;
+    // the batch ray caster's pass instead of task graphs
+    bool isRender = false;
 };
 
 struct mwhip_exec {
@@ -494,6 +500,15 @@ struct mwhip_exec {
     bool checkAfterRun = true;
     bool sortBatching = true;
     uint32_t rowSnapshotMode = 1;   // 0 never, 1 nodes that can append rows, 2 all
+
+    // batch ray caster: geometry (bottom-level BVHs) + where the ECS keeps what
+    // it reads and writes
+    bool haveRenderGeometry = false;
+    bool haveRenderLayout = false;
+    RenderGeometryHost renderGeometry;
+    RenderGeometryDev renderGeometryDev {};
+    mwhip_render_layout renderLayout {};
+    BvhNode *tlasNodes = nullptr;
 };
 
 static int devAlloc(mwhip_exec *exec, void **out, size_t bytes, bool zero = true)
@@ -1013,6 +1028,43 @@ extern "C" void *mwhip_get_exported(const mwhip_exec *exec, uint32_t slot)
 // ---------------------------------------------------------------------------
 // state construction
 // ---------------------------------------------------------------------------
+// Bottom-level BVHs, triangles and materials of the ray caster -> device.
+static int uploadRenderGeometry(mwhip_exec *exec)
+{
+    const RenderGeometryHost &g = exec->renderGeometry;
+    RenderGeometryDev &d = exec->renderGeometryDev;
+    d.numObjects = g.numObjects;
+    d.numMaterials = g.numMaterials;
+
+    auto upload = [exec](const void *src, size_t bytes, const void **out) -> int {
+        void *dev = nullptr;
+        int rc = devAlloc(exec, &dev, bytes, false);
+        if (rc != 0) return rc;
+        if (bytes != 0) {
+            HIPCHK(hipMemcpy(dev, src, bytes, hipMemcpyHostToDevice));
+        }
+        *out = dev;
+        return 0;
+    };
+    int rc = upload(g.nodes.data(), g.nodes.size() * sizeof(BvhNode),
+                    (const void **)&d.nodes);
+    if (rc != 0) return rc;
+    rc = upload(g.triangleVertices.data(), g.triangleVertices.size() * 4,
+                (const void **)&d.triangleVertices);
+    if (rc != 0) return rc;
+    rc = upload(g.objectNodeOffset.data(), g.objectNodeOffset.size() * 4,
+                (const void **)&d.objectNodeOffset);
+    if (rc != 0) return rc;
+    rc = upload(g.objectTriangleOffset.data(), g.objectTriangleOffset.size() * 4,
+                (const void **)&d.objectTriangleOffset);
+    if (rc != 0) return rc;
+    rc = upload(g.objectMaterial.data(), g.objectMaterial.size() * 4,
+                (const void **)&d.objectMaterial);
+    if (rc != 0) return rc;
+    return upload(g.materialColor.data(), g.materialColor.size() * 4,
+                  (const void **)&d.materialColor);
+}
+
 static int buildDeviceState(mwhip_exec *exec)
 {
     const uint32_t W = exec->cfg.num_worlds;
@@ -1168,16 +1220,31 @@ static int buildDeviceState(mwhip_exec *exec)
     // batch ray caster configuration (render-prep systems read it on the device)
     hs.raycastOutputResolution = exec->cfg.raycast_output_resolution;
     hs.raycastRGBD = exec->cfg.raycast_rgbd;
-    if (exec->cfg.object_root_aabbs != nullptr &&
-            exec->cfg.num_object_root_aabbs != 0) {
-        void *aabbs_dev = nullptr;
-        const size_t bytes = (size_t)exec->cfg.num_object_root_aabbs * 24;
-        rc = devAlloc(exec, &aabbs_dev, bytes, false);
-        if (rc != 0) return rc;
-        HIPCHK(hipMemcpy(aabbs_dev, exec->cfg.object_root_aabbs, bytes,
-                         hipMemcpyHostToDevice));
-        hs.moduleData[2] = aabbs_dev;
+    {
+        // object-space root boxes (TLBVH leaves are made from them): as given,
+        // else those of the geometry handed over for the ray caster
+        const float *boxes = exec->cfg.object_root_aabbs;
+        uint32_t num_boxes = exec->cfg.num_object_root_aabbs;
+        if ((boxes == nullptr || num_boxes == 0) && exec->haveRenderGeometry) {
+            boxes = exec->renderGeometry.objectRootBox.data();
+            num_boxes = exec->renderGeometry.numObjects;
+        }
+        if (boxes != nullptr && num_boxes != 0) {
+            void *aabbs_dev = nullptr;
+            const size_t bytes = (size_t)num_boxes * 24;
+            rc = devAlloc(exec, &aabbs_dev, bytes, false);
+            if (rc != 0) return rc;
+            HIPCHK(hipMemcpy(aabbs_dev, boxes, bytes, hipMemcpyHostToDevice));
+            hs.moduleData[2] = aabbs_dev;
+        }
     }
+    if (exec->haveRenderGeometry) {
+        rc = uploadRenderGeometry(exec);
+        if (rc != 0) return rc;
+    }
+    // (caller's memory: not valid after mwhip_create returns)
+    exec->cfg.object_root_aabbs = nullptr;
+    exec->cfg.render_geometry = nullptr;
 
     // device -> host requests for table memory
     HIPCHK(hipHostMalloc((void **)&exec->growMailbox, sizeof(GrowMailbox),
@@ -1336,6 +1403,11 @@ static const char *describeError(uint32_t flags)
     }
     if (flags & kErrInitBlocks) {
         return "world constructors are not deterministic";
+    }
+    if (flags & kErrRender) {
+        return "ray caster: a world holds more than 1024 instances, the "
+               "instance table was not world-sorted, or a traversal stack "
+               "overflowed";
     }
     return "unknown device error";
 }
@@ -1779,7 +1851,8 @@ static int buildLaunchList(mwhip_exec *exec, const std::vector<uint32_t> &tg_ids
         k.block = dim3(256, 1, 1);
         int32_t *host_out = nullptr;
         HIPCHK(hipHostGetDevicePointer((void **)&host_out, exec->statsHost, 0));
-        k.setArgs(exec->stateDev, host_out, exec->replaySignal);
+        k.setArgs(exec->stateDev, host_out, exec->replaySignal,
+                  lg.isRender ? 0u : 1u);
         k.name = "stats";
         k.role = "health";
         k.kind = MWHIP_NODE_RECYCLE;
@@ -2041,6 +2114,15 @@ extern "C" int mwhip_create(const mwhip_state_config *cfg,
     HIPCHK(hipStreamCreateWithFlags(&exec->stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&exec->serviceStream, hipStreamNonBlocking));
 
+    if (cfg->render_geometry != nullptr) {
+        std::string error;
+        if (buildRenderGeometry(*cfg->render_geometry, exec->renderGeometry,
+                                error) != 0) {
+            return fail(-2, "%s", error.c_str());
+        }
+        exec->haveRenderGeometry = true;
+    }
+
     // ---- registerTypes (host) -------------------------------------------------
     exec->registrationOpen = true;
     entry->register_types(exec.get(), cfg->user_config_ptr);
@@ -2230,6 +2312,85 @@ static int topoSort(TaskGraphRec &tg)
 // launch graphs
 // ---------------------------------------------------------------------------
 // Launch list (grids sized from the tables' current capacities) + hipGraph.
+// The ray caster's launches for the tables as they are now (grids follow the
+// camera table's capacity: the kernels loop over the views that exist).
+static int renderLaunches(mwhip_exec *exec, std::vector<KernelLaunch> &out)
+{
+    const mwhip_render_layout &lay = exec->renderLayout;
+    auto column_of = [exec](uint32_t archetype, uint32_t component,
+                            uint32_t *out_col) -> int {
+        if (archetype >= exec->archetypes.size() ||
+                !exec->archetypes[archetype].registered) {
+            return fail(-3, "render layout: archetype %u is not registered",
+                        archetype);
+        }
+        const ArchetypeRec &arch = exec->archetypes[archetype];
+        for (uint32_t c = 2; c < arch.numColumns; c++) {
+            if (arch.colComponent[c] == component) {
+                *out_col = c;
+                return 0;
+            }
+        }
+        return fail(-3, "render layout: archetype %u has no component %u",
+                    archetype, component);
+    };
+
+    RenderParams params {};
+    params.layout = lay;
+    int rc = column_of(lay.renderable_archetype, lay.instance_component,
+                       &params.instanceColumn);
+    if (rc != 0) return rc;
+    rc = column_of(lay.renderable_archetype, lay.morton_component,
+                   &params.mortonColumn);
+    if (rc != 0) return rc;
+    rc = column_of(lay.renderable_archetype, lay.tlbvh_component,
+                   &params.tlbvhColumn);
+    if (rc != 0) return rc;
+    rc = column_of(lay.camera_archetype, lay.camera_component,
+                   &params.cameraColumn);
+    if (rc != 0) return rc;
+    rc = column_of(lay.light_archetype, lay.light_component, &params.lightColumn);
+    if (rc != 0) return rc;
+    rc = column_of(lay.output_archetype, lay.rgb_component, &params.rgbColumn);
+    if (rc != 0) return rc;
+    rc = column_of(lay.output_archetype, lay.depth_component,
+                   &params.depthColumn);
+    if (rc != 0) return rc;
+
+    const ArchetypeRec &inst = exec->archetypes[lay.renderable_archetype];
+    const ArchetypeRec &cams = exec->archetypes[lay.camera_archetype];
+    const ArchetypeRec &outs = exec->archetypes[lay.output_archetype];
+    const uint32_t res = exec->cfg.raycast_output_resolution;
+    if (inst.colBytes[params.instanceColumn] != 64 ||
+            inst.colBytes[params.tlbvhColumn] != 32 ||
+            cams.colBytes[params.cameraColumn] != 48 ||
+            exec->archetypes[lay.light_archetype].colBytes[params.lightColumn] != 40 ||
+            outs.colBytes[params.depthColumn] != res * res * 4u) {
+        return fail(-3, "render layout: component sizes are not those of "
+                    "madrona/render/ecs.hpp");
+    }
+
+    if (exec->tlasNodes == nullptr) {
+        // one node slot per instance row the table can ever hold (a world of n
+        // instances uses n - 1 of its n slots)
+        rc = devAllocT(exec, &exec->tlasNodes, inst.reservedCapacity, false);
+        if (rc != 0) return rc;
+    }
+
+    params.resolution = res;
+    params.rgbd = exec->cfg.raycast_rgbd;
+    params.tlasNodes = exec->tlasNodes;
+    params.geometry = exec->renderGeometryDev;
+    // (any grid is correct: workgroups stride over the tiles of the views that
+    // exist; sized for the views the table held when the graph was built)
+    uint32_t views = cams.capacity;
+    if (lay.camera_archetype < exec->rowsAtGraphBuild.size()) {
+        views = std::max(exec->rowsAtGraphBuild[lay.camera_archetype], 16u);
+    }
+    buildRenderLaunches(exec->stateDev, params, exec->cfg.num_worlds, views, out);
+    return 0;
+}
+
 static int instantiateLaunchGraph(mwhip_exec *exec,
                                   const std::vector<uint32_t> &ids,
                                   const std::string &stat_name,
@@ -2254,8 +2415,17 @@ static int instantiateLaunchGraph(mwhip_exec *exec,
         exec->rowsAtGraphBuild.clear();
     }
 
+    lg->isRender = pack_from != nullptr && pack_from->isRender;
     int rc = buildLaunchList(exec, ids, *lg);
     if (rc != 0) return rc;
+
+    if (lg->isRender) {
+        // TLAS build + ray caster, before the health kernel
+        std::vector<KernelLaunch> render;
+        rc = renderLaunches(exec, render);
+        if (rc != 0) return rc;
+        lg->launches.insert(lg->launches.end() - 1, render.begin(), render.end());
+    }
 
     if (pack_from != nullptr && pack_from->hasPack) {
         lg->hasPack = true;
@@ -2542,6 +2712,48 @@ extern "C" int mwhip_build_launch_graph(mwhip_exec *exec,
     std::unique_ptr<LaunchGraph> lg;
     int rc = instantiateLaunchGraph(exec, ids,
                                     stat_name != nullptr ? stat_name : "", lg);
+    if (rc != 0) return rc;
+
+    uint64_t handle = exec->nextGraphHandle++;
+    exec->launchGraphs[handle] = std::move(lg);
+    *graph_out = handle;
+    return 0;
+}
+
+extern "C" int mwhip_set_render_layout(mwhip_exec *exec,
+                                       const mwhip_render_layout *layout)
+{
+    if (layout == nullptr) {
+        return fail(-2, "set_render_layout: null layout");
+    }
+    exec->renderLayout = *layout;
+    exec->haveRenderLayout = true;
+    return 0;
+}
+
+extern "C" int mwhip_build_render_graph(mwhip_exec *exec, uint64_t *graph_out)
+{
+    HIPCHK(hipSetDevice(exec->cfg.gpu_id));
+    if (exec->cfg.raycast_output_resolution == 0) {
+        return fail(-3, "buildRenderGraph: the executor was created without a "
+                    "render configuration");
+    }
+    if (!exec->haveRenderGeometry) {
+        return fail(-3, "buildRenderGraph: no geometry "
+                    "(mwhip_state_config::render_geometry)");
+    }
+    if (!exec->haveRenderLayout) {
+        return fail(-3, "buildRenderGraph: RenderingSystem::registerTypes did "
+                    "not run (mwhip_set_render_layout)");
+    }
+
+    int rc = growTablesFromDevice(exec);
+    if (rc != 0) return rc;
+
+    LaunchGraph like {};
+    like.isRender = true;
+    std::unique_ptr<LaunchGraph> lg;
+    rc = instantiateLaunchGraph(exec, {}, "render", lg, &like);
     if (rc != 0) return rc;
 
     uint64_t handle = exec->nextGraphHandle++;

@@ -18,6 +18,7 @@
 #include <madrona/span.hpp>
 #include <madrona/optional.hpp>
 #include <madrona/types.hpp>
+#include <madrona/math.hpp>
 
 #include <mwhip.h>
 
@@ -59,6 +60,28 @@ struct CompileConfig {
 // side (geoBVHData / materialData) is not built on this backend yet (SURVEY
 // 8f-1); what the render-prep systems need of it is one object-space root AABB
 // per object id.
+namespace render {
+
+// Triangle geometry of the renderable objects, host memory (the reference's
+// MeshBVHData holds Embree-built QBVHs already on the device,
+// render/cuda_batch_render_assets.hpp:8-20; this executor builds its own
+// bottom-level BVHs from the triangles).
+struct MeshBVHData {
+    Span<const math::Vector3> vertices = {};        // all objects
+    Span<const uint32_t> indices = {};              // 3 per triangle, object-local
+    Span<const uint32_t> objectVertexOffsets = {};  // [numObjects + 1]
+    Span<const uint32_t> objectTriangleOffsets = {};// [numObjects + 1]
+};
+
+// One untextured material per object (the reference: per mesh, optionally
+// textured, cuda_batch_render_assets.hpp:22-28).
+struct MaterialData {
+    Span<const math::Vector3> materialColors = {};
+    Span<const int32_t> objectMaterials = {};       // [numObjects], -1: none
+};
+
+}
+
 struct CudaBatchRenderConfig {
     enum class RenderMode : uint32_t {
         RGBD,
@@ -66,7 +89,10 @@ struct CudaBatchRenderConfig {
     };
 
     RenderMode renderMode = RenderMode::RGBD;
-    // 6 floats per object id (min xyz, max xyz), host memory, may be empty
+    render::MeshBVHData geoBVHData = {};
+    render::MaterialData materialData = {};
+    // 6 floats per object id (min xyz, max xyz), host memory; empty: taken from
+    // geoBVHData
     Span<const float> objectRootAABBs = {};
     // the ray caster's outputs are renderResolution x renderResolution
     uint32_t renderResolution = 0;
@@ -140,7 +166,25 @@ public:
         : exec_(nullptr), num_taskgraphs_(state_cfg.numTaskGraphs)
     {
         mwhip_state_config cfg {};
+        mwhip_render_geometry geometry {};
         if (render_cfg.has_value()) {
+            const render::MeshBVHData &geo = render_cfg->geoBVHData;
+            if (geo.objectTriangleOffsets.size() > 1) {
+                geometry.num_objects =
+                    (uint32_t)geo.objectTriangleOffsets.size() - 1u;
+                geometry.vertices = (const float *)geo.vertices.data();
+                geometry.indices = geo.indices.data();
+                geometry.object_vertex_offset = geo.objectVertexOffsets.data();
+                geometry.object_triangle_offset =
+                    geo.objectTriangleOffsets.data();
+                const render::MaterialData &mats = render_cfg->materialData;
+                geometry.num_materials = (uint32_t)mats.materialColors.size();
+                geometry.material_color =
+                    (const float *)mats.materialColors.data();
+                geometry.object_material = mats.objectMaterials.size() != 0 ?
+                    mats.objectMaterials.data() : nullptr;
+                cfg.render_geometry = &geometry;
+            }
             cfg.raycast_output_resolution = render_cfg->renderResolution;
             cfg.raycast_rgbd = render_cfg->renderMode ==
                 CudaBatchRenderConfig::RenderMode::RGBD ? 1u : 0u;
@@ -220,6 +264,16 @@ public:
         for (uint32_t i = 0; i < num_taskgraphs_; i++) ids[i] = i;
         return buildLaunchGraph(
             Span<const uint32_t>(ids.data(), (CountT)ids.size()));
+    }
+
+    // TLAS build + ray cast of every view into the RaycastOutputArchetype
+    // columns (reference mw_gpu.hpp:150, cuda_exec.cpp:2527-2700); run it after
+    // the step graph
+    MWCudaLaunchGraph buildRenderGraph()
+    {
+        uint64_t graph = 0;
+        req(mwhip_build_render_graph(exec_, &graph), "buildRenderGraph");
+        return MWCudaLaunchGraph(exec_, graph);
     }
 
     // synchronous (reference cuda_exec.cpp:2756-2794)

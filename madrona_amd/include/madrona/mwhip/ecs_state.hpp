@@ -55,6 +55,7 @@ enum ErrorFlags : uint32_t {
     kErrSortLookback = 1u << 4,
     kErrPersistOverflow = 1u << 5,
     kErrPhysics = 1u << 6,
+    kErrRender = 1u << 7,
 };
 
 struct TableHdr {

@@ -97,6 +97,28 @@ public:
         return state_mgr_->renderConfig(1) != 0;
     }
 
+    // tells the executor's ray caster where its inputs and outputs live (the
+    // reference hands pointers to its BVH kernels in BVHParams,
+    // src/mw/cuda_exec.cpp)
+    template <typename RenderableT, typename CameraT, typename LightT,
+              typename OutputT, typename InstanceC, typename MortonC,
+              typename LeafC, typename CameraC, typename LightC, typename RGBC,
+              typename DepthC>
+    MADRONA_HOST_API void setRenderLayout()
+    {
+        const uint32_t archetypes[4] = {
+            TypeTracker::typeID<RenderableT>(), TypeTracker::typeID<CameraT>(),
+            TypeTracker::typeID<LightT>(), TypeTracker::typeID<OutputT>(),
+        };
+        const uint32_t components[7] = {
+            TypeTracker::typeID<InstanceC>(), TypeTracker::typeID<MortonC>(),
+            TypeTracker::typeID<LeafC>(), TypeTracker::typeID<CameraC>(),
+            TypeTracker::typeID<LightC>(), TypeTracker::typeID<RGBC>(),
+            TypeTracker::typeID<DepthC>(),
+        };
+        state_mgr_->setRenderLayout(archetypes, components);
+    }
+
 private:
     StateManager *state_mgr_;
     void **export_ptrs_;

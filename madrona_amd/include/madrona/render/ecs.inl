@@ -220,6 +220,11 @@ MADRONA_HOST_API inline void registerTypes(ECSRegistry &registry,
     registry.registerArchetype<RenderableArchetype>();
 
     registry.registerSingleton<RenderingSystemState>();
+
+    registry.setRenderLayout<RenderableArchetype, RenderCameraArchetype,
+        LightArchetype, RaycastOutputArchetype, InstanceData, MortonCode,
+        TLBVHNode, PerspectiveCameraData, LightDesc, RGBOutputBuffer,
+        DepthOutputBuffer>();
 }
 
 MADRONA_HOST_API inline TaskGraphNodeID setupTasks(

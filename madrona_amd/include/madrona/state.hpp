@@ -59,6 +59,11 @@ public:
     MADRONA_HOST_API ComponentID registerComponent(uint32_t num_bytes = 0);
     // host: which = 0 ray caster resolution, 1 RGBD flag
     MADRONA_HOST_API inline uint32_t renderConfig(int which) const;
+    // host: the tables / components of the batch ray caster, by type id
+    // (archetypes: renderable, camera, light, output; components: instance,
+    // Morton code, TLBVH leaf, camera, light, RGB, depth)
+    MADRONA_HOST_API inline void setRenderLayout(const uint32_t (&archetypes)[4],
+                                                 const uint32_t (&components)[7]);
 
     template <typename ArchetypeT, typename... MetadataComponentTs>
     MADRONA_HOST_API ArchetypeID registerArchetype(

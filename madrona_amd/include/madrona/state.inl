@@ -123,6 +123,30 @@ MADRONA_HOST_API inline uint32_t StateManager::renderConfig(int which) const
 #endif
 }
 
+MADRONA_HOST_API inline void StateManager::setRenderLayout(
+    const uint32_t (&archetypes)[4], const uint32_t (&components)[7])
+{
+#if MADRONA_ON_HOST
+    mwhip_render_layout layout {};
+    layout.renderable_archetype = archetypes[0];
+    layout.camera_archetype = archetypes[1];
+    layout.light_archetype = archetypes[2];
+    layout.output_archetype = archetypes[3];
+    layout.instance_component = components[0];
+    layout.morton_component = components[1];
+    layout.tlbvh_component = components[2];
+    layout.camera_component = components[3];
+    layout.light_component = components[4];
+    layout.rgb_component = components[5];
+    layout.depth_component = components[6];
+    mwhip::check(mwhip_set_render_layout(exec(), &layout), "setRenderLayout");
+#else
+    (void)archetypes;
+    (void)components;
+    MADRONA_DEVICE_STUB();
+#endif
+}
+
 template <typename SingletonT>
 MADRONA_HOST_API void StateManager::registerSingleton()
 {

@@ -88,6 +88,10 @@ def _bind(lib: C.CDLL) -> None:
     lib.sim_column_dump_raw.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64]
     lib.sim_hip_exec.restype = C.c_void_p
     lib.sim_hip_exec.argtypes = [C.c_void_p]
+    lib.sim_hip_render.restype = C.c_int
+    lib.sim_hip_render.argtypes = [C.c_void_p]
+    lib.sim_hip_render_graph.restype = C.c_uint64
+    lib.sim_hip_render_graph.argtypes = [C.c_void_p]
     lib.sim_hip_step_graph.restype = C.c_uint64
     lib.sim_hip_step_graph.argtypes = [C.c_void_p]
 
@@ -247,6 +251,18 @@ class Simulator:
         rc = self.lib.sim_hip_run_taskgraph(self.handle, taskgraph_id)
         if rc != 0:
             raise RuntimeError(f"sim_hip_run_taskgraph({taskgraph_id}) -> {rc}")
+
+    def render(self) -> None:
+        """MWCudaExecutor::buildRenderGraph + run: TLAS build and ray cast of every
+        view into the simulator's "rgb" / "depth" tensors (HIP backend)."""
+        rc = self.lib.sim_hip_render(self.handle)
+        if rc != 0:
+            raise RuntimeError(f"sim_hip_render -> {rc}: "
+                               f"{runtime_lib().mwhip_last_error().decode()}")
+
+    def render_graph(self) -> int:
+        """Launch-graph handle of the render pass (for step_async(graph=...))."""
+        return int(self.lib.sim_hip_render_graph(self.handle))
 
     def dump_column_raw(self, idx: int, max_rows: int):
         """Column `idx` in table order, destroyed rows included (HIP backend)."""

@@ -154,6 +154,7 @@ struct SimHandle {
     madrona::MWCudaExecutor *exec;
     madrona::MWCudaLaunchGraph *stepGraph;
     std::vector<madrona::MWCudaLaunchGraph *> probeGraphs;
+    madrona::MWCudaLaunchGraph *renderGraph;
 #endif
 };
 
@@ -218,6 +219,7 @@ void sim_destroy(SimHandle *h)
 #ifndef SIM_BACKEND_REF_CPU
     delete h->stepGraph;
     for (auto *g : h->probeGraphs) delete g;
+    delete h->renderGraph;
 #endif
     delete h->exec;
     delete h;
@@ -362,6 +364,32 @@ int sim_hip_run_taskgraph(SimHandle *h, uint32_t taskgraph_id)
             h->exec->buildLaunchGraph(taskgraph_id));
     }
     h->exec->run(*h->probeGraphs[taskgraph_id]);
+    return 0;
+#endif
+}
+
+uint64_t sim_hip_render_graph(SimHandle *h)
+{
+#ifdef SIM_BACKEND_REF_CPU
+    (void)h;
+    return 0;
+#else
+    if (h->renderGraph == nullptr) {
+        h->renderGraph =
+            new madrona::MWCudaLaunchGraph(h->exec->buildRenderGraph());
+    }
+    return h->renderGraph->handle();
+#endif
+}
+
+int sim_hip_render(SimHandle *h)
+{
+#ifdef SIM_BACKEND_REF_CPU
+    (void)h;
+    return -1;
+#else
+    (void)sim_hip_render_graph(h);
+    h->exec->run(*h->renderGraph);
     return 0;
 #endif
 }

@@ -72,6 +72,13 @@ SIM_API int sim_hip_run_taskgraph(SimHandle *h, uint32_t taskgraph_id);
 SIM_API int64_t sim_column_dump_raw(SimHandle *h, uint32_t idx, void *dst,
                                     uint64_t dst_bytes);
 
+/* HIP backend only: the batch ray caster's pass (MWCudaExecutor::
+ * buildRenderGraph) over the tables as the last step left them; outputs land in
+ * the simulator's "rgb" / "depth" tensors.  sim_hip_render runs it and waits;
+ * sim_hip_render_graph returns its launch-graph handle (0 on the reference). */
+SIM_API int sim_hip_render(SimHandle *h);
+SIM_API uint64_t sim_hip_render_graph(SimHandle *h);
+
 /* HIP backend only (NULL/0 on the reference): opaque mwhip_exec* for profiling */
 SIM_API void *sim_hip_exec(SimHandle *h);
 /* launch-graph handle of the per-step graph inside that executor (0 on the reference) */

@@ -24,6 +24,12 @@ void Sim::registerTypes(ECSRegistry &registry, const Config &cfg)
     registry.registerArchetype<Lamp>();
 
     registry.exportSingleton<RosterCounts>((uint32_t)ExportID::Roster);
+#ifdef MADRONA_GPU_MODE
+    registry.exportColumn<RaycastOutputArchetype, RGBOutputBuffer>(
+        (uint32_t)ExportID::RGB);
+    registry.exportColumn<RaycastOutputArchetype, DepthOutputBuffer>(
+        (uint32_t)ExportID::Depth);
+#endif
 }
 
 static inline float randInRange(RNG &rng, float lo, float hi)
@@ -200,6 +206,20 @@ Sim::Sim(Engine &ctx, const Config &cfg, const WorldInit &)
     ctx.get<LightDescIntensity>(lamp).intensity = 1.f;
     ctx.get<LightDescActive>(lamp).active = true;
     RenderingSystem::makeEntityLightCarrier(ctx, lamp);
+
+    sun = Entity::none();
+    if (global_world % 3u == 0u) {
+        sun = ctx.makeEntity<Lamp>();
+        ctx.get<Position>(sun) = Vector3 { 0.f, 0.f, 50.f };
+        ctx.get<LightDescDirection>(sun) =
+            LightDescDirection(Vector3 { -0.5f, 0.25f, -0.75f });
+        ctx.get<LightDescType>(sun).type = LightDesc::Directional;
+        ctx.get<LightDescShadow>(sun).castShadow = global_world % 2u == 1u;
+        ctx.get<LightDescCutoffAngle>(sun).cutoff = -1.f;
+        ctx.get<LightDescIntensity>(sun).intensity = 1.f;
+        ctx.get<LightDescActive>(sun).active = true;
+        RenderingSystem::makeEntityLightCarrier(ctx, sun);
+    }
 
     rng = init_rng;
 }

@@ -33,6 +33,10 @@ inline constexpr float arena = 12.f;
 
 enum class ExportID : uint32_t {
     Roster,
+    // ray caster outputs, one row per view (HIP backend; the reference's CPU
+    // mode has no ray caster)
+    RGB,
+    Depth,
     NumExports,
 };
 
@@ -100,6 +104,7 @@ struct Sim : public madrona::WorldBase {
     RNG rng;
     Entity viewers[consts::numViewers];
     Entity lamp;
+    Entity sun;     // every third world: a second, directional light
     uint32_t step;
 };
 

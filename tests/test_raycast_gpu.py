@@ -1,0 +1,132 @@
+"""GPU: the batch ray caster (BASELINE config 5; reference
+src/mw/device/bvh_raycast.cpp) -- MWCudaExecutor::buildRenderGraph on
+sims/render_prep: one-wavefront-per-world TLAS build + tiled ray cast into the
+RaycastOutputArchetype columns.
+
+Oracle: the reference's ray caster ITSELF (bvhRaycastEntry and everything under
+it), compiled for the host by oracle/ref_shims/raycast_ref_shim.cpp and fed the
+instance / view / light rows of the HIP backend's own tables plus the meshes the
+simulator handed to the executor.  The two walk different acceleration
+structures (the reference: 4-wide quantised nodes; here: binary fp32 nodes), so
+the ORDER in which instances are entered differs, and each entered instance
+moves t_max by an ulp (t_max * t_scale / t_scale): depth agrees to 1e-5
+relative (BASELINE north_star), colours to one 8-bit step, and the rare pixel
+whose ray grazes a triangle edge may resolve to the other side."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from madrona_amd.simlib import Simulator, hip_lib_path
+from raycast_utils import (Geometry, INSTANCE_DT, LIGHT_DT, REF_LIB, VIEW_DT, cube_geometry,
+                           ref_render)
+
+pytestmark = pytest.mark.gpu
+
+
+def _sim_geometry(sim):
+    """The meshes / materials sims/render_prep/mgr.cpp gave the executor."""
+    f = sim.lib.render_prep_geometry
+    f.restype = C.c_int32
+    f.argtypes = [C.c_void_p] * 7
+    counts = np.zeros(3, np.uint32)
+    n_obj = f(None, None, None, None, None, None, counts.ctypes.data)
+    verts = np.zeros((counts[0], 3), np.float32)
+    idx = np.zeros((counts[1], 3), np.uint32)
+    voff = np.zeros(n_obj + 1, np.uint32)
+    toff = np.zeros(n_obj + 1, np.uint32)
+    mats = np.zeros((counts[2], 3), np.float32)
+    omat = np.zeros(n_obj, np.int32)
+    f(verts.ctypes.data, idx.ctypes.data, voff.ctypes.data, toff.ctypes.data,
+      mats.ctypes.data, omat.ctypes.data, None)
+    return Geometry(verts, idx, voff, toff, omat, mats)
+
+
+def _offsets(counts):
+    return np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.int32)
+
+
+def _compare(hip_rgb, hip_depth, ref_rgb, ref_depth, rgbd, what):
+    assert hip_depth.shape == ref_depth.shape
+    hit_h, hit_r = hip_depth > 0, ref_depth > 0
+    total = hit_r.size
+    flipped = int((hit_h != hit_r).sum())
+    both = hit_h & hit_r
+    rel = np.abs(hip_depth[both] - ref_depth[both]) / ref_depth[both]
+    far = int((rel > 1e-5).sum())       # tolerance of BASELINE north_star
+    # (edge-grazing rays: the other triangle / the background wins)
+    assert flipped + far <= max(2, total // 2000), (what, flipped, far, total,
+                                                    float(rel.max()) if rel.size else 0)
+    assert hit_r.mean() > 0.05, (what, "the scene is not in view")
+    if rgbd:
+        same = both & (rel.reshape(-1)[np.cumsum(both.ravel()) - 1].reshape(both.shape) <= 1e-5
+                       if rel.size else both)
+        diff = np.abs(hip_rgb.astype(np.int32) - ref_rgb.astype(np.int32))
+        assert (hip_rgb[..., 3] == 255).all()
+        # misses are black on both sides
+        assert (hip_rgb[~hit_h][:, :3] == 0).all()
+        off = int((diff[same][:, :3].max(-1) > 1).sum())
+        # (a shadow ray or the spot cone's edge may go the other way for a pixel)
+        assert off <= max(2, total // 500), (what, off, total)
+        assert hip_rgb[same][:, :3].max() > 60, (what, "nothing is lit")
+
+
+@pytest.mark.parametrize("worlds,res,steps,flags", [
+    (1, 32, 3, 1), (37, 32, 12, 1), (64, 64, 5, 1), (300, 16, 8, 0), (33, 48, 6, 1 | 2)])
+def test_raycast_against_reference(built, worlds, res, steps, flags):
+    if not os.path.exists(REF_LIB):
+        pytest.skip("oracle/_ref/libraycast_ref.so missing on this box")
+    rgbd = (flags & 2) == 0
+    with Simulator(hip_lib_path("render_prep"), worlds, seed=11,
+                   flags=flags | (res << 8)) as hip:
+        geo = _sim_geometry(hip)
+        for step in range(steps):
+            hip.step(1)
+            if step not in (0, steps // 2, steps - 1):
+                continue
+            hip.render()
+            d = hip.dump_all()
+            inst, inst_counts = d["Renderable.InstanceData"]
+            views, view_counts = d["Camera.PerspectiveCameraData"]
+            lights, light_counts = d["Light.LightDesc"]
+            assert (view_counts == 2).all() and (inst_counts > 0).all()
+            ref_rgb, ref_depth = ref_render(
+                geo, worlds, inst, _offsets(inst_counts), inst_counts, views, lights,
+                _offsets(light_counts), light_counts, res, rgbd=rgbd,
+                threads=min(32, os.cpu_count() or 1))
+            hip_depth = hip.read_tensor("depth")
+            hip_rgb = hip.read_tensor("rgb") if rgbd else None
+            _compare(hip_rgb, hip_depth, ref_rgb, ref_depth, rgbd, (worlds, res, step))
+
+
+def test_raycast_is_repeatable_and_follows_the_tables(built):
+    """Rendering twice without stepping gives identical bytes; stepping changes
+    the image; outputs are in output-slot order (view row v -> tensor row v)."""
+    worlds, res = 16, 32
+    with Simulator(hip_lib_path("render_prep"), worlds, seed=2, flags=1 | (res << 8)) as hip:
+        hip.step(3)
+        hip.render()
+        a_rgb, a_depth = hip.read_tensor("rgb").copy(), hip.read_tensor("depth").copy()
+        hip.render()
+        assert np.array_equal(a_rgb, hip.read_tensor("rgb"))
+        assert np.array_equal(a_depth.view(np.uint32), hip.read_tensor("depth").view(np.uint32))
+        hip.step(5)
+        hip.render()
+        assert not np.array_equal(a_depth, hip.read_tensor("depth"))
+        assert a_depth.shape == (2 * worlds, res, res) and a_rgb.shape == (2 * worlds, res, res, 4)
+
+
+def test_render_graph_needs_a_render_configuration(built):
+    """mwhip_build_render_graph on an executor created without the ray caster
+    reports an error (the C++ shim turns it into a fatal error, like the
+    reference's FATAL)."""
+    from madrona_amd.simlib import runtime_lib
+    rt = runtime_lib()
+    rt.mwhip_build_render_graph.restype = C.c_int
+    rt.mwhip_build_render_graph.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    with Simulator(hip_lib_path("render_prep"), 4, seed=2, flags=1) as hip:
+        hip.step(1)
+        out = C.c_uint64(0)
+        assert rt.mwhip_build_render_graph(hip.hip_exec(), C.byref(out)) != 0
+        assert b"render configuration" in rt.mwhip_last_error()
