@@ -36,7 +36,7 @@ pmc() {    # sim, worlds, bench args...
   for ctr in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/pmc_${sim}_${worlds}_$ctr
     timeout 600 rocprofv3 --kernel-trace --pmc $ctr -d /tmp/pmc_${sim}_${worlds}_$ctr -o out -- \
-        python $R/bench.py --sim $sim --worlds $worlds "$@" --steps 100 --warmup 20 \
+        python $R/bench.py --sim $sim --worlds $worlds "$@" --steps 100 --warmup 20 --settle 30 \
         --no-cpu-baseline --no-secondary > /dev/null 2> $O/pmc_${sim}_${worlds}_$ctr.err
     db=$(find /tmp/pmc_${sim}_${worlds}_$ctr -name '*.db' | head -1)
     python $R/profiles/summarize_pmc.py $db > $O/${ROUND}_pmc_${sim}_w${worlds}_$ctr.txt

@@ -13,6 +13,7 @@
 #pragma once
 
 #include "sim_c_api.h"
+#include "mesh_set.hpp"
 
 #include <cstdio>
 #include <cstdlib>
@@ -98,6 +99,17 @@ struct ColumnList {
 }
 
 namespace simmgr {
+// optional: the meshes the simulator gives the ray caster
+template <typename T>
+static const simmesh::MeshSet *renderMeshes()
+{
+    if constexpr (requires { T::renderMeshes(); }) {
+        return &T::renderMeshes();
+    } else {
+        return nullptr;
+    }
+}
+
 // optional hook of a simulator's traits, run before every step
 template <typename T>
 static void preStep()
@@ -366,6 +378,34 @@ int sim_hip_run_taskgraph(SimHandle *h, uint32_t taskgraph_id)
     h->exec->run(*h->probeGraphs[taskgraph_id]);
     return 0;
 #endif
+}
+
+int32_t sim_render_geometry(float *vertices, uint32_t *indices,
+                            uint32_t *vertex_offsets, uint32_t *triangle_offsets,
+                            float *material_colors, int32_t *object_materials,
+                            uint32_t *counts)
+{
+    const simmesh::MeshSet *m = simmgr::renderMeshes<SimTraits>();
+    if (m == nullptr) {
+        return 0;
+    }
+    auto copy = [](auto *dst, const auto &src) {
+        if (dst != nullptr && !src.empty()) {
+            memcpy(dst, src.data(), src.size() * sizeof(src[0]));
+        }
+    };
+    copy(vertices, m->vertices);
+    copy(indices, m->indices);
+    copy(vertex_offsets, m->vertexOffsets);
+    copy(triangle_offsets, m->triangleOffsets);
+    copy(material_colors, m->materialColors);
+    copy(object_materials, m->objectMaterials);
+    if (counts != nullptr) {
+        counts[0] = (uint32_t)(m->vertices.size() / 3);
+        counts[1] = (uint32_t)(m->indices.size() / 3);
+        counts[2] = (uint32_t)(m->materialColors.size() / 3);
+    }
+    return (int32_t)m->numObjects();
 }
 
 uint64_t sim_hip_render_graph(SimHandle *h)

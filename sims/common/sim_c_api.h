@@ -72,6 +72,16 @@ SIM_API int sim_hip_run_taskgraph(SimHandle *h, uint32_t taskgraph_id);
 SIM_API int64_t sim_column_dump_raw(SimHandle *h, uint32_t idx, void *dst,
                                     uint64_t dst_bytes);
 
+/* The meshes and materials the simulator hands to the batch ray caster (for the
+ * tests' oracle).  Any pointer may be NULL; returns the number of objects (0:
+ * the simulator draws nothing) and, through counts, { vertices, triangles,
+ * materials }. */
+SIM_API int32_t sim_render_geometry(float *vertices, uint32_t *indices,
+                                    uint32_t *vertex_offsets,
+                                    uint32_t *triangle_offsets,
+                                    float *material_colors,
+                                    int32_t *object_materials, uint32_t *counts);
+
 /* HIP backend only: the batch ray caster's pass (MWCudaExecutor::
  * buildRenderGraph) over the tables as the last step left them; outputs land in
  * the simulator's "rgb" / "depth" tensors.  sim_hip_render runs it and waits;

@@ -7,6 +7,12 @@
 
 struct SimTraits;
 #include "common/sim_c_api.h"
+#ifdef ESCPHYS_RENDER
+#include "common/mesh_set.hpp"
+#ifndef SIM_BACKEND_REF_CPU
+#include "common/render_config.hpp"
+#endif
+#endif
 
 #include <vector>
 #include <string>
@@ -123,6 +129,43 @@ ObjectManager *loadPhysicsObjects(const SimCreateArgs &args)
     return mgr;
 }
 
+#ifdef ESCPHYS_RENDER
+// What the ray caster draws for each SimObject: boxes for the cube-hull bodies
+// (instances scale them), a 352-triangle ellipsoid for the agents, a quad for
+// the floor.
+const simmesh::MeshSet &meshes()
+{
+    static const simmesh::MeshSet set = [] {
+        simmesh::MeshSet m;
+        const int32_t cube = m.material(0.8f, 0.45f, 0.2f);
+        const int32_t wall = m.material(0.55f, 0.55f, 0.6f);
+        const int32_t door = m.material(0.2f, 0.6f, 0.25f);
+        const int32_t agent = m.material(0.9f, 0.85f, 0.2f);
+        const int32_t button = m.material(0.85f, 0.15f, 0.15f);
+        const int32_t floor = m.material(0.35f, 0.3f, 0.28f);
+        const int32_t mats[] = { cube, wall, door, agent, button, floor };
+        for (int32_t obj = 0; obj < (int32_t)SimObject::NumObjects; obj++) {
+            if (obj == (int32_t)SimObject::Agent) {
+                m.ellipsoid(0.f, 0.f, 0.f, 0.5f, 0.5f, 0.5f, 16, 12);
+            } else if (obj == (int32_t)SimObject::Plane) {
+                const uint32_t a = m.vert(-40.f, -20.f, 0.f);
+                m.vert(40.f, -20.f, 0.f);
+                m.vert(40.f, 60.f, 0.f);
+                m.vert(-40.f, 60.f, 0.f);
+                m.quad(a, a + 1, a + 2, a + 3);
+            } else {
+                m.box(-0.5f, -0.5f, -0.5f, 0.5f, 0.5f, 0.5f);
+            }
+            m.endObject(mats[obj]);
+        }
+        return m;
+    }();
+    return set;
+}
+
+uint32_t g_resolution = 0;
+#endif
+
 }
 
 struct SimTraits {
@@ -133,14 +176,39 @@ struct SimTraits {
         (uint32_t)escphys::ExportID::NumExports;
     static constexpr uint32_t numTaskGraphs = 1;
 
-    // flags: low 16 bits = autoResetDenom (0 disables random resets)
+    // flags: low 16 bits = autoResetDenom (0 disables random resets); render
+    // variant: bits 16-23 = output resolution (0: 64), bit 24 = depth only,
+    // bit 25 = the sun casts shadows
     static Sim::Config makeConfig(const SimCreateArgs &args)
     {
         return Sim::Config {
             args.seed, args.world_base, args.flags & 0xFFFFu,
             loadPhysicsObjects(args),
+#ifdef ESCPHYS_RENDER
+            (args.flags >> 25) & 1u,
+#endif
         };
     }
+
+#ifdef ESCPHYS_RENDER
+    static const simmesh::MeshSet &renderMeshes() { return meshes(); }
+
+#ifndef SIM_BACKEND_REF_CPU
+    static madrona::Optional<madrona::CudaBatchRenderConfig> renderConfig(
+        const SimCreateArgs &args)
+    {
+        madrona::CudaBatchRenderConfig cfg {};
+        cfg.renderMode = (args.flags >> 24) & 1u ?
+            madrona::CudaBatchRenderConfig::RenderMode::Depth :
+            madrona::CudaBatchRenderConfig::RenderMode::RGBD;
+        cfg.renderResolution = (args.flags >> 16) & 0xFFu;
+        if (cfg.renderResolution == 0) cfg.renderResolution = 64;
+        g_resolution = cfg.renderResolution;
+        simmgr::meshesToRenderConfig(meshes(), cfg);
+        return madrona::Optional<madrona::CudaBatchRenderConfig>::make(cfg);
+    }
+#endif
+#endif
 
     static void makeInits(const SimCreateArgs &, Sim::WorldInit *) {}
 
@@ -176,6 +244,11 @@ void SimTraits::describeTensors(T &out, uint32_t num_worlds)
                     (uint32_t)ExportID::Lidar });
     out.push_back({ "steps_remaining", SIM_I32, { W, A, 1 },
                     (uint32_t)ExportID::StepsRemaining });
+#if defined(ESCPHYS_RENDER) && !defined(SIM_BACKEND_REF_CPU)
+    const int64_t R = g_resolution;
+    out.push_back({ "rgb", SIM_U8, { W * A, R, R, 4 }, (uint32_t)ExportID::RGB });
+    out.push_back({ "depth", SIM_F32, { W * A, R, R }, (uint32_t)ExportID::Depth });
+#endif
 }
 
 template <typename T>
@@ -219,4 +292,10 @@ void SimTraits::describeColumns(T &cols)
     cols.template add<ButtonEntity, Entity>("ButtonEntity.Entity", false);
     cols.template add<ButtonEntity, Position>("ButtonEntity.Position", true);
     cols.template add<ButtonEntity, ButtonState>("ButtonEntity.ButtonState", false);
+#if defined(ESCPHYS_RENDER) && !defined(SIM_BACKEND_REF_CPU)
+    using namespace madrona::render;
+    cols.template add<RenderableArchetype, InstanceData>("Renderable.InstanceData", false);
+    cols.template add<RenderCameraArchetype, PerspectiveCameraData>("Camera.PerspectiveCameraData", false);
+    cols.template add<LightArchetype, LightDesc>("Light.LightDesc", false);
+#endif
 }

@@ -8,6 +8,13 @@ using namespace madrona;
 using namespace madrona::math;
 using namespace madrona::phys;
 
+#ifdef ESCPHYS_RENDER
+namespace RenderingSystem = madrona::render::RenderingSystem;
+#define ESCPHYS_IF_RENDER(...) __VA_ARGS__
+#else
+#define ESCPHYS_IF_RENDER(...)
+#endif
+
 namespace escphys {
 
 // cos / sin of k * 2pi / 8 and of k * 2pi / 30 as literals: libm results differ
@@ -40,6 +47,7 @@ void Sim::registerTypes(ECSRegistry &registry, const Config &)
 {
     base::registerTypes(registry);
     PhysicsSystem::registerTypes(registry);
+    ESCPHYS_IF_RENDER(RenderingSystem::registerTypes(registry, nullptr);)
 
     registry.registerComponent<Action>();
     registry.registerComponent<Reward>();
@@ -65,6 +73,13 @@ void Sim::registerTypes(ECSRegistry &registry, const Config &)
     registry.registerArchetype<PhysicsEntity>();
     registry.registerArchetype<DoorEntity>();
     registry.registerArchetype<ButtonEntity>();
+#ifdef ESCPHYS_RENDER
+    registry.registerArchetype<SunEntity>();
+    registry.exportColumn<render::RaycastOutputArchetype, render::RGBOutputBuffer>(
+        (uint32_t)ExportID::RGB);
+    registry.exportColumn<render::RaycastOutputArchetype, render::DepthOutputBuffer>(
+        (uint32_t)ExportID::Depth);
+#endif
 
     registry.exportSingleton<WorldReset>((uint32_t)ExportID::Reset);
     registry.exportColumn<Agent, Action>((uint32_t)ExportID::Action);
@@ -109,6 +124,7 @@ static inline void setupRigidBody(Engine &ctx, Entity e, Vector3 pos, Quat rot,
     ctx.get<broadphase::LeafID>(e) =
         PhysicsSystem::registerEntity(ctx, e, obj_id);
     ctx.get<EntityType>(e) = type;
+    ESCPHYS_IF_RENDER(RenderingSystem::makeEntityRenderable(ctx, e);)
 }
 
 static inline void registerRigidBodyEntity(Engine &ctx, Entity e)
@@ -154,6 +170,7 @@ static void generateLevel(Engine &ctx, RNG &rng)
             ctx.get<ObjectID>(button) = ObjectID { (int32_t)SimObject::Button };
             ctx.get<ButtonState>(button).isPressed = 0;
             ctx.get<EntityType>(button) = EntityType::Button;
+            ESCPHYS_IF_RENDER(RenderingSystem::makeEntityRenderable(ctx, button);)
             room.buttons[b] = button;
         }
 
@@ -282,6 +299,9 @@ static void createPersistentEntities(Engine &ctx)
         setupRigidBody(ctx, agent, Vector3 { 0, 0, 1.f }, Quat { 1, 0, 0, 0 },
             SimObject::Agent, EntityType::Agent, ResponseType::Dynamic,
             Diag3x3 { 1.5f, 1.5f, 2.f });
+        // (the reference Escape Room's camera: 100 degrees, at head height)
+        ESCPHYS_IF_RENDER(RenderingSystem::attachEntityToView(ctx, agent, 100.f,
+            0.001f, 1.5f * math::up);)
     }
 
     for (int32_t i = 0; i < consts::numAgents; i++) {
@@ -327,6 +347,18 @@ static void cleanupWorld(Engine &ctx)
     LevelState &level = ctx.singleton<LevelState>();
     for (int32_t r = 0; r < consts::numRooms; r++) {
         Room &room = level.rooms[r];
+#ifdef ESCPHYS_RENDER
+        // (render entities go first, as the API asks)
+        for (int32_t c = 0; c < consts::numCubesPerRoom; c++) {
+            RenderingSystem::cleanupRenderableEntity(ctx, room.cubes[c]);
+        }
+        RenderingSystem::cleanupRenderableEntity(ctx, room.walls[0]);
+        RenderingSystem::cleanupRenderableEntity(ctx, room.walls[1]);
+        RenderingSystem::cleanupRenderableEntity(ctx, room.door);
+        for (int32_t b = 0; b < consts::numButtonsPerRoom; b++) {
+            RenderingSystem::cleanupRenderableEntity(ctx, room.buttons[b]);
+        }
+#endif
         for (int32_t c = 0; c < consts::numCubesPerRoom; c++) {
             ctx.destroyEntity(room.cubes[c]);
         }
@@ -779,6 +811,11 @@ void Sim::setupTasks(TaskGraphManager &taskgraph_mgr, const Config &)
         >>({collect_obs});
 
     (void)lidar;
+
+#ifdef ESCPHYS_RENDER
+    // instance / view records, Morton order, world grouping for the ray caster
+    RenderingSystem::setupTasks(builder, {lidar}, false);
+#endif
 }
 
 Sim::Sim(Engine &ctx, const Config &cfg, const WorldInit &)
@@ -797,8 +834,25 @@ Sim::Sim(Engine &ctx, const Config &cfg, const WorldInit &)
         consts::numPhysicsSubsteps, -9.8f * math::up,
         consts::maxRigidBodies);
 
+#ifdef ESCPHYS_RENDER
+    RenderingSystem::init(ctx, nullptr);
+#endif
+
     createPersistentEntities(ctx);
     initWorld(ctx);
+
+#ifdef ESCPHYS_RENDER
+    Entity sun = ctx.makeEntity<SunEntity>();
+    ctx.get<Position>(sun) = Vector3 { 0.f, 0.f, 30.f };
+    ctx.get<render::LightDescDirection>(sun) = render::LightDescDirection(
+        Vector3 { 0.3713907f, 0.5570860f, -0.7427814f });
+    ctx.get<render::LightDescType>(sun).type = render::LightDesc::Directional;
+    ctx.get<render::LightDescShadow>(sun).castShadow = cfg.sunCastsShadows != 0u;
+    ctx.get<render::LightDescCutoffAngle>(sun).cutoff = -1.f;
+    ctx.get<render::LightDescIntensity>(sun).intensity = 1.f;
+    ctx.get<render::LightDescActive>(sun).active = true;
+    RenderingSystem::makeEntityLightCarrier(ctx, sun);
+#endif
 }
 
 #ifdef MADRONA_GPU_MODE

@@ -16,6 +16,18 @@
 #include <madrona/rand.hpp>
 #include <madrona/physics.hpp>
 
+// BASELINE config 5 = this simulator + the batch ray caster: the variant in
+// sims/escape_room_render compiles these sources with ESCPHYS_RENDER defined
+// (every body drawable, a camera on each agent, 64 x 64 RGB-D per agent).
+#ifdef ESCPHYS_RENDER
+#include <madrona/render/ecs.hpp>
+#define ESCPHYS_DRAWABLE , madrona::render::Renderable
+#define ESCPHYS_VIEWER , madrona::render::RenderCamera
+#else
+#define ESCPHYS_DRAWABLE
+#define ESCPHYS_VIEWER
+#endif
+
 namespace escphys {
 
 using madrona::Entity;
@@ -72,6 +84,10 @@ enum class ExportID : uint32_t {
     DoorObservation,
     Lidar,
     StepsRemaining,
+#ifdef ESCPHYS_RENDER
+    RGB,
+    Depth,
+#endif
     NumExports,
 };
 
@@ -216,11 +232,14 @@ struct Agent : public madrona::Archetype<
     OtherAgents,
     GrabState,
     EntityType
+    ESCPHYS_DRAWABLE
+    ESCPHYS_VIEWER
 > {};
 
 struct PhysicsEntity : public madrona::Archetype<
     RigidBody,
     EntityType
+    ESCPHYS_DRAWABLE
 > {};
 
 struct DoorEntity : public madrona::Archetype<
@@ -228,13 +247,29 @@ struct DoorEntity : public madrona::Archetype<
     OpenState,
     DoorProperties,
     EntityType
+    ESCPHYS_DRAWABLE
 > {};
 
 struct ButtonEntity : public madrona::Archetype<
     madrona::base::ObjectInstance,
     ButtonState,
     EntityType
+    ESCPHYS_DRAWABLE
 > {};
+
+#ifdef ESCPHYS_RENDER
+// the world's one light
+struct SunEntity : public madrona::Archetype<
+    Position,
+    madrona::render::LightDescDirection,
+    madrona::render::LightDescType,
+    madrona::render::LightDescShadow,
+    madrona::render::LightDescCutoffAngle,
+    madrona::render::LightDescIntensity,
+    madrona::render::LightDescActive,
+    madrona::render::LightCarrier
+> {};
+#endif
 
 class Engine;
 
@@ -246,6 +281,9 @@ struct Sim : public madrona::WorldBase {
         // (0 disables) in addition to episode timeouts / external resets
         uint32_t autoResetDenom;
         madrona::phys::ObjectManager *rigidBodyObjMgr;
+#ifdef ESCPHYS_RENDER
+        uint32_t sunCastsShadows;
+#endif
     };
 
     struct WorldInit {};

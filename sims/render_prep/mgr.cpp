@@ -2,13 +2,14 @@
 
 struct SimTraits;
 #include "common/sim_c_api.h"
+#include "common/mesh_set.hpp"
 
 #include <cmath>
 #include <cstring>
 #include <vector>
 
 #ifndef SIM_BACKEND_REF_CPU
-#include <madrona/mw_gpu.hpp>
+#include "common/render_config.hpp"
 #endif
 
 #ifdef SIM_BACKEND_REF_CPU
@@ -48,108 +49,33 @@ const float kRootAABBs[renderprep::consts::numObjects * 6] = {
 
 // Triangle meshes of the four "models", inside those boxes: a cube, an
 // ellipsoid (168 triangles: a bottom-level BVH several levels deep), a flat
-// cylinder and a wedge.  Materials: one per object, the wedge has none.
-struct Meshes {
-    std::vector<float> vertices;
-    std::vector<uint32_t> indices;
-    std::vector<uint32_t> vertexOffsets { 0 };
-    std::vector<uint32_t> triangleOffsets { 0 };
-    std::vector<float> materialColors;
-    std::vector<int32_t> objectMaterials;
-
-    uint32_t vert(float x, float y, float z)
-    {
-        vertices.insert(vertices.end(), { x, y, z });
-        return (uint32_t)(vertices.size() / 3) - vertexOffsets.back() - 1u;
-    }
-    void tri(uint32_t a, uint32_t b, uint32_t c)
-    {
-        indices.insert(indices.end(), { a, b, c });
-    }
-    void quad(uint32_t a, uint32_t b, uint32_t c, uint32_t d)
-    {
-        tri(a, b, c);
-        tri(a, c, d);
-    }
-    void endObject()
-    {
-        vertexOffsets.push_back((uint32_t)(vertices.size() / 3));
-        triangleOffsets.push_back((uint32_t)(indices.size() / 3));
-    }
-
-    Meshes()
-    {
-        // 0: cube
-        for (int i = 0; i < 8; i++) {
-            vert(i & 1 ? 0.5f : -0.5f, i & 2 ? 0.5f : -0.5f, i & 4 ? 0.5f : -0.5f);
-        }
-        quad(0, 2, 3, 1); quad(4, 5, 7, 6); quad(0, 1, 5, 4);
-        quad(2, 6, 7, 3); quad(0, 4, 6, 2); quad(1, 3, 7, 5);
-        endObject();
-
-        // 1: ellipsoid, centre (0, 0, 1), radii (1, 0.25, 1)
-        {
-            const int slices = 12, stacks = 8;
-            const uint32_t south = vert(0.f, 0.f, 0.f);
-            for (int st = 1; st < stacks; st++) {
-                const float phi = 3.14159265f * (float)st / (float)stacks;
-                for (int sl = 0; sl < slices; sl++) {
-                    const float th = 6.2831853f * (float)sl / (float)slices;
-                    vert(sinf(phi) * cosf(th), 0.25f * sinf(phi) * sinf(th),
-                         1.f - cosf(phi));
-                }
-            }
-            const uint32_t north = vert(0.f, 0.f, 2.f);
-            auto ring = [&](int st, int sl) {
-                return 1u + (uint32_t)((st - 1) * slices + sl % slices);
-            };
-            for (int sl = 0; sl < slices; sl++) {
-                tri(south, ring(1, sl + 1), ring(1, sl));
-                tri(north, ring(stacks - 1, sl), ring(stacks - 1, sl + 1));
-                for (int st = 1; st < stacks - 1; st++) {
-                    quad(ring(st, sl), ring(st, sl + 1), ring(st + 1, sl + 1),
-                         ring(st + 1, sl));
-                }
-            }
-        }
-        endObject();
-
-        // 2: cylinder, radius 0.75, z in [-0.1, 0.1]
-        {
-            const int segs = 16;
-            const uint32_t lo = vert(0.f, 0.f, -0.1f), hi = vert(0.f, 0.f, 0.1f);
-            for (int i = 0; i < segs; i++) {
-                const float th = 6.2831853f * (float)i / (float)segs;
-                vert(0.75f * cosf(th), 0.75f * sinf(th), -0.1f);
-                vert(0.75f * cosf(th), 0.75f * sinf(th), 0.1f);
-            }
-            for (int i = 0; i < segs; i++) {
-                const uint32_t a = 2u + 2u * (uint32_t)i;
-                const uint32_t b = 2u + 2u * (uint32_t)((i + 1) % segs);
-                tri(lo, b, a);
-                tri(hi, a + 1, b + 1);
-                quad(a, b, b + 1, a + 1);
-            }
-        }
-        endObject();
-
-        // 3: wedge in [0, 1.5] x [0, 1] x [0, 0.5]
-        vert(0.f, 0.f, 0.f); vert(1.5f, 0.f, 0.f); vert(0.f, 1.f, 0.f);
-        vert(1.5f, 1.f, 0.f); vert(0.f, 0.f, 0.5f); vert(0.f, 1.f, 0.5f);
-        quad(0, 2, 3, 1); quad(0, 4, 5, 2); quad(1, 3, 5, 4);
-        tri(0, 1, 4); tri(2, 5, 3);
-        endObject();
-
-        materialColors = { 0.8f, 0.2f, 0.2f,  0.2f, 0.7f, 0.3f,  0.25f, 0.35f, 0.9f,
-                           0.9f, 0.8f, 0.1f,  0.5f, 0.5f, 0.5f };
-        objectMaterials = { 0, 1, 2, -1 };
-    }
-};
-
-const Meshes &meshes()
+// cylinder and a wedge.  Materials: one per object, the wedge has none; a fifth
+// material is only ever reached through MaterialOverride.
+const simmesh::MeshSet &meshes()
 {
-    static const Meshes m;
-    return m;
+    static const simmesh::MeshSet set = [] {
+        simmesh::MeshSet m;
+        const int32_t red = m.material(0.8f, 0.2f, 0.2f);
+        const int32_t green = m.material(0.2f, 0.7f, 0.3f);
+        const int32_t blue = m.material(0.25f, 0.35f, 0.9f);
+        m.material(0.9f, 0.8f, 0.1f);
+        m.material(0.5f, 0.5f, 0.5f);
+
+        m.box(-0.5f, -0.5f, -0.5f, 0.5f, 0.5f, 0.5f);
+        m.endObject(red);
+        m.ellipsoid(0.f, 0.f, 1.f, 1.f, 0.25f, 1.f, 12, 8);
+        m.endObject(green);
+        m.cylinder(0.75f, -0.1f, 0.1f, 16);
+        m.endObject(blue);
+        // wedge in [0, 1.5] x [0, 1] x [0, 0.5]
+        m.vert(0.f, 0.f, 0.f); m.vert(1.5f, 0.f, 0.f); m.vert(0.f, 1.f, 0.f);
+        m.vert(1.5f, 1.f, 0.f); m.vert(0.f, 0.f, 0.5f); m.vert(0.f, 1.f, 0.5f);
+        m.quad(0, 2, 3, 1); m.quad(0, 4, 5, 2); m.quad(1, 3, 5, 4);
+        m.tri(0, 1, 4); m.tri(2, 5, 3);
+        m.endObject(-1);
+        return m;
+    }();
+    return set;
 }
 
 uint32_t g_resolution = 0;
@@ -197,6 +123,8 @@ struct SimTraits {
 
     static void makeInits(const SimCreateArgs &, Sim::WorldInit *) {}
 
+    static const simmesh::MeshSet &renderMeshes() { return meshes(); }
+
 #ifdef SIM_BACKEND_REF_CPU
     // the renderer zeroes the append counters before every step
     static void preStep()
@@ -217,22 +145,7 @@ struct SimTraits {
         if ((args.flags & 2u) != 0u) {
             cfg.renderMode = madrona::CudaBatchRenderConfig::RenderMode::Depth;
         }
-        const Meshes &m = meshes();
-        cfg.geoBVHData.vertices = madrona::Span<const madrona::math::Vector3>(
-            (const madrona::math::Vector3 *)m.vertices.data(),
-            (madrona::CountT)(m.vertices.size() / 3));
-        cfg.geoBVHData.indices = madrona::Span<const uint32_t>(
-            m.indices.data(), (madrona::CountT)m.indices.size());
-        cfg.geoBVHData.objectVertexOffsets = madrona::Span<const uint32_t>(
-            m.vertexOffsets.data(), (madrona::CountT)m.vertexOffsets.size());
-        cfg.geoBVHData.objectTriangleOffsets = madrona::Span<const uint32_t>(
-            m.triangleOffsets.data(), (madrona::CountT)m.triangleOffsets.size());
-        cfg.materialData.materialColors =
-            madrona::Span<const madrona::math::Vector3>(
-                (const madrona::math::Vector3 *)m.materialColors.data(),
-                (madrona::CountT)(m.materialColors.size() / 3));
-        cfg.materialData.objectMaterials = madrona::Span<const int32_t>(
-            m.objectMaterials.data(), (madrona::CountT)m.objectMaterials.size());
+        simmgr::meshesToRenderConfig(meshes(), cfg);
         return madrona::Optional<madrona::CudaBatchRenderConfig>::make(cfg);
     }
 #endif
@@ -293,42 +206,6 @@ void SimTraits::describeColumns(T &cols)
     cols.template add<RenderCameraArchetype, RenderOutputIndex>("Camera.RenderOutputIndex", false);
     cols.template add<RenderCameraArchetype, RenderOutputRef>("Camera.RenderOutputRef", false);
 #endif
-}
-
-// The meshes and materials the ray caster was given (for the test's brute-force
-// oracle).  Any pointer may be NULL; returns the number of objects and, through
-// counts, { vertices, triangles, materials }.
-extern "C" SIM_API int32_t render_prep_geometry(float *vertices, uint32_t *indices,
-                                                uint32_t *vertex_offsets,
-                                                uint32_t *triangle_offsets,
-                                                float *material_colors,
-                                                int32_t *object_materials,
-                                                uint32_t *counts)
-{
-    const Meshes &m = meshes();
-    if (vertices) memcpy(vertices, m.vertices.data(), m.vertices.size() * 4);
-    if (indices) memcpy(indices, m.indices.data(), m.indices.size() * 4);
-    if (vertex_offsets) {
-        memcpy(vertex_offsets, m.vertexOffsets.data(), m.vertexOffsets.size() * 4);
-    }
-    if (triangle_offsets) {
-        memcpy(triangle_offsets, m.triangleOffsets.data(),
-               m.triangleOffsets.size() * 4);
-    }
-    if (material_colors) {
-        memcpy(material_colors, m.materialColors.data(),
-               m.materialColors.size() * 4);
-    }
-    if (object_materials) {
-        memcpy(object_materials, m.objectMaterials.data(),
-               m.objectMaterials.size() * 4);
-    }
-    if (counts) {
-        counts[0] = (uint32_t)(m.vertices.size() / 3);
-        counts[1] = (uint32_t)(m.indices.size() / 3);
-        counts[2] = (uint32_t)(m.materialColors.size() / 3);
-    }
-    return renderprep::consts::numObjects;
 }
 
 // CPU mode: the records of the last step as the reference appended them to the

@@ -26,8 +26,8 @@ pytestmark = pytest.mark.gpu
 
 
 def _sim_geometry(sim):
-    """The meshes / materials sims/render_prep/mgr.cpp gave the executor."""
-    f = sim.lib.render_prep_geometry
+    """The meshes / materials the simulator's manager gave the executor."""
+    f = sim.lib.sim_render_geometry
     f.restype = C.c_int32
     f.argtypes = [C.c_void_p] * 7
     counts = np.zeros(3, np.uint32)
@@ -98,6 +98,38 @@ def test_raycast_against_reference(built, worlds, res, steps, flags):
             hip_depth = hip.read_tensor("depth")
             hip_rgb = hip.read_tensor("rgb") if rgbd else None
             _compare(hip_rgb, hip_depth, ref_rgb, ref_depth, rgbd, (worlds, res, step))
+
+
+@pytest.mark.parametrize("worlds,res,shadows", [(24, 64, 0), (150, 32, 1)])
+def test_escape_room_views_against_reference(built, worlds, res, shadows):
+    """BASELINE config 5's shape: the Escape Room with physics, every body drawn
+    (27 instances per world + the floor, resets churning the instance table), a
+    camera on each agent -- against the reference's ray caster on the same rows."""
+    if not os.path.exists(REF_LIB):
+        pytest.skip("oracle/_ref/libraycast_ref.so missing on this box")
+    flags = 40 | (res << 16) | (shadows << 25)      # a reset every ~40 steps per world
+    with Simulator(hip_lib_path("escape_room_render"), worlds, seed=4, flags=flags) as hip:
+        geo = _sim_geometry(hip)
+        rng = np.random.default_rng(0)
+        for step in range(24):
+            act = np.stack([rng.integers(0, 4, (worlds, 2)), rng.integers(0, 8, (worlds, 2)),
+                            rng.integers(-2, 3, (worlds, 2)), rng.integers(0, 2, (worlds, 2))],
+                           -1).astype(np.int32)
+            hip.write_tensor("action", act)
+            hip.step(1)
+            if step not in (0, 11, 23):
+                continue
+            hip.render()
+            d = hip.dump_all()
+            inst, inst_counts = d["Renderable.InstanceData"]
+            views, view_counts = d["Camera.PerspectiveCameraData"]
+            lights, light_counts = d["Light.LightDesc"]
+            assert (view_counts == 2).all() and (inst_counts == 36).all()
+            ref_rgb, ref_depth = ref_render(
+                geo, worlds, inst, _offsets(inst_counts), inst_counts, views, lights,
+                _offsets(light_counts), light_counts, res, threads=min(32, os.cpu_count() or 1))
+            _compare(hip.read_tensor("rgb"), hip.read_tensor("depth"), ref_rgb, ref_depth,
+                     True, ("escape_room", worlds, step))
 
 
 def test_raycast_is_repeatable_and_follows_the_tables(built):
