@@ -5,13 +5,14 @@
 // What is reproduced from the reference (src/mw/device/bvh_raycast.cpp): the
 // image.  Ray generation (:58-88), the object-space ray per instance with its
 // t rescaling (:627-646, :747-766), Woop's watertight ray / triangle test with
-// the same fmaf placement and the double-precision edge fallback (:318-438,
-// :228-270), closest hit, material / override colour (:772-812), the light loop
+// back-face culling, the same fmaf placement and the double-precision edge
+// fallback (:318-447, :228-270), closest hit, material / override colour (:772-812), the light loop
 // with spot cut-off and optional shadow rays (:840-930), pixel encoding
-// (:816-835), depth 0 / black on a miss.  Results agree with a brute-force
-// restatement (oracle/restate/raycast.c) to float rounding: the only freedom a
-// ray caster has is the ORDER in which it visits instances, and that moves
-// t_max by an ulp per visited instance (t_max * t_scale / t_scale).
+// (:816-835), depth 0 / black on a miss.  Results agree with the reference's
+// own code compiled for the host (oracle/ref_shims/raycast_ref_shim.cpp) to
+// float rounding: the only freedom a ray caster has is the ORDER in which it
+// visits instances, and that moves t_max by an ulp per visited instance
+// (t_max * t_scale / t_scale).
 //
 // What is not: the acceleration structures.  The reference builds 4-wide
 // quantised nodes with Embree on the host (BLAS) and a ~1000-line multi-kernel
@@ -279,8 +280,11 @@ __device__ inline RayIsect rayIsectInfo(const Vector3 &d, const Vector3 &inv_d)
     return r;
 }
 
-// watertight ray / triangle test, no back-face culling (reference
-// bvh_raycast.cpp:318-438: same fmaf placement, same fallback, same epsilons)
+// watertight ray / triangle test WITH back-face culling: the reference compiles
+// its test with MADRONA_MESHBVH_BACKFACE_CULLING (defined by mesh_bvh.inl:3,
+// which bvh_raycast.cpp includes), i.e. bvh_raycast.cpp:318-447 with the
+// culling branches -- same fmaf placement, same double-precision edge fallback,
+// same epsilons.  A camera inside a closed mesh sees nothing of it.
 __device__ inline bool rayTriangle(const Vector3 &ta, const Vector3 &tb,
                                    const Vector3 &tc, const RayIsect &r,
                                    const Vector3 &org, float t_max,
@@ -304,7 +308,7 @@ __device__ inline bool rayTriangle(const Vector3 &ta, const Vector3 &tb,
     if (V > -eps_tol && V < eps_tol) V = 0.f;
     if (W > -eps_tol && W < eps_tol) W = 0.f;
 
-    if ((U < 0.f || V < 0.f || W < 0.f) && (U > 0.f || V > 0.f || W > 0.f)) {
+    if (U < 0.f || V < 0.f || W < 0.f) {
         return false;
     }
 
@@ -312,8 +316,7 @@ __device__ inline bool rayTriangle(const Vector3 &ta, const Vector3 &tb,
         U = (float)((double)Cx * (double)By - (double)Cy * (double)Bx);
         V = (float)((double)Ax * (double)Cy - (double)Ay * (double)Cx);
         W = (float)((double)Bx * (double)Ay - (double)By * (double)Ax);
-        if ((U < 0.f || V < 0.f || W < 0.f) &&
-                (U > 0.f || V > 0.f || W > 0.f)) {
+        if (U < 0.f || V < 0.f || W < 0.f) {
             return false;
         }
     }
@@ -325,11 +328,7 @@ __device__ inline bool rayTriangle(const Vector3 &ta, const Vector3 &tb,
 
     const float Az = r.Sz * a_kz, Bz = r.Sz * b_kz, Cz = r.Sz * c_kz;
     const float T = fmaf(U, Az, fmaf(V, Bz, W * Cz));
-
-    const uint32_t det_sign = __float_as_uint(det) & 0x80000000u;
-    const float xor_T = __uint_as_float(__float_as_uint(T) ^ det_sign);
-    const float abs_det = copysignf(det, 1.f);
-    if (xor_T < 0.f || xor_T > t_max * abs_det) {
+    if (T < 0.f || T > t_max * det) {
         return false;
     }
 

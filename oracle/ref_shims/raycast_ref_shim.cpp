@@ -23,6 +23,8 @@
 #include <bit>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <utility>
@@ -128,6 +130,14 @@ uint32_t buildNode(std::vector<QBVHNode> &nodes, BuildItem *items,
         }
     }
 
+    if (getenv("RAYCAST_REF_DEBUG") != nullptr) {
+        for (uint32_t g = 0; g < num_groups; g++) {
+            fprintf(stderr, "node %u group %u: first %u count %u ref %d box [%f %f %f | %f %f %f]\n",
+                    self, g, group_first[g], group_count[g], child_refs[g],
+                    child_boxes[g].pMin.x, child_boxes[g].pMin.y, child_boxes[g].pMin.z,
+                    child_boxes[g].pMax.x, child_boxes[g].pMax.y, child_boxes[g].pMax.z);
+        }
+    }
     QBVHNode node = QBVHNode::construct(num_groups, child_boxes, child_refs);
     for (int i = 0; i < 4; i++) node.triSize[i] = tri_sizes[i];
     nodes[self] = node;
@@ -139,6 +149,43 @@ AABB inflate(AABB b)
 {
     const Vector3 eps { 1e-3f, 1e-3f, 1e-3f };
     return AABB { b.pMin - eps, b.pMax + eps };
+}
+
+// self-check: every child box, as the traversal will
+// dequantise it, contains the triangles below it
+bool validate(const std::vector<QBVHNode> &nodes, uint32_t idx,
+              const std::vector<MeshBVH::BVHVertex> &verts,
+              std::vector<uint32_t> &tris_out)
+{
+    const QBVHNode &node = nodes[idx];
+    bool ok = true;
+    for (int c = 0; c < 4; c++) {
+        if (!node.hasChild(c)) continue;
+        std::vector<uint32_t> below;
+        if (node.isLeaf(c)) {
+            uint32_t first = node.childrenIdx[c] & ~0x8000'0000u;
+            for (uint32_t t = 0; t < node.triSize[c]; t++) below.push_back(first + t);
+        } else {
+            ok = validate(nodes, node.childrenIdx[c], verts, below) && ok;
+        }
+        AABB box = node.convertToAABB(c);
+        for (uint32_t t : below) {
+            for (int k = 0; k < 3; k++) {
+                Vector3 p = verts[3 * t + k].pos;
+                if (p.x < box.pMin.x || p.y < box.pMin.y || p.z < box.pMin.z ||
+                        p.x > box.pMax.x || p.y > box.pMax.y || p.z > box.pMax.z) {
+                    fprintf(stderr, "node %u child %d: triangle %u outside "
+                            "(%f %f %f) not in [%f %f %f | %f %f %f] exp %d %d %d\n",
+                            idx, c, t, p.x, p.y, p.z, box.pMin.x, box.pMin.y,
+                            box.pMin.z, box.pMax.x, box.pMax.y, box.pMax.z,
+                            node.expX, node.expY, node.expZ);
+                    ok = false;
+                }
+            }
+            tris_out.push_back(t);
+        }
+    }
+    return ok;
 }
 
 struct ObjectBVH {
@@ -179,12 +226,14 @@ int raycast_ref_render(
 
         std::vector<AABB> tri_boxes(num_tris);
         for (uint32_t t = 0; t < num_tris; t++) {
-            AABB box = AABB::invalid();
+            AABB box {};
             for (int k = 0; k < 3; k++) {
                 const float *p = verts + 3 * (size_t)indices[3 * (size_t)(tri_first + t) + k];
                 Vector3 pos { p[0], p[1], p[2] };
                 obj.vertices.push_back({ pos, Vector2 { 0.f, 0.f } });
-                box.expand(pos);
+                // (AABB::expand on AABB::invalid() only ever moves one bound
+                // per axis and point: start from the first vertex)
+                box = k == 0 ? AABB::point(pos) : AABB::merge(box, AABB::point(pos));
             }
             tri_boxes[t] = inflate(box);
             obj.leafMats.push_back({ { { -1 } } });
@@ -204,6 +253,14 @@ int raycast_ref_render(
         obj.root = items[0].box;
         for (const BuildItem &it : items) obj.root = AABB::merge(obj.root, it.box);
         buildNode(obj.nodes, items.data(), 0, (uint32_t)items.size());
+        {
+            std::vector<uint32_t> all;
+            if (!validate(obj.nodes, 0, obj.vertices, all) || all.size() != num_tris) {
+                fprintf(stderr, "object %u: bad BVH (%zu of %u triangles)\n", o,
+                        all.size(), num_tris);
+                return -5;
+            }
+        }
 
         MeshBVH &bvh = bvhs[o];
         bvh.nodes = obj.nodes.data();

@@ -28,7 +28,7 @@ namespace consts {
 inline constexpr int32_t maxMovers = 24;
 inline constexpr int32_t numViewers = 2;
 inline constexpr int32_t numObjects = 4;
-inline constexpr float arena = 12.f;
+inline constexpr float arena = 7.f;
 }
 
 enum class ExportID : uint32_t {
