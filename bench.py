@@ -297,6 +297,77 @@ def run_single(sim_name, worlds, gpu_id, seed, denom, steps, warmup, profile_rep
     }
 
 
+def run_render(worlds, gpu_id, seed, denom, steps, warmup, profile_reps, settle,
+               resolution=64, cpu_sample=True):
+    """BASELINE.json configs[4]: the physics Escape Room + the batch ray caster,
+    resolution^2 RGB-D per agent.  A step = one replay of the step graph followed
+    by one replay of the render graph (TLAS build + ray cast of every view)."""
+    import torch
+    from madrona_amd.simlib import Simulator, hip_lib_path
+
+    flags = denom | (resolution << 16)
+    with Simulator(hip_lib_path("escape_room_render"), worlds, seed=seed, gpu_id=gpu_id,
+                   flags=flags) as sim:
+        fill_actions("escape_room_phys", sim, worlds, gpu_id, 77)
+        sim.step_async(settle)
+        render = sim.render_graph()
+
+        def run(n):
+            for _ in range(n):
+                sim.step_async(1)
+                sim.step_async(1, graph=render)
+
+        run(warmup)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(steps)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        sim.sync()
+        step_stats = sim.profile(profile_reps)
+        render_stats = sim.profile(profile_reps, graph=render)
+        views = worlds * AGENTS["escape_room_phys"]
+        # instances per world: floor, 4 borders, 2 agents, 3 x (2 walls, door, 4
+        # cubes, 2 buttons)
+        instances = 34
+    ms = dt / steps * 1e3
+    rays = views * resolution * resolution
+    cast = [k for k in render_stats if "raycast" in k["name"]]
+    tlas = [k for k in render_stats if "tlas" in k["name"]]
+    cast_us = sum(k["avg_us"] for k in cast)
+    # what a view has to move: its world's instance records, leaf boxes and TLAS
+    # nodes in, resolution^2 x (RGBA8 + f32 depth) out
+    cast_bytes = views * (instances * (64 + 32 + 64) + resolution * resolution * 8)
+    out = {
+        "workload": f"Escape-Room + XPBD + batch ray caster, {resolution}x{resolution} "
+                    f"RGB-D per agent, {worlds} worlds (BASELINE.json configs[4]), "
+                    f"{views} views, {instances} instances/world, 1 directional light, "
+                    f"auto-reset p=1/{denom} per world per step",
+        "value": worlds * steps / dt, "unit": "steps/s", "ms_per_step": ms,
+        "steps": steps, "warmup": warmup,
+        "step_graph_us": round(sum(k["avg_us"] for k in step_stats), 1),
+        "render_graph_us": round(sum(k["avg_us"] for k in render_stats), 1),
+        "primary_rays_per_s": rays / (cast_us * 1e-6) if cast_us > 0 else None,
+        "roofline": {
+            "kernel": "render:raycast (16x16 tile of one view per workgroup, world's "
+                      "TLAS + instances in LDS, binary BVH traversal, shading)",
+            "bound": "hbm", "achieved": round(cast_bytes / (cast_us * 1e-6) / 1e9, 1)
+            if cast_us > 0 else 0.0,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(cast_bytes / (cast_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+            if cast_us > 0 else 0.0,
+            "traffic": None, "avg_us": round(cast_us, 1),
+            "algo_bytes_per_launch": int(cast_bytes),
+            "note": "traversal is instruction/latency bound: the HBM figure says how "
+                    "far the kernel is from merely writing its images",
+        },
+        "kernels": [{"name": k["name"], "avg_us": round(k["avg_us"], 2)}
+                    for k in render_stats],
+        "tlas_build_us": round(sum(k["avg_us"] for k in tlas), 2),
+    }
+    return out
+
+
 def main():
     args = parse_args()
 
@@ -443,6 +514,13 @@ def main():
                                args.auto_reset_denom, 3000, 200, args.profile_reps,
                                settle=args.settle)
 
+    # BASELINE configs[4]: the same worlds + 64x64 RGB-D per agent
+    render = None
+    if (rank == 0 and world_size == 1 and args.sim == "escape_room_phys"
+            and not args.no_secondary):
+        render = run_render(args.worlds, local_rank, seed, args.auto_reset_denom,
+                            200, 30, 10, min(args.settle, 200))
+
     dist_world = dist.get_world_size() if distributed else 1
     if distributed:
         dist.barrier()
@@ -482,6 +560,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "ecs_config2": secondary,
+            "render_config5": render,
             "kernels": kernels,
         }
         # flush what C libraries buffered for "stdout" while it pointed at stderr

@@ -57,6 +57,11 @@ typedef struct mwhip_state_config {
      * fills from Embree-built MeshBVHs): host memory, copied; the executor
      * builds its own bottom-level BVHs.  NULL: no ray caster. */
     const struct mwhip_render_geometry *render_geometry;
+    /* most views a world will ever hold (0: unknown).  Sizes the render-target
+     * table: at 64 x 64 RGB-D a row is 32 KiB, and a table of unknown size gets
+     * the executor's default rows per world. */
+    uint32_t raycast_max_views_per_world;
+    uint32_t pad2_;
 } mwhip_state_config;
 
 typedef struct mwhip_render_geometry {
@@ -188,6 +193,7 @@ uint32_t mwhip_num_worlds(const mwhip_exec *exec);
  * reference src/render/ecs_system.cpp:385-404) */
 void mwhip_render_config(const mwhip_exec *exec, uint32_t *resolution_out,
                          uint32_t *rgbd_out);
+uint32_t mwhip_render_max_views(const mwhip_exec *exec);
 int mwhip_set_render_layout(mwhip_exec *exec, const mwhip_render_layout *layout);
 /* MWCudaExecutor::buildRenderGraph (reference mw_gpu.hpp:140, cuda_exec.cpp:
  * 2294-2331): a launch graph that builds every world's top-level BVH over its

@@ -28,6 +28,22 @@ struct alignas(16) BvhNode {
 };
 static_assert(sizeof(BvhNode) == 64);
 
+// An instance as the trace loop wants it: the inverse rotation and inverse
+// scale of the world -> object map (applied in the reference's order, so that
+// object-space rays agree with its to the bit), and where the object's
+// bottom-level tree lives.  Written by the TLAS build (one per row of the
+// renderable table).
+struct alignas(16) PreparedInstance {
+    math::Quat invRotation;
+    math::Diag3x3 invScale;
+    math::Vector3 position;
+    uint32_t pad0[2];
+    uint32_t nodeOffset;        // first node of the object's tree
+    uint32_t triangleOffset;    // first triangle of the object
+    int32_t valid;              // 0: no volume (all-zero scale) or no such object
+    uint32_t pad;
+};
+
 struct RenderGeometryDev {
     uint32_t numObjects;
     uint32_t numMaterials;
@@ -57,8 +73,11 @@ struct RenderParams {
     uint32_t cameraColumn, lightColumn, rgbColumn, depthColumn;
     uint32_t resolution;
     uint32_t rgbd;
+    uint32_t numGeoNodes;       // all objects
+    uint32_t numGeoTriangles;
     uint32_t pad_;
     BvhNode *tlasNodes;         // one slot per row of the renderable table
+    PreparedInstance *prepared; // likewise
     RenderGeometryDev geometry;
 };
 
@@ -70,7 +89,7 @@ int buildRenderGeometry(const mwhip_render_geometry &src, RenderGeometryHost &ou
 // ray caster (a 16 x 16 tile of one view per workgroup)
 void buildRenderLaunches(EcsState *state_dev, const RenderParams &params,
                          uint32_t num_worlds, uint32_t view_capacity,
-                         std::vector<KernelLaunch> &out);
+                         uint32_t max_workgroups, std::vector<KernelLaunch> &out);
 
 }
 }

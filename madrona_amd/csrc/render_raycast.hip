@@ -122,6 +122,30 @@ __device__ inline AABB merge(const AABB &a, const AABB &b)
 }
 
 
+// (inverse rotation / scale and the object's offsets are worked out once per
+// instance by the TLAS build instead of once per ray that enters it)
+static_assert(sizeof(PreparedInstance) == 64);
+
+__device__ inline PreparedInstance prepareInstance(const InstanceRec &inst,
+                                                   const RenderGeometryDev &geo)
+{
+    PreparedInstance p;
+    p.invRotation = inst.rotation.inv();
+    p.invScale = inst.scale.inv();
+    p.pad0[0] = p.pad0[1] = 0;
+    p.position = inst.position;
+    const bool has_volume = !(inst.scale.d0 == 0.f && inst.scale.d1 == 0.f &&
+                              inst.scale.d2 == 0.f);
+    const bool known = (uint32_t)inst.objectID < geo.numObjects;
+    const uint32_t obj = known ? (uint32_t)inst.objectID : 0u;
+    p.nodeOffset = geo.objectNodeOffset[obj];
+    p.triangleOffset = geo.objectTriangleOffset[obj];
+    p.valid = has_volume && known ? 1 : 0;
+    p.pad = 0;
+    return p;
+}
+
+
 struct TlasLDS {
     uint32_t codes[kMaxTlasLeaves];
     uint32_t left[kMaxTlasLeaves];      // children of internal node i
@@ -153,6 +177,15 @@ renderTlasBuild(EcsState *S, RenderParams params)
     const LeafBox *leaf_boxes =
         (const LeafBox *)tbl.columns[params.tlbvhColumn] + first;
     BvhNode *nodes = params.tlasNodes + first;
+
+    // the instances as the trace kernel wants them (world -> object matrices)
+    {
+        const InstanceRec *records =
+            (const InstanceRec *)tbl.columns[params.instanceColumn] + first;
+        for (int32_t i = (int32_t)lane; i < n; i += 64) {
+            params.prepared[first + i] = prepareInstance(records[i], params.geometry);
+        }
+    }
 
     if (n == 1) {
         if (lane == 0) {
@@ -262,24 +295,6 @@ __device__ inline float comp(const Vector3 &v, int32_t k)
     return k == 0 ? v.x : (k == 1 ? v.y : v.z);
 }
 
-// Woop et al. 2013 shear constants (reference bvh_raycast.cpp:228-270)
-__device__ inline RayIsect rayIsectInfo(const Vector3 &d, const Vector3 &inv_d)
-{
-    const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
-    int32_t kz = (ax > ay && ax > az) ? 0 : (ay > az ? 1 : 2);
-    int32_t kx = kz + 1 == 3 ? 0 : kz + 1;
-    int32_t ky = kx + 1 == 3 ? 0 : kx + 1;
-    if (comp(d, kz) < 0.f) {
-        int32_t t = kx; kx = ky; ky = t;
-    }
-    RayIsect r;
-    r.kx = kx; r.ky = ky; r.kz = kz;
-    r.Sx = comp(d, kx) * comp(inv_d, kz);
-    r.Sy = comp(d, ky) * comp(inv_d, kz);
-    r.Sz = comp(inv_d, kz);
-    return r;
-}
-
 // watertight ray / triangle test WITH back-face culling: the reference compiles
 // its test with MADRONA_MESHBVH_BACKFACE_CULLING (defined by mesh_bvh.inl:3,
 // which bvh_raycast.cpp includes), i.e. bvh_raycast.cpp:318-447 with the
@@ -288,7 +303,7 @@ __device__ inline RayIsect rayIsectInfo(const Vector3 &d, const Vector3 &inv_d)
 __device__ inline bool rayTriangle(const Vector3 &ta, const Vector3 &tb,
                                    const Vector3 &tc, const RayIsect &r,
                                    const Vector3 &org, float t_max,
-                                   float *t_out, Vector3 *normal_out)
+                                   float *t_out)
 {
     const Vector3 A = ta - org, B = tb - org, C = tc - org;
     const float a_kz = comp(A, r.kz), a_kx = comp(A, r.kx), a_ky = comp(A, r.ky);
@@ -334,82 +349,118 @@ __device__ inline bool rayTriangle(const Vector3 &ta, const Vector3 &tb,
 
     const float rcp_det = 1.f / det;
     *t_out = T * rcp_det;
-    *normal_out = math::cross(B - A, C - A).normalize();
     return true;
 }
 
-// entry distance of the ray into a box over [0, t_max], or +inf on a miss
-__device__ inline float boxEntry(const AABB &b, const Vector3 &o,
-                                 const Vector3 &inv_d, float t_max)
+// A ray prepared for slab tests: t = b * inv - o_inv per bound.  inv from
+// v_rcp_f32 (1 ulp): the boxes only steer the traversal, and boxEntry() keeps a
+// margin.  (A direction component of exactly 0 gives inf / NaN terms that
+// fminf / fmaxf drop: that slab then never rejects, which is conservative.)
+struct SlabRay {
+    Vector3 inv;
+    Vector3 oInv;
+};
+
+__device__ inline SlabRay slabRay(const Vector3 &o, const Vector3 &d)
 {
-    const float tx0 = (b.pMin.x - o.x) * inv_d.x, tx1 = (b.pMax.x - o.x) * inv_d.x;
-    const float ty0 = (b.pMin.y - o.y) * inv_d.y, ty1 = (b.pMax.y - o.y) * inv_d.y;
-    const float tz0 = (b.pMin.z - o.z) * inv_d.z, tz1 = (b.pMax.z - o.z) * inv_d.z;
-    // (fminf / fmaxf drop the NaN of 0 * inf: a ray inside a slab it runs
-    // parallel to is not rejected by that slab)
+    SlabRay r;
+    r.inv = Vector3 { __builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y),
+                      __builtin_amdgcn_rcpf(d.z) };
+    r.oInv = Vector3 { o.x * r.inv.x, o.y * r.inv.y, o.z * r.inv.z };
+    return r;
+}
+
+// entry distance of the ray into a box over [0, t_max], or +inf on a miss
+__device__ inline float boxEntry(const AABB &b, const SlabRay &r, float t_max)
+{
+    const float tx0 = fmaf(b.pMin.x, r.inv.x, -r.oInv.x);
+    const float tx1 = fmaf(b.pMax.x, r.inv.x, -r.oInv.x);
+    const float ty0 = fmaf(b.pMin.y, r.inv.y, -r.oInv.y);
+    const float ty1 = fmaf(b.pMax.y, r.inv.y, -r.oInv.y);
+    const float tz0 = fmaf(b.pMin.z, r.inv.z, -r.oInv.z);
+    const float tz1 = fmaf(b.pMax.z, r.inv.z, -r.oInv.z);
     const float t_near = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)),
                                fmaxf(fminf(tz0, tz1), 0.f));
     const float t_far = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)),
                               fminf(fmaxf(tz0, tz1), t_max));
     // a little slack: the boxes are exact, the triangle test is watertight and
     // may accept a hit an ulp outside the box
-    return t_near <= t_far * 1.00001f + 1e-6f ? t_near : INFINITY;
+    return t_near <= fmaf(t_far, 1.00001f, 1e-6f) ? t_near : INFINITY;
 }
 
-constexpr uint32_t kStackDepth = 48;
+constexpr uint32_t kStackDepth = 24;
+// bottom-level trees + triangles of all objects are kept in LDS when they fit
+constexpr uint32_t kGeoLdsDwords = 8192;
 
+template <bool GeoInLds>
 struct TraceLDS {
     static constexpr int maxInstances = 64;
     static constexpr int maxLights = 8;
 
     BvhNode nodes[maxInstances];
-    InstanceRec instances[maxInstances];
+    PreparedInstance instances[maxInstances];
     LightRec lights[maxLights];
     // traversal stack (both levels), one column per thread
     uint16_t stack[kStackDepth][256];
+    // [nodes of every object][triangle vertices of every object]
+    uint32_t geo[GeoInLds ? kGeoLdsDwords : 4];
 };
 
 struct Hit {
     bool hit;
     float t;            // world-space distance along the normalised ray
     int32_t instance;   // index inside the world
-    Vector3 normal;     // object space, geometric
+    uint32_t triangle;  // index into the executor's triangle array
 };
 
 struct WorldView {
-    const BvhNode *nodes;          // LDS or HBM
-    const InstanceRec *instances;   // LDS or HBM
+    const BvhNode *nodes;                  // LDS or HBM
+    const PreparedInstance *prepared;      // LDS or HBM
     int32_t numInstances;
+};
+
+struct GeoView {
+    const BvhNode *nodes;
+    const Vector3 *triangles;
 };
 
 // closest hit of the ray against one instance's triangles: the ray goes to
 // object space, t is rescaled on the way in and out (reference :627-646,
-// :747-766).  The stack above `sp` is free.
-__device__ inline void traceInstance(EcsState *S, const RenderGeometryDev &geo,
-                                     const InstanceRec &inst, int32_t inst_idx,
-                                     const Vector3 &world_o,
-                                     const Vector3 &world_d, float &t_max,
-                                     Hit &best, TraceLDS *lds, uint32_t sp_base,
-                                     uint32_t tid)
+// :747-766).  The stack above `sp_base` is free.
+template <bool AnyHit, bool GeoInLds>
+__device__ __forceinline__ void traceInstance(
+    EcsState *S, const GeoView &geo, const PreparedInstance &inst,
+    int32_t inst_idx, const Vector3 &world_o, const Vector3 &world_d,
+    float &t_max, Hit &best, TraceLDS<GeoInLds> *lds, uint32_t sp_base,
+    uint32_t tid)
 {
-    if (inst.scale.d0 == 0.f && inst.scale.d1 == 0.f && inst.scale.d2 == 0.f) {
+    if (inst.valid == 0) {
         return;
     }
-    const Diag3x3 inv_scale = inst.scale.inv();
-    const Quat inv_rot = inst.rotation.inv();
-    const Vector3 o = inv_scale * inv_rot.rotateVec(world_o - inst.position);
-    Vector3 d = inv_scale * inv_rot.rotateVec(world_d);
+    const Vector3 o =
+        inst.invScale * inst.invRotation.rotateVec(world_o - inst.position);
+    Vector3 d = inst.invScale * inst.invRotation.rotateVec(world_d);
     const float t_scale = d.length();
     t_max *= t_scale;
     d /= t_scale;
-    const Vector3 inv_d { 1.f / d.x, 1.f / d.y, 1.f / d.z };
-    const RayIsect isect = rayIsectInfo(d, inv_d);
+    const SlabRay slab = slabRay(o, d);
 
-    const uint32_t obj = (uint32_t)inst.objectID < geo.numObjects ?
-        (uint32_t)inst.objectID : 0u;
-    const BvhNode *nodes = geo.nodes + geo.objectNodeOffset[obj];
-    const Vector3 *tris = geo.triangleVertices +
-                          3u * (size_t)geo.objectTriangleOffset[obj];
+    // shear constants: exact division for the axis the hit distance is measured
+    // along (reference computeRayIsectInfo, :228-270)
+    const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    RayIsect isect;
+    isect.kz = (ax > ay && ax > az) ? 0 : (ay > az ? 1 : 2);
+    isect.kx = isect.kz + 1 == 3 ? 0 : isect.kz + 1;
+    isect.ky = isect.kx + 1 == 3 ? 0 : isect.kx + 1;
+    if (comp(d, isect.kz) < 0.f) {
+        const int32_t t = isect.kx; isect.kx = isect.ky; isect.ky = t;
+    }
+    isect.Sz = 1.f / comp(d, isect.kz);
+    isect.Sx = comp(d, isect.kx) * isect.Sz;
+    isect.Sy = comp(d, isect.ky) * isect.Sz;
+
+    const BvhNode *nodes = geo.nodes + inst.nodeOffset;
+    const Vector3 *tris = geo.triangles + 3u * (size_t)inst.triangleOffset;
 
     uint32_t sp = sp_base;
     uint32_t cur = 0;
@@ -419,7 +470,7 @@ __device__ inline void traceInstance(EcsState *S, const RenderGeometryDev &geo,
 #pragma unroll
         for (int c = 0; c < 2; c++) {
             entry[c] = node.child[c] == kNoChild ? INFINITY :
-                boxEntry(node.box[c], o, inv_d, t_max);
+                boxEntry(node.box[c], slab, t_max);
         }
         const int near = entry[1] < entry[0] ? 1 : 0;
         uint32_t next = kNoChild;
@@ -437,13 +488,15 @@ __device__ inline void traceInstance(EcsState *S, const RenderGeometryDev &geo,
                 for (uint32_t t_idx = 0; t_idx < num_tris; t_idx++) {
                     const Vector3 *tri = tris + 3u * (size_t)(first_tri + t_idx);
                     float t;
-                    Vector3 nrm;
-                    if (rayTriangle(tri[0], tri[1], tri[2], isect, o, t_max, &t,
-                                    &nrm)) {
+                    if (rayTriangle(tri[0], tri[1], tri[2], isect, o, t_max, &t)) {
                         t_max = t;
                         best.hit = true;
                         best.instance = inst_idx;
-                        best.normal = nrm;
+                        best.triangle = inst.triangleOffset + first_tri + t_idx;
+                        if constexpr (AnyHit) {
+                            t_max = t_max / t_scale;
+                            return;
+                        }
                     }
                 }
             } else if (next == kNoChild) {
@@ -465,21 +518,21 @@ __device__ inline void traceInstance(EcsState *S, const RenderGeometryDev &geo,
     t_max = t_max / t_scale;
 }
 
-__device__ inline Hit traceWorld(EcsState *S, const RenderGeometryDev &geo,
-                                 const WorldView &w, const Vector3 &o,
-                                 const Vector3 &d, float t_max, TraceLDS *lds,
-                                 uint32_t tid)
+template <bool AnyHit, bool GeoInLds>
+__device__ __forceinline__ Hit traceWorld(
+    EcsState *S, const GeoView &geo, const WorldView &w, const Vector3 &o, const Vector3 &d, float t_max,
+    TraceLDS<GeoInLds> *lds, uint32_t tid)
 {
     Hit best;
     best.hit = false;
     best.t = 0.f;
     best.instance = -1;
-    best.normal = Vector3 { 0.f, 0.f, 0.f };
+    best.triangle = 0;
 
     if (w.numInstances <= 0) {
         return best;
     }
-    const Vector3 inv_d { 1.f / d.x, 1.f / d.y, 1.f / d.z };
+    const SlabRay slab = slabRay(o, d);
 
     uint32_t sp = 0;
     uint32_t cur = 0;       // internal node index
@@ -489,7 +542,7 @@ __device__ inline Hit traceWorld(EcsState *S, const RenderGeometryDev &geo,
 #pragma unroll
         for (int c = 0; c < 2; c++) {
             entry[c] = node.child[c] == kNoChild ? INFINITY :
-                boxEntry(node.box[c], o, inv_d, t_max);
+                boxEntry(node.box[c], slab, t_max);
         }
         const int near = entry[1] < entry[0] ? 1 : 0;
         uint32_t next = kNoChild;
@@ -502,8 +555,14 @@ __device__ inline Hit traceWorld(EcsState *S, const RenderGeometryDev &geo,
             const uint32_t child = node.child[c];
             if ((child & kLeafBit) != 0u) {
                 const int32_t idx = (int32_t)(child & ~kLeafBit);
-                traceInstance(S, geo, w.instances[idx], idx, o, d, t_max, best,
-                              lds, sp, tid);
+                traceInstance<AnyHit>(S, geo, w.prepared[idx], idx, o, d, t_max,
+                                      best, lds, sp, tid);
+                if constexpr (AnyHit) {
+                    if (best.hit) {
+                        best.t = t_max;
+                        return best;
+                    }
+                }
             } else if (next == kNoChild) {
                 next = child;
             } else if (sp < kStackDepth) {
@@ -531,11 +590,14 @@ __device__ inline Vector3 hexToRgb(uint32_t hex)
                      (float)(hex & 0xFFu) / 255.f };
 }
 
-// one 16 x 16 tile of one view per workgroup
+// Workgroups stride over the 16 x 16 tiles of all views.  GeoInLds: the
+// bottom-level trees and triangles of every object are copied to LDS once per
+// workgroup (they fit: kGeoLdsDwords), so that only the image leaves the CU.
+template <bool GeoInLds>
 __global__ void __launch_bounds__(256)
 renderRaycast(EcsState *S, RenderParams params)
 {
-    __shared__ TraceLDS lds;
+    __shared__ TraceLDS<GeoInLds> lds;
 
     const uint32_t res = params.resolution;
     const uint32_t tiles_per_side = (res + 15u) / 16u;
@@ -549,12 +611,37 @@ renderRaycast(EcsState *S, RenderParams params)
     const uint32_t num_views = (uint32_t)cam_tbl.numRows;
     const uint32_t total_tiles = num_views * tiles_per_view;
 
-    const RenderGeometryDev geo = params.geometry;
+    const RenderGeometryDev geo_dev = params.geometry;
+    GeoView geo;
+    if constexpr (GeoInLds) {
+        const uint32_t node_dw = params.numGeoNodes * 16u;
+        const uint32_t tri_dw = params.numGeoTriangles * 9u;
+        for (uint32_t i = tid; i < node_dw; i += 256u) {
+            lds.geo[i] = ((const uint32_t *)geo_dev.nodes)[i];
+        }
+        for (uint32_t i = tid; i < tri_dw; i += 256u) {
+            lds.geo[node_dw + i] = ((const uint32_t *)geo_dev.triangleVertices)[i];
+        }
+        geo.nodes = (const BvhNode *)&lds.geo[0];
+        geo.triangles = (const Vector3 *)&lds.geo[node_dw];
+    } else {
+        geo.nodes = geo_dev.nodes;
+        geo.triangles = geo_dev.triangleVertices;
+    }
+
     uint8_t *rgb_out = (uint8_t *)out_tbl.columns[params.rgbColumn];
     float *depth_out = (float *)out_tbl.columns[params.depthColumn];
     const uint32_t pixels_per_view = res * res;
+    int32_t staged_world = -1;
 
-    for (uint32_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+    // a contiguous run of tiles per workgroup: the tiles of a view, and the views
+    // of a world, follow each other
+    const uint32_t tiles_per_wg = (total_tiles + gridDim.x - 1u) / gridDim.x;
+    const uint32_t tile_begin = blockIdx.x * tiles_per_wg;
+    const uint32_t tile_end = tile_begin + tiles_per_wg < total_tiles ?
+        tile_begin + tiles_per_wg : total_tiles;
+
+    for (uint32_t tile = tile_begin; tile < tile_end; tile++) {
         const uint32_t view_idx = tile / tiles_per_view;
         const uint32_t tile_in_view = tile % tiles_per_view;
         const ViewRec view =
@@ -565,40 +652,44 @@ renderRaycast(EcsState *S, RenderParams params)
         const int32_t num_inst = inst_tbl.worldCounts[world];
         const int32_t light_first = light_tbl.worldOffsets[world];
         int32_t num_lights = light_tbl.worldCounts[world];
-        num_lights = num_lights < TraceLDS::maxLights ? num_lights :
-                                                        TraceLDS::maxLights;
+        num_lights = num_lights < lds.maxLights ? num_lights : lds.maxLights;
 
-        // ---- stage the world next to the CU ---------------------------------
-        __syncthreads();
         const InstanceRec *inst_hbm =
             (const InstanceRec *)inst_tbl.columns[params.instanceColumn] +
             inst_first;
         const BvhNode *nodes_hbm = params.tlasNodes + inst_first;
-        const bool staged = num_inst <= TraceLDS::maxInstances;
-        if (staged) {
-            const uint32_t inst_dw = (uint32_t)num_inst * 16u;
-            for (uint32_t i = tid; i < inst_dw; i += 256u) {
-                ((uint32_t *)lds.instances)[i] = ((const uint32_t *)inst_hbm)[i];
+        const PreparedInstance *prepared_hbm = params.prepared + inst_first;
+        const bool staged = num_inst <= lds.maxInstances;
+
+        // ---- stage the world next to the CU (tiles of one world follow each
+        // other: once per world, not per tile) -------------------------------
+        if (world != staged_world) {
+            __syncthreads();
+            if (staged) {
+                const uint32_t inst_dw = (uint32_t)num_inst * 16u;
+                for (uint32_t i = tid; i < inst_dw; i += 256u) {
+                    ((uint32_t *)lds.instances)[i] =
+                        ((const uint32_t *)prepared_hbm)[i];
+                }
+                const uint32_t node_dw =
+                    (uint32_t)(num_inst > 1 ? num_inst - 1 : num_inst) * 16u;
+                for (uint32_t i = tid; i < node_dw; i += 256u) {
+                    ((uint32_t *)lds.nodes)[i] = ((const uint32_t *)nodes_hbm)[i];
+                }
             }
-            const uint32_t node_dw =
-                (uint32_t)(num_inst > 1 ? num_inst - 1 : num_inst) * 16u;
-            for (uint32_t i = tid; i < node_dw; i += 256u) {
-                ((uint32_t *)lds.nodes)[i] = ((const uint32_t *)nodes_hbm)[i];
-            }
-        }
-        {
             const uint32_t light_dw = (uint32_t)num_lights * 10u;
             const uint32_t *src = (const uint32_t *)((const LightRec *)
                 light_tbl.columns[params.lightColumn] + light_first);
             for (uint32_t i = tid; i < light_dw; i += 256u) {
                 ((uint32_t *)lds.lights)[i] = src[i];
             }
+            staged_world = world;
+            __syncthreads();
         }
-        __syncthreads();
 
         WorldView wv;
         wv.nodes = staged ? lds.nodes : nodes_hbm;
-        wv.instances = staged ? lds.instances : inst_hbm;
+        wv.prepared = staged ? lds.instances : prepared_hbm;
         wv.numInstances = num_inst;
 
         const uint32_t px = (tile_in_view % tiles_per_side) * 16u + (tid & 15u);
@@ -625,8 +716,8 @@ renderRaycast(EcsState *S, RenderParams params)
         const Vector3 ray_dir = (lower_left + pixel_u * horizontal +
                                  pixel_v * vertical - ray_start).normalize();
 
-        const Hit first = traceWorld(S, geo, wv, ray_start, ray_dir, 10000.f,
-                                     &lds, tid);
+        const Hit first = traceWorld<false>(S, geo, wv, ray_start,
+                                            ray_dir, 10000.f, &lds, tid);
 
         const uint32_t pixel = px + py * res;
         float depth = 0.f;
@@ -634,24 +725,28 @@ renderRaycast(EcsState *S, RenderParams params)
         if (first.hit) {
             depth = first.t;
             if (params.rgbd != 0u) {
-                const InstanceRec &inst = wv.instances[first.instance];
+                const InstanceRec inst = inst_hbm[first.instance];
                 // reference traceRay, :772-812 (one material per object here,
                 // untextured)
                 int32_t material = inst.matID;
                 if (material == -1) {
-                    material = (uint32_t)inst.objectID < geo.numObjects ?
-                        geo.objectMaterial[inst.objectID] : -1;
+                    material = (uint32_t)inst.objectID < geo_dev.numObjects ?
+                        geo_dev.objectMaterial[inst.objectID] : -1;
                 }
                 Vector3 color { 1.f, 1.f, 1.f };
                 if (inst.matID == -2) {
                     color = hexToRgb(inst.color);
                 } else if (material >= 0 &&
-                           (uint32_t)material < geo.numMaterials) {
-                    color = Vector3 { geo.materialColor[3 * material],
-                                      geo.materialColor[3 * material + 1],
-                                      geo.materialColor[3 * material + 2] };
+                           (uint32_t)material < geo_dev.numMaterials) {
+                    color = Vector3 { geo_dev.materialColor[3 * material],
+                                      geo_dev.materialColor[3 * material + 1],
+                                      geo_dev.materialColor[3 * material + 2] };
                 }
-                const Vector3 normal = inst.rotation.rotateVec(first.normal);
+                // geometric normal of the hit triangle (reference :443-446)
+                const Vector3 *tri = geo.triangles + 3u * (size_t)first.triangle;
+                const Vector3 obj_normal =
+                    math::cross(tri[1] - tri[0], tri[2] - tri[0]).normalize();
+                const Vector3 normal = inst.rotation.rotateVec(obj_normal);
                 const Vector3 hit_pos = ray_start + first.t * ray_dir;
 
                 // ---- lights (reference computeFragment, :840-930) -------------
@@ -672,8 +767,10 @@ renderRaycast(EcsState *S, RenderParams params)
                     }
                     if (light.castShadow) {
                         if (light_dir.dot(normal) > 0.f) {
-                            const Hit shadow = traceWorld(S, geo, wv, hit_pos,
-                                light_dir, 10000.f, &lds, tid);
+                            // (any hit will do: the reference looks for the
+                            // closest one and only asks whether there is one)
+                            const Hit shadow = traceWorld<true>(S, geo,
+                                wv, hit_pos, light_dir, 10000.f, &lds, tid);
                             if (!shadow.hit) {
                                 light_contrib += fminf(fmaxf(
                                     normal.dot(light_dir), 0.f), 1.f);
@@ -857,7 +954,7 @@ int buildRenderGeometry(const mwhip_render_geometry &src, RenderGeometryHost &ou
 
 void buildRenderLaunches(EcsState *state_dev, const RenderParams &params,
                          uint32_t num_worlds, uint32_t view_capacity,
-                         std::vector<KernelLaunch> &out)
+                         uint32_t max_workgroups, std::vector<KernelLaunch> &out)
 {
     {
         KernelLaunch k;
@@ -871,12 +968,17 @@ void buildRenderLaunches(EcsState *state_dev, const RenderParams &params,
     }
     {
         KernelLaunch k;
-        k.fn = (const void *)&renderRaycast;
+        const bool geo_in_lds = params.numGeoNodes * 16u +
+            params.numGeoTriangles * 9u <= kGeoLdsDwords;
+        k.fn = geo_in_lds ? (const void *)&renderRaycast<true> :
+                            (const void *)&renderRaycast<false>;
         const uint32_t tiles_per_side = (params.resolution + 15u) / 16u;
         const uint64_t tiles =
             (uint64_t)view_capacity * tiles_per_side * tiles_per_side;
+        // persistent workgroups (each copies the geometry to LDS once and walks
+        // a contiguous run of tiles); a few per slot so that uneven runs even out
         k.grid = dim3((uint32_t)std::min<uint64_t>(std::max<uint64_t>(tiles, 1),
-                                                  1u << 20), 1, 1);
+                                                  max_workgroups), 1, 1);
         k.block = dim3(256, 1, 1);
         k.setArgs(state_dev, params);
         k.name = "render";

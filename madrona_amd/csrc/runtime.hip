@@ -509,6 +509,7 @@ struct mwhip_exec {
     RenderGeometryDev renderGeometryDev {};
     mwhip_render_layout renderLayout {};
     BvhNode *tlasNodes = nullptr;
+    PreparedInstance *preparedInstances = nullptr;
 };
 
 static int devAlloc(mwhip_exec *exec, void **out, size_t bytes, bool zero = true)
@@ -1011,6 +1012,11 @@ extern "C" void mwhip_render_config(const mwhip_exec *exec,
 {
     *resolution_out = exec->cfg.raycast_output_resolution;
     *rgbd_out = exec->cfg.raycast_rgbd;
+}
+
+extern "C" uint32_t mwhip_render_max_views(const mwhip_exec *exec)
+{
+    return exec->cfg.raycast_max_views_per_world;
 }
 
 extern "C" uint32_t mwhip_num_task_graphs(const mwhip_exec *exec)
@@ -2375,11 +2381,15 @@ static int renderLaunches(mwhip_exec *exec, std::vector<KernelLaunch> &out)
         // instances uses n - 1 of its n slots)
         rc = devAllocT(exec, &exec->tlasNodes, inst.reservedCapacity, false);
         if (rc != 0) return rc;
+        rc = devAllocT(exec, &exec->preparedInstances, inst.reservedCapacity,
+                       false);
+        if (rc != 0) return rc;
     }
 
     params.resolution = res;
     params.rgbd = exec->cfg.raycast_rgbd;
     params.tlasNodes = exec->tlasNodes;
+    params.prepared = exec->preparedInstances;
     params.geometry = exec->renderGeometryDev;
     // (any grid is correct: workgroups stride over the tiles of the views that
     // exist; sized for the views the table held when the graph was built)
@@ -2387,7 +2397,12 @@ static int renderLaunches(mwhip_exec *exec, std::vector<KernelLaunch> &out)
     if (lay.camera_archetype < exec->rowsAtGraphBuild.size()) {
         views = std::max(exec->rowsAtGraphBuild[lay.camera_archetype], 16u);
     }
-    buildRenderLaunches(exec->stateDev, params, exec->cfg.num_worlds, views, out);
+    params.numGeoNodes = (uint32_t)exec->renderGeometry.nodes.size();
+    params.numGeoTriangles =
+        (uint32_t)(exec->renderGeometry.triangleVertices.size() / 9);
+    static const uint32_t max_wgs = envU32("MADRONA_MWHIP_RAYCAST_WGS", 3072);
+    buildRenderLaunches(exec->stateDev, params, exec->cfg.num_worlds, views,
+                        std::max(max_wgs, 1u), out);
     return 0;
 }
 

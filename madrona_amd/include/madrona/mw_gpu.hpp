@@ -98,6 +98,9 @@ struct CudaBatchRenderConfig {
     uint32_t renderResolution = 0;
     float nearPlane = 0.f;
     float farPlane = 0.f;
+    // (this backend) most views a world will hold, 0 = unknown: sizes the
+    // render-target table, 8 * renderResolution^2 bytes a view
+    uint32_t maxViewsPerWorld = 0;
 };
 
 // Opaque device context handle (the reference returns a CUcontext)
@@ -186,6 +189,7 @@ public:
                 cfg.render_geometry = &geometry;
             }
             cfg.raycast_output_resolution = render_cfg->renderResolution;
+            cfg.raycast_max_views_per_world = render_cfg->maxViewsPerWorld;
             cfg.raycast_rgbd = render_cfg->renderMode ==
                 CudaBatchRenderConfig::RenderMode::RGBD ? 1u : 0u;
             cfg.object_root_aabbs = render_cfg->objectRootAABBs.data();

@@ -97,6 +97,12 @@ public:
         return state_mgr_->renderConfig(1) != 0;
     }
 
+    // most views per world the render configuration promised (0: unknown)
+    MADRONA_HOST_API uint32_t raycastMaxViewsPerWorld() const
+    {
+        return state_mgr_->renderConfig(2);
+    }
+
     // tells the executor's ray caster where its inputs and outputs live (the
     // reference hands pointers to its BVH kernels in BVHParams,
     // src/mw/cuda_exec.cpp)

@@ -214,9 +214,14 @@ MADRONA_HOST_API inline void registerTypes(ECSRegistry &registry,
     registry.registerComponent<RenderOutputRef>();
     registry.registerComponent<TLBVHNode>();
 
-    registry.registerArchetype<RaycastOutputArchetype>();
+    // (render targets are 8 * res^2 bytes a row: sized by the configuration's
+    // promise when there is one)
+    const CountT max_views = (CountT)registry.raycastMaxViewsPerWorld();
+    registry.registerArchetype<RaycastOutputArchetype>(
+        ComponentMetadataSelector<> {}, ArchetypeFlags::None, max_views);
     registry.registerArchetype<LightArchetype>();
-    registry.registerArchetype<RenderCameraArchetype>();
+    registry.registerArchetype<RenderCameraArchetype>(
+        ComponentMetadataSelector<> {}, ArchetypeFlags::None, max_views);
     registry.registerArchetype<RenderableArchetype>();
 
     registry.registerSingleton<RenderingSystemState>();

@@ -57,7 +57,7 @@ public:
     // ---- host: registration (reference device state.inl:7-158) -------------
     template <typename ComponentT>
     MADRONA_HOST_API ComponentID registerComponent(uint32_t num_bytes = 0);
-    // host: which = 0 ray caster resolution, 1 RGBD flag
+    // host: which = 0 ray caster resolution, 1 RGBD flag, 2 max views per world
     MADRONA_HOST_API inline uint32_t renderConfig(int which) const;
     // host: the tables / components of the batch ray caster, by type id
     // (archetypes: renderable, camera, light, output; components: instance,

@@ -116,6 +116,9 @@ MADRONA_HOST_API inline uint32_t StateManager::renderConfig(int which) const
 #if MADRONA_ON_HOST
     uint32_t res = 0, rgbd = 0;
     mwhip_render_config((const mwhip_exec *)hostExec, &res, &rgbd);
+    if (which == 2) {
+        return mwhip_render_max_views((const mwhip_exec *)hostExec);
+    }
     return which == 0 ? res : rgbd;
 #else
     (void)which;

@@ -356,13 +356,15 @@ class Simulator:
             raise RuntimeError(
                 f"mwhip_synchronize -> {rc}: {rt.mwhip_last_error().decode()}")
 
-    def profile(self, reps: int = 20):
+    def profile(self, reps: int = 20, graph: int = 0):
         """Per-kernel timing of one step (HIP events on the executor's stream,
         kernels queued back to back behind a gate).  Advances the simulation by
-        `reps` steps.  Returns a list of dicts."""
+        `reps` steps.  graph: another launch graph of this executor (e.g.
+        render_graph()) instead of the step graph.  Returns a list of dicts."""
         rt = runtime_lib()
         stats = (KernelStat * 512)()
-        n = rt.mwhip_profile(self.hip_exec(), self.lib.sim_hip_step_graph(self.handle),
+        n = rt.mwhip_profile(self.hip_exec(),
+                             graph or self.lib.sim_hip_step_graph(self.handle),
                              reps, stats, 512)
         if n < 0:
             raise RuntimeError(f"mwhip_profile -> {n}: {rt.mwhip_last_error().decode()}")

@@ -204,6 +204,7 @@ struct SimTraits {
         cfg.renderResolution = (args.flags >> 16) & 0xFFu;
         if (cfg.renderResolution == 0) cfg.renderResolution = 64;
         g_resolution = cfg.renderResolution;
+        cfg.maxViewsPerWorld = escphys::consts::numAgents;
         simmgr::meshesToRenderConfig(meshes(), cfg);
         return madrona::Optional<madrona::CudaBatchRenderConfig>::make(cfg);
     }
