@@ -1524,7 +1524,8 @@ static int makeSortBatch(mwhip_exec *exec,
             // limit (checked again after every replay, sortsOutgrown())
             uint64_t rows_now = archetype_id < exec->rowsAtGraphBuild.size() ?
                 exec->rowsAtGraphBuild[archetype_id] : arch.capacity;
-            if (arch.capacity <= sortSmallRowLimit()) rows_now = 0;
+            // (a table that can never hold more than that quarter stays small)
+            if ((uint64_t)arch.capacity * 4 <= sortSmallRowLimit()) rows_now = 0;
             if (arch.bigSort || rows_now * 4 > sortSmallRowLimit()) {
                 all_small = false;
             }

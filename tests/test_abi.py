@@ -9,7 +9,7 @@ import pytest
 from madrona_amd.simlib import HIP_BUILD_DIR, REPO_ROOT, hip_lib_path
 
 SIMS = ["cartpole", "escape_room", "sort_stress", "escape_room_phys", "hideseek",
-        "ball_pit", "broadphase_only", "render_prep"]
+        "ball_pit", "broadphase_only", "render_prep", "escape_room_render"]
 
 
 def declared_functions(header_path):
