@@ -482,6 +482,8 @@ struct mwhip_exec {
     // device -> host requests for table memory (mwhip::GrowMailbox) and the
     // lock that orders the service thread against growth between replays
     hipStream_t serviceStream = nullptr;    // fills of freshly mapped memory
+    VmRange *entityVm = nullptr;            // entity slots (growable)
+    VmRange *tmpVm = nullptr;               // Context::tmpAlloc region (growable)
     GrowMailbox *growMailbox = nullptr;
     std::mutex growMutex;
     bool headersStale = false;      // device headers / graphs lag the mapped rows
@@ -1141,9 +1143,30 @@ static int buildDeviceState(mwhip_exec *exec)
     if (entity_capacity > 0x7FFFFFF0ull) {
         return fail(-2, "entity store overflow");
     }
+    const uint64_t default_entity_capacity = entity_capacity;
+    // (test hook) start with a fraction of the ids the defaults provide
+    if (const char *div = getenv("MADRONA_MWHIP_INITIAL_ID_CAPACITY_DIV")) {
+        uint64_t d = strtoull(div, nullptr, 10);
+        if (d > 1) {
+            entity_capacity = std::max<uint64_t>(
+                exec->singletonIdEnd + ((entity_capacity - exec->singletonIdEnd) / d +
+                    kIdsPerBlock - 1) / kIdsPerBlock * kIdsPerBlock,
+                exec->singletonIdEnd + kIdsPerBlock);
+        }
+    }
     hs.entityCapacity = (int32_t)entity_capacity;
-    rc = devAllocT(exec, &hs.entities, entity_capacity);
-    if (rc != 0) return rc;
+    if (exec->tableGrowth > 1) {
+        // growable like the tables: address space for 16 x the ids
+        const uint64_t reserve_ids =
+            std::min<uint64_t>(default_entity_capacity * 16, 0x7FFFFFF0ull);
+        rc = vmAlloc(exec, (void **)&hs.entities, &exec->entityVm,
+                     reserve_ids * sizeof(EntitySlot),
+                     entity_capacity * sizeof(EntitySlot), true);
+        if (rc != 0) return rc;
+    } else {
+        rc = devAllocT(exec, &hs.entities, entity_capacity);
+        if (rc != 0) return rc;
+    }
     rc = devAllocT(exec, &hs.worldCaches, W);
     if (rc != 0) return rc;
     rc = devAllocT(exec, &hs.initBlockBase, W);
@@ -1159,8 +1182,14 @@ static int buildDeviceState(mwhip_exec *exec)
 
     hs.tmpCapacity =
         (unsigned long long)envU32("MADRONA_MWHIP_TMP_MB", 64) << 20;
-    rc = devAlloc(exec, (void **)&hs.tmpBase, hs.tmpCapacity, false);
-    if (rc != 0) return rc;
+    if (exec->tableGrowth > 1) {
+        rc = vmAlloc(exec, (void **)&hs.tmpBase, &exec->tmpVm,
+                     hs.tmpCapacity * 16, hs.tmpCapacity, false);
+        if (rc != 0) return rc;
+    } else {
+        rc = devAlloc(exec, (void **)&hs.tmpBase, hs.tmpCapacity, false);
+        if (rc != 0) return rc;
+    }
     hs.tmpOffset = 0;
 
     hs.persistCapacity = (unsigned long long)W *
@@ -1261,6 +1290,8 @@ static int buildDeviceState(mwhip_exec *exec)
             exec->growMailbox->capacity[a] = (int32_t)exec->archetypes[a].capacity;
         }
     }
+    exec->growMailbox->capacity[kGrowSlotEntities] = hs.entityCapacity;
+    exec->growMailbox->capacity[kGrowSlotTmp] = (int32_t)(hs.tmpCapacity >> 10);
     HIPCHK(hipHostGetDevicePointer((void **)&hs.growMailbox,
                                    exec->growMailbox, 0));
 
@@ -1960,6 +1991,69 @@ static int resetForInitPass(mwhip_exec *exec)
 }
 
 static int growTablesFromDevice(mwhip_exec *exec);
+// Entity store / scratch region: more memory mapped behind them (addresses do
+// not change), the mailbox told; the device header follows at the next replay
+// boundary (growTables).  Caller holds growMutex (or runs before the service
+// thread exists).
+static int growEntityStore(mwhip_exec *exec, uint64_t new_ids)
+{
+    EcsState &hs = exec->hostState;
+    if (exec->entityVm == nullptr) {
+        return fail(-4, "the entity store is a fixed allocation "
+                    "(MADRONA_MWHIP_TABLE_GROWTH=1)");
+    }
+    new_ids = (new_ids + kIdsPerBlock - 1) / kIdsPerBlock * kIdsPerBlock;
+    new_ids = std::min<uint64_t>(new_ids,
+                                 exec->entityVm->reserved / sizeof(EntitySlot));
+    if (new_ids <= (uint64_t)hs.entityCapacity) {
+        return fail(-4, "the entity store's reserved address space is used up "
+                    "(%d ids)", hs.entityCapacity);
+    }
+    int rc = vmEnsure(exec, *exec->entityVm, new_ids * sizeof(EntitySlot), true);
+    if (rc != 0) return rc;
+    hs.entityCapacity = (int32_t)new_ids;
+    if (exec->growMailbox != nullptr) {
+        __atomic_store_n(&exec->growMailbox->capacity[kGrowSlotEntities],
+                         (int32_t)new_ids, __ATOMIC_RELEASE);
+    }
+    exec->numGrowths++;
+    exec->headersStale = true;
+    if (getenv("MADRONA_MWHIP_DEBUG_GROWTH") != nullptr) {
+        fprintf(stderr, "madrona_amd: entity store now holds %llu ids\n",
+                (unsigned long long)new_ids);
+    }
+    return 0;
+}
+
+static int growTmpRegion(mwhip_exec *exec, uint64_t new_bytes)
+{
+    EcsState &hs = exec->hostState;
+    if (exec->tmpVm == nullptr) {
+        return fail(-4, "the scratch region is a fixed allocation "
+                    "(MADRONA_MWHIP_TABLE_GROWTH=1)");
+    }
+    new_bytes = std::min<uint64_t>((new_bytes + kVmChunk - 1) / kVmChunk * kVmChunk,
+                                   exec->tmpVm->reserved);
+    if (new_bytes <= hs.tmpCapacity) {
+        return fail(-4, "the scratch region's reserved address space is used up "
+                    "(%llu bytes)", (unsigned long long)hs.tmpCapacity);
+    }
+    int rc = vmEnsure(exec, *exec->tmpVm, new_bytes, false);
+    if (rc != 0) return rc;
+    hs.tmpCapacity = new_bytes;
+    if (exec->growMailbox != nullptr) {
+        __atomic_store_n(&exec->growMailbox->capacity[kGrowSlotTmp],
+                         (int32_t)(new_bytes >> 10), __ATOMIC_RELEASE);
+    }
+    exec->numGrowths++;
+    exec->headersStale = true;
+    if (getenv("MADRONA_MWHIP_DEBUG_GROWTH") != nullptr) {
+        fprintf(stderr, "madrona_amd: scratch region now %llu MiB\n",
+                (unsigned long long)(new_bytes >> 20));
+    }
+    return 0;
+}
+
 static void serviceGrowRequests(mwhip_exec *exec);
 
 static int constructWorlds(mwhip_exec *exec)
@@ -2013,11 +2107,28 @@ static int constructWorlds(mwhip_exec *exec)
     // registration: full tables grow (they live in reserved address space,
     // growTables) and pass 1 runs again, until everything fits or the
     // reservations are exhausted.
-    for (int attempt = 0; (err & kErrTableOverflow) != 0u &&
-             (err & ~(uint32_t)kErrTableOverflow) == 0u && attempt < 6; attempt++) {
+    // Likewise the entity store when the constructors take more id blocks than
+    // it was sized for.
+    constexpr uint32_t kGrowable = kErrTableOverflow | kErrEntityOverflow;
+    for (int attempt = 0; (err & kGrowable) != 0u &&
+             (err & ~kGrowable) == 0u && attempt < 8; attempt++) {
         const uint32_t before = exec->numGrowths;
-        rc = growTablesFromDevice(exec);
-        if (rc != 0) return rc;
+        if ((err & kErrEntityOverflow) != 0u && exec->entityVm != nullptr) {
+            int32_t wanted = 0;     // (pass 1 keeps counting past the end)
+            HIPCHK(hipMemcpy(&wanted, (char *)exec->stateDev +
+                offsetof(EcsState, numIds), sizeof(wanted),
+                hipMemcpyDeviceToHost));
+            rc = growEntityStore(exec, std::max<uint64_t>(
+                (uint64_t)wanted + (uint64_t)wanted / 4,
+                2ull * (uint64_t)hs.entityCapacity));
+            if (rc != 0) return rc;
+            rc = pokeState(exec, &EcsState::entityCapacity, hs.entityCapacity);
+            if (rc != 0) return rc;
+        }
+        if ((err & kErrTableOverflow) != 0u) {
+            rc = growTablesFromDevice(exec);
+            if (rc != 0) return rc;
+        }
         if (exec->numGrowths == before) {
             break;      // nothing left to grow: report the overflow
         }
@@ -2048,9 +2159,16 @@ static int constructWorlds(mwhip_exec *exec)
         bases[w] = (int32_t)next;
         next += (int64_t)caches[w].initBlocksUsed * kIdsPerBlock;
     }
-    if (next > hs.entityCapacity) {
-        return fail(-4, "world construction failed: %s",
-                    describeError(kErrEntityOverflow));
+    if (next + (int64_t)kIdsPerBlock > hs.entityCapacity) {
+        if (exec->entityVm == nullptr) {
+            return fail(-4, "world construction failed: %s",
+                        describeError(kErrEntityOverflow));
+        }
+        rc = growEntityStore(exec, (uint64_t)next + (uint64_t)next / 4 +
+                                   kIdsPerBlock);
+        if (rc != 0) return rc;
+        rc = pokeState(exec, &EcsState::entityCapacity, hs.entityCapacity);
+        if (rc != 0) return rc;
     }
 
     rc = resetForInitPass(exec);
@@ -2536,10 +2654,31 @@ static void serviceGrowRequests(mwhip_exec *exec)
             break;
         }
     }
+    for (uint32_t slot : { kGrowSlotEntities, kGrowSlotTmp }) {
+        if (__atomic_load_n(&mb->requested[slot], __ATOMIC_RELAXED) >
+                mb->capacity[slot]) {
+            pending = true;
+        }
+    }
     if (!pending) return;
 
     std::lock_guard<std::mutex> guard(exec->growMutex);
     (void)hipSetDevice(exec->cfg.gpu_id);
+    {
+        const int64_t ids = __atomic_load_n(&mb->requested[kGrowSlotEntities],
+                                            __ATOMIC_RELAXED);
+        if (ids > mb->capacity[kGrowSlotEntities] && exec->entityVm != nullptr) {
+            // a layer of run-time blocks (one per world) at least
+            (void)growEntityStore(exec, std::max<uint64_t>(
+                2ull * (uint64_t)ids, 2ull * (uint64_t)exec->hostState.entityCapacity));
+        }
+        const int64_t kib = __atomic_load_n(&mb->requested[kGrowSlotTmp],
+                                            __ATOMIC_RELAXED);
+        if (kib > mb->capacity[kGrowSlotTmp] && exec->tmpVm != nullptr) {
+            (void)growTmpRegion(exec, std::max<uint64_t>(
+                2ull * ((uint64_t)kib << 10), 2ull * exec->hostState.tmpCapacity));
+        }
+    }
     for (uint32_t a = 0; a < exec->archetypes.size() && a < kMaxArchetypes; a++) {
         ArchetypeRec &arch = exec->archetypes[a];
         const int64_t wanted = __atomic_load_n(&mb->requested[a], __ATOMIC_RELAXED);
@@ -2625,6 +2764,13 @@ static int growTables(mwhip_exec *exec, RowsFn &&rows_of)
         HIPCHK(hipMemcpy((char *)(exec->hostState.tables + a) +
                              offsetof(TableHdr, capacity),
                          &cap, sizeof(cap), hipMemcpyHostToDevice));
+    }
+    {
+        int rc = pokeState(exec, &EcsState::entityCapacity,
+                           exec->hostState.entityCapacity);
+        if (rc != 0) return rc;
+        rc = pokeState(exec, &EcsState::tmpCapacity, exec->hostState.tmpCapacity);
+        if (rc != 0) return rc;
     }
     exec->headersStale = false;
 

@@ -133,9 +133,15 @@ struct HostPrintRing {
 // executor's service thread to map more behind the table's columns (addresses
 // do not change); the reference's device code asks its host thread the same
 // way (src/mw/device/memory.cpp:27-121, src/mw/cuda_exec.cpp:1603-1719).
+// (two more slots after the archetypes': the entity store, in ids, and the
+// per-step scratch region of Context::tmpAlloc, in KiB)
+inline constexpr uint32_t kGrowSlotEntities = kMaxArchetypes;
+inline constexpr uint32_t kGrowSlotTmp = kMaxArchetypes + 1;
+inline constexpr uint32_t kGrowSlots = kMaxArchetypes + 2;
+
 struct GrowMailbox {
-    int32_t capacity[kMaxArchetypes];   // rows mapped; written by the host
-    int32_t requested[kMaxArchetypes];  // rows wanted; raised by the device
+    int32_t capacity[kGrowSlots];       // rows mapped; written by the host
+    int32_t requested[kGrowSlots];      // rows wanted; raised by the device
     uint32_t serviceEnabled;            // a host thread is answering
     // diagnostics of the first append that gave up: archetype, row, rows mapped
     int32_t failedArchetype;
@@ -324,6 +330,8 @@ MWHIP_DEV inline int32_t popCachedId(EcsState *S, int32_t *head, uint32_t *gen_o
 // bit for bit as long as worlds get their blocks during construction -- the
 // case for Escape-Room / Hide-and-Seek style simulators -- and are otherwise a
 // per-world renaming of them.  DESIGN.md §5.)
+MWHIP_DEV inline bool waitForMailbox(EcsState *S, uint32_t arch, int32_t row);
+
 MWHIP_DEV inline int32_t expandIdStore(EcsState *S, int32_t world, IdCache &cache)
 {
     int32_t block_start;
@@ -340,7 +348,11 @@ MWHIP_DEV inline int32_t expandIdStore(EcsState *S, int32_t world, IdCache &cach
         cache.runtimeBlocksUsed += 1;
     }
 
-    if (block_start + kIdsPerBlock > S->entityCapacity) {
+    // past what the header says is mapped: the store lives in reserved address
+    // space like the tables, the service thread maps more behind it
+    if (block_start + kIdsPerBlock > S->entityCapacity &&
+            !waitForMailbox(S, kGrowSlotEntities,
+                            block_start + kIdsPerBlock - 1)) {
         raiseError(S, kErrEntityOverflow);
         block_start = 0;
     }
@@ -506,13 +518,14 @@ MWHIP_DEV inline int32_t appendRowIssue(TableHdr &tbl)
 // the mailbox, and if the row really is unmapped, request it and wait for the
 // service thread.  Bounded: without an answer in ~0.2 s the append fails like
 // on a fixed-capacity table.
-MWHIP_DEV inline bool waitForTableMemory(EcsState *S, TableHdr &tbl, int32_t row)
+// Waits until slot `arch` of the mailbox covers unit `row` (a table row, an
+// entity id, a KiB of scratch), asking the executor's service thread for it.
+MWHIP_DEV inline bool waitForMailbox(EcsState *S, uint32_t arch, int32_t row)
 {
     GrowMailbox *mb = S->growMailbox;
     if (mb == nullptr) {
         return false;
     }
-    const uint32_t arch = (uint32_t)(&tbl - tablesOf(S));
     if (row < __hip_atomic_load(&mb->capacity[arch], __ATOMIC_ACQUIRE,
                                 __HIP_MEMORY_SCOPE_SYSTEM)) {
         return true;
@@ -538,6 +551,11 @@ MWHIP_DEV inline bool waitForTableMemory(EcsState *S, TableHdr &tbl, int32_t row
         }
     }
     return false;
+}
+
+MWHIP_DEV inline bool waitForTableMemory(EcsState *S, TableHdr &tbl, int32_t row)
+{
+    return waitForMailbox(S, (uint32_t)(&tbl - tablesOf(S)), row);
 }
 
 MWHIP_DEV inline int32_t appendRowCheck(EcsState *S, TableHdr &tbl, int32_t row)

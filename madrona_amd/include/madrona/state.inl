@@ -592,7 +592,11 @@ MADRONA_HD void *StateManager::tmpAlloc(uint64_t num_bytes)
     unsigned long long off = __hip_atomic_fetch_add(&tmpOffset,
         (unsigned long long)num_bytes, __ATOMIC_RELAXED,
         __HIP_MEMORY_SCOPE_AGENT);
-    if (off + num_bytes > tmpCapacity) {
+    // (the region grows like a table: reserved address space, more of it mapped
+    // on request)
+    if (off + num_bytes > tmpCapacity &&
+            !mwhip::waitForMailbox(this, mwhip::kGrowSlotTmp,
+                (int32_t)((off + num_bytes + 1023ull) >> 10) - 1)) {
         mwhip::raiseError(this, mwhip::kErrTmpOverflow);
         return tmpBase;
     }

@@ -39,7 +39,11 @@ def _worker(rank, world_size, port, sim_name, out_dir):
     sys.path.insert(0, REPO)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    # (a rendezvous that cannot complete -- the port taken between _free_port()
+    # and here -- fails after a minute instead of gloo's default half hour)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world_size,
+                            timeout=datetime.timedelta(seconds=60))
     try:
         names, total_worlds, steps = CASES[sim_name]
         shard = shard_for(rank, world_size, total_worlds=total_worlds)
@@ -74,9 +78,14 @@ def test_two_rank_allgather_is_partition_invariant(built, tmp_path, sim_name):
     if not os.path.exists(ref_lib_path(sim_name)):
         pytest.skip("oracle/_ref not built here (no /root/reference)")
     names, total_worlds, steps = CASES[sim_name]
-    port = _free_port()
-    mp.spawn(_worker, args=(2, port, sim_name, str(tmp_path)), nprocs=2,
-             join=True)
+    for attempt in range(3):
+        try:
+            mp.spawn(_worker, args=(2, _free_port(), sim_name, str(tmp_path)),
+                     nprocs=2, join=True)
+            break
+        except Exception:       # noqa: BLE001 -- a lost rendezvous: new port
+            if attempt == 2:
+                raise
     got = np.load(os.path.join(str(tmp_path), "gathered.npz"))
 
     # one process owning all worlds must produce the same tensors bit for bit

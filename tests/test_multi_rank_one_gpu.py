@@ -47,7 +47,9 @@ def _worker(rank, world_size, port, out_dir):
     from madrona_amd.simlib import Simulator, hip_lib_path
 
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world_size,
+                            timeout=datetime.timedelta(seconds=90))
     try:
         shard = shard_for(rank, world_size, total_worlds=TOTAL_WORLDS)
 

@@ -639,3 +639,49 @@ def test_tables_grow_under_a_queue_of_replays(built, monkeypatch):
             probs = compare_columns(r.dump_all(), h.dump_all())
             assert not probs, (chunk, probs[:3])
         assert rt.mwhip_num_table_growths(h.hip_exec()) >= grown_at_start + 3
+
+
+def test_entity_store_and_scratch_region_grow(built, monkeypatch):
+    """The entity store and the Context::tmpAlloc region live in reserved address
+    space like the tables.  Started at a sixty-fourth of their
+    default sizes: the world constructors already outrun the id store (it grows
+    between the constructor passes), the first steps outrun the 1 MiB scratch
+    region and the ids (requests through the mailbox while the replay runs).
+    Results stay bit-identical to the reference; worlds that start empty take
+    run-time id blocks from memory mapped on demand."""
+    import ctypes as C
+    from madrona_amd.simlib import runtime_lib
+    _need_ref("sort_stress")
+    monkeypatch.setenv("MADRONA_MWHIP_INITIAL_ID_CAPACITY_DIV", "64")
+    monkeypatch.setenv("MADRONA_MWHIP_TMP_MB", "1")
+    rt = runtime_lib()
+    rt.mwhip_num_table_growths.restype = C.c_uint32
+    rt.mwhip_num_table_growths.argtypes = [C.c_void_p]
+
+    # populated worlds: ids bit for bit (one 256-byte scratch block per world and
+    # step: 6000 worlds ask for 1.5 MiB)
+    W, steps = 6000, 24
+    with Simulator(ref_lib_path("sort_stress"), W, seed=3, num_workers=1) as r, \
+            Simulator(hip_lib_path("sort_stress"), W, seed=3) as h:
+        for chunk in range(steps // 8):
+            r.step(8)
+            h.step_async(8)
+            h.sync()
+            probs = compare_columns(r.dump_all(), h.dump_all())
+            assert not probs, (chunk, probs[:3])
+        assert rt.mwhip_num_table_growths(h.hip_exec()) >= 2
+
+    # worlds that start empty: run-time id blocks (ids are a renaming, above)
+    W = 255
+    with Simulator(ref_lib_path("sort_stress"), W, seed=7, num_workers=1, flags=1) as r, \
+            Simulator(hip_lib_path("sort_stress"), W, seed=7, flags=1) as h:
+        r.step(30)
+        h.step(30)
+        ref, hip = r.dump_all(), h.dump_all()
+        ref_ids = ref.pop("Item.Entity")[0].view(np.int32).reshape(-1, 2)
+        hip_ids = hip.pop("Item.Entity")[0].view(np.int32).reshape(-1, 2)
+        assert not compare_columns(ref, hip)
+        assert np.array_equal(ref_ids[:, 0], hip_ids[:, 0])
+        pairs = np.unique(np.stack([ref_ids[:, 1], hip_ids[:, 1]], 1), axis=0)
+        assert len(np.unique(pairs[:, 0])) == len(pairs) == len(np.unique(pairs[:, 1]))
+        assert rt.mwhip_num_table_growths(h.hip_exec()) >= 1
