@@ -21,8 +21,9 @@ struct SimTraits;
 namespace {
 
 // flags: bit 0 = RenderingSystem::setupTasks(update_visual_properties = true),
+// bit 1 = depth only, bit 2 = crowded worlds,
 // bits 8-15 = ray caster output resolution (HIP backend; 0 = ray caster off)
-constexpr uint32_t kMaxRecordsPerWorld = 64;
+constexpr uint32_t kMaxRecordsPerWorld = 128;
 
 #ifdef SIM_BACKEND_REF_CPU
 // What the reference's Vulkan renderer would own: the buffers its CPU-mode
@@ -118,7 +119,7 @@ struct SimTraits {
         bridge = &b;
 #endif
         return Sim::Config { args.seed, args.world_base, args.flags & 1u,
-                             bridge };
+                             (args.flags >> 2) & 1u, bridge };
     }
 
     static void makeInits(const SimCreateArgs &, Sim::WorldInit *) {}

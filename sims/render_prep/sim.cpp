@@ -99,7 +99,7 @@ inline void churnSystem(Engine &ctx, Roster &roster)
         roster.movers[victim] = roster.movers[roster.numMovers - 1];
         roster.hidden[victim] = roster.hidden[roster.numMovers - 1];
         roster.numMovers -= 1;
-    } else if (action <= 4 && roster.numMovers < consts::maxMovers) {
+    } else if (action <= 4 && roster.numMovers < sim.moverCap) {
         roster.movers[roster.numMovers] = makeMover(ctx, rng);
         roster.hidden[roster.numMovers] = 0;
         roster.numMovers += 1;
@@ -169,12 +169,15 @@ Sim::Sim(Engine &ctx, const Config &cfg, const WorldInit &)
     RNG init_rng(rand::split_i(rand::initKey(cfg.seed), global_world));
     step = 0;
 
+    moverCap = cfg.dense != 0u ? consts::maxMovers : consts::sparseMovers;
+
     RenderingSystem::init(ctx, cfg.bridge);
 
     Roster &roster = ctx.singleton<Roster>();
     roster.numMovers = 0;
     roster.numHidden = 0;
-    int32_t initial = 3 + (int32_t)(global_world * 5u % 14u);
+    int32_t initial = cfg.dense != 0u ? 70 + (int32_t)(global_world * 7u % 26u) :
+                                        3 + (int32_t)(global_world * 5u % 14u);
     for (int32_t i = 0; i < initial; i++) {
         roster.movers[i] = makeMover(ctx, init_rng);
         roster.hidden[i] = 0;

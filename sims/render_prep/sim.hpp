@@ -25,7 +25,10 @@ using madrona::base::Rotation;
 using madrona::base::Scale;
 
 namespace consts {
-inline constexpr int32_t maxMovers = 24;
+inline constexpr int32_t maxMovers = 96;
+// population cap of an ordinary (not crowded) world: its entities fit the one
+// block of 64 ids a world takes during construction
+inline constexpr int32_t sparseMovers = 24;
 inline constexpr int32_t numViewers = 2;
 inline constexpr int32_t numObjects = 4;
 inline constexpr float arena = 7.f;
@@ -88,6 +91,9 @@ struct Sim : public madrona::WorldBase {
         uint32_t worldBase;
         // RenderingSystem::setupTasks(update_visual_properties)
         uint32_t updateVisuals;
+        // crowded worlds: 70 .. 95 movers from the start (more instances than
+        // the ray caster keeps in LDS per world)
+        uint32_t dense;
         // reference CPU backend: the buffers its systems append to
         const madrona::render::RenderECSBridge *bridge;
     };
@@ -105,6 +111,7 @@ struct Sim : public madrona::WorldBase {
     Entity viewers[consts::numViewers];
     Entity lamp;
     Entity sun;     // every third world: a second, directional light
+    int32_t moverCap;
     uint32_t step;
 };
 

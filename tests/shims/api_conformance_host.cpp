@@ -3,6 +3,8 @@
 // physics loader, importer structs, containers, py::Tensor -- compiled as plain
 // host C++ and exercised through a few C entry points (tests/test_api_
 // conformance.py; nothing here needs a GPU until conf_run is called).
+#define MADRONA_TRACING 1
+#include <madrona/tracing.hpp>
 #include <madrona/mw_gpu.hpp>
 #include <madrona/exec_mode.hpp>
 #include <madrona/importer.hpp>
@@ -97,6 +99,23 @@ API int conf_containers()
     lock.lock();
     if (lock.tryLock()) return 16;
     lock.unlock();
+    return 0;
+}
+
+// host tracing with the reference's interface: three events, then the log file
+// (<dir><trace name>_madrona_host_tracing.bin: N codes, then N time stamps)
+API int conf_tracing(const char *dir)
+{
+    HOST_TRACING.events.clear();
+    HOST_TRACING.time_stamps.clear();
+    HostEventLogging(HostEvent::initStart);
+    HostEventLogging(HostEvent::initEnd);
+    HostEventLogging(HostEvent::megaKernelStart);
+    if (HOST_TRACING.events.size() != 3 ||
+            HOST_TRACING.time_stamps[2] < HOST_TRACING.time_stamps[0]) {
+        return 1;
+    }
+    FinalizeLogging(dir);
     return 0;
 }
 

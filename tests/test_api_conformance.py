@@ -46,6 +46,17 @@ def test_host_containers_and_atomics(conf):
     assert conf.conf_containers() == 0
 
 
+def test_host_tracing_log(conf, tmp_path, monkeypatch):
+    """madrona/tracing.hpp (reference include/madrona/tracing.hpp,
+    src/common/tracing.cpp:44-58): N event codes, then N time stamps, int64."""
+    monkeypatch.setenv("MADRONA_MWGPU_TRACE_NAME", "conf")
+    conf.conf_tracing.argtypes = [C.c_char_p]
+    assert conf.conf_tracing((str(tmp_path) + "/").encode()) == 0
+    log = np.fromfile(tmp_path / "conf_madrona_host_tracing.bin", dtype=np.int64)
+    assert log.shape == (6,) and log[:3].tolist() == [0, 1, 2]
+    assert log[3] <= log[4] <= log[5]
+
+
 def test_py_tensor_reference_constructor(conf):
     buf = np.zeros((4, 3, 2), dtype=np.float32)
     dims = (C.c_int64 * 3)(4, 3, 2)

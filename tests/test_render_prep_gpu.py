@@ -44,7 +44,7 @@ def _bridge(sim, kind, worlds):
     sim.lib.render_prep_bridge_records.argtypes = [C.c_int32, C.c_void_p, C.c_void_p,
                                                    C.c_uint64]
     size = 64 if kind == 0 else 48
-    cap = worlds * 64
+    cap = worlds * 128
     rec = np.zeros((cap, size), np.uint8)
     keys = np.zeros(cap, np.uint64)
     n = sim.lib.render_prep_bridge_records(kind, rec.ctypes.data, keys.ctypes.data, cap)
