@@ -37,7 +37,8 @@ struct alignas(16) PreparedInstance {
     math::Quat invRotation;
     math::Diag3x3 invScale;
     math::Vector3 position;
-    uint32_t pad0[2];
+    uint32_t objectID;
+    uint32_t isBox;             // the object is an axis-aligned box (objectBounds)
     uint32_t nodeOffset;        // first node of the object's tree
     uint32_t triangleOffset;    // first triangle of the object
     int32_t valid;              // 0: no volume (all-zero scale) or no such object
@@ -52,6 +53,10 @@ struct RenderGeometryDev {
     const uint32_t *objectNodeOffset;       // [numObjects + 1]
     const uint32_t *objectTriangleOffset;   // [numObjects + 1]
     const int32_t *objectMaterial;          // [numObjects], -1: none (white)
+    const float *objectBounds;              // [numObjects][6] object-space min, max
+    const uint32_t *objectIsBox;            // [numObjects] mesh == its bounds, faces outward
+    const uint32_t *objectBoxFaces;         // [numObjects][12] the two triangles of face
+                                            // axis * 2 + (max side), object-local ids
     const float *materialColor;             // rgb per material
 };
 
@@ -65,6 +70,8 @@ struct RenderGeometryHost {
     std::vector<int32_t> objectMaterial;
     std::vector<float> materialColor;
     std::vector<float> objectRootBox;       // 6 per object: what TLBVHNode uses
+    std::vector<uint32_t> objectIsBox;      // the mesh IS that box (12 outward triangles)
+    std::vector<uint32_t> objectBoxFaces;   // 12 per object (leaf-order triangle ids)
 };
 
 struct RenderParams {

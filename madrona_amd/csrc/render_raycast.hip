@@ -132,12 +132,13 @@ __device__ inline PreparedInstance prepareInstance(const InstanceRec &inst,
     PreparedInstance p;
     p.invRotation = inst.rotation.inv();
     p.invScale = inst.scale.inv();
-    p.pad0[0] = p.pad0[1] = 0;
     p.position = inst.position;
     const bool has_volume = !(inst.scale.d0 == 0.f && inst.scale.d1 == 0.f &&
                               inst.scale.d2 == 0.f);
     const bool known = (uint32_t)inst.objectID < geo.numObjects;
     const uint32_t obj = known ? (uint32_t)inst.objectID : 0u;
+    p.objectID = obj;
+    p.isBox = geo.objectIsBox[obj];
     p.nodeOffset = geo.objectNodeOffset[obj];
     p.triangleOffset = geo.objectTriangleOffset[obj];
     p.valid = has_volume && known ? 1 : 0;
@@ -422,7 +423,27 @@ struct WorldView {
 struct GeoView {
     const BvhNode *nodes;
     const Vector3 *triangles;
+    const float *bounds;        // 6 per object
+    const uint32_t *boxFaces;   // 12 per object
 };
+
+// shear constants of Woop's test: exact division for the axis the hit distance
+// is measured along (reference computeRayIsectInfo, :228-270)
+__device__ inline RayIsect rayIsect(const Vector3 &d)
+{
+    const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    RayIsect isect;
+    isect.kz = (ax > ay && ax > az) ? 0 : (ay > az ? 1 : 2);
+    isect.kx = isect.kz + 1 == 3 ? 0 : isect.kz + 1;
+    isect.ky = isect.kx + 1 == 3 ? 0 : isect.kx + 1;
+    if (comp(d, isect.kz) < 0.f) {
+        const int32_t t = isect.kx; isect.kx = isect.ky; isect.ky = t;
+    }
+    isect.Sz = 1.f / comp(d, isect.kz);
+    isect.Sx = comp(d, isect.kx) * isect.Sz;
+    isect.Sy = comp(d, isect.ky) * isect.Sz;
+    return isect;
+}
 
 // closest hit of the ray against one instance's triangles: the ray goes to
 // object space, t is rescaled on the way in and out (reference :627-646,
@@ -443,24 +464,69 @@ __device__ __forceinline__ void traceInstance(
     const float t_scale = d.length();
     t_max *= t_scale;
     d /= t_scale;
+
+    const Vector3 *tris = geo.triangles + 3u * (size_t)inst.triangleOffset;
     const SlabRay slab = slabRay(o, d);
 
-    // shear constants: exact division for the axis the hit distance is measured
-    // along (reference computeRayIsectInfo, :228-270)
-    const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
-    RayIsect isect;
-    isect.kz = (ax > ay && ax > az) ? 0 : (ay > az ? 1 : 2);
-    isect.kx = isect.kz + 1 == 3 ? 0 : isect.kz + 1;
-    isect.ky = isect.kx + 1 == 3 ? 0 : isect.kx + 1;
-    if (comp(d, isect.kz) < 0.f) {
-        const int32_t t = isect.kx; isect.kx = isect.ky; isect.ky = t;
+    if (inst.isBox != 0u) {
+        // The mesh is its own bounding box (12 outward triangles): a ray from
+        // outside can only hit the face through which it enters the slabs (from
+        // inside every face is a back face: culled).  The slabs pick the face,
+        // its two triangles go through the reference's test -- the same t, bit
+        // for bit -- instead of a tree walk over all twelve.
+        const float *b = geo.bounds + 6u * inst.objectID;
+        const float tx0 = fmaf(b[0], slab.inv.x, -slab.oInv.x);
+        const float tx1 = fmaf(b[3], slab.inv.x, -slab.oInv.x);
+        const float ty0 = fmaf(b[1], slab.inv.y, -slab.oInv.y);
+        const float ty1 = fmaf(b[4], slab.inv.y, -slab.oInv.y);
+        const float tz0 = fmaf(b[2], slab.inv.z, -slab.oInv.z);
+        const float tz1 = fmaf(b[5], slab.inv.z, -slab.oInv.z);
+        const float nx = fminf(tx0, tx1), ny = fminf(ty0, ty1), nz = fminf(tz0, tz1);
+        const float t_near = fmaxf(fmaxf(nx, ny), nz);
+        const float t_far = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)),
+                                  fminf(fmaxf(tz0, tz1), t_max));
+        if (t_near <= fmaf(t_far, 1.00001f, 1e-6f)) {
+            const RayIsect isect = rayIsect(d);
+            const uint32_t axis = nx >= ny && nx >= nz ? 0u : (ny >= nz ? 1u : 2u);
+            const float dir = axis == 0u ? d.x : (axis == 1u ? d.y : d.z);
+            const uint32_t face = axis * 2u + (dir > 0.f ? 0u : 1u);
+            const uint32_t *face_tris =
+                geo.boxFaces + 12u * inst.objectID + 2u * face;
+            bool found = false;
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const uint32_t tri_idx = face_tris[k];
+                const Vector3 *tri = tris + 3u * (size_t)tri_idx;
+                float t;
+                if (rayTriangle(tri[0], tri[1], tri[2], isect, o, t_max, &t)) {
+                    t_max = t;
+                    best.hit = true;
+                    best.instance = inst_idx;
+                    best.triangle = inst.triangleOffset + tri_idx;
+                    found = true;
+                }
+            }
+            // (a ray grazing an edge of the box: the slabs and the watertight
+            // test may disagree about the face -- all twelve, then)
+            if (!found && fabsf(t_near - t_far) <= 1e-4f * fabsf(t_far) + 1e-6f) {
+                for (uint32_t tri_idx = 0; tri_idx < 12u; tri_idx++) {
+                    const Vector3 *tri = tris + 3u * (size_t)tri_idx;
+                    float t;
+                    if (rayTriangle(tri[0], tri[1], tri[2], isect, o, t_max, &t)) {
+                        t_max = t;
+                        best.hit = true;
+                        best.instance = inst_idx;
+                        best.triangle = inst.triangleOffset + tri_idx;
+                    }
+                }
+            }
+        }
+        t_max = t_max / t_scale;
+        return;
     }
-    isect.Sz = 1.f / comp(d, isect.kz);
-    isect.Sx = comp(d, isect.kx) * isect.Sz;
-    isect.Sy = comp(d, isect.ky) * isect.Sz;
 
+    const RayIsect isect = rayIsect(d);
     const BvhNode *nodes = geo.nodes + inst.nodeOffset;
-    const Vector3 *tris = geo.triangles + 3u * (size_t)inst.triangleOffset;
 
     uint32_t sp = sp_base;
     uint32_t cur = 0;
@@ -622,11 +688,23 @@ renderRaycast(EcsState *S, RenderParams params)
         for (uint32_t i = tid; i < tri_dw; i += 256u) {
             lds.geo[node_dw + i] = ((const uint32_t *)geo_dev.triangleVertices)[i];
         }
+        const uint32_t bounds_dw = geo_dev.numObjects * 6u;
+        for (uint32_t i = tid; i < bounds_dw; i += 256u) {
+            lds.geo[node_dw + tri_dw + i] = ((const uint32_t *)geo_dev.objectBounds)[i];
+        }
+        const uint32_t faces_dw = geo_dev.numObjects * 12u;
+        for (uint32_t i = tid; i < faces_dw; i += 256u) {
+            lds.geo[node_dw + tri_dw + bounds_dw + i] = geo_dev.objectBoxFaces[i];
+        }
         geo.nodes = (const BvhNode *)&lds.geo[0];
         geo.triangles = (const Vector3 *)&lds.geo[node_dw];
+        geo.bounds = (const float *)&lds.geo[node_dw + tri_dw];
+        geo.boxFaces = &lds.geo[node_dw + tri_dw + bounds_dw];
     } else {
         geo.nodes = geo_dev.nodes;
         geo.triangles = geo_dev.triangleVertices;
+        geo.bounds = geo_dev.objectBounds;
+        geo.boxFaces = geo_dev.objectBoxFaces;
     }
 
     uint8_t *rgb_out = (uint8_t *)out_tbl.columns[params.rgbColumn];
@@ -827,6 +905,63 @@ AABB boxOf(const std::vector<BuildTri> &tris, uint32_t first, uint32_t count)
 
 constexpr uint32_t kLeafTris = 4;
 
+// Is the mesh exactly its own axis-aligned bounding box, seen from outside:
+// twelve triangles, each flat on one face with its normal pointing out, the
+// two of a face covering it?  (What the ray caster may then intersect as slabs.)
+bool meshIsItsBounds(const std::vector<BuildTri> &tris, uint32_t *face_tris)
+{
+    if (tris.size() != 12) {
+        return false;
+    }
+    const AABB box = boxOf(tris, 0, 12);
+    const float lo[3] = { box.pMin.x, box.pMin.y, box.pMin.z };
+    const float hi[3] = { box.pMax.x, box.pMax.y, box.pMax.z };
+    for (int a = 0; a < 3; a++) {
+        if (!(hi[a] > lo[a])) return false;
+    }
+    double face_area[6] = { 0, 0, 0, 0, 0, 0 };
+    int face_count[6] = { 0, 0, 0, 0, 0, 0 };
+    for (size_t tri_idx = 0; tri_idx < tris.size(); tri_idx++) {
+        const BuildTri &t = tris[tri_idx];
+        int face = -1;
+        for (int a = 0; a < 3 && face < 0; a++) {
+            if (t.v[a] == lo[a] && t.v[3 + a] == lo[a] && t.v[6 + a] == lo[a]) {
+                face = 2 * a;
+            } else if (t.v[a] == hi[a] && t.v[3 + a] == hi[a] &&
+                       t.v[6 + a] == hi[a]) {
+                face = 2 * a + 1;
+            }
+        }
+        if (face < 0) return false;
+        // every vertex a corner of the box
+        for (int k = 0; k < 9; k++) {
+            if (t.v[k] != lo[k % 3] && t.v[k] != hi[k % 3]) return false;
+        }
+        const double e1[3] = { (double)t.v[3] - t.v[0], (double)t.v[4] - t.v[1],
+                               (double)t.v[5] - t.v[2] };
+        const double e2[3] = { (double)t.v[6] - t.v[0], (double)t.v[7] - t.v[1],
+                               (double)t.v[8] - t.v[2] };
+        const double n[3] = { e1[1] * e2[2] - e1[2] * e2[1],
+                              e1[2] * e2[0] - e1[0] * e2[2],
+                              e1[0] * e2[1] - e1[1] * e2[0] };
+        const int a = face / 2;
+        const double outward = (face & 1) != 0 ? n[a] : -n[a];
+        if (!(outward > 0.0) || face_count[face] >= 2) return false;
+        face_area[face] += 0.5 * outward;
+        face_tris[2 * face + face_count[face]++] = (uint32_t)tri_idx;
+    }
+    for (int a = 0; a < 3; a++) {
+        const double want = ((double)hi[(a + 1) % 3] - lo[(a + 1) % 3]) *
+                            ((double)hi[(a + 2) % 3] - lo[(a + 2) % 3]);
+        for (int side = 0; side < 2; side++) {
+            if (std::fabs(face_area[2 * a + side] - want) > 1e-6 * want) {
+                return false;
+            }
+        }
+    }
+    return true;
+}
+
 // node `node_idx` covers triangles [first, first + count), count > kLeafTris:
 // median split along the widest axis of the centroids
 void buildBlas(std::vector<BuildTri> &tris, uint32_t first, uint32_t count,
@@ -877,6 +1012,8 @@ int buildRenderGeometry(const mwhip_render_geometry &src, RenderGeometryHost &ou
     out.objectTriangleOffset.assign(src.num_objects + 1, 0);
     out.objectRootBox.assign((size_t)src.num_objects * 6, 0.f);
     out.objectMaterial.assign(src.num_objects, -1);
+    out.objectIsBox.assign(src.num_objects, 0u);
+    out.objectBoxFaces.assign((size_t)src.num_objects * 12, 0u);
     if (src.object_material != nullptr) {
         out.objectMaterial.assign(src.object_material,
                                   src.object_material + src.num_objects);
@@ -940,6 +1077,9 @@ int buildRenderGeometry(const mwhip_render_geometry &src, RenderGeometryHost &ou
             out.triangleVertices.insert(out.triangleVertices.end(), t.v, t.v + 9);
         }
         if (tri_count > 0) {
+            // (tris are in leaf order by now: ids as the trace kernel sees them)
+            out.objectIsBox[obj] = meshIsItsBounds(
+                tris, out.objectBoxFaces.data() + 12 * (size_t)obj) ? 1u : 0u;
             const AABB root = boxOf(tris, 0, tri_count);
             float *rb = out.objectRootBox.data() + 6 * (size_t)obj;
             rb[0] = root.pMin.x; rb[1] = root.pMin.y; rb[2] = root.pMin.z;
@@ -969,7 +1109,8 @@ void buildRenderLaunches(EcsState *state_dev, const RenderParams &params,
     {
         KernelLaunch k;
         const bool geo_in_lds = params.numGeoNodes * 16u +
-            params.numGeoTriangles * 9u <= kGeoLdsDwords;
+            params.numGeoTriangles * 9u + params.geometry.numObjects * 18u <=
+                kGeoLdsDwords;
         k.fn = geo_in_lds ? (const void *)&renderRaycast<true> :
                             (const void *)&renderRaycast<false>;
         const uint32_t tiles_per_side = (params.resolution + 15u) / 16u;

@@ -1069,6 +1069,15 @@ static int uploadRenderGeometry(mwhip_exec *exec)
     rc = upload(g.objectMaterial.data(), g.objectMaterial.size() * 4,
                 (const void **)&d.objectMaterial);
     if (rc != 0) return rc;
+    rc = upload(g.objectRootBox.data(), g.objectRootBox.size() * 4,
+                (const void **)&d.objectBounds);
+    if (rc != 0) return rc;
+    rc = upload(g.objectIsBox.data(), g.objectIsBox.size() * 4,
+                (const void **)&d.objectIsBox);
+    if (rc != 0) return rc;
+    rc = upload(g.objectBoxFaces.data(), g.objectBoxFaces.size() * 4,
+                (const void **)&d.objectBoxFaces);
+    if (rc != 0) return rc;
     return upload(g.materialColor.data(), g.materialColor.size() * 4,
                   (const void **)&d.materialColor);
 }
