@@ -415,8 +415,8 @@ struct Hit {
 };
 
 struct WorldView {
-    const BvhNode *nodes;                  // LDS or HBM
-    const PreparedInstance *prepared;      // LDS or HBM
+    const BvhNode *nodes;                  // HBM (worlds too big for the LDS slot)
+    const PreparedInstance *prepared;
     int32_t numInstances;
 };
 
@@ -584,11 +584,17 @@ __device__ __forceinline__ void traceInstance(
     t_max = t_max / t_scale;
 }
 
-template <bool AnyHit, bool GeoInLds>
+// Staged: the world's nodes and instances are the workgroup's LDS copies (known
+// at compile time, so that they are read with LDS instructions, not through
+// flat pointers)
+template <bool AnyHit, bool Staged, bool GeoInLds>
 __device__ __forceinline__ Hit traceWorld(
-    EcsState *S, const GeoView &geo, const WorldView &w, const Vector3 &o, const Vector3 &d, float t_max,
-    TraceLDS<GeoInLds> *lds, uint32_t tid)
+    EcsState *S, const GeoView &geo, const WorldView &w, const Vector3 &o,
+    const Vector3 &d, float t_max, TraceLDS<GeoInLds> *lds, uint32_t tid)
 {
+    const BvhNode *world_nodes = Staged ? lds->nodes : w.nodes;
+    const PreparedInstance *world_instances = Staged ? lds->instances : w.prepared;
+
     Hit best;
     best.hit = false;
     best.t = 0.f;
@@ -603,7 +609,7 @@ __device__ __forceinline__ Hit traceWorld(
     uint32_t sp = 0;
     uint32_t cur = 0;       // internal node index
     while (true) {
-        const BvhNode node = w.nodes[cur];
+        const BvhNode node = world_nodes[cur];
         float entry[2];
 #pragma unroll
         for (int c = 0; c < 2; c++) {
@@ -621,7 +627,7 @@ __device__ __forceinline__ Hit traceWorld(
             const uint32_t child = node.child[c];
             if ((child & kLeafBit) != 0u) {
                 const int32_t idx = (int32_t)(child & ~kLeafBit);
-                traceInstance<AnyHit>(S, geo, w.prepared[idx], idx, o, d, t_max,
+                traceInstance<AnyHit>(S, geo, world_instances[idx], idx, o, d, t_max,
                                       best, lds, sp, tid);
                 if constexpr (AnyHit) {
                     if (best.hit) {
@@ -766,8 +772,8 @@ renderRaycast(EcsState *S, RenderParams params)
         }
 
         WorldView wv;
-        wv.nodes = staged ? lds.nodes : nodes_hbm;
-        wv.prepared = staged ? lds.instances : prepared_hbm;
+        wv.nodes = nodes_hbm;
+        wv.prepared = prepared_hbm;
         wv.numInstances = num_inst;
 
         const uint32_t px = (tile_in_view % tiles_per_side) * 16u + (tid & 15u);
@@ -794,8 +800,11 @@ renderRaycast(EcsState *S, RenderParams params)
         const Vector3 ray_dir = (lower_left + pixel_u * horizontal +
                                  pixel_v * vertical - ray_start).normalize();
 
-        const Hit first = traceWorld<false>(S, geo, wv, ray_start,
-                                            ray_dir, 10000.f, &lds, tid);
+        const Hit first = staged ?
+            traceWorld<false, true>(S, geo, wv, ray_start, ray_dir, 10000.f, &lds,
+                                    tid) :
+            traceWorld<false, false>(S, geo, wv, ray_start, ray_dir, 10000.f,
+                                     &lds, tid);
 
         const uint32_t pixel = px + py * res;
         float depth = 0.f;
@@ -847,8 +856,11 @@ renderRaycast(EcsState *S, RenderParams params)
                         if (light_dir.dot(normal) > 0.f) {
                             // (any hit will do: the reference looks for the
                             // closest one and only asks whether there is one)
-                            const Hit shadow = traceWorld<true>(S, geo,
-                                wv, hit_pos, light_dir, 10000.f, &lds, tid);
+                            const Hit shadow = staged ?
+                                traceWorld<true, true>(S, geo, wv, hit_pos,
+                                    light_dir, 10000.f, &lds, tid) :
+                                traceWorld<true, false>(S, geo, wv, hit_pos,
+                                    light_dir, 10000.f, &lds, tid);
                             if (!shadow.hit) {
                                 light_contrib += fminf(fmaxf(
                                     normal.dot(light_dir), 0.f), 1.f);
