@@ -391,7 +391,7 @@ __device__ inline float boxEntry(const AABB &b, const SlabRay &r, float t_max)
 
 constexpr uint32_t kStackDepth = 24;
 // bottom-level trees + triangles of all objects are kept in LDS when they fit
-constexpr uint32_t kGeoLdsDwords = 8192;
+constexpr uint32_t kGeoLdsDwords = 7680;
 
 template <bool GeoInLds>
 struct TraceLDS {
@@ -401,6 +401,11 @@ struct TraceLDS {
     BvhNode nodes[maxInstances];
     PreparedInstance instances[maxInstances];
     LightRec lights[maxLights];
+    // world-space boxes of the instances, and the ones the current tile's
+    // frustum touches, near to far
+    AABB leafBox[maxInstances];
+    uint32_t tileCount;
+    uint8_t tileList[maxInstances];
     // traversal stack (both levels), one column per thread
     uint16_t stack[kStackDepth][256];
     // [nodes of every object][triangle vertices of every object]
@@ -655,6 +660,33 @@ __device__ __forceinline__ Hit traceWorld(
     return best;
 }
 
+// Primary rays of a tile whose world is staged: instead of a top-level walk per
+// ray, the instances the tile's frustum touches (culled once per tile by one
+// wavefront, ordered near to far) are tried in turn behind their own box test.
+template <bool GeoInLds>
+__device__ __forceinline__ Hit traceTileList(
+    EcsState *S, const GeoView &geo, const Vector3 &o, const Vector3 &d,
+    float t_max, TraceLDS<GeoInLds> *lds, uint32_t tid)
+{
+    Hit best;
+    best.hit = false;
+    best.t = 0.f;
+    best.instance = -1;
+    best.triangle = 0;
+
+    const SlabRay slab = slabRay(o, d);
+    const uint32_t n = lds->tileCount;
+    for (uint32_t k = 0; k < n; k++) {
+        const uint32_t idx = lds->tileList[k];
+        if (boxEntry(lds->leafBox[idx], slab, t_max) <= t_max) {
+            traceInstance<false>(S, geo, lds->instances[idx], (int32_t)idx, o, d,
+                                 t_max, best, lds, 0u, tid);
+        }
+    }
+    best.t = t_max;
+    return best;
+}
+
 __device__ inline Vector3 hexToRgb(uint32_t hex)
 {
     return Vector3 { (float)((hex >> 16) & 0xFFu) / 255.f,
@@ -760,6 +792,11 @@ renderRaycast(EcsState *S, RenderParams params)
                 for (uint32_t i = tid; i < node_dw; i += 256u) {
                     ((uint32_t *)lds.nodes)[i] = ((const uint32_t *)nodes_hbm)[i];
                 }
+                const LeafBox *boxes_hbm = (const LeafBox *)
+                    inst_tbl.columns[params.tlbvhColumn] + inst_first;
+                if ((int32_t)tid < num_inst) {
+                    lds.leafBox[tid] = boxes_hbm[tid].aabb;
+                }
             }
             const uint32_t light_dw = (uint32_t)num_lights * 10u;
             const uint32_t *src = (const uint32_t *)((const LightRec *)
@@ -776,13 +813,12 @@ renderRaycast(EcsState *S, RenderParams params)
         wv.prepared = prepared_hbm;
         wv.numInstances = num_inst;
 
-        const uint32_t px = (tile_in_view % tiles_per_side) * 16u + (tid & 15u);
-        const uint32_t py = (tile_in_view / tiles_per_side) * 16u + (tid >> 4);
-        if (px >= res || py >= res) {
-            continue;
-        }
+        const uint32_t tile_x = (tile_in_view % tiles_per_side) * 16u;
+        const uint32_t tile_y = (tile_in_view / tiles_per_side) * 16u;
+        const uint32_t px = tile_x + (tid & 15u);
+        const uint32_t py = tile_y + (tid >> 4);
 
-        // ---- primary ray (reference calculateOutRay, :58-88) -------------------
+        // ---- the view's rays (reference calculateOutRay, :58-88) --------------
         const Quat rot = view.rotation;
         const Vector3 ray_start = view.position;
         const Vector3 look_at = rot.inv().rotateVec(Vector3 { 0.f, 1.f, 0.f });
@@ -795,14 +831,84 @@ renderRaycast(EcsState *S, RenderParams params)
         const Vector3 vertical = v * viewport;
         const Vector3 lower_left =
             ray_start - horizontal / 2.f - vertical / 2.f + forward;
+
+        // ---- which instances can the tile's rays meet at all -------------------
+        if (staged) {
+            __syncthreads();        // the previous tile's list is not read any more
+            if (tid < 64u) {
+                // frustum through the outer edges of the tile's pixels
+                const float u0 = (float)tile_x / (float)res;
+                const float v0 = (float)tile_y / (float)res;
+                const float u1 = (float)(tile_x + 16u < res ? tile_x + 16u : res) /
+                                 (float)res;
+                const float v1 = (float)(tile_y + 16u < res ? tile_y + 16u : res) /
+                                 (float)res;
+                const Vector3 base = lower_left - ray_start;
+                const Vector3 corner[4] = {
+                    base + u0 * horizontal + v0 * vertical,
+                    base + u1 * horizontal + v0 * vertical,
+                    base + u1 * horizontal + v1 * vertical,
+                    base + u0 * horizontal + v1 * vertical,
+                };
+                const Vector3 centre = corner[0] + corner[2];
+
+                bool inside = (int32_t)tid < num_inst &&
+                              lds.instances[tid < 64u ? tid : 0u].valid != 0;
+                const AABB box = lds.leafBox[tid < (uint32_t)lds.maxInstances ?
+                                             tid : 0u];
+                const Vector3 lo = box.pMin - ray_start;
+                const Vector3 hi = box.pMax - ray_start;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    Vector3 n = math::cross(corner[k], corner[(k + 1) & 3]);
+                    if (n.dot(centre) < 0.f) {
+                        n = -n;
+                    }
+                    // the box corner furthest along the inward normal
+                    const float reach = n.x * (n.x > 0.f ? hi.x : lo.x) +
+                                        n.y * (n.y > 0.f ? hi.y : lo.y) +
+                                        n.z * (n.z > 0.f ? hi.z : lo.z);
+                    // (a margin: culling must never lose an instance a ray hits)
+                    inside = inside && reach >= -1e-4f * (fabsf(n.x) + fabsf(n.y) +
+                                                          fabsf(n.z));
+                }
+                const float ahead = forward.x * (forward.x > 0.f ? hi.x : lo.x) +
+                                    forward.y * (forward.y > 0.f ? hi.y : lo.y) +
+                                    forward.z * (forward.z > 0.f ? hi.z : lo.z);
+                inside = inside && ahead >= 0.f;
+                // near to far by where the box starts along the view direction
+                const float key = forward.x * (forward.x > 0.f ? lo.x : hi.x) +
+                                  forward.y * (forward.y > 0.f ? lo.y : hi.y) +
+                                  forward.z * (forward.z > 0.f ? lo.z : hi.z);
+
+                const uint64_t mask = __builtin_amdgcn_ballot_w64(inside);
+                uint32_t rank = 0;
+                for (uint64_t m = mask; m != 0; m &= m - 1) {
+                    const uint32_t j = (uint32_t)__builtin_ctzll(m);
+                    const float other = __shfl(key, (int)j);
+                    rank += (other < key || (other == key && j < tid)) ? 1u : 0u;
+                }
+                if (inside) {
+                    lds.tileList[rank] = (uint8_t)tid;
+                }
+                if (tid == 0u) {
+                    lds.tileCount = (uint32_t)__builtin_popcountll(mask);
+                }
+            }
+            __syncthreads();
+        }
+
+        if (px >= res || py >= res) {
+            continue;
+        }
+
         const float pixel_u = ((float)px + 0.5f) / (float)res;
         const float pixel_v = ((float)py + 0.5f) / (float)res;
         const Vector3 ray_dir = (lower_left + pixel_u * horizontal +
                                  pixel_v * vertical - ray_start).normalize();
 
         const Hit first = staged ?
-            traceWorld<false, true>(S, geo, wv, ray_start, ray_dir, 10000.f, &lds,
-                                    tid) :
+            traceTileList(S, geo, ray_start, ray_dir, 10000.f, &lds, tid) :
             traceWorld<false, false>(S, geo, wv, ray_start, ray_dir, 10000.f,
                                      &lds, tid);
 
