@@ -391,7 +391,41 @@ __device__ inline float boxEntry(const AABB &b, const SlabRay &r, float t_max)
 
 constexpr uint32_t kStackDepth = 24;
 // bottom-level trees + triangles of all objects are kept in LDS when they fit
-constexpr uint32_t kGeoLdsDwords = 7680;
+constexpr uint32_t kGeoLdsDwords = 7168;
+
+// what shading a hit on an instance needs: its rotation (normals) and its colour
+// (material / override resolved once per instance, reference traceRay :772-812;
+// one untextured material per object here)
+struct alignas(16) ShadeRec {
+    Quat rotation;
+    Vector3 color;
+    uint32_t pad;
+};
+
+__device__ inline ShadeRec shadeRecord(const InstanceRec &inst,
+                                       const RenderGeometryDev &geo)
+{
+    int32_t material = inst.matID;
+    if (material == -1) {
+        material = (uint32_t)inst.objectID < geo.numObjects ?
+            geo.objectMaterial[inst.objectID] : -1;
+    }
+    Vector3 color { 1.f, 1.f, 1.f };
+    if (inst.matID == -2) {
+        color = Vector3 { (float)((inst.color >> 16) & 0xFFu) / 255.f,
+                          (float)((inst.color >> 8) & 0xFFu) / 255.f,
+                          (float)(inst.color & 0xFFu) / 255.f };
+    } else if (material >= 0 && (uint32_t)material < geo.numMaterials) {
+        color = Vector3 { geo.materialColor[3 * material],
+                          geo.materialColor[3 * material + 1],
+                          geo.materialColor[3 * material + 2] };
+    }
+    ShadeRec rec;
+    rec.rotation = inst.rotation;
+    rec.color = color;
+    rec.pad = 0;
+    return rec;
+}
 
 template <bool GeoInLds>
 struct TraceLDS {
@@ -404,6 +438,7 @@ struct TraceLDS {
     // world-space boxes of the instances, and the ones the current tile's
     // frustum touches, near to far
     AABB leafBox[maxInstances];
+    ShadeRec shade[maxInstances];
     uint32_t tileCount;
     uint8_t tileList[maxInstances];
     // traversal stack (both levels), one column per thread
@@ -687,13 +722,6 @@ __device__ __forceinline__ Hit traceTileList(
     return best;
 }
 
-__device__ inline Vector3 hexToRgb(uint32_t hex)
-{
-    return Vector3 { (float)((hex >> 16) & 0xFFu) / 255.f,
-                     (float)((hex >> 8) & 0xFFu) / 255.f,
-                     (float)(hex & 0xFFu) / 255.f };
-}
-
 // Workgroups stride over the 16 x 16 tiles of all views.  GeoInLds: the
 // bottom-level trees and triangles of every object are copied to LDS once per
 // workgroup (they fit: kGeoLdsDwords), so that only the image leaves the CU.
@@ -796,6 +824,7 @@ renderRaycast(EcsState *S, RenderParams params)
                     inst_tbl.columns[params.tlbvhColumn] + inst_first;
                 if ((int32_t)tid < num_inst) {
                     lds.leafBox[tid] = boxes_hbm[tid].aabb;
+                    lds.shade[tid] = shadeRecord(inst_hbm[tid], geo_dev);
                 }
             }
             const uint32_t light_dw = (uint32_t)num_lights * 10u;
@@ -918,28 +947,14 @@ renderRaycast(EcsState *S, RenderParams params)
         if (first.hit) {
             depth = first.t;
             if (params.rgbd != 0u) {
-                const InstanceRec inst = inst_hbm[first.instance];
-                // reference traceRay, :772-812 (one material per object here,
-                // untextured)
-                int32_t material = inst.matID;
-                if (material == -1) {
-                    material = (uint32_t)inst.objectID < geo_dev.numObjects ?
-                        geo_dev.objectMaterial[inst.objectID] : -1;
-                }
-                Vector3 color { 1.f, 1.f, 1.f };
-                if (inst.matID == -2) {
-                    color = hexToRgb(inst.color);
-                } else if (material >= 0 &&
-                           (uint32_t)material < geo_dev.numMaterials) {
-                    color = Vector3 { geo_dev.materialColor[3 * material],
-                                      geo_dev.materialColor[3 * material + 1],
-                                      geo_dev.materialColor[3 * material + 2] };
-                }
+                const ShadeRec shade = staged ? lds.shade[first.instance] :
+                    shadeRecord(inst_hbm[first.instance], geo_dev);
+                const Vector3 color = shade.color;
                 // geometric normal of the hit triangle (reference :443-446)
                 const Vector3 *tri = geo.triangles + 3u * (size_t)first.triangle;
                 const Vector3 obj_normal =
                     math::cross(tri[1] - tri[0], tri[2] - tri[0]).normalize();
-                const Vector3 normal = inst.rotation.rotateVec(obj_normal);
+                const Vector3 normal = shade.rotation.rotateVec(obj_normal);
                 const Vector3 hit_pos = ray_start + first.t * ray_dir;
 
                 // ---- lights (reference computeFragment, :840-930) -------------
