@@ -261,9 +261,14 @@ MADRONA_HOST_API inline TaskGraphNodeID setupTasks(
         mortonCodeUpdate,
             Entity, Position, Renderable>>({node});
 
-    // instances: drop destroyed rows, order by Morton code, group by world again
-    // (stable: Morton order survives inside each world)
-    node = builder.addToGraph<CompactArchetypeNode<RenderableArchetype>>({node});
+    // instances: order by Morton code, then group by world (stable: Morton
+    // order survives inside each world) dropping the destroyed rows.  The
+    // reference compacts the table before the Morton sort as well
+    // (ecs_system.cpp:551-566); the table that leaves the three chains is the
+    // same without it -- both sorts are stable, and a compaction keeps the
+    // relative order of a world's rows, which is all that decides ties between
+    // equal codes -- so that chain (two key passes and a gather of every column,
+    // every step) is left out.
     node = builder.addToGraph<
         SortArchetypeNode<RenderableArchetype, MortonCode>>({node});
     node = builder.addToGraph<ResetTmpAllocNode>({node});

@@ -1,7 +1,7 @@
 // Render-prep test simulator (BASELINE config 5's ECS side):
 // worlds of drifting, appearing, disappearing and hidden renderable entities,
 // two viewers and a lamp, stepped through madrona::render::RenderingSystem --
-// instance / view / light records, Morton codes, and the six sort chains of its
+// instance / view / light records, Morton codes, and the sort chains of its
 // task graph (reference src/render/ecs_system.cpp:486-597), including the only
 // SortArchetypeNode over non-WorldID keys any reference system uses.  Compiled
 // unchanged against the reference (CPU mode: records go to RenderECSBridge

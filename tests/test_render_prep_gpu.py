@@ -1,6 +1,6 @@
 """GPU: the render-prep ECS systems (reference
 src/render/ecs_system.cpp) on sims/render_prep -- instance / view / light
-records, Morton codes, and the six sort chains of RenderingSystem::setupTasks,
+records, Morton codes, and the sort chains of RenderingSystem::setupTasks,
 two of them SortArchetypeNode over non-WorldID keys.
 
 Oracle: the reference itself, stepped in lock step.  Its CPU mode writes
