@@ -105,7 +105,9 @@ def _compare(hip_rgb, hip_depth, ref_rgb, ref_depth, rgbd, what):
 @pytest.mark.parametrize("worlds,res,steps,flags", [
     (1, 32, 3, 1), (37, 32, 12, 1), (64, 64, 5, 1), (300, 16, 8, 0), (33, 48, 6, 1 | 2),
     # crowded worlds, 70 .. 96 instances: more than a workgroup stages in LDS
-    (21, 32, 6, 1 | 4)])
+    (21, 32, 6, 1 | 4),
+    # a resolution that is no multiple of the 16-pixel tiles
+    (9, 33, 4, 1)])
 def test_raycast_against_reference(built, worlds, res, steps, flags):
     if not os.path.exists(REF_LIB):
         pytest.skip("oracle/_ref/libraycast_ref.so missing on this box")
