@@ -795,8 +795,11 @@ renderRaycast(EcsState *S, RenderParams params)
         const int32_t inst_first = inst_tbl.worldOffsets[world];
         const int32_t num_inst = inst_tbl.worldCounts[world];
         const int32_t light_first = light_tbl.worldOffsets[world];
-        int32_t num_lights = light_tbl.worldCounts[world];
-        num_lights = num_lights < lds.maxLights ? num_lights : lds.maxLights;
+        const int32_t num_lights = light_tbl.worldCounts[world];
+        const int32_t staged_lights =
+            num_lights < lds.maxLights ? num_lights : lds.maxLights;
+        const LightRec *lights_hbm = (const LightRec *)
+            light_tbl.columns[params.lightColumn] + light_first;
 
         const InstanceRec *inst_hbm =
             (const InstanceRec *)inst_tbl.columns[params.instanceColumn] +
@@ -827,7 +830,7 @@ renderRaycast(EcsState *S, RenderParams params)
                     lds.shade[tid] = shadeRecord(inst_hbm[tid], geo_dev);
                 }
             }
-            const uint32_t light_dw = (uint32_t)num_lights * 10u;
+            const uint32_t light_dw = (uint32_t)staged_lights * 10u;
             const uint32_t *src = (const uint32_t *)((const LightRec *)
                 light_tbl.columns[params.lightColumn] + light_first);
             for (uint32_t i = tid; i < light_dw; i += 256u) {
@@ -960,7 +963,9 @@ renderRaycast(EcsState *S, RenderParams params)
                 // ---- lights (reference computeFragment, :840-930) -------------
                 float light_contrib = 0.f;
                 for (int32_t i = 0; i < num_lights; i++) {
-                    const LightRec light = lds.lights[i];
+                    // (the first few of a world's lights are in LDS)
+                    const LightRec light = i < lds.maxLights ? lds.lights[i] :
+                                                               lights_hbm[i];
                     Vector3 light_dir = -light.direction;
                     if (!light.directional) {
                         light_dir = (light.position - hit_pos).normalize();

@@ -224,6 +224,24 @@ Sim::Sim(Engine &ctx, const Config &cfg, const WorldInit &)
         RenderingSystem::makeEntityLightCarrier(ctx, sun);
     }
 
+    // crowded worlds are also lit from all sides: more lights than the ray caster
+    // keeps next to the CU
+    if (cfg.dense != 0u) {
+        for (int32_t i = 0; i < 10; i++) {
+            Entity extra = ctx.makeEntity<Lamp>();
+            ctx.get<Position>(extra) = Vector3 { (float)i, 0.f, 20.f };
+            ctx.get<LightDescDirection>(extra) = LightDescDirection(Vector3 {
+                0.125f * (float)(i - 5), 0.0625f * (float)((i * 3) % 7 - 3),
+                -0.25f - 0.0625f * (float)i });
+            ctx.get<LightDescType>(extra).type = LightDesc::Directional;
+            ctx.get<LightDescShadow>(extra).castShadow = i == 9;
+            ctx.get<LightDescCutoffAngle>(extra).cutoff = -1.f;
+            ctx.get<LightDescIntensity>(extra).intensity = 1.f;
+            ctx.get<LightDescActive>(extra).active = true;
+            RenderingSystem::makeEntityLightCarrier(ctx, extra);
+        }
+    }
+
     rng = init_rng;
 }
 
