@@ -297,6 +297,71 @@ def run_single(sim_name, worlds, gpu_id, seed, denom, steps, warmup, profile_rep
     }
 
 
+def cpu_raycast_sample(sim, worlds, resolution, sample_worlds=8192):
+    """cpu_baseline leg of config 5's render pass: the reference's own ray caster
+    (src/mw/device/bvh_raycast.cpp compiled for the host, oracle/_ref/
+    libraycast_ref.so) over the instance / view / light rows of the first
+    `sample_worlds` worlds, one thread per host core.  Its QBVHs are built by the
+    oracle shim (median splits), not by Embree: a reported baseline only."""
+    import ctypes as C
+    import numpy as np
+    path = os.path.join(REPO, "oracle", "_ref", "libraycast_ref.so")
+    if not os.path.exists(path):
+        return None
+    lib = C.CDLL(path)
+    p = C.c_void_p
+    lib.raycast_ref_render.restype = C.c_int
+    lib.raycast_ref_render.argtypes = [C.c_uint32, p, p, p, p, p, C.c_uint32, p,
+                                       C.c_uint32, p, p, p, p, C.c_uint32, p, p, p,
+                                       C.c_uint32, C.c_uint32, C.c_uint32, p, p]
+    geo = sim.lib.sim_render_geometry
+    geo.restype = C.c_int32
+    geo.argtypes = [p] * 7
+    counts = np.zeros(3, np.uint32)
+    n_obj = geo(None, None, None, None, None, None, counts.ctypes.data)
+    verts = np.zeros((counts[0], 3), np.float32)
+    idx = np.zeros((counts[1], 3), np.uint32)
+    voff = np.zeros(n_obj + 1, np.uint32)
+    toff = np.zeros(n_obj + 1, np.uint32)
+    mats = np.zeros((counts[2], 3), np.float32)
+    omat = np.zeros(n_obj, np.int32)
+    geo(verts.ctypes.data, idx.ctypes.data, voff.ctypes.data, toff.ctypes.data,
+        mats.ctypes.data, omat.ctypes.data, None)
+
+    d = sim.dump_all()
+    inst, ic = d["Renderable.InstanceData"]
+    views, vc = d["Camera.PerspectiveCameraData"]
+    lights, lc = d["Light.LightDesc"]
+    W = min(sample_worlds, worlds)
+    ic, vc, lc = ic[:W], vc[:W], lc[:W]
+    offs = lambda c: np.concatenate([[0], np.cumsum(c)[:-1]]).astype(np.int32)
+    nv = int(vc.sum())
+    inst = np.ascontiguousarray(inst[:int(ic.sum())])
+    views = np.ascontiguousarray(views[:nv])
+    lights = np.ascontiguousarray(lights[:max(int(lc.sum()), 1)])
+    io, lo = offs(ic), offs(lc)
+    rgb = np.zeros((nv, resolution, resolution, 4), np.uint8)
+    depth = np.zeros((nv, resolution, resolution), np.float32)
+    cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    rc = lib.raycast_ref_render(
+        n_obj, verts.ctypes.data, idx.ctypes.data, voff.ctypes.data, toff.ctypes.data,
+        omat.ctypes.data, len(mats), mats.ctypes.data, W, inst.ctypes.data,
+        io.ctypes.data, np.ascontiguousarray(ic, np.int32).ctypes.data,
+        views.ctypes.data, nv, lights.ctypes.data, lo.ctypes.data,
+        np.ascontiguousarray(lc, np.int32).ctypes.data, resolution, 1,
+        min(cores, resolution), rgb.ctypes.data, depth.ctypes.data)
+    dt = time.perf_counter() - t0
+    if rc != 0:
+        return None
+    return {"value": nv / dt, "unit": "views/s", "cores": min(cores, resolution),
+            "kind": "reference",
+            "sample": f"{nv} views of {resolution}x{resolution} RGB-D ({W} worlds, "
+                      f"{dt:.2f} s incl. building its BVHs) through the reference's "
+                      f"bvhRaycastEntry compiled for the host (oracle/ref_shims/"
+                      f"raycast_ref_shim.cpp)"}
+
+
 def run_render(worlds, gpu_id, seed, denom, steps, warmup, profile_reps, settle,
                resolution=64, cpu_sample=True):
     """BASELINE.json configs[4]: the physics Escape Room + the batch ray caster,
@@ -326,6 +391,7 @@ def run_render(worlds, gpu_id, seed, denom, steps, warmup, profile_reps, settle,
         sim.sync()
         step_stats = sim.profile(profile_reps)
         render_stats = sim.profile(profile_reps, graph=render)
+        cpu_views = cpu_raycast_sample(sim, worlds, resolution) if cpu_sample else None
         views = worlds * AGENTS["escape_room_phys"]
         # instances per world: floor, 4 borders, 2 agents, 3 x (2 walls, door, 4
         # cubes, 2 buttons)
@@ -348,6 +414,8 @@ def run_render(worlds, gpu_id, seed, denom, steps, warmup, profile_reps, settle,
         "step_graph_us": round(sum(k["avg_us"] for k in step_stats), 1),
         "render_graph_us": round(sum(k["avg_us"] for k in render_stats), 1),
         "primary_rays_per_s": rays / (cast_us * 1e-6) if cast_us > 0 else None,
+        "views_per_s_render_pass": views / (sum(k["avg_us"] for k in render_stats) * 1e-6),
+        "cpu_baseline_render_pass": cpu_views,
         "roofline": {
             "kernel": "render:raycast (16x16 tile of one view per workgroup, world's "
                       "TLAS + instances in LDS, binary BVH traversal, shading)",
@@ -519,7 +587,8 @@ def main():
     if (rank == 0 and world_size == 1 and args.sim == "escape_room_phys"
             and not args.no_secondary):
         render = run_render(args.worlds, local_rank, seed, args.auto_reset_denom,
-                            200, 30, 10, min(args.settle, 200))
+                            200, 30, 10, min(args.settle, 200),
+                            cpu_sample=not args.no_cpu_baseline)
 
     dist_world = dist.get_world_size() if distributed else 1
     if distributed:
