@@ -147,15 +147,22 @@ __device__ inline PreparedInstance prepareInstance(const InstanceRec &inst,
 }
 
 
+template <int MAXN>
 struct TlasLDS {
-    uint32_t codes[kMaxTlasLeaves];
-    uint32_t left[kMaxTlasLeaves];      // children of internal node i
-    uint32_t right[kMaxTlasLeaves];
-    int32_t parent[2 * kMaxTlasLeaves]; // [0, n-1): internal, [n-1 ..): leaves
-    uint32_t arrivals[kMaxTlasLeaves];
-    AABB box[kMaxTlasLeaves];           // internal nodes
+    uint32_t codes[MAXN];
+    uint32_t left[MAXN];                // children of internal node i
+    uint32_t right[MAXN];
+    int32_t parent[2 * MAXN];           // [0, n-1): internal, [n-1 ..): leaves
+    uint32_t arrivals[MAXN];
+    AABB box[MAXN];                     // internal nodes
 };
 
+// worlds of up to this many instances are built by the small instantiation (3 KB
+// of LDS: two dozen worlds per CU at a time instead of three), the rest by the
+// large one; each launch skips the other's worlds
+constexpr int32_t kSmallTlasLeaves = 64;
+
+template <int MAXN>
 __global__ void __launch_bounds__(64)
 renderTlasBuild(EcsState *S, RenderParams params)
 {
@@ -169,8 +176,13 @@ renderTlasBuild(EcsState *S, RenderParams params)
         return;
     }
     if (n > (int32_t)kMaxTlasLeaves || tbl.needsSort != 0u) {
-        raiseError(S, kErrRender);
+        if (MAXN == (int)kMaxTlasLeaves) {
+            raiseError(S, kErrRender);
+        }
         return;
+    }
+    if ((MAXN == kSmallTlasLeaves) != (n <= kSmallTlasLeaves)) {
+        return;     // the other instantiation's world
     }
 
     const uint32_t *codes_hbm =
@@ -200,7 +212,7 @@ renderTlasBuild(EcsState *S, RenderParams params)
         return;
     }
 
-    __shared__ TlasLDS lds;
+    __shared__ TlasLDS<MAXN> lds;
 
     for (int32_t i = (int32_t)lane; i < n; i += 64) {
         lds.codes[i] = codes_hbm[i];
@@ -1236,12 +1248,15 @@ void buildRenderLaunches(EcsState *state_dev, const RenderParams &params,
 {
     {
         KernelLaunch k;
-        k.fn = (const void *)&renderTlasBuild;
+        k.fn = (const void *)&renderTlasBuild<kSmallTlasLeaves>;
         k.grid = dim3(num_worlds, 1, 1);
         k.block = dim3(64, 1, 1);
         k.setArgs(state_dev, params);
         k.name = "render";
         k.role = "tlas.build";
+        out.push_back(k);
+        k.fn = (const void *)&renderTlasBuild<(int)kMaxTlasLeaves>;
+        k.role = "tlas.build.large";
         out.push_back(k);
     }
     {
