@@ -57,6 +57,8 @@ WORKLOADS = {
     "escape_room_phys": (8192, "Escape-Room + XPBD rigid body + LBVH broadphase, {w} "
                                "worlds per GPU (BASELINE.json configs[2]), 28 rigid "
                                "bodies + 6 buttons/world, 4 substeps, grab joints"),
+    "escape_room_render": (8192, "Escape-Room + XPBD + batch ray caster, {w} worlds "
+                                 "(BASELINE.json configs[4])"),
     "hideseek": (8192, "Hide-and-Seek-shaped: XPBD + LBVH, {w} worlds per GPU "
                        "(BASELINE.json configs[3] = 8 x 8192), 29 rigid bodies/world "
                        "(5 agents, 9 boxes, 2 wedge ramps, 12 walls, plane), lock "
@@ -456,6 +458,46 @@ def main():
     default_worlds, workload_fmt = WORKLOADS.get(args.sim, (4096, args.sim + ", {w} worlds"))
     if args.worlds <= 0:
         args.worlds = default_worlds
+
+    if args.sim == "escape_room_render":
+        # BASELINE configs[4] as the line itself (one GPU): step graph + render
+        # graph per step
+        if world_size != 1:
+            raise SystemExit("--sim escape_room_render is a one-GPU line")
+        import torch
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the HIP backend has no CPU fallback")
+        torch.cuda.set_device(local_rank)
+        if args.settle < 0:
+            args.settle = 200
+        worlds = args.worlds
+        r = run_render(worlds, local_rank, 5, args.auto_reset_denom, args.steps,
+                       args.warmup, args.profile_reps, args.settle,
+                       cpu_sample=not args.no_cpu_baseline)
+        out = {
+            "metric": "aggregate env steps/sec", "value": r["value"], "unit": "steps/s",
+            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": r["ms_per_step"], "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": f"synthetic (worlds advanced {args.settle} steps while being set "
+                    f"up; constant random actions resident in HBM)",
+            "config": {"workload": r["workload"], "sim": args.sim,
+                       "worlds_per_gpu": worlds, "settle_steps": args.settle,
+                       "total_worlds": worlds, "dist_world_size": 1,
+                       "parallelism": "worlds sharded over 1 GPU(s)"},
+            "roofline": r["roofline"],
+            "cpu_baseline": r["cpu_baseline_render_pass"],
+            "render": {k: r[k] for k in ("step_graph_us", "render_graph_us",
+                                         "primary_rays_per_s",
+                                         "views_per_s_render_pass", "tlas_build_us",
+                                         "kernels")},
+        }
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        print(json.dumps(out), flush=True)
+        return
 
     import torch
     import torch.distributed as dist
