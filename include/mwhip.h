@@ -194,6 +194,15 @@ uint32_t mwhip_num_worlds(const mwhip_exec *exec);
 void mwhip_render_config(const mwhip_exec *exec, uint32_t *resolution_out,
                          uint32_t *rgbd_out);
 uint32_t mwhip_render_max_views(const mwhip_exec *exec);
+/* Host-side preview of what mwhip_create builds from a geometry description (no
+ * GPU needed): per object the number of bottom-level BVH nodes, whether the mesh
+ * is its own axis-aligned bounds seen from outside (such objects are intersected
+ * as slabs + the two triangles of the entry face), and the object-space bounds
+ * (6 floats each).  Any output may be NULL.  Returns 0, or -1 with
+ * mwhip_last_error() set when the description is malformed. */
+int mwhip_render_geometry_info(const struct mwhip_render_geometry *geometry,
+                               uint32_t *num_nodes_out, uint32_t *is_box_out,
+                               float *bounds_out);
 int mwhip_set_render_layout(mwhip_exec *exec, const mwhip_render_layout *layout);
 /* MWCudaExecutor::buildRenderGraph (reference mw_gpu.hpp:140, cuda_exec.cpp:
  * 2294-2331): a launch graph that builds every world's top-level BVH over its

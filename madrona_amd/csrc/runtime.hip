@@ -1016,6 +1016,34 @@ extern "C" void mwhip_render_config(const mwhip_exec *exec,
     *rgbd_out = exec->cfg.raycast_rgbd;
 }
 
+extern "C" int mwhip_render_geometry_info(const mwhip_render_geometry *geometry,
+                                          uint32_t *num_nodes_out,
+                                          uint32_t *is_box_out, float *bounds_out)
+{
+    if (geometry == nullptr) {
+        return fail(-1, "render_geometry_info: null geometry");
+    }
+    RenderGeometryHost built;
+    std::string error;
+    if (buildRenderGeometry(*geometry, built, error) != 0) {
+        return fail(-1, "%s", error.c_str());
+    }
+    for (uint32_t obj = 0; obj < built.numObjects; obj++) {
+        if (num_nodes_out != nullptr) {
+            num_nodes_out[obj] =
+                built.objectNodeOffset[obj + 1] - built.objectNodeOffset[obj];
+        }
+        if (is_box_out != nullptr) {
+            is_box_out[obj] = built.objectIsBox[obj];
+        }
+    }
+    if (bounds_out != nullptr) {
+        memcpy(bounds_out, built.objectRootBox.data(),
+               built.objectRootBox.size() * sizeof(float));
+    }
+    return 0;
+}
+
 extern "C" uint32_t mwhip_render_max_views(const mwhip_exec *exec)
 {
     return exec->cfg.raycast_max_views_per_world;
