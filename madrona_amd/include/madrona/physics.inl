@@ -363,13 +363,17 @@ MADRONA_UNROLL
                 }
             }
 
+            // (until a leaf test shrinks t_max the mask IS the re-test: the box
+            // -- three dependent loads away -- is only fetched again after a hit)
+            const float mask_t_max = t_max;
             while (candidates != 0) {
                 const int32_t j = (int32_t)__builtin_ctzll(candidates);
                 candidates &= candidates - 1;
 
                 const int32_t leaf_idx = dfs_leaves_[base + j];
-                if (leafSlotBounds(leaf_idx).rayIntersects(o, inv_d, 0.f,
-                                                           t_max)) {
+                if (t_max == mask_t_max ||
+                        leafSlotBounds(leaf_idx).rayIntersects(o, inv_d, 0.f,
+                                                               t_max)) {
                     visitLeaf(leaf_idx);
                 }
             }
