@@ -406,6 +406,8 @@ def run_render(worlds, gpu_id, seed, denom, steps, warmup, profile_reps, settle,
     # what a view has to move: its world's instance records, leaf boxes and TLAS
     # nodes in, resolution^2 x (RGBA8 + f32 depth) out
     cast_bytes = views * (instances * (64 + 32 + 64) + resolution * resolution * 8)
+    cast_traffic, cast_traffic_src = traffic_for(
+        recorded_traffic(), "escape_room_render", worlds, "render:raycast")
     out = {
         "workload": f"Escape-Room + XPBD + batch ray caster, {resolution}x{resolution} "
                     f"RGB-D per agent, {worlds} worlds (BASELINE.json configs[4]), "
@@ -426,7 +428,8 @@ def run_render(worlds, gpu_id, seed, denom, steps, warmup, profile_reps, settle,
             "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(cast_bytes / (cast_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
             if cast_us > 0 else 0.0,
-            "traffic": None, "avg_us": round(cast_us, 1),
+            "traffic": cast_traffic, "traffic_source": cast_traffic_src,
+            "avg_us": round(cast_us, 1),
             "algo_bytes_per_launch": int(cast_bytes),
             "note": "traversal is instruction/latency bound: the HBM figure says how "
                     "far the kernel is from merely writing its images",
