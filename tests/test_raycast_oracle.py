@@ -141,3 +141,82 @@ def test_two_worlds_do_not_see_each_other():
     c = (res // 2, res // 2)
     dy = primary_rays(views[0], res)[c][1]
     assert abs(depth[0][c] - 2.5 / dy) < 1e-5 and abs(depth[1][c] - 5.5 / dy) < 1e-5
+
+
+def _quat_rot(q, v):
+    w, p = q[0], q[1:]
+    a = np.cross(p, v)
+    return v + 2.0 * (a * w + np.cross(p, a))
+
+
+def test_random_scene_of_every_mesh_kind_against_brute_force():
+    """Rotated, scaled instances of the four render_prep meshes (box, 168-triangle
+    ellipsoid, cylinder, wedge: bottom-level trees several levels deep in the
+    shim's builder) against a float64 Moeller-Trumbore over all triangles with
+    the reference's back-face culling."""
+    import ctypes as C
+    from madrona_amd.simlib import ref_lib_path
+    from raycast_utils import Geometry
+    lib_path = ref_lib_path("render_prep")
+    if not os.path.exists(lib_path):
+        pytest.skip("oracle/_ref/librender_prep_ref.so not built")
+    lib = C.CDLL(lib_path)
+    f = lib.sim_render_geometry
+    f.restype = C.c_int32
+    f.argtypes = [C.c_void_p] * 7
+    counts = np.zeros(3, np.uint32)
+    n_obj = f(None, None, None, None, None, None, counts.ctypes.data)
+    verts = np.zeros((counts[0], 3), np.float32)
+    idx = np.zeros((counts[1], 3), np.uint32)
+    voff = np.zeros(n_obj + 1, np.uint32)
+    toff = np.zeros(n_obj + 1, np.uint32)
+    mats = np.zeros((counts[2], 3), np.float32)
+    omat = np.zeros(n_obj, np.int32)
+    f(verts.ctypes.data, idx.ctypes.data, voff.ctypes.data, toff.ctypes.data,
+      mats.ctypes.data, omat.ctypes.data, None)
+    geo = Geometry(verts, idx, voff, toff, omat, mats)
+
+    rng = np.random.default_rng(5)
+    n = 14
+    inst = np.zeros(n, INSTANCE_DT)
+    inst["position"] = np.stack([rng.uniform(-5, 5, n), rng.uniform(3, 12, n),
+                                 rng.uniform(-3, 3, n)], -1)
+    q = rng.normal(size=(n, 4))
+    inst["rotation"] = q / np.linalg.norm(q, axis=1, keepdims=True)
+    inst["scale"] = rng.uniform(0.5, 2.0, (n, 3))
+    inst["matID"], inst["objectID"] = -1, np.arange(n) % n_obj
+    view = _view()
+    res = 48
+    _, depth = ref_render(geo, 1, inst, [0], [n], view, _sun([0, 1, 0]), [0], [1], res)
+
+    tris = []
+    for i in inst:
+        o = int(i["objectID"])
+        v = geo.vertices[voff[o]:voff[o + 1]].astype(np.float64) * i["scale"]
+        world = np.array([_quat_rot(i["rotation"].astype(np.float64), p) for p in v])
+        tris.append((world + i["position"])[geo.indices[toff[o]:toff[o + 1]]])
+    T = np.concatenate(tris)
+    e1, e2 = T[:, 1] - T[:, 0], T[:, 2] - T[:, 0]
+    normal = np.cross(e1, e2)
+    rays = primary_rays(view[0], res)
+    want = np.zeros((res, res))
+    for py in range(res):
+        for px in range(res):
+            d = rays[py, px]
+            pv = np.cross(d, e2)
+            det = (e1 * pv).sum(-1)
+            with np.errstate(all="ignore"):
+                inv = 1.0 / det
+                u = (-T[:, 0] * pv).sum(-1) * inv
+                qv = np.cross(-T[:, 0], e1)
+                v = (qv * d).sum(-1) * inv
+                t = (e2 * qv).sum(-1) * inv
+            ok = ((np.abs(det) > 1e-14) & (u >= 0) & (v >= 0) & (u + v <= 1) & (t > 0) &
+                  ((normal * d).sum(-1) < 0))        # front faces only
+            want[py, px] = t[ok].min() if ok.any() else 0.0
+    hit = want > 0
+    assert hit.mean() > 0.1
+    agree = (depth[0] > 0) == hit
+    assert agree.mean() > 0.995, float(agree.mean())
+    both = hit & (depth[0] > 0)
+    assert np.allclose(depth[0][both], want[both], rtol=1e-4)
