@@ -384,12 +384,19 @@ def run_render(worlds, gpu_id, seed, denom, steps, warmup, profile_reps, settle,
                 sim.step_async(1)
                 sim.step_async(1, graph=render)
 
+        from madrona_amd.simlib import runtime_lib
+        rt = runtime_lib()
         run(warmup)
+        torch.cuda.synchronize()
+        # marker dispatches: the rocprofv3 summaries in profiles/ are trimmed to
+        # the kernels between them (profiles/summarize_rocprof.py)
+        rt.mwhip_mark_window(sim.hip_exec(), 1)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         run(steps)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        rt.mwhip_mark_window(sim.hip_exec(), 2)
         sim.sync()
         step_stats = sim.profile(profile_reps)
         render_stats = sim.profile(profile_reps, graph=render)

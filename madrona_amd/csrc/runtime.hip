@@ -91,6 +91,7 @@ __global__ void miscOpsKernel(EcsState *S, const MiscOp *ops, uint32_t num_ops)
             tbl.peakRows = tbl.numRows;
         }
         tbl.numRows = 0;
+        tbl.sortedRows = 0;
     } else if (op.kind == kOpResetTmpAlloc) {
         S->tmpOffset = 0ull;
     }
@@ -324,7 +325,8 @@ constexpr uint32_t kStatsRows = 2;                          // [kMaxArchetypes]
 constexpr uint32_t kStatsGate = 2 + kMaxArchetypes;         // profiling gate flag
 constexpr uint32_t kStatsPeaks = 3 + kMaxArchetypes;        // [kMaxArchetypes]
 constexpr uint32_t kStatsReplays = 3 + 2 * kMaxArchetypes;  // replays completed
-constexpr uint32_t kStatsWords = 4 + 2 * kMaxArchetypes;
+constexpr uint32_t kStatsTails = 4 + 2 * kMaxArchetypes;    // [kMaxArchetypes]
+constexpr uint32_t kStatsWords = 4 + 3 * kMaxArchetypes;
 
 // report_rows == 0 (render pass): error flags and the replay counter only -- the
 // step's row statistics and high-water marks stay as its own health kernel
@@ -340,6 +342,9 @@ __global__ void statsKernel(EcsState *S, int32_t *host_out,
         host_out[kStatsPeaks + a] = tbl.registered ?
             (tbl.peakRows > tbl.numRows ? tbl.peakRows : tbl.numRows) : -1;
         tbl.peakRows = 0;
+        // longest appended tail a compaction sort of the step met
+        host_out[kStatsTails + a] = tbl.registered ? tbl.tailRows : 0;
+        tbl.tailRows = 0;
     }
     if (a == 0) {
         host_out[0] = (int32_t)S->errorFlags;
@@ -387,6 +392,13 @@ struct ArchetypeRec {
     uint32_t maxPerWorld = 0;
     bool singleton = false;
     bool bigSort = false;           // outgrew the single-launch sort once
+    // world sorts of this table take the compaction chain unless something
+    // other than world sorts reorders / truncates it (a sort by another key,
+    // ClearTmp, a scan node writing its row count: scrambled), or its appended
+    // tails keep outgrowing what one workgroup sorts (noCompact)
+    bool scrambled = false;
+    bool noCompact = false;
+    uint32_t longTails = 0;         // steps whose tail exceeded the limit
     int64_t peakSeen = 0;           // largest per-step peak reported so far
     uint32_t fillingUntil = 0;      // replay count until which the queue is kept short
     int32_t singletonOrdinal = -1;
@@ -409,6 +421,8 @@ struct ArchetypeRec {
     uint32_t *keysA = nullptr, *keysB = nullptr;
     int32_t *idxA = nullptr, *idxB = nullptr;
     unsigned long long *lookback = nullptr;
+    int32_t *tileCounts = nullptr;      // compaction chain, per prefix tile
+    int32_t *tileTailStart = nullptr;
 };
 
 struct QueryRec {
@@ -501,6 +515,10 @@ struct mwhip_exec {
     uint32_t numGrowths = 0;
     bool checkAfterRun = true;
     bool sortBatching = true;
+    // MADRONA_MWHIP_SORT_COMPACT: 0 never, 1 world sorts of tables nothing else
+    // reorders, 2 every world sort (tests: the chain is correct on any table,
+    // its one-workgroup tail sort is just slow when the whole table is "tail")
+    uint32_t sortCompaction = 1;
     uint32_t rowSnapshotMode = 1;   // 0 never, 1 nodes that can append rows, 2 all
 
     // batch ray caster: geometry (bottom-level BVHs) + where the ECS keeps what
@@ -1527,15 +1545,29 @@ static int ensureSortScratch(mwhip_exec *exec, ArchetypeRec &arch)
     size_t tiles =
         (arch.reservedCapacity + sortTileSize() - 1) / sortTileSize();
     rc = devAllocT(exec, &arch.lookback, tiles * 256);
+    if (rc != 0) return rc;
+    rc = devAllocT(exec, &arch.tileCounts, tiles + 2);
+    if (rc != 0) return rc;
+    rc = devAllocT(exec, &arch.tileTailStart, tiles + 2);
     return rc;
+}
+
+// Can the world sort of this archetype start from what the last one left?
+static bool compactionEligible(const mwhip_exec *exec, uint32_t archetype_id,
+                               uint32_t component_id)
+{
+    const ArchetypeRec &arch = exec->archetypes[archetype_id];
+    if (component_id != 1 || exec->sortCompaction == 0) return false;
+    return exec->sortCompaction == 2 || (!arch.scrambled && !arch.noCompact);
 }
 
 static int makeSortBatch(mwhip_exec *exec,
                          const std::vector<std::pair<uint32_t, uint32_t>> &specs,
-                         std::unique_ptr<SortBatch> &out)
+                         std::unique_ptr<SortBatch> &out, bool compact = false)
 {
     out.reset(new SortBatch {});
     out->stateDev = exec->stateDev;
+    out->compact = compact;
 
     std::vector<SortSite> sites;
     std::vector<GatherColumn> cols;
@@ -1584,6 +1616,8 @@ static int makeSortBatch(mwhip_exec *exec,
         site.idxB = arch.idxB;
         site.lookback = arch.lookback;
         site.state = arch.sortState;
+        site.tileCounts = arch.tileCounts;
+        site.tileTailStart = arch.tileTailStart;
         sites.push_back(site);
 
         out->maxCapacity = std::max(out->maxCapacity, arch.capacity);
@@ -1696,9 +1730,47 @@ static uint64_t queryCapacityRows(mwhip_exec *exec, uint32_t offset,
     return 0;
 }
 
+// Which tables does something other than a world sort reorder or truncate?
+// (every task graph of the executor counts, not only the ones being built: a
+// launch graph over another task graph may run in between)
+static int findScrambledTables(mwhip_exec *exec)
+{
+    for (ArchetypeRec &arch : exec->archetypes) {
+        arch.scrambled = false;
+    }
+    for (TaskGraphRec &tg : exec->taskGraphs) {
+        for (const NodeRec &node : tg.nodes) {
+            const mwhip_node_desc &d = node.desc;
+            if (d.kind == MWHIP_NODE_CLEAR_TMP ||
+                    (d.kind == MWHIP_NODE_SORT_ARCHETYPE && d.component_id != 1)) {
+                if (d.archetype_id < exec->archetypes.size()) {
+                    exec->archetypes[d.archetype_id].scrambled = true;
+                }
+            } else if (d.kind == MWHIP_NODE_EXCLUSIVE_SCAN && d.node_data_id >= 0) {
+                // a scan that writes its total into a table's row count
+                mwhip_scan_params params;
+                HIPCHK(hipMemcpy(&params, tg.dataDev[d.node_data_id],
+                                 sizeof(params), hipMemcpyDeviceToHost));
+                const char *first = (const char *)exec->hostState.tables;
+                const char *at = (const char *)params.total_out;
+                if (at >= first && at < first + exec->tablesHost.size() *
+                                                 sizeof(TableHdr)) {
+                    exec->archetypes[(size_t)(at - first) / sizeof(TableHdr)]
+                        .scrambled = true;
+                }
+            }
+        }
+    }
+    return 0;
+}
+
 static int buildLaunchList(mwhip_exec *exec, const std::vector<uint32_t> &tg_ids,
                            LaunchGraph &lg)
 {
+    {
+        int rc = findScrambledTables(exec);
+        if (rc != 0) return rc;
+    }
     for (uint32_t tg_id : tg_ids) {
         if (tg_id >= exec->taskGraphs.size()) {
             return fail(-3, "task graph %u does not exist", tg_id);
@@ -1842,17 +1914,44 @@ static int buildLaunchList(mwhip_exec *exec, const std::vector<uint32_t> &tg_ids
                     if (pending_misc.size() > 1) pending_misc.resize(1);
                 }
 
-                std::unique_ptr<SortBatch> batch;
-                rc = makeSortBatch(exec, specs, batch);
-                if (rc != 0) return rc;
-
-                size_t first = lg.launches.size();
-                buildSortLaunches(*batch, lg.launches);
-                for (size_t i = first; i < lg.launches.size(); i++) {
-                    lg.launches[i].name = name;
-                    lg.launches[i].archetype = specs[0].first;
+                // World sorts of tables that nothing else reorders start from
+                // what the last sort left (compaction chain); the rest of the
+                // batch takes the radix chain.  Sites of one batch sort
+                // different tables, so the two chains commute.
+                // (Batches of small tables stay whole: one launch either way.)
+                std::vector<std::pair<uint32_t, uint32_t>> by_chain[2];
+                bool any_compact = false;
+                for (auto &spec : specs) {
+                    any_compact = any_compact ||
+                        compactionEligible(exec, spec.first, spec.second);
                 }
-                lg.sortBatches.push_back(std::move(batch));
+                std::unique_ptr<SortBatch> whole;
+                rc = makeSortBatch(exec, specs, whole, false);
+                if (rc != 0) return rc;
+                const bool split = any_compact && !whole->small;
+                for (auto &spec : specs) {
+                    by_chain[split && compactionEligible(exec, spec.first,
+                                                         spec.second) ?
+                             1 : 0].push_back(spec);
+                }
+                for (int chain = 0; chain < 2; chain++) {
+                    if (by_chain[chain].empty()) continue;
+                    std::unique_ptr<SortBatch> batch;
+                    if (!split) {
+                        batch = std::move(whole);
+                    } else {
+                        rc = makeSortBatch(exec, by_chain[chain], batch, chain == 1);
+                        if (rc != 0) return rc;
+                    }
+
+                    size_t first = lg.launches.size();
+                    buildSortLaunches(*batch, lg.launches);
+                    for (size_t i = first; i < lg.launches.size(); i++) {
+                        lg.launches[i].name = name;
+                        lg.launches[i].archetype = by_chain[chain][0].first;
+                    }
+                    lg.sortBatches.push_back(std::move(batch));
+                }
                 oi = oj - 1;
             } break;
             case MWHIP_NODE_EXCLUSIVE_SCAN: {
@@ -2271,6 +2370,7 @@ extern "C" int mwhip_create(const mwhip_state_config *cfg,
     exec->taskGraphs.resize(cfg->num_task_graphs);
     exec->checkAfterRun = envU32("MADRONA_MWHIP_CHECK", 1) != 0;
     exec->sortBatching = envU32("MADRONA_MWHIP_SORT_BATCH", 1) != 0;
+    exec->sortCompaction = envU32("MADRONA_MWHIP_SORT_COMPACT", 1);
     exec->rowSnapshotMode = envU32("MADRONA_MWHIP_ROW_SNAPSHOT", 1);
     exec->tableGrowth = std::max(envU32("MADRONA_MWHIP_TABLE_GROWTH", 4), 1u);
     HIPCHK(hipStreamCreateWithFlags(&exec->stream, hipStreamNonBlocking));
@@ -2346,6 +2446,16 @@ extern "C" void mwhip_destroy(mwhip_exec *exec)
     if (exec == nullptr) return;
     (void)hipSetDevice(exec->cfg.gpu_id);
     (void)hipStreamSynchronize(exec->stream);
+    // The service thread (host prints + on-demand growth) goes first: it maps
+    // memory into the reserved ranges and walks exec->vmRanges / archetypes,
+    // all of which are released below.
+    if (exec->growMailbox != nullptr) {
+        __atomic_store_n(&exec->growMailbox->serviceEnabled, 0u, __ATOMIC_RELEASE);
+    }
+    exec->printStop.store(true);
+    if (exec->printThread.joinable()) exec->printThread.join();
+    (void)hipStreamSynchronize(exec->serviceStream);
+    drainHostPrints(exec, false);
     for (auto &kv : exec->launchGraphs) {
         if (kv.second->graphExec) (void)hipGraphExecDestroy(kv.second->graphExec);
         if (kv.second->graph) (void)hipGraphDestroy(kv.second->graph);
@@ -2354,9 +2464,6 @@ extern "C" void mwhip_destroy(mwhip_exec *exec)
         (void)hipFree(p);
     }
     vmFreeAll(exec);
-    exec->printStop.store(true);
-    if (exec->printThread.joinable()) exec->printThread.join();
-    drainHostPrints(exec, false);
     if (exec->printRing) (void)hipHostFree(exec->printRing);
     if (exec->growMailbox) (void)hipHostFree(exec->growMailbox);
     if (exec->statsHost) (void)hipHostFree(exec->statsHost);
@@ -2849,6 +2956,20 @@ static int growTablesFromDevice(mwhip_exec *exec)
 static int sortsOutgrown(mwhip_exec *exec)
 {
     bool rebuild = false;
+    // a table whose appended tails keep exceeding what the compaction chain's
+    // one workgroup sorts quickly goes back to the radix chain
+    for (uint32_t a = 0; a < exec->archetypes.size() && a < kMaxArchetypes; a++) {
+        ArchetypeRec &arch = exec->archetypes[a];
+        if (!arch.registered || arch.noCompact || exec->sortCompaction != 1) continue;
+        if ((uint32_t)std::max(exec->statsHost[kStatsTails + a], 0) >
+                sortCompactTailLimit()) {
+            exec->statsHost[kStatsTails + a] = 0;   // (counted once per report)
+            if (++arch.longTails >= 3u) {
+                arch.noCompact = true;
+                rebuild = true;
+            }
+        }
+    }
     for (auto &kv : exec->launchGraphs) {
         for (const auto &batch : kv.second->sortBatches) {
             if (!batch->small) continue;
@@ -3037,20 +3158,26 @@ extern "C" int mwhip_run_async(mwhip_exec *exec, uint64_t graph, void *hip_strea
         // population in steady state -- resets that destroy and re-create the
         // same number of rows -- does not throttle the queue)
         bool filling = false;
-        for (uint32_t a = 0; a < exec->archetypes.size(); a++) {
-            ArchetypeRec &arch = exec->archetypes[a];
-            if (!arch.registered || arch.reservedCapacity <= arch.capacity) {
-                continue;
-            }
-            const int64_t peak = exec->statsHost[kStatsPeaks + a];
-            if (peak > arch.peakSeen) {
-                arch.peakSeen = peak;
-                if (4 * peak > (int64_t)arch.capacity) {
-                    arch.fillingUntil = exec->replaysLaunched + 4u;
+        {
+            // the service thread changes arch.capacity under this lock (never
+            // held across a stream wait: a replay in flight may be waiting for
+            // that thread)
+            std::lock_guard<std::mutex> capacities(exec->growMutex);
+            for (uint32_t a = 0; a < exec->archetypes.size(); a++) {
+                ArchetypeRec &arch = exec->archetypes[a];
+                if (!arch.registered || arch.reservedCapacity <= arch.capacity) {
+                    continue;
                 }
-            }
-            if (exec->replaysLaunched < arch.fillingUntil) {
-                filling = true;
+                const int64_t peak = exec->statsHost[kStatsPeaks + a];
+                if (peak > arch.peakSeen) {
+                    arch.peakSeen = peak;
+                    if (4 * peak > (int64_t)arch.capacity) {
+                        arch.fillingUntil = exec->replaysLaunched + 4u;
+                    }
+                }
+                if (exec->replaysLaunched < arch.fillingUntil) {
+                    filling = true;
+                }
             }
         }
         static const bool limit_queue =
@@ -3499,6 +3626,12 @@ extern "C" int32_t mwhip_profile(mwhip_exec *exec, uint64_t graph, uint32_t reps
                 break;
             case SortRole::Gather: bytes = gather; break;
             case SortRole::Finalize: bytes = fin; break;
+            // The compaction chain stands in for histogram + key passes: the
+            // node keeps SURVEY 8d's algorithmic bytes (what a sort node is
+            // priced at), split over its two kernels the way the radix chain
+            // splits them; what they move is 8 N + 8 N'.
+            case SortRole::CompactPrepare: bytes = hist + pass0; break;
+            case SortRole::CompactScatter: bytes = passes_small; break;
             case SortRole::Small:
                 bytes = hist + pass0 + passes_small + gather;
                 break;

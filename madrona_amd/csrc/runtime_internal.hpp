@@ -29,6 +29,15 @@ namespace mwhip {
 //               itself works from the key / index buffers
 //   gather      old buffers (now columnsAlt) -> current buffers; one workgroup
 //               cleans the state the passes have finished with
+// Compaction chain (world sorts of tables that are still sorted from the last
+// time, see sort_archetype.hip):
+//   prepare     workgroup 0 records active / rowsIn / prefixRows / keyColumn,
+//               sorts the appended tail and assigns its rows to prefix tiles;
+//               the others count the prefix's survivors per tile
+//   scatter     workgroup 0 publishes; every tile writes the permutation and
+//               the sorted keys of its surviving rows and of the tail rows
+//               that land in it
+//   gather      as above
 struct SortState {
     uint32_t bins[4 * 256];         // digit histograms of up to 4 passes
     uint32_t numValid;              // rows whose key != 0xFFFFFFFF
@@ -41,6 +50,10 @@ struct SortState {
     unsigned long long statRowsIn;  // cumulative, for measurement
     unsigned long long statRowsOut;
     unsigned long long statRuns;
+    // compaction chain
+    int32_t prefixRows;             // rows of the sorted prefix this run starts from
+    int32_t tailLive;               // live rows behind it (sorted by world by prepare)
+    unsigned long long statTailRows;// cumulative rows behind the prefix
 };
 
 struct SortSite {
@@ -56,6 +69,10 @@ struct SortSite {
     int32_t *idxB;
     unsigned long long *lookback;   // [numTiles][256] granules
     SortState *state;
+    // compaction chain: survivors of every 2048-row tile of the sorted prefix,
+    // and for every tile the first row of the sorted tail that lands in it
+    int32_t *tileCounts;            // [numTiles]
+    int32_t *tileTailStart;         // [numTiles + 1]
 };
 
 // pseudo-column of a world-sort site: rebuild worldOffsets / worldCounts
@@ -79,7 +96,8 @@ struct SortSiteHost {
     SortState *stateDev;
 };
 
-enum class SortRole : uint32_t { None, Histogram, Onesweep, Gather, Finalize, Small };
+enum class SortRole : uint32_t { None, Histogram, Onesweep, Gather, Finalize, Small,
+                                 CompactPrepare, CompactScatter };
 
 struct SortBatch {
     std::vector<SortSiteHost> sites;
@@ -93,6 +111,9 @@ struct SortBatch {
     // of the chain.  Decided from the rows the tables hold when the graph is
     // built; the executor rebuilds its graphs when one outgrows it.
     bool small = false;
+    // every site is a world sort of a table that nothing but world sorts
+    // reorders: prepare + scatter instead of histogram + key passes
+    bool compact = false;
 };
 
 // ---- launches ------------------------------------------------------------------
@@ -148,6 +169,7 @@ struct KernelLaunch {
 int sortNumPasses(bool world_sort, uint32_t num_worlds);
 uint32_t sortTileSize();
 uint32_t sortSmallRowLimit();
+uint32_t sortCompactTailLimit();
 void buildSortLaunches(const SortBatch &batch, std::vector<KernelLaunch> &out);
 
 }

@@ -7,35 +7,61 @@
 // entity_store[e.id].loc.row updated, worldOffsets[]/worldCounts[] rebuilt.
 //
 // This is NOT the reference's CUB-derived pipeline (~20 megakernel nodes, 512
-// key tiles, every payload column moved twice).  Design for CDNA4:
-//   kernel 1  sortHistogram   per-tile LDS histograms of all P digits at once,
-//                             count of surviving rows, offsets/counts cleared
-//   kernel 2..P+1 sortOnesweep  one LSD pass each: 2048-key tiles (8 keys per
-//                             lane, 4 wave64s), wave-ballot digit matching +
-//                             mbcnt ranking, keys/indices staged through LDS
-//                             so the global scatter is digit-contiguous,
-//                             decoupled look-back through 8-byte
-//                             {epoch tag, status|count} granules stored and
-//                             polled with relaxed agent-scope atomics (no
-//                             fences needed: the data is the flag), tiles
-//                             ordered by an atomic ticket so a spinning tile's
-//                             predecessors are always resident
-//   kernel P+2 sortGather     ONE fused out-of-place gather over all columns
-//                             (grid.y = column) into the ping-pong twin of each
-//                             column, vectorised to 16/8/4-byte words so stores
-//                             are fully coalesced; entity Loc remap and world
-//                             boundary detection fused in
-//   kernel P+3 sortFinalize   empty-world fix-up, copy-back of pinned
-//                             (exported) columns, and -- by the last block to
-//                             finish -- column pointer swap, new row count,
-//                             self-cleaning of bins/counters for the next run
+// key tiles, every payload column moved twice).  Three ways through the node,
+// all ending in the same fused gather:
+//
+// (1) radix chain -- any key, any state of the table:
+//   sortHistogram    histograms of all P digits at once (few fat workgroups:
+//                    one atomic per non-empty bin per workgroup), survivors
+//   sortOnesweep x P one LSD pass each: 2048-key tiles (8 keys per lane, 4
+//                    wave64s), wave-ballot digit matching + mbcnt ranking,
+//                    keys / indices staged through LDS so the global scatter is
+//                    digit-contiguous, decoupled look-back through 8-byte
+//                    {epoch tag, status | count} granules stored and polled
+//                    with relaxed agent-scope atomics (the data is the flag;
+//                    tile = workgroup index, no tickets or arrival counters).
+//                    Workgroup 0 of the LAST pass publishes the table (column
+//                    pointer swap, new row count): nothing reads the table
+//                    until the chain ends.
+//   sortGather       ONE fused out-of-place gather of every column (grid.y =
+//                    column) from the old buffers (now the twins) into the
+//                    current ones, in 16/8/4-byte words; entity Loc remap, the
+//                    new WorldID column and the world ranges (two binary
+//                    searches per world over the sorted keys) ride along; one
+//                    workgroup cleans the state the passes are done with
+//   sortFinalize     only for batches with exported (pinned) columns: those
+//                    were gathered into their twin and are copied back
+//
+// (2) compaction chain -- world sorts of tables that nothing but world sorts
+//     reorders.  After a step such a table is what the last world sort left
+//     (rows grouped by world, TableHdr::sortedRows of them), minus the rows
+//     destroyed in place since, plus a short appended tail: radix-sorting it
+//     again moves 40 bytes per row to find out what is already known.
+//   sortCompactPrepare  workgroup 0 sorts the TAIL by world (stable, one
+//                    workgroup) and hands its rows to the prefix tiles they
+//                    land in; the others count the survivors of every
+//                    2048-row tile of the prefix
+//   sortCompactScatter  per tile: survivor flags + tail rows landing in the
+//                    tile -> one block scan -> permutation and sorted keys.
+//                    dest(prefix row i of world w) = survivors before i + tail
+//                    rows of worlds < w; dest(tail row j of world w) =
+//                    survivors before the end of w's old range + j.  No
+//                    inter-workgroup dependency (the tile counts come from the
+//                    kernel before).  Workgroup 0 publishes.
+//   sortGather / sortFinalize  as above
+//
+// (3) sortSmall -- tables that hold few rows: the whole node in one launch.
+//
 // Every kernel takes an array of sort "sites" and picks sites[blockIdx.y /
 // column map], so consecutive sort nodes of a task graph run as ONE chain.
 //
-// Algorithmic HBM bytes per sort (SURVEY.md §8d): 4N (histogram) + P*16N
+// Algorithmic HBM bytes per sort (SURVEY.md 8d): 4N (histogram) + P*16N
 // (key+index read & write per pass, first pass reads keys only) + 4N' (index
-// read) + 2*B_row*N' (every column read once, written once).
+// read) + 2*B_row*N' (every column read once, written once).  The compaction
+// chain moves 8N + 8N' instead of the first two terms.
 #include "runtime_internal.hpp"
+
+#include <cstdlib>
 
 namespace madrona {
 namespace mwhip {
@@ -216,6 +242,7 @@ __device__ inline void publishSite(EcsState *S, const SortSite &site,
         // world sort / compaction must not early-out, worldOffsets / worldCounts
         // are stale until then (reference sort_archetype.cpp:1001-1007).
         tbl.needsSort = site.worldSort ? 0u : 1u;
+        tbl.sortedRows = site.worldSort ? n_out : 0;
     }
 }
 
@@ -270,12 +297,14 @@ sortOnesweep(EcsState *S, const SortSite *sites, uint32_t pass)
 
     __shared__ OnesweepLDS lds;
 
-    // Tile = workgroup index: workgroups are dispatched in index order, so the
-    // predecessors a tile waits for in the look-back below are already running
-    // (or done).  No ticket counter: one atomic per tile on one address costs
-    // more than the rest of a small pass.
-    // (a table that grew during the replay -- on-demand growth -- has more
-    // tiles than the grid was sized for: workgroups take further rounds)
+    // Tile = workgroup index + round * grid.  Workgroups are dispatched in index
+    // order and the grid never exceeds what the chip keeps resident at once
+    // (buildSortLaunches caps it), so the predecessors a tile waits for in the
+    // look-back below are running or done: in round 0 they have a lower
+    // workgroup index, in later rounds every workgroup is resident.  No ticket
+    // counter: one atomic per tile on one address costs more than the rest of
+    // a small pass.  (Rounds beyond the first: tables of more tiles than the
+    // cap, or a table that grew during the replay -- on-demand growth.)
     for (uint32_t tile = blockIdx.x;
          (int32_t)(tile * (uint32_t)kSortTile) < n; tile += gridDim.x) {
     const int32_t tile_base = (int32_t)(tile * (uint32_t)kSortTile);
@@ -689,19 +718,14 @@ struct SmallSortLDS {
     uint32_t valid;
 };
 
-__global__ void __launch_bounds__(kSmallThreads)
-sortSmall(EcsState *S, const SortSite *sites, const GatherColumn *columns,
-          uint32_t num_columns)
+// Stable LSD radix passes over n keys by ONE kSmallThreads-wide workgroup.
+// Pass 0 reads keys0[i] (source row first_row + i); pass p writes keys / rows to
+// buffer (first_out + p) & 1 of { A, B } and reads what pass p - 1 wrote.
+// Leaves the number of keys != 0xFFFFFFFF in lds.valid (they sort last).
+__device__ inline void oneGroupRadixPasses(SmallSortLDS &lds, const SortSite &site,
+                                           const uint32_t *keys0, int32_t first_row,
+                                           int32_t n, int32_t first_out)
 {
-    const SortSite &site = sites[blockIdx.x];
-    TableHdr &tbl = S->tables[site.archetype];
-    if (site.worldSort && tbl.needsSort == 0u) {
-        return;
-    }
-
-    __shared__ SmallSortLDS lds;
-
-    const int32_t n = tbl.numRows;
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = laneId();
     const uint32_t wave = tid >> 6;
@@ -710,13 +734,13 @@ sortSmall(EcsState *S, const SortSite *sites, const GatherColumn *columns,
     if (tid == 0) lds.valid = 0;
 
     for (int32_t pass = 0; pass < site.numPasses; pass++) {
-        const uint32_t *keys_in = pass == 0 ?
-            (const uint32_t *)tbl.columns[site.keyColumn] :
-            ((pass & 1) ? site.keysA : site.keysB);
+        const bool out_b = ((first_out + pass) & 1) != 0;
+        const uint32_t *keys_in = pass == 0 ? keys0 :
+            (out_b ? site.keysA : site.keysB);
         const int32_t *idx_in = pass == 0 ? nullptr :
-            ((pass & 1) ? site.idxA : site.idxB);
-        uint32_t *keys_out = (pass & 1) ? site.keysB : site.keysA;
-        int32_t *idx_out = (pass & 1) ? site.idxB : site.idxA;
+            (out_b ? site.idxA : site.idxB);
+        uint32_t *keys_out = out_b ? site.keysB : site.keysA;
+        int32_t *idx_out = out_b ? site.idxB : site.idxA;
         const uint32_t shift = (uint32_t)pass * kRadixBits;
 
         if (tid < (uint32_t)kRadixDigits) lds.hist[tid] = 0;
@@ -766,7 +790,8 @@ sortSmall(EcsState *S, const SortSite *sites, const GatherColumn *columns,
             const int32_t i = tile + (int32_t)tid;
             const bool valid = i < n;
             const uint32_t key = valid ? keys_in[i] : 0xFFFFFFFFu;
-            const int32_t src = valid ? (idx_in != nullptr ? idx_in[i] : i) : -1;
+            const int32_t src = valid ?
+                (idx_in != nullptr ? idx_in[i] : first_row + i) : -1;
             const uint32_t digit = (key >> shift) & 0xFFu;
 
             unsigned long long match = ballot64(valid);
@@ -803,6 +828,26 @@ sortSmall(EcsState *S, const SortSite *sites, const GatherColumn *columns,
             __syncthreads();
         }
     }
+}
+
+__global__ void __launch_bounds__(kSmallThreads)
+sortSmall(EcsState *S, const SortSite *sites, const GatherColumn *columns,
+          uint32_t num_columns)
+{
+    const SortSite &site = sites[blockIdx.x];
+    TableHdr &tbl = S->tables[site.archetype];
+    if (site.worldSort && tbl.needsSort == 0u) {
+        return;
+    }
+
+    __shared__ SmallSortLDS lds;
+
+    const int32_t n = tbl.numRows;
+    const uint32_t tid = threadIdx.x;
+
+    // (pass p writes buffer p & 1: the last one lands where the gather looks)
+    oneGroupRadixPasses(lds, site, (const uint32_t *)tbl.columns[site.keyColumn],
+                        0, n, 0);
     __syncthreads();
 
     // same order as the chain: publish (swap), then gather old -> current
@@ -836,6 +881,335 @@ sortSmall(EcsState *S, const SortSite *sites, const GatherColumn *columns,
     cleanSortState(state);
 }
 
+// ---------------------------------------------------------------------------
+// compaction chain (world sorts of tables that are still sorted from last time)
+// ---------------------------------------------------------------------------
+// State of such a table when its next world sort runs:
+//   rows [0, P)   P = TableHdr::sortedRows: what the last world sort left, in
+//                 world order, some of them destroyed in place since (key
+//                 0xFFFFFFFF); worldOffsets / worldCounts still describe them
+//   rows [P, N)   appended since, any world order, some destroyed again
+// The stable sort of that is: per world, its surviving prefix rows in order,
+// then its tail rows in tail order.  With s(i) = survivors among prefix rows
+// [0, i), end(w) = worldOffsets[w] + worldCounts[w], and the live tail rows
+// sorted (stably) by world, j = index in that order:
+//   prefix row i, world w:  dest = s(i) + #{ tail rows of worlds < w }
+//   tail row j, world w:    dest = s(end(w)) + j
+// A tail row "lands" at end(w); tile t of the prefix (2048 rows) owns the tail
+// rows landing in [2048 t, 2048 (t + 1)), the last tile also those landing at P.
+// Landing points are monotone in w, so every tile owns a contiguous range of
+// the sorted tail, and #{ tail rows of worlds < w } for a prefix row i of a tile
+// = tail rows owned by earlier tiles + owned ones landing at or before i.
+constexpr int kCompactTile = kSortTile;            // prefix rows per scatter tile
+constexpr int kCompactTileShift = 11;
+static_assert((1 << kCompactTileShift) == kCompactTile);
+constexpr int kPrepTilesPerGroup = 4;              // count: 16 waves x 512 rows
+
+__device__ inline int32_t compactNumTiles(int32_t prefix)
+{
+    const int32_t t = (prefix + kCompactTile - 1) >> kCompactTileShift;
+    return t > 0 ? t : 1;
+}
+
+__global__ void __launch_bounds__(kSmallThreads)
+sortCompactPrepare(EcsState *S, const SortSite *sites)
+{
+    const SortSite &site = sites[blockIdx.y];
+    TableHdr &tbl = S->tables[site.archetype];
+    SortState *state = site.state;
+
+    // (the header does not change before the scatter kernel publishes)
+    const bool active = tbl.needsSort != 0u;
+    const int32_t n = tbl.numRows;
+    int32_t prefix = tbl.sortedRows;
+    if (prefix < 0 || prefix > n) {
+        prefix = 0;         // whatever truncated the table: everything is "tail"
+    }
+    const uint32_t *keys = (const uint32_t *)tbl.columns[site.keyColumn];
+    const uint32_t tid = threadIdx.x;
+
+    if (blockIdx.x == 0 && tid == 0) {
+        state->active = active ? 1u : 0u;
+        state->rowsIn = n;
+        state->keyColumn = keys;
+        state->prefixRows = prefix;
+    }
+    if (!active) {
+        return;
+    }
+
+    if (blockIdx.x != 0) {
+        // ---- survivors of the prefix, per scatter tile ----
+        __shared__ uint32_t tile_live[kPrepTilesPerGroup];
+        const uint32_t lane = laneId();
+        const uint32_t wave = tid >> 6;
+        const int32_t group_rows = kPrepTilesPerGroup * kCompactTile;
+        for (int32_t group = (int32_t)blockIdx.x - 1; group * group_rows < prefix;
+             group += (int32_t)gridDim.x - 1) {
+            if (tid < (uint32_t)kPrepTilesPerGroup) tile_live[tid] = 0;
+            __syncthreads();
+            // wave w: rows [512 w, 512 w + 512) of the group, lane-strided
+            const int32_t base = group * group_rows + (int32_t)wave * 512;
+            uint32_t live = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int32_t i = base + j * 64 + (int32_t)lane;
+                live += (i < prefix && keys[i] != 0xFFFFFFFFu) ? 1u : 0u;
+            }
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) {
+                live += __shfl_down(live, d, 64);
+            }
+            if (lane == 0 && live != 0) {
+                atomicAdd(&tile_live[wave >> 2], live);
+            }
+            __syncthreads();
+            if (tid < (uint32_t)kPrepTilesPerGroup) {
+                const int32_t tile = group * kPrepTilesPerGroup + (int32_t)tid;
+                if ((tile << kCompactTileShift) < prefix) {
+                    site.tileCounts[tile] = (int32_t)tile_live[tid];
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---- workgroup 0: the tail, sorted by world ----
+    __shared__ SmallSortLDS lds;
+    const int32_t tail = n - prefix;
+    // first_out = 1: the last pass lands in the buffer the gather does NOT read
+    // (the scatter kernel fills that one while tiles still read the tail)
+    oneGroupRadixPasses(lds, site, keys + prefix, prefix, tail, 1);
+    __syncthreads();
+    const int32_t tail_live = (int32_t)lds.valid;
+    const bool final_in_b = ((site.numPasses - 1) & 1) != 0;
+    const uint32_t *tail_keys = final_in_b ? site.keysA : site.keysB;
+
+    if (tid == 0) {
+        state->tailLive = tail_live;
+        state->statTailRows += (unsigned long long)tail;
+        if (tail > tbl.tailRows) {
+            tbl.tailRows = tail;
+        }
+    }
+
+    // tileTailStart[t] = first sorted tail row landing in tile t or later
+    const int32_t num_tiles = compactNumTiles(prefix);
+    const int32_t *offs = tbl.worldOffsets;
+    const int32_t *cnts = tbl.worldCounts;
+    auto tile_of = [&](uint32_t w) {
+        const int32_t land = offs[w] + cnts[w];
+        const int32_t t = land >> kCompactTileShift;
+        return t < num_tiles - 1 ? t : num_tiles - 1;
+    };
+    if (tail_live == 0) {
+        for (int32_t t = (int32_t)tid; t <= num_tiles; t += kSmallThreads) {
+            site.tileTailStart[t] = 0;
+        }
+        return;
+    }
+    for (int32_t j = (int32_t)tid; j < tail_live; j += kSmallThreads) {
+        const int32_t mine = tile_of(tail_keys[j]);
+        const int32_t before = j > 0 ? tile_of(tail_keys[j - 1]) : -1;
+        for (int32_t t = before + 1; t <= mine; t++) {
+            site.tileTailStart[t] = j;
+        }
+        if (j == tail_live - 1) {
+            for (int32_t t = mine + 1; t <= num_tiles; t++) {
+                site.tileTailStart[t] = tail_live;
+            }
+        }
+    }
+}
+
+struct alignas(16) CompactLDS {
+    uint32_t landing[kCompactTile + 4];     // tail rows landing at each position
+    uint32_t liveBefore[kCompactTile + 4];  // survivors of the tile before each position
+    unsigned long long scan[kSortWaves];
+    int32_t reduce[kSortWaves];
+};
+
+__device__ inline int32_t blockSum256(int32_t v, int32_t *scratch)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        v += __shfl_down(v, d, 64);
+    }
+    __syncthreads();
+    if (laneId() == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    int32_t total = 0;
+#pragma unroll
+    for (int w = 0; w < kSortWaves; w++) total += scratch[w];
+    return total;
+}
+
+// exclusive scan of one 64-bit value per thread across a 256-thread block
+__device__ inline unsigned long long blockExclusiveScan256U64(
+    unsigned long long v, unsigned long long *scratch)
+{
+    const uint32_t lane = laneId();
+    const uint32_t wave = threadIdx.x >> 6;
+    unsigned long long incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        unsigned long long up = __shfl_up(incl, d, 64);
+        if ((int)lane >= d) incl += up;
+    }
+    __syncthreads();
+    if (lane == 63) scratch[wave] = incl;
+    __syncthreads();
+    unsigned long long wave_base = 0;
+#pragma unroll
+    for (int w = 0; w < kSortWaves; w++) {
+        if (w < (int)wave) wave_base += scratch[w];
+    }
+    return wave_base + incl - v;
+}
+
+__global__ void __launch_bounds__(kSortThreads)
+sortCompactScatter(EcsState *S, const SortSite *sites)
+{
+    const SortSite &site = sites[blockIdx.y];
+    TableHdr &tbl = S->tables[site.archetype];
+    SortState *state = site.state;
+    if (state->active == 0u) {
+        return;
+    }
+
+    __shared__ CompactLDS lds;
+
+    const int32_t n = state->rowsIn;
+    const int32_t prefix = state->prefixRows;
+    const int32_t tail_live = state->tailLive;
+    const int32_t num_tiles = compactNumTiles(prefix);
+    const uint32_t *keys = state->keyColumn;
+    const int32_t tid = (int32_t)threadIdx.x;
+
+    const bool final_in_b = ((site.numPasses - 1) & 1) != 0;
+    uint32_t *out_keys = final_in_b ? site.keysB : site.keysA;
+    int32_t *out_rows = final_in_b ? site.idxB : site.idxA;
+    const uint32_t *tail_keys = final_in_b ? site.keysA : site.keysB;
+    const int32_t *tail_rows = final_in_b ? site.idxA : site.idxB;
+    const int32_t *offs = tbl.worldOffsets;
+    const int32_t *cnts = tbl.worldCounts;
+
+    auto tile_count = [&](int32_t t) {
+        return (t << kCompactTileShift) < prefix ? site.tileCounts[t] : 0;
+    };
+
+    if (blockIdx.x == 0) {
+        // rows the sorted table has = survivors of the prefix + live tail rows
+        int32_t part = 0;
+        for (int32_t t = tid; t < num_tiles; t += kSortThreads) {
+            part += tile_count(t);
+        }
+        const int32_t survivors = blockSum256(part, lds.reduce);
+        if (tid == 0) {
+            state->numValid = (uint32_t)(survivors + tail_live);
+        }
+        __syncthreads();
+        publishSite(S, site, tbl, n);
+        __syncthreads();
+    }
+
+    for (int32_t tile = (int32_t)blockIdx.x; tile < num_tiles;
+         tile += (int32_t)gridDim.x) {
+        const int32_t first = tile << kCompactTileShift;
+        const int32_t last = min(first + kCompactTile, prefix);
+
+        for (int32_t i = tid; i < kCompactTile + 4; i += kSortThreads) {
+            lds.landing[i] = 0;
+        }
+
+        // this thread's eight consecutive prefix rows
+        uint32_t key[kSortItems];
+        const int32_t mine = first + tid * kSortItems;
+        if (mine + kSortItems <= last) {
+            const uint4 lo = *(const uint4 *)(keys + mine);
+            const uint4 hi = *(const uint4 *)(keys + mine + 4);
+            key[0] = lo.x; key[1] = lo.y; key[2] = lo.z; key[3] = lo.w;
+            key[4] = hi.x; key[5] = hi.y; key[6] = hi.z; key[7] = hi.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < kSortItems; j++) {
+                key[j] = mine + j < last ? keys[mine + j] : 0xFFFFFFFFu;
+            }
+        }
+
+        // survivors of the tiles before this one (the sum's barriers also order
+        // the clearing of lds.landing before the atomics below)
+        int32_t part = 0;
+        for (int32_t t = tid; t < tile; t += kSortThreads) {
+            part += tile_count(t);
+        }
+        const int32_t live_before_tile = blockSum256(part, lds.reduce);
+
+        // the sorted tail rows landing in this tile
+        const int32_t tail_first = site.tileTailStart[tile];
+        const int32_t tail_end = site.tileTailStart[tile + 1];
+        for (int32_t j = tail_first + tid; j < tail_end; j += kSortThreads) {
+            const uint32_t w = tail_keys[j];
+            int32_t at = offs[w] + cnts[w] - first;
+            at = at < 0 ? 0 : (at > kCompactTile ? kCompactTile : at);
+            atomicAdd(&lds.landing[at], 1u);
+        }
+        __syncthreads();
+
+        uint32_t land[kSortItems];
+        {
+            const uint4 lo = *(const uint4 *)&lds.landing[tid * kSortItems];
+            const uint4 hi = *(const uint4 *)&lds.landing[tid * kSortItems + 4];
+            land[0] = lo.x; land[1] = lo.y; land[2] = lo.z; land[3] = lo.w;
+            land[4] = hi.x; land[5] = hi.y; land[6] = hi.z; land[7] = hi.w;
+        }
+        uint32_t my_live = 0, my_land = 0;
+#pragma unroll
+        for (int j = 0; j < kSortItems; j++) {
+            my_live += key[j] != 0xFFFFFFFFu ? 1u : 0u;
+            my_land += land[j];
+        }
+        const unsigned long long excl = blockExclusiveScan256U64(
+            (unsigned long long)my_live | ((unsigned long long)my_land << 32),
+            lds.scan);
+        uint32_t live = (uint32_t)excl;             // survivors of the tile before my rows
+        uint32_t landed = (uint32_t)(excl >> 32);   // owned tail rows landing before them
+
+        uint32_t live_at[kSortItems];
+#pragma unroll
+        for (int j = 0; j < kSortItems; j++) {
+            landed += land[j];
+            live_at[j] = live;
+            if (key[j] != 0xFFFFFFFFu) {
+                const int32_t dest = live_before_tile + (int32_t)live +
+                    tail_first + (int32_t)landed;
+                out_rows[dest] = mine + j;
+                out_keys[dest] = key[j];
+                live += 1u;
+            }
+        }
+        *(uint4 *)&lds.liveBefore[tid * kSortItems] =
+            make_uint4(live_at[0], live_at[1], live_at[2], live_at[3]);
+        *(uint4 *)&lds.liveBefore[tid * kSortItems + 4] =
+            make_uint4(live_at[4], live_at[5], live_at[6], live_at[7]);
+        if (tid == kSortThreads - 1) {
+            lds.liveBefore[kCompactTile] = live;    // the tile's survivors
+        }
+        __syncthreads();
+
+        for (int32_t j = tail_first + tid; j < tail_end; j += kSortThreads) {
+            const uint32_t w = tail_keys[j];
+            int32_t at = offs[w] + cnts[w] - first;
+            at = at < 0 ? 0 : (at > kCompactTile ? kCompactTile : at);
+            const int32_t dest = live_before_tile + (int32_t)lds.liveBefore[at] + j;
+            out_rows[dest] = tail_rows[j];
+            out_keys[dest] = w;
+        }
+        __syncthreads();
+    }
+}
+
 }
 
 // ---------------------------------------------------------------------------
@@ -855,6 +1229,24 @@ int sortNumPasses(bool world_sort, uint32_t num_worlds)
 uint32_t sortTileSize() { return (uint32_t)kSortTile; }
 
 uint32_t sortSmallRowLimit() { return kSmallSortRows; }
+
+// rows behind the sorted prefix one workgroup sorts about as fast as the radix
+// chain would take for the whole table; tables that keep exceeding it go back
+// to the radix chain (runtime.hip, sortsOutgrown)
+uint32_t sortCompactTailLimit() { return 16384u; }
+
+// Key-pass workgroups spin on their predecessor tiles: all of a grid must be
+// able to be resident at once (4 workgroups of 22.5 KB LDS / 4 waves per CU on
+// 256 CUs; the kernels fit 6), larger tables take rounds.
+// MADRONA_MWHIP_SORT_MAX_GRID overrides it (tests: grids smaller than the tile
+// count).
+static uint32_t sortMaxGrid()
+{
+    // (read when a graph is built, not cached: tests switch it per executor)
+    const char *e = getenv("MADRONA_MWHIP_SORT_MAX_GRID");
+    const uint32_t n = e != nullptr ? (uint32_t)strtoul(e, nullptr, 10) : 0u;
+    return n == 0 ? 1024u : n;
+}
 
 void buildSortLaunches(const SortBatch &batch, std::vector<KernelLaunch> &out)
 {
@@ -883,11 +1275,41 @@ void buildSortLaunches(const SortBatch &batch, std::vector<KernelLaunch> &out)
         max_passes = std::max(max_passes, s.numPasses);
     }
 
-    const uint32_t tiles = (max_capacity + kSortTile - 1) / kSortTile;
+    const uint32_t tiles = std::min<uint32_t>(
+        (max_capacity + kSortTile - 1) / kSortTile, sortMaxGrid());
     const uint32_t stream_blocks = std::min<uint32_t>(
         std::max<uint32_t>((max_capacity + kSortThreads * 4 - 1) /
                            (kSortThreads * 4), 1u), 1024u);
 
+    if (batch.compact) {
+        {
+            KernelLaunch k;
+            k.fn = (const void *)&sortCompactPrepare;
+            const uint32_t group_rows = kPrepTilesPerGroup * kCompactTile;
+            k.grid = dim3(1u + std::min<uint32_t>(std::max<uint32_t>(
+                (max_capacity + group_rows - 1) / group_rows, 1u), sortMaxGrid()),
+                num_sites, 1);
+            k.block = dim3(kSmallThreads, 1, 1);
+            k.setArgs(batch.stateDev, batch.sitesDev);
+            k.role = "sort.compact.prepare";
+            k.kind = MWHIP_NODE_SORT_ARCHETYPE;
+            k.sortBatch = &batch;
+            k.sortRole = SortRole::CompactPrepare;
+            out.push_back(k);
+        }
+        {
+            KernelLaunch k;
+            k.fn = (const void *)&sortCompactScatter;
+            k.grid = dim3(std::max(tiles, 1u), num_sites, 1);
+            k.block = dim3(kSortThreads, 1, 1);
+            k.setArgs(batch.stateDev, batch.sitesDev);
+            k.role = "sort.compact.scatter";
+            k.kind = MWHIP_NODE_SORT_ARCHETYPE;
+            k.sortBatch = &batch;
+            k.sortRole = SortRole::CompactScatter;
+            out.push_back(k);
+        }
+    } else {
     {
         KernelLaunch k;
         k.fn = (const void *)&sortHistogram;
@@ -916,6 +1338,7 @@ void buildSortLaunches(const SortBatch &batch, std::vector<KernelLaunch> &out)
         k.sortRole = SortRole::Onesweep;
         out.push_back(k);
     }
+    }   // radix chain
 
     {
         KernelLaunch k;

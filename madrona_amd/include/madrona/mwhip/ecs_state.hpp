@@ -78,6 +78,16 @@ struct TableHdr {
     // growth is sized by.  Raised where rows are dropped (sort, ClearTmp), read
     // and reset by the end-of-replay health kernel.
     int32_t peakRows;
+    // Rows [0, sortedRows) are what the last world sort left: grouped by world
+    // in world order, except that some have been destroyed in place since
+    // (WorldID -1); everything appended since sits behind them.  Set where a
+    // world sort publishes the table, zeroed by whatever else reorders or
+    // truncates it (a sort by another key, ClearTmp).  The compaction path of
+    // the sort node (csrc/sort_archetype.hip) starts from it.
+    int32_t sortedRows;
+    // rows behind the sorted prefix at the largest world sort of the running
+    // step (health kernel: read and reset)
+    int32_t tailRows;
 };
 
 // == IDMap::Node with V = Loc (reference impl/id_map.hpp:41-53): a live slot

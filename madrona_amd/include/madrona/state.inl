@@ -447,6 +447,7 @@ MADRONA_HD inline void StateManager::clearTemporaries(uint32_t archetype_id)
         tbl.needsSort = 1u;
     }
     tbl.numRows = 0;
+    tbl.sortedRows = 0;
 }
 
 MADRONA_HD int32_t StateManager::getArchetypeColumnIndex(uint32_t archetype_id,

@@ -9,6 +9,7 @@ struct SimTraits;
 #include "common/sim_c_api.h"
 #ifdef ESCPHYS_RENDER
 #include "common/mesh_set.hpp"
+#include "common/cpu_render_bridge.hpp"
 #ifndef SIM_BACKEND_REF_CPU
 #include "common/render_config.hpp"
 #endif
@@ -164,6 +165,11 @@ const simmesh::MeshSet &meshes()
 }
 
 uint32_t g_resolution = 0;
+#ifdef SIM_BACKEND_REF_CPU
+// floor + 4 borders + 2 agents + 3 rooms x 9 = 34 instances, 2 views per world
+constexpr uint32_t kMaxRecordsPerWorld = 64;
+simmgr::CpuRenderBridge *g_bridge = nullptr;
+#endif
 #endif
 
 }
@@ -181,14 +187,29 @@ struct SimTraits {
     // bit 25 = the sun casts shadows
     static Sim::Config makeConfig(const SimCreateArgs &args)
     {
+#if defined(ESCPHYS_RENDER) && defined(SIM_BACKEND_REF_CPU)
+        delete g_bridge;
+        g_bridge = new simmgr::CpuRenderBridge(
+            args.num_worlds, kMaxRecordsPerWorld, 64,
+            escphys::consts::numAgents, kMaxRecordsPerWorld);
+#endif
         return Sim::Config {
             args.seed, args.world_base, args.flags & 0xFFFFu,
             loadPhysicsObjects(args),
 #ifdef ESCPHYS_RENDER
             (args.flags >> 25) & 1u,
+#ifdef SIM_BACKEND_REF_CPU
+            &g_bridge->bridge,
+#else
+            nullptr,
+#endif
 #endif
         };
     }
+
+#if defined(ESCPHYS_RENDER) && defined(SIM_BACKEND_REF_CPU)
+    static void preStep() { g_bridge->beginStep(); }
+#endif
 
 #ifdef ESCPHYS_RENDER
     static const simmesh::MeshSet &renderMeshes() { return meshes(); }
@@ -293,10 +314,39 @@ void SimTraits::describeColumns(T &cols)
     cols.template add<ButtonEntity, Entity>("ButtonEntity.Entity", false);
     cols.template add<ButtonEntity, Position>("ButtonEntity.Position", true);
     cols.template add<ButtonEntity, ButtonState>("ButtonEntity.ButtonState", false);
-#if defined(ESCPHYS_RENDER) && !defined(SIM_BACKEND_REF_CPU)
+#ifdef ESCPHYS_RENDER
     using namespace madrona::render;
-    cols.template add<RenderableArchetype, InstanceData>("Renderable.InstanceData", false);
-    cols.template add<RenderCameraArchetype, PerspectiveCameraData>("Camera.PerspectiveCameraData", false);
+    // the light table is filled the same way on both backends
     cols.template add<LightArchetype, LightDesc>("Light.LightDesc", false);
+    cols.template add<PhysicsEntity, Renderable>("PhysicsEntity.Renderable", false);
+    cols.template add<ButtonEntity, Renderable>("ButtonEntity.Renderable", false);
+    cols.template add<Agent, Renderable>("Agent.Renderable", false);
+    cols.template add<Agent, RenderCamera>("Agent.RenderCamera", false);
+#ifndef SIM_BACKEND_REF_CPU
+    // GPU mode only: the render entities' rows ARE the renderer's records
+    cols.template add<RenderableArchetype, InstanceData>("Renderable.InstanceData", false);
+    cols.template add<RenderableArchetype, MortonCode>("Renderable.MortonCode", false);
+    cols.template add<RenderCameraArchetype, PerspectiveCameraData>("Camera.PerspectiveCameraData", false);
+    cols.template add<RenderCameraArchetype, RenderOutputIndex>("Camera.RenderOutputIndex", false);
+#endif
 #endif
 }
+
+#ifdef ESCPHYS_RENDER
+// CPU mode: the instance (kind 0, 64 B) / view (kind 1, 48 B) records the
+// reference appended to its bridge during the last step, arrival order, + the
+// (world << 32 | entity id) key of each.  Returns the count (-1 on HIP: there
+// the render entities' rows are the records).
+extern "C" SIM_API int64_t render_prep_bridge_records(int32_t kind, void *dst,
+                                                      uint64_t *keys_dst,
+                                                      uint64_t max_records)
+{
+#ifdef SIM_BACKEND_REF_CPU
+    if (g_bridge == nullptr) return -1;
+    return g_bridge->records(kind, dst, keys_dst, max_records);
+#else
+    (void)kind; (void)dst; (void)keys_dst; (void)max_records;
+    return -1;
+#endif
+}
+#endif

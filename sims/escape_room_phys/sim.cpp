@@ -43,11 +43,12 @@ static constexpr float kLidarSin[consts::numLidarSamples] = {
     -0.74314483f, -0.58778525f, -0.40673664f, -0.20791169f,
 };
 
-void Sim::registerTypes(ECSRegistry &registry, const Config &)
+void Sim::registerTypes(ECSRegistry &registry, const Config &cfg)
 {
+    (void)cfg;
     base::registerTypes(registry);
     PhysicsSystem::registerTypes(registry);
-    ESCPHYS_IF_RENDER(RenderingSystem::registerTypes(registry, nullptr);)
+    ESCPHYS_IF_RENDER(RenderingSystem::registerTypes(registry, cfg.bridge);)
 
     registry.registerComponent<Action>();
     registry.registerComponent<Reward>();
@@ -835,7 +836,7 @@ Sim::Sim(Engine &ctx, const Config &cfg, const WorldInit &)
         consts::maxRigidBodies);
 
 #ifdef ESCPHYS_RENDER
-    RenderingSystem::init(ctx, nullptr);
+    RenderingSystem::init(ctx, cfg.bridge);
 #endif
 
     createPersistentEntities(ctx);

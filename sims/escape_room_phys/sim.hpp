@@ -283,6 +283,10 @@ struct Sim : public madrona::WorldBase {
         madrona::phys::ObjectManager *rigidBodyObjMgr;
 #ifdef ESCPHYS_RENDER
         uint32_t sunCastsShadows;
+        // reference CPU backend: where its render-prep systems append their
+        // records (the manager's stand-in for the Vulkan renderer); null on
+        // the GPU backend, whose render entities' rows are the records
+        const madrona::render::RenderECSBridge *bridge;
 #endif
     };
 

@@ -12,11 +12,7 @@ struct SimTraits;
 #include "common/render_config.hpp"
 #endif
 
-#ifdef SIM_BACKEND_REF_CPU
-// the reference's private bridge struct, where it lies (oracle build only)
-#include "ecs_interop.hpp"
-#include <madrona/sync.hpp>
-#endif
+#include "common/cpu_render_bridge.hpp"
 
 namespace {
 
@@ -26,18 +22,7 @@ namespace {
 constexpr uint32_t kMaxRecordsPerWorld = 128;
 
 #ifdef SIM_BACKEND_REF_CPU
-// What the reference's Vulkan renderer would own: the buffers its CPU-mode
-// systems append instance / view records to (src/render/ecs_interop.hpp).
-struct CpuBridge {
-    madrona::render::RenderECSBridge bridge {};
-    std::vector<madrona::render::PerspectiveCameraData> views;
-    std::vector<madrona::render::InstanceData> instances;
-    std::vector<uint64_t> instanceKeys, viewKeys;
-    uint32_t totalViews = 0, totalInstances = 0;
-    madrona::AtomicU32 viewCounter { 0 };
-    madrona::AtomicU32 instanceCounter { 0 };
-};
-CpuBridge *g_bridge = nullptr;
+simmgr::CpuRenderBridge *g_bridge = nullptr;
 #endif
 
 // object-space root boxes of the four "models" (HIP backend, ray caster on)
@@ -96,27 +81,10 @@ struct SimTraits {
         const madrona::render::RenderECSBridge *bridge = nullptr;
 #ifdef SIM_BACKEND_REF_CPU
         delete g_bridge;
-        g_bridge = new CpuBridge();
-        const size_t cap = (size_t)args.num_worlds * kMaxRecordsPerWorld;
-        g_bridge->views.resize(cap);
-        g_bridge->instances.resize(cap);
-        g_bridge->instanceKeys.resize(cap);
-        g_bridge->viewKeys.resize(cap);
-        auto &b = g_bridge->bridge;
-        b.views = g_bridge->views.data();
-        b.instances = g_bridge->instances.data();
-        b.totalNumViews = &g_bridge->totalViews;
-        b.totalNumInstances = &g_bridge->totalInstances;
-        b.totalNumViewsCPUInc = &g_bridge->viewCounter;
-        b.totalNumInstancesCPUInc = &g_bridge->instanceCounter;
-        b.instancesWorldIDs = g_bridge->instanceKeys.data();
-        b.viewsWorldIDs = g_bridge->viewKeys.data();
-        b.renderWidth = 64;
-        b.renderHeight = 64;
-        b.maxViewsPerworld = renderprep::consts::numViewers;
-        b.maxInstancesPerWorld = renderprep::consts::maxMovers;
-        b.isGPUBackend = false;
-        bridge = &b;
+        g_bridge = new simmgr::CpuRenderBridge(
+            args.num_worlds, kMaxRecordsPerWorld, 64,
+            renderprep::consts::numViewers, renderprep::consts::maxMovers);
+        bridge = &g_bridge->bridge;
 #endif
         return Sim::Config { args.seed, args.world_base, args.flags & 1u,
                              (args.flags >> 2) & 1u, bridge };
@@ -128,11 +96,7 @@ struct SimTraits {
 
 #ifdef SIM_BACKEND_REF_CPU
     // the renderer zeroes the append counters before every step
-    static void preStep()
-    {
-        g_bridge->viewCounter.store_relaxed(0);
-        g_bridge->instanceCounter.store_relaxed(0);
-    }
+    static void preStep() { g_bridge->beginStep(); }
 #else
     static madrona::Optional<madrona::CudaBatchRenderConfig> renderConfig(
         const SimCreateArgs &args)
@@ -218,17 +182,7 @@ extern "C" SIM_API int64_t render_prep_bridge_records(int32_t kind, void *dst,
 {
 #ifdef SIM_BACKEND_REF_CPU
     if (g_bridge == nullptr) return -1;
-    const uint64_t n = kind == 0 ? g_bridge->instanceCounter.load_relaxed() :
-                                   g_bridge->viewCounter.load_relaxed();
-    if (n > max_records) return -2;
-    if (kind == 0) {
-        memcpy(dst, g_bridge->instances.data(), n * 64);
-        memcpy(keys_dst, g_bridge->instanceKeys.data(), n * 8);
-    } else {
-        memcpy(dst, g_bridge->views.data(), n * 48);
-        memcpy(keys_dst, g_bridge->viewKeys.data(), n * 8);
-    }
-    return (int64_t)n;
+    return g_bridge->records(kind, dst, keys_dst, max_records);
 #else
     (void)kind; (void)dst; (void)keys_dst; (void)max_records;
     return -1;

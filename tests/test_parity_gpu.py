@@ -292,6 +292,54 @@ def test_sort_stress_lockstep(built, worlds):
     assert not probs, (step, probs[:3])
 
 
+# Every way through the sort node, on the same workloads:
+#   compact 0          radix chain only (histogram + key passes + gather)
+#   compact 1          default: compaction chain where nothing but world sorts
+#                      reorders the table, radix chain elsewhere
+#   compact 2          compaction chain for EVERY world sort: also tables that a
+#                      key sort or ClearTmp leaves with no sorted prefix (the
+#                      whole table is then "tail": one workgroup sorts it)
+#   grid N             key-pass / scatter grids capped at N workgroups: tiles
+#                      beyond the grid are taken in further rounds
+#                      (sort_archetype.hip: tile = workgroup + round * grid)
+SORT_CHAINS = [("0", ""), ("2", ""), ("2", "3"), ("0", "2"), ("1", "1")]
+
+
+@pytest.mark.parametrize("compact,grid", SORT_CHAINS)
+@pytest.mark.parametrize("sim,worlds,steps,denom", [
+    ("sort_stress", 1500, 25, 0), ("sort_stress", 37, 40, 0),
+    ("escape_room", 2048, 60, 30)])
+def test_sort_chains_lockstep(built, monkeypatch, sim, worlds, steps, denom, compact,
+                              grid):
+    _need_ref(sim)
+    monkeypatch.setenv("MADRONA_MWHIP_SORT_COMPACT", compact)
+    if grid:
+        monkeypatch.setenv("MADRONA_MWHIP_SORT_MAX_GRID", grid)
+    if worlds < 100:
+        # small tables: force the chains instead of the single-launch sort
+        monkeypatch.setenv("MADRONA_MWHIP_SORT_SMALL", "0")
+    probs, step = run_pair(sim, worlds, steps, seed=7, flags=denom, check_every=5,
+                           actions=_escape_actions(9) if sim == "escape_room" else None,
+                           check_init=False, ref_workers=0)
+    assert not probs, (step, probs[:3])
+
+
+@pytest.mark.parametrize("compact", ["1", "2"])
+def test_compaction_chain_heavy_churn(built, monkeypatch, compact):
+    """The compaction chain where it is the default: the Escape Room with a reset
+    every ~3 steps per world (a third of every table destroyed and re-created
+    per step: long tails, many tail rows landing in one prefix tile, worlds whose
+    whole prefix range died), 4096 worlds, against the reference.  In mode 1
+    the executor sends such a table back to the radix chain after three long
+    tails (graphs rebuilt mid-run); mode 2 keeps the compaction chain on it."""
+    _need_ref("escape_room")
+    monkeypatch.setenv("MADRONA_MWHIP_SORT_COMPACT", compact)
+    probs, step = run_pair("escape_room", 4096, 40, seed=21, flags=3, check_every=4,
+                           actions=_escape_actions(10), check_init=False,
+                           ref_workers=0)
+    assert not probs, (step, probs[:3])
+
+
 def test_sort_stress_cold_start_runtime_id_blocks(built):
     """Worlds that start empty take their first block of entity ids at run
     time.  The CPU backend numbers such blocks in world-major order within a

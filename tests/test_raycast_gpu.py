@@ -47,7 +47,7 @@ def _offsets(counts):
     return np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.int32)
 
 
-def _reference_images(geo, worlds, d, res, rgbd):
+def _reference_images(geo, worlds, d, res, rgbd, threads=None):
     """The reference's images for the dumped tables.  Worlds without instances
     are left out (the reference's kernel reads a root node for every view's
     world; the HIP kernel renders them as all misses, which is what is returned
@@ -71,11 +71,27 @@ def _reference_images(geo, worlds, d, res, rgbd):
     ic, lc = inst_counts[keep], light_counts[keep]
     rgb[view_kept], depth[view_kept] = ref_render(
         geo, len(keep), inst, _offsets(ic), ic, v, l, _offsets(lc), lc, res, rgbd=rgbd,
-        threads=min(32, os.cpu_count() or 1))
+        threads=threads or min(32, os.cpu_count() or 1))
     return rgb, depth
 
 
-def _compare(hip_rgb, hip_depth, ref_rgb, ref_depth, rgbd, what):
+def _log_stats(what, **stats):
+    """Appends the pixel statistics of a comparison to $RAYCAST_STATS_FILE (how
+    the allowances below were chosen: they are what the runs show)."""
+    path = os.environ.get("RAYCAST_STATS_FILE")
+    if path:
+        import json
+        with open(path, "a") as f:
+            f.write(json.dumps({"case": [str(w) for w in what], **stats}) + "\n")
+
+
+def _compare(hip_rgb, hip_depth, ref_rgb, ref_depth, rgbd, what, flips=0, offs=0):
+    """flips: pixels allowed to differ in hit / miss or by more than 1e-5 in depth
+    (a ray grazing a triangle edge resolves to the other side: the two ray
+    casters enter instances in different orders and each entered instance moves
+    t_max by an ulp); offs: pixels allowed to differ by more than one 8-bit step
+    in colour (a shadow ray or a spot cone's edge going the other way).  Both
+    are ZERO unless the case is known to need them."""
     assert hip_depth.shape == ref_depth.shape
     hit_h, hit_r = hip_depth > 0, ref_depth > 0
     total = hit_r.size
@@ -83,21 +99,26 @@ def _compare(hip_rgb, hip_depth, ref_rgb, ref_depth, rgbd, what):
     both = hit_h & hit_r
     rel = np.abs(hip_depth[both] - ref_depth[both]) / ref_depth[both]
     far = int((rel > 1e-5).sum())       # tolerance of BASELINE north_star
-    # (edge-grazing rays: the other triangle / the background wins)
-    assert flipped + far <= max(2, total // 2000), (what, flipped, far, total,
-                                                    float(rel.max()) if rel.size else 0)
+    off = 0
+    same = None
+    if rgbd:
+        same = both.copy()
+        same[both] = rel <= 1e-5
+        diff = np.abs(hip_rgb.astype(np.int32) - ref_rgb.astype(np.int32))
+        off = int((diff[same][:, :3].max(-1) > 1).sum())
+    _log_stats(what, total=total, flipped=flipped, far=far, off=off,
+               max_rel=float(rel.max()) if rel.size else 0.0,
+               hit_fraction=float(hit_r.mean()))
+    survey = bool(os.environ.get("RAYCAST_STATS_ONLY"))   # collecting, not judging
+    assert survey or flipped + far <= flips, (what, flipped, far, total,
+                                              float(rel.max()) if rel.size else 0)
     if hit_r.shape[0] >= 48:
         assert hit_r.mean() > 0.03, (what, "the scene is not in view", float(hit_r.mean()))
     if rgbd:
-        same = both & (rel.reshape(-1)[np.cumsum(both.ravel()) - 1].reshape(both.shape) <= 1e-5
-                       if rel.size else both)
-        diff = np.abs(hip_rgb.astype(np.int32) - ref_rgb.astype(np.int32))
         assert (hip_rgb[..., 3] == 255).all()
         # misses are black on both sides
         assert (hip_rgb[~hit_h][:, :3] == 0).all()
-        off = int((diff[same][:, :3].max(-1) > 1).sum())
-        # (a shadow ray or the spot cone's edge may go the other way for a pixel)
-        assert off <= max(2, total // 500), (what, off, total)
+        assert survey or off <= offs, (what, off, total)
         if hit_r.shape[0] >= 48:
             assert hip_rgb[same][:, :3].max() > 60, (what, "nothing is lit")
 
