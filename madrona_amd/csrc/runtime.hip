@@ -410,7 +410,7 @@ struct ArchetypeRec {
     std::vector<void *> alt;
     // growable archetypes: the ranges behind primary / alt / sort buffers
     std::vector<VmRange *> primaryVm, altVm;
-    VmRange *sortVm[4] = { nullptr, nullptr, nullptr, nullptr };
+    VmRange *sortVm[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
     std::vector<uint32_t> colBytes;
     std::vector<uint32_t> colFlags;
     std::vector<uint32_t> colComponent;
@@ -423,6 +423,7 @@ struct ArchetypeRec {
     unsigned long long *lookback = nullptr;
     int32_t *tileCounts = nullptr;      // compaction chain, per prefix tile
     int32_t *tileTailStart = nullptr;
+    int32_t *tailLand = nullptr;        // [capacity] where each sorted tail row lands
 };
 
 struct QueryRec {
@@ -1523,9 +1524,10 @@ static int ensureSortScratch(mwhip_exec *exec, ArchetypeRec &arch)
     int rc = devAllocT(exec, &arch.sortState, 1);
     if (rc != 0) return rc;
     if (arch.reservedCapacity > arch.capacity) {
-        void **bufs[4] = { (void **)&arch.keysA, (void **)&arch.keysB,
-                           (void **)&arch.idxA, (void **)&arch.idxB };
-        for (int i = 0; i < 4; i++) {
+        void **bufs[5] = { (void **)&arch.keysA, (void **)&arch.keysB,
+                           (void **)&arch.idxA, (void **)&arch.idxB,
+                           (void **)&arch.tailLand };
+        for (int i = 0; i < 5; i++) {
             rc = vmAlloc(exec, bufs[i], &arch.sortVm[i],
                          (size_t)arch.reservedCapacity * 4,
                          (size_t)arch.capacity * 4, false);
@@ -1539,6 +1541,8 @@ static int ensureSortScratch(mwhip_exec *exec, ArchetypeRec &arch)
         rc = devAllocT(exec, &arch.idxA, arch.capacity, false);
         if (rc != 0) return rc;
         rc = devAllocT(exec, &arch.idxB, arch.capacity, false);
+        if (rc != 0) return rc;
+        rc = devAllocT(exec, &arch.tailLand, arch.capacity, false);
         if (rc != 0) return rc;
     }
     // (look-back slots for every tile the table can ever have)
@@ -1618,6 +1622,7 @@ static int makeSortBatch(mwhip_exec *exec,
         site.state = arch.sortState;
         site.tileCounts = arch.tileCounts;
         site.tileTailStart = arch.tileTailStart;
+        site.tailLand = arch.tailLand;
         sites.push_back(site);
 
         out->maxCapacity = std::max(out->maxCapacity, arch.capacity);
@@ -1657,6 +1662,13 @@ static int makeSortBatch(mwhip_exec *exec,
             gc.wordsPerRow = bytes / gc.wordBytes;
             gc.invMagic = gc.wordsPerRow <= 1 ? 0ull :
                 (~0ull / gc.wordsPerRow) + 1ull;
+            // MADRONA_MWHIP_GATHER_WIDE=0: every column word by word (measurement)
+            const bool wide = envU32("MADRONA_MWHIP_GATHER_WIDE", 1) != 0;
+            if (wide && bytes % 4 == 0 && bytes != 0) {
+                gc.rowDwords = bytes / 4;
+                gc.invMagicDwords = gc.rowDwords <= 1 ? 0ull :
+                    (~0ull / gc.rowDwords) + 1ull;
+            }
             cols.push_back(gc);
         }
         sites.back().numGatherColumns = site_columns;

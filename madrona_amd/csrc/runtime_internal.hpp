@@ -73,6 +73,7 @@ struct SortSite {
     // and for every tile the first row of the sorted tail that lands in it
     int32_t *tileCounts;            // [numTiles]
     int32_t *tileTailStart;         // [numTiles + 1]
+    int32_t *tailLand;              // [rows] prefix position each sorted tail row lands at
 };
 
 // pseudo-column of a world-sort site: rebuild worldOffsets / worldCounts
@@ -84,6 +85,11 @@ struct GatherColumn {
     uint32_t wordBytes;             // 16 / 8 / 4 / 1
     uint32_t wordsPerRow;
     unsigned long long invMagic;    // floor(2^64 / wordsPerRow) + 1
+    // rows of whole dwords move in 16-byte chunks of the destination
+    // (gatherRowsWide); 0: word by word as described above
+    uint32_t rowDwords;
+    uint32_t pad_;
+    unsigned long long invMagicDwords;  // floor(2^64 / rowDwords) + 1
 };
 
 struct SortSiteHost {

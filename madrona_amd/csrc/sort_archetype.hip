@@ -535,6 +535,107 @@ __device__ inline void gatherWords(const WordT *__restrict__ src,
     }
 }
 
+// Columns whose rows are whole dwords (all but 1- / 2-byte components), moved in
+// 16-byte chunks of the DESTINATION: dst is a dense array of rows, so chunk k
+// = dwords [4k, 4k + 4) of it is one aligned 16-byte store.  Its source dwords
+// belong to at most two rows when a row has >= 2 dwords, to four rows of a
+// 4-byte column; they are contiguous in the source too whenever those rows are
+// consecutive there (perm[r + 1] == perm[r] + 1) -- almost always: a world
+// sort moves rows in long runs -- and then they are one (dword-aligned) 16-byte
+// load.  12- and 28-byte components (positions, solver state: most of a rigid
+// body's bytes) would otherwise move 4 bytes per lane per instruction.
+struct __attribute__((packed, aligned(4))) Dwords4 { uint32_t x, y, z, w; };
+
+__device__ inline void gatherRowsWide(const uint32_t *__restrict__ src,
+                                      uint32_t *__restrict__ dst,
+                                      const int32_t *__restrict__ perm,
+                                      int32_t num_rows, uint32_t row_dwords,
+                                      unsigned long long inv_magic,
+                                      int32_t first, int32_t step)
+{
+    const long long total = (long long)num_rows * row_dwords;
+    const long long chunks = total >> 2;
+    constexpr int kBatch = 4;
+
+    auto move = [&](long long k0, int count) {
+        // (count <= kBatch chunks k0, k0 + step, ...: independent chains)
+        long long src_at[kBatch];   // source dword of the chunk's first dword
+        int32_t row_b[kBatch];      // source row of the dwords behind `split`
+        uint32_t split[kBatch];     // dwords of the chunk that come from the first row
+        bool contiguous[kBatch];
+        uint4 rows4[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; u++) {
+            if (u >= count) continue;
+            const long long d0 = (k0 + (long long)u * step) << 2;
+            if (row_dwords == 1u) {
+                const uint4 p = *(const uint4 *)(perm + d0);
+                rows4[u] = p;
+                src_at[u] = (long long)(int32_t)p.x;
+                contiguous[u] = p.y == p.x + 1u && p.z == p.x + 2u && p.w == p.x + 3u;
+                split[u] = 1u;
+                row_b[u] = 0;
+            } else {
+                const uint32_t r0 =
+                    (uint32_t)__umul64hi((unsigned long long)d0, inv_magic);
+                const uint32_t o0 = (uint32_t)(d0 - (long long)r0 * row_dwords);
+                const int32_t p0 = perm[r0];
+                // (the chunk ends inside row r0, or in row r0 + 1 which exists:
+                // d0 + 3 < total)
+                const bool crosses = o0 + 4u > row_dwords;
+                const int32_t p1 = crosses ? perm[r0 + 1u] : p0 + 1;
+                src_at[u] = (long long)p0 * row_dwords + o0;
+                split[u] = crosses ? row_dwords - o0 : 4u;
+                row_b[u] = p1;
+                contiguous[u] = p1 == p0 + 1;
+            }
+        }
+        uint4 v[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; u++) {
+            if (u >= count) continue;
+            if (contiguous[u]) {
+                const Dwords4 w = *(const Dwords4 *)(src + src_at[u]);
+                v[u] = make_uint4(w.x, w.y, w.z, w.w);
+            } else if (row_dwords == 1u) {
+                v[u] = make_uint4(src[(int32_t)rows4[u].x], src[(int32_t)rows4[u].y],
+                                  src[(int32_t)rows4[u].z], src[(int32_t)rows4[u].w]);
+            } else {
+                const long long b = (long long)row_b[u] * row_dwords -
+                    (long long)split[u];
+                uint32_t w[4];
+#pragma unroll
+                for (uint32_t e = 0; e < 4u; e++) {
+                    w[e] = e < split[u] ? src[src_at[u] + e] : src[b + e];
+                }
+                v[u] = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; u++) {
+            if (u >= count) continue;
+            *(uint4 *)(dst + ((k0 + (long long)u * step) << 2)) = v[u];
+        }
+    };
+
+    long long k = first;
+    for (; k + (long long)(kBatch - 1) * step < chunks; k += (long long)kBatch * step) {
+        move(k, kBatch);
+    }
+    for (; k < chunks; k += step) {
+        move(k, 1);
+    }
+    // the last, partial chunk
+    if (first == 0) {
+        for (long long d = chunks << 2; d < total; d++) {
+            const uint32_t row = row_dwords == 1u ? (uint32_t)d :
+                (uint32_t)__umul64hi((unsigned long long)d, inv_magic);
+            const uint32_t off = (uint32_t)(d - (long long)row * row_dwords);
+            dst[d] = src[(long long)perm[row] * row_dwords + off];
+        }
+    }
+}
+
 struct alignas(16) Word16 { uint32_t v[4]; };
 struct alignas(8) Word8 { uint32_t v[2]; };
 
@@ -645,6 +746,12 @@ __device__ inline void gatherColumn(EcsState *S, const SortSite &site,
         return;
     }
 
+    if (gc.rowDwords != 0u) {
+        gatherRowsWide((const uint32_t *)src, (uint32_t *)dst, perm, n_out,
+                       gc.rowDwords, gc.invMagicDwords, tid, stride);
+        return;
+    }
+
     switch (gc.wordBytes) {
     case 16:
         gatherWords<Word16>((const Word16 *)src, (Word16 *)dst, perm, n_out,
@@ -718,11 +825,18 @@ struct SmallSortLDS {
     uint32_t valid;
 };
 
+// ping-pong buffers of the one-workgroup passes (global memory or LDS)
+struct RadixBuffers {
+    uint32_t *keys[2];
+    int32_t *rows[2];
+};
+
 // Stable LSD radix passes over n keys by ONE kSmallThreads-wide workgroup.
 // Pass 0 reads keys0[i] (source row first_row + i); pass p writes keys / rows to
-// buffer (first_out + p) & 1 of { A, B } and reads what pass p - 1 wrote.
+// buffer (first_out + p) & 1 and reads what pass p - 1 wrote.
 // Leaves the number of keys != 0xFFFFFFFF in lds.valid (they sort last).
-__device__ inline void oneGroupRadixPasses(SmallSortLDS &lds, const SortSite &site,
+__device__ inline void oneGroupRadixPasses(SmallSortLDS &lds, int32_t num_passes,
+                                           const RadixBuffers &buf,
                                            const uint32_t *keys0, int32_t first_row,
                                            int32_t n, int32_t first_out)
 {
@@ -733,14 +847,12 @@ __device__ inline void oneGroupRadixPasses(SmallSortLDS &lds, const SortSite &si
 
     if (tid == 0) lds.valid = 0;
 
-    for (int32_t pass = 0; pass < site.numPasses; pass++) {
-        const bool out_b = ((first_out + pass) & 1) != 0;
-        const uint32_t *keys_in = pass == 0 ? keys0 :
-            (out_b ? site.keysA : site.keysB);
-        const int32_t *idx_in = pass == 0 ? nullptr :
-            (out_b ? site.idxA : site.idxB);
-        uint32_t *keys_out = out_b ? site.keysB : site.keysA;
-        int32_t *idx_out = out_b ? site.idxB : site.idxA;
+    for (int32_t pass = 0; pass < num_passes; pass++) {
+        const int out = (first_out + pass) & 1;
+        const uint32_t *keys_in = pass == 0 ? keys0 : buf.keys[out ^ 1];
+        const int32_t *idx_in = pass == 0 ? nullptr : buf.rows[out ^ 1];
+        uint32_t *keys_out = buf.keys[out];
+        int32_t *idx_out = buf.rows[out];
         const uint32_t shift = (uint32_t)pass * kRadixBits;
 
         if (tid < (uint32_t)kRadixDigits) lds.hist[tid] = 0;
@@ -846,8 +958,10 @@ sortSmall(EcsState *S, const SortSite *sites, const GatherColumn *columns,
     const uint32_t tid = threadIdx.x;
 
     // (pass p writes buffer p & 1: the last one lands where the gather looks)
-    oneGroupRadixPasses(lds, site, (const uint32_t *)tbl.columns[site.keyColumn],
-                        0, n, 0);
+    const RadixBuffers buffers { { site.keysA, site.keysB },
+                                 { site.idxA, site.idxB } };
+    oneGroupRadixPasses(lds, site.numPasses, buffers,
+                        (const uint32_t *)tbl.columns[site.keyColumn], 0, n, 0);
     __syncthreads();
 
     // same order as the chain: publish (swap), then gather old -> current
@@ -904,6 +1018,7 @@ constexpr int kCompactTile = kSortTile;            // prefix rows per scatter ti
 constexpr int kCompactTileShift = 11;
 static_assert((1 << kCompactTileShift) == kCompactTile);
 constexpr int kPrepTilesPerGroup = 4;              // count: 16 waves x 512 rows
+constexpr int kLdsTailRows = 2048;                 // tails sorted in LDS
 
 __device__ inline int32_t compactNumTiles(int32_t prefix)
 {
@@ -977,14 +1092,32 @@ sortCompactPrepare(EcsState *S, const SortSite *sites)
 
     // ---- workgroup 0: the tail, sorted by world ----
     __shared__ SmallSortLDS lds;
+    // a short tail (the steady state) is sorted without leaving the CU
+    __shared__ uint32_t tail_keys_lds[2][kLdsTailRows];
+    __shared__ int32_t tail_rows_lds[2][kLdsTailRows];
+
     const int32_t tail = n - prefix;
-    // first_out = 1: the last pass lands in the buffer the gather does NOT read
-    // (the scatter kernel fills that one while tiles still read the tail)
-    oneGroupRadixPasses(lds, site, keys + prefix, prefix, tail, 1);
+    const bool in_lds = tail <= kLdsTailRows;
+    // The last pass lands in the buffer the gather does NOT read (first_out = 1
+    // with { A, B }): the scatter kernel fills the other one while tiles still
+    // read the tail.
+    const bool final_in_b = ((site.numPasses - 1) & 1) != 0;
+    uint32_t *tail_keys = final_in_b ? site.keysA : site.keysB;
+    int32_t *tail_rows = final_in_b ? site.idxA : site.idxB;
+    const int final_buf = (1 + site.numPasses - 1) & 1;
+    {
+        // (assigned, not brace-initialised: LDS addresses are no constant
+        // expressions for a static initialiser)
+        RadixBuffers buffers;
+        buffers.keys[0] = in_lds ? tail_keys_lds[0] : site.keysA;
+        buffers.keys[1] = in_lds ? tail_keys_lds[1] : site.keysB;
+        buffers.rows[0] = in_lds ? tail_rows_lds[0] : site.idxA;
+        buffers.rows[1] = in_lds ? tail_rows_lds[1] : site.idxB;
+        oneGroupRadixPasses(lds, site.numPasses, buffers, keys + prefix, prefix,
+                            tail, 1);
+    }
     __syncthreads();
     const int32_t tail_live = (int32_t)lds.valid;
-    const bool final_in_b = ((site.numPasses - 1) & 1) != 0;
-    const uint32_t *tail_keys = final_in_b ? site.keysA : site.keysB;
 
     if (tid == 0) {
         state->tailLive = tail_live;
@@ -994,12 +1127,27 @@ sortCompactPrepare(EcsState *S, const SortSite *sites)
         }
     }
 
-    // tileTailStart[t] = first sorted tail row landing in tile t or later
+    // where every sorted tail row lands in the prefix: the end of its world's
+    // old range
     const int32_t num_tiles = compactNumTiles(prefix);
     const int32_t *offs = tbl.worldOffsets;
     const int32_t *cnts = tbl.worldCounts;
-    auto tile_of = [&](uint32_t w) {
+    int32_t *land_lds = (int32_t *)tail_keys_lds[final_buf ^ 1];    // (free now)
+    for (int32_t j = (int32_t)tid; j < tail_live; j += kSmallThreads) {
+        const uint32_t w = in_lds ? tail_keys_lds[final_buf][j] : tail_keys[j];
         const int32_t land = offs[w] + cnts[w];
+        site.tailLand[j] = land;
+        if (in_lds) {
+            land_lds[j] = land;
+            tail_keys[j] = w;
+            tail_rows[j] = tail_rows_lds[final_buf][j];
+        }
+    }
+    __syncthreads();
+
+    // tileTailStart[t] = first sorted tail row landing in tile t or later
+    auto tile_of = [&](int32_t j) {
+        const int32_t land = in_lds ? land_lds[j] : site.tailLand[j];
         const int32_t t = land >> kCompactTileShift;
         return t < num_tiles - 1 ? t : num_tiles - 1;
     };
@@ -1010,8 +1158,8 @@ sortCompactPrepare(EcsState *S, const SortSite *sites)
         return;
     }
     for (int32_t j = (int32_t)tid; j < tail_live; j += kSmallThreads) {
-        const int32_t mine = tile_of(tail_keys[j]);
-        const int32_t before = j > 0 ? tile_of(tail_keys[j - 1]) : -1;
+        const int32_t mine = tile_of(j);
+        const int32_t before = j > 0 ? tile_of(j - 1) : -1;
         for (int32_t t = before + 1; t <= mine; t++) {
             site.tileTailStart[t] = j;
         }
@@ -1092,9 +1240,6 @@ sortCompactScatter(EcsState *S, const SortSite *sites)
     int32_t *out_rows = final_in_b ? site.idxB : site.idxA;
     const uint32_t *tail_keys = final_in_b ? site.keysA : site.keysB;
     const int32_t *tail_rows = final_in_b ? site.idxA : site.idxB;
-    const int32_t *offs = tbl.worldOffsets;
-    const int32_t *cnts = tbl.worldCounts;
-
     auto tile_count = [&](int32_t t) {
         return (t << kCompactTileShift) < prefix ? site.tileCounts[t] : 0;
     };
@@ -1138,6 +1283,23 @@ sortCompactScatter(EcsState *S, const SortSite *sites)
             }
         }
 
+        // the sorted tail rows landing in this tile (typically a handful: the
+        // first one per thread stays in registers)
+        const int32_t tail_first = site.tileTailStart[tile];
+        const int32_t tail_end = site.tileTailStart[tile + 1];
+        auto landing_at = [&](int32_t j) {
+            int32_t at = site.tailLand[j] - first;
+            return at < 0 ? 0 : (at > kCompactTile ? kCompactTile : at);
+        };
+        const int32_t my_tail = tail_first + tid;
+        int32_t my_at = 0, my_row = 0;
+        uint32_t my_world = 0;
+        if (my_tail < tail_end) {
+            my_at = landing_at(my_tail);
+            my_row = tail_rows[my_tail];
+            my_world = tail_keys[my_tail];
+        }
+
         // survivors of the tiles before this one (the sum's barriers also order
         // the clearing of lds.landing before the atomics below)
         int32_t part = 0;
@@ -1146,14 +1308,11 @@ sortCompactScatter(EcsState *S, const SortSite *sites)
         }
         const int32_t live_before_tile = blockSum256(part, lds.reduce);
 
-        // the sorted tail rows landing in this tile
-        const int32_t tail_first = site.tileTailStart[tile];
-        const int32_t tail_end = site.tileTailStart[tile + 1];
-        for (int32_t j = tail_first + tid; j < tail_end; j += kSortThreads) {
-            const uint32_t w = tail_keys[j];
-            int32_t at = offs[w] + cnts[w] - first;
-            at = at < 0 ? 0 : (at > kCompactTile ? kCompactTile : at);
-            atomicAdd(&lds.landing[at], 1u);
+        if (my_tail < tail_end) {
+            atomicAdd(&lds.landing[my_at], 1u);
+        }
+        for (int32_t j = my_tail + kSortThreads; j < tail_end; j += kSortThreads) {
+            atomicAdd(&lds.landing[landing_at(j)], 1u);
         }
         __syncthreads();
 
@@ -1198,13 +1357,17 @@ sortCompactScatter(EcsState *S, const SortSite *sites)
         }
         __syncthreads();
 
-        for (int32_t j = tail_first + tid; j < tail_end; j += kSortThreads) {
-            const uint32_t w = tail_keys[j];
-            int32_t at = offs[w] + cnts[w] - first;
-            at = at < 0 ? 0 : (at > kCompactTile ? kCompactTile : at);
-            const int32_t dest = live_before_tile + (int32_t)lds.liveBefore[at] + j;
+        if (my_tail < tail_end) {
+            const int32_t dest = live_before_tile +
+                (int32_t)lds.liveBefore[my_at] + my_tail;
+            out_rows[dest] = my_row;
+            out_keys[dest] = my_world;
+        }
+        for (int32_t j = my_tail + kSortThreads; j < tail_end; j += kSortThreads) {
+            const int32_t dest = live_before_tile +
+                (int32_t)lds.liveBefore[landing_at(j)] + j;
             out_rows[dest] = tail_rows[j];
-            out_keys[dest] = w;
+            out_keys[dest] = tail_keys[j];
         }
         __syncthreads();
     }

@@ -184,7 +184,9 @@ struct SimTraits {
 
     // flags: low 16 bits = autoResetDenom (0 disables random resets); render
     // variant: bits 16-23 = output resolution (0: 64), bit 24 = depth only,
-    // bit 25 = the sun casts shadows
+    // bit 25 = the sun casts shadows, bit 26 = no ray caster (render-prep
+    // systems only: without render-target entities the entity ids are the CPU
+    // backend's, whose CPU mode has no ray caster either)
     static Sim::Config makeConfig(const SimCreateArgs &args)
     {
 #if defined(ESCPHYS_RENDER) && defined(SIM_BACKEND_REF_CPU)
@@ -222,6 +224,10 @@ struct SimTraits {
         cfg.renderMode = (args.flags >> 24) & 1u ?
             madrona::CudaBatchRenderConfig::RenderMode::Depth :
             madrona::CudaBatchRenderConfig::RenderMode::RGBD;
+        if (((args.flags >> 26) & 1u) != 0u) {
+            g_resolution = 0;
+            return madrona::Optional<madrona::CudaBatchRenderConfig>::none();
+        }
         cfg.renderResolution = (args.flags >> 16) & 0xFFu;
         if (cfg.renderResolution == 0) cfg.renderResolution = 64;
         g_resolution = cfg.renderResolution;
@@ -268,8 +274,10 @@ void SimTraits::describeTensors(T &out, uint32_t num_worlds)
                     (uint32_t)ExportID::StepsRemaining });
 #if defined(ESCPHYS_RENDER) && !defined(SIM_BACKEND_REF_CPU)
     const int64_t R = g_resolution;
-    out.push_back({ "rgb", SIM_U8, { W * A, R, R, 4 }, (uint32_t)ExportID::RGB });
-    out.push_back({ "depth", SIM_F32, { W * A, R, R }, (uint32_t)ExportID::Depth });
+    if (R != 0) {
+        out.push_back({ "rgb", SIM_U8, { W * A, R, R, 4 }, (uint32_t)ExportID::RGB });
+        out.push_back({ "depth", SIM_F32, { W * A, R, R }, (uint32_t)ExportID::Depth });
+    }
 #endif
 }
 

@@ -137,7 +137,7 @@ def test_escape_room_render_lockstep(built, worlds, steps, denom):
     with Simulator(ref_lib_path("escape_room_render"), worlds, seed=4, flags=denom,
                    num_workers=1 if worlds <= 64 else 0) as ref, \
             Simulator(hip_lib_path("escape_room_render"), worlds, seed=4,
-                      flags=denom | (16 << 16)) as hip:
+                      flags=denom | (1 << 26)) as hip:    # (no render-target entities)
         for step in range(1, steps + 1):
             act = _actions(rng, worlds)
             ref.write_tensor("action", act)
@@ -176,5 +176,7 @@ def test_config5_render_pass_full_size(built):
                                                threads=os.cpu_count() or 1)
         hip_rgb, hip_depth = hip.read_tensor("rgb"), hip.read_tensor("depth")
         assert hip_depth.shape == (2 * worlds, res, res)
+        # (67 M pixels; the runs show 1 depth beyond 1e-5 and 1 colour off by more
+        # than a step: a ray grazing a triangle edge)
         _compare(hip_rgb, hip_depth, ref_rgb, ref_depth, True, ("config5", worlds, res),
-                 flips=8, offs=8)
+                 flips=4, offs=4)

@@ -302,17 +302,21 @@ def test_sort_stress_lockstep(built, worlds):
 #   grid N             key-pass / scatter grids capped at N workgroups: tiles
 #                      beyond the grid are taken in further rounds
 #                      (sort_archetype.hip: tile = workgroup + round * grid)
-SORT_CHAINS = [("0", ""), ("2", ""), ("2", "3"), ("0", "2"), ("1", "1")]
+#   wide 0             gather word by word instead of in 16-byte chunks of the
+#                      destination
+SORT_CHAINS = [("0", "", "1"), ("2", "", "1"), ("2", "3", "1"), ("0", "2", "1"),
+               ("1", "1", "1"), ("1", "", "0"), ("0", "", "0")]
 
 
-@pytest.mark.parametrize("compact,grid", SORT_CHAINS)
+@pytest.mark.parametrize("compact,grid,wide", SORT_CHAINS)
 @pytest.mark.parametrize("sim,worlds,steps,denom", [
     ("sort_stress", 1500, 25, 0), ("sort_stress", 37, 40, 0),
     ("escape_room", 2048, 60, 30)])
 def test_sort_chains_lockstep(built, monkeypatch, sim, worlds, steps, denom, compact,
-                              grid):
+                              grid, wide):
     _need_ref(sim)
     monkeypatch.setenv("MADRONA_MWHIP_SORT_COMPACT", compact)
+    monkeypatch.setenv("MADRONA_MWHIP_GATHER_WIDE", wide)
     if grid:
         monkeypatch.setenv("MADRONA_MWHIP_SORT_MAX_GRID", grid)
     if worlds < 100:
