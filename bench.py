@@ -94,6 +94,42 @@ def parse_args():
     return p.parse_args()
 
 
+def measure_hbm_bandwidth(seconds=0.2):
+    """the 8 TB/s spec next to what THIS box's HBM delivers: a device
+    copy (read + write, 512 MiB each way per launch: far beyond the caches) and a
+    triad a = b + s * c on fp32 (2 reads + 1 write), timed with events on the
+    current stream for about `seconds` each.  GB/s of bytes moved."""
+    import torch
+    n = 128 * 1024 * 1024           # 512 MiB of fp32 per array
+    a = torch.empty(n, dtype=torch.float32, device="cuda")
+    b = torch.ones(n, dtype=torch.float32, device="cuda")
+    c = torch.ones(n, dtype=torch.float32, device="cuda")
+    out = {}
+    for name, fn, nbytes in (("copy", lambda: a.copy_(b), 2 * 4 * n),
+                             ("triad", lambda: torch.add(b, c, alpha=2.0, out=a),
+                              3 * 4 * n)):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev1 = torch.cuda.Event(enable_timing=True)
+        reps, total_ms = 0, 0.0
+        while total_ms < seconds * 1e3 and reps < 2000:
+            ev0.record()
+            for _ in range(10):
+                fn()
+            ev1.record()
+            torch.cuda.synchronize()
+            total_ms += ev0.elapsed_time(ev1)
+            reps += 10
+        out[name] = nbytes * reps / (total_ms * 1e-3) / 1e9
+    del a, b, c
+    torch.cuda.empty_cache()
+    return {"copy_GBps": round(out["copy"], 1), "triad_GBps": round(out["triad"], 1),
+            "note": "torch device copy / fused add on 512 MiB fp32 arrays, events "
+                    "around 10 launches at a time"}
+
+
 def recorded_traffic():
     """HBM bytes per launch measured with the PMC counters (rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE in separate passes; rocprofv3 cannot run inside the

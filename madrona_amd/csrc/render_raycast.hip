@@ -111,6 +111,23 @@ __device__ inline int32_t lcp(const uint32_t *codes, int32_t n, int32_t i,
     return 32 + __builtin_clz((uint32_t)i ^ (uint32_t)j);
 }
 
+// Boxes that only steer a traversal (top- and bottom-level nodes, the staged
+// leaf boxes) are grown by a hair: a ray running exactly along a face of the
+// geometry (axis-aligned scenes seen through the exact centre row / column of
+// an odd resolution) must still enter the box -- the watertight triangle test
+// behind it counts a hit on that face's edge, and so does the reference
+// (whose dequantised node boxes are conservative too).
+__host__ __device__ inline AABB inflated(const AABB &b)
+{
+    auto grow = [](float v) { return 1e-5f * (v < 0.f ? -v : v) + 1e-6f; };
+    return AABB {
+        { b.pMin.x - grow(b.pMin.x), b.pMin.y - grow(b.pMin.y),
+          b.pMin.z - grow(b.pMin.z) },
+        { b.pMax.x + grow(b.pMax.x), b.pMax.y + grow(b.pMax.y),
+          b.pMax.z + grow(b.pMax.z) },
+    };
+}
+
 __device__ inline AABB merge(const AABB &a, const AABB &b)
 {
     return AABB {
@@ -203,7 +220,7 @@ renderTlasBuild(EcsState *S, RenderParams params)
     if (n == 1) {
         if (lane == 0) {
             BvhNode root {};
-            root.box[0] = leaf_boxes[0].aabb;
+            root.box[0] = inflated(leaf_boxes[0].aabb);
             root.box[1] = root.box[0];
             root.child[0] = kLeafBit | 0u;
             root.child[1] = kNoChild;
@@ -273,9 +290,9 @@ renderTlasBuild(EcsState *S, RenderParams params)
             }
             const uint32_t l = lds.left[cur], r = lds.right[cur];
             const AABB lb = (l & kLeafBit) != 0u ?
-                leaf_boxes[l & ~kLeafBit].aabb : lds.box[l];
+                inflated(leaf_boxes[l & ~kLeafBit].aabb) : lds.box[l];
             const AABB rb = (r & kLeafBit) != 0u ?
-                leaf_boxes[r & ~kLeafBit].aabb : lds.box[r];
+                inflated(leaf_boxes[r & ~kLeafBit].aabb) : lds.box[r];
             lds.box[cur] = merge(lb, rb);
             cur = lds.parent[cur];
         }
@@ -285,10 +302,10 @@ renderTlasBuild(EcsState *S, RenderParams params)
     for (int32_t i = (int32_t)lane; i < n - 1; i += 64) {
         const uint32_t l = lds.left[i], r = lds.right[i];
         BvhNode node {};
-        node.box[0] = (l & kLeafBit) != 0u ? leaf_boxes[l & ~kLeafBit].aabb :
-                                             lds.box[l];
-        node.box[1] = (r & kLeafBit) != 0u ? leaf_boxes[r & ~kLeafBit].aabb :
-                                             lds.box[r];
+        node.box[0] = (l & kLeafBit) != 0u ?
+            inflated(leaf_boxes[l & ~kLeafBit].aabb) : lds.box[l];
+        node.box[1] = (r & kLeafBit) != 0u ?
+            inflated(leaf_boxes[r & ~kLeafBit].aabb) : lds.box[r];
         node.child[0] = l;
         node.child[1] = r;
         nodes[i] = node;
@@ -367,8 +384,11 @@ __device__ inline bool rayTriangle(const Vector3 &ta, const Vector3 &tb,
 
 // A ray prepared for slab tests: t = b * inv - o_inv per bound.  inv from
 // v_rcp_f32 (1 ulp): the boxes only steer the traversal, and boxEntry() keeps a
-// margin.  (A direction component of exactly 0 gives inf / NaN terms that
-// fminf / fmaxf drop: that slab then never rejects, which is conservative.)
+// margin.  A direction component of exactly 0 would give inf - inf = NaN terms
+// (and fmaxf(-inf, NaN) = -inf: a box the ray runs through rejected); such a
+// component takes a huge finite reciprocal instead, so that t = (b - o) * 1e25
+// has the right sign and is far outside [0, t_max] unless o sits on the bound
+// -- which the hair the steering boxes are grown by (inflated()) excludes.
 struct SlabRay {
     Vector3 inv;
     Vector3 oInv;
@@ -377,8 +397,10 @@ struct SlabRay {
 __device__ inline SlabRay slabRay(const Vector3 &o, const Vector3 &d)
 {
     SlabRay r;
-    r.inv = Vector3 { __builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y),
-                      __builtin_amdgcn_rcpf(d.z) };
+    r.inv = Vector3 {
+        d.x == 0.f ? __builtin_copysignf(1e25f, d.x) : __builtin_amdgcn_rcpf(d.x),
+        d.y == 0.f ? __builtin_copysignf(1e25f, d.y) : __builtin_amdgcn_rcpf(d.y),
+        d.z == 0.f ? __builtin_copysignf(1e25f, d.z) : __builtin_amdgcn_rcpf(d.z) };
     r.oInv = Vector3 { o.x * r.inv.x, o.y * r.inv.y, o.z * r.inv.z };
     return r;
 }
@@ -533,10 +555,31 @@ __device__ __forceinline__ void traceInstance(
         const float ty1 = fmaf(b[4], slab.inv.y, -slab.oInv.y);
         const float tz0 = fmaf(b[2], slab.inv.z, -slab.oInv.z);
         const float tz1 = fmaf(b[5], slab.inv.z, -slab.oInv.z);
-        const float nx = fminf(tx0, tx1), ny = fminf(ty0, ty1), nz = fminf(tz0, tz1);
+        float nx = fminf(tx0, tx1), ny = fminf(ty0, ty1), nz = fminf(tz0, tz1);
+        float fx = fmaxf(tx0, tx1), fy = fmaxf(ty0, ty1), fz = fmaxf(tz0, tz1);
+        // A ray parallel to a pair of faces is inside that slab for every t or
+        // for none -- bounds included: running exactly along a face it meets
+        // the neighbouring faces on their shared edge, which the watertight
+        // test (and so the reference) counts as a hit.
+        bool outside = false;
+        if (d.x == 0.f) {
+            outside = outside || o.x < b[0] || o.x > b[3];
+            nx = -INFINITY; fx = INFINITY;
+        }
+        if (d.y == 0.f) {
+            outside = outside || o.y < b[1] || o.y > b[4];
+            ny = -INFINITY; fy = INFINITY;
+        }
+        if (d.z == 0.f) {
+            outside = outside || o.z < b[2] || o.z > b[5];
+            nz = -INFINITY; fz = INFINITY;
+        }
+        if (outside) {
+            t_max = t_max / t_scale;
+            return;
+        }
         const float t_near = fmaxf(fmaxf(nx, ny), nz);
-        const float t_far = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)),
-                                  fminf(fmaxf(tz0, tz1), t_max));
+        const float t_far = fminf(fminf(fx, fy), fminf(fz, t_max));
         if (t_near <= fmaf(t_far, 1.00001f, 1e-6f)) {
             const RayIsect isect = rayIsect(d);
             const uint32_t axis = nx >= ny && nx >= nz ? 0u : (ny >= nz ? 1u : 2u);
@@ -838,7 +881,7 @@ renderRaycast(EcsState *S, RenderParams params)
                 const LeafBox *boxes_hbm = (const LeafBox *)
                     inst_tbl.columns[params.tlbvhColumn] + inst_first;
                 if ((int32_t)tid < num_inst) {
-                    lds.leafBox[tid] = boxes_hbm[tid].aabb;
+                    lds.leafBox[tid] = inflated(boxes_hbm[tid].aabb);
                     lds.shade[tid] = shadeRecord(inst_hbm[tid], geo_dev);
                 }
             }
@@ -1138,7 +1181,7 @@ void buildBlas(std::vector<BuildTri> &tris, uint32_t first, uint32_t count,
     const uint32_t part_first[2] = { first, first + half };
     const uint32_t part_count[2] = { half, count - half };
     for (int c = 0; c < 2; c++) {
-        nodes[node_idx].box[c] = boxOf(tris, part_first[c], part_count[c]);
+        nodes[node_idx].box[c] = inflated(boxOf(tris, part_first[c], part_count[c]));
         if (part_count[c] <= kLeafTris) {
             nodes[node_idx].child[c] =
                 kLeafBit | ((part_count[c] - 1u) << 28) | part_first[c];
@@ -1205,7 +1248,7 @@ int buildRenderGeometry(const mwhip_render_geometry &src, RenderGeometryHost &ou
         if (tri_count > kLeafTris) {
             buildBlas(tris, 0, tri_count, nodes, 0);
         } else if (tri_count > 0) {
-            nodes[0].box[0] = boxOf(tris, 0, tri_count);
+            nodes[0].box[0] = inflated(boxOf(tris, 0, tri_count));
             nodes[0].child[0] = kLeafBit | ((tri_count - 1u) << 28);
         }
         if (nodes.size() > kMaxBlasNodes) {

@@ -1684,6 +1684,43 @@ static int makeSortBatch(mwhip_exec *exec,
     HIPCHK(hipMemcpy(out->gatherColumnsDev, cols.data(),
         cols.size() * sizeof(GatherColumn), hipMemcpyHostToDevice));
     out->numGatherColumns = (uint32_t)cols.size();
+
+    // ---- the gather's workgroups, shared out by bytes to move ----
+    {
+        const uint32_t target = std::max(envU32("MADRONA_MWHIP_GATHER_BLOCKS", 2048), 1u);
+        std::vector<double> weight(cols.size(), 0.0);
+        double total = 0.0;
+        for (size_t c = 0; c < cols.size(); c++) {
+            const SortSiteHost &site = out->sites[cols[c].site];
+            const ArchetypeRec &arch = exec->archetypes[site.archetype];
+            uint64_t rows = site.archetype < exec->rowsAtGraphBuild.size() ?
+                exec->rowsAtGraphBuild[site.archetype] : 0;
+            if (rows == 0) rows = arch.capacity;
+            if (cols[c].column == kWorldRangesColumn) {
+                // two binary searches per world: latency, not bytes
+                weight[c] = 64.0 * exec->cfg.num_worlds;
+            } else {
+                // (+ the 4-byte permutation entry every row of a column reads)
+                weight[c] = (double)rows * (arch.colBytes[cols[c].column] + 4.0);
+            }
+            total += weight[c];
+        }
+        std::vector<GatherSlice> slices;
+        for (size_t c = 0; c < cols.size(); c++) {
+            uint32_t n = (uint32_t)(target * weight[c] / std::max(total, 1.0) + 0.5);
+            // at least 4 KB of work per workgroup, at least one workgroup
+            n = std::min<uint32_t>(n, (uint32_t)(weight[c] / 4096.0) + 1u);
+            n = std::max<uint32_t>(n, 1u);
+            for (uint32_t i = 0; i < n; i++) {
+                slices.push_back(GatherSlice { (uint32_t)c, i, n, 0u });
+            }
+        }
+        rc = devAllocT(exec, &out->gatherSlicesDev, slices.size());
+        if (rc != 0) return rc;
+        HIPCHK(hipMemcpy(out->gatherSlicesDev, slices.data(),
+            slices.size() * sizeof(GatherSlice), hipMemcpyHostToDevice));
+        out->numGatherSlices = (uint32_t)slices.size();
+    }
     return 0;
 }
 

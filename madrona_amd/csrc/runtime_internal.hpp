@@ -92,6 +92,17 @@ struct GatherColumn {
     unsigned long long invMagicDwords;  // floor(2^64 / rowDwords) + 1
 };
 
+// One workgroup of the gather: slice `slice` of `numSlices` of a column.  The
+// workgroups of a launch are shared out over the columns by the bytes each has
+// to move (a 28-byte solver-state column gets seven times the workgroups of a
+// 4-byte id column), about as many in total as the chip keeps resident at once.
+struct GatherSlice {
+    uint32_t column;                // index into the batch's GatherColumn list
+    uint32_t slice;
+    uint32_t numSlices;
+    uint32_t pad_;
+};
+
 struct SortSiteHost {
     uint32_t archetype;
     uint32_t keyColumn;
@@ -111,6 +122,8 @@ struct SortBatch {
     SortSite *sitesDev = nullptr;
     GatherColumn *gatherColumnsDev = nullptr;
     uint32_t numGatherColumns = 0;
+    GatherSlice *gatherSlicesDev = nullptr;
+    uint32_t numGatherSlices = 0;
     bool hasPinned = false;         // a sorted table has exported columns
     uint32_t maxCapacity = 0;
     // every table of the batch holds few rows: one launch (sortSmall) instead

@@ -678,9 +678,11 @@ __device__ inline void gatherColumn(EcsState *S, const SortSite &site,
                                     int32_t n_out, int32_t tid, int32_t stride);
 
 __global__ void __launch_bounds__(kSortThreads)
-sortGather(EcsState *S, const SortSite *sites, const GatherColumn *columns)
+sortGather(EcsState *S, const SortSite *sites, const GatherColumn *columns,
+           const GatherSlice *slices)
 {
-    const GatherColumn gc = columns[blockIdx.y];
+    const GatherSlice slice = slices[blockIdx.x];
+    const GatherColumn gc = columns[slice.column];
     const SortSite &site = sites[gc.site];
     TableHdr &tbl = S->tables[site.archetype];
 
@@ -691,11 +693,11 @@ sortGather(EcsState *S, const SortSite *sites, const GatherColumn *columns)
     const int32_t n_out = state->rowsOut;
 
     gatherColumn(S, site, gc, tbl, n_out,
-                 (int32_t)(blockIdx.x * kSortThreads + threadIdx.x),
-                 (int32_t)(gridDim.x * kSortThreads));
+                 (int32_t)(slice.slice * kSortThreads + threadIdx.x),
+                 (int32_t)(slice.numSlices * kSortThreads));
 
     // (the passes are over: their histograms and counters are dead)
-    if (gc.column == 0u && blockIdx.x == 0) {
+    if (gc.column == 0u && slice.slice == 0u) {
         cleanSortState(state);
     }
 }
@@ -1506,17 +1508,12 @@ void buildSortLaunches(const SortBatch &batch, std::vector<KernelLaunch> &out)
     {
         KernelLaunch k;
         k.fn = (const void *)&sortGather;
-        // Small tables: about 4096 workgroups over all columns (two resident
-        // rounds on 256 CUs) with 4 words in flight per thread beat one
-        // workgroup per 1024 rows (measured at 4096 worlds: 13.8 -> 10.5 us);
-        // large tables keep the row-proportional grid.
-        const uint32_t gather_blocks = std::min<uint32_t>(stream_blocks,
-            std::max<uint32_t>(
-                4096u / std::max<uint32_t>(batch.numGatherColumns, 1u),
-                (max_capacity + kSortThreads * 8 - 1) / (kSortThreads * 8)));
-        k.grid = dim3(gather_blocks, (uint32_t)batch.numGatherColumns, 1);
+        // one workgroup per slice of a column (runtime.hip, makeSortBatch: the
+        // workgroups are shared out over the columns by the bytes they move)
+        k.grid = dim3(std::max(batch.numGatherSlices, 1u), 1, 1);
         k.block = dim3(kSortThreads, 1, 1);
-        k.setArgs(batch.stateDev, batch.sitesDev, batch.gatherColumnsDev);
+        k.setArgs(batch.stateDev, batch.sitesDev, batch.gatherColumnsDev,
+                  batch.gatherSlicesDev);
         k.role = "sort.gather";
         k.kind = MWHIP_NODE_SORT_ARCHETYPE;
         k.sortBatch = &batch;

@@ -5,20 +5,32 @@
     python profiles/tools/sort_variants.py > gpurun_out/sort_variants.jsonl
 
 Prints one JSON line per (workload, variant): the sort kernels of a step with
-their event-timed averages, and the node's SURVEY 8d roofline fraction."""
+their event-timed averages, and the node's SURVEY 8d roofline fraction; first
+line: the box's measured copy / triad bandwidth."""
 import json
 import os
 import subprocess
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-WORKLOADS = [("escape_room_phys", 8192), ("escape_room", 4096), ("escape_room", 65536)]
-VARIANTS = {
-    "radix": {"MADRONA_MWHIP_SORT_COMPACT": "0", "MADRONA_MWHIP_GATHER_WIDE": "0"},
-    "radix+wide": {"MADRONA_MWHIP_SORT_COMPACT": "0"},
-    "compact": {"MADRONA_MWHIP_GATHER_WIDE": "0"},
-    "compact+wide": {},
-}
+sys.path.insert(0, REPO)
+RADIX = {"MADRONA_MWHIP_SORT_COMPACT": "0"}
+RUNS = [
+    ("escape_room_phys", 8192, "radix", RADIX),
+    ("escape_room_phys", 8192, "compact b1024", {"MADRONA_MWHIP_GATHER_BLOCKS": "1024"}),
+    ("escape_room_phys", 8192, "compact b2048", {}),
+    ("escape_room_phys", 8192, "compact b4096", {"MADRONA_MWHIP_GATHER_BLOCKS": "4096"}),
+    ("escape_room_phys", 8192, "compact b8192", {"MADRONA_MWHIP_GATHER_BLOCKS": "8192"}),
+    ("escape_room_phys", 8192, "compact b2048 narrow", {"MADRONA_MWHIP_GATHER_WIDE": "0"}),
+    ("escape_room", 4096, "radix", RADIX),
+    ("escape_room", 4096, "compact b2048", {}),
+    ("escape_room", 4096, "compact b4096", {"MADRONA_MWHIP_GATHER_BLOCKS": "4096"}),
+    ("escape_room", 65536, "radix", RADIX),
+    ("escape_room", 65536, "compact b2048", {}),
+    ("escape_room", 65536, "compact b4096", {"MADRONA_MWHIP_GATHER_BLOCKS": "4096"}),
+    ("escape_room", 65536, "compact b8192", {"MADRONA_MWHIP_GATHER_BLOCKS": "8192"}),
+    ("escape_room", 65536, "compact b2048 narrow", {"MADRONA_MWHIP_GATHER_WIDE": "0"}),
+]
 
 CHILD = r"""
 import json, sys
@@ -35,8 +47,12 @@ print(json.dumps({"sim": sim, "worlds": worlds, "ms_per_step": r["ms_per_step"],
                   "sort_node_MB": node and node["algo_bytes_per_launch"] / 1e6}))
 """ % REPO
 
-for sim, worlds in WORKLOADS:
-    for name, env in VARIANTS.items():
+if __name__ == "__main__":
+    import bench
+    import torch
+    torch.cuda.set_device(0)
+    print(json.dumps({"hbm": bench.measure_hbm_bandwidth()}), flush=True)
+    for sim, worlds, name, env in RUNS:
         e = dict(os.environ)
         e.update(env)
         out = subprocess.run([sys.executable, "-c", CHILD, sim, str(worlds)], env=e,
