@@ -42,39 +42,65 @@ __device__ inline void phaseFence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// The helpers below work on groups of LPW consecutive lanes (LPW = 64: the whole
+// wavefront; 32: two worlds share a wavefront, one per half).  `lane` is the
+// index inside the group; the lanes of a group are always converged when they
+// get here, the other group of the wavefront need not be.
+template <int LPW = 64>
 __device__ inline uint32_t exclusiveScan(uint32_t v, uint32_t lane,
                                          uint32_t *total)
 {
     uint32_t incl = v;
 #pragma unroll
-    for (uint32_t d = 1; d < 64; d <<= 1) {
-        uint32_t up = __shfl_up(incl, d, 64);
+    for (uint32_t d = 1; d < (uint32_t)LPW; d <<= 1) {
+        uint32_t up = __shfl_up(incl, d, LPW);
         if (lane >= d) incl += up;
     }
-    *total = __shfl(incl, 63, 64);
+    *total = __shfl(incl, LPW - 1, LPW);
     return incl - v;
 }
 
+template <int LPW = 64>
 __device__ inline uint32_t maxReduce(uint32_t v)
 {
 #pragma unroll
-    for (uint32_t d = 32; d > 0; d >>= 1) {
-        uint32_t o = __shfl_xor(v, d, 64);
+    for (uint32_t d = LPW / 2; d > 0; d >>= 1) {
+        uint32_t o = __shfl_xor(v, d, LPW);
         v = o > v ? o : v;
     }
     return v;
+}
+
+// ballot over the lanes of my group: bit i = lane i of the group
+template <int LPW = 64>
+__device__ inline uint64_t groupBallot(bool pred)
+{
+    const uint64_t all = __builtin_amdgcn_ballot_w64(pred);
+    if constexpr (LPW == 64) {
+        return all;
+    } else {
+        const uint32_t first = laneID() & ~(uint32_t)(LPW - 1);
+        return (all >> first) & ((1ull << LPW) - 1ull);
+    }
+}
+
+// set bits of a group ballot below my lane
+__device__ inline uint32_t rankInGroup(uint64_t mask, uint32_t lane)
+{
+    return (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
 }
 
 // arg-max over the wave where the LOWEST index wins among equal values -- the
 // result of a sequential "if (v > best)" scan in index order.  Every lane
 // returns the winner.  (Lane-local values are never NaN: they start at
 // -FLT_MAX and are only replaced through a strict >.)
+template <int LPW = 64>
 __device__ inline void argMaxFirst(float &v, uint32_t &idx)
 {
 #pragma unroll
-    for (uint32_t d = 32; d > 0; d >>= 1) {
-        float ov = __shfl_xor(v, d, 64);
-        uint32_t oi = __shfl_xor(idx, d, 64);
+    for (uint32_t d = LPW / 2; d > 0; d >>= 1) {
+        float ov = __shfl_xor(v, d, LPW);
+        uint32_t oi = __shfl_xor(idx, d, LPW);
         if (ov > v || (ov == v && oi < idx)) {
             v = ov;
             idx = oi;
@@ -128,7 +154,7 @@ __device__ inline uint32_t faceVertexCount(const HullT &h, uint32_t face_idx)
 
 // SAT face query with the faces of `a` spread over the lanes (sequential
 // reference: narrowphase.hpp queryFaceDirections)
-template <typename HullA, typename HullB>
+template <int LPW = 64, typename HullA, typename HullB>
 __device__ inline FaceQuery queryFaceDirectionsWave(uint32_t lane,
                                                     const HullA &a,
                                                     const HullB &b)
@@ -137,14 +163,14 @@ __device__ inline FaceQuery queryFaceDirectionsWave(uint32_t lane,
     uint32_t best_face = 0xFFFFFFFFu;
 
     const uint32_t num_a_faces = (uint32_t)a.numFaces();
-    for (uint32_t f = lane; f < num_a_faces; f += 64) {
+    for (uint32_t f = lane; f < num_a_faces; f += LPW) {
         float face_dist = getHullDistanceFromPlane(a.plane(f), b);
         if (face_dist > best_sep) {
             best_sep = face_dist;
             best_face = f;
         }
     }
-    wave::argMaxFirst(best_sep, best_face);
+    wave::argMaxFirst<LPW>(best_sep, best_face);
 
     FaceQuery best;
     best.separation = best_sep;
@@ -160,7 +186,7 @@ __device__ inline FaceQuery queryFaceDirectionsWave(uint32_t lane,
 
 // SAT edge query with the (edge of a, edge of b) pairs spread over the lanes
 // (sequential reference: narrowphase.hpp queryEdgeDirections)
-template <typename HullA, typename HullB>
+template <int LPW = 64, typename HullA, typename HullB>
 __device__ inline EdgeQuery queryEdgeDirectionsWave(uint32_t lane,
                                                     const HullA &a,
                                                     const HullB &b)
@@ -170,7 +196,7 @@ __device__ inline EdgeQuery queryEdgeDirectionsWave(uint32_t lane,
 
     const uint32_t b_num_edges = (uint32_t)b.numEdges();
     const uint32_t num_pairs = (uint32_t)a.numEdges() * b_num_edges;
-    for (uint32_t p = lane; p < num_pairs; p += 64) {
+    for (uint32_t p = lane; p < num_pairs; p += LPW) {
         int32_t he_idx_a = (int32_t)((p / b_num_edges) * 2);
         int32_t he_idx_b = (int32_t)((p % b_num_edges) * 2);
         EdgeTestResult r = testEdgePair(a, b, he_idx_a, he_idx_b);
@@ -179,7 +205,7 @@ __device__ inline EdgeQuery queryEdgeDirectionsWave(uint32_t lane,
             best_pair = p;
         }
     }
-    wave::argMaxFirst(best_sep, best_pair);
+    wave::argMaxFirst<LPW>(best_sep, best_pair);
 
     EdgeQuery best;
     best.separation = best_sep;
@@ -226,7 +252,7 @@ __device__ inline HullState makeHullStateWave(uint32_t lane,
     return HullState { world_mesh, center };
 }
 
-template <typename HullA, typename HullB>
+template <int LPW = 64, typename HullA, typename HullB>
 __device__ inline bool hullHullWaveSAT(uint32_t lane, const PairSetup &pair,
                                        const HullA &a, const HullB &b,
                                        WaveScratch *scratch,
@@ -236,7 +262,7 @@ __device__ inline bool hullHullWaveSAT(uint32_t lane, const PairSetup &pair,
 // false with *too_big set when the clipped polygon may not fit the LDS scratch.
 // (A template so that only the device pass instantiates it.  Keeping it out of
 // line to confine its register footprint was measured: 1166 -> 1637 us.)
-template <int = 0>
+template <int LPW = 64>
 __device__ inline bool
 hullHullWave(uint32_t lane, const PairSetup &pair,
                                     WaveScratch *scratch,
@@ -254,31 +280,31 @@ hullHullWave(uint32_t lane, const PairSetup &pair,
             scratch->hullVerts[0], scratch->hullPlanes[0]);
         HullState b = makeHullStateWave(lane, b_mesh, pair.b,
             scratch->hullVerts[1], scratch->hullPlanes[1]);
-        return hullHullWaveSAT(lane, pair, a, b, scratch, out, too_big);
+        return hullHullWaveSAT<LPW>(lane, pair, a, b, scratch, out, too_big);
     }
 
     LazyHull a(a_mesh, pair.a.pos, pair.a.rot, pair.a.scale);
     LazyHull b(b_mesh, pair.b.pos, pair.b.rot, pair.b.scale);
-    return hullHullWaveSAT(lane, pair, a, b, scratch, out, too_big);
+    return hullHullWaveSAT<LPW>(lane, pair, a, b, scratch, out, too_big);
 }
 
-template <typename HullA, typename HullB>
+template <int LPW, typename HullA, typename HullB>
 __device__ inline bool hullHullWaveSAT(uint32_t lane, const PairSetup &pair,
                                        const HullA &a, const HullB &b,
                                        WaveScratch *scratch,
                                        ContactConstraint *out, bool *too_big)
 {
-    FaceQuery face_query_a = queryFaceDirectionsWave(lane, a, b);
+    FaceQuery face_query_a = queryFaceDirectionsWave<LPW>(lane, a, b);
     if (face_query_a.separation > 0.0f) {
         return false;
     }
 
-    FaceQuery face_query_b = queryFaceDirectionsWave(lane, b, a);
+    FaceQuery face_query_b = queryFaceDirectionsWave<LPW>(lane, b, a);
     if (face_query_b.separation > 0.0f) {
         return false;
     }
 
-    EdgeQuery edge_query = queryEdgeDirectionsWave(lane, a, b);
+    EdgeQuery edge_query = queryEdgeDirectionsWave<LPW>(lane, a, b);
     if (edge_query.separation > 0.0f) {
         return false;
     }
@@ -361,14 +387,15 @@ struct WorldBodies {
 
 // Dependency levels for a window of <= 64 constraints held one per lane.
 // key_a / key_b: the two bodies (0 = static / none, never conflicts).
+template <int LPW = 64>
 __device__ inline uint32_t constraintLevels(uint32_t lane, uint32_t n,
                                             uint64_t key_a, uint64_t key_b)
 {
     uint32_t level = 0;
     for (uint32_t j = 0; j + 1 < n; j++) {
-        uint64_t ja = __shfl(key_a, j, 64);
-        uint64_t jb = __shfl(key_b, j, 64);
-        uint32_t jl = __shfl(level, j, 64);
+        uint64_t ja = __shfl(key_a, j, LPW);
+        uint64_t jb = __shfl(key_b, j, LPW);
+        uint32_t jl = __shfl(level, j, LPW);
         bool conflict =
             (ja != 0 && (ja == key_a || ja == key_b)) ||
             (jb != 0 && (jb == key_a || jb == key_b));
@@ -747,7 +774,7 @@ struct WaveCandidate {
     uint8_t bPrim;
 };
 
-template <int MAXB>
+template <int MAXB, int LPW = 64>
 struct WorldBlock {
     static constexpr int maxBodies = MAXB;
     // sized so that a 32-body block stays under 20 KB of LDS: eight
@@ -755,9 +782,10 @@ struct WorldBlock {
     // the kernel admits.  Six candidates per body in LDS (a dense pile of n
     // bodies has up to n (n - 1) / 2 pairs); more spill to HBM.
     static constexpr int maxCandidates = MAXB * 6;
-    // (at least a wave's worth: the narrowphase stages one contact per lane)
+    // (at least one per lane of the world: the narrowphase stages one contact
+    // per lane)
     static constexpr int maxContacts =
-        MAXB + MAXB / 4 > 64 ? MAXB + MAXB / 4 : 64;
+        MAXB + MAXB / 4 > LPW ? MAXB + MAXB / 4 : LPW;
     static constexpr int maxJoints = 6;         // more: read from HBM
     static constexpr int maxPrims = (int)PrimImage::maxPrims;   // more: hull data stays in HBM
     static constexpr int arenaDwords = (int)PrimImage::arenaDwords;   // object-space hull meshes
@@ -834,11 +862,12 @@ struct WorldBlock {
     }
 };
 
-// Copies `count` dwords with all lanes.
+// Copies `count` dwords with all lanes (of the world's group of LPW).
+template <int LPW = 64>
 __device__ inline void waveCopyDwords(uint32_t lane, uint32_t *dst,
                                       const uint32_t *src, uint32_t count)
 {
-    for (uint32_t i = lane; i < count; i += 64) {
+    for (uint32_t i = lane; i < count; i += LPW) {
         dst[i] = src[i];
     }
 }
@@ -846,13 +875,13 @@ __device__ inline void waveCopyDwords(uint32_t lane, uint32_t *dst,
 // Stages primitives [0, num_prims) of the object manager in LDS.  Returns an
 // ObjectManager whose primitive arrays point at the copies (or the original
 // when they do not fit).
-template <int MAXB>
+template <int MAXB, int LPW>
 __device__ inline ObjectManager stagePrimitives(uint32_t lane,
-                                                WorldBlock<MAXB> *w,
+                                                WorldBlock<MAXB, LPW> *w,
                                                 const ObjectManager &obj_mgr,
                                                 uint32_t num_prims)
 {
-    using Block = WorldBlock<MAXB>;
+    using Block = WorldBlock<MAXB, LPW>;
     if (num_prims > (uint32_t)Block::maxPrims) {
         return obj_mgr;
     }
@@ -863,13 +892,13 @@ __device__ inline ObjectManager stagePrimitives(uint32_t lane,
     if (image != nullptr) {
         const uint32_t image_prims = image->numPrims;
         if (image_prims >= num_prims && image_prims != 0) {
-            waveCopyDwords(lane, (uint32_t *)w->prims,
+            waveCopyDwords<LPW>(lane, (uint32_t *)w->prims,
                 (const uint32_t *)image->prims,
                 image_prims * (uint32_t)(sizeof(CollisionPrimitive) / 4));
-            waveCopyDwords(lane, (uint32_t *)w->primAABBs,
+            waveCopyDwords<LPW>(lane, (uint32_t *)w->primAABBs,
                 (const uint32_t *)image->primAABBs,
                 image_prims * (uint32_t)(sizeof(math::AABB) / 4));
-            waveCopyDwords(lane, w->arena, image->arena, image->arenaUsed);
+            waveCopyDwords<LPW>(lane, w->arena, image->arena, image->arenaUsed);
             int32_t offsets[4] = { -1, -1, -1, -1 };
             if (lane < image_prims) {
 #pragma unroll
@@ -894,10 +923,10 @@ __device__ inline ObjectManager stagePrimitives(uint32_t lane,
         }
     }
 
-    waveCopyDwords(lane, (uint32_t *)w->prims,
+    waveCopyDwords<LPW>(lane, (uint32_t *)w->prims,
         (const uint32_t *)obj_mgr.collisionPrimitives,
         num_prims * (uint32_t)(sizeof(CollisionPrimitive) / 4));
-    waveCopyDwords(lane, (uint32_t *)w->primAABBs,
+    waveCopyDwords<LPW>(lane, (uint32_t *)w->primAABBs,
         (const uint32_t *)obj_mgr.primitiveAABBs,
         num_prims * (uint32_t)(sizeof(math::AABB) / 4));
     wave::phaseFence();
@@ -946,12 +975,12 @@ __device__ inline ObjectManager stagePrimitives(uint32_t lane,
         }
 
         uint32_t *dst = w->arena + arena_used;
-        waveCopyDwords(lane, dst, (const uint32_t *)src.facePlanes, plane_dw);
-        waveCopyDwords(lane, dst + plane_dw,
+        waveCopyDwords<LPW>(lane, dst, (const uint32_t *)src.facePlanes, plane_dw);
+        waveCopyDwords<LPW>(lane, dst + plane_dw,
                        (const uint32_t *)src.halfEdges, hedge_dw);
-        waveCopyDwords(lane, dst + plane_dw + hedge_dw,
+        waveCopyDwords<LPW>(lane, dst + plane_dw + hedge_dw,
                        (const uint32_t *)src.vertices, vert_dw);
-        waveCopyDwords(lane, dst + plane_dw + hedge_dw + vert_dw,
+        waveCopyDwords<LPW>(lane, dst + plane_dw + hedge_dw + vert_dw,
                        src.faceBaseHalfEdges, base_dw);
         if (lane == 0) {
             geo::HalfEdgeMesh &staged = w->prims[p].hull.halfEdgeMesh;
@@ -971,9 +1000,9 @@ __device__ inline ObjectManager stagePrimitives(uint32_t lane,
     return staged;
 }
 
-template <int MAXB>
+template <int MAXB, int LPW = 64>
 struct LdsBodyStore {
-    WorldBlock<MAXB> *w;
+    WorldBlock<MAXB, LPW> *w;
 
     __device__ inline math::Vector3 &position(Loc l) { return w->pos[l.row]; }
     __device__ inline math::Quat &rotation(Loc l) { return w->rot[l.row]; }
@@ -996,15 +1025,15 @@ struct LdsBodyStore {
     }
 };
 
-template <int MAXB>
-__device__ inline uint64_t ldsBodyKey(const WorldBlock<MAXB> *w, int32_t k)
+template <int MAXB, int LPW>
+__device__ inline uint64_t ldsBodyKey(const WorldBlock<MAXB, LPW> *w, int32_t k)
 {
     return (w->resp[k] == (uint32_t)ResponseType::Static &&
             staticBodyIsInert(w->rot[k])) ? 0ull : (uint64_t)(k + 1);
 }
 
-template <int MAXB>
-__device__ inline PairSetup ldsSetupPair(const WorldBlock<MAXB> *w,
+template <int MAXB, int LPW>
+__device__ inline PairSetup ldsSetupPair(const WorldBlock<MAXB, LPW> *w,
                                          const ObjectManager &obj_mgr,
                                          const WaveCandidate &candidate)
 {
@@ -1022,15 +1051,15 @@ __device__ inline PairSetup ldsSetupPair(const WorldBlock<MAXB> *w,
 // the block `dst` (in LDS when the step kernel loads for itself, in HBM when
 // physicsPackKernel prepares the world image).  leaf_rank: leaf id -> position
 // in the BVH's traversal order (LDS).
-template <int MAXB>
-__device__ inline void loadWorldBodies(uint32_t lane, WorldBlock<MAXB> *dst,
+template <int MAXB, int LPW>
+__device__ inline void loadWorldBodies(uint32_t lane, WorldBlock<MAXB, LPW> *dst,
                                        const uint16_t *leaf_rank, Context &ctx,
                                        const WorldBodies &bodies,
                                        const broadphase::BVH &bvh,
                                        const ObjectManager &hbm_obj_mgr,
                                        int32_t num_bodies)
 {
-    for (int32_t k = (int32_t)lane; k < num_bodies; k += 64) {
+    for (int32_t k = (int32_t)lane; k < num_bodies; k += LPW) {
         Loc loc = bodies.loc(k);
         dst->bodyLoc[k] = loc;
         dst->pos[k] = ctx.getDirect<base::Position>(RGDCols::Position, loc);
@@ -1120,8 +1149,8 @@ physicsPackKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
 
         Block *image = (Block *)((char *)params.worldImages +
                                  (size_t)world * Block::imageBytes());
-        loadWorldBodies<MAXB>(lane, image, leaf_rank, ctx, bodies, bvh,
-                              hbm_obj_mgr, num_bodies);
+        loadWorldBodies<MAXB, 64>(lane, image, leaf_rank, ctx, bodies, bvh,
+                                  hbm_obj_mgr, num_bodies);
         wave::phaseFence();
     }
 }
@@ -1133,36 +1162,47 @@ physicsPackKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
 #ifndef MADRONA_PHYS_LDS_WAVES_PER_EU
 #define MADRONA_PHYS_LDS_WAVES_PER_EU 2
 #endif
-template <int MAXB>
+//
+// LPW = lanes per world.  64: one world per wavefront.  32: TWO worlds per
+// wavefront, one per half (MAXB <= 32): a 28-body world with ~14 contacts and
+// ~40 candidates keeps 45 % of 64 lanes busy, and the kernel is bound by
+// instruction issue -- the same instruction stream then advances two worlds.
+// Every wave-level primitive works on the world's group of LPW lanes
+// (wave::groupBallot, shuffles of width LPW); loop trip counts, early exits and
+// the level loops of the solver are per group, the halves diverge where their
+// worlds differ.  Two 32-body blocks are 35 KB of LDS: four wavefronts per CU,
+// one per SIMD, with the whole register file (512) to themselves.
+template <int MAXB, int LPW = 64>
 __global__ void __launch_bounds__(64)
-__attribute__((amdgpu_waves_per_eu(MAXB <= 64 ? MADRONA_PHYS_LDS_WAVES_PER_EU : 1)))
+__attribute__((amdgpu_waves_per_eu(
+    MAXB <= 64 && LPW == 64 ? MADRONA_PHYS_LDS_WAVES_PER_EU : 1)))
 physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
 {
-    using Block = WorldBlock<MAXB>;
+    using Block = WorldBlock<MAXB, LPW>;
+    static_assert(LPW == 64 || (LPW == 32 && MAXB <= 32));
+    constexpr int worlds_per_wave = 64 / LPW;
 
     StateManager *state_mgr = static_cast<StateManager *>(S);
     PhysicsScratch *ps = detail::scratch(S);
     const PhysicsStepParams params = *(const PhysicsStepParams *)node_data;
 
-    const uint32_t lane = wave::laneID();
+    // lane = index inside the world's group of LPW lanes
+    const uint32_t lane = wave::laneID() & (uint32_t)(LPW - 1);
+    const int32_t group = (int32_t)(wave::laneID() / (uint32_t)LPW);
     const int32_t num_worlds = S->numWorlds;
 
-    __shared__ Block block;
-    Block *w = &block;
-    LdsBodyStore<MAXB> store { w };
-
-    // generic fallback only (hulls whose faces outgrow the LDS scratch)
-    constexpr int32_t max_elems = MADRONA_PHYS_MAX_HULL_ELEMS;
-    geo::Plane tmp_faces[max_elems];
-    math::Vector3 tmp_vertices[max_elems];
+    __shared__ Block blocks[worlds_per_wave];
+    Block *w = &blocks[group];
+    LdsBodyStore<MAXB, LPW> store { w };
 
 #ifdef MADRONA_PHYS_PROFILE
     unsigned long long prof_t = __builtin_readcyclecounter();
     unsigned long long prof_acc[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 #endif
 
-    for (int32_t world = (int32_t)blockIdx.x; world < num_worlds;
-         world += (int32_t)gridDim.x) {
+    for (int32_t world = (int32_t)blockIdx.x * worlds_per_wave + group;
+         world < num_worlds;
+         world += (int32_t)gridDim.x * worlds_per_wave) {
         Context ctx = TaskGraph::makeContext<Context>(
             state_mgr, WorldID { world }, true);
         const ObjectManager &hbm_obj_mgr = *ctx.singleton<ObjectData>().mgr;
@@ -1188,26 +1228,27 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
         }
 
         // ---- load: HBM -> LDS ---------------------------------------------------
-        const char *world_images = (const char *)params.worldImages;
+        const char *world_images =
+            LPW == 64 ? (const char *)params.worldImages : nullptr;
         if (world_images != nullptr) {
             // packed by physicsPackKernel just before this launch
             const uint4 *src = (const uint4 *)(
                 world_images + (size_t)world * Block::imageBytes());
             uint4 *dst = (uint4 *)w;
             constexpr uint32_t num_vec = (uint32_t)(Block::imageBytes() / 16);
-            for (uint32_t i = lane; i < num_vec; i += 64) {
+            for (uint32_t i = lane; i < num_vec; i += LPW) {
                 dst[i] = src[i];
             }
         } else {
             {
                 const int32_t *order = bvh.traversalOrder();
-                for (int32_t r = (int32_t)lane; r < num_bodies; r += 64) {
+                for (int32_t r = (int32_t)lane; r < num_bodies; r += LPW) {
                     w->leafRank[order[r]] = (uint16_t)r;
                 }
             }
             wave::phaseFence();
-            loadWorldBodies<MAXB>(lane, w, w->leafRank, ctx, bodies, bvh,
-                                  hbm_obj_mgr, num_bodies);
+            loadWorldBodies<MAXB, LPW>(lane, w, w->leafRank, ctx, bodies, bvh,
+                                       hbm_obj_mgr, num_bodies);
         }
         if (lane == 0) {
             w->sys = ctx.singleton<PhysicsSystemState>();
@@ -1217,13 +1258,13 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
 
         // primitives referenced by this world's bodies
         uint32_t prim_end = 0;
-        for (int32_t k = (int32_t)lane; k < num_bodies; k += 64) {
+        for (int32_t k = (int32_t)lane; k < num_bodies; k += LPW) {
             uint32_t end = (uint32_t)w->primOffset[k] + w->primCount[k];
             prim_end = end > prim_end ? end : prim_end;
         }
-        prim_end = wave::maxReduce(prim_end);
+        prim_end = wave::maxReduce<LPW>(prim_end);
         const ObjectManager obj_mgr =
-            stagePrimitives(lane, w, hbm_obj_mgr, prim_end);
+            stagePrimitives<MAXB, LPW>(lane, w, hbm_obj_mgr, prim_end);
         PHYS_PROF(9);
 
         // ---- broadphase: candidate pairs in (body, traversal) order -----------
@@ -1239,7 +1280,7 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
             ps->candidatesPerWorld *
                 (uint32_t)(sizeof(CandidateCollision) / sizeof(WaveCandidate));
         uint32_t num_candidates = 0;
-        for (int32_t chunk = 0; chunk < num_bodies; chunk += 64) {
+        for (int32_t chunk = 0; chunk < num_bodies; chunk += LPW) {
             const int32_t k = chunk + (int32_t)lane;
             const bool active = k < num_bodies;
 
@@ -1282,7 +1323,7 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
 
             uint32_t chunk_total;
             uint32_t out = num_candidates +
-                wave::exclusiveScan(n, lane, &chunk_total);
+                wave::exclusiveScan<LPW>(n, lane, &chunk_total);
 
             if (active && n != 0 && out + n <= candidate_capacity) {
                 const uint32_t a_prims = w->primCount[k];
@@ -1350,7 +1391,7 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
         };
         const bool joints_staged = num_joints <= Block::maxJoints;
         if (joints_staged) {
-            for (int32_t i = (int32_t)lane; i < num_joints; i += 64) {
+            for (int32_t i = (int32_t)lane; i < num_joints; i += LPW) {
                 w->joints[i] = joints[i];
                 w->jointBodies[i][0] =
                     (uint16_t)jointBodyLoc(joints[i].e1).row;
@@ -1363,7 +1404,7 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
         PHYS_PROF(7);
         for (int32_t substep = 0; substep < params.numSubsteps; substep++) {
             // ---- integrate (xpbd.cpp substepRigidBodies) ------------------------
-            for (int32_t k = (int32_t)lane; k < num_bodies; k += 64) {
+            for (int32_t k = (int32_t)lane; k < num_bodies; k += LPW) {
                 Vector3 x = w->pos[k];
                 Quat q = w->rot[k];
 
@@ -1407,7 +1448,7 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                     break;
                 }
                 uint32_t width = num_candidates - chunk;
-                width = width < 64 ? width : 64;
+                width = width < (uint32_t)LPW ? width : (uint32_t)LPW;
                 width = width < free_slots ? width : free_slots;
 
                 ContactConstraint *stage = w->contacts() + num_contacts;
@@ -1429,8 +1470,8 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                     PHYS_PROF(0);
 
                     // lanes on their own, in rounds of lanePolyRows scratch rows
-                    uint64_t solo = __builtin_amdgcn_ballot_w64(kind == 1);
-                    const uint32_t solo_rank = wave::rankInBallot(solo);
+                    uint64_t solo = wave::groupBallot<LPW>(kind == 1);
+                    const uint32_t solo_rank = wave::rankInGroup(solo, lane);
                     const uint32_t solo_count =
                         (uint32_t)__builtin_popcountll(solo);
                     for (uint32_t first = 0; first < solo_count;
@@ -1446,7 +1487,7 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                 }
 
                 PHYS_PROF(3);
-                uint64_t hull_pairs = __builtin_amdgcn_ballot_w64(kind == 2);
+                uint64_t hull_pairs = wave::groupBallot<LPW>(kind == 2);
                 while (hull_pairs != 0) {
                     const uint32_t src = (uint32_t)__builtin_ctzll(hull_pairs);
                     hull_pairs &= hull_pairs - 1;
@@ -1455,19 +1496,39 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                         ldsSetupPair(w, obj_mgr, candidateAt(chunk + src));
                     bool shared_too_big = false;
                     // every lane writes the same contact to src's slot
-                    bool found = hullHullWave(lane, shared_pair, &w->scratch,
-                        stage + src, &shared_too_big);
+                    bool found = hullHullWave<LPW>(lane, shared_pair,
+                        &w->scratch, stage + src, &shared_too_big);
                     if (lane == src) {
                         has_contact = found;
                         too_big = shared_too_big;
                     }
                 }
 
-                if (too_big) {
-                    PairSetup pair = ldsSetupPair(w, obj_mgr,
-                                                  candidateAt(chunk + lane));
-                    has_contact = collidePairStored(pair, tmp_vertices,
-                        tmp_faces, max_elems, stage + lane, &unsupported);
+                // Hulls whose faces outgrow the LDS scratch (rare: none in the
+                // Escape Room or Hide-and-Seek shapes): the generic routine,
+                // one lane at a time through the world's scratch in HBM -- no
+                // per-lane arrays in private memory for a path that is almost
+                // never taken.
+                uint64_t big_pairs = wave::groupBallot<LPW>(too_big);
+                while (big_pairs != 0) {
+                    const uint32_t src = (uint32_t)__builtin_ctzll(big_pairs);
+                    big_pairs &= big_pairs - 1;
+                    if (lane == src) {
+                        geo::Plane *tmp_faces = (geo::Plane *)(
+                            ps->worldHullScratch +
+                            (size_t)world * PhysicsScratch::hullScratchBytes);
+                        static_assert(PhysicsScratch::hullScratchBytes >=
+                            MADRONA_PHYS_MAX_HULL_ELEMS *
+                                (sizeof(geo::Plane) + sizeof(math::Vector3)));
+                        math::Vector3 *tmp_vertices = (math::Vector3 *)(
+                            tmp_faces + MADRONA_PHYS_MAX_HULL_ELEMS);
+                        PairSetup pair = ldsSetupPair(w, obj_mgr,
+                                                      candidateAt(chunk + lane));
+                        has_contact = collidePairStored(pair, tmp_vertices,
+                            tmp_faces, MADRONA_PHYS_MAX_HULL_ELEMS, stage + lane,
+                            &unsupported);
+                    }
+                    wave::phaseFence();
                 }
                 if (unsupported) {
                     mwhip::raiseError(S, mwhip::kErrPhysics);
@@ -1475,8 +1536,8 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                 wave::phaseFence();
 
                 // compact in place: all reads, then all writes
-                uint64_t mask = __builtin_amdgcn_ballot_w64(has_contact);
-                const uint32_t rank = wave::rankInBallot(mask);
+                uint64_t mask = wave::groupBallot<LPW>(has_contact);
+                const uint32_t rank = wave::rankInGroup(mask, lane);
                 const bool moves = has_contact && rank != lane;
                 ContactConstraint moved;
                 if (moves) {
@@ -1496,17 +1557,17 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
             PHYS_PROF(5);
 
             // ---- position solve: contacts, then joints, level by level ----------
-            for (uint32_t base = 0; base < num_contacts; base += 64) {
-                const uint32_t n = num_contacts - base < 64 ?
-                    num_contacts - base : 64;
+            for (uint32_t base = 0; base < num_contacts; base += LPW) {
+                const uint32_t n = num_contacts - base < (uint32_t)LPW ?
+                    num_contacts - base : (uint32_t)LPW;
                 const uint32_t i = base + lane;
                 uint64_t key_a = 0, key_b = 0;
                 if (lane < n) {
                     key_a = ldsBodyKey(w, w->contacts()[i].ref.row);
                     key_b = ldsBodyKey(w, w->contacts()[i].alt.row);
                 }
-                uint32_t level = constraintLevels(lane, n, key_a, key_b);
-                uint32_t max_level = wave::maxReduce(lane < n ? level : 0);
+                uint32_t level = constraintLevels<LPW>(lane, n, key_a, key_b);
+                uint32_t max_level = wave::maxReduce<LPW>(lane < n ? level : 0);
 
                 for (uint32_t l = 0; l <= max_level; l++) {
                     if (lane < n && level == l) {
@@ -1518,9 +1579,9 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                 }
             }
 
-            for (int32_t base = 0; base < num_joints; base += 64) {
-                const uint32_t n = num_joints - base < 64 ?
-                    (uint32_t)(num_joints - base) : 64u;
+            for (int32_t base = 0; base < num_joints; base += LPW) {
+                const uint32_t n = num_joints - base < LPW ?
+                    (uint32_t)(num_joints - base) : (uint32_t)LPW;
                 const int32_t i = base + (int32_t)lane;
                 Loc l1 { 0, 0 }, l2 { 0, 0 };
                 uint64_t key_a = 0, key_b = 0;
@@ -1535,8 +1596,8 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                     key_a = ldsBodyKey(w, l1.row);
                     key_b = ldsBodyKey(w, l2.row);
                 }
-                uint32_t level = constraintLevels(lane, n, key_a, key_b);
-                uint32_t max_level = wave::maxReduce(lane < n ? level : 0);
+                uint32_t level = constraintLevels<LPW>(lane, n, key_a, key_b);
+                uint32_t max_level = wave::maxReduce<LPW>(lane < n ? level : 0);
 
                 for (uint32_t l = 0; l <= max_level; l++) {
                     if (lane < n && level == l) {
@@ -1549,24 +1610,24 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
 
             PHYS_PROF(4);
             // ---- velocities -----------------------------------------------------
-            for (int32_t k = (int32_t)lane; k < num_bodies; k += 64) {
+            for (int32_t k = (int32_t)lane; k < num_bodies; k += LPW) {
                 w->vel[k] = xpbd::deriveVelocity(w->pos[k], w->rot[k],
                                                  w->prev[k], w->sys.h);
             }
             wave::phaseFence();
             PHYS_PROF(4);
 
-            for (uint32_t base = 0; base < num_contacts; base += 64) {
-                const uint32_t n = num_contacts - base < 64 ?
-                    num_contacts - base : 64;
+            for (uint32_t base = 0; base < num_contacts; base += LPW) {
+                const uint32_t n = num_contacts - base < (uint32_t)LPW ?
+                    num_contacts - base : (uint32_t)LPW;
                 const uint32_t i = base + lane;
                 uint64_t key_a = 0, key_b = 0;
                 if (lane < n) {
                     key_a = ldsBodyKey(w, w->contacts()[i].ref.row);
                     key_b = ldsBodyKey(w, w->contacts()[i].alt.row);
                 }
-                uint32_t level = constraintLevels(lane, n, key_a, key_b);
-                uint32_t max_level = wave::maxReduce(lane < n ? level : 0);
+                uint32_t level = constraintLevels<LPW>(lane, n, key_a, key_b);
+                uint32_t max_level = wave::maxReduce<LPW>(lane < n ? level : 0);
 
                 for (uint32_t l = 0; l <= max_level; l++) {
                     if (lane < n && level == l) {
@@ -1582,7 +1643,7 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
 
         PHYS_PROF(6);
         // ---- store: LDS -> HBM --------------------------------------------------
-        for (int32_t k = (int32_t)lane; k < num_bodies; k += 64) {
+        for (int32_t k = (int32_t)lane; k < num_bodies; k += LPW) {
             Loc loc = w->bodyLoc[k];
             ctx.getDirect<base::Position>(RGDCols::Position, loc) = w->pos[k];
             ctx.getDirect<base::Rotation>(RGDCols::Rotation, loc) = w->rot[k];

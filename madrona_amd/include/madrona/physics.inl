@@ -56,6 +56,11 @@ struct PhysicsScratch {
     CandidateCollision *worldCandidates;
     ContactConstraint *worldContacts;
     float *worldLambdas;
+    // per world: world-space planes + vertices of one hull, for the pairs of the
+    // LDS step kernels whose faces outgrow the LDS clipping scratch (taken one
+    // lane at a time; phys_impl/narrowphase.hpp: 128 elements each)
+    static constexpr uint32_t hullScratchBytes = 128u * (16u + 12u);
+    char *worldHullScratch;
 };
 
 // node data of the fused per-world step kernel
@@ -1458,11 +1463,14 @@ inline PhysicsScratch *scratchHost(TaskGraphBuilder &builder,
         num_worlds * ps.contactsPerWorld * sizeof(ContactConstraint), 0);
     ps.worldLambdas = (float *)mwhip_alloc_device(exec,
         num_worlds * ps.contactsPerWorld * sizeof(float), 0);
+    ps.worldHullScratch = (char *)mwhip_alloc_device(exec,
+        num_worlds * PhysicsScratch::hullScratchBytes, 0);
 
     PhysicsScratch *dev = (PhysicsScratch *)mwhip_alloc_device(
         exec, sizeof(PhysicsScratch), 0);
     if (dev == nullptr || ps.worldCandidates == nullptr ||
-            ps.worldContacts == nullptr || ps.worldLambdas == nullptr) {
+            ps.worldContacts == nullptr || ps.worldLambdas == nullptr ||
+            ps.worldHullScratch == nullptr) {
         FATAL("madrona_amd physics: scratch allocation failed: %s",
               mwhip_last_error());
     }
@@ -1613,8 +1621,12 @@ MADRONA_HOST_API inline TaskGraphNodeID setupPhysicsStepTasks(
     Solver)
 {
 #if defined(__HIPCC__)
-    [[maybe_unused]] auto step_stub = [] __host__ (int max_bodies)
+    [[maybe_unused]] auto step_stub = [] __host__ (int max_bodies, int lanes)
             -> const void * {
+        if (max_bodies == 32 && lanes == 32) {
+            // two worlds per wavefront
+            return (const void *)&kernels::physicsStepLdsKernel<32, 32>;
+        }
         switch (max_bodies) {
         case 32: return (const void *)&kernels::physicsStepLdsKernel<32>;
         case 64: return (const void *)&kernels::physicsStepLdsKernel<64>;
@@ -1638,7 +1650,7 @@ MADRONA_HOST_API inline TaskGraphNodeID setupPhysicsStepTasks(
         }
     };
 #else
-    auto step_stub = [](int) -> const void * { return nullptr; };
+    auto step_stub = [](int, int) -> const void * { return nullptr; };
     auto pack_stub = [](int) -> const void * { return nullptr; };
     auto image_bytes = [](int) -> size_t { return 0; };
 #endif
@@ -1697,8 +1709,13 @@ MADRONA_HOST_API inline TaskGraphNodeID setupPhysicsStepTasks(
     // worlds the step kernel gets 15 us faster and the pack costs 32 us -- at
     // two waves per SIMD the load chain mostly hides behind the other world's
     // arithmetic (profiles/r02_physics_phases.txt).
+    // MADRONA_MWHIP_PHYS_LANES=32: worlds of at most 32 bodies go two to a
+    // wavefront (one per half: phys_impl/world_step.inl)
+    const int lanes_per_world = max_bodies == 32 &&
+        phys::detail::capacityHint("MADRONA_MWHIP_PHYS_LANES", 64) == 32 ? 32 : 64;
+
     void *world_images = nullptr;
-    if (max_bodies != 0 &&
+    if (max_bodies != 0 && lanes_per_world == 64 &&
             phys::detail::capacityHint("MADRONA_MWHIP_PHYS_PACK", 0) != 0) {
         world_images = mwhip_alloc_device(exec,
             (uint64_t)mwhip_num_worlds(exec) * image_bytes(max_bodies), 1);
@@ -1724,9 +1741,14 @@ MADRONA_HOST_API inline TaskGraphNodeID setupPhysicsStepTasks(
     desc.kind = MWHIP_NODE_KERNEL;
     desc.name = max_bodies != 0 ? "physics:worldStep(LDS)" :
                                   "physics:worldStep";
-    desc.kernel = step_stub(max_bodies);
+    desc.kernel = step_stub(max_bodies, lanes_per_world);
     desc.count_mode = MWHIP_COUNT_PER_WORLD;
     desc.threads_per_invocation = 64;
+    if (lanes_per_world == 32) {
+        // one wavefront per PAIR of worlds
+        desc.count_mode = MWHIP_COUNT_FIXED;
+        desc.fixed_count = (mwhip_num_worlds(exec) + 1u) / 2u;
+    }
     desc.arg0 = max_bodies != 0 ? 1u : 0u;
     cur_node = builder.addRuntimeNode(desc, params.id, {cur_node});
 #else

@@ -171,6 +171,31 @@ def test_ball_pit_kernel_variants(built, monkeypatch, max_bodies):
     assert not probs, (step, probs[:3])
 
 
+@pytest.mark.parametrize("sim,worlds,steps,denom,agents", [
+    ("escape_room_phys", 49, 90, 25, 2),       # odd: the last wavefront has one world
+    ("escape_room_phys", 1, 60, 10, 2),
+    ("escape_room_phys", 1024, 40, 100, 2),
+    ("ball_pit", 33, 120, 40, 0),              # spheres, two-primitive object, the
+                                               # coins' faces that outgrow the LDS
+                                               # scratch (HBM hull scratch, one
+                                               # lane at a time), 8 joints
+    ("ball_pit", 256, 60, 30, 0)])
+def test_physics_two_worlds_per_wavefront(built, monkeypatch, sim, worlds, steps, denom,
+                                          agents):
+    """physicsStepLdsKernel<32, 32>: worlds of at most 32 bodies go two to a
+    wavefront, one per half -- every wave-level primitive on groups of 32 lanes,
+    the halves diverging wherever their worlds differ (candidate / contact counts,
+    hull-hull pairs, solver levels).  Same bit-for-bit bar as one world per wave."""
+    _need_ref(sim)
+    monkeypatch.setenv("MADRONA_MWHIP_PHYS_LANES", "32")
+    probs, step = run_pair(sim, worlds, steps, flags=denom,
+                           check_every=1 if worlds <= 64 else 10,
+                           actions=_escape_actions(worlds + 5, grab=True, agents=agents)
+                           if agents else None,
+                           check_init=False, ref_workers=0 if worlds > 64 else 1)
+    assert not probs, (step, probs[:3])
+
+
 @pytest.mark.parametrize("extra,kernel", [(60, "LDS<128>"), (140, "HBM")])
 def test_ball_pit_crowd(built, monkeypatch, extra, kernel):
     """Worlds of 79 and 159 rigid bodies (ball_pit's crowd mode): more bodies
