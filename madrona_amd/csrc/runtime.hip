@@ -1687,7 +1687,11 @@ static int makeSortBatch(mwhip_exec *exec,
 
     // ---- the gather's workgroups, shared out by bytes to move ----
     {
-        const uint32_t target = std::max(envU32("MADRONA_MWHIP_GATHER_BLOCKS", 2048), 1u);
+        // about one workgroup per 32 KB, between one and four resident rounds of
+        // the chip (measured, profiles/r03_sort_variants.jsonl: 2048 is best at
+        // 38 MB, 4096 at 94 MB, 8192 at 610 MB); MADRONA_MWHIP_GATHER_BLOCKS
+        // overrides
+        uint32_t target = envU32("MADRONA_MWHIP_GATHER_BLOCKS", 0);
         std::vector<double> weight(cols.size(), 0.0);
         double total = 0.0;
         for (size_t c = 0; c < cols.size(); c++) {
@@ -1704,6 +1708,9 @@ static int makeSortBatch(mwhip_exec *exec,
                 weight[c] = (double)rows * (arch.colBytes[cols[c].column] + 4.0);
             }
             total += weight[c];
+        }
+        if (target == 0) {
+            target = (uint32_t)std::min(std::max(total / 32768.0, 2048.0), 8192.0);
         }
         std::vector<GatherSlice> slices;
         for (size_t c = 0; c < cols.size(); c++) {

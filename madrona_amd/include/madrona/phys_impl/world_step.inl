@@ -1228,8 +1228,9 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
         }
 
         // ---- load: HBM -> LDS ---------------------------------------------------
-        const char *world_images =
-            LPW == 64 ? (const char *)params.worldImages : nullptr;
+        // (the image part of the block does not depend on LPW)
+        static_assert(Block::imageBytes() == WorldBlock<MAXB, 64>::imageBytes());
+        const char *world_images = (const char *)params.worldImages;
         if (world_images != nullptr) {
             // packed by physicsPackKernel just before this launch
             const uint4 *src = (const uint4 *)(

@@ -1709,13 +1709,15 @@ MADRONA_HOST_API inline TaskGraphNodeID setupPhysicsStepTasks(
     // worlds the step kernel gets 15 us faster and the pack costs 32 us -- at
     // two waves per SIMD the load chain mostly hides behind the other world's
     // arithmetic (profiles/r02_physics_phases.txt).
-    // MADRONA_MWHIP_PHYS_LANES=32: worlds of at most 32 bodies go two to a
-    // wavefront (one per half: phys_impl/world_step.inl)
+    // Worlds of at most 32 bodies go two to a wavefront, one per half
+    // (phys_impl/world_step.inl; measured on 8192 Escape-Room worlds: 830 ->
+    // 712 us per step, profiles/r03_phys_variants.jsonl).
+    // MADRONA_MWHIP_PHYS_LANES=64 keeps one world per wavefront.
     const int lanes_per_world = max_bodies == 32 &&
-        phys::detail::capacityHint("MADRONA_MWHIP_PHYS_LANES", 64) == 32 ? 32 : 64;
+        phys::detail::capacityHint("MADRONA_MWHIP_PHYS_LANES", 32) == 32 ? 32 : 64;
 
     void *world_images = nullptr;
-    if (max_bodies != 0 && lanes_per_world == 64 &&
+    if (max_bodies != 0 &&
             phys::detail::capacityHint("MADRONA_MWHIP_PHYS_PACK", 0) != 0) {
         world_images = mwhip_alloc_device(exec,
             (uint64_t)mwhip_num_worlds(exec) * image_bytes(max_bodies), 1);

@@ -8,13 +8,17 @@ import subprocess
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ONE = {"MADRONA_MWHIP_PHYS_LANES": "64"}
+PACK = {"MADRONA_MWHIP_PHYS_PACK": "1"}
 RUNS = [
-    ("escape_room_phys", 8192, "one world per wavefront (2 waves/SIMD)", {}),
-    ("escape_room_phys", 8192, "two worlds per wavefront (1 wave/SIMD)",
-     {"MADRONA_MWHIP_PHYS_LANES": "32"}),
-    ("escape_room_phys", 8192, "one world per wavefront, again", {}),
-    ("escape_room_phys", 8192, "two worlds per wavefront, again",
-     {"MADRONA_MWHIP_PHYS_LANES": "32"}),
+    ("escape_room_phys", 8192, "one world per wavefront (2 waves/SIMD)", ONE),
+    ("escape_room_phys", 8192, "two worlds per wavefront (1 wave/SIMD)", {}),
+    ("escape_room_phys", 8192, "two worlds per wavefront + world images", PACK),
+    ("escape_room_phys", 8192, "one world per wavefront + world images",
+     {**ONE, **PACK}),
+    ("hideseek", 8192, "one world per wavefront (2 waves/SIMD)", ONE),
+    ("hideseek", 8192, "two worlds per wavefront (1 wave/SIMD)", {}),
+    ("hideseek", 8192, "two worlds per wavefront + world images", PACK),
 ]
 
 CHILD = r"""
@@ -24,7 +28,7 @@ import bench, torch
 torch.cuda.set_device(0)
 sim, worlds = sys.argv[1], int(sys.argv[2])
 r = bench.run_single(sim, worlds, 0, 5, 200, 300, 50, 30, settle=400)
-phys = [k for k in r["kernels"] if "worldStep" in k["name"]]
+phys = [k for k in r["kernels"] if "worldStep" in k["name"] or "packWorlds" in k["name"]]
 print(json.dumps({"sim": sim, "worlds": worlds, "ms_per_step": r["ms_per_step"],
                   "value": r["value"], "physics_step_us": [k["avg_us"] for k in phys]}))
 """ % REPO

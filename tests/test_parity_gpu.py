@@ -180,14 +180,18 @@ def test_ball_pit_kernel_variants(built, monkeypatch, max_bodies):
                                                # scratch (HBM hull scratch, one
                                                # lane at a time), 8 joints
     ("ball_pit", 256, 60, 30, 0)])
-def test_physics_two_worlds_per_wavefront(built, monkeypatch, sim, worlds, steps, denom,
-                                          agents):
-    """physicsStepLdsKernel<32, 32>: worlds of at most 32 bodies go two to a
-    wavefront, one per half -- every wave-level primitive on groups of 32 lanes,
-    the halves diverging wherever their worlds differ (candidate / contact counts,
-    hull-hull pairs, solver levels).  Same bit-for-bit bar as one world per wave."""
+@pytest.mark.parametrize("lanes,pack", [("32", "0"), ("64", "0"), ("32", "1")])
+def test_physics_lanes_per_world(built, monkeypatch, sim, worlds, steps, denom, agents,
+                                 lanes, pack):
+    """physicsStepLdsKernel<32, 32> (the default for worlds of at most 32 bodies):
+    two worlds per wavefront, one per half -- every wave-level primitive on groups
+    of 32 lanes, the halves diverging wherever their worlds differ (candidate /
+    contact counts, hull-hull pairs, solver levels) -- and <32, 64>, one world per
+    wavefront; with and without the world images of physicsPackKernel.  Same
+    bit-for-bit bar for all."""
     _need_ref(sim)
-    monkeypatch.setenv("MADRONA_MWHIP_PHYS_LANES", "32")
+    monkeypatch.setenv("MADRONA_MWHIP_PHYS_LANES", lanes)
+    monkeypatch.setenv("MADRONA_MWHIP_PHYS_PACK", pack)
     probs, step = run_pair(sim, worlds, steps, flags=denom,
                            check_every=1 if worlds <= 64 else 10,
                            actions=_escape_actions(worlds + 5, grab=True, agents=agents)
