@@ -818,7 +818,6 @@ sortFinalize(EcsState *S, const SortSite *sites)
 // barriers only.
 constexpr int kSmallThreads = 1024;
 constexpr int kSmallWaves = kSmallThreads / 64;
-constexpr int kSmallItems = 8;      // keys per thread and tile of the passes
 
 struct SmallSortLDS {
     uint32_t hist[kRadixDigits];
@@ -895,86 +894,54 @@ __device__ inline void oneGroupRadixPasses(SmallSortLDS &lds, int32_t num_passes
             __syncthreads();
         }
 
-        // Tiles of kSmallThreads x kSmallItems keys, wave-striped (wave w owns a
-        // contiguous run of 64 x kSmallItems keys, item j of lane l is key
-        // j * 64 + l of the run: position order = (wave, item, lane) order, which
-        // is what keeps the pass stable): a handful of workgroup barriers per
-        // 8192 keys.
-        constexpr int32_t tile_keys = kSmallThreads * kSmallItems;
-        for (int32_t tile = 0; tile < n; tile += tile_keys) {
+        // One key per thread and tile.  (Eight keys per thread, wave-striped as in
+        // the one-sweep kernel -- a quarter of the barriers -- was measured
+        // slower: 13.3 -> 16.5 us for the 1100-row tails of 8192 Escape-Room
+        // worlds, three busy waves with eight dependent ranking rounds each.)
+        for (int32_t tile = 0; tile < n; tile += kSmallThreads) {
             for (uint32_t i = tid; i < (uint32_t)(kSmallWaves * kRadixDigits);
                  i += kSmallThreads) {
                 (&lds.waveBase[0][0])[i] = 0;
             }
             __syncthreads();
 
-            const int32_t run = tile + (int32_t)wave * 64 * kSmallItems;
-            uint32_t key[kSmallItems];
-            int32_t src[kSmallItems];
-            uint32_t rank[kSmallItems];
+            const int32_t i = tile + (int32_t)tid;
+            const bool valid = i < n;
+            const uint32_t key = valid ? keys_in[i] : 0xFFFFFFFFu;
+            const int32_t src = valid ?
+                (idx_in != nullptr ? idx_in[i] : first_row + i) : -1;
+            const uint32_t digit = (key >> shift) & 0xFFu;
+
+            unsigned long long match = ballot64(valid);
 #pragma unroll
-            for (int j = 0; j < kSmallItems; j++) {
-                const int32_t i = run + j * 64 + (int32_t)lane;
-                const bool valid = i < n;
-                key[j] = valid ? keys_in[i] : 0xFFFFFFFFu;
-                src[j] = valid ? (idx_in != nullptr ? idx_in[i] : first_row + i) : -1;
+            for (int b = 0; b < kRadixBits; b++) {
+                bool bit = ((digit >> b) & 1u) != 0u;
+                unsigned long long vote = ballot64(bit && valid);
+                match &= bit ? vote : ~vote;
             }
-#pragma unroll
-            for (int j = 0; j < kSmallItems; j++) {
-                rank[j] = 0;
-                if (run + j * 64 >= n) {
-                    continue;       // (wave-uniform: nothing left in this run)
-                }
-                const int32_t i = run + j * 64 + (int32_t)lane;
-                const bool valid = i < n;
-                const uint32_t digit = (key[j] >> shift) & 0xFFu;
-
-                unsigned long long match = ballot64(valid);
-#pragma unroll
-                for (int b = 0; b < kRadixBits; b++) {
-                    bool bit = ((digit >> b) & 1u) != 0u;
-                    unsigned long long vote = ballot64(bit && valid);
-                    match &= bit ? vote : ~vote;
-                }
-                const uint32_t before = (uint32_t)__popcll(match & lane_lt);
-                const uint32_t count = (uint32_t)__popcll(match);
-
-                // the wave's running count of this digit (wave-private row)
-                uint32_t prev = 0;
-                if (valid) {
-                    prev = lds.waveBase[wave][digit];
-                }
-                __builtin_amdgcn_wave_barrier();
-                if (valid && before == 0) {
-                    lds.waveBase[wave][digit] = prev + count;
-                }
-                __builtin_amdgcn_wave_barrier();
-                rank[j] = prev + before;
+            const uint32_t before = (uint32_t)__popcll(match & lane_lt);
+            if (valid && before == 0) {
+                lds.waveBase[wave][digit] = (uint32_t)__popcll(match);
             }
             __syncthreads();
 
             // digit d: running base over the waves of this tile, then over tiles
             if (tid < (uint32_t)kRadixDigits) {
-                uint32_t total = lds.binBase[tid];
+                uint32_t run = lds.binBase[tid];
 #pragma unroll
                 for (int w = 0; w < kSmallWaves; w++) {
                     uint32_t c = lds.waveBase[w][tid];
-                    lds.waveBase[w][tid] = total;
-                    total += c;
+                    lds.waveBase[w][tid] = run;
+                    run += c;
                 }
-                lds.binBase[tid] = total;
+                lds.binBase[tid] = run;
             }
             __syncthreads();
 
-#pragma unroll
-            for (int j = 0; j < kSmallItems; j++) {
-                const int32_t i = run + j * 64 + (int32_t)lane;
-                if (i < n) {
-                    const uint32_t digit = (key[j] >> shift) & 0xFFu;
-                    const uint32_t dst = lds.waveBase[wave][digit] + rank[j];
-                    keys_out[dst] = key[j];
-                    idx_out[dst] = src[j];
-                }
+            if (valid) {
+                const uint32_t dst = lds.waveBase[wave][digit] + before;
+                keys_out[dst] = key;
+                idx_out[dst] = src;
             }
             __syncthreads();
         }

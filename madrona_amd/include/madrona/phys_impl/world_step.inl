@@ -131,11 +131,17 @@ inline constexpr uint32_t wavePolyVerts = 24;
 // world-space copies of the two hulls of a cooperative hull-hull test
 inline constexpr uint32_t waveHullElems = 16;   // vertices, faces per hull
 
-struct alignas(16) WaveScratch {
-    float lanePoly[lanePolyRows * lanePolyDwords];
+// scratch of ONE cooperative hull-hull test (a world runs as many at a time as
+// it has lane groups for them: hullHullWave<G>)
+struct alignas(16) HullScratch {
     math::Vector3 clip[2][wavePolyVerts];
     math::Vector3 hullVerts[2][waveHullElems];
     geo::Plane hullPlanes[2][waveHullElems];
+};
+
+struct alignas(16) WaveScratch {
+    float lanePoly[lanePolyRows * lanePolyDwords];
+    HullScratch hull;
 };
 
 // number of vertices of face `face_idx`
@@ -222,7 +228,8 @@ __device__ inline EdgeQuery queryEdgeDirectionsWave(uint32_t lane,
     return best;
 }
 
-// makeHullState with the vertices / planes spread over the lanes
+// makeHullState with the vertices / planes spread over the G lanes of the test
+template <int G = 64>
 __device__ inline HullState makeHullStateWave(uint32_t lane,
                                               const HalfEdgeMesh &mesh,
                                               const PrimitiveTransform &txfm,
@@ -230,11 +237,11 @@ __device__ inline HullState makeHullStateWave(uint32_t lane,
                                               Plane *dst_planes)
 {
     LazyHull lazy(mesh, txfm.pos, txfm.rot, txfm.scale, false);
-    if (lane < mesh.numVertices) {
-        dst_vertices[lane] = lazy.vertex(lane);
+    for (uint32_t i = lane; i < mesh.numVertices; i += G) {
+        dst_vertices[i] = lazy.vertex(i);
     }
-    if (lane < mesh.numFaces) {
-        dst_planes[lane] = lazy.plane(lane);
+    for (uint32_t i = lane; i < mesh.numFaces; i += G) {
+        dst_planes[i] = lazy.plane(i);
     }
     wave::phaseFence();
 
@@ -255,17 +262,18 @@ __device__ inline HullState makeHullStateWave(uint32_t lane,
 template <int LPW = 64, typename HullA, typename HullB>
 __device__ inline bool hullHullWaveSAT(uint32_t lane, const PairSetup &pair,
                                        const HullA &a, const HullB &b,
-                                       WaveScratch *scratch,
+                                       HullScratch *scratch,
                                        ContactConstraint *out, bool *too_big);
 
-// Hull-hull pair handled by the whole wave (`pair` is wave-uniform).  Returns
-// false with *too_big set when the clipped polygon may not fit the LDS scratch.
+// Hull-hull pair handled by a group of LPW lanes (`pair` is uniform across the
+// group; `lane` = index inside it).  Returns false with *too_big set when the
+// clipped polygon may not fit the LDS scratch.
 // (A template so that only the device pass instantiates it.  Keeping it out of
 // line to confine its register footprint was measured: 1166 -> 1637 us.)
 template <int LPW = 64>
 __device__ inline bool
 hullHullWave(uint32_t lane, const PairSetup &pair,
-                                    WaveScratch *scratch,
+                                    HullScratch *scratch,
                                     ContactConstraint *out, bool *too_big)
 {
     const HalfEdgeMesh &a_mesh = pair.aPrim->hull.halfEdgeMesh;
@@ -276,9 +284,9 @@ hullHullWave(uint32_t lane, const PairSetup &pair,
         b_mesh.numVertices <= waveHullElems &&
         b_mesh.numFaces <= waveHullElems) {
         // small hulls: transform once into LDS
-        HullState a = makeHullStateWave(lane, a_mesh, pair.a,
+        HullState a = makeHullStateWave<LPW>(lane, a_mesh, pair.a,
             scratch->hullVerts[0], scratch->hullPlanes[0]);
-        HullState b = makeHullStateWave(lane, b_mesh, pair.b,
+        HullState b = makeHullStateWave<LPW>(lane, b_mesh, pair.b,
             scratch->hullVerts[1], scratch->hullPlanes[1]);
         return hullHullWaveSAT<LPW>(lane, pair, a, b, scratch, out, too_big);
     }
@@ -291,7 +299,7 @@ hullHullWave(uint32_t lane, const PairSetup &pair,
 template <int LPW, typename HullA, typename HullB>
 __device__ inline bool hullHullWaveSAT(uint32_t lane, const PairSetup &pair,
                                        const HullA &a, const HullB &b,
-                                       WaveScratch *scratch,
+                                       HullScratch *scratch,
                                        ContactConstraint *out, bool *too_big)
 {
     FaceQuery face_query_a = queryFaceDirectionsWave<LPW>(lane, a, b);
@@ -620,7 +628,7 @@ physicsStepKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                         setupPair(ctx, obj_mgr, candidates[chunk + src]);
                     ContactConstraint shared_contact;
                     bool shared_too_big = false;
-                    bool found = hullHullWave(lane, shared_pair, scratch,
+                    bool found = hullHullWave(lane, shared_pair, &scratch->hull,
                         &shared_contact, &shared_too_big);
                     if (lane == src) {
                         contact = shared_contact;
@@ -774,6 +782,18 @@ struct WaveCandidate {
     uint8_t bPrim;
 };
 
+// hull-hull scratch of a world's lane groups beyond the first (none when the
+// whole world works on one pair at a time)
+template <int N>
+struct ExtraHullScratch {
+    HullScratch group[N];
+    __device__ inline HullScratch *at(int i) { return &group[i]; }
+};
+template <>
+struct ExtraHullScratch<0> {
+    __device__ inline HullScratch *at(int) { return nullptr; }
+};
+
 template <int MAXB, int LPW = 64>
 struct WorldBlock {
     static constexpr int maxBodies = MAXB;
@@ -837,6 +857,13 @@ struct WorldBlock {
     const void *primMeshKey[maxPrims];      // HBM vertex array of each hull prim
     alignas(16) uint32_t arena[arenaDwords];
     WaveScratch scratch;
+    // Two worlds per wavefront: a world's 32 lanes run TWO hull-hull tests at a
+    // time, 16 lanes each (a cube pair has 6 + 6 faces, 8 + 8 vertices and 144
+    // edge pairs: the face queries, the hull transforms and the clipping, which
+    // every lane repeats, take the same instructions with 16 lanes as with 32).
+    static constexpr int hullLanes = LPW == 32 ? 16 : LPW;
+    static constexpr int hullGroups = LPW / hullLanes;
+    [[no_unique_address]] ExtraHullScratch<hullGroups - 1> extraHull;
 
     // by body: the box a body queries the tree with; by traversal rank: the
     // slot box the traversal tests and the entity id of that leaf's body
@@ -1489,19 +1516,48 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
 
                 PHYS_PROF(3);
                 uint64_t hull_pairs = wave::groupBallot<LPW>(kind == 2);
+                constexpr int hull_lanes = Block::hullLanes;
+                constexpr int hull_groups = Block::hullGroups;
+                static_assert(hull_groups == 1 || hull_groups == 2);
+                const uint32_t hull_group = lane / (uint32_t)hull_lanes;
+                const uint32_t hull_lane = lane % (uint32_t)hull_lanes;
+                HullScratch *hull_scratch = hull_group == 0 ?
+                    &w->scratch.hull : w->extraHull.at(0);
                 while (hull_pairs != 0) {
-                    const uint32_t src = (uint32_t)__builtin_ctzll(hull_pairs);
+                    // the next pairs of the world, one per group of hull_lanes
+                    const uint32_t src0 = (uint32_t)__builtin_ctzll(hull_pairs);
                     hull_pairs &= hull_pairs - 1;
+                    uint32_t src1 = 0xFFFFFFFFu;
+                    if (hull_groups == 2 && hull_pairs != 0) {
+                        src1 = (uint32_t)__builtin_ctzll(hull_pairs);
+                        hull_pairs &= hull_pairs - 1;
+                    }
+                    const uint32_t src = hull_group == 0 ? src0 : src1;
 
-                    PairSetup shared_pair =
-                        ldsSetupPair(w, obj_mgr, candidateAt(chunk + src));
-                    bool shared_too_big = false;
-                    // every lane writes the same contact to src's slot
-                    bool found = hullHullWave<LPW>(lane, shared_pair,
-                        &w->scratch, stage + src, &shared_too_big);
-                    if (lane == src) {
-                        has_contact = found;
-                        too_big = shared_too_big;
+                    bool found = false;
+                    bool pair_too_big = false;
+                    if (src != 0xFFFFFFFFu) {
+                        PairSetup shared_pair =
+                            ldsSetupPair(w, obj_mgr, candidateAt(chunk + src));
+                        // every lane of the group writes the same contact to
+                        // src's slot
+                        found = hullHullWave<hull_lanes>(hull_lane, shared_pair,
+                            hull_scratch, stage + src, &pair_too_big);
+                    }
+                    // the lane that owns the candidate learns the outcome
+                    const uint32_t outcome =
+                        (found ? 1u : 0u) | (pair_too_big ? 2u : 0u);
+                    const uint32_t outcome0 = __shfl(outcome, 0, LPW);
+                    if (lane == src0) {
+                        has_contact = (outcome0 & 1u) != 0u;
+                        too_big = (outcome0 & 2u) != 0u;
+                    }
+                    if (hull_groups == 2) {
+                        const uint32_t outcome1 = __shfl(outcome, hull_lanes, LPW);
+                        if (lane == src1) {
+                            has_contact = (outcome1 & 1u) != 0u;
+                            too_big = (outcome1 & 2u) != 0u;
+                        }
                     }
                 }
 

@@ -22,6 +22,8 @@ from summarize_pmc import short_name  # noqa: E402
 BENCH_NAMES = [
     (r"sortHistogram", "SortArchetype:sort.histogram"),
     (r"sortOnesweep", "SortArchetype:sort.onesweep"),
+    (r"sortCompactPrepare", "SortArchetype:sort.compact.prepare"),
+    (r"sortCompactScatter", "SortArchetype:sort.compact.scatter"),
     (r"sortGather", "SortArchetype:sort.gather"),
     (r"sortFinalize", "SortArchetype:sort.finalize"),
     (r"sortSmall", "SortArchetype:sort.small"),

@@ -9,6 +9,9 @@
 //                               LDS kernel's plane / sphere path)
 //   mode 2  hullHullWave        one wavefront per pair (the LDS kernel's
 //                               cooperative hull-hull SAT)
+//   mode 3  hullHullWave<32>    two pairs per wavefront, 32 lanes each
+//   mode 4  hullHullWave<16>    four pairs per wavefront, 16 lanes each (what
+//                               the two-worlds-per-wavefront kernel runs)
 #include <madrona/mwhip/user_prelude.hpp>
 // (the physics headers are written like simulator sources: unannotated
 // definitions, made host + device by the wrapper's pragma -- madrona_amd/Makefile)
@@ -61,9 +64,15 @@ collideKernel(const ObjectManager *obj_mgr, const PairIn *pairs,
               int32_t *flags)
 {
     __shared__ kernels::WaveScratch scratch;
+    __shared__ kernels::HullScratch group_scratch[4];
 
     const uint32_t lane = threadIdx.x;
-    const uint32_t p = mode == 2 ? blockIdx.x : blockIdx.x * 64 + lane;
+    // lanes per pair and pairs per wavefront of the cooperative modes
+    const uint32_t group_lanes = mode == 3 ? 32u : (mode == 4 ? 16u : 64u);
+    const uint32_t group = lane / group_lanes;
+    const uint32_t p = mode == 2 ? blockIdx.x :
+        (mode >= 3 ? blockIdx.x * (64u / group_lanes) + group :
+                     blockIdx.x * 64 + lane);
     const bool active = p < num_pairs;
 
     PairSetup pair {};
@@ -103,14 +112,24 @@ collideKernel(const ObjectManager *obj_mgr, const PairIn *pairs,
                     &contact, &too_big, &unsupported);
             }
         }
-    } else {
+    } else if (mode == 2) {
         if (active) {   // wave-uniform
-            has = kernels::hullHullWave(lane, pair, &scratch, &contact,
+            has = kernels::hullHullWave(lane, pair, &scratch.hull, &contact,
                                         &too_big);
+        }
+    } else if (mode == 3) {
+        if (active) {   // uniform per 32-lane group
+            has = kernels::hullHullWave<32>(lane % 32u, pair,
+                &group_scratch[group], &contact, &too_big);
+        }
+    } else {
+        if (active) {   // uniform per 16-lane group
+            has = kernels::hullHullWave<16>(lane % 16u, pair,
+                &group_scratch[group], &contact, &too_big);
         }
     }
 
-    if (active && (mode != 2 || lane == 0)) {
+    if (active && (mode < 2 || lane % group_lanes == 0)) {
         storeContact(has, contact, kind, out + (size_t)p * 28);
         flags[p] = (too_big ? 1 : 0) | (unsupported ? 2 : 0);
     }
@@ -236,7 +255,9 @@ API int32_t dev_collide_pairs(const float *verts, uint32_t num_verts,
     (void)hipMemcpy(d_pairs, pairs, sizeof(PairIn) * num_pairs,
                     hipMemcpyHostToDevice);
 
-    const uint32_t blocks = mode == 2 ? num_pairs : (num_pairs + 63) / 64;
+    const uint32_t blocks = mode == 2 ? num_pairs :
+        mode == 3 ? (num_pairs + 1) / 2 :
+        mode == 4 ? (num_pairs + 3) / 4 : (num_pairs + 63) / 64;
     hipLaunchKernelGGL(collideKernel, dim3(blocks), dim3(64), 0, 0,
                        &loader.getObjectManager(), d_pairs, num_pairs, kind,
                        mode, d_out, d_flags);

@@ -61,7 +61,10 @@ def _configs(rng, kind, n):
 
 
 @pytest.mark.parametrize("mesh", ["cube", "wedge", "coin16"])
-@pytest.mark.parametrize("kind,mode", [(0, 0), (0, 2), (1, 0), (1, 1), (2, 0), (2, 1)])
+# (modes 3 / 4: the cooperative hull-hull test on 32- / 16-lane groups, two / four
+# pairs per wavefront -- what the two-worlds-per-wavefront step kernel runs)
+@pytest.mark.parametrize("kind,mode", [(0, 0), (0, 2), (0, 3), (0, 4), (1, 0), (1, 1),
+                                       (2, 0), (2, 1)])
 def test_device_narrowphase_matches_reference(libs, mesh, kind, mode):
     dev, ref = libs
     verts, idx, counts = MESHES[mesh]
