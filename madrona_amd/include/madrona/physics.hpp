@@ -153,7 +153,7 @@ namespace PhysicsSystem {
 
 enum class Solver : uint32_t {
     XPBD,
-    TGS,    // not available in this backend yet
+    TGS,    // phys_impl/tgs.hpp
 };
 
 // ---- world constructor / reset ---------------------------------------------------

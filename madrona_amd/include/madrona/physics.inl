@@ -19,6 +19,8 @@ struct PhysicsSystemState {
 
 struct CandidateTemporary : Archetype<CandidateCollision> {};
 
+#include <madrona/phys_impl/tgs.hpp>
+
 namespace xpbd {
 
 // The reference keeps its Query objects here (xpbd.cpp:21-24); this backend
@@ -1171,7 +1173,7 @@ MADRONA_HD inline void init(Context &ctx,
                             CountT num_substeps,
                             math::Vector3 gravity,
                             CountT max_dynamic_objects,
-                            Solver)
+                            Solver solver)
 {
     broadphase::BVH &bvh = ctx.singleton<broadphase::BVH>();
 
@@ -1191,12 +1193,21 @@ MADRONA_HD inline void init(Context &ctx,
     state.g = gravity;
     state.gMagnitude = g_mag;
     state.restitutionThreshold = 2.f * g_mag * h;
-    state.contactArchetypeID = TypeTracker::typeID<xpbd::Contact>();
-    state.jointArchetypeID = TypeTracker::typeID<xpbd::Joint>();
-
-    xpbd::SolverState &solver_state = ctx.singleton<xpbd::SolverState>();
-    for (int i = 0; i < 8; i++) {
-        solver_state.unused[i] = 0;
+    // (reference physics.cpp:113-137: the solver's archetypes and its state)
+    if (solver == Solver::TGS) {
+        state.contactArchetypeID = TypeTracker::typeID<tgs::Contact>();
+        state.jointArchetypeID = TypeTracker::typeID<tgs::Joint>();
+        tgs::SolverState &solver_state = ctx.singleton<tgs::SolverState>();
+        for (int i = 0; i < 8; i++) {
+            solver_state.unused[i] = 0;
+        }
+    } else {
+        state.contactArchetypeID = TypeTracker::typeID<xpbd::Contact>();
+        state.jointArchetypeID = TypeTracker::typeID<xpbd::Joint>();
+        xpbd::SolverState &solver_state = ctx.singleton<xpbd::SolverState>();
+        for (int i = 0; i < 8; i++) {
+            solver_state.unused[i] = 0;
+        }
     }
 
     ctx.singleton<ObjectData>() = ObjectData { obj_mgr };
@@ -1352,14 +1363,6 @@ MADRONA_HD inline Entity makeHingeJoint(Context &ctx,
 
 MADRONA_HOST_API inline void registerTypes(ECSRegistry &registry, Solver solver)
 {
-#if MADRONA_ON_HOST
-    if (solver != Solver::XPBD) {
-        FATAL("madrona_amd physics: only the XPBD solver is available");
-    }
-#else
-    (void)solver;
-#endif
-
     // Same order as the reference (physics.cpp:308-341, xpbd.cpp:1046-1060):
     // singleton registration order fixes singleton entity ids.  (Not inside a
     // host-only block: the device pass instantiates the per-type id symbols
@@ -1386,20 +1389,29 @@ MADRONA_HOST_API inline void registerTypes(ECSRegistry &registry, Solver solver)
     registry.registerSingleton<PhysicsSystemState>();
     registry.registerSingleton<ObjectData>();
 
-    registry.registerComponent<xpbd::SubstepPrevState>();
-    registry.registerComponent<xpbd::PreSolvePositional>();
-    registry.registerComponent<xpbd::PreSolveVelocity>();
-    registry.registerComponent<xpbd::XPBDContactState>();
+    if (solver == Solver::TGS) {
+        // reference tgs.cpp:29-44
+        registry.registerArchetype<tgs::Joint>();
+        registry.registerArchetype<tgs::Contact>();
+        registry.registerBundle<tgs::TGSRigidBodyState>();
+        registry.registerBundleAlias<SolverBundleAlias, tgs::TGSRigidBodyState>();
+        registry.registerSingleton<tgs::SolverState>();
+    } else {
+        registry.registerComponent<xpbd::SubstepPrevState>();
+        registry.registerComponent<xpbd::PreSolvePositional>();
+        registry.registerComponent<xpbd::PreSolveVelocity>();
+        registry.registerComponent<xpbd::XPBDContactState>();
 
-    registry.registerArchetype<xpbd::Joint>();
-    registry.registerArchetype<xpbd::Contact>(
-        ComponentMetadataSelector<> {}, ArchetypeFlags::None,
-        detail::capacityHint("MADRONA_MWHIP_MAX_CONTACTS_PER_WORLD", 64));
+        registry.registerArchetype<xpbd::Joint>();
+        registry.registerArchetype<xpbd::Contact>(
+            ComponentMetadataSelector<> {}, ArchetypeFlags::None,
+            detail::capacityHint("MADRONA_MWHIP_MAX_CONTACTS_PER_WORLD", 64));
 
-    registry.registerSingleton<xpbd::SolverState>();
+        registry.registerSingleton<xpbd::SolverState>();
 
-    registry.registerBundle<xpbd::XPBDRigidBodyState>();
-    registry.registerBundleAlias<SolverBundleAlias, xpbd::XPBDRigidBodyState>();
+        registry.registerBundle<xpbd::XPBDRigidBodyState>();
+        registry.registerBundleAlias<SolverBundleAlias, xpbd::XPBDRigidBodyState>();
+    }
 
     registry.registerBundle<RigidBody>();
 }
@@ -1618,8 +1630,32 @@ MADRONA_HOST_API inline TaskGraphNodeID setupPhysicsStepTasks(
     TaskGraphBuilder &builder,
     Span<const TaskGraphNodeID> deps,
     CountT num_substeps,
-    Solver)
+    Solver solver)
 {
+    if (solver == Solver::TGS) {
+        // reference tgs.cpp:225-304 without the stages that have no effect
+        // (phys_impl/tgs.hpp): per substep the two integrators, then the leaf
+        // update every solver is followed by
+        TaskGraphNodeID cur {};
+        bool first = true;
+        for (CountT i = 0; i < num_substeps; i++) {
+            cur = first ?
+                builder.addToGraph<ParallelForNode<Context,
+                    tgs::integrateVelocities, base::Rotation, ResponseType,
+                    ExternalForce, ExternalTorque, base::ObjectID, Velocity>>(
+                        deps) :
+                builder.addToGraph<ParallelForNode<Context,
+                    tgs::integrateVelocities, base::Rotation, ResponseType,
+                    ExternalForce, ExternalTorque, base::ObjectID, Velocity>>(
+                        {cur});
+            first = false;
+            cur = builder.addToGraph<ParallelForNode<Context,
+                tgs::integratePositions, base::Position, base::Rotation,
+                Velocity>>({cur});
+        }
+        return detail::setupPostIntegrationTasks(builder, {cur});
+    }
+
 #if defined(__HIPCC__)
     [[maybe_unused]] auto step_stub = [] __host__ (int max_bodies, int lanes)
             -> const void * {

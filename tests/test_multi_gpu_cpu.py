@@ -44,6 +44,8 @@ def _worker(rank, world_size, port, sim_name, out_dir):
     import datetime
     dist.init_process_group("gloo", rank=rank, world_size=world_size,
                             timeout=datetime.timedelta(seconds=60))
+    # (the parent retries a run only while no rank got this far)
+    open(os.path.join(out_dir, f"rendezvous_ok_{rank}"), "w").close()
     try:
         names, total_worlds, steps = CASES[sim_name]
         shard = shard_for(rank, world_size, total_worlds=total_worlds)
@@ -78,14 +80,28 @@ def test_two_rank_allgather_is_partition_invariant(built, tmp_path, sim_name):
     if not os.path.exists(ref_lib_path(sim_name)):
         pytest.skip("oracle/_ref not built here (no /root/reference)")
     names, total_worlds, steps = CASES[sim_name]
+    import glob
+    import time
     for attempt in range(3):
+        ctx = mp.spawn(_worker, args=(2, _free_port(), sim_name, str(tmp_path)),
+                       nprocs=2, join=False)
+        error = None
+        deadline = time.monotonic() + 240
         try:
-            mp.spawn(_worker, args=(2, _free_port(), sim_name, str(tmp_path)),
-                     nprocs=2, join=True)
+            while not ctx.join(timeout=5):
+                if time.monotonic() > deadline:
+                    raise TimeoutError("the two ranks did not finish in 240 s")
             break
-        except Exception:       # noqa: BLE001 -- a lost rendezvous: new port
-            if attempt == 2:
-                raise
+        except Exception as e:      # noqa: BLE001
+            error = e
+            for proc in ctx.processes:      # (exactly the processes started here)
+                if proc.is_alive():
+                    proc.kill()
+        # Only a lost rendezvous (the port taken between _free_port() and
+        # init_process_group) is retried, on a new port: once a rank got past
+        # it, a failure is a failure of what is under test.
+        if glob.glob(os.path.join(str(tmp_path), "rendezvous_ok_*")) or attempt == 2:
+            raise error
     got = np.load(os.path.join(str(tmp_path), "gathered.npz"))
 
     # one process owning all worlds must produce the same tensors bit for bit

@@ -321,6 +321,21 @@ def test_sort_stress_lockstep(built, worlds):
     assert not probs, (step, probs[:3])
 
 
+@pytest.mark.parametrize("worlds,steps", [(1, 60), (33, 120), (1000, 50)])
+def test_tgs_solver_lockstep(built, worlds, steps):
+    """PhysicsSystem with Solver::TGS (SURVEY 8f-3; reference src/physics/tgs.cpp:
+    integrateVelocities :93-145 with the body-space gyroscopic term,
+    integratePositions :172-196, task wiring :225-304): dynamic, kinematic and
+    static bodies, a cube and an anisotropic slab, random forces and torques
+    every step -- positions, rotations and velocities bit for bit against the
+    reference built with the same solver switch."""
+    _need_ref("tgs_drop")
+    probs, step = run_pair("tgs_drop", worlds, steps, seed=9,
+                           check_every=1 if worlds <= 64 else 10,
+                           ref_workers=0 if worlds > 64 else 1)
+    assert not probs, (step, probs[:3])
+
+
 # Every way through the sort node, on the same workloads (DESIGN.md §4):
 #   compact 0          radix chain only (histogram + key passes + gather)
 #   compact 1          default: compaction chain where nothing but world sorts
