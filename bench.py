@@ -33,6 +33,16 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 MIN_WINDOW_S = 0.5      # a timed window shorter than this is repeated over more steps
+# instruction issue (the yardstick of the kernels that HBM says nothing about):
+# 256 CUs x 4 SIMDs; a wavefront issues at most one instruction every ~4 cycles
+# (MI355X_MICROARCH.md, "8 issue slots of ~4 cyc" per 32-cycle MFMA at one wave
+# per SIMD), so ONE wave per SIMD -- what the LDS-resident physics step runs at
+# -- tops out at 0.25 wave-instructions per cycle and SIMD; two waves per SIMD
+# can interleave up to 0.5 (a wave64 VALU op occupies the SIMD-32 for 2 cycles)
+NUM_SIMDS = 1024
+SHADER_CLOCK_HZ = 2.4e9
+ISSUE_PEAK_ONE_WAVE = 0.25
+ISSUE_PEAK_SIMD = 0.5
 
 OBS_TENSORS = {
     "escape_room": ["self_obs", "partner_obs", "room_ent_obs", "door_obs", "lidar",
@@ -145,6 +155,59 @@ def recorded_traffic():
         except (OSError, ValueError, KeyError):
             pass
     return entries
+
+
+def recorded_issue_counters():
+    """SQ instruction / cycle counters per launch (rocprofv3 --pmc, kernel trace
+    only, two passes: profiles/tools/refresh_r03.sh + make_issue_json.py): the
+    newest profiles/rNN_issue_counters.json."""
+    import glob
+    entries = []
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_issue_counters.json"))):
+        try:
+            with open(path) as f:
+                for e in json.load(f)["entries"]:
+                    e["source"] = os.path.relpath(path, REPO)
+                    entries.append(e)
+        except (OSError, ValueError, KeyError):
+            pass
+    return entries
+
+
+def issue_roofline(name, sim, worlds, kernel_pattern, avg_us, waves_per_simd, note):
+    """`valu-issue` roofline of a kernel: wave-instructions issued per cycle and
+    SIMD (recorded SQ_INSTS_* per launch / the LIVE event-timed duration of this
+    run), against what the waves this kernel keeps per SIMD can issue."""
+    match = None
+    for e in recorded_issue_counters():
+        if (e["sim"], e["worlds"]) == (sim, worlds) and kernel_pattern in e["kernel"]:
+            match = e           # later files override earlier ones
+    if match is None or avg_us <= 0 or "SQ_INSTS_VALU" not in match:
+        return None
+    insts = (match.get("SQ_INSTS_VALU", 0.0) + match.get("SQ_INSTS_SALU", 0.0) +
+             match.get("SQ_INSTS_LDS", 0.0))
+    cycles = avg_us * 1e-6 * SHADER_CLOCK_HZ
+    achieved = insts / (cycles * NUM_SIMDS)
+    peak = ISSUE_PEAK_ONE_WAVE if waves_per_simd <= 1 else ISSUE_PEAK_SIMD
+    out = {
+        "kernel": name, "bound": "valu-issue",
+        "achieved": round(achieved, 4), "peak": peak,
+        "unit": "wave-instructions/cycle/SIMD", "frac": round(achieved / peak, 4),
+        "valu_only": round(match["SQ_INSTS_VALU"] / (cycles * NUM_SIMDS), 4),
+        "waves_per_simd": waves_per_simd, "avg_us": round(avg_us, 2),
+        "insts_per_launch": {k: match[k] for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU",
+                                                   "SQ_INSTS_LDS", "SQ_WAVES")
+                             if k in match},
+        "counters_source": match["source"], "note": note,
+    }
+    wc = match.get("SQ_WAVE_CYCLES")
+    if wc:
+        out["wave_cycles"] = {
+            "issuing": round(match.get("SQ_ACTIVE_INST_ANY", 0.0) / wc, 3),
+            "parked_on_waitcnt": round(match.get("SQ_WAIT_ANY", 0.0) / wc, 3),
+            "issue_stalls": round(match.get("SQ_WAIT_INST_ANY", 0.0) / wc, 3),
+        }
+    return out
 
 
 def traffic_for(entries, sim, worlds, kernel_pattern):
@@ -272,7 +335,16 @@ def rooflines(stats, sim_name, worlds, ms_per_step):
         "SortArchetype/CompactArchetype nodes (histogram + onesweep passes + gather "
         "+ finalize of every sort chain in the step)", sort_k, t, src,
         "BASELINE's 'achieved HBM GB/s on sort node': all kernels of the node, not "
-        "its best one; bytes = SURVEY 8d formula x rows the sorts measured")
+        "its best one; bytes = SURVEY 8d formula x rows the sorts measured (what a "
+        "sort node is priced at: 40 N + 2 B_row N').  World sorts of tables that "
+        "are still sorted from the last step take the compaction chain (prepare + "
+        "scatter: 8 N + 8 N' instead of the 40 N of histogram + key passes)")
+    if nodes["sort_node"]:
+        rows_in = sum(k["rows"] for k in sort_k if "gather" in k["name"])
+        gather_bytes = sum(k["algo_bytes"] for k in sort_k if "gather" in k["name"])
+        nodes["sort_node"]["bytes_moved_estimate"] = int(gather_bytes + 16.0 * rows_in) \
+            if any("compact" in k["name"] for k in sort_k) else \
+            nodes["sort_node"]["algo_bytes_per_launch"]
     t, src = traffic_for(entries, sim_name, worlds, "physics:worldStep")
     nodes["physics_step"] = node_roofline(
         "physics:worldStep (broadphase pairs + 4 x (integrate, narrowphase, XPBD "
@@ -280,6 +352,14 @@ def rooflines(stats, sim_name, worlds, ms_per_step):
         phys_k, t, src,
         "latency/issue-bound: HBM sees one read + one write of the body columns "
         "per step (288 B/body); DESIGN.md §10")
+    if phys_k:
+        nodes["physics_step_issue"] = issue_roofline(
+            "physics:worldStep (same kernel, instruction-issue yardstick)", sim_name,
+            worlds, "physics:worldStep", sum(k["avg_us"] for k in phys_k),
+            1 if PHYS_BODIES.get(sim_name, 64) <= 32 else 2,
+            "two worlds per wavefront, one wavefront per SIMD (LDS: 2 x 17 KB per "
+            "wave): the kernel is bound by how fast one wave issues, not by HBM "
+            "(DESIGN.md §10)")
     # step level: every kernel's algorithmic bytes over the measured step time
     step_bytes = sum(k["algo_bytes"] for k in stats)
     t, src = traffic_for(entries, sim_name, worlds, "step:all-kernels")
@@ -481,6 +561,14 @@ def run_render(worlds, gpu_id, seed, denom, steps, warmup, profile_reps, settle,
                     for k in render_stats],
         "tlas_build_us": round(sum(k["avg_us"] for k in tlas), 2),
     }
+    issue = issue_roofline(
+        "render:raycast (same kernel, instruction-issue yardstick)",
+        "escape_room_render", worlds, "render:raycast", cast_us, 3,
+        "a traversal: bound by instruction issue and the latency of dependent node "
+        "/ triangle fetches from LDS, not by HBM (DESIGN.md §12); three 256-thread "
+        "workgroups per CU = three waves per SIMD")
+    if issue is not None:
+        out["roofline"]["nodes"] = {"raycast_issue": issue}
     return out
 
 
@@ -517,6 +605,7 @@ def main():
         if args.settle < 0:
             args.settle = 200
         worlds = args.worlds
+        hbm_measured = measure_hbm_bandwidth()
         r = run_render(worlds, local_rank, 5, args.auto_reset_denom, args.steps,
                        args.warmup, args.profile_reps, args.settle,
                        cpu_sample=not args.no_cpu_baseline)
@@ -531,7 +620,7 @@ def main():
                        "worlds_per_gpu": worlds, "settle_steps": args.settle,
                        "total_worlds": worlds, "dist_world_size": 1,
                        "parallelism": "worlds sharded over 1 GPU(s)"},
-            "roofline": r["roofline"],
+            "roofline": dict(r["roofline"], peak_measured=hbm_measured),
             "cpu_baseline": r["cpu_baseline_render_pass"],
             "render": {k: r[k] for k in ("step_graph_us", "render_graph_us",
                                          "primary_rays_per_s",
@@ -563,6 +652,9 @@ def main():
 
     from madrona_amd.distributed import ShardedSimulator, shard_for
     from madrona_amd.simlib import Simulator, hip_lib_path, runtime_lib
+
+    # the spec peak next to what this box's HBM delivers
+    hbm_measured = measure_hbm_bandwidth() if rank == 0 else None
 
     shard = shard_for(rank, world_size, worlds_per_rank=args.worlds)
     seed = 5
@@ -621,15 +713,27 @@ def main():
     value = total_worlds * args.steps / elapsed
     ms_per_step = elapsed / args.steps * 1e3
 
-    # a window this short (the driver's --steps 20 is ~25 ms) says little:
-    # repeat over enough steps for MIN_WINDOW_S and report that next to it
+    # A window this short (the driver's --steps 20 is ~25 ms) says little: it is
+    # repeated over enough steps for MIN_WINDOW_S, and THAT window is the line's
+    # `value` / `ms_per_step`; the --steps window stays next to it as
+    # `short_window`.
     long_window = None
+    short_window = None
     if elapsed < MIN_WINDOW_S:
         more = int(math.ceil(MIN_WINDOW_S / max(elapsed / args.steps, 1e-7)))
-        el2, _ = timed(more, mark=False)
+        el2, per_rank2 = timed(more, mark=False)
         long_window = {"steps": more, "seconds": round(el2, 4),
                        "ms_per_step": el2 / more * 1e3,
                        "value": total_worlds * more / el2}
+        short_window = {"steps": args.steps, "seconds": round(elapsed, 5),
+                        "ms_per_step": ms_per_step, "value": value,
+                        "per_rank_ms_per_step":
+                            [round(t / args.steps * 1e3, 5) for t in per_rank]}
+        value = long_window["value"]
+        ms_per_step = long_window["ms_per_step"]
+        per_rank_ms = [round(t / more * 1e3, 5) for t in per_rank2]
+    else:
+        per_rank_ms = [round(t / args.steps * 1e3, 5) for t in per_rank]
 
     # the collective on its own (packed observation record, RCCL all-gather)
     allgather = None
@@ -646,13 +750,35 @@ def main():
         allgather = {"ms": ev0.elapsed_time(ev1) / reps, "gathered_bytes": nbytes,
                      "per_rank_bytes": nbytes // max(world_size, 1)}
 
+    # What the per-step exchange is bounded by on one node: every
+    # rank contributes its packed observation record; xGMI is point to point
+    # (7 links x ~153 GB/s per GPU): with all peers pushing directly a rank
+    # receives (N - 1) records over N - 1 links at once, a ring moves
+    # (N - 1) / N of the gathered buffer over one link.
+    xgmi_bound = None
+    if distributed and sharded._packed_global is not None:
+        per_rank_bytes = sharded._packed_global.numel() * 4 // max(world_size, 1)
+        gathered = per_rank_bytes * world_size
+        link = 153e9
+        xgmi_bound = {
+            "per_rank_bytes": per_rank_bytes, "gathered_bytes": gathered,
+            "link_GBps": link / 1e9, "links_per_gpu": 7,
+            "direct_ms": per_rank_bytes / link * 1e3 if world_size > 1 else 0.0,
+            "ring_ms": (world_size - 1) / max(world_size, 1) * gathered / link * 1e3,
+            "note": "lower bounds for the all-gather of the packed observation "
+                    "record: direct = every peer pushes its record over its own "
+                    "link at once, ring = (N-1)/N of the gathered buffer over one "
+                    "link; compare with allgather.ms",
+        }
+
     # ---- per-kernel timing (HIP events on the executor's stream) + roofline ----
     roofline = None
     kernels = []
     if rank == 0:
         stats = sim.profile(args.profile_reps)
-        roofline = rooflines(stats, args.sim, args.worlds,
-                             (long_window or {}).get("ms_per_step", ms_per_step))
+        roofline = rooflines(stats, args.sim, args.worlds, ms_per_step)
+        if roofline is not None:
+            roofline["peak_measured"] = hbm_measured
         kernels = kernel_table(stats, args.sim, args.worlds)
 
     cpu = None
@@ -710,10 +836,14 @@ def main():
                                + (", one packed RCCL all-gather of the observation "
                                   "tensors per step" if distributed else ""),
             },
-            "window_s": round(elapsed, 5),
+            "window_s": round(long_window["seconds"] if long_window else elapsed, 5),
+            "timed_steps": long_window["steps"] if long_window else args.steps,
+            "short_window": short_window,
             "long_window": long_window,
-            "per_rank_ms_per_step": [round(t / args.steps * 1e3, 5) for t in per_rank],
+            "per_rank_ms_per_step": per_rank_ms,
             "allgather": allgather,
+            "xgmi_bound": xgmi_bound,
+            "hbm_measured": hbm_measured,
             "roofline": roofline,
             "cpu_baseline": cpu,
             "ecs_config2": secondary,
