@@ -431,7 +431,8 @@ def cpu_raycast_sample(sim, worlds, resolution, sample_worlds=8192):
     lib.raycast_ref_render.restype = C.c_int
     lib.raycast_ref_render.argtypes = [C.c_uint32, p, p, p, p, p, C.c_uint32, p,
                                        C.c_uint32, p, p, p, p, C.c_uint32, p, p, p,
-                                       C.c_uint32, C.c_uint32, C.c_uint32, p, p]
+                                       C.c_uint32, C.c_uint32, C.c_uint32, p, p,
+                                       p, p, p, C.c_uint32, p, p]
     geo = sim.lib.sim_render_geometry
     geo.restype = C.c_int32
     geo.argtypes = [p] * 7
@@ -468,7 +469,8 @@ def cpu_raycast_sample(sim, worlds, resolution, sample_worlds=8192):
         io.ctypes.data, np.ascontiguousarray(ic, np.int32).ctypes.data,
         views.ctypes.data, nv, lights.ctypes.data, lo.ctypes.data,
         np.ascontiguousarray(lc, np.int32).ctypes.data, resolution, 1,
-        min(cores, resolution), rgb.ctypes.data, depth.ctypes.data)
+        min(cores, resolution), rgb.ctypes.data, depth.ctypes.data,
+        None, None, None, 0, None, None)    # (the Escape Room's meshes are untextured)
     dt = time.perf_counter() - t0
     if rc != 0:
         return None

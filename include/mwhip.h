@@ -71,10 +71,33 @@ typedef struct mwhip_render_geometry {
     const uint32_t *indices;            /* 3 per triangle, object-local vertex ids */
     const uint32_t *object_vertex_offset;   /* [num_objects + 1] into vertices */
     const uint32_t *object_triangle_offset; /* [num_objects + 1] into indices / 3 */
-    const int32_t *object_material;     /* [num_objects] material id, -1: none
-                                         * (white); NULL: none anywhere */
+    const int32_t *object_material;     /* [num_objects] material id of the whole
+                                         * mesh (reference MeshBVH::materialIDX,
+                                         * mesh_bvh.hpp:304); -1: per triangle
+                                         * (triangle_material) or, without those,
+                                         * none (white); NULL: -1 everywhere */
     const float *material_color;        /* rgb per material */
+    /* ---- per-triangle materials and textures (reference
+     * MeshBVH::LeafMaterial / BVHVertex::uv, mesh_bvh.hpp:167-178; Material,
+     * :148-156; bvh_raycast.cpp:772-800).  All optional (NULL / 0). ---- */
+    const float *vertex_uv;             /* uv per vertex, all objects */
+    const int32_t *triangle_material;   /* per triangle, all objects: material id
+                                         * or -1 (none: white); read for objects
+                                         * whose object_material is -1 */
+    const int32_t *material_texture;    /* [num_materials] texture id or -1 */
+    uint32_t num_textures;
+    uint32_t pad_;
+    const struct mwhip_texture *textures;   /* [num_textures] */
 } mwhip_render_geometry;
+
+/* An RGBA8 texture, row 0 first (what the reference uploads into a cudaArray of
+ * uchar4 and samples through a texture object with wrap addressing, linear
+ * filtering and normalised coordinates, render/asset_processor.cpp:312-345). */
+typedef struct mwhip_texture {
+    uint32_t width;
+    uint32_t height;
+    const uint8_t *rgba8;               /* width * height * 4 bytes, host memory */
+} mwhip_texture;
 
 /* Which tables the batch ray caster reads and writes: set once by
  * RenderingSystem::registerTypes (the type ids are assigned there).
@@ -342,6 +365,9 @@ int64_t mwhip_dump_column_raw(mwhip_exec *exec, uint32_t archetype_id,
                               uint64_t dst_bytes);
 int mwhip_memcpy_d2h(void *dst_host, const void *src_dev, uint64_t num_bytes);
 int mwhip_memcpy_h2d(void *dst_dev, const void *src_host, uint64_t num_bytes);
+/* to host memory from wherever `src` lives (host or device: a renderer's asset
+ * buffers, reference render/cuda_batch_render_assets.hpp, may be either) */
+int mwhip_memcpy_any(void *dst_host, const void *src, uint64_t num_bytes);
 
 /* Packs `num_columns` exported columns into one row-major record per row:
  * dst[row] = column 0's words | column 1's words | ...  (4-byte words;

@@ -58,6 +58,15 @@ struct RenderGeometryDev {
     const uint32_t *objectBoxFaces;         // [numObjects][12] the two triangles of face
                                             // axis * 2 + (max side), object-local ids
     const float *materialColor;             // rgb per material
+    // per-triangle materials / textures (all may be null: untextured objects
+    // with one material each take none of this)
+    const float *triangleUV;                // 6 per triangle, leaf order
+    const int32_t *triangleMaterial;        // per triangle, leaf order
+    const int32_t *materialTexture;         // per material, -1: none
+    const uint32_t *textureInfo;            // [numTextures][4] first texel, width, height, -
+    const uint32_t *texels;                 // RGBA8
+    uint32_t numTextures;
+    uint32_t pad_;
 };
 
 struct RenderGeometryHost {
@@ -72,6 +81,11 @@ struct RenderGeometryHost {
     std::vector<float> objectRootBox;       // 6 per object: what TLBVHNode uses
     std::vector<uint32_t> objectIsBox;      // the mesh IS that box (12 outward triangles)
     std::vector<uint32_t> objectBoxFaces;   // 12 per object (leaf-order triangle ids)
+    std::vector<float> triangleUV;          // empty: no uvs given
+    std::vector<int32_t> triangleMaterial;  // empty: no per-triangle materials
+    std::vector<int32_t> materialTexture;   // empty: no textures
+    std::vector<uint32_t> textureInfo;
+    std::vector<uint32_t> texels;
 };
 
 struct RenderParams {

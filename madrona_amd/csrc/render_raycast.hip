@@ -333,7 +333,7 @@ __device__ inline float comp(const Vector3 &v, int32_t k)
 __device__ inline bool rayTriangle(const Vector3 &ta, const Vector3 &tb,
                                    const Vector3 &tc, const RayIsect &r,
                                    const Vector3 &org, float t_max,
-                                   float *t_out)
+                                   float *t_out, Vector3 *bary_out = nullptr)
 {
     const Vector3 A = ta - org, B = tb - org, C = tc - org;
     const float a_kz = comp(A, r.kz), a_kx = comp(A, r.kx), a_ky = comp(A, r.ky);
@@ -379,6 +379,10 @@ __device__ inline bool rayTriangle(const Vector3 &ta, const Vector3 &tb,
 
     const float rcp_det = 1.f / det;
     *t_out = T * rcp_det;
+    if (bary_out != nullptr) {
+        // (reference rayTriangleIntersection :441: Vector3{U,V,W} * rcpDet)
+        *bary_out = Vector3 { U, V, W } * rcp_det;
+    }
     return true;
 }
 
@@ -428,37 +432,97 @@ constexpr uint32_t kStackDepth = 24;
 constexpr uint32_t kGeoLdsDwords = 7168;
 
 // what shading a hit on an instance needs: its rotation (normals) and its colour
-// (material / override resolved once per instance, reference traceRay :772-812;
-// one untextured material per object here)
+// -- material / override resolved once per instance (reference traceRay
+// :772-812) unless the hit itself decides: a textured material (sampled at the
+// hit's uv) or a mesh with per-triangle materials
+constexpr int32_t kShadeFinal = -1;         // `color` is the colour
+constexpr int32_t kShadePerTriangle = -3;   // material from the hit triangle
+
 struct alignas(16) ShadeRec {
     Quat rotation;
     Vector3 color;
-    uint32_t pad;
+    int32_t material;   // kShadeFinal / kShadePerTriangle / a textured material
 };
+
+__device__ inline Vector3 materialColorOf(const RenderGeometryDev &geo, int32_t m)
+{
+    return Vector3 { geo.materialColor[3 * m], geo.materialColor[3 * m + 1],
+                     geo.materialColor[3 * m + 2] };
+}
+
+__device__ inline bool materialIsTextured(const RenderGeometryDev &geo, int32_t m)
+{
+    return geo.materialTexture != nullptr && geo.materialTexture[m] >= 0;
+}
 
 __device__ inline ShadeRec shadeRecord(const InstanceRec &inst,
                                        const RenderGeometryDev &geo)
 {
-    int32_t material = inst.matID;
-    if (material == -1) {
-        material = (uint32_t)inst.objectID < geo.numObjects ?
-            geo.objectMaterial[inst.objectID] : -1;
-    }
-    Vector3 color { 1.f, 1.f, 1.f };
-    if (inst.matID == -2) {
-        color = Vector3 { (float)((inst.color >> 16) & 0xFFu) / 255.f,
-                          (float)((inst.color >> 8) & 0xFFu) / 255.f,
-                          (float)(inst.color & 0xFFu) / 255.f };
-    } else if (material >= 0 && (uint32_t)material < geo.numMaterials) {
-        color = Vector3 { geo.materialColor[3 * material],
-                          geo.materialColor[3 * material + 1],
-                          geo.materialColor[3 * material + 2] };
-    }
     ShadeRec rec;
     rec.rotation = inst.rotation;
-    rec.color = color;
-    rec.pad = 0;
+    rec.color = Vector3 { 1.f, 1.f, 1.f };
+    rec.material = kShadeFinal;
+
+    if (inst.matID == -2) {             // MaterialOverride::UseOverrideColor
+        rec.color = Vector3 { (float)((inst.color >> 16) & 0xFFu) / 255.f,
+                              (float)((inst.color >> 8) & 0xFFu) / 255.f,
+                              (float)(inst.color & 0xFFu) / 255.f };
+        return rec;
+    }
+    int32_t material = inst.matID;
+    if (material == -1) {               // UseDefaultMaterial: the mesh's own
+        material = (uint32_t)inst.objectID < geo.numObjects ?
+            geo.objectMaterial[inst.objectID] : -1;
+        if (material == -1 && geo.triangleMaterial != nullptr &&
+                (uint32_t)inst.objectID < geo.numObjects) {
+            rec.material = kShadePerTriangle;
+            return rec;
+        }
+    }
+    if (material >= 0 && (uint32_t)material < geo.numMaterials) {
+        rec.color = materialColorOf(geo, material);
+        if (materialIsTextured(geo, material)) {
+            rec.material = material;
+        }
+    }
     return rec;
+}
+
+// tex2D<float4>(tex, x, y) of a texture object over an RGBA8 array with wrap
+// addressing, linear filtering, normalised coordinates and normalised-float
+// reads (how the reference creates its textures, render/asset_processor.cpp:
+// 312-345), as the CUDA programming guide defines it: xB = N x - 0.5,
+// i = floor(xB), alpha = frac(xB) kept in 9-bit fixed point with 8 fractional
+// bits, tex = (1 - a)(1 - b) T[i, j] + a (1 - b) T[i + 1, j] + (1 - a) b
+// T[i, j + 1] + a b T[i + 1, j + 1], indices wrapped.  The same definition is
+// the oracle's tex2D (oracle/ref_shims/raycast_ref_shim.cpp): there is no CUDA
+// texture unit here to compare either of them with.
+__device__ inline Vector3 sampleTexture(const RenderGeometryDev &geo, int32_t tex,
+                                        float x, float y)
+{
+    const uint32_t first = geo.textureInfo[4 * tex];
+    const int32_t width = (int32_t)geo.textureInfo[4 * tex + 1];
+    const int32_t height = (int32_t)geo.textureInfo[4 * tex + 2];
+    const float xb = x * (float)width - 0.5f;
+    const float yb = y * (float)height - 0.5f;
+    const float xf = floorf(xb), yf = floorf(yb);
+    const float a = floorf((xb - xf) * 256.f + 0.5f) * (1.f / 256.f);
+    const float b = floorf((yb - yf) * 256.f + 0.5f) * (1.f / 256.f);
+    auto wrap = [](int32_t i, int32_t n) {
+        i %= n;
+        return i < 0 ? i + n : i;
+    };
+    const int32_t i0 = wrap((int32_t)xf, width), i1 = wrap((int32_t)xf + 1, width);
+    const int32_t j0 = wrap((int32_t)yf, height), j1 = wrap((int32_t)yf + 1, height);
+    auto texel = [&](int32_t i, int32_t j) {
+        const uint32_t t = geo.texels[first + (uint32_t)(j * width + i)];
+        return Vector3 { (float)(t & 0xFFu) / 255.f, (float)((t >> 8) & 0xFFu) / 255.f,
+                         (float)((t >> 16) & 0xFFu) / 255.f };
+    };
+    const Vector3 t00 = texel(i0, j0), t10 = texel(i1, j0);
+    const Vector3 t01 = texel(i0, j1), t11 = texel(i1, j1);
+    return (1.f - a) * (1.f - b) * t00 + a * (1.f - b) * t10 +
+           (1.f - a) * b * t01 + a * b * t11;
 }
 
 template <bool GeoInLds>
@@ -1007,9 +1071,48 @@ renderRaycast(EcsState *S, RenderParams params)
             if (params.rgbd != 0u) {
                 const ShadeRec shade = staged ? lds.shade[first.instance] :
                     shadeRecord(inst_hbm[first.instance], geo_dev);
-                const Vector3 color = shade.color;
+                Vector3 color = shade.color;
                 // geometric normal of the hit triangle (reference :443-446)
                 const Vector3 *tri = geo.triangles + 3u * (size_t)first.triangle;
+                if (shade.material != kShadeFinal) {
+                    // the hit decides: the triangle's own material and / or a
+                    // texture sampled at the hit's uv (reference :772-800)
+                    int32_t material = shade.material;
+                    if (material == kShadePerTriangle) {
+                        material = geo_dev.triangleMaterial[first.triangle];
+                        color = Vector3 { 1.f, 1.f, 1.f };
+                        if (material >= 0 && (uint32_t)material < geo_dev.numMaterials) {
+                            color = materialColorOf(geo_dev, material);
+                        } else {
+                            material = -1;
+                        }
+                    }
+                    if (material >= 0 && materialIsTextured(geo_dev, material) &&
+                            geo_dev.triangleUV != nullptr) {
+                        // barycentrics of the hit: the triangle test once more,
+                        // on the object-space ray of this instance (:469-478)
+                        const PreparedInstance &pi = staged ?
+                            lds.instances[first.instance] :
+                            prepared_hbm[first.instance];
+                        const Vector3 obj_o = pi.invScale *
+                            pi.invRotation.rotateVec(ray_start - pi.position);
+                        Vector3 obj_d =
+                            pi.invScale * pi.invRotation.rotateVec(ray_dir);
+                        obj_d /= obj_d.length();
+                        float t_again;
+                        Vector3 bary { 1.f, 0.f, 0.f };
+                        (void)rayTriangle(tri[0], tri[1], tri[2], rayIsect(obj_d),
+                                          obj_o, INFINITY, &t_again, &bary);
+                        const float *uv = geo_dev.triangleUV + 6u * (size_t)first.triangle;
+                        const float u = uv[0] * bary.x + uv[2] * bary.y + uv[4] * bary.z;
+                        const float v = uv[1] * bary.x + uv[3] * bary.y + uv[5] * bary.z;
+                        const Vector3 texel = sampleTexture(geo_dev,
+                            geo_dev.materialTexture[material], u, 1.f - v);
+                        const Vector3 base = materialColorOf(geo_dev, material);
+                        color = Vector3 { texel.x * base.x, texel.y * base.y,
+                                          texel.z * base.z };
+                    }
+                }
                 const Vector3 obj_normal =
                     math::cross(tri[1] - tri[0], tri[2] - tri[0]).normalize();
                 const Vector3 normal = shade.rotation.rotateVec(obj_normal);
@@ -1080,6 +1183,8 @@ namespace {
 struct BuildTri {
     float v[9];
     float c[3];
+    float uv[6];        // travels with the triangle into leaf order
+    int32_t material;
 };
 
 AABB boxOf(const std::vector<BuildTri> &tris, uint32_t first, uint32_t count)
@@ -1215,6 +1320,33 @@ int buildRenderGeometry(const mwhip_render_geometry &src, RenderGeometryHost &ou
         out.materialColor.assign(src.material_color,
                                  src.material_color + 3 * (size_t)src.num_materials);
     }
+    const bool have_uv = src.vertex_uv != nullptr;
+    const bool have_tri_mat = src.triangle_material != nullptr;
+    if (src.material_texture != nullptr && src.num_materials != 0) {
+        out.materialTexture.assign(src.material_texture,
+                                   src.material_texture + src.num_materials);
+        for (uint32_t t = 0; t < src.num_textures; t++) {
+            const mwhip_texture &tex = src.textures[t];
+            if (tex.width == 0 || tex.height == 0 || tex.rgba8 == nullptr) {
+                error = "render geometry: texture " + std::to_string(t) + " is empty";
+                return -1;
+            }
+            out.textureInfo.push_back((uint32_t)out.texels.size());
+            out.textureInfo.push_back(tex.width);
+            out.textureInfo.push_back(tex.height);
+            out.textureInfo.push_back(0u);
+            const uint32_t *px = (const uint32_t *)tex.rgba8;
+            out.texels.insert(out.texels.end(), px,
+                              px + (size_t)tex.width * tex.height);
+        }
+        for (int32_t t : out.materialTexture) {
+            if (t >= (int32_t)src.num_textures) {
+                error = "render geometry: a material names texture " +
+                        std::to_string(t) + " of " + std::to_string(src.num_textures);
+                return -1;
+            }
+        }
+    }
 
     for (uint32_t obj = 0; obj < src.num_objects; obj++) {
         const uint32_t tri_first = src.object_triangle_offset[obj];
@@ -1236,7 +1368,13 @@ int buildRenderGeometry(const mwhip_render_geometry &src, RenderGeometryHost &ou
                 for (int a = 0; a < 3; a++) {
                     tris[t].v[3 * k + a] = verts[3 * (size_t)vi + a];
                 }
+                for (int a = 0; a < 2; a++) {
+                    tris[t].uv[2 * k + a] = have_uv ?
+                        src.vertex_uv[2 * ((size_t)vert_first + vi) + a] : 0.f;
+                }
             }
+            tris[t].material = have_tri_mat ?
+                src.triangle_material[tri_first + t] : -1;
             for (int a = 0; a < 3; a++) {
                 tris[t].c[a] =
                     (tris[t].v[a] + tris[t].v[3 + a] + tris[t].v[6 + a]) / 3.f;
@@ -1268,6 +1406,12 @@ int buildRenderGeometry(const mwhip_render_geometry &src, RenderGeometryHost &ou
         out.nodes.insert(out.nodes.end(), nodes.begin(), nodes.end());
         for (const BuildTri &t : tris) {
             out.triangleVertices.insert(out.triangleVertices.end(), t.v, t.v + 9);
+            if (have_uv) {
+                out.triangleUV.insert(out.triangleUV.end(), t.uv, t.uv + 6);
+            }
+            if (have_tri_mat) {
+                out.triangleMaterial.push_back(t.material);
+            }
         }
         if (tri_count > 0) {
             // (tris are in leaf order by now: ids as the trace kernel sees them)

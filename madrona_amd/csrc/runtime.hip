@@ -1125,8 +1125,36 @@ static int uploadRenderGeometry(mwhip_exec *exec)
     rc = upload(g.objectBoxFaces.data(), g.objectBoxFaces.size() * 4,
                 (const void **)&d.objectBoxFaces);
     if (rc != 0) return rc;
-    return upload(g.materialColor.data(), g.materialColor.size() * 4,
-                  (const void **)&d.materialColor);
+    rc = upload(g.materialColor.data(), g.materialColor.size() * 4,
+                (const void **)&d.materialColor);
+    if (rc != 0) return rc;
+    d.triangleUV = nullptr;
+    d.triangleMaterial = nullptr;
+    d.materialTexture = nullptr;
+    d.textureInfo = nullptr;
+    d.texels = nullptr;
+    d.numTextures = (uint32_t)(g.textureInfo.size() / 4);
+    if (!g.triangleUV.empty()) {
+        rc = upload(g.triangleUV.data(), g.triangleUV.size() * 4,
+                    (const void **)&d.triangleUV);
+        if (rc != 0) return rc;
+    }
+    if (!g.triangleMaterial.empty()) {
+        rc = upload(g.triangleMaterial.data(), g.triangleMaterial.size() * 4,
+                    (const void **)&d.triangleMaterial);
+        if (rc != 0) return rc;
+    }
+    if (!g.materialTexture.empty()) {
+        rc = upload(g.materialTexture.data(), g.materialTexture.size() * 4,
+                    (const void **)&d.materialTexture);
+        if (rc != 0) return rc;
+        rc = upload(g.textureInfo.data(), g.textureInfo.size() * 4,
+                    (const void **)&d.textureInfo);
+        if (rc != 0) return rc;
+        rc = upload(g.texels.data(), g.texels.size() * 4, (const void **)&d.texels);
+        if (rc != 0) return rc;
+    }
+    return 0;
 }
 
 static int buildDeviceState(mwhip_exec *exec)
@@ -3504,6 +3532,22 @@ extern "C" int mwhip_memcpy_d2h(void *dst_host, const void *src_dev,
                                 uint64_t num_bytes)
 {
     HIPCHK(hipMemcpy(dst_host, src_dev, num_bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int mwhip_memcpy_any(void *dst_host, const void *src,
+                                uint64_t num_bytes)
+{
+    if (num_bytes == 0) return 0;
+    hipPointerAttribute_t attr {};
+    const hipError_t res = hipPointerGetAttributes(&attr, src);
+    if (res != hipSuccess || attr.type == hipMemoryTypeUnregistered ||
+            attr.type == hipMemoryTypeHost) {
+        (void)hipGetLastError();    // (plain host memory is not an error)
+        memcpy(dst_host, src, num_bytes);
+        return 0;
+    }
+    HIPCHK(hipMemcpy(dst_host, src, num_bytes, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -19,12 +19,14 @@
 #include <madrona/optional.hpp>
 #include <madrona/types.hpp>
 #include <madrona/math.hpp>
+#include <madrona/render/cuda_batch_render_assets.hpp>
 
 #include <mwhip.h>
 
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstdint>
 #include <vector>
 
 // Defined by MADRONA_BUILD_MWGPU_ENTRY in the simulator's device TU.
@@ -56,28 +58,34 @@ struct CompileConfig {
     OptMode optMode = OptMode::LTO;
 };
 
-// Batch ray caster configuration (reference mw_gpu.hpp:77-96).  The geometry
-// side (geoBVHData / materialData) is not built on this backend yet (SURVEY
-// 8f-1); what the render-prep systems need of it is one object-space root AABB
-// per object id.
+// Batch ray caster configuration (reference mw_gpu.hpp:77-96).  Geometry and
+// materials arrive either in the reference's own form -- geoBVHData /
+// materialData, the types of <madrona/render/cuda_batch_render_assets.hpp>:
+// 4-wide quantised mesh BVHs with de-indexed vertices, per-triangle materials
+// and texture objects, as a renderer's asset processor produces them -- or, for
+// applications without such a processor (it needs Embree), as plain indexed
+// triangles: geoTriangles / triangleMaterials, an addition of this backend.
+// Either way the executor builds its own bottom-level trees from the triangles
+// (any valid BVH gives the same image); of a MeshBVHData it reads the leaves.
 namespace render {
 
-// Triangle geometry of the renderable objects, host memory (the reference's
-// MeshBVHData holds Embree-built QBVHs already on the device,
-// render/cuda_batch_render_assets.hpp:8-20; this executor builds its own
-// bottom-level BVHs from the triangles).
-struct MeshBVHData {
+// indexed triangles of the renderable objects, host memory
+struct TriangleMeshData {
     Span<const math::Vector3> vertices = {};        // all objects
     Span<const uint32_t> indices = {};              // 3 per triangle, object-local
     Span<const uint32_t> objectVertexOffsets = {};  // [numObjects + 1]
     Span<const uint32_t> objectTriangleOffsets = {};// [numObjects + 1]
+    Span<const math::Vector2> vertexUVs = {};       // per vertex, or empty
+    // per triangle (all objects): the material of triangles of objects whose
+    // objectMaterials entry is -1 (reference MeshBVH::leafMats); or empty
+    Span<const int32_t> triangleMaterials = {};
 };
 
-// One untextured material per object (the reference: per mesh, optionally
-// textured, cuda_batch_render_assets.hpp:22-28).
-struct MaterialData {
+struct TriangleMaterialData {
     Span<const math::Vector3> materialColors = {};
-    Span<const int32_t> objectMaterials = {};       // [numObjects], -1: none
+    Span<const int32_t> objectMaterials = {};       // [numObjects], -1: per triangle / none
+    Span<const int32_t> materialTextures = {};      // per material: texture or -1; or empty
+    Span<const TextureRGBA8> textures = {};
 };
 
 }
@@ -92,15 +100,25 @@ struct CudaBatchRenderConfig {
     render::MeshBVHData geoBVHData = {};
     render::MaterialData materialData = {};
     // 6 floats per object id (min xyz, max xyz), host memory; empty: taken from
-    // geoBVHData
+    // the geometry
     Span<const float> objectRootAABBs = {};
     // the ray caster's outputs are renderResolution x renderResolution
     uint32_t renderResolution = 0;
+    // (reference mw_gpu.hpp:89-90.  Its ray caster hands nearPlane down as
+    // BVHParams::nearSphere -> TraceInfo::tMin, bvh_raycast.cpp:983, and never
+    // reads tMin again: accepted here, with the same effect)
     float nearPlane = 0.f;
     float farPlane = 0.f;
-    // (this backend) most views a world will hold, 0 = unknown: sizes the
-    // render-target table, 8 * renderResolution^2 bytes a view
+    // ---- this backend ----
+    // most views a world will hold, 0 = unknown: sizes the render-target table,
+    // 8 * renderResolution^2 bytes a view
     uint32_t maxViewsPerWorld = 0;
+    // the geometry as plain triangles (used when geoBVHData holds no meshes)
+    render::TriangleMeshData geoTriangles = {};
+    render::TriangleMaterialData triangleMaterials = {};
+    // entries of materialData.materials (the reference's struct carries no
+    // count); 0: one past the largest material id the meshes name
+    uint32_t numMaterials = 0;
 };
 
 // Opaque device context handle (the reference returns a CUcontext)
@@ -155,7 +173,124 @@ private:
 friend class MWCudaExecutor;
 };
 
+namespace detail {
+
+// A renderer's MeshBVHData / MaterialData (host or device memory) as the
+// triangle description the executor's C ABI takes: every leaf child of every
+// node names `triSize` consecutive triangles, three de-indexed BVHVertex each
+// (reference mesh_bvh.hpp:33-47, bvh_raycast.cpp:303-313).
+struct ReferenceAssets {
+    std::vector<float> vertices;            // 3 per triangle corner
+    std::vector<float> uvs;
+    std::vector<uint32_t> indices;          // 0, 1, 2, ... per object
+    std::vector<uint32_t> vertexOffsets { 0u };
+    std::vector<uint32_t> triangleOffsets { 0u };
+    std::vector<int32_t> triangleMaterials;
+    std::vector<int32_t> objectMaterials;
+    std::vector<float> materialColors;
+    std::vector<int32_t> materialTextures;
+    std::vector<render::TextureRGBA8> textureDescs;
+
+    template <typename T>
+    static std::vector<T> fetch(const T *src, uint64_t count)
+    {
+        std::vector<T> host(count);
+        if (count != 0 && mwhip_memcpy_any(host.data(), src,
+                                           count * sizeof(T)) != 0) {
+            fprintf(stderr, "madrona_amd: cannot read the render assets: %s\n",
+                    mwhip_last_error());
+            abort();
+        }
+        return host;
+    }
+
+    template <typename ConfigT>
+    void read(const ConfigT &cfg)
+    {
+        const render::MeshBVHData &geo = cfg.geoBVHData;
+        const std::vector<MeshBVH> meshes = fetch(geo.meshBVHs, geo.numBVHs);
+        int32_t max_material = -1;
+        for (const MeshBVH &mesh : meshes) {
+            const std::vector<QBVHNode> nodes = fetch(mesh.nodes, mesh.numNodes);
+            const std::vector<MeshBVH::BVHVertex> verts =
+                fetch(mesh.vertices, mesh.numVerts);
+            const std::vector<MeshBVH::LeafMaterial> leaf_mats =
+                mesh.materialIDX == -1 && mesh.leafMats != nullptr ?
+                    fetch(mesh.leafMats, mesh.numVerts / 3u) :
+                    std::vector<MeshBVH::LeafMaterial>();
+            uint32_t corner = 0;
+            for (const QBVHNode &node : nodes) {
+                for (uint32_t c = 0; c < (uint32_t)MADRONA_BVH_WIDTH; c++) {
+                    if (!node.hasChild(c) || !node.isLeaf(c)) continue;
+                    const uint32_t first = node.leafIDX(c);
+                    for (uint32_t t = 0; t < node.triSize[c]; t++) {
+                        for (uint32_t k = 0; k < 3u; k++) {
+                            const MeshBVH::BVHVertex &v =
+                                verts[(size_t)(first + t) * 3u + k];
+                            vertices.insert(vertices.end(),
+                                            { v.pos.x, v.pos.y, v.pos.z });
+                            uvs.insert(uvs.end(), { v.uv.x, v.uv.y });
+                            indices.push_back(corner++);
+                        }
+                        const int32_t m = leaf_mats.empty() ? -1 :
+                            leaf_mats[first + t].material[0].matIDX;
+                        triangleMaterials.push_back(m);
+                        max_material = m > max_material ? m : max_material;
+                    }
+                }
+            }
+            vertexOffsets.push_back((uint32_t)(vertices.size() / 3));
+            triangleOffsets.push_back((uint32_t)(indices.size() / 3));
+            objectMaterials.push_back(mesh.materialIDX);
+            max_material = mesh.materialIDX > max_material ?
+                mesh.materialIDX : max_material;
+        }
+
+        const uint32_t num_materials = cfg.numMaterials != 0 ?
+            cfg.numMaterials : (uint32_t)(max_material + 1);
+        const std::vector<Material> materials =
+            fetch(cfg.materialData.materials,
+                  cfg.materialData.materials != nullptr ? num_materials : 0u);
+        for (const Material &m : materials) {
+            materialColors.insert(materialColors.end(),
+                                  { m.color.x, m.color.y, m.color.z });
+            materialTextures.push_back(m.textureIdx);
+        }
+        const std::vector<cudaTextureObject_t> handles = fetch(
+            cfg.materialData.textures, cfg.materialData.numTextureBuffers);
+        for (cudaTextureObject_t h : handles) {
+            textureDescs.push_back(*(const render::TextureRGBA8 *)(uintptr_t)h);
+        }
+    }
+
+    void describe(mwhip_render_geometry &geometry,
+                  std::vector<mwhip_texture> &textures) const
+    {
+        geometry.num_objects = (uint32_t)triangleOffsets.size() - 1u;
+        geometry.vertices = vertices.data();
+        geometry.indices = indices.data();
+        geometry.object_vertex_offset = vertexOffsets.data();
+        geometry.object_triangle_offset = triangleOffsets.data();
+        geometry.vertex_uv = uvs.data();
+        geometry.triangle_material = triangleMaterials.data();
+        geometry.object_material = objectMaterials.data();
+        geometry.num_materials = (uint32_t)(materialColors.size() / 3);
+        geometry.material_color = materialColors.data();
+        if (!textureDescs.empty()) {
+            geometry.material_texture = materialTextures.data();
+            for (const render::TextureRGBA8 &t : textureDescs) {
+                textures.push_back({ t.width, t.height, t.pixels });
+            }
+            geometry.num_textures = (uint32_t)textures.size();
+            geometry.textures = textures.data();
+        }
+    }
+};
+
+}
+
 class MWCudaExecutor {
+    using ReferenceAssets = detail::ReferenceAssets;
 public:
     static CUcontext initCUDA(int gpu_id) { return CUcontext { gpu_id }; }
 
@@ -170,9 +305,16 @@ public:
     {
         mwhip_state_config cfg {};
         mwhip_render_geometry geometry {};
+        std::vector<mwhip_texture> textures;
+        ReferenceAssets from_reference;
         if (render_cfg.has_value()) {
-            const render::MeshBVHData &geo = render_cfg->geoBVHData;
-            if (geo.objectTriangleOffsets.size() > 1) {
+            const render::TriangleMeshData &geo = render_cfg->geoTriangles;
+            if (render_cfg->geoBVHData.numBVHs != 0) {
+                // the reference's asset form: read the leaves of its mesh BVHs
+                from_reference.read(*render_cfg);
+                from_reference.describe(geometry, textures);
+                cfg.render_geometry = &geometry;
+            } else if (geo.objectTriangleOffsets.size() > 1) {
                 geometry.num_objects =
                     (uint32_t)geo.objectTriangleOffsets.size() - 1u;
                 geometry.vertices = (const float *)geo.vertices.data();
@@ -180,12 +322,25 @@ public:
                 geometry.object_vertex_offset = geo.objectVertexOffsets.data();
                 geometry.object_triangle_offset =
                     geo.objectTriangleOffsets.data();
-                const render::MaterialData &mats = render_cfg->materialData;
+                geometry.vertex_uv = geo.vertexUVs.size() != 0 ?
+                    (const float *)geo.vertexUVs.data() : nullptr;
+                geometry.triangle_material = geo.triangleMaterials.size() != 0 ?
+                    geo.triangleMaterials.data() : nullptr;
+                const render::TriangleMaterialData &mats =
+                    render_cfg->triangleMaterials;
                 geometry.num_materials = (uint32_t)mats.materialColors.size();
                 geometry.material_color =
                     (const float *)mats.materialColors.data();
                 geometry.object_material = mats.objectMaterials.size() != 0 ?
                     mats.objectMaterials.data() : nullptr;
+                if (mats.materialTextures.size() != 0) {
+                    geometry.material_texture = mats.materialTextures.data();
+                    for (const render::TextureRGBA8 &t : mats.textures) {
+                        textures.push_back({ t.width, t.height, t.pixels });
+                    }
+                    geometry.num_textures = (uint32_t)textures.size();
+                    geometry.textures = textures.data();
+                }
                 cfg.render_geometry = &geometry;
             }
             cfg.raycast_output_resolution = render_cfg->renderResolution;

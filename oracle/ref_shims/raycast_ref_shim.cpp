@@ -42,10 +42,47 @@ struct Dim3 { uint32_t x, y, z; };
 }
 static thread_local Dim3 threadIdx, blockIdx, blockDim, gridDim;
 
+// A texture object = the address of one of these.  tex2D<float4> over an RGBA8
+// array with wrap addressing, linear filtering, normalised coordinates and
+// normalised-float reads (how the reference creates its textures,
+// src/render/asset_processor.cpp:312-345), as the CUDA programming guide
+// defines the fetch: xB = N x - 0.5, i = floor(xB), alpha = frac(xB) in 9-bit
+// fixed point with 8 fractional bits, bilinear blend of the four wrapped
+// texels.  (No CUDA texture unit exists here to pin this against: the
+// definition is the oracle.)
 typedef unsigned long long cudaTextureObject_t;
 struct float4 { float x, y, z, w; };
+struct ShimTexture {
+    uint32_t width, height;
+    const uint8_t *rgba8;
+};
 template <typename T>
-static inline T tex2D(cudaTextureObject_t, float, float) { return T {}; }
+static inline T tex2D(cudaTextureObject_t handle, float x, float y)
+{
+    const ShimTexture &tex = *(const ShimTexture *)(uintptr_t)handle;
+    const int32_t width = (int32_t)tex.width, height = (int32_t)tex.height;
+    const float xb = x * (float)width - 0.5f;
+    const float yb = y * (float)height - 0.5f;
+    const float xf = floorf(xb), yf = floorf(yb);
+    const float a = floorf((xb - xf) * 256.f + 0.5f) * (1.f / 256.f);
+    const float b = floorf((yb - yf) * 256.f + 0.5f) * (1.f / 256.f);
+    auto wrap = [](int32_t i, int32_t n) {
+        i %= n;
+        return i < 0 ? i + n : i;
+    };
+    const int32_t i0 = wrap((int32_t)xf, width), i1 = wrap((int32_t)xf + 1, width);
+    const int32_t j0 = wrap((int32_t)yf, height), j1 = wrap((int32_t)yf + 1, height);
+    auto texel = [&](int32_t i, int32_t j, int c) {
+        return (float)tex.rgba8[4 * ((size_t)j * width + i) + c] / 255.f;
+    };
+    float out[3];
+    for (int c = 0; c < 3; c++) {
+        out[c] = (1.f - a) * (1.f - b) * texel(i0, j0, c) +
+                 a * (1.f - b) * texel(i1, j0, c) +
+                 (1.f - a) * b * texel(i0, j1, c) + a * b * texel(i1, j1, c);
+    }
+    return T { out[0], out[1], out[2], 1.f };
+}
 
 static inline float __uint_as_float(uint32_t v) { return std::bit_cast<float>(v); }
 static inline uint32_t __float_as_uint(float v) { return std::bit_cast<uint32_t>(v); }
@@ -209,7 +246,12 @@ int raycast_ref_render(
     const void *views, uint32_t num_views,
     const void *lights, const int32_t *light_offsets, const int32_t *light_counts,
     uint32_t resolution, uint32_t rgbd, uint32_t num_threads,
-    uint8_t *rgb_out, float *depth_out)
+    uint8_t *rgb_out, float *depth_out,
+    // optional (NULL / 0): uv per vertex, material per triangle (for objects
+    // whose object material is -1), texture id per material, RGBA8 textures
+    const float *vertex_uvs, const int32_t *triangle_materials,
+    const int32_t *material_textures, uint32_t num_textures,
+    const uint32_t *texture_dims, const uint8_t *texels)
 {
     static_assert(sizeof(InstanceData) == 64 &&
                   sizeof(PerspectiveCameraData) == 48 && sizeof(LightDesc) == 40);
@@ -228,15 +270,22 @@ int raycast_ref_render(
         for (uint32_t t = 0; t < num_tris; t++) {
             AABB box {};
             for (int k = 0; k < 3; k++) {
-                const float *p = verts + 3 * (size_t)indices[3 * (size_t)(tri_first + t) + k];
+                const uint32_t vi = indices[3 * (size_t)(tri_first + t) + k];
+                const float *p = verts + 3 * (size_t)vi;
                 Vector3 pos { p[0], p[1], p[2] };
-                obj.vertices.push_back({ pos, Vector2 { 0.f, 0.f } });
+                Vector2 uv { 0.f, 0.f };
+                if (vertex_uvs != nullptr) {
+                    const float *q = vertex_uvs + 2 * ((size_t)vertex_offsets[o] + vi);
+                    uv = Vector2 { q[0], q[1] };
+                }
+                obj.vertices.push_back({ pos, uv });
                 // (AABB::expand on AABB::invalid() only ever moves one bound
                 // per axis and point: start from the first vertex)
                 box = k == 0 ? AABB::point(pos) : AABB::merge(box, AABB::point(pos));
             }
             tri_boxes[t] = inflate(box);
-            obj.leafMats.push_back({ { { -1 } } });
+            obj.leafMats.push_back({ { { triangle_materials != nullptr ?
+                triangle_materials[tri_first + t] : -1 } } });
         }
         std::vector<BuildItem> items;
         for (uint32_t t = 0; t < num_tris; t += 2) {
@@ -278,9 +327,21 @@ int raycast_ref_render(
     for (uint32_t m = 0; m < num_materials; m++) {
         materials[m].color = Vector4 { material_colors[3 * m],
             material_colors[3 * m + 1], material_colors[3 * m + 2], 1.f };
-        materials[m].textureIdx = -1;
+        materials[m].textureIdx =
+            material_textures != nullptr ? material_textures[m] : -1;
         materials[m].roughness = 0.f;
         materials[m].metalness = 0.f;
+    }
+    std::vector<ShimTexture> shim_textures(num_textures);
+    std::vector<cudaTextureObject_t> texture_objects(num_textures);
+    {
+        size_t at = 0;
+        for (uint32_t t = 0; t < num_textures; t++) {
+            shim_textures[t] = { texture_dims[2 * t], texture_dims[2 * t + 1],
+                                 texels + at };
+            at += (size_t)texture_dims[2 * t] * texture_dims[2 * t + 1] * 4;
+            texture_objects[t] = (cudaTextureObject_t)(uintptr_t)&shim_textures[t];
+        }
     }
 
     // ---- top level: one tree per world, in the world's slice of the node array --------
@@ -334,7 +395,7 @@ int raycast_ref_render(
     bvhParams.renderOutputResolution = resolution;
     bvhParams.raycastRGBD = rgbd;
     bvhParams.materials = materials.data();
-    bvhParams.textures = nullptr;
+    bvhParams.textures = texture_objects.data();
     bvhParams.nearSphere = 0.f;
 
     // ---- the kernel: one "thread" per pixel, each looping over all views ---------

@@ -15,19 +15,39 @@ struct MeshSet {
     std::vector<uint32_t> vertexOffsets { 0 };      // [objects + 1]
     std::vector<uint32_t> triangleOffsets { 0 };    // [objects + 1]
     std::vector<float> materialColors;              // rgb per material
-    std::vector<int32_t> objectMaterials;           // per object, -1: none
+    std::vector<int32_t> objectMaterials;           // per object, -1: per triangle / none
     std::vector<float> rootAABBs;                   // 6 per object
+    // per-triangle materials and textures (reference MeshBVH::leafMats,
+    // BVHVertex::uv, Material::textureIdx): uvs per vertex (0, 0 unless set with
+    // uv()), one material per triangle (read for objects whose material is -1)
+    std::vector<float> vertexUVs;                   // 2 per vertex
+    std::vector<int32_t> triangleMaterials;         // per triangle
+    std::vector<int32_t> materialTextures;          // per material, -1: none
+    struct Texture {
+        uint32_t width, height;
+        std::vector<uint8_t> rgba8;
+    };
+    std::vector<Texture> textures;
+    int32_t currentTriangleMaterial = -1;           // what tri() tags triangles with
 
     uint32_t numObjects() const { return (uint32_t)triangleOffsets.size() - 1u; }
 
     uint32_t vert(float x, float y, float z)
     {
         vertices.insert(vertices.end(), { x, y, z });
+        vertexUVs.insert(vertexUVs.end(), { 0.f, 0.f });
         return (uint32_t)(vertices.size() / 3) - vertexOffsets.back() - 1u;
+    }
+    // uv of the vertex added last
+    void uv(float u, float v)
+    {
+        vertexUVs[vertexUVs.size() - 2] = u;
+        vertexUVs[vertexUVs.size() - 1] = v;
     }
     void tri(uint32_t a, uint32_t b, uint32_t c)
     {
         indices.insert(indices.end(), { a, b, c });
+        triangleMaterials.push_back(currentTriangleMaterial);
     }
     void quad(uint32_t a, uint32_t b, uint32_t c, uint32_t d)
     {
@@ -51,10 +71,30 @@ struct MeshSet {
         objectMaterials.push_back(material);
     }
 
-    int32_t material(float r, float g, float b)
+    int32_t material(float r, float g, float b, int32_t texture = -1)
     {
         materialColors.insert(materialColors.end(), { r, g, b });
+        materialTextures.push_back(texture);
         return (int32_t)(materialColors.size() / 3) - 1;
+    }
+
+    // a width x height checker of two colours with a gradient over it (so that
+    // neighbouring texels differ and filtering shows)
+    int32_t checkerTexture(uint32_t width, uint32_t height, uint32_t cell)
+    {
+        Texture t { width, height, std::vector<uint8_t>((size_t)width * height * 4) };
+        for (uint32_t y = 0; y < height; y++) {
+            for (uint32_t x = 0; x < width; x++) {
+                const bool on = ((x / cell) + (y / cell)) % 2u == 0u;
+                uint8_t *px = t.rgba8.data() + 4 * ((size_t)y * width + x);
+                px[0] = (uint8_t)(on ? 230 : 40 + (200 * x) / width);
+                px[1] = (uint8_t)(on ? 60 + (150 * y) / height : 220);
+                px[2] = (uint8_t)(on ? 30 : 120);
+                px[3] = 255;
+            }
+        }
+        textures.push_back(std::move(t));
+        return (int32_t)textures.size() - 1;
     }
 
     void box(float x0, float y0, float z0, float x1, float y1, float z1)

@@ -408,6 +408,41 @@ int32_t sim_render_geometry(float *vertices, uint32_t *indices,
     return (int32_t)m->numObjects();
 }
 
+int32_t sim_render_geometry_ex(float *vertex_uvs, int32_t *triangle_materials,
+                               int32_t *material_textures, uint32_t *texture_dims,
+                               uint8_t *texels, uint32_t *counts)
+{
+    const simmesh::MeshSet *m = simmgr::renderMeshes<SimTraits>();
+    if (m == nullptr) {
+        return 0;
+    }
+    auto copy = [](auto *dst, const auto &src) {
+        if (dst != nullptr && !src.empty()) {
+            memcpy(dst, src.data(), src.size() * sizeof(src[0]));
+        }
+    };
+    copy(vertex_uvs, m->vertexUVs);
+    copy(triangle_materials, m->triangleMaterials);
+    copy(material_textures, m->materialTextures);
+    size_t bytes = 0;
+    for (size_t t = 0; t < m->textures.size(); t++) {
+        if (texture_dims != nullptr) {
+            texture_dims[2 * t] = m->textures[t].width;
+            texture_dims[2 * t + 1] = m->textures[t].height;
+        }
+        if (texels != nullptr) {
+            memcpy(texels + bytes, m->textures[t].rgba8.data(),
+                   m->textures[t].rgba8.size());
+        }
+        bytes += m->textures[t].rgba8.size();
+    }
+    if (counts != nullptr) {
+        counts[0] = (uint32_t)m->textures.size();
+        counts[1] = (uint32_t)bytes;
+    }
+    return (int32_t)m->textures.size();
+}
+
 uint64_t sim_hip_render_graph(SimHandle *h)
 {
 #ifdef SIM_BACKEND_REF_CPU

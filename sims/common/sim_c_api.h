@@ -82,6 +82,15 @@ SIM_API int32_t sim_render_geometry(float *vertices, uint32_t *indices,
                                     float *material_colors,
                                     int32_t *object_materials, uint32_t *counts);
 
+/* ... and their per-vertex uvs, per-triangle materials (read for objects whose
+ * object material is -1), per-material texture ids and RGBA8 textures.
+ * texture_dims: width, height per texture; texels: all textures back to back.
+ * counts: { textures, texel bytes }.  Returns the number of textures. */
+SIM_API int32_t sim_render_geometry_ex(float *vertex_uvs, int32_t *triangle_materials,
+                                       int32_t *material_textures,
+                                       uint32_t *texture_dims, uint8_t *texels,
+                                       uint32_t *counts);
+
 /* HIP backend only: the batch ray caster's pass (MWCudaExecutor::
  * buildRenderGraph) over the tables as the last step left them; outputs land in
  * the simulator's "rgb" / "depth" tensors.  sim_hip_render runs it and waits;

@@ -17,7 +17,9 @@ struct SimTraits;
 namespace {
 
 // flags: bit 0 = RenderingSystem::setupTasks(update_visual_properties = true),
-// bit 1 = depth only, bit 2 = crowded worlds,
+// bit 1 = depth only, bit 2 = crowded worlds, bit 3 = the geometry goes to the
+// executor in the reference's asset form (MeshBVHData / MaterialData) instead
+// of as plain triangles,
 // bits 8-15 = ray caster output resolution (HIP backend; 0 = ray caster off)
 constexpr uint32_t kMaxRecordsPerWorld = 128;
 
@@ -35,8 +37,11 @@ const float kRootAABBs[renderprep::consts::numObjects * 6] = {
 
 // Triangle meshes of the four "models", inside those boxes: a cube, an
 // ellipsoid (168 triangles: a bottom-level BVH several levels deep), a flat
-// cylinder and a wedge.  Materials: one per object, the wedge has none; a fifth
-// material is only ever reached through MaterialOverride.
+// cylinder and a wedge.  Materials: one per object for the first three; the
+// wedge's mesh has none of its own (-1): its triangles carry theirs -- a
+// textured one (a checker, sampled at the hit's interpolated uv) on the floor
+// and the slope, a plain one on the sides, none on the back; a fifth material
+// is only ever reached through MaterialOverride, a sixth (textured) too.
 const simmesh::MeshSet &meshes()
 {
     static const simmesh::MeshSet set = [] {
@@ -46,6 +51,11 @@ const simmesh::MeshSet &meshes()
         const int32_t blue = m.material(0.25f, 0.35f, 0.9f);
         m.material(0.9f, 0.8f, 0.1f);
         m.material(0.5f, 0.5f, 0.5f);
+        const int32_t checker = m.checkerTexture(16, 8, 2);
+        const int32_t stripes = m.checkerTexture(5, 7, 1);
+        const int32_t tiled = m.material(1.f, 0.9f, 0.8f, checker);
+        const int32_t plain = m.material(0.3f, 0.8f, 0.8f);
+        m.material(0.7f, 1.f, 0.6f, stripes);
 
         m.box(-0.5f, -0.5f, -0.5f, 0.5f, 0.5f, 0.5f);
         m.endObject(red);
@@ -54,10 +64,22 @@ const simmesh::MeshSet &meshes()
         m.cylinder(0.75f, -0.1f, 0.1f, 16);
         m.endObject(blue);
         // wedge in [0, 1.5] x [0, 1] x [0, 0.5]
-        m.vert(0.f, 0.f, 0.f); m.vert(1.5f, 0.f, 0.f); m.vert(0.f, 1.f, 0.f);
-        m.vert(1.5f, 1.f, 0.f); m.vert(0.f, 0.f, 0.5f); m.vert(0.f, 1.f, 0.5f);
-        m.quad(0, 2, 3, 1); m.quad(0, 4, 5, 2); m.quad(1, 3, 5, 4);
+        // (uvs run past [0, 1]: wrap addressing)
+        m.vert(0.f, 0.f, 0.f); m.uv(0.f, 0.f);
+        m.vert(1.5f, 0.f, 0.f); m.uv(1.5f, 0.f);
+        m.vert(0.f, 1.f, 0.f); m.uv(0.f, 1.f);
+        m.vert(1.5f, 1.f, 0.f); m.uv(1.5f, 1.f);
+        m.vert(0.f, 0.f, 0.5f); m.uv(-0.25f, 0.1f);
+        m.vert(0.f, 1.f, 0.5f); m.uv(-0.25f, 0.9f);
+        m.currentTriangleMaterial = tiled;
+        m.quad(0, 2, 3, 1);         // floor
+        m.currentTriangleMaterial = -1;
+        m.quad(0, 4, 5, 2);         // back
+        m.currentTriangleMaterial = tiled;
+        m.quad(1, 3, 5, 4);         // slope
+        m.currentTriangleMaterial = plain;
         m.tri(0, 1, 4); m.tri(2, 5, 3);
+        m.currentTriangleMaterial = -1;
         m.endObject(-1);
         return m;
     }();
@@ -110,7 +132,13 @@ struct SimTraits {
         if ((args.flags & 2u) != 0u) {
             cfg.renderMode = madrona::CudaBatchRenderConfig::RenderMode::Depth;
         }
-        simmgr::meshesToRenderConfig(meshes(), cfg);
+        if ((args.flags & 8u) != 0u) {
+            // (kept alive with the process: the executor copies what it needs
+            // while it is constructed)
+            simmgr::meshesToReferenceAssets(meshes(), cfg);
+        } else {
+            simmgr::meshesToRenderConfig(meshes(), cfg);
+        }
         return madrona::Optional<madrona::CudaBatchRenderConfig>::make(cfg);
     }
 #endif

@@ -54,9 +54,11 @@ static Entity makeMover(Engine &ctx, RNG &rng)
     ctx.get<Drift>(e).v = Vector3 {
         randInRange(rng, -1.f, 1.f), randInRange(rng, -1.f, 1.f), 0.f,
     };
-    // every third mover overrides its colour, every fifth its material
+    // every third mover overrides its colour, every fifth its material (with
+    // an untextured one, or -- style 10 -- the textured material 7, which then
+    // samples the mover's own uvs: all zero except on the wedge)
     int32_t style = rng.sampleI32(0, 15);
-    ctx.get<MaterialOverride>(e).matID = style % 5 == 0 ? 3 :
+    ctx.get<MaterialOverride>(e).matID = style % 5 == 0 ? (style == 10 ? 7 : 3) :
         (style % 3 == 0 ? (int32_t)MaterialOverride::UseOverrideColor :
                           (int32_t)MaterialOverride::UseDefaultMaterial);
     ctx.get<ColorOverride>(e).color = 0xFF000000u | (uint32_t)(style * 1118481);

@@ -26,7 +26,8 @@ class Geometry:
     object_materials [O] i32 (-1: none), material_colors [M,3] f32"""
 
     def __init__(self, vertices, indices, vertex_offsets, triangle_offsets,
-                 object_materials, material_colors):
+                 object_materials, material_colors, vertex_uvs=None,
+                 triangle_materials=None, material_textures=None, textures=()):
         self.vertices = np.ascontiguousarray(vertices, np.float32).reshape(-1, 3)
         self.indices = np.ascontiguousarray(indices, np.uint32).reshape(-1, 3)
         self.vertex_offsets = np.ascontiguousarray(vertex_offsets, np.uint32)
@@ -34,6 +35,16 @@ class Geometry:
         self.object_materials = np.ascontiguousarray(object_materials, np.int32)
         self.material_colors = np.ascontiguousarray(material_colors, np.float32).reshape(-1, 3)
         self.num_objects = len(self.triangle_offsets) - 1
+        # per-vertex uvs [V,2], per-triangle materials [T] (objects whose material
+        # is -1), texture id per material [M], textures = [(width, height, rgba8
+        # bytes [h,w,4])]
+        self.vertex_uvs = None if vertex_uvs is None else \
+            np.ascontiguousarray(vertex_uvs, np.float32).reshape(-1, 2)
+        self.triangle_materials = None if triangle_materials is None else \
+            np.ascontiguousarray(triangle_materials, np.int32)
+        self.material_textures = None if material_textures is None else \
+            np.ascontiguousarray(material_textures, np.int32)
+        self.textures = list(textures)
 
 
 def cube_geometry():
@@ -52,7 +63,8 @@ def ref_render(geo, num_worlds, instances, inst_offsets, inst_counts, views, lig
     p = C.c_void_p
     lib.raycast_ref_render.argtypes = [C.c_uint32, p, p, p, p, p, C.c_uint32, p,
                                        C.c_uint32, p, p, p, p, C.c_uint32, p, p, p,
-                                       C.c_uint32, C.c_uint32, C.c_uint32, p, p]
+                                       C.c_uint32, C.c_uint32, C.c_uint32, p, p,
+                                       p, p, p, C.c_uint32, p, p]
     instances = np.ascontiguousarray(instances)
     views = np.ascontiguousarray(views)
     lights = np.ascontiguousarray(lights)
@@ -66,6 +78,9 @@ def ref_render(geo, num_worlds, instances, inst_offsets, inst_counts, views, lig
     depth = np.zeros((nv, resolution, resolution), np.float32)
     if lights.size == 0:
         lights = np.zeros(1, LIGHT_DT)
+    tex_dims = np.array([[w, h] for w, h, _ in geo.textures] or [[0, 0]], np.uint32)
+    texels = np.concatenate([np.frombuffer(bytes(px), np.uint8) for _, _, px in geo.textures]
+                            or [np.zeros(4, np.uint8)])
     rc = lib.raycast_ref_render(
         geo.num_objects, geo.vertices.ctypes.data, geo.indices.ctypes.data,
         geo.vertex_offsets.ctypes.data, geo.triangle_offsets.ctypes.data,
@@ -73,7 +88,11 @@ def ref_render(geo, num_worlds, instances, inst_offsets, inst_counts, views, lig
         geo.material_colors.ctypes.data, num_worlds, instances.ctypes.data,
         io.ctypes.data, ic.ctypes.data, views.ctypes.data, nv, lights.ctypes.data,
         lo.ctypes.data, lc.ctypes.data, resolution, 1 if rgbd else 0, threads,
-        rgb.ctypes.data, depth.ctypes.data)
+        rgb.ctypes.data, depth.ctypes.data,
+        None if geo.vertex_uvs is None else geo.vertex_uvs.ctypes.data,
+        None if geo.triangle_materials is None else geo.triangle_materials.ctypes.data,
+        None if geo.material_textures is None else geo.material_textures.ctypes.data,
+        len(geo.textures), tex_dims.ctypes.data, texels.ctypes.data)
     assert rc == 0, f"raycast_ref_render failed: {rc}"
     return rgb, depth
 

@@ -40,7 +40,28 @@ def _sim_geometry(sim):
     omat = np.zeros(n_obj, np.int32)
     f(verts.ctypes.data, idx.ctypes.data, voff.ctypes.data, toff.ctypes.data,
       mats.ctypes.data, omat.ctypes.data, None)
-    return Geometry(verts, idx, voff, toff, omat, mats)
+
+    # uvs, per-triangle materials, textures
+    g = sim.lib.sim_render_geometry_ex
+    g.restype = C.c_int32
+    g.argtypes = [C.c_void_p] * 6
+    tcounts = np.zeros(2, np.uint32)
+    n_tex = g(None, None, None, None, None, tcounts.ctypes.data)
+    uvs = np.zeros((counts[0], 2), np.float32)
+    tri_mats = np.zeros(counts[1], np.int32)
+    mat_tex = np.zeros(max(counts[2], 1), np.int32)
+    dims = np.zeros((max(n_tex, 1), 2), np.uint32)
+    texels = np.zeros(max(int(tcounts[1]), 4), np.uint8)
+    g(uvs.ctypes.data, tri_mats.ctypes.data, mat_tex.ctypes.data, dims.ctypes.data,
+      texels.ctypes.data, None)
+    textures, at = [], 0
+    for t in range(n_tex):
+        w, h = int(dims[t, 0]), int(dims[t, 1])
+        textures.append((w, h, texels[at:at + 4 * w * h].copy()))
+        at += 4 * w * h
+    return Geometry(verts, idx, voff, toff, omat, mats, vertex_uvs=uvs,
+                    triangle_materials=tri_mats,
+                    material_textures=mat_tex[:counts[2]], textures=textures)
 
 
 def _offsets(counts):
@@ -134,6 +155,10 @@ def _compare(hip_rgb, hip_depth, ref_rgb, ref_depth, rgbd, what, flips=0, offs=0
     # crowded worlds, 70 .. 96 instances: more than a workgroup stages in LDS;
     # twelve lights, most of them casting shadows: shadow rays grazing an edge
     (21, 32, 6, 1 | 4, 0, 20),
+    # the geometry handed over in the reference's asset form (MeshBVHData /
+    # MaterialData: quantised 4-wide mesh BVHs, de-indexed vertices, texture
+    # objects) instead of as plain triangles
+    (37, 32, 12, 1 | 8, 0, 2),
     # a resolution that is no multiple of the 16-pixel tiles -- and odd: the
     # centre row's rays have a direction component of exactly 0 and run exactly
     # along the top faces of boxes at the camera's height
@@ -184,6 +209,30 @@ def test_escape_room_views_against_reference(built, worlds, res, shadows):
             ref_rgb, ref_depth = _reference_images(geo, worlds, d, res, True)
             _compare(hip.read_tensor("rgb"), hip.read_tensor("depth"), ref_rgb, ref_depth,
                      True, ("escape_room", worlds, step))
+
+
+def test_reference_asset_form_gives_the_same_image(built):
+    """CudaBatchRenderConfig::geoBVHData / materialData in the reference's own
+    layout (render/cuda_batch_render_assets.hpp:8-28) and the same meshes as plain
+    triangles: identical bytes (the executor builds the same bottom-level trees
+    from the leaves it reads), and the textured, two-material wedge is in view."""
+    worlds, res = 24, 48
+    images = []
+    for form in (0, 8):
+        with Simulator(hip_lib_path("render_prep"), worlds, seed=6,
+                       flags=1 | form | (res << 8)) as hip:
+            hip.step(4)
+            hip.render()
+            images.append((hip.read_tensor("rgb").copy(), hip.read_tensor("depth").copy(),
+                           hip.dump_all()["Renderable.InstanceData"][0].copy()))
+    assert np.array_equal(images[0][0], images[1][0])
+    assert np.array_equal(images[0][1].view(np.uint32), images[1][1].view(np.uint32))
+    # wedges (object 3) without a material override are drawn, and textured:
+    # more distinct colours than the handful of flat materials could give
+    inst = images[0][2].view(np.uint32).reshape(-1, 16)
+    assert ((inst[:, 11] == 3) & (inst[:, 10].view(np.int32) == -1)).any()
+    colours = np.unique(images[0][0].reshape(-1, 4), axis=0)
+    assert len(colours) > 300, len(colours)
 
 
 def test_raycast_is_repeatable_and_follows_the_tables(built):
