@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MWHIP_ABI_VERSION 2u
+#define MWHIP_ABI_VERSION 3u   /* 3: mwhip_render_geometry grew (uvs, per-triangle materials, textures) */
 
 typedef struct mwhip_exec mwhip_exec; /* opaque; == MWCudaExecutor::Impl */
 

@@ -16,7 +16,11 @@ class RenderGeometry(C.Structure):
                 ("vertices", C.c_void_p), ("indices", C.c_void_p),
                 ("object_vertex_offset", C.c_void_p),
                 ("object_triangle_offset", C.c_void_p),
-                ("object_material", C.c_void_p), ("material_color", C.c_void_p)]
+                ("object_material", C.c_void_p), ("material_color", C.c_void_p),
+                # per-triangle materials and textures (optional: NULL / 0)
+                ("vertex_uv", C.c_void_p), ("triangle_material", C.c_void_p),
+                ("material_texture", C.c_void_p), ("num_textures", C.c_uint32),
+                ("pad_", C.c_uint32), ("textures", C.c_void_p)]
 
 
 def _info(objects):
@@ -26,7 +30,8 @@ def _info(objects):
     voff = np.cumsum([0] + [len(np.asarray(v).reshape(-1, 3)) for v, _ in objects]).astype(np.uint32)
     toff = np.cumsum([0] + [len(np.asarray(t).reshape(-1, 3)) for _, t in objects]).astype(np.uint32)
     g = RenderGeometry(len(objects), 0, verts.ctypes.data, tris.ctypes.data,
-                       voff.ctypes.data, toff.ctypes.data, None, None)
+                       voff.ctypes.data, toff.ctypes.data, None, None,
+                       None, None, None, 0, 0, None)
     rt = runtime_lib()
     rt.mwhip_render_geometry_info.restype = C.c_int
     rt.mwhip_render_geometry_info.argtypes = [C.POINTER(RenderGeometry), C.c_void_p,
