@@ -65,6 +65,39 @@ public:
         state_mgr_->destroyEntityNow(world_id_, e, exclusive_world_);
     }
 
+    // ---- this backend, systems that run 64 lanes per invocation
+    // (CustomParallelForNode<..., 64, 1, ...> under MADRONA_GPU_MODE): all 64
+    // lanes call together; the effect -- entity ids, generations, row order --
+    // is that of the lanes with `want` calling makeEntity / destroyEntity one
+    // after the other in lane order (state.hpp) ----
+    template <typename ArchetypeT>
+    MADRONA_HD inline Entity makeEntityOrdered(bool want)
+    {
+        return makeEntityOrdered(TypeTracker::typeID<ArchetypeT>(), want);
+    }
+
+    // (lanes may ask for different archetypes: ids still go out in lane order)
+    MADRONA_HD inline Entity makeEntityOrdered(uint32_t archetype_id, bool want)
+    {
+        Loc loc { 0, 0 };
+        Entity e = state_mgr_->makeEntityOrdered(world_id_, archetype_id, want,
+                                                 exclusive_world_, &loc);
+        if (want) {
+            cached_id_ = e.id;
+            cached_gen_ = e.gen;
+            cached_loc_ = loc;
+        }
+        return e;
+    }
+
+    MADRONA_HD inline void destroyEntityOrdered(Entity e, bool want)
+    {
+        if (want && e.id == cached_id_) {
+            cached_id_ = -1;
+        }
+        state_mgr_->destroyEntityOrdered(world_id_, e, want, exclusive_world_);
+    }
+
     MADRONA_HD inline Loc loc(Entity e) const
     {
         return state_mgr_->getLoc(e);

@@ -124,6 +124,20 @@ public:
     MADRONA_HD Loc makeTemporary(WorldID world_id, uint32_t archetype_id);
     MADRONA_HD void destroyEntityNow(WorldID caller_world, Entity e,
                                      bool exclusive = false);
+
+    // ---- wave-cooperative creation / destruction (this backend, device only;
+    // CustomParallelForNode<..., 64, 1> systems) ------------------------------
+    // All 64 lanes of the invocation's wavefront call together.  The effect is
+    // that of the lanes with `want` set calling makeEntityNow / destroyEntityNow
+    // one after the other in lane order -- same entity ids and generations (ids
+    // are popped from / pushed onto the world's id cache in that order), rows in
+    // lane order -- at the latency of one such call: rows come from one atomic,
+    // a single lane walks the id free list, everything else is per lane.
+    // destroy: the wanted entities must be distinct.
+    MADRONA_HD Entity makeEntityOrdered(WorldID world_id, uint32_t archetype_id,
+                                        bool want, bool exclusive, Loc *loc_out);
+    MADRONA_HD void destroyEntityOrdered(WorldID caller_world, Entity e, bool want,
+                                         bool exclusive);
     MADRONA_HD void clearTemporaries(uint32_t archetype_id);
 
     template <typename ArchetypeT, typename ComponentT>

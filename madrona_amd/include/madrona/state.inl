@@ -440,6 +440,170 @@ MADRONA_HD inline void StateManager::destroyEntityNow(WorldID caller_world, Enti
 #endif
 }
 
+MADRONA_HD inline Entity StateManager::makeEntityOrdered(
+    WorldID world_id, uint32_t archetype_id, bool want, bool exclusive,
+    Loc *loc_out)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ int32_t ordered_ids[64];
+    __shared__ uint32_t ordered_gens[64];
+
+    const uint64_t mask = __builtin_amdgcn_ballot_w64(want);
+    if (mask == 0) {
+        return Entity::none();
+    }
+    const uint32_t lane =
+        __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const uint32_t count = (uint32_t)__builtin_popcountll(mask);
+    const uint32_t rank =
+        (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+    const uint32_t leader = (uint32_t)__builtin_ctzll(mask);
+
+    if (lane == leader) {
+        // the ids the sequential calls would have taken, in their order; the
+        // cache lives in registers while the list is walked (one dependent
+        // read per id: the popped slot names the next head)
+        auto take = [&](mwhip::IdCache &cache) {
+            mwhip::IdCache local = cache;
+            for (uint32_t k = 0; k < count; k++) {
+                uint32_t gen = 0;
+                ordered_ids[k] =
+                    mwhip::acquireIdLocked(this, world_id.idx, local, &gen);
+                ordered_gens[k] = gen;
+            }
+            local.lock = cache.lock;
+            cache = local;
+        };
+        if (exclusive) {
+            take(mwhip::worldCachesOf(this)[world_id.idx]);
+        } else {
+            mwhip::withWorldCache(this, world_id.idx, take);
+        }
+    }
+
+    // rows: one atomic per archetype among the wanted lanes (they may ask for
+    // different ones), a table's rows in lane order
+    int32_t my_row = 0;
+    for (uint64_t remaining = mask; remaining != 0; ) {
+        const uint32_t first_lane = (uint32_t)__builtin_ctzll(remaining);
+        const uint32_t arch = (uint32_t)__shfl((int)archetype_id, (int)first_lane, 64);
+        const uint64_t same =
+            __builtin_amdgcn_ballot_w64(want && archetype_id == arch);
+        int32_t first_row = 0;
+        if (lane == first_lane) {
+            mwhip::TableHdr &shared_tbl = mwhip::tablesOf(this)[arch];
+            mwhip::markRowAppender();
+            shared_tbl.needsSort = 1u;
+            first_row = mwhip::atomicAddI32(&shared_tbl.numRows,
+                                            (int32_t)__builtin_popcountll(same));
+        }
+        first_row = __shfl(first_row, (int)first_lane, 64);
+        if (want && archetype_id == arch) {
+            my_row = first_row +
+                (int32_t)__builtin_popcountll(same & ((1ull << lane) - 1ull));
+        }
+        remaining &= ~same;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+    Entity e = Entity::none();
+    if (want) {
+        mwhip::TableHdr &tbl = mwhip::tablesOf(this)[archetype_id];
+        const int32_t row = mwhip::appendRowCheck(this, tbl, my_row);
+        const int32_t id = ordered_ids[rank];
+        const uint32_t gen = ordered_gens[rank];
+
+        mwhip::EntitySlot &slot = mwhip::entitiesOf(this)[id];
+        slot.loc.archetype = archetype_id;
+        slot.loc.row = row;
+
+        e = Entity { gen, id };
+        ((Entity *)mwhip::columnOf(tbl, 0))[row] = e;
+        ((WorldID *)mwhip::columnOf(tbl, 1))[row] = world_id;
+        if (loc_out != nullptr) {
+            *loc_out = Loc { archetype_id, row };
+        }
+    }
+    // (the next ordered call reuses the two arrays)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return e;
+#else
+    (void)world_id; (void)archetype_id; (void)want; (void)exclusive; (void)loc_out;
+    mwhip::hostOnlyAbort("makeEntityOrdered"); return Entity::none();
+#endif
+}
+
+MADRONA_HD inline void StateManager::destroyEntityOrdered(
+    WorldID caller_world, Entity e, bool want, bool exclusive)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ int32_t ordered_ids[64];
+    __shared__ uint32_t ordered_gens[64];
+
+    // every lane looks at its own entity (stale handles are ignored, as in
+    // destroyEntityNow) and tags its row -- before any id goes back: a free
+    // slot's links overwrite the location
+    bool valid = false;
+    uint32_t slot_gen = 0;
+    if (want && e.id >= 0) {
+        const mwhip::EntitySlot &slot = mwhip::entitiesOf(this)[e.id];
+        slot_gen = slot.gen;
+        const Loc loc { slot.loc.archetype, slot.loc.row };
+        if (slot_gen == e.gen) {
+            valid = true;
+            mwhip::TableHdr &tbl = mwhip::tablesOf(this)[loc.archetype];
+            ((Entity *)mwhip::columnOf(tbl, 0))[loc.row] = Entity::none();
+            ((WorldID *)mwhip::columnOf(tbl, 1))[loc.row] = WorldID { -1 };
+            tbl.needsSort = 1u;
+        }
+    }
+
+    const uint64_t mask = __builtin_amdgcn_ballot_w64(valid);
+    if (mask == 0) {
+        return;
+    }
+    const uint32_t lane =
+        __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const uint32_t count = (uint32_t)__builtin_popcountll(mask);
+    const uint32_t rank =
+        (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+    if (valid) {
+        ordered_ids[rank] = e.id;
+        ordered_gens[rank] = slot_gen;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+    if (lane == (uint32_t)__builtin_ctzll(mask)) {
+        // back onto the world's free list in lane order (stores only)
+        auto give = [&](mwhip::IdCache &cache) {
+            mwhip::IdCache local = cache;
+            for (uint32_t k = 0; k < count; k++) {
+                mwhip::releaseIdLocked(this, local, ordered_ids[k], ordered_gens[k]);
+            }
+            local.lock = cache.lock;
+            cache = local;
+        };
+        if (exclusive) {
+            give(mwhip::worldCachesOf(this)[caller_world.idx]);
+        } else {
+            mwhip::withWorldCache(this, caller_world.idx, give);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#else
+    (void)caller_world; (void)e; (void)want; (void)exclusive;
+    mwhip::hostOnlyAbort("destroyEntityOrdered");
+#endif
+}
+
 MADRONA_HD inline void StateManager::clearTemporaries(uint32_t archetype_id)
 {
     mwhip::TableHdr &tbl = tables[archetype_id];

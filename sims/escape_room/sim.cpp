@@ -1,5 +1,7 @@
 #include "sim.hpp"
 
+#include <cstring>
+
 #ifdef MADRONA_GPU_MODE
 #include <madrona/mw_gpu_entry.hpp>
 #endif
@@ -468,6 +470,188 @@ inline void stepTrackerSystem(Engine &,
     }
 }
 
+#ifdef MADRONA_GPU_MODE
+// The reset of a world on the GPU backends: the reset system runs 64 lanes per
+// world (CustomParallelForNode<..., 64, 1>, the reference simulators' way of
+// spreading heavy per-world work over a warp) and lane i destroys / creates /
+// fills in entity i, instead of one lane doing 27 of each in sequence.  What
+// comes out is what cleanupWorld() + initWorld() above leave: the same entities
+// with the same ids (Context::destroyEntityOrdered / makeEntityOrdered hand ids
+// back and out in lane order = the order of the loops above), the same rows in
+// the same order, and the same random numbers -- the RNG is counter based,
+// sample i of an episode is split_i(episode key, i), and the loops above draw a
+// fixed number per entity, so every lane computes the indices of its own draws:
+//   agent a:   3 a + { 0: x, 1: y, 2: heading }
+//   room r:    base = 3 numAgents + r * (2 numButtons + 3 + 5 numCubes)
+//     button b:  base + 2 b + { 0: x, 1: y }
+//     door:      base + 2 numButtons + { 0: x, 1: numButtons, 2: isPersistent }
+//     cube c:    base + 2 numButtons + 3 + 5 c + { 0: x, 1: y, 2: vx, 3: vy, 4: wz }
+static inline void resetWorldWave(Engine &ctx)
+{
+    Sim &sim = ctx.data();
+    LevelState &level = ctx.singleton<LevelState>();
+
+    constexpr int32_t per_room = consts::numButtonsPerRoom + 1 + consts::numCubesPerRoom;
+    constexpr int32_t num_level = consts::numRooms * per_room;
+    constexpr uint32_t draws_per_room =
+        2u * consts::numButtonsPerRoom + 3u + 5u * consts::numCubesPerRoom;
+    constexpr uint32_t num_draws = 3u * consts::numAgents +
+        (uint32_t)consts::numRooms * draws_per_room;
+    static_assert(num_level + consts::numAgents <= 64);
+
+    const int32_t lane = (int32_t)(threadIdx.x % 64);
+    const int32_t r = lane / per_room;
+    const int32_t k = lane % per_room;
+    const bool in_level = lane < num_level;
+
+    // ---- cleanupWorld(): per room the cubes, the door, the buttons ----
+    {
+        Entity e = Entity::none();
+        if (in_level) {
+            const Room &room = level.rooms[r];
+            e = k < consts::numCubesPerRoom ? room.cubes[k] :
+                (k == consts::numCubesPerRoom ? room.door :
+                 room.buttons[k - consts::numCubesPerRoom - 1]);
+        }
+        ctx.destroyEntityOrdered(e, in_level);
+    }
+
+    // ---- initWorld() ----
+    const RandKey episode = rand::split_i(sim.initRandKey, sim.curWorldEpisode);
+    auto key = [&](uint32_t i) { return rand::split_i(episode, i); };
+    auto in_range = [&](uint32_t i, float lo, float hi) {
+        return lo + rand::sampleUniform(key(i)) * (hi - lo);
+    };
+    const float half_width = consts::worldWidth / 2.f;
+
+    // resetAgents(): one lane per agent, behind the level's lanes
+    if (lane >= num_level && lane < num_level + consts::numAgents) {
+        const int32_t i = lane - num_level;
+        const uint32_t base = 3u * (uint32_t)i;
+        Entity agent = sim.agents[i];
+
+        Vector3 pos {
+            in_range(base, -half_width + 2.f, half_width - 2.f),
+            in_range(base + 1u, 1.5f, 3.f),
+            0.f,
+        };
+        int32_t heading = rand::sampleI32(key(base + 2u), 0, 8);
+        float c = kMoveCos[heading];
+        float sn = kMoveSin[heading];
+        float ch = sqrtf((1.f + c) * 0.5f);
+        float sh = sqrtf((1.f - c) * 0.5f);
+        if (sn < 0.f) sh = -sh;
+        Quat rot = Quat { ch, 0.f, 0.f, sh }.normalize();
+
+        ctx.get<Position>(agent) = pos;
+        ctx.get<Rotation>(agent) = rot;
+        ctx.get<Velocity>(agent) = Velocity { Vector3::zero(), Vector3::zero() };
+        ctx.get<ExternalForce>(agent) = Vector3::zero();
+        ctx.get<ExternalTorque>(agent) = Vector3::zero();
+        ctx.get<SubstepPrevState>(agent) = SubstepPrevState { pos, rot };
+        ctx.get<PreSolvePositional>(agent) = PreSolvePositional { pos, rot };
+        ctx.get<PreSolveVelocity>(agent) =
+            PreSolveVelocity { Vector3::zero(), Vector3::zero() };
+        ctx.get<Action>(agent) = Action { 0, 0, 0, 0 };
+        ctx.get<Progress>(agent).maxY = pos.y;
+        ctx.get<StepsRemaining>(agent).t = consts::episodeLen;
+        ctx.get<GrabState>(agent).constraintEntity = Entity::none();
+        ctx.get<Reward>(agent).v = 0.f;
+        ctx.get<Done>(agent).v = 0;
+    }
+
+    // generateLevel(): per room the buttons, the door, the cubes -- in that
+    // order, which is the order ids are handed out in
+    const bool is_button = in_level && k < consts::numButtonsPerRoom;
+    const bool is_door = in_level && k == consts::numButtonsPerRoom;
+    const bool is_cube = in_level && k > consts::numButtonsPerRoom;
+    const uint32_t archetype = is_button ? TypeTracker::typeID<ButtonEntity>() :
+        (is_door ? TypeTracker::typeID<DoorEntity>() :
+                   TypeTracker::typeID<PhysicsEntity>());
+    const Entity e = ctx.makeEntityOrdered(archetype, in_level);
+
+    // (the door wants its room's buttons)
+    Entity room_buttons[consts::numButtonsPerRoom];
+    for (int32_t b = 0; b < consts::numButtonsPerRoom; b++) {
+        const int32_t src = (r < consts::numRooms ? r : 0) * per_room + b;
+        room_buttons[b].gen = (uint32_t)__shfl((int)e.gen, src, 64);
+        room_buttons[b].id = __shfl(e.id, src, 64);
+    }
+
+    if (in_level) {
+        Room &room = level.rooms[r];
+        const float y_min = (float)r * consts::roomLength;
+        const float y_max = y_min + consts::roomLength;
+        const uint32_t base =
+            3u * consts::numAgents + (uint32_t)r * draws_per_room;
+
+        if (is_button) {
+            const uint32_t at = base + 2u * (uint32_t)k;
+            Vector3 pos {
+                in_range(at, -half_width + 2.f, half_width - 2.f),
+                in_range(at + 1u, y_min + 2.f, y_max - 3.f),
+                0.f,
+            };
+            ctx.get<Position>(e) = pos;
+            ctx.get<Rotation>(e) = Quat::id();
+            ctx.get<Scale>(e) = Diag3x3 {
+                consts::buttonWidth, consts::buttonWidth, 0.2f,
+            };
+            ctx.get<ObjectID>(e) = ObjectID { (int32_t)SimObject::Button };
+            ctx.get<ButtonState>(e).isPressed = 0;
+            ctx.get<EntityType>(e) = EntityType::Button;
+            room.buttons[k] = e;
+        } else if (is_door) {
+            const uint32_t at = base + 2u * consts::numButtonsPerRoom;
+            setupRigidBody<DoorEntity>(ctx, e,
+                Vector3 { in_range(at, -half_width + 3.f, half_width - 3.f),
+                          y_max, 0.f },
+                Quat::id(), SimObject::Door, EntityType::Door,
+                ResponseType::Static, Diag3x3 { 3.f * 0.8f, 1.f, 1.75f });
+            ctx.get<OpenState>(e).isOpen = 0;
+            DoorProperties &props = ctx.get<DoorProperties>(e);
+            for (int32_t b = 0; b < 4; b++) {
+                props.buttons[b] = b < consts::numButtonsPerRoom ?
+                    room_buttons[b] : Entity::none();
+            }
+            props.numButtons = 1 + rand::sampleI32(key(at + 1u), 0,
+                                                   consts::numButtonsPerRoom);
+            props.isPersistent = rand::sampleBool(key(at + 2u)) ? 1 : 0;
+            room.door = e;
+        } else {
+            const int32_t c = k - consts::numButtonsPerRoom - 1;
+            const uint32_t at =
+                base + 2u * consts::numButtonsPerRoom + 3u + 5u * (uint32_t)c;
+            Vector3 pos {
+                in_range(at, -half_width + 1.5f, half_width - 1.5f),
+                in_range(at + 1u, y_min + 1.5f, y_max - 2.5f),
+                0.75f,
+            };
+            setupRigidBody<PhysicsEntity>(ctx, e, pos, Quat::id(),
+                SimObject::Cube, EntityType::Cube, ResponseType::Dynamic,
+                Diag3x3 { 1.5f, 1.5f, 1.5f });
+            ctx.get<Velocity>(e).linear = Vector3 {
+                in_range(at + 2u, -1.f, 1.f), in_range(at + 3u, -1.f, 1.f), 0.f,
+            };
+            ctx.get<Velocity>(e).angular = Vector3 {
+                0.f, 0.f, in_range(at + 4u, -0.5f, 0.5f),
+            };
+            room.cubes[c] = e;
+        }
+    }
+
+    if (lane == 0) {
+        // what `sim.rng = rng` leaves after the sequential draws: the episode's
+        // stream, advanced past them (RNG = { key, samples drawn })
+        struct RNGState { RandKey k; uint32_t count; };
+        static_assert(sizeof(RNGState) == sizeof(RNG));
+        RNGState state { episode, num_draws };
+        memcpy(&sim.rng, &state, sizeof(RNG));
+        sim.curWorldEpisode += 1;
+    }
+}
+#endif
+
 inline void resetSystem(Engine &ctx, WorldReset &reset)
 {
     Sim &sim = ctx.data();
@@ -480,6 +664,25 @@ inline void resetSystem(Engine &ctx, WorldReset &reset)
         }
     }
 
+#ifdef MADRONA_GPU_MODE
+    // 64 lanes per world: lane 0 advances the reset stream, everybody learns
+    // the outcome
+    int32_t auto_reset = 0;
+    if (sim.autoResetDenom != 0 && threadIdx.x % 64 == 0) {
+        auto_reset =
+            sim.resetRng.sampleI32(0, (int32_t)sim.autoResetDenom) == 0 ? 1 : 0;
+    }
+    if (__shfl(auto_reset, 0, 64) != 0) {
+        should_reset = 1;
+    }
+
+    if (should_reset != 0) {
+        if (threadIdx.x % 64 == 0) {
+            reset.reset = 0;
+        }
+        resetWorldWave(ctx);
+    }
+#else
     if (sim.autoResetDenom != 0) {
         if (sim.resetRng.sampleI32(0, (int32_t)sim.autoResetDenom) == 0) {
             should_reset = 1;
@@ -491,6 +694,7 @@ inline void resetSystem(Engine &ctx, WorldReset &reset)
         cleanupWorld(ctx);
         initWorld(ctx);
     }
+#endif
 }
 
 inline void collectObservationsSystem(Engine &ctx,
@@ -675,8 +879,14 @@ void Sim::setupTasks(TaskGraphManager &taskgraph_mgr, const Config &)
             Done
         >>({reward_sys});
 
+#ifdef MADRONA_GPU_MODE
+    // 64 lanes per world: lane i resets entity i (resetWorldWave)
+    auto reset_sys = builder.addToGraph<CustomParallelForNode<Engine,
+        resetSystem, 64, 1,
+#else
     auto reset_sys = builder.addToGraph<ParallelForNode<Engine,
         resetSystem,
+#endif
             WorldReset
         >>({done_sys});
 
