@@ -82,6 +82,18 @@ public:
                           float leaf_accel_expansion);
 
     MADRONA_HD inline LeafID reserveLeaf(Entity e, base::ObjectID obj_id);
+
+    // (this backend: reset systems that run 64 lanes per world) the leaf a
+    // sequence of reserveLeaf calls would have given its idx-th caller, taken
+    // by the lanes in parallel; one lane then sets the count
+    MADRONA_HD inline LeafID reserveLeafAt(int32_t idx, Entity e,
+                                           base::ObjectID obj_id)
+    {
+        leaf_entities_[idx] = e;
+        leaf_obj_ids_[idx] = obj_id;
+        return LeafID { idx };
+    }
+    MADRONA_HD inline void setNumLeaves(int32_t n) { num_leaves_ = n; }
     MADRONA_HD inline math::AABB getLeafAABB(LeafID leaf_id) const
     {
         return leaf_aabbs_[leaf_id.id];

@@ -1,5 +1,7 @@
 #include "sim.hpp"
 
+#include <cstring>
+
 #ifdef MADRONA_GPU_MODE
 #include <madrona/mw_gpu_entry.hpp>
 #endif
@@ -558,6 +560,284 @@ inline void stepTrackerSystem(Engine &,
     }
 }
 
+#ifdef MADRONA_GPU_MODE
+// The reset of a world on the GPU backends: 64 lanes per world
+// (CustomParallelForNode<..., 64, 1>), lane i destroys / creates / fills in
+// entity i instead of one lane doing all of them in sequence.  What comes out is
+// what cleanupWorld() + initWorld() above leave, bit for bit:
+//   * entity ids: Context::destroyEntityOrdered / makeEntityOrdered hand ids
+//     back and out in lane order, and the lanes are laid out in the order of
+//     the loops above (render variant: every body is followed by its render
+//     entity, as makeEntityRenderable creates it inside setupRigidBody);
+//   * rows: a table's rows in lane order;
+//   * BVH leaves: initWorld() registers floor, borders, agents, then per room
+//     walls, door, cubes -- leaf = position in that sequence (reserveLeafAt);
+//   * random numbers: sample i of an episode is split_i(episode key, i) and the
+//     loops draw a fixed number per entity:
+//       agent a:  3 a + { x, y, heading }
+//       room r:   base = 3 numAgents + r * (2 numButtons + 3 + 2 numCubes)
+//         button b: base + 2 b + { x, y };  door gap: base + 2 numButtons;
+//         door: ... + 1 numButtons, + 2 isPersistent;  cube c: ... + 3 + 2 c + { x, y }
+static inline void resetWorldWave(Engine &ctx)
+{
+    Sim &sim = ctx.data();
+    LevelState &level = ctx.singleton<LevelState>();
+    broadphase::BVH &bvh = ctx.singleton<broadphase::BVH>();
+
+#ifdef ESCPHYS_RENDER
+    constexpr int32_t stride = 2;       // body, its render entity, body, ...
+#else
+    constexpr int32_t stride = 1;
+#endif
+    constexpr int32_t per_room =
+        consts::numButtonsPerRoom + 2 + 1 + consts::numCubesPerRoom;
+    constexpr int32_t num_bodies = consts::numRooms * per_room;
+    constexpr int32_t num_persistent = 1 + consts::numBorderWalls + consts::numAgents;
+    constexpr int32_t leaves_per_room = 2 + 1 + consts::numCubesPerRoom;
+    constexpr uint32_t draws_per_room =
+        2u * consts::numButtonsPerRoom + 3u + 2u * consts::numCubesPerRoom;
+    constexpr uint32_t num_draws = 3u * consts::numAgents +
+        (uint32_t)consts::numRooms * draws_per_room;
+    static_assert(num_bodies * stride <= 64 && num_persistent <= 64 &&
+                  2 + num_bodies * stride <= 64);
+
+    const int32_t lane = (int32_t)(threadIdx.x % 64);
+
+    // ---- cleanupWorld() ----
+    // the agents' grab joints first
+    {
+        Entity joint = Entity::none();
+        if (lane < consts::numAgents) {
+            GrabState &grab = ctx.get<GrabState>(sim.agents[lane]);
+            joint = grab.constraintEntity;
+            grab.constraintEntity = Entity::none();
+        }
+        ctx.destroyEntityOrdered(joint, joint != Entity::none());
+    }
+    // then per room: (render variant: the render entities of) cubes, walls,
+    // door, buttons; then those bodies themselves
+    {
+        constexpr int32_t group = per_room * stride;
+        const int32_t r = lane / group;
+        const int32_t in_room = lane % group;
+        const int32_t g = in_room % per_room;
+        const bool want = lane < consts::numRooms * group;
+        Entity e = Entity::none();
+        if (want) {
+            const Room &room = level.rooms[r];
+            e = g < consts::numCubesPerRoom ? room.cubes[g] :
+                (g < consts::numCubesPerRoom + 2 ? room.walls[g - consts::numCubesPerRoom] :
+                 (g == consts::numCubesPerRoom + 2 ? room.door :
+                  room.buttons[g - consts::numCubesPerRoom - 3]));
+#ifdef ESCPHYS_RENDER
+            if (in_room < per_room) {
+                e = ctx.get<render::Renderable>(e).renderEntity;
+            }
+#endif
+        }
+        ctx.destroyEntityOrdered(e, want);
+    }
+
+    // ---- initWorld() ----
+    if (lane == 0) {
+        // every body re-registers with an emptied BVH
+        PhysicsSystem::reset(ctx);
+        bvh.setNumLeaves(num_persistent + consts::numRooms * leaves_per_room);
+    }
+
+    const RandKey episode = rand::split_i(sim.initRandKey, sim.curWorldEpisode);
+    auto key = [&](uint32_t i) { return rand::split_i(episode, i); };
+    auto in_range = [&](uint32_t i, float lo, float hi) {
+        return lo + rand::sampleUniform(key(i)) * (hi - lo);
+    };
+    const float half_width = consts::worldWidth / 2.f;
+
+    // resetPersistentEntities(): floor, borders, agents re-register (leaves 0 ..),
+    // the agents get a new pose
+    if (lane < num_persistent) {
+        const Entity e = lane == 0 ? sim.floorPlane :
+            (lane <= consts::numBorderWalls ? sim.borders[lane - 1] :
+             sim.agents[lane - 1 - consts::numBorderWalls]);
+        ctx.get<broadphase::LeafID>(e) =
+            bvh.reserveLeafAt(lane, e, ctx.get<ObjectID>(e));
+
+        if (lane > consts::numBorderWalls) {
+            const int32_t i = lane - 1 - consts::numBorderWalls;
+            const uint32_t base = 3u * (uint32_t)i;
+            Entity agent = e;
+
+            float x_lo = i == 0 ? -half_width + 2.f : 1.5f;
+            float x_hi = i == 0 ? -1.5f : half_width - 2.f;
+            Vector3 pos {
+                in_range(base, x_lo, x_hi),
+                in_range(base + 1u, 1.5f, 3.f),
+                1.f,
+            };
+            int32_t heading = rand::sampleI32(key(base + 2u), 0, 8);
+            float c = kMoveCos[heading];
+            float sn = kMoveSin[heading];
+            float ch = sqrtf((1.f + c) * 0.5f);
+            float sh = sqrtf((1.f - c) * 0.5f);
+            if (sn < 0.f) sh = -sh;
+            Quat rot = Quat { ch, 0.f, 0.f, sh }.normalize();
+
+            ctx.get<Position>(agent) = pos;
+            ctx.get<Rotation>(agent) = rot;
+            ctx.get<Velocity>(agent) = Velocity { Vector3::zero(), Vector3::zero() };
+            ctx.get<ExternalForce>(agent) = Vector3::zero();
+            ctx.get<ExternalTorque>(agent) = Vector3::zero();
+            ctx.get<Action>(agent) = Action { 0, 0, 0, 0 };
+            ctx.get<Progress>(agent).maxY = pos.y;
+            ctx.get<StepsRemaining>(agent).t = consts::episodeLen;
+            ctx.get<GrabState>(agent).constraintEntity = Entity::none();
+            ctx.get<Reward>(agent).v = 0.f;
+            ctx.get<Done>(agent).v = 0;
+        }
+    }
+
+    // generateLevel(): per room buttons, walls, door, cubes
+    const int32_t body = lane / stride;
+    const bool on_level = body < num_bodies;
+    const bool is_render = stride == 2 && (lane & 1) != 0;
+    const int32_t r = body / per_room;
+    const int32_t k = body % per_room;
+    const bool is_button = k < consts::numButtonsPerRoom;
+    const bool is_wall = !is_button && k < consts::numButtonsPerRoom + 2;
+    const bool is_door = k == consts::numButtonsPerRoom + 2;
+
+    uint32_t archetype = is_button ? TypeTracker::typeID<ButtonEntity>() :
+        (is_door ? TypeTracker::typeID<DoorEntity>() :
+                   TypeTracker::typeID<PhysicsEntity>());
+#ifdef ESCPHYS_RENDER
+    if (is_render) {
+        archetype = TypeTracker::typeID<render::RenderableArchetype>();
+    }
+#endif
+    const Entity e = ctx.makeEntityOrdered(archetype, on_level);
+
+    // (the door wants its room's buttons, a body its render entity)
+    Entity room_buttons[consts::numButtonsPerRoom];
+    for (int32_t b = 0; b < consts::numButtonsPerRoom; b++) {
+        const int32_t src = ((on_level ? r : 0) * per_room + b) * stride;
+        room_buttons[b].gen = (uint32_t)__shfl((int)e.gen, src, 64);
+        room_buttons[b].id = __shfl(e.id, src, 64);
+    }
+    Entity render_entity;
+    render_entity.gen = (uint32_t)__shfl((int)e.gen, (lane + 1) & 63, 64);
+    render_entity.id = __shfl(e.id, (lane + 1) & 63, 64);
+    (void)render_entity;
+
+    if (on_level && is_render) {
+#ifdef ESCPHYS_RENDER
+        // (RenderingSystem::makeEntityRenderable's part on the render entity)
+        render::InstanceData &inst = ctx.get<render::InstanceData>(e);
+        inst.matID = render::MaterialOverride::UseDefaultMaterial;
+        inst.color = 0;
+#endif
+    } else if (on_level) {
+        Room &room = level.rooms[r];
+        const float y_min = (float)r * consts::roomLength;
+        const float y_max = y_min + consts::roomLength;
+        const uint32_t base =
+            3u * consts::numAgents + (uint32_t)r * draws_per_room;
+        const float door_x = in_range(base + 2u * consts::numButtonsPerRoom,
+                                      -half_width + 4.f, half_width - 4.f);
+        const int32_t first_leaf = num_persistent + r * leaves_per_room;
+
+        // setupRigidBody() with the leaf this body has in the sequence
+        auto fill_body = [&](Vector3 pos, SimObject obj, EntityType type,
+                             ResponseType response, Diag3x3 scale, int32_t leaf) {
+            ObjectID obj_id { (int32_t)obj };
+            ctx.get<Position>(e) = pos;
+            ctx.get<Rotation>(e) = Quat { 1, 0, 0, 0 };
+            ctx.get<Scale>(e) = scale;
+            ctx.get<ObjectID>(e) = obj_id;
+            ctx.get<ResponseType>(e) = response;
+            ctx.get<Velocity>(e) = Velocity { Vector3::zero(), Vector3::zero() };
+            ctx.get<ExternalForce>(e) = Vector3::zero();
+            ctx.get<ExternalTorque>(e) = Vector3::zero();
+            ctx.get<broadphase::LeafID>(e) = bvh.reserveLeafAt(leaf, e, obj_id);
+            ctx.get<EntityType>(e) = type;
+            ESCPHYS_IF_RENDER(
+                ctx.get<render::Renderable>(e).renderEntity = render_entity;)
+        };
+
+        if (is_button) {
+            const uint32_t at = base + 2u * (uint32_t)k;
+            Vector3 pos {
+                in_range(at, -half_width + 2.f, half_width - 2.f),
+                in_range(at + 1u, y_min + 2.f, y_max - 3.f),
+                0.f,
+            };
+            ctx.get<Position>(e) = pos;
+            ctx.get<Rotation>(e) = Quat { 1, 0, 0, 0 };
+            ctx.get<Scale>(e) = Diag3x3 {
+                consts::buttonWidth, consts::buttonWidth, 0.2f,
+            };
+            ctx.get<ObjectID>(e) = ObjectID { (int32_t)SimObject::Button };
+            ctx.get<ButtonState>(e).isPressed = 0;
+            ctx.get<EntityType>(e) = EntityType::Button;
+            ESCPHYS_IF_RENDER(
+                ctx.get<render::Renderable>(e).renderEntity = render_entity;)
+            room.buttons[k] = e;
+        } else if (is_wall) {
+            const int32_t side = k - consts::numButtonsPerRoom;
+            // makeWall()
+            const float x_min = side == 0 ? -half_width :
+                                            door_x + consts::doorWidth * 0.5f;
+            const float x_max = side == 0 ? door_x - consts::doorWidth * 0.5f :
+                                            half_width;
+            fill_body(
+                Vector3 { (x_min + x_max) * 0.5f, y_max, consts::wallHeight * 0.5f },
+                SimObject::Wall, EntityType::Wall, ResponseType::Static,
+                Diag3x3 { x_max - x_min, consts::wallWidth, consts::wallHeight },
+                first_leaf + side);
+            room.walls[side] = e;
+        } else if (is_door) {
+            const uint32_t at = base + 2u * consts::numButtonsPerRoom;
+            fill_body(Vector3 { door_x, y_max, 0.f }, SimObject::Door,
+                EntityType::Door, ResponseType::Static,
+                Diag3x3 { consts::doorWidth * 0.8f, consts::wallWidth,
+                          2.f * consts::wallHeight },
+                first_leaf + 2);
+            ctx.get<OpenState>(e).isOpen = 0;
+            DoorProperties &props = ctx.get<DoorProperties>(e);
+            for (int32_t b = 0; b < 4; b++) {
+                props.buttons[b] = b < consts::numButtonsPerRoom ?
+                    room_buttons[b] : Entity::none();
+            }
+            props.numButtons = 1 + rand::sampleI32(key(at + 1u), 0,
+                                                   consts::numButtonsPerRoom);
+            props.isPersistent = rand::sampleBool(key(at + 2u)) ? 1 : 0;
+            room.door = e;
+        } else {
+            const int32_t c = k - consts::numButtonsPerRoom - 3;
+            const uint32_t at =
+                base + 2u * consts::numButtonsPerRoom + 3u + 2u * (uint32_t)c;
+            Vector3 pos {
+                in_range(at, -half_width + 1.5f, half_width - 1.5f),
+                in_range(at + 1u, y_min + 4.f, y_max - 2.5f),
+                consts::cubeSize * 0.5f,
+            };
+            fill_body(pos, SimObject::Cube, EntityType::Cube,
+                ResponseType::Dynamic,
+                Diag3x3 { consts::cubeSize, consts::cubeSize, consts::cubeSize },
+                first_leaf + 3 + c);
+            room.cubes[c] = e;
+        }
+    }
+
+    if (lane == 0) {
+        // what `sim.rng = rng` leaves after the sequential draws
+        struct RNGState { RandKey k; uint32_t count; };
+        static_assert(sizeof(RNGState) == sizeof(RNG));
+        RNGState state { episode, num_draws };
+        memcpy(&sim.rng, &state, sizeof(RNG));
+        sim.curWorldEpisode += 1;
+    }
+}
+#endif
+
 inline void resetSystem(Engine &ctx, WorldReset &reset)
 {
     Sim &sim = ctx.data();
@@ -570,6 +850,25 @@ inline void resetSystem(Engine &ctx, WorldReset &reset)
         }
     }
 
+#ifdef MADRONA_GPU_MODE
+    // 64 lanes per world: lane 0 advances the reset stream, everybody learns
+    // the outcome
+    int32_t auto_reset = 0;
+    if (sim.autoResetDenom != 0 && threadIdx.x % 64 == 0) {
+        auto_reset =
+            sim.resetRng.sampleI32(0, (int32_t)sim.autoResetDenom) == 0 ? 1 : 0;
+    }
+    if (__shfl(auto_reset, 0, 64) != 0) {
+        should_reset = 1;
+    }
+
+    if (should_reset != 0) {
+        if (threadIdx.x % 64 == 0) {
+            reset.reset = 0;
+        }
+        resetWorldWave(ctx);
+    }
+#else
     if (sim.autoResetDenom != 0) {
         if (sim.resetRng.sampleI32(0, (int32_t)sim.autoResetDenom) == 0) {
             should_reset = 1;
@@ -581,6 +880,7 @@ inline void resetSystem(Engine &ctx, WorldReset &reset)
         cleanupWorld(ctx);
         initWorld(ctx);
     }
+#endif
 }
 
 inline void collectObservationsSystem(Engine &ctx,
@@ -764,8 +1064,14 @@ void Sim::setupTasks(TaskGraphManager &taskgraph_mgr, const Config &)
             Done
         >>({reward_sys});
 
+#ifdef MADRONA_GPU_MODE
+    // 64 lanes per world: lane i resets entity i (resetWorldWave)
+    auto reset_sys = builder.addToGraph<CustomParallelForNode<Engine,
+        resetSystem, 64, 1,
+#else
     auto reset_sys = builder.addToGraph<ParallelForNode<Engine,
         resetSystem,
+#endif
             WorldReset
         >>({done_sys});
 
