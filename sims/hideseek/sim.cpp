@@ -1,5 +1,7 @@
 #include "sim.hpp"
 
+#include <cstring>
+
 #ifdef MADRONA_GPU_MODE
 #include <madrona/mw_gpu_entry.hpp>
 #endif
@@ -530,6 +532,215 @@ inline void stepTrackerSystem(Engine &,
     }
 }
 
+#ifdef MADRONA_GPU_MODE
+// The reset of a world on the GPU backends: 64 lanes per world
+// (CustomParallelForNode<..., 64, 1>), lane i destroys / creates / fills in
+// entity i.  Same result as cleanupWorld() + initWorld() above, bit for bit:
+// ids through Context::destroyEntityOrdered / makeEntityOrdered (lane order =
+// the order of the loops above), BVH leaves by position in the registration
+// sequence (floor, borders, agents, boxes, ramps, walls), random numbers by
+// sample index -- sample i of an episode is split_i(episode key, i), and the
+// loops draw a fixed number per object:
+//   cell shuffle: 0 .. numAgents + numMovable - 1
+//   agent a:   S + 3 a + { x, y, heading }                    (S = shuffle draws)
+//   box i:     A + 3 i (+ i - 6 for the three long ones) + { x, y, sunk, [quarter] }
+//   ramp i:    B + 3 i + { x, y, quarter };   wall i:  R + 3 i + { along_y, line, seg }
+static inline void resetWorldWave(Engine &ctx)
+{
+    Sim &sim = ctx.data();
+    LevelState &level = ctx.singleton<LevelState>();
+    broadphase::BVH &bvh = ctx.singleton<broadphase::BVH>();
+
+    constexpr int32_t num_level =
+        consts::numBoxes + consts::numRamps + consts::numInteriorWalls;
+    constexpr int32_t num_persistent = 1 + consts::numBorderWalls + consts::numAgents;
+    constexpr int32_t num_cells = consts::gridDim * consts::gridDim;
+    constexpr int32_t num_placed = consts::numAgents + consts::numMovable;
+    constexpr int32_t num_long = 3;
+    constexpr uint32_t draws_shuffle = (uint32_t)num_placed;
+    constexpr uint32_t draws_agents = draws_shuffle + 3u * consts::numAgents;
+    constexpr uint32_t draws_boxes = draws_agents + 3u * consts::numBoxes + num_long;
+    constexpr uint32_t draws_ramps = draws_boxes + 3u * consts::numRamps;
+    constexpr uint32_t num_draws = draws_ramps + 3u * consts::numInteriorWalls;
+    static_assert(num_level <= 64 && num_persistent <= 64);
+
+    const int32_t lane = (int32_t)(threadIdx.x % 64);
+    const bool on_level = lane < num_level;
+    const bool is_box = lane < consts::numBoxes;
+    const bool is_ramp = !is_box && lane < consts::numBoxes + consts::numRamps;
+
+    // ---- cleanupWorld(): boxes, ramps, walls ----
+    {
+        Entity e = Entity::none();
+        if (on_level) {
+            e = is_box ? level.boxes[lane] :
+                (is_ramp ? level.ramps[lane - consts::numBoxes] :
+                 level.walls[lane - consts::numBoxes - consts::numRamps]);
+        }
+        ctx.destroyEntityOrdered(e, on_level);
+    }
+
+    // ---- initWorld() ----
+    if (lane == 0) {
+        PhysicsSystem::reset(ctx);
+        bvh.setNumLeaves(num_persistent + num_level);
+    }
+
+    const RandKey episode = rand::split_i(sim.initRandKey, sim.curWorldEpisode);
+    auto key = [&](uint32_t i) { return rand::split_i(episode, i); };
+    auto in_range = [&](uint32_t i, float lo, float hi) {
+        return lo + rand::sampleUniform(key(i)) * (hi - lo);
+    };
+
+    // the partial shuffle of the cell list (every lane, the same)
+    int32_t cells[num_cells];
+    for (int32_t i = 0; i < num_cells; i++) {
+        cells[i] = i;
+    }
+    for (int32_t i = 0; i < num_placed; i++) {
+        int32_t j = i + rand::sampleI32(key((uint32_t)i), 0, num_cells - i);
+        int32_t tmp = cells[i];
+        cells[i] = cells[j];
+        cells[j] = tmp;
+    }
+    // slot: agents, boxes, ramps in that order; the draws of its x and y
+    auto cell_pos = [&](int32_t slot, uint32_t at, float z) {
+        int32_t cell = cells[slot];
+        return Vector3 {
+            cellCenter(cell % consts::gridDim) + in_range(at, -0.25f, 0.25f),
+            cellCenter(cell / consts::gridDim) + in_range(at + 1u, -0.25f, 0.25f),
+            z,
+        };
+    };
+
+    // resetPersistentEntities() + the agents' part of generateLevel()
+    if (lane < num_persistent) {
+        const Entity e = lane == 0 ? sim.floorPlane :
+            (lane <= consts::numBorderWalls ? sim.borders[lane - 1] :
+             sim.agents[lane - 1 - consts::numBorderWalls]);
+        ctx.get<broadphase::LeafID>(e) =
+            bvh.reserveLeafAt(lane, e, ctx.get<ObjectID>(e));
+
+        if (lane > consts::numBorderWalls) {
+            const int32_t i = lane - 1 - consts::numBorderWalls;
+            Entity agent = e;
+            ctx.get<Velocity>(agent) = Velocity { Vector3::zero(), Vector3::zero() };
+            ctx.get<ExternalForce>(agent) = Vector3::zero();
+            ctx.get<ExternalTorque>(agent) = Vector3::zero();
+            ctx.get<Action>(agent) = Action { 0, 0, 0, 0 };
+            ctx.get<StepsRemaining>(agent).t = consts::episodeLen;
+            ctx.get<Visibility>(agent) = Visibility { { 0, 0, 0, 0 } };
+            ctx.get<Reward>(agent).v = 0.f;
+            ctx.get<Done>(agent).v = 0;
+
+            const uint32_t at = draws_shuffle + 3u * (uint32_t)i;
+            Vector3 pos = cell_pos(i, at, 1.f);
+            int32_t heading = rand::sampleI32(key(at + 2u), 0, 8);
+            float c = kMoveCos[heading];
+            float sn = kMoveSin[heading];
+            float ch = sqrtf((1.f + c) * 0.5f);
+            float sh = sqrtf((1.f - c) * 0.5f);
+            if (sn < 0.f) sh = -sh;
+            ctx.get<Position>(agent) = pos;
+            ctx.get<Rotation>(agent) = Quat { ch, 0.f, 0.f, sh }.normalize();
+        }
+    }
+
+    // generateLevel(): boxes, ramps (MovableObject), walls (StaticObject)
+    const uint32_t archetype = is_box || is_ramp ?
+        TypeTracker::typeID<MovableObject>() : TypeTracker::typeID<StaticObject>();
+    const Entity e = ctx.makeEntityOrdered(archetype, on_level);
+
+    if (on_level) {
+        // setupRigidBody() with the leaf this body has in the sequence
+        auto fill_body = [&](Vector3 pos, Quat rot, SimObject obj, EntityType type,
+                             ResponseType response, Diag3x3 scale) {
+            ObjectID obj_id { (int32_t)obj };
+            ctx.get<Position>(e) = pos;
+            ctx.get<Rotation>(e) = rot;
+            ctx.get<Scale>(e) = scale;
+            ctx.get<ObjectID>(e) = obj_id;
+            ctx.get<ResponseType>(e) = response;
+            ctx.get<Velocity>(e) = Velocity { Vector3::zero(), Vector3::zero() };
+            ctx.get<ExternalForce>(e) = Vector3::zero();
+            ctx.get<ExternalTorque>(e) = Vector3::zero();
+            ctx.get<broadphase::LeafID>(e) =
+                bvh.reserveLeafAt(num_persistent + lane, e, obj_id);
+            ctx.get<EntityType>(e) = type;
+        };
+
+        if (is_box) {
+            const int32_t i = lane;
+            const bool is_long = i >= consts::numBoxes - num_long;
+            const uint32_t at = draws_agents + 3u * (uint32_t)i +
+                (is_long ? (uint32_t)(i - (consts::numBoxes - num_long)) : 0u);
+            Vector3 pos = cell_pos(consts::numAgents + i, at, 0.75f);
+            if (rand::sampleUniform(key(at + 2u)) < 0.1f) {
+                pos.z -= 0.01f;
+            }
+            int32_t quarter = is_long ? rand::sampleI32(key(at + 3u), 0, 2) : 0;
+            if (i == consts::numBoxes - 1) {
+                fill_body(pos,
+                    Quat { kQuarterW[quarter], 0.f, 0.f, kQuarterZ[quarter] },
+                    SimObject::LBlock, EntityType::Box, ResponseType::Dynamic,
+                    Diag3x3 { 1.4f, 1.4f, 1.4f });
+            } else {
+                fill_body(pos,
+                    Quat { kQuarterW[quarter], 0.f, 0.f, kQuarterZ[quarter] },
+                    is_long ? SimObject::LongBox : SimObject::Box,
+                    EntityType::Box, ResponseType::Dynamic,
+                    is_long ? Diag3x3 { 3.f, 1.2f, 1.5f } :
+                              Diag3x3 { 1.5f, 1.5f, 1.5f });
+            }
+            ctx.get<LockState>(e) = LockState { 0, 0 };
+            level.boxes[i] = e;
+        } else if (is_ramp) {
+            const int32_t i = lane - consts::numBoxes;
+            const uint32_t at = draws_boxes + 3u * (uint32_t)i;
+            Vector3 pos = cell_pos(consts::numAgents + consts::numBoxes + i, at, 0.8f);
+            int32_t quarter = rand::sampleI32(key(at + 2u), 0, 4);
+            fill_body(pos,
+                Quat { kQuarterW[quarter], 0.f, 0.f, kQuarterZ[quarter] },
+                SimObject::Ramp, EntityType::Ramp, ResponseType::Dynamic,
+                Diag3x3 { 2.5f, 3.f, 1.5f });
+            ctx.get<LockState>(e) = LockState { 0, 0 };
+            level.ramps[i] = e;
+        } else {
+            const int32_t i = lane - consts::numBoxes - consts::numRamps;
+            const uint32_t at = draws_ramps + 3u * (uint32_t)i;
+            int32_t along_y = rand::sampleI32(key(at), 0, 2);
+            int32_t line = 1 + rand::sampleI32(key(at + 1u), 0, consts::gridDim - 1);
+            int32_t seg = rand::sampleI32(key(at + 2u), 0, consts::gridDim);
+
+            float line_coord =
+                (float)line * consts::cellSize - consts::arenaSize * 0.5f;
+            float seg_coord = cellCenter(seg);
+
+            Vector3 pos = along_y != 0 ?
+                Vector3 { line_coord, seg_coord, consts::wallHeight * 0.5f } :
+                Vector3 { seg_coord, line_coord, consts::wallHeight * 0.5f };
+            Diag3x3 scale = along_y != 0 ?
+                Diag3x3 { consts::wallThickness, consts::cellSize,
+                          consts::wallHeight } :
+                Diag3x3 { consts::cellSize, consts::wallThickness,
+                          consts::wallHeight };
+            fill_body(pos, Quat { 1, 0, 0, 0 }, SimObject::Wall, EntityType::Wall,
+                      ResponseType::Static, scale);
+            level.walls[i] = e;
+        }
+    }
+
+    if (lane == 0) {
+        // what `sim.rng = rng` leaves after the sequential draws
+        struct RNGState { RandKey k; uint32_t count; };
+        static_assert(sizeof(RNGState) == sizeof(RNG));
+        RNGState state { episode, num_draws };
+        memcpy(&sim.rng, &state, sizeof(RNG));
+        sim.curWorldEpisode += 1;
+    }
+}
+#endif
+
 inline void resetSystem(Engine &ctx, WorldReset &reset)
 {
     Sim &sim = ctx.data();
@@ -542,6 +753,25 @@ inline void resetSystem(Engine &ctx, WorldReset &reset)
         }
     }
 
+#ifdef MADRONA_GPU_MODE
+    // 64 lanes per world: lane 0 advances the reset stream, everybody learns
+    // the outcome
+    int32_t auto_reset = 0;
+    if (sim.autoResetDenom != 0 && threadIdx.x % 64 == 0) {
+        auto_reset =
+            sim.resetRng.sampleI32(0, (int32_t)sim.autoResetDenom) == 0 ? 1 : 0;
+    }
+    if (__shfl(auto_reset, 0, 64) != 0) {
+        should_reset = 1;
+    }
+
+    if (should_reset != 0) {
+        if (threadIdx.x % 64 == 0) {
+            reset.reset = 0;
+        }
+        resetWorldWave(ctx);
+    }
+#else
     if (sim.autoResetDenom != 0) {
         if (sim.resetRng.sampleI32(0, (int32_t)sim.autoResetDenom) == 0) {
             should_reset = 1;
@@ -553,6 +783,7 @@ inline void resetSystem(Engine &ctx, WorldReset &reset)
         cleanupWorld(ctx);
         initWorld(ctx);
     }
+#endif
 }
 
 static inline ObjectObservation observeObject(Engine &ctx, Entity e,
@@ -703,8 +934,14 @@ void Sim::setupTasks(TaskGraphManager &taskgraph_mgr, const Config &)
             Done
         >>({phys_done});
 
+#ifdef MADRONA_GPU_MODE
+    // 64 lanes per world: lane i resets entity i (resetWorldWave)
+    auto reset_sys = builder.addToGraph<CustomParallelForNode<Engine,
+        resetSystem, 64, 1,
+#else
     auto reset_sys = builder.addToGraph<ParallelForNode<Engine,
         resetSystem,
+#endif
             WorldReset
         >>({done_sys});
 
