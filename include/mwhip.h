@@ -336,7 +336,12 @@ int mwhip_build_launch_graph(mwhip_exec *exec, const uint32_t *taskgraph_ids,
 void mwhip_free_launch_graph(mwhip_exec *exec, uint64_t graph);
 /* MWCudaExecutor::run (cuda_exec.cpp:2756-2794): synchronous */
 int mwhip_run(mwhip_exec *exec, uint64_t graph);
-/* MWCudaExecutor::runAsync (:2796-2800) */
+/* MWCudaExecutor::runAsync (:2796-2800).  Replays of ONE executor's launch
+ * graphs run one at a time, in the order they were queued -- queue them on one
+ * stream (the executor's own, mwhip_stream, or one of the caller's): nodes that
+ * can append rows agree on their row counts through a per-replay tag, and two
+ * graphs of one executor in flight at once on different streams would not
+ * (they time out with a device error, they do not hang). */
 int mwhip_run_async(mwhip_exec *exec, uint64_t graph, void *hip_stream);
 /* the executor's private stream (cu::makeStream, cuda_exec.cpp:2342) */
 void *mwhip_stream(mwhip_exec *exec);

@@ -506,6 +506,8 @@ struct mwhip_exec {
     std::mutex printMutex;
     std::thread printThread;
     std::atomic<bool> printStop { false };
+    uint64_t printStallTail = ~0ull;    // ticket the drain thread is waiting for
+    uint32_t printStallPolls = 0;
     int32_t *statsHost = nullptr;           // pinned, device-visible
     std::vector<void *> allocations;
     std::vector<std::unique_ptr<VmRange>> vmRanges;
@@ -1463,8 +1465,23 @@ static void drainHostPrints(mwhip_exec *exec, bool in_flight)
             printRecord(rec);
             printed = true;
         } else if (in_flight) {
-            break;
+            // Not there yet: its writer is still filling it in -- or dropped it
+            // (a writer that finds the ring full takes a ticket and writes
+            // nothing).  A record takes microseconds to fill; one that has not
+            // appeared over 32 polls of this thread (~5 ms) was dropped, and
+            // waiting for it would keep the ring full for every later message
+            // until the next mwhip_run / mwhip_synchronize.
+            if (exec->printStallTail == tail) {
+                if (++exec->printStallPolls < 32u) {
+                    break;
+                }
+            } else {
+                exec->printStallTail = tail;
+                exec->printStallPolls = 1;
+                break;
+            }
         }
+        exec->printStallTail = ~0ull;
         tail += 1;
         __atomic_store_n(&ring->tail, tail, __ATOMIC_RELEASE);
     }
@@ -2753,7 +2770,8 @@ static int renderLaunches(mwhip_exec *exec, std::vector<KernelLaunch> &out)
     int num_cus = 256;
     (void)hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount,
                                 exec->cfg.gpu_id);
-    static const uint32_t max_wgs =
+    // (per executor: its own device's CU count)
+    const uint32_t max_wgs =
         envU32("MADRONA_MWHIP_RAYCAST_WGS", (uint32_t)std::max(num_cus, 1) * 6u);
     buildRenderLaunches(exec->stateDev, params, exec->cfg.num_worlds, views,
                         std::max(max_wgs, 1u), out);

@@ -157,11 +157,24 @@ MADRONA_DEVICE inline void pforRowSnapshot(EcsState *S, PforRowSync *sync,
         } else {
             for (uint32_t a = 0; a < num_tables; a++) {
                 unsigned long long g;
+                // (bounded: the tag is the executor's replay count, so this
+                // relies on the launch graphs of one executor running one at a
+                // time -- mwhip.h, mwhip_run_async -- ; two of them in flight
+                // on different streams would wait for a tag nobody publishes.
+                // Then: the live row count and an error flag instead of a hang)
+                uint32_t spins = 0;
                 while (true) {
                     g = __hip_atomic_load(&sync->rows[a], __ATOMIC_RELAXED,
                                           __HIP_MEMORY_SCOPE_AGENT);
                     if ((g >> 32) == tag) break;
                     __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1u << 24)) {
+                        mwhip::raiseError(S, mwhip::kErrSortLookback);
+                        g = (unsigned long long)(uint32_t)__hip_atomic_load(
+                            &table_of(a)->numRows, __ATOMIC_RELAXED,
+                            __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
                 }
                 out[a] = (int32_t)(uint32_t)g;
             }
