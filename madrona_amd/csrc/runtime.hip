@@ -67,34 +67,12 @@ static uint32_t envU32(const char *name, uint32_t fallback)
 // ---------------------------------------------------------------------------
 namespace {
 
-enum MiscOpKind : uint32_t { kOpClearTmp = 0, kOpResetTmpAlloc = 1 };
-
-struct MiscOp {
-    uint32_t kind;
-    uint32_t archetype;
-};
-
 // ClearTmpNode / ResetTmpAllocNode (reference taskgraph_utils.cpp:171-230):
-// a handful of scalar stores; consecutive ones share one launch.
+// a handful of scalar stores; consecutive ones share one launch -- or ride on
+// the last kernel of the sort chain they follow (sort_archetype.hip).
 __global__ void miscOpsKernel(EcsState *S, const MiscOp *ops, uint32_t num_ops)
 {
-    uint32_t i = threadIdx.x;
-    if (i >= num_ops) return;
-
-    MiscOp op = ops[i];
-    if (op.kind == kOpClearTmp) {
-        TableHdr &tbl = S->tables[op.archetype];
-        if (tbl.numRows != 0) {
-            tbl.needsSort = 1u;
-        }
-        if (tbl.numRows > tbl.peakRows) {
-            tbl.peakRows = tbl.numRows;
-        }
-        tbl.numRows = 0;
-        tbl.sortedRows = 0;
-    } else if (op.kind == kOpResetTmpAlloc) {
-        S->tmpOffset = 0ull;
-    }
+    applyMiscOps(S, ops, num_ops, threadIdx.x);
 }
 
 // ---- exclusive scan over a few device arrays (MWHIP_NODE_EXCLUSIVE_SCAN) ----
@@ -518,6 +496,7 @@ struct mwhip_exec {
     uint32_t numGrowths = 0;
     bool checkAfterRun = true;
     bool sortBatching = true;
+    bool sortCarriesMisc = true;    // MADRONA_MWHIP_SORT_CARRIES_MISC
     // MADRONA_MWHIP_SORT_COMPACT: 0 never, 1 world sorts of tables nothing else
     // reorders, 2 every world sort (tests: the chain is correct on any table,
     // its one-workgroup tail sort is just slow when the whole table is "tail")
@@ -2053,6 +2032,24 @@ static int buildLaunchList(mwhip_exec *exec, const std::vector<uint32_t> &tg_ids
                     }
                     lg.sortBatches.push_back(std::move(batch));
                 }
+                // The ResetTmpAlloc nodes deferred behind the batch ride on its
+                // last kernel instead of taking a launch of their own (~4 us):
+                // the sort uses neither the scratch allocator nor their result.
+                if (!pending_misc.empty() && exec->sortCarriesMisc) {
+                    MiscOp *ops_dev;
+                    rc = devAllocT(exec, &ops_dev, pending_misc.size());
+                    if (rc != 0) return rc;
+                    HIPCHK(hipMemcpy(ops_dev, pending_misc.data(),
+                        pending_misc.size() * sizeof(MiscOp), hipMemcpyHostToDevice));
+                    // (the last kernel of a chain is sortSmall, sortGather or
+                    // sortFinalize: each ends in (ops, count), empty by default)
+                    KernelLaunch &last = lg.launches.back();
+                    last.numArgs -= 2;
+                    last.pushArg((const MiscOp *)ops_dev);
+                    last.pushArg((uint32_t)pending_misc.size());
+                    last.carriesMisc = true;
+                    pending_misc.clear();
+                }
                 oi = oj - 1;
             } break;
             case MWHIP_NODE_EXCLUSIVE_SCAN: {
@@ -2471,6 +2468,7 @@ extern "C" int mwhip_create(const mwhip_state_config *cfg,
     exec->taskGraphs.resize(cfg->num_task_graphs);
     exec->checkAfterRun = envU32("MADRONA_MWHIP_CHECK", 1) != 0;
     exec->sortBatching = envU32("MADRONA_MWHIP_SORT_BATCH", 1) != 0;
+    exec->sortCarriesMisc = envU32("MADRONA_MWHIP_SORT_CARRIES_MISC", 1) != 0;
     exec->sortCompaction = envU32("MADRONA_MWHIP_SORT_COMPACT", 1);
     exec->rowSnapshotMode = envU32("MADRONA_MWHIP_ROW_SNAPSHOT", 1);
     exec->tableGrowth = std::max(envU32("MADRONA_MWHIP_TABLE_GROWTH", 4), 1u);

@@ -135,6 +135,37 @@ struct SortBatch {
     bool compact = false;
 };
 
+// ---- ClearTmp / ResetTmpAlloc ---------------------------------------------------
+enum MiscOpKind : uint32_t { kOpClearTmp = 0, kOpResetTmpAlloc = 1 };
+
+struct MiscOp {
+    uint32_t kind;
+    uint32_t archetype;
+};
+
+#if defined(__HIPCC__)
+// thread `tid` of the caller applies op `tid`
+__device__ inline void applyMiscOps(EcsState *S, const MiscOp *ops,
+                                    uint32_t num_ops, uint32_t tid)
+{
+    if (tid >= num_ops) return;
+    const MiscOp op = ops[tid];
+    if (op.kind == kOpClearTmp) {
+        TableHdr &tbl = S->tables[op.archetype];
+        if (tbl.numRows != 0) {
+            tbl.needsSort = 1u;
+        }
+        if (tbl.numRows > tbl.peakRows) {
+            tbl.peakRows = tbl.numRows;
+        }
+        tbl.numRows = 0;
+        tbl.sortedRows = 0;
+    } else if (op.kind == kOpResetTmpAlloc) {
+        S->tmpOffset = 0ull;
+    }
+}
+#endif
+
 // ---- launches ------------------------------------------------------------------
 
 struct KernelLaunch {
@@ -142,7 +173,7 @@ struct KernelLaunch {
     dim3 grid { 1, 1, 1 };
     dim3 block { 1, 1, 1 };
     alignas(16) unsigned char argStorage[320] {};
-    uint32_t argOffsets[8] {};
+    uint32_t argOffsets[9] {};
     uint32_t numArgs = 0;
     uint32_t dynamicLds = 0;        // bytes of dynamic LDS
 
@@ -157,6 +188,7 @@ struct KernelLaunch {
     uint32_t numMatching = 0;
     const SortBatch *sortBatch = nullptr;
     SortRole sortRole = SortRole::None;
+    bool carriesMisc = false;       // trailing (ops, count) arguments were pushed
 
     template <typename T>
     void pushArg(const T &v)

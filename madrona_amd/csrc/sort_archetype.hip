@@ -679,8 +679,13 @@ __device__ inline void gatherColumn(EcsState *S, const SortSite &site,
 
 __global__ void __launch_bounds__(kSortThreads)
 sortGather(EcsState *S, const SortSite *sites, const GatherColumn *columns,
-           const GatherSlice *slices)
+           const GatherSlice *slices, const MiscOp *trailing_ops,
+           uint32_t num_trailing_ops)
 {
+    // (ResetTmpAlloc nodes that followed the chain in the task graph)
+    if (blockIdx.x == 0) {
+        applyMiscOps(S, trailing_ops, num_trailing_ops, threadIdx.x);
+    }
     const GatherSlice slice = slices[blockIdx.x];
     const GatherColumn gc = columns[slice.column];
     const SortSite &site = sites[gc.site];
@@ -780,8 +785,12 @@ __device__ inline void gatherColumn(EcsState *S, const SortSite &site,
 // An exported column must keep its address (PyTorch holds it): it was gathered
 // into its twin; the rows come back here.
 __global__ void __launch_bounds__(kSortThreads)
-sortFinalize(EcsState *S, const SortSite *sites)
+sortFinalize(EcsState *S, const SortSite *sites, const MiscOp *trailing_ops,
+             uint32_t num_trailing_ops)
 {
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+        applyMiscOps(S, trailing_ops, num_trailing_ops, threadIdx.x);
+    }
     const SortSite &site = sites[blockIdx.y];
     TableHdr &tbl = S->tables[site.archetype];
     SortState *state = site.state;
@@ -950,8 +959,12 @@ __device__ inline void oneGroupRadixPasses(SmallSortLDS &lds, int32_t num_passes
 
 __global__ void __launch_bounds__(kSmallThreads)
 sortSmall(EcsState *S, const SortSite *sites, const GatherColumn *columns,
-          uint32_t num_columns)
+          uint32_t num_columns, const MiscOp *trailing_ops,
+          uint32_t num_trailing_ops)
 {
+    if (blockIdx.x == 0) {
+        applyMiscOps(S, trailing_ops, num_trailing_ops, threadIdx.x);
+    }
     const SortSite &site = sites[blockIdx.x];
     TableHdr &tbl = S->tables[site.archetype];
     if (site.worldSort && tbl.needsSort == 0u) {
@@ -1032,6 +1045,102 @@ __device__ inline int32_t compactNumTiles(int32_t prefix)
     return t > 0 ? t : 1;
 }
 
+// a short tail (the steady state) is sorted without leaving the CU
+struct TailSortLDS {
+    uint32_t keys[2][kLdsTailRows];
+    int32_t rows[2][kLdsTailRows];
+};
+
+// One kSmallThreads-wide workgroup: rows [prefix, n) sorted by world (stable,
+// destroyed rows dropped) into the key / index buffers the gather does NOT
+// read, where each of them lands in the prefix (tailLand), and for every prefix
+// tile the first sorted tail row landing in it or later (tileTailStart).
+// Returns the live tail rows (also left in state->tailLive).
+__device__ inline int32_t compactSortTail(const SortSite &site, TableHdr &tbl,
+                                          SortState *state, const uint32_t *keys,
+                                          int32_t n, int32_t prefix,
+                                          SmallSortLDS &lds, TailSortLDS &tail_lds)
+{
+    const uint32_t tid = threadIdx.x;
+    auto &tail_keys_lds = tail_lds.keys;
+    auto &tail_rows_lds = tail_lds.rows;
+
+    const int32_t tail = n - prefix;
+    const bool in_lds = tail <= kLdsTailRows;
+    // The last pass lands in the buffer the gather does NOT read (first_out = 1
+    // with { A, B }): the scatter fills the other one while tiles still read
+    // the tail.
+    const bool final_in_b = ((site.numPasses - 1) & 1) != 0;
+    uint32_t *tail_keys = final_in_b ? site.keysA : site.keysB;
+    int32_t *tail_rows = final_in_b ? site.idxA : site.idxB;
+    const int final_buf = (1 + site.numPasses - 1) & 1;
+    {
+        // (assigned, not brace-initialised: LDS addresses are no constant
+        // expressions for a static initialiser)
+        RadixBuffers buffers;
+        buffers.keys[0] = in_lds ? tail_keys_lds[0] : site.keysA;
+        buffers.keys[1] = in_lds ? tail_keys_lds[1] : site.keysB;
+        buffers.rows[0] = in_lds ? tail_rows_lds[0] : site.idxA;
+        buffers.rows[1] = in_lds ? tail_rows_lds[1] : site.idxB;
+        oneGroupRadixPasses(lds, site.numPasses, buffers, keys + prefix, prefix,
+                            tail, 1);
+    }
+    __syncthreads();
+    const int32_t tail_live = (int32_t)lds.valid;
+
+    if (tid == 0) {
+        state->tailLive = tail_live;
+        state->statTailRows += (unsigned long long)tail;
+        if (tail > tbl.tailRows) {
+            tbl.tailRows = tail;
+        }
+    }
+
+    // where every sorted tail row lands in the prefix: the end of its world's
+    // old range
+    const int32_t num_tiles = compactNumTiles(prefix);
+    const int32_t *offs = tbl.worldOffsets;
+    const int32_t *cnts = tbl.worldCounts;
+    int32_t *land_lds = (int32_t *)tail_keys_lds[final_buf ^ 1];    // (free now)
+    for (int32_t j = (int32_t)tid; j < tail_live; j += kSmallThreads) {
+        const uint32_t w = in_lds ? tail_keys_lds[final_buf][j] : tail_keys[j];
+        const int32_t land = offs[w] + cnts[w];
+        site.tailLand[j] = land;
+        if (in_lds) {
+            land_lds[j] = land;
+            tail_keys[j] = w;
+            tail_rows[j] = tail_rows_lds[final_buf][j];
+        }
+    }
+    __syncthreads();
+
+    // tileTailStart[t] = first sorted tail row landing in tile t or later
+    auto tile_of = [&](int32_t j) {
+        const int32_t land = in_lds ? land_lds[j] : site.tailLand[j];
+        const int32_t t = land >> kCompactTileShift;
+        return t < num_tiles - 1 ? t : num_tiles - 1;
+    };
+    if (tail_live == 0) {
+        for (int32_t t = (int32_t)tid; t <= num_tiles; t += kSmallThreads) {
+            site.tileTailStart[t] = 0;
+        }
+        return 0;
+    }
+    for (int32_t j = (int32_t)tid; j < tail_live; j += kSmallThreads) {
+        const int32_t mine = tile_of(j);
+        const int32_t before = j > 0 ? tile_of(j - 1) : -1;
+        for (int32_t t = before + 1; t <= mine; t++) {
+            site.tileTailStart[t] = j;
+        }
+        if (j == tail_live - 1) {
+            for (int32_t t = mine + 1; t <= num_tiles; t++) {
+                site.tileTailStart[t] = tail_live;
+            }
+        }
+    }
+    return tail_live;
+}
+
 __global__ void __launch_bounds__(kSmallThreads)
 sortCompactPrepare(EcsState *S, const SortSite *sites)
 {
@@ -1098,93 +1207,20 @@ sortCompactPrepare(EcsState *S, const SortSite *sites)
 
     // ---- workgroup 0: the tail, sorted by world ----
     __shared__ SmallSortLDS lds;
-    // a short tail (the steady state) is sorted without leaving the CU
-    __shared__ uint32_t tail_keys_lds[2][kLdsTailRows];
-    __shared__ int32_t tail_rows_lds[2][kLdsTailRows];
-
-    const int32_t tail = n - prefix;
-    const bool in_lds = tail <= kLdsTailRows;
-    // The last pass lands in the buffer the gather does NOT read (first_out = 1
-    // with { A, B }): the scatter kernel fills the other one while tiles still
-    // read the tail.
-    const bool final_in_b = ((site.numPasses - 1) & 1) != 0;
-    uint32_t *tail_keys = final_in_b ? site.keysA : site.keysB;
-    int32_t *tail_rows = final_in_b ? site.idxA : site.idxB;
-    const int final_buf = (1 + site.numPasses - 1) & 1;
-    {
-        // (assigned, not brace-initialised: LDS addresses are no constant
-        // expressions for a static initialiser)
-        RadixBuffers buffers;
-        buffers.keys[0] = in_lds ? tail_keys_lds[0] : site.keysA;
-        buffers.keys[1] = in_lds ? tail_keys_lds[1] : site.keysB;
-        buffers.rows[0] = in_lds ? tail_rows_lds[0] : site.idxA;
-        buffers.rows[1] = in_lds ? tail_rows_lds[1] : site.idxB;
-        oneGroupRadixPasses(lds, site.numPasses, buffers, keys + prefix, prefix,
-                            tail, 1);
-    }
-    __syncthreads();
-    const int32_t tail_live = (int32_t)lds.valid;
-
-    if (tid == 0) {
-        state->tailLive = tail_live;
-        state->statTailRows += (unsigned long long)tail;
-        if (tail > tbl.tailRows) {
-            tbl.tailRows = tail;
-        }
-    }
-
-    // where every sorted tail row lands in the prefix: the end of its world's
-    // old range
-    const int32_t num_tiles = compactNumTiles(prefix);
-    const int32_t *offs = tbl.worldOffsets;
-    const int32_t *cnts = tbl.worldCounts;
-    int32_t *land_lds = (int32_t *)tail_keys_lds[final_buf ^ 1];    // (free now)
-    for (int32_t j = (int32_t)tid; j < tail_live; j += kSmallThreads) {
-        const uint32_t w = in_lds ? tail_keys_lds[final_buf][j] : tail_keys[j];
-        const int32_t land = offs[w] + cnts[w];
-        site.tailLand[j] = land;
-        if (in_lds) {
-            land_lds[j] = land;
-            tail_keys[j] = w;
-            tail_rows[j] = tail_rows_lds[final_buf][j];
-        }
-    }
-    __syncthreads();
-
-    // tileTailStart[t] = first sorted tail row landing in tile t or later
-    auto tile_of = [&](int32_t j) {
-        const int32_t land = in_lds ? land_lds[j] : site.tailLand[j];
-        const int32_t t = land >> kCompactTileShift;
-        return t < num_tiles - 1 ? t : num_tiles - 1;
-    };
-    if (tail_live == 0) {
-        for (int32_t t = (int32_t)tid; t <= num_tiles; t += kSmallThreads) {
-            site.tileTailStart[t] = 0;
-        }
-        return;
-    }
-    for (int32_t j = (int32_t)tid; j < tail_live; j += kSmallThreads) {
-        const int32_t mine = tile_of(j);
-        const int32_t before = j > 0 ? tile_of(j - 1) : -1;
-        for (int32_t t = before + 1; t <= mine; t++) {
-            site.tileTailStart[t] = j;
-        }
-        if (j == tail_live - 1) {
-            for (int32_t t = mine + 1; t <= num_tiles; t++) {
-                site.tileTailStart[t] = tail_live;
-            }
-        }
-    }
+    __shared__ TailSortLDS tail_lds;
+    compactSortTail(site, tbl, state, keys, n, prefix, lds, tail_lds);
 }
 
+template <int THREADS>
 struct alignas(16) CompactLDS {
     uint32_t landing[kCompactTile + 4];     // tail rows landing at each position
     uint32_t liveBefore[kCompactTile + 4];  // survivors of the tile before each position
-    unsigned long long scan[kSortWaves];
-    int32_t reduce[kSortWaves];
+    unsigned long long scan[THREADS / 64];
+    int32_t reduce[THREADS / 64];
 };
 
-__device__ inline int32_t blockSum256(int32_t v, int32_t *scratch)
+template <int THREADS>
+__device__ inline int32_t blockSum(int32_t v, int32_t *scratch)
 {
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
@@ -1195,12 +1231,13 @@ __device__ inline int32_t blockSum256(int32_t v, int32_t *scratch)
     __syncthreads();
     int32_t total = 0;
 #pragma unroll
-    for (int w = 0; w < kSortWaves; w++) total += scratch[w];
+    for (int w = 0; w < THREADS / 64; w++) total += scratch[w];
     return total;
 }
 
-// exclusive scan of one 64-bit value per thread across a 256-thread block
-__device__ inline unsigned long long blockExclusiveScan256U64(
+// exclusive scan of one 64-bit value per thread across the block
+template <int THREADS>
+__device__ inline unsigned long long blockExclusiveScanU64(
     unsigned long long v, unsigned long long *scratch)
 {
     const uint32_t lane = laneId();
@@ -1216,10 +1253,131 @@ __device__ inline unsigned long long blockExclusiveScan256U64(
     __syncthreads();
     unsigned long long wave_base = 0;
 #pragma unroll
-    for (int w = 0; w < kSortWaves; w++) {
+    for (int w = 0; w < THREADS / 64; w++) {
         if (w < (int)wave) wave_base += scratch[w];
     }
     return wave_base + incl - v;
+}
+
+// this thread's ITEMS consecutive prefix rows of the tile
+template <int ITEMS>
+__device__ inline void loadTileKeys(const uint32_t *keys, int32_t mine, int32_t last,
+                                    uint32_t (&key)[ITEMS])
+{
+    if (mine + ITEMS <= last) {
+        if constexpr (ITEMS == 8) {
+            const uint4 lo = *(const uint4 *)(keys + mine);
+            const uint4 hi = *(const uint4 *)(keys + mine + 4);
+            key[0] = lo.x; key[1] = lo.y; key[2] = lo.z; key[3] = lo.w;
+            key[4] = hi.x; key[5] = hi.y; key[6] = hi.z; key[7] = hi.w;
+        } else {
+            static_assert(ITEMS == 2);
+            const uint2 v = *(const uint2 *)(keys + mine);
+            key[0] = v.x; key[1] = v.y;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < ITEMS; j++) {
+            key[j] = mine + j < last ? keys[mine + j] : 0xFFFFFFFFu;
+        }
+    }
+}
+
+// One prefix tile [first, last) whose keys the block holds (ITEMS per thread,
+// thread-major): the surviving rows and the sorted tail rows landing in the
+// tile go to their place in the sorted order.  live_before_tile = survivors of
+// the tiles before this one.  Ends with a barrier.
+template <int THREADS, int ITEMS>
+__device__ inline void compactScatterTile(const SortSite &site, CompactLDS<THREADS> &lds,
+                                          int32_t tile, int32_t first,
+                                          const uint32_t (&key)[ITEMS],
+                                          int32_t live_before_tile,
+                                          uint32_t *out_keys, int32_t *out_rows,
+                                          const uint32_t *tail_keys,
+                                          const int32_t *tail_rows)
+{
+    static_assert(THREADS * ITEMS == kCompactTile);
+    const int32_t tid = (int32_t)threadIdx.x;
+    const int32_t mine = first + tid * ITEMS;
+
+    // the sorted tail rows landing in this tile (typically a handful: the
+    // first one per thread stays in registers)
+    const int32_t tail_first = site.tileTailStart[tile];
+    const int32_t tail_end = site.tileTailStart[tile + 1];
+    auto landing_at = [&](int32_t j) {
+        int32_t at = site.tailLand[j] - first;
+        return at < 0 ? 0 : (at > kCompactTile ? kCompactTile : at);
+    };
+    const int32_t my_tail = tail_first + tid;
+    int32_t my_at = 0, my_row = 0;
+    uint32_t my_world = 0;
+    if (my_tail < tail_end) {
+        my_at = landing_at(my_tail);
+        my_row = tail_rows[my_tail];
+        my_world = tail_keys[my_tail];
+    }
+
+    // (lds.landing was cleared before a barrier by the caller)
+    if (my_tail < tail_end) {
+        atomicAdd(&lds.landing[my_at], 1u);
+    }
+    for (int32_t j = my_tail + THREADS; j < tail_end; j += THREADS) {
+        atomicAdd(&lds.landing[landing_at(j)], 1u);
+    }
+    __syncthreads();
+
+    uint32_t land[ITEMS];
+    if constexpr (ITEMS == 8) {
+        const uint4 lo = *(const uint4 *)&lds.landing[tid * ITEMS];
+        const uint4 hi = *(const uint4 *)&lds.landing[tid * ITEMS + 4];
+        land[0] = lo.x; land[1] = lo.y; land[2] = lo.z; land[3] = lo.w;
+        land[4] = hi.x; land[5] = hi.y; land[6] = hi.z; land[7] = hi.w;
+    } else {
+        const uint2 v = *(const uint2 *)&lds.landing[tid * ITEMS];
+        land[0] = v.x; land[1] = v.y;
+    }
+    uint32_t my_live = 0, my_land = 0;
+#pragma unroll
+    for (int j = 0; j < ITEMS; j++) {
+        my_live += key[j] != 0xFFFFFFFFu ? 1u : 0u;
+        my_land += land[j];
+    }
+    const unsigned long long excl = blockExclusiveScanU64<THREADS>(
+        (unsigned long long)my_live | ((unsigned long long)my_land << 32),
+        lds.scan);
+    uint32_t live = (uint32_t)excl;             // survivors of the tile before my rows
+    uint32_t landed = (uint32_t)(excl >> 32);   // owned tail rows landing before them
+
+#pragma unroll
+    for (int j = 0; j < ITEMS; j++) {
+        landed += land[j];
+        lds.liveBefore[tid * ITEMS + j] = live;
+        if (key[j] != 0xFFFFFFFFu) {
+            const int32_t dest = live_before_tile + (int32_t)live +
+                tail_first + (int32_t)landed;
+            out_rows[dest] = mine + j;
+            out_keys[dest] = key[j];
+            live += 1u;
+        }
+    }
+    if (tid == THREADS - 1) {
+        lds.liveBefore[kCompactTile] = live;    // the tile's survivors
+    }
+    __syncthreads();
+
+    if (my_tail < tail_end) {
+        const int32_t dest = live_before_tile +
+            (int32_t)lds.liveBefore[my_at] + my_tail;
+        out_rows[dest] = my_row;
+        out_keys[dest] = my_world;
+    }
+    for (int32_t j = my_tail + THREADS; j < tail_end; j += THREADS) {
+        const int32_t dest = live_before_tile +
+            (int32_t)lds.liveBefore[landing_at(j)] + j;
+        out_rows[dest] = tail_rows[j];
+        out_keys[dest] = tail_keys[j];
+    }
+    __syncthreads();
 }
 
 __global__ void __launch_bounds__(kSortThreads)
@@ -1232,7 +1390,7 @@ sortCompactScatter(EcsState *S, const SortSite *sites)
         return;
     }
 
-    __shared__ CompactLDS lds;
+    __shared__ CompactLDS<kSortThreads> lds;
 
     const int32_t n = state->rowsIn;
     const int32_t prefix = state->prefixRows;
@@ -1256,7 +1414,7 @@ sortCompactScatter(EcsState *S, const SortSite *sites)
         for (int32_t t = tid; t < num_tiles; t += kSortThreads) {
             part += tile_count(t);
         }
-        const int32_t survivors = blockSum256(part, lds.reduce);
+        const int32_t survivors = blockSum<kSortThreads>(part, lds.reduce);
         if (tid == 0) {
             state->numValid = (uint32_t)(survivors + tail_live);
         }
@@ -1273,112 +1431,31 @@ sortCompactScatter(EcsState *S, const SortSite *sites)
         for (int32_t i = tid; i < kCompactTile + 4; i += kSortThreads) {
             lds.landing[i] = 0;
         }
-
-        // this thread's eight consecutive prefix rows
         uint32_t key[kSortItems];
-        const int32_t mine = first + tid * kSortItems;
-        if (mine + kSortItems <= last) {
-            const uint4 lo = *(const uint4 *)(keys + mine);
-            const uint4 hi = *(const uint4 *)(keys + mine + 4);
-            key[0] = lo.x; key[1] = lo.y; key[2] = lo.z; key[3] = lo.w;
-            key[4] = hi.x; key[5] = hi.y; key[6] = hi.z; key[7] = hi.w;
-        } else {
-#pragma unroll
-            for (int j = 0; j < kSortItems; j++) {
-                key[j] = mine + j < last ? keys[mine + j] : 0xFFFFFFFFu;
-            }
-        }
-
-        // the sorted tail rows landing in this tile (typically a handful: the
-        // first one per thread stays in registers)
-        const int32_t tail_first = site.tileTailStart[tile];
-        const int32_t tail_end = site.tileTailStart[tile + 1];
-        auto landing_at = [&](int32_t j) {
-            int32_t at = site.tailLand[j] - first;
-            return at < 0 ? 0 : (at > kCompactTile ? kCompactTile : at);
-        };
-        const int32_t my_tail = tail_first + tid;
-        int32_t my_at = 0, my_row = 0;
-        uint32_t my_world = 0;
-        if (my_tail < tail_end) {
-            my_at = landing_at(my_tail);
-            my_row = tail_rows[my_tail];
-            my_world = tail_keys[my_tail];
-        }
+        loadTileKeys<kSortItems>(keys, first + tid * kSortItems, last, key);
 
         // survivors of the tiles before this one (the sum's barriers also order
-        // the clearing of lds.landing before the atomics below)
+        // the clearing of lds.landing before the atomics of the tile)
         int32_t part = 0;
         for (int32_t t = tid; t < tile; t += kSortThreads) {
             part += tile_count(t);
         }
-        const int32_t live_before_tile = blockSum256(part, lds.reduce);
+        const int32_t live_before_tile = blockSum<kSortThreads>(part, lds.reduce);
 
-        if (my_tail < tail_end) {
-            atomicAdd(&lds.landing[my_at], 1u);
-        }
-        for (int32_t j = my_tail + kSortThreads; j < tail_end; j += kSortThreads) {
-            atomicAdd(&lds.landing[landing_at(j)], 1u);
-        }
-        __syncthreads();
-
-        uint32_t land[kSortItems];
-        {
-            const uint4 lo = *(const uint4 *)&lds.landing[tid * kSortItems];
-            const uint4 hi = *(const uint4 *)&lds.landing[tid * kSortItems + 4];
-            land[0] = lo.x; land[1] = lo.y; land[2] = lo.z; land[3] = lo.w;
-            land[4] = hi.x; land[5] = hi.y; land[6] = hi.z; land[7] = hi.w;
-        }
-        uint32_t my_live = 0, my_land = 0;
-#pragma unroll
-        for (int j = 0; j < kSortItems; j++) {
-            my_live += key[j] != 0xFFFFFFFFu ? 1u : 0u;
-            my_land += land[j];
-        }
-        const unsigned long long excl = blockExclusiveScan256U64(
-            (unsigned long long)my_live | ((unsigned long long)my_land << 32),
-            lds.scan);
-        uint32_t live = (uint32_t)excl;             // survivors of the tile before my rows
-        uint32_t landed = (uint32_t)(excl >> 32);   // owned tail rows landing before them
-
-        uint32_t live_at[kSortItems];
-#pragma unroll
-        for (int j = 0; j < kSortItems; j++) {
-            landed += land[j];
-            live_at[j] = live;
-            if (key[j] != 0xFFFFFFFFu) {
-                const int32_t dest = live_before_tile + (int32_t)live +
-                    tail_first + (int32_t)landed;
-                out_rows[dest] = mine + j;
-                out_keys[dest] = key[j];
-                live += 1u;
-            }
-        }
-        *(uint4 *)&lds.liveBefore[tid * kSortItems] =
-            make_uint4(live_at[0], live_at[1], live_at[2], live_at[3]);
-        *(uint4 *)&lds.liveBefore[tid * kSortItems + 4] =
-            make_uint4(live_at[4], live_at[5], live_at[6], live_at[7]);
-        if (tid == kSortThreads - 1) {
-            lds.liveBefore[kCompactTile] = live;    // the tile's survivors
-        }
-        __syncthreads();
-
-        if (my_tail < tail_end) {
-            const int32_t dest = live_before_tile +
-                (int32_t)lds.liveBefore[my_at] + my_tail;
-            out_rows[dest] = my_row;
-            out_keys[dest] = my_world;
-        }
-        for (int32_t j = my_tail + kSortThreads; j < tail_end; j += kSortThreads) {
-            const int32_t dest = live_before_tile +
-                (int32_t)lds.liveBefore[landing_at(j)] + j;
-            out_rows[dest] = tail_rows[j];
-            out_keys[dest] = tail_keys[j];
-        }
-        __syncthreads();
+        compactScatterTile<kSortThreads, kSortItems>(site, lds, tile, first, key,
+            live_before_tile, out_keys, out_rows, tail_keys, tail_rows);
     }
 }
 
+// (Round 3 also built prepare + scatter as ONE launch -- workgroup 0 handing the
+// sorted tail to the tile workgroups through an agent-scope release / acquire
+// pair and tagged granules, tiles exchanging their survivor counts the same
+// way -- and measured it slower: 34 us against 13 + 10.5 at 264 K rows, 236
+// against 85 + 18 at 1.8 M (profiles/r03_sort_variants_plan_kernel.jsonl).
+// Every tile polling its predecessors' counts puts T^2 / 2 uncached loads on a
+// handful of cache lines, and with that fixed the hand-off itself -- header
+// broadcast, fence, flag, poll -- costs about the launch floor it removes.
+// Not kept.)
 }
 
 // ---------------------------------------------------------------------------
@@ -1428,7 +1505,7 @@ void buildSortLaunches(const SortBatch &batch, std::vector<KernelLaunch> &out)
         k.grid = dim3(num_sites, 1, 1);
         k.block = dim3(kSmallThreads, 1, 1);
         k.setArgs(batch.stateDev, batch.sitesDev, batch.gatherColumnsDev,
-                  batch.numGatherColumns);
+                  batch.numGatherColumns, (const MiscOp *)nullptr, 0u);
         k.role = "sort.small";
         k.kind = MWHIP_NODE_SORT_ARCHETYPE;
         k.sortBatch = &batch;
@@ -1517,7 +1594,7 @@ void buildSortLaunches(const SortBatch &batch, std::vector<KernelLaunch> &out)
         k.grid = dim3(std::max(batch.numGatherSlices, 1u), 1, 1);
         k.block = dim3(kSortThreads, 1, 1);
         k.setArgs(batch.stateDev, batch.sitesDev, batch.gatherColumnsDev,
-                  batch.gatherSlicesDev);
+                  batch.gatherSlicesDev, (const MiscOp *)nullptr, 0u);
         k.role = "sort.gather";
         k.kind = MWHIP_NODE_SORT_ARCHETYPE;
         k.sortBatch = &batch;
@@ -1532,7 +1609,7 @@ void buildSortLaunches(const SortBatch &batch, std::vector<KernelLaunch> &out)
         // every block pays a device-scope fence for the last-block hand-off
         k.grid = dim3(std::min<uint32_t>(stream_blocks, 16u), num_sites, 1);
         k.block = dim3(kSortThreads, 1, 1);
-        k.setArgs(batch.stateDev, batch.sitesDev);
+        k.setArgs(batch.stateDev, batch.sitesDev, (const MiscOp *)nullptr, 0u);
         k.role = "sort.finalize";
         k.kind = MWHIP_NODE_SORT_ARCHETYPE;
         k.sortBatch = &batch;

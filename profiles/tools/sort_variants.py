@@ -15,21 +15,18 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 RADIX = {"MADRONA_MWHIP_SORT_COMPACT": "0"}
+APART = {"MADRONA_MWHIP_SORT_CARRIES_MISC": "0"}
 RUNS = [
     ("escape_room_phys", 8192, "radix", RADIX),
-    ("escape_room_phys", 8192, "compact b1024", {"MADRONA_MWHIP_GATHER_BLOCKS": "1024"}),
-    ("escape_room_phys", 8192, "compact b2048", {}),
-    ("escape_room_phys", 8192, "compact b4096", {"MADRONA_MWHIP_GATHER_BLOCKS": "4096"}),
-    ("escape_room_phys", 8192, "compact b8192", {"MADRONA_MWHIP_GATHER_BLOCKS": "8192"}),
-    ("escape_room_phys", 8192, "compact b2048 narrow", {"MADRONA_MWHIP_GATHER_WIDE": "0"}),
+    ("escape_room_phys", 8192, "compact", {}),
+    ("escape_room_phys", 8192, "compact, misc ops in a launch of their own", APART),
+    ("escape_room_phys", 8192, "compact, b4096", {"MADRONA_MWHIP_GATHER_BLOCKS": "4096"}),
+    ("escape_room_phys", 8192, "compact, narrow gather", {"MADRONA_MWHIP_GATHER_WIDE": "0"}),
     ("escape_room", 4096, "radix", RADIX),
-    ("escape_room", 4096, "compact b2048", {}),
-    ("escape_room", 4096, "compact b4096", {"MADRONA_MWHIP_GATHER_BLOCKS": "4096"}),
+    ("escape_room", 4096, "compact", {}),
     ("escape_room", 65536, "radix", RADIX),
-    ("escape_room", 65536, "compact b2048", {}),
-    ("escape_room", 65536, "compact b4096", {"MADRONA_MWHIP_GATHER_BLOCKS": "4096"}),
-    ("escape_room", 65536, "compact b8192", {"MADRONA_MWHIP_GATHER_BLOCKS": "8192"}),
-    ("escape_room", 65536, "compact b2048 narrow", {"MADRONA_MWHIP_GATHER_WIDE": "0"}),
+    ("escape_room", 65536, "compact", {}),
+    ("escape_room", 65536, "compact, b8192", {"MADRONA_MWHIP_GATHER_BLOCKS": "8192"}),
 ]
 
 CHILD = r"""

@@ -352,18 +352,21 @@ def test_tgs_solver_lockstep(built, worlds, steps):
 #                      (sort_archetype.hip: tile = workgroup + round * grid)
 #   wide 0             gather word by word instead of in 16-byte chunks of the
 #                      destination
-SORT_CHAINS = [("0", "", "1"), ("2", "", "1"), ("2", "3", "1"), ("0", "2", "1"),
-               ("1", "1", "1"), ("1", "", "0"), ("0", "", "0")]
+# (compaction mode, grid cap, wide gather, trailing misc ops ride on the chain)
+SORT_CHAINS = [("0", "", "1", "1"), ("2", "", "1", "1"), ("2", "3", "1", "1"),
+               ("0", "2", "1", "1"), ("1", "1", "1", "1"), ("1", "", "0", "1"),
+               ("0", "", "0", "1"), ("2", "", "1", "0"), ("0", "", "1", "0")]
 
 
-@pytest.mark.parametrize("compact,grid,wide", SORT_CHAINS)
+@pytest.mark.parametrize("compact,grid,wide,carry", SORT_CHAINS)
 @pytest.mark.parametrize("sim,worlds,steps,denom", [
     ("sort_stress", 1500, 25, 0), ("sort_stress", 37, 40, 0),
     ("escape_room", 2048, 60, 30)])
 def test_sort_chains_lockstep(built, monkeypatch, sim, worlds, steps, denom, compact,
-                              grid, wide):
+                              grid, wide, carry):
     _need_ref(sim)
     monkeypatch.setenv("MADRONA_MWHIP_SORT_COMPACT", compact)
+    monkeypatch.setenv("MADRONA_MWHIP_SORT_CARRIES_MISC", carry)
     monkeypatch.setenv("MADRONA_MWHIP_GATHER_WIDE", wide)
     if grid:
         monkeypatch.setenv("MADRONA_MWHIP_SORT_MAX_GRID", grid)
