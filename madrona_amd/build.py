@@ -19,6 +19,12 @@ def _make(directory: str, *targets: str) -> None:
 def build_hip() -> None:
     """libmadrona_hip.so + every simulator in sims/ for gfx950."""
     _make(os.path.join(REPO_ROOT, "madrona_amd"), "all")
+    # the MADRONA_TRACING flavour (device event log in every kernel,
+    # madrona/mw_gpu/tracing.hpp) of the runtime and of the two simulators its
+    # test runs, apart from the product build
+    _make(os.path.join(REPO_ROOT, "madrona_amd"), "TRACING=1", "OUT=_build_tracing",
+          "runtime", "_build_tracing/libescape_room_hip.so",
+          "_build_tracing/libcartpole_hip.so")
 
 
 def build_oracle() -> None:

@@ -183,6 +183,7 @@ template <int MAXN>
 __global__ void __launch_bounds__(64)
 renderTlasBuild(EcsState *S, RenderParams params)
 {
+    TraceScope trace_scope(S);
     const int32_t world = (int32_t)blockIdx.x;
     const uint32_t lane = laneId();
 
@@ -848,6 +849,7 @@ template <bool GeoInLds>
 __global__ void __launch_bounds__(256)
 renderRaycast(EcsState *S, RenderParams params)
 {
+    TraceScope trace_scope(S);
     __shared__ TraceLDS<GeoInLds> lds;
 
     const uint32_t res = params.resolution;

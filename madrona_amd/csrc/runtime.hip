@@ -9,6 +9,8 @@
 // and graph construction are host code, every node is its own kernel, and a
 // step is one hipGraph replay on the executor's private stream.
 #include "runtime_internal.hpp"
+#include <madrona/tracing.hpp>
+#include <cstddef>
 #include "render_internal.hpp"
 
 #include <hip/hip_ext.h>
@@ -72,6 +74,7 @@ namespace {
 // the last kernel of the sort chain they follow (sort_archetype.hip).
 __global__ void miscOpsKernel(EcsState *S, const MiscOp *ops, uint32_t num_ops)
 {
+    TraceScope trace_scope(S);
     applyMiscOps(S, ops, num_ops, threadIdx.x);
 }
 
@@ -99,6 +102,7 @@ struct ScanNode {
 __global__ void __launch_bounds__(kScanThreads)
 exclusiveScanKernel(EcsState *S, const ScanNode *node_ptr)
 {
+    TraceScope trace_scope(S);
     const ScanNode &node = *node_ptr;
     const mwhip_scan_params &p = node.params;
 
@@ -306,12 +310,69 @@ constexpr uint32_t kStatsReplays = 3 + 2 * kMaxArchetypes;  // replays completed
 constexpr uint32_t kStatsTails = 4 + 2 * kMaxArchetypes;    // [kMaxArchetypes]
 constexpr uint32_t kStatsWords = 4 + 3 * kMaxArchetypes;
 
+#ifdef MADRONA_TRACING
+// One thread in front of every kernel of a traced graph (mw_gpu/tracing.hpp):
+// calibration starts a step's log, nodeStart names the kernel whose
+// workgroups log next, blockExit ends the step.
+__global__ void __launch_bounds__(256)
+traceMarkKernel(EcsState *S, uint32_t event, uint32_t node_id, uint32_t func_id,
+                uint32_t invocations, uint32_t workgroups)
+{
+    using mwGPU::DeviceEvent;
+    using mwGPU::DeviceTracing;
+    DeviceTracing *t = (DeviceTracing *)S->deviceTracing;
+    if (t == nullptr) return;
+    __shared__ uint32_t first_slot;
+    if (threadIdx.x == 0) {
+        first_slot = DeviceTracing::unusedSlot;
+        if ((DeviceEvent)event == DeviceEvent::calibration) {
+            __hip_atomic_store(&t->cur_index_, 0, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // this record + two per workgroup of the kernel that follows
+        const uint32_t want = 1u + 2u * workgroups;
+        int32_t base = __hip_atomic_load(&t->cur_index_, __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_AGENT);
+        if (base >= 0) {
+            base = __hip_atomic_fetch_add(&t->cur_index_, (int32_t)want,
+                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((uint64_t)base + want > DeviceTracing::maxLogSize) {
+                // this step's trace is incomplete: dropped by the host
+                __hip_atomic_store(&t->cur_index_, -1, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+                base = -1;
+            }
+        }
+        DeviceTracing::Cursor cur { node_id, func_id, 0u, 0u };
+        if (base >= 0) {
+            t->device_logs_[base] = DeviceTracing::DeviceLog {
+                (DeviceEvent)event, func_id, invocations, node_id, 0u, 0u,
+                DeviceTracing::computeUnitID(), (uint32_t)base,
+                DeviceTracing::globalTimer(),
+            };
+            cur.firstSlot = (uint32_t)base + 1u;
+            cur.numWorkgroups = workgroups;
+            first_slot = cur.firstSlot;
+        }
+        *(DeviceTracing::Cursor *)S->traceCursor = cur;
+    }
+    __syncthreads();
+    // (a kernel without a TraceScope leaves its slots like this)
+    if (first_slot != DeviceTracing::unusedSlot) {
+        for (uint32_t i = threadIdx.x; i < 2u * workgroups; i += blockDim.x) {
+            t->device_logs_[first_slot + i].event = (DeviceEvent)DeviceTracing::unusedSlot;
+        }
+    }
+}
+#endif
+
 // report_rows == 0 (render pass): error flags and the replay counter only -- the
 // step's row statistics and high-water marks stay as its own health kernel
 // reported them
 __global__ void statsKernel(EcsState *S, int32_t *host_out,
                             uint32_t *replay_signal, uint32_t report_rows)
 {
+    TraceScope trace_scope(S);
     uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a < S->numArchetypeSlots && report_rows != 0u) {
         TableHdr &tbl = S->tables[a];
@@ -497,6 +558,14 @@ struct mwhip_exec {
     bool checkAfterRun = true;
     bool sortBatching = true;
     bool sortCarriesMisc = true;    // MADRONA_MWHIP_SORT_CARRIES_MISC
+
+    // MADRONA_TRACING builds: the device event log (mw_gpu/tracing.hpp), the
+    // records of the first steps, the names funcID indexes
+    void *deviceTracing = nullptr;
+    void *traceCursor = nullptr;
+    std::vector<mwGPU::DeviceTracing::DeviceLog> traceLogs;
+    std::vector<std::string> traceNames;
+    uint32_t traceSteps = 0;
     // MADRONA_MWHIP_SORT_COMPACT: 0 never, 1 world sorts of tables nothing else
     // reorders, 2 every world sort (tests: the chain is correct on any table,
     // its one-workgroup tail sort is just slow when the whole table is "tail")
@@ -1316,6 +1385,20 @@ static int buildDeviceState(mwhip_exec *exec)
     exec->allocations.push_back(exec->replaySignal);
     HIPCHK(hipMemset(exec->replaySignal, 0, 256));
     hs.replayCounter = exec->replaySignal;
+#ifdef MADRONA_TRACING
+    {
+        // (only the index needs clearing; -1 until a traced graph starts a step)
+        HIPCHK(hipMalloc(&exec->deviceTracing, sizeof(mwGPU::DeviceTracing)));
+        exec->allocations.push_back(exec->deviceTracing);
+        const int32_t off = -1;
+        HIPCHK(hipMemcpy(exec->deviceTracing, &off, sizeof(off), hipMemcpyHostToDevice));
+        HIPCHK(hipMalloc(&exec->traceCursor, 256));
+        exec->allocations.push_back(exec->traceCursor);
+        HIPCHK(hipMemset(exec->traceCursor, 0, 256));
+        hs.deviceTracing = exec->deviceTracing;
+        hs.traceCursor = exec->traceCursor;
+    }
+#endif
 
     // batch ray caster configuration (render-prep systems read it on the device)
     hs.raycastOutputResolution = exec->cfg.raycast_output_resolution;
@@ -2131,6 +2214,50 @@ static int buildLaunchList(mwhip_exec *exec, const std::vector<uint32_t> &tg_ids
         lg.launches.push_back(k);
     }
 
+#ifdef MADRONA_TRACING
+    {
+        using mwGPU::DeviceEvent;
+        auto mark = [&](DeviceEvent event, uint32_t node_id, uint32_t func_id,
+                        uint32_t invocations, uint32_t workgroups) {
+            KernelLaunch k;
+            k.fn = (const void *)&traceMarkKernel;
+            k.grid = dim3(1, 1, 1);
+            k.block = dim3(256, 1, 1);
+            k.setArgs(exec->stateDev, (uint32_t)event, node_id, func_id, invocations,
+                      workgroups);
+            k.name = "trace";
+            k.role = "mark";
+            k.kind = MWHIP_NODE_RECYCLE;
+            return k;
+        };
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, exec->cfg.gpu_id));
+        std::vector<KernelLaunch> traced;
+        traced.push_back(mark(DeviceEvent::calibration,
+                              (uint32_t)prop.multiProcessorCount, 4u, 0u, 0u));
+        uint32_t node_id = 0;
+        for (const KernelLaunch &k : lg.launches) {
+            const std::string label =
+                k.role[0] != '\0' ? k.name + ":" + k.role : k.name;
+            uint32_t func_id = 0;
+            while (func_id < exec->traceNames.size() &&
+                   exec->traceNames[func_id] != label) {
+                func_id++;
+            }
+            if (func_id == exec->traceNames.size()) {
+                exec->traceNames.push_back(label);
+            }
+            const uint32_t workgroups = k.grid.x * k.grid.y * k.grid.z;
+            traced.push_back(mark(DeviceEvent::nodeStart, node_id, func_id,
+                workgroups * k.block.x * k.block.y * k.block.z, workgroups));
+            traced.push_back(k);
+            node_id++;
+        }
+        traced.push_back(mark(DeviceEvent::blockExit, node_id, 0u, 0u, 0u));
+        lg.launches = std::move(traced);
+    }
+#endif
+
     return 0;
 }
 
@@ -2540,6 +2667,10 @@ extern "C" int mwhip_create(const mwhip_state_config *cfg,
     return 0;
 }
 
+#ifdef MADRONA_TRACING
+static void writeDeviceTrace(mwhip_exec *exec);
+#endif
+
 extern "C" void mwhip_destroy(mwhip_exec *exec)
 {
     if (exec == nullptr) return;
@@ -2555,6 +2686,9 @@ extern "C" void mwhip_destroy(mwhip_exec *exec)
     if (exec->printThread.joinable()) exec->printThread.join();
     (void)hipStreamSynchronize(exec->serviceStream);
     drainHostPrints(exec, false);
+#ifdef MADRONA_TRACING
+    writeDeviceTrace(exec);
+#endif
     for (auto &kv : exec->launchGraphs) {
         if (kv.second->graphExec) (void)hipGraphExecDestroy(kv.second->graphExec);
         if (kv.second->graph) (void)hipGraphDestroy(kv.second->graph);
@@ -3199,6 +3333,81 @@ extern "C" void mwhip_free_launch_graph(mwhip_exec *exec, uint64_t graph)
     exec->launchGraphs.erase(it);
 }
 
+#ifdef MADRONA_TRACING
+// The step that just completed -> exec->traceLogs (the first 100 steps, like the
+// reference's DeviceTracingManager, cuda_exec.cpp:204-257), with a nodeFinish
+// record per kernel: its latest blockWait.
+static int collectDeviceTrace(mwhip_exec *exec)
+{
+    using mwGPU::DeviceEvent;
+    using Log = mwGPU::DeviceTracing::DeviceLog;
+    if (exec->deviceTracing == nullptr || exec->traceSteps >= 100u) return 0;
+    int32_t count = 0;
+    HIPCHK(hipMemcpy(&count, exec->deviceTracing, sizeof(count), hipMemcpyDeviceToHost));
+    if (count <= 0) return 0;       // nothing logged, or the step overflowed
+    count = std::min<int32_t>(count, (int32_t)mwGPU::DeviceTracing::maxLogSize);
+    std::vector<Log> step((size_t)count);
+    HIPCHK(hipMemcpy(step.data(),
+        (const char *)exec->deviceTracing + offsetof(mwGPU::DeviceTracing, device_logs_),
+        step.size() * sizeof(Log), hipMemcpyDeviceToHost));
+    // (slots reserved for a kernel whose workgroups log nothing)
+    step.erase(std::remove_if(step.begin(), step.end(), [](const Log &l) {
+        return (uint32_t)l.event == mwGPU::DeviceTracing::unusedSlot;
+    }), step.end());
+    // a step begins with the calibration record: slot 0 of the log
+    for (size_t i = 0; i < step.size(); i++) {
+        step[i].padding = (uint32_t)i;
+    }
+    std::vector<Log> finish;
+    for (const Log &l : step) {
+        if (l.event == DeviceEvent::nodeStart) {
+            if (finish.size() <= l.nodeID) finish.resize(l.nodeID + 1, Log {});
+            Log f = l;      // (a kernel whose workgroups log nothing: zero length)
+            f.event = DeviceEvent::nodeFinish;
+            finish[l.nodeID] = f;
+        }
+    }
+    for (const Log &l : step) {
+        if (l.event == DeviceEvent::blockWait && l.nodeID < finish.size() &&
+                l.cycleCount >= finish[l.nodeID].cycleCount) {
+            Log &f = finish[l.nodeID];
+            f.cycleCount = l.cycleCount;
+            f.smID = l.smID;
+            f.warpID = l.warpID;
+            f.blockID = l.blockID;
+        }
+    }
+    uint32_t next = (uint32_t)step.size();
+    for (Log &f : finish) {
+        if (f.event != DeviceEvent::nodeFinish) continue;
+        f.padding = next++;
+        step.push_back(f);
+    }
+    exec->traceLogs.insert(exec->traceLogs.end(), step.begin(), step.end());
+    exec->traceSteps++;
+    // (until the next traced graph starts its step)
+    const int32_t off = -1;
+    HIPCHK(hipMemcpy(exec->deviceTracing, &off, sizeof(off), hipMemcpyHostToDevice));
+    return 0;
+}
+
+static void writeDeviceTrace(mwhip_exec *exec)
+{
+    if (exec->traceLogs.empty()) return;
+    const char *dir = getenv("MADRONA_MWHIP_TRACE_DIR");
+    const std::string path = dir != nullptr ? std::string(dir) + "/" : "/tmp/";
+    ::madrona::WriteToFile<mwGPU::DeviceTracing::DeviceLog>(
+        exec->traceLogs.data(), exec->traceLogs.size(), path,
+        "_madrona_device_tracing");
+    std::string names;
+    for (const std::string &n : exec->traceNames) {
+        names += n + "\n";
+    }
+    ::madrona::WriteToFile((void *)names.data(), names.size(), path,
+                           "_madrona_device_tracing_nodes");
+}
+#endif
+
 static int checkHealth(mwhip_exec *exec)
 {
     if (!exec->checkAfterRun) return 0;
@@ -3232,11 +3441,21 @@ extern "C" int mwhip_run(mwhip_exec *exec, uint64_t graph)
     drainHostPrints(exec, false);
     int rc = checkHealth(exec);
     if (rc != 0) return rc;
+#ifdef MADRONA_TRACING
+    rc = collectDeviceTrace(exec);
+    if (rc != 0) return rc;
+#endif
     return growTablesAfterReplay(exec);
 }
 
 extern "C" int mwhip_run_async(mwhip_exec *exec, uint64_t graph, void *hip_stream)
 {
+#ifdef MADRONA_TRACING
+    // every step's log is read back before the next one overwrites it
+    if ((hipStream_t)hip_stream == exec->stream) {
+        return mwhip_run(exec, graph);
+    }
+#endif
     auto it = exec->launchGraphs.find(graph);
     if (it == exec->launchGraphs.end()) {
         return fail(-3, "unknown launch graph");
@@ -3415,6 +3634,10 @@ extern "C" int mwhip_synchronize(mwhip_exec *exec)
     drainHostPrints(exec, false);
     int rc = checkHealth(exec);
     if (rc != 0) return rc;
+#ifdef MADRONA_TRACING
+    rc = collectDeviceTrace(exec);
+    if (rc != 0) return rc;
+#endif
     return growTablesAfterReplay(exec);
 }
 

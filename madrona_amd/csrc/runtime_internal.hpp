@@ -5,6 +5,7 @@
 
 #include <madrona/ecs.hpp>
 #include <madrona/mwhip/ecs_state.hpp>
+#include <madrona/mw_gpu/tracing.hpp>
 #include <mwhip.h>
 
 #include <algorithm>

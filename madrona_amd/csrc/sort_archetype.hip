@@ -141,6 +141,7 @@ __device__ inline uint32_t blockExclusiveScan256(uint32_t v, uint32_t *scratch,
 __global__ void __launch_bounds__(kSortThreads)
 sortHistogram(EcsState *S, const SortSite *sites)
 {
+    TraceScope trace_scope(S);
     const SortSite &site = sites[blockIdx.y];
     TableHdr &tbl = S->tables[site.archetype];
 
@@ -274,6 +275,7 @@ struct alignas(16) OnesweepLDS {
 __global__ void __launch_bounds__(kSortThreads)
 sortOnesweep(EcsState *S, const SortSite *sites, uint32_t pass)
 {
+    TraceScope trace_scope(S);
     const SortSite &site = sites[blockIdx.y];
     TableHdr &tbl = S->tables[site.archetype];
 
@@ -682,6 +684,7 @@ sortGather(EcsState *S, const SortSite *sites, const GatherColumn *columns,
            const GatherSlice *slices, const MiscOp *trailing_ops,
            uint32_t num_trailing_ops)
 {
+    TraceScope trace_scope(S);
     // (ResetTmpAlloc nodes that followed the chain in the task graph)
     if (blockIdx.x == 0) {
         applyMiscOps(S, trailing_ops, num_trailing_ops, threadIdx.x);
@@ -788,6 +791,7 @@ __global__ void __launch_bounds__(kSortThreads)
 sortFinalize(EcsState *S, const SortSite *sites, const MiscOp *trailing_ops,
              uint32_t num_trailing_ops)
 {
+    TraceScope trace_scope(S);
     if (blockIdx.x == 0 && blockIdx.y == 0) {
         applyMiscOps(S, trailing_ops, num_trailing_ops, threadIdx.x);
     }
@@ -962,6 +966,7 @@ sortSmall(EcsState *S, const SortSite *sites, const GatherColumn *columns,
           uint32_t num_columns, const MiscOp *trailing_ops,
           uint32_t num_trailing_ops)
 {
+    TraceScope trace_scope(S);
     if (blockIdx.x == 0) {
         applyMiscOps(S, trailing_ops, num_trailing_ops, threadIdx.x);
     }
@@ -1144,6 +1149,7 @@ __device__ inline int32_t compactSortTail(const SortSite &site, TableHdr &tbl,
 __global__ void __launch_bounds__(kSmallThreads)
 sortCompactPrepare(EcsState *S, const SortSite *sites)
 {
+    TraceScope trace_scope(S);
     const SortSite &site = sites[blockIdx.y];
     TableHdr &tbl = S->tables[site.archetype];
     SortState *state = site.state;
@@ -1383,6 +1389,7 @@ __device__ inline void compactScatterTile(const SortSite &site, CompactLDS<THREA
 __global__ void __launch_bounds__(kSortThreads)
 sortCompactScatter(EcsState *S, const SortSite *sites)
 {
+    TraceScope trace_scope(S);
     const SortSite &site = sites[blockIdx.y];
     TableHdr &tbl = S->tables[site.archetype];
     SortState *state = site.state;

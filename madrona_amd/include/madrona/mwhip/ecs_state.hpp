@@ -204,6 +204,11 @@ struct EcsState {
     uint32_t raycastOutputResolution;
     uint32_t raycastRGBD;
     GrowMailbox *growMailbox;       // pinned host memory, or nullptr
+    // MADRONA_TRACING builds of the runtime (mw_gpu/tracing.hpp): the device
+    // event log, and which kernel of the graph is running (written by a
+    // marker launch in front of every kernel); nullptr otherwise
+    void *deviceTracing;
+    void *traceCursor;
 };
 
 // Load through the constant address space: for data no kernel of the *user*

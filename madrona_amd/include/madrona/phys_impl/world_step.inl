@@ -444,6 +444,7 @@ __global__ void __launch_bounds__(256)
 __attribute__((amdgpu_waves_per_eu(MADRONA_PHYS_WAVES_PER_EU)))
 physicsStepKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
 {
+    mwhip::TraceScope trace_scope(S);
     StateManager *state_mgr = static_cast<StateManager *>(S);
     PhysicsScratch *ps = detail::scratch(S);
     const PhysicsStepParams params = *(const PhysicsStepParams *)node_data;
@@ -1133,6 +1134,7 @@ template <int MAXB>
 __global__ void __launch_bounds__(64)
 physicsPackKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
 {
+    mwhip::TraceScope trace_scope(S);
     using Block = WorldBlock<MAXB>;
 
     StateManager *state_mgr = static_cast<StateManager *>(S);
@@ -1205,6 +1207,7 @@ __attribute__((amdgpu_waves_per_eu(
     MAXB <= 64 && LPW == 64 ? MADRONA_PHYS_LDS_WAVES_PER_EU : 1)))
 physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
 {
+    mwhip::TraceScope trace_scope(S);
     using Block = WorldBlock<MAXB, LPW>;
     static_assert(LPW == 64 || (LPW == 32 && MAXB <= 32));
     constexpr int worlds_per_wave = 64 / LPW;

@@ -1013,6 +1013,7 @@ template <bool fill>
 __global__ void __launch_bounds__(256)
 candidateKernel(EcsState *S, void *, uint32_t, uint32_t)
 {
+    mwhip::TraceScope trace_scope(S);
     StateManager *state_mgr = static_cast<StateManager *>(S);
     PhysicsScratch *ps = detail::scratch(S);
 
@@ -1082,6 +1083,7 @@ candidateKernel(EcsState *S, void *, uint32_t, uint32_t)
 __global__ void __launch_bounds__(64)
 bvhUpdateKernel(EcsState *S, void *, uint32_t, uint32_t)
 {
+    mwhip::TraceScope trace_scope(S);
     constexpr int32_t max_leaves = 64;
     constexpr int32_t max_nodes = 21 + max_leaves;    // numInternalNodes(64)
 

@@ -23,6 +23,7 @@
 #include <madrona/query.hpp>
 #include <madrona/span.hpp>
 #include <madrona/state.hpp>
+#include <madrona/mw_gpu/tracing.hpp>
 
 #include <mwhip.h>
 
@@ -63,6 +64,42 @@ MADRONA_HD inline StateManager *getStateManager()
     return nullptr;
 #endif
 }
+
+#if defined(__HIPCC__)
+// mw_gpu/tracing.hpp: no-ops unless MADRONA_TRACING, as in the reference
+MADRONA_DEVICE inline void DeviceTracing::resetIndex()
+{
+#ifdef MADRONA_TRACING
+    DeviceTracing *t = get(getStateManager());
+    if (t != nullptr) {
+        __hip_atomic_store(&t->cur_index_, 0, __ATOMIC_RELEASE,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+#endif
+}
+
+MADRONA_DEVICE inline void DeviceTracing::Log([[maybe_unused]] DeviceEvent event,
+                                              [[maybe_unused]] uint32_t func_id,
+                                              [[maybe_unused]] uint32_t num_invocations,
+                                              [[maybe_unused]] uint32_t node_id)
+{
+#ifdef MADRONA_TRACING
+    LogTo(getStateManager(), event, func_id, num_invocations, node_id,
+          threadIdx.x == 0);
+#endif
+}
+
+MADRONA_DEVICE inline void DeviceTracing::Log([[maybe_unused]] DeviceEvent event,
+                                              [[maybe_unused]] uint32_t func_id,
+                                              [[maybe_unused]] uint32_t num_invocations,
+                                              [[maybe_unused]] uint32_t node_id,
+                                              [[maybe_unused]] bool is_leader)
+{
+#ifdef MADRONA_TRACING
+    LogTo(getStateManager(), event, func_id, num_invocations, node_id, is_leader);
+#endif
+}
+#endif
 
 }
 

@@ -189,6 +189,7 @@ __global__ void __launch_bounds__(256)
 parallelForKernel(EcsState *S, void *, uint32_t query_offset,
                   uint32_t num_matching_and_flags, mwhip_pfor_args query)
 {
+    TraceScope trace_scope(S);
     constexpr size_t N = sizeof...(ComponentTs);
     extern __shared__ int32_t pfor_snapshot_rows[];
 
@@ -266,6 +267,7 @@ __global__ void __launch_bounds__(256)
 parallelForBatchKernel(EcsState *S, void *, uint32_t query_offset,
                        uint32_t num_matching_and_flags, mwhip_pfor_args query)
 {
+    TraceScope trace_scope(S);
     constexpr size_t N = sizeof...(ComponentTs);
     extern __shared__ int32_t pfor_snapshot_rows[];
     const uint32_t num_matching = num_matching_and_flags & 0x7FFFFFFFu;
@@ -313,8 +315,9 @@ MADRONA_UNROLL
 // count is fixed or NodeT::numInvocations() evaluated on the device.
 template <typename NodeT, auto fn, bool dynamic_count>
 __global__ void __launch_bounds__(256)
-customNodeKernel(EcsState *, void *node_data, uint32_t fixed_count, uint32_t)
+customNodeKernel(EcsState *S, void *node_data, uint32_t fixed_count, uint32_t)
 {
+    TraceScope trace_scope(S);
     NodeT *node = (NodeT *)node_data;
 
     uint32_t count = fixed_count;
