@@ -404,6 +404,19 @@ int mwhip_pack_rows(mwhip_exec *exec, uint32_t num_columns,
                     const uint32_t *words_per_row, uint32_t num_rows,
                     void *dst);
 
+/* Device-resident input ring: the k-th replay (of any step graph of this
+ * executor, k = 0, 1, ...) after this call starts by copying slot k % num_slots
+ * of `ring` (num_slots x slot_bytes, device memory, whole dwords) into `dst` -- normally an exported
+ * action column (mwhip_exported) --, so that a policy's outputs for the next
+ * steps can be queued with the replays that consume them; nothing foreign sits
+ * on the executor's stream between two graph launches (which costs 20-35 us of
+ * launch pipelining each).  ring == NULL removes the ring of
+ * `dst`.  Rebuilds the launch graphs (handles stay valid); waits for the
+ * executor's stream.  (No reference counterpart: its managers write the action
+ * tensor between steps, include/madrona/mw_gpu.hpp:146 runAsync + PyTorch.) */
+int mwhip_set_input_ring(mwhip_exec *exec, void *dst, const void *ring,
+                         uint64_t slot_bytes, uint32_t num_slots);
+
 /* Queues a one-wave marker kernel (benchWindowMarker) on the executor's stream:
  * a pair of them brackets a measurement window in a rocprofv3 kernel trace
  * (profiles/summarize_rocprof.py trims to it).  Measurement only. */

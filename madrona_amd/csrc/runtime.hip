@@ -310,6 +310,25 @@ constexpr uint32_t kStatsReplays = 3 + 2 * kMaxArchetypes;  // replays completed
 constexpr uint32_t kStatsTails = 4 + 2 * kMaxArchetypes;    // [kMaxArchetypes]
 constexpr uint32_t kStatsWords = 4 + 3 * kMaxArchetypes;
 
+// First kernel of a step graph with an input ring (mwhip_set_input_ring): slot
+// (replays since the ring was set) % num_slots of a device-resident ring -> an exported
+// column, i.e. a new set of actions every step without the host touching the
+// executor's stream between two graph launches.
+__global__ void __launch_bounds__(256)
+inputRingKernel(EcsState *S, uint32_t *dst, const uint32_t *ring,
+                uint32_t slot_words, uint32_t num_slots, uint32_t first_replay)
+{
+    TraceScope trace_scope(S);
+    const uint32_t replay = __hip_atomic_load(S->replayCounter, __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t *src =
+        ring + (size_t)((replay - first_replay) % num_slots) * slot_words;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < slot_words;
+         i += gridDim.x * blockDim.x) {
+        dst[i] = src[i];
+    }
+}
+
 #ifdef MADRONA_TRACING
 // One thread in front of every kernel of a traced graph (mw_gpu/tracing.hpp):
 // calibration starts a step's log, nodeStart names the kernel whose
@@ -558,6 +577,16 @@ struct mwhip_exec {
     bool checkAfterRun = true;
     bool sortBatching = true;
     bool sortCarriesMisc = true;    // MADRONA_MWHIP_SORT_CARRIES_MISC
+
+    // mwhip_set_input_ring
+    struct InputRing {
+        uint32_t *dst;
+        const uint32_t *ring;
+        uint32_t slotWords;
+        uint32_t numSlots;
+        uint32_t firstReplay;   // replays completed when the ring was set
+    };
+    std::vector<InputRing> inputRings;
 
     // MADRONA_TRACING builds: the device event log (mw_gpu/tracing.hpp), the
     // records of the first steps, the names funcID indexes
@@ -1934,6 +1963,20 @@ static int buildLaunchList(mwhip_exec *exec, const std::vector<uint32_t> &tg_ids
         int rc = findScrambledTables(exec);
         if (rc != 0) return rc;
     }
+    if (!lg.isRender) {
+        for (const mwhip_exec::InputRing &ring : exec->inputRings) {
+            KernelLaunch k;
+            k.fn = (const void *)&inputRingKernel;
+            k.grid = dim3(std::min<uint32_t>((ring.slotWords + 255u) / 256u, 1024u), 1, 1);
+            k.block = dim3(256, 1, 1);
+            k.setArgs(exec->stateDev, ring.dst, ring.ring, ring.slotWords, ring.numSlots,
+                      ring.firstReplay);
+            k.name = "input";
+            k.role = "ring";
+            k.kind = MWHIP_NODE_RECYCLE;
+            lg.launches.push_back(k);
+        }
+    }
     for (uint32_t tg_id : tg_ids) {
         if (tg_id >= exec->taskGraphs.size()) {
             return fail(-3, "task graph %u does not exist", tg_id);
@@ -2213,50 +2256,6 @@ static int buildLaunchList(mwhip_exec *exec, const std::vector<uint32_t> &tg_ids
         k.kind = MWHIP_NODE_RECYCLE;
         lg.launches.push_back(k);
     }
-
-#ifdef MADRONA_TRACING
-    {
-        using mwGPU::DeviceEvent;
-        auto mark = [&](DeviceEvent event, uint32_t node_id, uint32_t func_id,
-                        uint32_t invocations, uint32_t workgroups) {
-            KernelLaunch k;
-            k.fn = (const void *)&traceMarkKernel;
-            k.grid = dim3(1, 1, 1);
-            k.block = dim3(256, 1, 1);
-            k.setArgs(exec->stateDev, (uint32_t)event, node_id, func_id, invocations,
-                      workgroups);
-            k.name = "trace";
-            k.role = "mark";
-            k.kind = MWHIP_NODE_RECYCLE;
-            return k;
-        };
-        hipDeviceProp_t prop;
-        HIPCHK(hipGetDeviceProperties(&prop, exec->cfg.gpu_id));
-        std::vector<KernelLaunch> traced;
-        traced.push_back(mark(DeviceEvent::calibration,
-                              (uint32_t)prop.multiProcessorCount, 4u, 0u, 0u));
-        uint32_t node_id = 0;
-        for (const KernelLaunch &k : lg.launches) {
-            const std::string label =
-                k.role[0] != '\0' ? k.name + ":" + k.role : k.name;
-            uint32_t func_id = 0;
-            while (func_id < exec->traceNames.size() &&
-                   exec->traceNames[func_id] != label) {
-                func_id++;
-            }
-            if (func_id == exec->traceNames.size()) {
-                exec->traceNames.push_back(label);
-            }
-            const uint32_t workgroups = k.grid.x * k.grid.y * k.grid.z;
-            traced.push_back(mark(DeviceEvent::nodeStart, node_id, func_id,
-                workgroups * k.block.x * k.block.y * k.block.z, workgroups));
-            traced.push_back(k);
-            node_id++;
-        }
-        traced.push_back(mark(DeviceEvent::blockExit, node_id, 0u, 0u, 0u));
-        lg.launches = std::move(traced);
-    }
-#endif
 
     return 0;
 }
@@ -2910,6 +2909,56 @@ static int renderLaunches(mwhip_exec *exec, std::vector<KernelLaunch> &out)
     return 0;
 }
 
+#ifdef MADRONA_TRACING
+// Marker launches (traceMarkKernel) around the kernels of a graph: called last,
+// when render / pack kernels have been spliced in.
+static int addTraceMarkers(mwhip_exec *exec, LaunchGraph &lg)
+{
+    {
+        using mwGPU::DeviceEvent;
+        auto mark = [&](DeviceEvent event, uint32_t node_id, uint32_t func_id,
+                        uint32_t invocations, uint32_t workgroups) {
+            KernelLaunch k;
+            k.fn = (const void *)&traceMarkKernel;
+            k.grid = dim3(1, 1, 1);
+            k.block = dim3(256, 1, 1);
+            k.setArgs(exec->stateDev, (uint32_t)event, node_id, func_id, invocations,
+                      workgroups);
+            k.name = "trace";
+            k.role = "mark";
+            k.kind = MWHIP_NODE_RECYCLE;
+            return k;
+        };
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, exec->cfg.gpu_id));
+        std::vector<KernelLaunch> traced;
+        traced.push_back(mark(DeviceEvent::calibration,
+                              (uint32_t)prop.multiProcessorCount, 4u, 0u, 0u));
+        uint32_t node_id = 0;
+        for (const KernelLaunch &k : lg.launches) {
+            const std::string label =
+                k.role[0] != '\0' ? k.name + ":" + k.role : k.name;
+            uint32_t func_id = 0;
+            while (func_id < exec->traceNames.size() &&
+                   exec->traceNames[func_id] != label) {
+                func_id++;
+            }
+            if (func_id == exec->traceNames.size()) {
+                exec->traceNames.push_back(label);
+            }
+            const uint32_t workgroups = k.grid.x * k.grid.y * k.grid.z;
+            traced.push_back(mark(DeviceEvent::nodeStart, node_id, func_id,
+                workgroups * k.block.x * k.block.y * k.block.z, workgroups));
+            traced.push_back(k);
+            node_id++;
+        }
+        traced.push_back(mark(DeviceEvent::blockExit, node_id, 0u, 0u, 0u));
+        lg.launches = std::move(traced);
+    }
+    return 0;
+}
+#endif
+
 static int instantiateLaunchGraph(mwhip_exec *exec,
                                   const std::vector<uint32_t> &ids,
                                   const std::string &stat_name,
@@ -2965,6 +3014,11 @@ static int instantiateLaunchGraph(mwhip_exec *exec,
         // before the health kernel that closes every replay
         lg->launches.insert(lg->launches.end() - 1, k);
     }
+
+#ifdef MADRONA_TRACING
+    rc = addTraceMarkers(exec, *lg);
+    if (rc != 0) return rc;
+#endif
 
     HIPCHK(hipStreamBeginCapture(exec->stream, hipStreamCaptureModeThreadLocal));
     for (KernelLaunch &k : lg->launches) {
@@ -3572,6 +3626,51 @@ extern "C" int mwhip_build_launch_graph_with_pack(
     exec->launchGraphs[handle] = std::move(lg);
     *graph_out = handle;
     return 0;
+}
+
+static int rebuildAllLaunchGraphs(mwhip_exec *exec)
+{
+    HIPCHK(hipStreamSynchronize(exec->stream));
+    for (auto &kv : exec->launchGraphs) {
+        std::unique_ptr<LaunchGraph> fresh;
+        int rc = instantiateLaunchGraph(exec, kv.second->taskGraphIds,
+                                        kv.second->statName, fresh,
+                                        kv.second.get());
+        if (rc != 0) return rc;
+        if (kv.second->graphExec) (void)hipGraphExecDestroy(kv.second->graphExec);
+        if (kv.second->graph) (void)hipGraphDestroy(kv.second->graph);
+        kv.second = std::move(fresh);
+    }
+    return 0;
+}
+
+extern "C" int mwhip_set_input_ring(mwhip_exec *exec, void *dst, const void *ring,
+                                    uint64_t slot_bytes, uint32_t num_slots)
+{
+    if (dst == nullptr) {
+        return fail(-2, "set_input_ring: no destination");
+    }
+    HIPCHK(hipSetDevice(exec->cfg.gpu_id));
+    auto &rings = exec->inputRings;
+    rings.erase(std::remove_if(rings.begin(), rings.end(),
+        [dst](const mwhip_exec::InputRing &r) { return r.dst == dst; }), rings.end());
+    if (ring != nullptr) {
+        if (num_slots == 0 || slot_bytes == 0 || slot_bytes % 4 != 0 ||
+                slot_bytes / 4 > 0xFFFFFFFFull) {
+            return fail(-2, "set_input_ring: %llu bytes x %u slots (whole dwords, "
+                        "at least one slot)", (unsigned long long)slot_bytes, num_slots);
+        }
+        if (rings.size() >= 4) {
+            return fail(-2, "set_input_ring: at most 4 rings");
+        }
+        // (every replay of every graph of the executor counts)
+        HIPCHK(hipStreamSynchronize(exec->stream));
+        uint32_t done = 0;
+        HIPCHK(hipMemcpy(&done, exec->replaySignal, sizeof(done), hipMemcpyDeviceToHost));
+        rings.push_back({ (uint32_t *)dst, (const uint32_t *)ring,
+                          (uint32_t)(slot_bytes / 4), num_slots, done });
+    }
+    return rebuildAllLaunchGraphs(exec);
 }
 
 // Another stream waits for every replay queued so far WITHOUT touching the

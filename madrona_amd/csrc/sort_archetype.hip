@@ -961,6 +961,53 @@ __device__ inline void oneGroupRadixPasses(SmallSortLDS &lds, int32_t num_passes
     }
 }
 
+// worldOffsets / worldCounts of a small table by ONE kSmallThreads-wide
+// workgroup: rows per world counted in LDS, exclusive scan, eight consecutive
+// worlds per thread.
+constexpr int32_t kSmallRangeWorlds = 8192;
+
+template <int THREADS>
+__device__ inline unsigned long long blockExclusiveScanU64(
+    unsigned long long v, unsigned long long *scratch);
+
+__device__ inline void smallWorldRanges(TableHdr &tbl, const uint32_t *sorted,
+                                        int32_t n_out, int32_t num_worlds,
+                                        uint32_t *world_rows,
+                                        unsigned long long *scan_scratch)
+{
+    const int32_t tid = (int32_t)threadIdx.x;
+    for (int32_t w = tid; w < kSmallRangeWorlds; w += kSmallThreads) {
+        world_rows[w] = 0;
+    }
+    __syncthreads();
+    for (int32_t i = tid; i < n_out; i += kSmallThreads) {
+        const uint32_t w = sorted[i];
+        if (w < (uint32_t)num_worlds) {
+            atomicAdd(&world_rows[w], 1u);
+        }
+    }
+    __syncthreads();
+    constexpr int32_t per_thread = kSmallRangeWorlds / kSmallThreads;
+    uint32_t mine[per_thread];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int32_t j = 0; j < per_thread; j++) {
+        mine[j] = world_rows[tid * per_thread + j];
+        sum += mine[j];
+    }
+    uint32_t run = (uint32_t)blockExclusiveScanU64<kSmallThreads>(sum, scan_scratch);
+#pragma unroll
+    for (int32_t j = 0; j < per_thread; j++) {
+        const int32_t w = tid * per_thread + j;
+        if (w < num_worlds) {
+            tbl.worldOffsets[w] = (int32_t)run;
+            tbl.worldCounts[w] = (int32_t)mine[j];
+        }
+        run += mine[j];
+    }
+    __syncthreads();
+}
+
 __global__ void __launch_bounds__(kSmallThreads)
 sortSmall(EcsState *S, const SortSite *sites, const GatherColumn *columns,
           uint32_t num_columns, const MiscOp *trailing_ops,
@@ -977,9 +1024,13 @@ sortSmall(EcsState *S, const SortSite *sites, const GatherColumn *columns,
     }
 
     __shared__ SmallSortLDS lds;
+    __shared__ uint32_t world_rows[kSmallRangeWorlds];
+    __shared__ unsigned long long range_scan[kSmallWaves];
 
     const int32_t n = tbl.numRows;
     const uint32_t tid = threadIdx.x;
+    const uint32_t *final_keys =
+        ((site.numPasses - 1) & 1) != 0 ? site.keysB : site.keysA;
 
     // (pass p writes buffer p & 1: the last one lands where the gather looks)
     const RadixBuffers buffers { { site.keysA, site.keysB },
@@ -1002,6 +1053,14 @@ sortSmall(EcsState *S, const SortSite *sites, const GatherColumn *columns,
     for (uint32_t c = 0; c < num_columns; c++) {
         const GatherColumn gc = columns[c];
         if (gc.site != blockIdx.x) continue;
+        if (gc.column == kWorldRangesColumn && S->numWorlds <= kSmallRangeWorlds) {
+            // Two binary searches per world are ~24 dependent loads each, and
+            // ONE workgroup doing them for 8192 worlds was 55 of this kernel's
+            // 70 us (device trace, joint table of 8192 Escape-Room worlds):
+            // count the rows of every world in LDS and scan instead.
+            smallWorldRanges(tbl, final_keys, n_out, S->numWorlds, world_rows, range_scan);
+            continue;
+        }
         gatherColumn(S, site, gc, tbl, n_out, (int32_t)tid, kSmallThreads);
     }
     __syncthreads();
@@ -1481,7 +1540,13 @@ int sortNumPasses(bool world_sort, uint32_t num_worlds)
 
 uint32_t sortTileSize() { return (uint32_t)kSortTile; }
 
-uint32_t sortSmallRowLimit() { return kSmallSortRows; }
+// (MADRONA_MWHIP_SORT_SMALL_ROWS overrides it: measurements)
+uint32_t sortSmallRowLimit()
+{
+    const char *e = getenv("MADRONA_MWHIP_SORT_SMALL_ROWS");
+    const uint32_t n = e != nullptr ? (uint32_t)strtoul(e, nullptr, 10) : 0u;
+    return n == 0 ? kSmallSortRows : n;
+}
 
 // rows behind the sorted prefix one workgroup sorts about as fast as the radix
 // chain would take for the whole table; tables that keep exceeding it go back

@@ -521,11 +521,38 @@ MWHIP_DEV inline void markRowAppender()
     *(volatile uint32_t *)&mwhip_row_appender_marker = 1u;
 }
 
+// One atomic per wavefront and table, not per lane: an atomic on one address
+// costs 11 ns serialised on an idle chip and several times that under load
+// (profiles/r02_atomic_microbench.txt) -- a system in which a few thousand
+// lanes each append one row spent its time queueing on the row counter.  The
+// lanes that are in this call together and append to the same table take
+// consecutive rows in lane order (deterministic, unlike arrival order).
 MWHIP_DEV inline int32_t appendRowIssue(TableHdr &tbl)
 {
     markRowAppender();
-    tbl.needsSort = 1u;
-    return atomicAddI32(&tbl.numRows, 1);
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const unsigned long long mine = (unsigned long long)&tbl;
+    unsigned long long todo = __ballot(1);
+    int32_t row = 0;
+    while (todo != 0ull) {
+        const int leader = __builtin_ctzll(todo);
+        const unsigned long long lead_tbl =
+            ((unsigned long long)(uint32_t)__shfl((int32_t)(mine >> 32), leader, 64) << 32) |
+            (unsigned long long)(uint32_t)__shfl((int32_t)mine, leader, 64);
+        const bool same = mine == lead_tbl;
+        const unsigned long long group = __ballot(same) & todo;
+        if (same) {
+            int32_t base = 0;
+            if ((int)lane == leader) {
+                tbl.needsSort = 1u;
+                base = atomicAddI32(&tbl.numRows, (int32_t)__builtin_popcountll(group));
+            }
+            base = __shfl(base, leader, 64);
+            row = base + (int32_t)__builtin_popcountll(group & ((1ull << lane) - 1ull));
+        }
+        todo &= ~group;
+    }
+    return row;
 }
 
 // Slow path of appendRowCheck: the row lies past what the table's header says

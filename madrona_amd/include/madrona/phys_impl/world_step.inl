@@ -1230,9 +1230,17 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
     unsigned long long prof_acc[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 #endif
 
-    for (int32_t world = (int32_t)blockIdx.x * worlds_per_wave + group;
-         world < num_worlds;
-         world += (int32_t)gridDim.x * worlds_per_wave) {
+    // Worlds are taken in the order physicsOrderKernel left: the ones that took
+    // longest last step first, so that the launch does not end on a few heavy
+    // worlds with most of the chip idle (and the two worlds of a wavefront,
+    // neighbours in that order, cost about the same).
+    const int32_t *world_order = params.worldOrder;
+    for (int32_t slot = (int32_t)blockIdx.x * worlds_per_wave + group;
+         slot < num_worlds;
+         slot += (int32_t)gridDim.x * worlds_per_wave) {
+        const int32_t world = world_order != nullptr ? world_order[slot] : slot;
+        const long long cost_t0 = (long long)wall_clock64();
+        uint32_t cost_work = 1;    // (what the world asked of the wavefront, roughly)
         Context ctx = TaskGraph::makeContext<Context>(
             state_mgr, WorldID { world }, true);
         const ObjectManager &hbm_obj_mgr = *ctx.singleton<ObjectData>().mgr;
@@ -1519,6 +1527,7 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
 
                 PHYS_PROF(3);
                 uint64_t hull_pairs = wave::groupBallot<LPW>(kind == 2);
+                cost_work += 24u * (uint32_t)__builtin_popcountll(hull_pairs);
                 constexpr int hull_lanes = Block::hullLanes;
                 constexpr int hull_groups = Block::hullGroups;
                 static_assert(hull_groups == 1 || hull_groups == 2);
@@ -1613,6 +1622,7 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
             if (contacts_overflow) {
                 mwhip::raiseError(S, mwhip::kErrTableOverflow);
             }
+            cost_work += 8u * num_contacts;
             wave::phaseFence();
             PHYS_PROF(5);
 
@@ -1717,6 +1727,20 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
         }
         wave::phaseFence();
         PHYS_PROF(7);
+
+        // what this world cost: the wavefront's time, shared out between its two
+        // worlds (they run in lock step: the clock alone cannot tell them apart)
+        if (params.worldCost != nullptr) {
+            uint32_t cost = (uint32_t)((long long)wall_clock64() - cost_t0);
+            if (LPW == 32) {
+                const uint32_t other = __shfl_xor(cost_work, 32, 64);
+                const uint32_t most = cost_work > other ? cost_work : other;
+                cost = (uint32_t)(((uint64_t)cost * cost_work) / most);
+            }
+            if (lane == 0) {
+                params.worldCost[world] = cost;
+            }
+        }
     }
 
 #ifdef MADRONA_PHYS_PROFILE
@@ -1727,4 +1751,58 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
         }
     }
 #endif
+}
+
+// Heaviest worlds first (longest-processing-time order): a counting sort of the
+// worlds by what they cost last step, 256 buckets, one 1024-thread workgroup.
+// The order only decides WHEN a world is stepped, never the result.
+__global__ void __launch_bounds__(1024)
+physicsOrderKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
+{
+    mwhip::TraceScope trace_scope(S);
+    const PhysicsStepParams params = *(const PhysicsStepParams *)node_data;
+    const int32_t num_worlds = S->numWorlds;
+    const uint32_t tid = threadIdx.x;
+
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t wave_max[16];
+    __shared__ uint32_t most_shared;
+
+    uint32_t most = 0;
+    for (int32_t w = (int32_t)tid; w < num_worlds; w += 1024) {
+        const uint32_t c = params.worldCost[w];
+        most = c > most ? c : most;
+    }
+    most = wave::maxReduce<64>(most);
+    if (tid < 256) hist[tid] = 0;
+    if (tid % 64 == 0) wave_max[tid / 64] = most;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t m = 1;
+        for (int i = 0; i < 16; i++) m = wave_max[i] > m ? wave_max[i] : m;
+        most_shared = m;
+    }
+    __syncthreads();
+    most = most_shared;
+
+    auto bucket_of = [most](uint32_t cost) {
+        return 255u - (uint32_t)(((uint64_t)cost * 255ull) / most);
+    };
+    for (int32_t w = (int32_t)tid; w < num_worlds; w += 1024) {
+        atomicAdd(&hist[bucket_of(params.worldCost[w])], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (int b = 0; b < 256; b++) {
+            const uint32_t n = hist[b];
+            hist[b] = run;
+            run += n;
+        }
+    }
+    __syncthreads();
+    for (int32_t w = (int32_t)tid; w < num_worlds; w += 1024) {
+        const uint32_t at = atomicAdd(&hist[bucket_of(params.worldCost[w])], 1u);
+        params.worldOrder[at] = w;
+    }
 }

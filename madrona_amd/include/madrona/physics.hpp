@@ -169,6 +169,28 @@ MADRONA_HD inline broadphase::LeafID registerEntity(
 template <typename Fn>
 MADRONA_HD inline void findEntitiesWithinAABB(Context &ctx, math::AABB aabb,
                                               Fn &&fn);
+#if defined(__HIPCC__)
+// This backend, device code only: for each of num_boxes query boxes the FIRST
+// entity findEntitiesWithinAABB would report for which accept(entity) holds
+// (Entity::none() if there is none), found by the 64 lanes of the calling
+// wavefront together: a lane per BVH leaf answering for all boxes, instead of a
+// tree walk per box with a chain of dependent loads per hit.  Every lane calls
+// with the same boxes; `accept` is evaluated by different lanes for different
+// entities and must not have side effects; the queries see the state as it is
+// when the call is made.  For systems that run a wavefront per world
+// (CustomParallelForNode<..., 64, 1, ...>).
+template <int MAX_BOXES, typename Fn>
+MADRONA_DEVICE inline void findFirstEntitiesWithinAABBsWave(Context &ctx,
+                                                            const math::AABB *boxes,
+                                                            int32_t num_boxes,
+                                                            Entity *out,
+                                                            Fn &&accept);
+template <typename Fn>
+MADRONA_DEVICE inline Entity findFirstEntityWithinAABBWave(Context &ctx,
+                                                           math::AABB aabb,
+                                                           Fn &&accept);
+#endif
+
 MADRONA_HD inline bool checkEntityAABBOverlap(Context &ctx, math::AABB aabb,
                                               Entity e);
 

@@ -73,6 +73,11 @@ struct PhysicsStepParams {
     // right before the step kernel reads them), or nullptr: the step kernel
     // reads the tables itself
     void *worldImages;
+    // LDS step kernels: what every world cost the last time it was stepped
+    // (100 MHz ticks), and the worlds sorted by it, heaviest first
+    // (physicsOrderKernel); nullptr: worlds are stepped in index order
+    uint32_t *worldCost;
+    int32_t *worldOrder;
 };
 
 namespace detail {
@@ -1243,6 +1248,191 @@ MADRONA_HD inline void findEntitiesWithinAABB(Context &ctx,
     });
 }
 
+#if defined(__HIPCC__)
+// checkEntityAABBOverlap(ctx, boxes[b], e) for every b < num_boxes at once (bit b
+// of the result): the transformed primitive boxes and the hull's extents along
+// the world axes do not depend on the query box and are computed once.  Same
+// expressions in the same order as the single-box function, so the bits are
+// what num_boxes separate calls return.
+template <int MAX_BOXES>
+MADRONA_DEVICE inline uint32_t checkEntityAABBsOverlap(Context &ctx,
+                                                       const math::AABB *boxes,
+                                                       int32_t num_boxes,
+                                                       uint32_t candidates,
+                                                       Entity e)
+{
+    using namespace math;
+    static_assert(MAX_BOXES <= 32);
+
+    const ObjectManager &obj_mgr = *ctx.singleton<ObjectData>().mgr;
+
+    base::ObjectID e_obj_id = ctx.get<base::ObjectID>(e);
+    Vector3 e_pos = ctx.get<base::Position>(e);
+    Quat e_rot = ctx.get<base::Rotation>(e);
+    Diag3x3 e_scale = ctx.get<base::Scale>(e);
+
+    uint32_t num_prims = obj_mgr.rigidBodyPrimitiveCounts[e_obj_id.idx];
+    uint32_t base_prim_offset = obj_mgr.rigidBodyPrimitiveOffsets[e_obj_id.idx];
+
+    uint32_t result = 0;
+    for (uint32_t prim_offset = 0; prim_offset < num_prims; prim_offset++) {
+        uint32_t prim_idx = base_prim_offset + prim_offset;
+
+        const CollisionPrimitive &prim = obj_mgr.collisionPrimitives[prim_idx];
+        if (prim.type != CollisionPrimitive::Type::Hull) {
+            continue;
+        }
+
+        AABB prim_aabb = obj_mgr.primitiveAABBs[prim_idx];
+        AABB txfmed_aabb = prim_aabb.applyTRS(e_pos, e_rot, e_scale);
+
+        // boxes this primitive can still decide (a box an earlier primitive
+        // accepted stays accepted: the single-box function returns there)
+        uint32_t open = 0;
+        for (int32_t b = 0; b < num_boxes; b++) {
+            if (((candidates & ~result) >> b & 1u) != 0u &&
+                    txfmed_aabb.overlaps(boxes[b])) {
+                open |= 1u << b;
+            }
+        }
+        if (open == 0u) {
+            continue;
+        }
+
+        // exact extent of the transformed hull along the world axes
+        const Vector3 *vertices = prim.hull.halfEdgeMesh.vertices;
+        CountT num_verts = (CountT)prim.hull.halfEdgeMesh.numVertices;
+
+        const Vector3 axes[3] { right, fwd, up };
+        float min_hull_projs[3] { FLT_MAX, FLT_MAX, FLT_MAX };
+        float max_hull_projs[3] { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+
+#pragma clang loop unroll(disable)
+        for (CountT vert_idx = 0; vert_idx < num_verts; vert_idx++) {
+            Vector3 v = e_rot.rotateVec(e_scale * vertices[vert_idx]) + e_pos;
+
+            for (CountT i = 0; i < 3; i++) {
+                float proj = dot(v, axes[i]);
+                if (proj < min_hull_projs[i]) {
+                    min_hull_projs[i] = proj;
+                }
+                if (proj > max_hull_projs[i]) {
+                    max_hull_projs[i] = proj;
+                }
+            }
+        }
+
+        for (int32_t b = 0; b < num_boxes; b++) {
+            if ((open >> b & 1u) == 0u) {
+                continue;
+            }
+            bool axes_overlap = true;
+            for (CountT i = 0; i < 3; i++) {
+                bool proj_overlap = max_hull_projs[i] > boxes[b].pMin[i] &&
+                    boxes[b].pMax[i] > min_hull_projs[i];
+                if (!proj_overlap) {
+                    axes_overlap = false;
+                }
+            }
+            if (axes_overlap) {
+                result |= 1u << b;
+            }
+        }
+    }
+
+    return result;
+}
+
+template <int MAX_BOXES, typename Fn>
+MADRONA_DEVICE inline void findFirstEntitiesWithinAABBsWave(Context &ctx,
+                                                            const math::AABB *boxes,
+                                                            int32_t num_boxes,
+                                                            Entity *out,
+                                                            Fn &&accept)
+{
+    const broadphase::BVH &bvh = ctx.singleton<broadphase::BVH>();
+    const uint32_t lane = threadIdx.x % 64u;
+    for (int32_t b = 0; b < num_boxes; b++) {
+        out[b] = Entity::none();
+    }
+    if (num_boxes <= 0) {
+        return;
+    }
+
+    if (bvh.needsRebuild()) {
+        // (no traversal order yet: one lane walks the tree, box after box)
+        for (int32_t b = 0; b < num_boxes; b++) {
+            Entity found = Entity::none();
+            if (lane == 0) {
+                findEntitiesWithinAABB(ctx, boxes[b], [&](Entity e) {
+                    if (found == Entity::none() && accept(e)) {
+                        found = e;
+                    }
+                });
+            }
+            out[b] = Entity { (uint32_t)__shfl((int32_t)found.gen, 0, 64),
+                              __shfl(found.id, 0, 64) };
+        }
+        return;
+    }
+
+    // A query reports its leaves as a subsequence of the tree's full traversal
+    // order, and it reaches a leaf iff it overlaps the leaf's slot box (ancestor
+    // boxes contain it: refits only grow them) -- BVH::traversalOrder.  Lane i
+    // takes the i-th leaf of that order and answers for every box; per box the
+    // first accepting lane wins.
+    const int32_t n = bvh.numLeaves();
+    const int32_t *order = bvh.traversalOrder();
+    uint32_t open = num_boxes >= 32 ? 0xFFFFFFFFu : (1u << num_boxes) - 1u;
+    for (int32_t base = 0; base < n && open != 0u; base += 64) {
+        const int32_t i = base + (int32_t)lane;
+        Entity e = Entity::none();
+        uint32_t hits = 0;
+        if (i < n) {
+            const int32_t leaf = order[i];
+            const math::AABB slot = bvh.leafSlotBounds(leaf);
+            uint32_t reached = 0;
+            for (int32_t b = 0; b < num_boxes; b++) {
+                if ((open >> b & 1u) != 0u && boxes[b].overlaps(slot)) {
+                    reached |= 1u << b;
+                }
+            }
+            if (reached != 0u) {
+                e = bvh.leafEntity(leaf);
+                hits = checkEntityAABBsOverlap<MAX_BOXES>(ctx, boxes, num_boxes,
+                                                          reached, e);
+                if (hits != 0u && !accept(e)) {
+                    hits = 0u;
+                }
+            }
+        }
+        for (int32_t b = 0; b < num_boxes; b++) {
+            if ((open >> b & 1u) == 0u) {
+                continue;
+            }
+            const unsigned long long mask = __ballot((hits >> b & 1u) != 0u);
+            if (mask != 0ull) {
+                const int first = __builtin_ctzll(mask);
+                out[b] = Entity { (uint32_t)__shfl((int32_t)e.gen, first, 64),
+                                  __shfl(e.id, first, 64) };
+                open &= ~(1u << b);
+            }
+        }
+    }
+}
+
+template <typename Fn>
+MADRONA_DEVICE inline Entity findFirstEntityWithinAABBWave(Context &ctx,
+                                                           math::AABB aabb,
+                                                           Fn &&accept)
+{
+    Entity found;
+    findFirstEntitiesWithinAABBsWave<1>(ctx, &aabb, 1, &found,
+                                        std::forward<Fn>(accept));
+    return found;
+}
+#endif
+
 MADRONA_HD inline bool checkEntityAABBOverlap(Context &ctx,
                                               math::AABB aabb,
                                               Entity e)
@@ -1282,6 +1472,9 @@ MADRONA_HD inline bool checkEntityAABBOverlap(Context &ctx,
         float min_hull_projs[3] { FLT_MAX, FLT_MAX, FLT_MAX };
         float max_hull_projs[3] { -FLT_MAX, -FLT_MAX, -FLT_MAX };
 
+        // (rolled: unrolled eight times it takes 116 registers, and its callers are
+        // latency-bound systems that want wavefronts in flight, not registers)
+#pragma clang loop unroll(disable)
         for (CountT vert_idx = 0; vert_idx < num_verts; vert_idx++) {
             Vector3 v = e_rot.rotateVec(e_scale * vertices[vert_idx]) + e_pos;
 
@@ -1680,6 +1873,9 @@ MADRONA_HOST_API inline TaskGraphNodeID setupPhysicsStepTasks(
         default: return (const void *)&kernels::physicsPackKernel<128>;
         }
     };
+    [[maybe_unused]] auto order_stub = [] __host__ () -> const void * {
+        return (const void *)&kernels::physicsOrderKernel;
+    };
     [[maybe_unused]] auto image_bytes = [] __host__ (int max_bodies) -> size_t {
         switch (max_bodies) {
         case 32: return kernels::WorldBlock<32>::imageBytes();
@@ -1690,6 +1886,7 @@ MADRONA_HOST_API inline TaskGraphNodeID setupPhysicsStepTasks(
 #else
     auto step_stub = [](int, int) -> const void * { return nullptr; };
     auto pack_stub = [](int) -> const void * { return nullptr; };
+    auto order_stub = []() -> const void * { return nullptr; };
     auto image_bytes = [](int) -> size_t { return 0; };
 #endif
 
@@ -1764,8 +1961,36 @@ MADRONA_HOST_API inline TaskGraphNodeID setupPhysicsStepTasks(
                   mwhip_last_error());
         }
     }
+    // Heaviest worlds first: without it the launch ends on a few contact-rich
+    // worlds with most SIMDs idle (device trace, 8192 Escape-Room worlds: the
+    // last quarter of the kernel ran a third of the chip).
+    // MADRONA_MWHIP_PHYS_ORDER=0 steps the worlds in index order.
+    uint32_t *world_cost = nullptr;
+    int32_t *world_order = nullptr;
+    const char *order_env = getenv("MADRONA_MWHIP_PHYS_ORDER");
+    if (max_bodies != 0 && (order_env == nullptr || atoi(order_env) != 0)) {
+        const uint64_t bytes = (uint64_t)mwhip_num_worlds(exec) * 4u;
+        world_cost = (uint32_t *)mwhip_alloc_device(exec, bytes, 1);
+        world_order = (int32_t *)mwhip_alloc_device(exec, bytes, 1);
+        if (world_cost == nullptr || world_order == nullptr) {
+            FATAL("madrona_amd physics: world order allocation failed: %s",
+                  mwhip_last_error());
+        }
+    }
     auto params = builder.constructNodeData<PhysicsStepParams>(
-        PhysicsStepParams { (int32_t)num_substeps, 0, world_images });
+        PhysicsStepParams { (int32_t)num_substeps, 0, world_images, world_cost,
+                            world_order });
+
+    if (world_order != nullptr) {
+        mwhip_node_desc order {};
+        order.kind = MWHIP_NODE_KERNEL;
+        order.name = "physics:orderWorlds";
+        order.kernel = order_stub();
+        order.count_mode = MWHIP_COUNT_FIXED;
+        order.fixed_count = 1;
+        order.threads_per_invocation = 1024;
+        cur_node = builder.addRuntimeNode(order, params.id, {cur_node});
+    }
 
     if (world_images != nullptr) {
         mwhip_node_desc pack {};

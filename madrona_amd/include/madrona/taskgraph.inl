@@ -183,9 +183,21 @@ MADRONA_DEVICE inline void pforRowSnapshot(EcsState *S, PforRowSync *sync,
     __syncthreads();
 }
 
+// Waves per SIMD a system's kernel is compiled for, i.e. its register budget
+// (512 / waves VGPRs per lane); 0 = the compiler's choice.  A system that is a
+// chain of dependent loads with one wavefront per world (a BVH query, entity
+// creation) and inlines enough code to take 150+ registers runs a quarter of
+// the worlds at a time; a simulator caps it with
+//   template <> inline constexpr unsigned madrona::mwhip::systemWavesPerSIMD<fn> = 4;
+// before its setupTasks.  (Measured both ways: the lidar systems -- arithmetic
+// heavy -- lose from more waves, profiles/r03_lidar_occupancy_variants.jsonl.)
+template <auto Fn>
+inline constexpr unsigned systemWavesPerSIMD = 0;
+
 template <typename ContextT, auto Fn, int32_t threads_per_invocation,
           typename... ComponentTs>
 __global__ void __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(systemWavesPerSIMD<Fn>)))
 parallelForKernel(EcsState *S, void *, uint32_t query_offset,
                   uint32_t num_matching_and_flags, mwhip_pfor_args query)
 {

@@ -90,6 +90,8 @@ def main(argv=None):
     ap.add_argument("--nodes", help="kernel names, one per line (funcID = line number)")
     ap.add_argument("--step", type=int, default=-1, help="which step to print (default: last)")
     ap.add_argument("--json", action="store_true")
+    ap.add_argument("--node", type=int, default=None,
+                    help="also print the workgroup statistics of this node")
     args = ap.parse_args(argv)
 
     nodes_path = args.nodes
@@ -119,7 +121,42 @@ def main(argv=None):
         print(f"{n['nodeID']:4d} {n['start_ns'] / 1e3:9.2f} {n['duration_ns'] / 1e3:8.2f} "
               f"{n['percent_of_kernels']:5.1f} {n['workgroups']:6d} {n['compute_units']:4d} "
               f"{mean} {mx}  {n['name']}")
+    if args.node is not None:
+        print_node(steps[args.step], args.node)
     return 0
+
+
+def print_node(step, nid):
+    """How a kernel's workgroups spread over its duration: the quantiles of their
+    own run times, and when which share of them had started / finished."""
+    s = step[(step["event"] == BLOCK_START) & (step["nodeID"] == nid)]
+    w = step[(step["event"] == BLOCK_WAIT) & (step["nodeID"] == nid)]
+    if not len(s) or len(s) != len(w):
+        print(f"node {nid}: no complete workgroup records")
+        return
+    s = s[np.argsort(s["numInvocations"], kind="stable")]
+    w = w[np.argsort(w["numInvocations"], kind="stable")]
+    t0 = int(s["cycleCount"].min())
+    begin = s["cycleCount"].astype(np.int64) - t0
+    end = w["cycleCount"].astype(np.int64) - t0
+    run = end - begin
+    q = [0, 10, 50, 90, 99, 100]
+    print(f"node {nid}: {len(s)} workgroups, kernel {end.max() / 1e3:.1f} us")
+    print("  run time us, percentiles " + str(q) + ": " +
+          " ".join(f"{np.percentile(run, p) / 1e3:.1f}" for p in q))
+    print("  started by us, percentiles:  " +
+          " ".join(f"{np.percentile(begin, p) / 1e3:.1f}" for p in q))
+    print("  finished by us, percentiles: " +
+          " ".join(f"{np.percentile(end, p) / 1e3:.1f}" for p in q))
+    # workgroups in flight over time (20 bins)
+    edges = np.linspace(0, end.max(), 21)
+    mids = 0.5 * (edges[1:] + edges[:-1])
+    flight = [(int(((begin <= m) & (end > m)).sum())) for m in mids]
+    print("  in flight at 2.5 %, 7.5 %, ... of the kernel: " + " ".join(map(str, flight)))
+    # dispatch order: mean run time of each tenth of the workgroups, by index
+    tenths = np.array_split(run, 10)
+    print("  mean run time us by tenth of the workgroup index: " +
+          " ".join(f"{t.mean() / 1e3:.1f}" for t in tenths if len(t)))
 
 
 if __name__ == "__main__":

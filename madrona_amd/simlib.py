@@ -138,6 +138,9 @@ def runtime_lib() -> C.CDLL:
         C.POINTER(C.c_uint32), C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64)]
     lib.mwhip_stream_wait_replays.restype = C.c_int
     lib.mwhip_stream_wait_replays.argtypes = [C.c_void_p, C.c_void_p]
+    lib.mwhip_set_input_ring.restype = C.c_int
+    lib.mwhip_set_input_ring.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_uint64, C.c_uint32]
     lib.mwhip_mark_window.restype = C.c_int
     lib.mwhip_mark_window.argtypes = [C.c_void_p, C.c_uint32]
     lib.mwhip_pack_rows.restype = C.c_int
@@ -325,6 +328,20 @@ class Simulator:
             if rc != 0:
                 raise RuntimeError(
                     f"mwhip_run_async -> {rc}: {rt.mwhip_last_error().decode()}")
+
+    def set_input_ring(self, name: str, ring_ptr: int, num_slots: int) -> None:
+        """The k-th replay after this call starts by copying slot k % num_slots
+        of the device-resident ring at `ring_ptr` (num_slots x the tensor's
+        bytes) into exported tensor `name` (mwhip_set_input_ring); ring_ptr = 0
+        removes the ring."""
+        rt = runtime_lib()
+        _, dtype, dims, _ = self._tensor_info[name]
+        slot_bytes = int(np.prod(dims)) * dtype.itemsize
+        rc = rt.mwhip_set_input_ring(self.hip_exec(), self.tensor_ptr(name),
+                                     ring_ptr or None, slot_bytes, num_slots)
+        if rc != 0:
+            raise RuntimeError(f"mwhip_set_input_ring -> {rc}: "
+                               f"{rt.mwhip_last_error().decode()}")
 
     def stream_wait_replays(self, hip_stream: int) -> None:
         """Makes `hip_stream` (a hipStream_t) wait for every replay queued so

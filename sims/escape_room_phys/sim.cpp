@@ -407,6 +407,81 @@ inline void movementSystem(Engine &,
 // invocation per world, agents in order: entity creation order inside a world
 // is then the same on every backend (parallel per-agent creation would make
 // joint ids depend on scheduling).
+// (kept out of line on the GPU: inlined into grabSystem, the joint record and the
+// entity bookkeeping push its kernel to 178 registers, i.e. two wavefronts per
+// SIMD for a system that is nothing but dependent loads)
+#ifdef MADRONA_GPU_MODE
+#define ESCPHYS_COLD __attribute__((noinline))
+#else
+#define ESCPHYS_COLD
+#endif
+
+ESCPHYS_COLD static void attachGrab(Engine &ctx, Entity e, Entity grab_entity,
+                                    Vector3 pos, Quat rot, GrabState &grab)
+{
+    Vector3 other_pos = ctx.get<Position>(grab_entity);
+    Quat other_rot = ctx.get<Rotation>(grab_entity);
+
+    Vector3 r1 = Vector3 { 0.f, 1.25f, 0.f };
+    Vector3 r2 = Vector3::zero();
+    Quat attach1 { 1, 0, 0, 0 };
+    Quat attach2 = (other_rot.inv() * rot).normalize();
+    float separation = (other_pos - pos).length() - 1.25f;
+
+    grab.constraintEntity = PhysicsSystem::makeFixedJoint(
+        ctx, e, grab_entity, attach1, attach2, r1, r2, separation);
+}
+
+ESCPHYS_COLD static void releaseGrab(Engine &ctx, Entity held, GrabState &grab)
+{
+    ctx.destroyEntity(held);
+    grab.constraintEntity = Entity::none();
+}
+
+#ifdef MADRONA_GPU_MODE
+// The GPU graph splits the grab in two.  This node runs a wavefront per world
+// (CustomParallelForNode<..., 64, 1, ...>): the box queries of all agents that
+// reach for something, a lane per BVH leaf (grabbing moves no body, so the
+// queries see what the CPU's sequential loop sees).  grabSystem then runs one
+// lane per world and only creates / destroys joints: lanes of a wavefront that
+// append to one table share one atomic, waves of their own would queue on it.
+inline void grabQuerySystem(Engine &ctx, LevelState &)
+{
+    Sim &sim = ctx.data();
+
+    AABB boxes[consts::numAgents];
+    int32_t owner[consts::numAgents];
+    int32_t num_boxes = 0;
+    for (int32_t i = 0; i < consts::numAgents; i++) {
+        Entity e = sim.agents[i];
+        if (ctx.get<Action>(e).grab == 0 ||
+                ctx.get<GrabState>(e).constraintEntity != Entity::none()) {
+            continue;
+        }
+        Vector3 reach = ctx.get<Position>(e) +
+            ctx.get<Rotation>(e).rotateVec(Vector3 { 0.f, 1.75f, 0.f });
+        boxes[num_boxes] = AABB {
+            reach - Vector3 { 1.f, 1.f, 1.f },
+            reach + Vector3 { 1.f, 1.f, 1.f },
+        };
+        owner[num_boxes++] = i;
+    }
+    Entity first[consts::numAgents];
+    PhysicsSystem::findFirstEntitiesWithinAABBsWave<consts::numAgents>(
+        ctx, boxes, num_boxes, first, [&](Entity other) {
+            return ctx.get<EntityType>(other) == EntityType::Cube;
+        });
+    if (threadIdx.x % 64 == 0) {
+        for (int32_t i = 0; i < consts::numAgents; i++) {
+            sim.grabTargets[i] = Entity::none();
+        }
+        for (int32_t b = 0; b < num_boxes; b++) {
+            sim.grabTargets[owner[b]] = first[b];
+        }
+    }
+}
+#endif
+
 inline void grabSystem(Engine &ctx, LevelState &)
 {
     Sim &sim = ctx.data();
@@ -419,14 +494,16 @@ inline void grabSystem(Engine &ctx, LevelState &)
 
         GrabState &grab = ctx.get<GrabState>(e);
         if (grab.constraintEntity != Entity::none()) {
-            ctx.destroyEntity(grab.constraintEntity);
-            grab.constraintEntity = Entity::none();
+            releaseGrab(ctx, grab.constraintEntity, grab);
             continue;
         }
 
         Vector3 pos = ctx.get<Position>(e);
         Quat rot = ctx.get<Rotation>(e);
 
+#ifdef MADRONA_GPU_MODE
+        Entity grab_entity = sim.grabTargets[i];
+#else
         Vector3 reach = pos + rot.rotateVec(Vector3 { 0.f, 1.75f, 0.f });
         AABB reach_box {
             reach - Vector3 { 1.f, 1.f, 1.f },
@@ -443,22 +520,11 @@ inline void grabSystem(Engine &ctx, LevelState &)
                     grab_entity = other;
                 }
             });
+#endif
 
-        if (grab_entity == Entity::none()) {
-            continue;
+        if (grab_entity != Entity::none()) {
+            attachGrab(ctx, e, grab_entity, pos, rot, grab);
         }
-
-        Vector3 other_pos = ctx.get<Position>(grab_entity);
-        Quat other_rot = ctx.get<Rotation>(grab_entity);
-
-        Vector3 r1 = Vector3 { 0.f, 1.25f, 0.f };
-        Vector3 r2 = Vector3::zero();
-        Quat attach1 { 1, 0, 0, 0 };
-        Quat attach2 = (other_rot.inv() * rot).normalize();
-        float separation = (other_pos - pos).length() - 1.25f;
-
-        grab.constraintEntity = PhysicsSystem::makeFixedJoint(
-            ctx, e, grab_entity, attach1, attach2, r1, r2, separation);
     }
 }
 
@@ -1016,10 +1082,19 @@ void Sim::setupTasks(TaskGraphManager &taskgraph_mgr, const Config &)
     auto broadphase_setup_sys =
         PhysicsSystem::setupBroadphaseTasks(builder, {move_sys});
 
+#ifdef MADRONA_GPU_MODE
+    // 64 lanes per world: the grab queries test a BVH leaf per lane
+    auto grab_query_sys = builder.addToGraph<CustomParallelForNode<Engine,
+        grabQuerySystem, 64, 1,
+            LevelState
+        >>({broadphase_setup_sys});
+#else
+    auto grab_query_sys = broadphase_setup_sys;
+#endif
     auto grab_sys = builder.addToGraph<ParallelForNode<Engine,
         grabSystem,
             LevelState
-        >>({broadphase_setup_sys});
+        >>({grab_query_sys});
 
     auto substep_sys = PhysicsSystem::setupPhysicsStepTasks(builder,
         {grab_sys}, consts::numPhysicsSubsteps);

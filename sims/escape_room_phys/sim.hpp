@@ -308,6 +308,12 @@ struct Sim : public madrona::WorldBase {
     Entity floorPlane;
     Entity borders[consts::numBorderWalls];
     Entity agents[consts::numAgents];
+
+#ifdef MADRONA_GPU_MODE
+    // what grabQuerySystem found in front of each agent this step, for
+    // grabSystem (sim.cpp)
+    Entity grabTargets[consts::numAgents];
+#endif
 };
 
 class Engine : public madrona::CustomContext<Engine, Sim> {

@@ -384,6 +384,45 @@ inline void lockSystem(Engine &ctx, LevelState &)
 {
     Sim &sim = ctx.data();
 
+#ifdef MADRONA_GPU_MODE
+    // 64 lanes per world (CustomParallelForNode<..., 64, 1, ...>).  First the
+    // box queries of all agents that press the lock button, a lane per BVH leaf
+    // (locking moves nothing, so they see what the sequential loop sees); then
+    // lane 0 toggles the locks agent by agent, in the CPU's order.
+    Entity found[consts::numAgents];
+    {
+        AABB boxes[consts::numAgents];
+        int32_t owner[consts::numAgents];
+        int32_t num_boxes = 0;
+        for (int32_t i = 0; i < consts::numAgents; i++) {
+            Entity e = sim.agents[i];
+            found[i] = Entity::none();
+            if (ctx.get<Action>(e).lock == 0) {
+                continue;
+            }
+            Vector3 reach = ctx.get<Position>(e) +
+                ctx.get<Rotation>(e).rotateVec(Vector3 { 0.f, 1.6f, 0.f });
+            boxes[num_boxes] = AABB {
+                reach - Vector3 { 1.f, 1.f, 1.f },
+                reach + Vector3 { 1.f, 1.f, 1.f },
+            };
+            owner[num_boxes++] = i;
+        }
+        Entity first[consts::numAgents];
+        PhysicsSystem::findFirstEntitiesWithinAABBsWave<consts::numAgents>(
+            ctx, boxes, num_boxes, first, [&](Entity other) {
+                EntityType type = ctx.get<EntityType>(other);
+                return type == EntityType::Box || type == EntityType::Ramp;
+            });
+        for (int32_t b = 0; b < num_boxes; b++) {
+            found[owner[b]] = first[b];
+        }
+    }
+    if (threadIdx.x % 64 != 0) {
+        return;
+    }
+#endif
+
     for (int32_t i = 0; i < consts::numAgents; i++) {
         Entity e = sim.agents[i];
         if (ctx.get<Action>(e).lock == 0) {
@@ -391,6 +430,9 @@ inline void lockSystem(Engine &ctx, LevelState &)
         }
         const int32_t is_hider = i < consts::numHiders ? 1 : 0;
 
+#ifdef MADRONA_GPU_MODE
+        Entity target = found[i];
+#else
         Vector3 pos = ctx.get<Position>(e);
         Quat rot = ctx.get<Rotation>(e);
 
@@ -411,6 +453,7 @@ inline void lockSystem(Engine &ctx, LevelState &)
                     target = other;
                 }
             });
+#endif
 
         if (target == Entity::none()) {
             continue;
@@ -911,8 +954,14 @@ void Sim::setupTasks(TaskGraphManager &taskgraph_mgr, const Config &)
     auto broadphase_setup_sys =
         PhysicsSystem::setupBroadphaseTasks(builder, {move_sys});
 
+#ifdef MADRONA_GPU_MODE
+    // 64 lanes per world: the lock queries test a BVH leaf per lane
+    auto lock_sys = builder.addToGraph<CustomParallelForNode<Engine,
+        lockSystem, 64, 1,
+#else
     auto lock_sys = builder.addToGraph<ParallelForNode<Engine,
         lockSystem,
+#endif
             LevelState
         >>({broadphase_setup_sys});
 

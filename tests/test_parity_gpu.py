@@ -788,3 +788,37 @@ def test_entity_store_and_scratch_region_grow(built, monkeypatch):
         pairs = np.unique(np.stack([ref_ids[:, 1], hip_ids[:, 1]], 1), axis=0)
         assert len(np.unique(pairs[:, 0])) == len(pairs) == len(np.unique(pairs[:, 1]))
         assert rt.mwhip_num_table_growths(h.hip_exec()) >= 1
+
+
+@pytest.mark.parametrize("sim,worlds", [("escape_room", 300), ("escape_room_phys", 64)])
+def test_input_ring_feeds_actions(built, sim, worlds):
+    """mwhip_set_input_ring: replays queued back to back take their actions from
+    a device-resident ring, slot (replays completed) % slots -- the same run as
+    writing the action tensor before every step."""
+    import torch
+    from madrona_amd.tensor import to_torch
+    slots, steps = 5, 23
+    rng = np.random.default_rng(4)
+    ring = np.stack([np.stack([rng.integers(0, 4, (worlds, 2)), rng.integers(0, 8, (worlds, 2)),
+                               rng.integers(-2, 3, (worlds, 2)),
+                               rng.integers(0, 2, (worlds, 2))], -1)
+                     for _ in range(slots)]).astype(np.int32)
+    with Simulator(hip_lib_path(sim), worlds, seed=3, flags=9) as a, \
+            Simulator(hip_lib_path(sim), worlds, seed=3, flags=9) as b:
+        dev = torch.from_numpy(ring).cuda()
+        a.set_input_ring("action", dev.data_ptr(), slots)
+        a.step_async(steps)
+        a.sync()
+        for step in range(steps):
+            b.write_tensor("action", ring[step % slots])
+            b.step(1)
+        assert not compare_columns(a.dump_all(), b.dump_all())
+        # (the simulators clear the actions of worlds they reset)
+        assert np.array_equal(a.read_tensor("action"), b.read_tensor("action"))
+        # removing the ring: the tensor is the caller's again
+        a.set_input_ring("action", 0, 1)
+        for s in (a, b):
+            s.write_tensor("action", ring[0])
+            s.step(3)
+        assert not compare_columns(a.dump_all(), b.dump_all())
+        del dev, to_torch
