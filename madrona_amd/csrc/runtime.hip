@@ -449,7 +449,8 @@ struct ArchetypeRec {
     uint32_t flags = 0;
     uint32_t maxPerWorld = 0;
     bool singleton = false;
-    bool bigSort = false;           // outgrew the single-launch sort once
+    bool bigSort = false;
+    uint32_t smallBusy = 0;     // consecutive reports of a busy one-launch sort           // outgrew the single-launch sort once
     // world sorts of this table take the compaction chain unless something
     // other than world sorts reorders / truncates it (a sort by another key,
     // ClearTmp, a scan node writing its row count: scrambled), or its appended
@@ -3264,10 +3265,26 @@ static int sortsOutgrown(mwhip_exec *exec)
             for (const SortSiteHost &site : batch->sites) {
                 int64_t rows = site.archetype < kMaxArchetypes ?
                     exec->statsHost[kStatsRows + site.archetype] : 0;
-                if (rows * 2 > (int64_t)sortSmallRowLimit() &&
-                        !exec->archetypes[site.archetype].bigSort) {
-                    exec->archetypes[site.archetype].bigSort = true;
+                ArchetypeRec &arch = exec->archetypes[site.archetype];
+                if (rows * 2 > (int64_t)sortSmallRowLimit() && !arch.bigSort) {
+                    arch.bigSort = true;
                     rebuild = true;
+                }
+                // One workgroup moving a few thousand rows is slower than the
+                // compaction chain's three launches (8192 Escape-Room worlds,
+                // ~2 K joints re-sorted every step: 50 us against 27); the one
+                // launch wins while the table is tiny or mostly idle (4 us
+                // against 3 x 4 when nothing changed).  Three reports in a
+                // row above the mark move a world-sorted table to the chain.
+                if (!arch.bigSort && site.worldSort &&
+                        compactionEligible(exec, site.archetype, 1u) &&
+                        rows >= (int64_t)sortSmallBusyRows()) {
+                    if (++arch.smallBusy >= 3u) {
+                        arch.bigSort = true;
+                        rebuild = true;
+                    }
+                } else {
+                    arch.smallBusy = 0;
                 }
             }
         }

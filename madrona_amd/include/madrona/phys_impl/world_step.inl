@@ -1088,37 +1088,56 @@ __device__ inline void loadWorldBodies(uint32_t lane, WorldBlock<MAXB, LPW> *dst
                                        int32_t num_bodies)
 {
     for (int32_t k = (int32_t)lane; k < num_bodies; k += LPW) {
-        Loc loc = bodies.loc(k);
-        dst->bodyLoc[k] = loc;
-        dst->pos[k] = ctx.getDirect<base::Position>(RGDCols::Position, loc);
-        dst->rot[k] = ctx.getDirect<base::Rotation>(RGDCols::Rotation, loc);
-        dst->scale[k] = ctx.getDirect<base::Scale>(RGDCols::Scale, loc);
-        dst->vel[k] = ctx.getDirect<Velocity>(RGDCols::Velocity, loc);
-        dst->extForce[k] =
+        const Loc loc = bodies.loc(k);
+
+        // Everything is read into registers before anything is written to the
+        // block: `dst` and the columns are generic pointers, so a store to the
+        // block between two column reads orders them -- load, wait, store,
+        // load, wait, store ... was a chain of ~20 round trips per world (14 %
+        // of the step kernel, profiles/r03_physics_phases_*); like this the
+        // row is three rounds: the columns; what the object id and the leaf id
+        // lead to; the leaf's slot in its parent node.
+        const base::Position pos =
+            ctx.getDirect<base::Position>(RGDCols::Position, loc);
+        const base::Rotation rot =
+            ctx.getDirect<base::Rotation>(RGDCols::Rotation, loc);
+        const base::Scale scale = ctx.getDirect<base::Scale>(RGDCols::Scale, loc);
+        const Velocity vel = ctx.getDirect<Velocity>(RGDCols::Velocity, loc);
+        const ExternalForce ext_force =
             ctx.getDirect<ExternalForce>(RGDCols::ExternalForce, loc);
-        dst->extTorque[k] =
+        const ExternalTorque ext_torque =
             ctx.getDirect<ExternalTorque>(RGDCols::ExternalTorque, loc);
-
-        ResponseType resp =
+        const ResponseType resp =
             ctx.getDirect<ResponseType>(RGDCols::ResponseType, loc);
-        dst->resp[k] = (uint32_t)resp;
         const int32_t entity_id = ctx.getDirect<Entity>(0, loc).id;
-        dst->entityID[k] = entity_id;
-
-        base::ObjectID obj_id =
+        const base::ObjectID obj_id =
             ctx.getDirect<base::ObjectID>(RGDCols::ObjectID, loc);
-        const RigidBodyMetadata metadata = hbm_obj_mgr.metadata[obj_id.idx];
-        dst->constants[k] = xpbd::bodyConstants(metadata, resp);
-        dst->primOffset[k] = (uint16_t)
-            hbm_obj_mgr.rigidBodyPrimitiveOffsets[obj_id.idx];
-        dst->primCount[k] = (uint16_t)
-            hbm_obj_mgr.rigidBodyPrimitiveCounts[obj_id.idx];
-
-        int32_t leaf = ctx.getDirect<broadphase::LeafID>(
+        const int32_t leaf = ctx.getDirect<broadphase::LeafID>(
             RGDCols::LeafID, loc).id;
+
+        const RigidBodyMetadata metadata = hbm_obj_mgr.metadata[obj_id.idx];
+        const uint32_t prim_offset =
+            hbm_obj_mgr.rigidBodyPrimitiveOffsets[obj_id.idx];
+        const uint32_t prim_count =
+            hbm_obj_mgr.rigidBodyPrimitiveCounts[obj_id.idx];
+        const math::AABB query_box = bvh.getLeafAABB(broadphase::LeafID { leaf });
+        const math::AABB slot_box = bvh.leafSlotBounds(leaf);
         const uint32_t rank = leaf_rank[leaf];
-        dst->queryBox()[k] = bvh.getLeafAABB(broadphase::LeafID { leaf });
-        dst->rankSlotBox()[rank] = bvh.leafSlotBounds(leaf);
+
+        dst->bodyLoc[k] = loc;
+        dst->pos[k] = pos;
+        dst->rot[k] = rot;
+        dst->scale[k] = scale;
+        dst->vel[k] = vel;
+        dst->extForce[k] = ext_force;
+        dst->extTorque[k] = ext_torque;
+        dst->resp[k] = (uint32_t)resp;
+        dst->entityID[k] = entity_id;
+        dst->constants[k] = xpbd::bodyConstants(metadata, resp);
+        dst->primOffset[k] = (uint16_t)prim_offset;
+        dst->primCount[k] = (uint16_t)prim_count;
+        dst->queryBox()[k] = query_box;
+        dst->rankSlotBox()[rank] = slot_box;
         dst->rankEntity()[rank] = entity_id;
         dst->orderBody[rank] = (uint16_t)k;
     }
@@ -1714,16 +1733,23 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
         PHYS_PROF(6);
         // ---- store: LDS -> HBM --------------------------------------------------
         for (int32_t k = (int32_t)lane; k < num_bodies; k += LPW) {
-            Loc loc = w->bodyLoc[k];
-            ctx.getDirect<base::Position>(RGDCols::Position, loc) = w->pos[k];
-            ctx.getDirect<base::Rotation>(RGDCols::Rotation, loc) = w->rot[k];
-            ctx.getDirect<Velocity>(RGDCols::Velocity, loc) = w->vel[k];
+            // (out of the block first, then the stores: see loadWorldBodies)
+            const Loc loc = w->bodyLoc[k];
+            const base::Position pos = w->pos[k];
+            const base::Rotation rot = w->rot[k];
+            const Velocity vel = w->vel[k];
+            const xpbd::SubstepPrevState prev = w->prev[k];
+            const xpbd::PreSolvePositional pre_pos = w->prePos[k];
+            const xpbd::PreSolveVelocity pre_vel = w->preVel[k];
+            ctx.getDirect<base::Position>(RGDCols::Position, loc) = pos;
+            ctx.getDirect<base::Rotation>(RGDCols::Rotation, loc) = rot;
+            ctx.getDirect<Velocity>(RGDCols::Velocity, loc) = vel;
             ctx.getDirect<xpbd::SubstepPrevState>(
-                xpbd::XPBDCols::SubstepPrevState, loc) = w->prev[k];
+                xpbd::XPBDCols::SubstepPrevState, loc) = prev;
             ctx.getDirect<xpbd::PreSolvePositional>(
-                xpbd::XPBDCols::PreSolvePositional, loc) = w->prePos[k];
+                xpbd::XPBDCols::PreSolvePositional, loc) = pre_pos;
             ctx.getDirect<xpbd::PreSolveVelocity>(
-                xpbd::XPBDCols::PreSolveVelocity, loc) = w->preVel[k];
+                xpbd::XPBDCols::PreSolveVelocity, loc) = pre_vel;
         }
         wave::phaseFence();
         PHYS_PROF(7);

@@ -16,11 +16,15 @@ with Simulator(hip_lib_path('escape_room_phys'), W, seed=5, flags=200) as hip:
     rt.mwhip_alloc_device.argtypes = [C.c_void_p, C.c_uint64, C.c_int]
     rt.mwhip_set_module_data.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
     rt.mwhip_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    import torch
     rng = np.random.default_rng(0)
-    a = np.stack([rng.integers(0, 4, (W, 2)), rng.integers(0, 8, (W, 2)),
-                  rng.integers(-2, 3, (W, 2)), rng.integers(0, 2, (W, 2))], -1).astype(np.int32)
-    hip.write_tensor('action', a)
-    hip.step(50)
+    # a new action set every step (the bench's input ring)
+    ring = np.stack([np.stack([rng.integers(0, 4, (W, 2)), rng.integers(0, 8, (W, 2)),
+                               rng.integers(-2, 3, (W, 2)), rng.integers(0, 2, (W, 2))], -1)
+                     for _ in range(61)]).astype(np.int32)
+    dev = torch.from_numpy(ring).cuda()
+    hip.set_input_ring('action', dev.data_ptr(), 61)
+    hip.step(300)
     buf = rt.mwhip_alloc_device(hip.hip_exec(), 96, 1)
     rt.mwhip_set_module_data(hip.hip_exec(), 1, buf)
     N = 50
