@@ -13,24 +13,6 @@ O=$R/gpurun_out/refresh
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 
-timeout 300 python $R/bench.py > $O/${ROUND}_bench_default.json 2> $O/bench_default.err
-timeout 200 python $R/bench.py --sim hideseek > $O/${ROUND}_bench_hideseek_w8192.json 2> $O/bench_hideseek.err
-timeout 200 python $R/bench.py --sim escape_room --steps 3000 > $O/${ROUND}_bench_escape_room_w4096.json 2> $O/bench_er.err
-timeout 200 python $R/bench.py --sim escape_room --worlds 65536 --steps 300 --no-cpu-baseline > $O/${ROUND}_bench_escape_room_w65536.json 2> $O/bench_er64k.err
-timeout 300 python $R/bench.py --sim escape_room_render > $O/${ROUND}_bench_escape_room_render_w8192.json 2> $O/bench_render.err
-
-prof() {   # name, command...
-  name=$1; shift
-  rm -rf /tmp/prof_$name
-  timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_$name -o out -- "$@" \
-      > $O/${ROUND}_${name}_under_rocprof.json 2> $O/${name}_under_rocprof.err
-  db=$(find /tmp/prof_$name -name '*.db' | head -1)
-  python $R/profiles/summarize_rocprof.py $db $O/${ROUND}_${name}_kernel_stats
-}
-prof bench_escape_room_phys_w8192 python $R/bench.py --steps 300 --warmup 100 --no-cpu-baseline --no-secondary
-prof render_config5_w8192 python $R/bench.py --sim escape_room_render --steps 100 --warmup 20 --no-cpu-baseline
-prof bench_hideseek_w8192 python $R/bench.py --sim hideseek --steps 300 --warmup 100 --no-cpu-baseline --no-secondary
-
 pmc() {    # sim, worlds, bench args...
   sim=$1; worlds=$2; shift; shift
   for ctr in FETCH_SIZE WRITE_SIZE; do
@@ -93,3 +75,26 @@ json.dump({"_comment": "SQ instruction / cycle counters per LAUNCH (rocprofv3 --
            "entries": entries}, open("$O/${ROUND}_issue_counters.json", "w"), indent=1)
 PYEOF
 ls -la $O
+
+# bench.py copies the recorded traffic / issue counters into its rooflines: the
+# files of THIS refresh, so they go where it looks before the bench lines run
+cp $O/${ROUND}_hbm_traffic.json $O/${ROUND}_issue_counters.json $R/profiles/ 2>/dev/null
+
+timeout 300 python $R/bench.py > $O/${ROUND}_bench_default.json 2> $O/bench_default.err
+timeout 200 python $R/bench.py --sim hideseek > $O/${ROUND}_bench_hideseek_w8192.json 2> $O/bench_hideseek.err
+timeout 200 python $R/bench.py --sim escape_room --steps 3000 > $O/${ROUND}_bench_escape_room_w4096.json 2> $O/bench_er.err
+timeout 200 python $R/bench.py --sim escape_room --worlds 65536 --steps 300 --no-cpu-baseline > $O/${ROUND}_bench_escape_room_w65536.json 2> $O/bench_er64k.err
+timeout 300 python $R/bench.py --sim escape_room_render > $O/${ROUND}_bench_escape_room_render_w8192.json 2> $O/bench_render.err
+
+prof() {   # name, command...
+  name=$1; shift
+  rm -rf /tmp/prof_$name
+  timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_$name -o out -- "$@" \
+      > $O/${ROUND}_${name}_under_rocprof.json 2> $O/${name}_under_rocprof.err
+  db=$(find /tmp/prof_$name -name '*.db' | head -1)
+  python $R/profiles/summarize_rocprof.py $db $O/${ROUND}_${name}_kernel_stats
+}
+prof bench_escape_room_phys_w8192 python $R/bench.py --steps 300 --warmup 100 --no-cpu-baseline --no-secondary
+prof render_config5_w8192 python $R/bench.py --sim escape_room_render --steps 100 --warmup 20 --no-cpu-baseline
+prof bench_hideseek_w8192 python $R/bench.py --sim hideseek --steps 300 --warmup 100 --no-cpu-baseline --no-secondary
+
