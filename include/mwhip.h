@@ -411,8 +411,9 @@ int mwhip_pack_rows(mwhip_exec *exec, uint32_t num_columns,
  * steps can be queued with the replays that consume them; nothing foreign sits
  * on the executor's stream between two graph launches (which costs 20-35 us of
  * launch pipelining each).  ring == NULL removes the ring of
- * `dst`.  Rebuilds the launch graphs (handles stay valid); waits for the
- * executor's stream.  (No reference counterpart: its managers write the action
+ * `dst`.  The ring belongs to the caller and must stay allocated until it is
+ * removed or the executor destroyed.  Rebuilds the launch graphs (handles stay
+ * valid); waits for the executor's stream.  (No reference counterpart: its managers write the action
  * tensor between steps, include/madrona/mw_gpu.hpp:146 runAsync + PyTorch.) */
 int mwhip_set_input_ring(mwhip_exec *exec, void *dst, const void *ring,
                          uint64_t slot_bytes, uint32_t num_slots);
