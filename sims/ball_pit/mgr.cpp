@@ -285,6 +285,8 @@ void SimTraits::describeTensors(T &out, uint32_t num_worlds)
     out.push_back({ "reset", SIM_I32, { W, 1 }, (uint32_t)ExportID::Reset });
     out.push_back({ "steps_remaining", SIM_I32, { W, 1 },
                     (uint32_t)ExportID::StepsRemaining });
+    out.push_back({ "query_probe", SIM_I32, { W, 2 },
+                    (uint32_t)ExportID::QueryProbe });
 }
 
 template <typename T>

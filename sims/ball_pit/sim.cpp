@@ -24,6 +24,7 @@ void Sim::registerTypes(ECSRegistry &registry, const Config &)
     registry.registerSingleton<WorldReset>();
     registry.registerSingleton<StepsRemaining>();
     registry.registerSingleton<LevelState>();
+    registry.registerSingleton<QueryProbe>();
 
     registry.registerArchetype<MovableObject>();
     registry.registerArchetype<StaticObject>();
@@ -31,6 +32,7 @@ void Sim::registerTypes(ECSRegistry &registry, const Config &)
     registry.exportSingleton<WorldReset>((uint32_t)ExportID::Reset);
     registry.exportSingleton<StepsRemaining>(
         (uint32_t)ExportID::StepsRemaining);
+    registry.exportSingleton<QueryProbe>((uint32_t)ExportID::QueryProbe);
 }
 
 static inline float randInRange(RNG &rng, float lo, float hi)
@@ -286,6 +288,56 @@ inline void kickSystem(Engine &ctx, LevelState &level)
     ctx.get<ExternalTorque>(level.movable[target]) = torque;
 }
 
+// Four box queries per world and step around objects picked by the step count:
+// the first dynamic body findEntitiesWithinAABB reports in each (QueryProbe).
+inline void probeSystem(Engine &ctx, QueryProbe &probe)
+{
+    constexpr int32_t num_boxes = 4;
+    const LevelState &level = ctx.singleton<LevelState>();
+    const int32_t t = ctx.singleton<StepsRemaining>().t;
+
+    math::AABB boxes[num_boxes];
+    for (int32_t k = 0; k < num_boxes; k++) {
+        const Entity anchor =
+            level.movable[(uint32_t)(t * 3 + k * 5) % (uint32_t)consts::numMovable];
+        const Vector3 centre = ctx.get<Position>(anchor) +
+            Vector3 { ((float)k - 1.5f) * 0.7f, 0.3f, 0.f };
+        const float half = 0.6f + 0.45f * (float)k;
+        boxes[k] = math::AABB {
+            .pMin = centre - Vector3 { half, half, half },
+            .pMax = centre + Vector3 { half, half, half },
+        };
+    }
+    auto accept = [&](Entity e) {
+        return ctx.get<ResponseType>(e) == ResponseType::Dynamic;
+    };
+
+    Entity first[num_boxes];
+#ifdef MADRONA_GPU_MODE
+    // (CustomParallelForNode<..., 64, 1, ...>: a wavefront per world)
+    PhysicsSystem::findFirstEntitiesWithinAABBsWave<num_boxes>(
+        ctx, boxes, num_boxes, first, accept);
+    if (threadIdx.x % 64 != 0) {
+        return;
+    }
+#else
+    for (int32_t k = 0; k < num_boxes; k++) {
+        first[k] = Entity::none();
+        PhysicsSystem::findEntitiesWithinAABB(ctx, boxes[k], [&](Entity e) {
+            if (first[k] == Entity::none() && accept(e)) {
+                first[k] = e;
+            }
+        });
+    }
+#endif
+
+    for (int32_t k = 0; k < num_boxes; k++) {
+        probe.digest = probe.digest * 0x9E3779B1u +
+            (uint32_t)(first[k].id + 1) * 31u + first[k].gen;
+        probe.found += first[k] != Entity::none() ? 1 : 0;
+    }
+}
+
 inline void resetSystem(Engine &ctx, WorldReset &reset)
 {
     Sim &sim = ctx.data();
@@ -323,8 +375,18 @@ void Sim::setupTasks(TaskGraphManager &taskgraph_mgr, const Config &)
     auto broadphase_setup_sys =
         PhysicsSystem::setupBroadphaseTasks(builder, {kick_sys});
 
+#ifdef MADRONA_GPU_MODE
+    auto probe_sys = builder.addToGraph<CustomParallelForNode<Engine,
+        probeSystem, 64, 1,
+#else
+    auto probe_sys = builder.addToGraph<ParallelForNode<Engine,
+        probeSystem,
+#endif
+            QueryProbe
+        >>({broadphase_setup_sys});
+
     auto substep_sys = PhysicsSystem::setupPhysicsStepTasks(builder,
-        {broadphase_setup_sys}, consts::numPhysicsSubsteps);
+        {probe_sys}, consts::numPhysicsSubsteps);
 
     auto phys_done =
         PhysicsSystem::setupCleanupTasks(builder, {substep_sys});
@@ -365,6 +427,7 @@ Sim::Sim(Engine &ctx, const Config &cfg, const WorldInit &)
     overlapMode = cfg.overlapMode;
 
     ctx.singleton<WorldReset>().reset = 0;
+    ctx.singleton<QueryProbe>() = QueryProbe { 0u, 0 };
 
     PhysicsSystem::init(ctx, cfg.rigidBodyObjMgr, consts::deltaT,
         consts::numPhysicsSubsteps, -9.8f * math::up,

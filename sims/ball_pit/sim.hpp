@@ -55,6 +55,7 @@ inline constexpr int32_t maxRigidBodies = 24 + maxExtra;
 enum class ExportID : uint32_t {
     Reset,
     StepsRemaining,
+    QueryProbe,
     NumExports,
 };
 
@@ -84,6 +85,15 @@ struct LevelState {
     // bodies: they must be solved in order)
     Entity joints[consts::numJoints];
     Entity extra[consts::maxExtra];
+};
+
+// Running digest of PhysicsSystem box queries made every step (probeSystem):
+// the CPU build asks findEntitiesWithinAABB, the GPU build the wave-cooperative
+// findFirstEntitiesWithinAABBsWave -- equal digests = equal answers on worlds
+// with spheres, multi-primitive objects and (crowd mode) more leaves than lanes.
+struct QueryProbe {
+    uint32_t digest;
+    int32_t found;
 };
 
 // which movable object this is (kick schedule)
