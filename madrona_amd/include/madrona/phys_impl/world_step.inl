@@ -375,21 +375,82 @@ __device__ inline bool collidePairLane(const PairSetup &pair, float *row,
 }
 
 struct WorldBodies {
-    uint32_t numArchetypes;
-    uint32_t archetype[PhysicsScratch::maxBodyArchetypes];
-    int32_t rowBase[PhysicsScratch::maxBodyArchetypes];
-    int32_t bodyBase[PhysicsScratch::maxBodyArchetypes + 1];
+    // Every loop over these arrays is fully unrolled with the bound below and
+    // predicated on numArchetypes: indexed by a run-time value they live in
+    // scratch memory, and filling them was a chain of scratch round trips at
+    // the head of every world (8 % of the step kernel's cycles).
+    static constexpr uint32_t maxArchetypes = PhysicsScratch::maxBodyArchetypes;
 
-    __device__ inline int32_t count() const { return bodyBase[numArchetypes]; }
+    uint32_t numArchetypes;
+    uint32_t archetype[maxArchetypes];
+    int32_t rowBase[maxArchetypes];
+    int32_t bodyBase[maxArchetypes + 1];
+
+    __device__ inline int32_t count() const
+    {
+        int32_t n = 0;
+#pragma unroll
+        for (uint32_t a = 0; a < maxArchetypes; a++) {
+            if (a < numArchetypes) {
+                n = bodyBase[a + 1];
+            }
+        }
+        return n;
+    }
 
     // k-th body of the world in the CPU backend's iteration order
     __device__ inline Loc loc(int32_t k) const
     {
-        uint32_t a = 0;
-        while (a + 1 < numArchetypes && k >= bodyBase[a + 1]) {
-            a++;
+        uint32_t arch = archetype[0];
+        int32_t row = rowBase[0] + k;
+#pragma unroll
+        for (uint32_t a = 1; a < maxArchetypes; a++) {
+            if (a < numArchetypes && k >= bodyBase[a]) {
+                arch = archetype[a];
+                row = rowBase[a] + (k - bodyBase[a]);
+            }
         }
-        return Loc { archetype[a], rowBase[a] + (k - bodyBase[a]) };
+        return Loc { arch, row };
+    }
+
+    // row ranges of `world` in the rigid-body tables; false: a table is unsorted
+    __device__ inline bool fill(mwhip::EcsState *S, const PhysicsScratch *ps,
+                                int32_t world)
+    {
+        numArchetypes = ps->numBodyArchetypes;
+        // (the pointers first, then what they lead to: two rounds of loads)
+        const int32_t *offsets[maxArchetypes];
+        const int32_t *counts[maxArchetypes];
+        uint32_t unsorted = 0;
+#pragma unroll
+        for (uint32_t a = 0; a < maxArchetypes; a++) {
+            offsets[a] = nullptr;
+            counts[a] = nullptr;
+            archetype[a] = 0;
+            if (a < numArchetypes) {
+                archetype[a] = ps->bodyArchetypes[a];
+                const mwhip::TableHdr &tbl = S->tables[archetype[a]];
+                offsets[a] = tbl.worldOffsets;
+                counts[a] = tbl.worldCounts;
+                unsorted |= tbl.needsSort;
+            }
+        }
+        int32_t rows[maxArchetypes];
+#pragma unroll
+        for (uint32_t a = 0; a < maxArchetypes; a++) {
+            rowBase[a] = 0;
+            rows[a] = 0;
+            if (a < numArchetypes) {
+                rowBase[a] = offsets[a][world];
+                rows[a] = counts[a][world];
+            }
+        }
+        bodyBase[0] = 0;
+#pragma unroll
+        for (uint32_t a = 0; a < maxArchetypes; a++) {
+            bodyBase[a + 1] = bodyBase[a] + rows[a];
+        }
+        return unsorted == 0;
     }
 };
 
@@ -486,17 +547,7 @@ physicsStepKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
 
         // ---- the world's bodies ---------------------------------------------
         WorldBodies bodies;
-        bodies.numArchetypes = ps->numBodyArchetypes;
-        bodies.bodyBase[0] = 0;
-        bool unsorted = false;
-        for (uint32_t a = 0; a < bodies.numArchetypes; a++) {
-            const TableHdr &tbl = S->tables[ps->bodyArchetypes[a]];
-            bodies.archetype[a] = ps->bodyArchetypes[a];
-            bodies.rowBase[a] = tbl.worldOffsets[world];
-            bodies.bodyBase[a + 1] =
-                bodies.bodyBase[a] + tbl.worldCounts[world];
-            unsorted = unsorted || tbl.needsSort != 0;
-        }
+        const bool unsorted = !bodies.fill(S, ps, world);
         if (unsorted) {
             mwhip::raiseError(S, mwhip::kErrPhysics);
             continue;
@@ -1173,17 +1224,7 @@ physicsPackKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
         const broadphase::BVH &bvh = ctx.singleton<broadphase::BVH>();
 
         WorldBodies bodies;
-        bodies.numArchetypes = ps->numBodyArchetypes;
-        bodies.bodyBase[0] = 0;
-        bool unsorted = false;
-        for (uint32_t a = 0; a < bodies.numArchetypes; a++) {
-            const TableHdr &tbl = S->tables[ps->bodyArchetypes[a]];
-            bodies.archetype[a] = ps->bodyArchetypes[a];
-            bodies.rowBase[a] = tbl.worldOffsets[world];
-            bodies.bodyBase[a + 1] =
-                bodies.bodyBase[a] + tbl.worldCounts[world];
-            unsorted = unsorted || tbl.needsSort != 0;
-        }
+        const bool unsorted = !bodies.fill(S, ps, world);
         const int32_t num_bodies = bodies.count();
         if (unsorted || num_bodies > MAXB || bvh.numLeaves() != num_bodies) {
             continue;       // the step kernel raises the error
@@ -1267,22 +1308,13 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
 
         // ---- the world's bodies ---------------------------------------------
         WorldBodies bodies;
-        bodies.numArchetypes = ps->numBodyArchetypes;
-        bodies.bodyBase[0] = 0;
-        bool unsorted = false;
-        for (uint32_t a = 0; a < bodies.numArchetypes; a++) {
-            const TableHdr &tbl = S->tables[ps->bodyArchetypes[a]];
-            bodies.archetype[a] = ps->bodyArchetypes[a];
-            bodies.rowBase[a] = tbl.worldOffsets[world];
-            bodies.bodyBase[a + 1] =
-                bodies.bodyBase[a] + tbl.worldCounts[world];
-            unsorted = unsorted || tbl.needsSort != 0;
-        }
+        const bool unsorted = !bodies.fill(S, ps, world);
         const int32_t num_bodies = bodies.count();
         if (unsorted || num_bodies > MAXB || bvh.numLeaves() != num_bodies) {
             mwhip::raiseError(S, mwhip::kErrPhysics);
             continue;
         }
+        PHYS_PROF(10);
 
         // ---- load: HBM -> LDS ---------------------------------------------------
         // (the image part of the block does not depend on LPW)
@@ -1305,6 +1337,7 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                 }
             }
             wave::phaseFence();
+            PHYS_PROF(11);
             loadWorldBodies<MAXB, LPW>(lane, w, w->leafRank, ctx, bodies, bvh,
                                        hbm_obj_mgr, num_bodies);
         }
