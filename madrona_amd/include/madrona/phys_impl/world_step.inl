@@ -1287,7 +1287,7 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
 
 #ifdef MADRONA_PHYS_PROFILE
     unsigned long long prof_t = __builtin_readcyclecounter();
-    unsigned long long prof_acc[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    unsigned long long prof_acc[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 #endif
 
     // Worlds are taken in the order physicsOrderKernel left: the ones that took
@@ -1580,6 +1580,15 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                 PHYS_PROF(3);
                 uint64_t hull_pairs = wave::groupBallot<LPW>(kind == 2);
                 cost_work += 24u * (uint32_t)__builtin_popcountll(hull_pairs);
+#ifdef MADRONA_PHYS_PROFILE
+                // (event counts next to the cycle counters: lane 0 of a world)
+                if (lane == 0) {
+                    prof_acc[12] += (unsigned long long)__builtin_popcountll(hull_pairs);
+                    prof_acc[14] += (unsigned long long)__builtin_popcountll(
+                        wave::groupBallot<LPW>(kind == 1));
+                    prof_acc[15] += width;
+                }
+#endif
                 constexpr int hull_lanes = Block::hullLanes;
                 constexpr int hull_groups = Block::hullGroups;
                 static_assert(hull_groups == 1 || hull_groups == 2);
@@ -1616,6 +1625,14 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                         has_contact = (outcome0 & 1u) != 0u;
                         too_big = (outcome0 & 2u) != 0u;
                     }
+#ifdef MADRONA_PHYS_PROFILE
+                    if (lane == 0) {
+                        prof_acc[13] += outcome0 & 1u;
+                        if (hull_groups == 2 && src1 != 0xFFFFFFFFu) {
+                            prof_acc[13] += __shfl(outcome, hull_lanes, LPW) & 1u;
+                        }
+                    }
+#endif
                     if (hull_groups == 2) {
                         const uint32_t outcome1 = __shfl(outcome, hull_lanes, LPW);
                         if (lane == src1) {
@@ -1805,7 +1822,7 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
 #ifdef MADRONA_PHYS_PROFILE
     if (lane == 0 && S->moduleData[1] != nullptr) {
         unsigned long long *dst = (unsigned long long *)S->moduleData[1];
-        for (int i = 0; i < 12; i++) {
+        for (int i = 0; i < 16; i++) {
             atomicAdd(&dst[i], prof_acc[i]);
         }
     }

@@ -25,12 +25,13 @@ with Simulator(hip_lib_path('escape_room_phys'), W, seed=5, flags=200) as hip:
     dev = torch.from_numpy(ring).cuda()
     hip.set_input_ring('action', dev.data_ptr(), 61)
     hip.step(300)
-    buf = rt.mwhip_alloc_device(hip.hip_exec(), 96, 1)
+    buf = rt.mwhip_alloc_device(hip.hip_exec(), 128, 1)
     rt.mwhip_set_module_data(hip.hip_exec(), 1, buf)
     N = 50
     hip.step(N)
-    out = np.zeros(12, np.uint64)
-    rt.mwhip_memcpy_d2h(out.ctypes.data, buf, 96)
+    out = np.zeros(16, np.uint64)
+    rt.mwhip_memcpy_d2h(out.ctypes.data, buf, 128)
+    events, out = out[12:], out[:12]
     # (slot 2 also collects the velocity solve of the substep before it, slot 6
     # only that of the last substep: see the PHYS_PROF marks in world_step.inl)
     names = ['np.setup', 'candidates', 'integrate (+ solveVel of substeps 1-3)', 'np.solo', 'solvePos+jnt+setVel', 'np.hull+compact', 'solveVel (last substep)', 'joints / store', 'load bodies (rows -> block)', 'stage prims', 'world lookup (singletons, row ranges)', 'leaf ranks']
@@ -38,3 +39,7 @@ with Simulator(hip_lib_path('escape_room_phys'), W, seed=5, flags=200) as hip:
     for n, v in zip(names, out):
         print(f'{n:42s} {v / N / W:10.0f} ticks/world/step  {100 * v / tot:5.1f}%')
     print('total ticks/world/step', tot / N / W, '(s_memtime @100MHz => us =', tot / N / W / 100, ')')
+    # event counts of the same steps (lane 0 of every world)
+    hull, hull_hit, solo, cands = (float(v) / N / W for v in events)
+    print(f'per world and step (4 substeps): {cands:.1f} candidate tests, {solo:.1f} per-lane '
+          f'pairs, {hull:.1f} hull-hull pairs of which {hull_hit:.1f} touch')
