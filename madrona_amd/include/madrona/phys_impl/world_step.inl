@@ -1596,6 +1596,35 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                 const uint32_t hull_lane = lane % (uint32_t)hull_lanes;
                 HullScratch *hull_scratch = hull_group == 0 ?
                     &w->scratch.hull : w->extraHull.at(0);
+                if constexpr (hull_groups == 2) {
+                    // Most chunks hold at most one hull-hull pair per world
+                    // (3.4 pairs per world and step on the Escape Room): then
+                    // all of the world's lanes take it instead of leaving one of
+                    // the two groups idle -- unless the other world of the
+                    // wavefront has more, whose path this one would have to sit
+                    // through anyway.
+                    const uint32_t mine =
+                        (uint32_t)__builtin_popcountll(hull_pairs);
+                    const uint32_t other = __shfl_xor(mine, LPW, 64);
+                    if (mine <= 1u && other <= 1u) {
+                        if (hull_pairs != 0) {
+                            const uint32_t src =
+                                (uint32_t)__builtin_ctzll(hull_pairs);
+                            hull_pairs = 0;
+                            bool pair_too_big = false;
+                            PairSetup shared_pair = ldsSetupPair(
+                                w, obj_mgr, candidateAt(chunk + src));
+                            const bool found = hullHullWave<LPW>(lane, shared_pair,
+                                &w->scratch.hull, stage + src, &pair_too_big);
+                            const uint32_t outcome = __shfl(
+                                (found ? 1u : 0u) | (pair_too_big ? 2u : 0u), 0, LPW);
+                            if (lane == src) {
+                                has_contact = (outcome & 1u) != 0u;
+                                too_big = (outcome & 2u) != 0u;
+                            }
+                        }
+                    }
+                }
                 while (hull_pairs != 0) {
                     // the next pairs of the world, one per group of hull_lanes
                     const uint32_t src0 = (uint32_t)__builtin_ctzll(hull_pairs);
