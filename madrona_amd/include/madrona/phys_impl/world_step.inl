@@ -1128,69 +1128,112 @@ __device__ inline PairSetup ldsSetupPair(const WorldBlock<MAXB, LPW> *w,
 
 // The part of a step that reads the ECS tables: body k of the world -> slot k of
 // the block `dst` (in LDS when the step kernel loads for itself, in HBM when
-// physicsPackKernel prepares the world image).  leaf_rank: leaf id -> position
-// in the BVH's traversal order (LDS).
+// physicsPackKernel prepares the world image).
+//
+// Everything a row leads to is read into registers (BodyRow) before anything is
+// written to the block: `dst` and the columns are generic pointers, so a store
+// to the block between two column reads orders them.  A row is then three
+// rounds of loads: the columns; what the object id and the leaf id lead to;
+// the leaf's slot in its parent node.
+struct BodyRow {
+    Loc loc;
+    math::Vector3 pos;
+    math::Quat rot;
+    math::Diag3x3 scale;
+    Velocity vel;
+    math::Vector3 extForce;
+    math::Vector3 extTorque;
+    ResponseType resp;
+    int32_t entityID;
+    RigidBodyMetadata metadata;
+    uint32_t primOffset;
+    uint32_t primCount;
+    int32_t leaf;
+    math::AABB queryBox;
+    math::AABB slotBox;
+};
+
+__device__ inline BodyRow readBodyRow(Context &ctx, const WorldBodies &bodies,
+                                      const broadphase::BVH &bvh,
+                                      const ObjectManager &hbm_obj_mgr, int32_t k)
+{
+    BodyRow row;
+    row.loc = bodies.loc(k);
+    const Loc loc = row.loc;
+    row.pos = ctx.getDirect<base::Position>(RGDCols::Position, loc);
+    row.rot = ctx.getDirect<base::Rotation>(RGDCols::Rotation, loc);
+    row.scale = ctx.getDirect<base::Scale>(RGDCols::Scale, loc);
+    row.vel = ctx.getDirect<Velocity>(RGDCols::Velocity, loc);
+    row.extForce = ctx.getDirect<ExternalForce>(RGDCols::ExternalForce, loc);
+    row.extTorque = ctx.getDirect<ExternalTorque>(RGDCols::ExternalTorque, loc);
+    row.resp = ctx.getDirect<ResponseType>(RGDCols::ResponseType, loc);
+    row.entityID = ctx.getDirect<Entity>(0, loc).id;
+    const base::ObjectID obj_id =
+        ctx.getDirect<base::ObjectID>(RGDCols::ObjectID, loc);
+    row.leaf = ctx.getDirect<broadphase::LeafID>(RGDCols::LeafID, loc).id;
+
+    row.metadata = hbm_obj_mgr.metadata[obj_id.idx];
+    row.primOffset = hbm_obj_mgr.rigidBodyPrimitiveOffsets[obj_id.idx];
+    row.primCount = hbm_obj_mgr.rigidBodyPrimitiveCounts[obj_id.idx];
+    row.queryBox = bvh.getLeafAABB(broadphase::LeafID { row.leaf });
+    row.slotBox = bvh.leafSlotBounds(row.leaf);
+    return row;
+}
+
+template <int MAXB, int LPW>
+__device__ inline void writeBodyRow(WorldBlock<MAXB, LPW> *dst,
+                                    const uint16_t *leaf_rank, int32_t k,
+                                    const BodyRow &row)
+{
+    const uint32_t rank = leaf_rank[row.leaf];
+    dst->bodyLoc[k] = row.loc;
+    dst->pos[k] = row.pos;
+    dst->rot[k] = row.rot;
+    dst->scale[k] = row.scale;
+    dst->vel[k] = row.vel;
+    dst->extForce[k] = row.extForce;
+    dst->extTorque[k] = row.extTorque;
+    dst->resp[k] = (uint32_t)row.resp;
+    dst->entityID[k] = row.entityID;
+    dst->constants[k] = xpbd::bodyConstants(row.metadata, row.resp);
+    dst->primOffset[k] = (uint16_t)row.primOffset;
+    dst->primCount[k] = (uint16_t)row.primCount;
+    dst->queryBox()[k] = row.queryBox;
+    dst->rankSlotBox()[rank] = row.slotBox;
+    dst->rankEntity()[rank] = row.entityID;
+    dst->orderBody[rank] = (uint16_t)k;
+}
+
+// leaf_rank (LDS, filled here): leaf id -> position in the BVH's traversal
+// order.  The first chunk of rows is read while the ranks are being written --
+// neither depends on the other, and with one wavefront per SIMD there is nothing
+// else to overlap a chain of cold misses with.
 template <int MAXB, int LPW>
 __device__ inline void loadWorldBodies(uint32_t lane, WorldBlock<MAXB, LPW> *dst,
-                                       const uint16_t *leaf_rank, Context &ctx,
+                                       uint16_t *leaf_rank, Context &ctx,
                                        const WorldBodies &bodies,
                                        const broadphase::BVH &bvh,
                                        const ObjectManager &hbm_obj_mgr,
                                        int32_t num_bodies)
 {
-    for (int32_t k = (int32_t)lane; k < num_bodies; k += LPW) {
-        const Loc loc = bodies.loc(k);
-
-        // Everything is read into registers before anything is written to the
-        // block: `dst` and the columns are generic pointers, so a store to the
-        // block between two column reads orders them -- load, wait, store,
-        // load, wait, store ... was a chain of ~20 round trips per world (14 %
-        // of the step kernel, profiles/r03_physics_phases_*); like this the
-        // row is three rounds: the columns; what the object id and the leaf id
-        // lead to; the leaf's slot in its parent node.
-        const base::Position pos =
-            ctx.getDirect<base::Position>(RGDCols::Position, loc);
-        const base::Rotation rot =
-            ctx.getDirect<base::Rotation>(RGDCols::Rotation, loc);
-        const base::Scale scale = ctx.getDirect<base::Scale>(RGDCols::Scale, loc);
-        const Velocity vel = ctx.getDirect<Velocity>(RGDCols::Velocity, loc);
-        const ExternalForce ext_force =
-            ctx.getDirect<ExternalForce>(RGDCols::ExternalForce, loc);
-        const ExternalTorque ext_torque =
-            ctx.getDirect<ExternalTorque>(RGDCols::ExternalTorque, loc);
-        const ResponseType resp =
-            ctx.getDirect<ResponseType>(RGDCols::ResponseType, loc);
-        const int32_t entity_id = ctx.getDirect<Entity>(0, loc).id;
-        const base::ObjectID obj_id =
-            ctx.getDirect<base::ObjectID>(RGDCols::ObjectID, loc);
-        const int32_t leaf = ctx.getDirect<broadphase::LeafID>(
-            RGDCols::LeafID, loc).id;
-
-        const RigidBodyMetadata metadata = hbm_obj_mgr.metadata[obj_id.idx];
-        const uint32_t prim_offset =
-            hbm_obj_mgr.rigidBodyPrimitiveOffsets[obj_id.idx];
-        const uint32_t prim_count =
-            hbm_obj_mgr.rigidBodyPrimitiveCounts[obj_id.idx];
-        const math::AABB query_box = bvh.getLeafAABB(broadphase::LeafID { leaf });
-        const math::AABB slot_box = bvh.leafSlotBounds(leaf);
-        const uint32_t rank = leaf_rank[leaf];
-
-        dst->bodyLoc[k] = loc;
-        dst->pos[k] = pos;
-        dst->rot[k] = rot;
-        dst->scale[k] = scale;
-        dst->vel[k] = vel;
-        dst->extForce[k] = ext_force;
-        dst->extTorque[k] = ext_torque;
-        dst->resp[k] = (uint32_t)resp;
-        dst->entityID[k] = entity_id;
-        dst->constants[k] = xpbd::bodyConstants(metadata, resp);
-        dst->primOffset[k] = (uint16_t)prim_offset;
-        dst->primCount[k] = (uint16_t)prim_count;
-        dst->queryBox()[k] = query_box;
-        dst->rankSlotBox()[rank] = slot_box;
-        dst->rankEntity()[rank] = entity_id;
-        dst->orderBody[rank] = (uint16_t)k;
+    const bool first_active = (int32_t)lane < num_bodies;
+    BodyRow first;
+    if (first_active) {
+        first = readBodyRow(ctx, bodies, bvh, hbm_obj_mgr, (int32_t)lane);
+    }
+    {
+        const int32_t *order = bvh.traversalOrder();
+        for (int32_t r = (int32_t)lane; r < num_bodies; r += LPW) {
+            leaf_rank[order[r]] = (uint16_t)r;
+        }
+    }
+    wave::phaseFence();
+    if (first_active) {
+        writeBodyRow<MAXB, LPW>(dst, leaf_rank, (int32_t)lane, first);
+    }
+    for (int32_t k = (int32_t)lane + LPW; k < num_bodies; k += LPW) {
+        const BodyRow row = readBodyRow(ctx, bodies, bvh, hbm_obj_mgr, k);
+        writeBodyRow<MAXB, LPW>(dst, leaf_rank, k, row);
     }
 }
 
@@ -1230,11 +1273,6 @@ physicsPackKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
             continue;       // the step kernel raises the error
         }
 
-        const int32_t *order = bvh.traversalOrder();
-        for (int32_t r = (int32_t)lane; r < num_bodies; r += 64) {
-            leaf_rank[order[r]] = (uint16_t)r;
-        }
-        wave::phaseFence();
 
         Block *image = (Block *)((char *)params.worldImages +
                                  (size_t)world * Block::imageBytes());
@@ -1330,18 +1368,18 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                 dst[i] = src[i];
             }
         } else {
-            {
-                const int32_t *order = bvh.traversalOrder();
-                for (int32_t r = (int32_t)lane; r < num_bodies; r += LPW) {
-                    w->leafRank[order[r]] = (uint16_t)r;
-                }
+            // (read before the rows, stored after them: one more load in flight)
+            PhysicsSystemState sys_regs {};
+            if (lane == 0) {
+                sys_regs = ctx.singleton<PhysicsSystemState>();
             }
-            wave::phaseFence();
-            PHYS_PROF(11);
             loadWorldBodies<MAXB, LPW>(lane, w, w->leafRank, ctx, bodies, bvh,
                                        hbm_obj_mgr, num_bodies);
+            if (lane == 0) {
+                w->sys = sys_regs;
+            }
         }
-        if (lane == 0) {
+        if (lane == 0 && world_images != nullptr) {
             w->sys = ctx.singleton<PhysicsSystemState>();
         }
         wave::phaseFence();
