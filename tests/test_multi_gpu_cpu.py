@@ -39,11 +39,15 @@ def _worker(rank, world_size, port, sim_name, out_dir):
     sys.path.insert(0, REPO)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    # (gloo otherwise picks its interface by resolving the host name, which in
+    # this container may not resolve -- or resolve slowly: the loopback device)
+    if os.path.exists("/sys/class/net/lo"):
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
     # (a rendezvous that cannot complete -- the port taken between _free_port()
     # and here -- fails after a minute instead of gloo's default half hour)
     import datetime
     dist.init_process_group("gloo", rank=rank, world_size=world_size,
-                            timeout=datetime.timedelta(seconds=60))
+                            timeout=datetime.timedelta(seconds=45))
     # (the parent retries a run only while no rank got this far)
     open(os.path.join(out_dir, f"rendezvous_ok_{rank}"), "w").close()
     try:
@@ -86,11 +90,11 @@ def test_two_rank_allgather_is_partition_invariant(built, tmp_path, sim_name):
         ctx = mp.spawn(_worker, args=(2, _free_port(), sim_name, str(tmp_path)),
                        nprocs=2, join=False)
         error = None
-        deadline = time.monotonic() + 240
+        deadline = time.monotonic() + 150
         try:
             while not ctx.join(timeout=5):
                 if time.monotonic() > deadline:
-                    raise TimeoutError("the two ranks did not finish in 240 s")
+                    raise TimeoutError("the two ranks did not finish in 150 s")
             break
         except Exception as e:      # noqa: BLE001
             error = e

@@ -48,6 +48,9 @@ def _worker(rank, world_size, port, out_dir):
 
     torch.cuda.set_device(0)
     import datetime
+    # (gloo otherwise resolves the host name to pick its interface)
+    if os.path.exists("/sys/class/net/lo"):
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
     dist.init_process_group("gloo", rank=rank, world_size=world_size,
                             timeout=datetime.timedelta(seconds=90))
     try:
