@@ -87,6 +87,13 @@ def parse_args():
                    help="default: escape_room_phys (configs[2]) on one GPU, "
                         "hideseek (configs[3]) with --gpus N > 1")
     p.add_argument("--auto-reset-denom", type=int, default=200)
+    p.add_argument("--action-slots", type=int, default=61,
+                   help="action sets in the device-resident ring the step graph "
+                        "takes its actions from, one per step (default 61; 1 = the "
+                        "same actions every step; 0 = what rounds 1-2 measured: the "
+                        "action tensor written ONCE before the run -- the simulators "
+                        "zero a world's actions when it resets, so most agents stand "
+                        "still by the time the clock starts)")
     p.add_argument("--settle", type=int, default=-1,
                    help="steps the synthetic worlds are advanced while they are set "
                         "up, before warm-up and timing (default 400: freshly spawned "
@@ -245,13 +252,14 @@ def cpu_baseline(sim, worlds, flags, seed, settle, budget_s=12.0):
         rng = np.random.default_rng(seed)
         ring = [np.stack(random_actions(sim, worlds, lambda lo, hi, shape:
                                         rng.integers(lo, hi, shape)), -1).astype(np.int32)
-                for _ in range(ACTION_SLOTS)]
+                for _ in range(max(ACTION_SLOTS, 1))]
         count = [0]
 
         def step(n):
             # a new action set every step, like the GPU run's input ring
             for _ in range(n):
-                s.write_tensor("action", ring[count[0] % ACTION_SLOTS])
+                if ACTION_SLOTS != 0 or count[0] == 0:
+                    s.write_tensor("action", ring[count[0] % max(ACTION_SLOTS, 1)])
                 count[0] += 1
                 s.step(1)
 
@@ -273,7 +281,9 @@ def cpu_baseline(sim, worlds, flags, seed, settle, budget_s=12.0):
     }
 
 
-ACTION_SLOTS = 61   # (odd: config 5 replays two graphs per step)
+ACTION_SLOTS = 61   # (odd: config 5 replays two graphs per step); --action-slots
+ACTION_WORKLOAD = ("a new set of random actions every step from a 61-slot ring "
+                   "resident in HBM")
 
 
 def random_actions(sim_name, worlds, rng_randint):
@@ -291,8 +301,9 @@ def fill_actions(sim_name, sim, worlds, gpu_id, seed):
     of ACTION_SLOTS action sets; every replay of the step graph starts by copying
     the next one into the exported action tensor (mwhip_set_input_ring), so the
     worlds are driven by fresh actions every step without the host touching the
-    executor's stream.  (Constant actions -- what rounds 1-2 measured -- let the
-    worlds go quiet: agents pressed against walls, no grabs, an idle joint sort.)"""
+    executor's stream.  (Rounds 1-2 wrote the tensor once: the simulators zero a
+    world's actions when it resets, so by the end of the settling steps most
+    agents stood still -- no grabs, an idle joint sort.  --action-slots 0.)"""
     import torch
     gen = torch.Generator(device="cuda")
     gen.manual_seed(seed)
@@ -300,8 +311,14 @@ def fill_actions(sim_name, sim, worlds, gpu_id, seed):
         torch.stack(random_actions(sim_name, worlds, lambda lo, hi, shape:
                                    torch.randint(lo, hi, shape, device="cuda",
                                                  generator=gen)), -1)
-        for _ in range(ACTION_SLOTS)]).to(torch.int32).contiguous()
+        for _ in range(max(ACTION_SLOTS, 1))]).to(torch.int32).contiguous()
     torch.cuda.synchronize()
+    if ACTION_SLOTS == 0:
+        # (--action-slots 0: rounds 1-2)
+        from madrona_amd.tensor import to_torch
+        to_torch(sim, "action", gpu_id).copy_(ring[0])
+        torch.cuda.synchronize()
+        return
     sim._action_ring = ring         # (keeps the memory alive)
     sim.set_input_ring("action", ring.data_ptr(), ACTION_SLOTS)
 
@@ -612,6 +629,17 @@ def run_render(worlds, gpu_id, seed, denom, steps, warmup, profile_reps, settle,
 
 def main():
     args = parse_args()
+    global ACTION_SLOTS, ACTION_WORKLOAD
+    ACTION_SLOTS = max(args.action_slots, 0)
+    if ACTION_SLOTS == 0:
+        ACTION_WORKLOAD = ("the action tensor written ONCE before the run and zeroed by "
+                           "every world's first reset -- the workload of rounds 1-2, "
+                           "not the default")
+    elif ACTION_SLOTS == 1:
+        ACTION_WORKLOAD = "the same set of random actions re-applied every step"
+    elif ACTION_SLOTS != 61:
+        ACTION_WORKLOAD = (f"a new set of random actions every step from a "
+                           f"{ACTION_SLOTS}-slot ring resident in HBM")
 
     # stdout carries exactly one JSON line: anything libraries print while the
     # benchmark runs (RCCL prints a version banner from C) goes to stderr
@@ -653,7 +681,7 @@ def main():
             "ms_per_step": r["ms_per_step"], "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": f"synthetic (worlds advanced {args.settle} steps while being set "
-                    f"up; a new set of random actions every step from a 61-slot ring resident in HBM)",
+                    f"up; {ACTION_WORKLOAD})",
             "config": {"workload": r["workload"], "sim": args.sim,
                        "worlds_per_gpu": worlds, "settle_steps": args.settle,
                        "total_worlds": worlds, "dist_world_size": 1,
@@ -861,7 +889,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": f"synthetic (worlds advanced {args.settle} steps to their steady "
-                    f"state while being set up; a new set of random actions every step from a 61-slot ring resident in HBM)",
+                    f"state while being set up; {ACTION_WORKLOAD})",
             "config": {
                 "workload": workload_fmt.format(w=args.worlds) +
                             f", auto-reset p=1/{args.auto_reset_denom} per world per step",
