@@ -178,7 +178,9 @@ MADRONA_HD inline void findEntitiesWithinAABB(Context &ctx, math::AABB aabb,
 // with the same boxes; `accept` is evaluated by different lanes for different
 // entities and must not have side effects; the queries see the state as it is
 // when the call is made.  For systems that run a wavefront per world
-// (CustomParallelForNode<..., 64, 1, ...>).
+// (CustomParallelForNode<..., 64, 1, ...>), after setupBroadphaseTasks has
+// brought the leaves up to date with the poses (leaves are culled by their own
+// box, which then contains the body with 100 dt^2 to spare).
 template <int MAX_BOXES, typename Fn>
 MADRONA_DEVICE inline void findFirstEntitiesWithinAABBsWave(Context &ctx,
                                                             const math::AABB *boxes,

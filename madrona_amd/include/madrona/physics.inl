@@ -329,24 +329,33 @@ Entity BVH::traceRay(math::Vector3 o,
         // and a leaf is met iff the ray hits its slot box: every ancestor's
         // box contains it (refits only grow boxes) and the slab test is
         // monotone in the box, so the ancestors' tests cannot cull a leaf
-        // whose own slot passes.  Testing the slot boxes in the order recorded
-        // by rebuild() therefore performs the same leaf tests in the same
-        // order with the same t_max, without the dependent node -> child ->
-        // node chain and without a stack.
+        // whose own slot passes.  Visiting the leaves in the order recorded by
+        // rebuild() therefore performs the same leaf tests in the same order
+        // with the same t_max, without the dependent node -> child -> node
+        // chain and without a stack.
         //
-        // Two passes per window of 64 leaves: every slot box against the
-        // initial t_max (all rays of an agent read the same boxes: broadcast
-        // loads, no divergence) leaves a bit mask of candidate leaves; then
-        // each ray walks ITS OWN set bits, re-testing the box with the current
-        // t_max as the stack walk would.  A wave then takes as many leaf-test
-        // steps as its busiest ray has candidates (a handful), not one per
-        // leaf that any of its rays touches.
+        // The box tested here is the leaf's OWN box (leaf_aabbs_), not its slot
+        // in the parent node: slots only grow between rebuilds -- after a few
+        // hundred steps of bodies moving about they cover much of the arena and
+        // most rays "hit" most of them --, while a leaf test can only succeed
+        // for a ray that passes the body's box, which contains the body with
+        // 100 dt^2 (16 cm) to spare on every side (expandAABBWithMotion), and
+        // is inside the slot and all its ancestors.  The leaves skipped this
+        // way are ones the reference visits and finds nothing in; the hits,
+        // their order and t_max are the same.  (One dependent load fewer, too.)
+        //
+        // Two passes per window of 64 leaves: every box against the initial
+        // t_max (all rays of an agent read the same boxes: broadcast loads, no
+        // divergence) leaves a bit mask of candidate leaves; then each ray
+        // walks ITS OWN set bits, re-testing the box with the current t_max.
+        // A wave then takes as many leaf-test steps as its busiest ray has
+        // candidates (a handful), not one per leaf that any of its rays touches.
         const int32_t n = num_tree_leaves_;
         for (int32_t base = 0; base < n; base += 64) {
             const int32_t window = n - base < 64 ? n - base : 64;
 
-            // (boxes fetched a group at a time: leaf index -> parent slot ->
-            // box is three dependent round trips, paid once per group)
+            // (boxes fetched a group at a time: leaf index -> box is two
+            // dependent round trips, paid once per group)
             uint64_t candidates = 0;
             constexpr int32_t group = 8;
             for (int32_t g = 0; g < window; g += group) {
@@ -356,16 +365,10 @@ MADRONA_UNROLL
                     const int32_t j = g + k < window ? g + k : window - 1;
                     leaf[k] = dfs_leaves_[base + j];
                 }
-                uint32_t parent[group];
-MADRONA_UNROLL
-                for (int32_t k = 0; k < group; k++) {
-                    parent[k] = leaf_parents_[leaf[k]];
-                }
                 AABB box[group];
 MADRONA_UNROLL
                 for (int32_t k = 0; k < group; k++) {
-                    box[k] = nodes_[parent[k] >> 2].bounds(
-                        (CountT)(parent[k] & 3u));
+                    box[k] = leaf_aabbs_[leaf[k]];
                 }
 MADRONA_UNROLL
                 for (int32_t k = 0; k < group; k++) {
@@ -376,7 +379,7 @@ MADRONA_UNROLL
             }
 
             // (until a leaf test shrinks t_max the mask IS the re-test: the box
-            // -- three dependent loads away -- is only fetched again after a hit)
+            // is only fetched again after a hit)
             const float mask_t_max = t_max;
             while (candidates != 0) {
                 const int32_t j = (int32_t)__builtin_ctzll(candidates);
@@ -384,8 +387,8 @@ MADRONA_UNROLL
 
                 const int32_t leaf_idx = dfs_leaves_[base + j];
                 if (t_max == mask_t_max ||
-                        leafSlotBounds(leaf_idx).rayIntersects(o, inv_d, 0.f,
-                                                               t_max)) {
+                        leaf_aabbs_[leaf_idx].rayIntersects(o, inv_d, 0.f,
+                                                            t_max)) {
                     visitLeaf(leaf_idx);
                 }
             }
@@ -1377,10 +1380,10 @@ MADRONA_DEVICE inline void findFirstEntitiesWithinAABBsWave(Context &ctx,
     }
 
     // A query reports its leaves as a subsequence of the tree's full traversal
-    // order, and it reaches a leaf iff it overlaps the leaf's slot box (ancestor
-    // boxes contain it: refits only grow them) -- BVH::traversalOrder.  Lane i
-    // takes the i-th leaf of that order and answers for every box; per box the
-    // first accepting lane wins.
+    // order (BVH::traversalOrder), and every leaf it can accept is one it
+    // reaches: the body's own box lies inside its slot box and all ancestors
+    // (refits only grow them).  Lane i takes the i-th leaf of that order and
+    // answers for every box; per box the first accepting lane wins.
     const int32_t n = bvh.numLeaves();
     const int32_t *order = bvh.traversalOrder();
     uint32_t open = num_boxes >= 32 ? 0xFFFFFFFFu : (1u << num_boxes) - 1u;
@@ -1390,10 +1393,15 @@ MADRONA_DEVICE inline void findFirstEntitiesWithinAABBsWave(Context &ctx,
         uint32_t hits = 0;
         if (i < n) {
             const int32_t leaf = order[i];
-            const math::AABB slot = bvh.leafSlotBounds(leaf);
+            // (the leaf's own box, not its slot in the parent node: the slot
+            // only grows between rebuilds, while the exact test below can only
+            // succeed for a box that meets the body's own box -- which contains
+            // the body with room to spare and lies inside the slot; the leaves
+            // skipped are ones the reference visits and rejects)
+            const math::AABB own = bvh.getLeafAABB(broadphase::LeafID { leaf });
             uint32_t reached = 0;
             for (int32_t b = 0; b < num_boxes; b++) {
-                if ((open >> b & 1u) != 0u && boxes[b].overlaps(slot)) {
+                if ((open >> b & 1u) != 0u && boxes[b].overlaps(own)) {
                     reached |= 1u << b;
                 }
             }
