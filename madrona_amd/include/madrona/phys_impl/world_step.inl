@@ -1620,11 +1620,15 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                 cost_work += 24u * (uint32_t)__builtin_popcountll(hull_pairs);
 #ifdef MADRONA_PHYS_PROFILE
                 // (event counts next to the cycle counters: lane 0 of a world)
-                if (lane == 0) {
-                    prof_acc[12] += (unsigned long long)__builtin_popcountll(hull_pairs);
-                    prof_acc[14] += (unsigned long long)__builtin_popcountll(
-                        wave::groupBallot<LPW>(kind == 1));
-                    prof_acc[15] += width;
+                {
+                    const uint64_t solo_pairs = wave::groupBallot<LPW>(kind == 1);
+                    if (lane == 0) {
+                        prof_acc[12] +=
+                            (unsigned long long)__builtin_popcountll(hull_pairs);
+                        prof_acc[14] +=
+                            (unsigned long long)__builtin_popcountll(solo_pairs);
+                        prof_acc[15] += width;
+                    }
                 }
 #endif
                 constexpr int hull_lanes = Block::hullLanes;
