@@ -392,6 +392,27 @@ def rooflines(stats, sim_name, worlds, ms_per_step):
         "are still sorted from the last step take the compaction chain (prepare + "
         "scatter: 8 N + 8 N' instead of the 40 N of histogram + key passes)")
     if nodes["sort_node"]:
+        # the step's sort chains one by one (kernels of a chain are adjacent in
+        # the launch list): e.g. the joint table before the physics step -- a
+        # few thousand rows behind three launch floors -- next to the compaction
+        # of the big tables after the reset
+        chains, run = [], []
+        for k in stats:
+            if ":sort." in k["name"]:
+                run.append(k)
+            elif run:
+                chains.append(run)
+                run = []
+        if run:
+            chains.append(run)
+        nodes["sort_node"]["chains"] = [{
+            "kernels": [k["name"].split(":", 1)[1] for k in c],
+            "avg_us": round(sum(k["avg_us"] for k in c), 2),
+            "algo_bytes": int(sum(k["algo_bytes"] for k in c)),
+            "frac": round(sum(k["algo_bytes"] for k in c) /
+                          max(sum(k["avg_us"] for k in c) * 1e-6, 1e-12) / 1e9 /
+                          HBM_PEAK_GBS, 4),
+        } for c in chains]
         rows_in = sum(k["rows"] for k in sort_k if "gather" in k["name"])
         gather_bytes = sum(k["algo_bytes"] for k in sort_k if "gather" in k["name"])
         nodes["sort_node"]["bytes_moved_estimate"] = int(gather_bytes + 16.0 * rows_in) \
