@@ -36,7 +36,7 @@ def _actions(step, worlds, base):
     return a[base:base + worlds]
 
 
-def _worker(rank, world_size, port, out_dir):
+def _worker(rank, world_size, port, out_dir, use_ring):
     sys.path.insert(0, REPO)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -62,10 +62,20 @@ def _worker(rank, world_size, port, out_dir):
 
         sharded = ShardedSimulator(make_sim, shard, NAMES)
         gathered = None
+        ring = None
+        if use_ring:
+            # the rank's shard of every step's actions, resident on the device:
+            # replay k of the (pack-carrying) step graphs copies slot k itself
+            # (mwhip_set_input_ring rebuilds those graphs, pack node included)
+            ring = torch.from_numpy(np.stack([
+                _actions(step, shard.worlds_per_rank, shard.world_base)
+                for step in range(1, STEPS + 1)])).cuda()
+            sharded.sim.set_input_ring("action", ring.data_ptr(), STEPS)
         t0 = time.perf_counter()
         for step in range(1, STEPS + 1):
-            sharded.sim.write_tensor(
-                "action", _actions(step, shard.worlds_per_rank, shard.world_base))
+            if not use_ring:
+                sharded.sim.write_tensor(
+                    "action", _actions(step, shard.worlds_per_rank, shard.world_base))
             gathered = sharded.step(1)
         torch.cuda.synchronize()
         sharded.sync()
@@ -77,14 +87,15 @@ def _worker(rank, world_size, port, out_dir):
         dist.destroy_process_group()
 
 
-def test_two_ranks_share_one_gpu(built, tmp_path):
+@pytest.mark.parametrize("use_ring", [False, True])
+def test_two_ranks_share_one_gpu(built, tmp_path, use_ring):
     import torch
     import torch.multiprocessing as mp
     from madrona_amd.simlib import Simulator, hip_lib_path
 
     assert torch.cuda.is_available()
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), use_ring), nprocs=2, join=True)
     got = [np.load(os.path.join(str(tmp_path), f"gathered_{r}.npz")) for r in (0, 1)]
 
     with Simulator(hip_lib_path("hideseek"), TOTAL_WORLDS, seed=5, flags=40) as s:
