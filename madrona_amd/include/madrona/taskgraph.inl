@@ -189,8 +189,9 @@ MADRONA_DEVICE inline void pforRowSnapshot(EcsState *S, PforRowSync *sync,
 // creation) and inlines enough code to take 150+ registers runs a quarter of
 // the worlds at a time; a simulator caps it with
 //   template <> inline constexpr unsigned madrona::mwhip::systemWavesPerSIMD<fn> = 4;
-// before its setupTasks.  (Measured both ways: the lidar systems -- arithmetic
-// heavy -- lose from more waves, profiles/r03_lidar_occupancy_variants.jsonl.)
+// before its setupTasks (sims/hideseek: the lock system, 109 -> 99 us).  Measured
+// both ways: the lidar systems -- arithmetic heavy -- lose from more waves
+// (profiles/r03_lidar_occupancy_variants.jsonl).
 template <auto Fn>
 inline constexpr unsigned systemWavesPerSIMD = 0;
 

@@ -939,6 +939,16 @@ inline void lidarSystem(Engine &ctx,
 #endif
 }
 
+#ifdef MADRONA_GPU_MODE
+// (this backend) the lock system is a chain of dependent loads with a wavefront
+// per world: four wavefronts per SIMD instead of the three its 154 registers
+// allow (109 -> 99 us at 8192 worlds; the ray systems do not profit)
+}
+template <> inline constexpr unsigned
+    madrona::mwhip::systemWavesPerSIMD<hideseek::lockSystem> = 4;
+namespace hideseek {
+#endif
+
 void Sim::setupTasks(TaskGraphManager &taskgraph_mgr, const Config &)
 {
     TaskGraphBuilder &builder = taskgraph_mgr.init(0);
