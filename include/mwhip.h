@@ -404,8 +404,9 @@ int mwhip_pack_rows(mwhip_exec *exec, uint32_t num_columns,
                     const uint32_t *words_per_row, uint32_t num_rows,
                     void *dst);
 
-/* Device-resident input ring: the k-th replay (of any step graph of this
- * executor, k = 0, 1, ...) after this call starts by copying slot k % num_slots
+/* Device-resident input ring: the k-th replay of a step graph of this executor
+ * (any graph from mwhip_build_launch_graph; replays of the render graph neither
+ * read nor advance the rings; k = 0, 1, ...) after this call starts by copying slot k % num_slots
  * of `ring` (num_slots x slot_bytes, device memory, whole dwords) into `dst` -- normally an exported
  * action column (mwhip_exported) --, so that a policy's outputs for the next
  * steps can be queued with the replays that consume them; nothing foreign sits

@@ -310,16 +310,23 @@ constexpr uint32_t kStatsReplays = 3 + 2 * kMaxArchetypes;  // replays completed
 constexpr uint32_t kStatsTails = 4 + 2 * kMaxArchetypes;    // [kMaxArchetypes]
 constexpr uint32_t kStatsWords = 4 + 3 * kMaxArchetypes;
 
+// word of the replay-signal block that counts completed replays of STEP graphs
+// only (the ones that start with the input rings); word 0 counts every replay
+constexpr uint32_t kStepReplayWord = 16;
+
 // First kernel of a step graph with an input ring (mwhip_set_input_ring): slot
-// (replays since the ring was set) % num_slots of a device-resident ring -> an exported
-// column, i.e. a new set of actions every step without the host touching the
-// executor's stream between two graph launches.
+// (step-graph replays since the ring was set) % num_slots of a device-resident
+// ring -> an exported column, i.e. a new set of actions every step without the
+// host touching the executor's stream between two graph launches.  Render
+// graphs neither read nor advance the rings (they bump word 0 only), so a
+// render replay between two steps does not skip a slot.
 __global__ void __launch_bounds__(256)
 inputRingKernel(EcsState *S, uint32_t *dst, const uint32_t *ring,
                 uint32_t slot_words, uint32_t num_slots, uint32_t first_replay)
 {
     TraceScope trace_scope(S);
-    const uint32_t replay = __hip_atomic_load(S->replayCounter, __ATOMIC_RELAXED,
+    const uint32_t replay = __hip_atomic_load(S->replayCounter + kStepReplayWord,
+                                              __ATOMIC_RELAXED,
                                               __HIP_MEMORY_SCOPE_AGENT);
     const uint32_t *src =
         ring + (size_t)((replay - first_replay) % num_slots) * slot_words;
@@ -409,6 +416,11 @@ __global__ void statsKernel(EcsState *S, int32_t *host_out,
         host_out[1] = S->numIds;
         // this replay is complete (mwhip_stream_wait_replays polls this; the
         // host reads the copy in pinned memory without waiting)
+        if (report_rows != 0u) {
+            // a step graph (not a render graph): the input rings move on
+            __hip_atomic_fetch_add(replay_signal + kStepReplayWord, 1u,
+                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         uint32_t done = __hip_atomic_fetch_add(replay_signal, 1u,
             __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM) + 1u;
         __hip_atomic_store((uint32_t *)&host_out[kStatsReplays], done,
@@ -3680,10 +3692,12 @@ extern "C" int mwhip_set_input_ring(mwhip_exec *exec, void *dst, const void *rin
         if (rings.size() >= 4) {
             return fail(-2, "set_input_ring: at most 4 rings");
         }
-        // (every replay of every graph of the executor counts)
+        // (every replay of every STEP graph of the executor counts; render
+        // graphs do not)
         HIPCHK(hipStreamSynchronize(exec->stream));
         uint32_t done = 0;
-        HIPCHK(hipMemcpy(&done, exec->replaySignal, sizeof(done), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(&done, exec->replaySignal + kStepReplayWord, sizeof(done),
+                         hipMemcpyDeviceToHost));
         rings.push_back({ (uint32_t *)dst, (const uint32_t *)ring,
                           (uint32_t)(slot_bytes / 4), num_slots, done });
     }

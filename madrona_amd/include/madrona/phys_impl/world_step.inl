@@ -259,11 +259,39 @@ __device__ inline HullState makeHullStateWave(uint32_t lane,
     return HullState { world_mesh, center };
 }
 
+// Profile builds (-DMADRONA_PHYS_PROFILE): cycles and exit counts of the stages
+// of a cooperative hull-hull test, added up by lane 0 of the group in
+// hh_prof[0..11] (moduleData[1] + 16 slots, profiles/tools/phys_phase_cycles.py).
+struct HullHullProf {
+#ifdef MADRONA_PHYS_PROFILE
+    unsigned long long *acc;
+    unsigned long long t;
+    __device__ inline void mark(uint32_t lane, int slot)
+    {
+        unsigned long long now = __builtin_readcyclecounter();
+        if (lane == 0 && acc != nullptr) {
+            atomicAdd(&acc[slot], now - t);
+        }
+        t = now;
+    }
+    __device__ inline void count(uint32_t lane, int slot)
+    {
+        if (lane == 0 && acc != nullptr) {
+            atomicAdd(&acc[slot], 1ull);
+        }
+    }
+#else
+    __device__ inline void mark(uint32_t, int) {}
+    __device__ inline void count(uint32_t, int) {}
+#endif
+};
+
 template <int LPW = 64, typename HullA, typename HullB>
 __device__ inline bool hullHullWaveSAT(uint32_t lane, const PairSetup &pair,
                                        const HullA &a, const HullB &b,
                                        HullScratch *scratch,
-                                       ContactConstraint *out, bool *too_big);
+                                       ContactConstraint *out, bool *too_big,
+                                       HullHullProf prof = HullHullProf {});
 
 // Hull-hull pair handled by a group of LPW lanes (`pair` is uniform across the
 // group; `lane` = index inside it).  Returns false with *too_big set when the
@@ -274,7 +302,8 @@ template <int LPW = 64>
 __device__ inline bool
 hullHullWave(uint32_t lane, const PairSetup &pair,
                                     HullScratch *scratch,
-                                    ContactConstraint *out, bool *too_big)
+                                    ContactConstraint *out, bool *too_big,
+                                    HullHullProf prof = HullHullProf {})
 {
     const HalfEdgeMesh &a_mesh = pair.aPrim->hull.halfEdgeMesh;
     const HalfEdgeMesh &b_mesh = pair.bPrim->hull.halfEdgeMesh;
@@ -288,34 +317,44 @@ hullHullWave(uint32_t lane, const PairSetup &pair,
             scratch->hullVerts[0], scratch->hullPlanes[0]);
         HullState b = makeHullStateWave<LPW>(lane, b_mesh, pair.b,
             scratch->hullVerts[1], scratch->hullPlanes[1]);
-        return hullHullWaveSAT<LPW>(lane, pair, a, b, scratch, out, too_big);
+        prof.mark(lane, 0);     // hulls into LDS
+        return hullHullWaveSAT<LPW>(lane, pair, a, b, scratch, out, too_big,
+                                    prof);
     }
 
     LazyHull a(a_mesh, pair.a.pos, pair.a.rot, pair.a.scale);
     LazyHull b(b_mesh, pair.b.pos, pair.b.rot, pair.b.scale);
-    return hullHullWaveSAT<LPW>(lane, pair, a, b, scratch, out, too_big);
+    return hullHullWaveSAT<LPW>(lane, pair, a, b, scratch, out, too_big, prof);
 }
 
 template <int LPW, typename HullA, typename HullB>
 __device__ inline bool hullHullWaveSAT(uint32_t lane, const PairSetup &pair,
                                        const HullA &a, const HullB &b,
                                        HullScratch *scratch,
-                                       ContactConstraint *out, bool *too_big)
+                                       ContactConstraint *out, bool *too_big,
+                                       HullHullProf prof)
 {
     FaceQuery face_query_a = queryFaceDirectionsWave<LPW>(lane, a, b);
+    prof.mark(lane, 1);
     if (face_query_a.separation > 0.0f) {
+        prof.count(lane, 5);
         return false;
     }
 
     FaceQuery face_query_b = queryFaceDirectionsWave<LPW>(lane, b, a);
+    prof.mark(lane, 2);
     if (face_query_b.separation > 0.0f) {
+        prof.count(lane, 6);
         return false;
     }
 
     EdgeQuery edge_query = queryEdgeDirectionsWave<LPW>(lane, a, b);
+    prof.mark(lane, 3);
     if (edge_query.separation > 0.0f) {
+        prof.count(lane, 7);
         return false;
     }
+    prof.count(lane, 8);
 
     // from here on every lane computes the same thing (cheap, and it keeps the
     // wave converged); the clipping polygons live in LDS
@@ -336,8 +375,10 @@ __device__ inline bool hullHullWaveSAT(uint32_t lane, const PairSetup &pair,
         }
     }
 
-    return satToContact(sat, a, b, pair.aLoc, pair.bLoc,
-                        scratch->clip[0], scratch->clip[1], out);
+    const bool found = satToContact(sat, a, b, pair.aLoc, pair.bLoc,
+                                    scratch->clip[0], scratch->clip[1], out);
+    prof.mark(lane, 4);
+    return found;
 }
 
 // Every other primitive pair: one lane, hull evaluated lazily, clipping
@@ -1289,6 +1330,13 @@ physicsPackKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
 #ifndef MADRONA_PHYS_LDS_WAVES_PER_EU
 #define MADRONA_PHYS_LDS_WAVES_PER_EU 2
 #endif
+// (two worlds per wavefront: one wavefront per SIMD with the whole register
+// file -- a pair of world blocks is 37.8 KB of LDS, four per CU; 2 = the
+// register cap a second wavefront per SIMD would need, measured by itself in
+// profiles/r04_phys_variants.jsonl)
+#ifndef MADRONA_PHYS_LDS32_WAVES_PER_EU
+#define MADRONA_PHYS_LDS32_WAVES_PER_EU 1
+#endif
 //
 // LPW = lanes per world.  64: one world per wavefront.  32: TWO worlds per
 // wavefront, one per half (MAXB <= 32): a 28-body world with ~14 contacts and
@@ -1299,10 +1347,18 @@ physicsPackKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
 // the level loops of the solver are per group, the halves diverge where their
 // worlds differ.  Two 32-body blocks are 35 KB of LDS: four wavefronts per CU,
 // one per SIMD, with the whole register file (512) to themselves.
+#ifdef MADRONA_PHYS_LDS_NUM_VGPR
+// (measurement builds: a register cap without the occupancy to go with it --
+// the compiler ignores amdgpu_waves_per_eu above what the LDS block admits)
+#define MADRONA_PHYS_VGPR_CAP __attribute__((amdgpu_num_vgpr(MADRONA_PHYS_LDS_NUM_VGPR)))
+#else
+#define MADRONA_PHYS_VGPR_CAP
+#endif
 template <int MAXB, int LPW = 64>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64) MADRONA_PHYS_VGPR_CAP
 __attribute__((amdgpu_waves_per_eu(
-    MAXB <= 64 && LPW == 64 ? MADRONA_PHYS_LDS_WAVES_PER_EU : 1)))
+    MAXB <= 64 && LPW == 64 ? MADRONA_PHYS_LDS_WAVES_PER_EU :
+    LPW == 32 ? MADRONA_PHYS_LDS32_WAVES_PER_EU : 1)))
 physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
 {
     mwhip::TraceScope trace_scope(S);
@@ -1326,6 +1382,12 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
 #ifdef MADRONA_PHYS_PROFILE
     unsigned long long prof_t = __builtin_readcyclecounter();
     unsigned long long prof_acc[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    // stages of the cooperative hull-hull tests: slots 16.. of the same buffer
+#define PHYS_HH_PROF() HullHullProf { S->moduleData[1] != nullptr ? \
+        (unsigned long long *)S->moduleData[1] + 16 : nullptr, \
+        (unsigned long long)__builtin_readcyclecounter() }
+#else
+#define PHYS_HH_PROF() HullHullProf {}
 #endif
 
     // Worlds are taken in the order physicsOrderKernel left: the ones that took
@@ -1657,7 +1719,8 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                             PairSetup shared_pair = ldsSetupPair(
                                 w, obj_mgr, candidateAt(chunk + src));
                             const bool found = hullHullWave<LPW>(lane, shared_pair,
-                                &w->scratch.hull, stage + src, &pair_too_big);
+                                &w->scratch.hull, stage + src, &pair_too_big,
+                                PHYS_HH_PROF());
                             const uint32_t outcome = __shfl(
                                 (found ? 1u : 0u) | (pair_too_big ? 2u : 0u), 0, LPW);
                             if (lane == src) {
@@ -1686,7 +1749,8 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                         // every lane of the group writes the same contact to
                         // src's slot
                         found = hullHullWave<hull_lanes>(hull_lane, shared_pair,
-                            hull_scratch, stage + src, &pair_too_big);
+                            hull_scratch, stage + src, &pair_too_big,
+                            PHYS_HH_PROF());
                     }
                     // the lane that owns the candidate learns the outcome
                     const uint32_t outcome =

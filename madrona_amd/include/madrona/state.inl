@@ -708,7 +708,12 @@ MADRONA_HD bool StateManager::archetypeNeedsSort(uint32_t archetype_id) const
 
 MADRONA_HD void StateManager::archetypeSetNeedsSort(uint32_t archetype_id)
 {
+    // A caller that asks for a re-sort may have rewritten the WorldID keys of
+    // rows that are already in the table: nothing of it counts as "still in
+    // world order" any more, so the next world sort takes the radix chain
+    // (the compaction chain trusts rows [0, sortedRows)).
     tables[archetype_id].needsSort = 1u;
+    tables[archetype_id].sortedRows = 0;
 }
 
 namespace mwhip {

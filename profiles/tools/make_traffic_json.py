@@ -67,7 +67,15 @@ def main():
     sim, worlds, fetch_db, write_db = sys.argv[1], int(sys.argv[2]), sys.argv[3], sys.argv[4]
     fetch = per_kernel(fetch_db, "FETCH_SIZE")
     write = per_kernel(write_db, "WRITE_SIZE")
-    steps = max(n for k, (_, n) in fetch.items() if "statsKernel" in k)
+    # Each pass is normalised by ITS OWN replay count: the bench repeats its
+    # timed window until it is long enough, so the two passes (different counter,
+    # different slowdown) replay the step graph a different number of times.
+    # (Round 3 divided both by the fetch pass's count: at 65536 Escape-Room
+    # worlds -- 262 replays in the fetch pass, 397 in the write pass -- every
+    # WRITE_SIZE per step came out 1.52 x too large, the "write amplification"
+    # of the gather in r03_hbm_traffic.json.)
+    fetch_steps = max(n for k, (_, n) in fetch.items() if "statsKernel" in k)
+    write_steps = max(n for k, (_, n) in write.items() if "statsKernel" in k)
     merged = defaultdict(lambda: [0.0, 0.0, 0])
     for short, (total, n) in fetch.items():
         merged[bench_name(short)][0] += total
@@ -78,11 +86,13 @@ def main():
     for name, (f_kib, w_kib, n) in sorted(merged.items()):
         if "benchWindowMarker" in name or "gateKernel" in name:
             continue
-        per_step = (2.0 * f_kib + w_kib) * 1024.0 / steps
+        per_step = (2.0 * f_kib / fetch_steps + w_kib / write_steps) * 1024.0
         entries.append({"sim": sim, "worlds": worlds, "kernel": name,
-                        "fetch_size_kib_per_step": round(f_kib / steps, 1),
-                        "write_size_kib_per_step": round(w_kib / steps, 1),
-                        "launches_per_step": round(n / steps, 2),
+                        "fetch_size_kib_per_step": round(f_kib / fetch_steps, 1),
+                        "write_size_kib_per_step": round(w_kib / write_steps, 1),
+                        "launches_per_step": round(n / fetch_steps, 2),
+                        "replays_fetch_pass": fetch_steps,
+                        "replays_write_pass": write_steps,
                         "traffic_bytes": int(per_step)})
     entries.append(step_entry(sim, worlds, entries))
     print(json.dumps(entries))

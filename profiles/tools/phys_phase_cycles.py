@@ -25,13 +25,13 @@ with Simulator(hip_lib_path('escape_room_phys'), W, seed=5, flags=200) as hip:
     dev = torch.from_numpy(ring).cuda()
     hip.set_input_ring('action', dev.data_ptr(), 61)
     hip.step(300)
-    buf = rt.mwhip_alloc_device(hip.hip_exec(), 128, 1)
+    buf = rt.mwhip_alloc_device(hip.hip_exec(), 256, 1)
     rt.mwhip_set_module_data(hip.hip_exec(), 1, buf)
     N = 50
     hip.step(N)
-    out = np.zeros(16, np.uint64)
-    rt.mwhip_memcpy_d2h(out.ctypes.data, buf, 128)
-    events, out = out[12:], out[:12]
+    out = np.zeros(32, np.uint64)
+    rt.mwhip_memcpy_d2h(out.ctypes.data, buf, 256)
+    hh, events, out = out[16:], out[12:16], out[:12]
     # (slot 2 also collects the velocity solve of the substep before it, slot 6
     # only that of the last substep: see the PHYS_PROF marks in world_step.inl)
     names = ['np.setup', 'candidates', 'integrate (+ solveVel of substeps 1-3)', 'np.solo', 'solvePos+jnt+setVel', 'np.hull+compact', 'solveVel (last substep)', 'joints / store', 'load bodies (rows -> block)', 'stage prims', 'world lookup (singletons, row ranges)', '(unused)']
@@ -43,3 +43,12 @@ with Simulator(hip_lib_path('escape_room_phys'), W, seed=5, flags=200) as hip:
     hull, hull_hit, solo, cands = (float(v) / N / W for v in events)
     print(f'per world and step (4 substeps): {cands:.1f} candidate tests, {solo:.1f} per-lane '
           f'pairs, {hull:.1f} hull-hull pairs of which {hull_hit:.1f} touch')
+    # stages of the cooperative hull-hull tests (HullHullProf, world_step.inl)
+    hh = hh.astype(np.float64) / N / W
+    tests = hh[5] + hh[6] + hh[7] + hh[8]
+    print(f'hull-hull tests per world and step: {tests:.2f}; separated by a face of A '
+          f'{hh[5]:.2f}, by a face of B {hh[6]:.2f}, by an edge pair {hh[7]:.2f}, '
+          f'overlapping {hh[8]:.2f}')
+    for n, v in zip(['hulls -> LDS', 'face query A', 'face query B', 'edge query',
+                     'manifold'], hh[:5]):
+        print(f'  hull-hull {n:14s} {v:10.0f} ticks/world/step')

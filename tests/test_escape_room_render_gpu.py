@@ -180,3 +180,36 @@ def test_config5_render_pass_full_size(built):
         # than a step: a ray grazing a triangle edge)
         _compare(hip_rgb, hip_depth, ref_rgb, ref_depth, True, ("config5", worlds, res),
                  flips=4, offs=4)
+
+
+def test_input_ring_ignores_render_replays(built):
+    """mwhip_set_input_ring with render-graph replays queued between the steps
+    (config 5's loop: step, render, step, render ...): the k-th STEP takes slot
+    k % slots -- render replays neither read nor advance the ring (ADVICE r3:
+    the ring used to index by replays of any graph, so every render skipped a
+    slot; an even number of slots then repeated half of the ring)."""
+    import torch
+    worlds, res, slots, steps = 48, 16, 4, 11
+    rng = np.random.default_rng(11)
+    ring = np.stack([_actions(rng, worlds) for _ in range(slots)])
+    flags = 9 | (res << 16)
+    with Simulator(hip_lib_path("escape_room_render"), worlds, seed=6, flags=flags) as a, \
+            Simulator(hip_lib_path("escape_room_render"), worlds, seed=6, flags=flags) as b:
+        dev = torch.from_numpy(ring).cuda()
+        a.render()      # (builds the render graph; a render before the ring is set)
+        b.render()
+        a.set_input_ring("action", dev.data_ptr(), slots)
+        render_graph = a.render_graph()
+        for step in range(steps):
+            a.step_async(1)
+            a.step_async(1 + step % 2, graph=render_graph)
+        a.sync()
+        for step in range(steps):
+            b.write_tensor("action", ring[step % slots])
+            b.step(1)
+        b.render()
+        assert not compare_columns(a.dump_all(), b.dump_all())
+        assert np.array_equal(a.read_tensor("action"), b.read_tensor("action"))
+        assert np.array_equal(a.read_tensor("rgb"), b.read_tensor("rgb"))
+        assert np.array_equal(a.read_tensor("depth"), b.read_tensor("depth"))
+        del dev
