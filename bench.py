@@ -347,6 +347,12 @@ def kernel_table(stats, sim_name, worlds):
             row["algo_MB"] = round(k["algo_bytes"] / 1e6, 4)
             row["GBps"] = (round(k["algo_bytes"] / (k["avg_us"] * 1e-6) / 1e9, 1)
                            if k["avg_us"] > 0 else 0.0)
+        elif k["algo_bytes"] > 0 and k.get("io_declared"):
+            # rows x (4 + declared reads + declared writes), SURVEY 8d
+            row["algo_MB"] = round(k["algo_bytes"] / 1e6, 4)
+            row["GBps"] = (round(k["algo_bytes"] / (k["avg_us"] * 1e-6) / 1e9, 1)
+                           if k["avg_us"] > 0 else 0.0)
+            row["bytes"] = "declared read/write set"
         elif k["algo_bytes"] > 0:
             row["algo_MB_signature_upper_bound"] = round(k["algo_bytes"] / 1e6, 4)
         rows.append(row)
@@ -433,6 +439,50 @@ def rooflines(stats, sim_name, worlds, ms_per_step):
             "two worlds per wavefront, one wavefront per SIMD (LDS: 2 x 17 KB per "
             "wave): the kernel is bound by how fast one wave issues, not by HBM "
             "(DESIGN.md §10)")
+    # ParallelFor nodes (north_star: "sort + ParallelFor nodes at >= 50 % of the
+    # HBM roofline"): bytes = rows x (4 + declared reads + declared writes) where
+    # the system declares its read / write set next to its definition
+    # (madrona::mwhip::systemIO), else the signature rule (an upper
+    # bound: T & = read + write), kept apart.
+    pfor_k = [k for k in stats if k["algo_bytes"] > 0 and ":sort." not in k["name"]
+              and not k["name"].startswith("physics:worldStep")]
+    for label, group in (("parallel_for", [k for k in pfor_k if k.get("io_declared")]),
+                         ("parallel_for_signature_rule",
+                          [k for k in pfor_k if not k.get("io_declared")])):
+        if not group:
+            continue
+        t_sum, t_src, t_missing = 0, None, []
+        for k in group:
+            t, src = traffic_for(entries, sim_name, worlds, k["name"])
+            if t is None:
+                t_missing.append(k["name"])
+            else:
+                t_sum, t_src = t_sum + t, src
+        node = node_roofline(
+            "ParallelFor nodes, read / write sets declared next to the systems"
+            if label == "parallel_for" else
+            "ParallelFor nodes without a declared set (signature rule: upper bound)",
+            group, t_sum if t_src else None, t_src,
+            "sum of rows x (4 B WorldID + declared reads + declared writes) over "
+            "the nodes / sum of their kernel times (HIP events on the dispatches); "
+            "at Escape-Room sizes most of these launches sit on the ~4.5 us floor "
+            "of a graph kernel node, not on bytes")
+        node["kernels"] = [{
+            "name": k["name"], "avg_us": round(k["avg_us"], 2),
+            "rows": round(k["rows"], 1), "algo_MB": round(k["algo_bytes"] / 1e6, 4),
+            "GBps": round(k["algo_bytes"] / max(k["avg_us"] * 1e-6, 1e-12) / 1e9, 1),
+        } for k in group]
+        if t_missing:
+            node["traffic_missing_for"] = t_missing
+        nodes[label] = node
+    # sort + declared ParallelFor nodes together: the clause as north_star words it
+    both = sort_k + [k for k in pfor_k if k.get("io_declared")]
+    if sort_k and len(both) > len(sort_k):
+        nodes["sort_and_parallel_for"] = node_roofline(
+            "sort nodes + ParallelFor nodes (declared sets) of the step", both,
+            None, None, "north_star's clause taken as a whole: summed algorithmic "
+            "bytes / summed kernel time")
+
     # step level: every kernel's algorithmic bytes over the measured step time
     step_bytes = sum(k["algo_bytes"] for k in stats)
     t, src = traffic_for(entries, sim_name, worlds, "step:all-kernels")
@@ -466,7 +516,9 @@ def run_single(sim_name, worlds, gpu_id, seed, denom, steps, warmup, profile_rep
     import torch
     from madrona_amd.simlib import Simulator, hip_lib_path
 
-    with Simulator(hip_lib_path(sim_name), worlds, seed=seed, gpu_id=gpu_id,
+    # "<sim>_portable": the same simulator built from its portable sources
+    lib_name, sim_name = sim_name, sim_name.removesuffix("_portable")
+    with Simulator(hip_lib_path(lib_name), worlds, seed=seed, gpu_id=gpu_id,
                    flags=denom) as sim:
         fill_actions(sim_name, sim, worlds, gpu_id, 99)
         sim.step_async(settle + warmup)
@@ -891,6 +943,33 @@ def main():
                             200, 30, 10, min(args.settle, 200),
                             cpu_sample=not args.no_cpu_baseline)
 
+    # What an UNCHANGED simulator gets: the same workloads from the simulators'
+    # portable sources (no wave-cooperative extensions; sims/*/sim.cpp
+    # SIM_PORTABLE, lib<sim>_portable_hip.so) -- north_star: "existing simulators
+    # ... link unchanged".
+    portable = None
+    if (rank == 0 and world_size == 1 and args.sim == "escape_room_phys"
+            and not args.no_secondary
+            and os.path.exists(hip_lib_path("escape_room_phys_portable"))):
+        portable = {}
+        for key, name, w, steps in (("config3", "escape_room_phys_portable",
+                                     args.worlds, 400),
+                                    ("config2", "escape_room_portable", 4096, 2000)):
+            r = run_single(name, w, local_rank, seed, args.auto_reset_denom,
+                           steps, 100, 10, settle=args.settle)
+            slow = sorted(r["kernels"], key=lambda k: -k["avg_us"])[:4]
+            portable[key] = {
+                "workload": r["workload"], "value": r["value"], "unit": "steps/s",
+                "ms_per_step": r["ms_per_step"],
+                "slowest_kernels": [[k["name"], k["avg_us"]] for k in slow],
+            }
+        portable["note"] = (
+            "the bench simulators compiled from their portable sources "
+            "(-DSIM_PORTABLE: plain makeEntity / destroyEntity / "
+            "findEntitiesWithinAABB, one lane per world); `value` above and "
+            "ecs_config2 are the same simulators with the wave-cooperative reset "
+            "/ grab systems (sims/*/sim.cpp, SIM_WAVE_API)")
+
     dist_world = dist.get_world_size() if distributed else 1
     if distributed:
         dist.barrier()
@@ -935,6 +1014,7 @@ def main():
             "cpu_baseline": cpu,
             "ecs_config2": secondary,
             "render_config5": render,
+            "portable_sim": portable,
             "kernels": kernels,
         }
         # flush what C libraries buffered for "stdout" while it pointed at stderr

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MWHIP_ABI_VERSION 3u   /* 3: mwhip_render_geometry grew (uvs, per-triangle materials, textures) */
+#define MWHIP_ABI_VERSION 4u   /* 4: mwhip_node_desc / mwhip_kernel_stat grew io_declared (declared read / write sets) */
 
 typedef struct mwhip_exec mwhip_exec; /* opaque; == MWCudaExecutor::Impl */
 
@@ -310,6 +310,11 @@ typedef struct mwhip_node_desc {
     /* SORT / CLEAR_TMP */
     uint32_t archetype_id;
     uint32_t component_id;
+    /* bytes_per_row comes from a read / write set declared next to the system
+     * (1; madrona::mwhip::systemIO, taskgraph.inl) or from the signature rule
+     * (0: const T & = read, T & = read + write -- an upper bound).  SURVEY §8d;
+     * the reference's per-row contract is device taskgraph.inl:164-300. */
+    uint32_t io_declared;
 } mwhip_node_desc;
 
 /* TaskGraph::Builder::constructNodeData (taskgraph.inl:43-57): copies a node
@@ -434,6 +439,9 @@ typedef struct mwhip_kernel_stat {
     double avg_us;          /* mean duration of this kernel per step */
     double algo_bytes;      /* mean algorithmic bytes per launch */
     double rows;            /* mean rows / invocations processed per launch */
+    uint32_t io_declared;   /* algo_bytes from a declared read / write set (1),
+                             * from the signature rule (0) */
+    uint32_t pad_;
 } mwhip_kernel_stat;
 int32_t mwhip_profile(mwhip_exec *exec, uint64_t graph, uint32_t reps,
                       mwhip_kernel_stat *out, uint32_t max_out);

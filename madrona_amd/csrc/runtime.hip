@@ -2079,6 +2079,7 @@ static int buildLaunchList(mwhip_exec *exec, const std::vector<uint32_t> &tg_ids
                 k.role = "";
                 k.kind = d.kind;
                 k.bytesPerRow = d.bytes_per_row;
+                k.ioDeclared = d.io_declared;
                 k.countMode = d.count_mode;
                 k.fixedCount = d.fixed_count;
                 k.queryOffset = d.query_offset;
@@ -4131,6 +4132,8 @@ extern "C" int32_t mwhip_profile(mwhip_exec *exec, uint64_t graph, uint32_t reps
         out[i].avg_us = total_us[i] / reps;
         out[i].algo_bytes = total_bytes[i] / reps;
         out[i].rows = total_rows[i] / reps;
+        out[i].io_declared = lg.launches[i].ioDeclared;
+        out[i].pad_ = 0;
     }
     return (int32_t)n;
 }

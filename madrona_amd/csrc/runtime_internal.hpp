@@ -183,6 +183,7 @@ struct KernelLaunch {
     uint32_t kind = MWHIP_NODE_KERNEL;
     uint32_t archetype = 0xFFFFFFFFu;
     uint32_t bytesPerRow = 0;
+    uint32_t ioDeclared = 0;        // bytesPerRow from a declared read / write set
     uint32_t countMode = 0;
     uint32_t fixedCount = 0;
     uint32_t queryOffset = 0;

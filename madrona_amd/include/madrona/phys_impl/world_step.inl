@@ -228,7 +228,10 @@ __device__ inline EdgeQuery queryEdgeDirectionsWave(uint32_t lane,
     return best;
 }
 
-// makeHullState with the vertices / planes spread over the G lanes of the test
+// makeHullState with the vertices / planes spread over the G lanes of the test.
+// The centroid is left out: only the edge query reads it, and only hull a's
+// (narrowphase.hpp testEdgePair) -- hullCentroid() below, once both face
+// queries have failed to separate the pair (half of the tests end before).
 template <int G = 64>
 __device__ inline HullState makeHullStateWave(uint32_t lane,
                                               const HalfEdgeMesh &mesh,
@@ -243,42 +246,43 @@ __device__ inline HullState makeHullStateWave(uint32_t lane,
     for (uint32_t i = lane; i < mesh.numFaces; i += G) {
         dst_planes[i] = lazy.plane(i);
     }
-    wave::phaseFence();
-
-    // the centroid is a sequential sum (fp order): every lane adds it up
-    Vector3 center = Vector3::zero();
-    const CountT num_vertices = (CountT)mesh.numVertices;
-    for (CountT i = 0; i < num_vertices; i++) {
-        center += dst_vertices[i];
-    }
-    center /= (float)num_vertices;
 
     HalfEdgeMesh world_mesh = mesh;
     world_mesh.facePlanes = dst_planes;
     world_mesh.vertices = dst_vertices;
-    return HullState { world_mesh, center };
+    return HullState { world_mesh, Vector3::zero() };
 }
 
+// the centroid is a sequential sum (fp order): every lane adds it up
+__device__ inline void hullCentroid(HullState &hull)
+{
+    Vector3 center = Vector3::zero();
+    const CountT num_vertices = (CountT)hull.mesh.numVertices;
+    for (CountT i = 0; i < num_vertices; i++) {
+        center += hull.mesh.vertices[i];
+    }
+    center /= (float)num_vertices;
+    hull.center = center;
+}
+__device__ inline void hullCentroid(LazyHull &) {}     // (has it already)
+
 // Profile builds (-DMADRONA_PHYS_PROFILE): cycles and exit counts of the stages
-// of a cooperative hull-hull test, added up by lane 0 of the group in
-// hh_prof[0..11] (moduleData[1] + 16 slots, profiles/tools/phys_phase_cycles.py).
+// of a cooperative hull-hull test, accumulated in the calling kernel's own
+// counters (slots 16.. of prof_acc: registers -- atomics per mark distort the
+// very thing they measure; profiles/tools/phys_phase_cycles.py).
 struct HullHullProf {
 #ifdef MADRONA_PHYS_PROFILE
     unsigned long long *acc;
     unsigned long long t;
-    __device__ inline void mark(uint32_t lane, int slot)
+    __device__ inline void mark(uint32_t, int slot)
     {
         unsigned long long now = __builtin_readcyclecounter();
-        if (lane == 0 && acc != nullptr) {
-            atomicAdd(&acc[slot], now - t);
-        }
+        acc[16 + slot] += now - t;
         t = now;
     }
-    __device__ inline void count(uint32_t lane, int slot)
+    __device__ inline void count(uint32_t, int slot)
     {
-        if (lane == 0 && acc != nullptr) {
-            atomicAdd(&acc[slot], 1ull);
-        }
+        acc[16 + slot] += 1ull;
     }
 #else
     __device__ inline void mark(uint32_t, int) {}
@@ -288,7 +292,7 @@ struct HullHullProf {
 
 template <int LPW = 64, typename HullA, typename HullB>
 __device__ inline bool hullHullWaveSAT(uint32_t lane, const PairSetup &pair,
-                                       const HullA &a, const HullB &b,
+                                       HullA &a, const HullB &b,
                                        HullScratch *scratch,
                                        ContactConstraint *out, bool *too_big,
                                        HullHullProf prof = HullHullProf {});
@@ -317,6 +321,12 @@ hullHullWave(uint32_t lane, const PairSetup &pair,
             scratch->hullVerts[0], scratch->hullPlanes[0]);
         HullState b = makeHullStateWave<LPW>(lane, b_mesh, pair.b,
             scratch->hullVerts[1], scratch->hullPlanes[1]);
+        wave::phaseFence();
+#ifdef MADRONA_PHYS_EAGER_CENTROID
+        // (round 3, for A/B measurements: both centroids up front)
+        hullCentroid(a);
+        hullCentroid(b);
+#endif
         prof.mark(lane, 0);     // hulls into LDS
         return hullHullWaveSAT<LPW>(lane, pair, a, b, scratch, out, too_big,
                                     prof);
@@ -329,7 +339,7 @@ hullHullWave(uint32_t lane, const PairSetup &pair,
 
 template <int LPW, typename HullA, typename HullB>
 __device__ inline bool hullHullWaveSAT(uint32_t lane, const PairSetup &pair,
-                                       const HullA &a, const HullB &b,
+                                       HullA &a, const HullB &b,
                                        HullScratch *scratch,
                                        ContactConstraint *out, bool *too_big,
                                        HullHullProf prof)
@@ -348,6 +358,9 @@ __device__ inline bool hullHullWaveSAT(uint32_t lane, const PairSetup &pair,
         return false;
     }
 
+#ifndef MADRONA_PHYS_EAGER_CENTROID
+    hullCentroid(a);
+#endif
     EdgeQuery edge_query = queryEdgeDirectionsWave<LPW>(lane, a, b);
     prof.mark(lane, 3);
     if (edge_query.separation > 0.0f) {
@@ -1381,10 +1394,10 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
 
 #ifdef MADRONA_PHYS_PROFILE
     unsigned long long prof_t = __builtin_readcyclecounter();
-    unsigned long long prof_acc[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-    // stages of the cooperative hull-hull tests: slots 16.. of the same buffer
-#define PHYS_HH_PROF() HullHullProf { S->moduleData[1] != nullptr ? \
-        (unsigned long long *)S->moduleData[1] + 16 : nullptr, \
+    unsigned long long prof_acc[32] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                                        0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    // stages of the cooperative hull-hull tests: slots 16.. (HullHullProf)
+#define PHYS_HH_PROF() HullHullProf { prof_acc, \
         (unsigned long long)__builtin_readcyclecounter() }
 #else
 #define PHYS_HH_PROF() HullHullProf {}
@@ -1394,10 +1407,33 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
     // longest last step first, so that the launch does not end on a few heavy
     // worlds with most of the chip idle (and the two worlds of a wavefront,
     // neighbours in that order, cost about the same).
+    //
+    // Which two worlds share a wavefront (LPW = 32): neighbours in that order.
+    // The other candidate -- the k-th heaviest with the k-th lightest
+    // (foldPairs, MADRONA_MWHIP_PHYS_ORDER=2), on the theory that what only one
+    // world does (a cooperative hull-hull test, 5-18 us) is time the other
+    // half sits out, so that a wavefront costs the SUM of its worlds' tests and
+    // equal sums pack better -- was measured slower (Escape Room 825 -> 844 us,
+    // Hide-and-Seek 930 -> 980 us): most of a world's cost is in the parts both
+    // halves run in lock step (loads, integration, solver levels), where a
+    // wavefront costs the LONGER of its two worlds, and similar worlds waste
+    // the least of it.
     const int32_t *world_order = params.worldOrder;
-    for (int32_t slot = (int32_t)blockIdx.x * worlds_per_wave + group;
-         slot < num_worlds;
-         slot += (int32_t)gridDim.x * worlds_per_wave) {
+    const bool fold_pairs = LPW == 32 && params.foldPairs != 0 &&
+        world_order != nullptr;
+    const int32_t num_jobs = (num_worlds + worlds_per_wave - 1) / worlds_per_wave;
+    for (int32_t job = (int32_t)blockIdx.x; job < num_jobs;
+         job += (int32_t)gridDim.x) {
+        int32_t slot = job * worlds_per_wave + group;
+        if (fold_pairs) {
+            slot = group == 0 ? job : num_worlds - 1 - job;
+            if (group != 0 && slot == job) {
+                continue;       // (odd world count: the middle one is alone)
+            }
+        }
+        if (slot >= num_worlds) {
+            continue;
+        }
         const int32_t world = world_order != nullptr ? world_order[slot] : slot;
         const long long cost_t0 = (long long)wall_clock64();
         uint32_t cost_work = 1;    // (what the world asked of the wavefront, roughly)
@@ -1957,7 +1993,8 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
 #ifdef MADRONA_PHYS_PROFILE
     if (lane == 0 && S->moduleData[1] != nullptr) {
         unsigned long long *dst = (unsigned long long *)S->moduleData[1];
-        for (int i = 0; i < 16; i++) {
+#pragma unroll
+        for (int i = 0; i < 32; i++) {
             atomicAdd(&dst[i], prof_acc[i]);
         }
     }

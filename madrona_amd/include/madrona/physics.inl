@@ -68,7 +68,10 @@ struct PhysicsScratch {
 // node data of the fused per-world step kernel
 struct PhysicsStepParams {
     int32_t numSubsteps;
-    int32_t pad_;
+    // two worlds per wavefront: 1 = wavefront k steps the k-th heaviest world
+    // next to the k-th lightest (worldOrder folded), 0 = next to its neighbour
+    // in that order
+    int32_t foldPairs;
     // per-world images of the LDS step's block (physicsPackKernel writes them
     // right before the step kernel reads them), or nullptr: the step kernel
     // reads the tables itself
@@ -944,6 +947,34 @@ inline void refitEntry(Context &ctx, LeafID leaf_id)
 }
 
 }
+
+}   // namespace madrona::phys
+
+// What the leaf systems move per body (madrona::mwhip::systemIO,
+// taskgraph.inl): the row's columns in, the leaf's box (24 B) and transform
+// (40 B: position, rotation, scale) out; the refit adds the leaf's slot in its
+// parent node (24 B, read + written when the box grew).  rigidBodyAABBs is a
+// shared read-only table of the object manager: excluded.
+template <> inline constexpr madrona::mwhip::SystemIOBytes
+    madrona::mwhip::systemIO<madrona::phys::broadphase::updateLeafPositionsEntry> =
+        madrona::mwhip::declareIO<
+            madrona::mwhip::Reads<madrona::phys::broadphase::LeafID,
+                madrona::base::Position, madrona::base::Rotation,
+                madrona::base::Scale, madrona::base::ObjectID,
+                madrona::phys::Velocity>,
+            madrona::mwhip::Writes<madrona::math::AABB,
+                madrona::mwhip::Times<float, 10>>>();
+template <> inline constexpr madrona::mwhip::SystemIOBytes
+    madrona::mwhip::systemIO<madrona::phys::broadphase::updateLeafAndRefitEntry> =
+        madrona::mwhip::declareIO<
+            madrona::mwhip::Reads<madrona::phys::broadphase::LeafID,
+                madrona::base::Position, madrona::base::Rotation,
+                madrona::base::Scale, madrona::base::ObjectID,
+                madrona::phys::Velocity, madrona::math::AABB>,
+            madrona::mwhip::Writes<madrona::math::AABB,
+                madrona::mwhip::Times<float, 10>, madrona::math::AABB>>();
+
+namespace madrona::phys {
 
 namespace xpbd {
 
@@ -1985,9 +2016,14 @@ MADRONA_HOST_API inline TaskGraphNodeID setupPhysicsStepTasks(
                   mwhip_last_error());
         }
     }
+    // Neighbours in the cost order share a wavefront.  MADRONA_MWHIP_PHYS_ORDER=2
+    // pairs the k-th heaviest with the k-th lightest instead: measured slower
+    // (profiles/r04_phys_variants.jsonl), see physicsStepLdsKernel.
+    const int32_t fold_pairs = lanes_per_world == 32 && world_order != nullptr &&
+        order_env != nullptr && atoi(order_env) >= 2 ? 1 : 0;
     auto params = builder.constructNodeData<PhysicsStepParams>(
-        PhysicsStepParams { (int32_t)num_substeps, 0, world_images, world_cost,
-                            world_order });
+        PhysicsStepParams { (int32_t)num_substeps, fold_pairs, world_images,
+                            world_cost, world_order });
 
     if (world_order != nullptr) {
         mwhip_node_desc order {};

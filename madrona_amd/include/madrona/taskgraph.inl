@@ -28,6 +28,49 @@ struct SystemTraits<void (*)(CtxT &, ArgTs...)> {
         4u + (0u + ... + systemArgBytes<ArgTs>());
 };
 
+// ---- what a system ACTUALLY reads and writes per row -------
+// "Each node declares its read/write set next to the kernel; when unknown,
+// fall back to the signature rule."  A simulator declares it next to the
+// system, outside its own namespace (as for systemWavesPerSIMD):
+//
+//   template <> inline constexpr madrona::mwhip::SystemIOBytes
+//       madrona::mwhip::systemIO<escape::movementSystem> =
+//           madrona::mwhip::declareIO<
+//               madrona::mwhip::Reads<escape::Action, madrona::base::Rotation>,
+//               madrona::mwhip::Writes<madrona::phys::ExternalForce,
+//                                      madrona::phys::ExternalTorque>>();
+//
+// Reads: every component value the function loads for a row -- the query's
+// columns it really looks at, and what it reaches through ctx.get(Entity) /
+// getDirect(Loc) (size per access, not per cache line; a type named twice is
+// counted twice, e.g. the Position of both agents); Entity if the signature
+// takes it.  Writes: every component it stores (a T & that is only written
+// appears in Writes alone; read and written: in both).  Shared read-only
+// tables (ObjectManager, BVH nodes) are excluded, as in SURVEY §8d.  The node's
+// algorithmic bytes are rows x (4 [WorldID] + reads + writes).
+template <typename... Ts> struct Reads {
+    static constexpr uint32_t bytes = (0u + ... + (uint32_t)sizeof(Ts));
+};
+template <typename... Ts> struct Writes {
+    static constexpr uint32_t bytes = (0u + ... + (uint32_t)sizeof(Ts));
+};
+// n copies of T (an observation of n other entities, a lidar of n samples)
+template <typename T, uint32_t n> struct Times { char bytes_[sizeof(T) * n]; };
+
+struct SystemIOBytes {
+    int32_t read;       // < 0: not declared, the signature rule applies
+    int32_t write;
+};
+
+template <auto Fn>
+inline constexpr SystemIOBytes systemIO = { -1, -1 };
+
+template <typename ReadsT, typename WritesT>
+constexpr SystemIOBytes declareIO()
+{
+    return SystemIOBytes { (int32_t)ReadsT::bytes, (int32_t)WritesT::bytes };
+}
+
 // Pulls "ns::fnName" out of __PRETTY_FUNCTION__ of a function templated on
 // <auto Fn> (host only, used to label kernels in profiles).
 template <auto Fn>
@@ -595,7 +638,12 @@ CustomParallelForNode<ContextT, Fn, threads_per_invocation,
     desc.num_matching = ref->numMatchingArchetypes;
     desc.threads_per_invocation = (uint32_t)threads_per_invocation;
 
-    if constexpr (items_per_invocation == 1) {
+    if constexpr (mwhip::systemIO<Fn>.read >= 0) {
+        // declared next to the system
+        desc.bytes_per_row = 4u + (uint32_t)mwhip::systemIO<Fn>.read +
+            (uint32_t)mwhip::systemIO<Fn>.write;
+        desc.io_declared = 1u;
+    } else if constexpr (items_per_invocation == 1) {
         desc.bytes_per_row = mwhip::SystemTraits<decltype(Fn)>::bytesPerRow;
     } else {
         desc.bytes_per_row = 4u + (0u + ... + (uint32_t)sizeof(ComponentTs));

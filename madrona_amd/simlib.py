@@ -104,6 +104,8 @@ class KernelStat(C.Structure):
         ("avg_us", C.c_double),
         ("algo_bytes", C.c_double),
         ("rows", C.c_double),
+        ("io_declared", C.c_uint32),
+        ("pad_", C.c_uint32),
     ]
 
 
@@ -387,4 +389,5 @@ class Simulator:
             raise RuntimeError(f"mwhip_profile -> {n}: {rt.mwhip_last_error().decode()}")
         return [dict(name=stats[i].name.decode(), kind=int(stats[i].node_kind),
                      avg_us=float(stats[i].avg_us), algo_bytes=float(stats[i].algo_bytes),
-                     rows=float(stats[i].rows)) for i in range(n)]
+                     rows=float(stats[i].rows),
+                     io_declared=bool(stats[i].io_declared)) for i in range(n)]

@@ -6,6 +6,18 @@
 #include <madrona/mw_gpu_entry.hpp>
 #endif
 
+// SIM_WAVE_API: this backend's wave-cooperative extensions (ordered create /
+// destroy by a wavefront per world, box queries with a lane per BVH leaf,
+// per-system occupancy) -- API the reference does not have.  -DSIM_PORTABLE
+// builds the simulator WITHOUT them even under MADRONA_GPU_MODE: the sources as
+// an unchanged reference simulator has them (plain makeEntity / destroyEntity /
+// findEntitiesWithinAABB, one lane per world; only the reference's own GPU
+// conventions remain: CustomParallelForNode for the ray systems,
+// RecycleEntitiesNode).  lib<sim>_portable_hip.so, the `portable_sim` bench line.
+#if defined(MADRONA_GPU_MODE) && !defined(SIM_PORTABLE)
+#define SIM_WAVE_API 1
+#endif
+
 using namespace madrona;
 using namespace madrona::math;
 
@@ -470,7 +482,7 @@ inline void stepTrackerSystem(Engine &,
     }
 }
 
-#ifdef MADRONA_GPU_MODE
+#ifdef SIM_WAVE_API
 // The reset of a world on the GPU backends: the reset system runs 64 lanes per
 // world (CustomParallelForNode<..., 64, 1>, the reference simulators' way of
 // spreading heavy per-world work over a warp) and lane i destroys / creates /
@@ -664,7 +676,7 @@ inline void resetSystem(Engine &ctx, WorldReset &reset)
         }
     }
 
-#ifdef MADRONA_GPU_MODE
+#ifdef SIM_WAVE_API
     // 64 lanes per world: lane 0 advances the reset stream, everybody learns
     // the outcome
     int32_t auto_reset = 0;
@@ -823,6 +835,88 @@ inline void lidarSystem(Engine &ctx,
     }
 }
 
+#ifdef MADRONA_GPU_MODE
+// ---------------------------------------------------------------------------
+// What each system reads and writes per row ("each node declares
+// its read/write set next to the kernel"; madrona::mwhip::systemIO,
+// taskgraph.inl) -- the algorithmic bytes the bench prices the ParallelFor
+// nodes at.  A row that returns early moves less: the set is what a row that
+// does the system's work moves.
+// ---------------------------------------------------------------------------
+}
+#define ESCAPE_SYSTEM_IO(fn, ...) \
+    template <> inline constexpr madrona::mwhip::SystemIOBytes \
+        madrona::mwhip::systemIO<escape::fn> = \
+            madrona::mwhip::declareIO<__VA_ARGS__>()
+namespace escape_io {
+using namespace escape;
+using madrona::Entity;
+using madrona::mwhip::Reads;
+using madrona::mwhip::Times;
+using madrona::mwhip::Writes;
+}
+ESCAPE_SYSTEM_IO(movementSystem,
+    escape_io::Reads<escape::Action, escape::Rotation>,
+    escape_io::Writes<escape::ExternalForce, escape::ExternalTorque>);
+// (a Dynamic row; the others stop after their ResponseType)
+ESCAPE_SYSTEM_IO(kinematicStepSystem,
+    escape_io::Reads<escape::Position, escape::Rotation, escape::Velocity,
+                     escape::ResponseType, escape::ExternalForce,
+                     escape::ExternalTorque>,
+    escape_io::Writes<escape::Position, escape::Rotation, escape::Velocity,
+                      escape::ExternalForce, escape::ExternalTorque,
+                      escape::SubstepPrevState, escape::PreSolvePositional,
+                      escape::PreSolveVelocity>);
+// own position + the position of both agents (ctx.get)
+ESCAPE_SYSTEM_IO(buttonSystem,
+    escape_io::Reads<escape::Position,
+                     escape_io::Times<escape::Position, escape::consts::numAgents>>,
+    escape_io::Writes<escape::ButtonState>);
+// the door's properties + the state of its (up to four, here two) buttons
+ESCAPE_SYSTEM_IO(doorOpenSystem,
+    escape_io::Reads<escape::DoorProperties,
+                     escape_io::Times<escape::ButtonState,
+                                      escape::consts::numButtonsPerRoom>>,
+    escape_io::Writes<escape::OpenState>);
+ESCAPE_SYSTEM_IO(setDoorPositionSystem,
+    escape_io::Reads<escape::Position, escape::OpenState>,
+    escape_io::Writes<escape::Position>);
+ESCAPE_SYSTEM_IO(rewardSystem,
+    escape_io::Reads<escape::Position, escape::Progress>,
+    escape_io::Writes<escape::Progress, escape::Reward>);
+ESCAPE_SYSTEM_IO(stepTrackerSystem,
+    escape_io::Reads<escape::StepsRemaining>,
+    escape_io::Writes<escape::StepsRemaining, escape::Done>);
+// a world that does not reset: its flag and both agents' Done (the work of a
+// reset is the simulator's level generation, not priced here)
+ESCAPE_SYSTEM_IO(resetSystem,
+    escape_io::Reads<escape::WorldReset,
+                     escape_io::Times<escape::Done, escape::consts::numAgents>>,
+    escape_io::Writes<>);
+// the agent's row, its room (LevelState singleton), the partner's position and
+// grab state, position + type of the room's cubes and buttons, the door
+ESCAPE_SYSTEM_IO(collectObservationsSystem,
+    escape_io::Reads<escape::Position, escape::Rotation, escape::Progress,
+                     escape::GrabState, escape::OtherAgents, escape::Room,
+                     escape::Position, escape::GrabState,
+                     escape_io::Times<escape::Position,
+                         escape::consts::numCubesPerRoom +
+                         escape::consts::numButtonsPerRoom>,
+                     escape_io::Times<escape::EntityType,
+                         escape::consts::numCubesPerRoom +
+                         escape::consts::numButtonsPerRoom>,
+                     escape::Position, escape::OpenState>,
+    escape_io::Writes<escape::SelfObservation, escape::PartnerObservation,
+                      escape::RoomEntityObservations, escape::DoorObservation>);
+// (the analytic stand-in for the ray cast: own pose, the other agent's position)
+ESCAPE_SYSTEM_IO(lidarSystem,
+    escape_io::Reads<escape_io::Entity, escape::Position, escape::Rotation,
+                     escape::OtherAgents, escape::Position>,
+    escape_io::Writes<escape::Lidar>);
+#undef ESCAPE_SYSTEM_IO
+namespace escape {
+#endif
+
 void Sim::setupTasks(TaskGraphManager &taskgraph_mgr, const Config &)
 {
     TaskGraphBuilder &builder = taskgraph_mgr.init(0);
@@ -879,7 +973,7 @@ void Sim::setupTasks(TaskGraphManager &taskgraph_mgr, const Config &)
             Done
         >>({reward_sys});
 
-#ifdef MADRONA_GPU_MODE
+#ifdef SIM_WAVE_API
     // 64 lanes per world: lane i resets entity i (resetWorldWave)
     auto reset_sys = builder.addToGraph<CustomParallelForNode<Engine,
         resetSystem, 64, 1,

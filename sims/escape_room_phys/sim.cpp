@@ -6,6 +6,18 @@
 #include <madrona/mw_gpu_entry.hpp>
 #endif
 
+// SIM_WAVE_API: this backend's wave-cooperative extensions (ordered create /
+// destroy by a wavefront per world, box queries with a lane per BVH leaf,
+// per-system occupancy) -- API the reference does not have.  -DSIM_PORTABLE
+// builds the simulator WITHOUT them even under MADRONA_GPU_MODE: the sources as
+// an unchanged reference simulator has them (plain makeEntity / destroyEntity /
+// findEntitiesWithinAABB, one lane per world; only the reference's own GPU
+// conventions remain: CustomParallelForNode for the ray systems,
+// RecycleEntitiesNode).  lib<sim>_portable_hip.so, the `portable_sim` bench line.
+#if defined(MADRONA_GPU_MODE) && !defined(SIM_PORTABLE)
+#define SIM_WAVE_API 1
+#endif
+
 using namespace madrona;
 using namespace madrona::math;
 using namespace madrona::phys;
@@ -438,7 +450,7 @@ ESCPHYS_COLD static void releaseGrab(Engine &ctx, Entity held, GrabState &grab)
     grab.constraintEntity = Entity::none();
 }
 
-#ifdef MADRONA_GPU_MODE
+#ifdef SIM_WAVE_API
 // The GPU graph splits the grab in two.  This node runs a wavefront per world
 // (CustomParallelForNode<..., 64, 1, ...>): the box queries of all agents that
 // reach for something, a lane per BVH leaf (grabbing moves no body, so the
@@ -501,7 +513,7 @@ inline void grabSystem(Engine &ctx, LevelState &)
         Vector3 pos = ctx.get<Position>(e);
         Quat rot = ctx.get<Rotation>(e);
 
-#ifdef MADRONA_GPU_MODE
+#ifdef SIM_WAVE_API
         Entity grab_entity = sim.grabTargets[i];
 #else
         Vector3 reach = pos + rot.rotateVec(Vector3 { 0.f, 1.75f, 0.f });
@@ -626,7 +638,7 @@ inline void stepTrackerSystem(Engine &,
     }
 }
 
-#ifdef MADRONA_GPU_MODE
+#ifdef SIM_WAVE_API
 // The reset of a world on the GPU backends: 64 lanes per world
 // (CustomParallelForNode<..., 64, 1>), lane i destroys / creates / fills in
 // entity i instead of one lane doing all of them in sequence.  What comes out is
@@ -916,7 +928,7 @@ inline void resetSystem(Engine &ctx, WorldReset &reset)
         }
     }
 
-#ifdef MADRONA_GPU_MODE
+#ifdef SIM_WAVE_API
     // 64 lanes per world: lane 0 advances the reset stream, everybody learns
     // the outcome
     int32_t auto_reset = 0;
@@ -1067,6 +1079,104 @@ inline void lidarSystem(Engine &ctx,
 #endif
 }
 
+#ifdef MADRONA_GPU_MODE
+// ---------------------------------------------------------------------------
+// What each system reads and writes per row (see
+// sims/escape_room/sim.cpp and madrona::mwhip::systemIO, taskgraph.inl).
+// bodiesPerWorld: the leaf boxes of the world's BVH a ray / box query walks
+// over (per-world data, read once per row; the object manager's meshes are the
+// shared read-only tables SURVEY §8d excludes).
+// ---------------------------------------------------------------------------
+}
+#define ESCPHYS_SYSTEM_IO(fn, ...) \
+    template <> inline constexpr madrona::mwhip::SystemIOBytes \
+        madrona::mwhip::systemIO<escphys::fn> = \
+            madrona::mwhip::declareIO<__VA_ARGS__>()
+namespace escphys_io {
+using madrona::Entity;
+using madrona::math::AABB;
+using madrona::mwhip::Reads;
+using madrona::mwhip::Times;
+using madrona::mwhip::Writes;
+// floor + 4 borders + 2 agents + 3 x (2 walls + door + 4 cubes)
+inline constexpr uint32_t bodiesPerWorld = 28;
+}
+ESCPHYS_SYSTEM_IO(movementSystem,
+    escphys_io::Reads<escphys::Action, escphys::Rotation>,
+    escphys_io::Writes<escphys::ExternalForce, escphys::ExternalTorque>);
+#ifdef SIM_WAVE_API
+// (per world) both agents' action + grab state + pose, the leaf boxes the box
+// queries test, the type of the entity found
+ESCPHYS_SYSTEM_IO(grabQuerySystem,
+    escphys_io::Reads<
+        escphys_io::Times<escphys::Action, escphys::consts::numAgents>,
+        escphys_io::Times<escphys::GrabState, escphys::consts::numAgents>,
+        escphys_io::Times<escphys::Position, escphys::consts::numAgents>,
+        escphys_io::Times<escphys::Rotation, escphys::consts::numAgents>,
+        escphys_io::Times<escphys_io::AABB, escphys_io::bodiesPerWorld>,
+        escphys_io::Times<escphys::EntityType, escphys::consts::numAgents>>,
+    escphys_io::Writes<escphys_io::Times<escphys_io::Entity,
+                                         escphys::consts::numAgents>>);
+#endif
+// (per world) the same agents' rows; a joint row created or destroyed
+ESCPHYS_SYSTEM_IO(grabSystem,
+    escphys_io::Reads<
+        escphys_io::Times<escphys::Action, escphys::consts::numAgents>,
+        escphys_io::Times<escphys::GrabState, escphys::consts::numAgents>,
+        escphys_io::Times<escphys::Position, escphys::consts::numAgents>,
+        escphys_io::Times<escphys::Rotation, escphys::consts::numAgents>,
+        escphys_io::Times<escphys_io::Entity, escphys::consts::numAgents>>,
+    escphys_io::Writes<escphys::GrabState, madrona::phys::JointConstraint>);
+ESCPHYS_SYSTEM_IO(agentZeroVelSystem,
+    escphys_io::Reads<>, escphys_io::Writes<escphys::Velocity>);
+ESCPHYS_SYSTEM_IO(buttonSystem,
+    escphys_io::Reads<escphys::Position,
+                      escphys_io::Times<escphys::Position, escphys::consts::numAgents>>,
+    escphys_io::Writes<escphys::ButtonState>);
+ESCPHYS_SYSTEM_IO(doorOpenSystem,
+    escphys_io::Reads<escphys::DoorProperties,
+                      escphys_io::Times<escphys::ButtonState,
+                                        escphys::consts::numButtonsPerRoom>>,
+    escphys_io::Writes<escphys::OpenState>);
+ESCPHYS_SYSTEM_IO(setDoorPositionSystem,
+    escphys_io::Reads<escphys::Position, escphys::OpenState>,
+    escphys_io::Writes<escphys::Position>);
+ESCPHYS_SYSTEM_IO(rewardSystem,
+    escphys_io::Reads<escphys::Position, escphys::Progress>,
+    escphys_io::Writes<escphys::Progress, escphys::Reward>);
+ESCPHYS_SYSTEM_IO(stepTrackerSystem,
+    escphys_io::Reads<escphys::StepsRemaining>,
+    escphys_io::Writes<escphys::StepsRemaining, escphys::Done>);
+// a world that does not reset (the work of a reset is level generation)
+ESCPHYS_SYSTEM_IO(resetSystem,
+    escphys_io::Reads<escphys::WorldReset,
+                      escphys_io::Times<escphys::Done, escphys::consts::numAgents>>,
+    escphys_io::Writes<>);
+ESCPHYS_SYSTEM_IO(collectObservationsSystem,
+    escphys_io::Reads<escphys::Position, escphys::Rotation, escphys::Progress,
+                      escphys::GrabState, escphys::OtherAgents, escphys::Room,
+                      escphys::Position, escphys::GrabState,
+                      escphys_io::Times<escphys::Position,
+                          escphys::consts::numCubesPerRoom +
+                          escphys::consts::numButtonsPerRoom>,
+                      escphys_io::Times<escphys::EntityType,
+                          escphys::consts::numCubesPerRoom +
+                          escphys::consts::numButtonsPerRoom>,
+                      escphys::Position, escphys::OpenState>,
+    escphys_io::Writes<escphys::SelfObservation, escphys::PartnerObservation,
+                       escphys::RoomEntityObservations, escphys::DoorObservation>);
+// per agent (30 rays share the origin): its handle and pose, the world's leaf
+// boxes, the type of what each ray hit
+ESCPHYS_SYSTEM_IO(lidarSystem,
+    escphys_io::Reads<escphys_io::Entity, escphys::Position, escphys::Rotation,
+                      escphys_io::Times<escphys_io::AABB, escphys_io::bodiesPerWorld>,
+                      escphys_io::Times<escphys::EntityType,
+                                        escphys::consts::numLidarSamples>>,
+    escphys_io::Writes<escphys::Lidar>);
+#undef ESCPHYS_SYSTEM_IO
+namespace escphys {
+#endif
+
 void Sim::setupTasks(TaskGraphManager &taskgraph_mgr, const Config &)
 {
     TaskGraphBuilder &builder = taskgraph_mgr.init(0);
@@ -1082,7 +1192,7 @@ void Sim::setupTasks(TaskGraphManager &taskgraph_mgr, const Config &)
     auto broadphase_setup_sys =
         PhysicsSystem::setupBroadphaseTasks(builder, {move_sys});
 
-#ifdef MADRONA_GPU_MODE
+#ifdef SIM_WAVE_API
     // 64 lanes per world: the grab queries test a BVH leaf per lane
     auto grab_query_sys = builder.addToGraph<CustomParallelForNode<Engine,
         grabQuerySystem, 64, 1,
@@ -1139,7 +1249,7 @@ void Sim::setupTasks(TaskGraphManager &taskgraph_mgr, const Config &)
             Done
         >>({reward_sys});
 
-#ifdef MADRONA_GPU_MODE
+#ifdef SIM_WAVE_API
     // 64 lanes per world: lane i resets entity i (resetWorldWave)
     auto reset_sys = builder.addToGraph<CustomParallelForNode<Engine,
         resetSystem, 64, 1,

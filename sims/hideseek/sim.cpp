@@ -6,6 +6,18 @@
 #include <madrona/mw_gpu_entry.hpp>
 #endif
 
+// SIM_WAVE_API: this backend's wave-cooperative extensions (ordered create /
+// destroy by a wavefront per world, box queries with a lane per BVH leaf,
+// per-system occupancy) -- API the reference does not have.  -DSIM_PORTABLE
+// builds the simulator WITHOUT them even under MADRONA_GPU_MODE: the sources as
+// an unchanged reference simulator has them (plain makeEntity / destroyEntity /
+// findEntitiesWithinAABB, one lane per world; only the reference's own GPU
+// conventions remain: CustomParallelForNode for the ray systems,
+// RecycleEntitiesNode).  lib<sim>_portable_hip.so, the `portable_sim` bench line.
+#if defined(MADRONA_GPU_MODE) && !defined(SIM_PORTABLE)
+#define SIM_WAVE_API 1
+#endif
+
 using namespace madrona;
 using namespace madrona::math;
 using namespace madrona::phys;
@@ -384,7 +396,7 @@ inline void lockSystem(Engine &ctx, LevelState &)
 {
     Sim &sim = ctx.data();
 
-#ifdef MADRONA_GPU_MODE
+#ifdef SIM_WAVE_API
     // 64 lanes per world (CustomParallelForNode<..., 64, 1, ...>).  First the
     // box queries of all agents that press the lock button, a lane per BVH leaf
     // (locking moves nothing, so they see what the sequential loop sees); then
@@ -430,7 +442,7 @@ inline void lockSystem(Engine &ctx, LevelState &)
         }
         const int32_t is_hider = i < consts::numHiders ? 1 : 0;
 
-#ifdef MADRONA_GPU_MODE
+#ifdef SIM_WAVE_API
         Entity target = found[i];
 #else
         Vector3 pos = ctx.get<Position>(e);
@@ -575,7 +587,7 @@ inline void stepTrackerSystem(Engine &,
     }
 }
 
-#ifdef MADRONA_GPU_MODE
+#ifdef SIM_WAVE_API
 // The reset of a world on the GPU backends: 64 lanes per world
 // (CustomParallelForNode<..., 64, 1>), lane i destroys / creates / fills in
 // entity i.  Same result as cleanupWorld() + initWorld() above, bit for bit:
@@ -796,7 +808,7 @@ inline void resetSystem(Engine &ctx, WorldReset &reset)
         }
     }
 
-#ifdef MADRONA_GPU_MODE
+#ifdef SIM_WAVE_API
     // 64 lanes per world: lane 0 advances the reset stream, everybody learns
     // the outcome
     int32_t auto_reset = 0;
@@ -939,7 +951,7 @@ inline void lidarSystem(Engine &ctx,
 #endif
 }
 
-#ifdef MADRONA_GPU_MODE
+#ifdef SIM_WAVE_API
 // (this backend) the lock system is a chain of dependent loads with a wavefront
 // per world: four wavefronts per SIMD instead of the three its 154 registers
 // allow (109 -> 99 us at 8192 worlds; the ray systems do not profit)
@@ -964,7 +976,7 @@ void Sim::setupTasks(TaskGraphManager &taskgraph_mgr, const Config &)
     auto broadphase_setup_sys =
         PhysicsSystem::setupBroadphaseTasks(builder, {move_sys});
 
-#ifdef MADRONA_GPU_MODE
+#ifdef SIM_WAVE_API
     // 64 lanes per world: the lock queries test a BVH leaf per lane
     auto lock_sys = builder.addToGraph<CustomParallelForNode<Engine,
         lockSystem, 64, 1,
@@ -993,7 +1005,7 @@ void Sim::setupTasks(TaskGraphManager &taskgraph_mgr, const Config &)
             Done
         >>({phys_done});
 
-#ifdef MADRONA_GPU_MODE
+#ifdef SIM_WAVE_API
     // 64 lanes per world: lane i resets entity i (resetWorldWave)
     auto reset_sys = builder.addToGraph<CustomParallelForNode<Engine,
         resetSystem, 64, 1,

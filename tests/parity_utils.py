@@ -46,13 +46,15 @@ def float_close(ref_rows, hip_rows, rtol=1e-5):
 
 
 def run_pair(sim, num_worlds, steps, seed=5, check_every=1, actions=None,
-             check_init=True, ref_workers=1, **kw):
+             check_init=True, ref_workers=1, hip_sim=None, **kw):
     """Steps both backends in lock step; returns (first mismatch list, step).
     ref_workers: threads of the reference CPU backend (0 = every core; worlds
-    are independent, so the result does not depend on it)."""
+    are independent, so the result does not depend on it).  hip_sim: another
+    HIP build of the same simulator (e.g. "<sim>_portable")."""
     with Simulator(ref_lib_path(sim), num_worlds, seed=seed,
                    num_workers=ref_workers, **kw) as ref, \
-            Simulator(hip_lib_path(sim), num_worlds, seed=seed, **kw) as hip:
+            Simulator(hip_lib_path(hip_sim or sim), num_worlds, seed=seed,
+                      **kw) as hip:
         if check_init:
             probs = compare_columns(ref.dump_all(), hip.dump_all())
             if probs:

@@ -478,6 +478,29 @@ def test_full_size_lockstep(built, sim, worlds, steps, agents):
     assert not probs, (step, probs[:3])
 
 
+# ---- 2c. what an UNCHANGED simulator gets ----------------------------------------
+@pytest.mark.parametrize("sim,worlds,steps,agents,denom", [
+    ("escape_room", 4096, 200, 2, 200),         # BASELINE configs[1], its size
+    ("escape_room", 333, 120, 2, 25),
+    ("escape_room_phys", 2048, 120, 2, 60),
+    ("hideseek", 2048, 120, 5, 80),
+])
+def test_portable_sources_lockstep(built, sim, worlds, steps, agents, denom):
+    """lib<sim>_portable_hip.so: the bench simulators compiled for the GPU from
+    their PORTABLE sources (-DSIM_PORTABLE: plain makeEntity / destroyEntity /
+    findEntitiesWithinAABB with one lane per world, none of this backend's
+    wave-cooperative extensions) -- what a reference simulator that links
+    unchanged runs.  Bit for bit against the reference CPU backend, like the
+    tuned builds."""
+    _need_ref(sim)
+    probs, step = run_pair(sim, worlds, steps, flags=denom, check_every=20,
+                           actions=_escape_actions(31, grab=sim != "escape_room",
+                                                   agents=agents),
+                           check_init=False, ref_workers=0,
+                           hip_sim=sim + "_portable")
+    assert not probs, (step, probs[:3])
+
+
 @pytest.mark.parametrize("seed", [11, 101])
 @pytest.mark.parametrize("sim,agents,steps,denom", [
     ("escape_room", 2, 200, 60), ("escape_room_phys", 2, 120, 60),
