@@ -845,7 +845,13 @@ __device__ __forceinline__ Hit traceTileList(
 // Workgroups stride over the 16 x 16 tiles of all views.  GeoInLds: the
 // bottom-level trees and triangles of every object are copied to LDS once per
 // workgroup (they fit: kGeoLdsDwords), so that only the image leaves the CU.
-template <bool GeoInLds>
+//
+// PlainMaterials: the scene has neither per-triangle materials nor textures
+// (geometry.triangleMaterial == nullptr and no material with a texture: then
+// shadeRecord never leaves kShadeFinal), so the per-hit material / texture
+// lookup is not even compiled in -- BASELINE config 5's scene; round 3 paid a
+// run-time branch and the registers of the texture path for it (4.36 -> 4.69 ms).
+template <bool GeoInLds, bool PlainMaterials>
 __global__ void __launch_bounds__(256)
 renderRaycast(EcsState *S, RenderParams params)
 {
@@ -1076,7 +1082,7 @@ renderRaycast(EcsState *S, RenderParams params)
                 Vector3 color = shade.color;
                 // geometric normal of the hit triangle (reference :443-446)
                 const Vector3 *tri = geo.triangles + 3u * (size_t)first.triangle;
-                if (shade.material != kShadeFinal) {
+                if (!PlainMaterials && shade.material != kShadeFinal) {
                     // the hit decides: the triangle's own material and / or a
                     // texture sampled at the hit's uv (reference :772-800)
                     int32_t material = shade.material;
@@ -1453,8 +1459,15 @@ void buildRenderLaunches(EcsState *state_dev, const RenderParams &params,
         const bool geo_in_lds = params.numGeoNodes * 16u +
             params.numGeoTriangles * 9u + params.geometry.numObjects * 18u <=
                 kGeoLdsDwords;
-        k.fn = geo_in_lds ? (const void *)&renderRaycast<true> :
-                            (const void *)&renderRaycast<false>;
+        // (what the geometry can ask of the shading, decided here once)
+        // (materialTexture is only uploaded for scenes that have textures)
+        const bool plain = params.geometry.triangleMaterial == nullptr &&
+            params.geometry.materialTexture == nullptr;
+        k.fn = geo_in_lds ?
+            (plain ? (const void *)&renderRaycast<true, true> :
+                     (const void *)&renderRaycast<true, false>) :
+            (plain ? (const void *)&renderRaycast<false, true> :
+                     (const void *)&renderRaycast<false, false>);
         const uint32_t tiles_per_side = (params.resolution + 15u) / 16u;
         const uint64_t tiles =
             (uint64_t)view_capacity * tiles_per_side * tiles_per_side;

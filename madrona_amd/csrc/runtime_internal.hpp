@@ -46,7 +46,9 @@ struct SortState {
     uint32_t active;                // this run sorts (world sort: table was dirty)
     int32_t rowsIn;                 // rows when the chain started
     int32_t rowsOut;                // rows the sorted table has
-    uint32_t pad_;
+    uint32_t tailByLands;           // compaction chain: 1 = tailLand[] holds where every
+                                    // RAW tail row lands (the scatter tiles pick and order
+                                    // their own), 0 = prepare sorted the tail by world
     const uint32_t *keyColumn;      // the key column when the chain started
     unsigned long long statRowsIn;  // cumulative, for measurement
     unsigned long long statRowsOut;
@@ -74,7 +76,8 @@ struct SortSite {
     // and for every tile the first row of the sorted tail that lands in it
     int32_t *tileCounts;            // [numTiles]
     int32_t *tileTailStart;         // [numTiles + 1]
-    int32_t *tailLand;              // [rows] prefix position each sorted tail row lands at
+    int32_t *tailLand;              // [rows] prefix position each tail row lands at (sorted
+                                    // tail order, or raw tail order: SortState::tailByLands)
 };
 
 // pseudo-column of a world-sort site: rebuild worldOffsets / worldCounts

@@ -1109,6 +1109,24 @@ __device__ inline int32_t compactNumTiles(int32_t prefix)
     return t > 0 ? t : 1;
 }
 
+// The tail by landing points (round 4).  Sorting the tail by world on ONE
+// workgroup (compactSortTail) is the chain's serial step: 10-13 us for the
+// ~1 K-row tails of 8192 worlds, 88 us for the ~10-30 K rows of 65536.  It is
+// not needed: a tail row of world w lands at end(w), a position of the sorted
+// prefix; the scatter tile that owns that position only has to know (1) how
+// many live tail rows land in earlier tiles and (2) its own rows in (world,
+// tail index) order -- both of which it gets from one scan of the landing
+// points, a 4-byte read per tail row that all tiles do side by side.  Used
+// whenever there is a sorted prefix to land in and the tail is not most of the
+// table (a cold start, a synchronised reset of every world: then the old path
+// or, after three long tails, the radix chain).
+constexpr int32_t kLandsMaxTail = 1 << 16;
+constexpr int32_t kOwnCap = 2048;       // own rows a scatter tile orders in LDS
+__device__ inline bool compactTailByLands(int32_t prefix, int32_t tail)
+{
+    return prefix > 0 && tail <= kLandsMaxTail;
+}
+
 // a short tail (the steady state) is sorted without leaving the CU
 struct TailSortLDS {
     uint32_t keys[2][kLdsTailRows];
@@ -1223,14 +1241,39 @@ sortCompactPrepare(EcsState *S, const SortSite *sites)
     const uint32_t *keys = (const uint32_t *)tbl.columns[site.keyColumn];
     const uint32_t tid = threadIdx.x;
 
+    // how the tail is handled: every workgroup of both kernels derives the
+    // same answer from the header
+    const int32_t tail = n - prefix;
+    const bool by_lands = compactTailByLands(prefix, tail);
     if (blockIdx.x == 0 && tid == 0) {
         state->active = active ? 1u : 0u;
         state->rowsIn = n;
         state->keyColumn = keys;
         state->prefixRows = prefix;
+        state->tailByLands = by_lands ? 1u : 0u;
     }
     if (!active) {
         return;
+    }
+
+    if (by_lands) {
+        // where every (raw) tail row lands in the prefix -- the end of its
+        // world's old range --, or -1 for a row destroyed again: all workgroups,
+        // a row per thread.  No sort: the scatter tiles pick out and order the
+        // few rows that land in them.
+        const int32_t *offs = tbl.worldOffsets;
+        const int32_t *cnts = tbl.worldCounts;
+        for (int32_t j = (int32_t)(blockIdx.x * kSmallThreads + tid); j < tail;
+             j += (int32_t)(gridDim.x * kSmallThreads)) {
+            const uint32_t w = keys[prefix + j];
+            site.tailLand[j] = w == 0xFFFFFFFFu ? -1 : offs[w] + cnts[w];
+        }
+        if (blockIdx.x == 0 && tid == 0) {
+            state->statTailRows += (unsigned long long)tail;
+            if (tail > tbl.tailRows) {
+                tbl.tailRows = tail;
+            }
+        }
     }
 
     if (blockIdx.x != 0) {
@@ -1270,6 +1313,10 @@ sortCompactPrepare(EcsState *S, const SortSite *sites)
         return;
     }
 
+    if (by_lands) {
+        return;
+    }
+
     // ---- workgroup 0: the tail, sorted by world ----
     __shared__ SmallSortLDS lds;
     __shared__ TailSortLDS tail_lds;
@@ -1282,6 +1329,13 @@ struct alignas(16) CompactLDS {
     uint32_t liveBefore[kCompactTile + 4];  // survivors of the tile before each position
     unsigned long long scan[THREADS / 64];
     int32_t reduce[THREADS / 64];
+    // tail by landing points: the tail rows that land in this tile (tail index,
+    // world), in tail order
+    int32_t ownJ[kOwnCap];
+    uint32_t ownW[kOwnCap];
+    int32_t waveOwn[THREADS / 64];
+    int32_t waveBefore[THREADS / 64];
+    int32_t waveLive[THREADS / 64];
 };
 
 template <int THREADS>
@@ -1445,6 +1499,150 @@ __device__ inline void compactScatterTile(const SortSite &site, CompactLDS<THREA
     __syncthreads();
 }
 
+// The same for a tail that was NOT sorted (SortState::tailByLands): the tile
+// scans the landing points of all `tail` raw tail rows (site.tailLand, -1 =
+// destroyed), counts the live ones landing in earlier tiles (= where its own
+// start in the sorted tail), collects its own in tail order and ranks them by
+// (world, tail index).  Returns the live tail rows (every tile counts them).
+// own rows beyond kOwnCap (a tile whose worlds appended more rows than the tile
+// holds: not the steady state) are kept in the site's spare key / index buffer
+// instead of LDS, at [before, before + own): disjoint between tiles.
+template <int THREADS, int ITEMS>
+__device__ inline int32_t compactScatterTileLands(
+    const SortSite &site, CompactLDS<THREADS> &lds, int32_t tile, int32_t num_tiles,
+    int32_t first, const uint32_t (&key)[ITEMS], int32_t live_before_tile,
+    uint32_t *out_keys, int32_t *out_rows, const uint32_t *table_keys,
+    int32_t prefix, int32_t tail, uint32_t *spare_keys, int32_t *spare_rows)
+{
+    static_assert(THREADS * ITEMS == kCompactTile);
+    constexpr int32_t waves = THREADS / 64;
+    const int32_t tid = (int32_t)threadIdx.x;
+    const uint32_t lane = laneId();
+    const int32_t wave = tid >> 6;
+    const int32_t mine = first + tid * ITEMS;
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+
+    auto tile_of = [&](int32_t land) {
+        const int32_t t = land >> kCompactTileShift;
+        return t < num_tiles - 1 ? t : num_tiles - 1;
+    };
+
+    // ---- pass 1 over the landing points: counts (a contiguous run per wave) ----
+    const int32_t seg = ((tail + waves * 64 - 1) / (waves * 64)) * 64;
+    const int32_t wave_first = wave * seg;
+    const int32_t wave_end = wave_first + seg < tail ? wave_first + seg : tail;
+    int32_t own_wave = 0, before_lane = 0, live_lane = 0;
+    for (int32_t base = wave_first; base < wave_end; base += 64) {
+        const int32_t j = base + (int32_t)lane;
+        const int32_t land = j < wave_end ? site.tailLand[j] : -1;
+        const int32_t t = land >= 0 ? tile_of(land) : -1;
+        live_lane += land >= 0 ? 1 : 0;
+        before_lane += (land >= 0 && t < tile) ? 1 : 0;
+        own_wave += (int32_t)__popcll(ballot64(t == tile));
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        before_lane += __shfl_down(before_lane, d, 64);
+        live_lane += __shfl_down(live_lane, d, 64);
+    }
+    if (lane == 0) {
+        lds.waveOwn[wave] = own_wave;
+        lds.waveBefore[wave] = before_lane;
+        lds.waveLive[wave] = live_lane;
+    }
+    __syncthreads();
+    int32_t own_base = 0, own_total = 0, before = 0, live_total = 0;
+#pragma unroll
+    for (int w = 0; w < waves; w++) {
+        own_base += w < wave ? lds.waveOwn[w] : 0;
+        own_total += lds.waveOwn[w];
+        before += lds.waveBefore[w];
+        live_total += lds.waveLive[w];
+    }
+    const bool spill = own_total > kOwnCap;
+    int32_t *own_j = spill ? spare_rows + before : lds.ownJ;
+    uint32_t *own_w = spill ? spare_keys + before : lds.ownW;
+
+    // ---- pass 2: my rows, in tail order, with their worlds ----
+    if (own_total != 0) {
+        int32_t run = own_base;
+        for (int32_t base = wave_first; base < wave_end; base += 64) {
+            const int32_t j = base + (int32_t)lane;
+            const int32_t land = j < wave_end ? site.tailLand[j] : -1;
+            const bool is_mine = land >= 0 && tile_of(land) == tile;
+            const unsigned long long m = ballot64(is_mine);
+            if (is_mine) {
+                const int32_t pos = run + (int32_t)__popcll(m & lane_lt);
+                own_j[pos] = j;
+                own_w[pos] = table_keys[prefix + j];
+                int32_t at = land - first;
+                at = at < 0 ? 0 : (at > kCompactTile ? kCompactTile : at);
+                atomicAdd(&lds.landing[at], 1u);    // (cleared by the caller)
+            }
+            run += (int32_t)__popcll(m);
+        }
+    }
+    __syncthreads();
+
+    // ---- the prefix rows of the tile (as compactScatterTile) ----
+    uint32_t land[ITEMS];
+    if constexpr (ITEMS == 8) {
+        const uint4 lo = *(const uint4 *)&lds.landing[tid * ITEMS];
+        const uint4 hi = *(const uint4 *)&lds.landing[tid * ITEMS + 4];
+        land[0] = lo.x; land[1] = lo.y; land[2] = lo.z; land[3] = lo.w;
+        land[4] = hi.x; land[5] = hi.y; land[6] = hi.z; land[7] = hi.w;
+    } else {
+        const uint2 v = *(const uint2 *)&lds.landing[tid * ITEMS];
+        land[0] = v.x; land[1] = v.y;
+    }
+    uint32_t my_live = 0, my_land = 0;
+#pragma unroll
+    for (int j = 0; j < ITEMS; j++) {
+        my_live += key[j] != 0xFFFFFFFFu ? 1u : 0u;
+        my_land += land[j];
+    }
+    const unsigned long long excl = blockExclusiveScanU64<THREADS>(
+        (unsigned long long)my_live | ((unsigned long long)my_land << 32),
+        lds.scan);
+    uint32_t live = (uint32_t)excl;
+    uint32_t landed = (uint32_t)(excl >> 32);
+#pragma unroll
+    for (int j = 0; j < ITEMS; j++) {
+        landed += land[j];
+        lds.liveBefore[tid * ITEMS + j] = live;
+        if (key[j] != 0xFFFFFFFFu) {
+            const int32_t dest = live_before_tile + (int32_t)live + before +
+                (int32_t)landed;
+            out_rows[dest] = mine + j;
+            out_keys[dest] = key[j];
+            live += 1u;
+        }
+    }
+    if (tid == THREADS - 1) {
+        lds.liveBefore[kCompactTile] = live;
+    }
+    __syncthreads();
+
+    // ---- my tail rows: rank by (world, tail index), then to their place ----
+    for (int32_t i = tid; i < own_total; i += THREADS) {
+        const uint32_t w = own_w[i];
+        int32_t rank = 0;
+        for (int32_t k = 0; k < own_total; k++) {
+            const uint32_t other = own_w[k];
+            rank += (other < w || (other == w && k < i)) ? 1 : 0;
+        }
+        const int32_t j = own_j[i];
+        int32_t at = site.tailLand[j] - first;
+        at = at < 0 ? 0 : (at > kCompactTile ? kCompactTile : at);
+        const int32_t dest = live_before_tile + (int32_t)lds.liveBefore[at] +
+            before + rank;
+        out_rows[dest] = prefix + j;
+        out_keys[dest] = w;
+    }
+    __syncthreads();
+    return live_total;
+}
+
 __global__ void __launch_bounds__(kSortThreads)
 sortCompactScatter(EcsState *S, const SortSite *sites)
 {
@@ -1460,7 +1658,9 @@ sortCompactScatter(EcsState *S, const SortSite *sites)
 
     const int32_t n = state->rowsIn;
     const int32_t prefix = state->prefixRows;
-    const int32_t tail_live = state->tailLive;
+    const bool by_lands = state->tailByLands != 0u;
+    const int32_t tail = n - prefix;
+    int32_t tail_live = by_lands ? 0 : state->tailLive;
     const int32_t num_tiles = compactNumTiles(prefix);
     const uint32_t *keys = state->keyColumn;
     const int32_t tid = (int32_t)threadIdx.x;
@@ -1481,6 +1681,16 @@ sortCompactScatter(EcsState *S, const SortSite *sites)
             part += tile_count(t);
         }
         const int32_t survivors = blockSum<kSortThreads>(part, lds.reduce);
+        if (by_lands) {
+            int32_t live = 0;
+            for (int32_t j = tid; j < tail; j += kSortThreads) {
+                live += site.tailLand[j] >= 0 ? 1 : 0;
+            }
+            tail_live = blockSum<kSortThreads>(live, lds.reduce);
+            if (tid == 0) {
+                state->tailLive = tail_live;
+            }
+        }
         if (tid == 0) {
             state->numValid = (uint32_t)(survivors + tail_live);
         }
@@ -1508,8 +1718,16 @@ sortCompactScatter(EcsState *S, const SortSite *sites)
         }
         const int32_t live_before_tile = blockSum<kSortThreads>(part, lds.reduce);
 
-        compactScatterTile<kSortThreads, kSortItems>(site, lds, tile, first, key,
-            live_before_tile, out_keys, out_rows, tail_keys, tail_rows);
+        if (by_lands) {
+            // (the spare key / index buffer: where the sorted tail would be)
+            (void)compactScatterTileLands<kSortThreads, kSortItems>(site, lds, tile,
+                num_tiles, first, key, live_before_tile, out_keys, out_rows, keys,
+                prefix, tail, const_cast<uint32_t *>(tail_keys),
+                const_cast<int32_t *>(tail_rows));
+        } else {
+            compactScatterTile<kSortThreads, kSortItems>(site, lds, tile, first, key,
+                live_before_tile, out_keys, out_rows, tail_keys, tail_rows);
+        }
     }
 }
 

@@ -313,6 +313,16 @@ private:
                                             float t_max,
                                             float *hit_t,
                                             math::Vector3 *hit_normal);
+    // the ray-independent part of a leaf test (physics.inl)
+    struct RayLeaf;
+    MADRONA_HD inline RayLeaf rayLeaf(int32_t leaf_idx,
+                                      math::Vector3 world_ray_o) const;
+    MADRONA_HD inline bool traceRayIntoLeaf(const RayLeaf &leaf,
+                                            math::Vector3 world_ray_d,
+                                            float t_min,
+                                            float t_max,
+                                            float *hit_t,
+                                            math::Vector3 *hit_normal);
 
     MADRONA_HD inline int32_t midpointSplit(int32_t base, int32_t num_elems);
     MADRONA_HD inline void growAncestors(int32_t child_idx,

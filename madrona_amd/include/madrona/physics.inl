@@ -232,13 +232,22 @@ MADRONA_HD inline bool traceRayIntoConvexPolyhedron(
 
 }
 
-bool BVH::traceRayIntoLeaf(int32_t leaf_idx,
-                           math::Vector3 world_ray_o,
-                           math::Vector3 world_ray_d,
-                           float t_min,
-                           float t_max,
-                           float *hit_t,
-                           math::Vector3 *hit_normal)
+// What a leaf test needs of its leaf that does not depend on the ray's
+// direction: the leaf's transform and primitives and the ray ORIGIN in the
+// object's frame -- the same for every ray that starts at the same point (the
+// 30 rays of an agent's lidar).  Same expressions as the reference's
+// traceRayIntoLeaf (broadphase.cpp), evaluated once per (origin, leaf).
+struct BVH::RayLeaf {
+    math::Quat rot;             // leaf_transforms_[leaf].rot
+    math::Diag3x3 scale;
+    math::Vector3 objRayO;      // rot^-1 (o - pos) / scale
+    int32_t primOffset;
+    int32_t numPrims;
+    math::AABB box;             // leaf_aabbs_[leaf]: what the traversal culls by
+    int32_t leafIdx;
+};
+
+BVH::RayLeaf BVH::rayLeaf(int32_t leaf_idx, math::Vector3 world_ray_o) const
 {
     using namespace math;
 
@@ -252,6 +261,38 @@ bool BVH::traceRayIntoLeaf(int32_t leaf_idx,
     obj_ray_o.y /= leaf_txfm.scale.d1;
     obj_ray_o.z /= leaf_txfm.scale.d2;
 
+    return RayLeaf {
+        leaf_txfm.rot, leaf_txfm.scale, obj_ray_o,
+        (int32_t)obj_mgr_->rigidBodyPrimitiveOffsets[obj_id.idx],
+        (int32_t)obj_mgr_->rigidBodyPrimitiveCounts[obj_id.idx],
+        leaf_aabbs_[leaf_idx], leaf_idx,
+    };
+}
+
+bool BVH::traceRayIntoLeaf(int32_t leaf_idx,
+                           math::Vector3 world_ray_o,
+                           math::Vector3 world_ray_d,
+                           float t_min,
+                           float t_max,
+                           float *hit_t,
+                           math::Vector3 *hit_normal)
+{
+    return traceRayIntoLeaf(rayLeaf(leaf_idx, world_ray_o), world_ray_d, t_min,
+                            t_max, hit_t, hit_normal);
+}
+
+bool BVH::traceRayIntoLeaf(const RayLeaf &leaf,
+                           math::Vector3 world_ray_d,
+                           float t_min,
+                           float t_max,
+                           float *hit_t,
+                           math::Vector3 *hit_normal)
+{
+    using namespace math;
+
+    struct { Quat rot; Diag3x3 scale; } leaf_txfm { leaf.rot, leaf.scale };
+    const Vector3 obj_ray_o = leaf.objRayO;
+
     Vector3 obj_ray_d = leaf_txfm.rot.inv().rotateVec(world_ray_d);
     obj_ray_d.x /= leaf_txfm.scale.d0;
     obj_ray_d.y /= leaf_txfm.scale.d1;
@@ -261,8 +302,8 @@ bool BVH::traceRayIntoLeaf(int32_t leaf_idx,
 
     Vector3 obj_hit_normal = Vector3::zero();
 
-    CountT prim_offset = (CountT)obj_mgr_->rigidBodyPrimitiveOffsets[obj_id.idx];
-    CountT num_prims = (CountT)obj_mgr_->rigidBodyPrimitiveCounts[obj_id.idx];
+    CountT prim_offset = (CountT)leaf.primOffset;
+    CountT num_prims = (CountT)leaf.numPrims;
 
     bool hit_leaf = false;
     for (CountT i = 0; i < num_prims; i++) {
@@ -313,11 +354,14 @@ Entity BVH::traceRay(math::Vector3 o,
     Entity closest_hit_entity = Entity::none();
     Vector3 closest_hit_normal = Vector3::zero();
 
-    auto visitLeaf = [&](int32_t leaf_idx) {
+    auto visitLeaf = [&](int32_t leaf_idx, const RayLeaf *shared_leaf) {
         float hit_t;
         Vector3 leaf_hit_normal;
-        bool leaf_hit = traceRayIntoLeaf(
-            leaf_idx, o, d, 0.f, t_max, &hit_t, &leaf_hit_normal);
+        bool leaf_hit = shared_leaf != nullptr ?
+            traceRayIntoLeaf(*shared_leaf, d, 0.f, t_max, &hit_t,
+                             &leaf_hit_normal) :
+            traceRayIntoLeaf(leaf_idx, o, d, 0.f, t_max, &hit_t,
+                             &leaf_hit_normal);
 
         if (leaf_hit) {
             t_max = hit_t;
@@ -354,13 +398,98 @@ Entity BVH::traceRay(math::Vector3 o,
         // A wave then takes as many leaf-test steps as its busiest ray has
         // candidates (a handful), not one per leaf that any of its rays touches.
         const int32_t n = num_tree_leaves_;
+
+#if defined(__HIP_DEVICE_COMPILE__)
+        // Rays that share their origin: the lanes of a half-wavefront that are
+        // in this call together with the SAME origin and tree (an agent's
+        // lidar: CustomParallelForNode<..., 32, 1, ...>, lane = ray) compute
+        // the ray-independent part of every leaf test ONCE per leaf -- a lane
+        // per leaf, into LDS -- instead of once per (ray, leaf): the leaf's
+        // transform and primitive range (a chain of dependent loads) and the
+        // origin in the object's frame (a quaternion rotation and three exact
+        // divisions of the ~15 a leaf test costs).  Same expressions, same
+        // inputs, so the same bits (rayLeaf); what a ray then does per
+        // candidate leaf only involves its direction.
+        constexpr int32_t ray_group_lanes = 32;
+        constexpr int32_t ray_groups_per_block = 8;     // 256-thread workgroups
+        __shared__ RayLeaf shared_leaves[ray_groups_per_block][64];
+        bool share_origin = false;
+        RayLeaf *group_leaves = nullptr;
+        {
+            const uint32_t lane = __builtin_amdgcn_mbcnt_hi(
+                ~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            const uint64_t active = __builtin_amdgcn_ballot_w64(true);
+            const uint32_t half_first = lane & ~(uint32_t)(ray_group_lanes - 1);
+            const uint64_t half_mask =
+                (active >> half_first) & ((1ull << ray_group_lanes) - 1ull);
+            const int32_t leader =
+                (int32_t)half_first + (int32_t)__builtin_ctzll(half_mask);
+            const bool same =
+                __shfl(o.x, leader, 64) == o.x && __shfl(o.y, leader, 64) == o.y &&
+                __shfl(o.z, leader, 64) == o.z &&
+                __shfl((uint32_t)(uintptr_t)this, leader, 64) ==
+                    (uint32_t)(uintptr_t)this &&
+                __shfl((uint32_t)((uintptr_t)this >> 32), leader, 64) ==
+                    (uint32_t)((uintptr_t)this >> 32);
+            const uint64_t agree = __builtin_amdgcn_ballot_w64(same);
+            const uint32_t num_active = (uint32_t)__builtin_popcountll(half_mask);
+            // (worth it from a handful of rays on; the block shape the LDS
+            // array is sized for)
+            share_origin = ((agree >> half_first) & half_mask) == half_mask &&
+                num_active >= 8u && blockDim.x <= 256u && blockDim.y == 1u;
+            if (share_origin) {
+                group_leaves = shared_leaves[threadIdx.x / ray_group_lanes];
+            }
+        }
+#endif
+
         for (int32_t base = 0; base < n; base += 64) {
             const int32_t window = n - base < 64 ? n - base : 64;
+
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (share_origin) {
+                // the window's leaves over the group's active lanes
+                const uint32_t lane = __builtin_amdgcn_mbcnt_hi(
+                    ~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+                const uint64_t active = __builtin_amdgcn_ballot_w64(true);
+                const uint32_t half_first = lane & ~(uint32_t)(ray_group_lanes - 1);
+                const uint64_t half_mask =
+                    (active >> half_first) & ((1ull << ray_group_lanes) - 1ull);
+                const int32_t rank = (int32_t)__builtin_popcountll(
+                    half_mask & ((1ull << (lane - half_first)) - 1ull));
+                const int32_t num_active = (int32_t)__builtin_popcountll(half_mask);
+                // (the previous window's entries are done with: every lane of
+                // the group has left its candidate loop)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                for (int32_t j = rank; j < window; j += num_active) {
+                    group_leaves[j] = rayLeaf(dfs_leaves_[base + j], o);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
+#endif
 
             // (boxes fetched a group at a time: leaf index -> box is two
             // dependent round trips, paid once per group)
             uint64_t candidates = 0;
             constexpr int32_t group = 8;
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (share_origin) {
+                // (the boxes are in LDS with the rest of the leaves)
+                for (int32_t g = 0; g < window; g += group) {
+MADRONA_UNROLL
+                    for (int32_t k = 0; k < group; k++) {
+                        const int32_t j = g + k < window ? g + k : window - 1;
+                        AABB box = group_leaves[j].box;
+                        const bool hit = g + k < window &&
+                            box.rayIntersects(o, inv_d, 0.f, t_max);
+                        candidates |= (uint64_t)hit << ((g + k) & 63);
+                    }
+                }
+            } else
+#endif
             for (int32_t g = 0; g < window; g += group) {
                 int32_t leaf[group];
 MADRONA_UNROLL
@@ -388,11 +517,22 @@ MADRONA_UNROLL
                 const int32_t j = (int32_t)__builtin_ctzll(candidates);
                 candidates &= candidates - 1;
 
+#if defined(__HIP_DEVICE_COMPILE__)
+                if (share_origin) {
+                    const RayLeaf *shared_leaf = &group_leaves[j];
+                    AABB leaf_box = shared_leaf->box;
+                    if (t_max == mask_t_max ||
+                            leaf_box.rayIntersects(o, inv_d, 0.f, t_max)) {
+                        visitLeaf(shared_leaf->leafIdx, shared_leaf);
+                    }
+                    continue;
+                }
+#endif
                 const int32_t leaf_idx = dfs_leaves_[base + j];
                 if (t_max == mask_t_max ||
                         leaf_aabbs_[leaf_idx].rayIntersects(o, inv_d, 0.f,
                                                             t_max)) {
-                    visitLeaf(leaf_idx);
+                    visitLeaf(leaf_idx, nullptr);
                 }
             }
         }
@@ -413,7 +553,7 @@ MADRONA_UNROLL
                 }
 
                 if (node.isLeaf(c)) {
-                    visitLeaf(node.leafIDX(c));
+                    visitLeaf(node.leafIDX(c), nullptr);
                 } else {
                     stack.push(node.children[c]);
                 }
