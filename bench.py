@@ -389,14 +389,17 @@ def rooflines(stats, sim_name, worlds, ms_per_step):
 
     nodes = {}
     t, src = traffic_for(entries, sim_name, worlds, ":sort.")
+    sort_roles = sorted({k["name"].split(":sort.", 1)[1] for k in sort_k})
     nodes["sort_node"] = node_roofline(
-        "SortArchetype/CompactArchetype nodes (histogram + onesweep passes + gather "
-        "+ finalize of every sort chain in the step)", sort_k, t, src,
+        "SortArchetype/CompactArchetype nodes: every kernel of every sort chain in "
+        "the step (" + ", ".join(sort_roles) + ")", sort_k, t, src,
         "BASELINE's 'achieved HBM GB/s on sort node': all kernels of the node, not "
-        "its best one; bytes = SURVEY 8d formula x rows the sorts measured (what a "
-        "sort node is priced at: 40 N + 2 B_row N').  World sorts of tables that "
-        "are still sorted from the last step take the compaction chain (prepare + "
-        "scatter: 8 N + 8 N' instead of the 40 N of histogram + key passes)")
+        "its best one; `frac` prices the node at SURVEY 8d's formula x the rows the "
+        "sorts measured (40 N + 2 B_row N': what any implementation of the node is "
+        "priced at); `frac_bytes_moved` at what these kernels move -- world sorts "
+        "of tables that are still sorted from the last step take the compaction "
+        "chain (prepare + scatter: 8 N + 8 N' instead of the 40 N of histogram + "
+        "key passes), so 8 N + 8 N' + 2 B_row N'")
     if nodes["sort_node"]:
         # the step's sort chains one by one (kernels of a chain are adjacent in
         # the launch list): e.g. the joint table before the physics step -- a
@@ -421,9 +424,21 @@ def rooflines(stats, sim_name, worlds, ms_per_step):
         } for c in chains]
         rows_in = sum(k["rows"] for k in sort_k if "gather" in k["name"])
         gather_bytes = sum(k["algo_bytes"] for k in sort_k if "gather" in k["name"])
-        nodes["sort_node"]["bytes_moved_estimate"] = int(gather_bytes + 16.0 * rows_in) \
-            if any("compact" in k["name"] for k in sort_k) else \
-            nodes["sort_node"]["algo_bytes_per_launch"]
+        # What the chains MOVE (next to what SURVEY 8d prices a sort node at):
+        # a compaction chain reads 4 N keys + writes 4 N' keys + 4 N' indices
+        # and re-reads them in the gather (8 N + 8 N') instead of the 40 N of
+        # histogram + key passes; the gather is 2 B_row N' either way.
+        compact_rows = sum(k["rows"] for k in sort_k if "compact.prepare" in k["name"])
+        radix_bytes = sum(k["algo_bytes"] for k in sort_k
+                          if "histogram" in k["name"] or "onesweep" in k["name"]
+                          or "small" in k["name"])
+        moved = gather_bytes + 16.0 * compact_rows + radix_bytes
+        node_us = nodes["sort_node"]["avg_us"]
+        nodes["sort_node"]["bytes_moved_estimate"] = int(moved)
+        nodes["sort_node"]["achieved_bytes_moved"] = round(
+            moved / max(node_us * 1e-6, 1e-12) / 1e9, 1)
+        nodes["sort_node"]["frac_bytes_moved"] = round(
+            moved / max(node_us * 1e-6, 1e-12) / 1e9 / HBM_PEAK_GBS, 4)
     t, src = traffic_for(entries, sim_name, worlds, "physics:worldStep")
     nodes["physics_step"] = node_roofline(
         "physics:worldStep (broadphase pairs + 4 x (integrate, narrowphase, XPBD "

@@ -441,6 +441,10 @@ typedef struct mwhip_kernel_stat {
     double rows;            /* mean rows / invocations processed per launch */
     uint32_t io_declared;   /* algo_bytes from a declared read / write set (1),
                              * from the signature rule (0) */
+    uint32_t workgroups;    /* grid of the launch */
+    uint32_t node_index;    /* position of the node in its task graph's execution
+                             * order (the key of MADRONA_MWHIP_EXEC_CONFIG_FILE),
+                             * 0xFFFFFFFF for kernels that are not a node's own */
     uint32_t pad_;
 } mwhip_kernel_stat;
 int32_t mwhip_profile(mwhip_exec *exec, uint64_t graph, uint32_t reps,

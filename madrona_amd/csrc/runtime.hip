@@ -613,6 +613,13 @@ struct mwhip_exec {
     // its one-workgroup tail sort is just slow when the whole table is "tail")
     uint32_t sortCompaction = 1;
     uint32_t rowSnapshotMode = 1;   // 0 never, 1 nodes that can append rows, 2 all
+    // MADRONA_MWHIP_EXEC_CONFIG_FILE (the reference's
+    // MADRONA_MWGPU_EXEC_CONFIG_FILE, cuda_exec.cpp:2115-2172): per task-graph
+    // node (index in execution order) the workgroups per CU its kernel may
+    // occupy -- the reference's "blocks per SM" of the megakernel that runs the
+    // node --, written by madrona_amd/scripts/profile.py.  0 / absent: default.
+    std::vector<uint32_t> nodeWorkgroupsPerCU;
+    uint32_t numCUs = 256;
 
     // batch ray caster: geometry (bottom-level BVHs) + where the ECS keeps what
     // it reads and writes
@@ -1672,6 +1679,13 @@ static int ensureSortScratch(mwhip_exec *exec, ArchetypeRec &arch)
 
     int rc = devAllocT(exec, &arch.sortState, 1);
     if (rc != 0) return rc;
+    // MADRONA_MWHIP_SORT_LANDS=0: the compaction chain always sorts its tail on
+    // one workgroup (round 3's path; measurements)
+    if (envU32("MADRONA_MWHIP_SORT_LANDS", 1) == 0) {
+        const uint32_t forever = 0x7FFFFFFFu;
+        HIPCHK(hipMemcpy((char *)arch.sortState + offsetof(SortState, landsBlocked),
+                         &forever, sizeof(forever), hipMemcpyHostToDevice));
+    }
     if (arch.reservedCapacity > arch.capacity) {
         void **bufs[5] = { (void **)&arch.keysA, (void **)&arch.keysB,
                            (void **)&arch.idxA, (void **)&arch.idxB,
@@ -2097,6 +2111,15 @@ static int buildLaunchList(mwhip_exec *exec, const std::vector<uint32_t> &tg_ids
                         (256ull * 1024ull) : std::max(d.fixed_count, 1u);
                 }
                 pickGrid(exec, k, max_inv, d.threads_per_invocation);
+                // exec config: workgroups per CU of this node's kernel (only
+                // ParallelFor kernels: they stride over their rows with the grid)
+                if (d.count_mode == MWHIP_COUNT_QUERY_ROWS &&
+                        oi < exec->nodeWorkgroupsPerCU.size() &&
+                        exec->nodeWorkgroupsPerCU[oi] != 0u) {
+                    k.grid.x = std::min<uint32_t>(k.grid.x,
+                        exec->nodeWorkgroupsPerCU[oi] * exec->numCUs);
+                }
+                k.nodeIndex = (uint32_t)oi;
                 lg.launches.push_back(k);
             } break;
             case MWHIP_NODE_SORT_ARCHETYPE: {
@@ -2578,6 +2601,77 @@ static int constructWorlds(mwhip_exec *exec)
     return pokeState(exec, &EcsState::initMode, 0u);
 }
 
+// MADRONA_MWHIP_EXEC_CONFIG_FILE: { "<node index>": <workgroups per CU>, ... } --
+// the format of the reference's exec-config file (cuda_exec.cpp:2115-2172:
+// node index -> blocks per SM).  Written by madrona_amd/scripts/profile.py.
+static int loadExecConfigFile(mwhip_exec *exec)
+{
+    const char *path = getenv("MADRONA_MWHIP_EXEC_CONFIG_FILE");
+    if (path == nullptr || path[0] == '\0') {
+        return 0;
+    }
+    FILE *f = fopen(path, "rb");
+    if (f == nullptr) {
+        return fail(-2, "MADRONA_MWHIP_EXEC_CONFIG_FILE: cannot open %s", path);
+    }
+    std::string text;
+    char buf[4096];
+    size_t got;
+    while ((got = fread(buf, 1, sizeof(buf), f)) > 0) {
+        text.append(buf, got);
+    }
+    fclose(f);
+
+    // a flat object of "digits": digits pairs
+    size_t at = 0;
+    auto skip = [&]() {
+        while (at < text.size() && (isspace((unsigned char)text[at]) ||
+                                    text[at] == ',')) at++;
+    };
+    skip();
+    if (at >= text.size() || text[at] != '{') {
+        return fail(-2, "MADRONA_MWHIP_EXEC_CONFIG_FILE points to invalid file");
+    }
+    at++;
+    for (;;) {
+        skip();
+        if (at < text.size() && text[at] == '}') break;
+        if (at >= text.size() || text[at] != '"') {
+            return fail(-2, "MADRONA_MWHIP_EXEC_CONFIG_FILE points to invalid file");
+        }
+        at++;
+        unsigned long long node = 0, value = 0;
+        size_t digits = 0;
+        while (at < text.size() && isdigit((unsigned char)text[at])) {
+            node = node * 10 + (unsigned)(text[at++] - '0');
+            digits++;
+        }
+        if (digits == 0 || at >= text.size() || text[at] != '"' || node > 16384) {
+            return fail(-2, "MADRONA_MWHIP_EXEC_CONFIG_FILE points to invalid file");
+        }
+        at++;
+        skip();
+        if (at >= text.size() || text[at] != ':') {
+            return fail(-2, "MADRONA_MWHIP_EXEC_CONFIG_FILE points to invalid file");
+        }
+        at++;
+        skip();
+        digits = 0;
+        while (at < text.size() && isdigit((unsigned char)text[at])) {
+            value = value * 10 + (unsigned)(text[at++] - '0');
+            digits++;
+        }
+        if (digits == 0 || value > 64) {
+            return fail(-2, "MADRONA_MWHIP_EXEC_CONFIG_FILE points to invalid file");
+        }
+        if (node >= exec->nodeWorkgroupsPerCU.size()) {
+            exec->nodeWorkgroupsPerCU.resize(node + 1, 0u);
+        }
+        exec->nodeWorkgroupsPerCU[node] = (uint32_t)value;
+    }
+    return 0;
+}
+
 // ---------------------------------------------------------------------------
 // create / destroy
 // ---------------------------------------------------------------------------
@@ -2611,6 +2705,13 @@ extern "C" int mwhip_create(const mwhip_state_config *cfg,
     exec->sortCarriesMisc = envU32("MADRONA_MWHIP_SORT_CARRIES_MISC", 1) != 0;
     exec->sortCompaction = envU32("MADRONA_MWHIP_SORT_COMPACT", 1);
     exec->rowSnapshotMode = envU32("MADRONA_MWHIP_ROW_SNAPSHOT", 1);
+    {
+        hipDeviceProp_t prop {};
+        HIPCHK(hipGetDeviceProperties(&prop, cfg->gpu_id));
+        exec->numCUs = std::max(prop.multiProcessorCount, 1);
+        int rc_cfg = loadExecConfigFile(exec.get());
+        if (rc_cfg != 0) return rc_cfg;
+    }
     exec->tableGrowth = std::max(envU32("MADRONA_MWHIP_TABLE_GROWTH", 4), 1u);
     HIPCHK(hipStreamCreateWithFlags(&exec->stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&exec->serviceStream, hipStreamNonBlocking));
@@ -4133,6 +4234,8 @@ extern "C" int32_t mwhip_profile(mwhip_exec *exec, uint64_t graph, uint32_t reps
         out[i].algo_bytes = total_bytes[i] / reps;
         out[i].rows = total_rows[i] / reps;
         out[i].io_declared = lg.launches[i].ioDeclared;
+        out[i].workgroups = lg.launches[i].grid.x * lg.launches[i].grid.y;
+        out[i].node_index = lg.launches[i].nodeIndex;
         out[i].pad_ = 0;
     }
     return (int32_t)n;

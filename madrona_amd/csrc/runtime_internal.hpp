@@ -57,6 +57,9 @@ struct SortState {
     int32_t prefixRows;             // rows of the sorted prefix this run starts from
     int32_t tailLive;               // live rows behind it (sorted by world by prepare)
     unsigned long long statTailRows;// cumulative rows behind the prefix
+    uint32_t landsBlocked;          // runs that still take the sorted-tail path after a
+                                    // scatter tile owned more tail rows than it orders in LDS
+    uint32_t pad2_;
 };
 
 struct SortSite {
@@ -187,6 +190,7 @@ struct KernelLaunch {
     uint32_t archetype = 0xFFFFFFFFu;
     uint32_t bytesPerRow = 0;
     uint32_t ioDeclared = 0;        // bytesPerRow from a declared read / write set
+    uint32_t nodeIndex = 0xFFFFFFFFu;   // position of the node in its task graph's order
     uint32_t countMode = 0;
     uint32_t fixedCount = 0;
     uint32_t queryOffset = 0;

@@ -673,6 +673,8 @@ __device__ inline void writeWorldRanges(TableHdr &tbl,
     }
 }
 
+__device__ inline int32_t compactNumTiles(int32_t prefix);
+
 // One column (blockIdx.y) of one site: rows move from the buffers the table
 // had when the chain started into its current ones.
 __device__ inline void gatherColumn(EcsState *S, const SortSite &site,
@@ -707,6 +709,12 @@ sortGather(EcsState *S, const SortSite *sites, const GatherColumn *columns,
     // (the passes are over: their histograms and counters are dead)
     if (gc.column == 0u && slice.slice == 0u) {
         cleanSortState(state);
+        // the per-tile landing counters of the compaction chain start every
+        // run at zero (whichever way the tail went this time)
+        const int32_t tiles = compactNumTiles(state->prefixRows) + 1;
+        for (int32_t t = (int32_t)threadIdx.x; t < tiles; t += (int32_t)blockDim.x) {
+            site.tileTailStart[t] = 0;
+        }
     }
 }
 
@@ -1116,15 +1124,28 @@ __device__ inline int32_t compactNumTiles(int32_t prefix)
 // prefix; the scatter tile that owns that position only has to know (1) how
 // many live tail rows land in earlier tiles and (2) its own rows in (world,
 // tail index) order -- both of which it gets from one scan of the landing
-// points, a 4-byte read per tail row that all tiles do side by side.  Used
-// whenever there is a sorted prefix to land in and the tail is not most of the
-// table (a cold start, a synchronised reset of every world: then the old path
-// or, after three long tails, the radix chain).
-constexpr int32_t kLandsMaxTail = 1 << 16;
+// points.  prepare leaves, per tail row, its landing point (tailLand) and,
+// per tile, how many land in it (tileTailStart doubles as that counter; one
+// atomic per tail row on one of hundreds of addresses); a tile that owns rows
+// picks them out of the landing points and orders them in LDS.  Used whenever
+// there is a sorted prefix to land in and the tail is short (else -- a cold
+// start, a synchronised reset of every world -- the old path or, after three
+// long tails, the radix chain).
+constexpr int32_t kLandsMaxTail = 1 << 14;
 constexpr int32_t kOwnCap = 2048;       // own rows a scatter tile orders in LDS
-__device__ inline bool compactTailByLands(int32_t prefix, int32_t tail)
+// (a tile that owns more -- worlds that multiplied their rows in one step --
+// ranks them the slow way once and sends the next runs down the old path)
+constexpr uint32_t kLandsBlockedRuns = 16;
+__device__ inline bool compactTailByLands(int32_t prefix, int32_t tail,
+                                          uint32_t blocked_runs)
 {
-    return prefix > 0 && tail <= kLandsMaxTail;
+    // (a SHORT tail: on average at most a quarter of a tile's threads get a
+    // row to place.  A table whose tail is comparable to its prefix -- the
+    // joint table of the physics step: ~2 K rows, a thousand of them new every
+    // step, all landing in its one tile -- is better off with the one-workgroup
+    // LDS radix sort of the old path)
+    return prefix > 0 && tail <= kLandsMaxTail && (long long)tail * 8 <= prefix &&
+        blocked_runs == 0u;
 }
 
 // a short tail (the steady state) is sorted without leaving the CU
@@ -1242,15 +1263,16 @@ sortCompactPrepare(EcsState *S, const SortSite *sites)
     const uint32_t tid = threadIdx.x;
 
     // how the tail is handled: every workgroup of both kernels derives the
-    // same answer from the header
+    // same answer (header values + a counter only the NEXT kernel changes)
     const int32_t tail = n - prefix;
-    const bool by_lands = compactTailByLands(prefix, tail);
+    const uint32_t blocked = state->landsBlocked;
+    const bool by_lands = compactTailByLands(prefix, tail, blocked);
     if (blockIdx.x == 0 && tid == 0) {
         state->active = active ? 1u : 0u;
         state->rowsIn = n;
         state->keyColumn = keys;
         state->prefixRows = prefix;
-        state->tailByLands = by_lands ? 1u : 0u;
+        state->tailByLands = (active && by_lands) ? 1u : 0u;
     }
     if (!active) {
         return;
@@ -1258,15 +1280,36 @@ sortCompactPrepare(EcsState *S, const SortSite *sites)
 
     if (by_lands) {
         // where every (raw) tail row lands in the prefix -- the end of its
-        // world's old range --, or -1 for a row destroyed again: all workgroups,
-        // a row per thread.  No sort: the scatter tiles pick out and order the
-        // few rows that land in them.
+        // world's old range --, or -1 for a row destroyed again, and how many
+        // land in each tile: all workgroups, a row per thread.  No sort.
         const int32_t *offs = tbl.worldOffsets;
         const int32_t *cnts = tbl.worldCounts;
-        for (int32_t j = (int32_t)(blockIdx.x * kSmallThreads + tid); j < tail;
-             j += (int32_t)(gridDim.x * kSmallThreads)) {
-            const uint32_t w = keys[prefix + j];
-            site.tailLand[j] = w == 0xFFFFFFFFu ? -1 : offs[w] + cnts[w];
+        const int32_t num_tiles = compactNumTiles(prefix);
+        const uint32_t lane = laneId();
+        for (int32_t j0 = (int32_t)(blockIdx.x * kSmallThreads + (tid & ~63u));
+             j0 < tail; j0 += (int32_t)(gridDim.x * kSmallThreads)) {
+            const int32_t j = j0 + (int32_t)lane;
+            int32_t land = -1, t = -1;
+            if (j < tail) {
+                const uint32_t w = keys[prefix + j];
+                if (w != 0xFFFFFFFFu) {
+                    land = offs[w] + cnts[w];
+                    t = land >> kCompactTileShift;
+                    t = t < num_tiles - 1 ? t : num_tiles - 1;
+                }
+                site.tailLand[j] = land;
+            }
+            // one atomic per RUN of lanes with the same tile (the rows a world
+            // appended in a step are neighbours in the tail: a wavefront
+            // usually holds a handful of runs, not 64 different counters)
+            const int32_t t_prev = __shfl_up(t, 1, 64);
+            const unsigned long long heads = ballot64(lane == 0u || t != t_prev);
+            if (t >= 0 && (lane == 0u || t != t_prev)) {
+                const unsigned long long later = lane == 63u ? 0ull : heads >> (lane + 1u);
+                const int32_t run = later != 0ull ? (int32_t)__builtin_ctzll(later) + 1 :
+                                                   64 - (int32_t)lane;
+                atomicAdd(&site.tileTailStart[t], run);
+            }
         }
         if (blockIdx.x == 0 && tid == 0) {
             state->statTailRows += (unsigned long long)tail;
@@ -1329,13 +1372,10 @@ struct alignas(16) CompactLDS {
     uint32_t liveBefore[kCompactTile + 4];  // survivors of the tile before each position
     unsigned long long scan[THREADS / 64];
     int32_t reduce[THREADS / 64];
-    // tail by landing points: the tail rows that land in this tile (tail index,
-    // world), in tail order
-    int32_t ownJ[kOwnCap];
-    uint32_t ownW[kOwnCap];
-    int32_t waveOwn[THREADS / 64];
-    int32_t waveBefore[THREADS / 64];
-    int32_t waveLive[THREADS / 64];
+    // tail by landing points: (world << 32 | tail index) of the tail rows that
+    // land in this tile, ordered here
+    unsigned long long ownKey[kOwnCap];
+    uint32_t ownCount;
 };
 
 template <int THREADS>
@@ -1499,90 +1539,96 @@ __device__ inline void compactScatterTile(const SortSite &site, CompactLDS<THREA
     __syncthreads();
 }
 
-// The same for a tail that was NOT sorted (SortState::tailByLands): the tile
-// scans the landing points of all `tail` raw tail rows (site.tailLand, -1 =
-// destroyed), counts the live ones landing in earlier tiles (= where its own
-// start in the sorted tail), collects its own in tail order and ranks them by
-// (world, tail index).  Returns the live tail rows (every tile counts them).
-// own rows beyond kOwnCap (a tile whose worlds appended more rows than the tile
-// holds: not the steady state) are kept in the site's spare key / index buffer
-// instead of LDS, at [before, before + own): disjoint between tiles.
+// The same for a tail that was NOT sorted (SortState::tailByLands).  `before` =
+// live tail rows landing in earlier tiles (= where this tile's start in the
+// sorted tail), `own_total` = the ones landing here (both from prepare's
+// per-tile counters).  The tile picks its rows out of the landing points
+// (site.tailLand, -1 = destroyed), orders them by (world, tail index) -- the
+// stable sort by world -- and writes them and its surviving prefix rows to
+// their places.  A tile that owns more than it can order in LDS ranks them by
+// counting (quadratic: not the steady state) and blocks the path for a while.
 template <int THREADS, int ITEMS>
-__device__ inline int32_t compactScatterTileLands(
-    const SortSite &site, CompactLDS<THREADS> &lds, int32_t tile, int32_t num_tiles,
-    int32_t first, const uint32_t (&key)[ITEMS], int32_t live_before_tile,
+__device__ inline void compactScatterTileLands(
+    const SortSite &site, SortState *state, CompactLDS<THREADS> &lds, int32_t tile,
+    int32_t num_tiles, int32_t first, const uint32_t (&key)[ITEMS],
+    int32_t live_before_tile, int32_t before, int32_t own_total,
     uint32_t *out_keys, int32_t *out_rows, const uint32_t *table_keys,
-    int32_t prefix, int32_t tail, uint32_t *spare_keys, int32_t *spare_rows)
+    int32_t prefix, int32_t tail)
 {
     static_assert(THREADS * ITEMS == kCompactTile);
-    constexpr int32_t waves = THREADS / 64;
     const int32_t tid = (int32_t)threadIdx.x;
-    const uint32_t lane = laneId();
-    const int32_t wave = tid >> 6;
     const int32_t mine = first + tid * ITEMS;
-    const unsigned long long lane_lt = (1ull << lane) - 1ull;
 
-    auto tile_of = [&](int32_t land) {
+    auto is_own = [&](int32_t land) {
+        if (land < 0) return false;
         const int32_t t = land >> kCompactTileShift;
-        return t < num_tiles - 1 ? t : num_tiles - 1;
+        return (t < num_tiles - 1 ? t : num_tiles - 1) == tile;
     };
+    auto at_of = [&](int32_t land) {
+        const int32_t at = land - first;
+        return at < 0 ? 0 : (at > kCompactTile ? kCompactTile : at);
+    };
+    const bool in_lds = own_total <= kOwnCap;
 
-    // ---- pass 1 over the landing points: counts (a contiguous run per wave) ----
-    const int32_t seg = ((tail + waves * 64 - 1) / (waves * 64)) * 64;
-    const int32_t wave_first = wave * seg;
-    const int32_t wave_end = wave_first + seg < tail ? wave_first + seg : tail;
-    int32_t own_wave = 0, before_lane = 0, live_lane = 0;
-    for (int32_t base = wave_first; base < wave_end; base += 64) {
-        const int32_t j = base + (int32_t)lane;
-        const int32_t land = j < wave_end ? site.tailLand[j] : -1;
-        const int32_t t = land >= 0 ? tile_of(land) : -1;
-        live_lane += land >= 0 ? 1 : 0;
-        before_lane += (land >= 0 && t < tile) ? 1 : 0;
-        own_wave += (int32_t)__popcll(ballot64(t == tile));
-    }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-        before_lane += __shfl_down(before_lane, d, 64);
-        live_lane += __shfl_down(live_lane, d, 64);
-    }
-    if (lane == 0) {
-        lds.waveOwn[wave] = own_wave;
-        lds.waveBefore[wave] = before_lane;
-        lds.waveLive[wave] = live_lane;
-    }
-    __syncthreads();
-    int32_t own_base = 0, own_total = 0, before = 0, live_total = 0;
-#pragma unroll
-    for (int w = 0; w < waves; w++) {
-        own_base += w < wave ? lds.waveOwn[w] : 0;
-        own_total += lds.waveOwn[w];
-        before += lds.waveBefore[w];
-        live_total += lds.waveLive[w];
-    }
-    const bool spill = own_total > kOwnCap;
-    int32_t *own_j = spill ? spare_rows + before : lds.ownJ;
-    uint32_t *own_w = spill ? spare_keys + before : lds.ownW;
-
-    // ---- pass 2: my rows, in tail order, with their worlds ----
+    // ---- my tail rows: picked out of the landing points ----
+    // (lds.landing and lds.ownCount were cleared before a barrier by the caller)
     if (own_total != 0) {
-        int32_t run = own_base;
-        for (int32_t base = wave_first; base < wave_end; base += 64) {
-            const int32_t j = base + (int32_t)lane;
-            const int32_t land = j < wave_end ? site.tailLand[j] : -1;
-            const bool is_mine = land >= 0 && tile_of(land) == tile;
-            const unsigned long long m = ballot64(is_mine);
-            if (is_mine) {
-                const int32_t pos = run + (int32_t)__popcll(m & lane_lt);
-                own_j[pos] = j;
-                own_w[pos] = table_keys[prefix + j];
-                int32_t at = land - first;
-                at = at < 0 ? 0 : (at > kCompactTile ? kCompactTile : at);
-                atomicAdd(&lds.landing[at], 1u);    // (cleared by the caller)
+        for (int32_t j0 = tid * 4; j0 < tail; j0 += THREADS * 4) {
+            int32_t land[4] = { -1, -1, -1, -1 };
+            if (j0 + 4 <= tail) {
+                const int4 v = *(const int4 *)(site.tailLand + j0);
+                land[0] = v.x; land[1] = v.y; land[2] = v.z; land[3] = v.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    land[e] = j0 + e < tail ? site.tailLand[j0 + e] : -1;
+                }
             }
-            run += (int32_t)__popcll(m);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                if (is_own(land[e])) {
+                    atomicAdd(&lds.landing[at_of(land[e])], 1u);
+                    if (in_lds) {
+                        const uint32_t slot = atomicAdd(&lds.ownCount, 1u);
+                        lds.ownKey[slot] =
+                            ((unsigned long long)table_keys[prefix + j0 + e] << 32) |
+                            (unsigned long long)(uint32_t)(j0 + e);
+                    }
+                }
+            }
         }
     }
     __syncthreads();
+
+    // ---- ... ordered by (world, tail index) ----
+    // a handful of rows (the steady state: what one or two worlds appended):
+    // every thread ranks its row by counting; more: bitonic, in LDS
+    constexpr int32_t rank_by_counting = THREADS;
+    if (own_total > rank_by_counting && in_lds) {
+        int32_t n_pad = 2;
+        while (n_pad < own_total) n_pad <<= 1;
+        for (int32_t i = own_total + tid; i < n_pad; i += THREADS) {
+            lds.ownKey[i] = ~0ull;
+        }
+        for (int32_t k = 2; k <= n_pad; k <<= 1) {
+            for (int32_t jj = k >> 1; jj > 0; jj >>= 1) {
+                __syncthreads();
+                for (int32_t i = tid; i < n_pad; i += THREADS) {
+                    const int32_t partner = i ^ jj;
+                    if (partner > i) {
+                        const unsigned long long a = lds.ownKey[i];
+                        const unsigned long long b = lds.ownKey[partner];
+                        const bool ascending = (i & k) == 0;
+                        if ((a > b) == ascending) {
+                            lds.ownKey[i] = b;
+                            lds.ownKey[partner] = a;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
 
     // ---- the prefix rows of the tile (as compactScatterTile) ----
     uint32_t land[ITEMS];
@@ -1623,24 +1669,52 @@ __device__ inline int32_t compactScatterTileLands(
     }
     __syncthreads();
 
-    // ---- my tail rows: rank by (world, tail index), then to their place ----
-    for (int32_t i = tid; i < own_total; i += THREADS) {
-        const uint32_t w = own_w[i];
-        int32_t rank = 0;
-        for (int32_t k = 0; k < own_total; k++) {
-            const uint32_t other = own_w[k];
-            rank += (other < w || (other == w && k < i)) ? 1 : 0;
+    // ---- my tail rows to their places ----
+    if (in_lds && own_total <= rank_by_counting) {
+        if (tid < own_total) {
+            const unsigned long long k = lds.ownKey[tid];
+            int32_t r = 0;
+            for (int32_t o = 0; o < own_total; o++) {
+                r += lds.ownKey[o] < k ? 1 : 0;
+            }
+            const int32_t j = (int32_t)(uint32_t)k;
+            const int32_t dest = live_before_tile +
+                (int32_t)lds.liveBefore[at_of(site.tailLand[j])] + before + r;
+            out_rows[dest] = prefix + j;
+            out_keys[dest] = (uint32_t)(k >> 32);
         }
-        const int32_t j = own_j[i];
-        int32_t at = site.tailLand[j] - first;
-        at = at < 0 ? 0 : (at > kCompactTile ? kCompactTile : at);
-        const int32_t dest = live_before_tile + (int32_t)lds.liveBefore[at] +
-            before + rank;
-        out_rows[dest] = prefix + j;
-        out_keys[dest] = w;
+    } else if (in_lds) {
+        for (int32_t r = tid; r < own_total; r += THREADS) {
+            const unsigned long long k = lds.ownKey[r];
+            const int32_t j = (int32_t)(uint32_t)k;
+            const int32_t dest = live_before_tile +
+                (int32_t)lds.liveBefore[at_of(site.tailLand[j])] + before + r;
+            out_rows[dest] = prefix + j;
+            out_keys[dest] = (uint32_t)(k >> 32);
+        }
+    } else {
+        // more rows than the tile orders in LDS: rank each by counting the own
+        // rows that sort before it
+        if (tid == 0) {
+            state->landsBlocked = kLandsBlockedRuns;
+        }
+        for (int32_t j = tid; j < tail; j += THREADS) {
+            const int32_t land_j = site.tailLand[j];
+            if (!is_own(land_j)) continue;
+            const uint32_t w = table_keys[prefix + j];
+            int32_t rank = 0;
+            for (int32_t k = 0; k < tail; k++) {
+                if (!is_own(site.tailLand[k])) continue;
+                const uint32_t other = table_keys[prefix + k];
+                rank += (other < w || (other == w && k < j)) ? 1 : 0;
+            }
+            const int32_t dest = live_before_tile +
+                (int32_t)lds.liveBefore[at_of(land_j)] + before + rank;
+            out_rows[dest] = prefix + j;
+            out_keys[dest] = w;
+        }
     }
     __syncthreads();
-    return live_total;
 }
 
 __global__ void __launch_bounds__(kSortThreads)
@@ -1674,22 +1748,25 @@ sortCompactScatter(EcsState *S, const SortSite *sites)
         return (t << kCompactTileShift) < prefix ? site.tileCounts[t] : 0;
     };
 
+    auto tile_lands = [&](int32_t t) {
+        return by_lands ? site.tileTailStart[t] : 0;
+    };
+
     if (blockIdx.x == 0) {
         // rows the sorted table has = survivors of the prefix + live tail rows
-        int32_t part = 0;
+        int32_t part = 0, lands = 0;
         for (int32_t t = tid; t < num_tiles; t += kSortThreads) {
             part += tile_count(t);
+            lands += tile_lands(t);
         }
         const int32_t survivors = blockSum<kSortThreads>(part, lds.reduce);
         if (by_lands) {
-            int32_t live = 0;
-            for (int32_t j = tid; j < tail; j += kSortThreads) {
-                live += site.tailLand[j] >= 0 ? 1 : 0;
-            }
-            tail_live = blockSum<kSortThreads>(live, lds.reduce);
+            tail_live = blockSum<kSortThreads>(lands, lds.reduce);
             if (tid == 0) {
                 state->tailLive = tail_live;
             }
+        } else if (tid == 0 && state->landsBlocked != 0u) {
+            state->landsBlocked -= 1u;
         }
         if (tid == 0) {
             state->numValid = (uint32_t)(survivors + tail_live);
@@ -1710,20 +1787,24 @@ sortCompactScatter(EcsState *S, const SortSite *sites)
         uint32_t key[kSortItems];
         loadTileKeys<kSortItems>(keys, first + tid * kSortItems, last, key);
 
-        // survivors of the tiles before this one (the sum's barriers also order
-        // the clearing of lds.landing before the atomics of the tile)
-        int32_t part = 0;
+        if (tid == 0) {
+            lds.ownCount = 0;
+        }
+        // survivors of the tiles before this one, and the live tail rows that
+        // land in them (the sums' barriers also order the clearing of
+        // lds.landing before the atomics of the tile)
+        int32_t part = 0, lands = 0;
         for (int32_t t = tid; t < tile; t += kSortThreads) {
             part += tile_count(t);
+            lands += tile_lands(t);
         }
         const int32_t live_before_tile = blockSum<kSortThreads>(part, lds.reduce);
 
         if (by_lands) {
-            // (the spare key / index buffer: where the sorted tail would be)
-            (void)compactScatterTileLands<kSortThreads, kSortItems>(site, lds, tile,
-                num_tiles, first, key, live_before_tile, out_keys, out_rows, keys,
-                prefix, tail, const_cast<uint32_t *>(tail_keys),
-                const_cast<int32_t *>(tail_rows));
+            const int32_t before = blockSum<kSortThreads>(lands, lds.reduce);
+            compactScatterTileLands<kSortThreads, kSortItems>(site, state, lds, tile,
+                num_tiles, first, key, live_before_tile, before, tile_lands(tile),
+                out_keys, out_rows, keys, prefix, tail);
         } else {
             compactScatterTile<kSortThreads, kSortItems>(site, lds, tile, first, key,
                 live_before_tile, out_keys, out_rows, tail_keys, tail_rows);

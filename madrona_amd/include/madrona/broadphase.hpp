@@ -112,6 +112,15 @@ public:
     // Closest hit of the ray o + t * d, 0 <= t <= t_max, against the collision
     // primitives of every leaf (hulls and planes).  Returns Entity::none() on a
     // miss.  Reference src/physics/broadphase.cpp:658-871.
+    // PRECONDITION (this backend): the leaf boxes are current, i.e.
+    // PhysicsSystem::setupBroadphaseTasks ran after the last write to a body's
+    // Position / Rotation / Scale.  The traversal culls by a leaf's OWN box
+    // (leaf_aabbs_), which only the leaf update refreshes; the reference culls
+    // by the boxes of the tree nodes, which are never smaller than a stale leaf
+    // box and may therefore still reach a body that was teleported (pose written,
+    // no leaf update) -- here such a body can be missed until the next leaf
+    // update.  The same holds for PhysicsSystem::findFirstEntitiesWithinAABBsWave.
+    // (Every simulator in sims/ runs the broadphase tasks before its ray systems.)
     MADRONA_HD inline Entity traceRay(math::Vector3 o,
                                       math::Vector3 d,
                                       float *out_hit_t,

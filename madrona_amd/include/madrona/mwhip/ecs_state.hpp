@@ -47,6 +47,34 @@ enum ColumnFlags : uint32_t {
     kColumnPinned = 1u << 0,    // exported: address must stay fixed across sorts
 };
 
+// Device-side error flags (EcsState::errorFlags, sticky, reported by the health
+// kernel at the end of every replay: mwhip_run / mwhip_synchronize return -10
+// and mwhip_last_error() names the flag).  The reference aborts the process in
+// these situations (FATAL / assert); here the replay COMPLETES and what it left
+// behind is partly stale -- after an error the exported tensors must not be
+// fed to a trainer:
+//   kErrTableOverflow   an append found its table full and no memory could be
+//                       mapped behind it in time: the entity was not created
+//                       (makeEntity returned Entity::none()); every tensor of
+//                       the worlds that asked is short of those rows.  In the
+//                       physics step: a world's candidate / contact budget ran
+//                       out -- that WORLD skipped its whole physics step.
+//   kErrPhysics         a rigid-body table was not grouped by world, a world has
+//                       more bodies than the step kernel was built for, or a
+//                       primitive pair is unsupported: the world skipped its
+//                       physics step for this replay.  Its Position, Rotation,
+//                       Velocity and solver-state columns hold the values of
+//                       the replay before; everything computed after the
+//                       physics nodes (observations, lidar, rewards, render
+//                       instance records) is computed from those stale poses.
+//                       Other worlds are unaffected.
+//   kErrRender          a world has more than 1024 instances / the instance
+//                       table was unsorted / a traversal stack overflowed: the
+//                       rgb / depth outputs of that world's views are stale or
+//                       partial.
+//   the others          (entity store, tmpAlloc, constructor blocks, sort
+//                       look-back) leave the tables in an undefined state:
+//                       discard the executor.
 enum ErrorFlags : uint32_t {
     kErrTableOverflow = 1u << 0,
     kErrEntityOverflow = 1u << 1,

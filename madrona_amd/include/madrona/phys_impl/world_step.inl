@@ -935,7 +935,7 @@ struct WorldBlock {
     uint16_t primOffset[MAXB];
     uint16_t primCount[MAXB];
     uint16_t orderBody[MAXB];               // traversal rank -> body index
-    uint16_t imagePad_[MAXB];               // (keeps `shared` 16-byte aligned)
+    uint16_t leafOf[MAXB];                  // body -> BVH leaf (epilogue refit)
 
     // broadphase boxes are dead once the candidates exist: the contacts of the
     // substeps reuse their storage
@@ -1256,6 +1256,7 @@ __device__ inline void writeBodyRow(WorldBlock<MAXB, LPW> *dst,
     dst->rankSlotBox()[rank] = row.slotBox;
     dst->rankEntity()[rank] = row.entityID;
     dst->orderBody[rank] = (uint16_t)k;
+    dst->leafOf[k] = (uint16_t)row.leaf;
 }
 
 // leaf_rank (LDS, filled here): leaf id -> position in the BVH's traversal
@@ -1419,7 +1420,7 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
     // wavefront costs the LONGER of its two worlds, and similar worlds waste
     // the least of it.
     const int32_t *world_order = params.worldOrder;
-    const bool fold_pairs = LPW == 32 && params.foldPairs != 0 &&
+    const bool fold_pairs = LPW == 32 && (params.foldPairs & 1) != 0 &&
         world_order != nullptr;
     const int32_t num_jobs = (num_worlds + worlds_per_wave - 1) / worlds_per_wave;
     for (int32_t job = (int32_t)blockIdx.x; job < num_jobs;
@@ -1971,6 +1972,20 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                 xpbd::XPBDCols::PreSolvePositional, loc) = pre_pos;
             ctx.getDirect<xpbd::PreSolveVelocity>(
                 xpbd::XPBDCols::PreSolveVelocity, loc) = pre_vel;
+        }
+        // ---- leaf boxes + refit (what setupPostIntegrationTasks's node does:
+        // reference broadphase.cpp updateLeafPositionsEntry + refitEntry) -------
+        if ((params.foldPairs & 2) != 0) {
+            broadphase::BVH &world_bvh = ctx.singleton<broadphase::BVH>();
+            for (int32_t k = (int32_t)lane; k < num_bodies; k += LPW) {
+                const Loc loc = w->bodyLoc[k];
+                const base::ObjectID obj_id =
+                    ctx.getDirect<base::ObjectID>(RGDCols::ObjectID, loc);
+                const math::AABB obj_aabb = hbm_obj_mgr.rigidBodyAABBs[obj_id.idx];
+                world_bvh.updateLeafAndRefit(
+                    broadphase::LeafID { (int32_t)w->leafOf[k] }, w->pos[k],
+                    w->rot[k], w->scale[k], w->vel[k].linear, obj_aabb);
+            }
         }
         wave::phaseFence();
         PHYS_PROF(7);

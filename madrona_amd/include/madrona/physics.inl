@@ -68,9 +68,10 @@ struct PhysicsScratch {
 // node data of the fused per-world step kernel
 struct PhysicsStepParams {
     int32_t numSubsteps;
-    // two worlds per wavefront: 1 = wavefront k steps the k-th heaviest world
-    // next to the k-th lightest (worldOrder folded), 0 = next to its neighbour
-    // in that order
+    // bit 0: two worlds per wavefront, wavefront k steps the k-th heaviest
+    // world next to the k-th lightest (worldOrder folded) instead of next to its
+    // neighbour in that order; bit 1: the LDS step kernels end with the leaf
+    // update + refit of their world (setupPostIntegrationTasks then adds no node)
     int32_t foldPairs;
     // per-world images of the LDS step's block (physicsPackKernel writes them
     // right before the step kernel reads them), or nullptr: the step kernel
@@ -2161,9 +2162,16 @@ MADRONA_HOST_API inline TaskGraphNodeID setupPhysicsStepTasks(
     // (profiles/r04_phys_variants.jsonl), see physicsStepLdsKernel.
     const int32_t fold_pairs = lanes_per_world == 32 && world_order != nullptr &&
         order_env != nullptr && atoi(order_env) >= 2 ? 1 : 0;
+    // The leaf update + refit that follows the step (setupPostIntegrationTasks:
+    // a ParallelFor over all bodies, ~25 us and the largest traffic ratio of the
+    // step -- atomic min / max on ancestor boxes) in the step kernel's epilogue:
+    // the wavefront still holds every pose of its world.  MADRONA_MWHIP_PHYS_REFIT=0
+    // keeps the separate node (measurements).
+    const int32_t refit_in_step = max_bodies != 0 &&
+        phys::detail::capacityHint("MADRONA_MWHIP_PHYS_REFIT", 1) != 0 ? 2 : 0;
     auto params = builder.constructNodeData<PhysicsStepParams>(
-        PhysicsStepParams { (int32_t)num_substeps, fold_pairs, world_images,
-                            world_cost, world_order });
+        PhysicsStepParams { (int32_t)num_substeps, fold_pairs | refit_in_step,
+                            world_images, world_cost, world_order });
 
     if (world_order != nullptr) {
         mwhip_node_desc order {};
@@ -2200,6 +2208,9 @@ MADRONA_HOST_API inline TaskGraphNodeID setupPhysicsStepTasks(
     }
     desc.arg0 = max_bodies != 0 ? 1u : 0u;
     cur_node = builder.addRuntimeNode(desc, params.id, {cur_node});
+    if (refit_in_step != 0) {
+        return cur_node;
+    }
 #else
     (void)num_substeps;
 #endif

@@ -105,6 +105,8 @@ class KernelStat(C.Structure):
         ("algo_bytes", C.c_double),
         ("rows", C.c_double),
         ("io_declared", C.c_uint32),
+        ("workgroups", C.c_uint32),
+        ("node_index", C.c_uint32),
         ("pad_", C.c_uint32),
     ]
 
@@ -390,4 +392,6 @@ class Simulator:
         return [dict(name=stats[i].name.decode(), kind=int(stats[i].node_kind),
                      avg_us=float(stats[i].avg_us), algo_bytes=float(stats[i].algo_bytes),
                      rows=float(stats[i].rows),
-                     io_declared=bool(stats[i].io_declared)) for i in range(n)]
+                     io_declared=bool(stats[i].io_declared),
+                     workgroups=int(stats[i].workgroups),
+                     node_index=int(stats[i].node_index)) for i in range(n)]
