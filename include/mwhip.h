@@ -331,6 +331,10 @@ int32_t mwhip_tg_add_node(mwhip_exec *exec, uint32_t taskgraph_id,
                           const mwhip_node_desc *desc, const int32_t *deps,
                           uint32_t num_deps);
 
+/* compute units of the executor's device (kernel nodes that size a persistent
+ * grid themselves) */
+uint32_t mwhip_device_cus(const mwhip_exec *exec);
+
 /* ---- execution ----------------------------------------------------------*/
 /* MWCudaExecutor::buildLaunchGraph(Span<const uint32_t>, stat_name)
  * (cuda_exec.cpp:2174-2292): captures one hipGraph running the given task

@@ -1728,6 +1728,9 @@ static bool compactionEligible(const mwhip_exec *exec, uint32_t archetype_id,
     return exec->sortCompaction == 2 || (!arch.scrambled && !arch.noCompact);
 }
 
+// batches that move at least this much take the gather's blocked assignment
+static constexpr double kGatherBlockedBytes = 256.0 * 1024.0 * 1024.0;
+
 static int makeSortBatch(mwhip_exec *exec,
                          const std::vector<std::pair<uint32_t, uint32_t>> &specs,
                          std::unique_ptr<SortBatch> &out, bool compact = false)
@@ -1825,8 +1828,13 @@ static int makeSortBatch(mwhip_exec *exec,
             gc.wordsPerRow = bytes / gc.wordBytes;
             gc.invMagic = gc.wordsPerRow <= 1 ? 0ull :
                 (~0ull / gc.wordsPerRow) + 1ull;
-            // MADRONA_MWHIP_GATHER_WIDE=0: every column word by word (measurement)
-            const bool wide = envU32("MADRONA_MWHIP_GATHER_WIDE", 1) != 0;
+            // MADRONA_MWHIP_GATHER_WIDE=1: rows of whole dwords in 16-byte chunks
+            // of the destination (round 3's default).  Re-measured in round 4
+            // next to the blocked assignment (profiles/r04_sort_variants.jsonl):
+            // word by word is as fast or faster at every size -- 15.0 against
+            // 15.6 us at 4096 Escape-Room worlds, 28.1 against 30.7 at 8192 with
+            // physics, 168 against 204 at 65536 -- so that is the default again.
+            const bool wide = envU32("MADRONA_MWHIP_GATHER_WIDE", 0) != 0;
             if (wide && bytes % 4 == 0 && bytes != 0) {
                 gc.rowDwords = bytes / 4;
                 gc.invMagicDwords = gc.rowDwords <= 1 ? 0ull :
@@ -1881,8 +1889,14 @@ static int makeSortBatch(mwhip_exec *exec,
             // at least 4 KB of work per workgroup, at least one workgroup
             n = std::min<uint32_t>(n, (uint32_t)(weight[c] / 4096.0) + 1u);
             n = std::max<uint32_t>(n, 1u);
+            // big tables: a contiguous run of rows per workgroup
+            // (MADRONA_MWHIP_GATHER_BLOCKED=0/1 forces; measured in
+            // profiles/r04_sort_variants.jsonl)
+            const uint32_t blocked_env = envU32("MADRONA_MWHIP_GATHER_BLOCKED", 2);
+            const uint32_t blocked = blocked_env != 2 ? blocked_env :
+                (total >= kGatherBlockedBytes ? 1u : 0u);
             for (uint32_t i = 0; i < n; i++) {
-                slices.push_back(GatherSlice { (uint32_t)c, i, n, 0u });
+                slices.push_back(GatherSlice { (uint32_t)c, i, n, blocked });
             }
         }
         rc = devAllocT(exec, &out->gatherSlicesDev, slices.size());
@@ -3773,6 +3787,11 @@ static int rebuildAllLaunchGraphs(mwhip_exec *exec)
         kv.second = std::move(fresh);
     }
     return 0;
+}
+
+extern "C" uint32_t mwhip_device_cus(const mwhip_exec *exec)
+{
+    return exec->numCUs;
 }
 
 extern "C" int mwhip_set_input_ring(mwhip_exec *exec, void *dst, const void *ring,

@@ -107,7 +107,7 @@ struct GatherSlice {
     uint32_t column;                // index into the batch's GatherColumn list
     uint32_t slice;
     uint32_t numSlices;
-    uint32_t pad_;
+    uint32_t blocked;               // 1: a contiguous run of rows, 0: strided over the column
 };
 
 struct SortSiteHost {

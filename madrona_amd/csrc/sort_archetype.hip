@@ -679,7 +679,8 @@ __device__ inline int32_t compactNumTiles(int32_t prefix);
 // had when the chain started into its current ones.
 __device__ inline void gatherColumn(EcsState *S, const SortSite &site,
                                     const GatherColumn &gc, TableHdr &tbl,
-                                    int32_t n_out, int32_t tid, int32_t stride);
+                                    int32_t row_begin, int32_t row_end,
+                                    int32_t tid, int32_t stride);
 
 __global__ void __launch_bounds__(kSortThreads)
 sortGather(EcsState *S, const SortSite *sites, const GatherColumn *columns,
@@ -702,9 +703,23 @@ sortGather(EcsState *S, const SortSite *sites, const GatherColumn *columns,
     }
     const int32_t n_out = state->rowsOut;
 
-    gatherColumn(S, site, gc, tbl, n_out,
-                 (int32_t)(slice.slice * kSortThreads + threadIdx.x),
-                 (int32_t)(slice.numSlices * kSortThreads));
+    if (slice.blocked != 0u && gc.column != kWorldRangesColumn) {
+        // a contiguous run of rows per workgroup (big tables: every workgroup
+        // stays inside a few pages of every buffer it touches instead of
+        // striding over all of them)
+        int32_t per = (n_out + (int32_t)slice.numSlices - 1) / (int32_t)slice.numSlices;
+        per = (per + 3) & ~3;       // (16-byte destination chunks stay aligned)
+        const int32_t row_begin = (int32_t)slice.slice * per;
+        const int32_t row_end = row_begin + per < n_out ? row_begin + per : n_out;
+        if (row_begin < row_end) {
+            gatherColumn(S, site, gc, tbl, row_begin, row_end,
+                         (int32_t)threadIdx.x, (int32_t)kSortThreads);
+        }
+    } else {
+        gatherColumn(S, site, gc, tbl, 0, n_out,
+                     (int32_t)(slice.slice * kSortThreads + threadIdx.x),
+                     (int32_t)(slice.numSlices * kSortThreads));
+    }
 
     // (the passes are over: their histograms and counters are dead)
     if (gc.column == 0u && slice.slice == 0u) {
@@ -718,18 +733,20 @@ sortGather(EcsState *S, const SortSite *sites, const GatherColumn *columns,
     }
 }
 
-// tid / stride: this thread's index among, and the number of, the threads
-// working on the column
+// Rows [row_begin, row_end) of the sorted table.  tid / stride: this thread's
+// index among, and the number of, the threads working on them.
 __device__ inline void gatherColumn(EcsState *S, const SortSite &site,
                                     const GatherColumn &gc, TableHdr &tbl,
-                                    int32_t n_out, int32_t tid, int32_t stride)
+                                    int32_t row_begin, int32_t row_end,
+                                    int32_t tid, int32_t stride)
 {
     const bool final_in_b = ((site.numPasses - 1) & 1) != 0;
-    const int32_t *perm = final_in_b ? site.idxB : site.idxA;
+    const int32_t *perm = (final_in_b ? site.idxB : site.idxA) + row_begin;
+    const int32_t n_rows = row_end - row_begin;
 
     const uint32_t col = gc.column;
     if (col == kWorldRangesColumn) {
-        writeWorldRanges(tbl, final_in_b ? site.keysB : site.keysA, n_out,
+        writeWorldRanges(tbl, final_in_b ? site.keysB : site.keysA, row_end,
                          S->numWorlds, tid, stride);
         return;
     }
@@ -744,8 +761,8 @@ __device__ inline void gatherColumn(EcsState *S, const SortSite &site,
         // Entity column: 8-byte handles; update the entity store's row
         const Entity *esrc = (const Entity *)src;
         Entity *edst = (Entity *)dst;
-        for (int32_t i = tid; i < n_out; i += stride) {
-            Entity e = esrc[perm[i]];
+        for (int32_t i = row_begin + tid; i < row_end; i += stride) {
+            Entity e = esrc[perm[i - row_begin]];
             edst[i] = e;
             if (e.id >= 0) {
                 S->entities[e.id].loc.row = i;
@@ -758,34 +775,36 @@ __device__ inline void gatherColumn(EcsState *S, const SortSite &site,
         // the sorted keys ARE the new WorldID column: contiguous copy
         const uint32_t *sorted = final_in_b ? site.keysB : site.keysA;
         int32_t *wdst = (int32_t *)dst;
-        for (int32_t i = tid; i < n_out; i += stride) {
+        for (int32_t i = row_begin + tid; i < row_end; i += stride) {
             wdst[i] = (int32_t)sorted[i];
         }
         return;
     }
 
+    const size_t row_bytes = tbl.columnBytes[col];
+    char *dst_rows = (char *)dst + (size_t)row_begin * row_bytes;
     if (gc.rowDwords != 0u) {
-        gatherRowsWide((const uint32_t *)src, (uint32_t *)dst, perm, n_out,
+        gatherRowsWide((const uint32_t *)src, (uint32_t *)dst_rows, perm, n_rows,
                        gc.rowDwords, gc.invMagicDwords, tid, stride);
         return;
     }
 
     switch (gc.wordBytes) {
     case 16:
-        gatherWords<Word16>((const Word16 *)src, (Word16 *)dst, perm, n_out,
+        gatherWords<Word16>((const Word16 *)src, (Word16 *)dst_rows, perm, n_rows,
                             gc.wordsPerRow, gc.invMagic, tid, stride);
         break;
     case 8:
-        gatherWords<Word8>((const Word8 *)src, (Word8 *)dst, perm, n_out,
+        gatherWords<Word8>((const Word8 *)src, (Word8 *)dst_rows, perm, n_rows,
                            gc.wordsPerRow, gc.invMagic, tid, stride);
         break;
     case 4:
-        gatherWords<uint32_t>((const uint32_t *)src, (uint32_t *)dst, perm,
-                              n_out, gc.wordsPerRow, gc.invMagic, tid, stride);
+        gatherWords<uint32_t>((const uint32_t *)src, (uint32_t *)dst_rows, perm,
+                              n_rows, gc.wordsPerRow, gc.invMagic, tid, stride);
         break;
     default:
-        gatherWords<uint8_t>((const uint8_t *)src, (uint8_t *)dst, perm,
-                             n_out, gc.wordsPerRow, gc.invMagic, tid, stride);
+        gatherWords<uint8_t>((const uint8_t *)src, (uint8_t *)dst_rows, perm,
+                             n_rows, gc.wordsPerRow, gc.invMagic, tid, stride);
         break;
     }
 }
@@ -1069,7 +1088,7 @@ sortSmall(EcsState *S, const SortSite *sites, const GatherColumn *columns,
             smallWorldRanges(tbl, final_keys, n_out, S->numWorlds, world_rows, range_scan);
             continue;
         }
-        gatherColumn(S, site, gc, tbl, n_out, (int32_t)tid, kSmallThreads);
+        gatherColumn(S, site, gc, tbl, 0, n_out, (int32_t)tid, kSmallThreads);
     }
     __syncthreads();
 

@@ -269,9 +269,12 @@ __device__ inline void hullCentroid(LazyHull &) {}     // (has it already)
 // Profile builds (-DMADRONA_PHYS_PROFILE): cycles and exit counts of the stages
 // of a cooperative hull-hull test, accumulated in the calling kernel's own
 // counters (slots 16.. of prof_acc: registers -- atomics per mark distort the
-// very thing they measure; profiles/tools/phys_phase_cycles.py).
+// very thing they measure; profiles/tools/phys_phase_cycles.py).  Its own
+// switch (-DMADRONA_PHYS_PROFILE_HH on top of -DMADRONA_PHYS_PROFILE): the 16
+// extra accumulators push the kernel into spilling, which inflates the phase
+// figures of the same build; use it for the stage split and exit counts only.
 struct HullHullProf {
-#ifdef MADRONA_PHYS_PROFILE
+#ifdef MADRONA_PHYS_PROFILE_HH
     unsigned long long *acc;
     unsigned long long t;
     __device__ inline void mark(uint32_t, int slot)
@@ -522,6 +525,26 @@ __device__ inline uint32_t constraintLevels(uint32_t lane, uint32_t n,
         bool conflict =
             (ja != 0 && (ja == key_a || ja == key_b)) ||
             (jb != 0 && (jb == key_a || jb == key_b));
+        if (lane > j && lane < n && conflict && jl + 1 > level) {
+            level = jl + 1;
+        }
+    }
+    return level;
+}
+
+// (32-bit keys: body indices inside an LDS-resident world)
+template <int LPW = 64>
+__device__ inline uint32_t constraintLevels(uint32_t lane, uint32_t n,
+                                            uint32_t key_a, uint32_t key_b)
+{
+    uint32_t level = 0;
+    for (uint32_t j = 0; j + 1 < n; j++) {
+        const uint32_t ja = __shfl(key_a, j, LPW);
+        const uint32_t jb = __shfl(key_b, j, LPW);
+        const uint32_t jl = __shfl(level, j, LPW);
+        const bool conflict =
+            (ja != 0u && (ja == key_a || ja == key_b)) ||
+            (jb != 0u && (jb == key_a || jb == key_b));
         if (lane > j && lane < n && conflict && jl + 1 > level) {
             level = jl + 1;
         }
@@ -950,6 +973,7 @@ struct WorldBlock {
     xpbd::PreSolvePositional prePos[MAXB];
     xpbd::PreSolveVelocity preVel[MAXB];
     uint16_t leafRank[MAXB];                // leaf id -> traversal rank
+    uint16_t solverKey[MAXB];               // ldsBodyKey: 0 = inert static body, else k + 1
     WaveCandidate candidates[maxCandidates];
     float lambdas[maxContacts];
 
@@ -1158,11 +1182,17 @@ struct LdsBodyStore {
     }
 };
 
+// Key of body k for the dependency levels of the solver: 0 = a static body the
+// solver cannot change (never orders constraints), else k + 1.  Whether a
+// static body is inert is decided ONCE per step, when the world is loaded
+// (solverKey): an inert one stays inert (the solver's writes to it are no-ops),
+// and one that is not is treated as dynamic for the whole step -- conservative,
+// so still the sequential result -- instead of normalising its rotation again
+// for every contact of every solve (round 3: twice per contact and substep).
 template <int MAXB, int LPW>
-__device__ inline uint64_t ldsBodyKey(const WorldBlock<MAXB, LPW> *w, int32_t k)
+__device__ inline uint32_t ldsBodyKey(const WorldBlock<MAXB, LPW> *w, int32_t k)
 {
-    return (w->resp[k] == (uint32_t)ResponseType::Static &&
-            staticBodyIsInert(w->rot[k])) ? 0ull : (uint64_t)(k + 1);
+    return (uint32_t)w->solverKey[k];
 }
 
 template <int MAXB, int LPW>
@@ -1398,8 +1428,12 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
     unsigned long long prof_acc[32] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
                                         0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     // stages of the cooperative hull-hull tests: slots 16.. (HullHullProf)
+#ifdef MADRONA_PHYS_PROFILE_HH
 #define PHYS_HH_PROF() HullHullProf { prof_acc, \
         (unsigned long long)__builtin_readcyclecounter() }
+#else
+#define PHYS_HH_PROF() HullHullProf {}
+#endif
 #else
 #define PHYS_HH_PROF() HullHullProf {}
 #endif
@@ -1423,19 +1457,63 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
     const bool fold_pairs = LPW == 32 && (params.foldPairs & 1) != 0 &&
         world_order != nullptr;
     const int32_t num_jobs = (num_worlds + worlds_per_wave - 1) / worlds_per_wave;
-    for (int32_t job = (int32_t)blockIdx.x; job < num_jobs;
-         job += (int32_t)gridDim.x) {
+
+    // Jobs (a world, or a pair of them) in that order.  With a job counter
+    // (params.jobCounter, zeroed by physicsOrderKernel) the launch is as many
+    // PERSISTENT wavefronts as the chip holds, each taking the next job from
+    // the counter when it is done -- the same heaviest-first greedy schedule
+    // the hardware's workgroup dispatcher gives a grid of one workgroup per
+    // job, minus a dispatch per job, and with the chance to look ahead: a
+    // wavefront knows its NEXT job while it still works on the current one, and
+    // fetches that world's header (its place in the order, its row ranges in
+    // the rigid-body tables: a chain of three dependent cold misses that
+    // nothing else can hide with one wavefront per SIMD) before it stores the
+    // current world, not after.  (4096 atomics on one address over ~800 us do
+    // not queue; round 2's persistent version strode statically and lost to
+    // the dispatcher's balancing.)
+    struct JobHeader {
+        int32_t world;          // -1: no world for this half of the wavefront
+        bool sorted;
+        WorldBodies bodies;
+    };
+    auto fetchHeader = [&](int32_t job, JobHeader &h) {
         int32_t slot = job * worlds_per_wave + group;
         if (fold_pairs) {
             slot = group == 0 ? job : num_worlds - 1 - job;
             if (group != 0 && slot == job) {
-                continue;       // (odd world count: the middle one is alone)
+                slot = num_worlds;  // (odd world count: the middle one is alone)
             }
         }
-        if (slot >= num_worlds) {
+        h.world = -1;
+        h.sorted = true;
+        if (job < num_jobs && slot < num_worlds) {
+            h.world = world_order != nullptr ? world_order[slot] : slot;
+            h.sorted = h.bodies.fill(S, ps, h.world);
+        }
+    };
+    int32_t *job_counter = params.jobCounter;
+    auto takeJob = [&]() {
+        int32_t taken = 0;
+        if (wave::laneID() == 0u) {
+            taken = __hip_atomic_fetch_add(job_counter, 1, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return __shfl(taken, 0, 64);
+    };
+
+    int32_t job = job_counter != nullptr ? takeJob() : (int32_t)blockIdx.x;
+    JobHeader cur_job;
+    fetchHeader(job, cur_job);
+    while (job < num_jobs) {
+        const int32_t next_job = job_counter != nullptr ? takeJob() :
+            job + (int32_t)gridDim.x;
+        JobHeader next_header;
+        bool have_next = false;
+    do {
+        if (cur_job.world < 0) {
             continue;
         }
-        const int32_t world = world_order != nullptr ? world_order[slot] : slot;
+        const int32_t world = cur_job.world;
         const long long cost_t0 = (long long)wall_clock64();
         uint32_t cost_work = 1;    // (what the world asked of the wavefront, roughly)
         Context ctx = TaskGraph::makeContext<Context>(
@@ -1444,8 +1522,8 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
         const broadphase::BVH &bvh = ctx.singleton<broadphase::BVH>();
 
         // ---- the world's bodies ---------------------------------------------
-        WorldBodies bodies;
-        const bool unsorted = !bodies.fill(S, ps, world);
+        const WorldBodies &bodies = cur_job.bodies;
+        const bool unsorted = !cur_job.sorted;
         const int32_t num_bodies = bodies.count();
         if (unsorted || num_bodies > MAXB || bvh.numLeaves() != num_bodies) {
             mwhip::raiseError(S, mwhip::kErrPhysics);
@@ -1489,6 +1567,9 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
         for (int32_t k = (int32_t)lane; k < num_bodies; k += LPW) {
             uint32_t end = (uint32_t)w->primOffset[k] + w->primCount[k];
             prim_end = end > prim_end ? end : prim_end;
+            w->solverKey[k] =
+                (w->resp[k] == (uint32_t)ResponseType::Static &&
+                 staticBodyIsInert(w->rot[k])) ? (uint16_t)0 : (uint16_t)(k + 1);
         }
         prim_end = wave::maxReduce<LPW>(prim_end);
         const ObjectManager obj_mgr =
@@ -1868,17 +1949,25 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
             PHYS_PROF(5);
 
             // ---- position solve: contacts, then joints, level by level ----------
+            // (the levels of the first window of contacts -- all of them, in
+            // every world seen so far -- serve the velocity solve as well: same
+            // contacts, same bodies)
+            uint32_t first_level = 0, first_max_level = 0;
             for (uint32_t base = 0; base < num_contacts; base += LPW) {
                 const uint32_t n = num_contacts - base < (uint32_t)LPW ?
                     num_contacts - base : (uint32_t)LPW;
                 const uint32_t i = base + lane;
-                uint64_t key_a = 0, key_b = 0;
+                uint32_t key_a = 0, key_b = 0;
                 if (lane < n) {
                     key_a = ldsBodyKey(w, w->contacts()[i].ref.row);
                     key_b = ldsBodyKey(w, w->contacts()[i].alt.row);
                 }
                 uint32_t level = constraintLevels<LPW>(lane, n, key_a, key_b);
                 uint32_t max_level = wave::maxReduce<LPW>(lane < n ? level : 0);
+                if (base == 0) {
+                    first_level = level;
+                    first_max_level = max_level;
+                }
 
                 for (uint32_t l = 0; l <= max_level; l++) {
                     if (lane < n && level == l) {
@@ -1895,7 +1984,7 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                     (uint32_t)(num_joints - base) : (uint32_t)LPW;
                 const int32_t i = base + (int32_t)lane;
                 Loc l1 { 0, 0 }, l2 { 0, 0 };
-                uint64_t key_a = 0, key_b = 0;
+                uint32_t key_a = 0, key_b = 0;
                 if (lane < n) {
                     if (joints_staged) {
                         l1 = Loc { 0, (int32_t)w->jointBodies[i][0] };
@@ -1932,13 +2021,17 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                 const uint32_t n = num_contacts - base < (uint32_t)LPW ?
                     num_contacts - base : (uint32_t)LPW;
                 const uint32_t i = base + lane;
-                uint64_t key_a = 0, key_b = 0;
-                if (lane < n) {
-                    key_a = ldsBodyKey(w, w->contacts()[i].ref.row);
-                    key_b = ldsBodyKey(w, w->contacts()[i].alt.row);
+                uint32_t level = first_level;
+                uint32_t max_level = first_max_level;
+                if (base != 0) {
+                    uint32_t key_a = 0, key_b = 0;
+                    if (lane < n) {
+                        key_a = ldsBodyKey(w, w->contacts()[i].ref.row);
+                        key_b = ldsBodyKey(w, w->contacts()[i].alt.row);
+                    }
+                    level = constraintLevels<LPW>(lane, n, key_a, key_b);
+                    max_level = wave::maxReduce<LPW>(lane < n ? level : 0);
                 }
-                uint32_t level = constraintLevels<LPW>(lane, n, key_a, key_b);
-                uint32_t max_level = wave::maxReduce<LPW>(lane < n ? level : 0);
 
                 for (uint32_t l = 0; l <= max_level; l++) {
                     if (lane < n && level == l) {
@@ -1950,9 +2043,13 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                     wave::phaseFence();
                 }
             }
+            PHYS_PROF(11);
         }
 
         PHYS_PROF(6);
+        // (the next job's header: on its way while this world is stored)
+        fetchHeader(next_job, next_header);
+        have_next = true;
         // ---- store: LDS -> HBM --------------------------------------------------
         for (int32_t k = (int32_t)lane; k < num_bodies; k += LPW) {
             // (out of the block first, then the stores: see loadWorldBodies)
@@ -2003,6 +2100,13 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                 params.worldCost[world] = cost;
             }
         }
+    } while (false);
+        // (a half that left its world early fetches its next header here)
+        if (!have_next) {
+            fetchHeader(next_job, next_header);
+        }
+        cur_job = next_header;
+        job = next_job;
     }
 
 #ifdef MADRONA_PHYS_PROFILE
@@ -2026,6 +2130,9 @@ physicsOrderKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
     const PhysicsStepParams params = *(const PhysicsStepParams *)node_data;
     const int32_t num_worlds = S->numWorlds;
     const uint32_t tid = threadIdx.x;
+    if (tid == 0 && params.jobCounter != nullptr) {
+        *params.jobCounter = 0;     // (the step kernel's persistent wavefronts)
+    }
 
     __shared__ uint32_t hist[256];
     __shared__ uint32_t wave_max[16];

@@ -82,6 +82,9 @@ struct PhysicsStepParams {
     // (physicsOrderKernel); nullptr: worlds are stepped in index order
     uint32_t *worldCost;
     int32_t *worldOrder;
+    // LDS step kernels: persistent wavefronts take jobs (a world / a pair of
+    // worlds, in worldOrder) from this counter; nullptr: one workgroup per job
+    int32_t *jobCounter;
 };
 
 namespace detail {
@@ -2167,11 +2170,31 @@ MADRONA_HOST_API inline TaskGraphNodeID setupPhysicsStepTasks(
     // step -- atomic min / max on ancestor boxes) in the step kernel's epilogue:
     // the wavefront still holds every pose of its world.  MADRONA_MWHIP_PHYS_REFIT=0
     // keeps the separate node (measurements).
+    const char *refit_env = getenv("MADRONA_MWHIP_PHYS_REFIT");
     const int32_t refit_in_step = max_bodies != 0 &&
-        phys::detail::capacityHint("MADRONA_MWHIP_PHYS_REFIT", 1) != 0 ? 2 : 0;
+        (refit_env == nullptr || atoi(refit_env) != 0) ? 2 : 0;
+    // MADRONA_MWHIP_PHYS_PERSIST=1: persistent wavefronts + look-ahead
+    // (physicsStepLdsKernel): as many workgroups as the chip holds of this
+    // kernel (its LDS block: four per CU), jobs from a counter the order kernel
+    // zeroes.  Built for the round-3 verdict and measured: no gain over one
+    // workgroup per job dispatched by the hardware (Escape Room 838 -> 841 us,
+    // Hide-and-Seek 946 -> 947 us, profiles/r04_phys_variants.jsonl) -- the
+    // dispatcher already hands the next job to a free slot within a
+    // microsecond, and the header look-ahead only has the few microseconds of
+    // the store phase to hide in.  Off by default.
+    int32_t *job_counter = nullptr;
+    const char *persist_env = getenv("MADRONA_MWHIP_PHYS_PERSIST");
+    if (world_order != nullptr && persist_env != nullptr &&
+            atoi(persist_env) != 0) {
+        job_counter = (int32_t *)mwhip_alloc_device(exec, 256, 1);
+        if (job_counter == nullptr) {
+            FATAL("madrona_amd physics: job counter allocation failed: %s",
+                  mwhip_last_error());
+        }
+    }
     auto params = builder.constructNodeData<PhysicsStepParams>(
         PhysicsStepParams { (int32_t)num_substeps, fold_pairs | refit_in_step,
-                            world_images, world_cost, world_order });
+                            world_images, world_cost, world_order, job_counter });
 
     if (world_order != nullptr) {
         mwhip_node_desc order {};
@@ -2205,6 +2228,18 @@ MADRONA_HOST_API inline TaskGraphNodeID setupPhysicsStepTasks(
         // one wavefront per PAIR of worlds
         desc.count_mode = MWHIP_COUNT_FIXED;
         desc.fixed_count = (mwhip_num_worlds(exec) + 1u) / 2u;
+    }
+    if (job_counter != nullptr) {
+        // persistent: what the chip holds at once (the LDS block admits four
+        // single-wave workgroups per CU with 32- / 64-body blocks, fewer
+        // above), times a small factor so that a slot the estimate missed does
+        // not stay empty -- surplus workgroups find the counter exhausted
+        const uint32_t jobs = lanes_per_world == 32 ?
+            (mwhip_num_worlds(exec) + 1u) / 2u : mwhip_num_worlds(exec);
+        const uint32_t resident = mwhip_device_cus(exec) *
+            (max_bodies <= 32 ? 4u : max_bodies <= 64 ? 4u : 2u);
+        desc.count_mode = MWHIP_COUNT_FIXED;
+        desc.fixed_count = jobs < resident ? jobs : resident;
     }
     desc.arg0 = max_bodies != 0 ? 1u : 0u;
     cur_node = builder.addRuntimeNode(desc, params.id, {cur_node});

@@ -34,7 +34,7 @@ with Simulator(hip_lib_path('escape_room_phys'), W, seed=5, flags=200) as hip:
     hh, events, out = out[16:], out[12:16], out[:12]
     # (slot 2 also collects the velocity solve of the substep before it, slot 6
     # only that of the last substep: see the PHYS_PROF marks in world_step.inl)
-    names = ['np.setup', 'candidates', 'integrate (+ solveVel of substeps 1-3)', 'np.solo', 'solvePos+jnt+setVel', 'np.hull+compact', 'solveVel (last substep)', 'joints / store', 'load bodies (rows -> block)', 'stage prims', 'world lookup (singletons, row ranges)', '(unused)']
+    names = ['np.setup', 'candidates', 'integrate', 'np.solo', 'solvePos+jnt+setVel', 'np.hull+compact', '(end of substeps)', 'joints / store (+ refit)', 'load bodies (rows -> block)', 'stage prims', 'world lookup (singletons, row ranges)', 'solveVel']
     tot = out.sum()
     for n, v in zip(names, out):
         print(f'{n:42s} {v / N / W:10.0f} ticks/world/step  {100 * v / tot:5.1f}%')
