@@ -1612,21 +1612,44 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                 for (int m = 0; m < mask_words; m++) {
                     const int32_t r_end = num_bodies - m * 64 < 64 ?
                         num_bodies - m * 64 : 64;
-                    for (int32_t j = 0; j < r_end; j++) {
-                        const int32_t r = m * 64 + j;
-                        bool hit = query.overlaps(w->rankSlotBox()[r]) &&
-                            my_id < w->rankEntity()[r];
-                        if (hit) {
-                            const int32_t kb = w->orderBody[r];
-                            if (my_static && w->resp[kb] ==
-                                    (uint32_t)ResponseType::Static) {
-                                hit = false;
-                            } else {
-                                n += a_prims * w->primCount[kb];
-                            }
+                    // the box tests first, branch-free and four at a time (the
+                    // boxes are broadcast reads: every lane of the world asks
+                    // for the same one; four in flight instead of one) ...
+                    uint64_t raw = 0;
+                    int32_t j = 0;
+                    for (; j + 4 <= r_end; j += 4) {
+#pragma unroll
+                        for (int32_t u = 0; u < 4; u++) {
+                            const int32_t r = m * 64 + j + u;
+                            const math::AABB slot = w->rankSlotBox()[r];
+                            const int32_t other_id = w->rankEntity()[r];
+                            const bool hit =
+                                (int)query.overlaps(slot) & (int)(my_id < other_id);
+                            raw |= (uint64_t)hit << (j + u);
                         }
-                        hits[m] |= (uint64_t)hit << j;
                     }
+                    for (; j < r_end; j++) {
+                        const int32_t r = m * 64 + j;
+                        const math::AABB slot = w->rankSlotBox()[r];
+                        const bool hit = (int)query.overlaps(slot) &
+                            (int)(my_id < w->rankEntity()[r]);
+                        raw |= (uint64_t)hit << j;
+                    }
+                    // ... then the few that passed: static pairs out, the rest
+                    // counted by primitive pairs
+                    uint64_t pending = raw;
+                    while (pending != 0) {
+                        const int32_t jj = (int32_t)__builtin_ctzll(pending);
+                        pending &= pending - 1;
+                        const int32_t kb = w->orderBody[m * 64 + jj];
+                        if (my_static && w->resp[kb] ==
+                                (uint32_t)ResponseType::Static) {
+                            raw &= ~(1ull << jj);
+                        } else {
+                            n += a_prims * w->primCount[kb];
+                        }
+                    }
+                    hits[m] = raw;
                 }
             }
 

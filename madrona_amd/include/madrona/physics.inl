@@ -2165,14 +2165,19 @@ MADRONA_HOST_API inline TaskGraphNodeID setupPhysicsStepTasks(
     // (profiles/r04_phys_variants.jsonl), see physicsStepLdsKernel.
     const int32_t fold_pairs = lanes_per_world == 32 && world_order != nullptr &&
         order_env != nullptr && atoi(order_env) >= 2 ? 1 : 0;
-    // The leaf update + refit that follows the step (setupPostIntegrationTasks:
-    // a ParallelFor over all bodies, ~25 us and the largest traffic ratio of the
-    // step -- atomic min / max on ancestor boxes) in the step kernel's epilogue:
-    // the wavefront still holds every pose of its world.  MADRONA_MWHIP_PHYS_REFIT=0
-    // keeps the separate node (measurements).
+    // MADRONA_MWHIP_PHYS_REFIT=1: the leaf update + refit that follows the step
+    // (setupPostIntegrationTasks: a ParallelFor over all bodies, ~27 us) runs in
+    // the step kernel's epilogue instead -- the wavefront still holds every pose
+    // of its world.  Built for the round-3 verdict and measured
+    // (profiles/r04_phys_variants.jsonl): one launch less, but the epilogue walks
+    // leaf -> parent -> slot with atomics from ONE wavefront per SIMD, 25 K cycles
+    // per world-step in the phase profile: the step kernel grows by 33 us for
+    // the 27 us node it saves (Escape Room 1.2522 -> 1.2549 ms per step,
+    // Hide-and-Seek 1.5069 -> 1.5158).  Off by default; what would make it pay
+    // is refitting a copy of the world's nodes in LDS without atomics.
     const char *refit_env = getenv("MADRONA_MWHIP_PHYS_REFIT");
-    const int32_t refit_in_step = max_bodies != 0 &&
-        (refit_env == nullptr || atoi(refit_env) != 0) ? 2 : 0;
+    const int32_t refit_in_step = max_bodies != 0 && refit_env != nullptr &&
+        atoi(refit_env) != 0 ? 2 : 0;
     // MADRONA_MWHIP_PHYS_PERSIST=1: persistent wavefronts + look-ahead
     // (physicsStepLdsKernel): as many workgroups as the chip holds of this
     // kernel (its LDS block: four per CU), jobs from a counter the order kernel
