@@ -1238,12 +1238,24 @@ static int uploadRenderGeometry(mwhip_exec *exec)
                     (const void **)&d.triangleUV);
         if (rc != 0) return rc;
     }
-    if (!g.triangleMaterial.empty()) {
+    // (only what the shading can reach is uploaded -- the ray cast kernel is
+    // compiled without the per-hit material / texture lookup when neither
+    // pointer is set: per-triangle materials are consulted for objects without
+    // a material of their own, textures through a material that has one)
+    bool some_object_without_material = false;
+    for (int32_t m : g.objectMaterial) {
+        some_object_without_material = some_object_without_material || m < 0;
+    }
+    bool some_textured_material = false;
+    for (int32_t t : g.materialTexture) {
+        some_textured_material = some_textured_material || t >= 0;
+    }
+    if (!g.triangleMaterial.empty() && some_object_without_material) {
         rc = upload(g.triangleMaterial.data(), g.triangleMaterial.size() * 4,
                     (const void **)&d.triangleMaterial);
         if (rc != 0) return rc;
     }
-    if (!g.materialTexture.empty()) {
+    if (!g.materialTexture.empty() && some_textured_material) {
         rc = upload(g.materialTexture.data(), g.materialTexture.size() * 4,
                     (const void **)&d.materialTexture);
         if (rc != 0) return rc;

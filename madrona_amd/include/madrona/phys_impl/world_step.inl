@@ -2119,7 +2119,20 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                 const uint32_t most = cost_work > other ? cost_work : other;
                 cost = (uint32_t)(((uint64_t)cost * cost_work) / most);
             }
+            if ((params.foldPairs & 64) != 0) {
+                // (measurement: order by the work proxy alone, not by time)
+                cost = cost_work * 16u;
+            }
             if (lane == 0) {
+                // (bits 4-5 of foldPairs: blend with what the world cost before,
+                // new = old + (measured - old) >> shift; 0 = last step's value)
+                const uint32_t shift = ((uint32_t)params.foldPairs >> 4) & 3u;
+                if (shift != 0u) {
+                    const uint32_t old = params.worldCost[world];
+                    cost = old == 0u ? cost :
+                        (uint32_t)((int32_t)old + (((int32_t)cost - (int32_t)old) >>
+                                                   (int32_t)shift));
+                }
                 params.worldCost[world] = cost;
             }
         }

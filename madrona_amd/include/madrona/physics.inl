@@ -2198,7 +2198,9 @@ MADRONA_HOST_API inline TaskGraphNodeID setupPhysicsStepTasks(
         }
     }
     auto params = builder.constructNodeData<PhysicsStepParams>(
-        PhysicsStepParams { (int32_t)num_substeps, fold_pairs | refit_in_step,
+        PhysicsStepParams { (int32_t)num_substeps, fold_pairs | refit_in_step |
+                                (int32_t)((phys::detail::capacityHint(
+                                    "MADRONA_MWHIP_PHYS_COST_BLEND", 0) & 7) << 4),
                             world_images, world_cost, world_order, job_counter });
 
     if (world_order != nullptr) {
