@@ -518,6 +518,12 @@ struct TaskGraphRec {
 };
 
 struct LaunchGraph {
+    // device memory that belongs to THIS graph (sort batches' site / column /
+    // slice tables, scan state, row-snapshot granules ...): released when the
+    // graph is rebuilt or freed, not at mwhip_destroy (every rebuild
+    // -- growth, a table outgrowing the one-launch sort, set_input_ring -- used
+    // to leave the previous graph's buffers allocated)
+    std::vector<void *> ownedAllocations;
     std::vector<KernelLaunch> launches;
     std::vector<std::unique_ptr<SortBatch>> sortBatches;
     hipGraph_t graph = nullptr;
@@ -560,6 +566,9 @@ struct mwhip_exec {
 
     std::vector<TaskGraphRec> taskGraphs;
     std::unordered_map<uint64_t, std::unique_ptr<LaunchGraph>> launchGraphs;
+    // where devAlloc records what it hands out: the graph being built, or
+    // (nullptr) the executor's own list, freed at mwhip_destroy
+    std::vector<void *> *allocScope = nullptr;
     uint64_t nextGraphHandle = 1;
 
     // mwGPU::HostPrint: ring in pinned host memory + the thread that drains it
@@ -637,7 +646,7 @@ static int devAlloc(mwhip_exec *exec, void **out, size_t bytes, bool zero = true
     bytes = (bytes + 255) & ~(size_t)255;
     if (bytes == 0) bytes = 256;
     HIPCHK(hipMalloc(out, bytes));
-    exec->allocations.push_back(*out);
+    (exec->allocScope != nullptr ? *exec->allocScope : exec->allocations).push_back(*out);
     if (zero) {
         HIPCHK(hipMemset(*out, 0, bytes));
     }
@@ -1688,6 +1697,12 @@ static int launchOne(mwhip_exec *exec, KernelLaunch &k, hipStream_t stream)
 static int ensureSortScratch(mwhip_exec *exec, ArchetypeRec &arch)
 {
     if (arch.sortState != nullptr) return 0;
+    // (shared by every graph that sorts this table: not the building graph's)
+    struct ScopeOff {
+        mwhip_exec *e; std::vector<void *> *saved;
+        explicit ScopeOff(mwhip_exec *x) : e(x), saved(x->allocScope) { x->allocScope = nullptr; }
+        ~ScopeOff() { e->allocScope = saved; }
+    } scope_off(exec);
 
     int rc = devAllocT(exec, &arch.sortState, 1);
     if (rc != 0) return rc;
@@ -1896,6 +1911,34 @@ static int makeSortBatch(mwhip_exec *exec,
             target = (uint32_t)std::min(std::max(total / 32768.0, 2048.0), 8192.0);
         }
         std::vector<GatherSlice> slices;
+        // big batches: row tiles -- a workgroup per 1024 rows of a site moves
+        // them in every column, the permutation staged once in LDS
+        // (MADRONA_MWHIP_GATHER_BLOCKED: 0 strided over each column, 1 a
+        // contiguous run of rows per column slice, 2 row tiles; default by size)
+        const uint32_t blocked_env = envU32("MADRONA_MWHIP_GATHER_BLOCKED", 3);
+        const uint32_t blocked_mode = blocked_env != 3 ? blocked_env :
+            (total >= kGatherBlockedBytes ? 2u : 0u);
+        if (blocked_mode == 2) {
+            for (size_t c = 0; c < cols.size(); c++) {
+                const SortSiteHost &site = out->sites[cols[c].site];
+                const ArchetypeRec &arch = exec->archetypes[site.archetype];
+                if (cols[c].column == kWorldRangesColumn) {
+                    const uint32_t n = std::max<uint32_t>(
+                        (uint32_t)(64.0 * exec->cfg.num_worlds / 4096.0), 1u);
+                    for (uint32_t i = 0; i < n; i++) {
+                        slices.push_back(GatherSlice { (uint32_t)c, i, n, 0u });
+                    }
+                } else if (cols[c].column == 0) {
+                    // (the site's real columns follow each other in the list)
+                    const uint32_t tiles = std::max<uint32_t>(
+                        (arch.capacity + sortGatherTileRows() - 1) /
+                            sortGatherTileRows(), 1u);
+                    for (uint32_t i = 0; i < tiles; i++) {
+                        slices.push_back(GatherSlice { (uint32_t)c, i, tiles, 2u });
+                    }
+                }
+            }
+        } else
         for (size_t c = 0; c < cols.size(); c++) {
             uint32_t n = (uint32_t)(target * weight[c] / std::max(total, 1.0) + 0.5);
             // at least 4 KB of work per workgroup, at least one workgroup
@@ -1904,9 +1947,7 @@ static int makeSortBatch(mwhip_exec *exec,
             // big tables: a contiguous run of rows per workgroup
             // (MADRONA_MWHIP_GATHER_BLOCKED=0/1 forces; measured in
             // profiles/r04_sort_variants.jsonl)
-            const uint32_t blocked_env = envU32("MADRONA_MWHIP_GATHER_BLOCKED", 2);
-            const uint32_t blocked = blocked_env != 2 ? blocked_env :
-                (total >= kGatherBlockedBytes ? 1u : 0u);
+            const uint32_t blocked = blocked_mode == 1 ? 1u : 0u;
             for (uint32_t i = 0; i < n; i++) {
                 slices.push_back(GatherSlice { (uint32_t)c, i, n, blocked });
             }
@@ -2701,6 +2742,8 @@ static int loadExecConfigFile(mwhip_exec *exec)
 // ---------------------------------------------------------------------------
 // create / destroy
 // ---------------------------------------------------------------------------
+static void releaseLaunchGraph(LaunchGraph &lg);
+
 extern "C" int mwhip_create(const mwhip_state_config *cfg,
                             const mwhip_user_entry *entry, mwhip_exec **out)
 {
@@ -2830,8 +2873,7 @@ extern "C" void mwhip_destroy(mwhip_exec *exec)
     writeDeviceTrace(exec);
 #endif
     for (auto &kv : exec->launchGraphs) {
-        if (kv.second->graphExec) (void)hipGraphExecDestroy(kv.second->graphExec);
-        if (kv.second->graph) (void)hipGraphDestroy(kv.second->graph);
+        releaseLaunchGraph(*kv.second);
     }
     for (void *p : exec->allocations) {
         (void)hipFree(p);
@@ -3014,7 +3056,14 @@ static int renderLaunches(mwhip_exec *exec, std::vector<KernelLaunch> &out)
 
     if (exec->tlasNodes == nullptr) {
         // one node slot per instance row the table can ever hold (a world of n
-        // instances uses n - 1 of its n slots)
+        // instances uses n - 1 of its n slots).  (The executor's, not the
+        // building graph's: every later render graph reuses them.)
+        std::vector<void *> *const saved_scope = exec->allocScope;
+        exec->allocScope = nullptr;
+        struct Restore {
+            mwhip_exec *e; std::vector<void *> *s;
+            ~Restore() { e->allocScope = s; }
+        } restore { exec, saved_scope };
         rc = devAllocT(exec, &exec->tlasNodes, inst.reservedCapacity, false);
         if (rc != 0) return rc;
         rc = devAllocT(exec, &exec->preparedInstances, inst.reservedCapacity,
@@ -3100,6 +3149,20 @@ static int addTraceMarkers(mwhip_exec *exec, LaunchGraph &lg)
 }
 #endif
 
+// the graph objects and the device memory the graph owns (the stream has been
+// waited for, or nothing of this graph is in flight)
+static void releaseLaunchGraph(LaunchGraph &lg)
+{
+    if (lg.graphExec) (void)hipGraphExecDestroy(lg.graphExec);
+    if (lg.graph) (void)hipGraphDestroy(lg.graph);
+    lg.graphExec = nullptr;
+    lg.graph = nullptr;
+    for (void *p : lg.ownedAllocations) {
+        (void)hipFree(p);
+    }
+    lg.ownedAllocations.clear();
+}
+
 static int instantiateLaunchGraph(mwhip_exec *exec,
                                   const std::vector<uint32_t> &ids,
                                   const std::string &stat_name,
@@ -3109,6 +3172,11 @@ static int instantiateLaunchGraph(mwhip_exec *exec,
     std::unique_ptr<LaunchGraph> lg(new LaunchGraph {});
     lg->statName = stat_name;
     lg->taskGraphIds = ids;
+    struct ScopeOn {
+        mwhip_exec *e;
+        ScopeOn(mwhip_exec *x, std::vector<void *> *v) : e(x) { x->allocScope = v; }
+        ~ScopeOn() { e->allocScope = nullptr; }
+    } scope_on(exec, &lg->ownedAllocations);
 
     if (envU32("MADRONA_MWHIP_GRIDS_FROM_ROWS", 1) != 0) {
         HIPCHK(hipStreamSynchronize(exec->stream));
@@ -3360,8 +3428,7 @@ static int growTables(mwhip_exec *exec, RowsFn &&rows_of)
                                         kv.second->statName, fresh,
                                         kv.second.get());
         if (rc != 0) return rc;
-        if (kv.second->graphExec) (void)hipGraphExecDestroy(kv.second->graphExec);
-        if (kv.second->graph) (void)hipGraphDestroy(kv.second->graph);
+        releaseLaunchGraph(*kv.second);
         kv.second = std::move(fresh);
     }
     return 0;
@@ -3439,8 +3506,7 @@ static int sortsOutgrown(mwhip_exec *exec)
                                         kv.second->statName, fresh,
                                         kv.second.get());
         if (rc != 0) return rc;
-        if (kv.second->graphExec) (void)hipGraphExecDestroy(kv.second->graphExec);
-        if (kv.second->graph) (void)hipGraphDestroy(kv.second->graph);
+        releaseLaunchGraph(*kv.second);
         kv.second = std::move(fresh);
     }
     return 0;
@@ -3539,8 +3605,7 @@ extern "C" void mwhip_free_launch_graph(mwhip_exec *exec, uint64_t graph)
     auto it = exec->launchGraphs.find(graph);
     if (it == exec->launchGraphs.end()) return;
     (void)hipStreamSynchronize(exec->stream);
-    if (it->second->graphExec) (void)hipGraphExecDestroy(it->second->graphExec);
-    if (it->second->graph) (void)hipGraphDestroy(it->second->graph);
+    releaseLaunchGraph(*it->second);
     exec->launchGraphs.erase(it);
 }
 
@@ -3794,8 +3859,7 @@ static int rebuildAllLaunchGraphs(mwhip_exec *exec)
                                         kv.second->statName, fresh,
                                         kv.second.get());
         if (rc != 0) return rc;
-        if (kv.second->graphExec) (void)hipGraphExecDestroy(kv.second->graphExec);
-        if (kv.second->graph) (void)hipGraphDestroy(kv.second->graph);
+        releaseLaunchGraph(*kv.second);
         kv.second = std::move(fresh);
     }
     return 0;

@@ -228,6 +228,7 @@ struct KernelLaunch {
 
 int sortNumPasses(bool world_sort, uint32_t num_worlds);
 uint32_t sortTileSize();
+uint32_t sortGatherTileRows();
 uint32_t sortSmallRowLimit();
 uint32_t sortSmallBusyRows();
 uint32_t sortCompactTailLimit();

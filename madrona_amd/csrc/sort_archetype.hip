@@ -75,6 +75,7 @@ constexpr int kSortThreads = 256;
 constexpr int kSortWaves = kSortThreads / 64;
 constexpr int kSortItems = 8;
 constexpr int kSortTile = kSortThreads * kSortItems;   // 2048 keys
+constexpr int kGatherTileRows = 1024;   // rows per workgroup of the row-tile gather
 constexpr int kRadixBits = 8;
 constexpr int kRadixDigits = 1 << kRadixBits;
 
@@ -680,7 +681,8 @@ __device__ inline int32_t compactNumTiles(int32_t prefix);
 __device__ inline void gatherColumn(EcsState *S, const SortSite &site,
                                     const GatherColumn &gc, TableHdr &tbl,
                                     int32_t row_begin, int32_t row_end,
-                                    int32_t tid, int32_t stride);
+                                    int32_t tid, int32_t stride,
+                                    const int32_t *perm_rows = nullptr);
 
 __global__ void __launch_bounds__(kSortThreads)
 sortGather(EcsState *S, const SortSite *sites, const GatherColumn *columns,
@@ -703,7 +705,33 @@ sortGather(EcsState *S, const SortSite *sites, const GatherColumn *columns,
     }
     const int32_t n_out = state->rowsOut;
 
-    if (slice.blocked != 0u && gc.column != kWorldRangesColumn) {
+    if (slice.blocked == 2u) {
+        // Row tiles (big tables): this workgroup moves rows [row_begin, row_end)
+        // of EVERY column of the site.  The permutation entries of the tile are
+        // read once into LDS instead of once per column (a 196-byte row has 17
+        // columns: 68 bytes of index reads for 196 of payload), and the
+        // workgroup stays inside one stretch of every buffer.
+        __shared__ int32_t perm_tile[kGatherTileRows];
+        const int32_t row_begin = (int32_t)slice.slice * kGatherTileRows;
+        const int32_t row_end = row_begin + kGatherTileRows < n_out ?
+            row_begin + kGatherTileRows : n_out;
+        if (row_begin < row_end) {
+            const bool final_in_b = ((site.numPasses - 1) & 1) != 0;
+            const int32_t *perm = final_in_b ? site.idxB : site.idxA;
+            for (int32_t i = (int32_t)threadIdx.x; i < row_end - row_begin;
+                 i += (int32_t)kSortThreads) {
+                perm_tile[i] = perm[row_begin + i];
+            }
+            __syncthreads();
+            // (slice.column = the site's first real column in the batch's list)
+            const uint32_t num_cols = (uint32_t)tbl.numColumns;
+            for (uint32_t c = 0; c < num_cols; c++) {
+                gatherColumn(S, site, columns[slice.column + c], tbl, row_begin,
+                             row_end, (int32_t)threadIdx.x, (int32_t)kSortThreads,
+                             perm_tile);
+            }
+        }
+    } else if (slice.blocked != 0u && gc.column != kWorldRangesColumn) {
         // a contiguous run of rows per workgroup (big tables: every workgroup
         // stays inside a few pages of every buffer it touches instead of
         // striding over all of them)
@@ -723,6 +751,8 @@ sortGather(EcsState *S, const SortSite *sites, const GatherColumn *columns,
 
     // (the passes are over: their histograms and counters are dead)
     if (gc.column == 0u && slice.slice == 0u) {
+        // (every thread of the workgroup is here: cleanSortState strides)
+        __syncthreads();
         cleanSortState(state);
         // the per-tile landing counters of the compaction chain start every
         // run at zero (whichever way the tail went this time)
@@ -735,13 +765,17 @@ sortGather(EcsState *S, const SortSite *sites, const GatherColumn *columns,
 
 // Rows [row_begin, row_end) of the sorted table.  tid / stride: this thread's
 // index among, and the number of, the threads working on them.
+// perm_rows: the permutation entries of rows [row_begin, row_end) if the caller
+// has them closer than the index buffer (LDS).
 __device__ inline void gatherColumn(EcsState *S, const SortSite &site,
                                     const GatherColumn &gc, TableHdr &tbl,
                                     int32_t row_begin, int32_t row_end,
-                                    int32_t tid, int32_t stride)
+                                    int32_t tid, int32_t stride,
+                                    const int32_t *perm_rows)
 {
     const bool final_in_b = ((site.numPasses - 1) & 1) != 0;
-    const int32_t *perm = (final_in_b ? site.idxB : site.idxA) + row_begin;
+    const int32_t *perm = perm_rows != nullptr ? perm_rows :
+        (final_in_b ? site.idxB : site.idxA) + row_begin;
     const int32_t n_rows = row_end - row_begin;
 
     const uint32_t col = gc.column;
@@ -1857,6 +1891,7 @@ int sortNumPasses(bool world_sort, uint32_t num_worlds)
 }
 
 uint32_t sortTileSize() { return (uint32_t)kSortTile; }
+uint32_t sortGatherTileRows() { return (uint32_t)kGatherTileRows; }
 
 // (MADRONA_MWHIP_SORT_SMALL_ROWS overrides it: measurements)
 uint32_t sortSmallRowLimit()
