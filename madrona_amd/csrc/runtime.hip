@@ -1916,8 +1916,13 @@ static int makeSortBatch(mwhip_exec *exec,
         // (MADRONA_MWHIP_GATHER_BLOCKED: 0 strided over each column, 1 a
         // contiguous run of rows per column slice, 2 row tiles; default by size)
         const uint32_t blocked_env = envU32("MADRONA_MWHIP_GATHER_BLOCKED", 3);
+        // (measured at 65536 / 16384 Escape-Room worlds, same box,
+        // profiles/r04_sort_variants.jsonl: strided 300 / 53 us, contiguous rows
+        // per column slice 252 / 52 us, row tiles 291 / 69 us -- a workgroup that
+        // walks 17 columns one after the other has too little in flight per
+        // column; the default for big batches is mode 1)
         const uint32_t blocked_mode = blocked_env != 3 ? blocked_env :
-            (total >= kGatherBlockedBytes ? 2u : 0u);
+            (total >= kGatherBlockedBytes ? 1u : 0u);
         if (blocked_mode == 2) {
             for (size_t c = 0; c < cols.size(); c++) {
                 const SortSiteHost &site = out->sites[cols[c].site];
