@@ -1293,6 +1293,9 @@ template <int LPW = 64>
 __device__ inline void waveCopyDwords(uint32_t lane, uint32_t *dst,
                                       const uint32_t *src, uint32_t count)
 {
+    // (batching eight loads ahead of the stores -- dst and src are generic
+    // pointers -- was measured: 744 -> 753 us, the counts are a few hundred
+    // dwords and the registers cost more than the L2 round trips)
     for (uint32_t i = lane; i < count; i += LPW) {
         dst[i] = src[i];
     }
@@ -1810,8 +1813,23 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                 world_images + (size_t)world * Block::imageBytes());
             uint4 *dst = (uint4 *)w;
             constexpr uint32_t num_vec = (uint32_t)(Block::imageBytes() / 16);
-            for (uint32_t i = lane; i < num_vec; i += LPW) {
-                dst[i] = src[i];
+            // every load of the image in flight before the first store to the
+            // block (generic pointers on both sides: a store in between orders
+            // the loads, and the copy would be a dozen round trips in a row)
+            constexpr uint32_t per_lane = (num_vec + LPW - 1) / LPW;
+            constexpr uint32_t batch = per_lane < 16u ? per_lane : 16u;
+            for (uint32_t first = 0; first < per_lane; first += batch) {
+                uint4 tmp[batch];
+#pragma unroll
+                for (uint32_t u = 0; u < batch; u++) {
+                    const uint32_t i = (first + u) * LPW + lane;
+                    tmp[u] = i < num_vec ? src[i] : uint4 { 0, 0, 0, 0 };
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < batch; u++) {
+                    const uint32_t i = (first + u) * LPW + lane;
+                    if (i < num_vec) dst[i] = tmp[u];
+                }
             }
         } else {
             // (read before the rows, stored after them: one more load in flight)
