@@ -84,3 +84,34 @@ def test_profile_script_writes_a_config(built, tmp_path, monkeypatch):
     # and the executor takes it
     monkeypatch.setenv("MADRONA_MWHIP_EXEC_CONFIG_FILE", str(out))
     _run(256, 3)
+
+
+def test_declared_read_write_sets_reach_the_profile(built, monkeypatch):
+    """madrona::mwhip::systemIO (SURVEY 8d: "each node declares its read/write
+    set next to the kernel"): a declared system is priced at rows x (4 + reads +
+    writes), flagged io_declared; the numbers are the component sizes of
+    sims/escape_room/sim.hpp."""
+    monkeypatch.delenv("MADRONA_MWHIP_EXEC_CONFIG_FILE", raising=False)
+    worlds = 512
+    with Simulator(hip_lib_path("escape_room"), worlds, seed=1, flags=0) as s:
+        s.step(5)
+        stats = {k["name"]: k for k in s.profile(4)}
+    per_row = {
+        # WorldID 4 + Action 16 + Rotation 16 -> ExternalForce 12 + ExternalTorque 12
+        "escape::movementSystem": (60, 2 * worlds),
+        # Position 12 + Progress 4 -> Progress 4 + Reward 4
+        "escape::rewardSystem": (28, 2 * worlds),
+        # StepsRemaining 4 -> StepsRemaining 4 + Done 4
+        "escape::stepTrackerSystem": (16, 2 * worlds),
+        # Position 12 + OpenState 4 -> Position 12
+        "escape::setDoorPositionSystem": (32, 3 * worlds),
+    }
+    for name, (bytes_per_row, rows) in per_row.items():
+        k = stats[name]
+        assert k["io_declared"], name
+        assert k["rows"] == rows, (name, k["rows"])
+        assert k["algo_bytes"] == pytest.approx(bytes_per_row * rows), name
+    # every system of the simulator is declared; the runtime's own kernels are not
+    systems = [k for n, k in stats.items() if n.startswith("escape::")]
+    assert len(systems) >= 10 and all(k["io_declared"] for k in systems)
+    assert not stats["stats:health"]["io_declared"]
