@@ -851,8 +851,23 @@ __device__ __forceinline__ Hit traceTileList(
 // shadeRecord never leaves kShadeFinal), so the per-hit material / texture
 // lookup is not even compiled in -- BASELINE config 5's scene; round 3 paid a
 // run-time branch and the registers of the texture path for it (4.36 -> 4.69 ms).
+//
+// Occupancy (round 4, profiles/r04_raycast_variants.jsonl, config 5): the
+// kernel is a chain of dependent node / triangle fetches per ray, so what it
+// needs is wavefronts to switch between.  With the geometry in LDS the block is
+// 53 KB: three workgroups per CU, three wavefronts per SIMD, 145 registers.
+// With the geometry left in HBM (it is a few KB that every workgroup reads: L2
+// and L1 hits) the block is 24 KB, and capped at 128 registers (13 spilled
+// dwords) four wavefronts share a SIMD: 4.84 -> 4.45 ms at the same grid; 96
+// registers for five spill 66 dwords and lose (4.28 ms against 3.42).  Hence:
+// geometry in HBM and four wavefronts per SIMD by default;
+// MADRONA_MWHIP_RAYCAST_GEO_LDS=1 brings the LDS copy back.
+#ifndef MADRONA_RAYCAST_WAVES
+#define MADRONA_RAYCAST_WAVES 4
+#endif
 template <bool GeoInLds, bool PlainMaterials>
 __global__ void __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(GeoInLds ? 3 : MADRONA_RAYCAST_WAVES)))
 renderRaycast(EcsState *S, RenderParams params)
 {
     TraceScope trace_scope(S);
@@ -907,7 +922,15 @@ renderRaycast(EcsState *S, RenderParams params)
 
     // a contiguous run of tiles per workgroup: the tiles of a view, and the views
     // of a world, follow each other
-    const uint32_t tiles_per_wg = (total_tiles + gridDim.x - 1u) / gridDim.x;
+    // (whole views where there are views enough to go round -- a workgroup that
+    // takes half a view stages the same world as its neighbour: config 5 at one
+    // workgroup per view 3.42 ms, at two 5.61 ms -- the grid is sized for the
+    // camera table's capacity, the rows it holds decide here)
+    uint32_t tiles_per_wg = (total_tiles + gridDim.x - 1u) / gridDim.x;
+    if (num_views >= gridDim.x || num_views >= 2048u) {
+        const uint32_t views_per_wg = (num_views + gridDim.x - 1u) / gridDim.x;
+        tiles_per_wg = (views_per_wg > 0u ? views_per_wg : 1u) * tiles_per_view;
+    }
     const uint32_t tile_begin = blockIdx.x * tiles_per_wg;
     const uint32_t tile_end = tile_begin + tiles_per_wg < total_tiles ?
         tile_begin + tiles_per_wg : total_tiles;
@@ -1456,9 +1479,13 @@ void buildRenderLaunches(EcsState *state_dev, const RenderParams &params,
     }
     {
         KernelLaunch k;
+        // (MADRONA_MWHIP_RAYCAST_GEO_LDS=1: bottom-level trees and triangles
+        // copied to LDS by every workgroup -- a 53 KB block instead of 24 KB;
+        // measured slower, see renderRaycast)
+        const char *geo_env = getenv("MADRONA_MWHIP_RAYCAST_GEO_LDS");
         const bool geo_in_lds = params.numGeoNodes * 16u +
             params.numGeoTriangles * 9u + params.geometry.numObjects * 18u <=
-                kGeoLdsDwords;
+                kGeoLdsDwords && geo_env != nullptr && atoi(geo_env) != 0;
         // (what the geometry can ask of the shading, decided here once)
         // (materialTexture is only uploaded for scenes that have textures)
         const bool plain = params.geometry.triangleMaterial == nullptr &&
@@ -1471,10 +1498,20 @@ void buildRenderLaunches(EcsState *state_dev, const RenderParams &params,
         const uint32_t tiles_per_side = (params.resolution + 15u) / 16u;
         const uint64_t tiles =
             (uint64_t)view_capacity * tiles_per_side * tiles_per_side;
-        // persistent workgroups (each copies the geometry to LDS once and walks
-        // a contiguous run of tiles); a few per slot so that uneven runs even out
+        // Workgroups walk contiguous runs of tiles and stage a world's
+        // instances when they enter it.  The grid that works best is ONE
+        // WORKGROUP PER VIEW (its run = the view's tiles, one staging per
+        // workgroup; config 5: 1536 workgroups 4.43 ms, 4096 3.68, 8192 3.56,
+        // 16384 = the views 3.42; 32768 -- half a view each, every world staged
+        // twice as often -- 5.61): as many workgroups as views, within
+        // [max_workgroups, 65536]; MADRONA_MWHIP_RAYCAST_WGS fixes the count.
+        uint64_t want = max_workgroups;
+        if (getenv("MADRONA_MWHIP_RAYCAST_WGS") == nullptr) {
+            want = std::min<uint64_t>(std::max<uint64_t>(view_capacity, max_workgroups),
+                                      65536);
+        }
         k.grid = dim3((uint32_t)std::min<uint64_t>(std::max<uint64_t>(tiles, 1),
-                                                  max_workgroups), 1, 1);
+                                                  want), 1, 1);
         k.block = dim3(256, 1, 1);
         k.setArgs(state_dev, params);
         k.name = "render";
