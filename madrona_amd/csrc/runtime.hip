@@ -1864,6 +1864,7 @@ static int makeSortBatch(mwhip_exec *exec,
             const bool wide = envU32("MADRONA_MWHIP_GATHER_WIDE", 0) != 0;
             if (wide && bytes % 4 == 0 && bytes != 0) {
                 gc.rowDwords = bytes / 4;
+                out->gatherWide = true;
                 gc.invMagicDwords = gc.rowDwords <= 1 ? 0ull :
                     (~0ull / gc.rowDwords) + 1ull;
             }
@@ -1911,39 +1912,14 @@ static int makeSortBatch(mwhip_exec *exec,
             target = (uint32_t)std::min(std::max(total / 32768.0, 2048.0), 8192.0);
         }
         std::vector<GatherSlice> slices;
-        // big batches: row tiles -- a workgroup per 1024 rows of a site moves
-        // them in every column, the permutation staged once in LDS
-        // (MADRONA_MWHIP_GATHER_BLOCKED: 0 strided over each column, 1 a
-        // contiguous run of rows per column slice, 2 row tiles; default by size)
+        // big batches: a contiguous run of rows per workgroup instead of a
+        // stride over the whole column (MADRONA_MWHIP_GATHER_BLOCKED=0/1 forces;
+        // measured at 65536 / 16384 Escape-Room worlds on one box,
+        // profiles/r04_sort_variants.jsonl: strided 300 / 53 us, contiguous
+        // 252 / 52 us)
         const uint32_t blocked_env = envU32("MADRONA_MWHIP_GATHER_BLOCKED", 3);
-        // (measured at 65536 / 16384 Escape-Room worlds, same box,
-        // profiles/r04_sort_variants.jsonl: strided 300 / 53 us, contiguous rows
-        // per column slice 252 / 52 us, row tiles 291 / 69 us -- a workgroup that
-        // walks 17 columns one after the other has too little in flight per
-        // column; the default for big batches is mode 1)
-        const uint32_t blocked_mode = blocked_env != 3 ? blocked_env :
+        const uint32_t blocked_mode = blocked_env < 2 ? blocked_env :
             (total >= kGatherBlockedBytes ? 1u : 0u);
-        if (blocked_mode == 2) {
-            for (size_t c = 0; c < cols.size(); c++) {
-                const SortSiteHost &site = out->sites[cols[c].site];
-                const ArchetypeRec &arch = exec->archetypes[site.archetype];
-                if (cols[c].column == kWorldRangesColumn) {
-                    const uint32_t n = std::max<uint32_t>(
-                        (uint32_t)(64.0 * exec->cfg.num_worlds / 4096.0), 1u);
-                    for (uint32_t i = 0; i < n; i++) {
-                        slices.push_back(GatherSlice { (uint32_t)c, i, n, 0u });
-                    }
-                } else if (cols[c].column == 0) {
-                    // (the site's real columns follow each other in the list)
-                    const uint32_t tiles = std::max<uint32_t>(
-                        (arch.capacity + sortGatherTileRows() - 1) /
-                            sortGatherTileRows(), 1u);
-                    for (uint32_t i = 0; i < tiles; i++) {
-                        slices.push_back(GatherSlice { (uint32_t)c, i, tiles, 2u });
-                    }
-                }
-            }
-        } else
         for (size_t c = 0; c < cols.size(); c++) {
             uint32_t n = (uint32_t)(target * weight[c] / std::max(total, 1.0) + 0.5);
             // at least 4 KB of work per workgroup, at least one workgroup

@@ -132,6 +132,7 @@ struct SortBatch {
     GatherSlice *gatherSlicesDev = nullptr;
     uint32_t numGatherSlices = 0;
     bool hasPinned = false;         // a sorted table has exported columns
+    bool gatherWide = false;        // some column moves in 16-byte chunks (sortGather<true>)
     uint32_t maxCapacity = 0;
     // every table of the batch holds few rows: one launch (sortSmall) instead
     // of the chain.  Decided from the rows the tables hold when the graph is
@@ -228,7 +229,6 @@ struct KernelLaunch {
 
 int sortNumPasses(bool world_sort, uint32_t num_worlds);
 uint32_t sortTileSize();
-uint32_t sortGatherTileRows();
 uint32_t sortSmallRowLimit();
 uint32_t sortSmallBusyRows();
 uint32_t sortCompactTailLimit();

@@ -75,7 +75,6 @@ constexpr int kSortThreads = 256;
 constexpr int kSortWaves = kSortThreads / 64;
 constexpr int kSortItems = 8;
 constexpr int kSortTile = kSortThreads * kSortItems;   // 2048 keys
-constexpr int kGatherTileRows = 1024;   // rows per workgroup of the row-tile gather
 constexpr int kRadixBits = 8;
 constexpr int kRadixDigits = 1 << kRadixBits;
 
@@ -678,13 +677,26 @@ __device__ inline int32_t compactNumTiles(int32_t prefix);
 
 // One column (blockIdx.y) of one site: rows move from the buffers the table
 // had when the chain started into its current ones.
+template <bool Wide = true>
 __device__ inline void gatherColumn(EcsState *S, const SortSite &site,
                                     const GatherColumn &gc, TableHdr &tbl,
                                     int32_t row_begin, int32_t row_end,
                                     int32_t tid, int32_t stride,
                                     const int32_t *perm_rows = nullptr);
 
+// Wide: some column of the batch moves in 16-byte destination chunks
+// (MADRONA_MWHIP_GATHER_WIDE=1).  The word-by-word kernel is a stream of
+// (index -> word -> store) chains: what it wants is wavefronts in flight, and
+// without the wide routine it fits EIGHT per SIMD (64 registers) -- measured
+// with the register cap alone, spilling the unused wide path
+// (profiles/r04_sort_variants.jsonl): 15.1 -> 12.3 us at 4096 Escape-Room worlds,
+// 28.4 -> 25.9 at 8192 with physics, 177 -> 159 at 65536.
+#ifndef MADRONA_SORT_GATHER_WAVES
+#define MADRONA_SORT_GATHER_WAVES 8
+#endif
+template <bool Wide>
 __global__ void __launch_bounds__(kSortThreads)
+__attribute__((amdgpu_waves_per_eu(Wide ? 0 : MADRONA_SORT_GATHER_WAVES)))
 sortGather(EcsState *S, const SortSite *sites, const GatherColumn *columns,
            const GatherSlice *slices, const MiscOp *trailing_ops,
            uint32_t num_trailing_ops)
@@ -705,33 +717,12 @@ sortGather(EcsState *S, const SortSite *sites, const GatherColumn *columns,
     }
     const int32_t n_out = state->rowsOut;
 
-    if (slice.blocked == 2u) {
-        // Row tiles (big tables): this workgroup moves rows [row_begin, row_end)
-        // of EVERY column of the site.  The permutation entries of the tile are
-        // read once into LDS instead of once per column (a 196-byte row has 17
-        // columns: 68 bytes of index reads for 196 of payload), and the
-        // workgroup stays inside one stretch of every buffer.
-        __shared__ int32_t perm_tile[kGatherTileRows];
-        const int32_t row_begin = (int32_t)slice.slice * kGatherTileRows;
-        const int32_t row_end = row_begin + kGatherTileRows < n_out ?
-            row_begin + kGatherTileRows : n_out;
-        if (row_begin < row_end) {
-            const bool final_in_b = ((site.numPasses - 1) & 1) != 0;
-            const int32_t *perm = final_in_b ? site.idxB : site.idxA;
-            for (int32_t i = (int32_t)threadIdx.x; i < row_end - row_begin;
-                 i += (int32_t)kSortThreads) {
-                perm_tile[i] = perm[row_begin + i];
-            }
-            __syncthreads();
-            // (slice.column = the site's first real column in the batch's list)
-            const uint32_t num_cols = (uint32_t)tbl.numColumns;
-            for (uint32_t c = 0; c < num_cols; c++) {
-                gatherColumn(S, site, columns[slice.column + c], tbl, row_begin,
-                             row_end, (int32_t)threadIdx.x, (int32_t)kSortThreads,
-                             perm_tile);
-            }
-        }
-    } else if (slice.blocked != 0u && gc.column != kWorldRangesColumn) {
+    // (Row tiles -- a workgroup per 1024 rows of a site moving them in EVERY
+    // column with the permutation staged once in LDS -- were built and measured
+    // in round 4: slower than contiguous rows per column slice, 291 against
+    // 252 us at 65536 Escape-Room worlds on one box, and its three inlined
+    // copies of the column routine cost the other modes 30 % as well.  Removed.)
+    if (slice.blocked != 0u && gc.column != kWorldRangesColumn) {
         // a contiguous run of rows per workgroup (big tables: every workgroup
         // stays inside a few pages of every buffer it touches instead of
         // striding over all of them)
@@ -740,19 +731,17 @@ sortGather(EcsState *S, const SortSite *sites, const GatherColumn *columns,
         const int32_t row_begin = (int32_t)slice.slice * per;
         const int32_t row_end = row_begin + per < n_out ? row_begin + per : n_out;
         if (row_begin < row_end) {
-            gatherColumn(S, site, gc, tbl, row_begin, row_end,
-                         (int32_t)threadIdx.x, (int32_t)kSortThreads);
+            gatherColumn<Wide>(S, site, gc, tbl, row_begin, row_end,
+                               (int32_t)threadIdx.x, (int32_t)kSortThreads);
         }
     } else {
-        gatherColumn(S, site, gc, tbl, 0, n_out,
-                     (int32_t)(slice.slice * kSortThreads + threadIdx.x),
-                     (int32_t)(slice.numSlices * kSortThreads));
+        gatherColumn<Wide>(S, site, gc, tbl, 0, n_out,
+                           (int32_t)(slice.slice * kSortThreads + threadIdx.x),
+                           (int32_t)(slice.numSlices * kSortThreads));
     }
 
     // (the passes are over: their histograms and counters are dead)
     if (gc.column == 0u && slice.slice == 0u) {
-        // (every thread of the workgroup is here: cleanSortState strides)
-        __syncthreads();
         cleanSortState(state);
         // the per-tile landing counters of the compaction chain start every
         // run at zero (whichever way the tail went this time)
@@ -766,7 +755,10 @@ sortGather(EcsState *S, const SortSite *sites, const GatherColumn *columns,
 // Rows [row_begin, row_end) of the sorted table.  tid / stride: this thread's
 // index among, and the number of, the threads working on them.
 // perm_rows: the permutation entries of rows [row_begin, row_end) if the caller
-// has them closer than the index buffer (LDS).
+// has them closer than the index buffer.  Wide = false leaves the 16-byte-chunk
+// routine out (and its registers: the word-by-word kernel then fits eight
+// wavefronts per SIMD).
+template <bool Wide>
 __device__ inline void gatherColumn(EcsState *S, const SortSite &site,
                                     const GatherColumn &gc, TableHdr &tbl,
                                     int32_t row_begin, int32_t row_end,
@@ -817,10 +809,12 @@ __device__ inline void gatherColumn(EcsState *S, const SortSite &site,
 
     const size_t row_bytes = tbl.columnBytes[col];
     char *dst_rows = (char *)dst + (size_t)row_begin * row_bytes;
-    if (gc.rowDwords != 0u) {
-        gatherRowsWide((const uint32_t *)src, (uint32_t *)dst_rows, perm, n_rows,
-                       gc.rowDwords, gc.invMagicDwords, tid, stride);
-        return;
+    if constexpr (Wide) {
+        if (gc.rowDwords != 0u) {
+            gatherRowsWide((const uint32_t *)src, (uint32_t *)dst_rows, perm, n_rows,
+                           gc.rowDwords, gc.invMagicDwords, tid, stride);
+            return;
+        }
     }
 
     switch (gc.wordBytes) {
@@ -1891,7 +1885,6 @@ int sortNumPasses(bool world_sort, uint32_t num_worlds)
 }
 
 uint32_t sortTileSize() { return (uint32_t)kSortTile; }
-uint32_t sortGatherTileRows() { return (uint32_t)kGatherTileRows; }
 
 // (MADRONA_MWHIP_SORT_SMALL_ROWS overrides it: measurements)
 uint32_t sortSmallRowLimit()
@@ -2023,7 +2016,8 @@ void buildSortLaunches(const SortBatch &batch, std::vector<KernelLaunch> &out)
 
     {
         KernelLaunch k;
-        k.fn = (const void *)&sortGather;
+        k.fn = batch.gatherWide ? (const void *)&sortGather<true> :
+                                  (const void *)&sortGather<false>;
         // one workgroup per slice of a column (runtime.hip, makeSortBatch: the
         // workgroups are shared out over the columns by the bytes they move)
         k.grid = dim3(std::max(batch.numGatherSlices, 1u), 1, 1);
