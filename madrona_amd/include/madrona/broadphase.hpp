@@ -102,6 +102,11 @@ public:
     template <typename Fn>
     MADRONA_HD inline void findIntersecting(const math::AABB &aabb,
                                             Fn &&fn) const;
+    // (see broadphase.inl: for callers that confirm entities against their
+    // geometry afterwards)
+    template <typename Fn>
+    MADRONA_HD inline void findIntersectingLeafBoxes(const math::AABB &aabb,
+                                                     Fn &&fn) const;
 
     template <typename Fn>
     MADRONA_HD inline void findLeafIntersecting(LeafID leaf_id, Fn &&fn) const

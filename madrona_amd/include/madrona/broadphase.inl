@@ -76,6 +76,46 @@ void BVH::findIntersecting(const math::AABB &aabb, Fn &&fn) const
     }
 }
 
+// The leaves whose OWN box (leaf_aabbs_) overlaps the query, in the order
+// findIntersecting reports leaves.  For callers that confirm every reported
+// entity against its actual geometry afterwards (findEntitiesWithinAABB): a
+// body whose hull overlaps the query also overlaps it with its leaf box -- the
+// hull plus a margin -- and a leaf is reached by the tree walk iff the query
+// overlaps its slot box, a superset of the leaf box; so the confirmed entities,
+// and their order, are those of the walk, without the dependent node -> child
+// -> node chain (one lane per world walks it alone in a portable simulator's
+// grab system: 169 us at 8192 worlds).  Same precondition as traceRay: the
+// leaf boxes are current.  A pending rebuild takes the walk.
+template <typename Fn>
+void BVH::findIntersectingLeafBoxes(const math::AABB &aabb, Fn &&fn) const
+{
+    if (force_rebuild_) {
+        findIntersecting(aabb, std::forward<Fn>(fn));
+        return;
+    }
+    const int32_t n = num_tree_leaves_;
+    constexpr int32_t group = 8;
+    for (int32_t g = 0; g < n; g += group) {
+        // (leaf index -> box: two dependent round trips, paid once per group)
+        int32_t leaf[group];
+MADRONA_UNROLL
+        for (int32_t k = 0; k < group; k++) {
+            leaf[k] = dfs_leaves_[g + k < n ? g + k : n - 1];
+        }
+        math::AABB box[group];
+MADRONA_UNROLL
+        for (int32_t k = 0; k < group; k++) {
+            box[k] = leaf_aabbs_[leaf[k]];
+        }
+MADRONA_UNROLL
+        for (int32_t k = 0; k < group; k++) {
+            if (g + k < n && aabb.overlaps(box[k])) {
+                fn(leaf_entities_[leaf[k]]);
+            }
+        }
+    }
+}
+
 namespace detail {
 
 // Leaf boxes are swept along the linear velocity and padded for acceleration

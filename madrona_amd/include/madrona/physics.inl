@@ -1419,7 +1419,9 @@ MADRONA_HD inline void findEntitiesWithinAABB(Context &ctx,
 {
     // BVH boxes are conservative (expanded for motion): confirm against the
     // body's actual hull extents (reference physics.inl:8-24)
-    ctx.singleton<broadphase::BVH>().findIntersecting(aabb, [&](Entity e) {
+    // (every reported entity is confirmed against its hull, so the leaves can be
+    // culled by their own boxes in traversal order: BVH::findIntersectingLeafBoxes)
+    ctx.singleton<broadphase::BVH>().findIntersectingLeafBoxes(aabb, [&](Entity e) {
         if (checkEntityAABBOverlap(ctx, aabb, e)) {
             fn(e);
         }
