@@ -462,6 +462,7 @@ struct ArchetypeRec {
     uint32_t maxPerWorld = 0;
     bool singleton = false;
     bool bigSort = false;
+    bool spreadSort = false;    // busy but small: the one-launch sort on several workgroups
     uint32_t smallBusy = 0;     // consecutive reports of a busy one-launch sort           // outgrew the single-launch sort once
     // world sorts of this table take the compaction chain unless something
     // other than world sorts reorders / truncates it (a sort by another key,
@@ -586,8 +587,6 @@ struct mwhip_exec {
     std::mutex printMutex;
     std::thread printThread;
     std::atomic<bool> printStop { false };
-    uint64_t printStallTail = ~0ull;    // ticket the drain thread is waiting for
-    uint32_t printStallPolls = 0;
     int32_t *statsHost = nullptr;           // pinned, device-visible
     std::vector<void *> allocations;
     std::vector<std::unique_ptr<VmRange>> vmRanges;
@@ -1577,10 +1576,10 @@ static void printRecord(const HostPrintRecord &rec)
     printf("%s\n", out.c_str());
 }
 
-// Prints completed records in ticket order.  in_flight: writers may still be
-// running, stop at the first incomplete record; otherwise (the stream has been
-// waited for) an incomplete record below head is one its writer dropped
-// because the ring was full.
+// Prints completed records in ticket order and stops at the first incomplete
+// one (its writer is still running).  in_flight: called between replays by the
+// service thread; otherwise the stream has been waited for, every record below
+// head is complete, and the drop count is reported.
 static void drainHostPrints(mwhip_exec *exec, bool in_flight)
 {
     HostPrintRing *ring = exec->printRing;
@@ -1596,24 +1595,14 @@ static void drainHostPrints(mwhip_exec *exec, bool in_flight)
         if (seq == tail + 1) {
             printRecord(rec);
             printed = true;
-        } else if (in_flight) {
-            // Not there yet: its writer is still filling it in -- or dropped it
-            // (a writer that finds the ring full takes a ticket and writes
-            // nothing).  A record takes microseconds to fill; one that has not
-            // appeared over 32 polls of this thread (~5 ms) was dropped, and
-            // waiting for it would keep the ring full for every later message
-            // until the next mwhip_run / mwhip_synchronize.
-            if (exec->printStallTail == tail) {
-                if (++exec->printStallPolls < 32u) {
-                    break;
-                }
-            } else {
-                exec->printStallTail = tail;
-                exec->printStallPolls = 1;
-                break;
-            }
+        } else {
+            // Not there yet: its writer is still filling it in (tickets are
+            // only taken when the ring has room, host_print.hpp: there are no
+            // holes to skip).  After a replay the host waited for, every
+            // writer has finished and this does not happen.
+            (void)in_flight;
+            break;
         }
-        exec->printStallTail = ~0ull;
         tail += 1;
         __atomic_store_n(&ring->tail, tail, __ATOMIC_RELEASE);
     }
@@ -1769,6 +1758,11 @@ static int makeSortBatch(mwhip_exec *exec,
     std::vector<SortSite> sites;
     std::vector<GatherColumn> cols;
     bool all_small = envU32("MADRONA_MWHIP_SORT_SMALL", 1) != 0;
+    // MADRONA_MWHIP_SORT_SPREAD: 0 = busy small tables go to the chain (round
+    // 3), 1 = they get the one-launch sort on several workgroups, 2 = every
+    // small batch does (tests)
+    const uint32_t spread_mode = envU32("MADRONA_MWHIP_SORT_SPREAD", 1);
+    bool any_spread = spread_mode == 2u;
 
     for (auto [archetype_id, component_id] : specs) {
         if (archetype_id >= exec->archetypes.size() ||
@@ -1829,8 +1823,10 @@ static int makeSortBatch(mwhip_exec *exec,
             if (arch.bigSort || rows_now * 4 > sortSmallRowLimit()) {
                 all_small = false;
             }
+            any_spread = any_spread || arch.spreadSort;
         }
         uint32_t site_columns = 0;
+        sites.back().firstGatherColumn = (uint32_t)cols.size();
         if (world_sort) {
             // first in the list: its two binary-search chains per world overlap
             // with the column traffic of the workgroups scheduled after it
@@ -1873,6 +1869,10 @@ static int makeSortBatch(mwhip_exec *exec,
         sites.back().numGatherColumns = site_columns;
     }
     out->small = all_small;
+    if (all_small && any_spread && spread_mode != 0u) {
+        out->spreadGroups = std::min(std::max(
+            envU32("MADRONA_MWHIP_SORT_SPREAD_GROUPS", 32), 1u), 64u);
+    }
 
     int rc = devAllocT(exec, &out->sitesDev, sites.size());
     if (rc != 0) return rc;
@@ -3464,11 +3464,23 @@ static int sortsOutgrown(mwhip_exec *exec)
                 // launch wins while the table is tiny or mostly idle (4 us
                 // against 3 x 4 when nothing changed).  Three reports in a
                 // row above the mark move a world-sorted table to the chain.
+                // (MADRONA_MWHIP_SORT_SPREAD=1: a busy table that fits the LDS
+                // buffers of sortSmallSpread stays with one launch, on several
+                // workgroups -- 29 us, off by default.)
+                const bool spread_ok =
+                    envU32("MADRONA_MWHIP_SORT_SPREAD", 0) != 0u &&
+                    rows * 8 <= (int64_t)sortSpreadRowLimit() * 7;
                 if (!arch.bigSort && site.worldSort &&
                         compactionEligible(exec, site.archetype, 1u) &&
-                        rows >= (int64_t)sortSmallBusyRows()) {
+                        rows >= (int64_t)sortSmallBusyRows() &&
+                        !(spread_ok && arch.spreadSort)) {
                     if (++arch.smallBusy >= 3u) {
-                        arch.bigSort = true;
+                        if (spread_ok) {
+                            arch.spreadSort = true;
+                            arch.smallBusy = 0;
+                        } else {
+                            arch.bigSort = true;
+                        }
                         rebuild = true;
                     }
                 } else {

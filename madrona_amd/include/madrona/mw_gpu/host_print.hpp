@@ -12,7 +12,7 @@
 // drains the ring after every replay it waits for (mwhip_run /
 // mwhip_synchronize) and from a background thread in between, printing in
 // sequence order.  Writers never wait for the host; when the ring is full the
-// message is counted as dropped and the drop count is reported.
+// message takes no ticket, is counted as dropped and the drop count is reported.
 #pragma once
 
 #include <madrona/taskgraph.hpp>
@@ -40,19 +40,33 @@ public:
             return;
         }
 
-        const uint64_t seq = __hip_atomic_fetch_add(&ring->head, 1ull,
+        // A ticket is only taken when the ring has room for it (compare-and-
+        // swap on head against the host's tail): every ticket below head is a
+        // record that is being, or has been, written, so the host can wait for
+        // a slow writer without ever mistaking it for a dropped message.  (A
+        // stale tail only makes the test conservative.)  Writers contend with
+        // each other only: a lost race means another message got its ticket,
+        // so the loop ends after at most as many rounds as the ring has room.
+        unsigned long long seq = __hip_atomic_load(&ring->head,
             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        const uint64_t tail = __hip_atomic_load(&ring->tail, __ATOMIC_RELAXED,
-                                                __HIP_MEMORY_SCOPE_SYSTEM);
-        mwhip::HostPrintRecord &rec =
-            ring->records[seq % mwhip::HostPrintRing::numRecords];
-        if (seq - tail >= mwhip::HostPrintRing::numRecords) {
-            // the host has not caught up: this slot still holds an unread
-            // message.  Publish an empty record so the sequence has no hole.
+        bool taken = false;
+        while (!taken) {
+            const uint64_t tail = __hip_atomic_load(&ring->tail,
+                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (seq - tail >= mwhip::HostPrintRing::numRecords) {
+                break;      // the host has not caught up
+            }
+            taken = __hip_atomic_compare_exchange_strong(&ring->head, &seq,
+                seq + 1ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if (!taken) {
             __hip_atomic_fetch_add(&ring->dropped, 1ull, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_SYSTEM);
             return;
         }
+        mwhip::HostPrintRecord &rec =
+            ring->records[seq % mwhip::HostPrintRing::numRecords];
 
         int32_t n = 0;
         while (n < mwhip::HostPrintRecord::maxChars - 1 && str[n] != '\0') {

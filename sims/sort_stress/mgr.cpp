@@ -20,7 +20,8 @@ struct SimTraits {
     static Sim::Config makeConfig(const SimCreateArgs &args)
     {
         return Sim::Config { args.seed, args.world_base, args.flags & 1u,
-                             (args.flags >> 1) & 1u };
+                             (args.flags >> 1) & 1u,
+                             (args.flags >> 2) & 1u };
     }
 
     static void makeInits(const SimCreateArgs &, Sim::WorldInit *) {}

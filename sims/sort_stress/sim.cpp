@@ -96,6 +96,9 @@ inline void churnSystem(Engine &ctx, Churn &churn)
             (float)sim.numItems * 0.5f, (uint64_t)0x123456789ABCull,
             (void *)&sim);
     }
+    if (sim.chatty != 0 && churn.step == 2u) {
+        mwGPU::HostPrint::log("sort_stress: chatty world {}", ctx.worldID().idx);
+    }
 #endif
 }
 
@@ -221,6 +224,7 @@ Sim::Sim(Engine &ctx, const Config &cfg, const WorldInit &)
     rng = RNG(rand::split_i(rand::initKey(cfg.seed), global_world));
     mixIds = cfg.coldStart == 0 ? 1u : 0u;
     rampUp = cfg.rampUp;
+    chatty = cfg.chatty;
     numItems = 0;
 
     Churn &churn = ctx.singleton<Churn>();

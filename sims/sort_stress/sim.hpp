@@ -78,6 +78,9 @@ struct Sim : public madrona::WorldBase {
         // 1: every world starts with one item and only creates until it is
         // full (a population that builds up at run time: table growth)
         uint32_t rampUp;
+        // 1: every world logs a message at its second step (more messages in
+        // one replay than the executor's message ring holds)
+        uint32_t chatty;
     };
 
     struct WorldInit {};
@@ -92,6 +95,7 @@ struct Sim : public madrona::WorldBase {
     RNG rng;
     uint32_t mixIds;
     uint32_t rampUp;
+    uint32_t chatty;
     int32_t numItems;
     Entity items[consts::maxItems];
 };

@@ -120,6 +120,31 @@ def test_host_print_from_a_simulator(built, capfd):
 
 
 @pytest.mark.gpu
+def test_host_print_ring_overflow(built, capfd):
+    """More messages in one replay than the ring holds (4096 worlds speak at
+    once, 1024 records): what fits is printed once each, the rest is counted as
+    dropped -- a message that does not fit takes no ticket, so the host never
+    has to guess whether a missing record is late or lost -- and the channel
+    works afterwards (world 3's message of the next step)."""
+    worlds = 4096
+    with Simulator(hip_lib_path("sort_stress"), worlds, seed=7, flags=4) as s:
+        s.step(2)
+        first = capfd.readouterr().out
+        s.step(1)
+        second = capfd.readouterr().out
+    chatty = [ln for ln in first.splitlines()
+              if ln.startswith("sort_stress: chatty world ")]
+    ids = [int(ln.rsplit(" ", 1)[1]) for ln in chatty]
+    assert len(set(ids)) == len(ids) and all(0 <= i < worlds for i in ids)
+    dropped = [ln for ln in first.splitlines() if "HostPrint ring overflow" in ln]
+    n_dropped = sum(int(ln.split("overflow, ")[1].split(" ")[0]) for ln in dropped)
+    assert len(ids) + n_dropped == worlds, (len(ids), n_dropped)
+    assert len(ids) >= 1024
+    assert sum(ln.startswith("sort_stress: world 3 step 3") for ln in
+               second.splitlines()) == 1, second[-2000:]
+
+
+@pytest.mark.gpu
 def test_pybind_tensor_to_torch_device(pymod, built):
     """The C++ py::Tensor route and the ctypes route give the same live view of
     an exported column (device kDLROCM -> torch 'cuda')."""

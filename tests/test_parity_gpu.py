@@ -379,6 +379,35 @@ def test_sort_chains_lockstep(built, monkeypatch, sim, worlds, steps, denom, com
     assert not probs, (step, probs[:3])
 
 
+@pytest.mark.parametrize("sim,worlds,steps,denom,groups,small_rows", [
+    ("sort_stress", 37, 40, 0, "16", ""),        # key sorts, pinned columns, scratch
+    ("sort_stress", 120, 30, 0, "5", ""),        # shares that do not divide the rows
+    ("sort_stress", 1500, 12, 0, "7", "4000000"),   # > 4096 rows: workgroup 0 alone
+    ("escape_room", 96, 60, 30, "16", ""),
+    ("escape_room_phys", 64, 60, 25, "3", ""),   # joint table: rows come and go
+])
+def test_sort_small_spread_lockstep(built, monkeypatch, sim, worlds, steps, denom,
+                                    groups, small_rows):
+    """The one-launch sort on several workgroups (sortSmallSpread: every
+    workgroup orders all keys in LDS and moves its share of the rows, the last
+    one to finish publishes), forced for every small batch, against the
+    reference.  By default only small tables that are re-sorted every step get
+    it (the joint table of test_full_size_lockstep's escape_room_phys case)."""
+    _need_ref(sim)
+    monkeypatch.setenv("MADRONA_MWHIP_SORT_SPREAD", "2")
+    monkeypatch.setenv("MADRONA_MWHIP_SORT_SPREAD_GROUPS", groups)
+    if small_rows:
+        monkeypatch.setenv("MADRONA_MWHIP_SORT_SMALL_ROWS", small_rows)
+    actions = None
+    if sim == "escape_room":
+        actions = _escape_actions(9)
+    elif sim == "escape_room_phys":
+        actions = _escape_actions(9, grab=True)
+    probs, step = run_pair(sim, worlds, steps, seed=7, flags=denom, check_every=5,
+                           actions=actions, check_init=False, ref_workers=0)
+    assert not probs, (step, probs[:3])
+
+
 @pytest.mark.parametrize("compact", ["1", "2"])
 def test_compaction_chain_heavy_churn(built, monkeypatch, compact):
     """The compaction chain where it is the default: the Escape Room with a reset
