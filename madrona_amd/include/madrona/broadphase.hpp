@@ -181,6 +181,41 @@ public:
         return leaf_entities_[leaf];
     }
 
+    // What the fused physics step reads of the tree, as addresses: a kernel that
+    // has them can fetch the boxes of all its leaves in one round of loads
+    // instead of going through the object once per box (phys_impl/
+    // world_step.inl, loadWorldFramed).
+    struct StepView {
+        const math::AABB *leafAABBs;
+        const uint32_t *leafParents;
+        const void *nodes;
+        const int32_t *traversalOrder;
+        int32_t numLeaves;
+    };
+    // (loads through the global address space: mwhip::loadGlobal)
+    MADRONA_HD static inline StepView loadStepView(const BVH *tree)
+    {
+        return StepView {
+            mwhip::loadGlobal(&tree->leaf_aabbs_),
+            mwhip::loadGlobal(&tree->leaf_parents_),
+            mwhip::loadGlobal(&tree->nodes_),
+            mwhip::loadGlobal(&tree->dfs_leaves_),
+            mwhip::loadGlobal(&tree->num_leaves_),
+        };
+    }
+    // == leafSlotBounds(leaf) with parent = view.leafParents[leaf]
+    MADRONA_HD static inline math::AABB loadSlotBounds(const void *nodes,
+                                                       uint32_t parent)
+    {
+        const Node *node = (const Node *)nodes + (parent >> 2);
+        const uint32_t c = parent & 3u;
+        return math::AABB {
+            { mwhip::loadGlobal(&node->minX[c]), mwhip::loadGlobal(&node->minY[c]),
+              mwhip::loadGlobal(&node->minZ[c]) },
+            { mwhip::loadGlobal(&node->maxX[c]), mwhip::loadGlobal(&node->maxY[c]),
+              mwhip::loadGlobal(&node->maxZ[c]) } };
+    }
+
     // ---- staged rebuild (physics.inl bvhUpdateKernel) -------------------------
     // The top-down build is a long chain of dependent accesses to a few KB:
     // run from HBM it is pure latency.  A kernel copies the leaf boxes next to

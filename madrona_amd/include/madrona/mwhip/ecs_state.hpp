@@ -265,6 +265,31 @@ MWHIP_HD inline T loadInvariant(const T *p)
 #endif
 }
 
+// Load through the GLOBAL address space (whole dwords of a trivially copyable
+// T).  Through a generic pointer the same load is a flat_load: it counts against
+// the LDS counter as well, so that the next wait for an LDS access also waits
+// for every row still on its way from HBM.  For loads whose whole point is to
+// be in flight together (phys_impl/world_step.inl, loadWorldFramed).
+template <typename T>
+MWHIP_HD inline T loadGlobal(const T *p)
+{
+#if !defined(__HIP_DEVICE_COMPILE__)
+    return *p;
+#else
+    static_assert(sizeof(T) % 4 == 0);
+    struct Words { unsigned int w[sizeof(T) / 4]; };
+    const __attribute__((address_space(1))) unsigned int *g =
+        (const __attribute__((address_space(1))) unsigned int *)
+            (unsigned long long)p;
+    Words words;
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; i++) {
+        words.w[i] = g[i];
+    }
+    return __builtin_bit_cast(T, words);
+#endif
+}
+
 // header fields that never change once the executor is built
 MWHIP_HD inline TableHdr *tablesOf(const EcsState *S)
 {

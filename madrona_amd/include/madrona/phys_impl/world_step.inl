@@ -1594,6 +1594,304 @@ __device__ inline void loadWorldBodies(uint32_t lane, WorldBlock<MAXB, LPW> *dst
     }
 }
 
+// ---------------------------------------------------------------------------
+// Loading a world through the frame (PhysicsFrame, physics.inl): the same
+// values in the same slots of the block as loadWorldBodies + the joint staging
+// of the step kernel leave, fetched in five rounds of loads instead of twenty.
+// Every round is issued in one go -- nothing is written, and nothing loaded is
+// looked at, before the loads of the round are on their way:
+//   1  (caller) the world's place in the order; the frame itself is hot
+//   2  row ranges in every rigid-body table, the tree's arrays, the object
+//      manager, the joint range, the solver parameters
+//   3  (frame: L2 hits) the columns of this lane's body; the traversal order
+//   4  the body's row in every column; the world's joints
+//   5  what the row names: object metadata, primitive range, leaf box, leaf
+//      parent; the entity slots of the joints' bodies
+//   6  the leaf's slot box in its parent node
+// ---------------------------------------------------------------------------
+struct FramedWorld {
+    int32_t numBodies;          // < 0: the world cannot be stepped (kErrPhysics)
+    int32_t jointBegin;
+    int32_t numJoints;
+    bool jointsStaged;
+    const ObjectManager *objMgr;    // the world's manager (HBM)
+};
+
+__device__ inline void fillPhysicsFrame(EcsState *S, const PhysicsScratch *ps,
+                                        PhysicsFrame *F, uint32_t tid,
+                                        uint32_t num_threads)
+{
+    StateManager *state_mgr = static_cast<StateManager *>(S);
+    const uint32_t num_arch = ps->numBodyArchetypes;
+    for (uint32_t i = tid; i < num_arch * PhysicsFrame::numColumns;
+         i += num_threads) {
+        const uint32_t a = i / PhysicsFrame::numColumns;
+        const uint32_t c = i % PhysicsFrame::numColumns;
+        const TableHdr &tbl = S->tables[ps->bodyArchetypes[a]];
+        F->columns[a][c] = (int32_t)c < tbl.numColumns ? tbl.columns[c] : nullptr;
+    }
+    if (tid < PhysicsFrame::maxArchetypes) {
+        // (entries behind the last archetype repeat the first: the step kernel
+        // reads all of them without a branch and ignores what it got)
+        const uint32_t id = ps->bodyArchetypes[tid < num_arch ? tid : 0u];
+        const TableHdr &tbl = S->tables[id];
+        F->archetype[tid] = id;
+        F->worldOffsets[tid] = tbl.worldOffsets;
+        F->worldCounts[tid] = tbl.worldCounts;
+    }
+    if (tid == 0) {
+        uint32_t unsorted = 0;
+        for (uint32_t a = 0; a < num_arch; a++) {
+            unsorted |= S->tables[ps->bodyArchetypes[a]].needsSort;
+        }
+        F->unsorted = unsorted;
+        F->numArchetypes = num_arch;
+        F->trees = state_mgr->getSingletonColumn<broadphase::BVH>();
+        F->systemStates = state_mgr->getSingletonColumn<PhysicsSystemState>();
+        F->objectData = state_mgr->getSingletonColumn<ObjectData>();
+        const ObjectManager *mgr = F->objectData[0].mgr;
+        F->objMgr = mgr;
+        F->objMgrCopy = *mgr;
+        const TableHdr &joint_tbl = S->tables[ps->jointArchetype];
+        F->jointOffsets = joint_tbl.worldOffsets;
+        F->jointCounts = joint_tbl.worldCounts;
+        F->joints = (const JointConstraint *)joint_tbl.columns[2];
+        F->entities = mwhip::entitiesOf(S);
+    }
+}
+
+// nothing moves across: what was issued before stays before, what uses it after
+__device__ __attribute__((always_inline)) inline void roundIssued()
+{
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int MAXB, int LPW>
+__device__ __attribute__((always_inline)) inline FramedWorld loadWorldFramed(
+    uint32_t lane, WorldBlock<MAXB, LPW> *w, const PhysicsFrame *F, int32_t world)
+{
+    using Block = WorldBlock<MAXB, LPW>;
+    using mwhip::loadGlobal;
+    using mwhip::loadInvariant;
+    constexpr uint32_t max_arch = PhysicsFrame::maxArchetypes;
+    constexpr int32_t chunks = (MAXB + LPW - 1) / LPW;
+    FramedWorld out {};
+
+    // ---- round 2 (the frame's own words: scalar loads, hot) ---------------------
+    const uint32_t num_arch = loadInvariant(&F->numArchetypes);
+    const uint32_t tables_unsorted = loadInvariant(&F->unsorted);
+    // (roundIssued(): the loads of a round are all on their way before the first
+    // of them is looked at.  Left to itself the scheduler -- the kernel is at its
+    // register limit -- pairs every load with its use: eight row counts became
+    // eight round trips one after the other.)
+    int32_t row_base[max_arch];
+    int32_t rows[max_arch];
+#pragma unroll
+    for (uint32_t a = 0; a < max_arch; a++) {
+        row_base[a] = loadGlobal(loadInvariant(&F->worldOffsets[a]) + world);
+        rows[a] = loadGlobal(loadInvariant(&F->worldCounts[a]) + world);
+    }
+    const broadphase::BVH::StepView tree =
+        broadphase::BVH::loadStepView(loadInvariant(&F->trees) + world);
+    const ObjectManager *world_mgr =
+        loadGlobal(&(loadInvariant(&F->objectData) + world)->mgr);
+    const int32_t joint_begin = loadGlobal(loadInvariant(&F->jointOffsets) + world);
+    const int32_t num_joints = loadGlobal(loadInvariant(&F->jointCounts) + world);
+    const PhysicsSystemState sys_regs =
+        loadGlobal(loadInvariant(&F->systemStates) + world);
+    roundIssued();
+
+    int32_t body_base[max_arch + 1];
+    body_base[0] = 0;
+#pragma unroll
+    for (uint32_t a = 0; a < max_arch; a++) {
+        rows[a] = a < num_arch ? rows[a] : 0;
+        body_base[a + 1] = body_base[a] + rows[a];
+    }
+    const int32_t num_bodies = body_base[max_arch];
+    out.numBodies = num_bodies;
+    out.jointBegin = joint_begin;
+    out.numJoints = num_joints;
+    out.jointsStaged = num_joints <= Block::maxJoints;
+    out.objMgr = world_mgr;
+    if (tables_unsorted != 0u || num_bodies > MAXB || tree.numLeaves != num_bodies) {
+        out.numBodies = -1;
+        return out;
+    }
+    if (lane == 0) {
+        w->sys = sys_regs;
+    }
+    if (num_bodies == 0) {
+        wave::phaseFence();
+        return out;
+    }
+    // (the manager's arrays: the frame's copy unless this world has its own)
+    const RigidBodyMetadata *metadata = loadInvariant(&F->objMgrCopy.metadata);
+    const uint32_t *prim_offsets =
+        loadInvariant(&F->objMgrCopy.rigidBodyPrimitiveOffsets);
+    const uint32_t *prim_counts =
+        loadInvariant(&F->objMgrCopy.rigidBodyPrimitiveCounts);
+    if (world_mgr != loadInvariant(&F->objMgr)) {
+        metadata = loadGlobal(&world_mgr->metadata);
+        prim_offsets = loadGlobal(&world_mgr->rigidBodyPrimitiveOffsets);
+        prim_counts = loadGlobal(&world_mgr->rigidBodyPrimitiveCounts);
+    }
+
+    // (the world's joints, when they fit the block: their rows go out first,
+    // the entity slots of their bodies with round 5 of the first chunk)
+    const bool my_joint = out.jointsStaged && (int32_t)lane < num_joints;
+    JointConstraint joint {};
+    mwhip::EntitySlot joint_slots[2] {};
+    if (my_joint) {
+        joint = loadGlobal(loadInvariant(&F->joints) + joint_begin + (int32_t)lane);
+    }
+
+    // (the traversal order of every chunk first: a body's rank in it is written
+    // by whichever lane holds that position of the order)
+    int32_t order_leaf[chunks];
+#pragma unroll
+    for (int32_t c = 0; c < chunks; c++) {
+        const int32_t k = c * LPW + (int32_t)lane;
+        order_leaf[c] = loadGlobal(tree.traversalOrder + (k < num_bodies ? k : 0));
+    }
+
+    // Lanes without a body load the world's first body again (no branches
+    // around the loads: a round stays one batch) and write nothing.
+#pragma unroll
+    for (int32_t c = 0; c < chunks; c++) {
+        const int32_t k = c * LPW + (int32_t)lane;
+        const bool active = k < num_bodies;
+        const int32_t kc = active ? k : 0;
+
+        // ---- round 3: where the body's rows are (frame: L2 hits) ------------------
+        uint32_t slot = 0;
+        int32_t row = row_base[0] + kc;
+#pragma unroll
+        for (uint32_t a = 1; a < max_arch; a++) {
+            if (kc >= body_base[a] && rows[a] != 0) {
+                slot = a;
+                row = row_base[a] + (kc - body_base[a]);
+            }
+        }
+        void *const *col = F->columns[slot];
+        const uint32_t archetype = loadGlobal(&F->archetype[slot]);
+        const Entity *col_entity = (const Entity *)loadGlobal(&col[0]);
+        const base::Position *col_pos =
+            (const base::Position *)loadGlobal(&col[RGDCols::Position]);
+        const base::Rotation *col_rot =
+            (const base::Rotation *)loadGlobal(&col[RGDCols::Rotation]);
+        const base::Scale *col_scale =
+            (const base::Scale *)loadGlobal(&col[RGDCols::Scale]);
+        const base::ObjectID *col_obj =
+            (const base::ObjectID *)loadGlobal(&col[RGDCols::ObjectID]);
+        const ResponseType *col_resp =
+            (const ResponseType *)loadGlobal(&col[RGDCols::ResponseType]);
+        const broadphase::LeafID *col_leaf =
+            (const broadphase::LeafID *)loadGlobal(&col[RGDCols::LeafID]);
+        const Velocity *col_vel =
+            (const Velocity *)loadGlobal(&col[RGDCols::Velocity]);
+        const ExternalForce *col_force =
+            (const ExternalForce *)loadGlobal(&col[RGDCols::ExternalForce]);
+        const ExternalTorque *col_torque =
+            (const ExternalTorque *)loadGlobal(&col[RGDCols::ExternalTorque]);
+        roundIssued();
+
+        // ---- round 4: the rows ---------------------------------------------------------
+        const base::Position pos = loadGlobal(col_pos + row);
+        const base::Rotation rot = loadGlobal(col_rot + row);
+        const base::Scale scale = loadGlobal(col_scale + row);
+        const Velocity vel = loadGlobal(col_vel + row);
+        const ExternalForce force = loadGlobal(col_force + row);
+        const ExternalTorque torque = loadGlobal(col_torque + row);
+        const ResponseType resp = loadGlobal(col_resp + row);
+        const Entity entity = loadGlobal(col_entity + row);
+        const base::ObjectID obj_id = loadGlobal(col_obj + row);
+        const int32_t leaf = loadGlobal(col_leaf + row).id;
+        roundIssued();
+
+        // ---- round 5: what the row names ----------------------------------------------
+        const RigidBodyMetadata body_metadata = loadGlobal(metadata + obj_id.idx);
+        const uint32_t prim_offset = loadGlobal(prim_offsets + obj_id.idx);
+        const uint32_t prim_count = loadGlobal(prim_counts + obj_id.idx);
+        const math::AABB query_box = loadGlobal(tree.leafAABBs + leaf);
+        const uint32_t parent = loadGlobal(tree.leafParents + leaf);
+        if (c == 0 && my_joint) {
+            // (StateManager::getLoc reads the slot of any non-negative id)
+            const mwhip::EntitySlot *entities = loadInvariant(&F->entities);
+            joint_slots[0] = loadGlobal(entities + (joint.e1.id >= 0 ? joint.e1.id : 0));
+            joint_slots[1] = loadGlobal(entities + (joint.e2.id >= 0 ? joint.e2.id : 0));
+        }
+        roundIssued();
+
+        // ---- round 6 -------------------------------------------------------------------
+        const math::AABB slot_box =
+            broadphase::BVH::loadSlotBounds(tree.nodes, parent);
+        roundIssued();
+
+        // ---- into the block (writeBodyRow) ---------------------------------------------
+        if (c == 0) {
+#pragma unroll
+            for (int32_t r = 0; r < chunks; r++) {
+                if (r * LPW + (int32_t)lane < num_bodies) {
+                    w->leafRank[order_leaf[r]] = (uint16_t)(r * LPW + (int32_t)lane);
+                }
+            }
+            wave::phaseFence();
+        }
+        if (active) {
+            const uint32_t rank = w->leafRank[leaf];
+            w->bodyLoc[k] = Loc { archetype, row };
+            w->pos[k] = pos;
+            w->rot[k] = rot;
+            w->scale[k] = scale;
+            w->vel[k] = vel;
+            w->extForce[k] = force;
+            w->extTorque[k] = torque;
+            w->resp[k] = (uint32_t)resp;
+            w->entityID[k] = entity.id;
+            w->constants[k] = xpbd::bodyConstants(body_metadata, resp);
+            w->primOffset[k] = (uint16_t)prim_offset;
+            w->primCount[k] = (uint16_t)prim_count;
+            w->queryBox()[k] = query_box;
+            w->rankSlotBox()[rank] = slot_box;
+            w->rankEntity()[rank] = entity.id;
+            w->orderBody[rank] = (uint16_t)k;
+            w->leafOf[k] = (uint16_t)leaf;
+        }
+    }
+    wave::phaseFence();
+
+    // ---- the world's joints (when they fit the block) -------------------------------
+    if (out.jointsStaged) {
+        if (my_joint) {
+            const Entity ends[2] = { joint.e1, joint.e2 };
+            uint16_t index[2] = { 0, 0 };
+#pragma unroll
+            for (int32_t e = 0; e < 2; e++) {
+                // (StateManager::getLoc: a stale or empty handle is nowhere)
+                Loc loc = Loc::none();
+                if (ends[e].id >= 0 && joint_slots[e].gen == ends[e].gen) {
+                    loc = Loc { joint_slots[e].loc.archetype, joint_slots[e].loc.row };
+                }
+                // body index of the end point: its row among the staged bodies
+                // (no match: body 0, like the table walk)
+                for (int32_t k = 0; k < num_bodies; k++) {
+                    const Loc at = w->bodyLoc[k];
+                    if (at.archetype == loc.archetype && at.row == loc.row) {
+                        index[e] = (uint16_t)k;
+                        break;
+                    }
+                }
+            }
+            w->joints[lane] = joint;
+            w->jointBodies[lane][0] = index[0];
+            w->jointBodies[lane][1] = index[1];
+        }
+        wave::phaseFence();
+    }
+    return out;
+}
+
 // World images for physicsStepLdsKernel<MAXB>: one wavefront per world runs the
 // table-reading part of the step and leaves the result in HBM in the layout of
 // the step's LDS block.  The chain of dependent loads is the same, but this
@@ -1743,6 +2041,10 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
     // current world, not after.  (4096 atomics on one address over ~800 us do
     // not queue; round 2's persistent version strode statically and lost to
     // the dispatcher's balancing.)
+    // (with a frame the row ranges are read with everything else the world
+    // index leads to: loadWorldFramed)
+    const PhysicsFrame *frame =
+        params.worldImages == nullptr ? params.frame : nullptr;
     struct JobHeader {
         int32_t world;          // -1: no world for this half of the wavefront
         bool sorted;
@@ -1760,7 +2062,9 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
         h.sorted = true;
         if (job < num_jobs && slot < num_worlds) {
             h.world = world_order != nullptr ? world_order[slot] : slot;
-            h.sorted = h.bodies.fill(S, ps, h.world);
+            if (frame == nullptr) {
+                h.sorted = h.bodies.fill(S, ps, h.world);
+            }
         }
     };
     int32_t *job_counter = params.jobCounter;
@@ -1790,13 +2094,30 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
         uint32_t cost_work = 1;    // (what the world asked of the wavefront, roughly)
         Context ctx = TaskGraph::makeContext<Context>(
             state_mgr, WorldID { world }, true);
-        const ObjectManager &hbm_obj_mgr = *ctx.singleton<ObjectData>().mgr;
+
+        int32_t num_bodies;
+        const ObjectManager *hbm_mgr;
+        FramedWorld framed {};
+        if (frame != nullptr) {
+            // ---- the world through the frame: HBM -> LDS in five rounds -----
+            framed = loadWorldFramed<MAXB, LPW>(lane, w, frame, world);
+            if (framed.numBodies < 0) {
+                mwhip::raiseError(S, mwhip::kErrPhysics);
+                continue;
+            }
+            num_bodies = framed.numBodies;
+            hbm_mgr = framed.objMgr == frame->objMgr ? &frame->objMgrCopy :
+                                                       framed.objMgr;
+            PHYS_PROF(8);
+        } else {
+        hbm_mgr = ctx.singleton<ObjectData>().mgr;
+        const ObjectManager &hbm_obj_mgr = *hbm_mgr;
         const broadphase::BVH &bvh = ctx.singleton<broadphase::BVH>();
 
         // ---- the world's bodies ---------------------------------------------
         const WorldBodies &bodies = cur_job.bodies;
         const bool unsorted = !cur_job.sorted;
-        const int32_t num_bodies = bodies.count();
+        num_bodies = bodies.count();
         if (unsorted || num_bodies > MAXB || bvh.numLeaves() != num_bodies) {
             mwhip::raiseError(S, mwhip::kErrPhysics);
             continue;
@@ -1848,6 +2169,9 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
         }
         wave::phaseFence();
         PHYS_PROF(8);
+
+        }
+        const ObjectManager &hbm_obj_mgr = *hbm_mgr;
 
         // primitives referenced by this world's bodies
         uint32_t prim_end = 0;
@@ -1989,11 +2313,19 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
         };
 
         // ---- the world's joints (table sorted by world just before) -----------
-        const TableHdr &joint_tbl = S->tables[ps->jointArchetype];
-        const int32_t joint_begin = joint_tbl.worldOffsets[world];
-        const int32_t num_joints = joint_tbl.worldCounts[world];
-        const JointConstraint *joints =
-            (const JointConstraint *)joint_tbl.columns[2] + joint_begin;
+        int32_t joint_begin;
+        int32_t num_joints;
+        const JointConstraint *joints;
+        if (frame != nullptr) {
+            joint_begin = framed.jointBegin;
+            num_joints = framed.numJoints;
+            joints = frame->joints + joint_begin;
+        } else {
+            const TableHdr &joint_tbl = S->tables[ps->jointArchetype];
+            joint_begin = joint_tbl.worldOffsets[world];
+            num_joints = joint_tbl.worldCounts[world];
+            joints = (const JointConstraint *)joint_tbl.columns[2] + joint_begin;
+        }
 
         // body index of a joint end point (the per-archetype row ranges are not
         // kept alive through the substeps: look the row up among the staged
@@ -2009,7 +2341,7 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
             return Loc { 0, 0 };
         };
         const bool joints_staged = num_joints <= Block::maxJoints;
-        if (joints_staged) {
+        if (joints_staged && frame == nullptr) {
             for (int32_t i = (int32_t)lane; i < num_joints; i += LPW) {
                 w->joints[i] = joints[i];
                 w->jointBodies[i][0] =
@@ -2455,6 +2787,10 @@ physicsOrderKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
     const uint32_t tid = threadIdx.x;
     if (tid == 0 && params.jobCounter != nullptr) {
         *params.jobCounter = 0;     // (the step kernel's persistent wavefronts)
+    }
+    if (params.frame != nullptr && tid >= 960u) {
+        // (the last wavefront: its share of the cost scan starts a moment later)
+        fillPhysicsFrame(S, detail::scratch(S), params.frame, tid - 960u, 64u);
     }
 
     __shared__ uint32_t hist[256];

@@ -65,6 +65,41 @@ struct PhysicsScratch {
     char *worldHullScratch;
 };
 
+// What a step of ANY world needs to find its rows, resolved once per launch
+// (physicsOrderKernel, the single-workgroup kernel in front of the step) instead
+// of once per world by every wavefront of the step kernel: the addresses of the
+// rigid-body tables' columns and world ranges, of the singleton columns, of the
+// joint table and the entity store, and the object manager.  A wavefront of
+// the step kernel runs alone on its SIMD with nothing to hide a cache miss
+// behind, every kernel starts with cold caches, and a dependent miss is ~1.5 us
+// here: through the tables (table header -> column address -> row, singleton ->
+// object -> array -> element) loading a world was a chain of ~20 of them, with
+// the frame it is 5 (world -> row ranges / tree -> rows -> what the rows name
+// -> the leaf's slot in its parent node).
+struct PhysicsFrame {
+    static constexpr uint32_t maxArchetypes = PhysicsScratch::maxBodyArchetypes;
+    // Entity, WorldID, the RigidBody bundle (RGDCols), the XPBD solver state
+    static constexpr uint32_t numColumns = 14;
+
+    uint32_t numArchetypes;
+    uint32_t unsorted;                  // some rigid-body table needs its world sort
+    uint32_t archetype[maxArchetypes];
+    const int32_t *worldOffsets[maxArchetypes];
+    const int32_t *worldCounts[maxArchetypes];
+    void *columns[maxArchetypes][numColumns];
+    // singleton columns (indexed by world)
+    const broadphase::BVH *trees;
+    const PhysicsSystemState *systemStates;
+    const ObjectData *objectData;
+    const ObjectManager *objMgr;        // world 0's manager and a copy of it
+    ObjectManager objMgrCopy;
+    // the joint table (sorted by world right before the step)
+    const int32_t *jointOffsets;
+    const int32_t *jointCounts;
+    const JointConstraint *joints;
+    const mwhip::EntitySlot *entities;
+};
+
 // node data of the fused per-world step kernel
 struct PhysicsStepParams {
     int32_t numSubsteps;
@@ -85,6 +120,9 @@ struct PhysicsStepParams {
     // LDS step kernels: persistent wavefronts take jobs (a world / a pair of
     // worlds, in worldOrder) from this counter; nullptr: one workgroup per job
     int32_t *jobCounter;
+    // LDS step kernels: filled by physicsOrderKernel; nullptr: every wavefront
+    // walks the tables itself
+    PhysicsFrame *frame;
 };
 
 namespace detail {
@@ -2199,11 +2237,25 @@ MADRONA_HOST_API inline TaskGraphNodeID setupPhysicsStepTasks(
                   mwhip_last_error());
         }
     }
+    // The frame (PhysicsFrame): where every world's rows are, resolved once per
+    // launch by the order kernel.  MADRONA_MWHIP_PHYS_FRAME=0: every wavefront
+    // of the step kernel walks the tables itself (rounds 1-3).
+    PhysicsFrame *frame = nullptr;
+    const char *frame_env = getenv("MADRONA_MWHIP_PHYS_FRAME");
+    if (world_order != nullptr && world_images == nullptr &&
+            (frame_env == nullptr || atoi(frame_env) != 0)) {
+        frame = (PhysicsFrame *)mwhip_alloc_device(exec, sizeof(PhysicsFrame), 1);
+        if (frame == nullptr) {
+            FATAL("madrona_amd physics: frame allocation failed: %s",
+                  mwhip_last_error());
+        }
+    }
     auto params = builder.constructNodeData<PhysicsStepParams>(
         PhysicsStepParams { (int32_t)num_substeps, fold_pairs | refit_in_step |
                                 (int32_t)((phys::detail::capacityHint(
                                     "MADRONA_MWHIP_PHYS_COST_BLEND", 0) & 7) << 4),
-                            world_images, world_cost, world_order, job_counter });
+                            world_images, world_cost, world_order, job_counter,
+                            frame });
 
     if (world_order != nullptr) {
         mwhip_node_desc order {};
