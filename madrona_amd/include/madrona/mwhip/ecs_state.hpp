@@ -290,6 +290,27 @@ MWHIP_HD inline T loadGlobal(const T *p)
 #endif
 }
 
+// ... and the store that goes with it (a flat_store of a value that came out of
+// LDS is held back by nothing, but the wait in front of the next flat access
+// counts it)
+template <typename T>
+MWHIP_HD inline void storeGlobal(T *p, const T &v)
+{
+#if !defined(__HIP_DEVICE_COMPILE__)
+    *p = v;
+#else
+    static_assert(sizeof(T) % 4 == 0);
+    struct Words { unsigned int w[sizeof(T) / 4]; };
+    const Words words = __builtin_bit_cast(Words, v);
+    __attribute__((address_space(1))) unsigned int *g =
+        (__attribute__((address_space(1))) unsigned int *)(unsigned long long)p;
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; i++) {
+        g[i] = words.w[i];
+    }
+#endif
+}
+
 // header fields that never change once the executor is built
 MWHIP_HD inline TableHdr *tablesOf(const EcsState *S)
 {

@@ -2693,8 +2693,14 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
         fetchHeader(next_job, next_header);
         have_next = true;
         // ---- store: LDS -> HBM --------------------------------------------------
+        // The addresses of the body's six columns in ONE round of loads, then
+        // the stores, none of them waited for.  (Through ctx.getDirect every
+        // column was: load the column address, wait -- for the stores before
+        // it as well, they share the counter --, store: 14 us per pair of
+        // worlds in the phase profile, now 2.)
+#ifdef MADRONA_PHYS_STORE_THROUGH_CTX
+        // (measurement builds: rounds 1-3)
         for (int32_t k = (int32_t)lane; k < num_bodies; k += LPW) {
-            // (out of the block first, then the stores: see loadWorldBodies)
             const Loc loc = w->bodyLoc[k];
             const base::Position pos = w->pos[k];
             const base::Rotation rot = w->rot[k];
@@ -2712,6 +2718,38 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
             ctx.getDirect<xpbd::PreSolveVelocity>(
                 xpbd::XPBDCols::PreSolveVelocity, loc) = pre_vel;
         }
+        wave::phaseFence();
+#else
+        for (int32_t k = (int32_t)lane; k < num_bodies; k += LPW) {
+            const Loc loc = w->bodyLoc[k];
+            const TableHdr &tbl = mwhip::tablesOf(S)[loc.archetype];
+            base::Position *col_pos = (base::Position *)
+                mwhip::loadGlobal(&tbl.columns[RGDCols::Position]);
+            base::Rotation *col_rot = (base::Rotation *)
+                mwhip::loadGlobal(&tbl.columns[RGDCols::Rotation]);
+            Velocity *col_vel = (Velocity *)
+                mwhip::loadGlobal(&tbl.columns[RGDCols::Velocity]);
+            xpbd::SubstepPrevState *col_prev = (xpbd::SubstepPrevState *)
+                mwhip::loadGlobal(&tbl.columns[xpbd::XPBDCols::SubstepPrevState]);
+            xpbd::PreSolvePositional *col_pre_pos = (xpbd::PreSolvePositional *)
+                mwhip::loadGlobal(&tbl.columns[xpbd::XPBDCols::PreSolvePositional]);
+            xpbd::PreSolveVelocity *col_pre_vel = (xpbd::PreSolveVelocity *)
+                mwhip::loadGlobal(&tbl.columns[xpbd::XPBDCols::PreSolveVelocity]);
+            roundIssued();
+            const base::Position pos = w->pos[k];
+            const base::Rotation rot = w->rot[k];
+            const Velocity vel = w->vel[k];
+            const xpbd::SubstepPrevState prev = w->prev[k];
+            const xpbd::PreSolvePositional pre_pos = w->prePos[k];
+            const xpbd::PreSolveVelocity pre_vel = w->preVel[k];
+            mwhip::storeGlobal(col_pos + loc.row, pos);
+            mwhip::storeGlobal(col_rot + loc.row, rot);
+            mwhip::storeGlobal(col_vel + loc.row, vel);
+            mwhip::storeGlobal(col_prev + loc.row, prev);
+            mwhip::storeGlobal(col_pre_pos + loc.row, pre_pos);
+            mwhip::storeGlobal(col_pre_vel + loc.row, pre_vel);
+        }
+#endif
         // ---- leaf boxes + refit (what setupPostIntegrationTasks's node does:
         // reference broadphase.cpp updateLeafPositionsEntry + refitEntry) -------
         if ((params.foldPairs & 2) != 0) {
@@ -2725,8 +2763,12 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                     broadphase::LeafID { (int32_t)w->leafOf[k] }, w->pos[k],
                     w->rot[k], w->scale[k], w->vel[k].linear, obj_aabb);
             }
+            wave::phaseFence();
         }
-        wave::phaseFence();
+        // (the stores are not waited for: nothing of this job reads them, the
+        // next job's first wait -- or the end of the kernel -- covers them, and
+        // the block is only rewritten by this wavefront's own later LDS writes)
+        __builtin_amdgcn_wave_barrier();
         PHYS_PROF(7);
 
         // what this world cost: the wavefront's time, shared out between its two
