@@ -231,9 +231,27 @@ MADRONA_HD inline bool traceRayIntoConvexPolyhedron(
 
     math::Vector3 closest_normal = math::Vector3::zero();
 
+    // The planes a batch at a time, all loads of a batch on their way before
+    // the first plane is clipped against (a cube is one batch): fetched where
+    // they are used -- through a generic pointer, between the early exits --
+    // every plane was a round trip of its own, and the clip of a six-sided box
+    // six L2 latencies in a row with nothing else for the lane to do.
     const CountT num_faces = (CountT)convex_mesh.numFaces;
-    for (CountT face_idx = 0; face_idx < num_faces; face_idx++) {
-        geo::Plane plane = convex_mesh.facePlanes[face_idx];
+    const geo::Plane *face_planes = convex_mesh.facePlanes;
+    constexpr CountT plane_batch = 6;
+    for (CountT first_face = 0; first_face < num_faces; first_face += plane_batch) {
+    geo::Plane batch_planes[plane_batch];
+MADRONA_UNROLL
+    for (CountT j = 0; j < plane_batch; j++) {
+        const CountT f = first_face + j < num_faces ? first_face + j : num_faces - 1;
+        batch_planes[j] = mwhip::loadGlobal(face_planes + f);
+    }
+MADRONA_UNROLL
+    for (CountT j = 0; j < plane_batch; j++) {
+        if (first_face + j >= num_faces) {
+            break;
+        }
+        const geo::Plane plane = batch_planes[j];
 
         float denom = dot(plane.normal, ray_d);
         float neg_dist = plane.d - dot(plane.normal, ray_o);
@@ -260,6 +278,7 @@ MADRONA_HD inline bool traceRayIntoConvexPolyhedron(
                 return false;
             }
         }
+    }
     }
 
     if (closest_normal.x == 0 && closest_normal.y == 0 &&
@@ -293,8 +312,18 @@ BVH::RayLeaf BVH::rayLeaf(int32_t leaf_idx, math::Vector3 world_ray_o) const
 {
     using namespace math;
 
-    base::ObjectID obj_id = leaf_obj_ids_[leaf_idx];
-    LeafTransform leaf_txfm = leaf_transforms_[leaf_idx];
+    // (global loads, the independent ones together: mwhip::loadGlobal)
+    const ObjectManager *obj_mgr = mwhip::loadGlobal(&obj_mgr_);
+    const base::ObjectID *leaf_obj_ids = mwhip::loadGlobal(&leaf_obj_ids_);
+    const LeafTransform *leaf_transforms = mwhip::loadGlobal(&leaf_transforms_);
+    const AABB *leaf_aabbs = mwhip::loadGlobal(&leaf_aabbs_);
+    const uint32_t *prim_offsets =
+        mwhip::loadGlobal(&obj_mgr->rigidBodyPrimitiveOffsets);
+    const uint32_t *prim_counts =
+        mwhip::loadGlobal(&obj_mgr->rigidBodyPrimitiveCounts);
+    base::ObjectID obj_id = mwhip::loadGlobal(leaf_obj_ids + leaf_idx);
+    LeafTransform leaf_txfm = mwhip::loadGlobal(leaf_transforms + leaf_idx);
+    const AABB leaf_box = mwhip::loadGlobal(leaf_aabbs + leaf_idx);
 
     Quat rot_to_local = leaf_txfm.rot.inv();
 
@@ -305,9 +334,9 @@ BVH::RayLeaf BVH::rayLeaf(int32_t leaf_idx, math::Vector3 world_ray_o) const
 
     return RayLeaf {
         leaf_txfm.rot, leaf_txfm.scale, obj_ray_o,
-        (int32_t)obj_mgr_->rigidBodyPrimitiveOffsets[obj_id.idx],
-        (int32_t)obj_mgr_->rigidBodyPrimitiveCounts[obj_id.idx],
-        leaf_aabbs_[leaf_idx], leaf_idx,
+        (int32_t)mwhip::loadGlobal(prim_offsets + obj_id.idx),
+        (int32_t)mwhip::loadGlobal(prim_counts + obj_id.idx),
+        leaf_box, leaf_idx,
     };
 }
 
@@ -347,24 +376,33 @@ bool BVH::traceRayIntoLeaf(const RayLeaf &leaf,
     CountT prim_offset = (CountT)leaf.primOffset;
     CountT num_prims = (CountT)leaf.numPrims;
 
+    // (the primitive's box and its header in one round of loads, the planes of
+    // a hull in the next: traceRayIntoConvexPolyhedron)
+    const ObjectManager *obj_mgr = mwhip::loadGlobal(&obj_mgr_);
+    const AABB *prim_aabbs = mwhip::loadGlobal(&obj_mgr->primitiveAABBs);
+    const CollisionPrimitive *prims =
+        mwhip::loadGlobal(&obj_mgr->collisionPrimitives);
+
     bool hit_leaf = false;
     for (CountT i = 0; i < num_prims; i++) {
         CountT prim_idx = prim_offset + i;
 
-        AABB prim_aabb = obj_mgr_->primitiveAABBs[prim_idx];
+        AABB prim_aabb = mwhip::loadGlobal(prim_aabbs + prim_idx);
+        const CollisionPrimitive *prim = prims + prim_idx;
+        const CollisionPrimitive::Type prim_type = mwhip::loadGlobal(&prim->type);
+        // (the bytes of a hull whatever the type: only read if it is one)
+        const geo::HalfEdgeMesh prim_mesh =
+            mwhip::loadGlobal(&prim->hull.halfEdgeMesh);
         if (!prim_aabb.rayIntersects(obj_ray_o, inv_obj_ray_d, 0.f, t_max)) {
             continue;
         }
 
-        const CollisionPrimitive *prim =
-            &obj_mgr_->collisionPrimitives[prim_idx];
-
         bool hit_prim = false;
-        if (prim->type == CollisionPrimitive::Type::Hull) {
+        if (prim_type == CollisionPrimitive::Type::Hull) {
             hit_prim = detail::traceRayIntoConvexPolyhedron(
-                prim->hull.halfEdgeMesh, obj_ray_o, obj_ray_d, t_min, t_max,
+                prim_mesh, obj_ray_o, obj_ray_d, t_min, t_max,
                 hit_t, &obj_hit_normal);
-        } else if (prim->type == CollisionPrimitive::Type::Plane) {
+        } else if (prim_type == CollisionPrimitive::Type::Plane) {
             hit_prim = detail::traceRayIntoPlane(
                 obj_ray_o, obj_ray_d, t_min, t_max, hit_t, &obj_hit_normal);
         }   // spheres cannot be ray cast (the reference asserts)
@@ -407,7 +445,8 @@ Entity BVH::traceRay(math::Vector3 o,
 
         if (leaf_hit) {
             t_max = hit_t;
-            closest_hit_entity = leaf_entities_[leaf_idx];
+            closest_hit_entity =
+                mwhip::loadGlobal(mwhip::loadGlobal(&leaf_entities_) + leaf_idx);
             closest_hit_normal = leaf_hit_normal;
         }
     };
@@ -440,6 +479,8 @@ Entity BVH::traceRay(math::Vector3 o,
         // A wave then takes as many leaf-test steps as its busiest ray has
         // candidates (a handful), not one per leaf that any of its rays touches.
         const int32_t n = num_tree_leaves_;
+        const int32_t *traversal_order = mwhip::loadGlobal(&dfs_leaves_);
+        const AABB *leaf_boxes = mwhip::loadGlobal(&leaf_aabbs_);
 
 #if defined(__HIP_DEVICE_COMPILE__)
         // Rays that share their origin: the lanes of a half-wavefront that are
@@ -505,7 +546,8 @@ Entity BVH::traceRay(math::Vector3 o,
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_wave_barrier();
                 for (int32_t j = rank; j < window; j += num_active) {
-                    group_leaves[j] = rayLeaf(dfs_leaves_[base + j], o);
+                    group_leaves[j] = rayLeaf(
+                        mwhip::loadGlobal(traversal_order + base + j), o);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_wave_barrier();
@@ -537,12 +579,12 @@ MADRONA_UNROLL
 MADRONA_UNROLL
                 for (int32_t k = 0; k < group; k++) {
                     const int32_t j = g + k < window ? g + k : window - 1;
-                    leaf[k] = dfs_leaves_[base + j];
+                    leaf[k] = mwhip::loadGlobal(traversal_order + base + j);
                 }
                 AABB box[group];
 MADRONA_UNROLL
                 for (int32_t k = 0; k < group; k++) {
-                    box[k] = leaf_aabbs_[leaf[k]];
+                    box[k] = mwhip::loadGlobal(leaf_boxes + leaf[k]);
                 }
 MADRONA_UNROLL
                 for (int32_t k = 0; k < group; k++) {
@@ -570,10 +612,14 @@ MADRONA_UNROLL
                     continue;
                 }
 #endif
-                const int32_t leaf_idx = dfs_leaves_[base + j];
-                if (t_max == mask_t_max ||
-                        leaf_aabbs_[leaf_idx].rayIntersects(o, inv_d, 0.f,
-                                                            t_max)) {
+                const int32_t leaf_idx =
+                    mwhip::loadGlobal(traversal_order + base + j);
+                bool visit = t_max == mask_t_max;
+                if (!visit) {
+                    AABB own_box = mwhip::loadGlobal(leaf_boxes + leaf_idx);
+                    visit = own_box.rayIntersects(o, inv_d, 0.f, t_max);
+                }
+                if (visit) {
                     visitLeaf(leaf_idx, nullptr);
                 }
             }

@@ -1174,6 +1174,11 @@ ESCPHYS_SYSTEM_IO(lidarSystem,
                                         escphys::consts::numLidarSamples>>,
     escphys_io::Writes<escphys::Lidar>);
 #undef ESCPHYS_SYSTEM_IO
+// (131 registers with the leaf tests' loads batched -- one too many for the
+// four wavefronts per SIMD the ray systems want:
+// profiles/r03_lidar_occupancy_variants.jsonl)
+template <> inline constexpr unsigned
+    madrona::mwhip::systemWavesPerSIMD<escphys::lidarSystem> = 4;
 namespace escphys {
 #endif
 

@@ -958,6 +958,13 @@ inline void lidarSystem(Engine &ctx,
 }
 template <> inline constexpr unsigned
     madrona::mwhip::systemWavesPerSIMD<hideseek::lockSystem> = 4;
+// (the ray systems: 131 / 133 registers with the leaf tests' loads batched
+// -- one too many for four wavefronts per SIMD, which is what they want:
+// profiles/r03_lidar_occupancy_variants.jsonl)
+template <> inline constexpr unsigned
+    madrona::mwhip::systemWavesPerSIMD<hideseek::lidarSystem> = 4;
+template <> inline constexpr unsigned
+    madrona::mwhip::systemWavesPerSIMD<hideseek::visibilitySystem> = 4;
 namespace hideseek {
 #endif
 
