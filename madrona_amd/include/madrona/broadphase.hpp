@@ -376,6 +376,8 @@ private:
     MADRONA_HD inline int32_t midpointSplit(int32_t base, int32_t num_elems);
     MADRONA_HD inline void growAncestors(int32_t child_idx,
                                          const math::AABB &leaf_aabb);
+    MADRONA_HD inline void growAncestors(Node *nodes, int32_t child_idx,
+                                         const math::AABB &leaf_aabb);
     MADRONA_HD inline void rebuild();
     MADRONA_HD inline void rebuild(RebuildStackEntry *stack);
 #if defined(__HIPCC__)

@@ -271,78 +271,107 @@ void BVH::updateLeafAndRefit(LeafID leaf_id,
                              const math::Vector3 &linear_vel,
                              const math::AABB &obj_aabb)
 {
+    using mwhip::loadGlobal;
+    using mwhip::storeGlobal;
     const int32_t leaf = leaf_id.id;
-    const bool refit = !force_rebuild_;
+
+    // (loads through the global address space, a round at a time: what the
+    // object holds; the leaf's parent; its slot in the parent node.  Through
+    // `this` every member and every element was a round trip of its own.)
+    const bool refit = !mwhip::loadGlobalBool(&force_rebuild_);
+    uint32_t *leaf_parents = loadGlobal(&leaf_parents_);
+    Node *nodes = loadGlobal(&nodes_);
+    math::AABB *leaf_aabbs = loadGlobal(&leaf_aabbs_);
+    LeafTransform *leaf_transforms = loadGlobal(&leaf_transforms_);
+    int32_t *sorted_leaves = loadGlobal(&sorted_leaves_);
+    const float velocity_expansion = loadGlobal(&leaf_velocity_expansion_);
+    const float accel_expansion = loadGlobal(&leaf_accel_expansion_);
 
     int32_t node_idx = 0;
     int32_t sub_idx = 0;
     math::AABB slot = math::AABB::invalid();
     if (refit) {
-        uint32_t leaf_parent = leaf_parents_[leaf];
+        uint32_t leaf_parent = loadGlobal(leaf_parents + leaf);
         node_idx = (int32_t)(leaf_parent >> 2);
         sub_idx = (int32_t)(leaf_parent & 3u);
-        slot = nodes_[node_idx].bounds(sub_idx);
+        const Node *node = nodes + node_idx;
+        slot = math::AABB {
+            { loadGlobal(&node->minX[sub_idx]), loadGlobal(&node->minY[sub_idx]),
+              loadGlobal(&node->minZ[sub_idx]) },
+            { loadGlobal(&node->maxX[sub_idx]), loadGlobal(&node->maxY[sub_idx]),
+              loadGlobal(&node->maxZ[sub_idx]) } };
     }
 
     math::AABB world_aabb = obj_aabb.applyTRS(pos, rot, scale);
     math::AABB leaf_aabb = detail::expandAABBWithMotion(
-        world_aabb, linear_vel, leaf_velocity_expansion_, leaf_accel_expansion_);
+        world_aabb, linear_vel, velocity_expansion, accel_expansion);
 
-    leaf_aabbs_[leaf] = leaf_aabb;
-    leaf_transforms_[leaf] = LeafTransform { pos, rot, scale };
-    sorted_leaves_[leaf] = leaf;
+    storeGlobal(leaf_aabbs + leaf, leaf_aabb);
+    storeGlobal(leaf_transforms + leaf, LeafTransform { pos, rot, scale });
+    storeGlobal(sorted_leaves + leaf, leaf);
 
     if (!refit) {
         return;
     }
 
     // the leaf's own slot is touched by this thread only: plain stores
-    Node &leaf_node = nodes_[node_idx];
+    Node &leaf_node = nodes[node_idx];
     bool grew = false;
     if (leaf_aabb.pMin.x < slot.pMin.x) {
-        leaf_node.minX[sub_idx] = leaf_aabb.pMin.x;
+        storeGlobal(&leaf_node.minX[sub_idx], leaf_aabb.pMin.x);
         grew = true;
     }
     if (leaf_aabb.pMin.y < slot.pMin.y) {
-        leaf_node.minY[sub_idx] = leaf_aabb.pMin.y;
+        storeGlobal(&leaf_node.minY[sub_idx], leaf_aabb.pMin.y);
         grew = true;
     }
     if (leaf_aabb.pMin.z < slot.pMin.z) {
-        leaf_node.minZ[sub_idx] = leaf_aabb.pMin.z;
+        storeGlobal(&leaf_node.minZ[sub_idx], leaf_aabb.pMin.z);
         grew = true;
     }
     if (leaf_aabb.pMax.x > slot.pMax.x) {
-        leaf_node.maxX[sub_idx] = leaf_aabb.pMax.x;
+        storeGlobal(&leaf_node.maxX[sub_idx], leaf_aabb.pMax.x);
         grew = true;
     }
     if (leaf_aabb.pMax.y > slot.pMax.y) {
-        leaf_node.maxY[sub_idx] = leaf_aabb.pMax.y;
+        storeGlobal(&leaf_node.maxY[sub_idx], leaf_aabb.pMax.y);
         grew = true;
     }
     if (leaf_aabb.pMax.z > slot.pMax.z) {
-        leaf_node.maxZ[sub_idx] = leaf_aabb.pMax.z;
+        storeGlobal(&leaf_node.maxZ[sub_idx], leaf_aabb.pMax.z);
         grew = true;
     }
     if (!grew) {
         return;
     }
 
-    growAncestors(node_idx, leaf_aabb);
+    growAncestors(nodes, node_idx, leaf_aabb);
 }
 
 // Upper levels of a refit: several leaves of a world grow them concurrently.
 void BVH::growAncestors(int32_t child_idx, const math::AABB &leaf_aabb)
 {
-    int32_t node_idx = nodes_[child_idx].parentID;
+    growAncestors(mwhip::loadGlobal(&nodes_), child_idx, leaf_aabb);
+}
+
+void BVH::growAncestors(Node *nodes, int32_t child_idx,
+                        const math::AABB &leaf_aabb)
+{
+    using mwhip::loadGlobal;
+    int32_t node_idx = loadGlobal(&nodes[child_idx].parentID);
 
     while (node_idx != sentinel_) {
-        Node &node = nodes_[node_idx];
+        Node &node = nodes[node_idx];
 
+        // (which child this is, and where the walk goes next: one round)
+        const int32_t children[4] = {
+            loadGlobal(&node.children[0]), loadGlobal(&node.children[1]),
+            loadGlobal(&node.children[2]), loadGlobal(&node.children[3]) };
+        const int32_t parent = loadGlobal(&node.parentID);
         int32_t child_offset = 0;
-        for (int32_t j = 0; j < 4; j++) {
-            if (node.children[j] == child_idx) {
+        for (int32_t j = 3; j >= 0; j--) {
+            if (children[j] == child_idx) {
                 child_offset = j;
-                break;
             }
         }
 
@@ -363,7 +392,7 @@ void BVH::growAncestors(int32_t child_idx, const math::AABB &leaf_aabb)
         }
 
         child_idx = node_idx;
-        node_idx = node.parentID;
+        node_idx = parent;
     }
 }
 

@@ -290,6 +290,16 @@ MWHIP_HD inline T loadGlobal(const T *p)
 #endif
 }
 
+MWHIP_HD inline bool loadGlobalBool(const bool *p)
+{
+#if !defined(__HIP_DEVICE_COMPILE__)
+    return *p;
+#else
+    return *(const __attribute__((address_space(1))) unsigned char *)
+        (unsigned long long)p != 0;
+#endif
+}
+
 // ... and the store that goes with it (a flat_store of a value that came out of
 // LDS is held back by nothing, but the wait in front of the next flat access
 // counts it)

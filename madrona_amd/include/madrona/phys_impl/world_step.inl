@@ -1301,6 +1301,31 @@ __device__ inline void waveCopyDwords(uint32_t lane, uint32_t *dst,
     }
 }
 
+// ... from HBM (global loads, four rounds of the group in flight: the copies
+// of a primitive image are a few hundred dwords, one row of lanes at a time
+// they were a dozen L2 round trips in a row)
+template <int LPW = 64>
+__device__ inline void waveCopyDwordsGlobal(uint32_t lane, uint32_t *dst,
+                                            const uint32_t *src, uint32_t count)
+{
+    constexpr uint32_t batch = 4;
+    for (uint32_t first = lane; first < count; first += LPW * batch) {
+        uint32_t v[batch];
+#pragma unroll
+        for (uint32_t u = 0; u < batch; u++) {
+            const uint32_t i = first + u * LPW;
+            v[u] = mwhip::loadGlobal(src + (i < count ? i : first));
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < batch; u++) {
+            const uint32_t i = first + u * LPW;
+            if (i < count) {
+                dst[i] = v[u];
+            }
+        }
+    }
+}
+
 // Stages primitives [0, num_prims) of the object manager in LDS.  Returns an
 // ObjectManager whose primitive arrays point at the copies (or the original
 // when they do not fit).
@@ -1319,22 +1344,24 @@ __device__ inline ObjectManager stagePrimitives(uint32_t lane,
     // copies and a pointer fix-up instead of the walk below
     const PrimImage *image = obj_mgr.primImage;
     if (image != nullptr) {
-        const uint32_t image_prims = image->numPrims;
+        const uint32_t image_prims = mwhip::loadGlobal(&image->numPrims);
+        const uint32_t arena_used = mwhip::loadGlobal(&image->arenaUsed);
         if (image_prims >= num_prims && image_prims != 0) {
-            waveCopyDwords<LPW>(lane, (uint32_t *)w->prims,
-                (const uint32_t *)image->prims,
-                image_prims * (uint32_t)(sizeof(CollisionPrimitive) / 4));
-            waveCopyDwords<LPW>(lane, (uint32_t *)w->primAABBs,
-                (const uint32_t *)image->primAABBs,
-                image_prims * (uint32_t)(sizeof(math::AABB) / 4));
-            waveCopyDwords<LPW>(lane, w->arena, image->arena, image->arenaUsed);
+            // (the mesh offsets with the first batch of the copies)
             int32_t offsets[4] = { -1, -1, -1, -1 };
             if (lane < image_prims) {
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    offsets[i] = image->meshOffset[lane][i];
+                    offsets[i] = mwhip::loadGlobal(&image->meshOffset[lane][i]);
                 }
             }
+            waveCopyDwordsGlobal<LPW>(lane, (uint32_t *)w->prims,
+                (const uint32_t *)image->prims,
+                image_prims * (uint32_t)(sizeof(CollisionPrimitive) / 4));
+            waveCopyDwordsGlobal<LPW>(lane, (uint32_t *)w->primAABBs,
+                (const uint32_t *)image->primAABBs,
+                image_prims * (uint32_t)(sizeof(math::AABB) / 4));
+            waveCopyDwordsGlobal<LPW>(lane, w->arena, image->arena, arena_used);
             wave::phaseFence();
             if (lane < image_prims && offsets[0] >= 0) {
                 geo::HalfEdgeMesh &staged = w->prims[lane].hull.halfEdgeMesh;
@@ -1639,14 +1666,25 @@ __device__ inline void fillPhysicsFrame(EcsState *S, const PhysicsScratch *ps,
         F->worldOffsets[tid] = tbl.worldOffsets;
         F->worldCounts[tid] = tbl.worldCounts;
     }
-    if (tid == 0) {
+    // what a replay can change: whether a table awaits its sort, and where the
+    // joint rows are (the sort in front of this kernel swaps its buffers)
+    if (tid == 1) {
         uint32_t unsorted = 0;
         for (uint32_t a = 0; a < num_arch; a++) {
             unsorted |= S->tables[ps->bodyArchetypes[a]].needsSort;
         }
         F->unsorted = unsorted;
         F->numArchetypes = num_arch;
-        F->trees = state_mgr->getSingletonColumn<broadphase::BVH>();
+    }
+    if (tid == 2) {
+        F->joints =
+            (const JointConstraint *)S->tables[ps->jointArchetype].columns[2];
+    }
+    // what it cannot -- the singleton columns (never sorted), the tables' world
+    // ranges, the entity store (addresses are reserved once, tables grow in
+    // place), the object manager -- is a chain of six dependent loads: followed
+    // on the first replay only (the frame starts out zeroed)
+    if (tid == 0 && F->trees == nullptr) {
         F->systemStates = state_mgr->getSingletonColumn<PhysicsSystemState>();
         F->objectData = state_mgr->getSingletonColumn<ObjectData>();
         const ObjectManager *mgr = F->objectData[0].mgr;
@@ -1655,8 +1693,8 @@ __device__ inline void fillPhysicsFrame(EcsState *S, const PhysicsScratch *ps,
         const TableHdr &joint_tbl = S->tables[ps->jointArchetype];
         F->jointOffsets = joint_tbl.worldOffsets;
         F->jointCounts = joint_tbl.worldCounts;
-        F->joints = (const JointConstraint *)joint_tbl.columns[2];
         F->entities = mwhip::entitiesOf(S);
+        F->trees = state_mgr->getSingletonColumn<broadphase::BVH>();
     }
 }
 
@@ -2194,10 +2232,16 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
         // collects many more candidates than contacts: what does not fit the
         // LDS list spills into the world's segment of the HBM candidate
         // scratch (4-byte records).
+        // (the scratch block's words never change: invariant loads, which the
+        // compiler may issue at the top of the kernel instead of here, two
+        // dependent round trips behind the block's last store)
+        const uint32_t candidates_per_world =
+            mwhip::loadInvariant(&ps->candidatesPerWorld);
         WaveCandidate *spilled_candidates = (WaveCandidate *)(
-            ps->worldCandidates + (size_t)world * ps->candidatesPerWorld);
+            mwhip::loadInvariant(&ps->worldCandidates) +
+            (size_t)world * candidates_per_world);
         const uint32_t candidate_capacity = (uint32_t)Block::maxCandidates +
-            ps->candidatesPerWorld *
+            candidates_per_world *
                 (uint32_t)(sizeof(CandidateCollision) / sizeof(WaveCandidate));
         uint32_t num_candidates = 0;
         for (int32_t chunk = 0; chunk < num_bodies; chunk += LPW) {

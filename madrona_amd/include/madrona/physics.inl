@@ -1157,8 +1157,12 @@ inline void updateLeafAndRefitEntry(Context &ctx,
                                     const Velocity &vel)
 {
     BVH &bvh = ctx.singleton<BVH>();
-    ObjectManager &obj_mgr = *ctx.singleton<ObjectData>().mgr;
-    math::AABB obj_aabb = obj_mgr.rigidBodyAABBs[obj_id.idx];
+    // (global loads: the chain manager -> table -> box runs next to the
+    // tree's own rounds in updateLeafAndRefit instead of in front of them)
+    const ObjectManager *obj_mgr =
+        mwhip::loadGlobal(&ctx.singleton<ObjectData>().mgr);
+    const math::AABB *body_aabbs = mwhip::loadGlobal(&obj_mgr->rigidBodyAABBs);
+    math::AABB obj_aabb = mwhip::loadGlobal(body_aabbs + obj_id.idx);
 
     bvh.updateLeafAndRefit(leaf_id, pos, rot, scale, vel.linear, obj_aabb);
 }

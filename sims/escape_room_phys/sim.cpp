@@ -1179,6 +1179,11 @@ ESCPHYS_SYSTEM_IO(lidarSystem,
 // profiles/r03_lidar_occupancy_variants.jsonl)
 template <> inline constexpr unsigned
     madrona::mwhip::systemWavesPerSIMD<escphys::lidarSystem> = 4;
+#ifdef SIM_WAVE_API
+// (131 registers as well; a wavefront per world of dependent loads: 50 -> 44 us)
+template <> inline constexpr unsigned
+    madrona::mwhip::systemWavesPerSIMD<escphys::grabQuerySystem> = 4;
+#endif
 namespace escphys {
 #endif
 
