@@ -494,6 +494,72 @@ inline void grabQuerySystem(Engine &ctx, LevelState &)
 }
 #endif
 
+#ifdef SIM_WAVE_API
+// (the joint of attachGrab with the cube's pose already read)
+ESCPHYS_COLD static void attachGrabAt(Engine &ctx, Entity e, Entity grab_entity,
+                                      Vector3 pos, Quat rot, Vector3 other_pos,
+                                      Quat other_rot, GrabState &grab)
+{
+    Vector3 r1 = Vector3 { 0.f, 1.25f, 0.f };
+    Vector3 r2 = Vector3::zero();
+    Quat attach1 { 1, 0, 0, 0 };
+    Quat attach2 = (other_rot.inv() * rot).normalize();
+    float separation = (other_pos - pos).length() - 1.25f;
+
+    grab.constraintEntity = PhysicsSystem::makeFixedJoint(
+        ctx, e, grab_entity, attach1, attach2, r1, r2, separation);
+}
+
+// One lane per world, 128 wavefronts on the whole chip: the system costs what
+// its longest chain of dependent loads costs (a cold miss is ~1.2 us), and read
+// where it is used -- agent after agent, behind each `if` -- everything an agent
+// may need was ~11 of them per agent.  Nothing the first agent's grab or release
+// writes (its own GrabState, a joint row) is read for the second: both agents'
+// handles, rows and their targets' poses are fetched up front, in three rounds.
+inline void grabSystem(Engine &ctx, LevelState &)
+{
+    Sim &sim = ctx.data();
+
+    Entity agent[consts::numAgents];
+    Entity target[consts::numAgents];
+    for (int32_t i = 0; i < consts::numAgents; i++) {
+        agent[i] = sim.agents[i];
+        target[i] = sim.grabTargets[i];
+    }
+    int32_t grab_action[consts::numAgents];
+    GrabState *grab[consts::numAgents];
+    Entity held[consts::numAgents];
+    Vector3 pos[consts::numAgents];
+    Quat rot[consts::numAgents];
+    Vector3 target_pos[consts::numAgents];
+    Quat target_rot[consts::numAgents];
+    for (int32_t i = 0; i < consts::numAgents; i++) {
+        // (no target: the agent's own row, read and not used)
+        const Entity other = target[i] != Entity::none() ? target[i] : agent[i];
+        grab_action[i] = ctx.get<Action>(agent[i]).grab;
+        grab[i] = &ctx.get<GrabState>(agent[i]);
+        held[i] = grab[i]->constraintEntity;
+        pos[i] = ctx.get<Position>(agent[i]);
+        rot[i] = ctx.get<Rotation>(agent[i]);
+        target_pos[i] = ctx.get<Position>(other);
+        target_rot[i] = ctx.get<Rotation>(other);
+    }
+
+    for (int32_t i = 0; i < consts::numAgents; i++) {
+        if (grab_action[i] == 0) {
+            continue;
+        }
+        if (held[i] != Entity::none()) {
+            releaseGrab(ctx, held[i], *grab[i]);
+            continue;
+        }
+        if (target[i] != Entity::none()) {
+            attachGrabAt(ctx, agent[i], target[i], pos[i], rot[i], target_pos[i],
+                         target_rot[i], *grab[i]);
+        }
+    }
+}
+#else
 inline void grabSystem(Engine &ctx, LevelState &)
 {
     Sim &sim = ctx.data();
@@ -539,6 +605,7 @@ inline void grabSystem(Engine &ctx, LevelState &)
         }
     }
 }
+#endif
 
 // agents stop dead every step: removes the need for drag
 inline void agentZeroVelSystem(Engine &,
