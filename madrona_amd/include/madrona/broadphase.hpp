@@ -203,6 +203,41 @@ public:
             mwhip::loadGlobal(&tree->num_leaves_),
         };
     }
+    // What updateLeafAndRefit reads of the object before it touches a leaf; a
+    // caller that updates many leaves of one tree loads it once, and can put
+    // the leaf's own loads (parent, slot) next to loads of its own
+    // (physicsStepLdsKernel's epilogue).
+    struct RefitView {
+        uint32_t *leafParents;
+        void *nodes;
+        math::AABB *leafAABBs;
+        void *leafTransforms;
+        int32_t *sortedLeaves;
+        float velocityExpansion;
+        float accelExpansion;
+        bool refit;         // false: a rebuild is pending, boxes are not grown
+    };
+    MADRONA_HD static inline RefitView loadRefitView(const BVH *tree)
+    {
+        return RefitView {
+            mwhip::loadGlobal(&tree->leaf_parents_),
+            mwhip::loadGlobal(&tree->nodes_),
+            mwhip::loadGlobal(&tree->leaf_aabbs_),
+            mwhip::loadGlobal(&tree->leaf_transforms_),
+            mwhip::loadGlobal(&tree->sorted_leaves_),
+            mwhip::loadGlobal(&tree->leaf_velocity_expansion_),
+            mwhip::loadGlobal(&tree->leaf_accel_expansion_),
+            !mwhip::loadGlobalBool(&tree->force_rebuild_),
+        };
+    }
+    // leaf_parent = view.leafParents[leaf], slot = loadSlotBounds(view.nodes,
+    // leaf_parent) (anything if !view.refit)
+    MADRONA_HD static inline void applyLeafUpdate(
+        const RefitView &view, int32_t leaf, uint32_t leaf_parent,
+        math::AABB slot, const math::Vector3 &pos, const math::Quat &rot,
+        const math::Diag3x3 &scale, const math::Vector3 &linear_vel,
+        const math::AABB &obj_aabb);
+
     // == leafSlotBounds(leaf) with parent = view.leafParents[leaf]
     MADRONA_HD static inline math::AABB loadSlotBounds(const void *nodes,
                                                        uint32_t parent)
@@ -376,8 +411,8 @@ private:
     MADRONA_HD inline int32_t midpointSplit(int32_t base, int32_t num_elems);
     MADRONA_HD inline void growAncestors(int32_t child_idx,
                                          const math::AABB &leaf_aabb);
-    MADRONA_HD inline void growAncestors(Node *nodes, int32_t child_idx,
-                                         const math::AABB &leaf_aabb);
+    MADRONA_HD static inline void growAncestors(Node *nodes, int32_t child_idx,
+                                                const math::AABB &leaf_aabb);
     MADRONA_HD inline void rebuild();
     MADRONA_HD inline void rebuild(RebuildStackEntry *stack);
 #if defined(__HIPCC__)

@@ -271,50 +271,48 @@ void BVH::updateLeafAndRefit(LeafID leaf_id,
                              const math::Vector3 &linear_vel,
                              const math::AABB &obj_aabb)
 {
-    using mwhip::loadGlobal;
-    using mwhip::storeGlobal;
     const int32_t leaf = leaf_id.id;
 
     // (loads through the global address space, a round at a time: what the
     // object holds; the leaf's parent; its slot in the parent node.  Through
     // `this` every member and every element was a round trip of its own.)
-    const bool refit = !mwhip::loadGlobalBool(&force_rebuild_);
-    uint32_t *leaf_parents = loadGlobal(&leaf_parents_);
-    Node *nodes = loadGlobal(&nodes_);
-    math::AABB *leaf_aabbs = loadGlobal(&leaf_aabbs_);
-    LeafTransform *leaf_transforms = loadGlobal(&leaf_transforms_);
-    int32_t *sorted_leaves = loadGlobal(&sorted_leaves_);
-    const float velocity_expansion = loadGlobal(&leaf_velocity_expansion_);
-    const float accel_expansion = loadGlobal(&leaf_accel_expansion_);
-
-    int32_t node_idx = 0;
-    int32_t sub_idx = 0;
+    const RefitView view = loadRefitView(this);
+    uint32_t leaf_parent = 0;
     math::AABB slot = math::AABB::invalid();
-    if (refit) {
-        uint32_t leaf_parent = loadGlobal(leaf_parents + leaf);
-        node_idx = (int32_t)(leaf_parent >> 2);
-        sub_idx = (int32_t)(leaf_parent & 3u);
-        const Node *node = nodes + node_idx;
-        slot = math::AABB {
-            { loadGlobal(&node->minX[sub_idx]), loadGlobal(&node->minY[sub_idx]),
-              loadGlobal(&node->minZ[sub_idx]) },
-            { loadGlobal(&node->maxX[sub_idx]), loadGlobal(&node->maxY[sub_idx]),
-              loadGlobal(&node->maxZ[sub_idx]) } };
+    if (view.refit) {
+        leaf_parent = mwhip::loadGlobal(view.leafParents + leaf);
+        slot = loadSlotBounds(view.nodes, leaf_parent);
     }
+    applyLeafUpdate(view, leaf, leaf_parent, slot, pos, rot, scale, linear_vel,
+                    obj_aabb);
+}
+
+void BVH::applyLeafUpdate(const RefitView &view, int32_t leaf,
+                          uint32_t leaf_parent, math::AABB slot,
+                          const math::Vector3 &pos, const math::Quat &rot,
+                          const math::Diag3x3 &scale,
+                          const math::Vector3 &linear_vel,
+                          const math::AABB &obj_aabb)
+{
+    using mwhip::storeGlobal;
 
     math::AABB world_aabb = obj_aabb.applyTRS(pos, rot, scale);
     math::AABB leaf_aabb = detail::expandAABBWithMotion(
-        world_aabb, linear_vel, velocity_expansion, accel_expansion);
+        world_aabb, linear_vel, view.velocityExpansion, view.accelExpansion);
 
-    storeGlobal(leaf_aabbs + leaf, leaf_aabb);
-    storeGlobal(leaf_transforms + leaf, LeafTransform { pos, rot, scale });
-    storeGlobal(sorted_leaves + leaf, leaf);
+    storeGlobal(view.leafAABBs + leaf, leaf_aabb);
+    storeGlobal((LeafTransform *)view.leafTransforms + leaf,
+                LeafTransform { pos, rot, scale });
+    storeGlobal(view.sortedLeaves + leaf, leaf);
 
-    if (!refit) {
+    if (!view.refit) {
         return;
     }
 
     // the leaf's own slot is touched by this thread only: plain stores
+    const int32_t node_idx = (int32_t)(leaf_parent >> 2);
+    const int32_t sub_idx = (int32_t)(leaf_parent & 3u);
+    Node *nodes = (Node *)view.nodes;
     Node &leaf_node = nodes[node_idx];
     bool grew = false;
     if (leaf_aabb.pMin.x < slot.pMin.x) {

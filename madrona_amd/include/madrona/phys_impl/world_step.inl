@@ -2742,30 +2742,24 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
         // column was: load the column address, wait -- for the stores before
         // it as well, they share the counter --, store: 14 us per pair of
         // worlds in the phase profile, now 2.)
-#ifdef MADRONA_PHYS_STORE_THROUGH_CTX
-        // (measurement builds: rounds 1-3)
-        for (int32_t k = (int32_t)lane; k < num_bodies; k += LPW) {
-            const Loc loc = w->bodyLoc[k];
-            const base::Position pos = w->pos[k];
-            const base::Rotation rot = w->rot[k];
-            const Velocity vel = w->vel[k];
-            const xpbd::SubstepPrevState prev = w->prev[k];
-            const xpbd::PreSolvePositional pre_pos = w->prePos[k];
-            const xpbd::PreSolveVelocity pre_vel = w->preVel[k];
-            ctx.getDirect<base::Position>(RGDCols::Position, loc) = pos;
-            ctx.getDirect<base::Rotation>(RGDCols::Rotation, loc) = rot;
-            ctx.getDirect<Velocity>(RGDCols::Velocity, loc) = vel;
-            ctx.getDirect<xpbd::SubstepPrevState>(
-                xpbd::XPBDCols::SubstepPrevState, loc) = prev;
-            ctx.getDirect<xpbd::PreSolvePositional>(
-                xpbd::XPBDCols::PreSolvePositional, loc) = pre_pos;
-            ctx.getDirect<xpbd::PreSolveVelocity>(
-                xpbd::XPBDCols::PreSolveVelocity, loc) = pre_vel;
+        // With the leaf update + refit of the world folded in (what
+        // setupPostIntegrationTasks's node does -- reference broadphase.cpp
+        // updateLeafPositionsEntry + refitEntry --, PhysicsStepParams::
+        // foldPairs bit 1): its loads ride on the same rounds -- the tree's
+        // members with the column addresses, the body's object id and its
+        // leaf's parent next, the object's box and the leaf's slot last.
+        const bool fold_refit = (params.foldPairs & 2) != 0;
+        broadphase::BVH::RefitView tree_view {};
+        const math::AABB *body_aabbs = nullptr;
+        if (fold_refit) {
+            tree_view = broadphase::BVH::loadRefitView(frame != nullptr ?
+                mwhip::loadInvariant(&frame->trees) + world :
+                &ctx.singleton<broadphase::BVH>());
+            body_aabbs = mwhip::loadGlobal(&hbm_mgr->rigidBodyAABBs);
         }
-        wave::phaseFence();
-#else
         for (int32_t k = (int32_t)lane; k < num_bodies; k += LPW) {
             const Loc loc = w->bodyLoc[k];
+            const int32_t leaf = (int32_t)w->leafOf[k];
             const TableHdr &tbl = mwhip::tablesOf(S)[loc.archetype];
             base::Position *col_pos = (base::Position *)
                 mwhip::loadGlobal(&tbl.columns[RGDCols::Position]);
@@ -2779,7 +2773,17 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                 mwhip::loadGlobal(&tbl.columns[xpbd::XPBDCols::PreSolvePositional]);
             xpbd::PreSolveVelocity *col_pre_vel = (xpbd::PreSolveVelocity *)
                 mwhip::loadGlobal(&tbl.columns[xpbd::XPBDCols::PreSolveVelocity]);
+            const base::ObjectID *col_obj = (const base::ObjectID *)
+                mwhip::loadGlobal(&tbl.columns[RGDCols::ObjectID]);
             roundIssued();
+            base::ObjectID obj_id { 0 };
+            uint32_t leaf_parent = 0;
+            if (fold_refit) {
+                obj_id = mwhip::loadGlobal(col_obj + loc.row);
+                if (tree_view.refit) {
+                    leaf_parent = mwhip::loadGlobal(tree_view.leafParents + leaf);
+                }
+            }
             const base::Position pos = w->pos[k];
             const base::Rotation rot = w->rot[k];
             const Velocity vel = w->vel[k];
@@ -2792,22 +2796,17 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
             mwhip::storeGlobal(col_prev + loc.row, prev);
             mwhip::storeGlobal(col_pre_pos + loc.row, pre_pos);
             mwhip::storeGlobal(col_pre_vel + loc.row, pre_vel);
-        }
-#endif
-        // ---- leaf boxes + refit (what setupPostIntegrationTasks's node does:
-        // reference broadphase.cpp updateLeafPositionsEntry + refitEntry) -------
-        if ((params.foldPairs & 2) != 0) {
-            broadphase::BVH &world_bvh = ctx.singleton<broadphase::BVH>();
-            for (int32_t k = (int32_t)lane; k < num_bodies; k += LPW) {
-                const Loc loc = w->bodyLoc[k];
-                const base::ObjectID obj_id =
-                    ctx.getDirect<base::ObjectID>(RGDCols::ObjectID, loc);
-                const math::AABB obj_aabb = hbm_obj_mgr.rigidBodyAABBs[obj_id.idx];
-                world_bvh.updateLeafAndRefit(
-                    broadphase::LeafID { (int32_t)w->leafOf[k] }, w->pos[k],
-                    w->rot[k], w->scale[k], w->vel[k].linear, obj_aabb);
+            if (fold_refit) {
+                const math::AABB obj_aabb =
+                    mwhip::loadGlobal(body_aabbs + obj_id.idx);
+                math::AABB slot = math::AABB::invalid();
+                if (tree_view.refit) {
+                    slot = broadphase::BVH::loadSlotBounds(tree_view.nodes,
+                                                           leaf_parent);
+                }
+                broadphase::BVH::applyLeafUpdate(tree_view, leaf, leaf_parent,
+                    slot, pos, rot, w->scale[k], vel.linear, obj_aabb);
             }
-            wave::phaseFence();
         }
         // (the stores are not waited for: nothing of this job reads them, the
         // next job's first wait -- or the end of the kernel -- covers them, and

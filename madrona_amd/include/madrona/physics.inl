@@ -2256,15 +2256,19 @@ MADRONA_HOST_API inline TaskGraphNodeID setupPhysicsStepTasks(
     const int32_t fold_pairs = lanes_per_world == 32 && world_order != nullptr &&
         order_env != nullptr && atoi(order_env) >= 2 ? 1 : 0;
     // MADRONA_MWHIP_PHYS_REFIT=1: the leaf update + refit that follows the step
-    // (setupPostIntegrationTasks: a ParallelFor over all bodies, ~27 us) runs in
+    // (setupPostIntegrationTasks: a ParallelFor over all bodies, 23 us) runs in
     // the step kernel's epilogue instead -- the wavefront still holds every pose
-    // of its world.  Built for the round-3 verdict and measured
-    // (profiles/r04_phys_variants.jsonl): one launch less, but the epilogue walks
-    // leaf -> parent -> slot with atomics from ONE wavefront per SIMD, 25 K cycles
-    // per world-step in the phase profile: the step kernel grows by 33 us for
-    // the 27 us node it saves (Escape Room 1.2522 -> 1.2549 ms per step,
-    // Hide-and-Seek 1.5069 -> 1.5158).  Off by default; what would make it pay
-    // is refitting a copy of the world's nodes in LDS without atomics.
+    // of its world, and the loads the refit needs ride on the rounds the
+    // epilogue makes anyway (the tree's members with the column addresses,
+    // object id and leaf parent next, object box and slot last).  Measured
+    // twice (profiles/r04_phys_variants.jsonl).  With the loads made where they
+    // were used -- nine round trips in a row from ONE wavefront per SIMD -- the
+    // step kernel grew by 33 us for the 27 us node it saved.  With them
+    // batched: + 19 us for 23.6 in the Escape Room (1.1775 -> 1.1687 ms per
+    // step), + 37 us for 24.5 in Hide-and-Seek (1.4024 -> 1.4121: more bodies
+    // move, more leaves outgrow their slot, and the walk up the tree is
+    // atomics one level at a time with nothing to overlap them).  Off by
+    // default.
     const char *refit_env = getenv("MADRONA_MWHIP_PHYS_REFIT");
     const int32_t refit_in_step = max_bodies != 0 && refit_env != nullptr &&
         atoi(refit_env) != 0 ? 2 : 0;

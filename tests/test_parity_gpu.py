@@ -113,6 +113,29 @@ def test_escape_room_physics_kernel_variants(built, monkeypatch, max_bodies):
     assert not probs, (step, probs[:3])
 
 
+@pytest.mark.parametrize("switch,value,lanes", [
+    ("MADRONA_MWHIP_PHYS_FRAME", "0", "32"),     # every wavefront walks the tables
+    ("MADRONA_MWHIP_PHYS_REFIT", "1", "32"),     # leaf update + refit in the epilogue
+    ("MADRONA_MWHIP_PHYS_REFIT", "1", "64"),
+    ("MADRONA_MWHIP_PHYS_PERSIST", "1", "32"),   # persistent wavefronts + look-ahead
+    ("MADRONA_MWHIP_PHYS_ORDER", "0", "32"),     # no order kernel (hence no frame)
+    ("MADRONA_MWHIP_PHYS_PACK", "1", "64"),      # world images
+])
+def test_escape_room_physics_step_switches(built, monkeypatch, switch, value, lanes):
+    """The step kernel's other ways in and out: without the
+    per-launch frame, with the leaf update + refit folded into the epilogue
+    instead of the ParallelFor node it is in the reference's graph, with
+    persistent wavefronts, in index order, from packed world images -- one
+    world and two worlds per wavefront."""
+    _need_ref("escape_room_phys")
+    monkeypatch.setenv(switch, value)
+    monkeypatch.setenv("MADRONA_MWHIP_PHYS_LANES", lanes)
+    probs, step = run_pair("escape_room_phys", 96, 60, flags=25,
+                           check_every=5, actions=_escape_actions(11, grab=True),
+                           check_init=False)
+    assert not probs, (step, probs[:3])
+
+
 @pytest.mark.parametrize("worlds,denom,steps", [(1, 0, 260), (16, 40, 150),
                                                 (64, 0, 300), (256, 100, 60),
                                                 (1024, 200, 30), (4096, 150, 20)])
