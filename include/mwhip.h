@@ -317,8 +317,13 @@ typedef struct mwhip_node_desc {
     uint32_t io_declared;
 } mwhip_node_desc;
 
+/* (the reference's TaskGraph::maxNodeDataBytes is 256; larger here because a
+ * node's data is what its kernel reaches with one load from its arguments) */
+#define MWHIP_MAX_NODE_DATA_BYTES 2048u
+
 /* TaskGraph::Builder::constructNodeData (taskgraph.inl:43-57): copies a node
- * data block (<= 256 B) to the device; several nodes may share one block.
+ * data block (<= MWHIP_MAX_NODE_DATA_BYTES) to the device; several nodes may
+ * share one block.
  * Returns the data id >= 0 or a negative error. */
 int32_t mwhip_tg_add_node_data(mwhip_exec *exec, uint32_t taskgraph_id,
                                const void *data, uint32_t num_bytes);

@@ -2878,11 +2878,12 @@ extern "C" int32_t mwhip_tg_add_node_data(mwhip_exec *exec, uint32_t tg_id,
         return fail(-3, "task graph %u out of range (numTaskGraphs=%zu)", tg_id,
                     exec->taskGraphs.size());
     }
-    if (num_bytes > 256) {
-        return fail(-2, "node data larger than 256 bytes");
+    if (num_bytes > MWHIP_MAX_NODE_DATA_BYTES) {
+        return fail(-2, "node data larger than %u bytes",
+                    (unsigned)MWHIP_MAX_NODE_DATA_BYTES);
     }
     void *dev = nullptr;
-    int rc = devAlloc(exec, &dev, 256);
+    int rc = devAlloc(exec, &dev, std::max<uint32_t>(num_bytes, 256u));
     if (rc != 0) return rc;
     if (num_bytes > 0) {
         HIPCHK(hipMemcpy(dev, data, num_bytes, hipMemcpyHostToDevice));

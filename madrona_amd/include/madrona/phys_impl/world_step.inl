@@ -2079,10 +2079,18 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
     // current world, not after.  (4096 atomics on one address over ~800 us do
     // not queue; round 2's persistent version strode statically and lost to
     // the dispatcher's balancing.)
+    // (the scratch block's words never change: invariant loads at the top of
+    // the kernel, not two dependent round trips in front of the candidate pass)
+    const uint32_t candidates_per_world =
+        mwhip::loadInvariant(&ps->candidatesPerWorld);
+    CandidateCollision *const world_candidates =
+        mwhip::loadInvariant(&ps->worldCandidates);
+
     // (with a frame the row ranges are read with everything else the world
     // index leads to: loadWorldFramed)
     const PhysicsFrame *frame =
-        params.worldImages == nullptr ? params.frame : nullptr;
+        params.worldImages == nullptr && params.useFrame != 0u ?
+            &((const PhysicsStepNode *)node_data)->frame : nullptr;
     struct JobHeader {
         int32_t world;          // -1: no world for this half of the wavefront
         bool sorted;
@@ -2232,14 +2240,8 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
         // collects many more candidates than contacts: what does not fit the
         // LDS list spills into the world's segment of the HBM candidate
         // scratch (4-byte records).
-        // (the scratch block's words never change: invariant loads, which the
-        // compiler may issue at the top of the kernel instead of here, two
-        // dependent round trips behind the block's last store)
-        const uint32_t candidates_per_world =
-            mwhip::loadInvariant(&ps->candidatesPerWorld);
         WaveCandidate *spilled_candidates = (WaveCandidate *)(
-            mwhip::loadInvariant(&ps->worldCandidates) +
-            (size_t)world * candidates_per_world);
+            world_candidates + (size_t)world * candidates_per_world);
         const uint32_t candidate_capacity = (uint32_t)Block::maxCandidates +
             candidates_per_world *
                 (uint32_t)(sizeof(CandidateCollision) / sizeof(WaveCandidate));
@@ -2363,7 +2365,7 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
         if (frame != nullptr) {
             joint_begin = framed.jointBegin;
             num_joints = framed.numJoints;
-            joints = frame->joints + joint_begin;
+            joints = mwhip::loadInvariant(&frame->joints) + joint_begin;
         } else {
             const TableHdr &joint_tbl = S->tables[ps->jointArchetype];
             joint_begin = joint_tbl.worldOffsets[world];
@@ -2873,9 +2875,10 @@ physicsOrderKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
     if (tid == 0 && params.jobCounter != nullptr) {
         *params.jobCounter = 0;     // (the step kernel's persistent wavefronts)
     }
-    if (params.frame != nullptr && tid >= 960u) {
+    if (params.useFrame != 0u && tid >= 960u) {
         // (the last wavefront: its share of the cost scan starts a moment later)
-        fillPhysicsFrame(S, detail::scratch(S), params.frame, tid - 960u, 64u);
+        fillPhysicsFrame(S, detail::scratch(S),
+                         &((PhysicsStepNode *)node_data)->frame, tid - 960u, 64u);
     }
 
     __shared__ uint32_t hist[256];

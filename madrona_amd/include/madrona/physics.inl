@@ -120,9 +120,19 @@ struct PhysicsStepParams {
     // LDS step kernels: persistent wavefronts take jobs (a world / a pair of
     // worlds, in worldOrder) from this counter; nullptr: one workgroup per job
     int32_t *jobCounter;
-    // LDS step kernels: filled by physicsOrderKernel; nullptr: every wavefront
-    // walks the tables itself
-    PhysicsFrame *frame;
+    // LDS step kernels: 1 = PhysicsStepNode::frame is filled by
+    // physicsOrderKernel; 0: every wavefront walks the tables itself
+    uint32_t useFrame;
+    uint32_t pad_;
+};
+
+// The step node's data: the parameters and, right behind them, the frame -- a
+// kernel has the address of both from its arguments, so the frame's words are
+// one load away, like the parameters (behind a pointer in the parameters they
+// were two: 2 us per pair of worlds in front of everything else).
+struct PhysicsStepNode {
+    PhysicsStepParams params;
+    PhysicsFrame frame;
 };
 
 namespace detail {
@@ -2294,22 +2304,17 @@ MADRONA_HOST_API inline TaskGraphNodeID setupPhysicsStepTasks(
     // The frame (PhysicsFrame): where every world's rows are, resolved once per
     // launch by the order kernel.  MADRONA_MWHIP_PHYS_FRAME=0: every wavefront
     // of the step kernel walks the tables itself (rounds 1-3).
-    PhysicsFrame *frame = nullptr;
     const char *frame_env = getenv("MADRONA_MWHIP_PHYS_FRAME");
-    if (world_order != nullptr && world_images == nullptr &&
-            (frame_env == nullptr || atoi(frame_env) != 0)) {
-        frame = (PhysicsFrame *)mwhip_alloc_device(exec, sizeof(PhysicsFrame), 1);
-        if (frame == nullptr) {
-            FATAL("madrona_amd physics: frame allocation failed: %s",
-                  mwhip_last_error());
-        }
-    }
-    auto params = builder.constructNodeData<PhysicsStepParams>(
-        PhysicsStepParams { (int32_t)num_substeps, fold_pairs | refit_in_step |
-                                (int32_t)((phys::detail::capacityHint(
-                                    "MADRONA_MWHIP_PHYS_COST_BLEND", 0) & 7) << 4),
-                            world_images, world_cost, world_order, job_counter,
-                            frame });
+    const uint32_t use_frame = world_order != nullptr && world_images == nullptr &&
+        (frame_env == nullptr || atoi(frame_env) != 0) ? 1u : 0u;
+    auto params = builder.constructNodeData<PhysicsStepNode>(
+        PhysicsStepNode {
+            PhysicsStepParams { (int32_t)num_substeps, fold_pairs | refit_in_step |
+                                    (int32_t)((phys::detail::capacityHint(
+                                        "MADRONA_MWHIP_PHYS_COST_BLEND", 0) & 7) << 4),
+                                world_images, world_cost, world_order, job_counter,
+                                use_frame, 0u },
+            PhysicsFrame {} });
 
     if (world_order != nullptr) {
         mwhip_node_desc order {};

@@ -105,7 +105,9 @@ MADRONA_DEVICE inline void DeviceTracing::Log([[maybe_unused]] DeviceEvent event
 
 class TaskGraph {
 public:
-    static inline constexpr uint32_t maxNodeDataBytes = 256;
+    // (reference: 256.  Node data is what a kernel reaches with ONE load from
+    // its arguments; the physics step keeps a table of addresses there)
+    static inline constexpr uint32_t maxNodeDataBytes = 2048;
 
     struct alignas(64) NodeData {
         char userData[maxNodeDataBytes];
