@@ -2269,28 +2269,47 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                 for (int m = 0; m < mask_words; m++) {
                     const int32_t r_end = num_bodies - m * 64 < 64 ?
                         num_bodies - m * 64 : 64;
-                    // the box tests first, branch-free and four at a time (the
-                    // boxes are broadcast reads: every lane of the world asks
-                    // for the same one; four in flight instead of one) ...
+                    // the box tests first, four at a time: the four slot boxes
+                    // and entity ids are read out of LDS into registers before
+                    // the first comparison (broadcast reads: every lane of the
+                    // world asks for the same ones), and a test is twelve
+                    // comparisons AND-ed as integers.  (AABB::overlaps is a
+                    // chain of &&: the compiler made it three dependent LDS
+                    // round trips and two branches per box -- the later
+                    // coordinates were only read if the earlier ones overlapped.)
                     uint64_t raw = 0;
-                    int32_t j = 0;
-                    for (; j + 4 <= r_end; j += 4) {
+                    for (int32_t j = 0; j < r_end; j += 4) {
+                        float box[4][6];
+                        int32_t other_id[4];
 #pragma unroll
                         for (int32_t u = 0; u < 4; u++) {
-                            const int32_t r = m * 64 + j + u;
+                            // (past the world's last body: its last one again)
+                            const int32_t r = m * 64 +
+                                (j + u < r_end ? j + u : r_end - 1);
                             const math::AABB slot = w->rankSlotBox()[r];
-                            const int32_t other_id = w->rankEntity()[r];
-                            const bool hit =
-                                (int)query.overlaps(slot) & (int)(my_id < other_id);
+                            box[u][0] = slot.pMin.x;
+                            box[u][1] = slot.pMin.y;
+                            box[u][2] = slot.pMin.z;
+                            box[u][3] = slot.pMax.x;
+                            box[u][4] = slot.pMax.y;
+                            box[u][5] = slot.pMax.z;
+                            other_id[u] = w->rankEntity()[r];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int32_t u = 0; u < 4; u++) {
+                            // == query.overlaps(slot) && my_id < other_id
+                            const uint32_t hit =
+                                (uint32_t)(query.pMin.x < box[u][3]) &
+                                (uint32_t)(box[u][0] < query.pMax.x) &
+                                (uint32_t)(query.pMin.y < box[u][4]) &
+                                (uint32_t)(box[u][1] < query.pMax.y) &
+                                (uint32_t)(query.pMin.z < box[u][5]) &
+                                (uint32_t)(box[u][2] < query.pMax.z) &
+                                (uint32_t)(my_id < other_id[u]) &
+                                (uint32_t)(j + u < r_end);
                             raw |= (uint64_t)hit << (j + u);
                         }
-                    }
-                    for (; j < r_end; j++) {
-                        const int32_t r = m * 64 + j;
-                        const math::AABB slot = w->rankSlotBox()[r];
-                        const bool hit = (int)query.overlaps(slot) &
-                            (int)(my_id < w->rankEntity()[r]);
-                        raw |= (uint64_t)hit << j;
                     }
                     // ... then the few that passed: static pairs out, the rest
                     // counted by primitive pairs
