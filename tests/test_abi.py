@@ -77,3 +77,21 @@ def test_overlay_headers_of_the_boundary_exist(built):
     for fn in ["conf_containers", "conf_tensor_bytes", "conf_run",
                "madronaMWHipUserEntry"]:
         assert hasattr(conf, fn), fn
+
+
+def test_node_data_limit_is_one_number(built):
+    """A node's data block: the limit the builder asserts at compile time
+    (TaskGraph::maxNodeDataBytes) is the one the C ABI enforces
+    (MWHIP_MAX_NODE_DATA_BYTES), and the physics step's node -- its parameters
+    with the per-launch frame of addresses behind them -- fits."""
+    header = open(os.path.join(REPO_ROOT, "include", "mwhip.h")).read()
+    abi = int(re.search(r"#define\s+MWHIP_MAX_NODE_DATA_BYTES\s+(\d+)u", header).group(1))
+    tg = open(os.path.join(REPO_ROOT, "madrona_amd", "include", "madrona",
+                           "taskgraph.hpp")).read()
+    builder = int(re.search(r"maxNodeDataBytes\s*=\s*(\d+);", tg).group(1))
+    assert abi == builder == 2048
+    # sizeof(PhysicsStepNode) from its members (8 rigid-body archetypes at most)
+    max_arch = 8
+    frame = 4 + 4 + 4 * max_arch + 2 * 8 * max_arch + 8 * max_arch * 14 + 4 * 8 + 7 * 8 + 4 * 8
+    params = 4 + 4 + 5 * 8 + 4 + 4
+    assert frame + params <= abi
