@@ -442,10 +442,11 @@ def rooflines(stats, sim_name, worlds, ms_per_step):
     t, src = traffic_for(entries, sim_name, worlds, "physics:worldStep")
     nodes["physics_step"] = node_roofline(
         "physics:worldStep (broadphase pairs + 4 x (integrate, narrowphase, XPBD "
-        "position + velocity solve) fused, one wavefront per world, world in LDS)",
+        "position + velocity solve) fused, two worlds per wavefront, worlds in LDS)",
         phys_k, t, src,
         "latency/issue-bound: HBM sees one read + one write of the body columns "
-        "per step (288 B/body); DESIGN.md §10")
+        "per step (288 B/body), loaded through a per-launch frame of addresses in "
+        "six rounds of global loads; DESIGN.md §10, §14.9")
     if phys_k:
         nodes["physics_step_issue"] = issue_roofline(
             "physics:worldStep (same kernel, instruction-issue yardstick)", sim_name,
