@@ -2762,8 +2762,9 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
         // the stores, none of them waited for.  (Through ctx.getDirect every
         // column was: load the column address, wait -- for the stores before
         // it as well, they share the counter --, store: 14 us per pair of
-        // worlds in the phase profile, now 2.)
-        // With the leaf update + refit of the world folded in (what
+        // worlds in the phase profile, now 3.)
+        // Opt-in (MADRONA_MWHIP_PHYS_REFIT=1, physics.inl): the leaf update +
+        // refit of the world folded in (what
         // setupPostIntegrationTasks's node does -- reference broadphase.cpp
         // updateLeafPositionsEntry + refitEntry --, PhysicsStepParams::
         // foldPairs bit 1): its loads ride on the same rounds -- the tree's
