@@ -121,3 +121,42 @@ def test_newest_committed_driver_line_schema():
     assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], abs=2e-4)
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and "sample" in c
+
+
+def test_driver_line_stays_small_whatever_the_kernel_tables_hold():
+    """BENCH_r04.json: `parsed: null` -- the one line had grown to 21 KB of
+    per-kernel tables.  bench.driver_line keeps the contract's keys + five-number
+    node summaries and sends the tables to a side file; here it is fed round 4's
+    full record blown up to a 200-entry kernel table per section."""
+    bench = _load("bench", os.path.join(ROOT, "bench.py"))
+    full = json.loads(open(os.path.join(ROOT, "profiles", "r04_bench_default.json"))
+                      .read().strip().splitlines()[-1])
+    assert len(json.dumps(full)) > 20000
+    fat = [{"name": f"sim::system{i}" + "x" * 60, "avg_us": 4.0 + i, "rows": 1e5,
+            "algo_MB": 1.0, "GBps": 100.0, "bytes": "declared read/write set"}
+           for i in range(200)]
+    full["kernels"] = fat
+    full["roofline"]["nodes"]["parallel_for"]["kernels"] = fat
+    full["ecs_config2"]["kernels"] = fat
+    full["render_config5"]["kernels"] = fat
+    full["roofline"]["nodes"]["sort_node"]["chains"] *= 50
+    line = bench.driver_line(full, "gpurun_out/bench_detail.json")
+    text = json.dumps(line)
+    assert len(text) < 8192 and len(text) < bench.LINE_BUDGET_BYTES
+    assert "\n" not in text
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                "roofline", "cpu_baseline"):
+        assert key in line, key
+    r = line["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+    assert r["frac"] == full["roofline"]["frac"] and r["bound"] == "hbm"
+    for node in ("sort_node", "parallel_for", "sort_and_parallel_for",
+                 "physics_step_issue"):
+        assert set(("achieved", "frac", "avg_us", "traffic", "algo_bytes")) <= set(
+            r["nodes"][node]), node
+    assert line["cpu_baseline"]["kind"] == "reference" and line["cpu_baseline"]["cores"] == 256
+    assert line["value"] == full["value"] and line["detail"].endswith("bench_detail.json")
+    assert line["ecs_config2"]["value"] == full["ecs_config2"]["value"]
+    assert line["portable_sim"]["config3"]["value"] == full["portable_sim"]["config3"]["value"]
