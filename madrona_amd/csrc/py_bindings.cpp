@@ -10,15 +10,22 @@
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
+#include <madrona/py/bindings.hpp>
+#include <madrona/py/hip_copy.hpp>
 #include <madrona/py/utils.hpp>
 
 #include <cstdint>
+#include <cstdlib>
+#include <cstring>
 #include <string>
 #include <vector>
 
 namespace pyb = pybind11;
+using madrona::py::JAXInterface;
+using madrona::py::NamedTensor;
 using madrona::py::Tensor;
 using madrona::py::TensorElementType;
+using madrona::py::TrainInterface;
 
 namespace {
 
@@ -96,6 +103,202 @@ pyb::capsule toDLPack(const Tensor &t)
                                       &capsuleDestructor), false);
 }
 
+
+// ---- a Manager-shaped class with the JAX entry points of a real simulator ----
+// (reference madrona_escape_room src/mgr.cpp: trainInterface(), cpuJAXInit /
+// cpuJAXStep(void **inputs, void **outputs), gpuJAXInit / gpuJAXStep(stream,
+// void **buffers)).  N "worlds", state in host memory (gpu_id < 0) or in device
+// memory; step(): obs[w] = { action[w][0] + action[w][1], resets[w], step count },
+// reward[w] = obs[w][0] / 2, done[w] = resets[w].  Used by tests/test_py_bridge.py
+// to drive TrainInterface and the XLA entry points without a simulator build.
+class DemoTrainSim {
+public:
+    DemoTrainSim(int64_t num_worlds, int gpu_id)
+        : n_(num_worlds), gpu_(gpu_id)
+    {
+        action_ = alloc(n_ * 2 * 4);
+        resets_ = alloc(n_ * 4);
+        ctrl_ = alloc(4);
+        obs_ = alloc(n_ * 3 * 4);
+        rewards_ = alloc(n_ * 4);
+        dones_ = alloc(n_ * 4);
+    }
+    ~DemoTrainSim()
+    {
+        for (void *p : owned_) {
+            if (gpu_ >= 0) (void)hipFree(p); else free(p);
+        }
+    }
+    DemoTrainSim(const DemoTrainSim &) = delete;
+
+    Tensor tensor(void *p, TensorElementType t, std::vector<int64_t> dims) const
+    {
+        return Tensor(p, t, madrona::Span<const int64_t>(dims.data(),
+                                                         (madrona::CountT)dims.size()),
+                      gpu_ >= 0 ? madrona::Optional<int>::make(gpu_) :
+                                  madrona::Optional<int>::none());
+    }
+    Tensor actionTensor() const { return tensor(action_, TensorElementType::Int32, { n_, 2 }); }
+    Tensor obsTensor() const { return tensor(obs_, TensorElementType::Float32, { n_, 3 }); }
+
+    TrainInterface trainInterface() const
+    {
+        NamedTensor actions[] = { { "move", actionTensor() } };
+        NamedTensor obs[] = { { "self", obsTensor() } };
+        return TrainInterface(
+            { madrona::Span<const NamedTensor>(actions, 1),
+              tensor(resets_, TensorElementType::Int32, { n_ }),
+              tensor(ctrl_, TensorElementType::Int32, { 1 }) },
+            { madrona::Span<const NamedTensor>(obs, 1),
+              tensor(rewards_, TensorElementType::Float32, { n_ }),
+              tensor(dones_, TensorElementType::Int32, { n_ }) });
+    }
+
+    void step()
+    {
+        steps_++;
+        std::vector<int32_t> a((size_t)n_ * 2), r((size_t)n_), d((size_t)n_);
+        std::vector<float> o((size_t)n_ * 3), rew((size_t)n_);
+        get(a.data(), action_, a.size() * 4);
+        get(r.data(), resets_, r.size() * 4);
+        for (int64_t w = 0; w < n_; w++) {
+            o[w * 3] = (float)(a[w * 2] + a[w * 2 + 1]);
+            o[w * 3 + 1] = (float)r[w];
+            o[w * 3 + 2] = (float)steps_;
+            rew[w] = o[w * 3] / 2.f;
+            d[w] = r[w];
+        }
+        put(obs_, o.data(), o.size() * 4);
+        put(rewards_, rew.data(), rew.size() * 4);
+        put(dones_, d.data(), d.size() * 4);
+    }
+
+    void cpuJAXInit(void **, void **outputs)
+    {
+        trainInterface().cpuCopyObservations(outputs);
+    }
+    void cpuJAXStep(void **inputs, void **outputs)
+    {
+        TrainInterface iface = trainInterface();
+        iface.cpuCopyStepInputs(inputs);
+        step();
+        iface.cpuCopyStepOutputs(outputs);
+    }
+    void gpuJAXInit(hipStream_t strm, void **buffers)
+    {
+        trainInterface().hipCopyObservations(strm, buffers);
+    }
+    void gpuJAXStep(hipStream_t strm, void **buffers)
+    {
+        TrainInterface iface = trainInterface();
+        void **outputs = iface.hipCopyStepInputs(strm, buffers);
+        // (a real Manager replays its step graph on `strm` here; the demo's
+        // arithmetic runs on the host: wait for the inputs first)
+        (void)hipStreamSynchronize(strm);
+        step();
+        iface.hipCopyStepOutputs(strm, outputs);
+    }
+    int64_t steps() const { return steps_; }
+
+private:
+    void *alloc(int64_t bytes)
+    {
+        void *p = nullptr;
+        if (gpu_ >= 0) {
+            madrona::py::detail::reqHip(hipSetDevice(gpu_), "hipSetDevice");
+            madrona::py::detail::reqHip(hipMalloc(&p, (size_t)bytes), "hipMalloc");
+            (void)hipMemset(p, 0, (size_t)bytes);
+        } else {
+            p = calloc(1, (size_t)bytes);
+        }
+        owned_.push_back(p);
+        return p;
+    }
+    void get(void *dst, const void *src, size_t n) const
+    {
+        if (gpu_ >= 0) (void)hipMemcpy(dst, src, n, hipMemcpyDeviceToHost);
+        else memcpy(dst, src, n);
+    }
+    void put(void *dst, const void *src, size_t n) const
+    {
+        if (gpu_ >= 0) (void)hipMemcpy(dst, src, n, hipMemcpyHostToDevice);
+        else memcpy(dst, src, n);
+    }
+
+    int64_t n_;
+    int gpu_;
+    int64_t steps_ = 0;
+    void *action_, *resets_, *ctrl_, *obs_, *rewards_, *dones_;
+    std::vector<void *> owned_;
+};
+
+std::vector<void *> pointerList(const std::vector<uintptr_t> &v)
+{
+    std::vector<void *> out;
+    for (uintptr_t p : v) out.push_back((void *)p);
+    return out;
+}
+
+void *capsulePointer(const pyb::capsule &c)
+{
+    return PyCapsule_GetPointer(c.ptr(), "xla._CUSTOM_CALL_TARGET");
+}
+
+TensorElementType fromDLType(uint8_t code, uint8_t bits)
+{
+    if (code == kDLInt) {
+        switch (bits) {
+        case 8: return TensorElementType::Int8;
+        case 16: return TensorElementType::Int16;
+        case 32: return TensorElementType::Int32;
+        case 64: return TensorElementType::Int64;
+        }
+    } else if (code == kDLUInt && bits == 8) {
+        return TensorElementType::UInt8;
+    } else if (code == kDLFloat) {
+        if (bits == 16) return TensorElementType::Float16;
+        if (bits == 32) return TensorElementType::Float32;
+    }
+    throw pyb::type_error("madrona::py::Tensor: unsupported dtype");
+}
+
+// Tensor(torch_tensor): reference bindings.cpp:313-338 (nanobind ndarray);
+// here through the tensor's own __dlpack__ (device kDLCPU, kDLROCM or kDLCUDA
+// -- PyTorch-ROCm reports its devices as either)
+Tensor tensorFromDLPack(pyb::object src)
+{
+    pyb::capsule cap = src.attr("__dlpack__")();
+    auto *m = (DLManagedTensor *)PyCapsule_GetPointer(cap.ptr(), "dltensor");
+    if (m == nullptr) {
+        throw pyb::type_error("madrona::py::Tensor: not a DLPack tensor");
+    }
+    const DLTensor &dl = m->dl_tensor;
+    if (dl.strides != nullptr) {
+        int64_t expect = 1;
+        for (int32_t i = dl.ndim - 1; i >= 0; i--) {
+            if (dl.shape[i] != 1 && dl.strides[i] != expect) {
+                throw pyb::value_error("madrona::py::Tensor: tensor is not contiguous");
+            }
+            expect *= dl.shape[i];
+        }
+    }
+    if (dl.ndim > Tensor::maxDimensions) {
+        throw pyb::value_error("madrona::py::Tensor: too many dimensions");
+    }
+    madrona::Optional<int> gpu = madrona::Optional<int>::none();
+    if (dl.device.device_type == kDLROCM || dl.device.device_type == 2 /* kDLCUDA */) {
+        gpu = madrona::Optional<int>::make(dl.device.device_id);
+    } else if (dl.device.device_type != kDLCPU) {
+        throw pyb::type_error("madrona::py::Tensor: unknown device type");
+    }
+    // (the view does not own: the caller keeps `src` alive, as in the reference;
+    // the capsule's deleter runs when `cap` dies, the storage stays with `src`)
+    return Tensor((char *)dl.data + dl.byte_offset,
+                  fromDLType(dl.dtype.code, dl.dtype.bits),
+                  madrona::Span<const int64_t>(dl.shape, (madrona::CountT)dl.ndim),
+                  gpu);
+}
+
 }
 
 PYBIND11_MODULE(_madrona_amd_py, m)
@@ -127,6 +330,8 @@ PYBIND11_MODULE(_madrona_amd_py, m)
                 gpu);
         }), pyb::arg("ptr"), pyb::arg("type"), pyb::arg("dims"),
             pyb::arg("gpu_id") = pyb::none())
+        // Tensor(torch_tensor): a view of the tensor's storage
+        .def(pyb::init(&tensorFromDLPack), pyb::arg("tensor"))
         .def_property_readonly("device_ptr", [](const Tensor &t) {
             return (uintptr_t)t.devicePtr();
         })
@@ -150,4 +355,48 @@ PYBIND11_MODULE(_madrona_amd_py, m)
                 pyb::module_::import("torch.utils.dlpack").attr("from_dlpack");
             return from_dlpack(toDLPack(t));
         });
+
+    pyb::class_<TrainInterface>(m, "TrainInterface")
+        // reference bindings.cpp:365-374 (pytrees of shapes and dtypes; numpy
+        // dtype names here, jax.ShapeDtypeStruct is built in jax_register.py)
+        .def("step_inputs", [](const TrainInterface &iface) {
+            return JAXInterface::inputsToPytree(iface);
+        })
+        .def("step_outputs", [](const TrainInterface &iface) {
+            return JAXInterface::outputsToPytree(iface);
+        });
+
+    pyb::class_<DemoTrainSim>(m, "_DemoTrainSim")
+        .def(pyb::init<int64_t, int>(), pyb::arg("num_worlds"),
+             pyb::arg("gpu_id") = -1)
+        .def("train_interface", &DemoTrainSim::trainInterface)
+        .def("action_tensor", &DemoTrainSim::actionTensor)
+        .def("obs_tensor", &DemoTrainSim::obsTensor)
+        .def("step", &DemoTrainSim::step)
+        .def_property_readonly("steps", &DemoTrainSim::steps)
+        .def("jax", JAXInterface::buildEntry<
+                &DemoTrainSim::trainInterface,
+                &DemoTrainSim::cpuJAXInit, &DemoTrainSim::cpuJAXStep,
+                &DemoTrainSim::gpuJAXInit, &DemoTrainSim::gpuJAXStep>(),
+             pyb::arg("xla_gpu"), pyb::arg("register") = true);
+
+    // what XLA does with a registered target, for tests (no jax here):
+    // CPU custom call: fn(void **out, void **in)
+    m.def("_call_cpu_custom_call", [](pyb::capsule target,
+                                      std::vector<uintptr_t> outs,
+                                      std::vector<uintptr_t> ins) {
+        auto fn = (void (*)(void **, void **))capsulePointer(target);
+        std::vector<void *> o = pointerList(outs), i = pointerList(ins);
+        fn(o.data(), i.data());
+    });
+    // GPU custom call: fn(stream, void **buffers, opaque, opaque_len)
+    m.def("_call_gpu_custom_call", [](pyb::capsule target, uintptr_t stream,
+                                      std::vector<uintptr_t> buffers,
+                                      pyb::bytes opaque) {
+        auto fn = (void (*)(hipStream_t, void **, const char *, size_t))
+            capsulePointer(target);
+        std::vector<void *> b = pointerList(buffers);
+        std::string o = opaque;
+        fn((hipStream_t)stream, b.data(), o.data(), o.size());
+    });
 }

@@ -16,6 +16,12 @@
 
 #include <array>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
 
 namespace madrona::py {
 
@@ -54,6 +60,13 @@ public:
             dimensions_[(size_t)i] = dimensions[(CountT)i];
         }
     }
+
+    // (not in the reference: an empty tensor, so that Optional<> of a struct
+    // that holds one has something to default to)
+    Tensor()
+        : dev_ptr_(nullptr), type_(TensorElementType::UInt8), gpu_id_(-1),
+          num_dimensions_(0), dimensions_ {}
+    {}
 
     Tensor(const Tensor &o) = default;
     Tensor &operator=(const Tensor &o) = default;
@@ -114,4 +127,76 @@ struct NamedTensor {
     Tensor tensor;
 };
 
+// What a training loop exchanges with a simulator per step, by name.
+// API contract: reference include/madrona/py/utils.hpp:148-204
+// (TrainStepInputInterface, TrainStepOutputInterface,
+// TrainCheckpointingInterface, TrainInterface) and src/python/utils.cpp:403-560
+// (the copy routines: actions..., resets, simCtrl, pbt... in; observations...,
+// rewards, dones, stats..., pbt... out -- the order the XLA custom call's
+// buffers arrive in).
+struct TrainStepInputInterface {
+    Span<const NamedTensor> actions;
+    Tensor resets;
+    Tensor simCtrl;
+    Span<const NamedTensor> pbt = {};
+};
+
+struct TrainStepOutputInterface {
+    Span<const NamedTensor> observations;
+    Tensor rewards;
+    Tensor dones;
+    Span<const NamedTensor> stats = {};
+    Span<const NamedTensor> pbt = {};
+};
+
+struct TrainCheckpointingInterface {
+    Tensor checkpointData;
+};
+
+// Owns copies of the spans (and of the names) it was given: a Manager builds it
+// from temporaries.
+class TrainInterface final {
+public:
+    inline TrainInterface() = default;
+    inline TrainInterface(TrainStepInputInterface step_inputs,
+                          TrainStepOutputInterface step_outputs,
+                          Optional<TrainCheckpointingInterface> checkpointing =
+                              Optional<TrainCheckpointingInterface>::none());
+    TrainInterface(TrainInterface &&o) = default;
+    TrainInterface &operator=(TrainInterface &&o) = default;
+    TrainInterface(const TrainInterface &) = delete;
+
+    inline TrainStepInputInterface stepInputs() const;
+    inline TrainStepOutputInterface stepOutputs() const;
+    inline Optional<TrainCheckpointingInterface> checkpointing() const;
+
+    // host buffers <-> the simulator's tensors (XLA's CPU custom call)
+    inline void cpuCopyStepInputs(void **buffers);
+    inline void cpuCopyObservations(void **buffers);
+    inline void cpuCopyStepOutputs(void **buffers);
+
+    // device buffers <-> the simulator's tensors on `strm` (XLA's GPU custom
+    // call hands over its stream): the reference's cudaCopy* (utils.cpp:498-560)
+    // on HIP.  `strm` is a hipStream_t; declared void * so that this header
+    // does not need the HIP runtime -- defined in <madrona/py/hip_copy.hpp>.
+    inline void **hipCopyStepInputs(void *strm, void **buffers);
+    inline void hipCopyObservations(void *strm, void **buffers);
+    inline void hipCopyStepOutputs(void *strm, void **buffers);
+
+    static inline uint64_t numTensorBytes(const Tensor &t)
+    {
+        return (uint64_t)t.numItems() * (uint64_t)t.numBytesPerItem();
+    }
+
+private:
+    struct Impl;
+    struct ImplDeleter { inline void operator()(Impl *p) const; };
+    std::unique_ptr<Impl, ImplDeleter> impl_;
+
+    template <typename Fn> inline void forEachInput(Fn &&fn);
+    template <typename Fn> inline void forEachOutput(Fn &&fn, bool obs_only);
+};
+
 }
+
+#include "utils.inl"
