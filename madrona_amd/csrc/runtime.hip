@@ -462,7 +462,6 @@ struct ArchetypeRec {
     uint32_t maxPerWorld = 0;
     bool singleton = false;
     bool bigSort = false;
-    bool spreadSort = false;    // busy but small: the one-launch sort on several workgroups
     uint32_t smallBusy = 0;     // consecutive reports of a busy one-launch sort           // outgrew the single-launch sort once
     // world sorts of this table take the compaction chain unless something
     // other than world sorts reorders / truncates it (a sort by another key,
@@ -1758,11 +1757,6 @@ static int makeSortBatch(mwhip_exec *exec,
     std::vector<SortSite> sites;
     std::vector<GatherColumn> cols;
     bool all_small = envU32("MADRONA_MWHIP_SORT_SMALL", 1) != 0;
-    // MADRONA_MWHIP_SORT_SPREAD: 0 = busy small tables go to the chain (round
-    // 3), 1 = they get the one-launch sort on several workgroups, 2 = every
-    // small batch does (tests)
-    const uint32_t spread_mode = envU32("MADRONA_MWHIP_SORT_SPREAD", 1);
-    bool any_spread = spread_mode == 2u;
 
     for (auto [archetype_id, component_id] : specs) {
         if (archetype_id >= exec->archetypes.size() ||
@@ -1823,7 +1817,6 @@ static int makeSortBatch(mwhip_exec *exec,
             if (arch.bigSort || rows_now * 4 > sortSmallRowLimit()) {
                 all_small = false;
             }
-            any_spread = any_spread || arch.spreadSort;
         }
         uint32_t site_columns = 0;
         sites.back().firstGatherColumn = (uint32_t)cols.size();
@@ -1869,10 +1862,6 @@ static int makeSortBatch(mwhip_exec *exec,
         sites.back().numGatherColumns = site_columns;
     }
     out->small = all_small;
-    if (all_small && any_spread && spread_mode != 0u) {
-        out->spreadGroups = std::min(std::max(
-            envU32("MADRONA_MWHIP_SORT_SPREAD_GROUPS", 32), 1u), 64u);
-    }
 
     int rc = devAllocT(exec, &out->sitesDev, sites.size());
     if (rc != 0) return rc;
@@ -3465,23 +3454,16 @@ static int sortsOutgrown(mwhip_exec *exec)
                 // launch wins while the table is tiny or mostly idle (4 us
                 // against 3 x 4 when nothing changed).  Three reports in a
                 // row above the mark move a world-sorted table to the chain.
-                // (MADRONA_MWHIP_SORT_SPREAD=1: a busy table that fits the LDS
-                // buffers of sortSmallSpread stays with one launch, on several
-                // workgroups -- 29 us, off by default.)
-                const bool spread_ok =
-                    envU32("MADRONA_MWHIP_SORT_SPREAD", 0) != 0u &&
-                    rows * 8 <= (int64_t)sortSpreadRowLimit() * 7;
+                // (One launch on 16-32 workgroups -- every workgroup ordering
+                // all keys in LDS, then moving its share -- was built in round 4
+                // and measured at 29 us: the device-scope hand-off between the
+                // workgroups costs more than the launches it saves.  Removed in
+                // round 5; profiles/r04_sort_variants.jsonl.)
                 if (!arch.bigSort && site.worldSort &&
                         compactionEligible(exec, site.archetype, 1u) &&
-                        rows >= (int64_t)sortSmallBusyRows() &&
-                        !(spread_ok && arch.spreadSort)) {
+                        rows >= (int64_t)sortSmallBusyRows()) {
                     if (++arch.smallBusy >= 3u) {
-                        if (spread_ok) {
-                            arch.spreadSort = true;
-                            arch.smallBusy = 0;
-                        } else {
-                            arch.bigSort = true;
-                        }
+                        arch.bigSort = true;
                         rebuild = true;
                     }
                 } else {
@@ -3718,6 +3700,25 @@ extern "C" int mwhip_run(mwhip_exec *exec, uint64_t graph)
     return growTablesAfterReplay(exec);
 }
 
+// One replay of a step graph on `stream`: the instantiated hipGraph, or -- 
+// MADRONA_MWHIP_EAGER=1, measurement -- the same launches one by one (a graph
+// kernel node costs ~4 us on this runtime whatever the kernel does; a
+// dependent launch on a stream 1.5 us of device time and 3-4 us of host time,
+// which a step of a millisecond hides).
+static int replayGraph(mwhip_exec *exec, LaunchGraph &lg, hipStream_t stream)
+{
+    static const bool eager = envU32("MADRONA_MWHIP_EAGER", 0) != 0;
+    if (!eager) {
+        HIPCHK(hipGraphLaunch(lg.graphExec, stream));
+        return 0;
+    }
+    for (KernelLaunch &k : lg.launches) {
+        int rc = launchOne(exec, k, stream);
+        if (rc != 0) return rc;
+    }
+    return 0;
+}
+
 extern "C" int mwhip_run_async(mwhip_exec *exec, uint64_t graph, void *hip_stream)
 {
 #ifdef MADRONA_TRACING
@@ -3788,7 +3789,8 @@ extern "C" int mwhip_run_async(mwhip_exec *exec, uint64_t graph, void *hip_strea
     }
     // (growing rebuilds the graphs: look the handle up again)
     it = exec->launchGraphs.find(graph);
-    HIPCHK(hipGraphLaunch(it->second->graphExec, (hipStream_t)hip_stream));
+    rc = replayGraph(exec, *it->second, (hipStream_t)hip_stream);
+    if (rc != 0) return rc;
     exec->replaysLaunched++;
     return 0;
 }

@@ -59,8 +59,7 @@ struct SortState {
     unsigned long long statTailRows;// cumulative rows behind the prefix
     uint32_t landsBlocked;          // runs that still take the sorted-tail path after a
                                     // scatter tile owned more tail rows than it orders in LDS
-    uint32_t spreadDone;            // sortSmallSpread: workgroups of this run that have
-                                    // moved their rows (the last one publishes)
+    uint32_t reserved_;
 };
 
 struct SortSite {
@@ -140,7 +139,6 @@ struct SortBatch {
     // of the chain.  Decided from the rows the tables hold when the graph is
     // built; the executor rebuilds its graphs when one outgrows it.
     bool small = false;
-    uint32_t spreadGroups = 1;      // small: workgroups per site (> 1: sortSmallSpread)
     // every site is a world sort of a table that nothing but world sorts
     // reorders: prepare + scatter instead of histogram + key passes
     bool compact = false;
@@ -233,7 +231,6 @@ struct KernelLaunch {
 int sortNumPasses(bool world_sort, uint32_t num_worlds);
 uint32_t sortTileSize();
 uint32_t sortSmallRowLimit();
-uint32_t sortSpreadRowLimit();
 uint32_t sortSmallBusyRows();
 uint32_t sortCompactTailLimit();
 void buildSortLaunches(const SortBatch &batch, std::vector<KernelLaunch> &out);

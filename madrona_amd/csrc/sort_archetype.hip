@@ -761,9 +761,9 @@ sortGather(EcsState *S, const SortSite *sites, const GatherColumn *columns,
 // routine out (and its registers: the word-by-word kernel then fits eight
 // wavefronts per SIMD).
 // sorted_keys: ALL sorted keys if the caller has them closer than the key
-// buffer.  published = false: publishSite has not run yet (sortSmallSpread: the
-// last workgroup to finish swaps the buffers), rows move from the current
-// buffers into the twins.
+// buffer.  published = false: publishSite has not run yet, rows move from the
+// current buffers into the twins (no caller left since the multi-workgroup
+// small sort was removed in round 5).
 template <bool Wide>
 __device__ inline void gatherColumn(EcsState *S, const SortSite &site,
                                     const GatherColumn &gc, TableHdr &tbl,
@@ -1153,288 +1153,6 @@ sortSmall(EcsState *S, const SortSite *sites, const GatherColumn *columns,
                       world_rows, range_scan);
 }
 
-// sortSmall on several workgroups, for small tables that are BUSY -- a couple of
-// thousand rows re-sorted every step (the joint table of 8192 Escape-Room
-// worlds: ~2.5 K rows, a thousand of them new each step).  One workgroup takes
-// 50 us for that; the three launches of the compaction chain 25, most of it
-// launch floors.  Here every one of gridDim.y workgroups sorts ALL the keys of
-// the site by itself, in LDS (no buffer anybody else sees), and moves ITS share
-// of the rows; nothing depends on another workgroup, so it is one launch.  What
-// must wait for all of them -- swapping the buffers (publishSite), copying
-// pinned columns back, cleaning the state -- is done by the workgroup that
-// finishes last (a counter in the site's state).  Until then the table is
-// exactly as it was when the kernel started, which is what every workgroup
-// reads.  A table that has outgrown the LDS buffers is sorted by workgroup 0
-// through the global buffers.
-//
-// MEASURED SLOWER than the chain and therefore OFF by default
-// (MADRONA_MWHIP_SORT_SPREAD=1 turns it on for busy tables, =2 for every small
-// batch): 28.6 - 31 us against 25 (profiles/r04_sort_variants.jsonl).  Device
-// timestamps of one workgroup (us from its start): keys' address known 6.3 (four
-// dependent cold loads), sorted 12.8, rows moved 14.9, __threadfence() + barrier
-// 23.7, counter 25.5, the last workgroup done 32.8.  The hand-off is the cost:
-// a device-scope release on this chip writes back the XCD's L2 (the eight L2s
-// are not coherent with each other), 9 us, and the acquire + publish of the
-// last workgroup is another 7 -- what a kernel boundary does for the chain
-// inside its 4.4 us launch floor.  In-kernel hand-offs between workgroups do
-// not pay on MI355X unless they replace more than three launches.
-constexpr int32_t kSpreadRows = 4096;
-struct SpreadLDS {
-    SmallSortLDS sort;
-    uint32_t keys[2][kSpreadRows];
-    int32_t rows[2][kSpreadRows];
-    uint32_t worldRows[kSmallRangeWorlds];
-    unsigned long long rangeScan[kSmallWaves];
-    uint32_t last;
-};
-
-// World sort of n <= kSpreadRows rows of at most kSmallRangeWorlds worlds by one
-// workgroup, as a COUNTING sort in LDS: rows per world (atomics), exclusive
-// scan (= the table's new worldOffsets, left in lds.worldRows), every row into
-// a slot of its world's range in arrival order, then -- the sort is stable --
-// each row to the place its table index has among the rows of its world (a
-// world has a handful of rows: a short scan of its range).  Five barriers
-// instead of the radix passes' ~20 per thousand rows (sortSmallSpread with the
-// radix passes: 43 us for the ~2.4 K joints of 8192 Escape-Room worlds).
-// false (every thread, nothing written): a key that is neither a world nor the
-// destroyed mark, or a world with more rows than kCountingMaxPerWorld -- the
-// radix passes take it.
-constexpr uint32_t kCountingMaxPerWorld = 128;
-__device__ inline bool oneGroupCountingSort(SpreadLDS &lds, const uint32_t *keys_in,
-                                            int32_t n, int32_t num_worlds,
-                                            uint32_t *sorted_out, int32_t *perm_out)
-{
-    static_assert(kSpreadRows == 4 * kSmallThreads);
-    static_assert(sizeof(lds.keys) == kSmallRangeWorlds * sizeof(uint32_t));
-    const int32_t tid = (int32_t)threadIdx.x;
-    uint32_t *counts = lds.worldRows;           // -> exclusive offsets
-    uint32_t *cursors = &lds.keys[0][0];        // rows of a world placed so far
-    int32_t *slots = lds.rows[0];               // arrival order within a world
-
-    constexpr int32_t per_thread = kSmallRangeWorlds / kSmallThreads;
-    for (int32_t w = tid; w < kSmallRangeWorlds; w += kSmallThreads) {
-        counts[w] = 0;
-        cursors[w] = 0;
-    }
-    if (tid == 0) {
-        lds.last = 0;       // (here: some key is out of range)
-    }
-    __syncthreads();
-
-    uint32_t key[4];
-#pragma unroll
-    for (int32_t j = 0; j < 4; j++) {
-        const int32_t i = j * kSmallThreads + tid;
-        key[j] = i < n ? keys_in[i] : 0xFFFFFFFFu;
-        if (key[j] < (uint32_t)num_worlds) {
-            atomicAdd(&counts[key[j]], 1u);
-        } else if (key[j] != 0xFFFFFFFFu) {
-            lds.last = 1u;
-        }
-    }
-    __syncthreads();
-
-    uint32_t mine[per_thread];
-    uint32_t sum = 0;
-    uint32_t most = 0;
-#pragma unroll
-    for (int32_t j = 0; j < per_thread; j++) {
-        mine[j] = counts[tid * per_thread + j];
-        sum += mine[j];
-        most = mine[j] > most ? mine[j] : most;
-    }
-    if (most > kCountingMaxPerWorld) {
-        lds.last = 1u;
-    }
-    // (two barriers inside: every thread has read its counts before any offset
-    // is written over them)
-    uint32_t run = (uint32_t)blockExclusiveScanU64<kSmallThreads>(sum, lds.rangeScan);
-    if (lds.last != 0u) {
-        __syncthreads();
-        return false;
-    }
-#pragma unroll
-    for (int32_t j = 0; j < per_thread; j++) {
-        counts[tid * per_thread + j] = run;
-        run += mine[j];
-    }
-    if (tid == kSmallThreads - 1) {
-        lds.sort.valid = run;       // live rows
-    }
-    __syncthreads();
-
-#pragma unroll
-    for (int32_t j = 0; j < 4; j++) {
-        if (key[j] != 0xFFFFFFFFu) {
-            const uint32_t slot = atomicAdd(&cursors[key[j]], 1u);
-            slots[counts[key[j]] + slot] = j * kSmallThreads + tid;
-        }
-    }
-    __syncthreads();
-
-    // rank of a row among the rows of its world = how many of them come before
-    // it in the table
-    uint32_t dest[4];
-#pragma unroll
-    for (int32_t j = 0; j < 4; j++) {
-        dest[j] = 0;
-        if (key[j] != 0xFFFFFFFFu) {
-            const int32_t i = j * kSmallThreads + tid;
-            const uint32_t first = counts[key[j]];
-            const uint32_t rows = cursors[key[j]];
-            uint32_t rank = 0;
-            for (uint32_t q = 0; q < rows; q++) {
-                rank += slots[first + q] < i ? 1u : 0u;
-            }
-            dest[j] = first + rank;
-        }
-    }
-    __syncthreads();        // (cursors are dead: sorted_out may alias them)
-#pragma unroll
-    for (int32_t j = 0; j < 4; j++) {
-        if (key[j] != 0xFFFFFFFFu) {
-            sorted_out[dest[j]] = key[j];
-            perm_out[dest[j]] = j * kSmallThreads + tid;
-        }
-    }
-    __syncthreads();
-    return true;
-}
-
-__global__ void __launch_bounds__(kSmallThreads)
-sortSmallSpread(EcsState *S, const SortSite *sites, const GatherColumn *columns,
-                uint32_t num_columns, const MiscOp *trailing_ops,
-                uint32_t num_trailing_ops)
-{
-    TraceScope trace_scope(S);
-    if (blockIdx.x == 0 && blockIdx.y == 0) {
-        applyMiscOps(S, trailing_ops, num_trailing_ops, threadIdx.x);
-    }
-    const SortSite &site = sites[blockIdx.x];
-    TableHdr &tbl = S->tables[site.archetype];
-    if (site.worldSort && tbl.needsSort == 0u) {
-        return;
-    }
-
-    __shared__ SpreadLDS lds;
-    // (numRows, needsSort, the column pointers: nothing of the table changes
-    // before every workgroup of the site has passed the counter below)
-    const int32_t n = tbl.numRows;
-    const int32_t groups = (int32_t)gridDim.y;
-    const int32_t group = (int32_t)blockIdx.y;
-    const uint32_t tid = threadIdx.x;
-    const int final_buf = (site.numPasses - 1) & 1;
-    SortState *state = site.state;
-
-    // too many rows for the LDS buffers: workgroup 0 alone, through the global
-    // ping-pong buffers; the others only take part in the hand-off
-    const bool in_lds = n <= kSpreadRows;
-    const int32_t my_groups = in_lds ? groups : 1;
-    if (in_lds || group == 0) {
-        const RadixBuffers buffers {
-            { in_lds ? lds.keys[0] : site.keysA, in_lds ? lds.keys[1] : site.keysB },
-            { in_lds ? lds.rows[0] : site.idxA, in_lds ? lds.rows[1] : site.idxB } };
-        const uint32_t *sorted = buffers.keys[final_buf];
-        const int32_t *perm = buffers.rows[final_buf];
-        const uint32_t *table_keys = (const uint32_t *)tbl.columns[site.keyColumn];
-        bool counted = false;
-        if (in_lds && site.worldSort != 0u && S->numWorlds <= kSmallRangeWorlds) {
-            counted = oneGroupCountingSort(lds, table_keys, n, S->numWorlds,
-                                           lds.keys[0], lds.rows[1]);
-            sorted = lds.keys[0];
-            perm = lds.rows[1];
-        }
-        if (!counted) {
-            sorted = buffers.keys[final_buf];
-            perm = buffers.rows[final_buf];
-            oneGroupRadixPasses(lds.sort, site.numPasses, buffers, table_keys, 0, n, 0);
-            __syncthreads();
-        }
-        const int32_t n_out = site.worldSort ? (int32_t)lds.sort.valid : n;
-        if (tid == 0) {
-            state->numValid = lds.sort.valid;   // (every workgroup: the same value)
-        }
-
-        // The rows to move, shared out by (column, slice of rows): a column is
-        // a chain of dependent loads before its first row moves (its
-        // descriptor, the table's buffers), and a workgroup that took a share
-        // of EVERY column paid that chain once per column, one after the other
-        // (30 us for the nine columns of the joint table); now a workgroup
-        // has one column, or one slice of one.
-        const int32_t site_columns = (int32_t)site.numGatherColumns;
-        const int32_t slices = my_groups / site_columns > 1 ?
-            my_groups / site_columns : 1;
-        int32_t per = (n_out + slices - 1) / slices;
-        per = (per + 3) & ~3;       // (whole 16-byte chunks of a column of dwords)
-        for (int32_t item = group; item < site_columns * slices; item += my_groups) {
-            const int32_t slice = item % slices;
-            const GatherColumn gc = columns[site.firstGatherColumn + item / slices];
-            if (gc.column == kWorldRangesColumn) {
-                if (slice != 0) continue;
-                if (counted) {
-                    // (the counting sort left the new offsets in lds.worldRows)
-                    const int32_t num_worlds = S->numWorlds;
-                    for (int32_t w = (int32_t)tid; w < num_worlds;
-                         w += kSmallThreads) {
-                        const int32_t first = (int32_t)lds.worldRows[w];
-                        const int32_t end = w + 1 < num_worlds ?
-                            (int32_t)lds.worldRows[w + 1] : n_out;
-                        tbl.worldOffsets[w] = first;
-                        tbl.worldCounts[w] = end - first;
-                    }
-                } else if (S->numWorlds <= kSmallRangeWorlds) {
-                    // (counts in LDS and a scan, sortSmallOneGroup)
-                    smallWorldRanges(tbl, sorted, n_out, S->numWorlds,
-                                     lds.worldRows, lds.rangeScan);
-                } else {
-                    gatherColumn(S, site, gc, tbl, 0, n_out, (int32_t)tid,
-                                 kSmallThreads, nullptr, sorted, false);
-                }
-                continue;
-            }
-            const int32_t row_begin = slice * per < n_out ? slice * per : n_out;
-            const int32_t row_end = row_begin + per < n_out ? row_begin + per : n_out;
-            if (row_begin < row_end) {
-                gatherColumn(S, site, gc, tbl, row_begin, row_end, (int32_t)tid,
-                             kSmallThreads, perm + row_begin, sorted, false);
-            }
-        }
-    }
-
-    // ---- the last workgroup to get here publishes ---------------------------
-    __threadfence();
-    __syncthreads();
-    if (tid == 0) {
-        const uint32_t before = __hip_atomic_fetch_add(&state->spreadDone, 1u,
-            __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        lds.last = before + 1u == (uint32_t)groups ? 1u : 0u;
-    }
-    __syncthreads();
-    if (lds.last == 0u) {
-        return;
-    }
-    __threadfence();
-    if (tid == 0) {
-        state->spreadDone = 0u;
-    }
-    // (numValid: written by a workgroup that counted before this one)
-    const int32_t n_out = site.worldSort ?
-        (int32_t)__hip_atomic_load(&state->numValid, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT) : n;
-    publishSite(S, site, tbl, n);
-    __syncthreads();
-    for (int32_t c = 0; c < tbl.numColumns; c++) {
-        if ((tbl.columnFlags[c] & kColumnPinned) == 0u) continue;
-        const uint32_t *src = (const uint32_t *)tbl.columnsAlt[c];
-        uint32_t *dst = (uint32_t *)tbl.columns[c];
-        long long words = ((long long)n_out * tbl.columnBytes[c] + 3) / 4;
-        for (long long j = tid; j < words; j += kSmallThreads) {
-            dst[j] = src[j];
-        }
-    }
-    __syncthreads();
-    cleanSortState(state);
-}
 
 // ---------------------------------------------------------------------------
 // compaction chain (world sorts of tables that are still sorted from last time)
@@ -2189,8 +1907,6 @@ int sortNumPasses(bool world_sort, uint32_t num_worlds)
 
 uint32_t sortTileSize() { return (uint32_t)kSortTile; }
 
-// rows the one-launch sort of a busy table (sortSmallSpread) orders in LDS
-uint32_t sortSpreadRowLimit() { return (uint32_t)kSpreadRows; }
 
 // (MADRONA_MWHIP_SORT_SMALL_ROWS overrides it: measurements)
 uint32_t sortSmallRowLimit()
@@ -2235,9 +1951,8 @@ void buildSortLaunches(const SortBatch &batch, std::vector<KernelLaunch> &out)
     // every table of the batch is small: the whole node in one launch
     if (batch.small) {
         KernelLaunch k;
-        k.fn = batch.spreadGroups > 1u ? (const void *)&sortSmallSpread :
-                                         (const void *)&sortSmall;
-        k.grid = dim3(num_sites, std::max(batch.spreadGroups, 1u), 1);
+        k.fn = (const void *)&sortSmall;
+        k.grid = dim3(num_sites, 1, 1);
         k.block = dim3(kSmallThreads, 1, 1);
         k.setArgs(batch.stateDev, batch.sitesDev, batch.gatherColumnsDev,
                   batch.numGatherColumns, (const MiscOp *)nullptr, 0u);

@@ -132,6 +132,23 @@ public:
                                       math::Vector3 *out_hit_normal,
                                       float t_max = float(INFINITY));
 
+    // (this backend) traceRay for rays that share their origin: called by the
+    // lanes of a 32-lane group together (an agent's lidar in a
+    // CustomParallelForNode<..., 32, 1, ...>: lane = ray) with the group's LDS
+    // scratch -- broadphase::rayGroupScratch() -- the ray-independent half of
+    // every leaf test is computed once per leaf instead of once per (ray,
+    // leaf).  Same hits, bit for bit.  scratch == nullptr, rays that turn out
+    // not to share origin and tree, or fewer than 8 of them: plain traceRay.
+    // Only kernels that call rayGroupScratch() carry its LDS (39 KB per
+    // 256-thread workgroup); plain traceRay carries none.
+    struct RayGroupScratch;
+    MADRONA_HD inline Entity traceRayShared(RayGroupScratch *scratch,
+                                            math::Vector3 o,
+                                            math::Vector3 d,
+                                            float *out_hit_t,
+                                            math::Vector3 *out_hit_normal,
+                                            float t_max = float(INFINITY));
+
     MADRONA_HD inline void updateLeafPosition(LeafID leaf_id,
                                               const math::Vector3 &pos,
                                               const math::Quat &rot,
@@ -407,6 +424,14 @@ private:
                                             float t_max,
                                             float *hit_t,
                                             math::Vector3 *hit_normal);
+
+    template <bool SharedOrigin>
+    MADRONA_HD inline Entity traceRayImpl(RayGroupScratch *scratch,
+                                          math::Vector3 o,
+                                          math::Vector3 d,
+                                          float *out_hit_t,
+                                          math::Vector3 *out_hit_normal,
+                                          float t_max);
 
     MADRONA_HD inline int32_t midpointSplit(int32_t base, int32_t num_elems);
     MADRONA_HD inline void growAncestors(int32_t child_idx,

@@ -849,7 +849,7 @@ __device__ inline uint64_t bodyKey(Context &ctx, Loc loc)
 #endif
 __global__ void __launch_bounds__(256)
 __attribute__((amdgpu_waves_per_eu(MADRONA_PHYS_WAVES_PER_EU)))
-physicsStepKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
+physicsStepKernel(EcsState *S, void *node_data, uint32_t fallback_mode, uint32_t)
 {
     mwhip::TraceScope trace_scope(S);
     StateManager *state_mgr = static_cast<StateManager *>(S);
@@ -883,8 +883,19 @@ physicsStepKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
     const uint32_t cand_stride = ps->candidatesPerWorld;
     const uint32_t contact_stride = ps->contactsPerWorld;
 
-    for (int32_t world = (int32_t)blockIdx.x * waves_per_block + wave_in_block;
-         world < num_worlds; world += (int32_t)gridDim.x * waves_per_block) {
+    // fallback mode (launched behind an LDS step kernel): only the worlds that
+    // kernel listed -- too many bodies or contacts for its block
+    const int32_t *fallback_list = fallback_mode != 0u ?
+        ((const PhysicsStepParams *)node_data)->fallbackList : nullptr;
+    const int32_t num_jobs = fallback_list != nullptr ?
+        __hip_atomic_load(fallback_list, __ATOMIC_RELAXED,
+                          __HIP_MEMORY_SCOPE_AGENT) : num_worlds;
+
+    for (int32_t job = (int32_t)blockIdx.x * waves_per_block + wave_in_block;
+         job < num_jobs; job += (int32_t)gridDim.x * waves_per_block) {
+        const int32_t world = fallback_list != nullptr ?
+            __hip_atomic_load(fallback_list + 1 + job, __ATOMIC_RELAXED,
+                              __HIP_MEMORY_SCOPE_AGENT) : job;
         Context ctx = TaskGraph::makeContext<Context>(
             state_mgr, WorldID { world }, true);
         const ObjectManager &obj_mgr = *ctx.singleton<ObjectData>().mgr;
@@ -1509,122 +1520,9 @@ __device__ inline PairSetup ldsSetupPair(const WorldBlock<MAXB, LPW> *w,
         PrimitiveTransform { w->pos[kb], w->rot[kb], w->scale[kb] });
 }
 
-// The part of a step that reads the ECS tables: body k of the world -> slot k of
-// the block `dst` (in LDS when the step kernel loads for itself, in HBM when
-// physicsPackKernel prepares the world image).
-//
-// Everything a row leads to is read into registers (BodyRow) before anything is
-// written to the block: `dst` and the columns are generic pointers, so a store
-// to the block between two column reads orders them.  A row is then three
-// rounds of loads: the columns; what the object id and the leaf id lead to;
-// the leaf's slot in its parent node.
-struct BodyRow {
-    Loc loc;
-    math::Vector3 pos;
-    math::Quat rot;
-    math::Diag3x3 scale;
-    Velocity vel;
-    math::Vector3 extForce;
-    math::Vector3 extTorque;
-    ResponseType resp;
-    int32_t entityID;
-    RigidBodyMetadata metadata;
-    uint32_t primOffset;
-    uint32_t primCount;
-    int32_t leaf;
-    math::AABB queryBox;
-    math::AABB slotBox;
-};
-
-__device__ inline BodyRow readBodyRow(Context &ctx, const WorldBodies &bodies,
-                                      const broadphase::BVH &bvh,
-                                      const ObjectManager &hbm_obj_mgr, int32_t k)
-{
-    BodyRow row;
-    row.loc = bodies.loc(k);
-    const Loc loc = row.loc;
-    row.pos = ctx.getDirect<base::Position>(RGDCols::Position, loc);
-    row.rot = ctx.getDirect<base::Rotation>(RGDCols::Rotation, loc);
-    row.scale = ctx.getDirect<base::Scale>(RGDCols::Scale, loc);
-    row.vel = ctx.getDirect<Velocity>(RGDCols::Velocity, loc);
-    row.extForce = ctx.getDirect<ExternalForce>(RGDCols::ExternalForce, loc);
-    row.extTorque = ctx.getDirect<ExternalTorque>(RGDCols::ExternalTorque, loc);
-    row.resp = ctx.getDirect<ResponseType>(RGDCols::ResponseType, loc);
-    row.entityID = ctx.getDirect<Entity>(0, loc).id;
-    const base::ObjectID obj_id =
-        ctx.getDirect<base::ObjectID>(RGDCols::ObjectID, loc);
-    row.leaf = ctx.getDirect<broadphase::LeafID>(RGDCols::LeafID, loc).id;
-
-    row.metadata = hbm_obj_mgr.metadata[obj_id.idx];
-    row.primOffset = hbm_obj_mgr.rigidBodyPrimitiveOffsets[obj_id.idx];
-    row.primCount = hbm_obj_mgr.rigidBodyPrimitiveCounts[obj_id.idx];
-    row.queryBox = bvh.getLeafAABB(broadphase::LeafID { row.leaf });
-    row.slotBox = bvh.leafSlotBounds(row.leaf);
-    return row;
-}
-
-template <int MAXB, int LPW>
-__device__ inline void writeBodyRow(WorldBlock<MAXB, LPW> *dst,
-                                    const uint16_t *leaf_rank, int32_t k,
-                                    const BodyRow &row)
-{
-    const uint32_t rank = leaf_rank[row.leaf];
-    dst->bodyLoc[k] = row.loc;
-    dst->pos[k] = row.pos;
-    dst->rot[k] = row.rot;
-    dst->scale[k] = row.scale;
-    dst->vel[k] = row.vel;
-    dst->extForce[k] = row.extForce;
-    dst->extTorque[k] = row.extTorque;
-    dst->resp[k] = (uint32_t)row.resp;
-    dst->entityID[k] = row.entityID;
-    dst->constants[k] = xpbd::bodyConstants(row.metadata, row.resp);
-    dst->primOffset[k] = (uint16_t)row.primOffset;
-    dst->primCount[k] = (uint16_t)row.primCount;
-    dst->queryBox()[k] = row.queryBox;
-    dst->rankSlotBox()[rank] = row.slotBox;
-    dst->rankEntity()[rank] = row.entityID;
-    dst->orderBody[rank] = (uint16_t)k;
-    dst->leafOf[k] = (uint16_t)row.leaf;
-}
-
-// leaf_rank (LDS, filled here): leaf id -> position in the BVH's traversal
-// order.  The first chunk of rows is read while the ranks are being written --
-// neither depends on the other, and with one wavefront per SIMD there is nothing
-// else to overlap a chain of cold misses with.
-template <int MAXB, int LPW>
-__device__ inline void loadWorldBodies(uint32_t lane, WorldBlock<MAXB, LPW> *dst,
-                                       uint16_t *leaf_rank, Context &ctx,
-                                       const WorldBodies &bodies,
-                                       const broadphase::BVH &bvh,
-                                       const ObjectManager &hbm_obj_mgr,
-                                       int32_t num_bodies)
-{
-    const bool first_active = (int32_t)lane < num_bodies;
-    BodyRow first;
-    if (first_active) {
-        first = readBodyRow(ctx, bodies, bvh, hbm_obj_mgr, (int32_t)lane);
-    }
-    {
-        const int32_t *order = bvh.traversalOrder();
-        for (int32_t r = (int32_t)lane; r < num_bodies; r += LPW) {
-            leaf_rank[order[r]] = (uint16_t)r;
-        }
-    }
-    wave::phaseFence();
-    if (first_active) {
-        writeBodyRow<MAXB, LPW>(dst, leaf_rank, (int32_t)lane, first);
-    }
-    for (int32_t k = (int32_t)lane + LPW; k < num_bodies; k += LPW) {
-        const BodyRow row = readBodyRow(ctx, bodies, bvh, hbm_obj_mgr, k);
-        writeBodyRow<MAXB, LPW>(dst, leaf_rank, k, row);
-    }
-}
-
 // ---------------------------------------------------------------------------
-// Loading a world through the frame (PhysicsFrame, physics.inl): the same
-// values in the same slots of the block as loadWorldBodies + the joint staging
-// of the step kernel leave, fetched in five rounds of loads instead of twenty.
+// Loading a world through the frame (PhysicsFrame, physics.inl): five rounds
+// of loads (rounds 1-3 walked the tables from every wavefront: twenty).
 // Every round is issued in one go -- nothing is written, and nothing loaded is
 // looked at, before the loads of the round are on their way:
 //   1  (caller) the world's place in the order; the frame itself is hot
@@ -1637,7 +1535,12 @@ __device__ inline void loadWorldBodies(uint32_t lane, WorldBlock<MAXB, LPW> *dst
 //   6  the leaf's slot box in its parent node
 // ---------------------------------------------------------------------------
 struct FramedWorld {
-    int32_t numBodies;          // < 0: the world cannot be stepped (kErrPhysics)
+    // numBodies < 0: not stepped by this kernel -- unsteppable: tables await
+    // their sort or the tree does not match them (kErrPhysics); tooManyBodies:
+    // more than the instantiation's MAXB (the HBM kernel takes the world)
+    static constexpr int32_t unsteppable = -1;
+    static constexpr int32_t tooManyBodies = -2;
+    int32_t numBodies;
     int32_t jointBegin;
     int32_t numJoints;
     bool jointsStaged;
@@ -1752,8 +1655,12 @@ __device__ __attribute__((always_inline)) inline FramedWorld loadWorldFramed(
     out.numJoints = num_joints;
     out.jointsStaged = num_joints <= Block::maxJoints;
     out.objMgr = world_mgr;
-    if (tables_unsorted != 0u || num_bodies > MAXB || tree.numLeaves != num_bodies) {
-        out.numBodies = -1;
+    if (tables_unsorted != 0u || tree.numLeaves != num_bodies) {
+        out.numBodies = FramedWorld::unsteppable;
+        return out;
+    }
+    if (num_bodies > MAXB) {
+        out.numBodies = FramedWorld::tooManyBodies;
         return out;
     }
     if (lane == 0) {
@@ -1930,51 +1837,6 @@ __device__ __attribute__((always_inline)) inline FramedWorld loadWorldFramed(
     return out;
 }
 
-// World images for physicsStepLdsKernel<MAXB>: one wavefront per world runs the
-// table-reading part of the step and leaves the result in HBM in the layout of
-// the step's LDS block.  The chain of dependent loads is the same, but this
-// kernel needs a handful of registers and 64 B of LDS per wave: eight waves per
-// SIMD (the step kernel: two) and every world of an 8192-world launch resident
-// at once, so the chains of different worlds overlap instead of queueing.
-template <int MAXB>
-__global__ void __launch_bounds__(64)
-physicsPackKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
-{
-    mwhip::TraceScope trace_scope(S);
-    using Block = WorldBlock<MAXB>;
-
-    StateManager *state_mgr = static_cast<StateManager *>(S);
-    PhysicsScratch *ps = detail::scratch(S);
-    const PhysicsStepParams params = *(const PhysicsStepParams *)node_data;
-
-    const uint32_t lane = wave::laneID();
-    const int32_t num_worlds = S->numWorlds;
-
-    __shared__ uint16_t leaf_rank[MAXB];
-
-    for (int32_t world = (int32_t)blockIdx.x; world < num_worlds;
-         world += (int32_t)gridDim.x) {
-        Context ctx = TaskGraph::makeContext<Context>(
-            state_mgr, WorldID { world }, true);
-        const ObjectManager &hbm_obj_mgr = *ctx.singleton<ObjectData>().mgr;
-        const broadphase::BVH &bvh = ctx.singleton<broadphase::BVH>();
-
-        WorldBodies bodies;
-        const bool unsorted = !bodies.fill(S, ps, world);
-        const int32_t num_bodies = bodies.count();
-        if (unsorted || num_bodies > MAXB || bvh.numLeaves() != num_bodies) {
-            continue;       // the step kernel raises the error
-        }
-
-
-        Block *image = (Block *)((char *)params.worldImages +
-                                 (size_t)world * Block::imageBytes());
-        loadWorldBodies<MAXB, 64>(lane, image, leaf_rank, ctx, bodies, bvh,
-                                  hbm_obj_mgr, num_bodies);
-        wave::phaseFence();
-    }
-}
-
 // Two waves per SIMD: PMC shows the step parked on s_waitcnt 45 % of its wave
 // cycles at one wave per SIMD (SQ_WAIT_ANY / SQ_WAVE_CYCLES); capping the
 // kernel at 256 registers costs spills but lets a second world fill those
@@ -2048,37 +1910,19 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
 
     // Worlds are taken in the order physicsOrderKernel left: the ones that took
     // longest last step first, so that the launch does not end on a few heavy
-    // worlds with most of the chip idle (and the two worlds of a wavefront,
-    // neighbours in that order, cost about the same).
-    //
-    // Which two worlds share a wavefront (LPW = 32): neighbours in that order.
-    // The other candidate -- the k-th heaviest with the k-th lightest
-    // (foldPairs, MADRONA_MWHIP_PHYS_ORDER=2), on the theory that what only one
-    // world does (a cooperative hull-hull test, 5-18 us) is time the other
-    // half sits out, so that a wavefront costs the SUM of its worlds' tests and
-    // equal sums pack better -- was measured slower (Escape Room 825 -> 844 us,
-    // Hide-and-Seek 930 -> 980 us): most of a world's cost is in the parts both
-    // halves run in lock step (loads, integration, solver levels), where a
-    // wavefront costs the LONGER of its two worlds, and similar worlds waste
-    // the least of it.
+    // worlds with most of the chip idle; the two worlds of a wavefront (LPW =
+    // 32) are neighbours in that order and cost about the same.  One workgroup
+    // per job (a world, or a pair of them): the hardware's dispatcher hands the
+    // next job to a free slot within a microsecond.  (Measured and removed in
+    // round 5, numbers in profiles/r04_phys_variants.jsonl and DESIGN.md: the
+    // k-th heaviest paired with the k-th lightest, + 20 us; persistent
+    // wavefronts taking jobs from a counter with the next world's header
+    // fetched ahead, +- 0; world images packed by a kernel of their own,
+    // + 21 us net; the leaf refit folded into the epilogue, + 6 us net; the
+    // order blended over several steps, +- 0.)
     const int32_t *world_order = params.worldOrder;
-    const bool fold_pairs = LPW == 32 && (params.foldPairs & 1) != 0 &&
-        world_order != nullptr;
     const int32_t num_jobs = (num_worlds + worlds_per_wave - 1) / worlds_per_wave;
 
-    // Jobs (a world, or a pair of them) in that order.  With a job counter
-    // (params.jobCounter, zeroed by physicsOrderKernel) the launch is as many
-    // PERSISTENT wavefronts as the chip holds, each taking the next job from
-    // the counter when it is done -- the same heaviest-first greedy schedule
-    // the hardware's workgroup dispatcher gives a grid of one workgroup per
-    // job, minus a dispatch per job, and with the chance to look ahead: a
-    // wavefront knows its NEXT job while it still works on the current one, and
-    // fetches that world's header (its place in the order, its row ranges in
-    // the rigid-body tables: a chain of three dependent cold misses that
-    // nothing else can hide with one wavefront per SIMD) before it stores the
-    // current world, not after.  (4096 atomics on one address over ~800 us do
-    // not queue; round 2's persistent version strode statically and lost to
-    // the dispatcher's balancing.)
     // (the scratch block's words never change: invariant loads at the top of
     // the kernel, not two dependent round trips in front of the candidate pass)
     const uint32_t candidates_per_world =
@@ -2086,137 +1930,54 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
     CandidateCollision *const world_candidates =
         mwhip::loadInvariant(&ps->worldCandidates);
 
-    // (with a frame the row ranges are read with everything else the world
-    // index leads to: loadWorldFramed)
-    const PhysicsFrame *frame =
-        params.worldImages == nullptr && params.useFrame != 0u ?
-            &((const PhysicsStepNode *)node_data)->frame : nullptr;
-    struct JobHeader {
-        int32_t world;          // -1: no world for this half of the wavefront
-        bool sorted;
-        WorldBodies bodies;
-    };
-    auto fetchHeader = [&](int32_t job, JobHeader &h) {
-        int32_t slot = job * worlds_per_wave + group;
-        if (fold_pairs) {
-            slot = group == 0 ? job : num_worlds - 1 - job;
-            if (group != 0 && slot == job) {
-                slot = num_worlds;  // (odd world count: the middle one is alone)
-            }
+    // the frame: where every world's rows are, resolved once per launch by
+    // physicsOrderKernel (fillPhysicsFrame)
+    const PhysicsFrame *frame = &((const PhysicsStepNode *)node_data)->frame;
+
+    // A world this instantiation cannot hold -- more than MAXB bodies, more
+    // contacts in a substep than the block has room for -- is left untouched
+    // (nothing of it has been stored yet) and handed to the kernel that works
+    // out of HBM, which runs right behind this one over the worlds listed here
+    // (physicsStepKernel, fallback mode; reference: no cap, its tables grow).
+    int32_t *const fallback_list = params.fallbackList;
+    const uint32_t contact_cap = params.contactCap != 0u &&
+        params.contactCap < (uint32_t)Block::maxContacts ?
+            params.contactCap : (uint32_t)Block::maxContacts;
+    auto toFallback = [&](int32_t world) {
+        if (lane == 0) {
+            const int32_t at = __hip_atomic_fetch_add(fallback_list, 1,
+                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            fallback_list[1 + at] = world;
         }
-        h.world = -1;
-        h.sorted = true;
-        if (job < num_jobs && slot < num_worlds) {
-            h.world = world_order != nullptr ? world_order[slot] : slot;
-            if (frame == nullptr) {
-                h.sorted = h.bodies.fill(S, ps, h.world);
-            }
-        }
-    };
-    int32_t *job_counter = params.jobCounter;
-    auto takeJob = [&]() {
-        int32_t taken = 0;
-        if (wave::laneID() == 0u) {
-            taken = __hip_atomic_fetch_add(job_counter, 1, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
-        }
-        return __shfl(taken, 0, 64);
     };
 
-    int32_t job = job_counter != nullptr ? takeJob() : (int32_t)blockIdx.x;
-    JobHeader cur_job;
-    fetchHeader(job, cur_job);
-    while (job < num_jobs) {
-        const int32_t next_job = job_counter != nullptr ? takeJob() :
-            job + (int32_t)gridDim.x;
-        JobHeader next_header;
-        bool have_next = false;
+    for (int32_t job = (int32_t)blockIdx.x; job < num_jobs;
+         job += (int32_t)gridDim.x) {
     do {
-        if (cur_job.world < 0) {
-            continue;
+        const int32_t order_slot = job * worlds_per_wave + group;
+        if (order_slot >= num_worlds) {
+            continue;       // (odd world count: this half has no world)
         }
-        const int32_t world = cur_job.world;
+        const int32_t world = world_order[order_slot];
         const long long cost_t0 = (long long)wall_clock64();
         uint32_t cost_work = 1;    // (what the world asked of the wavefront, roughly)
         Context ctx = TaskGraph::makeContext<Context>(
             state_mgr, WorldID { world }, true);
 
-        int32_t num_bodies;
-        const ObjectManager *hbm_mgr;
-        FramedWorld framed {};
-        if (frame != nullptr) {
-            // ---- the world through the frame: HBM -> LDS in five rounds -----
-            framed = loadWorldFramed<MAXB, LPW>(lane, w, frame, world);
-            if (framed.numBodies < 0) {
+        // ---- the world through the frame: HBM -> LDS in five rounds ---------
+        const FramedWorld framed = loadWorldFramed<MAXB, LPW>(lane, w, frame, world);
+        if (framed.numBodies < 0) {
+            if (framed.numBodies == FramedWorld::tooManyBodies) {
+                toFallback(world);
+            } else {
                 mwhip::raiseError(S, mwhip::kErrPhysics);
-                continue;
             }
-            num_bodies = framed.numBodies;
-            hbm_mgr = framed.objMgr == frame->objMgr ? &frame->objMgrCopy :
-                                                       framed.objMgr;
-            PHYS_PROF(8);
-        } else {
-        hbm_mgr = ctx.singleton<ObjectData>().mgr;
-        const ObjectManager &hbm_obj_mgr = *hbm_mgr;
-        const broadphase::BVH &bvh = ctx.singleton<broadphase::BVH>();
-
-        // ---- the world's bodies ---------------------------------------------
-        const WorldBodies &bodies = cur_job.bodies;
-        const bool unsorted = !cur_job.sorted;
-        num_bodies = bodies.count();
-        if (unsorted || num_bodies > MAXB || bvh.numLeaves() != num_bodies) {
-            mwhip::raiseError(S, mwhip::kErrPhysics);
             continue;
         }
-        PHYS_PROF(10);
-
-        // ---- load: HBM -> LDS ---------------------------------------------------
-        // (the image part of the block does not depend on LPW)
-        static_assert(Block::imageBytes() == WorldBlock<MAXB, 64>::imageBytes());
-        const char *world_images = (const char *)params.worldImages;
-        if (world_images != nullptr) {
-            // packed by physicsPackKernel just before this launch
-            const uint4 *src = (const uint4 *)(
-                world_images + (size_t)world * Block::imageBytes());
-            uint4 *dst = (uint4 *)w;
-            constexpr uint32_t num_vec = (uint32_t)(Block::imageBytes() / 16);
-            // every load of the image in flight before the first store to the
-            // block (generic pointers on both sides: a store in between orders
-            // the loads, and the copy would be a dozen round trips in a row)
-            constexpr uint32_t per_lane = (num_vec + LPW - 1) / LPW;
-            constexpr uint32_t batch = per_lane < 16u ? per_lane : 16u;
-            for (uint32_t first = 0; first < per_lane; first += batch) {
-                uint4 tmp[batch];
-#pragma unroll
-                for (uint32_t u = 0; u < batch; u++) {
-                    const uint32_t i = (first + u) * LPW + lane;
-                    tmp[u] = i < num_vec ? src[i] : uint4 { 0, 0, 0, 0 };
-                }
-#pragma unroll
-                for (uint32_t u = 0; u < batch; u++) {
-                    const uint32_t i = (first + u) * LPW + lane;
-                    if (i < num_vec) dst[i] = tmp[u];
-                }
-            }
-        } else {
-            // (read before the rows, stored after them: one more load in flight)
-            PhysicsSystemState sys_regs {};
-            if (lane == 0) {
-                sys_regs = ctx.singleton<PhysicsSystemState>();
-            }
-            loadWorldBodies<MAXB, LPW>(lane, w, w->leafRank, ctx, bodies, bvh,
-                                       hbm_obj_mgr, num_bodies);
-            if (lane == 0) {
-                w->sys = sys_regs;
-            }
-        }
-        if (lane == 0 && world_images != nullptr) {
-            w->sys = ctx.singleton<PhysicsSystemState>();
-        }
-        wave::phaseFence();
+        const int32_t num_bodies = framed.numBodies;
+        const ObjectManager *hbm_mgr = framed.objMgr == frame->objMgr ?
+            &frame->objMgrCopy : framed.objMgr;
         PHYS_PROF(8);
-
-        }
         const ObjectManager &hbm_obj_mgr = *hbm_mgr;
 
         // primitives referenced by this world's bodies
@@ -2378,19 +2139,9 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
         };
 
         // ---- the world's joints (table sorted by world just before) -----------
-        int32_t joint_begin;
-        int32_t num_joints;
-        const JointConstraint *joints;
-        if (frame != nullptr) {
-            joint_begin = framed.jointBegin;
-            num_joints = framed.numJoints;
-            joints = mwhip::loadInvariant(&frame->joints) + joint_begin;
-        } else {
-            const TableHdr &joint_tbl = S->tables[ps->jointArchetype];
-            joint_begin = joint_tbl.worldOffsets[world];
-            num_joints = joint_tbl.worldCounts[world];
-            joints = (const JointConstraint *)joint_tbl.columns[2] + joint_begin;
-        }
+        const int32_t num_joints = framed.numJoints;
+        const JointConstraint *joints =
+            mwhip::loadInvariant(&frame->joints) + framed.jointBegin;
 
         // body index of a joint end point (the per-archetype row ranges are not
         // kept alive through the substeps: look the row up among the staged
@@ -2405,19 +2156,11 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
             }
             return Loc { 0, 0 };
         };
-        const bool joints_staged = num_joints <= Block::maxJoints;
-        if (joints_staged && frame == nullptr) {
-            for (int32_t i = (int32_t)lane; i < num_joints; i += LPW) {
-                w->joints[i] = joints[i];
-                w->jointBodies[i][0] =
-                    (uint16_t)jointBodyLoc(joints[i].e1).row;
-                w->jointBodies[i][1] =
-                    (uint16_t)jointBodyLoc(joints[i].e2).row;
-            }
-            wave::phaseFence();
-        }
+        // (staged by loadWorldFramed when they fit the block)
+        const bool joints_staged = framed.jointsStaged;
 
         PHYS_PROF(7);
+        bool bailed = false;
         for (int32_t substep = 0; substep < params.numSubsteps; substep++) {
             // ---- integrate (xpbd.cpp substepRigidBodies) ------------------------
             for (int32_t k = (int32_t)lane; k < num_bodies; k += LPW) {
@@ -2457,8 +2200,7 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
             uint32_t num_contacts = 0;
             bool contacts_overflow = false;
             for (uint32_t chunk = 0; chunk < num_candidates; ) {
-                const uint32_t free_slots =
-                    (uint32_t)Block::maxContacts - num_contacts;
+                const uint32_t free_slots = contact_cap - num_contacts;
                 if (free_slots == 0) {
                     contacts_overflow = true;
                     break;
@@ -2649,7 +2391,11 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                 chunk += width;
             }
             if (contacts_overflow) {
-                mwhip::raiseError(S, mwhip::kErrTableOverflow);
+                // more contacts than the block holds: the world is stepped out
+                // of HBM instead (nothing of this step has left LDS yet)
+                toFallback(world);
+                bailed = true;
+                break;
             }
             cost_work += 8u * num_contacts;
             wave::phaseFence();
@@ -2754,34 +2500,17 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
         }
 
         PHYS_PROF(6);
-        // (the next job's header: on its way while this world is stored)
-        fetchHeader(next_job, next_header);
-        have_next = true;
+        if (bailed) {
+            continue;
+        }
         // ---- store: LDS -> HBM --------------------------------------------------
         // The addresses of the body's six columns in ONE round of loads, then
         // the stores, none of them waited for.  (Through ctx.getDirect every
         // column was: load the column address, wait -- for the stores before
         // it as well, they share the counter --, store: 14 us per pair of
         // worlds in the phase profile, now 3.)
-        // Opt-in (MADRONA_MWHIP_PHYS_REFIT=1, physics.inl): the leaf update +
-        // refit of the world folded in (what
-        // setupPostIntegrationTasks's node does -- reference broadphase.cpp
-        // updateLeafPositionsEntry + refitEntry --, PhysicsStepParams::
-        // foldPairs bit 1): its loads ride on the same rounds -- the tree's
-        // members with the column addresses, the body's object id and its
-        // leaf's parent next, the object's box and the leaf's slot last.
-        const bool fold_refit = (params.foldPairs & 2) != 0;
-        broadphase::BVH::RefitView tree_view {};
-        const math::AABB *body_aabbs = nullptr;
-        if (fold_refit) {
-            tree_view = broadphase::BVH::loadRefitView(frame != nullptr ?
-                mwhip::loadInvariant(&frame->trees) + world :
-                &ctx.singleton<broadphase::BVH>());
-            body_aabbs = mwhip::loadGlobal(&hbm_mgr->rigidBodyAABBs);
-        }
         for (int32_t k = (int32_t)lane; k < num_bodies; k += LPW) {
             const Loc loc = w->bodyLoc[k];
-            const int32_t leaf = (int32_t)w->leafOf[k];
             const TableHdr &tbl = mwhip::tablesOf(S)[loc.archetype];
             base::Position *col_pos = (base::Position *)
                 mwhip::loadGlobal(&tbl.columns[RGDCols::Position]);
@@ -2795,17 +2524,7 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                 mwhip::loadGlobal(&tbl.columns[xpbd::XPBDCols::PreSolvePositional]);
             xpbd::PreSolveVelocity *col_pre_vel = (xpbd::PreSolveVelocity *)
                 mwhip::loadGlobal(&tbl.columns[xpbd::XPBDCols::PreSolveVelocity]);
-            const base::ObjectID *col_obj = (const base::ObjectID *)
-                mwhip::loadGlobal(&tbl.columns[RGDCols::ObjectID]);
             roundIssued();
-            base::ObjectID obj_id { 0 };
-            uint32_t leaf_parent = 0;
-            if (fold_refit) {
-                obj_id = mwhip::loadGlobal(col_obj + loc.row);
-                if (tree_view.refit) {
-                    leaf_parent = mwhip::loadGlobal(tree_view.leafParents + leaf);
-                }
-            }
             const base::Position pos = w->pos[k];
             const base::Rotation rot = w->rot[k];
             const Velocity vel = w->vel[k];
@@ -2818,57 +2537,27 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
             mwhip::storeGlobal(col_prev + loc.row, prev);
             mwhip::storeGlobal(col_pre_pos + loc.row, pre_pos);
             mwhip::storeGlobal(col_pre_vel + loc.row, pre_vel);
-            if (fold_refit) {
-                const math::AABB obj_aabb =
-                    mwhip::loadGlobal(body_aabbs + obj_id.idx);
-                math::AABB slot = math::AABB::invalid();
-                if (tree_view.refit) {
-                    slot = broadphase::BVH::loadSlotBounds(tree_view.nodes,
-                                                           leaf_parent);
-                }
-                broadphase::BVH::applyLeafUpdate(tree_view, leaf, leaf_parent,
-                    slot, pos, rot, w->scale[k], vel.linear, obj_aabb);
-            }
         }
         // (the stores are not waited for: nothing of this job reads them, the
-        // next job's first wait -- or the end of the kernel -- covers them, and
-        // the block is only rewritten by this wavefront's own later LDS writes)
+        // end of the kernel covers them, and the block is only rewritten by
+        // this wavefront's own later LDS writes)
         __builtin_amdgcn_wave_barrier();
         PHYS_PROF(7);
 
         // what this world cost: the wavefront's time, shared out between its two
         // worlds (they run in lock step: the clock alone cannot tell them apart)
-        if (params.worldCost != nullptr) {
+        {
             uint32_t cost = (uint32_t)((long long)wall_clock64() - cost_t0);
             if (LPW == 32) {
                 const uint32_t other = __shfl_xor(cost_work, 32, 64);
                 const uint32_t most = cost_work > other ? cost_work : other;
                 cost = (uint32_t)(((uint64_t)cost * cost_work) / most);
             }
-            if ((params.foldPairs & 64) != 0) {
-                // (measurement: order by the work proxy alone, not by time)
-                cost = cost_work * 16u;
-            }
             if (lane == 0) {
-                // (bits 4-5 of foldPairs: blend with what the world cost before,
-                // new = old + (measured - old) >> shift; 0 = last step's value)
-                const uint32_t shift = ((uint32_t)params.foldPairs >> 4) & 3u;
-                if (shift != 0u) {
-                    const uint32_t old = params.worldCost[world];
-                    cost = old == 0u ? cost :
-                        (uint32_t)((int32_t)old + (((int32_t)cost - (int32_t)old) >>
-                                                   (int32_t)shift));
-                }
                 params.worldCost[world] = cost;
             }
         }
     } while (false);
-        // (a half that left its world early fetches its next header here)
-        if (!have_next) {
-            fetchHeader(next_job, next_header);
-        }
-        cur_job = next_header;
-        job = next_job;
     }
 
 #ifdef MADRONA_PHYS_PROFILE
@@ -2892,10 +2581,10 @@ physicsOrderKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
     const PhysicsStepParams params = *(const PhysicsStepParams *)node_data;
     const int32_t num_worlds = S->numWorlds;
     const uint32_t tid = threadIdx.x;
-    if (tid == 0 && params.jobCounter != nullptr) {
-        *params.jobCounter = 0;     // (the step kernel's persistent wavefronts)
+    if (tid == 0) {
+        params.fallbackList[0] = 0;     // (worlds the LDS step hands to the HBM one)
     }
-    if (params.useFrame != 0u && tid >= 960u) {
+    if (tid >= 960u) {
         // (the last wavefront: its share of the cost scan starts a moment later)
         fillPhysicsFrame(S, detail::scratch(S),
                          &((PhysicsStepNode *)node_data)->frame, tid - 960u, 64u);

@@ -103,27 +103,21 @@ struct PhysicsFrame {
 // node data of the fused per-world step kernel
 struct PhysicsStepParams {
     int32_t numSubsteps;
-    // bit 0: two worlds per wavefront, wavefront k steps the k-th heaviest
-    // world next to the k-th lightest (worldOrder folded) instead of next to its
-    // neighbour in that order; bit 1: the LDS step kernels end with the leaf
-    // update + refit of their world (setupPostIntegrationTasks then adds no node)
-    int32_t foldPairs;
-    // per-world images of the LDS step's block (physicsPackKernel writes them
-    // right before the step kernel reads them), or nullptr: the step kernel
-    // reads the tables itself
-    void *worldImages;
+    // LDS step kernels: contacts a world may hold per substep before it is
+    // handed to the HBM kernel; 0 = what the block has room for
+    // (MADRONA_MWHIP_PHYS_LDS_CONTACTS: lower it to exercise the fallback)
+    uint32_t contactCap;
     // LDS step kernels: what every world cost the last time it was stepped
     // (100 MHz ticks), and the worlds sorted by it, heaviest first
-    // (physicsOrderKernel); nullptr: worlds are stepped in index order
+    // (physicsOrderKernel)
     uint32_t *worldCost;
     int32_t *worldOrder;
-    // LDS step kernels: persistent wavefronts take jobs (a world / a pair of
-    // worlds, in worldOrder) from this counter; nullptr: one workgroup per job
-    int32_t *jobCounter;
-    // LDS step kernels: 1 = PhysicsStepNode::frame is filled by
-    // physicsOrderKernel; 0: every wavefront walks the tables itself
-    uint32_t useFrame;
-    uint32_t pad_;
+    // LDS step kernels: [0] = how many worlds of this step the instantiation
+    // could not hold (more bodies than MAXB, more contacts in a substep than
+    // the block has room for), [1 ..] = their indices; zeroed by
+    // physicsOrderKernel, filled by the LDS kernel, stepped by
+    // physicsStepKernel in fallback mode right behind it
+    int32_t *fallbackList;
 };
 
 // The step node's data: the parameters and, right behind them, the frame -- a
@@ -431,11 +425,62 @@ bool BVH::traceRayIntoLeaf(const RayLeaf &leaf,
     return true;
 }
 
+#if defined(__HIPCC__)
+// LDS of the rays that share an origin (traceRayShared): the ray-independent
+// part of the leaf tests of one 64-leaf window, per group of 32 lanes.
+struct BVH::RayGroupScratch {
+    RayLeaf leaves[64];
+};
+
+// The scratch of the calling lane's group of 32 in a 1-D workgroup of at most
+// 256 threads (what a CustomParallelForNode<..., 32, 1, ...> runs in); nullptr
+// in any other block shape.  Only kernels that call this carry the LDS.
+__device__ inline BVH::RayGroupScratch *rayGroupScratch()
+{
+    constexpr uint32_t groups_per_block = 8;
+    __shared__ BVH::RayGroupScratch scratch[groups_per_block];
+    if (blockDim.x > 32u * groups_per_block || blockDim.y != 1u ||
+            blockDim.z != 1u) {
+        return nullptr;
+    }
+    return &scratch[threadIdx.x / 32u];
+}
+#endif
+
 Entity BVH::traceRay(math::Vector3 o,
                      math::Vector3 d,
                      float *out_hit_t,
                      math::Vector3 *out_hit_normal,
                      float t_max)
+{
+    return traceRayImpl<false>(nullptr, o, d, out_hit_t, out_hit_normal, t_max);
+}
+
+Entity BVH::traceRayShared(RayGroupScratch *scratch,
+                           math::Vector3 o,
+                           math::Vector3 d,
+                           float *out_hit_t,
+                           math::Vector3 *out_hit_normal,
+                           float t_max)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (scratch != nullptr) {
+        return traceRayImpl<true>(scratch, o, d, out_hit_t, out_hit_normal, t_max);
+    }
+#endif
+    (void)scratch;
+    return traceRayImpl<false>(nullptr, o, d, out_hit_t, out_hit_normal, t_max);
+}
+
+// SharedOrigin: the caller's group of 32 lanes offered LDS (traceRayShared);
+// whether its rays really share origin and tree is still decided per call.
+template <bool SharedOrigin>
+Entity BVH::traceRayImpl([[maybe_unused]] RayGroupScratch *scratch,
+                         math::Vector3 o,
+                         math::Vector3 d,
+                         float *out_hit_t,
+                         math::Vector3 *out_hit_normal,
+                         float t_max)
 {
     using namespace math;
 
@@ -492,23 +537,28 @@ Entity BVH::traceRay(math::Vector3 o,
         const int32_t *traversal_order = mwhip::loadGlobal(&dfs_leaves_);
         const AABB *leaf_boxes = mwhip::loadGlobal(&leaf_aabbs_);
 
+        // Rays that share their origin (traceRayShared): the lanes of a
+        // half-wavefront that are in this call together with the SAME origin
+        // and tree (an agent's lidar: CustomParallelForNode<..., 32, 1, ...>,
+        // lane = ray) compute the ray-independent part of every leaf test ONCE
+        // per leaf -- a lane per leaf, into the caller's LDS scratch -- instead
+        // of once per (ray, leaf): the leaf's transform and primitive range (a
+        // chain of dependent loads) and the origin in the object's frame (a
+        // quaternion rotation and three exact divisions of the ~15 a leaf test
+        // costs).  Same expressions, same inputs, so the same bits (rayLeaf);
+        // what a ray then does per candidate leaf only involves its direction.
+        // The group's lanes re-read their active set at the top of every
+        // window (a lane whose ray is done with a window early waits there:
+        // wave_barrier), so the scratch of a window is only rewritten when
+        // every lane of the group has left the previous one; the two halves of
+        // a wavefront decide, fill and read independently (different trees and
+        // leaf counts included: a half whose tree has fewer windows simply
+        // leaves the loop earlier).
+        [[maybe_unused]] bool share_origin = false;
+        [[maybe_unused]] RayLeaf *group_leaves = nullptr;
 #if defined(__HIP_DEVICE_COMPILE__)
-        // Rays that share their origin: the lanes of a half-wavefront that are
-        // in this call together with the SAME origin and tree (an agent's
-        // lidar: CustomParallelForNode<..., 32, 1, ...>, lane = ray) compute
-        // the ray-independent part of every leaf test ONCE per leaf -- a lane
-        // per leaf, into LDS -- instead of once per (ray, leaf): the leaf's
-        // transform and primitive range (a chain of dependent loads) and the
-        // origin in the object's frame (a quaternion rotation and three exact
-        // divisions of the ~15 a leaf test costs).  Same expressions, same
-        // inputs, so the same bits (rayLeaf); what a ray then does per
-        // candidate leaf only involves its direction.
         constexpr int32_t ray_group_lanes = 32;
-        constexpr int32_t ray_groups_per_block = 8;     // 256-thread workgroups
-        __shared__ RayLeaf shared_leaves[ray_groups_per_block][64];
-        bool share_origin = false;
-        RayLeaf *group_leaves = nullptr;
-        {
+        if constexpr (SharedOrigin) {
             const uint32_t lane = __builtin_amdgcn_mbcnt_hi(
                 ~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
             const uint64_t active = __builtin_amdgcn_ballot_w64(true);
@@ -523,15 +573,16 @@ Entity BVH::traceRay(math::Vector3 o,
                 __shfl((uint32_t)(uintptr_t)this, leader, 64) ==
                     (uint32_t)(uintptr_t)this &&
                 __shfl((uint32_t)((uintptr_t)this >> 32), leader, 64) ==
-                    (uint32_t)((uintptr_t)this >> 32);
+                    (uint32_t)((uintptr_t)this >> 32) &&
+                __shfl((uint32_t)(uintptr_t)scratch, leader, 64) ==
+                    (uint32_t)(uintptr_t)scratch;
             const uint64_t agree = __builtin_amdgcn_ballot_w64(same);
             const uint32_t num_active = (uint32_t)__builtin_popcountll(half_mask);
-            // (worth it from a handful of rays on; the block shape the LDS
-            // array is sized for)
+            // (worth it from a handful of rays on)
             share_origin = ((agree >> half_first) & half_mask) == half_mask &&
-                num_active >= 8u && blockDim.x <= 256u && blockDim.y == 1u;
+                num_active >= 8u;
             if (share_origin) {
-                group_leaves = shared_leaves[threadIdx.x / ray_group_lanes];
+                group_leaves = scratch->leaves;
             }
         }
 #endif
@@ -2148,29 +2199,16 @@ MADRONA_HOST_API inline TaskGraphNodeID setupPhysicsStepTasks(
         default: return (const void *)&kernels::physicsStepKernel;
         }
     };
-    [[maybe_unused]] auto pack_stub = [] __host__ (int max_bodies)
-            -> const void * {
-        switch (max_bodies) {
-        case 32: return (const void *)&kernels::physicsPackKernel<32>;
-        case 64: return (const void *)&kernels::physicsPackKernel<64>;
-        default: return (const void *)&kernels::physicsPackKernel<128>;
-        }
+    [[maybe_unused]] auto fallback_stub = [] __host__ () -> const void * {
+        return (const void *)&kernels::physicsStepKernel;
     };
     [[maybe_unused]] auto order_stub = [] __host__ () -> const void * {
         return (const void *)&kernels::physicsOrderKernel;
     };
-    [[maybe_unused]] auto image_bytes = [] __host__ (int max_bodies) -> size_t {
-        switch (max_bodies) {
-        case 32: return kernels::WorldBlock<32>::imageBytes();
-        case 64: return kernels::WorldBlock<64>::imageBytes();
-        default: return kernels::WorldBlock<128>::imageBytes();
-        }
-    };
 #else
     auto step_stub = [](int, int) -> const void * { return nullptr; };
-    auto pack_stub = [](int) -> const void * { return nullptr; };
+    auto fallback_stub = []() -> const void * { return nullptr; };
     auto order_stub = []() -> const void * { return nullptr; };
-    auto image_bytes = [](int) -> size_t { return 0; };
 #endif
 
     // joints are created / destroyed by the simulator between steps: group
@@ -2212,21 +2250,20 @@ MADRONA_HOST_API inline TaskGraphNodeID setupPhysicsStepTasks(
                 per_world[w] += counts[w];
             }
         }
-        int32_t largest = 1;
-        for (int32_t n : per_world) {
-            largest = n > largest ? n : largest;
-        }
-        max_bodies = largest + largest / 16;
+        // The instantiation is sized for the bulk of the worlds, not for the
+        // largest one: what 98 % of them hold (+ 1/16); a world beyond it --
+        // at build time or later -- is stepped by the HBM kernel in fallback
+        // mode, in the same step (world_step.inl, FramedWorld::tooManyBodies).
+        std::sort(per_world.begin(), per_world.end());
+        const size_t covered = per_world.empty() ? 0 :
+            (per_world.size() - 1) - (per_world.size() - 1) / 50;
+        const int32_t bulk = per_world.empty() ? 1 :
+            (per_world[covered] > 1 ? per_world[covered] : 1);
+        max_bodies = bulk + bulk / 16;
     }
     max_bodies = max_bodies <= 32 ? 32 : max_bodies <= 64 ? 64 :
                  max_bodies <= 128 ? 128 : 0;
 
-    // MADRONA_MWHIP_PHYS_PACK=1: the LDS kernels start from per-world images
-    // packed by a high-occupancy kernel right before them instead of reading
-    // the tables themselves.  Off by default: measured on 8192 Escape-Room
-    // worlds the step kernel gets 15 us faster and the pack costs 32 us -- at
-    // two waves per SIMD the load chain mostly hides behind the other world's
-    // arithmetic (profiles/r02_physics_phases.txt).
     // Worlds of at most 32 bodies go two to a wavefront, one per half
     // (phys_impl/world_step.inl; measured on 8192 Escape-Room worlds: 830 ->
     // 712 us per step, profiles/r03_phys_variants.jsonl).
@@ -2234,86 +2271,37 @@ MADRONA_HOST_API inline TaskGraphNodeID setupPhysicsStepTasks(
     const int lanes_per_world = max_bodies == 32 &&
         phys::detail::capacityHint("MADRONA_MWHIP_PHYS_LANES", 32) == 32 ? 32 : 64;
 
-    void *world_images = nullptr;
-    if (max_bodies != 0 &&
-            phys::detail::capacityHint("MADRONA_MWHIP_PHYS_PACK", 0) != 0) {
-        world_images = mwhip_alloc_device(exec,
-            (uint64_t)mwhip_num_worlds(exec) * image_bytes(max_bodies), 1);
-        if (world_images == nullptr) {
-            FATAL("madrona_amd physics: world image allocation failed: %s",
-                  mwhip_last_error());
-        }
-    }
-    // Heaviest worlds first: without it the launch ends on a few contact-rich
-    // worlds with most SIMDs idle (device trace, 8192 Escape-Room worlds: the
-    // last quarter of the kernel ran a third of the chip).
-    // MADRONA_MWHIP_PHYS_ORDER=0 steps the worlds in index order.
+    // The LDS kernels take their worlds heaviest first (physicsOrderKernel:
+    // without it the launch ends on a few contact-rich worlds with most SIMDs
+    // idle), through a frame of addresses that kernel resolves once per launch
+    // (PhysicsFrame), and list the worlds they cannot hold for the HBM kernel
+    // that follows them (fallbackList).  What rounds 3-4 also built around this
+    // node and measured slower or equal -- world images packed by a kernel of
+    // their own, the k-th heaviest world paired with the k-th lightest, the
+    // leaf refit folded into the step's epilogue, persistent wavefronts with
+    // look-ahead, the order blended over steps, every wavefront walking the
+    // tables itself -- is out of the code since round 5; the measurements are
+    // in profiles/r04_phys_variants.jsonl and DESIGN.md section 14.
     uint32_t *world_cost = nullptr;
     int32_t *world_order = nullptr;
-    const char *order_env = getenv("MADRONA_MWHIP_PHYS_ORDER");
-    if (max_bodies != 0 && (order_env == nullptr || atoi(order_env) != 0)) {
-        const uint64_t bytes = (uint64_t)mwhip_num_worlds(exec) * 4u;
-        world_cost = (uint32_t *)mwhip_alloc_device(exec, bytes, 1);
-        world_order = (int32_t *)mwhip_alloc_device(exec, bytes, 1);
-        if (world_cost == nullptr || world_order == nullptr) {
+    int32_t *fallback_list = nullptr;
+    if (max_bodies != 0) {
+        const uint64_t worlds = mwhip_num_worlds(exec);
+        world_cost = (uint32_t *)mwhip_alloc_device(exec, worlds * 4u, 1);
+        world_order = (int32_t *)mwhip_alloc_device(exec, worlds * 4u, 1);
+        fallback_list = (int32_t *)mwhip_alloc_device(exec, (worlds + 1u) * 4u, 1);
+        if (world_cost == nullptr || world_order == nullptr ||
+                fallback_list == nullptr) {
             FATAL("madrona_amd physics: world order allocation failed: %s",
                   mwhip_last_error());
         }
     }
-    // Neighbours in the cost order share a wavefront.  MADRONA_MWHIP_PHYS_ORDER=2
-    // pairs the k-th heaviest with the k-th lightest instead: measured slower
-    // (profiles/r04_phys_variants.jsonl), see physicsStepLdsKernel.
-    const int32_t fold_pairs = lanes_per_world == 32 && world_order != nullptr &&
-        order_env != nullptr && atoi(order_env) >= 2 ? 1 : 0;
-    // MADRONA_MWHIP_PHYS_REFIT=1: the leaf update + refit that follows the step
-    // (setupPostIntegrationTasks: a ParallelFor over all bodies, 23 us) runs in
-    // the step kernel's epilogue instead -- the wavefront still holds every pose
-    // of its world, and the loads the refit needs ride on the rounds the
-    // epilogue makes anyway (the tree's members with the column addresses,
-    // object id and leaf parent next, object box and slot last).  Measured
-    // twice (profiles/r04_phys_variants.jsonl).  With the loads made where they
-    // were used -- nine round trips in a row from ONE wavefront per SIMD -- the
-    // step kernel grew by 33 us for the 27 us node it saved.  With them
-    // batched: + 19 us for 23.6 in the Escape Room (1.1775 -> 1.1687 ms per
-    // step), + 37 us for 24.5 in Hide-and-Seek (1.4024 -> 1.4121: more bodies
-    // move, more leaves outgrow their slot, and the walk up the tree is
-    // atomics one level at a time with nothing to overlap them).  Off by
-    // default.
-    const char *refit_env = getenv("MADRONA_MWHIP_PHYS_REFIT");
-    const int32_t refit_in_step = max_bodies != 0 && refit_env != nullptr &&
-        atoi(refit_env) != 0 ? 2 : 0;
-    // MADRONA_MWHIP_PHYS_PERSIST=1: persistent wavefronts + look-ahead
-    // (physicsStepLdsKernel): as many workgroups as the chip holds of this
-    // kernel (its LDS block: four per CU), jobs from a counter the order kernel
-    // zeroes.  Built for the round-3 verdict and measured: no gain over one
-    // workgroup per job dispatched by the hardware (Escape Room 838 -> 841 us,
-    // Hide-and-Seek 946 -> 947 us, profiles/r04_phys_variants.jsonl) -- the
-    // dispatcher already hands the next job to a free slot within a
-    // microsecond, and the header look-ahead only has the few microseconds of
-    // the store phase to hide in.  Off by default.
-    int32_t *job_counter = nullptr;
-    const char *persist_env = getenv("MADRONA_MWHIP_PHYS_PERSIST");
-    if (world_order != nullptr && persist_env != nullptr &&
-            atoi(persist_env) != 0) {
-        job_counter = (int32_t *)mwhip_alloc_device(exec, 256, 1);
-        if (job_counter == nullptr) {
-            FATAL("madrona_amd physics: job counter allocation failed: %s",
-                  mwhip_last_error());
-        }
-    }
-    // The frame (PhysicsFrame): where every world's rows are, resolved once per
-    // launch by the order kernel.  MADRONA_MWHIP_PHYS_FRAME=0: every wavefront
-    // of the step kernel walks the tables itself (rounds 1-3).
-    const char *frame_env = getenv("MADRONA_MWHIP_PHYS_FRAME");
-    const uint32_t use_frame = world_order != nullptr && world_images == nullptr &&
-        (frame_env == nullptr || atoi(frame_env) != 0) ? 1u : 0u;
     auto params = builder.constructNodeData<PhysicsStepNode>(
         PhysicsStepNode {
-            PhysicsStepParams { (int32_t)num_substeps, fold_pairs | refit_in_step |
-                                    (int32_t)((phys::detail::capacityHint(
-                                        "MADRONA_MWHIP_PHYS_COST_BLEND", 0) & 7) << 4),
-                                world_images, world_cost, world_order, job_counter,
-                                use_frame, 0u },
+            PhysicsStepParams { (int32_t)num_substeps,
+                                (uint32_t)phys::detail::capacityHint(
+                                    "MADRONA_MWHIP_PHYS_LDS_CONTACTS", 0),
+                                world_cost, world_order, fallback_list },
             PhysicsFrame {} });
 
     if (world_order != nullptr) {
@@ -2325,16 +2313,6 @@ MADRONA_HOST_API inline TaskGraphNodeID setupPhysicsStepTasks(
         order.fixed_count = 1;
         order.threads_per_invocation = 1024;
         cur_node = builder.addRuntimeNode(order, params.id, {cur_node});
-    }
-
-    if (world_images != nullptr) {
-        mwhip_node_desc pack {};
-        pack.kind = MWHIP_NODE_KERNEL;
-        pack.name = "physics:packWorlds";
-        pack.kernel = pack_stub(max_bodies);
-        pack.count_mode = MWHIP_COUNT_PER_WORLD;
-        pack.threads_per_invocation = 64;
-        cur_node = builder.addRuntimeNode(pack, params.id, {cur_node});
     }
 
     mwhip_node_desc desc {};
@@ -2349,22 +2327,22 @@ MADRONA_HOST_API inline TaskGraphNodeID setupPhysicsStepTasks(
         desc.count_mode = MWHIP_COUNT_FIXED;
         desc.fixed_count = (mwhip_num_worlds(exec) + 1u) / 2u;
     }
-    if (job_counter != nullptr) {
-        // persistent: what the chip holds at once (the LDS block admits four
-        // single-wave workgroups per CU with 32- / 64-body blocks, fewer
-        // above), times a small factor so that a slot the estimate missed does
-        // not stay empty -- surplus workgroups find the counter exhausted
-        const uint32_t jobs = lanes_per_world == 32 ?
-            (mwhip_num_worlds(exec) + 1u) / 2u : mwhip_num_worlds(exec);
-        const uint32_t resident = mwhip_device_cus(exec) *
-            (max_bodies <= 32 ? 4u : max_bodies <= 64 ? 4u : 2u);
-        desc.count_mode = MWHIP_COUNT_FIXED;
-        desc.fixed_count = jobs < resident ? jobs : resident;
-    }
-    desc.arg0 = max_bodies != 0 ? 1u : 0u;
+    desc.arg0 = 0u;
     cur_node = builder.addRuntimeNode(desc, params.id, {cur_node});
-    if (refit_in_step != 0) {
-        return cur_node;
+
+    if (max_bodies != 0) {
+        // the worlds the LDS kernel could not hold, out of HBM (usually none:
+        // the launch then costs its floor, ~4 us; the reference has no cap on
+        // a world's bodies or contacts, broadphase.cpp:892-1052)
+        mwhip_node_desc fb {};
+        fb.kind = MWHIP_NODE_KERNEL;
+        fb.name = "physics:worldStep(fallback)";
+        fb.kernel = fallback_stub();
+        fb.count_mode = MWHIP_COUNT_FIXED;
+        fb.fixed_count = 64u * 256u;    // 64 workgroups of four wavefronts
+        fb.threads_per_invocation = 1;
+        fb.arg0 = 1u;
+        cur_node = builder.addRuntimeNode(fb, params.id, {cur_node});
     }
 #else
     (void)num_substeps;

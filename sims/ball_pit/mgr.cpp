@@ -255,7 +255,8 @@ struct SimTraits {
 
     // flags: low 16 bits = autoResetDenom (0 disables random resets), bits
     // 16-23 = extra bodies per world (crowd mode), bit 24 = every other joint
-    // is a hinge, bit 25 = checkEntityAABBOverlap steers the kicks
+    // is a hinge, bit 25 = checkEntityAABBOverlap steers the kicks, bit 26 = only
+    // ONE world is crowded, the one whose global index is in bits 27-31
     static Sim::Config makeConfig(const SimCreateArgs &args)
     {
         return Sim::Config {
@@ -264,6 +265,8 @@ struct SimTraits {
             loadPhysicsObjects(args),
             (args.flags >> 24) & 1u,
             (args.flags >> 25) & 1u,
+            ((args.flags >> 26) & 1u) != 0 ?
+                (int32_t)((args.flags >> 27) & 31u) : -1,
         };
     }
 

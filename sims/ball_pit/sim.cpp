@@ -423,6 +423,9 @@ Sim::Sim(Engine &ctx, const Config &cfg, const WorldInit &)
     autoResetDenom = cfg.autoResetDenom;
     numExtra = (int32_t)cfg.numExtra < consts::maxExtra ?
         (int32_t)cfg.numExtra : consts::maxExtra;
+    if (cfg.crowdedWorld >= 0 && (int32_t)global_world != cfg.crowdedWorld) {
+        numExtra = 0;
+    }
     hingeMode = cfg.hingeMode;
     overlapMode = cfg.overlapMode;
 

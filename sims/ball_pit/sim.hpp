@@ -123,6 +123,8 @@ struct Sim : public madrona::WorldBase {
         uint32_t hingeMode;
         // 1: PhysicsSystem::checkEntityAABBOverlap steers the kicks
         uint32_t overlapMode;
+        // >= 0: only this world (global index) gets the numExtra bodies
+        int32_t crowdedWorld;
     };
 
     struct WorldInit {};

@@ -92,7 +92,7 @@ struct SimTraits {
 
     static Sim::Config makeConfig(const SimCreateArgs &args)
     {
-        return Sim::Config { args.seed, args.world_base, loadCube(args) };
+        return Sim::Config { args.seed, args.world_base, loadCube(args), args.flags };
     }
 
     static void makeInits(const SimCreateArgs &, Sim::WorldInit *) {}
@@ -124,6 +124,8 @@ void SimTraits::describeColumns(T &cols)
     cols.template add<Box, Position>("Box.Position", true);
     cols.template add<Box, madrona::phys::broadphase::LeafID>("Box.LeafID", false);
     cols.template add<Pillar, Entity>("Pillar.Entity", false);
+    cols.template add<Sensor, Position>("Sensor.Position", true);
+    cols.template add<Sensor, RayFan>("Sensor.RayFan", false);
     cols.template add<CandidateTemporary, CandidateCollision>(
         "Candidates.CandidateCollision", false);
 }

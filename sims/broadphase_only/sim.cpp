@@ -19,10 +19,12 @@ void Sim::registerTypes(ECSRegistry &registry, const Config &)
     PhysicsSystem::registerTypes(registry);
 
     registry.registerComponent<Drift>();
+    registry.registerComponent<RayFan>();
     registry.registerSingleton<StepCount>();
 
     registry.registerArchetype<Box>();
     registry.registerArchetype<Pillar>();
+    registry.registerArchetype<Sensor>();
 
     registry.exportSingleton<StepCount>((uint32_t)ExportID::StepCount);
 }
@@ -74,7 +76,7 @@ inline void reregisterSystem(Engine &ctx, StepCount &steps)
     }
 
     PhysicsSystem::reset(ctx);
-    for (int32_t i = consts::numBoxes - 1; i >= 0; i--) {
+    for (int32_t i = sim.numBoxes - 1; i >= 0; i--) {
         Entity e = sim.boxes[i];
         ctx.get<broadphase::LeafID>(e) =
             PhysicsSystem::registerEntity(ctx, e, ctx.get<ObjectID>(e));
@@ -86,7 +88,66 @@ inline void reregisterSystem(Engine &ctx, StepCount &steps)
     }
 }
 
-void Sim::setupTasks(TaskGraphManager &taskgraph_mgr, const Config &)
+// sensors drift like the boxes (no body: they are not in the BVH)
+inline void sensorDriftSystem(Engine &, Position &pos, Drift &drift, RayFan &)
+{
+    Vector3 p = pos;
+    Vector3 v = drift.v;
+    p += consts::deltaT * v;
+    if (p.x < -consts::arena) { p.x = -consts::arena; v.x = -v.x; }
+    if (p.x > consts::arena) { p.x = consts::arena; v.x = -v.x; }
+    if (p.y < -consts::arena) { p.y = -consts::arena; v.y = -v.y; }
+    if (p.y > consts::arena) { p.y = consts::arena; v.y = -v.y; }
+    pos = p;
+    drift.v = v;
+}
+
+// 32 rays from the sensor's position: a fan in the plane plus a tilt that
+// differs per ray, so that rays leave through tops and sides of the boxes
+inline void raySystem(Engine &ctx, const Position &pos, RayFan &fan)
+{
+    broadphase::BVH &bvh = ctx.singleton<broadphase::BVH>();
+    Vector3 ray_o = pos;
+
+#if defined(MADRONA_GPU_MODE) && !defined(SIM_PORTABLE)
+    broadphase::BVH::RayGroupScratch *ray_scratch = broadphase::rayGroupScratch();
+#endif
+    auto trace = [&](int32_t i) {
+        // (directions from integers: no transcendental functions, whose last
+        // bit differs between libm and the device library)
+        Vector3 ray_d = Vector3 {
+            (float)((i * 7) % 11 - 5) + 0.5f,
+            (float)((i * 3) % 13 - 6) + 0.25f,
+            0.75f * (float)((i % 5) - 2) }.normalize();
+        float hit_t;
+        Vector3 hit_normal;
+#if defined(MADRONA_GPU_MODE) && !defined(SIM_PORTABLE)
+        Entity hit = bvh.traceRayShared(ray_scratch, ray_o, ray_d, &hit_t,
+                                        &hit_normal, 40.f);
+#else
+        Entity hit = bvh.traceRay(ray_o, ray_d, &hit_t, &hit_normal, 40.f);
+#endif
+        if (hit == Entity::none()) {
+            fan.hitT[i] = 0.f;
+            fan.hitEntity[i] = -1;
+            fan.hitNormal[i] = Vector3::zero();
+        } else {
+            fan.hitT[i] = hit_t;
+            fan.hitEntity[i] = hit.id;
+            fan.hitNormal[i] = hit_normal;
+        }
+    };
+
+#ifdef MADRONA_GPU_MODE
+    trace((int32_t)(threadIdx.x % 32));
+#else
+    for (int32_t i = 0; i < consts::raysPerSensor; i++) {
+        trace(i);
+    }
+#endif
+}
+
+void Sim::setupTasks(TaskGraphManager &taskgraph_mgr, const Config &cfg)
 {
     TaskGraphBuilder &builder = taskgraph_mgr.init(0);
 
@@ -101,6 +162,18 @@ void Sim::setupTasks(TaskGraphManager &taskgraph_mgr, const Config &)
         reregisterSystem, StepCount>>({drift});
 
     auto bvh = PhysicsSystem::setupBroadphaseTasks(builder, {reregister});
+
+    if ((cfg.flags & 1u) != 0) {
+        auto sensor_drift = builder.addToGraph<ParallelForNode<Engine,
+            sensorDriftSystem, Position, Drift, RayFan>>({bvh});
+#ifdef MADRONA_GPU_MODE
+        bvh = builder.addToGraph<CustomParallelForNode<Engine,
+            raySystem, 32, 1, Position, RayFan>>({sensor_drift});
+#else
+        bvh = builder.addToGraph<ParallelForNode<Engine,
+            raySystem, Position, RayFan>>({sensor_drift});
+#endif
+    }
 
     auto overlaps =
         PhysicsSystem::setupStandaloneBroadphaseOverlapTasks(builder, {bvh});
@@ -121,8 +194,14 @@ Sim::Sim(Engine &ctx, const Config &cfg, const WorldInit &)
 
     ctx.singleton<StepCount>().n = 0;
 
+    const bool ray_mode = (cfg.flags & 1u) != 0;
+    // (ray mode: 10 .. 100 boxes, by the global world index)
+    numBoxes = ray_mode ?
+        10 + (int32_t)((global_world * 37u) % 91u) : consts::numBoxes;
+
     PhysicsSystem::init(ctx, cfg.rigidBodyObjMgr, consts::deltaT, 1,
-                        -9.8f * math::up, 32);
+                        -9.8f * math::up,
+                        ray_mode ? consts::maxBoxes + consts::numPillars : 32);
 
     for (int32_t i = 0; i < consts::numPillars; i++) {
         pillars[i] = ctx.makeEntity<Pillar>();
@@ -131,7 +210,7 @@ Sim::Sim(Engine &ctx, const Config &cfg, const WorldInit &)
             Diag3x3 { 1.f, 1.f, 2.f }, ResponseType::Static);
     }
 
-    for (int32_t i = 0; i < consts::numBoxes; i++) {
+    for (int32_t i = 0; i < numBoxes; i++) {
         boxes[i] = ctx.makeEntity<Box>();
         float size = 0.6f + rng.sampleUniform();
         setupBody(ctx, boxes[i],
@@ -144,6 +223,28 @@ Sim::Sim(Engine &ctx, const Config &cfg, const WorldInit &)
         ctx.get<Drift>(boxes[i]).v = Vector3 {
             rng.sampleUniform() * 4.f - 2.f, rng.sampleUniform() * 4.f - 2.f, 0.f,
         };
+    }
+
+    if (ray_mode) {
+        const int32_t num_sensors = 1 + (int32_t)(global_world % 3u);
+        for (int32_t i = 0; i < num_sensors; i++) {
+            Entity e = ctx.makeEntity<Sensor>();
+            ctx.get<Position>(e) = Vector3 {
+                (rng.sampleUniform() * 2.f - 1.f) * consts::arena,
+                (rng.sampleUniform() * 2.f - 1.f) * consts::arena,
+                0.3f + rng.sampleUniform(),
+            };
+            ctx.get<Drift>(e).v = Vector3 {
+                rng.sampleUniform() * 3.f - 1.5f, rng.sampleUniform() * 3.f - 1.5f,
+                0.f,
+            };
+            RayFan &fan = ctx.get<RayFan>(e);
+            for (int32_t r = 0; r < consts::raysPerSensor; r++) {
+                fan.hitT[r] = 0.f;
+                fan.hitEntity[r] = -1;
+                fan.hitNormal[r] = Vector3::zero();
+            }
+        }
     }
 }
 

@@ -1114,14 +1114,24 @@ inline void lidarSystem(Engine &ctx,
     // from inside the agent's own hull (only back faces are met: a miss)
     Vector3 ray_o = pos + 0.5f * math::up;
 
+#ifdef SIM_WAVE_API
+    broadphase::BVH::RayGroupScratch *ray_scratch = broadphase::rayGroupScratch();
+#endif
     auto traceRay = [&](int32_t i) {
         Vector3 ray_d = rot.rotateVec(
             Vector3 { kLidarCos[i], kLidarSin[i], 0.f }).normalize();
 
         float hit_t;
         Vector3 hit_normal;
+#ifdef SIM_WAVE_API
+        // (the agent's 30 rays start at the same point: this backend's
+        // shared-origin flavour, same hits)
+        Entity hit_entity = bvh.traceRayShared(ray_scratch, ray_o, ray_d,
+                                               &hit_t, &hit_normal, 200.f);
+#else
         Entity hit_entity =
             bvh.traceRay(ray_o, ray_d, &hit_t, &hit_normal, 200.f);
+#endif
 
         if (hit_entity == Entity::none()) {
             lidar.samples[i] = LidarSample { 0.f, 0.f };

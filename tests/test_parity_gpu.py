@@ -113,25 +113,44 @@ def test_escape_room_physics_kernel_variants(built, monkeypatch, max_bodies):
     assert not probs, (step, probs[:3])
 
 
-@pytest.mark.parametrize("switch,value,lanes", [
-    ("MADRONA_MWHIP_PHYS_FRAME", "0", "32"),     # every wavefront walks the tables
-    ("MADRONA_MWHIP_PHYS_REFIT", "1", "32"),     # leaf update + refit in the epilogue
-    ("MADRONA_MWHIP_PHYS_REFIT", "1", "64"),
-    ("MADRONA_MWHIP_PHYS_PERSIST", "1", "32"),   # persistent wavefronts + look-ahead
-    ("MADRONA_MWHIP_PHYS_ORDER", "0", "32"),     # no order kernel (hence no frame)
-    ("MADRONA_MWHIP_PHYS_PACK", "1", "64"),      # world images
-])
-def test_escape_room_physics_step_switches(built, monkeypatch, switch, value, lanes):
-    """The step kernel's other ways in and out: without the
-    per-launch frame, with the leaf update + refit folded into the epilogue
-    instead of the ParallelFor node it is in the reference's graph, with
-    persistent wavefronts, in index order, from packed world images -- one
-    world and two worlds per wavefront."""
-    _need_ref("escape_room_phys")
-    monkeypatch.setenv(switch, value)
-    monkeypatch.setenv("MADRONA_MWHIP_PHYS_LANES", lanes)
-    probs, step = run_pair("escape_room_phys", 96, 60, flags=25,
-                           check_every=5, actions=_escape_actions(11, grab=True),
+@pytest.mark.parametrize("worlds,crowded", [(256, 3), (64, 31)])
+def test_one_crowded_world_falls_back_to_the_hbm_step(built, monkeypatch, worlds, crowded):
+    """a world the LDS instantiation cannot hold is stepped out of
+    HBM in the same step instead of raising kErrPhysics (the reference has no
+    cap on a world's bodies: broadphase.cpp:892-1052).  ball_pit with ONE world
+    of 168 rigid bodies among worlds of 18 (flags bit 26 + the crowd size): the
+    step node is sized for the bulk of the worlds -- the 32-body block, two
+    worlds per wavefront -- and the crowded world, whose partner in the
+    wavefront stays in the LDS kernel, goes through physicsStepKernel in
+    fallback mode.  Lock step with the reference, no error flag (a raised flag
+    fails the step that raised it)."""
+    _need_ref("ball_pit")
+    monkeypatch.setenv("MADRONA_MWHIP_MAX_CANDIDATES_PER_WORLD", "4096")
+    monkeypatch.setenv("MADRONA_MWHIP_MAX_CONTACTS_PER_WORLD", "1024")
+    flags = (1 << 26) | (crowded << 27) | (150 << 16)
+    probs, step = run_pair("ball_pit", worlds, 50, flags=flags, check_every=5,
+                           check_init=False, ref_workers=0)
+    assert not probs, (step, probs[:3])
+    with Simulator(hip_lib_path("ball_pit"), worlds, flags=flags) as s:
+        s.step(20)
+        names = [k["name"] for k in s.profile(2)]
+        assert "physics:worldStep(LDS)" in names, names
+        assert "physics:worldStep(fallback)" in names, names
+        counts = s.dump_all()["MovableObject.Position"][1]
+        assert counts[crowded] == 14 + 150 and counts.sum() == 14 * worlds + 150
+
+
+def test_contacts_beyond_the_lds_block_fall_back(built, monkeypatch):
+    """The other capacity of the LDS block: more contacts in a substep than it
+    has room for (64 with the 32-body block).  19-body ball_pit worlds forced
+    into a tight pit pile up more; seed 11 is the one that used to raise
+    kErrTableOverflow before the constant was raised.  With the
+    capacity cut to 20 (MADRONA_MWHIP_PHYS_LDS_CONTACTS) the pile overflows
+    within a few steps in many worlds -- they take the HBM step for that step
+    and stay in lock step; with it at 1 every world with a contact does."""
+    _need_ref("ball_pit")
+    monkeypatch.setenv("MADRONA_MWHIP_PHYS_LDS_CONTACTS", "20")
+    probs, step = run_pair("ball_pit", 96, 60, flags=40, seed=11, check_every=5,
                            check_init=False)
     assert not probs, (step, probs[:3])
 
@@ -203,18 +222,16 @@ def test_ball_pit_kernel_variants(built, monkeypatch, max_bodies):
                                                # scratch (HBM hull scratch, one
                                                # lane at a time), 8 joints
     ("ball_pit", 256, 60, 30, 0)])
-@pytest.mark.parametrize("lanes,pack", [("32", "0"), ("64", "0"), ("32", "1")])
+@pytest.mark.parametrize("lanes", ["32", "64"])
 def test_physics_lanes_per_world(built, monkeypatch, sim, worlds, steps, denom, agents,
-                                 lanes, pack):
+                                 lanes):
     """physicsStepLdsKernel<32, 32> (the default for worlds of at most 32 bodies):
     two worlds per wavefront, one per half -- every wave-level primitive on groups
     of 32 lanes, the halves diverging wherever their worlds differ (candidate /
     contact counts, hull-hull pairs, solver levels) -- and <32, 64>, one world per
-    wavefront; with and without the world images of physicsPackKernel.  Same
-    bit-for-bit bar for all."""
+    wavefront.  Same bit-for-bit bar for both."""
     _need_ref(sim)
     monkeypatch.setenv("MADRONA_MWHIP_PHYS_LANES", lanes)
-    monkeypatch.setenv("MADRONA_MWHIP_PHYS_PACK", pack)
     probs, step = run_pair(sim, worlds, steps, flags=denom,
                            check_every=1 if worlds <= 64 else 10,
                            actions=_escape_actions(worlds + 5, grab=True, agents=agents)
@@ -302,6 +319,38 @@ def test_standalone_broadphase_candidates(built, worlds):
                 assert rw == hw and ra == ha and rb == hb
                 # CPU rows are world-local, GPU rows global
                 assert rp[0][0] == hp[0][1] and rp[1][0] == hp[1][1], (step, rw)
+
+
+@pytest.mark.parametrize("worlds", [5, 97])
+def test_rays_sharing_an_origin_big_and_uneven_trees(built, worlds):
+    """BVH::traceRayShared (32 lanes per sensor, the ray-independent half of a
+    leaf test once per leaf in LDS) against the reference's BVH::traceRay, ray by
+    ray: distance, entity id and normal bit for bit.  broadphase_only in ray mode:
+    10 .. 100 boxes per world -- trees of more than 64 leaves (two windows of
+    the shared scratch) next to small ones -- and 1 .. 3 sensors per world, so
+    that the two halves of a wavefront hold sensors of different worlds: different
+    trees, different leaf counts, different window counts.  The BVH is rebuilt
+    every 16 steps (the pending-rebuild walk in between is exercised too)."""
+    _need_ref("broadphase_only")
+    with Simulator(ref_lib_path("broadphase_only"), worlds, seed=3, num_workers=1,
+                   flags=1) as ref, \
+            Simulator(hip_lib_path("broadphase_only"), worlds, seed=3, flags=1) as hip:
+        hits = 0
+        for step in range(1, 36):
+            ref.step(1)
+            hip.step(1)
+            # (crowded worlds hold thousands of candidate pairs)
+            rd, hd = ref.dump_all(8192), hip.dump_all(8192)
+            for col in ("Box.Position", "Box.LeafID", "Sensor.Position"):
+                assert np.array_equal(rd[col][0], hd[col][0]), (step, col)
+            assert np.array_equal(rd["Sensor.RayFan"][1], hd["Sensor.RayFan"][1])
+            rf = rd["Sensor.RayFan"][0].view(np.int32).reshape(-1, 160)
+            hf = hd["Sensor.RayFan"][0].view(np.int32).reshape(-1, 160)
+            bad = np.argwhere(rf != hf)
+            assert bad.size == 0, (step, bad[:5], rf[tuple(bad[0])], hf[tuple(bad[0])])
+            hits += int((rf[:, 32:64] >= 0).sum())
+        assert rd["Box.LeafID"][1].max() > 64 and rd["Box.LeafID"][1].min() < 32
+        assert hits > 35 * worlds * 8       # the rays do meet boxes
 
 
 def test_ball_pit_hinge_joints(built):
@@ -399,35 +448,6 @@ def test_sort_chains_lockstep(built, monkeypatch, sim, worlds, steps, denom, com
     probs, step = run_pair(sim, worlds, steps, seed=7, flags=denom, check_every=5,
                            actions=_escape_actions(9) if sim == "escape_room" else None,
                            check_init=False, ref_workers=0)
-    assert not probs, (step, probs[:3])
-
-
-@pytest.mark.parametrize("sim,worlds,steps,denom,groups,small_rows", [
-    ("sort_stress", 37, 40, 0, "16", ""),        # key sorts, pinned columns, scratch
-    ("sort_stress", 120, 30, 0, "5", ""),        # shares that do not divide the rows
-    ("sort_stress", 1500, 12, 0, "7", "4000000"),   # > 4096 rows: workgroup 0 alone
-    ("escape_room", 96, 60, 30, "16", ""),
-    ("escape_room_phys", 64, 60, 25, "3", ""),   # joint table: rows come and go
-])
-def test_sort_small_spread_lockstep(built, monkeypatch, sim, worlds, steps, denom,
-                                    groups, small_rows):
-    """The one-launch sort on several workgroups (sortSmallSpread: every
-    workgroup orders all keys in LDS and moves its share of the rows, the last
-    one to finish publishes), forced for every small batch, against the
-    reference.  By default only small tables that are re-sorted every step get
-    it (the joint table of test_full_size_lockstep's escape_room_phys case)."""
-    _need_ref(sim)
-    monkeypatch.setenv("MADRONA_MWHIP_SORT_SPREAD", "2")
-    monkeypatch.setenv("MADRONA_MWHIP_SORT_SPREAD_GROUPS", groups)
-    if small_rows:
-        monkeypatch.setenv("MADRONA_MWHIP_SORT_SMALL_ROWS", small_rows)
-    actions = None
-    if sim == "escape_room":
-        actions = _escape_actions(9)
-    elif sim == "escape_room_phys":
-        actions = _escape_actions(9, grab=True)
-    probs, step = run_pair(sim, worlds, steps, seed=7, flags=denom, check_every=5,
-                           actions=actions, check_init=False, ref_workers=0)
     assert not probs, (step, probs[:3])
 
 
