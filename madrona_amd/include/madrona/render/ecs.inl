@@ -269,6 +269,16 @@ MADRONA_HOST_API inline TaskGraphNodeID setupTasks(
     // relative order of a world's rows, which is all that decides ties between
     // equal codes -- so that chain (two key passes and a gather of every column,
     // every step) is left out.
+    // (MADRONA_MWHIP_RENDER_PRECOMPACT=1 builds the reference's graph, that
+    // chain included: tests/test_render_prep_gpu.py compares the two tables
+    // row for row under churn and Morton-code ties)
+#if MADRONA_ON_HOST
+    if (const char *pre = getenv("MADRONA_MWHIP_RENDER_PRECOMPACT");
+            pre != nullptr && atoi(pre) != 0) {
+        node = builder.addToGraph<
+            CompactArchetypeNode<RenderableArchetype>>({node});
+    }
+#endif
     node = builder.addToGraph<
         SortArchetypeNode<RenderableArchetype, MortonCode>>({node});
     node = builder.addToGraph<ResetTmpAllocNode>({node});

@@ -16,7 +16,8 @@ struct SimTraits;
 
 namespace {
 
-// flags: bit 0 = RenderingSystem::setupTasks(update_visual_properties = true),
+// flags: bit 4 = movers stand on a coarse grid (Morton-code ties);
+// bit 0 = RenderingSystem::setupTasks(update_visual_properties = true),
 // bit 1 = depth only, bit 2 = crowded worlds, bit 3 = the geometry goes to the
 // executor in the reference's asset form (MeshBVHData / MaterialData) instead
 // of as plain triangles,
@@ -109,7 +110,8 @@ struct SimTraits {
         bridge = &g_bridge->bridge;
 #endif
         return Sim::Config { args.seed, args.world_base, args.flags & 1u,
-                             (args.flags >> 2) & 1u, bridge };
+                             (args.flags >> 2) & 1u, (args.flags >> 4) & 1u,
+                             bridge };
     }
 
     static void makeInits(const SimCreateArgs &, Sim::WorldInit *) {}

@@ -54,6 +54,14 @@ static Entity makeMover(Engine &ctx, RNG &rng)
     ctx.get<Drift>(e).v = Vector3 {
         randInRange(rng, -1.f, 1.f), randInRange(rng, -1.f, 1.f), 0.f,
     };
+    if (ctx.data().ties != 0u) {
+        // a 3 x 3 grid of standing places: equal positions, equal Morton codes
+        ctx.get<Position>(e) = Vector3 {
+            8.f * (float)rng.sampleI32(-1, 2), 8.f * (float)rng.sampleI32(-1, 2),
+            0.f,
+        };
+        ctx.get<Drift>(e).v = Vector3::zero();
+    }
     // every third mover overrides its colour, every fifth its material (with
     // an untextured one, or -- style 10 -- the textured material 7, which then
     // samples the mover's own uvs: all zero except on the wedge)
@@ -172,6 +180,7 @@ Sim::Sim(Engine &ctx, const Config &cfg, const WorldInit &)
     step = 0;
 
     moverCap = cfg.dense != 0u ? consts::maxMovers : consts::sparseMovers;
+    ties = cfg.ties;
 
     RenderingSystem::init(ctx, cfg.bridge);
 

@@ -94,6 +94,9 @@ struct Sim : public madrona::WorldBase {
         // crowded worlds: 70 .. 95 movers from the start (more instances than
         // the ray caster keeps in LDS per world)
         uint32_t dense;
+        // movers stand on a coarse grid and do not drift: many of a world's
+        // instances share a position, hence a Morton code (ties in the sort)
+        uint32_t ties;
         // reference CPU backend: the buffers its systems append to
         const madrona::render::RenderECSBridge *bridge;
     };
@@ -112,6 +115,7 @@ struct Sim : public madrona::WorldBase {
     Entity lamp;
     Entity sun;     // every third world: a second, directional light
     int32_t moverCap;
+    uint32_t ties;
     uint32_t step;
 };
 
