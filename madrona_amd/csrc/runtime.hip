@@ -537,7 +537,27 @@ struct LaunchGraph {
     void *packDst = nullptr;
     // the batch ray caster's pass instead of task graphs
     bool isRender = false;
+
+    LaunchGraph() = default;
+    LaunchGraph(const LaunchGraph &) = delete;
+    LaunchGraph &operator=(const LaunchGraph &) = delete;
+    // (a graph that dies on an error path of instantiateLaunchGraph or of a
+    // rebuild loop gives back what it had allocated so far; the caller has
+    // made sure nothing of it is in flight)
+    ~LaunchGraph()
+    {
+        if (graphExec) (void)hipGraphExecDestroy(graphExec);
+        if (graph) (void)hipGraphDestroy(graph);
+        for (void *p : ownedAllocations) {
+            (void)hipFree(p);
+        }
+    }
 };
+
+// Where devAlloc records what it hands out while THIS thread builds a launch
+// graph (the graph then owns the memory); another thread's allocations stay with
+// their executor.
+static thread_local std::vector<void *> *t_allocScope = nullptr;
 
 struct mwhip_exec {
     mwhip_state_config cfg {};
@@ -568,7 +588,6 @@ struct mwhip_exec {
     std::unordered_map<uint64_t, std::unique_ptr<LaunchGraph>> launchGraphs;
     // where devAlloc records what it hands out: the graph being built, or
     // (nullptr) the executor's own list, freed at mwhip_destroy
-    std::vector<void *> *allocScope = nullptr;
     uint64_t nextGraphHandle = 1;
 
     // mwGPU::HostPrint: ring in pinned host memory + the thread that drains it
@@ -644,7 +663,7 @@ static int devAlloc(mwhip_exec *exec, void **out, size_t bytes, bool zero = true
     bytes = (bytes + 255) & ~(size_t)255;
     if (bytes == 0) bytes = 256;
     HIPCHK(hipMalloc(out, bytes));
-    (exec->allocScope != nullptr ? *exec->allocScope : exec->allocations).push_back(*out);
+    (t_allocScope != nullptr ? *t_allocScope : exec->allocations).push_back(*out);
     if (zero) {
         HIPCHK(hipMemset(*out, 0, bytes));
     }
@@ -1688,8 +1707,8 @@ static int ensureSortScratch(mwhip_exec *exec, ArchetypeRec &arch)
     // (shared by every graph that sorts this table: not the building graph's)
     struct ScopeOff {
         mwhip_exec *e; std::vector<void *> *saved;
-        explicit ScopeOff(mwhip_exec *x) : e(x), saved(x->allocScope) { x->allocScope = nullptr; }
-        ~ScopeOff() { e->allocScope = saved; }
+        explicit ScopeOff(mwhip_exec *x) : e(x), saved(t_allocScope) { t_allocScope = nullptr; }
+        ~ScopeOff() { (void)e; t_allocScope = saved; }
     } scope_off(exec);
 
     int rc = devAllocT(exec, &arch.sortState, 1);
@@ -3029,11 +3048,11 @@ static int renderLaunches(mwhip_exec *exec, std::vector<KernelLaunch> &out)
         // one node slot per instance row the table can ever hold (a world of n
         // instances uses n - 1 of its n slots).  (The executor's, not the
         // building graph's: every later render graph reuses them.)
-        std::vector<void *> *const saved_scope = exec->allocScope;
-        exec->allocScope = nullptr;
+        std::vector<void *> *const saved_scope = t_allocScope;
+        t_allocScope = nullptr;
         struct Restore {
             mwhip_exec *e; std::vector<void *> *s;
-            ~Restore() { e->allocScope = s; }
+            ~Restore() { (void)e; t_allocScope = s; }
         } restore { exec, saved_scope };
         rc = devAllocT(exec, &exec->tlasNodes, inst.reservedCapacity, false);
         if (rc != 0) return rc;
@@ -3145,8 +3164,8 @@ static int instantiateLaunchGraph(mwhip_exec *exec,
     lg->taskGraphIds = ids;
     struct ScopeOn {
         mwhip_exec *e;
-        ScopeOn(mwhip_exec *x, std::vector<void *> *v) : e(x) { x->allocScope = v; }
-        ~ScopeOn() { e->allocScope = nullptr; }
+        ScopeOn(mwhip_exec *x, std::vector<void *> *v) : e(x) { t_allocScope = v; }
+        ~ScopeOn() { (void)e; t_allocScope = nullptr; }
     } scope_on(exec, &lg->ownedAllocations);
 
     if (envU32("MADRONA_MWHIP_GRIDS_FROM_ROWS", 1) != 0) {

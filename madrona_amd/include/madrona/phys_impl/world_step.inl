@@ -1579,15 +1579,22 @@ __device__ inline void fillPhysicsFrame(EcsState *S, const PhysicsScratch *ps,
         F->unsorted = unsorted;
         F->numArchetypes = num_arch;
     }
+    // (the frame's column slots cover the body archetypes' Entity, WorldID,
+    // RigidBody bundle and XPBD solver state, and the joint table's constraint
+    // is its first component column)
+    static_assert(PhysicsFrame::numColumns ==
+                  (uint32_t)xpbd::XPBDCols::PreSolveVelocity + 1u);
+    static_assert(RGDCols::JointConstraint == 2);
     if (tid == 2) {
-        F->joints =
-            (const JointConstraint *)S->tables[ps->jointArchetype].columns[2];
+        F->joints = (const JointConstraint *)
+            S->tables[ps->jointArchetype].columns[RGDCols::JointConstraint];
     }
-    // what it cannot -- the singleton columns (never sorted), the tables' world
-    // ranges, the entity store (addresses are reserved once, tables grow in
-    // place), the object manager -- is a chain of six dependent loads: followed
-    // on the first replay only (the frame starts out zeroed)
-    if (tid == 0 && F->trees == nullptr) {
+    // the singleton columns, the tables' world ranges, the entity store, the
+    // object manager: a chain of six dependent loads by one thread, behind the
+    // cost scan of the other wavefronts.  Followed on EVERY launch (round 4
+    // kept the first replay's answers: stale if a simulator ever swaps its
+    // object manager's arrays or the store moves).
+    if (tid == 0) {
         F->systemStates = state_mgr->getSingletonColumn<PhysicsSystemState>();
         F->objectData = state_mgr->getSingletonColumn<ObjectData>();
         const ObjectManager *mgr = F->objectData[0].mgr;

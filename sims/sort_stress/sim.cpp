@@ -55,6 +55,26 @@ inline void churnSystem(Engine &ctx, Churn &churn)
     Sim &sim = ctx.data();
     RNG &rng = sim.rng;
 
+    if (sim.burst == 1u || sim.burst == 3u) {
+        // burst mode: no churn; the bursting worlds fill up at steps 3 and 30
+        // and empty again at steps 13 and 40
+        if (sim.burst == 1u && (churn.step == 2u || churn.step == 29u)) {
+            while (sim.numItems < 31) {
+                Entity e = ctx.makeEntity<Item>();
+                fillItem(ctx, e, rng);
+                sim.items[sim.numItems++] = e;
+            }
+        }
+        if (sim.burst == 1u && (churn.step == 12u || churn.step == 39u)) {
+            while (sim.numItems > 1) {
+                ctx.destroyEntity(sim.items[--sim.numItems]);
+            }
+        }
+        churn.step += 1;
+        churn.numItems = (uint32_t)sim.numItems;
+        return;
+    }
+
     int32_t num_destroy = rng.sampleI32(0, consts::maxChurn + 1);
     if (sim.rampUp != 0 && sim.numItems < consts::maxItems) {
         num_destroy = 0;
@@ -236,8 +256,13 @@ Sim::Sim(Engine &ctx, const Config &cfg, const WorldInit &)
     int32_t initial = cfg.coldStart != 0 ?
         (int32_t)((global_world * 7u) % (uint32_t)consts::maxItems) :
         1 + (int32_t)((global_world * 7u) % (uint32_t)(consts::maxItems - 1));
-    if (cfg.rampUp != 0) {
+    if (cfg.rampUp != 0 || cfg.burst != 0) {
         initial = 1;
+    }
+    burst = 0;
+    if (cfg.burst != 0) {
+        burst = global_world < 100u ? 1u :
+            (global_world >= 200u && global_world < 264u) ? 2u : 3u;
     }
     for (int32_t i = 0; i < initial; i++) {
         Entity e = ctx.makeEntity<Item>();

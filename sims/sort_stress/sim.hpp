@@ -81,6 +81,12 @@ struct Sim : public madrona::WorldBase {
         // 1: every world logs a message at its second step (more messages in
         // one replay than the executor's message ring holds)
         uint32_t chatty;
+        // 1: every world starts with one item; worlds [0, 100) create 30 items
+        // at once at their 3rd and 30th step (and destroy them again ten steps
+        // later), worlds [200, 264) churn as usual, the rest stand still -- a
+        // short tail behind a long sorted prefix in which ONE scatter tile of
+        // the compaction chain owns more new rows than it orders in LDS
+        uint32_t burst;
     };
 
     struct WorldInit {};
@@ -96,6 +102,7 @@ struct Sim : public madrona::WorldBase {
     uint32_t mixIds;
     uint32_t rampUp;
     uint32_t chatty;
+    uint32_t burst;         // 0: off, 1: a bursting world, 2: churns, 3: stands still
     int32_t numItems;
     Entity items[consts::maxItems];
 };

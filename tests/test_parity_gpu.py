@@ -467,6 +467,21 @@ def test_compaction_chain_heavy_churn(built, monkeypatch, compact):
     assert not probs, (step, probs[:3])
 
 
+def test_compaction_tile_owning_more_rows_than_it_orders_in_lds(built):
+    """the by-landing-points path of the compaction chain when ONE
+    scatter tile owns more tail rows than its LDS buffer (kOwnCap = 2048) -- the
+    rank-by-counting fallback -- and the 16-run countdown (landsBlocked) that
+    sends the following runs down the sorted-tail path before the landing-point
+    path is taken again.  sort_stress in burst mode: 30 000 worlds of one item,
+    the first hundred create 30 items each in ONE step (3 000 new rows behind a
+    30 000-row sorted prefix, all landing in the first tile), twice, 27 steps
+    apart, with a few worlds churning in between so that every step sorts."""
+    _need_ref("sort_stress")
+    probs, step = run_pair("sort_stress", 30000, 45, seed=5, flags=8,
+                           check_every=1, check_init=False, ref_workers=0)
+    assert not probs, (step, probs[:3])
+
+
 def test_sort_stress_cold_start_runtime_id_blocks(built):
     """Worlds that start empty take their first block of entity ids at run
     time.  The CPU backend numbers such blocks in world-major order within a
