@@ -247,6 +247,25 @@ public:
             !mwhip::loadGlobalBool(&tree->force_rebuild_),
         };
     }
+    // ... plus what a wavefront that refreshes ALL leaves of the tree starts
+    // from (physics.inl bvhRefreshKernel): who the leaves are
+    struct RefreshView {
+        RefitView refit;
+        const Entity *leafEntities;
+        const base::ObjectID *leafObjIDs;
+        const ObjectManager *objMgr;
+        int32_t numLeaves;
+    };
+    MADRONA_HD static inline RefreshView loadRefreshView(const BVH *tree)
+    {
+        return RefreshView {
+            loadRefitView(tree),
+            mwhip::loadGlobal(&tree->leaf_entities_),
+            mwhip::loadGlobal(&tree->leaf_obj_ids_),
+            mwhip::loadGlobal(&tree->obj_mgr_),
+            mwhip::loadGlobal(&tree->num_leaves_),
+        };
+    }
     // leaf_parent = view.leafParents[leaf], slot = loadSlotBounds(view.nodes,
     // leaf_parent) (anything if !view.refit)
     MADRONA_HD static inline void applyLeafUpdate(

@@ -1405,6 +1405,117 @@ candidateKernel(EcsState *S, void *, uint32_t, uint32_t)
 
 #include <madrona/phys_impl/world_step.inl>
 
+// Leaf update + refit of EVERY body, a wavefront per world, a lane per leaf
+// (what setupBroadphaseTasks / setupPostIntegrationTasks run: the reference's
+// updateLeafPositionsEntry + refitEntry ParallelFor nodes, broadphase.cpp:
+// 440-647 + 892-1052).  Rounds 1-4 ran it as a ParallelFor over the body rows
+// (updateLeafAndRefitEntry): every ROW went tree -> its arrays -> the leaf's
+// parent -> the slot, and manager -> table -> box, 16-24 us per launch, three
+// launches per step.  Here the tree's words are fetched once per world and the
+// lanes go leaf -> entity -> row -> components in batched rounds:
+//   1  the tree (the singleton column is resolved once per wavefront)
+//   2  its arrays, the object manager, the expansions, the rebuild flag
+//   3  per lane: the leaf's entity, object id and parent; the manager's box table
+//   4  the entity's slot in the store, the object's box, the leaf's slot bounds
+//   5  the row's five column addresses
+//   6  position, rotation, scale, object id, velocity
+// then the same arithmetic and the same stores (BVH::applyLeafUpdate: the
+// leaf's own slot plain, ancestors that have to grow with atomic min / max --
+// order independent, so the boxes are those of any other schedule).  A leaf
+// whose entity is gone (destroyed without a reset of the tree) is skipped: the
+// ParallelFor had no row for it either.  No LDS, 32 wavefronts per CU.
+__global__ void __launch_bounds__(64)
+bvhRefreshKernel(EcsState *S, void *, uint32_t, uint32_t)
+{
+    mwhip::TraceScope trace_scope(S);
+    using namespace base;
+    using broadphase::BVH;
+    using mwhip::loadGlobal;
+    using mwhip::loadInvariant;
+
+    StateManager *state_mgr = static_cast<StateManager *>(S);
+    const uint32_t lane = wave::laneID();
+    const int32_t num_worlds = S->numWorlds;
+
+    BVH *trees = state_mgr->getSingletonColumn<BVH>();
+    const mwhip::EntitySlot *entities = mwhip::entitiesOf(S);
+    void *const *col_ptrs = loadInvariant(&S->colPtr);
+    const uint32_t num_slots = loadInvariant(&S->numComponentSlots);
+    const uint32_t id_pos = TypeTracker::typeID<Position>();
+    const uint32_t id_rot = TypeTracker::typeID<Rotation>();
+    const uint32_t id_scale = TypeTracker::typeID<Scale>();
+    const uint32_t id_obj = TypeTracker::typeID<ObjectID>();
+    const uint32_t id_vel = TypeTracker::typeID<Velocity>();
+
+    for (int32_t world = (int32_t)blockIdx.x; world < num_worlds;
+         world += (int32_t)gridDim.x) {
+        const BVH::RefreshView view = BVH::loadRefreshView(trees + world);
+        const math::AABB *body_aabbs = nullptr;
+        for (int32_t leaf = (int32_t)lane; leaf < view.numLeaves; leaf += 64) {
+            // ---- round 3 ----
+            if (body_aabbs == nullptr) {
+                body_aabbs = loadGlobal(&view.objMgr->rigidBodyAABBs);
+            }
+            const Entity e = loadGlobal(view.leafEntities + leaf);
+            const ObjectID leaf_obj = loadGlobal(view.leafObjIDs + leaf);
+            uint32_t leaf_parent = 0;
+            if (view.refit.refit) {
+                leaf_parent = loadGlobal(view.refit.leafParents + leaf);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+
+            // ---- round 4 ----
+            const mwhip::EntitySlot slot_of_e =
+                loadGlobal(entities + (e.id >= 0 ? e.id : 0));
+            math::AABB obj_aabb = loadGlobal(body_aabbs + leaf_obj.idx);
+            math::AABB slot = math::AABB::invalid();
+            if (view.refit.refit) {
+                slot = BVH::loadSlotBounds(view.refit.nodes, leaf_parent);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (e.id < 0 || slot_of_e.gen != e.gen) {
+                continue;
+            }
+            const uint32_t arch = slot_of_e.loc.archetype;
+            const int32_t row = slot_of_e.loc.row;
+
+            // ---- round 5 ----
+            const uint32_t base = arch * num_slots;
+            const Position *col_pos =
+                (const Position *)loadInvariant(&col_ptrs[base + id_pos]);
+            const Rotation *col_rot =
+                (const Rotation *)loadInvariant(&col_ptrs[base + id_rot]);
+            const Scale *col_scale =
+                (const Scale *)loadInvariant(&col_ptrs[base + id_scale]);
+            const ObjectID *col_obj =
+                (const ObjectID *)loadInvariant(&col_ptrs[base + id_obj]);
+            const Velocity *col_vel =
+                (const Velocity *)loadInvariant(&col_ptrs[base + id_vel]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (col_pos == nullptr || col_rot == nullptr || col_scale == nullptr ||
+                    col_obj == nullptr || col_vel == nullptr) {
+                continue;       // (not a rigid body row: the query would not match)
+            }
+
+            // ---- round 6 ----
+            const Position pos = loadGlobal(col_pos + row);
+            const Rotation rot = loadGlobal(col_rot + row);
+            const Scale scale = loadGlobal(col_scale + row);
+            const ObjectID obj_id = loadGlobal(col_obj + row);
+            const Velocity vel = loadGlobal(col_vel + row);
+            __builtin_amdgcn_sched_barrier(0);
+            if (obj_id.idx != leaf_obj.idx) {
+                // (the component was changed after the body was registered:
+                // the row is what the reference's system reads)
+                obj_aabb = loadGlobal(body_aabbs + obj_id.idx);
+            }
+
+            BVH::applyLeafUpdate(view.refit, leaf, leaf_parent, slot, pos, rot,
+                                 scale, vel.linear, obj_aabb);
+        }
+    }
+}
+
 // BVH rebuild for the worlds that asked for one (a reset re-registered their
 // bodies): one wavefront per world, the build runs out of LDS on a rebased
 // copy of the tree (BVH::rebased) and the arrays go back to HBM once.  The
@@ -2106,15 +2217,44 @@ MADRONA_HOST_API inline TaskGraphNodeID setupCandidateTasks(
 #endif
 }
 
-MADRONA_HOST_API inline TaskGraphNodeID setupPostIntegrationTasks(
+// the leaf update + refit of every body (kernels::bvhRefreshKernel; the
+// ParallelFor over the body rows it replaces is still there for measurements:
+// MADRONA_MWHIP_BVH_REFRESH=0)
+MADRONA_HOST_API inline TaskGraphNodeID setupLeafRefreshTasks(
     TaskGraphBuilder &builder, Span<const TaskGraphNodeID> deps)
 {
     using namespace base;
     using broadphase::LeafID;
 
+#if defined(__HIPCC__)
+    [[maybe_unused]] auto refresh_stub = [] __host__ () -> const void * {
+        return (const void *)&kernels::bvhRefreshKernel;
+    };
+#else
+    auto refresh_stub = []() -> const void * { return nullptr; };
+#endif
+
+#if MADRONA_ON_HOST
+    const char *refresh_env = getenv("MADRONA_MWHIP_BVH_REFRESH");
+    if (refresh_env == nullptr || atoi(refresh_env) != 0) {
+        mwhip_node_desc desc {};
+        desc.kind = MWHIP_NODE_KERNEL;
+        desc.name = "physics:bvhRefresh";
+        desc.kernel = refresh_stub();
+        desc.count_mode = MWHIP_COUNT_PER_WORLD;
+        desc.threads_per_invocation = 64;
+        return builder.addRuntimeNode(desc, -1, deps);
+    }
+#endif
     return builder.addToGraph<ParallelForNode<Context,
         broadphase::updateLeafAndRefitEntry,
             LeafID, Position, Rotation, Scale, ObjectID, Velocity>>(deps);
+}
+
+MADRONA_HOST_API inline TaskGraphNodeID setupPostIntegrationTasks(
+    TaskGraphBuilder &builder, Span<const TaskGraphNodeID> deps)
+{
+    return setupLeafRefreshTasks(builder, deps);
 }
 
 }
@@ -2134,9 +2274,7 @@ MADRONA_HOST_API inline TaskGraphNodeID setupBroadphaseTasks(
     auto bvh_stub = []() -> const void * { return nullptr; };
 #endif
 
-    auto update_leaves = builder.addToGraph<ParallelForNode<Context,
-        broadphase::updateLeafAndRefitEntry,
-            LeafID, Position, Rotation, Scale, ObjectID, Velocity>>(deps);
+    auto update_leaves = detail::setupLeafRefreshTasks(builder, deps);
 
     TaskGraphNodeID bvh_update = update_leaves;
 #if MADRONA_ON_HOST

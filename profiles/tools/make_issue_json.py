@@ -22,7 +22,9 @@ sys.path.insert(0, __file__.rsplit("/", 2)[0])
 from summarize_pmc import short_name  # noqa: E402
 
 KERNELS = [
-    (r"physicsStepLdsKernel|physicsStepKernel", "physics:worldStep(LDS)"),
+    (r"physicsStepLdsKernel", "physics:worldStep(LDS)"),
+    (r"physicsStepKernel", "physics:worldStep(HBM)"),
+    (r"bvhRefreshKernel", "physics:bvhRefresh"),
     (r"renderRaycast", "render:raycast"),
     (r"resetSystem", "resetSystem"),
     (r"lidarSystem", "lidarSystem"),

@@ -27,8 +27,11 @@ BENCH_NAMES = [
     (r"sortGather", "SortArchetype:sort.gather"),
     (r"sortFinalize", "SortArchetype:sort.finalize"),
     (r"sortSmall", "SortArchetype:sort.small"),
-    (r"physicsStepLdsKernel|physicsStepKernel", "physics:worldStep(LDS)"),
-    (r"physicsPackKernel", "physics:packWorlds"),
+    (r"physicsStepLdsKernel", "physics:worldStep(LDS)"),
+    # (main kernel of worlds beyond 128 bodies, and the fallback launch behind
+    # the LDS kernel)
+    (r"physicsStepKernel", "physics:worldStep(HBM)"),
+    (r"bvhRefreshKernel", "physics:bvhRefresh"),
     (r"physicsOrderKernel", "physics:orderWorlds"),
     (r"inputRingKernel", "input:ring"),
     (r"bvhUpdateKernel", "physics:bvhUpdate"),
