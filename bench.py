@@ -190,9 +190,14 @@ def driver_line(full, detail_path):
 
 def write_detail(full):
     """Per-kernel tables, chains and notes of the run: gpurun_out/ when it exists
-    (it travels back from the GPU box), else next to bench.py."""
+    (it travels back from the GPU box), else next to bench.py.  One file per
+    workload (bench_detail_<sim>_w<worlds>_g<gpus>.json)."""
     d = os.path.join(REPO, "gpurun_out")
-    path = os.path.join(d if os.path.isdir(d) else REPO, "bench_detail.json")
+    cfg = full.get("config") or {}
+    name = "bench_detail_%s_w%s_g%s.json" % (cfg.get("sim", "sim"),
+                                             cfg.get("worlds_per_gpu", 0),
+                                             full.get("n_gpus", 1))
+    path = os.path.join(d if os.path.isdir(d) else REPO, name)
     try:
         with open(path, "w") as f:
             json.dump(full, f, indent=1)
@@ -313,7 +318,12 @@ def issue_roofline(name, sim, worlds, kernel_pattern, avg_us, waves_per_simd, no
     match = None
     for e in recorded_issue_counters():
         if (e["sim"], e["worlds"]) == (sim, worlds) and kernel_pattern in e["kernel"]:
-            match = e           # later files override earlier ones
+            # later files override earlier ones; of one file's entries the one
+            # that issued the most (the fallback launch behind the LDS step --
+            # "physics:worldStep(HBM)" -- matches the same pattern and is empty)
+            if (match is None or e["source"] != match["source"] or
+                    e.get("SQ_INSTS_VALU", 0.0) > match.get("SQ_INSTS_VALU", 0.0)):
+                match = e
     if match is None or avg_us <= 0 or "SQ_INSTS_VALU" not in match:
         return None
     insts = (match.get("SQ_INSTS_VALU", 0.0) + match.get("SQ_INSTS_SALU", 0.0) +
@@ -608,8 +618,11 @@ def rooflines(stats, sim_name, worlds, ms_per_step):
                           [k for k in pfor_k if not k.get("io_declared")])):
         if not group:
             continue
-        t_sum, t_src, t_missing = 0, None, []
+        t_sum, t_src, t_missing, seen = 0, None, [], set()
         for k in group:
+            if k["name"] in seen:
+                continue        # (recorded traffic is per STEP: every launch of
+            seen.add(k["name"])     # a kernel that runs several times is in it)
             t, src = traffic_for(entries, sim_name, worlds, k["name"])
             if t is None:
                 t_missing.append(k["name"])
