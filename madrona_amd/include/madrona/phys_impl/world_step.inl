@@ -1,5 +1,9 @@
 // The fused rigid-body step: ONE kernel per simulation step, one wavefront per
-// world (included by physics.inl inside namespace madrona::phys::kernels).
+// world (included by physics.inl inside namespace madrona::phys::kernels).  The
+// code is split by what it does: step_wave.inl (wavefront primitives),
+// step_narrowphase.inl (cooperative SAT / clipping / manifolds), step_hbm.inl
+// (the step out of HBM + shared pieces), step_lds.inl (the step with the world
+// in LDS), step_order.inl (the order / frame kernel in front of it).
 //
 // Worlds are independent, and everything the physics step does is per world:
 // find candidate pairs, then per substep integrate, collide, solve positions,
@@ -25,2628 +29,9 @@
 
 using namespace narrowphase;
 
-namespace wave {
 
-__device__ inline uint32_t laneID()
-{
-    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-}
-
-// phase boundary inside a wave: earlier global writes of any lane become
-// visible to later reads of every lane (same CU), and the compiler may not
-// move memory operations across it
-__device__ inline void phaseFence()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
-// The helpers below work on groups of LPW consecutive lanes (LPW = 64: the whole
-// wavefront; 32: two worlds share a wavefront, one per half).  `lane` is the
-// index inside the group; the lanes of a group are always converged when they
-// get here, the other group of the wavefront need not be.
-template <int LPW = 64>
-__device__ inline uint32_t exclusiveScan(uint32_t v, uint32_t lane,
-                                         uint32_t *total)
-{
-    uint32_t incl = v;
-#pragma unroll
-    for (uint32_t d = 1; d < (uint32_t)LPW; d <<= 1) {
-        uint32_t up = __shfl_up(incl, d, LPW);
-        if (lane >= d) incl += up;
-    }
-    *total = __shfl(incl, LPW - 1, LPW);
-    return incl - v;
-}
-
-template <int LPW = 64>
-__device__ inline uint32_t maxReduce(uint32_t v)
-{
-#pragma unroll
-    for (uint32_t d = LPW / 2; d > 0; d >>= 1) {
-        uint32_t o = __shfl_xor(v, d, LPW);
-        v = o > v ? o : v;
-    }
-    return v;
-}
-
-// ballot over the lanes of my group: bit i = lane i of the group
-template <int LPW = 64>
-__device__ inline uint64_t groupBallot(bool pred)
-{
-    const uint64_t all = __builtin_amdgcn_ballot_w64(pred);
-    if constexpr (LPW == 64) {
-        return all;
-    } else {
-        const uint32_t first = laneID() & ~(uint32_t)(LPW - 1);
-        return (all >> first) & ((1ull << LPW) - 1ull);
-    }
-}
-
-// set bits of a group ballot below my lane
-__device__ inline uint32_t rankInGroup(uint64_t mask, uint32_t lane)
-{
-    return (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
-}
-
-// arg-max over the wave where the LOWEST index wins among equal values -- the
-// result of a sequential "if (v > best)" scan in index order.  Every lane
-// returns the winner.  (Lane-local values are never NaN: they start at
-// -FLT_MAX and are only replaced through a strict >.)
-template <int LPW = 64>
-__device__ inline void argMaxFirst(float &v, uint32_t &idx)
-{
-#pragma unroll
-    for (uint32_t d = LPW / 2; d > 0; d >>= 1) {
-        float ov = __shfl_xor(v, d, LPW);
-        uint32_t oi = __shfl_xor(idx, d, LPW);
-        if (ov > v || (ov == v && oi < idx)) {
-            v = ov;
-            idx = oi;
-        }
-    }
-}
-
-__device__ inline uint32_t rankInBallot(uint64_t mask)
-{
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-        __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-}
-
-}
-
-// ---------------------------------------------------------------------------
-// narrowphase on a wavefront
-// ---------------------------------------------------------------------------
-// Per-lane clipping scratch in LDS: lanePolyVerts points + depths per lane,
-// rows padded to an odd dword count so lanes fall into different banks.
-inline constexpr uint32_t lanePolyVerts = 8;
-inline constexpr uint32_t lanePolyDwords = lanePolyVerts * 4 + 1;
-// rows available per round; lanes that need one are served in rounds
-inline constexpr uint32_t lanePolyRows = 16;
-// clipping scratch of the wave-cooperative hull-hull path (2 polygons)
-inline constexpr uint32_t wavePolyVerts = 24;
-
-// world-space copies of the two hulls of a cooperative hull-hull test
-inline constexpr uint32_t waveHullElems = 16;   // vertices, faces per hull
-
-// scratch of ONE cooperative hull-hull test (a world runs as many at a time as
-// it has lane groups for them: hullHullWave<G>)
-struct alignas(16) HullScratch {
-    math::Vector3 clip[2][wavePolyVerts];
-    math::Vector3 hullVerts[2][waveHullElems];
-    geo::Plane hullPlanes[2][waveHullElems];
-};
-
-struct alignas(16) WaveScratch {
-    float lanePoly[lanePolyRows * lanePolyDwords];
-    HullScratch hull;
-};
-
-// number of vertices of face `face_idx`
-template <typename HullT>
-__device__ inline uint32_t faceVertexCount(const HullT &h, uint32_t face_idx)
-{
-    uint32_t n = 0;
-    uint32_t hedge_idx = h.faceBaseHedge(face_idx);
-    const uint32_t start = hedge_idx;
-    do {
-        hedge_idx = h.hedge(hedge_idx).next;
-        n++;
-    } while (hedge_idx != start);
-    return n;
-}
-
-// SAT face query with the faces of `a` spread over the lanes (sequential
-// reference: narrowphase.hpp queryFaceDirections)
-template <int LPW = 64, typename HullA, typename HullB>
-__device__ inline FaceQuery queryFaceDirectionsWave(uint32_t lane,
-                                                    const HullA &a,
-                                                    const HullB &b)
-{
-    float best_sep = -FLT_MAX;
-    uint32_t best_face = 0xFFFFFFFFu;
-
-    const uint32_t num_a_faces = (uint32_t)a.numFaces();
-    for (uint32_t f = lane; f < num_a_faces; f += LPW) {
-        float face_dist = getHullDistanceFromPlane(a.plane(f), b);
-        if (face_dist > best_sep) {
-            best_sep = face_dist;
-            best_face = f;
-        }
-    }
-    wave::argMaxFirst<LPW>(best_sep, best_face);
-
-    FaceQuery best;
-    best.separation = best_sep;
-    if (best_face == 0xFFFFFFFFu) {
-        best.faceIdx = -1;
-        best.plane = Plane { Vector3::zero(), 0.f };
-    } else {
-        best.faceIdx = (CountT)best_face;
-        best.plane = a.plane(best_face);
-    }
-    return best;
-}
-
-// SAT edge query with the (edge of a, edge of b) pairs spread over the lanes
-// (sequential reference: narrowphase.hpp queryEdgeDirections)
-template <int LPW = 64, typename HullA, typename HullB>
-__device__ inline EdgeQuery queryEdgeDirectionsWave(uint32_t lane,
-                                                    const HullA &a,
-                                                    const HullB &b)
-{
-    float best_sep = -FLT_MAX;
-    uint32_t best_pair = 0xFFFFFFFFu;
-
-    const uint32_t b_num_edges = (uint32_t)b.numEdges();
-    const uint32_t num_pairs = (uint32_t)a.numEdges() * b_num_edges;
-    for (uint32_t p = lane; p < num_pairs; p += LPW) {
-        int32_t he_idx_a = (int32_t)((p / b_num_edges) * 2);
-        int32_t he_idx_b = (int32_t)((p % b_num_edges) * 2);
-        EdgeTestResult r = testEdgePair(a, b, he_idx_a, he_idx_b);
-        if (r.separation > best_sep) {
-            best_sep = r.separation;
-            best_pair = p;
-        }
-    }
-    wave::argMaxFirst<LPW>(best_sep, best_pair);
-
-    EdgeQuery best;
-    best.separation = best_sep;
-    if (best_pair == 0xFFFFFFFFu) {
-        best.normal = Vector3::zero();
-        best.edgeIdxA = 0;
-        best.edgeIdxB = 0;
-    } else {
-        best.edgeIdxA = (int32_t)((best_pair / b_num_edges) * 2);
-        best.edgeIdxB = (int32_t)((best_pair % b_num_edges) * 2);
-        best.normal =
-            testEdgePair(a, b, best.edgeIdxA, best.edgeIdxB).normal;
-    }
-    return best;
-}
-
-// makeHullState with the vertices / planes spread over the G lanes of the test.
-// The centroid is left out: only the edge query reads it, and only hull a's
-// (narrowphase.hpp testEdgePair) -- hullCentroid() below, once both face
-// queries have failed to separate the pair (half of the tests end before).
-template <int G = 64>
-__device__ inline HullState makeHullStateWave(uint32_t lane,
-                                              const HalfEdgeMesh &mesh,
-                                              const PrimitiveTransform &txfm,
-                                              Vector3 *dst_vertices,
-                                              Plane *dst_planes)
-{
-    LazyHull lazy(mesh, txfm.pos, txfm.rot, txfm.scale, false);
-    for (uint32_t i = lane; i < mesh.numVertices; i += G) {
-        dst_vertices[i] = lazy.vertex(i);
-    }
-    for (uint32_t i = lane; i < mesh.numFaces; i += G) {
-        dst_planes[i] = lazy.plane(i);
-    }
-
-    HalfEdgeMesh world_mesh = mesh;
-    world_mesh.facePlanes = dst_planes;
-    world_mesh.vertices = dst_vertices;
-    return HullState { world_mesh, Vector3::zero() };
-}
-
-// the centroid is a sequential sum (fp order): every lane adds it up
-__device__ inline void hullCentroid(HullState &hull)
-{
-    Vector3 center = Vector3::zero();
-    const CountT num_vertices = (CountT)hull.mesh.numVertices;
-    for (CountT i = 0; i < num_vertices; i++) {
-        center += hull.mesh.vertices[i];
-    }
-    center /= (float)num_vertices;
-    hull.center = center;
-}
-__device__ inline void hullCentroid(LazyHull &) {}     // (has it already)
-
-// Profile builds (-DMADRONA_PHYS_PROFILE): cycles and exit counts of the stages
-// of a cooperative hull-hull test, accumulated in the calling kernel's own
-// counters (slots 16.. of prof_acc: registers -- atomics per mark distort the
-// very thing they measure; profiles/tools/phys_phase_cycles.py).  Its own
-// switch (-DMADRONA_PHYS_PROFILE_HH on top of -DMADRONA_PHYS_PROFILE): the 16
-// extra accumulators push the kernel into spilling, which inflates the phase
-// figures of the same build; use it for the stage split and exit counts only.
-struct HullHullProf {
-#ifdef MADRONA_PHYS_PROFILE_HH
-    unsigned long long *acc;
-    unsigned long long t;
-    __device__ inline void mark(uint32_t, int slot)
-    {
-        unsigned long long now = __builtin_readcyclecounter();
-        acc[16 + slot] += now - t;
-        t = now;
-    }
-    __device__ inline void count(uint32_t, int slot)
-    {
-        acc[16 + slot] += 1ull;
-    }
-#else
-    __device__ inline void mark(uint32_t, int) {}
-    __device__ inline void count(uint32_t, int) {}
-#endif
-};
-
-template <int LPW = 64, typename HullA, typename HullB>
-__device__ inline bool hullHullWaveSAT(uint32_t lane, const PairSetup &pair,
-                                       HullA &a, const HullB &b,
-                                       HullScratch *scratch,
-                                       ContactConstraint *out, bool *too_big,
-                                       HullHullProf prof = HullHullProf {});
-
-// Hull-hull pair handled by a group of LPW lanes (`pair` is uniform across the
-// group; `lane` = index inside it).  Returns false with *too_big set when the
-// clipped polygon may not fit the LDS scratch.
-// (A template so that only the device pass instantiates it.  Keeping it out of
-// line to confine its register footprint was measured: 1166 -> 1637 us.)
-template <int LPW = 64>
-__device__ inline bool
-hullHullWave(uint32_t lane, const PairSetup &pair,
-                                    HullScratch *scratch,
-                                    ContactConstraint *out, bool *too_big,
-                                    HullHullProf prof = HullHullProf {})
-{
-    const HalfEdgeMesh &a_mesh = pair.aPrim->hull.halfEdgeMesh;
-    const HalfEdgeMesh &b_mesh = pair.bPrim->hull.halfEdgeMesh;
-
-    if (a_mesh.numVertices <= waveHullElems &&
-        a_mesh.numFaces <= waveHullElems &&
-        b_mesh.numVertices <= waveHullElems &&
-        b_mesh.numFaces <= waveHullElems) {
-        // small hulls: transform once into LDS
-        HullState a = makeHullStateWave<LPW>(lane, a_mesh, pair.a,
-            scratch->hullVerts[0], scratch->hullPlanes[0]);
-        HullState b = makeHullStateWave<LPW>(lane, b_mesh, pair.b,
-            scratch->hullVerts[1], scratch->hullPlanes[1]);
-        wave::phaseFence();
-#ifdef MADRONA_PHYS_EAGER_CENTROID
-        // (round 3, for A/B measurements: both centroids up front)
-        hullCentroid(a);
-        hullCentroid(b);
-#endif
-        prof.mark(lane, 0);     // hulls into LDS
-        return hullHullWaveSAT<LPW>(lane, pair, a, b, scratch, out, too_big,
-                                    prof);
-    }
-
-    LazyHull a(a_mesh, pair.a.pos, pair.a.rot, pair.a.scale);
-    LazyHull b(b_mesh, pair.b.pos, pair.b.rot, pair.b.scale);
-    return hullHullWaveSAT<LPW>(lane, pair, a, b, scratch, out, too_big, prof);
-}
-
-// ---------------------------------------------------------------------------
-// Face contact with the polygon spread over the lanes (sequential reference:
-// narrowphase.hpp createFaceContact + clipPolygon + buildFaceContactManifold).
-// The sequential routines walk polygons of <= 8 vertices through LDS one vertex
-// at a time -- a few hundred dependent LDS round trips per overlapping pair,
-// which every lane of the group repeats in lock step: 20 K of the ~45 K cycles
-// such a pair costs.  Here lane i HOLDS vertex i:
-//   * Sutherland-Hodgman against side plane k: lane i looks at the edge
-//     (vertex i - 1 -> vertex i), emits 0, 1 or 2 vertices, and finds its place
-//     in the output with two ballots (the sequential loop's order);
-//   * the reduction to four points: "first index that reaches the maximum, if it
-//     beats the starting value" = wave::argMaxFirst over the lanes, three times.
-// Same expressions on the same operands, so the same bits; every lane returns
-// the same manifold.  Requires n_ref, n_inc and every clipped polygon <= LPW
-// vertices (a clip adds at most one vertex per plane).
-// ---------------------------------------------------------------------------
-template <int LPW>
-__device__ inline Vector3 shflVec3(Vector3 v, int src)
-{
-    return Vector3 { __shfl(v.x, src, LPW), __shfl(v.y, src, LPW),
-                     __shfl(v.z, src, LPW) };
-}
-
-template <int LPW>
-__device__ inline Manifold createFaceContactWave(uint32_t lane, Plane ref_plane,
-                                                 int32_t ref_face_idx,
-                                                 int32_t incident_face_idx,
-                                                 const HullState &ref,
-                                                 const HullState &other,
-                                                 Vector3 *lds_a, float *lds_b)
-{
-    const uint64_t lane_lt = (1ull << lane) - 1ull;
-
-    // lane i: vertex i of the incident face, vertex i of the reference face
-    // (the rings are linked lists: every lane walks them, keeps its own)
-    Vector3 v = Vector3::zero();
-    int32_t n = 0;
-    {
-        uint32_t hedge_idx = other.faceBaseHedge(incident_face_idx);
-        const uint32_t start_hedge_idx = hedge_idx;
-        uint32_t my_root = 0;
-        do {
-            const HalfEdge cur_hedge = other.hedge(hedge_idx);
-            hedge_idx = cur_hedge.next;
-            if ((uint32_t)n == lane) my_root = cur_hedge.rootVertex;
-            n++;
-        } while (hedge_idx != start_hedge_idx);
-        if ((int32_t)lane < n) v = other.vertex(my_root);
-    }
-    Plane side_plane { Vector3::zero(), 0.f };
-    int32_t n_ref = 0;
-    {
-        uint32_t hedge_idx = ref.faceBaseHedge(ref_face_idx);
-        const uint32_t start_hedge_idx = hedge_idx;
-        uint32_t my_root = 0;
-        do {
-            const HalfEdge cur_hedge = ref.hedge(hedge_idx);
-            hedge_idx = cur_hedge.next;
-            if ((uint32_t)n_ref == lane) my_root = cur_hedge.rootVertex;
-            n_ref++;
-        } while (hedge_idx != start_hedge_idx);
-        Vector3 cur_point = Vector3::zero();
-        if ((int32_t)lane < n_ref) cur_point = ref.vertex(my_root);
-        // side plane k runs from point k to point k + 1 (the ring closes)
-        const int32_t next_lane = (int32_t)lane + 1 < n_ref ? (int32_t)lane + 1 : 0;
-        const Vector3 next_point = shflVec3<LPW>(cur_point, next_lane);
-        const Vector3 edge = next_point - cur_point;
-        const Vector3 plane_normal = cross(edge, ref_plane.normal);
-        side_plane = Plane { plane_normal, dot(plane_normal, cur_point) };
-    }
-
-    // ---- clip against every side plane, in ring order ----
-    for (int32_t k = 0; k < n_ref; k++) {
-        const Plane clip {
-            shflVec3<LPW>(side_plane.normal, k), __shfl(side_plane.d, k, LPW) };
-        const bool have = (int32_t)lane < n;
-        const float d2 = getDistanceFromPlane(clip, v);
-        const int32_t prev = lane == 0u ? n - 1 : (int32_t)lane - 1;
-        const Vector3 v1 = shflVec3<LPW>(v, prev < 0 ? 0 : prev);
-        const float d1 = __shfl(d2, prev < 0 ? 0 : prev, LPW);
-
-        // what the sequential loop emits for the edge v1 -> v (in this order)
-        const bool crossing = have && ((d1 <= 0.0f && d2 > 0.0f) ||
-                                       (d2 <= 0.0f && d1 > 0.0f));
-        const bool keep = have && d2 <= 0.0f;
-        const uint64_t m_cross = wave::groupBallot<LPW>(crossing);
-        const uint64_t m_keep = wave::groupBallot<LPW>(keep);
-        const int32_t at = (int32_t)__builtin_popcountll(m_cross & lane_lt) +
-            (int32_t)__builtin_popcountll(m_keep & lane_lt);
-        if (crossing) {
-            lds_a[at] = planeIntersection(clip, v1, v);
-        }
-        if (keep) {
-            lds_a[at + (crossing ? 1 : 0)] = v;
-        }
-        n = (int32_t)__builtin_popcountll(m_cross) +
-            (int32_t)__builtin_popcountll(m_keep);
-        wave::phaseFence();
-        v = (int32_t)lane < n ? lds_a[lane] : Vector3::zero();
-        wave::phaseFence();
-    }
-
-    // ---- what lies below the reference plane, projected onto it ----
-    float depth = 0.f;
-    int32_t m = 0;
-    {
-        const float d = getDistanceFromPlane(ref_plane, v);
-        const bool below = (int32_t)lane < n && d <= 0.0f;
-        const uint64_t m_below = wave::groupBallot<LPW>(below);
-        if (below) {
-            const int32_t at = (int32_t)__builtin_popcountll(m_below & lane_lt);
-            lds_a[at] = v - d * ref_plane.normal;
-            lds_b[at] = -d;
-        }
-        m = (int32_t)__builtin_popcountll(m_below);
-        wave::phaseFence();
-        v = (int32_t)lane < m ? lds_a[lane] : Vector3::zero();
-        depth = (int32_t)lane < m ? lds_b[lane] : 0.f;
-        wave::phaseFence();
-    }
-
-    // ---- the <= 4 points that best preserve the polygon (lane i = contact i) ----
-    Manifold manifold;
-    for (int i = 0; i < 4; i++) {
-        manifold.contactPoints[i] = Vector3::zero();
-        manifold.penetrationDepths[i] = 0.f;
-    }
-    auto contactOf = [&](uint32_t src, int slot) {
-        manifold.contactPoints[slot] = shflVec3<LPW>(v, (int)src);
-        manifold.penetrationDepths[slot] = __shfl(depth, (int)src, LPW);
-    };
-    const Vector3 contact_normal = ref_plane.normal;
-    if (m <= 4) {
-        manifold.numContactPoints = m;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const Vector3 p = shflVec3<LPW>(v, i);
-            const float dp = __shfl(depth, i, LPW);
-            if (i < m) {
-                manifold.contactPoints[i] = p;
-                manifold.penetrationDepths[i] = dp;
-            }
-        }
-    } else {
-        manifold.numContactPoints = 4;
-        contactOf(0u, 0);
-        const bool candidate = lane >= 1u && (int32_t)lane < m;
-
-        // farthest from the first point (first index wins, must beat 0)
-        float max_dist_sq = 0.f;
-        {
-            float val = candidate ? manifold.contactPoints[0].distance2(v) : -FLT_MAX;
-            uint32_t idx = lane;
-            wave::argMaxFirst<LPW>(val, idx);
-            if (val > 0.f) {
-                max_dist_sq = val;
-                contactOf(idx, 1);
-            }
-        }
-        Vector3 ba = manifold.contactPoints[1] - manifold.contactPoints[0];
-
-        // largest triangle with the first two
-        float max_tri_area = 0.0f;
-        {
-            const Vector3 bc = v - manifold.contactPoints[1];
-            const float signed_area = contact_normal.dot(cross(ba, bc));
-            float val = candidate ? copysignf(signed_area, 1.f) : -FLT_MAX;
-            uint32_t idx = lane;
-            wave::argMaxFirst<LPW>(val, idx);
-            if (val > 0.f) {
-                max_tri_area = val;
-                contactOf(idx, 2);
-            }
-            // (the reference keeps the winning sign in a bool that is never -1:
-            // its swap of the first two points never happens, narrowphase.hpp)
-        }
-
-        const Vector3 cb = manifold.contactPoints[2] - manifold.contactPoints[1];
-        const Vector3 ac = manifold.contactPoints[0] - manifold.contactPoints[2];
-
-        // most outside that triangle
-        float most_neg_area = 0.f;
-        {
-            const Vector3 aq = manifold.contactPoints[0] - v;
-            const Vector3 qc = v - manifold.contactPoints[2];
-            const float abq_area = contact_normal.dot(cross(ba, aq));
-            const float bcq_area = contact_normal.dot(cross(cb, qc));
-            const float caq_area = contact_normal.dot(cross(aq, ac));
-            const float q_min_area = fminf(abq_area, fminf(bcq_area, caq_area));
-            float val = candidate ? -q_min_area : -FLT_MAX;
-            uint32_t idx = lane;
-            wave::argMaxFirst<LPW>(val, idx);
-            if (val > 0.f) {
-                most_neg_area = -val;
-                contactOf(idx, 3);
-            }
-        }
-
-        if (max_dist_sq == 0.f || max_tri_area == 0.f || most_neg_area == 0.f) {
-            manifold.numContactPoints = 0;
-            manifold.normal = Vector3::zero();
-            return manifold;
-        }
-    }
-
-    // (the identity transform of the sequential routine: it turns -0 into +0)
-    const Vector3 world_offset { 0, 0, 0 };
-    const Quat to_world_frame { 1, 0, 0, 0 };
-    for (int i = 0; i < 4; i++) {
-        if (i < manifold.numContactPoints) {
-            manifold.contactPoints[i] =
-                to_world_frame.rotateVec(manifold.contactPoints[i]) + world_offset;
-        }
-    }
-    manifold.normal = to_world_frame.rotateVec(contact_normal);
-    return manifold;
-}
-
-// (only hulls staged in LDS take the lane-parallel manifold)
-template <int LPW, typename HullA, typename HullB>
-__device__ inline bool faceContactWave(uint32_t, const SATResult &, const HullA &,
-                                       const HullB &, const PairSetup &,
-                                       HullScratch *, uint32_t, uint32_t,
-                                       ContactConstraint *, bool *)
-{
-    return false;
-}
-
-template <int LPW>
-__device__ inline bool faceContactWave(uint32_t lane, const SATResult &sat,
-                                       const HullState &a, const HullState &b,
-                                       const PairSetup &pair, HullScratch *scratch,
-                                       uint32_t n_ref, uint32_t n_inc,
-                                       ContactConstraint *out, bool *found)
-{
-#ifdef MADRONA_PHYS_SEQUENTIAL_MANIFOLD
-    return false;
-#else
-    // every polygon of the clipping fits the group: the incident face gains at
-    // most one vertex per side plane
-    if (n_ref + n_inc > (uint32_t)LPW) {
-        return false;
-    }
-    const uint32_t ref_face = sat.contact.refFaceIdxOrEdgeIdxA & 0x7FFFFFFFu;
-    const bool a_is_ref = ref_face == sat.contact.refFaceIdxOrEdgeIdxA;
-    const Plane ref_plane { sat.contact.normal, sat.contact.planeDOrSeparation };
-    const Manifold manifold = a_is_ref ?
-        createFaceContactWave<LPW>(lane, ref_plane, (int32_t)ref_face,
-            (int32_t)sat.contact.incidentFaceIdxOrEdgeIdxB, a, b,
-            scratch->clip[0], (float *)scratch->clip[1]) :
-        createFaceContactWave<LPW>(lane, ref_plane, (int32_t)ref_face,
-            (int32_t)sat.contact.incidentFaceIdxOrEdgeIdxB, b, a,
-            scratch->clip[0], (float *)scratch->clip[1]);
-    // barely touching pairs can lose every clipped point to fp32
-    *found = manifold.numContactPoints != 0;
-    if (*found) {
-        manifoldToContact(manifold, a_is_ref ? pair.aLoc : pair.bLoc,
-                          a_is_ref ? pair.bLoc : pair.aLoc, out);
-    }
-    return true;
-#endif
-}
-
-template <int LPW, typename HullA, typename HullB>
-__device__ inline bool hullHullWaveSAT(uint32_t lane, const PairSetup &pair,
-                                       HullA &a, const HullB &b,
-                                       HullScratch *scratch,
-                                       ContactConstraint *out, bool *too_big,
-                                       HullHullProf prof)
-{
-    FaceQuery face_query_a = queryFaceDirectionsWave<LPW>(lane, a, b);
-    prof.mark(lane, 1);
-    if (face_query_a.separation > 0.0f) {
-        prof.count(lane, 5);
-        return false;
-    }
-
-    FaceQuery face_query_b = queryFaceDirectionsWave<LPW>(lane, b, a);
-    prof.mark(lane, 2);
-    if (face_query_b.separation > 0.0f) {
-        prof.count(lane, 6);
-        return false;
-    }
-
-#ifndef MADRONA_PHYS_EAGER_CENTROID
-    hullCentroid(a);
-#endif
-    EdgeQuery edge_query = queryEdgeDirectionsWave<LPW>(lane, a, b);
-    prof.mark(lane, 3);
-    if (edge_query.separation > 0.0f) {
-        prof.count(lane, 7);
-        return false;
-    }
-    prof.count(lane, 8);
-
-    // from here on every lane computes the same thing (cheap, and it keeps the
-    // wave converged); the clipping polygons live in LDS
-    const SATResult sat =
-        chooseSATContact(a, b, face_query_a, face_query_b, edge_query);
-
-    if (sat.type == ContactType::SATFace) {
-        uint32_t ref_face = sat.contact.refFaceIdxOrEdgeIdxA & 0x7FFFFFFFu;
-        bool a_is_ref = ref_face == sat.contact.refFaceIdxOrEdgeIdxA;
-        uint32_t inc_face = sat.contact.incidentFaceIdxOrEdgeIdxB;
-        uint32_t n_ref = a_is_ref ? faceVertexCount(a, ref_face) :
-                                    faceVertexCount(b, ref_face);
-        uint32_t n_inc = a_is_ref ? faceVertexCount(b, inc_face) :
-                                    faceVertexCount(a, inc_face);
-        if (n_ref + n_inc > wavePolyVerts) {
-            *too_big = true;
-            return false;
-        }
-        bool found_wave = false;
-        if (faceContactWave<LPW>(lane, sat, a, b, pair, scratch, n_ref, n_inc, out,
-                                 &found_wave)) {
-            prof.mark(lane, 4);
-            return found_wave;
-        }
-    }
-
-    const bool found = satToContact(sat, a, b, pair.aLoc, pair.bLoc,
-                                    scratch->clip[0], scratch->clip[1], out);
-    prof.mark(lane, 4);
-    return found;
-}
-
-// Every other primitive pair: one lane, hull evaluated lazily, clipping
-// scratch in the lane's LDS row.
-__device__ inline bool collidePairLane(const PairSetup &pair, float *row,
-                                       ContactConstraint *out,
-                                       bool *too_big, bool *unsupported)
-{
-    switch (pair.test) {
-    case NarrowphaseTest::SphereSphere:
-        return sphereSphereContact(pair, out);
-    case NarrowphaseTest::SpherePlane:
-        return spherePlaneContact(pair, out);
-    case NarrowphaseTest::HullPlane: {
-        LazyHull a(pair.aPrim->hull.halfEdgeMesh, pair.a.pos, pair.a.rot,
-                   pair.a.scale, false);
-
-        // the contact polygon is (part of) the face SAT picks: it must fit
-        // the lane's LDS row
-        return hullPlaneContact(a, pair.b, pair.aLoc, pair.bLoc,
-                                row, row + lanePolyVerts * 3, out,
-                                (CountT)lanePolyVerts, too_big);
-    }
-    case NarrowphaseTest::SphereHull: {
-        // hull in the sphere's frame, evaluated lazily (no centroid needed)
-        LazyHull b(pair.bPrim->hull.halfEdgeMesh, pair.b.pos - pair.a.pos,
-                   pair.b.rot, pair.b.scale, false);
-        return sphereHullContact(pair, b, out);
-    }
-    case NarrowphaseTest::PlanePlane:
-    default:
-        *unsupported = true;
-        return false;
-    }
-}
-
-struct WorldBodies {
-    // Every loop over these arrays is fully unrolled with the bound below and
-    // predicated on numArchetypes: indexed by a run-time value they live in
-    // scratch memory, and filling them was a chain of scratch round trips at
-    // the head of every world (8 % of the step kernel's cycles).
-    static constexpr uint32_t maxArchetypes = PhysicsScratch::maxBodyArchetypes;
-
-    uint32_t numArchetypes;
-    uint32_t archetype[maxArchetypes];
-    int32_t rowBase[maxArchetypes];
-    int32_t bodyBase[maxArchetypes + 1];
-
-    __device__ inline int32_t count() const
-    {
-        int32_t n = 0;
-#pragma unroll
-        for (uint32_t a = 0; a < maxArchetypes; a++) {
-            if (a < numArchetypes) {
-                n = bodyBase[a + 1];
-            }
-        }
-        return n;
-    }
-
-    // k-th body of the world in the CPU backend's iteration order
-    __device__ inline Loc loc(int32_t k) const
-    {
-        uint32_t arch = archetype[0];
-        int32_t row = rowBase[0] + k;
-#pragma unroll
-        for (uint32_t a = 1; a < maxArchetypes; a++) {
-            if (a < numArchetypes && k >= bodyBase[a]) {
-                arch = archetype[a];
-                row = rowBase[a] + (k - bodyBase[a]);
-            }
-        }
-        return Loc { arch, row };
-    }
-
-    // row ranges of `world` in the rigid-body tables; false: a table is unsorted
-    __device__ inline bool fill(mwhip::EcsState *S, const PhysicsScratch *ps,
-                                int32_t world)
-    {
-        numArchetypes = ps->numBodyArchetypes;
-        // (the pointers first, then what they lead to: two rounds of loads)
-        const int32_t *offsets[maxArchetypes];
-        const int32_t *counts[maxArchetypes];
-        uint32_t unsorted = 0;
-#pragma unroll
-        for (uint32_t a = 0; a < maxArchetypes; a++) {
-            offsets[a] = nullptr;
-            counts[a] = nullptr;
-            archetype[a] = 0;
-            if (a < numArchetypes) {
-                archetype[a] = ps->bodyArchetypes[a];
-                const mwhip::TableHdr &tbl = S->tables[archetype[a]];
-                offsets[a] = tbl.worldOffsets;
-                counts[a] = tbl.worldCounts;
-                unsorted |= tbl.needsSort;
-            }
-        }
-        int32_t rows[maxArchetypes];
-#pragma unroll
-        for (uint32_t a = 0; a < maxArchetypes; a++) {
-            rowBase[a] = 0;
-            rows[a] = 0;
-            if (a < numArchetypes) {
-                rowBase[a] = offsets[a][world];
-                rows[a] = counts[a][world];
-            }
-        }
-        bodyBase[0] = 0;
-#pragma unroll
-        for (uint32_t a = 0; a < maxArchetypes; a++) {
-            bodyBase[a + 1] = bodyBase[a] + rows[a];
-        }
-        return unsorted == 0;
-    }
-};
-
-// Dependency levels for a window of <= 64 constraints held one per lane.
-// key_a / key_b: the two bodies (0 = static / none, never conflicts).
-template <int LPW = 64>
-__device__ inline uint32_t constraintLevels(uint32_t lane, uint32_t n,
-                                            uint64_t key_a, uint64_t key_b)
-{
-    uint32_t level = 0;
-    for (uint32_t j = 0; j + 1 < n; j++) {
-        uint64_t ja = __shfl(key_a, j, LPW);
-        uint64_t jb = __shfl(key_b, j, LPW);
-        uint32_t jl = __shfl(level, j, LPW);
-        bool conflict =
-            (ja != 0 && (ja == key_a || ja == key_b)) ||
-            (jb != 0 && (jb == key_a || jb == key_b));
-        if (lane > j && lane < n && conflict && jl + 1 > level) {
-            level = jl + 1;
-        }
-    }
-    return level;
-}
-
-// (32-bit keys: body indices inside an LDS-resident world)
-template <int LPW = 64>
-__device__ inline uint32_t constraintLevels(uint32_t lane, uint32_t n,
-                                            uint32_t key_a, uint32_t key_b)
-{
-    uint32_t level = 0;
-    for (uint32_t j = 0; j + 1 < n; j++) {
-        const uint32_t ja = __shfl(key_a, j, LPW);
-        const uint32_t jb = __shfl(key_b, j, LPW);
-        const uint32_t jl = __shfl(level, j, LPW);
-        const bool conflict =
-            (ja != 0u && (ja == key_a || ja == key_b)) ||
-            (jb != 0u && (jb == key_a || jb == key_b));
-        if (lane > j && lane < n && conflict && jl + 1 > level) {
-            level = jl + 1;
-        }
-    }
-    return level;
-}
-
-// A static body does not order the constraints that touch it as long as the
-// solver's writes to it are no-ops.  Positions are (x += 0), but the reference
-// renormalises the rotation in every positional update (xpbd.cpp
-// applyPositionalUpdate), so that only holds while the rotation is a fixed
-// point of normalize() -- e.g. not for a tilted body that was switched to
-// Static mid-flight; such a body orders its constraints like a dynamic one.
-__device__ inline bool staticBodyIsInert(math::Quat q)
-{
-    math::Quat n = q.normalize();
-    return n.w == q.w && n.x == q.x && n.y == q.y && n.z == q.z;
-}
-
-__device__ inline uint64_t bodyKey(Context &ctx, Loc loc)
-{
-    if (ctx.getDirect<ResponseType>(RGDCols::ResponseType, loc) ==
-            ResponseType::Static &&
-        staticBodyIsInert(
-            ctx.getDirect<base::Rotation>(RGDCols::Rotation, loc))) {
-        return 0;
-    }
-    return ((uint64_t)(loc.archetype + 1) << 32) | (uint64_t)(uint32_t)loc.row;
-}
-
-#ifndef MADRONA_PHYS_WAVES_PER_EU
-#define MADRONA_PHYS_WAVES_PER_EU 1
-#endif
-__global__ void __launch_bounds__(256)
-__attribute__((amdgpu_waves_per_eu(MADRONA_PHYS_WAVES_PER_EU)))
-physicsStepKernel(EcsState *S, void *node_data, uint32_t fallback_mode, uint32_t)
-{
-    mwhip::TraceScope trace_scope(S);
-    StateManager *state_mgr = static_cast<StateManager *>(S);
-    PhysicsScratch *ps = detail::scratch(S);
-    const PhysicsStepParams params = *(const PhysicsStepParams *)node_data;
-
-    const uint32_t lane = wave::laneID();
-    const int32_t waves_per_block = (int32_t)(blockDim.x / 64);
-    const int32_t wave_in_block = __builtin_amdgcn_readfirstlane(
-        (int32_t)(threadIdx.x / 64));
-    const int32_t num_worlds = S->numWorlds;
-
-    // generic fallback only (hulls whose faces outgrow the LDS scratch)
-    constexpr int32_t max_elems = MADRONA_PHYS_MAX_HULL_ELEMS;
-    geo::Plane tmp_faces[max_elems];
-    math::Vector3 tmp_vertices[max_elems];
-
-    __shared__ WaveScratch block_scratch[4];
-    WaveScratch *scratch = &block_scratch[wave_in_block];
-
-#ifdef MADRONA_PHYS_PROFILE
-    // per-phase cycle counters (debug builds): moduleData[1] -> uint64[8]
-    unsigned long long prof_t = __builtin_readcyclecounter();
-    unsigned long long prof_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-#define PHYS_PROF(slot) do { unsigned long long now_ = __builtin_readcyclecounter(); \
-        prof_acc[slot] += now_ - prof_t; prof_t = now_; } while (0)
-#else
-#define PHYS_PROF(slot) do {} while (0)
-#endif
-
-    const uint32_t cand_stride = ps->candidatesPerWorld;
-    const uint32_t contact_stride = ps->contactsPerWorld;
-
-    // fallback mode (launched behind an LDS step kernel): only the worlds that
-    // kernel listed -- too many bodies or contacts for its block
-    const int32_t *fallback_list = fallback_mode != 0u ?
-        ((const PhysicsStepParams *)node_data)->fallbackList : nullptr;
-    const int32_t num_jobs = fallback_list != nullptr ?
-        __hip_atomic_load(fallback_list, __ATOMIC_RELAXED,
-                          __HIP_MEMORY_SCOPE_AGENT) : num_worlds;
-
-    for (int32_t job = (int32_t)blockIdx.x * waves_per_block + wave_in_block;
-         job < num_jobs; job += (int32_t)gridDim.x * waves_per_block) {
-        const int32_t world = fallback_list != nullptr ?
-            __hip_atomic_load(fallback_list + 1 + job, __ATOMIC_RELAXED,
-                              __HIP_MEMORY_SCOPE_AGENT) : job;
-        Context ctx = TaskGraph::makeContext<Context>(
-            state_mgr, WorldID { world }, true);
-        const ObjectManager &obj_mgr = *ctx.singleton<ObjectData>().mgr;
-        const PhysicsSystemState physics_sys =
-            ctx.singleton<PhysicsSystemState>();
-
-        // ---- the world's bodies ---------------------------------------------
-        WorldBodies bodies;
-        const bool unsorted = !bodies.fill(S, ps, world);
-        if (unsorted) {
-            mwhip::raiseError(S, mwhip::kErrPhysics);
-            continue;
-        }
-        const int32_t num_bodies = bodies.count();
-        PHYS_PROF(0);
-
-        CandidateCollision *candidates =
-            ps->worldCandidates + (uint64_t)world * cand_stride;
-        ContactConstraint *contacts =
-            ps->worldContacts + (uint64_t)world * contact_stride;
-        float *lambdas = ps->worldLambdas + (uint64_t)world * contact_stride;
-
-        // ---- broadphase: candidate pairs in (body, traversal) order -----------
-        uint32_t num_candidates = 0;
-        for (int32_t chunk = 0; chunk < num_bodies; chunk += 64) {
-            const int32_t k = chunk + (int32_t)lane;
-            const bool active = k < num_bodies;
-
-            Loc a_loc = active ? bodies.loc(k) : Loc { 0, 0 };
-            Entity e = Entity::none();
-            broadphase::LeafID leaf_id { 0 };
-            uint32_t n = 0;
-            if (active) {
-                e = ctx.getDirect<Entity>(0, a_loc);
-                leaf_id = ctx.getDirect<broadphase::LeafID>(
-                    RGDCols::LeafID, a_loc);
-                detail::forEachCandidate(ctx, e, leaf_id, a_loc,
-                    [&](Loc, CountT a_num_prims, CountT b_num_prims) {
-                        n += (uint32_t)(a_num_prims * b_num_prims);
-                    });
-            }
-
-            uint32_t chunk_total;
-            uint32_t out = num_candidates +
-                wave::exclusiveScan(n, lane, &chunk_total);
-
-            if (active && n != 0 && out + n <= cand_stride) {
-                detail::forEachCandidate(ctx, e, leaf_id, a_loc,
-                    [&](Loc b_loc, CountT a_num_prims, CountT b_num_prims) {
-                        CountT total_checks = a_num_prims * b_num_prims;
-                        for (CountT c = 0; c < total_checks; c++) {
-                            CandidateCollision &candidate = candidates[out++];
-                            candidate.a = a_loc;
-                            candidate.b = b_loc;
-                            candidate.aPrim = (uint32_t)(c / b_num_prims);
-                            candidate.bPrim = (uint32_t)(c % b_num_prims);
-                        }
-                    });
-            }
-            num_candidates += chunk_total;
-        }
-        if (num_candidates > cand_stride) {
-            mwhip::raiseError(S, mwhip::kErrTableOverflow);
-            continue;
-        }
-        wave::phaseFence();
-        PHYS_PROF(1);
-
-        // ---- the world's joints (table sorted by world just before) -----------
-        const TableHdr &joint_tbl = S->tables[ps->jointArchetype];
-        const int32_t joint_begin = joint_tbl.worldOffsets[world];
-        const int32_t num_joints = joint_tbl.worldCounts[world];
-        const JointConstraint *joints =
-            (const JointConstraint *)joint_tbl.columns[2] + joint_begin;
-
-        for (int32_t substep = 0; substep < params.numSubsteps; substep++) {
-            // ---- integrate ------------------------------------------------------
-            for (int32_t k = (int32_t)lane; k < num_bodies; k += 64) {
-                Loc loc = bodies.loc(k);
-                xpbd::substepRigidBodies(ctx,
-                    ctx.getDirect<base::Position>(RGDCols::Position, loc),
-                    ctx.getDirect<base::Rotation>(RGDCols::Rotation, loc),
-                    ctx.getDirect<Velocity>(RGDCols::Velocity, loc),
-                    ctx.getDirect<base::ObjectID>(RGDCols::ObjectID, loc),
-                    ctx.getDirect<ResponseType>(RGDCols::ResponseType, loc),
-                    ctx.getDirect<ExternalForce>(RGDCols::ExternalForce, loc),
-                    ctx.getDirect<ExternalTorque>(RGDCols::ExternalTorque, loc),
-                    ctx.getDirect<xpbd::SubstepPrevState>(
-                        xpbd::XPBDCols::SubstepPrevState, loc),
-                    ctx.getDirect<xpbd::PreSolvePositional>(
-                        xpbd::XPBDCols::PreSolvePositional, loc),
-                    ctx.getDirect<xpbd::PreSolveVelocity>(
-                        xpbd::XPBDCols::PreSolveVelocity, loc));
-            }
-            wave::phaseFence();
-            PHYS_PROF(2);
-
-            // ---- narrowphase: contacts in candidate order ------------------------
-            uint32_t num_contacts = 0;
-            for (uint32_t chunk = 0; chunk < num_candidates; chunk += 64) {
-                const uint32_t c = chunk + lane;
-                ContactConstraint contact;
-                bool has_contact = false;
-                bool too_big = false;
-                bool unsupported = false;
-
-                // per lane: order the pair, reject by world AABBs, classify
-                uint32_t kind = 0;      // 1: this lane alone, 2: whole wave
-                PairSetup pair;
-                if (c < num_candidates) {
-                    pair = setupPair(ctx, obj_mgr, candidates[c]);
-                    if (pair.aabbOverlap) {
-                        kind = pair.test == NarrowphaseTest::HullHull ? 2 : 1;
-                    }
-                }
-
-                // lanes on their own, in rounds of lanePolyRows scratch rows
-                uint64_t solo = __builtin_amdgcn_ballot_w64(kind == 1);
-                const uint32_t solo_rank = wave::rankInBallot(solo);
-                const uint32_t solo_count = (uint32_t)__builtin_popcountll(solo);
-                for (uint32_t first = 0; first < solo_count;
-                     first += lanePolyRows) {
-                    if (kind == 1 && solo_rank >= first &&
-                            solo_rank < first + lanePolyRows) {
-                        has_contact = collidePairLane(pair,
-                            scratch->lanePoly +
-                                (solo_rank - first) * lanePolyDwords,
-                            &contact, &too_big, &unsupported);
-                    }
-                }
-
-                // hull-hull pairs: one after the other, SAT loops over the lanes
-                uint64_t hull_pairs = __builtin_amdgcn_ballot_w64(kind == 2);
-                while (hull_pairs != 0) {
-                    const uint32_t src = (uint32_t)__builtin_ctzll(hull_pairs);
-                    hull_pairs &= hull_pairs - 1;
-
-                    PairSetup shared_pair =
-                        setupPair(ctx, obj_mgr, candidates[chunk + src]);
-                    ContactConstraint shared_contact;
-                    bool shared_too_big = false;
-                    bool found = hullHullWave(lane, shared_pair, &scratch->hull,
-                        &shared_contact, &shared_too_big);
-                    if (lane == src) {
-                        contact = shared_contact;
-                        has_contact = found;
-                        too_big = shared_too_big;
-                    }
-                }
-
-                // rare: polygons larger than the LDS scratch -> generic path
-                // with the hulls stored in the lane's private memory
-                if (too_big) {
-                    has_contact = collidePairStored(pair, tmp_vertices,
-                        tmp_faces, max_elems, &contact, &unsupported);
-                }
-                if (unsupported) {
-                    mwhip::raiseError(S, mwhip::kErrPhysics);
-                }
-
-                uint64_t mask = __builtin_amdgcn_ballot_w64(has_contact);
-                uint32_t dst = num_contacts + wave::rankInBallot(mask);
-                if (has_contact && dst < contact_stride) {
-                    contacts[dst] = contact;
-                }
-                num_contacts += (uint32_t)__builtin_popcountll(mask);
-            }
-            if (num_contacts > contact_stride) {
-                mwhip::raiseError(S, mwhip::kErrTableOverflow);
-                num_contacts = contact_stride;
-            }
-            wave::phaseFence();
-            PHYS_PROF(3);
-
-            // ---- position solve: contacts, then joints, level by level ----------
-            for (uint32_t base = 0; base < num_contacts; base += 64) {
-                const uint32_t n = num_contacts - base < 64 ?
-                    num_contacts - base : 64;
-                const uint32_t i = base + lane;
-                uint64_t key_a = 0, key_b = 0;
-                if (lane < n) {
-                    key_a = bodyKey(ctx, contacts[i].ref);
-                    key_b = bodyKey(ctx, contacts[i].alt);
-                }
-                uint32_t level = constraintLevels(lane, n, key_a, key_b);
-                uint32_t max_level = wave::maxReduce(lane < n ? level : 0);
-
-                for (uint32_t l = 0; l <= max_level; l++) {
-                    if (lane < n && level == l) {
-                        float lambda_n[4] { 0.f, 0.f, 0.f, 0.f };
-                        xpbd::handleContact(ctx, obj_mgr, contacts[i], lambda_n);
-                        lambdas[i] = lambda_n[0];
-                    }
-                    wave::phaseFence();
-                }
-            }
-
-            for (int32_t base = 0; base < num_joints; base += 64) {
-                const uint32_t n = num_joints - base < 64 ?
-                    (uint32_t)(num_joints - base) : 64u;
-                const int32_t i = base + (int32_t)lane;
-                uint64_t key_a = 0, key_b = 0;
-                if (lane < n) {
-                    key_a = bodyKey(ctx, ctx.loc(joints[i].e1));
-                    key_b = bodyKey(ctx, ctx.loc(joints[i].e2));
-                }
-                uint32_t level = constraintLevels(lane, n, key_a, key_b);
-                uint32_t max_level = wave::maxReduce(lane < n ? level : 0);
-
-                for (uint32_t l = 0; l <= max_level; l++) {
-                    if (lane < n && level == l) {
-                        xpbd::handleJointConstraint(ctx, obj_mgr, joints[i]);
-                    }
-                    wave::phaseFence();
-                }
-            }
-
-            PHYS_PROF(4);
-            // ---- velocities -----------------------------------------------------
-            for (int32_t k = (int32_t)lane; k < num_bodies; k += 64) {
-                Loc loc = bodies.loc(k);
-                xpbd::setVelocities(ctx,
-                    ctx.getDirect<base::Position>(RGDCols::Position, loc),
-                    ctx.getDirect<base::Rotation>(RGDCols::Rotation, loc),
-                    ctx.getDirect<xpbd::SubstepPrevState>(
-                        xpbd::XPBDCols::SubstepPrevState, loc),
-                    ctx.getDirect<Velocity>(RGDCols::Velocity, loc));
-            }
-            wave::phaseFence();
-            PHYS_PROF(5);
-
-            for (uint32_t base = 0; base < num_contacts; base += 64) {
-                const uint32_t n = num_contacts - base < 64 ?
-                    num_contacts - base : 64;
-                const uint32_t i = base + lane;
-                uint64_t key_a = 0, key_b = 0;
-                if (lane < n) {
-                    key_a = bodyKey(ctx, contacts[i].ref);
-                    key_b = bodyKey(ctx, contacts[i].alt);
-                }
-                uint32_t level = constraintLevels(lane, n, key_a, key_b);
-                uint32_t max_level = wave::maxReduce(lane < n ? level : 0);
-
-                for (uint32_t l = 0; l <= max_level; l++) {
-                    if (lane < n && level == l) {
-                        float lambda_n[4] { lambdas[i], 0.f, 0.f, 0.f };
-                        xpbd::solveVelocitiesForContact(ctx, obj_mgr,
-                            contacts[i], lambda_n, physics_sys.h,
-                            physics_sys.restitutionThreshold);
-                    }
-                    wave::phaseFence();
-                }
-            }
-            PHYS_PROF(6);
-        }
-    }
-
-#ifdef MADRONA_PHYS_PROFILE
-    if (lane == 0 && S->moduleData[1] != nullptr) {
-        unsigned long long *dst = (unsigned long long *)S->moduleData[1];
-        for (int i = 0; i < 8; i++) {
-            atomicAdd(&dst[i], prof_acc[i]);
-        }
-    }
-#endif
-}
-// ===========================================================================
-// The same step with the world resident in LDS.
-//
-// The generic kernel above is bound by dependent HBM/L2 round trips (each
-// constraint chases Loc -> column pointer -> row for both bodies; measured:
-// ~870 K cycles per world-step, > 95 % of them waiting).  A world's rigid-body
-// state is a few KB, so this variant loads it once (coalesced, all lanes), runs
-// candidates + every substep against LDS, and stores positions / velocities /
-// solver state back once.  HBM traffic per world-step: one read and one write
-// of the body columns; everything else stays on the CU.
-//
-// Candidate pairs come from the BVH without walking it: the traversal reports a
-// leaf iff the query box overlaps the leaf's slot box (ancestor boxes are
-// supersets), in an order that does not depend on the query
-// (BVH::traversalOrder), so lane a tests its box against the slot boxes in
-// that order.
-//
-// MAXB bounds bodies per world (LDS capacity); the host picks the instantiation
-// and worlds that exceed it raise kErrPhysics.
-// ===========================================================================
-// candidate pair of the LDS step: body indices inside the world
-// (4 bytes: MAXB <= 128 bodies, < 256 primitives per object)
-struct WaveCandidate {
-    uint8_t a;
-    uint8_t b;
-    uint8_t aPrim;
-    uint8_t bPrim;
-};
-
-// hull-hull scratch of a world's lane groups beyond the first (none when the
-// whole world works on one pair at a time)
-template <int N>
-struct ExtraHullScratch {
-    HullScratch group[N];
-    __device__ inline HullScratch *at(int i) { return &group[i]; }
-};
-template <>
-struct ExtraHullScratch<0> {
-    __device__ inline HullScratch *at(int) { return nullptr; }
-};
-
-template <int MAXB, int LPW = 64>
-struct WorldBlock {
-    static constexpr int maxBodies = MAXB;
-    // sized so that a 32-body block stays under 20 KB of LDS: eight
-    // single-wave workgroups per CU, two per SIMD -- what the register cap of
-    // the kernel admits.  Six candidates per body in LDS (a dense pile of n
-    // bodies has up to n (n - 1) / 2 pairs); more spill to HBM.
-    static constexpr int maxCandidates = MAXB * 6;
-    // (at least one per lane of the world: the narrowphase stages one contact
-    // per lane)
-    static constexpr int maxContacts =
-        MAXB + MAXB / 4 > LPW ? MAXB + MAXB / 4 : LPW;
-    static constexpr int maxJoints = 6;         // more: read from HBM
-    static constexpr int maxPrims = (int)PrimImage::maxPrims;   // more: hull data stays in HBM
-    static constexpr int arenaDwords = (int)PrimImage::arenaDwords;   // object-space hull meshes
-
-    // ---- the world image: what a step reads from the ECS tables -----------
-    // The first imageBytes of this struct are exactly what physicsPackKernel
-    // leaves per world in HBM (same layout), so that the step kernel starts
-    // with ONE coalesced copy instead of a dozen dependent round trips
-    // (row ranges -> column pointers -> body columns -> object metadata ->
-    // leaf -> parent node slot), exposed at two waves per SIMD.
-    math::Vector3 pos[MAXB];
-    math::Quat rot[MAXB];
-    math::Diag3x3 scale[MAXB];
-    Velocity vel[MAXB];
-    math::Vector3 extForce[MAXB];
-    math::Vector3 extTorque[MAXB];
-    xpbd::BodyConstants constants[MAXB];    // zeroed for static bodies
-    uint32_t resp[MAXB];
-    Loc bodyLoc[MAXB];                      // where the body's row is (store phase)
-    int32_t entityID[MAXB];
-    uint16_t primOffset[MAXB];
-    uint16_t primCount[MAXB];
-    uint16_t orderBody[MAXB];               // traversal rank -> body index
-    uint16_t leafOf[MAXB];                  // body -> BVH leaf (epilogue refit)
-
-    // broadphase boxes are dead once the candidates exist: the contacts of the
-    // substeps reuse their storage
-    static constexpr size_t boxBytes =
-        MAXB * (2 * sizeof(math::AABB) + sizeof(int32_t));
-    static constexpr size_t contactBytes =
-        maxContacts * sizeof(ContactConstraint);
-    alignas(16) char shared[boxBytes > contactBytes ? boxBytes : contactBytes];
-    // ---- end of the image (imageBytes below) ------------------------------
-
-    xpbd::SubstepPrevState prev[MAXB];
-    xpbd::PreSolvePositional prePos[MAXB];
-    xpbd::PreSolveVelocity preVel[MAXB];
-    uint16_t leafRank[MAXB];                // leaf id -> traversal rank
-    uint16_t solverKey[MAXB];               // ldsBodyKey: 0 = inert static body, else k + 1
-    WaveCandidate candidates[maxCandidates];
-    float lambdas[maxContacts];
-
-    JointConstraint joints[maxJoints];
-    uint16_t jointBodies[maxJoints][2];
-    PhysicsSystemState sys;
-    // the object manager's primitives (and as many hull meshes as fit) copied
-    // next to the CU; hull pointers inside `prims` are rebased onto `arena`
-    CollisionPrimitive prims[maxPrims];
-    math::AABB primAABBs[maxPrims];
-    const void *primMeshKey[maxPrims];      // HBM vertex array of each hull prim
-    alignas(16) uint32_t arena[arenaDwords];
-    WaveScratch scratch;
-    // Two worlds per wavefront: a world's 32 lanes run TWO hull-hull tests at a
-    // time, 16 lanes each (a cube pair has 6 + 6 faces, 8 + 8 vertices and 144
-    // edge pairs: the face queries, the hull transforms and the clipping, which
-    // every lane repeats, take the same instructions with 16 lanes as with 32).
-    static constexpr int hullLanes = LPW == 32 ? 16 : LPW;
-    static constexpr int hullGroups = LPW / hullLanes;
-    [[no_unique_address]] ExtraHullScratch<hullGroups - 1> extraHull;
-
-    // by body: the box a body queries the tree with; by traversal rank: the
-    // slot box the traversal tests and the entity id of that leaf's body
-    __device__ inline math::AABB *queryBox() { return (math::AABB *)shared; }
-    __device__ inline math::AABB *rankSlotBox()
-    {
-        return (math::AABB *)shared + MAXB;
-    }
-    __device__ inline int32_t *rankEntity()
-    {
-        return (int32_t *)((math::AABB *)shared + 2 * MAXB);
-    }
-    __device__ inline ContactConstraint *contacts()
-    {
-        return (ContactConstraint *)shared;
-    }
-
-    // bytes of the world image (a multiple of 16)
-    __host__ __device__ static constexpr size_t imageBytes()
-    {
-        return (__builtin_offsetof(WorldBlock, shared) + boxBytes + 15) &
-            ~(size_t)15;
-    }
-};
-
-// Copies `count` dwords with all lanes (of the world's group of LPW).
-template <int LPW = 64>
-__device__ inline void waveCopyDwords(uint32_t lane, uint32_t *dst,
-                                      const uint32_t *src, uint32_t count)
-{
-    // (batching eight loads ahead of the stores -- dst and src are generic
-    // pointers -- was measured: 744 -> 753 us, the counts are a few hundred
-    // dwords and the registers cost more than the L2 round trips)
-    for (uint32_t i = lane; i < count; i += LPW) {
-        dst[i] = src[i];
-    }
-}
-
-// ... from HBM (global loads, four rounds of the group in flight: the copies
-// of a primitive image are a few hundred dwords, one row of lanes at a time
-// they were a dozen L2 round trips in a row)
-template <int LPW = 64>
-__device__ inline void waveCopyDwordsGlobal(uint32_t lane, uint32_t *dst,
-                                            const uint32_t *src, uint32_t count)
-{
-    constexpr uint32_t batch = 4;
-    for (uint32_t first = lane; first < count; first += LPW * batch) {
-        uint32_t v[batch];
-#pragma unroll
-        for (uint32_t u = 0; u < batch; u++) {
-            const uint32_t i = first + u * LPW;
-            v[u] = mwhip::loadGlobal(src + (i < count ? i : first));
-        }
-#pragma unroll
-        for (uint32_t u = 0; u < batch; u++) {
-            const uint32_t i = first + u * LPW;
-            if (i < count) {
-                dst[i] = v[u];
-            }
-        }
-    }
-}
-
-// Stages primitives [0, num_prims) of the object manager in LDS.  Returns an
-// ObjectManager whose primitive arrays point at the copies (or the original
-// when they do not fit).
-template <int MAXB, int LPW>
-__device__ inline ObjectManager stagePrimitives(uint32_t lane,
-                                                WorldBlock<MAXB, LPW> *w,
-                                                const ObjectManager &obj_mgr,
-                                                uint32_t num_prims)
-{
-    using Block = WorldBlock<MAXB, LPW>;
-    if (num_prims > (uint32_t)Block::maxPrims) {
-        return obj_mgr;
-    }
-
-    // the loader's ready-made image covers these primitives: three coalesced
-    // copies and a pointer fix-up instead of the walk below
-    const PrimImage *image = obj_mgr.primImage;
-    if (image != nullptr) {
-        const uint32_t image_prims = mwhip::loadGlobal(&image->numPrims);
-        const uint32_t arena_used = mwhip::loadGlobal(&image->arenaUsed);
-        if (image_prims >= num_prims && image_prims != 0) {
-            // (the mesh offsets with the first batch of the copies)
-            int32_t offsets[4] = { -1, -1, -1, -1 };
-            if (lane < image_prims) {
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    offsets[i] = mwhip::loadGlobal(&image->meshOffset[lane][i]);
-                }
-            }
-            waveCopyDwordsGlobal<LPW>(lane, (uint32_t *)w->prims,
-                (const uint32_t *)image->prims,
-                image_prims * (uint32_t)(sizeof(CollisionPrimitive) / 4));
-            waveCopyDwordsGlobal<LPW>(lane, (uint32_t *)w->primAABBs,
-                (const uint32_t *)image->primAABBs,
-                image_prims * (uint32_t)(sizeof(math::AABB) / 4));
-            waveCopyDwordsGlobal<LPW>(lane, w->arena, image->arena, arena_used);
-            wave::phaseFence();
-            if (lane < image_prims && offsets[0] >= 0) {
-                geo::HalfEdgeMesh &staged = w->prims[lane].hull.halfEdgeMesh;
-                staged.facePlanes = (geo::Plane *)(w->arena + offsets[0]);
-                staged.halfEdges = (geo::HalfEdge *)(w->arena + offsets[1]);
-                staged.vertices = (math::Vector3 *)(w->arena + offsets[2]);
-                staged.faceBaseHalfEdges = w->arena + offsets[3];
-            }
-            wave::phaseFence();
-
-            ObjectManager staged = obj_mgr;
-            staged.collisionPrimitives = w->prims;
-            staged.primitiveAABBs = w->primAABBs;
-            return staged;
-        }
-    }
-
-    waveCopyDwords<LPW>(lane, (uint32_t *)w->prims,
-        (const uint32_t *)obj_mgr.collisionPrimitives,
-        num_prims * (uint32_t)(sizeof(CollisionPrimitive) / 4));
-    waveCopyDwords<LPW>(lane, (uint32_t *)w->primAABBs,
-        (const uint32_t *)obj_mgr.primitiveAABBs,
-        num_prims * (uint32_t)(sizeof(math::AABB) / 4));
-    wave::phaseFence();
-    if (lane < num_prims) {
-        w->primMeshKey[lane] =
-            w->prims[lane].type == CollisionPrimitive::Type::Hull ?
-                (const void *)w->prims[lane].hull.halfEdgeMesh.vertices :
-                nullptr;
-    }
-    wave::phaseFence();
-
-    // every lane walks the (short) primitive list; meshes shared by several
-    // primitives are staged once
-    uint32_t arena_used = 0;
-    for (uint32_t p = 0; p < num_prims; p++) {
-        if (w->prims[p].type != CollisionPrimitive::Type::Hull) {
-            continue;
-        }
-
-        // still the HBM pointers: a primitive is only patched in its own turn
-        const geo::HalfEdgeMesh src = w->prims[p].hull.halfEdgeMesh;
-
-        bool shared = false;
-        for (uint32_t q = 0; q < p; q++) {
-            if (w->primMeshKey[q] == (const void *)src.vertices) {
-                if (lane == 0) {
-                    w->prims[p].hull.halfEdgeMesh =
-                        w->prims[q].hull.halfEdgeMesh;
-                }
-                shared = true;
-                break;
-            }
-        }
-        if (shared) {
-            wave::phaseFence();
-            continue;
-        }
-
-        const uint32_t hedge_dw = src.numHalfEdges * 3;
-        const uint32_t base_dw = src.numFaces;
-        const uint32_t plane_dw = src.numFaces * 4;
-        const uint32_t vert_dw = src.numVertices * 3;
-        const uint32_t need = hedge_dw + base_dw + plane_dw + vert_dw;
-        if (arena_used + need > (uint32_t)Block::arenaDwords) {
-            continue;       // stays in HBM
-        }
-
-        uint32_t *dst = w->arena + arena_used;
-        waveCopyDwords<LPW>(lane, dst, (const uint32_t *)src.facePlanes, plane_dw);
-        waveCopyDwords<LPW>(lane, dst + plane_dw,
-                       (const uint32_t *)src.halfEdges, hedge_dw);
-        waveCopyDwords<LPW>(lane, dst + plane_dw + hedge_dw,
-                       (const uint32_t *)src.vertices, vert_dw);
-        waveCopyDwords<LPW>(lane, dst + plane_dw + hedge_dw + vert_dw,
-                       src.faceBaseHalfEdges, base_dw);
-        if (lane == 0) {
-            geo::HalfEdgeMesh &staged = w->prims[p].hull.halfEdgeMesh;
-            staged.facePlanes = (geo::Plane *)dst;
-            staged.halfEdges = (geo::HalfEdge *)(dst + plane_dw);
-            staged.vertices = (math::Vector3 *)(dst + plane_dw + hedge_dw);
-            staged.faceBaseHalfEdges = dst + plane_dw + hedge_dw + vert_dw;
-        }
-        arena_used += need;
-        wave::phaseFence();
-    }
-    wave::phaseFence();
-
-    ObjectManager staged = obj_mgr;
-    staged.collisionPrimitives = w->prims;
-    staged.primitiveAABBs = w->primAABBs;
-    return staged;
-}
-
-template <int MAXB, int LPW = 64>
-struct LdsBodyStore {
-    WorldBlock<MAXB, LPW> *w;
-
-    __device__ inline math::Vector3 &position(Loc l) { return w->pos[l.row]; }
-    __device__ inline math::Quat &rotation(Loc l) { return w->rot[l.row]; }
-    __device__ inline Velocity &velocity(Loc l) { return w->vel[l.row]; }
-    __device__ inline xpbd::SubstepPrevState prevState(Loc l)
-    {
-        return w->prev[l.row];
-    }
-    __device__ inline xpbd::PreSolvePositional presolvePositional(Loc l)
-    {
-        return w->prePos[l.row];
-    }
-    __device__ inline xpbd::PreSolveVelocity presolveVelocity(Loc l)
-    {
-        return w->preVel[l.row];
-    }
-    __device__ inline xpbd::BodyConstants constants(Loc l)
-    {
-        return w->constants[l.row];
-    }
-};
-
-// Key of body k for the dependency levels of the solver: 0 = a static body the
-// solver cannot change (never orders constraints), else k + 1.  Whether a
-// static body is inert is decided ONCE per step, when the world is loaded
-// (solverKey): an inert one stays inert (the solver's writes to it are no-ops),
-// and one that is not is treated as dynamic for the whole step -- conservative,
-// so still the sequential result -- instead of normalising its rotation again
-// for every contact of every solve (round 3: twice per contact and substep).
-template <int MAXB, int LPW>
-__device__ inline uint32_t ldsBodyKey(const WorldBlock<MAXB, LPW> *w, int32_t k)
-{
-    return (uint32_t)w->solverKey[k];
-}
-
-template <int MAXB, int LPW>
-__device__ inline PairSetup ldsSetupPair(const WorldBlock<MAXB, LPW> *w,
-                                         const ObjectManager &obj_mgr,
-                                         const WaveCandidate &candidate)
-{
-    const int32_t ka = candidate.a;
-    const int32_t kb = candidate.b;
-
-    return setupPair(obj_mgr, Loc { 0, ka }, Loc { 0, kb },
-        (uint32_t)w->primOffset[ka] + candidate.aPrim,
-        (uint32_t)w->primOffset[kb] + candidate.bPrim,
-        PrimitiveTransform { w->pos[ka], w->rot[ka], w->scale[ka] },
-        PrimitiveTransform { w->pos[kb], w->rot[kb], w->scale[kb] });
-}
-
-// ---------------------------------------------------------------------------
-// Loading a world through the frame (PhysicsFrame, physics.inl): five rounds
-// of loads (rounds 1-3 walked the tables from every wavefront: twenty).
-// Every round is issued in one go -- nothing is written, and nothing loaded is
-// looked at, before the loads of the round are on their way:
-//   1  (caller) the world's place in the order; the frame itself is hot
-//   2  row ranges in every rigid-body table, the tree's arrays, the object
-//      manager, the joint range, the solver parameters
-//   3  (frame: L2 hits) the columns of this lane's body; the traversal order
-//   4  the body's row in every column; the world's joints
-//   5  what the row names: object metadata, primitive range, leaf box, leaf
-//      parent; the entity slots of the joints' bodies
-//   6  the leaf's slot box in its parent node
-// ---------------------------------------------------------------------------
-struct FramedWorld {
-    // numBodies < 0: not stepped by this kernel -- unsteppable: tables await
-    // their sort or the tree does not match them (kErrPhysics); tooManyBodies:
-    // more than the instantiation's MAXB (the HBM kernel takes the world)
-    static constexpr int32_t unsteppable = -1;
-    static constexpr int32_t tooManyBodies = -2;
-    int32_t numBodies;
-    int32_t jointBegin;
-    int32_t numJoints;
-    bool jointsStaged;
-    const ObjectManager *objMgr;    // the world's manager (HBM)
-};
-
-__device__ inline void fillPhysicsFrame(EcsState *S, const PhysicsScratch *ps,
-                                        PhysicsFrame *F, uint32_t tid,
-                                        uint32_t num_threads)
-{
-    StateManager *state_mgr = static_cast<StateManager *>(S);
-    const uint32_t num_arch = ps->numBodyArchetypes;
-    for (uint32_t i = tid; i < num_arch * PhysicsFrame::numColumns;
-         i += num_threads) {
-        const uint32_t a = i / PhysicsFrame::numColumns;
-        const uint32_t c = i % PhysicsFrame::numColumns;
-        const TableHdr &tbl = S->tables[ps->bodyArchetypes[a]];
-        F->columns[a][c] = (int32_t)c < tbl.numColumns ? tbl.columns[c] : nullptr;
-    }
-    if (tid < PhysicsFrame::maxArchetypes) {
-        // (entries behind the last archetype repeat the first: the step kernel
-        // reads all of them without a branch and ignores what it got)
-        const uint32_t id = ps->bodyArchetypes[tid < num_arch ? tid : 0u];
-        const TableHdr &tbl = S->tables[id];
-        F->archetype[tid] = id;
-        F->worldOffsets[tid] = tbl.worldOffsets;
-        F->worldCounts[tid] = tbl.worldCounts;
-    }
-    // what a replay can change: whether a table awaits its sort, and where the
-    // joint rows are (the sort in front of this kernel swaps its buffers)
-    if (tid == 1) {
-        uint32_t unsorted = 0;
-        for (uint32_t a = 0; a < num_arch; a++) {
-            unsorted |= S->tables[ps->bodyArchetypes[a]].needsSort;
-        }
-        F->unsorted = unsorted;
-        F->numArchetypes = num_arch;
-    }
-    // (the frame's column slots cover the body archetypes' Entity, WorldID,
-    // RigidBody bundle and XPBD solver state, and the joint table's constraint
-    // is its first component column)
-    static_assert(PhysicsFrame::numColumns ==
-                  (uint32_t)xpbd::XPBDCols::PreSolveVelocity + 1u);
-    static_assert(RGDCols::JointConstraint == 2);
-    if (tid == 2) {
-        F->joints = (const JointConstraint *)
-            S->tables[ps->jointArchetype].columns[RGDCols::JointConstraint];
-    }
-    // the singleton columns, the tables' world ranges, the entity store, the
-    // object manager: a chain of six dependent loads by one thread, behind the
-    // cost scan of the other wavefronts.  Followed on EVERY launch (round 4
-    // kept the first replay's answers: stale if a simulator ever swaps its
-    // object manager's arrays or the store moves).
-    if (tid == 0) {
-        F->systemStates = state_mgr->getSingletonColumn<PhysicsSystemState>();
-        F->objectData = state_mgr->getSingletonColumn<ObjectData>();
-        const ObjectManager *mgr = F->objectData[0].mgr;
-        F->objMgr = mgr;
-        F->objMgrCopy = *mgr;
-        const TableHdr &joint_tbl = S->tables[ps->jointArchetype];
-        F->jointOffsets = joint_tbl.worldOffsets;
-        F->jointCounts = joint_tbl.worldCounts;
-        F->entities = mwhip::entitiesOf(S);
-        F->trees = state_mgr->getSingletonColumn<broadphase::BVH>();
-    }
-}
-
-// nothing moves across: what was issued before stays before, what uses it after
-__device__ __attribute__((always_inline)) inline void roundIssued()
-{
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-template <int MAXB, int LPW>
-__device__ __attribute__((always_inline)) inline FramedWorld loadWorldFramed(
-    uint32_t lane, WorldBlock<MAXB, LPW> *w, const PhysicsFrame *F, int32_t world)
-{
-    using Block = WorldBlock<MAXB, LPW>;
-    using mwhip::loadGlobal;
-    using mwhip::loadInvariant;
-    constexpr uint32_t max_arch = PhysicsFrame::maxArchetypes;
-    constexpr int32_t chunks = (MAXB + LPW - 1) / LPW;
-    FramedWorld out {};
-
-    // ---- round 2 (the frame's own words: scalar loads, hot) ---------------------
-    const uint32_t num_arch = loadInvariant(&F->numArchetypes);
-    const uint32_t tables_unsorted = loadInvariant(&F->unsorted);
-    // (roundIssued(): the loads of a round are all on their way before the first
-    // of them is looked at.  Left to itself the scheduler -- the kernel is at its
-    // register limit -- pairs every load with its use: eight row counts became
-    // eight round trips one after the other.)
-    int32_t row_base[max_arch];
-    int32_t rows[max_arch];
-#pragma unroll
-    for (uint32_t a = 0; a < max_arch; a++) {
-        row_base[a] = loadGlobal(loadInvariant(&F->worldOffsets[a]) + world);
-        rows[a] = loadGlobal(loadInvariant(&F->worldCounts[a]) + world);
-    }
-    const broadphase::BVH::StepView tree =
-        broadphase::BVH::loadStepView(loadInvariant(&F->trees) + world);
-    const ObjectManager *world_mgr =
-        loadGlobal(&(loadInvariant(&F->objectData) + world)->mgr);
-    const int32_t joint_begin = loadGlobal(loadInvariant(&F->jointOffsets) + world);
-    const int32_t num_joints = loadGlobal(loadInvariant(&F->jointCounts) + world);
-    const PhysicsSystemState sys_regs =
-        loadGlobal(loadInvariant(&F->systemStates) + world);
-    roundIssued();
-
-    int32_t body_base[max_arch + 1];
-    body_base[0] = 0;
-#pragma unroll
-    for (uint32_t a = 0; a < max_arch; a++) {
-        rows[a] = a < num_arch ? rows[a] : 0;
-        body_base[a + 1] = body_base[a] + rows[a];
-    }
-    const int32_t num_bodies = body_base[max_arch];
-    out.numBodies = num_bodies;
-    out.jointBegin = joint_begin;
-    out.numJoints = num_joints;
-    out.jointsStaged = num_joints <= Block::maxJoints;
-    out.objMgr = world_mgr;
-    if (tables_unsorted != 0u || tree.numLeaves != num_bodies) {
-        out.numBodies = FramedWorld::unsteppable;
-        return out;
-    }
-    if (num_bodies > MAXB) {
-        out.numBodies = FramedWorld::tooManyBodies;
-        return out;
-    }
-    if (lane == 0) {
-        w->sys = sys_regs;
-    }
-    if (num_bodies == 0) {
-        wave::phaseFence();
-        return out;
-    }
-    // (the manager's arrays: the frame's copy unless this world has its own)
-    const RigidBodyMetadata *metadata = loadInvariant(&F->objMgrCopy.metadata);
-    const uint32_t *prim_offsets =
-        loadInvariant(&F->objMgrCopy.rigidBodyPrimitiveOffsets);
-    const uint32_t *prim_counts =
-        loadInvariant(&F->objMgrCopy.rigidBodyPrimitiveCounts);
-    if (world_mgr != loadInvariant(&F->objMgr)) {
-        metadata = loadGlobal(&world_mgr->metadata);
-        prim_offsets = loadGlobal(&world_mgr->rigidBodyPrimitiveOffsets);
-        prim_counts = loadGlobal(&world_mgr->rigidBodyPrimitiveCounts);
-    }
-
-    // (the world's joints, when they fit the block: their rows go out first,
-    // the entity slots of their bodies with round 5 of the first chunk)
-    const bool my_joint = out.jointsStaged && (int32_t)lane < num_joints;
-    JointConstraint joint {};
-    mwhip::EntitySlot joint_slots[2] {};
-    if (my_joint) {
-        joint = loadGlobal(loadInvariant(&F->joints) + joint_begin + (int32_t)lane);
-    }
-
-    // (the traversal order of every chunk first: a body's rank in it is written
-    // by whichever lane holds that position of the order)
-    int32_t order_leaf[chunks];
-#pragma unroll
-    for (int32_t c = 0; c < chunks; c++) {
-        const int32_t k = c * LPW + (int32_t)lane;
-        order_leaf[c] = loadGlobal(tree.traversalOrder + (k < num_bodies ? k : 0));
-    }
-
-    // Lanes without a body load the world's first body again (no branches
-    // around the loads: a round stays one batch) and write nothing.
-#pragma unroll
-    for (int32_t c = 0; c < chunks; c++) {
-        const int32_t k = c * LPW + (int32_t)lane;
-        const bool active = k < num_bodies;
-        const int32_t kc = active ? k : 0;
-
-        // ---- round 3: where the body's rows are (frame: L2 hits) ------------------
-        uint32_t slot = 0;
-        int32_t row = row_base[0] + kc;
-#pragma unroll
-        for (uint32_t a = 1; a < max_arch; a++) {
-            if (kc >= body_base[a] && rows[a] != 0) {
-                slot = a;
-                row = row_base[a] + (kc - body_base[a]);
-            }
-        }
-        void *const *col = F->columns[slot];
-        const uint32_t archetype = loadGlobal(&F->archetype[slot]);
-        const Entity *col_entity = (const Entity *)loadGlobal(&col[0]);
-        const base::Position *col_pos =
-            (const base::Position *)loadGlobal(&col[RGDCols::Position]);
-        const base::Rotation *col_rot =
-            (const base::Rotation *)loadGlobal(&col[RGDCols::Rotation]);
-        const base::Scale *col_scale =
-            (const base::Scale *)loadGlobal(&col[RGDCols::Scale]);
-        const base::ObjectID *col_obj =
-            (const base::ObjectID *)loadGlobal(&col[RGDCols::ObjectID]);
-        const ResponseType *col_resp =
-            (const ResponseType *)loadGlobal(&col[RGDCols::ResponseType]);
-        const broadphase::LeafID *col_leaf =
-            (const broadphase::LeafID *)loadGlobal(&col[RGDCols::LeafID]);
-        const Velocity *col_vel =
-            (const Velocity *)loadGlobal(&col[RGDCols::Velocity]);
-        const ExternalForce *col_force =
-            (const ExternalForce *)loadGlobal(&col[RGDCols::ExternalForce]);
-        const ExternalTorque *col_torque =
-            (const ExternalTorque *)loadGlobal(&col[RGDCols::ExternalTorque]);
-        roundIssued();
-
-        // ---- round 4: the rows ---------------------------------------------------------
-        const base::Position pos = loadGlobal(col_pos + row);
-        const base::Rotation rot = loadGlobal(col_rot + row);
-        const base::Scale scale = loadGlobal(col_scale + row);
-        const Velocity vel = loadGlobal(col_vel + row);
-        const ExternalForce force = loadGlobal(col_force + row);
-        const ExternalTorque torque = loadGlobal(col_torque + row);
-        const ResponseType resp = loadGlobal(col_resp + row);
-        const Entity entity = loadGlobal(col_entity + row);
-        const base::ObjectID obj_id = loadGlobal(col_obj + row);
-        const int32_t leaf = loadGlobal(col_leaf + row).id;
-        roundIssued();
-
-        // ---- round 5: what the row names ----------------------------------------------
-        const RigidBodyMetadata body_metadata = loadGlobal(metadata + obj_id.idx);
-        const uint32_t prim_offset = loadGlobal(prim_offsets + obj_id.idx);
-        const uint32_t prim_count = loadGlobal(prim_counts + obj_id.idx);
-        const math::AABB query_box = loadGlobal(tree.leafAABBs + leaf);
-        const uint32_t parent = loadGlobal(tree.leafParents + leaf);
-        if (c == 0 && my_joint) {
-            // (StateManager::getLoc reads the slot of any non-negative id)
-            const mwhip::EntitySlot *entities = loadInvariant(&F->entities);
-            joint_slots[0] = loadGlobal(entities + (joint.e1.id >= 0 ? joint.e1.id : 0));
-            joint_slots[1] = loadGlobal(entities + (joint.e2.id >= 0 ? joint.e2.id : 0));
-        }
-        roundIssued();
-
-        // ---- round 6 -------------------------------------------------------------------
-        const math::AABB slot_box =
-            broadphase::BVH::loadSlotBounds(tree.nodes, parent);
-        roundIssued();
-
-        // ---- into the block (writeBodyRow) ---------------------------------------------
-        if (c == 0) {
-#pragma unroll
-            for (int32_t r = 0; r < chunks; r++) {
-                if (r * LPW + (int32_t)lane < num_bodies) {
-                    w->leafRank[order_leaf[r]] = (uint16_t)(r * LPW + (int32_t)lane);
-                }
-            }
-            wave::phaseFence();
-        }
-        if (active) {
-            const uint32_t rank = w->leafRank[leaf];
-            w->bodyLoc[k] = Loc { archetype, row };
-            w->pos[k] = pos;
-            w->rot[k] = rot;
-            w->scale[k] = scale;
-            w->vel[k] = vel;
-            w->extForce[k] = force;
-            w->extTorque[k] = torque;
-            w->resp[k] = (uint32_t)resp;
-            w->entityID[k] = entity.id;
-            w->constants[k] = xpbd::bodyConstants(body_metadata, resp);
-            w->primOffset[k] = (uint16_t)prim_offset;
-            w->primCount[k] = (uint16_t)prim_count;
-            w->queryBox()[k] = query_box;
-            w->rankSlotBox()[rank] = slot_box;
-            w->rankEntity()[rank] = entity.id;
-            w->orderBody[rank] = (uint16_t)k;
-            w->leafOf[k] = (uint16_t)leaf;
-        }
-    }
-    wave::phaseFence();
-
-    // ---- the world's joints (when they fit the block) -------------------------------
-    if (out.jointsStaged) {
-        if (my_joint) {
-            const Entity ends[2] = { joint.e1, joint.e2 };
-            uint16_t index[2] = { 0, 0 };
-#pragma unroll
-            for (int32_t e = 0; e < 2; e++) {
-                // (StateManager::getLoc: a stale or empty handle is nowhere)
-                Loc loc = Loc::none();
-                if (ends[e].id >= 0 && joint_slots[e].gen == ends[e].gen) {
-                    loc = Loc { joint_slots[e].loc.archetype, joint_slots[e].loc.row };
-                }
-                // body index of the end point: its row among the staged bodies
-                // (no match: body 0, like the table walk)
-                for (int32_t k = 0; k < num_bodies; k++) {
-                    const Loc at = w->bodyLoc[k];
-                    if (at.archetype == loc.archetype && at.row == loc.row) {
-                        index[e] = (uint16_t)k;
-                        break;
-                    }
-                }
-            }
-            w->joints[lane] = joint;
-            w->jointBodies[lane][0] = index[0];
-            w->jointBodies[lane][1] = index[1];
-        }
-        wave::phaseFence();
-    }
-    return out;
-}
-
-// Two waves per SIMD: PMC shows the step parked on s_waitcnt 45 % of its wave
-// cycles at one wave per SIMD (SQ_WAIT_ANY / SQ_WAVE_CYCLES); capping the
-// kernel at 256 registers costs spills but lets a second world fill those
-// gaps (measured 1140 -> 868 us per step at 8192 worlds).
-#ifndef MADRONA_PHYS_LDS_WAVES_PER_EU
-#define MADRONA_PHYS_LDS_WAVES_PER_EU 2
-#endif
-// (two worlds per wavefront: one wavefront per SIMD with the whole register
-// file -- a pair of world blocks is 37.8 KB of LDS, four per CU; 2 = the
-// register cap a second wavefront per SIMD would need, measured by itself in
-// profiles/r04_phys_variants.jsonl)
-#ifndef MADRONA_PHYS_LDS32_WAVES_PER_EU
-#define MADRONA_PHYS_LDS32_WAVES_PER_EU 1
-#endif
-//
-// LPW = lanes per world.  64: one world per wavefront.  32: TWO worlds per
-// wavefront, one per half (MAXB <= 32): a 28-body world with ~14 contacts and
-// ~40 candidates keeps 45 % of 64 lanes busy, and the kernel is bound by
-// instruction issue -- the same instruction stream then advances two worlds.
-// Every wave-level primitive works on the world's group of LPW lanes
-// (wave::groupBallot, shuffles of width LPW); loop trip counts, early exits and
-// the level loops of the solver are per group, the halves diverge where their
-// worlds differ.  Two 32-body blocks are 35 KB of LDS: four wavefronts per CU,
-// one per SIMD, with the whole register file (512) to themselves.
-#ifdef MADRONA_PHYS_LDS_NUM_VGPR
-// (measurement builds: a register cap without the occupancy to go with it --
-// the compiler ignores amdgpu_waves_per_eu above what the LDS block admits)
-#define MADRONA_PHYS_VGPR_CAP __attribute__((amdgpu_num_vgpr(MADRONA_PHYS_LDS_NUM_VGPR)))
-#else
-#define MADRONA_PHYS_VGPR_CAP
-#endif
-template <int MAXB, int LPW = 64>
-__global__ void __launch_bounds__(64) MADRONA_PHYS_VGPR_CAP
-__attribute__((amdgpu_waves_per_eu(
-    MAXB <= 64 && LPW == 64 ? MADRONA_PHYS_LDS_WAVES_PER_EU :
-    LPW == 32 ? MADRONA_PHYS_LDS32_WAVES_PER_EU : 1)))
-physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
-{
-    mwhip::TraceScope trace_scope(S);
-    using Block = WorldBlock<MAXB, LPW>;
-    static_assert(LPW == 64 || (LPW == 32 && MAXB <= 32));
-    constexpr int worlds_per_wave = 64 / LPW;
-
-    StateManager *state_mgr = static_cast<StateManager *>(S);
-    PhysicsScratch *ps = detail::scratch(S);
-    const PhysicsStepParams params = *(const PhysicsStepParams *)node_data;
-
-    // lane = index inside the world's group of LPW lanes
-    const uint32_t lane = wave::laneID() & (uint32_t)(LPW - 1);
-    const int32_t group = (int32_t)(wave::laneID() / (uint32_t)LPW);
-    const int32_t num_worlds = S->numWorlds;
-
-    __shared__ Block blocks[worlds_per_wave];
-    Block *w = &blocks[group];
-    LdsBodyStore<MAXB, LPW> store { w };
-
-#ifdef MADRONA_PHYS_PROFILE
-    unsigned long long prof_t = __builtin_readcyclecounter();
-    unsigned long long prof_acc[32] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
-                                        0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-    // stages of the cooperative hull-hull tests: slots 16.. (HullHullProf)
-#ifdef MADRONA_PHYS_PROFILE_HH
-#define PHYS_HH_PROF() HullHullProf { prof_acc, \
-        (unsigned long long)__builtin_readcyclecounter() }
-#else
-#define PHYS_HH_PROF() HullHullProf {}
-#endif
-#else
-#define PHYS_HH_PROF() HullHullProf {}
-#endif
-
-    // Worlds are taken in the order physicsOrderKernel left: the ones that took
-    // longest last step first, so that the launch does not end on a few heavy
-    // worlds with most of the chip idle; the two worlds of a wavefront (LPW =
-    // 32) are neighbours in that order and cost about the same.  One workgroup
-    // per job (a world, or a pair of them): the hardware's dispatcher hands the
-    // next job to a free slot within a microsecond.  (Measured and removed in
-    // round 5, numbers in profiles/r04_phys_variants.jsonl and DESIGN.md: the
-    // k-th heaviest paired with the k-th lightest, + 20 us; persistent
-    // wavefronts taking jobs from a counter with the next world's header
-    // fetched ahead, +- 0; world images packed by a kernel of their own,
-    // + 21 us net; the leaf refit folded into the epilogue, + 6 us net; the
-    // order blended over several steps, +- 0.)
-    const int32_t *world_order = params.worldOrder;
-    const int32_t num_jobs = (num_worlds + worlds_per_wave - 1) / worlds_per_wave;
-
-    // (the scratch block's words never change: invariant loads at the top of
-    // the kernel, not two dependent round trips in front of the candidate pass)
-    const uint32_t candidates_per_world =
-        mwhip::loadInvariant(&ps->candidatesPerWorld);
-    CandidateCollision *const world_candidates =
-        mwhip::loadInvariant(&ps->worldCandidates);
-
-    // the frame: where every world's rows are, resolved once per launch by
-    // physicsOrderKernel (fillPhysicsFrame)
-    const PhysicsFrame *frame = &((const PhysicsStepNode *)node_data)->frame;
-
-    // A world this instantiation cannot hold -- more than MAXB bodies, more
-    // contacts in a substep than the block has room for -- is left untouched
-    // (nothing of it has been stored yet) and handed to the kernel that works
-    // out of HBM, which runs right behind this one over the worlds listed here
-    // (physicsStepKernel, fallback mode; reference: no cap, its tables grow).
-    int32_t *const fallback_list = params.fallbackList;
-    const uint32_t contact_cap = params.contactCap != 0u &&
-        params.contactCap < (uint32_t)Block::maxContacts ?
-            params.contactCap : (uint32_t)Block::maxContacts;
-    auto toFallback = [&](int32_t world) {
-        if (lane == 0) {
-            const int32_t at = __hip_atomic_fetch_add(fallback_list, 1,
-                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            fallback_list[1 + at] = world;
-        }
-    };
-
-    for (int32_t job = (int32_t)blockIdx.x; job < num_jobs;
-         job += (int32_t)gridDim.x) {
-    do {
-        const int32_t order_slot = job * worlds_per_wave + group;
-        if (order_slot >= num_worlds) {
-            continue;       // (odd world count: this half has no world)
-        }
-        const int32_t world = world_order[order_slot];
-        const long long cost_t0 = (long long)wall_clock64();
-        uint32_t cost_work = 1;    // (what the world asked of the wavefront, roughly)
-        Context ctx = TaskGraph::makeContext<Context>(
-            state_mgr, WorldID { world }, true);
-
-        // ---- the world through the frame: HBM -> LDS in five rounds ---------
-        const FramedWorld framed = loadWorldFramed<MAXB, LPW>(lane, w, frame, world);
-        if (framed.numBodies < 0) {
-            if (framed.numBodies == FramedWorld::tooManyBodies) {
-                toFallback(world);
-            } else {
-                mwhip::raiseError(S, mwhip::kErrPhysics);
-            }
-            continue;
-        }
-        const int32_t num_bodies = framed.numBodies;
-        const ObjectManager *hbm_mgr = framed.objMgr == frame->objMgr ?
-            &frame->objMgrCopy : framed.objMgr;
-        PHYS_PROF(8);
-        const ObjectManager &hbm_obj_mgr = *hbm_mgr;
-
-        // primitives referenced by this world's bodies
-        uint32_t prim_end = 0;
-        for (int32_t k = (int32_t)lane; k < num_bodies; k += LPW) {
-            uint32_t end = (uint32_t)w->primOffset[k] + w->primCount[k];
-            prim_end = end > prim_end ? end : prim_end;
-            w->solverKey[k] =
-                (w->resp[k] == (uint32_t)ResponseType::Static &&
-                 staticBodyIsInert(w->rot[k])) ? (uint16_t)0 : (uint16_t)(k + 1);
-        }
-        prim_end = wave::maxReduce<LPW>(prim_end);
-        const ObjectManager obj_mgr =
-            stagePrimitives<MAXB, LPW>(lane, w, hbm_obj_mgr, prim_end);
-        PHYS_PROF(9);
-
-        // ---- broadphase: candidate pairs in (body, traversal) order -----------
-        // lane = body; one pass over the slot boxes in traversal order leaves a
-        // bit mask of hits, the pairs are written from the mask.  Slot boxes
-        // only grow between rebuilds, so a long-lived world with mobile bodies
-        // collects many more candidates than contacts: what does not fit the
-        // LDS list spills into the world's segment of the HBM candidate
-        // scratch (4-byte records).
-        WaveCandidate *spilled_candidates = (WaveCandidate *)(
-            world_candidates + (size_t)world * candidates_per_world);
-        const uint32_t candidate_capacity = (uint32_t)Block::maxCandidates +
-            candidates_per_world *
-                (uint32_t)(sizeof(CandidateCollision) / sizeof(WaveCandidate));
-        uint32_t num_candidates = 0;
-        for (int32_t chunk = 0; chunk < num_bodies; chunk += LPW) {
-            const int32_t k = chunk + (int32_t)lane;
-            const bool active = k < num_bodies;
-
-            constexpr int mask_words = (MAXB + 63) / 64;
-            uint64_t hits[mask_words];
-#pragma unroll
-            for (int m = 0; m < mask_words; m++) {
-                hits[m] = 0;
-            }
-
-            uint32_t n = 0;
-            if (active) {
-                const math::AABB query = w->queryBox()[k];
-                const int32_t my_id = w->entityID[k];
-                const bool my_static =
-                    w->resp[k] == (uint32_t)ResponseType::Static;
-                const uint32_t a_prims = w->primCount[k];
-
-#pragma unroll
-                for (int m = 0; m < mask_words; m++) {
-                    const int32_t r_end = num_bodies - m * 64 < 64 ?
-                        num_bodies - m * 64 : 64;
-                    // the box tests first, four at a time: the four slot boxes
-                    // and entity ids are read out of LDS into registers before
-                    // the first comparison (broadcast reads: every lane of the
-                    // world asks for the same ones), and a test is twelve
-                    // comparisons AND-ed as integers.  (AABB::overlaps is a
-                    // chain of &&: the compiler made it three dependent LDS
-                    // round trips and two branches per box -- the later
-                    // coordinates were only read if the earlier ones overlapped.)
-                    uint64_t raw = 0;
-                    for (int32_t j = 0; j < r_end; j += 4) {
-                        float box[4][6];
-                        int32_t other_id[4];
-#pragma unroll
-                        for (int32_t u = 0; u < 4; u++) {
-                            // (past the world's last body: its last one again)
-                            const int32_t r = m * 64 +
-                                (j + u < r_end ? j + u : r_end - 1);
-                            const math::AABB slot = w->rankSlotBox()[r];
-                            box[u][0] = slot.pMin.x;
-                            box[u][1] = slot.pMin.y;
-                            box[u][2] = slot.pMin.z;
-                            box[u][3] = slot.pMax.x;
-                            box[u][4] = slot.pMax.y;
-                            box[u][5] = slot.pMax.z;
-                            other_id[u] = w->rankEntity()[r];
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int32_t u = 0; u < 4; u++) {
-                            // == query.overlaps(slot) && my_id < other_id
-                            const uint32_t hit =
-                                (uint32_t)(query.pMin.x < box[u][3]) &
-                                (uint32_t)(box[u][0] < query.pMax.x) &
-                                (uint32_t)(query.pMin.y < box[u][4]) &
-                                (uint32_t)(box[u][1] < query.pMax.y) &
-                                (uint32_t)(query.pMin.z < box[u][5]) &
-                                (uint32_t)(box[u][2] < query.pMax.z) &
-                                (uint32_t)(my_id < other_id[u]) &
-                                (uint32_t)(j + u < r_end);
-                            raw |= (uint64_t)hit << (j + u);
-                        }
-                    }
-                    // ... then the few that passed: static pairs out, the rest
-                    // counted by primitive pairs
-                    uint64_t pending = raw;
-                    while (pending != 0) {
-                        const int32_t jj = (int32_t)__builtin_ctzll(pending);
-                        pending &= pending - 1;
-                        const int32_t kb = w->orderBody[m * 64 + jj];
-                        if (my_static && w->resp[kb] ==
-                                (uint32_t)ResponseType::Static) {
-                            raw &= ~(1ull << jj);
-                        } else {
-                            n += a_prims * w->primCount[kb];
-                        }
-                    }
-                    hits[m] = raw;
-                }
-            }
-
-            uint32_t chunk_total;
-            uint32_t out = num_candidates +
-                wave::exclusiveScan<LPW>(n, lane, &chunk_total);
-
-            if (active && n != 0 && out + n <= candidate_capacity) {
-                const uint32_t a_prims = w->primCount[k];
-#pragma unroll
-                for (int m = 0; m < mask_words; m++) {
-                    uint64_t pending = hits[m];
-                    while (pending != 0) {
-                        const int32_t r =
-                            m * 64 + (int32_t)__builtin_ctzll(pending);
-                        pending &= pending - 1;
-                        const int32_t kb = w->orderBody[r];
-                        const uint32_t b_prims = w->primCount[kb];
-                        const uint32_t total_checks = a_prims * b_prims;
-                        for (uint32_t c = 0; c < total_checks; c++) {
-                            const WaveCandidate candidate {
-                                (uint8_t)k, (uint8_t)kb,
-                                (uint8_t)(c / b_prims),
-                                (uint8_t)(c % b_prims),
-                            };
-                            if (out < (uint32_t)Block::maxCandidates) {
-                                w->candidates[out] = candidate;
-                            } else {
-                                spilled_candidates[
-                                    out - (uint32_t)Block::maxCandidates] =
-                                        candidate;
-                            }
-                            out++;
-                        }
-                    }
-                }
-            }
-            num_candidates += chunk_total;
-        }
-        if (num_candidates > candidate_capacity) {
-            mwhip::raiseError(S, mwhip::kErrTableOverflow);
-            continue;
-        }
-        wave::phaseFence();
-        PHYS_PROF(1);
-
-        auto candidateAt = [&](uint32_t c) {
-            return c < (uint32_t)Block::maxCandidates ? w->candidates[c] :
-                spilled_candidates[c - (uint32_t)Block::maxCandidates];
-        };
-
-        // ---- the world's joints (table sorted by world just before) -----------
-        const int32_t num_joints = framed.numJoints;
-        const JointConstraint *joints =
-            mwhip::loadInvariant(&frame->joints) + framed.jointBegin;
-
-        // body index of a joint end point (the per-archetype row ranges are not
-        // kept alive through the substeps: look the row up among the staged
-        // bodies -- a handful of LDS reads, once per joint)
-        auto jointBodyLoc = [&](Entity e) {
-            Loc loc = ctx.loc(e);
-            for (int32_t k = 0; k < num_bodies; k++) {
-                Loc body = w->bodyLoc[k];
-                if (body.archetype == loc.archetype && body.row == loc.row) {
-                    return Loc { 0, k };
-                }
-            }
-            return Loc { 0, 0 };
-        };
-        // (staged by loadWorldFramed when they fit the block)
-        const bool joints_staged = framed.jointsStaged;
-
-        PHYS_PROF(7);
-        bool bailed = false;
-        for (int32_t substep = 0; substep < params.numSubsteps; substep++) {
-            // ---- integrate (xpbd.cpp substepRigidBodies) ------------------------
-            for (int32_t k = (int32_t)lane; k < num_bodies; k += LPW) {
-                Vector3 x = w->pos[k];
-                Quat q = w->rot[k];
-
-                w->prev[k] = xpbd::SubstepPrevState { x, q };
-
-                if (w->resp[k] == (uint32_t)ResponseType::Static) {
-                    w->prePos[k] = xpbd::PreSolvePositional { x, q };
-                    w->preVel[k] = xpbd::PreSolveVelocity {
-                        Vector3::zero(), Vector3::zero() };
-                    continue;
-                }
-
-                xpbd::SubstepResult next = xpbd::integrateBody(
-                    x, q, w->vel[k].linear, w->vel[k].angular,
-                    w->constants[k].invMass, w->constants[k].invInertia,
-                    w->extForce[k],
-                    w->extTorque[k], w->sys.g, w->sys.h,
-                    w->resp[k] == (uint32_t)ResponseType::Dynamic);
-
-                w->pos[k] = next.x;
-                w->rot[k] = next.q;
-                w->prePos[k] = xpbd::PreSolvePositional { next.x, next.q };
-                w->preVel[k] = xpbd::PreSolveVelocity { next.v, next.omega };
-            }
-            wave::phaseFence();
-            PHYS_PROF(2);
-
-            // ---- narrowphase: contacts in candidate order ------------------------
-            // A lane's contact is staged in LDS at slot (num_contacts + lane)
-            // and the chunk is compacted in place afterwards: nothing as wide
-            // as a ContactConstraint stays live in registers across the
-            // cooperative hull-hull tests.  A chunk is as wide as the free
-            // slots allow.
-            uint32_t num_contacts = 0;
-            bool contacts_overflow = false;
-            for (uint32_t chunk = 0; chunk < num_candidates; ) {
-                const uint32_t free_slots = contact_cap - num_contacts;
-                if (free_slots == 0) {
-                    contacts_overflow = true;
-                    break;
-                }
-                uint32_t width = num_candidates - chunk;
-                width = width < (uint32_t)LPW ? width : (uint32_t)LPW;
-                width = width < free_slots ? width : free_slots;
-
-                ContactConstraint *stage = w->contacts() + num_contacts;
-                bool has_contact = false;
-                bool too_big = false;
-                bool unsupported = false;
-
-                uint32_t kind = 0;      // 1: this lane alone, 2: whole wave
-                {
-                    PairSetup pair;
-                    if (lane < width) {
-                        pair = ldsSetupPair(w, obj_mgr,
-                                            candidateAt(chunk + lane));
-                        if (pair.aabbOverlap) {
-                            kind = pair.test == NarrowphaseTest::HullHull ?
-                                2 : 1;
-                        }
-                    }
-                    PHYS_PROF(0);
-
-                    // lanes on their own, in rounds of lanePolyRows scratch rows
-                    uint64_t solo = wave::groupBallot<LPW>(kind == 1);
-                    const uint32_t solo_rank = wave::rankInGroup(solo, lane);
-                    const uint32_t solo_count =
-                        (uint32_t)__builtin_popcountll(solo);
-                    for (uint32_t first = 0; first < solo_count;
-                         first += lanePolyRows) {
-                        if (kind == 1 && solo_rank >= first &&
-                                solo_rank < first + lanePolyRows) {
-                            has_contact = collidePairLane(pair,
-                                w->scratch.lanePoly +
-                                    (solo_rank - first) * lanePolyDwords,
-                                stage + lane, &too_big, &unsupported);
-                        }
-                    }
-                }
-
-                PHYS_PROF(3);
-                uint64_t hull_pairs = wave::groupBallot<LPW>(kind == 2);
-                cost_work += 24u * (uint32_t)__builtin_popcountll(hull_pairs);
-#ifdef MADRONA_PHYS_PROFILE
-                // (event counts next to the cycle counters: lane 0 of a world)
-                {
-                    const uint64_t solo_pairs = wave::groupBallot<LPW>(kind == 1);
-                    if (lane == 0) {
-                        prof_acc[12] +=
-                            (unsigned long long)__builtin_popcountll(hull_pairs);
-                        prof_acc[14] +=
-                            (unsigned long long)__builtin_popcountll(solo_pairs);
-                        prof_acc[15] += width;
-                    }
-                }
-#endif
-                constexpr int hull_lanes = Block::hullLanes;
-                constexpr int hull_groups = Block::hullGroups;
-                static_assert(hull_groups == 1 || hull_groups == 2);
-                const uint32_t hull_group = lane / (uint32_t)hull_lanes;
-                const uint32_t hull_lane = lane % (uint32_t)hull_lanes;
-                HullScratch *hull_scratch = hull_group == 0 ?
-                    &w->scratch.hull : w->extraHull.at(0);
-                if constexpr (hull_groups == 2) {
-                    // Most chunks hold at most one hull-hull pair per world
-                    // (3.4 pairs per world and step on the Escape Room): then
-                    // all of the world's lanes take it instead of leaving one of
-                    // the two groups idle -- unless the other world of the
-                    // wavefront has more, whose path this one would have to sit
-                    // through anyway.
-                    const uint32_t mine =
-                        (uint32_t)__builtin_popcountll(hull_pairs);
-                    const uint32_t other = __shfl_xor(mine, LPW, 64);
-                    if (mine <= 1u && other <= 1u) {
-                        if (hull_pairs != 0) {
-                            const uint32_t src =
-                                (uint32_t)__builtin_ctzll(hull_pairs);
-                            hull_pairs = 0;
-                            bool pair_too_big = false;
-                            PairSetup shared_pair = ldsSetupPair(
-                                w, obj_mgr, candidateAt(chunk + src));
-                            const bool found = hullHullWave<LPW>(lane, shared_pair,
-                                &w->scratch.hull, stage + src, &pair_too_big,
-                                PHYS_HH_PROF());
-                            const uint32_t outcome = __shfl(
-                                (found ? 1u : 0u) | (pair_too_big ? 2u : 0u), 0, LPW);
-                            if (lane == src) {
-                                has_contact = (outcome & 1u) != 0u;
-                                too_big = (outcome & 2u) != 0u;
-                            }
-                        }
-                    }
-                }
-                while (hull_pairs != 0) {
-                    // the next pairs of the world, one per group of hull_lanes
-                    const uint32_t src0 = (uint32_t)__builtin_ctzll(hull_pairs);
-                    hull_pairs &= hull_pairs - 1;
-                    uint32_t src1 = 0xFFFFFFFFu;
-                    if (hull_groups == 2 && hull_pairs != 0) {
-                        src1 = (uint32_t)__builtin_ctzll(hull_pairs);
-                        hull_pairs &= hull_pairs - 1;
-                    }
-                    const uint32_t src = hull_group == 0 ? src0 : src1;
-
-                    bool found = false;
-                    bool pair_too_big = false;
-                    if (src != 0xFFFFFFFFu) {
-                        PairSetup shared_pair =
-                            ldsSetupPair(w, obj_mgr, candidateAt(chunk + src));
-                        // every lane of the group writes the same contact to
-                        // src's slot
-                        found = hullHullWave<hull_lanes>(hull_lane, shared_pair,
-                            hull_scratch, stage + src, &pair_too_big,
-                            PHYS_HH_PROF());
-                    }
-                    // the lane that owns the candidate learns the outcome
-                    const uint32_t outcome =
-                        (found ? 1u : 0u) | (pair_too_big ? 2u : 0u);
-                    const uint32_t outcome0 = __shfl(outcome, 0, LPW);
-                    if (lane == src0) {
-                        has_contact = (outcome0 & 1u) != 0u;
-                        too_big = (outcome0 & 2u) != 0u;
-                    }
-#ifdef MADRONA_PHYS_PROFILE
-                    if (lane == 0) {
-                        prof_acc[13] += outcome0 & 1u;
-                        if (hull_groups == 2 && src1 != 0xFFFFFFFFu) {
-                            prof_acc[13] += __shfl(outcome, hull_lanes, LPW) & 1u;
-                        }
-                    }
-#endif
-                    if (hull_groups == 2) {
-                        const uint32_t outcome1 = __shfl(outcome, hull_lanes, LPW);
-                        if (lane == src1) {
-                            has_contact = (outcome1 & 1u) != 0u;
-                            too_big = (outcome1 & 2u) != 0u;
-                        }
-                    }
-                }
-
-                // Hulls whose faces outgrow the LDS scratch (rare: none in the
-                // Escape Room or Hide-and-Seek shapes): the generic routine,
-                // one lane at a time through the world's scratch in HBM -- no
-                // per-lane arrays in private memory for a path that is almost
-                // never taken.
-                uint64_t big_pairs = wave::groupBallot<LPW>(too_big);
-                while (big_pairs != 0) {
-                    const uint32_t src = (uint32_t)__builtin_ctzll(big_pairs);
-                    big_pairs &= big_pairs - 1;
-                    if (lane == src) {
-                        geo::Plane *tmp_faces = (geo::Plane *)(
-                            ps->worldHullScratch +
-                            (size_t)world * PhysicsScratch::hullScratchBytes);
-                        static_assert(PhysicsScratch::hullScratchBytes >=
-                            MADRONA_PHYS_MAX_HULL_ELEMS *
-                                (sizeof(geo::Plane) + sizeof(math::Vector3)));
-                        math::Vector3 *tmp_vertices = (math::Vector3 *)(
-                            tmp_faces + MADRONA_PHYS_MAX_HULL_ELEMS);
-                        PairSetup pair = ldsSetupPair(w, obj_mgr,
-                                                      candidateAt(chunk + lane));
-                        has_contact = collidePairStored(pair, tmp_vertices,
-                            tmp_faces, MADRONA_PHYS_MAX_HULL_ELEMS, stage + lane,
-                            &unsupported);
-                    }
-                    wave::phaseFence();
-                }
-                if (unsupported) {
-                    mwhip::raiseError(S, mwhip::kErrPhysics);
-                }
-                wave::phaseFence();
-
-                // compact in place: all reads, then all writes
-                uint64_t mask = wave::groupBallot<LPW>(has_contact);
-                const uint32_t rank = wave::rankInGroup(mask, lane);
-                const bool moves = has_contact && rank != lane;
-                ContactConstraint moved;
-                if (moves) {
-                    moved = stage[lane];
-                }
-                wave::phaseFence();
-                if (moves) {
-                    stage[rank] = moved;
-                }
-                num_contacts += (uint32_t)__builtin_popcountll(mask);
-                chunk += width;
-            }
-            if (contacts_overflow) {
-                // more contacts than the block holds: the world is stepped out
-                // of HBM instead (nothing of this step has left LDS yet)
-                toFallback(world);
-                bailed = true;
-                break;
-            }
-            cost_work += 8u * num_contacts;
-            wave::phaseFence();
-            PHYS_PROF(5);
-
-            // ---- position solve: contacts, then joints, level by level ----------
-            // (the levels of the first window of contacts -- all of them, in
-            // every world seen so far -- serve the velocity solve as well: same
-            // contacts, same bodies)
-            uint32_t first_level = 0, first_max_level = 0;
-            for (uint32_t base = 0; base < num_contacts; base += LPW) {
-                const uint32_t n = num_contacts - base < (uint32_t)LPW ?
-                    num_contacts - base : (uint32_t)LPW;
-                const uint32_t i = base + lane;
-                uint32_t key_a = 0, key_b = 0;
-                if (lane < n) {
-                    key_a = ldsBodyKey(w, w->contacts()[i].ref.row);
-                    key_b = ldsBodyKey(w, w->contacts()[i].alt.row);
-                }
-                uint32_t level = constraintLevels<LPW>(lane, n, key_a, key_b);
-                uint32_t max_level = wave::maxReduce<LPW>(lane < n ? level : 0);
-                if (base == 0) {
-                    first_level = level;
-                    first_max_level = max_level;
-                }
-
-                for (uint32_t l = 0; l <= max_level; l++) {
-                    if (lane < n && level == l) {
-                        float lambda_n[4] { 0.f, 0.f, 0.f, 0.f };
-                        xpbd::handleContact(store, w->contacts()[i], lambda_n);
-                        w->lambdas[i] = lambda_n[0];
-                    }
-                    wave::phaseFence();
-                }
-            }
-
-            for (int32_t base = 0; base < num_joints; base += LPW) {
-                const uint32_t n = num_joints - base < LPW ?
-                    (uint32_t)(num_joints - base) : (uint32_t)LPW;
-                const int32_t i = base + (int32_t)lane;
-                Loc l1 { 0, 0 }, l2 { 0, 0 };
-                uint32_t key_a = 0, key_b = 0;
-                if (lane < n) {
-                    if (joints_staged) {
-                        l1 = Loc { 0, (int32_t)w->jointBodies[i][0] };
-                        l2 = Loc { 0, (int32_t)w->jointBodies[i][1] };
-                    } else {
-                        l1 = jointBodyLoc(joints[i].e1);
-                        l2 = jointBodyLoc(joints[i].e2);
-                    }
-                    key_a = ldsBodyKey(w, l1.row);
-                    key_b = ldsBodyKey(w, l2.row);
-                }
-                uint32_t level = constraintLevels<LPW>(lane, n, key_a, key_b);
-                uint32_t max_level = wave::maxReduce<LPW>(lane < n ? level : 0);
-
-                for (uint32_t l = 0; l <= max_level; l++) {
-                    if (lane < n && level == l) {
-                        xpbd::handleJointConstraint(store, l1, l2,
-                            joints_staged ? w->joints[i] : joints[i]);
-                    }
-                    wave::phaseFence();
-                }
-            }
-
-            PHYS_PROF(4);
-            // ---- velocities -----------------------------------------------------
-            for (int32_t k = (int32_t)lane; k < num_bodies; k += LPW) {
-                w->vel[k] = xpbd::deriveVelocity(w->pos[k], w->rot[k],
-                                                 w->prev[k], w->sys.h);
-            }
-            wave::phaseFence();
-            PHYS_PROF(4);
-
-            for (uint32_t base = 0; base < num_contacts; base += LPW) {
-                const uint32_t n = num_contacts - base < (uint32_t)LPW ?
-                    num_contacts - base : (uint32_t)LPW;
-                const uint32_t i = base + lane;
-                uint32_t level = first_level;
-                uint32_t max_level = first_max_level;
-                if (base != 0) {
-                    uint32_t key_a = 0, key_b = 0;
-                    if (lane < n) {
-                        key_a = ldsBodyKey(w, w->contacts()[i].ref.row);
-                        key_b = ldsBodyKey(w, w->contacts()[i].alt.row);
-                    }
-                    level = constraintLevels<LPW>(lane, n, key_a, key_b);
-                    max_level = wave::maxReduce<LPW>(lane < n ? level : 0);
-                }
-
-                for (uint32_t l = 0; l <= max_level; l++) {
-                    if (lane < n && level == l) {
-                        float lambda_n[4] { w->lambdas[i], 0.f, 0.f, 0.f };
-                        xpbd::solveVelocitiesForContact(store, w->contacts()[i],
-                            lambda_n, w->sys.h,
-                            w->sys.restitutionThreshold);
-                    }
-                    wave::phaseFence();
-                }
-            }
-            PHYS_PROF(11);
-        }
-
-        PHYS_PROF(6);
-        if (bailed) {
-            continue;
-        }
-        // ---- store: LDS -> HBM --------------------------------------------------
-        // The addresses of the body's six columns in ONE round of loads, then
-        // the stores, none of them waited for.  (Through ctx.getDirect every
-        // column was: load the column address, wait -- for the stores before
-        // it as well, they share the counter --, store: 14 us per pair of
-        // worlds in the phase profile, now 3.)
-        for (int32_t k = (int32_t)lane; k < num_bodies; k += LPW) {
-            const Loc loc = w->bodyLoc[k];
-            const TableHdr &tbl = mwhip::tablesOf(S)[loc.archetype];
-            base::Position *col_pos = (base::Position *)
-                mwhip::loadGlobal(&tbl.columns[RGDCols::Position]);
-            base::Rotation *col_rot = (base::Rotation *)
-                mwhip::loadGlobal(&tbl.columns[RGDCols::Rotation]);
-            Velocity *col_vel = (Velocity *)
-                mwhip::loadGlobal(&tbl.columns[RGDCols::Velocity]);
-            xpbd::SubstepPrevState *col_prev = (xpbd::SubstepPrevState *)
-                mwhip::loadGlobal(&tbl.columns[xpbd::XPBDCols::SubstepPrevState]);
-            xpbd::PreSolvePositional *col_pre_pos = (xpbd::PreSolvePositional *)
-                mwhip::loadGlobal(&tbl.columns[xpbd::XPBDCols::PreSolvePositional]);
-            xpbd::PreSolveVelocity *col_pre_vel = (xpbd::PreSolveVelocity *)
-                mwhip::loadGlobal(&tbl.columns[xpbd::XPBDCols::PreSolveVelocity]);
-            roundIssued();
-            const base::Position pos = w->pos[k];
-            const base::Rotation rot = w->rot[k];
-            const Velocity vel = w->vel[k];
-            const xpbd::SubstepPrevState prev = w->prev[k];
-            const xpbd::PreSolvePositional pre_pos = w->prePos[k];
-            const xpbd::PreSolveVelocity pre_vel = w->preVel[k];
-            mwhip::storeGlobal(col_pos + loc.row, pos);
-            mwhip::storeGlobal(col_rot + loc.row, rot);
-            mwhip::storeGlobal(col_vel + loc.row, vel);
-            mwhip::storeGlobal(col_prev + loc.row, prev);
-            mwhip::storeGlobal(col_pre_pos + loc.row, pre_pos);
-            mwhip::storeGlobal(col_pre_vel + loc.row, pre_vel);
-        }
-        // (the stores are not waited for: nothing of this job reads them, the
-        // end of the kernel covers them, and the block is only rewritten by
-        // this wavefront's own later LDS writes)
-        __builtin_amdgcn_wave_barrier();
-        PHYS_PROF(7);
-
-        // what this world cost: the wavefront's time, shared out between its two
-        // worlds (they run in lock step: the clock alone cannot tell them apart)
-        {
-            uint32_t cost = (uint32_t)((long long)wall_clock64() - cost_t0);
-            if (LPW == 32) {
-                const uint32_t other = __shfl_xor(cost_work, 32, 64);
-                const uint32_t most = cost_work > other ? cost_work : other;
-                cost = (uint32_t)(((uint64_t)cost * cost_work) / most);
-            }
-            if (lane == 0) {
-                params.worldCost[world] = cost;
-            }
-        }
-    } while (false);
-    }
-
-#ifdef MADRONA_PHYS_PROFILE
-    if (lane == 0 && S->moduleData[1] != nullptr) {
-        unsigned long long *dst = (unsigned long long *)S->moduleData[1];
-#pragma unroll
-        for (int i = 0; i < 32; i++) {
-            atomicAdd(&dst[i], prof_acc[i]);
-        }
-    }
-#endif
-}
-
-// Heaviest worlds first (longest-processing-time order): a counting sort of the
-// worlds by what they cost last step, 256 buckets, one 1024-thread workgroup.
-// The order only decides WHEN a world is stepped, never the result.
-__global__ void __launch_bounds__(1024)
-physicsOrderKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
-{
-    mwhip::TraceScope trace_scope(S);
-    const PhysicsStepParams params = *(const PhysicsStepParams *)node_data;
-    const int32_t num_worlds = S->numWorlds;
-    const uint32_t tid = threadIdx.x;
-    if (tid == 0) {
-        params.fallbackList[0] = 0;     // (worlds the LDS step hands to the HBM one)
-    }
-    if (tid >= 960u) {
-        // (the last wavefront: its share of the cost scan starts a moment later)
-        fillPhysicsFrame(S, detail::scratch(S),
-                         &((PhysicsStepNode *)node_data)->frame, tid - 960u, 64u);
-    }
-
-    __shared__ uint32_t hist[256];
-    __shared__ uint32_t wave_max[16];
-    __shared__ uint32_t most_shared;
-
-    uint32_t most = 0;
-    for (int32_t w = (int32_t)tid; w < num_worlds; w += 1024) {
-        const uint32_t c = params.worldCost[w];
-        most = c > most ? c : most;
-    }
-    most = wave::maxReduce<64>(most);
-    if (tid < 256) hist[tid] = 0;
-    if (tid % 64 == 0) wave_max[tid / 64] = most;
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t m = 1;
-        for (int i = 0; i < 16; i++) m = wave_max[i] > m ? wave_max[i] : m;
-        most_shared = m;
-    }
-    __syncthreads();
-    most = most_shared;
-
-    auto bucket_of = [most](uint32_t cost) {
-        return 255u - (uint32_t)(((uint64_t)cost * 255ull) / most);
-    };
-    for (int32_t w = (int32_t)tid; w < num_worlds; w += 1024) {
-        atomicAdd(&hist[bucket_of(params.worldCost[w])], 1u);
-    }
-    __syncthreads();
-    // exclusive scan of the 256 buckets by the first four wavefronts (one thread
-    // walking them: 256 dependent LDS round trips; 10.9 -> 9.0 us)
-    {
-        const uint32_t lane = tid & 63u;
-        const uint32_t v = tid < 256u ? hist[tid] : 0u;
-        uint32_t incl = v;
-#pragma unroll
-        for (uint32_t d = 1; d < 64u; d <<= 1) {
-            const uint32_t up = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += up;
-        }
-        if (tid < 256u && lane == 63u) wave_max[tid >> 6] = incl;
-        __syncthreads();
-        if (tid < 256u) {
-            uint32_t base = 0;
-            for (uint32_t wv = 0; wv < (tid >> 6); wv++) base += wave_max[wv];
-            hist[tid] = base + incl - v;
-        }
-    }
-    __syncthreads();
-    for (int32_t w = (int32_t)tid; w < num_worlds; w += 1024) {
-        const uint32_t at = atomicAdd(&hist[bucket_of(params.worldCost[w])], 1u);
-        params.worldOrder[at] = w;
-    }
-}
+#include "step_wave.inl"
+#include "step_narrowphase.inl"
+#include "step_hbm.inl"
+#include "step_lds.inl"
+#include "step_order.inl"
