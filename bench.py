@@ -469,7 +469,7 @@ def annotate(stats, sim_name, worlds):
             k["algo_bytes"] = (float(worlds) * PHYS_BYTES_PER_BODY *
                                PHYS_BODIES.get(sim_name, 28))
             k["exact"] = True
-        elif k["name"] == "physics:bvhRefresh":
+        elif k["name"] in ("physics:bvhRefresh", "physics:bvhRefresh+rebuild"):
             # the leaf update + refit of every body, a wavefront per world: the
             # declared read / write set of the ParallelFor node it replaces
             # (systemIO<updateLeafAndRefitEntry>, physics.inl) x the body rows

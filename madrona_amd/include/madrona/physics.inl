@@ -1405,6 +1405,78 @@ candidateKernel(EcsState *S, void *, uint32_t, uint32_t)
 
 #include <madrona/phys_impl/world_step.inl>
 
+// LDS of one staged tree rebuild (<= 64 leaves)
+struct BvhRebuildStaging {
+    static constexpr int32_t maxLeaves = 64;
+    static constexpr int32_t maxNodes = 21 + maxLeaves;    // numInternalNodes(64)
+    alignas(16) char nodes[maxNodes * broadphase::BVH::nodeBytes];
+    math::AABB leafAABBs[maxLeaves];
+    math::Vector3 leafCenters[maxLeaves];
+    uint32_t leafParents[maxLeaves];
+    int32_t sortedLeaves[maxLeaves];
+    int32_t traversalOrder[maxLeaves];
+    broadphase::BVH::RebuildStackEntry
+        buildStack[broadphase::BVH::rebuildStackSize];
+    int32_t numNodes;
+};
+
+// The rebuild of ONE world's tree by its wavefront (the tree asked for it: a
+// reset re-registered its bodies): the build runs out of LDS on a rebased copy
+// of the tree (BVH::rebased) and the arrays go back to HBM once.  The top-down
+// build is a chain of a few thousand dependent accesses to a few KB; from HBM
+// that chain is pure latency (measured 230 us per step for ~40 rebuilding
+// worlds with the reference's one-thread-per-world updateBVHEntry ParallelFor,
+// broadphase.cpp:1003-1004).  Leaf boxes must be current (and visible to this
+// wavefront).
+__device__ inline void rebuildTreeStaged(broadphase::BVH &bvh, uint32_t lane,
+                                         BvhRebuildStaging &staging)
+{
+    const int32_t num_leaves = bvh.numLeaves();
+    if (num_leaves > BvhRebuildStaging::maxLeaves ||
+            bvh.nodeCapacity() > BvhRebuildStaging::maxNodes) {
+        if (lane == 0) {
+            bvh.updateTree();       // too large to stage: build in place
+        }
+        return;
+    }
+
+    for (int32_t i = (int32_t)lane; i < num_leaves; i += 64) {
+        math::AABB aabb = bvh.rawLeafAABBs()[i];
+        staging.leafAABBs[i] = aabb;
+        staging.leafCenters[i] = (aabb.pMin + aabb.pMax) / 2.f;
+        staging.sortedLeaves[i] = bvh.rawSortedLeaves()[i];
+    }
+    wave::phaseFence();
+
+    broadphase::BVH local = bvh.rebased(staging.nodes,
+        staging.leafAABBs, staging.leafParents, staging.sortedLeaves,
+        staging.traversalOrder, staging.leafCenters);
+#ifdef MADRONA_PHYS_SERIAL_BVH_REBUILD
+    if (lane == 0) {
+        staging.numNodes = local.rebuildStaged(staging.buildStack);
+    }
+    wave::phaseFence();
+    const int32_t num_nodes = staging.numNodes;
+#else
+    const int32_t num_nodes =
+        local.rebuildStagedWave(lane, staging.buildStack);
+    wave::phaseFence();
+#endif
+
+    waveCopyDwords(lane, (uint32_t *)bvh.rawNodes(),
+        (const uint32_t *)staging.nodes,
+        (uint32_t)num_nodes * (broadphase::BVH::nodeBytes / 4));
+    for (int32_t i = (int32_t)lane; i < num_leaves; i += 64) {
+        bvh.rawLeafParents()[i] = staging.leafParents[i];
+        bvh.rawSortedLeaves()[i] = staging.sortedLeaves[i];
+        bvh.rawTraversalOrder()[i] = staging.traversalOrder[i];
+    }
+    if (lane == 0) {
+        bvh.finishRebuild(num_nodes);
+    }
+    wave::phaseFence();
+}
+
 // Leaf update + refit of EVERY body, a wavefront per world, a lane per leaf
 // (what setupBroadphaseTasks / setupPostIntegrationTasks run: the reference's
 // updateLeafPositionsEntry + refitEntry ParallelFor nodes, broadphase.cpp:
@@ -1423,7 +1495,15 @@ candidateKernel(EcsState *S, void *, uint32_t, uint32_t)
 // leaf's own slot plain, ancestors that have to grow with atomic min / max --
 // order independent, so the boxes are those of any other schedule).  A leaf
 // whose entity is gone (destroyed without a reset of the tree) is skipped: the
-// ParallelFor had no row for it either.  No LDS, 32 wavefronts per CU.
+// ParallelFor had no row for it either.
+// WithRebuild (setupBroadphaseTasks: the reference's updateBVHEntry node follows
+// the leaf update there): a world whose tree asked for a rebuild builds it right
+// behind its leaf update, in the same launch -- the ~40 us latency of a build (a
+// step resets ~1 world in 200) then runs beside the other worlds' refresh
+// instead of in a launch of its own with the chip idle.  The staging costs
+// 14 KB of LDS (11 wavefronts per CU instead of 32); setupPostIntegrationTasks
+// has no rebuild behind it and takes the plain variant (no LDS).
+template <bool WithRebuild>
 __global__ void __launch_bounds__(64)
 bvhRefreshKernel(EcsState *S, void *, uint32_t, uint32_t)
 {
@@ -1513,35 +1593,26 @@ bvhRefreshKernel(EcsState *S, void *, uint32_t, uint32_t)
             BVH::applyLeafUpdate(view.refit, leaf, leaf_parent, slot, pos, rot,
                                  scale, vel.linear, obj_aabb);
         }
+        if constexpr (WithRebuild) {
+            if (!view.refit.refit) {
+                // (a rebuild is pending: the leaf boxes just stored are what it
+                // builds from)
+                __shared__ BvhRebuildStaging staging;
+                wave::phaseFence();
+                rebuildTreeStaged(trees[world], lane, staging);
+            }
+        }
     }
 }
 
-// BVH rebuild for the worlds that asked for one (a reset re-registered their
-// bodies): one wavefront per world, the build runs out of LDS on a rebased
-// copy of the tree (BVH::rebased) and the arrays go back to HBM once.  The
-// top-down build is a chain of a few thousand dependent accesses to a few KB;
-// from HBM that chain is pure latency (measured 230 us per step for ~40
-// rebuilding worlds with the reference's one-thread-per-world updateBVHEntry
-// ParallelFor, broadphase.cpp:1003-1004).
+// BVH rebuild for the worlds that asked for one, as a launch of its own (behind
+// the ParallelFor flavour of the leaf update, MADRONA_MWHIP_BVH_REFRESH=0; the
+// refresh kernel rebuilds in place, bvhRefreshKernel<true>).
 __global__ void __launch_bounds__(64)
 bvhUpdateKernel(EcsState *S, void *, uint32_t, uint32_t)
 {
     mwhip::TraceScope trace_scope(S);
-    constexpr int32_t max_leaves = 64;
-    constexpr int32_t max_nodes = 21 + max_leaves;    // numInternalNodes(64)
-
-    struct Staging {
-        alignas(16) char nodes[max_nodes * broadphase::BVH::nodeBytes];
-        math::AABB leafAABBs[max_leaves];
-        math::Vector3 leafCenters[max_leaves];
-        uint32_t leafParents[max_leaves];
-        int32_t sortedLeaves[max_leaves];
-        int32_t traversalOrder[max_leaves];
-        broadphase::BVH::RebuildStackEntry
-            buildStack[broadphase::BVH::rebuildStackSize];
-        int32_t numNodes;
-    };
-    __shared__ Staging staging;
+    __shared__ BvhRebuildStaging staging;
 
     StateManager *state_mgr = static_cast<StateManager *>(S);
     const uint32_t lane = wave::laneID();
@@ -1556,50 +1627,7 @@ bvhUpdateKernel(EcsState *S, void *, uint32_t, uint32_t)
         if (!bvh.needsRebuild()) {
             continue;
         }
-
-        const int32_t num_leaves = bvh.numLeaves();
-        if (num_leaves > max_leaves || bvh.nodeCapacity() > max_nodes) {
-            if (lane == 0) {
-                bvh.updateTree();       // too large to stage: build in place
-            }
-            continue;
-        }
-
-        for (int32_t i = (int32_t)lane; i < num_leaves; i += 64) {
-            math::AABB aabb = bvh.rawLeafAABBs()[i];
-            staging.leafAABBs[i] = aabb;
-            staging.leafCenters[i] = (aabb.pMin + aabb.pMax) / 2.f;
-            staging.sortedLeaves[i] = bvh.rawSortedLeaves()[i];
-        }
-        wave::phaseFence();
-
-        broadphase::BVH local = bvh.rebased(staging.nodes,
-            staging.leafAABBs, staging.leafParents, staging.sortedLeaves,
-            staging.traversalOrder, staging.leafCenters);
-#ifdef MADRONA_PHYS_SERIAL_BVH_REBUILD
-        if (lane == 0) {
-            staging.numNodes = local.rebuildStaged(staging.buildStack);
-        }
-        wave::phaseFence();
-        const int32_t num_nodes = staging.numNodes;
-#else
-        const int32_t num_nodes =
-            local.rebuildStagedWave(lane, staging.buildStack);
-        wave::phaseFence();
-#endif
-
-        waveCopyDwords(lane, (uint32_t *)bvh.rawNodes(),
-            (const uint32_t *)staging.nodes,
-            (uint32_t)num_nodes * (broadphase::BVH::nodeBytes / 4));
-        for (int32_t i = (int32_t)lane; i < num_leaves; i += 64) {
-            bvh.rawLeafParents()[i] = staging.leafParents[i];
-            bvh.rawSortedLeaves()[i] = staging.sortedLeaves[i];
-            bvh.rawTraversalOrder()[i] = staging.traversalOrder[i];
-        }
-        if (lane == 0) {
-            bvh.finishRebuild(num_nodes);
-        }
-        wave::phaseFence();
+        rebuildTreeStaged(bvh, lane, staging);
     }
 }
 }
@@ -2220,31 +2248,47 @@ MADRONA_HOST_API inline TaskGraphNodeID setupCandidateTasks(
 // the leaf update + refit of every body (kernels::bvhRefreshKernel; the
 // ParallelFor over the body rows it replaces is still there for measurements:
 // MADRONA_MWHIP_BVH_REFRESH=0)
+// with_rebuild: trees that asked for a rebuild are rebuilt in the same launch
+// (*rebuilt_out = true) -- MADRONA_MWHIP_BVH_REFRESH: 0 = the ParallelFor, 1 =
+// the refresh kernel with a rebuild launch of its own behind it, 2 (default) =
+// the refresh kernel rebuilds
 MADRONA_HOST_API inline TaskGraphNodeID setupLeafRefreshTasks(
-    TaskGraphBuilder &builder, Span<const TaskGraphNodeID> deps)
+    TaskGraphBuilder &builder, Span<const TaskGraphNodeID> deps,
+    bool with_rebuild = false, bool *rebuilt_out = nullptr)
 {
     using namespace base;
     using broadphase::LeafID;
 
 #if defined(__HIPCC__)
-    [[maybe_unused]] auto refresh_stub = [] __host__ () -> const void * {
-        return (const void *)&kernels::bvhRefreshKernel;
+    [[maybe_unused]] auto refresh_stub = [] __host__ (bool rebuild) -> const void * {
+        return rebuild ? (const void *)&kernels::bvhRefreshKernel<true> :
+                         (const void *)&kernels::bvhRefreshKernel<false>;
     };
 #else
-    auto refresh_stub = []() -> const void * { return nullptr; };
+    auto refresh_stub = [](bool) -> const void * { return nullptr; };
 #endif
 
+    if (rebuilt_out != nullptr) {
+        *rebuilt_out = false;
+    }
 #if MADRONA_ON_HOST
     const char *refresh_env = getenv("MADRONA_MWHIP_BVH_REFRESH");
-    if (refresh_env == nullptr || atoi(refresh_env) != 0) {
+    const int mode = refresh_env == nullptr ? 2 : atoi(refresh_env);
+    if (mode != 0) {
+        const bool rebuild = with_rebuild && mode >= 2;
         mwhip_node_desc desc {};
         desc.kind = MWHIP_NODE_KERNEL;
-        desc.name = "physics:bvhRefresh";
-        desc.kernel = refresh_stub();
+        desc.name = rebuild ? "physics:bvhRefresh+rebuild" : "physics:bvhRefresh";
+        desc.kernel = refresh_stub(rebuild);
         desc.count_mode = MWHIP_COUNT_PER_WORLD;
         desc.threads_per_invocation = 64;
+        if (rebuilt_out != nullptr) {
+            *rebuilt_out = rebuild;
+        }
         return builder.addRuntimeNode(desc, -1, deps);
     }
+#else
+    (void)with_rebuild;
 #endif
     return builder.addToGraph<ParallelForNode<Context,
         broadphase::updateLeafAndRefitEntry,
@@ -2274,11 +2318,12 @@ MADRONA_HOST_API inline TaskGraphNodeID setupBroadphaseTasks(
     auto bvh_stub = []() -> const void * { return nullptr; };
 #endif
 
-    auto update_leaves = detail::setupLeafRefreshTasks(builder, deps);
+    bool rebuilt = false;
+    auto update_leaves = detail::setupLeafRefreshTasks(builder, deps, true, &rebuilt);
 
     TaskGraphNodeID bvh_update = update_leaves;
 #if MADRONA_ON_HOST
-    {
+    if (!rebuilt) {
         mwhip_node_desc desc {};
         desc.kind = MWHIP_NODE_KERNEL;
         desc.name = "physics:bvhUpdate";
