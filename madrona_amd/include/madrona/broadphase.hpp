@@ -346,6 +346,33 @@ public:
     // node, as rebuild().  Needs leaf_centers_.
     __device__ inline int32_t rebuildStagedWave(uint32_t lane,
                                                 RebuildStackEntry *stack);
+
+    // The same tree again, built breadth first: every range of a level is
+    // split at once (the lanes hold the leaves in sorted position; a range is a
+    // segment of lanes), node ids, merged bounds and the traversal order are
+    // derived afterwards from the range records.  A level costs two segmented
+    // partitions whatever the number of ranges in it; the stack machine above
+    // walks the ranges one by one (15 partitions, 16 leaf nodes and 20 merges in
+    // a row for a 28-leaf tree).  Returns -1 if the tree needs more range
+    // records than `scratch` holds (the caller then takes rebuildStagedWave).
+    struct RebuildRange {
+        int16_t lo;             // first sorted position
+        int16_t n;              // leaves (0 .. 64)
+        int16_t parent;         // range index, -1: root
+        int16_t firstChild;     // range index of child 0, -1: a leaf node
+        int16_t node;           // node id (pre-order, as rebuild() numbers them)
+        int16_t subtreeNodes;
+        int16_t leafStart;      // first traversal rank of the subtree's leaves
+        int16_t slot;           // child index in the parent
+    };
+    static constexpr int32_t maxRebuildRanges = 96;
+    struct SegmentedScratch {
+        RebuildRange ranges[maxRebuildRanges];
+        int32_t fromLeft[64];
+        int32_t fromRight[64];
+    };
+    __device__ inline int32_t rebuildStagedSegmented(uint32_t lane,
+                                                     SegmentedScratch *scratch);
 #endif
 
     MADRONA_HD inline void finishRebuild(int32_t num_nodes)

@@ -859,6 +859,256 @@ int32_t BVH::rebuildStagedWave(uint32_t lane, RebuildStackEntry *stack)
 
     return (int32_t)num_nodes_;
 }
+
+// rebuild() breadth first (broadphase.hpp).  Lane p holds sorted position p.
+// Equivalence with the stack machine: a midpoint split only reads the centres of
+// its own range and only permutes sorted_leaves_ inside it, so splitting
+// disjoint ranges in any order -- or at once -- gives the same permutation; node
+// ids are rebuild()'s pre-order numbers (a node is numbered when it is first
+// reached, children 0..3 in order), children fill their parent's slots in that
+// order, merged bounds are min / max over the same boxes (exact, order free),
+// and the traversal order is the one the unpruned stack walk produces: a node's
+// inner children are pushed 0..3 and popped 3..0.
+int32_t BVH::rebuildStagedSegmented(uint32_t lane, SegmentedScratch *scratch)
+{
+    using math::Vector3;
+    const int32_t num_leaves = num_leaves_;
+    num_tree_leaves_ = num_leaves;
+    num_nodes_ = numInternalNodes(num_leaves);
+    RebuildRange *ranges = scratch->ranges;
+
+    if (lane == 0) {
+        ranges[0] = RebuildRange { 0, (int16_t)num_leaves, -1, -1, 0, 1, 0, 0 };
+    }
+    detail::waveFence();
+
+    const int32_t p = (int32_t)lane;
+    // the range this lane's position is in while it is being split (-1: settled)
+    int32_t my_range = p < num_leaves && num_leaves > 4 ? 0 : -1;
+    int32_t num_ranges = 1;
+    int32_t level_first = 0;        // ranges of the current level: [first, num_ranges)
+    int32_t depth = 0;
+
+    // one segmented midpoint split of [s_lo, s_lo + s_n) for every lane with
+    // s_n > 0; returns the size of the lower part (midpointSplit's value)
+    auto splitSegments = [&](int32_t s_lo, int32_t s_n) -> int32_t {
+        const bool active = s_n > 0;
+        int32_t leaf = 0;
+        Vector3 center { 0.f, 0.f, 0.f };
+        if (active) {
+            leaf = sorted_leaves_[p];
+            center = leaf_centers_[leaf];
+        }
+        const int32_t s_end = s_lo + s_n;
+        float lo[3], hi[3];
+MADRONA_UNROLL
+        for (int32_t a = 0; a < 3; a++) {
+            lo[a] = active ? center[a] : FLT_MAX;
+            hi[a] = active ? center[a] : -FLT_MAX;
+        }
+        // (suffix reduction inside the segment, then everyone reads the head)
+MADRONA_UNROLL
+        for (int32_t d = 1; d < 64; d <<= 1) {
+            const bool take = active && p + d < s_end;
+MADRONA_UNROLL
+            for (int32_t a = 0; a < 3; a++) {
+                const float l = __shfl_down(lo[a], (uint32_t)d, 64);
+                const float h = __shfl_down(hi[a], (uint32_t)d, 64);
+                if (take) {
+                    lo[a] = fminf(lo[a], l);
+                    hi[a] = fmaxf(hi[a], h);
+                }
+            }
+        }
+MADRONA_UNROLL
+        for (int32_t a = 0; a < 3; a++) {
+            lo[a] = __shfl(lo[a], active ? s_lo : p, 64);
+            hi[a] = __shfl(hi[a], active ? s_lo : p, 64);
+        }
+
+        Vector3 center_min { lo[0], lo[1], lo[2] };
+        Vector3 center_max { hi[0], hi[1], hi[2] };
+        Vector3 center_diff = center_max - center_min;
+        int32_t axis;
+        if (center_diff.x > center_diff.y && center_diff.x > center_diff.z) {
+            axis = 0;
+        } else if (center_diff.y > center_diff.x && center_diff.y > center_diff.z) {
+            axis = 1;
+        } else {
+            axis = 2;
+        }
+        const float split_val = 0.5f * (center_min[axis] + center_max[axis]);
+        const float v = axis == 0 ? center.x : axis == 1 ? center.y : center.z;
+        const bool below = active && v < split_val;
+        const bool above = active && v >= split_val;
+        const uint64_t below_mask = __builtin_amdgcn_ballot_w64(below);
+        const uint64_t above_mask = __builtin_amdgcn_ballot_w64(above);
+
+        const uint64_t seg_mask = !active ? 0ull :
+            (s_n >= 64 ? ~0ull : (((1ull << s_n) - 1ull) << s_lo));
+        const int32_t boundary =
+            (int32_t)__builtin_popcountll(below_mask & seg_mask);
+        const uint64_t left = !active ? 0ull :
+            (boundary >= 64 ? ~0ull : (((1ull << boundary) - 1ull) << s_lo));
+        const uint64_t wrong_above = above_mask & seg_mask & left;      // move right
+        const uint64_t wrong_below = below_mask & seg_mask & ~left;     // move left
+
+        const bool moves_right = ((wrong_above >> lane) & 1ull) != 0;
+        const bool moves_left = ((wrong_below >> lane) & 1ull) != 0;
+        const bool any_moves =
+            __builtin_amdgcn_ballot_w64(moves_right || moves_left) != 0ull;
+        if (any_moves) {
+            uint32_t k = 0;
+            if (moves_right) {          // k-th of its segment from the left
+                k = (uint32_t)__builtin_popcountll(
+                    wrong_above & detail::lanesBelow(lane));
+                scratch->fromLeft[s_lo + (int32_t)k] = leaf;
+            } else if (moves_left) {    // k-th of its segment from the right
+                k = (uint32_t)__builtin_popcountll(
+                    wrong_below & ~(detail::lanesBelow(lane) | (1ull << lane)));
+                scratch->fromRight[s_lo + (int32_t)k] = leaf;
+            }
+            detail::waveFence();
+            if (moves_right) {
+                sorted_leaves_[p] = scratch->fromRight[s_lo + (int32_t)k];
+            } else if (moves_left) {
+                sorted_leaves_[p] = scratch->fromLeft[s_lo + (int32_t)k];
+            }
+            detail::waveFence();
+        }
+
+        if (boundary > 0 && boundary < s_n) {
+            return boundary;
+        }
+        return s_n / 2;
+    };
+
+    bool overflow = false;
+    while (__builtin_amdgcn_ballot_w64(my_range >= 0) != 0ull) {
+        depth++;
+        // ---- the half split of every range of the level with more than 4 ----
+        int32_t r_lo = 0, r_n = 0;
+        if (my_range >= 0) {
+            r_lo = ranges[my_range].lo;
+            r_n = ranges[my_range].n;
+        }
+        const int32_t h1 = splitSegments(r_lo, r_n);
+        // ---- both quarter splits ----
+        const bool upper = my_range >= 0 && p >= r_lo + h1;
+        const int32_t q_lo = my_range < 0 ? 0 : (upper ? r_lo + h1 : r_lo);
+        const int32_t q_n = my_range < 0 ? 0 : (upper ? r_n - h1 : h1);
+        const int32_t q = splitSegments(q_lo, q_n);
+        // (the head of the range needs the split of BOTH halves: the upper
+        // half's from its first lane; h1 is in [1, r_n - 1], so both exist)
+        const int32_t first_split = __shfl(q, my_range >= 0 ? r_lo : p, 64);
+        const int32_t third_split = __shfl(q, my_range >= 0 ? r_lo + h1 : p, 64);
+
+        // ---- the four children of every split range: records ----
+        const bool head = my_range >= 0 && p == r_lo;
+        const uint64_t heads = __builtin_amdgcn_ballot_w64(head);
+        const int32_t num_split = (int32_t)__builtin_popcountll(heads);
+        const int32_t child_base = num_ranges + 4 * (int32_t)__builtin_popcountll(
+            heads & detail::lanesBelow(lane));
+        if (num_ranges + 4 * num_split > maxRebuildRanges) {
+            overflow = true;
+            break;
+        }
+        const int32_t c_lo[4] = { r_lo, r_lo + first_split, r_lo + h1,
+                                  r_lo + h1 + third_split };
+        const int32_t c_n[4] = { first_split, h1 - first_split, third_split,
+                                 r_n - h1 - third_split };
+        if (head) {
+            ranges[my_range].firstChild = (int16_t)child_base;
+MADRONA_UNROLL
+            for (int32_t c = 0; c < 4; c++) {
+                ranges[child_base + c] = RebuildRange {
+                    (int16_t)c_lo[c], (int16_t)c_n[c], (int16_t)my_range, -1,
+                    0, 1, 0, (int16_t)c };
+            }
+        }
+        // where this lane's position went
+        if (my_range >= 0) {
+            const int32_t base = __shfl(child_base, r_lo, 64);
+            int32_t c = p >= c_lo[3] ? 3 : (p >= c_lo[2] ? 2 : (p >= c_lo[1] ? 1 : 0));
+            my_range = c_n[c] > 4 ? base + c : -1;
+        }
+        level_first = num_ranges;
+        num_ranges += 4 * num_split;
+        detail::waveFence();
+    }
+    (void)level_first;
+    if (overflow) {
+        return -1;
+    }
+
+    // ---- subtree sizes, bottom up (a child's index is above its parent's) ----
+    for (int32_t it = 0; it < depth; it++) {
+        for (int32_t r = p; r < num_ranges; r += 64) {
+            const int32_t fc = ranges[r].firstChild;
+            if (fc >= 0) {
+                ranges[r].subtreeNodes = (int16_t)(1 + ranges[fc].subtreeNodes +
+                    ranges[fc + 1].subtreeNodes + ranges[fc + 2].subtreeNodes +
+                    ranges[fc + 3].subtreeNodes);
+            }
+        }
+        detail::waveFence();
+    }
+    // ---- node ids (pre-order) and traversal ranks (inner children 3..0), top down
+    for (int32_t it = 0; it < depth; it++) {
+        for (int32_t r = p; r < num_ranges; r += 64) {
+            const int32_t par = ranges[r].parent;
+            if (par >= 0) {
+                const int32_t fc = ranges[par].firstChild;
+                const int32_t c = ranges[r].slot;
+                int32_t node = ranges[par].node + 1;
+                int32_t rank = ranges[par].leafStart;
+                for (int32_t o = 0; o < 4; o++) {
+                    if (o < c) node += ranges[fc + o].subtreeNodes;
+                    if (o > c) rank += ranges[fc + o].n;
+                }
+                ranges[r].node = (int16_t)node;
+                ranges[r].leafStart = (int16_t)rank;
+            }
+        }
+        detail::waveFence();
+    }
+
+    // ---- the nodes ----
+    for (int32_t r = p; r < num_ranges; r += 64) {
+        const RebuildRange range = ranges[r];
+        Node &node = nodes_[range.node];
+        node.parentID = range.parent >= 0 ? (int32_t)ranges[range.parent].node :
+                                           sentinel_;
+        if (range.firstChild < 0) {
+            for (int32_t i = 0; i < 4; i++) {
+                if (i < range.n) {
+                    const int32_t leaf_id = sorted_leaves_[range.lo + i];
+                    leaf_parents_[leaf_id] =
+                        ((uint32_t)range.node << 2) | (uint32_t)i;
+                    node.setLeaf(i, leaf_id);
+                    node.setBounds(i, leaf_aabbs_[leaf_id]);
+                    dfs_leaves_[range.leafStart + i] = leaf_id;
+                } else {
+                    node.children[i] = sentinel_;
+                    node.setBounds(i, math::AABB::invalid());
+                }
+            }
+        } else {
+            for (int32_t c = 0; c < 4; c++) {
+                const RebuildRange child = ranges[range.firstChild + c];
+                math::AABB merged = math::AABB::invalid();
+                for (int32_t i = 0; i < child.n; i++) {
+                    merged = math::AABB::merge(
+                        merged, leaf_aabbs_[sorted_leaves_[child.lo + i]]);
+                }
+                node.children[c] = child.node;
+                node.setBounds(c, merged);
+            }
+        }
+    }
+    detail::waveFence();
+    return (int32_t)num_nodes_;
+}
 #endif
 
 void BVH::updateTree()

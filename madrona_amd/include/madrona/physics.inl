@@ -1415,8 +1415,12 @@ struct BvhRebuildStaging {
     uint32_t leafParents[maxLeaves];
     int32_t sortedLeaves[maxLeaves];
     int32_t traversalOrder[maxLeaves];
-    broadphase::BVH::RebuildStackEntry
-        buildStack[broadphase::BVH::rebuildStackSize];
+    union {
+        // (the stack machine's stack / the breadth-first build's range records)
+        broadphase::BVH::RebuildStackEntry
+            buildStack[broadphase::BVH::rebuildStackSize];
+        broadphase::BVH::SegmentedScratch segmented;
+    };
     int32_t numNodes;
 };
 
@@ -1428,8 +1432,14 @@ struct BvhRebuildStaging {
 // worlds with the reference's one-thread-per-world updateBVHEntry ParallelFor,
 // broadphase.cpp:1003-1004).  Leaf boxes must be current (and visible to this
 // wavefront).
+// Check (tests, bvhUpdateKernel<true>): the breadth-first build's tree is
+// compared, word for word, with the stack machine's from the same leaves;
+// kErrPhysics if they differ.
+template <bool Check = false>
 __device__ inline void rebuildTreeStaged(broadphase::BVH &bvh, uint32_t lane,
-                                         BvhRebuildStaging &staging)
+                                         BvhRebuildStaging &staging,
+                                         BvhRebuildStaging *check_staging = nullptr,
+                                         EcsState *S = nullptr)
 {
     const int32_t num_leaves = bvh.numLeaves();
     if (num_leaves > BvhRebuildStaging::maxLeaves ||
@@ -1458,9 +1468,70 @@ __device__ inline void rebuildTreeStaged(broadphase::BVH &bvh, uint32_t lane,
     wave::phaseFence();
     const int32_t num_nodes = staging.numNodes;
 #else
-    const int32_t num_nodes =
-        local.rebuildStagedWave(lane, staging.buildStack);
+    // breadth first, every range of a level at once (broadphase.inl); the
+    // stack machine only if the tree needs more range records than the scratch
+    // holds (not expected: a range is a node, and the reference sizes its node
+    // array with the same bound)
+#ifdef MADRONA_PHYS_STACK_REBUILD
+    int32_t num_nodes = -1;     // (measurement builds: rounds 2-4's build)
+#else
+    int32_t num_nodes = local.rebuildStagedSegmented(lane, &staging.segmented);
     wave::phaseFence();
+#endif
+    if (num_nodes < 0) {
+        for (int32_t i = (int32_t)lane; i < num_leaves; i += 64) {
+            staging.sortedLeaves[i] = bvh.rawSortedLeaves()[i];
+        }
+        wave::phaseFence();
+        num_nodes = local.rebuildStagedWave(lane, staging.buildStack);
+        wave::phaseFence();
+    }
+    if constexpr (Check) {
+        BvhRebuildStaging &other = *check_staging;
+        for (int32_t i = (int32_t)lane; i < num_leaves; i += 64) {
+            other.leafAABBs[i] = staging.leafAABBs[i];
+            other.leafCenters[i] = staging.leafCenters[i];
+            other.sortedLeaves[i] = bvh.rawSortedLeaves()[i];
+        }
+        wave::phaseFence();
+        broadphase::BVH reference_tree = bvh.rebased(other.nodes,
+            other.leafAABBs, other.leafParents, other.sortedLeaves,
+            other.traversalOrder, other.leafCenters);
+        const int32_t ref_nodes =
+            reference_tree.rebuildStagedWave(lane, other.buildStack);
+        wave::phaseFence();
+        bool same = ref_nodes == num_nodes;
+        // (nodes the tree uses: the root's subtree, numbered 0 .. count - 1)
+        int32_t used = 0;
+        {
+            // count by walking the stack machine's tree: every node has a
+            // parent id below its own; the largest referenced child id + 1
+            used = 1;
+            for (int32_t n = 0; n < ref_nodes; n++) {
+                const int32_t *words = (const int32_t *)(
+                    other.nodes + (size_t)n * broadphase::BVH::nodeBytes);
+                if (n >= used) break;
+                for (int32_t c = 0; c < 4; c++) {
+                    const int32_t child = words[24 + c];
+                    if (child >= 0 && child + 1 > used) used = child + 1;
+                }
+            }
+        }
+        const uint32_t words_used =
+            (uint32_t)used * (broadphase::BVH::nodeBytes / 4);
+        for (uint32_t i = lane; i < words_used; i += 64) {
+            same = same && ((const uint32_t *)staging.nodes)[i] ==
+                           ((const uint32_t *)other.nodes)[i];
+        }
+        for (int32_t i = (int32_t)lane; i < num_leaves; i += 64) {
+            same = same && staging.leafParents[i] == other.leafParents[i] &&
+                staging.sortedLeaves[i] == other.sortedLeaves[i] &&
+                staging.traversalOrder[i] == other.traversalOrder[i];
+        }
+        if (__builtin_amdgcn_ballot_w64(!same) != 0ull) {
+            mwhip::raiseError(S, mwhip::kErrPhysics);
+        }
+    }
 #endif
 
     waveCopyDwords(lane, (uint32_t *)bvh.rawNodes(),
@@ -1608,11 +1679,17 @@ bvhRefreshKernel(EcsState *S, void *, uint32_t, uint32_t)
 // BVH rebuild for the worlds that asked for one, as a launch of its own (behind
 // the ParallelFor flavour of the leaf update, MADRONA_MWHIP_BVH_REFRESH=0; the
 // refresh kernel rebuilds in place, bvhRefreshKernel<true>).
+template <bool Check>
 __global__ void __launch_bounds__(64)
 bvhUpdateKernel(EcsState *S, void *, uint32_t, uint32_t)
 {
     mwhip::TraceScope trace_scope(S);
     __shared__ BvhRebuildStaging staging;
+    [[maybe_unused]] BvhRebuildStaging *check_staging = nullptr;
+    if constexpr (Check) {
+        __shared__ BvhRebuildStaging second;
+        check_staging = &second;
+    }
 
     StateManager *state_mgr = static_cast<StateManager *>(S);
     const uint32_t lane = wave::laneID();
@@ -1627,7 +1704,7 @@ bvhUpdateKernel(EcsState *S, void *, uint32_t, uint32_t)
         if (!bvh.needsRebuild()) {
             continue;
         }
-        rebuildTreeStaged(bvh, lane, staging);
+        rebuildTreeStaged<Check>(bvh, lane, staging, check_staging, S);
     }
 }
 }
@@ -2311,11 +2388,12 @@ MADRONA_HOST_API inline TaskGraphNodeID setupBroadphaseTasks(
     using broadphase::LeafID;
 
 #if defined(__HIPCC__)
-    [[maybe_unused]] auto bvh_stub = [] __host__ () -> const void * {
-        return (const void *)&kernels::bvhUpdateKernel;
+    [[maybe_unused]] auto bvh_stub = [] __host__ (bool check) -> const void * {
+        return check ? (const void *)&kernels::bvhUpdateKernel<true> :
+                       (const void *)&kernels::bvhUpdateKernel<false>;
     };
 #else
-    auto bvh_stub = []() -> const void * { return nullptr; };
+    auto bvh_stub = [](bool) -> const void * { return nullptr; };
 #endif
 
     bool rebuilt = false;
@@ -2327,7 +2405,10 @@ MADRONA_HOST_API inline TaskGraphNodeID setupBroadphaseTasks(
         mwhip_node_desc desc {};
         desc.kind = MWHIP_NODE_KERNEL;
         desc.name = "physics:bvhUpdate";
-        desc.kernel = bvh_stub();
+        // MADRONA_MWHIP_BVH_CHECK=1 (with MADRONA_MWHIP_BVH_REFRESH=1): every
+        // rebuild is done both ways and compared (tests)
+        const char *check_env = getenv("MADRONA_MWHIP_BVH_CHECK");
+        desc.kernel = bvh_stub(check_env != nullptr && atoi(check_env) != 0);
         desc.count_mode = MWHIP_COUNT_PER_WORLD;
         desc.threads_per_invocation = 64;
         bvh_update = builder.addRuntimeNode(desc, -1, {update_leaves});

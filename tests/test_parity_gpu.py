@@ -353,6 +353,47 @@ def test_rays_sharing_an_origin_big_and_uneven_trees(built, worlds):
         assert hits > 35 * worlds * 8       # the rays do meet boxes
 
 
+@pytest.mark.parametrize("sim,worlds,steps,flags", [
+    ("escape_room_phys", 200, 80, 10),     # 28 leaves, a world in ten resets per step
+    ("hideseek", 150, 80, 8),              # 29 leaves, wedges
+    ("ball_pit", 256, 80, 12),             # 18 leaves
+    ("ball_pit", 40, 40, (40 << 16) | 6),  # 58 leaves: close to the staging's 64
+    ("broadphase_only", 97, 40, 1),        # 14 .. 104 leaves, rebuilt every 16 steps
+                                           # (> 64: the in-place build)
+])
+def test_breadth_first_bvh_rebuild_equals_the_stack_machine(built, monkeypatch, sim,
+                                                            worlds, steps, flags):
+    """BVH::rebuildStagedSegmented (every range of a level split at once; node
+    ids, bounds and traversal order derived from the range records) against
+    BVH::rebuildStagedWave (the reference's stack machine on a wavefront) on the
+    same leaves, word for word: nodes, leaf parents, sorted order, traversal
+    order (bvhUpdateKernel<true>, MADRONA_MWHIP_BVH_CHECK=1; a difference
+    raises kErrPhysics and fails the step) -- in lock step with the reference
+    on top.  Frequent resets: every reset is a rebuild."""
+    _need_ref(sim)
+    monkeypatch.setenv("MADRONA_MWHIP_BVH_REFRESH", "1")
+    monkeypatch.setenv("MADRONA_MWHIP_BVH_CHECK", "1")
+    monkeypatch.setenv("MADRONA_MWHIP_MAX_CANDIDATES_PER_WORLD", "2048")
+    monkeypatch.setenv("MADRONA_MWHIP_MAX_CONTACTS_PER_WORLD", "1024")
+    agents = {"escape_room_phys": 2, "hideseek": 5}.get(sim, 0)
+    if sim == "broadphase_only":
+        with Simulator(ref_lib_path(sim), worlds, seed=3, num_workers=1,
+                       flags=flags) as ref, \
+                Simulator(hip_lib_path(sim), worlds, seed=3, flags=flags) as hip:
+            for step in range(1, steps + 1):
+                ref.step(1)
+                hip.step(1)
+                rd, hd = ref.dump_all(8192), hip.dump_all(8192)
+                for col in ("Box.Position", "Sensor.RayFan"):
+                    assert np.array_equal(rd[col][0], hd[col][0]), (step, col)
+        return
+    probs, step = run_pair(sim, worlds, steps, flags=flags, check_every=10,
+                           actions=_escape_actions(worlds + 2, grab=True, agents=agents)
+                           if agents else None,
+                           check_init=False, ref_workers=0)
+    assert not probs, (step, probs[:3])
+
+
 def test_ball_pit_hinge_joints(built):
     """Hinge joints (reference src/physics/xpbd.cpp:686-693 and the two
     orientation constraints before it).  A hinged chain is not stable on the
