@@ -639,6 +639,7 @@ struct mwhip_exec {
     // its one-workgroup tail sort is just slow when the whole table is "tail")
     uint32_t sortCompaction = 1;
     uint32_t rowSnapshotMode = 1;   // 0 never, 1 nodes that can append rows, 2 all
+    bool eagerReplay = false;       // MADRONA_MWHIP_EAGER (measurement, replayGraph)
     // MADRONA_MWHIP_EXEC_CONFIG_FILE (the reference's
     // MADRONA_MWGPU_EXEC_CONFIG_FILE, cuda_exec.cpp:2115-2172): per task-graph
     // node (index in execution order) the workgroups per CU its kernel may
@@ -2763,6 +2764,7 @@ extern "C" int mwhip_create(const mwhip_state_config *cfg,
     exec->sortCarriesMisc = envU32("MADRONA_MWHIP_SORT_CARRIES_MISC", 1) != 0;
     exec->sortCompaction = envU32("MADRONA_MWHIP_SORT_COMPACT", 1);
     exec->rowSnapshotMode = envU32("MADRONA_MWHIP_ROW_SNAPSHOT", 1);
+    exec->eagerReplay = envU32("MADRONA_MWHIP_EAGER", 0) != 0;
     {
         hipDeviceProp_t prop {};
         HIPCHK(hipGetDeviceProperties(&prop, cfg->gpu_id));
@@ -3700,13 +3702,18 @@ static int checkHealth(mwhip_exec *exec)
     return 0;
 }
 
+static int replayGraph(mwhip_exec *exec, LaunchGraph &lg, hipStream_t stream);
+
 extern "C" int mwhip_run(mwhip_exec *exec, uint64_t graph)
 {
     auto it = exec->launchGraphs.find(graph);
     if (it == exec->launchGraphs.end()) {
         return fail(-3, "unknown launch graph");
     }
-    HIPCHK(hipGraphLaunch(it->second->graphExec, exec->stream));
+    {
+        int launch_rc = replayGraph(exec, *it->second, exec->stream);
+        if (launch_rc != 0) return launch_rc;
+    }
     exec->replaysLaunched++;
     HIPCHK(hipStreamSynchronize(exec->stream));
     drainHostPrints(exec, false);
@@ -3726,8 +3733,7 @@ extern "C" int mwhip_run(mwhip_exec *exec, uint64_t graph)
 // which a step of a millisecond hides).
 static int replayGraph(mwhip_exec *exec, LaunchGraph &lg, hipStream_t stream)
 {
-    static const bool eager = envU32("MADRONA_MWHIP_EAGER", 0) != 0;
-    if (!eager) {
+    if (!exec->eagerReplay) {
         HIPCHK(hipGraphLaunch(lg.graphExec, stream));
         return 0;
     }

@@ -113,8 +113,10 @@ def test_escape_room_physics_kernel_variants(built, monkeypatch, max_bodies):
     assert not probs, (step, probs[:3])
 
 
-@pytest.mark.parametrize("worlds,crowded", [(256, 3), (64, 31)])
-def test_one_crowded_world_falls_back_to_the_hbm_step(built, monkeypatch, worlds, crowded):
+@pytest.mark.parametrize("worlds,crowded,block", [(256, 3, ""), (64, 31, ""),
+                                                  (48, 7, "64"), (48, 8, "128")])
+def test_one_crowded_world_falls_back_to_the_hbm_step(built, monkeypatch, worlds, crowded,
+                                                      block):
     """a world the LDS instantiation cannot hold is stepped out of
     HBM in the same step instead of raising kErrPhysics (the reference has no
     cap on a world's bodies: broadphase.cpp:892-1052).  ball_pit with ONE world
@@ -123,8 +125,12 @@ def test_one_crowded_world_falls_back_to_the_hbm_step(built, monkeypatch, worlds
     worlds per wavefront -- and the crowded world, whose partner in the
     wavefront stays in the LDS kernel, goes through physicsStepKernel in
     fallback mode.  Lock step with the reference, no error flag (a raised flag
-    fails the step that raised it)."""
+    fails the step that raised it).  `block`: the same under the 64- and 128-body
+    blocks (one world per wavefront, MADRONA_MWHIP_PHYS_MAX_BODIES), which the
+    crowded world outgrows as well."""
     _need_ref("ball_pit")
+    if block:
+        monkeypatch.setenv("MADRONA_MWHIP_PHYS_MAX_BODIES", block)
     monkeypatch.setenv("MADRONA_MWHIP_MAX_CANDIDATES_PER_WORLD", "4096")
     monkeypatch.setenv("MADRONA_MWHIP_MAX_CONTACTS_PER_WORLD", "1024")
     flags = (1 << 26) | (crowded << 27) | (150 << 16)
@@ -140,7 +146,8 @@ def test_one_crowded_world_falls_back_to_the_hbm_step(built, monkeypatch, worlds
         assert counts[crowded] == 14 + 150 and counts.sum() == 14 * worlds + 150
 
 
-def test_contacts_beyond_the_lds_block_fall_back(built, monkeypatch):
+@pytest.mark.parametrize("cap,lanes", [("20", ""), ("1", ""), ("20", "64")])
+def test_contacts_beyond_the_lds_block_fall_back(built, monkeypatch, cap, lanes):
     """The other capacity of the LDS block: more contacts in a substep than it
     has room for (64 with the 32-body block).  19-body ball_pit worlds forced
     into a tight pit pile up more; seed 11 is the one that used to raise
@@ -149,7 +156,9 @@ def test_contacts_beyond_the_lds_block_fall_back(built, monkeypatch):
     within a few steps in many worlds -- they take the HBM step for that step
     and stay in lock step; with it at 1 every world with a contact does."""
     _need_ref("ball_pit")
-    monkeypatch.setenv("MADRONA_MWHIP_PHYS_LDS_CONTACTS", "20")
+    monkeypatch.setenv("MADRONA_MWHIP_PHYS_LDS_CONTACTS", cap)
+    if lanes:
+        monkeypatch.setenv("MADRONA_MWHIP_PHYS_LANES", lanes)
     probs, step = run_pair("ball_pit", 96, 60, flags=40, seed=11, check_every=5,
                            check_init=False)
     assert not probs, (step, probs[:3])
@@ -391,6 +400,21 @@ def test_breadth_first_bvh_rebuild_equals_the_stack_machine(built, monkeypatch, 
                            actions=_escape_actions(worlds + 2, grab=True, agents=agents)
                            if agents else None,
                            check_init=False, ref_workers=0)
+    assert not probs, (step, probs[:3])
+
+
+@pytest.mark.parametrize("sim,worlds,steps,flags", [("escape_room_phys", 96, 50, 25),
+                                                    ("sort_stress", 200, 30, 0)])
+def test_eager_replay_is_the_same_step(built, monkeypatch, sim, worlds, steps, flags):
+    """MADRONA_MWHIP_EAGER=1 (the launches of a step issued one by one
+    on the stream instead of the instantiated hipGraph -- a measurement switch):
+    the same kernels in the same order, so the same results."""
+    _need_ref(sim)
+    monkeypatch.setenv("MADRONA_MWHIP_EAGER", "1")
+    probs, step = run_pair(sim, worlds, steps, flags=flags, check_every=10,
+                           actions=_escape_actions(worlds + 4, grab=True)
+                           if sim == "escape_room_phys" else None,
+                           check_init=False)
     assert not probs, (step, probs[:3])
 
 
