@@ -38,11 +38,18 @@ if __name__ == "__main__":
             e = dict(os.environ)
             e["MADRONA_HIP_BUILD_DIR"] = v.get("build", "_build")
             e.update(v.get("env", {}))
-            out = subprocess.run([sys.executable, "-c", CHILD, v["sim"],
-                                  str(v["worlds"]), v.get("kernels", "worldStep")],
-                                 env=e, capture_output=True, text=True)
-            line = [l for l in out.stdout.splitlines() if l.startswith("{")]
-            rec = json.loads(line[-1]) if line else {"error": out.stderr[-600:]}
+            # (a variant that hangs must not take the GPU call with it: round 5
+            # lost 25 GPU-minutes to ROC_SYSTEM_SCOPE_SIGNAL=0)
+            try:
+                out = subprocess.run([sys.executable, "-c", CHILD, v["sim"],
+                                      str(v["worlds"]), v.get("kernels", "worldStep")],
+                                     env=e, capture_output=True, text=True,
+                                     timeout=float(v.get("timeout", 240)))
+                line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+                rec = (json.loads(line[-1]) if line else
+                       {"error": out.stderr[-600:]})
+            except subprocess.TimeoutExpired:
+                rec = {"error": "timed out"}
             rec.update(label=v["label"], build=v.get("build", "_build"),
                        env=v.get("env", {}), repeat=rep)
             print(json.dumps(rec), flush=True)
