@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MWHIP_ABI_VERSION 4u   /* 4: mwhip_node_desc / mwhip_kernel_stat grew io_declared (declared read / write sets) */
+#define MWHIP_ABI_VERSION 5u   /* 5: mwhip_node_desc::pfor_body, mwhip_pfor_body(), mwhip_set_pfor_group_kernel() (side-by-side ParallelFor nodes in one launch); 4: io_declared */
 
 typedef struct mwhip_exec mwhip_exec; /* opaque; == MWCudaExecutor::Impl */
 
@@ -315,7 +315,28 @@ typedef struct mwhip_node_desc {
      * (0: const T & = read, T & = read + write -- an upper bound).  SURVEY §8d;
      * the reference's per-row contract is device taskgraph.inl:164-300. */
     uint32_t io_declared;
+    /* ParallelFor nodes (items_per_invocation == 1): device address of the
+     * node's body as a __device__ function (mwhip_pfor_body), or NULL.  Nodes
+     * that name the SAME dependencies, cannot append rows and carry a body are
+     * run side by side in ONE launch of the simulator's group kernel
+     * (mwhip_set_pfor_group_kernel): blockIdx.y selects the node.  The reference
+     * runs independent nodes of its task graph one after the other
+     * (device taskgraph.cpp:142-317); results are the same by the independence
+     * the simulator declared with its dependency lists. */
+    const void *pfor_body;
 } mwhip_node_desc;
+
+/* Members of a grouped launch, in device memory (the group kernel's argument). */
+#define MWHIP_PFOR_GROUP_MAX 6
+typedef struct mwhip_pfor_group {
+    uint32_t count;
+    uint32_t pad_;
+    const void *body[MWHIP_PFOR_GROUP_MAX];        /* void (*)(ecs_state *, uint32_t,
+                                                     * uint32_t, const mwhip_pfor_args *) */
+    uint32_t query_offset[MWHIP_PFOR_GROUP_MAX];
+    uint32_t num_matching_and_flags[MWHIP_PFOR_GROUP_MAX];
+    mwhip_pfor_args query[MWHIP_PFOR_GROUP_MAX];
+} mwhip_pfor_group;
 
 /* (the reference's TaskGraph::maxNodeDataBytes is 256; larger here because a
  * node's data is what its kernel reaches with one load from its arguments) */
@@ -335,6 +356,17 @@ void *mwhip_tg_node_data(mwhip_exec *exec, uint32_t taskgraph_id, int32_t data_i
 int32_t mwhip_tg_add_node(mwhip_exec *exec, uint32_t taskgraph_id,
                           const mwhip_node_desc *desc, const int32_t *deps,
                           uint32_t num_deps);
+
+/* Device address of a ParallelFor kernel's body: launches `kernel` (host stub of
+ * a parallelForKernel instantiation) once in its report mode
+ * (num_matching_and_flags = 0xFFFFFFFF: thread 0 stores the address of the
+ * instantiation's __device__ body at node_data_dev and returns).  NULL on
+ * error. */
+const void *mwhip_pfor_body(mwhip_exec *exec, const void *kernel);
+/* The simulator's group kernel -- __global__ void(ecs_state *, const
+ * mwhip_pfor_group *), in the SAME code object as the bodies (device function
+ * addresses are only called from the module that defines them). */
+int mwhip_set_pfor_group_kernel(mwhip_exec *exec, const void *kernel);
 
 /* compute units of the executor's device (kernel nodes that size a persistent
  * grid themselves) */

@@ -23,6 +23,7 @@
 #include <thread>
 #include <cstdio>
 #include <cstdlib>
+#include <map>
 #include <memory>
 #include <unordered_map>
 
@@ -640,6 +641,8 @@ struct mwhip_exec {
     uint32_t sortCompaction = 1;
     uint32_t rowSnapshotMode = 1;   // 0 never, 1 nodes that can append rows, 2 all
     bool eagerReplay = false;       // MADRONA_MWHIP_EAGER (measurement, replayGraph)
+    const void *pforGroupKernel = nullptr;  // mwhip_set_pfor_group_kernel
+    void *pforBodyScratch = nullptr;        // 8 bytes: where report mode writes
     // MADRONA_MWHIP_EXEC_CONFIG_FILE (the reference's
     // MADRONA_MWGPU_EXEC_CONFIG_FILE, cuda_exec.cpp:2115-2172): per task-graph
     // node (index in execution order) the workgroups per CU its kernel may
@@ -2145,6 +2148,11 @@ static int buildLaunchList(mwhip_exec *exec, const std::vector<uint32_t> &tg_ids
                         k.dynamicLds = 4u * d.num_matching;
                     }
                     k.pushArg(pa);
+                    k.pforArgs = pa;
+                    k.rowSnapshot = pa.row_sync != nullptr;
+                    k.pforBody = d.pfor_body;
+                    k.pforArg1 = d.arg1;
+                    k.pforVgprs = (uint32_t)std::max(attr.numRegs, 0);
                 }
                 k.name = node.name;
                 k.role = "";
@@ -2177,6 +2185,9 @@ static int buildLaunchList(mwhip_exec *exec, const std::vector<uint32_t> &tg_ids
                         exec->nodeWorkgroupsPerCU[oi] * exec->numCUs);
                 }
                 k.nodeIndex = (uint32_t)oi;
+                k.dagKernel = true;
+                k.tgId = tg_id;
+                k.tgNode = order[oi];
                 lg.launches.push_back(k);
             } break;
             case MWHIP_NODE_SORT_ARCHETYPE: {
@@ -2912,6 +2923,41 @@ extern "C" void *mwhip_tg_node_data(mwhip_exec *exec, uint32_t tg_id,
     return tg.dataDev[data_id];
 }
 
+extern "C" const void *mwhip_pfor_body(mwhip_exec *exec, const void *kernel)
+{
+    if (kernel == nullptr) return nullptr;
+    if (exec->pforBodyScratch == nullptr) {
+        if (devAlloc(exec, &exec->pforBodyScratch, 16) != 0) return nullptr;
+    }
+    if (hipMemsetAsync(exec->pforBodyScratch, 0, 16, exec->stream) != hipSuccess) {
+        return nullptr;
+    }
+    EcsState *state = exec->stateDev;
+    void *report_to = exec->pforBodyScratch;
+    uint32_t query_offset = 0, report_mode = 0xFFFFFFFFu;
+    mwhip_pfor_args none {};
+    void *args[] = { &state, &report_to, &query_offset, &report_mode, &none };
+    if (hipLaunchKernel(kernel, dim3(1, 1, 1), dim3(64, 1, 1), args, 0,
+                        exec->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    const void *body = nullptr;
+    if (hipStreamSynchronize(exec->stream) != hipSuccess ||
+            hipMemcpy(&body, exec->pforBodyScratch, sizeof(body),
+                      hipMemcpyDeviceToHost) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return body;
+}
+
+extern "C" int mwhip_set_pfor_group_kernel(mwhip_exec *exec, const void *kernel)
+{
+    exec->pforGroupKernel = kernel;
+    return 0;
+}
+
 extern "C" int32_t mwhip_tg_add_node(mwhip_exec *exec, uint32_t tg_id,
                                      const mwhip_node_desc *desc,
                                      const int32_t *deps, uint32_t num_deps)
@@ -3155,6 +3201,150 @@ static void releaseLaunchGraph(LaunchGraph &lg)
     lg.ownedAllocations.clear();
 }
 
+// ParallelFor nodes that named the same dependencies -- the simulator's statement
+// that they do not depend on one another -- become ONE launch of the simulator's
+// group kernel (taskgraph.inl pforGroupKernel: blockIdx.y = the node): a launch
+// is ~4 us on this stack whatever it does, a group of k nodes saves k - 1 of
+// them.  Only nodes that cannot append rows (no row snapshot) and carry a body;
+// consecutive in the builder's order.  MADRONA_MWHIP_GROUP=0: every node its own
+// launch (rounds 1-4).
+static int groupLaunches(mwhip_exec *exec, LaunchGraph &lg)
+{
+    if (envU32("MADRONA_MWHIP_GROUP", 1) == 0 || exec->pforGroupKernel == nullptr ||
+            exec->eagerReplay) {
+        return 0;
+    }
+    // A member is reached through a function pointer: the shared kernel is
+    // compiled for the registers of the heaviest body in the module and a body
+    // runs out of line.  Row functions of a few loads and stores do not notice;
+    // a long one does (the portable lidar system, 121 VGPRs, next to
+    // collectObservations: step + 38 us, profiles/r05_group_variants.jsonl), so
+    // a node whose own kernel needs more than this many VGPRs keeps its launch.
+    const uint32_t max_vgprs = envU32("MADRONA_MWHIP_GROUP_MAX_VGPRS", 96);
+    auto groupable = [&](const KernelLaunch &k) {
+        return k.dagKernel && k.pforBody != nullptr && !k.rowSnapshot &&
+            k.pforVgprs <= max_vgprs &&
+            k.countMode == MWHIP_COUNT_QUERY_ROWS && k.tgNode >= 0 &&
+            k.tgId < exec->taskGraphs.size();
+    };
+    auto depsOf = [&](const KernelLaunch &k) {
+        std::vector<int32_t> d = exec->taskGraphs[k.tgId].nodes[(size_t)k.tgNode].deps;
+        std::sort(d.begin(), d.end());
+        d.erase(std::unique(d.begin(), d.end()), d.end());
+        return d;
+    };
+    std::vector<KernelLaunch> out;
+    for (size_t i = 0; i < lg.launches.size(); ) {
+        size_t j = i + 1;
+        if (groupable(lg.launches[i])) {
+            const std::vector<int32_t> deps = depsOf(lg.launches[i]);
+            while (j < lg.launches.size() && j - i < MWHIP_PFOR_GROUP_MAX &&
+                   groupable(lg.launches[j]) &&
+                   lg.launches[j].tgId == lg.launches[i].tgId &&
+                   depsOf(lg.launches[j]) == deps) {
+                j++;
+            }
+        }
+        if (j - i < 2) {
+            out.push_back(lg.launches[i]);
+            i = j;
+            continue;
+        }
+        mwhip_pfor_group group {};
+        group.count = (uint32_t)(j - i);
+        KernelLaunch g;
+        g.fn = exec->pforGroupKernel;
+        uint32_t threads = 0;
+        std::string name = "group[";
+        for (size_t m = i; m < j; m++) {
+            const KernelLaunch &k = lg.launches[m];
+            group.body[m - i] = k.pforBody;
+            group.query_offset[m - i] = k.queryOffset;
+            group.num_matching_and_flags[m - i] = k.pforArg1;
+            group.query[m - i] = k.pforArgs;
+            threads = std::max(threads, k.grid.x * k.block.x);
+            name += (m == i ? "" : " | ") + k.name;
+            g.members.push_back({ k.name, k.queryOffset, k.bytesPerRow, k.ioDeclared });
+        }
+        name += "]";
+        mwhip_pfor_group *group_dev = nullptr;
+        int rc = devAllocT(exec, &group_dev, 1);
+        if (rc != 0) return rc;
+        HIPCHK(hipMemcpy(group_dev, &group, sizeof(group), hipMemcpyHostToDevice));
+        g.grid = dim3(std::max((threads + 255u) / 256u, 1u), group.count, 1);
+        g.block = dim3(256, 1, 1);
+        g.setArgs(exec->stateDev, (const mwhip_pfor_group *)group_dev);
+        g.name = name;
+        g.role = "";
+        g.kind = MWHIP_NODE_KERNEL;
+        g.countMode = MWHIP_COUNT_QUERY_ROWS;
+        g.ioDeclared = 1;
+        for (const auto &mem : g.members) {
+            g.ioDeclared = g.ioDeclared && mem.ioDeclared != 0u ? 1u : 0u;
+        }
+        g.nodeIndex = lg.launches[i].nodeIndex;
+        // (waits for what its members named; everything that named a member
+        // waits for it: the group stands in the chain where its first member
+        // stood, the others were right behind it)
+        g.dagKernel = false;
+        out.push_back(g);
+        i = j;
+    }
+    lg.launches.swap(out);
+    return 0;
+}
+
+// Edges of the step's DAG (KernelLaunch::deps).  Launches are in the builder's
+// topological order; a task-graph kernel node depends on the launches of the
+// nodes it named, everything else is a barrier.  OFF by default
+// (MADRONA_MWHIP_DAG=1 turns it on): measured, branches of a hipGraph cost more
+// than the launches they overlap on this runtime -- configs[1] 141 -> 170 us per
+// step, configs[2] 1.110 -> 1.190 ms (profiles/r05_dag_variants.jsonl) --, so
+// the step stays a chain and nodes that may run side by side share ONE launch
+// instead (groupLaunches).
+static void buildLaunchDeps(mwhip_exec *exec, LaunchGraph &lg)
+{
+    const bool dag = envU32("MADRONA_MWHIP_DAG", 0) != 0 && !exec->eagerReplay;
+    std::map<std::pair<uint32_t, int32_t>, int32_t> launch_of_node;
+    int32_t barrier = -1;
+    std::vector<int32_t> leaves;    // launches since the barrier nobody waits for yet
+    for (size_t i = 0; i < lg.launches.size(); i++) {
+        KernelLaunch &k = lg.launches[i];
+        k.deps.clear();
+        if (dag && k.dagKernel && k.tgId < exec->taskGraphs.size() &&
+                k.tgNode >= 0) {
+            const TaskGraphRec &tg = exec->taskGraphs[k.tgId];
+            for (int32_t d : tg.nodes[(size_t)k.tgNode].deps) {
+                auto it = launch_of_node.find({ k.tgId, d });
+                // (a dependency at or before the barrier is implied by it: every
+                // launch after a barrier waits for it, directly or not)
+                if (it != launch_of_node.end() && it->second > barrier &&
+                        std::find(k.deps.begin(), k.deps.end(), it->second) ==
+                            k.deps.end()) {
+                    k.deps.push_back(it->second);
+                }
+            }
+            if (k.deps.empty() && barrier >= 0) {
+                k.deps.push_back(barrier);
+            }
+            for (int32_t d : k.deps) {
+                leaves.erase(std::remove(leaves.begin(), leaves.end(), d),
+                             leaves.end());
+            }
+            leaves.push_back((int32_t)i);
+            launch_of_node[{ k.tgId, k.tgNode }] = (int32_t)i;
+        } else {
+            if (!leaves.empty()) {
+                k.deps = leaves;
+            } else if (barrier >= 0) {
+                k.deps.push_back(barrier);
+            }
+            barrier = (int32_t)i;
+            leaves.clear();
+        }
+    }
+}
+
 static int instantiateLaunchGraph(mwhip_exec *exec,
                                   const std::vector<uint32_t> &ids,
                                   const std::string &stat_name,
@@ -3219,19 +3409,39 @@ static int instantiateLaunchGraph(mwhip_exec *exec,
 #ifdef MADRONA_TRACING
     rc = addTraceMarkers(exec, *lg);
     if (rc != 0) return rc;
+    // (a traced step logs kernel after kernel: no side-by-side launches)
+    for (KernelLaunch &k : lg->launches) {
+        k.dagKernel = false;
+    }
 #endif
 
-    HIPCHK(hipStreamBeginCapture(exec->stream, hipStreamCaptureModeThreadLocal));
-    for (KernelLaunch &k : lg->launches) {
-        rc = launchOne(exec, k, exec->stream);
-        if (rc != 0) {
-            hipGraph_t dead = nullptr;
-            (void)hipStreamEndCapture(exec->stream, &dead);
-            if (dead) (void)hipGraphDestroy(dead);
-            return rc;
+    rc = groupLaunches(exec, *lg);
+    if (rc != 0) return rc;
+    buildLaunchDeps(exec, *lg);
+
+    // The step as an explicit hipGraph: one kernel node per launch, edges from
+    // buildLaunchDeps.  (Rounds 1-4 captured the launches from the stream: a
+    // chain, whatever the task graph said.)
+    HIPCHK(hipGraphCreate(&lg->graph, 0));
+    std::vector<hipGraphNode_t> nodes(lg->launches.size(), nullptr);
+    for (size_t i = 0; i < lg->launches.size(); i++) {
+        KernelLaunch &k = lg->launches[i];
+        void *args[8];
+        k.argPointers(args);
+        hipKernelNodeParams params {};
+        params.func = const_cast<void *>(k.fn);
+        params.gridDim = k.grid;
+        params.blockDim = k.block;
+        params.sharedMemBytes = k.dynamicLds;
+        params.kernelParams = args;
+        params.extra = nullptr;
+        std::vector<hipGraphNode_t> deps;
+        for (int32_t d : k.deps) {
+            deps.push_back(nodes[(size_t)d]);
         }
+        HIPCHK(hipGraphAddKernelNode(&nodes[i], lg->graph, deps.data(),
+                                     deps.size(), &params));
     }
-    HIPCHK(hipStreamEndCapture(exec->stream, &lg->graph));
     HIPCHK(hipGraphInstantiate(&lg->graphExec, lg->graph, nullptr, nullptr, 0));
     out = std::move(lg);
     return 0;
@@ -4244,19 +4454,32 @@ extern "C" int32_t mwhip_profile(mwhip_exec *exec, uint64_t graph, uint32_t reps
             if (k.kind == MWHIP_NODE_KERNEL &&
                     k.countMode == MWHIP_COUNT_QUERY_ROWS) {
                 // rows at the start of the step (steady-state approximation)
-                double nrows = 0;
-                for (const QueryRec &q : exec->queries) {
-                    if (q.offset != k.queryOffset) continue;
-                    const uint32_t *p =
-                        exec->queryDataHost.data() + q.offset;
-                    for (uint32_t m = 0; m < q.numMatching; m++) {
-                        nrows += rows[p[0]];
-                        p += 1 + q.comps.size();
+                auto rowsOf = [&](uint32_t query_offset) {
+                    double nrows = 0;
+                    for (const QueryRec &q : exec->queries) {
+                        if (q.offset != query_offset) continue;
+                        const uint32_t *p =
+                            exec->queryDataHost.data() + q.offset;
+                        for (uint32_t m = 0; m < q.numMatching; m++) {
+                            nrows += rows[p[0]];
+                            p += 1 + q.comps.size();
+                        }
+                        break;
                     }
-                    break;
+                    return nrows;
+                };
+                if (k.members.empty()) {
+                    const double nrows = rowsOf(k.queryOffset);
+                    total_rows[i] += nrows;
+                    total_bytes[i] += nrows * k.bytesPerRow;
+                } else {
+                    // a grouped launch: the sum over its nodes
+                    for (const KernelLaunch::Member &mem : k.members) {
+                        const double nrows = rowsOf(mem.queryOffset);
+                        total_rows[i] += nrows;
+                        total_bytes[i] += nrows * mem.bytesPerRow;
+                    }
                 }
-                total_rows[i] += nrows;
-                total_bytes[i] += nrows * k.bytesPerRow;
             }
         }
     }

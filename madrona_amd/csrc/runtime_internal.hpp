@@ -201,6 +201,29 @@ struct KernelLaunch {
     SortRole sortRole = SortRole::None;
     bool carriesMisc = false;       // trailing (ops, count) arguments were pushed
 
+    // ---- the launch's place in the step's DAG (buildLaunchDeps) ----
+    // A kernel node of a task graph (ParallelFor / custom kernel) waits for the
+    // launches of the nodes IT NAMED as dependencies, like the reference's
+    // builder orders them -- nodes that name the same dependency may run side
+    // by side --; every other launch (sorts, misc ops, the runtime's own
+    // kernels) waits for everything before it and everything after waits for it.
+    bool dagKernel = false;
+    uint32_t tgId = 0;              // task graph the node belongs to
+    int32_t tgNode = -1;            // node id inside it (mwhip_tg_add_node's return)
+    std::vector<int32_t> deps;      // indices into LaunchGraph::launches
+
+    // ---- side-by-side ParallelFor nodes in one launch (groupLaunches) ----
+    const void *pforBody = nullptr;         // mwhip_node_desc::pfor_body
+    uint32_t pforArg1 = 0;                  // num_matching | exclusive-world flag
+    bool rowSnapshot = false;               // the node can append rows: never grouped
+    uint32_t pforVgprs = 0;                 // of the node's own kernel (groupLaunches)
+    mwhip_pfor_args pforArgs {};
+    struct Member {                         // of a grouped launch (profiles)
+        std::string name;
+        uint32_t queryOffset, bytesPerRow, ioDeclared;
+    };
+    std::vector<Member> members;
+
     template <typename T>
     void pushArg(const T &v)
     {

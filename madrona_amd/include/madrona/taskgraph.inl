@@ -238,13 +238,91 @@ MADRONA_DEVICE inline void pforRowSnapshot(EcsState *S, PforRowSync *sync,
 template <auto Fn>
 inline constexpr unsigned systemWavesPerSIMD = 0;
 
+// ---- a node's body as a __device__ function ----------------------------------
+// Nodes that named the same dependencies and cannot append rows are run side by
+// side in ONE launch (pforGroupKernel below, blockIdx.y = the node): a launch is
+// ~4 us on this stack whatever it does (an empty kernel event-times at 4.0 us in
+// the step graph), and branches of a hipGraph cost more than
+// they save (15.7).  The group kernel reaches a node through the address of this
+// function (mwhip_node_desc::pfor_body, handed out by the kernel's report mode).
+using PforBodyFn = void (*)(EcsState *, uint32_t, uint32_t, const mwhip_pfor_args *);
+
+template <typename ContextT, auto Fn, int32_t threads_per_invocation,
+          typename... ComponentTs>
+__device__ __attribute__((noinline)) void parallelForBody(
+    EcsState *S, uint32_t query_offset, uint32_t num_matching_and_flags,
+    const mwhip_pfor_args *query_ptr)
+{
+    constexpr size_t N = sizeof...(ComponentTs);
+    const uint32_t num_matching = num_matching_and_flags & 0x7FFFFFFFu;
+    const bool exclusive_world = (num_matching_and_flags >> 31) != 0u;
+    StateManager *state_mgr = static_cast<StateManager *>(S);
+    const mwhip_pfor_args &query = *query_ptr;
+
+    // (never with a row snapshot: nodes that can append rows are not grouped)
+    if (query.num_inline == num_matching) {
+        int32_t num_rows[MWHIP_PFOR_MAX_INLINE];
+MADRONA_UNROLL
+        for (uint32_t a = 0; a < MWHIP_PFOR_MAX_INLINE; a++) {
+            num_rows[a] = a >= num_matching ? 0 :
+                ((const TableHdr *)query.tables[a])->numRows;
+        }
+        int32_t rows_before = 0;
+MADRONA_UNROLL
+        for (uint32_t a = 0; a < MWHIP_PFOR_MAX_INLINE; a++) {
+            if (a < num_matching) {
+                parallelForTable<ContextT, Fn, threads_per_invocation,
+                                 ComponentTs...>(
+                    state_mgr, *(TableHdr *)query.tables[a], query.columns[a],
+                    exclusive_world, num_rows[a], rows_before);
+                rows_before += num_rows[a];
+            }
+        }
+        return;
+    }
+    const uint32_t *query_values = S->queryData + query_offset;
+    for (uint32_t a = 0; a < num_matching; a++) {
+        uint16_t col_indices[N > 0 ? N : 1];
+MADRONA_UNROLL
+        for (size_t c = 0; c < N; c++) {
+            col_indices[c] = (uint16_t)query_values[1 + c];
+        }
+        TableHdr &tbl = S->tables[query_values[0]];
+        parallelForTable<ContextT, Fn, threads_per_invocation,
+                         ComponentTs...>(
+            state_mgr, tbl, col_indices, exclusive_world, tbl.numRows, 0);
+        query_values += 1 + N;
+    }
+}
+
+// blockIdx.y = member of the group; every member strides over its rows with the
+// launch's x grid
+template <int Unused = 0>     // (a template: one definition however often included)
+__global__ void __launch_bounds__(256)
+pforGroupKernel(EcsState *S, const mwhip_pfor_group *group)
+{
+    TraceScope trace_scope(S);
+    const uint32_t m = blockIdx.y;
+    const PforBodyFn body = (PforBodyFn)loadInvariant(&group->body[m]);
+    body(S, loadInvariant(&group->query_offset[m]),
+         loadInvariant(&group->num_matching_and_flags[m]), &group->query[m]);
+}
+
 template <typename ContextT, auto Fn, int32_t threads_per_invocation,
           typename... ComponentTs>
 __global__ void __launch_bounds__(256)
 __attribute__((amdgpu_waves_per_eu(systemWavesPerSIMD<Fn>)))
-parallelForKernel(EcsState *S, void *, uint32_t query_offset,
+parallelForKernel(EcsState *S, void *report_to, uint32_t query_offset,
                   uint32_t num_matching_and_flags, mwhip_pfor_args query)
 {
+    if (num_matching_and_flags == 0xFFFFFFFFu) {
+        // report mode (mwhip_pfor_body): where this node's body lives
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            *(PforBodyFn *)report_to = &parallelForBody<
+                ContextT, Fn, threads_per_invocation, ComponentTs...>;
+        }
+        return;
+    }
     TraceScope trace_scope(S);
     constexpr size_t N = sizeof...(ComponentTs);
     extern __shared__ int32_t pfor_snapshot_rows[];
@@ -611,8 +689,13 @@ CustomParallelForNode<ContextT, Fn, threads_per_invocation,
                 ComponentTs...>;
         }
     };
+    // (this module's group kernel: side-by-side nodes in one launch)
+    [[maybe_unused]] auto group_stub = [] __host__ () -> const void * {
+        return (const void *)&mwhip::pforGroupKernel<0>;
+    };
 #else
     auto kernel_stub = []() -> const void * { return nullptr; };
+    [[maybe_unused]] auto group_stub = []() -> const void * { return nullptr; };
 #endif
 
 #if MADRONA_ON_HOST
@@ -637,6 +720,13 @@ CustomParallelForNode<ContextT, Fn, threads_per_invocation,
     desc.query_offset = ref->offset;
     desc.num_matching = ref->numMatchingArchetypes;
     desc.threads_per_invocation = (uint32_t)threads_per_invocation;
+#if defined(__HIPCC__)
+    if constexpr (items_per_invocation == 1) {
+        // the node's body for grouped launches, and this module's group kernel
+        desc.pfor_body = mwhip_pfor_body(builder.exec(), desc.kernel);
+        (void)mwhip_set_pfor_group_kernel(builder.exec(), group_stub());
+    }
+#endif
 
     if constexpr (mwhip::systemIO<Fn>.read >= 0) {
         // declared next to the system

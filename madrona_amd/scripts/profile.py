@@ -63,6 +63,9 @@ def measure(args, per_cu):
     (None: the executor's default launch)."""
     env = dict(os.environ)
     env.pop("MADRONA_MWHIP_EXEC_CONFIG_FILE", None)
+    # every node timed in its own launch (the step itself puts nodes that named
+    # the same dependencies into one, sized for the largest of their grids)
+    env["MADRONA_MWHIP_GROUP"] = "0"
     tmp = None
     if per_cu is not None:
         tmp = tempfile.NamedTemporaryFile("w", suffix=".json", delete=False)

@@ -917,6 +917,14 @@ ESCAPE_SYSTEM_IO(lidarSystem,
 namespace escape {
 #endif
 
+// The dependencies are the real ones, not a chain: the button -> door chain, the
+// reward and the step counter all follow the kinematic step and touch disjoint
+// components (ButtonState / OpenState / door Position; Progress / Reward;
+// StepsRemaining / Done -- the agents' Position is only read); observations and
+// lidar both only read the state the step left.  A backend that runs nodes one
+// after the other in the builder's order (the reference's) is unaffected; the
+// MI355X executor runs nodes that wait for the same launches side by side
+// (DESIGN.md section 15.7).
 void Sim::setupTasks(TaskGraphManager &taskgraph_mgr, const Config &)
 {
     TaskGraphBuilder &builder = taskgraph_mgr.init(0);
@@ -948,6 +956,21 @@ void Sim::setupTasks(TaskGraphManager &taskgraph_mgr, const Config &)
             ButtonState
         >>({kinematic_sys});
 
+    auto reward_sys = builder.addToGraph<ParallelForNode<Engine,
+        rewardSystem,
+            Position,
+            Progress,
+            Reward
+        >>({kinematic_sys});
+
+    auto done_sys = builder.addToGraph<ParallelForNode<Engine,
+        stepTrackerSystem,
+            StepsRemaining,
+            Done
+        >>({kinematic_sys});
+
+    // (the door chain is registered behind the nodes that share the button
+    // system's dependency: the executor runs those in one launch)
     auto door_open_sys = builder.addToGraph<ParallelForNode<Engine,
         doorOpenSystem,
             OpenState,
@@ -960,19 +983,6 @@ void Sim::setupTasks(TaskGraphManager &taskgraph_mgr, const Config &)
             OpenState
         >>({door_open_sys});
 
-    auto reward_sys = builder.addToGraph<ParallelForNode<Engine,
-        rewardSystem,
-            Position,
-            Progress,
-            Reward
-        >>({set_door_pos_sys});
-
-    auto done_sys = builder.addToGraph<ParallelForNode<Engine,
-        stepTrackerSystem,
-            StepsRemaining,
-            Done
-        >>({reward_sys});
-
 #ifdef SIM_WAVE_API
     // 64 lanes per world: lane i resets entity i (resetWorldWave)
     auto reset_sys = builder.addToGraph<CustomParallelForNode<Engine,
@@ -982,7 +992,7 @@ void Sim::setupTasks(TaskGraphManager &taskgraph_mgr, const Config &)
         resetSystem,
 #endif
             WorldReset
-        >>({done_sys});
+        >>({set_door_pos_sys, reward_sys, done_sys});
 
 #ifdef MADRONA_GPU_MODE
     auto recycle_sys = builder.addToGraph<RecycleEntitiesNode>({reset_sys});
@@ -1015,8 +1025,9 @@ void Sim::setupTasks(TaskGraphManager &taskgraph_mgr, const Config &)
         lidarSystem,
             Entity,
             Lidar
-        >>({collect_obs});
+        >>({compact_buttons});
 
+    (void)collect_obs;
     (void)lidar;
 }
 

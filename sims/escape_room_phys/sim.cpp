@@ -1296,14 +1296,17 @@ void Sim::setupTasks(TaskGraphManager &taskgraph_mgr, const Config &)
     auto substep_sys = PhysicsSystem::setupPhysicsStepTasks(builder,
         {grab_sys}, consts::numPhysicsSubsteps);
 
+    // (the real dependencies, not a chain -- sims/escape_room/sim.cpp: zeroing
+    // the agents' velocities, the button -> door chain, the reward and the step
+    // counter all follow the physics step and touch disjoint components)
+    auto phys_done =
+        PhysicsSystem::setupCleanupTasks(builder, {substep_sys});
+
     auto agent_zero_vel = builder.addToGraph<ParallelForNode<Engine,
         agentZeroVelSystem,
             Velocity,
             Action
-        >>({substep_sys});
-
-    auto phys_done =
-        PhysicsSystem::setupCleanupTasks(builder, {agent_zero_vel});
+        >>({phys_done});
 
     auto button_sys = builder.addToGraph<ParallelForNode<Engine,
         buttonSystem,
@@ -1311,6 +1314,21 @@ void Sim::setupTasks(TaskGraphManager &taskgraph_mgr, const Config &)
             ButtonState
         >>({phys_done});
 
+    auto reward_sys = builder.addToGraph<ParallelForNode<Engine,
+        rewardSystem,
+            Position,
+            Progress,
+            Reward
+        >>({phys_done});
+
+    auto done_sys = builder.addToGraph<ParallelForNode<Engine,
+        stepTrackerSystem,
+            StepsRemaining,
+            Done
+        >>({phys_done});
+
+    // (the door chain is registered behind the nodes that share the button
+    // system's dependency: the executor runs those in one launch)
     auto door_open_sys = builder.addToGraph<ParallelForNode<Engine,
         doorOpenSystem,
             OpenState,
@@ -1323,19 +1341,6 @@ void Sim::setupTasks(TaskGraphManager &taskgraph_mgr, const Config &)
             OpenState
         >>({door_open_sys});
 
-    auto reward_sys = builder.addToGraph<ParallelForNode<Engine,
-        rewardSystem,
-            Position,
-            Progress,
-            Reward
-        >>({set_door_pos_sys});
-
-    auto done_sys = builder.addToGraph<ParallelForNode<Engine,
-        stepTrackerSystem,
-            StepsRemaining,
-            Done
-        >>({reward_sys});
-
 #ifdef SIM_WAVE_API
     // 64 lanes per world: lane i resets entity i (resetWorldWave)
     auto reset_sys = builder.addToGraph<CustomParallelForNode<Engine,
@@ -1345,7 +1350,7 @@ void Sim::setupTasks(TaskGraphManager &taskgraph_mgr, const Config &)
         resetSystem,
 #endif
             WorldReset
-        >>({done_sys});
+        >>({agent_zero_vel, set_door_pos_sys, reward_sys, done_sys});
 
 #ifdef MADRONA_GPU_MODE
     auto recycle_sys = builder.addToGraph<RecycleEntitiesNode>({reset_sys});
@@ -1387,13 +1392,14 @@ void Sim::setupTasks(TaskGraphManager &taskgraph_mgr, const Config &)
 #endif
             Entity,
             Lidar
-        >>({collect_obs});
+        >>({post_reset_broadphase});      // (beside the observations: both only read)
 
+    (void)collect_obs;
     (void)lidar;
 
 #ifdef ESCPHYS_RENDER
     // instance / view records, Morton order, world grouping for the ray caster
-    RenderingSystem::setupTasks(builder, {lidar}, false);
+    RenderingSystem::setupTasks(builder, {collect_obs, lidar}, false);
 #endif
 }
 

@@ -1007,14 +1007,16 @@ void Sim::setupTasks(TaskGraphManager &taskgraph_mgr, const Config &)
     auto substep_sys = PhysicsSystem::setupPhysicsStepTasks(builder,
         {lock_sys}, consts::numPhysicsSubsteps);
 
+    // (the real dependencies, not a chain -- sims/escape_room/sim.cpp: the
+    // velocity reset and the step counter touch different components)
+    auto phys_done =
+        PhysicsSystem::setupCleanupTasks(builder, {substep_sys});
+
     auto agent_zero_vel = builder.addToGraph<ParallelForNode<Engine,
         agentZeroVelSystem,
             Velocity,
             Action
-        >>({substep_sys});
-
-    auto phys_done =
-        PhysicsSystem::setupCleanupTasks(builder, {agent_zero_vel});
+        >>({phys_done});
 
     auto done_sys = builder.addToGraph<ParallelForNode<Engine,
         stepTrackerSystem,
@@ -1031,7 +1033,7 @@ void Sim::setupTasks(TaskGraphManager &taskgraph_mgr, const Config &)
         resetSystem,
 #endif
             WorldReset
-        >>({done_sys});
+        >>({agent_zero_vel, done_sys});
 
 #ifdef MADRONA_GPU_MODE
     auto recycle_sys = builder.addToGraph<RecycleEntitiesNode>({reset_sys});
@@ -1087,7 +1089,7 @@ void Sim::setupTasks(TaskGraphManager &taskgraph_mgr, const Config &)
             AgentObservations,
             BoxObservations,
             RampObservations
-        >>({reward_sys});
+        >>({visibility_sys});     // (beside the reward: both read Visibility)
 
 #ifdef MADRONA_GPU_MODE
     auto lidar = builder.addToGraph<CustomParallelForNode<Engine,
@@ -1098,8 +1100,10 @@ void Sim::setupTasks(TaskGraphManager &taskgraph_mgr, const Config &)
 #endif
             Entity,
             Lidar
-        >>({collect_obs});
+        >>({post_reset_broadphase});      // (rays need the tree, nothing else)
 
+    (void)reward_sys;
+    (void)collect_obs;
     (void)lidar;
 }
 

@@ -35,8 +35,10 @@ def test_exec_config_caps_node_grids(built, tmp_path, monkeypatch):
     worlds = 3000
     monkeypatch.delenv("MADRONA_MWHIP_EXEC_CONFIG_FILE", raising=False)
     plain, base = _run(worlds, 25)
+    # (a launch shared by several nodes carries its first node's index and the
+    # largest of their grids)
     nodes = [k for k in base if k["node_index"] != 0xFFFFFFFF and k["rows"] > 0]
-    assert len(nodes) >= 8
+    assert len(nodes) >= 6 and any(k["name"].startswith("group[") for k in nodes)
     # every ParallelFor node on one workgroup per CU
     cfg = tmp_path / "node_config.json"
     cfg.write_text(json.dumps({str(k["node_index"]): 1 for k in nodes}))
@@ -93,6 +95,22 @@ def test_declared_read_write_sets_reach_the_profile(built, monkeypatch):
     sims/escape_room/sim.hpp."""
     monkeypatch.delenv("MADRONA_MWHIP_EXEC_CONFIG_FILE", raising=False)
     worlds = 512
+    # a grouped launch (nodes that named the same dependencies share one) is
+    # priced at the sum over its nodes
+    with Simulator(hip_lib_path("escape_room"), worlds, seed=1, flags=0) as s:
+        s.step(5)
+        grouped = {k["name"]: k for k in s.profile(4)}
+    group = [k for n, k in grouped.items() if n.startswith("group[")
+             and "escape::rewardSystem" in n and "escape::stepTrackerSystem" in n
+             and "escape::buttonSystem" in n]
+    assert len(group) == 1 and group[0]["io_declared"]
+    # buttons 6 x (4 + Position 12 + 2 x Position 12 + ButtonState 4) + agents 2 x
+    # (28 + 16) per world
+    assert group[0]["rows"] == (6 + 2 + 2) * worlds
+    assert group[0]["algo_bytes"] == pytest.approx(
+        (6 * 44 + 2 * 28 + 2 * 16) * worlds)
+    # ... node by node with the grouping off
+    monkeypatch.setenv("MADRONA_MWHIP_GROUP", "0")
     with Simulator(hip_lib_path("escape_room"), worlds, seed=1, flags=0) as s:
         s.step(5)
         stats = {k["name"]: k for k in s.profile(4)}
