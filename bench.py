@@ -620,10 +620,13 @@ def rooflines(stats, sim_name, worlds, ms_per_step):
             continue
         t_sum, t_src, t_missing, seen = 0, None, [], set()
         for k in group:
-            if k["name"] in seen:
+            # (nodes sharing a launch run in pforGroupKernel: the counters see
+            # ONE kernel for all such launches of a step)
+            key = "group[" if k["name"].startswith("group[") else k["name"]
+            if key in seen:
                 continue        # (recorded traffic is per STEP: every launch of
-            seen.add(k["name"])     # a kernel that runs several times is in it)
-            t, src = traffic_for(entries, sim_name, worlds, k["name"])
+            seen.add(key)           # a kernel that runs several times is in it)
+            t, src = traffic_for(entries, sim_name, worlds, key)
             if t is None:
                 t_missing.append(k["name"])
             else:

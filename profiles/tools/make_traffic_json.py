@@ -32,6 +32,8 @@ BENCH_NAMES = [
     # the LDS kernel)
     (r"physicsStepKernel", "physics:worldStep(HBM)"),
     (r"bvhRefreshKernel", "physics:bvhRefresh"),
+    # (every launch that several ParallelFor nodes share)
+    (r"pforGroupKernel", "group[nodes sharing a launch]"),
     (r"physicsOrderKernel", "physics:orderWorlds"),
     (r"inputRingKernel", "input:ring"),
     (r"bvhUpdateKernel", "physics:bvhUpdate"),
