@@ -71,8 +71,59 @@ constexpr SystemIOBytes declareIO()
     return SystemIOBytes { (int32_t)ReadsT::bytes, (int32_t)WritesT::bytes };
 }
 
+// ---- two systems over the same rows in ONE node ------
+// rowChain<fnA, fnB, Ctx, Cs...> is a system over the components Cs... that runs
+// fnA and then fnB on the row: each takes the components of Cs... its signature
+// names.  For a pair the task graph would chain (fnB waits for fnA) where both
+// only touch THEIR OWN row's components of Cs... -- whatever else they reach
+// through ctx.get() must not be written by the other: the caller's claim, the
+// read / write sets do not carry it.  One launch instead of two, and what fnA
+// wrote for the row is still in registers when fnB reads it.
+//
+//   builder.addToGraph<ParallelForNode<Engine,
+//       mwhip::rowChain<doorOpenSystem, setDoorPositionSystem,
+//                       Engine, OpenState, DoorProperties, Position>,
+//       OpenState, DoorProperties, Position>>({button_sys});
+template <typename WantT, typename FirstT, typename... RestTs>
+MADRONA_HD constexpr WantT & rowChainArg(FirstT &first, RestTs &...rest)
+{
+    if constexpr (std::is_same_v<WantT, FirstT>) {
+        return first;
+    } else {
+        static_assert(sizeof...(RestTs) > 0,
+            "rowChain: a system takes a component the node does not list");
+        return rowChainArg<WantT>(rest...);
+    }
+}
+
+template <typename FnT> struct RowChainCall;
+template <typename CtxT, typename... ArgTs>
+struct RowChainCall<void (*)(CtxT &, ArgTs...)> {
+    template <auto Fn, typename... ComponentTs>
+    MADRONA_HD static inline void call(CtxT &ctx, ComponentTs &...row)
+    {
+        Fn(ctx, rowChainArg<std::remove_cv_t<std::remove_reference_t<ArgTs>>>(
+                    row...)...);
+    }
+};
+
+// (a class, so that the systems' names are part of the function's: profiles
+// label the node "chain[ns::fnA > ns::fnB]")
+template <auto FnA, auto FnB, typename CtxT, typename... ComponentTs>
+struct RowChain {
+    MADRONA_HD static inline void run(CtxT &ctx, ComponentTs &...row)
+    {
+        RowChainCall<decltype(FnA)>::template call<FnA>(ctx, row...);
+        RowChainCall<decltype(FnB)>::template call<FnB>(ctx, row...);
+    }
+};
+
+template <auto FnA, auto FnB, typename CtxT, typename... ComponentTs>
+inline constexpr auto rowChain = &RowChain<FnA, FnB, CtxT, ComponentTs...>::run;
+
 // Pulls "ns::fnName" out of __PRETTY_FUNCTION__ of a function templated on
-// <auto Fn> (host only, used to label kernels in profiles).
+// <auto Fn> (host only, used to label kernels in profiles); a rowChain is
+// "chain[ns::fnA > ns::fnB]".
 template <auto Fn>
 inline std::string systemName()
 {
@@ -83,6 +134,19 @@ inline std::string systemName()
     }
     start += 5;
     if (pretty[start] == '&') start++;
+    auto plain = [&](size_t from) {
+        if (pretty[from] == '&') from++;
+        size_t end = pretty.find_first_of("];,<>", from);
+        return pretty.substr(from, end - from);
+    };
+    const size_t chain = pretty.find("RowChain<", start);
+    if (chain != std::string::npos) {
+        const size_t first = chain + 9;
+        const size_t comma = pretty.find(", ", first);
+        if (comma != std::string::npos) {
+            return "chain[" + plain(first) + " > " + plain(comma + 2) + "]";
+        }
+    }
     size_t end = pretty.find_first_of("];,", start);
     return pretty.substr(start, end - start);
 }

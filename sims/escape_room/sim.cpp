@@ -17,6 +17,10 @@
 #if defined(MADRONA_GPU_MODE) && !defined(SIM_PORTABLE)
 #define SIM_WAVE_API 1
 #endif
+// (measurement: -DSIM_NO_ROW_CHAIN keeps the two door systems two nodes)
+#if defined(SIM_WAVE_API) && !defined(SIM_NO_ROW_CHAIN)
+#define SIM_ROW_CHAIN 1
+#endif
 
 using namespace madrona;
 using namespace madrona::math;
@@ -448,6 +452,17 @@ inline void setDoorPositionSystem(Engine &,
         pos.z = 0.f;
     }
 }
+
+#ifdef SIM_ROW_CHAIN
+// Both door systems in one node: each only touches its own door's row (the
+// button states doorOpenSystem reaches for are written by neither), so row i
+// may run the second right behind the first -- one launch instead of two
+// (madrona::mwhip::rowChain).  The portable sources
+// and the CPU build keep the two nodes.
+inline constexpr auto doorSystem = madrona::mwhip::rowChain<
+    doorOpenSystem, setDoorPositionSystem, Engine,
+    OpenState, DoorProperties, Position>;
+#endif
 
 inline void rewardSystem(Engine &,
                          Position &pos,
@@ -881,6 +896,15 @@ ESCAPE_SYSTEM_IO(doorOpenSystem,
 ESCAPE_SYSTEM_IO(setDoorPositionSystem,
     escape_io::Reads<escape::Position, escape::OpenState>,
     escape_io::Writes<escape::Position>);
+#ifdef SIM_ROW_CHAIN
+// (the chain of the two: OpenState is read -- a persistent door keeps it -- and
+// written once, not written, stored, and read back)
+ESCAPE_SYSTEM_IO(doorSystem,
+    escape_io::Reads<escape::DoorProperties,
+                escape_io::Times<escape::ButtonState, escape::consts::numButtonsPerRoom>,
+                escape::OpenState, escape::Position>,
+    escape_io::Writes<escape::OpenState, escape::Position>);
+#endif
 ESCAPE_SYSTEM_IO(rewardSystem,
     escape_io::Reads<escape::Position, escape::Progress>,
     escape_io::Writes<escape::Progress, escape::Reward>);
@@ -971,6 +995,14 @@ void Sim::setupTasks(TaskGraphManager &taskgraph_mgr, const Config &)
 
     // (the door chain is registered behind the nodes that share the button
     // system's dependency: the executor runs those in one launch)
+#ifdef SIM_ROW_CHAIN
+    auto set_door_pos_sys = builder.addToGraph<ParallelForNode<Engine,
+        doorSystem,
+            OpenState,
+            DoorProperties,
+            Position
+        >>({button_sys});
+#else
     auto door_open_sys = builder.addToGraph<ParallelForNode<Engine,
         doorOpenSystem,
             OpenState,
@@ -982,6 +1014,7 @@ void Sim::setupTasks(TaskGraphManager &taskgraph_mgr, const Config &)
             Position,
             OpenState
         >>({door_open_sys});
+#endif
 
 #ifdef SIM_WAVE_API
     // 64 lanes per world: lane i resets entity i (resetWorldWave)

@@ -17,6 +17,10 @@
 #if defined(MADRONA_GPU_MODE) && !defined(SIM_PORTABLE)
 #define SIM_WAVE_API 1
 #endif
+// (measurement: -DSIM_NO_ROW_CHAIN keeps the two door systems two nodes)
+#if defined(SIM_WAVE_API) && !defined(SIM_NO_ROW_CHAIN)
+#define SIM_ROW_CHAIN 1
+#endif
 
 using namespace madrona;
 using namespace madrona::math;
@@ -672,6 +676,17 @@ inline void setDoorPositionSystem(Engine &,
     }
 }
 
+#ifdef SIM_ROW_CHAIN
+// Both door systems in one node: each only touches its own door's row (the
+// button states doorOpenSystem reaches for are written by neither), so row i
+// may run the second right behind the first -- one launch instead of two
+// (madrona::mwhip::rowChain).  The portable sources
+// and the CPU build keep the two nodes.
+inline constexpr auto doorSystem = madrona::mwhip::rowChain<
+    doorOpenSystem, setDoorPositionSystem, Engine,
+    OpenState, DoorProperties, Position>;
+#endif
+
 inline void rewardSystem(Engine &,
                          Position &pos,
                          Progress &progress,
@@ -1218,6 +1233,15 @@ ESCPHYS_SYSTEM_IO(doorOpenSystem,
 ESCPHYS_SYSTEM_IO(setDoorPositionSystem,
     escphys_io::Reads<escphys::Position, escphys::OpenState>,
     escphys_io::Writes<escphys::Position>);
+#ifdef SIM_ROW_CHAIN
+// (the chain of the two: OpenState is read -- a persistent door keeps it -- and
+// written once, not written, stored, and read back)
+ESCPHYS_SYSTEM_IO(doorSystem,
+    escphys_io::Reads<escphys::DoorProperties,
+                escphys_io::Times<escphys::ButtonState, escphys::consts::numButtonsPerRoom>,
+                escphys::OpenState, escphys::Position>,
+    escphys_io::Writes<escphys::OpenState, escphys::Position>);
+#endif
 ESCPHYS_SYSTEM_IO(rewardSystem,
     escphys_io::Reads<escphys::Position, escphys::Progress>,
     escphys_io::Writes<escphys::Progress, escphys::Reward>);
@@ -1329,6 +1353,14 @@ void Sim::setupTasks(TaskGraphManager &taskgraph_mgr, const Config &)
 
     // (the door chain is registered behind the nodes that share the button
     // system's dependency: the executor runs those in one launch)
+#ifdef SIM_ROW_CHAIN
+    auto set_door_pos_sys = builder.addToGraph<ParallelForNode<Engine,
+        doorSystem,
+            OpenState,
+            DoorProperties,
+            Position
+        >>({button_sys});
+#else
     auto door_open_sys = builder.addToGraph<ParallelForNode<Engine,
         doorOpenSystem,
             OpenState,
@@ -1340,6 +1372,7 @@ void Sim::setupTasks(TaskGraphManager &taskgraph_mgr, const Config &)
             Position,
             OpenState
         >>({door_open_sys});
+#endif
 
 #ifdef SIM_WAVE_API
     // 64 lanes per world: lane i resets entity i (resetWorldWave)

@@ -418,6 +418,27 @@ def test_eager_replay_is_the_same_step(built, monkeypatch, sim, worlds, steps, f
     assert not probs, (step, probs[:3])
 
 
+@pytest.mark.parametrize("env", [{"MADRONA_MWHIP_GROUP": "0"},
+                                 {"MADRONA_MWHIP_GROUP_MAX_VGPRS": "1000"}])
+@pytest.mark.parametrize("sim,hip_sim,worlds,steps,agents", [
+    ("escape_room_phys", "escape_room_phys_portable", 96, 40, 2),
+    ("hideseek", "hideseek", 64, 40, 5)])
+def test_shared_launches_are_the_same_step(built, monkeypatch, env, sim, hip_sim, worlds,
+                                           steps, agents):
+    """ParallelFor nodes that named the same dependencies share one
+    launch (every other lock step runs that way).  The two switches around it:
+    every node its own launch, and no register limit on the members -- the
+    portable lidar system (a BVH traversal per row, 121 VGPRs) then runs through
+    the shared kernel's function pointer next to the observations."""
+    _need_ref(sim)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    probs, step = run_pair(sim, worlds, steps, check_every=10,
+                           actions=_escape_actions(worlds + 6, grab=True, agents=agents),
+                           check_init=False, ref_workers=0, hip_sim=hip_sim)
+    assert not probs, (step, probs[:3])
+
+
 def test_ball_pit_hinge_joints(built):
     """Hinge joints (reference src/physics/xpbd.cpp:686-693 and the two
     orientation constraints before it).  A hinged chain is not stable on the
