@@ -7,6 +7,8 @@
 // build.  Compiled for gfx950 + host by madrona_amd/Makefile; the simulator in
 // it runs in tests/test_api_conformance.py (-m gpu part).
 #include <madrona/mwhip/user_prelude.hpp>
+#include <cstdio>
+#include <string>
 #pragma clang force_cuda_host_device begin
 #include <madrona/taskgraph_builder.hpp>
 #include <madrona/custom_context.hpp>
@@ -128,4 +130,43 @@ Sim::Sim(Engine &ctx, const Config &, const WorldInit &)
 MADRONA_BUILD_MWGPU_ENTRY(Engine, Sim, Sim::Config, Sim::WorldInit);
 
 }
+
+// madrona::mwhip::rowChain on plain objects (runs on the host, CPU test): each
+// system gets the components of the node's list its signature names, by
+// reference, const reference or value, first system first
+namespace conformance_chain {
+struct Ctx { int order; };
+struct Open { int v; };
+struct Props { int v; };
+struct Pos { int v; };
+inline void openSystem(Ctx &ctx, Open &open, const Props &props)
+{
+    open.v = props.v + 1;
+    ctx.order = ctx.order * 10 + 1;
+}
+inline void moveSystem(Ctx &ctx, Pos &pos, Open open)
+{
+    pos.v = open.v * 2;
+    ctx.order = ctx.order * 10 + 2;
+}
+inline constexpr auto chained = madrona::mwhip::rowChain<
+    openSystem, moveSystem, Ctx, Open, Props, Pos>;
+}
 #pragma clang force_cuda_host_device end
+
+extern "C" __attribute__((visibility("default")))
+int conf_row_chain(char *name_out, int32_t name_cap)
+{
+    using namespace conformance_chain;
+    Ctx ctx { 0 };
+    Open open { -1 };
+    Props props { 20 };
+    Pos pos { -1 };
+    chained(ctx, open, props, pos);
+    if (open.v != 21 || pos.v != 42 || props.v != 20 || ctx.order != 12) {
+        return 1;
+    }
+    std::string name = madrona::mwhip::systemName<chained>();
+    snprintf(name_out, (size_t)name_cap, "%s", name.c_str());
+    return 0;
+}

@@ -46,6 +46,17 @@ def test_host_containers_and_atomics(conf):
     assert conf.conf_containers() == 0
 
 
+def test_row_chain_on_the_host(conf):
+    """madrona::mwhip::rowChain (taskgraph.inl, DESIGN 15.7): two systems over
+    one row -- each gets the components its signature names, the first runs
+    first -- and the name profiles give the node."""
+    name = C.create_string_buffer(256)
+    conf.conf_row_chain.argtypes = [C.c_char_p, C.c_int32]
+    assert conf.conf_row_chain(name, 256) == 0
+    assert name.value.decode() == \
+        "chain[conformance_chain::openSystem > conformance_chain::moveSystem]"
+
+
 def test_host_tracing_log(conf, tmp_path, monkeypatch):
     """madrona/tracing.hpp (reference include/madrona/tracing.hpp,
     src/common/tracing.cpp:44-58): N event codes, then N time stamps, int64."""
