@@ -26,7 +26,18 @@ def short_name(kname):
             # c++filt of this image does not know `TnDa` (auto non-type
             # template parameter): pull the system name out by hand
             m = re.search(r"parallelForKernelIN\d+(\w+?)\d+EngineE.*?XadL_ZNS\d_(\d+)", name)
-            if m:
+            chain = re.search(r"parallelForKernelIN\d+(\w+?)\d+EngineE.*?8RowChainI"
+                              r"XadL_ZNS\d_(\d+)", name)
+            if chain:
+                # mwhip::RowChain<&ns::fnA, &ns::fnB, ...>::run: both systems' names
+                n = int(chain.group(2))
+                first = name[chain.end():chain.end() + n]
+                second = re.search(r"XadL_ZNS\d_(\d+)", name[chain.end() + n:])
+                at = chain.end() + n + (second.end() if second else 0)
+                second = name[at:at + int(second.group(1))] if second else "?"
+                ns = chain.group(1)
+                name = (f"parallelForKernel<chain[{ns}::{first} > {ns}::{second}]>(")
+            elif m:
                 n = int(m.group(2))
                 name = ("parallelForKernel<" + m.group(1) + "::" +
                         name[m.end():m.end() + n] + ">(")

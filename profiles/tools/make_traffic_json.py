@@ -64,7 +64,8 @@ def bench_name(short):
     for pat, name in BENCH_NAMES:
         if re.search(pat, short):
             return name
-    m = re.match(r"parallelForKernel<([\w:]+)>", short)
+    m = re.match(r"parallelForKernel<(chain\[[^\]]+\])>", short) or \
+        re.match(r"parallelForKernel<([\w:]+)>", short)
     return m.group(1) if m else short
 
 
