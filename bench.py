@@ -11,11 +11,15 @@ one MI355X (sims/escape_room_phys; synthetic worlds, random actions resident in
 HBM, every world resets itself with probability 1/200 per step so that the
 compaction sorts and BVH rebuilds run on live data every step).  configs[1]
 (physics off, 4096 worlds) rides along as the secondary key `ecs_config2`.
-N>1 workload = BASELINE.json configs[3]: Hide-and-Seek-shaped worlds, 8192 per
-GPU (weak scaling, worlds sharded by global index), one packed all-gather of
-the observation tensors per step over RCCL/xGMI.
+N>1 runs the SAME workload (weak scaling: 8192 worlds per GPU, worlds sharded
+by global index) with one packed all-gather of the observation tensors per step
+over RCCL/xGMI, so that the points of a 1 -> 8 GPU curve compare.  BASELINE.json
+configs[3] (Hide-and-Seek-shaped worlds, 8 x 8192) is `--sim hideseek`; its
+one-GPU share rides along at N=1 as `hideseek_config4_share`, the Cartpole
+plumbing case (configs[0]) as `cartpole_config1`.
 
     python bench.py --gpus 1 --steps 600 --warmup 100
+    python bench.py --gpus 8 ...        # launches its own ranks, or:
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 \
         --master-addr 127.0.0.1 --master-port 29500 bench.py --gpus 8 ...
 
@@ -177,10 +181,22 @@ def driver_line(full, detail_path):
         line["portable_sim"] = {k: {"value": v.get("value"),
                                     "ms_per_step": v.get("ms_per_step")}
                                 for k, v in ps.items() if isinstance(v, dict)}
+    hs = full.get("hideseek_config4_share")
+    if hs:
+        hr = hs.get("roofline") or {}
+        line["hideseek_config4_share"] = {
+            "value": hs.get("value"), "ms_per_step": hs.get("ms_per_step"),
+            "worlds": 8192, "physics_step_us": hr.get("avg_us")}
+    cp = full.get("cartpole_config1")
+    if cp:
+        line["cartpole_config1"] = {
+            "value": cp.get("value"), "ms_per_step": cp.get("ms_per_step"),
+            "worlds": 64,
+            "cpu_reference": (cp.get("cpu_reference") or {}).get("value")}
     line["detail"] = detail_path
     # whatever happens upstream, the line stays parseable by the driver
-    for drop in ("portable_sim", "render_config5", "ecs_config2", "short_window",
-                 "allgather"):
+    for drop in ("cartpole_config1", "hideseek_config4_share", "portable_sim",
+                 "render_config5", "ecs_config2", "short_window", "allgather"):
         if len(json.dumps(line)) < LINE_BUDGET_BYTES:
             break
         line.pop(drop, None)
@@ -214,8 +230,13 @@ def parse_args():
     p.add_argument("--worlds", type=int, default=0,
                    help="worlds per GPU (default: the BASELINE size of the workload)")
     p.add_argument("--sim", default="",
-                   help="default: escape_room_phys (configs[2]) on one GPU, "
-                        "hideseek (configs[3]) with --gpus N > 1")
+                   help="default: escape_room_phys (configs[2]) for every --gpus N "
+                        "(one workload along a scaling curve); hideseek = "
+                        "configs[3]'s worlds")
+    p.add_argument("--dry-launch", action="store_true",
+                   help="launch / rendezvous check without a GPU: the ranks meet "
+                        "over gloo, all-gather their world ranges and rank 0 prints "
+                        "one JSON line (tests/test_bench_contract.py)")
     p.add_argument("--auto-reset-denom", type=int, default=200)
     p.add_argument("--action-slots", type=int, default=61,
                    help="action sets in the device-resident ring the step graph "
@@ -713,6 +734,43 @@ def run_single(sim_name, worlds, gpu_id, seed, denom, steps, warmup, profile_rep
     }
 
 
+def run_cartpole(gpu_id, worlds=64, steps=2000, cpu_sample=True):
+    """BASELINE configs[0]: the Cartpole-style 2-component ECS, 64 worlds -- quoted
+    on the reference's CPU executor (plumbing); the same simulator on the HIP
+    executor next to it.  At 64 worlds a step is launch floors, not bandwidth."""
+    import numpy as np
+    import torch
+    from madrona_amd.simlib import Simulator, hip_lib_path, ref_lib_path
+    rng = np.random.default_rng(3)
+    actions = rng.integers(0, 2, (worlds, 1)).astype(np.int32)
+    out = {"workload": f"Cartpole-style 2-component ECS, {worlds} worlds "
+                       "(BASELINE.json configs[0])"}
+    with Simulator(hip_lib_path("cartpole"), worlds, seed=5, gpu_id=gpu_id) as sim:
+        sim.write_tensor("action", actions)
+        sim.step_async(200)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sim.step_async(steps)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        sim.sync()
+    out.update(value=worlds * steps / dt, unit="steps/s", ms_per_step=dt / steps * 1e3)
+    path = ref_lib_path("cartpole", speed=True)
+    if not os.path.exists(path):
+        path = ref_lib_path("cartpole")
+    if cpu_sample and os.path.exists(path):
+        with Simulator(path, worlds, seed=5, num_workers=0) as ref:
+            ref.write_tensor("action", actions)
+            ref.step(200)
+            t0 = time.perf_counter()
+            ref.step(steps)
+            dt = time.perf_counter() - t0
+        out["cpu_reference"] = {"value": worlds * steps / dt, "unit": "steps/s",
+                                "cores": len(os.sched_getaffinity(0)),
+                                "ms_per_step": dt / steps * 1e3}
+    return out
+
+
 def cpu_raycast_sample(sim, worlds, resolution, sample_worlds=8192):
     """cpu_baseline leg of config 5's render pass: the reference's own ray caster
     (src/mw/device/bvh_raycast.cpp compiled for the host, oracle/_ref/
@@ -873,6 +931,55 @@ def run_render(worlds, gpu_id, seed, denom, steps, warmup, profile_reps, settle,
     return out
 
 
+def self_launch(gpus):
+    """`python bench.py --gpus N` outside torchrun: re-runs this command line as N
+    ranks (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1`, a free port) and returns its exit code; the ranks'
+    stdout (rank 0's ONE line) and stderr pass through."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_launch(args, rank, world_size, saved_stdout):
+    """The launch path without a GPU: every rank joins a gloo group on
+    127.0.0.1, the ranks all-gather their world ranges (the sharding the real run
+    uses) and rank 0 prints one line."""
+    import torch
+    import torch.distributed as dist
+    from madrona_amd.distributed import shard_for
+    if world_size > 1:
+        dist.init_process_group("gloo")
+    shard = shard_for(rank, world_size, worlds_per_rank=args.worlds or 8192)
+    mine = torch.tensor([shard.world_base, shard.worlds_per_rank], dtype=torch.int64)
+    ranges = [mine]
+    if world_size > 1:
+        ranges = [torch.zeros_like(mine) for _ in range(world_size)]
+        dist.all_gather(ranges, mine)
+        dist.barrier()
+    if world_size > 1:
+        dist.destroy_process_group()
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
+    if rank == 0:
+        print(json.dumps({
+            "dry_launch": True, "n_gpus": args.gpus, "ranks": world_size,
+            "backend": "gloo", "sim": args.sim,
+            "world_ranges": [[int(r[0]), int(r[1])] for r in ranges],
+            "total_worlds": shard.total_worlds}), flush=True)
+
+
 def main():
     args = parse_args()
     global ACTION_SLOTS, ACTION_WORKLOAD
@@ -896,11 +1003,18 @@ def main():
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` by itself: one rank per GPU under
+        # torch.distributed.run, this process only relays rank 0's line
+        os.dup2(saved_stdout, 1)
+        raise SystemExit(self_launch(args.gpus))
     if world_size != args.gpus:
-        if world_size == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}")
     if not args.sim:
-        args.sim = "hideseek" if world_size > 1 else "escape_room_phys"
+        # ONE workload for every N: the points of a scaling run compare
+        args.sim = "escape_room_phys"
+    if args.dry_launch:
+        return dry_launch(args, rank, world_size, saved_stdout)
     default_worlds, workload_fmt = WORKLOADS.get(args.sim, (4096, args.sim + ", {w} worlds"))
     if args.worlds <= 0:
         args.worlds = default_worlds
@@ -1143,7 +1257,22 @@ def main():
             "ecs_config2 are the same simulators with the wave-cooperative reset "
             "/ grab systems (sims/*/sim.cpp, SIM_WAVE_API)")
 
+    # BASELINE configs[3]'s one-GPU share (Hide-and-Seek-shaped worlds, 8192 of
+    # the 8 x 8192) and configs[0] (the Cartpole plumbing case, 64 worlds: the
+    # HIP executor next to the reference's CPU executor it is quoted on)
+    hideseek = None
+    cartpole = None
+    if (rank == 0 and world_size == 1 and args.sim == "escape_room_phys"
+            and not args.no_secondary):
+        r = run_single("hideseek", 8192, local_rank, seed, args.auto_reset_denom,
+                       300, 50, 10, settle=args.settle)
+        hideseek = {"workload": r["workload"], "value": r["value"],
+                    "unit": "steps/s", "ms_per_step": r["ms_per_step"],
+                    "roofline": r["roofline"], "kernels": r["kernels"]}
+        cartpole = run_cartpole(local_rank, cpu_sample=not args.no_cpu_baseline)
+
     dist_world = dist.get_world_size() if distributed else 1
+    rccl_ranks = dist_world if distributed and dist.get_backend() == "nccl" else 0
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
@@ -1171,6 +1300,7 @@ def main():
                 "settle_steps": args.settle,
                 "total_worlds": total_worlds,
                 "dist_world_size": dist_world,
+                "rccl_ranks": rccl_ranks,
                 "parallelism": f"worlds sharded over {world_size} GPU(s)"
                                + (", one packed RCCL all-gather of the observation "
                                   "tensors per step" if distributed else ""),
@@ -1188,6 +1318,8 @@ def main():
             "ecs_config2": secondary,
             "render_config5": render,
             "portable_sim": portable,
+            "hideseek_config4_share": hideseek,
+            "cartpole_config1": cartpole,
             "kernels": kernels,
         }
         # flush what C libraries buffered for "stdout" while it pointed at stderr

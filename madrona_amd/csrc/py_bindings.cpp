@@ -111,11 +111,19 @@ pyb::capsule toDLPack(const Tensor &t)
 // memory; step(): obs[w] = { action[w][0] + action[w][1], resets[w], step count },
 // reward[w] = obs[w][0] / 2, done[w] = resets[w].  Used by tests/test_py_bridge.py
 // to drive TrainInterface and the XLA entry points without a simulator build.
+// with_extras: one more tensor of every optional kind -- a pbt input "policy"
+// (int32 [N]), a stats output "episodes" (int32 [N] = 10 * step + w) and a pbt
+// output "fitness" (float32 [N] = policy[w] - w) -- so that the buffer order
+// actions..., resets, simCtrl, pbt... / observations..., rewards, dones,
+// stats..., pbt... is exercised end to end.
 class DemoTrainSim {
 public:
-    DemoTrainSim(int64_t num_worlds, int gpu_id)
-        : n_(num_worlds), gpu_(gpu_id)
+    DemoTrainSim(int64_t num_worlds, int gpu_id, bool with_extras = false)
+        : n_(num_worlds), gpu_(gpu_id), extras_(with_extras)
     {
+        policy_ = alloc(n_ * 4);
+        episodes_ = alloc(n_ * 4);
+        fitness_ = alloc(n_ * 4);
         action_ = alloc(n_ * 2 * 4);
         resets_ = alloc(n_ * 4);
         ctrl_ = alloc(4);
@@ -145,6 +153,24 @@ public:
     {
         NamedTensor actions[] = { { "move", actionTensor() } };
         NamedTensor obs[] = { { "self", obsTensor() } };
+        if (extras_) {
+            NamedTensor pbt_in[] = {
+                { "policy", tensor(policy_, TensorElementType::Int32, { n_ }) } };
+            NamedTensor stats[] = {
+                { "episodes", tensor(episodes_, TensorElementType::Int32, { n_ }) } };
+            NamedTensor pbt_out[] = {
+                { "fitness", tensor(fitness_, TensorElementType::Float32, { n_ }) } };
+            return TrainInterface(
+                { madrona::Span<const NamedTensor>(actions, 1),
+                  tensor(resets_, TensorElementType::Int32, { n_ }),
+                  tensor(ctrl_, TensorElementType::Int32, { 1 }),
+                  madrona::Span<const NamedTensor>(pbt_in, 1) },
+                { madrona::Span<const NamedTensor>(obs, 1),
+                  tensor(rewards_, TensorElementType::Float32, { n_ }),
+                  tensor(dones_, TensorElementType::Int32, { n_ }),
+                  madrona::Span<const NamedTensor>(stats, 1),
+                  madrona::Span<const NamedTensor>(pbt_out, 1) });
+        }
         return TrainInterface(
             { madrona::Span<const NamedTensor>(actions, 1),
               tensor(resets_, TensorElementType::Int32, { n_ }),
@@ -171,6 +197,17 @@ public:
         put(obs_, o.data(), o.size() * 4);
         put(rewards_, rew.data(), rew.size() * 4);
         put(dones_, d.data(), d.size() * 4);
+        if (extras_) {
+            std::vector<int32_t> pol((size_t)n_), ep((size_t)n_);
+            std::vector<float> fit((size_t)n_);
+            get(pol.data(), policy_, pol.size() * 4);
+            for (int64_t w = 0; w < n_; w++) {
+                ep[w] = (int32_t)(10 * steps_ + w);
+                fit[w] = (float)(pol[w] - (int32_t)w);
+            }
+            put(episodes_, ep.data(), ep.size() * 4);
+            put(fitness_, fit.data(), fit.size() * 4);
+        }
     }
 
     void cpuJAXInit(void **, void **outputs)
@@ -227,8 +264,10 @@ private:
 
     int64_t n_;
     int gpu_;
+    bool extras_;
     int64_t steps_ = 0;
     void *action_, *resets_, *ctrl_, *obs_, *rewards_, *dones_;
+    void *policy_, *episodes_, *fitness_;
     std::vector<void *> owned_;
 };
 
@@ -367,8 +406,8 @@ PYBIND11_MODULE(_madrona_amd_py, m)
         });
 
     pyb::class_<DemoTrainSim>(m, "_DemoTrainSim")
-        .def(pyb::init<int64_t, int>(), pyb::arg("num_worlds"),
-             pyb::arg("gpu_id") = -1)
+        .def(pyb::init<int64_t, int, bool>(), pyb::arg("num_worlds"),
+             pyb::arg("gpu_id") = -1, pyb::arg("with_extras") = false)
         .def("train_interface", &DemoTrainSim::trainInterface)
         .def("action_tensor", &DemoTrainSim::actionTensor)
         .def("obs_tensor", &DemoTrainSim::obsTensor)

@@ -15,7 +15,12 @@ the operands and LAST among the results so that the C++ entry point can skip
 two buffers and write the rest in order (bindings.hpp: cpuEntryFn `in + 2`,
 gpuEntryFn `buffers + 2`).  init() -> {"state", "obs"}; step({"state",
 "actions", "resets", "sim_ctrl", "pbt"}) -> {"state", "obs", "rewards",
-"dones", "pbt"}.
+"dones", "stats", "pbt"}.  The step's result buffers are exactly the tensors
+TrainInterface::forEachOutput (include/madrona/py/utils.inl) walks, in its
+order: observations..., rewards, dones, stats..., pbt... -- `step_buffer_specs`
+below; the reference's script leaves the stats out of its result list while its
+C++ side copies them (a simulator that exports a stats tensor would write past
+XLA's result array there).
 
 jax is not installed in the build image: this module has only been exercised
 up to the import (tests/test_py_bridge.py checks the ImportError); the entry
@@ -24,6 +29,32 @@ points themselves are tested by calling the capsules the way XLA does.
 from functools import partial
 
 import numpy as np
+
+
+def step_buffer_specs(outs):
+    """(names, specs) of the step call's result buffers from the outputs pytree
+    (JAXInterface::outputsToPytree): the order cpuCopyStepOutputs /
+    hipCopyStepOutputs write them in.  No jax needed (tests/test_py_bridge.py
+    checks it against what the C++ side writes)."""
+    obs_names = list(outs["obs"].keys())
+    stats_names = list(outs.get("stats", {}).keys())
+    pbt_names = list(outs.get("pbt", {}).keys())
+    specs = ([outs["obs"][k] for k in obs_names] + [outs["rewards"], outs["dones"]] +
+             [outs["stats"][k] for k in stats_names] +
+             [outs["pbt"][k] for k in pbt_names])
+    return {"obs": obs_names, "stats": stats_names, "pbt": pbt_names}, specs
+
+
+def step_input_order(ins):
+    """Names of the step call's input buffers behind the token: actions...,
+    resets, sim_ctrl, pbt... (cpuCopyStepInputs / hipCopyStepInputs)."""
+    return (list(ins["actions"].keys()), list(ins.get("pbt", {}).keys()))
+
+
+def xla_platforms(platform):
+    """XLA registry names a custom-call target goes under: jaxlib files 'gpu'
+    under CUDA, and a jax-rocm build looks GPU targets up under ROCM."""
+    return ["ROCM", "gpu"] if platform == "gpu" else [platform]
 
 
 def _require_jax():
@@ -49,7 +80,12 @@ class _EntryPoint:
         self.sim_ptr = np.uint64(sim_ptr)
         self.sim_encode = sim_encode
         self.out_specs = list(out_specs)     # [(shape, dtype)]
-        xla_client.register_custom_call_target(name, capsule, platform=platform)
+        for registry in xla_platforms(platform):
+            try:
+                xla_client.register_custom_call_target(name, capsule, platform=registry)
+            except Exception:   # (a jaxlib without that registry)
+                if registry == xla_platforms(platform)[-1]:
+                    raise
 
         prim = core.Primitive(name)
         prim.multiple_results = True
@@ -106,11 +142,11 @@ def register(scope):
     platform = scope["platform"]
     prefix = f"{type(scope['sim_obj']).__name__}_{id(scope['sim_obj'])}"
     ins, outs = scope["step_inputs_iface"], scope["step_outputs_iface"]
-    obs_names = list(outs["obs"].keys())
+    out_names, step_specs = step_buffer_specs(outs)
+    obs_names, stats_names, pbt_out_names = (out_names["obs"], out_names["stats"],
+                                             out_names["pbt"])
     obs_specs = [outs["obs"][k] for k in obs_names]
-    pbt_out_names = list(outs["pbt"].keys())
-    step_specs = (obs_specs + [outs["rewards"], outs["dones"]] +
-                  [outs["pbt"][k] for k in pbt_out_names])
+    action_names, pbt_in_names = step_input_order(ins)
 
     def entry(kind, specs):
         return _EntryPoint(f"{prefix}_{kind}", scope[kind], platform,
@@ -125,14 +161,15 @@ def register(scope):
 
     def step_func(step_inputs):
         flat_in = [step_inputs["state"]]
-        flat_in += [step_inputs["actions"][k] for k in ins["actions"].keys()]
+        flat_in += [step_inputs["actions"][k] for k in action_names]
         flat_in += [step_inputs["resets"], step_inputs["sim_ctrl"]]
-        flat_in += [step_inputs["pbt"][k] for k in ins["pbt"].keys()]
+        flat_in += [step_inputs["pbt"][k] for k in pbt_in_names]
         state, flat = step_entry.bind(*flat_in)
-        n = len(obs_names)
+        n, m = len(obs_names), len(stats_names)
         return {"state": state, "obs": dict(zip(obs_names, flat[:n])),
                 "rewards": flat[n], "dones": flat[n + 1],
-                "pbt": dict(zip(pbt_out_names, flat[n + 2:]))}
+                "stats": dict(zip(stats_names, flat[n + 2:n + 2 + m])),
+                "pbt": dict(zip(pbt_out_names, flat[n + 2 + m:]))}
 
     fns = {"init": jax.jit(init_func), "step": jax.jit(step_func)}
 

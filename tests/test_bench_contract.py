@@ -160,3 +160,47 @@ def test_driver_line_stays_small_whatever_the_kernel_tables_hold():
     assert line["value"] == full["value"] and line["detail"].endswith("bench_detail.json")
     assert line["ecs_config2"]["value"] == full["ecs_config2"]["value"]
     assert line["portable_sim"]["config3"]["value"] == full["portable_sim"]["config3"]["value"]
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` without torchrun (how the driver runs a scaling
+    point) starts two ranks that rendezvous on 127.0.0.1; --dry-launch stops after
+    the meeting (gloo, no GPU).  One workload for every N: the default simulator
+    does not change with --gpus."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    lines = {}
+    for n in (1, 2):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus",
+                              str(n), "--dry-launch"], env=env, capture_output=True,
+                             text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        printed = [l for l in out.stdout.splitlines() if l.strip()]
+        assert len(printed) == 1, out.stdout       # ONE line, rank 0's
+        lines[n] = json.loads(printed[0])
+    two = lines[2]
+    assert two["dry_launch"] and two["ranks"] == 2 and two["n_gpus"] == 2
+    assert two["world_ranges"] == [[0, 8192], [8192, 8192]]
+    assert two["total_worlds"] == 16384
+    assert lines[1]["sim"] == two["sim"] == "escape_room_phys"
+
+
+def test_driver_line_carries_every_baseline_config():
+    """configs[0] (Cartpole) and configs[3]'s one-GPU share (Hide-and-Seek) ride on
+    the driver line as one-number summaries next to configs[1], [2] and [4]."""
+    bench = _load("bench", os.path.join(ROOT, "bench.py"))
+    full = json.loads(open(os.path.join(ROOT, "profiles", "r04_bench_default.json"))
+                      .read().strip().splitlines()[-1])
+    full["hideseek_config4_share"] = {
+        "value": 6.1e6, "ms_per_step": 1.34, "roofline": {"avg_us": 700.0},
+        "kernels": [{"name": "x" * 80, "avg_us": 1.0}] * 100}
+    full["cartpole_config1"] = {"value": 3.0e6, "ms_per_step": 0.02,
+                                "cpu_reference": {"value": 1.0e6, "cores": 8}}
+    full["config"]["rccl_ranks"] = 0
+    line = bench.driver_line(full, "gpurun_out/bench_detail.json")
+    assert line["hideseek_config4_share"] == {
+        "value": 6.1e6, "ms_per_step": 1.34, "worlds": 8192, "physics_step_us": 700.0}
+    assert line["cartpole_config1"]["cpu_reference"] == 1.0e6
+    assert line["config"]["rccl_ranks"] == 0
+    assert len(json.dumps(line)) < bench.LINE_BUDGET_BYTES

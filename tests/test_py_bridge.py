@@ -148,3 +148,47 @@ def test_gpu_custom_call_entry_points(pymod):
     # the simulator's exported tensor is a live PyTorch-ROCm tensor
     t = sim.obs_tensor().to_torch()
     assert t.is_cuda and torch.equal(t, obs)
+
+
+def test_step_buffers_with_stats_and_pbt(pymod):
+    """A simulator that exports a stats tensor and pbt tensors both ways: the
+    result list jax_register.step_buffer_specs declares is exactly what
+    cpuCopyStepOutputs writes, in its order (observations..., rewards, dones,
+    stats..., pbt...) -- nothing lands in a neighbour's buffer, nothing is
+    written behind the last one."""
+    from madrona_amd import jax_register
+    n = 5
+    sim = pymod._DemoTrainSim(n, -1, True)
+    entry = sim.jax(False, register=False)
+    ins, outs = entry["step_inputs_iface"], entry["step_outputs_iface"]
+    assert ins["pbt"] == {"policy": ((n,), "int32")}
+    assert outs["stats"] == {"episodes": ((n,), "int32")}
+    assert outs["pbt"] == {"fitness": ((n,), "float32")}
+    names, specs = jax_register.step_buffer_specs(outs)
+    assert names == {"obs": ["self"], "stats": ["episodes"], "pbt": ["fitness"]}
+    assert specs == [((n, 3), "float32"), ((n,), "float32"), ((n,), "int32"),
+                     ((n,), "int32"), ((n,), "float32")]
+    assert jax_register.step_input_order(ins) == (["move"], ["policy"])
+    assert jax_register.xla_platforms("gpu") == ["ROCM", "gpu"]
+    assert jax_register.xla_platforms("cpu") == ["cpu"]
+
+    # result buffers allocated from the declared specs, each with a guard word
+    # behind it, and a guard entry behind the token in the pointer list
+    bufs = [np.full(int(np.prod(shape)) + 1, -7, np.dtype(dt)) for shape, dt in specs]
+    token = np.empty((0,), np.float32)
+    sim_addr = np.array([entry["sim_ptr"]], dtype=np.uint64)
+    actions = np.arange(n * 2, dtype=np.int32).reshape(n, 2)
+    resets = np.array([1, 0, 0, 1, 0], np.int32)
+    ctrl = np.zeros(1, np.int32)
+    policy = np.arange(n, dtype=np.int32) * 3
+    pymod._call_cpu_custom_call(
+        entry["step"], [b.ctypes.data for b in bufs] + [token.ctypes.data],
+        [sim_addr.ctypes.data, token.ctypes.data, actions.ctypes.data,
+         resets.ctypes.data, ctrl.ctypes.data, policy.ctypes.data])
+    obs, rewards, dones, episodes, fitness = bufs
+    assert all(b[-1] == -7 for b in bufs)                      # guards intact
+    assert np.array_equal(obs[:-1].reshape(n, 3)[:, 0], actions.sum(1))
+    assert np.array_equal(rewards[:-1], actions.sum(1) / 2)
+    assert np.array_equal(dones[:-1], resets)
+    assert np.array_equal(episodes[:-1], 10 + np.arange(n))
+    assert np.array_equal(fitness[:-1], (policy - np.arange(n)).astype(np.float32))
