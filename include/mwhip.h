@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MWHIP_ABI_VERSION 5u   /* 5: mwhip_node_desc::pfor_body, mwhip_pfor_body(), mwhip_set_pfor_group_kernel() (side-by-side ParallelFor nodes in one launch); 4: io_declared */
+#define MWHIP_ABI_VERSION 6u   /* 6: mwhip_node_desc::write_mask (same-dependency nodes whose signatures clash keep their own launches); 5: mwhip_node_desc::pfor_body, mwhip_pfor_body(), mwhip_set_pfor_group_kernel() (side-by-side ParallelFor nodes in one launch); 4: io_declared */
 
 typedef struct mwhip_exec mwhip_exec; /* opaque; == MWCudaExecutor::Impl */
 
@@ -324,6 +324,14 @@ typedef struct mwhip_node_desc {
      * (device taskgraph.cpp:142-317); results are the same by the independence
      * the simulator declared with its dependency lists. */
     const void *pfor_body;
+    /* ParallelFor nodes: bit i set = the system may write component i of its
+     * query (in query order): a non-const reference in its signature.  The
+     * runtime does not put two nodes into one launch when one of them writes a
+     * component the other one names on a table both match (the reference runs
+     * them one after the other, device taskgraph.cpp:142-317: same-dependency
+     * siblings may still rely on registration order).  0 with pfor_body set
+     * means "writes nothing"; nodes built without a signature pass ~0u. */
+    uint32_t write_mask;
 } mwhip_node_desc;
 
 /* Members of a grouped launch, in device memory (the group kernel's argument). */

@@ -94,9 +94,7 @@ struct RenderParams {
     uint32_t cameraColumn, lightColumn, rgbColumn, depthColumn;
     uint32_t resolution;
     uint32_t rgbd;
-    uint32_t numGeoNodes;       // all objects
-    uint32_t numGeoTriangles;
-    uint32_t pad_;
+    uint32_t pad_[3];
     BvhNode *tlasNodes;         // one slot per row of the renderable table
     PreparedInstance *prepared; // likewise
     RenderGeometryDev geometry;

@@ -429,8 +429,6 @@ __device__ inline float boxEntry(const AABB &b, const SlabRay &r, float t_max)
 }
 
 constexpr uint32_t kStackDepth = 24;
-// bottom-level trees + triangles of all objects are kept in LDS when they fit
-constexpr uint32_t kGeoLdsDwords = 7168;
 
 // what shading a hit on an instance needs: its rotation (normals) and its colour
 // -- material / override resolved once per instance (reference traceRay
@@ -526,7 +524,6 @@ __device__ inline Vector3 sampleTexture(const RenderGeometryDev &geo, int32_t te
            (1.f - a) * b * t01 + a * b * t11;
 }
 
-template <bool GeoInLds>
 struct TraceLDS {
     static constexpr int maxInstances = 64;
     static constexpr int maxLights = 8;
@@ -542,8 +539,6 @@ struct TraceLDS {
     uint8_t tileList[maxInstances];
     // traversal stack (both levels), one column per thread
     uint16_t stack[kStackDepth][256];
-    // [nodes of every object][triangle vertices of every object]
-    uint32_t geo[GeoInLds ? kGeoLdsDwords : 4];
 };
 
 struct Hit {
@@ -587,11 +582,11 @@ __device__ inline RayIsect rayIsect(const Vector3 &d)
 // closest hit of the ray against one instance's triangles: the ray goes to
 // object space, t is rescaled on the way in and out (reference :627-646,
 // :747-766).  The stack above `sp_base` is free.
-template <bool AnyHit, bool GeoInLds>
+template <bool AnyHit>
 __device__ __forceinline__ void traceInstance(
     EcsState *S, const GeoView &geo, const PreparedInstance &inst,
     int32_t inst_idx, const Vector3 &world_o, const Vector3 &world_d,
-    float &t_max, Hit &best, TraceLDS<GeoInLds> *lds, uint32_t sp_base,
+    float &t_max, Hit &best, TraceLDS *lds, uint32_t sp_base,
     uint32_t tid)
 {
     if (inst.valid == 0) {
@@ -747,10 +742,10 @@ __device__ __forceinline__ void traceInstance(
 // Staged: the world's nodes and instances are the workgroup's LDS copies (known
 // at compile time, so that they are read with LDS instructions, not through
 // flat pointers)
-template <bool AnyHit, bool Staged, bool GeoInLds>
+template <bool AnyHit, bool Staged>
 __device__ __forceinline__ Hit traceWorld(
     EcsState *S, const GeoView &geo, const WorldView &w, const Vector3 &o,
-    const Vector3 &d, float t_max, TraceLDS<GeoInLds> *lds, uint32_t tid)
+    const Vector3 &d, float t_max, TraceLDS *lds, uint32_t tid)
 {
     const BvhNode *world_nodes = Staged ? lds->nodes : w.nodes;
     const PreparedInstance *world_instances = Staged ? lds->instances : w.prepared;
@@ -818,10 +813,9 @@ __device__ __forceinline__ Hit traceWorld(
 // Primary rays of a tile whose world is staged: instead of a top-level walk per
 // ray, the instances the tile's frustum touches (culled once per tile by one
 // wavefront, ordered near to far) are tried in turn behind their own box test.
-template <bool GeoInLds>
 __device__ __forceinline__ Hit traceTileList(
     EcsState *S, const GeoView &geo, const Vector3 &o, const Vector3 &d,
-    float t_max, TraceLDS<GeoInLds> *lds, uint32_t tid)
+    float t_max, TraceLDS *lds, uint32_t tid)
 {
     Hit best;
     best.hit = false;
@@ -842,9 +836,7 @@ __device__ __forceinline__ Hit traceTileList(
     return best;
 }
 
-// Workgroups stride over the 16 x 16 tiles of all views.  GeoInLds: the
-// bottom-level trees and triangles of every object are copied to LDS once per
-// workgroup (they fit: kGeoLdsDwords), so that only the image leaves the CU.
+// Workgroups stride over the 16 x 16 tiles of all views.
 //
 // PlainMaterials: the scene has neither per-triangle materials nor textures
 // (geometry.triangleMaterial == nullptr and no material with a texture: then
@@ -860,18 +852,18 @@ __device__ __forceinline__ Hit traceTileList(
 // and L1 hits) the block is 24 KB, and capped at 128 registers (13 spilled
 // dwords) four wavefronts share a SIMD: 4.84 -> 4.45 ms at the same grid; 96
 // registers for five spill 66 dwords and lose (4.28 ms against 3.42).  Hence:
-// geometry in HBM and four wavefronts per SIMD by default;
-// MADRONA_MWHIP_RAYCAST_GEO_LDS=1 brings the LDS copy back.
+// geometry in HBM and four wavefronts per SIMD (the LDS copy and its switch
+// are out of the code since round 6).
 #ifndef MADRONA_RAYCAST_WAVES
 #define MADRONA_RAYCAST_WAVES 4
 #endif
-template <bool GeoInLds, bool PlainMaterials>
+template <bool PlainMaterials>
 __global__ void __launch_bounds__(256)
-__attribute__((amdgpu_waves_per_eu(GeoInLds ? 3 : MADRONA_RAYCAST_WAVES)))
+__attribute__((amdgpu_waves_per_eu(MADRONA_RAYCAST_WAVES)))
 renderRaycast(EcsState *S, RenderParams params)
 {
     TraceScope trace_scope(S);
-    __shared__ TraceLDS<GeoInLds> lds;
+    __shared__ TraceLDS lds;
 
     const uint32_t res = params.resolution;
     const uint32_t tiles_per_side = (res + 15u) / 16u;
@@ -886,34 +878,14 @@ renderRaycast(EcsState *S, RenderParams params)
     const uint32_t total_tiles = num_views * tiles_per_view;
 
     const RenderGeometryDev geo_dev = params.geometry;
+    // (bottom-level trees and triangles stay in HBM: a few KB every workgroup
+    // reads, L2 / L1 hits; copied to LDS they made the block 53 KB and cost a
+    // wavefront per SIMD -- round 4, profiles/r04_raycast_variants.jsonl)
     GeoView geo;
-    if constexpr (GeoInLds) {
-        const uint32_t node_dw = params.numGeoNodes * 16u;
-        const uint32_t tri_dw = params.numGeoTriangles * 9u;
-        for (uint32_t i = tid; i < node_dw; i += 256u) {
-            lds.geo[i] = ((const uint32_t *)geo_dev.nodes)[i];
-        }
-        for (uint32_t i = tid; i < tri_dw; i += 256u) {
-            lds.geo[node_dw + i] = ((const uint32_t *)geo_dev.triangleVertices)[i];
-        }
-        const uint32_t bounds_dw = geo_dev.numObjects * 6u;
-        for (uint32_t i = tid; i < bounds_dw; i += 256u) {
-            lds.geo[node_dw + tri_dw + i] = ((const uint32_t *)geo_dev.objectBounds)[i];
-        }
-        const uint32_t faces_dw = geo_dev.numObjects * 12u;
-        for (uint32_t i = tid; i < faces_dw; i += 256u) {
-            lds.geo[node_dw + tri_dw + bounds_dw + i] = geo_dev.objectBoxFaces[i];
-        }
-        geo.nodes = (const BvhNode *)&lds.geo[0];
-        geo.triangles = (const Vector3 *)&lds.geo[node_dw];
-        geo.bounds = (const float *)&lds.geo[node_dw + tri_dw];
-        geo.boxFaces = &lds.geo[node_dw + tri_dw + bounds_dw];
-    } else {
-        geo.nodes = geo_dev.nodes;
-        geo.triangles = geo_dev.triangleVertices;
-        geo.bounds = geo_dev.objectBounds;
-        geo.boxFaces = geo_dev.objectBoxFaces;
-    }
+    geo.nodes = geo_dev.nodes;
+    geo.triangles = geo_dev.triangleVertices;
+    geo.bounds = geo_dev.objectBounds;
+    geo.boxFaces = geo_dev.objectBoxFaces;
 
     uint8_t *rgb_out = (uint8_t *)out_tbl.columns[params.rgbColumn];
     float *depth_out = (float *)out_tbl.columns[params.depthColumn];
@@ -1479,22 +1451,12 @@ void buildRenderLaunches(EcsState *state_dev, const RenderParams &params,
     }
     {
         KernelLaunch k;
-        // (MADRONA_MWHIP_RAYCAST_GEO_LDS=1: bottom-level trees and triangles
-        // copied to LDS by every workgroup -- a 53 KB block instead of 24 KB;
-        // measured slower, see renderRaycast)
-        const char *geo_env = getenv("MADRONA_MWHIP_RAYCAST_GEO_LDS");
-        const bool geo_in_lds = params.numGeoNodes * 16u +
-            params.numGeoTriangles * 9u + params.geometry.numObjects * 18u <=
-                kGeoLdsDwords && geo_env != nullptr && atoi(geo_env) != 0;
         // (what the geometry can ask of the shading, decided here once)
         // (materialTexture is only uploaded for scenes that have textures)
         const bool plain = params.geometry.triangleMaterial == nullptr &&
             params.geometry.materialTexture == nullptr;
-        k.fn = geo_in_lds ?
-            (plain ? (const void *)&renderRaycast<true, true> :
-                     (const void *)&renderRaycast<true, false>) :
-            (plain ? (const void *)&renderRaycast<false, true> :
-                     (const void *)&renderRaycast<false, false>);
+        k.fn = plain ? (const void *)&renderRaycast<true> :
+                       (const void *)&renderRaycast<false>;
         const uint32_t tiles_per_side = (params.resolution + 15u) / 16u;
         const uint64_t tiles =
             (uint64_t)view_capacity * tiles_per_side * tiles_per_side;
@@ -1504,12 +1466,9 @@ void buildRenderLaunches(EcsState *state_dev, const RenderParams &params,
         // workgroup; config 5: 1536 workgroups 4.43 ms, 4096 3.68, 8192 3.56,
         // 16384 = the views 3.42; 32768 -- half a view each, every world staged
         // twice as often -- 5.61): as many workgroups as views, within
-        // [max_workgroups, 65536]; MADRONA_MWHIP_RAYCAST_WGS fixes the count.
-        uint64_t want = max_workgroups;
-        if (getenv("MADRONA_MWHIP_RAYCAST_WGS") == nullptr) {
-            want = std::min<uint64_t>(std::max<uint64_t>(view_capacity, max_workgroups),
-                                      65536);
-        }
+        // [max_workgroups, 65536].
+        const uint64_t want = std::min<uint64_t>(
+            std::max<uint64_t>(view_capacity, max_workgroups), 65536);
         k.grid = dim3((uint32_t)std::min<uint64_t>(std::max<uint64_t>(tiles, 1),
                                                   want), 1, 1);
         k.block = dim3(256, 1, 1);

@@ -615,7 +615,6 @@ struct mwhip_exec {
     uint32_t tableGrowth = 1;               // reserved / initial rows
     uint32_t numGrowths = 0;
     bool checkAfterRun = true;
-    bool sortBatching = true;
     bool sortCarriesMisc = true;    // MADRONA_MWHIP_SORT_CARRIES_MISC
 
     // mwhip_set_input_ring
@@ -639,7 +638,6 @@ struct mwhip_exec {
     // reorders, 2 every world sort (tests: the chain is correct on any table,
     // its one-workgroup tail sort is just slow when the whole table is "tail")
     uint32_t sortCompaction = 1;
-    uint32_t rowSnapshotMode = 1;   // 0 never, 1 nodes that can append rows, 2 all
     bool eagerReplay = false;       // MADRONA_MWHIP_EAGER (measurement, replayGraph)
     const void *pforGroupKernel = nullptr;  // mwhip_set_pfor_group_kernel
     void *pforBodyScratch = nullptr;        // 8 bytes: where report mode writes
@@ -1717,13 +1715,6 @@ static int ensureSortScratch(mwhip_exec *exec, ArchetypeRec &arch)
 
     int rc = devAllocT(exec, &arch.sortState, 1);
     if (rc != 0) return rc;
-    // MADRONA_MWHIP_SORT_LANDS=0: the compaction chain always sorts its tail on
-    // one workgroup (round 3's path; measurements)
-    if (envU32("MADRONA_MWHIP_SORT_LANDS", 1) == 0) {
-        const uint32_t forever = 0x7FFFFFFFu;
-        HIPCHK(hipMemcpy((char *)arch.sortState + offsetof(SortState, landsBlocked),
-                         &forever, sizeof(forever), hipMemcpyHostToDevice));
-    }
     if (arch.reservedCapacity > arch.capacity) {
         void **bufs[5] = { (void **)&arch.keysA, (void **)&arch.keysB,
                            (void **)&arch.idxA, (void **)&arch.idxB,
@@ -1900,9 +1891,7 @@ static int makeSortBatch(mwhip_exec *exec,
     {
         // about one workgroup per 32 KB, between one and four resident rounds of
         // the chip (measured, profiles/r03_sort_variants.jsonl: 2048 is best at
-        // 38 MB, 4096 at 94 MB, 8192 at 610 MB); MADRONA_MWHIP_GATHER_BLOCKS
-        // overrides
-        uint32_t target = envU32("MADRONA_MWHIP_GATHER_BLOCKS", 0);
+        // 38 MB, 4096 at 94 MB, 8192 at 610 MB)
         std::vector<double> weight(cols.size(), 0.0);
         double total = 0.0;
         for (size_t c = 0; c < cols.size(); c++) {
@@ -1920,27 +1909,19 @@ static int makeSortBatch(mwhip_exec *exec,
             }
             total += weight[c];
         }
-        if (target == 0) {
-            target = (uint32_t)std::min(std::max(total / 32768.0, 2048.0), 8192.0);
-        }
+        const uint32_t target =
+            (uint32_t)std::min(std::max(total / 32768.0, 2048.0), 8192.0);
         std::vector<GatherSlice> slices;
         // big batches: a contiguous run of rows per workgroup instead of a
-        // stride over the whole column (MADRONA_MWHIP_GATHER_BLOCKED=0/1 forces;
-        // measured at 65536 / 16384 Escape-Room worlds on one box,
-        // profiles/r04_sort_variants.jsonl: strided 300 / 53 us, contiguous
-        // 252 / 52 us)
-        const uint32_t blocked_env = envU32("MADRONA_MWHIP_GATHER_BLOCKED", 3);
-        const uint32_t blocked_mode = blocked_env < 2 ? blocked_env :
-            (total >= kGatherBlockedBytes ? 1u : 0u);
+        // stride over the whole column (measured at 65536 / 16384 Escape-Room
+        // worlds on one box, profiles/r04_sort_variants.jsonl: strided 300 /
+        // 53 us, contiguous 252 / 52 us)
+        const uint32_t blocked = total >= kGatherBlockedBytes ? 1u : 0u;
         for (size_t c = 0; c < cols.size(); c++) {
             uint32_t n = (uint32_t)(target * weight[c] / std::max(total, 1.0) + 0.5);
             // at least 4 KB of work per workgroup, at least one workgroup
             n = std::min<uint32_t>(n, (uint32_t)(weight[c] / 4096.0) + 1u);
             n = std::max<uint32_t>(n, 1u);
-            // big tables: a contiguous run of rows per workgroup
-            // (MADRONA_MWHIP_GATHER_BLOCKED=0/1 forces; measured in
-            // profiles/r04_sort_variants.jsonl)
-            const uint32_t blocked = blocked_mode == 1 ? 1u : 0u;
             for (uint32_t i = 0; i < n; i++) {
                 slices.push_back(GatherSlice { (uint32_t)c, i, n, blocked });
             }
@@ -2133,13 +2114,10 @@ static int buildLaunchList(mwhip_exec *exec, const std::vector<uint32_t> &tg_ids
                     // static LDS marker of appendRowIssue; any other static
                     // LDS errs on the safe side) must not visit rows created
                     // during its own node: such nodes fix their row counts
-                    // once per launch.  MADRONA_MWHIP_ROW_SNAPSHOT=0 / 2
-                    // switches this off / on for every node (measurement).
+                    // once per launch.
                     hipFuncAttributes attr {};
                     HIPCHK(hipFuncGetAttributes(&attr, d.kernel));
-                    const uint32_t snap_mode = exec->rowSnapshotMode;
-                    if (d.num_matching > 0 && snap_mode != 0 &&
-                            (attr.sharedSizeBytes != 0 || snap_mode == 2)) {
+                    if (d.num_matching > 0 && attr.sharedSizeBytes != 0) {
                         void *sync_dev = nullptr;
                         int src = devAlloc(exec, &sync_dev,
                             sizeof(PforRowSync) + 8ull * d.num_matching);
@@ -2153,6 +2131,7 @@ static int buildLaunchList(mwhip_exec *exec, const std::vector<uint32_t> &tg_ids
                     k.pforBody = d.pfor_body;
                     k.pforArg1 = d.arg1;
                     k.pforVgprs = (uint32_t)std::max(attr.numRegs, 0);
+                    k.pforWriteMask = d.write_mask;
                 }
                 k.name = node.name;
                 k.role = "";
@@ -2201,7 +2180,7 @@ static int buildLaunchList(mwhip_exec *exec, const std::vector<uint32_t> &tg_ids
                 specs.emplace_back(d.archetype_id, d.component_id);
                 std::string name = node.name;
                 size_t oj = oi + 1;
-                if (exec->sortBatching) {
+                {
                     for (; oj < order.size(); oj++) {
                         const mwhip_node_desc &nd = tg.nodes[order[oj]].desc;
                         if (nd.kind == MWHIP_NODE_RESET_TMP_ALLOC) {
@@ -2771,10 +2750,8 @@ extern "C" int mwhip_create(const mwhip_state_config *cfg,
     exec->exported.assign(cfg->num_exported_buffers, nullptr);
     exec->taskGraphs.resize(cfg->num_task_graphs);
     exec->checkAfterRun = envU32("MADRONA_MWHIP_CHECK", 1) != 0;
-    exec->sortBatching = envU32("MADRONA_MWHIP_SORT_BATCH", 1) != 0;
     exec->sortCarriesMisc = envU32("MADRONA_MWHIP_SORT_CARRIES_MISC", 1) != 0;
     exec->sortCompaction = envU32("MADRONA_MWHIP_SORT_COMPACT", 1);
-    exec->rowSnapshotMode = envU32("MADRONA_MWHIP_ROW_SNAPSHOT", 1);
     exec->eagerReplay = envU32("MADRONA_MWHIP_EAGER", 0) != 0;
     {
         hipDeviceProp_t prop {};
@@ -3120,18 +3097,13 @@ static int renderLaunches(mwhip_exec *exec, std::vector<KernelLaunch> &out)
     if (lay.camera_archetype < exec->rowsAtGraphBuild.size()) {
         views = std::max(exec->rowsAtGraphBuild[lay.camera_archetype], 16u);
     }
-    params.numGeoNodes = (uint32_t)exec->renderGeometry.nodes.size();
-    params.numGeoTriangles =
-        (uint32_t)(exec->renderGeometry.triangleVertices.size() / 9);
-    // persistent workgroups: three fit a CU (LDS), two rounds of them even out
-    // uneven tile runs (measured at config 5: 768 / 1536 workgroups 4.37 ms,
-    // 3072: 4.5, 12288: 4.9 -- every workgroup copies the geometry to LDS)
+    // (the grid: one workgroup per view, at least six per CU -- see
+    // buildRenderLaunches)
     int num_cus = 256;
     (void)hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount,
                                 exec->cfg.gpu_id);
     // (per executor: its own device's CU count)
-    const uint32_t max_wgs =
-        envU32("MADRONA_MWHIP_RAYCAST_WGS", (uint32_t)std::max(num_cus, 1) * 6u);
+    const uint32_t max_wgs = (uint32_t)std::max(num_cus, 1) * 6u;
     buildRenderLaunches(exec->stateDev, params, exec->cfg.num_worlds, views,
                         std::max(max_wgs, 1u), out);
     return 0;
@@ -3233,6 +3205,47 @@ static int groupLaunches(mwhip_exec *exec, LaunchGraph &lg)
         d.erase(std::unique(d.begin(), d.end()), d.end());
         return d;
     };
+    // The reference runs same-dependency siblings one after the other, so a
+    // simulator may lean on registration order without saying so.  What the
+    // signatures show is checked here: two nodes do not share a launch when one
+    // may write (non-const reference) a component the other names, on a table
+    // both queries match.  (What a system reaches through ctx.get() is not in
+    // its signature: INTEGRATION.md section 3, MADRONA_MWHIP_GROUP=0.)
+    auto queryOf = [&](const KernelLaunch &k) -> const QueryRec * {
+        for (const QueryRec &q : exec->queries) {
+            if (q.offset == k.queryOffset) return &q;
+        }
+        return nullptr;
+    };
+    auto tablesOfQuery = [&](const QueryRec &q) {
+        std::vector<uint32_t> tables;
+        const uint32_t *p = exec->queryDataHost.data() + q.offset;
+        for (uint32_t m = 0; m < q.numMatching; m++) {
+            tables.push_back(p[0]);
+            p += 1 + q.comps.size();
+        }
+        return tables;
+    };
+    auto conflicts = [&](const KernelLaunch &a, const KernelLaunch &b) {
+        const QueryRec *qa = queryOf(a), *qb = queryOf(b);
+        if (qa == nullptr || qb == nullptr) return true;
+        bool shared_table = false;
+        const std::vector<uint32_t> tb = tablesOfQuery(*qb);
+        for (uint32_t t : tablesOfQuery(*qa)) {
+            shared_table = shared_table ||
+                std::find(tb.begin(), tb.end(), t) != tb.end();
+        }
+        if (!shared_table) return false;
+        for (size_t ia = 0; ia < qa->comps.size(); ia++) {
+            for (size_t ib = 0; ib < qb->comps.size(); ib++) {
+                if (qa->comps[ia] != qb->comps[ib]) continue;
+                const bool wa = ia >= 32 || ((a.pforWriteMask >> ia) & 1u) != 0u;
+                const bool wb = ib >= 32 || ((b.pforWriteMask >> ib) & 1u) != 0u;
+                if (wa || wb) return true;
+            }
+        }
+        return false;
+    };
     std::vector<KernelLaunch> out;
     for (size_t i = 0; i < lg.launches.size(); ) {
         size_t j = i + 1;
@@ -3242,6 +3255,11 @@ static int groupLaunches(mwhip_exec *exec, LaunchGraph &lg)
                    groupable(lg.launches[j]) &&
                    lg.launches[j].tgId == lg.launches[i].tgId &&
                    depsOf(lg.launches[j]) == deps) {
+                bool clash = false;
+                for (size_t m = i; m < j; m++) {
+                    clash = clash || conflicts(lg.launches[m], lg.launches[j]);
+                }
+                if (clash) break;
                 j++;
             }
         }
@@ -3294,53 +3312,20 @@ static int groupLaunches(mwhip_exec *exec, LaunchGraph &lg)
     return 0;
 }
 
-// Edges of the step's DAG (KernelLaunch::deps).  Launches are in the builder's
-// topological order; a task-graph kernel node depends on the launches of the
-// nodes it named, everything else is a barrier.  OFF by default
-// (MADRONA_MWHIP_DAG=1 turns it on): measured, branches of a hipGraph cost more
-// than the launches they overlap on this runtime -- configs[1] 141 -> 170 us per
-// step, configs[2] 1.110 -> 1.190 ms (profiles/r05_dag_variants.jsonl) --, so
-// the step stays a chain and nodes that may run side by side share ONE launch
-// instead (groupLaunches).
-static void buildLaunchDeps(mwhip_exec *exec, LaunchGraph &lg)
+// Edges of the step's graph (KernelLaunch::deps): a chain in the builder's
+// topological order.  (Round 5 also built the task graph's real edges as
+// branches of the hipGraph and measured them slower than the chain on this
+// runtime -- configs[1] 141 -> 170 us per step, configs[2] 1.110 -> 1.190 ms,
+// profiles/r05_dag_variants.jsonl: a fork / join costs more than the launch
+// floors it overlaps.  Nodes that may run side by side share ONE launch instead,
+// groupLaunches.  The switch is gone since round 6.)
+static void buildLaunchDeps(LaunchGraph &lg)
 {
-    const bool dag = envU32("MADRONA_MWHIP_DAG", 0) != 0 && !exec->eagerReplay;
-    std::map<std::pair<uint32_t, int32_t>, int32_t> launch_of_node;
-    int32_t barrier = -1;
-    std::vector<int32_t> leaves;    // launches since the barrier nobody waits for yet
     for (size_t i = 0; i < lg.launches.size(); i++) {
         KernelLaunch &k = lg.launches[i];
         k.deps.clear();
-        if (dag && k.dagKernel && k.tgId < exec->taskGraphs.size() &&
-                k.tgNode >= 0) {
-            const TaskGraphRec &tg = exec->taskGraphs[k.tgId];
-            for (int32_t d : tg.nodes[(size_t)k.tgNode].deps) {
-                auto it = launch_of_node.find({ k.tgId, d });
-                // (a dependency at or before the barrier is implied by it: every
-                // launch after a barrier waits for it, directly or not)
-                if (it != launch_of_node.end() && it->second > barrier &&
-                        std::find(k.deps.begin(), k.deps.end(), it->second) ==
-                            k.deps.end()) {
-                    k.deps.push_back(it->second);
-                }
-            }
-            if (k.deps.empty() && barrier >= 0) {
-                k.deps.push_back(barrier);
-            }
-            for (int32_t d : k.deps) {
-                leaves.erase(std::remove(leaves.begin(), leaves.end(), d),
-                             leaves.end());
-            }
-            leaves.push_back((int32_t)i);
-            launch_of_node[{ k.tgId, k.tgNode }] = (int32_t)i;
-        } else {
-            if (!leaves.empty()) {
-                k.deps = leaves;
-            } else if (barrier >= 0) {
-                k.deps.push_back(barrier);
-            }
-            barrier = (int32_t)i;
-            leaves.clear();
+        if (i > 0) {
+            k.deps.push_back((int32_t)i - 1);
         }
     }
 }
@@ -3360,7 +3345,9 @@ static int instantiateLaunchGraph(mwhip_exec *exec,
         ~ScopeOn() { (void)e; t_allocScope = nullptr; }
     } scope_on(exec, &lg->ownedAllocations);
 
-    if (envU32("MADRONA_MWHIP_GRIDS_FROM_ROWS", 1) != 0) {
+    // (ParallelFor grids are sized from the rows the tables hold now, not from
+    // their capacities)
+    {
         HIPCHK(hipStreamSynchronize(exec->stream));
         std::vector<TableHdr> hdrs(exec->tablesHost.size());
         HIPCHK(hipMemcpy(hdrs.data(), exec->hostState.tables,
@@ -3370,8 +3357,6 @@ static int instantiateLaunchGraph(mwhip_exec *exec,
             exec->rowsAtGraphBuild[a] =
                 (uint32_t)std::max(hdrs[a].numRows, 0);
         }
-    } else {
-        exec->rowsAtGraphBuild.clear();
     }
 
     lg->isRender = pack_from != nullptr && pack_from->isRender;
@@ -3417,7 +3402,7 @@ static int instantiateLaunchGraph(mwhip_exec *exec,
 
     rc = groupLaunches(exec, *lg);
     if (rc != 0) return rc;
-    buildLaunchDeps(exec, *lg);
+    buildLaunchDeps(*lg);
 
     // The step as an explicit hipGraph: one kernel node per launch, edges from
     // buildLaunchDeps.  (Rounds 1-4 captured the launches from the stream: a

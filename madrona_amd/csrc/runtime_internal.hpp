@@ -217,6 +217,7 @@ struct KernelLaunch {
     uint32_t pforArg1 = 0;                  // num_matching | exclusive-world flag
     bool rowSnapshot = false;               // the node can append rows: never grouped
     uint32_t pforVgprs = 0;                 // of the node's own kernel (groupLaunches)
+    uint32_t pforWriteMask = 0xFFFFFFFFu;   // query components the system may write
     mwhip_pfor_args pforArgs {};
     struct Member {                         // of a grouped launch (profiles)
         std::string name;

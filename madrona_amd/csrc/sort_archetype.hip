@@ -1908,23 +1908,11 @@ int sortNumPasses(bool world_sort, uint32_t num_worlds)
 uint32_t sortTileSize() { return (uint32_t)kSortTile; }
 
 
-// (MADRONA_MWHIP_SORT_SMALL_ROWS overrides it: measurements)
-uint32_t sortSmallRowLimit()
-{
-    const char *e = getenv("MADRONA_MWHIP_SORT_SMALL_ROWS");
-    const uint32_t n = e != nullptr ? (uint32_t)strtoul(e, nullptr, 10) : 0u;
-    return n == 0 ? kSmallSortRows : n;
-}
+uint32_t sortSmallRowLimit() { return kSmallSortRows; }
 
 // rows from which a table that keeps being re-sorted is better off with the
-// compaction chain than with the one-launch sort (runtime.hip, sortsOutgrown;
-// MADRONA_MWHIP_SORT_SMALL_BUSY_ROWS overrides it: measurements)
-uint32_t sortSmallBusyRows()
-{
-    const char *e = getenv("MADRONA_MWHIP_SORT_SMALL_BUSY_ROWS");
-    const uint32_t n = e != nullptr ? (uint32_t)strtoul(e, nullptr, 10) : 0u;
-    return n == 0 ? 768u : n;
-}
+// compaction chain than with the one-launch sort (runtime.hip, sortsOutgrown)
+uint32_t sortSmallBusyRows() { return 768u; }
 
 // rows behind the sorted prefix one workgroup sorts about as fast as the radix
 // chain would take for the whole table; tables that keep exceeding it go back

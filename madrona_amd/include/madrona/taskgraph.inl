@@ -28,6 +28,31 @@ struct SystemTraits<void (*)(CtxT &, ArgTs...)> {
         4u + (0u + ... + systemArgBytes<ArgTs>());
 };
 
+// ---- which of its query's components a system may write ---------------------
+// bit i = argument i behind the context is a non-const lvalue reference.  Only
+// meaningful when the signature has one argument per query component (in the
+// query's order); anything else -- functors, batch systems -- is "all of them".
+template <typename FnT, size_t NumComponents> struct SystemWriteMask {
+    static constexpr uint32_t value = 0xFFFFFFFFu;
+};
+
+template <typename CtxT, typename... ArgTs, size_t NumComponents>
+struct SystemWriteMask<void (*)(CtxT &, ArgTs...), NumComponents> {
+    static constexpr uint32_t compute()
+    {
+        if constexpr (sizeof...(ArgTs) != NumComponents || NumComponents > 32) {
+            return 0xFFFFFFFFu;
+        } else {
+            uint32_t mask = 0, bit = 0;
+            ((mask |= (std::is_lvalue_reference_v<ArgTs> &&
+                       !std::is_const_v<std::remove_reference_t<ArgTs>>) ?
+                          (1u << bit) : 0u, bit++), ...);
+            return mask;
+        }
+    }
+    static constexpr uint32_t value = compute();
+};
+
 // ---- what a system ACTUALLY reads and writes per row -------
 // "Each node declares its read/write set next to the kernel; when unknown,
 // fall back to the signature rule."  A simulator declares it next to the
@@ -791,6 +816,10 @@ CustomParallelForNode<ContextT, Fn, threads_per_invocation,
         (void)mwhip_set_pfor_group_kernel(builder.exec(), group_stub());
     }
 #endif
+
+    // (what the runtime checks before it lets two nodes share a launch)
+    desc.write_mask = mwhip::SystemWriteMask<
+        std::decay_t<decltype(Fn)>, sizeof...(ComponentTs)>::value;
 
     if constexpr (mwhip::systemIO<Fn>.read >= 0) {
         // declared next to the system

@@ -22,7 +22,8 @@ struct SimTraits {
         return Sim::Config { args.seed, args.world_base, args.flags & 1u,
                              (args.flags >> 1) & 1u,
                              (args.flags >> 2) & 1u,
-                             (args.flags >> 3) & 1u };
+                             (args.flags >> 3) & 1u,
+                             (args.flags >> 4) & 1u };
     }
 
     static void makeInits(const SimCreateArgs &, Sim::WorldInit *) {}

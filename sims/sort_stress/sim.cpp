@@ -179,7 +179,28 @@ inline void scratchSumSystem(Engine &ctx, Churn &churn)
     churn.scratchSum = sum;
 }
 
-void Sim::setupTasks(TaskGraphManager &taskgraph_mgr, const Config &)
+// Three nodes that name the same dependency (Config::siblings).  The second
+// reads what the first writes: right only behind it.  The reference runs nodes
+// in registration order whatever they declared; this backend runs nodes with
+// equal dependencies in one launch UNLESS their signatures clash (a non-const
+// reference to a component the other names, on a shared table) -- the first two
+// must stay apart, the last two may share a launch.
+inline void siblingWriteSystem(Engine &, Quad &q)
+{
+    q.v[0] = q.v[0] * 0.5f + 1.f;
+}
+
+inline void siblingReadSystem(Engine &, const Quad &q, Vec3 &v)
+{
+    v.v[2] = q.v[0] + q.v[1];
+}
+
+inline void siblingOtherSystem(Engine &, Blob20 &b)
+{
+    b.v[4] += 3u;
+}
+
+void Sim::setupTasks(TaskGraphManager &taskgraph_mgr, const Config &cfg)
 {
     TaskGraphBuilder &builder = taskgraph_mgr.init(TaskGraphID::Step);
 
@@ -217,7 +238,14 @@ void Sim::setupTasks(TaskGraphManager &taskgraph_mgr, const Config &)
     auto sum_sys = builder.addToGraph<ParallelForNode<Engine,
         scratchSumSystem, Churn>>({scale_sys});
     auto reset_tmp = builder.addToGraph<ResetTmpAllocNode>({sum_sys});
-    (void)reset_tmp;
+    if (cfg.siblings != 0) {
+        builder.addToGraph<ParallelForNode<Engine,
+            siblingWriteSystem, Quad>>({reset_tmp});
+        builder.addToGraph<ParallelForNode<Engine,
+            siblingReadSystem, Quad, Vec3>>({reset_tmp});
+        builder.addToGraph<ParallelForNode<Engine,
+            siblingOtherSystem, Blob20>>({reset_tmp});
+    }
 
 #ifdef MADRONA_GPU_MODE
     {

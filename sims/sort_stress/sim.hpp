@@ -87,6 +87,12 @@ struct Sim : public madrona::WorldBase {
         // short tail behind a long sorted prefix in which ONE scatter tile of
         // the compaction chain owns more new rows than it orders in LDS
         uint32_t burst;
+        // 1: three more nodes behind the step's last one, all naming the SAME
+        // dependency: siblingWriteSystem writes Quad, siblingReadSystem reads
+        // Quad (it only comes out right if it runs behind the first, which is
+        // the registration order the reference's executors follow),
+        // siblingOtherSystem touches Blob20 alone
+        uint32_t siblings;
     };
 
     struct WorldInit {};

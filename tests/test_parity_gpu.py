@@ -1048,3 +1048,22 @@ def test_ball_pit_wave_box_queries(built, monkeypatch, worlds, extra, steps):
         found = hip.read_tensor("query_probe")[:, 1]
         # (the probes do find bodies, in every world)
         assert (found > steps).all(), found.min()
+
+
+def test_same_dependency_siblings_that_clash_keep_their_order(built):
+    """Nodes that named the same dependencies share one launch -- unless their
+    signatures clash: sort_stress with three siblings behind one
+    node, the second reading the Quad the first writes (right only in
+    registration order, which is what the reference's executors run), the third
+    on a column of its own.  Lock step with the reference, and the launch list:
+    the writer alone, the other two side by side."""
+    _need_ref("sort_stress")
+    probs, step = run_pair("sort_stress", 300, 25, seed=7, flags=16, check_every=5)
+    assert not probs, (step, probs[:3])
+    with Simulator(hip_lib_path("sort_stress"), 300, seed=7, flags=16) as s:
+        s.step(2)
+        names = [k["name"] for k in s.profile(2)]
+    assert "sortstress::siblingWriteSystem" in names, names
+    groups = [n for n in names if n.startswith("group[")]
+    assert groups == ["group[sortstress::siblingReadSystem | "
+                      "sortstress::siblingOtherSystem]"], names
