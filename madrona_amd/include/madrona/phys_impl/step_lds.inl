@@ -84,7 +84,7 @@ struct WorldBlock {
     // broadphase boxes are dead once the candidates exist: the contacts of the
     // substeps reuse their storage
     static constexpr size_t boxBytes =
-        MAXB * (2 * sizeof(math::AABB) + sizeof(int32_t));
+        MAXB * (2 * sizeof(math::AABB) + 2 * sizeof(int32_t));
     static constexpr size_t contactBytes =
         maxContacts * sizeof(ContactConstraint);
     alignas(16) char shared[boxBytes > contactBytes ? boxBytes : contactBytes];
@@ -123,10 +123,21 @@ struct WorldBlock {
     {
         return (math::AABB *)shared + MAXB;
     }
-    __device__ inline int32_t *rankEntity()
+    // by traversal rank: { the leaf's entity id, packRankInfo(its body) } -- one
+    // 8-byte read per box test gives everything the candidate pass asks of the
+    // other body
+    __device__ inline int2 *rankEntityInfo()
     {
-        return (int32_t *)((math::AABB *)shared + 2 * MAXB);
+        return (int2 *)((math::AABB *)shared + 2 * MAXB);
     }
+    // body index | primitive count << 8 | (response type is Static) << 16
+    __device__ static inline int32_t packRankInfo(int32_t body, uint32_t prim_count,
+                                                  bool is_static)
+    {
+        return (int32_t)((uint32_t)body | (prim_count << 8) |
+                         (is_static ? 1u << 16 : 0u));
+    }
+    static_assert(MAXB <= 256);
     __device__ inline ContactConstraint *contacts()
     {
         return (ContactConstraint *)shared;
@@ -647,7 +658,9 @@ __device__ __attribute__((always_inline)) inline FramedWorld loadWorldFramed(
             w->primCount[k] = (uint16_t)prim_count;
             w->queryBox()[k] = query_box;
             w->rankSlotBox()[rank] = slot_box;
-            w->rankEntity()[rank] = entity.id;
+            w->rankEntityInfo()[rank] = int2 { entity.id,
+                Block::packRankInfo(k, prim_count,
+                                    resp == ResponseType::Static) };
             w->orderBody[rank] = (uint16_t)k;
             w->leafOf[k] = (uint16_t)leaf;
         }
@@ -886,10 +899,17 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                     // chain of &&: the compiler made it three dependent LDS
                     // round trips and two branches per box -- the later
                     // coordinates were only read if the earlier ones overlapped.)
+                    // ... and so is what used to be a second loop over the
+                    // boxes that passed (orderBody -> resp / primCount: three
+                    // dependent LDS round trips per hit, the lanes of the world
+                    // waiting for the one with the most hits): a pair of two
+                    // static bodies is no candidate, the others count their
+                    // primitive pairs -- both from the word packed next to the
+                    // entity id (rankEntityInfo).
                     uint64_t raw = 0;
                     for (int32_t j = 0; j < r_end; j += 4) {
                         float box[4][6];
-                        int32_t other_id[4];
+                        int2 other[4];
 #pragma unroll
                         for (int32_t u = 0; u < 4; u++) {
                             // (past the world's last body: its last one again)
@@ -902,12 +922,16 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                             box[u][3] = slot.pMax.x;
                             box[u][4] = slot.pMax.y;
                             box[u][5] = slot.pMax.z;
-                            other_id[u] = w->rankEntity()[r];
+                            other[u] = w->rankEntityInfo()[r];
                         }
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int32_t u = 0; u < 4; u++) {
-                            // == query.overlaps(slot) && my_id < other_id
+                            const uint32_t info = (uint32_t)other[u].y;
+                            const uint32_t both_static =
+                                (my_static ? 1u : 0u) & (info >> 16);
+                            // == query.overlaps(slot) && my_id < other_id &&
+                            //    !(both static)
                             const uint32_t hit =
                                 (uint32_t)(query.pMin.x < box[u][3]) &
                                 (uint32_t)(box[u][0] < query.pMax.x) &
@@ -915,23 +939,11 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                                 (uint32_t)(box[u][1] < query.pMax.y) &
                                 (uint32_t)(query.pMin.z < box[u][5]) &
                                 (uint32_t)(box[u][2] < query.pMax.z) &
-                                (uint32_t)(my_id < other_id[u]) &
-                                (uint32_t)(j + u < r_end);
+                                (uint32_t)(my_id < other[u].x) &
+                                (uint32_t)(j + u < r_end) &
+                                (both_static ^ 1u);
                             raw |= (uint64_t)hit << (j + u);
-                        }
-                    }
-                    // ... then the few that passed: static pairs out, the rest
-                    // counted by primitive pairs
-                    uint64_t pending = raw;
-                    while (pending != 0) {
-                        const int32_t jj = (int32_t)__builtin_ctzll(pending);
-                        pending &= pending - 1;
-                        const int32_t kb = w->orderBody[m * 64 + jj];
-                        if (my_static && w->resp[kb] ==
-                                (uint32_t)ResponseType::Static) {
-                            raw &= ~(1ull << jj);
-                        } else {
-                            n += a_prims * w->primCount[kb];
+                            n += hit * a_prims * ((info >> 8) & 0xFFu);
                         }
                     }
                     hits[m] = raw;
@@ -951,15 +963,20 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                         const int32_t r =
                             m * 64 + (int32_t)__builtin_ctzll(pending);
                         pending &= pending - 1;
-                        const int32_t kb = w->orderBody[r];
-                        const uint32_t b_prims = w->primCount[kb];
+                        const uint32_t info = (uint32_t)w->rankEntityInfo()[r].y;
+                        const int32_t kb = (int32_t)(info & 0xFFu);
+                        const uint32_t b_prims = (info >> 8) & 0xFFu;
                         const uint32_t total_checks = a_prims * b_prims;
+                        uint32_t ca = 0, cb = 0;    // c / b_prims, c % b_prims
                         for (uint32_t c = 0; c < total_checks; c++) {
                             const WaveCandidate candidate {
-                                (uint8_t)k, (uint8_t)kb,
-                                (uint8_t)(c / b_prims),
-                                (uint8_t)(c % b_prims),
+                                (uint8_t)k, (uint8_t)kb, (uint8_t)ca, (uint8_t)cb,
                             };
+                            cb++;
+                            if (cb == b_prims) {
+                                cb = 0;
+                                ca++;
+                            }
                             if (out < (uint32_t)Block::maxCandidates) {
                                 w->candidates[out] = candidate;
                             } else {
