@@ -32,16 +32,95 @@ struct WaveCandidate {
     uint8_t bPrim;
 };
 
-// hull-hull scratch of a world's lane groups beyond the first (none when the
-// whole world works on one pair at a time)
-template <int N>
-struct ExtraHullScratch {
-    HullScratch group[N];
-    __device__ inline HullScratch *at(int i) { return &group[i]; }
+// A contact of the LDS step: the bodies are indices inside the world, so the two
+// Locs and the point count of a ContactConstraint (96 B) fit one word (80 B).
+struct PackedContact {
+    math::Vector4 points[4];    // xyz = world position, w = penetration depth
+    math::Vector3 normal;
+    uint32_t meta;              // ref body | alt body << 8 | numPoints << 16
+
+    __device__ static inline PackedContact pack(const ContactConstraint &c)
+    {
+        return PackedContact {
+            { c.points[0], c.points[1], c.points[2], c.points[3] }, c.normal,
+            (uint32_t)c.ref.row | ((uint32_t)c.alt.row << 8) |
+                ((uint32_t)c.numPoints << 16),
+        };
+    }
+    // what the solver reads of a contact (xpbd.hpp, ContactT): the points stay
+    // where they are -- its loops over them index memory, not registers
+    struct View {
+        Loc ref, alt;
+        const math::Vector4 *points;
+        int32_t numPoints;
+        math::Vector3 normal;
+    };
+    __device__ inline View view() const
+    {
+        return View {
+            Loc { 0, (int32_t)(meta & 0xFFu) },
+            Loc { 0, (int32_t)((meta >> 8) & 0xFFu) },
+            points, (int32_t)(meta >> 16), normal,
+        };
+    }
+    __device__ inline int32_t refBody() const { return (int32_t)(meta & 0xFFu); }
+    __device__ inline int32_t altBody() const { return (int32_t)((meta >> 8) & 0xFFu); }
 };
+static_assert(sizeof(PackedContact) == 80);
+
+// Narrowphase scratch of a world in the LDS step: clipping rows of the lanes that
+// test a pair on their own, and the scratch of its cooperative hull-hull tests.
+// One world per wavefront: rows and ONE hull-hull scratch side by side
+// (WaveScratch), a test takes all 64 lanes.  Two worlds per wavefront: the rows
+// are dead when the hull-hull tests of a chunk start, so they share their
+// storage with TWO small hull-hull scratch blocks -- a world's 32 lanes run two
+// tests at a time, 16 lanes each, when a chunk holds more than one (a cube pair
+// has 6 + 6 faces, 8 + 8 vertices and 144 edge pairs: the face queries, the
+// hull transforms and the clipping, which every lane repeats, take the same
+// instructions with 16 lanes as with 32).  Small: hulls of up to 8 vertices and
+// faces in world space (boxes, wedges; larger ones are evaluated lazily), 12
+// corners of clipping; rows of four corners (a hull with larger faces takes the
+// per-lane HBM path), 21 of them -- a chunk of the Escape Room holds ~13
+// hull-plane pairs.
+template <int LPW>
+struct BlockScratch {
+    static constexpr uint32_t polyVerts = lanePolyVerts;
+    static constexpr uint32_t polyDwords = lanePolyDwords;
+    static constexpr uint32_t polyRows = lanePolyRows;
+    static constexpr int hullLanes = LPW;
+    using Hull = HullScratch;
+    WaveScratch both;
+    __device__ inline float *lanePoly() { return both.lanePoly; }
+    __device__ inline Hull *hull(uint32_t) { return &both.hull; }
+};
+
 template <>
-struct ExtraHullScratch<0> {
-    __device__ inline HullScratch *at(int) { return nullptr; }
+struct BlockScratch<32> {
+    static constexpr uint32_t polyVerts = 4;
+    static constexpr uint32_t polyDwords = polyVerts * 4 + 1;
+    static constexpr uint32_t polyRows = 21;
+    static constexpr int hullLanes = 16;
+    using Hull = HullScratchT<8, 12>;
+    union alignas(16) {
+        float rows[polyRows * polyDwords];
+        Hull hullScratch[2];
+    };
+    static_assert(sizeof(float) * polyRows * polyDwords <= 2 * sizeof(Hull));
+    __device__ inline float *lanePoly() { return rows; }
+    __device__ inline Hull *hull(uint32_t group) { return &hullScratch[group]; }
+};
+
+// The object manager's primitives (and as many hull meshes as fit) copied next
+// to the CU; hull pointers inside `prims` are rebased onto `arena`.  One copy
+// per WORKGROUP: the worlds of a wavefront share it (an executor has one
+// object manager; a world with a manager of its own reads it from HBM).
+struct PrimBlock {
+    static constexpr int maxPrims = (int)PrimImage::maxPrims;   // more: hull data stays in HBM
+    static constexpr int arenaDwords = (int)PrimImage::arenaDwords;   // object-space hull meshes
+    CollisionPrimitive prims[maxPrims];
+    math::AABB primAABBs[maxPrims];
+    const void *primMeshKey[maxPrims];      // HBM vertex array of each hull prim
+    alignas(16) uint32_t arena[arenaDwords];
 };
 
 template <int MAXB, int LPW = 64>
@@ -51,14 +130,20 @@ struct WorldBlock {
     // single-wave workgroups per CU, two per SIMD -- what the register cap of
     // the kernel admits.  Six candidates per body in LDS (a dense pile of n
     // bodies has up to n (n - 1) / 2 pairs); more spill to HBM.
-    static constexpr int maxCandidates = MAXB * 6;
+    // (two worlds per wavefront: three per body and as many contacts as lanes --
+    // the Escape Room holds ~21 candidates and ~14 contacts per world; a world
+    // with more candidates spills them, one with more contacts takes the HBM
+    // kernel for the step)
+    static constexpr int maxCandidates = LPW == 32 ? MAXB * 3 : MAXB * 6;
     // (at least one per lane of the world: the narrowphase stages one contact
     // per lane)
-    static constexpr int maxContacts =
-        MAXB + MAXB / 4 > LPW ? MAXB + MAXB / 4 : LPW;
-    static constexpr int maxJoints = 6;         // more: read from HBM
-    static constexpr int maxPrims = (int)PrimImage::maxPrims;   // more: hull data stays in HBM
-    static constexpr int arenaDwords = (int)PrimImage::arenaDwords;   // object-space hull meshes
+    static constexpr int maxContacts = LPW == 32 ? LPW :
+        (MAXB + MAXB / 4 > LPW ? MAXB + MAXB / 4 : LPW);
+    // joints whose ROWS are kept in the block (more: their rows are read from
+    // HBM in every substep) and joints whose body indices are (more: the world
+    // takes the HBM kernel)
+    static constexpr int maxJoints = 2;
+    static constexpr int maxJointBodies = 8;
 
     // ---- the world image: what a step reads from the ECS tables -----------
     // The first imageBytes of this struct are exactly what physicsPackKernel
@@ -66,55 +151,61 @@ struct WorldBlock {
     // with ONE coalesced copy instead of a dozen dependent round trips
     // (row ranges -> column pointers -> body columns -> object metadata ->
     // leaf -> parent node slot), exposed at two waves per SIMD.
-    math::Vector3 pos[MAXB];
-    math::Quat rot[MAXB];
+    // poses[0, MAXB): where the bodies are; behind them the substep's records of
+    // the bodies the solver can change (solverSlot): where each was when the
+    // substep began, then where the integration put it (same layout as
+    // xpbd::SubstepPrevState / PreSolvePositional) -- one array, so that "the
+    // record of body k" is an index and not a branch: an inert static body's
+    // records ARE its pose (LdsBodyStore)
+    struct Pose {
+        math::Vector3 x;
+        math::Quat q;
+    };
+    static_assert(sizeof(Pose) == sizeof(xpbd::SubstepPrevState) &&
+                  sizeof(Pose) == sizeof(xpbd::PreSolvePositional));
     math::Diag3x3 scale[MAXB];
     Velocity vel[MAXB];
-    math::Vector3 extForce[MAXB];
-    math::Vector3 extTorque[MAXB];
+    // (what only the lane that owns a body ever looks at -- external force and
+    // torque, where its row is, its entity id -- stays in that lane's
+    // registers: LaneBodies)
     xpbd::BodyConstants constants[MAXB];    // zeroed for static bodies
-    uint32_t resp[MAXB];
-    Loc bodyLoc[MAXB];                      // where the body's row is (store phase)
-    int32_t entityID[MAXB];
     uint16_t primOffset[MAXB];
-    uint16_t primCount[MAXB];
-    uint16_t orderBody[MAXB];               // traversal rank -> body index
-    uint16_t leafOf[MAXB];                  // body -> BVH leaf (epilogue refit)
+    uint8_t primCount[MAXB];
+    uint8_t resp[MAXB];
+    uint8_t solverKey[MAXB];                // ldsBodyKey: 0 = inert static body, else k + 1
+    static_assert(MAXB < 255);
 
     // broadphase boxes are dead once the candidates exist: the contacts of the
     // substeps reuse their storage
     static constexpr size_t boxBytes =
         MAXB * (2 * sizeof(math::AABB) + 2 * sizeof(int32_t));
     static constexpr size_t contactBytes =
-        maxContacts * sizeof(ContactConstraint);
+        maxContacts * sizeof(PackedContact);
     alignas(16) char shared[boxBytes > contactBytes ? boxBytes : contactBytes];
     // ---- end of the image (imageBytes below) ------------------------------
 
-    xpbd::SubstepPrevState prev[MAXB];
-    xpbd::PreSolvePositional prePos[MAXB];
-    xpbd::PreSolveVelocity preVel[MAXB];
-    uint16_t leafRank[MAXB];                // leaf id -> traversal rank
-    uint16_t solverKey[MAXB];               // ldsBodyKey: 0 = inert static body, else k + 1
+    // State of the substep for the bodies the solver can change (solverKey != 0;
+    // slot = solverSlot[body]).  An inert static body -- most of an Escape
+    // Room's: floor, borders, walls -- is where it was when the substep began
+    // and has no pre-solve velocity: its records are made up from pos / rot
+    // when they are asked for (LdsBodyStore) and when the step is stored.  Two
+    // worlds per wavefront keep 20 slots for 32 bodies (a world with more
+    // takes the HBM kernel; setupPhysicsStepTasks looks at the worlds before
+    // it picks this layout).
+    static constexpr int maxSolverBodies = LPW == 32 ? 20 : MAXB;
+    static constexpr int prevBase = MAXB;
+    static constexpr int prePosBase = MAXB + maxSolverBodies;
+    Pose poses[MAXB + 2 * maxSolverBodies];
+    xpbd::PreSolveVelocity preVel[maxSolverBodies];
+    uint8_t solverSlot[MAXB];               // 0xFF: an inert static body
+    static constexpr uint32_t noSlot = 0xFFu;
     WaveCandidate candidates[maxCandidates];
     float lambdas[maxContacts];
 
     JointConstraint joints[maxJoints];
-    uint16_t jointBodies[maxJoints][2];
+    uint8_t jointBodies[maxJointBodies][2];
     PhysicsSystemState sys;
-    // the object manager's primitives (and as many hull meshes as fit) copied
-    // next to the CU; hull pointers inside `prims` are rebased onto `arena`
-    CollisionPrimitive prims[maxPrims];
-    math::AABB primAABBs[maxPrims];
-    const void *primMeshKey[maxPrims];      // HBM vertex array of each hull prim
-    alignas(16) uint32_t arena[arenaDwords];
-    WaveScratch scratch;
-    // Two worlds per wavefront: a world's 32 lanes run TWO hull-hull tests at a
-    // time, 16 lanes each (a cube pair has 6 + 6 faces, 8 + 8 vertices and 144
-    // edge pairs: the face queries, the hull transforms and the clipping, which
-    // every lane repeats, take the same instructions with 16 lanes as with 32).
-    static constexpr int hullLanes = LPW == 32 ? 16 : LPW;
-    static constexpr int hullGroups = LPW / hullLanes;
-    [[no_unique_address]] ExtraHullScratch<hullGroups - 1> extraHull;
+    BlockScratch<LPW> scratch;
 
     // by body: the box a body queries the tree with; by traversal rank: the
     // slot box the traversal tests and the entity id of that leaf's body
@@ -138,10 +229,14 @@ struct WorldBlock {
                          (is_static ? 1u << 16 : 0u));
     }
     static_assert(MAXB <= 256);
-    __device__ inline ContactConstraint *contacts()
+    __device__ inline PackedContact *contacts()
     {
-        return (ContactConstraint *)shared;
+        return (PackedContact *)shared;
     }
+    // leaf id -> traversal rank, while the world is loaded (the candidate list
+    // does not exist yet)
+    __device__ inline uint16_t *leafRank() { return (uint16_t *)candidates; }
+    static_assert(sizeof(WaveCandidate) * maxCandidates >= sizeof(uint16_t) * MAXB);
 
     // bytes of the world image (a multiple of 16)
     __host__ __device__ static constexpr size_t imageBytes()
@@ -151,37 +246,46 @@ struct WorldBlock {
     }
 };
 
-// Copies `count` dwords with all lanes (of the world's group of LPW).
-template <int LPW = 64>
-__device__ inline void waveCopyDwords(uint32_t lane, uint32_t *dst,
+// What only the lane that owns a body reads: kept in its registers from the
+// load of the world to the store (chunk c of lane l = body c * LPW + l).
+template <int CHUNKS>
+struct LaneBodies {
+    math::Vector3 extForce[CHUNKS];
+    math::Vector3 extTorque[CHUNKS];
+    Loc loc[CHUNKS];            // the body's row
+    int32_t entityID[CHUNKS];
+};
+
+// Copies `count` dwords with `lanes` lanes (`lane` = this one's index among them).
+__device__ inline void waveCopyDwords(uint32_t lane, uint32_t lanes, uint32_t *dst,
                                       const uint32_t *src, uint32_t count)
 {
     // (batching eight loads ahead of the stores -- dst and src are generic
     // pointers -- was measured: 744 -> 753 us, the counts are a few hundred
     // dwords and the registers cost more than the L2 round trips)
-    for (uint32_t i = lane; i < count; i += LPW) {
+    for (uint32_t i = lane; i < count; i += lanes) {
         dst[i] = src[i];
     }
 }
 
-// ... from HBM (global loads, four rounds of the group in flight: the copies
+// ... from HBM (global loads, four rounds of the lanes in flight: the copies
 // of a primitive image are a few hundred dwords, one row of lanes at a time
 // they were a dozen L2 round trips in a row)
-template <int LPW = 64>
-__device__ inline void waveCopyDwordsGlobal(uint32_t lane, uint32_t *dst,
-                                            const uint32_t *src, uint32_t count)
+__device__ inline void waveCopyDwordsGlobal(uint32_t lane, uint32_t lanes,
+                                            uint32_t *dst, const uint32_t *src,
+                                            uint32_t count)
 {
     constexpr uint32_t batch = 4;
-    for (uint32_t first = lane; first < count; first += LPW * batch) {
+    for (uint32_t first = lane; first < count; first += lanes * batch) {
         uint32_t v[batch];
 #pragma unroll
         for (uint32_t u = 0; u < batch; u++) {
-            const uint32_t i = first + u * LPW;
+            const uint32_t i = first + u * lanes;
             v[u] = mwhip::loadGlobal(src + (i < count ? i : first));
         }
 #pragma unroll
         for (uint32_t u = 0; u < batch; u++) {
-            const uint32_t i = first + u * LPW;
+            const uint32_t i = first + u * lanes;
             if (i < count) {
                 dst[i] = v[u];
             }
@@ -189,17 +293,20 @@ __device__ inline void waveCopyDwordsGlobal(uint32_t lane, uint32_t *dst,
     }
 }
 
-// Stages primitives [0, num_prims) of the object manager in LDS.  Returns an
-// ObjectManager whose primitive arrays point at the copies (or the original
-// when they do not fit).
-template <int MAXB, int LPW>
-__device__ inline ObjectManager stagePrimitives(uint32_t lane,
-                                                WorldBlock<MAXB, LPW> *w,
+// Stages primitives [0, num_prims) of the object manager in LDS, with the
+// `lanes` lanes that are in the call together (`lane` = this one's index among
+// them: a world's group, or the whole wavefront when both of its worlds use
+// the same manager).  Returns an ObjectManager whose primitive arrays point at
+// the copies (or the original when they do not fit).
+// image_only: only from the loader's ready-made image (what the copy holds then
+// does not depend on num_prims: callers that share the block may each fill it).
+__device__ inline ObjectManager stagePrimitives(uint32_t lane, uint32_t lanes,
+                                                PrimBlock *pb,
                                                 const ObjectManager &obj_mgr,
-                                                uint32_t num_prims)
+                                                uint32_t num_prims,
+                                                bool image_only)
 {
-    using Block = WorldBlock<MAXB, LPW>;
-    if (num_prims > (uint32_t)Block::maxPrims) {
+    if (num_prims > (uint32_t)PrimBlock::maxPrims) {
         return obj_mgr;
     }
 
@@ -218,41 +325,45 @@ __device__ inline ObjectManager stagePrimitives(uint32_t lane,
                     offsets[i] = mwhip::loadGlobal(&image->meshOffset[lane][i]);
                 }
             }
-            waveCopyDwordsGlobal<LPW>(lane, (uint32_t *)w->prims,
+            waveCopyDwordsGlobal(lane, lanes, (uint32_t *)pb->prims,
                 (const uint32_t *)image->prims,
                 image_prims * (uint32_t)(sizeof(CollisionPrimitive) / 4));
-            waveCopyDwordsGlobal<LPW>(lane, (uint32_t *)w->primAABBs,
+            waveCopyDwordsGlobal(lane, lanes, (uint32_t *)pb->primAABBs,
                 (const uint32_t *)image->primAABBs,
                 image_prims * (uint32_t)(sizeof(math::AABB) / 4));
-            waveCopyDwordsGlobal<LPW>(lane, w->arena, image->arena, arena_used);
+            waveCopyDwordsGlobal(lane, lanes, pb->arena, image->arena, arena_used);
             wave::phaseFence();
             if (lane < image_prims && offsets[0] >= 0) {
-                geo::HalfEdgeMesh &staged = w->prims[lane].hull.halfEdgeMesh;
-                staged.facePlanes = (geo::Plane *)(w->arena + offsets[0]);
-                staged.halfEdges = (geo::HalfEdge *)(w->arena + offsets[1]);
-                staged.vertices = (math::Vector3 *)(w->arena + offsets[2]);
-                staged.faceBaseHalfEdges = w->arena + offsets[3];
+                geo::HalfEdgeMesh &staged = pb->prims[lane].hull.halfEdgeMesh;
+                staged.facePlanes = (geo::Plane *)(pb->arena + offsets[0]);
+                staged.halfEdges = (geo::HalfEdge *)(pb->arena + offsets[1]);
+                staged.vertices = (math::Vector3 *)(pb->arena + offsets[2]);
+                staged.faceBaseHalfEdges = pb->arena + offsets[3];
             }
             wave::phaseFence();
 
             ObjectManager staged = obj_mgr;
-            staged.collisionPrimitives = w->prims;
-            staged.primitiveAABBs = w->primAABBs;
+            staged.collisionPrimitives = pb->prims;
+            staged.primitiveAABBs = pb->primAABBs;
             return staged;
         }
     }
 
-    waveCopyDwords<LPW>(lane, (uint32_t *)w->prims,
+    if (image_only) {
+        return obj_mgr;
+    }
+
+    waveCopyDwords(lane, lanes, (uint32_t *)pb->prims,
         (const uint32_t *)obj_mgr.collisionPrimitives,
         num_prims * (uint32_t)(sizeof(CollisionPrimitive) / 4));
-    waveCopyDwords<LPW>(lane, (uint32_t *)w->primAABBs,
+    waveCopyDwords(lane, lanes, (uint32_t *)pb->primAABBs,
         (const uint32_t *)obj_mgr.primitiveAABBs,
         num_prims * (uint32_t)(sizeof(math::AABB) / 4));
     wave::phaseFence();
     if (lane < num_prims) {
-        w->primMeshKey[lane] =
-            w->prims[lane].type == CollisionPrimitive::Type::Hull ?
-                (const void *)w->prims[lane].hull.halfEdgeMesh.vertices :
+        pb->primMeshKey[lane] =
+            pb->prims[lane].type == CollisionPrimitive::Type::Hull ?
+                (const void *)pb->prims[lane].hull.halfEdgeMesh.vertices :
                 nullptr;
     }
     wave::phaseFence();
@@ -261,19 +372,19 @@ __device__ inline ObjectManager stagePrimitives(uint32_t lane,
     // primitives are staged once
     uint32_t arena_used = 0;
     for (uint32_t p = 0; p < num_prims; p++) {
-        if (w->prims[p].type != CollisionPrimitive::Type::Hull) {
+        if (pb->prims[p].type != CollisionPrimitive::Type::Hull) {
             continue;
         }
 
         // still the HBM pointers: a primitive is only patched in its own turn
-        const geo::HalfEdgeMesh src = w->prims[p].hull.halfEdgeMesh;
+        const geo::HalfEdgeMesh src = pb->prims[p].hull.halfEdgeMesh;
 
         bool shared = false;
         for (uint32_t q = 0; q < p; q++) {
-            if (w->primMeshKey[q] == (const void *)src.vertices) {
+            if (pb->primMeshKey[q] == (const void *)src.vertices) {
                 if (lane == 0) {
-                    w->prims[p].hull.halfEdgeMesh =
-                        w->prims[q].hull.halfEdgeMesh;
+                    pb->prims[p].hull.halfEdgeMesh =
+                        pb->prims[q].hull.halfEdgeMesh;
                 }
                 shared = true;
                 break;
@@ -289,20 +400,20 @@ __device__ inline ObjectManager stagePrimitives(uint32_t lane,
         const uint32_t plane_dw = src.numFaces * 4;
         const uint32_t vert_dw = src.numVertices * 3;
         const uint32_t need = hedge_dw + base_dw + plane_dw + vert_dw;
-        if (arena_used + need > (uint32_t)Block::arenaDwords) {
+        if (arena_used + need > (uint32_t)PrimBlock::arenaDwords) {
             continue;       // stays in HBM
         }
 
-        uint32_t *dst = w->arena + arena_used;
-        waveCopyDwords<LPW>(lane, dst, (const uint32_t *)src.facePlanes, plane_dw);
-        waveCopyDwords<LPW>(lane, dst + plane_dw,
+        uint32_t *dst = pb->arena + arena_used;
+        waveCopyDwords(lane, lanes, dst, (const uint32_t *)src.facePlanes, plane_dw);
+        waveCopyDwords(lane, lanes, dst + plane_dw,
                        (const uint32_t *)src.halfEdges, hedge_dw);
-        waveCopyDwords<LPW>(lane, dst + plane_dw + hedge_dw,
+        waveCopyDwords(lane, lanes, dst + plane_dw + hedge_dw,
                        (const uint32_t *)src.vertices, vert_dw);
-        waveCopyDwords<LPW>(lane, dst + plane_dw + hedge_dw + vert_dw,
+        waveCopyDwords(lane, lanes, dst + plane_dw + hedge_dw + vert_dw,
                        src.faceBaseHalfEdges, base_dw);
         if (lane == 0) {
-            geo::HalfEdgeMesh &staged = w->prims[p].hull.halfEdgeMesh;
+            geo::HalfEdgeMesh &staged = pb->prims[p].hull.halfEdgeMesh;
             staged.facePlanes = (geo::Plane *)dst;
             staged.halfEdges = (geo::HalfEdge *)(dst + plane_dw);
             staged.vertices = (math::Vector3 *)(dst + plane_dw + hedge_dw);
@@ -314,29 +425,47 @@ __device__ inline ObjectManager stagePrimitives(uint32_t lane,
     wave::phaseFence();
 
     ObjectManager staged = obj_mgr;
-    staged.collisionPrimitives = w->prims;
-    staged.primitiveAABBs = w->primAABBs;
+    staged.collisionPrimitives = pb->prims;
+    staged.primitiveAABBs = pb->primAABBs;
     return staged;
 }
 
 template <int MAXB, int LPW = 64>
 struct LdsBodyStore {
-    WorldBlock<MAXB, LPW> *w;
+    using Block = WorldBlock<MAXB, LPW>;
+    Block *w;
 
-    __device__ inline math::Vector3 &position(Loc l) { return w->pos[l.row]; }
-    __device__ inline math::Quat &rotation(Loc l) { return w->rot[l.row]; }
+    __device__ inline math::Vector3 &position(Loc l) { return w->poses[l.row].x; }
+    __device__ inline math::Quat &rotation(Loc l) { return w->poses[l.row].q; }
     __device__ inline Velocity &velocity(Loc l) { return w->vel[l.row]; }
+    // (an inert static body: see WorldBlock::poses.  No branches: a contact's
+    // two bodies are of different kinds lane by lane)
     __device__ inline xpbd::SubstepPrevState prevState(Loc l)
     {
-        return w->prev[l.row];
+        const uint32_t slot = w->solverSlot[l.row];
+        const auto p = w->poses[slot == Block::noSlot ? (uint32_t)l.row :
+                                (uint32_t)Block::prevBase + slot];
+        return xpbd::SubstepPrevState { p.x, p.q };
     }
     __device__ inline xpbd::PreSolvePositional presolvePositional(Loc l)
     {
-        return w->prePos[l.row];
+        const uint32_t slot = w->solverSlot[l.row];
+        const auto p = w->poses[slot == Block::noSlot ? (uint32_t)l.row :
+                                (uint32_t)Block::prePosBase + slot];
+        return xpbd::PreSolvePositional { p.x, p.q };
     }
     __device__ inline xpbd::PreSolveVelocity presolveVelocity(Loc l)
     {
-        return w->preVel[l.row];
+        const uint32_t slot = w->solverSlot[l.row];
+        const bool inert = slot == Block::noSlot;
+        xpbd::PreSolveVelocity v = w->preVel[inert ? 0u : slot];
+        v.v.x = inert ? 0.f : v.v.x;
+        v.v.y = inert ? 0.f : v.v.y;
+        v.v.z = inert ? 0.f : v.v.z;
+        v.omega.x = inert ? 0.f : v.omega.x;
+        v.omega.y = inert ? 0.f : v.omega.y;
+        v.omega.z = inert ? 0.f : v.omega.z;
+        return v;
     }
     __device__ inline xpbd::BodyConstants constants(Loc l)
     {
@@ -368,8 +497,8 @@ __device__ inline PairSetup ldsSetupPair(const WorldBlock<MAXB, LPW> *w,
     return setupPair(obj_mgr, Loc { 0, ka }, Loc { 0, kb },
         (uint32_t)w->primOffset[ka] + candidate.aPrim,
         (uint32_t)w->primOffset[kb] + candidate.bPrim,
-        PrimitiveTransform { w->pos[ka], w->rot[ka], w->scale[ka] },
-        PrimitiveTransform { w->pos[kb], w->rot[kb], w->scale[kb] });
+        PrimitiveTransform { w->poses[ka].x, w->poses[ka].q, w->scale[ka] },
+        PrimitiveTransform { w->poses[kb].x, w->poses[kb].q, w->scale[kb] });
 }
 
 // ---------------------------------------------------------------------------
@@ -391,11 +520,10 @@ struct FramedWorld {
     // their sort or the tree does not match them (kErrPhysics); tooManyBodies:
     // more than the instantiation's MAXB (the HBM kernel takes the world)
     static constexpr int32_t unsteppable = -1;
-    static constexpr int32_t tooManyBodies = -2;
+    static constexpr int32_t tooManyBodies = -2;    // (or joints)
     int32_t numBodies;
     int32_t jointBegin;
     int32_t numJoints;
-    bool jointsStaged;
     const ObjectManager *objMgr;    // the world's manager (HBM)
 };
 
@@ -468,7 +596,8 @@ __device__ __attribute__((always_inline)) inline void roundIssued()
 
 template <int MAXB, int LPW>
 __device__ __attribute__((always_inline)) inline FramedWorld loadWorldFramed(
-    uint32_t lane, WorldBlock<MAXB, LPW> *w, const PhysicsFrame *F, int32_t world)
+    uint32_t lane, WorldBlock<MAXB, LPW> *w, const PhysicsFrame *F, int32_t world,
+    LaneBodies<(MAXB + LPW - 1) / LPW> &mine)
 {
     using Block = WorldBlock<MAXB, LPW>;
     using mwhip::loadGlobal;
@@ -512,13 +641,12 @@ __device__ __attribute__((always_inline)) inline FramedWorld loadWorldFramed(
     out.numBodies = num_bodies;
     out.jointBegin = joint_begin;
     out.numJoints = num_joints;
-    out.jointsStaged = num_joints <= Block::maxJoints;
     out.objMgr = world_mgr;
     if (tables_unsorted != 0u || tree.numLeaves != num_bodies) {
         out.numBodies = FramedWorld::unsteppable;
         return out;
     }
-    if (num_bodies > MAXB) {
+    if (num_bodies > MAXB || num_joints > Block::maxJointBodies) {
         out.numBodies = FramedWorld::tooManyBodies;
         return out;
     }
@@ -543,7 +671,7 @@ __device__ __attribute__((always_inline)) inline FramedWorld loadWorldFramed(
 
     // (the world's joints, when they fit the block: their rows go out first,
     // the entity slots of their bodies with round 5 of the first chunk)
-    const bool my_joint = out.jointsStaged && (int32_t)lane < num_joints;
+    const bool my_joint = (int32_t)lane < num_joints;
     JointConstraint joint {};
     mwhip::EntitySlot joint_slots[2] {};
     if (my_joint) {
@@ -637,91 +765,115 @@ __device__ __attribute__((always_inline)) inline FramedWorld loadWorldFramed(
 #pragma unroll
             for (int32_t r = 0; r < chunks; r++) {
                 if (r * LPW + (int32_t)lane < num_bodies) {
-                    w->leafRank[order_leaf[r]] = (uint16_t)(r * LPW + (int32_t)lane);
+                    w->leafRank()[order_leaf[r]] = (uint16_t)(r * LPW + (int32_t)lane);
                 }
             }
             wave::phaseFence();
         }
+        mine.loc[c] = Loc { archetype, active ? row : -1 };
+        mine.extForce[c] = force;
+        mine.extTorque[c] = torque;
+        mine.entityID[c] = entity.id;
         if (active) {
-            const uint32_t rank = w->leafRank[leaf];
-            w->bodyLoc[k] = Loc { archetype, row };
-            w->pos[k] = pos;
-            w->rot[k] = rot;
+            const uint32_t rank = w->leafRank()[leaf];
+            w->poses[k].x = pos;
+            w->poses[k].q = rot;
             w->scale[k] = scale;
             w->vel[k] = vel;
-            w->extForce[k] = force;
-            w->extTorque[k] = torque;
-            w->resp[k] = (uint32_t)resp;
-            w->entityID[k] = entity.id;
+            w->resp[k] = (uint8_t)resp;
             w->constants[k] = xpbd::bodyConstants(body_metadata, resp);
             w->primOffset[k] = (uint16_t)prim_offset;
-            w->primCount[k] = (uint16_t)prim_count;
+            w->primCount[k] = (uint8_t)prim_count;
             w->queryBox()[k] = query_box;
             w->rankSlotBox()[rank] = slot_box;
             w->rankEntityInfo()[rank] = int2 { entity.id,
                 Block::packRankInfo(k, prim_count,
                                     resp == ResponseType::Static) };
-            w->orderBody[rank] = (uint16_t)k;
-            w->leafOf[k] = (uint16_t)leaf;
         }
     }
+    // (the candidate list -- leafRank's storage -- is written next: the ranks
+    // have been read by now)
     wave::phaseFence();
 
-    // ---- the world's joints (when they fit the block) -------------------------------
-    if (out.jointsStaged) {
+    // ---- the world's joints: which bodies they join ------------------------------
+    if (num_joints > 0) {
+        // (StateManager::getLoc: a stale or empty handle is nowhere)
+        Loc end_loc[2] = { Loc::none(), Loc::none() };
         if (my_joint) {
             const Entity ends[2] = { joint.e1, joint.e2 };
-            uint16_t index[2] = { 0, 0 };
 #pragma unroll
             for (int32_t e = 0; e < 2; e++) {
-                // (StateManager::getLoc: a stale or empty handle is nowhere)
-                Loc loc = Loc::none();
                 if (ends[e].id >= 0 && joint_slots[e].gen == ends[e].gen) {
-                    loc = Loc { joint_slots[e].loc.archetype, joint_slots[e].loc.row };
-                }
-                // body index of the end point: its row among the staged bodies
-                // (no match: body 0, like the table walk)
-                for (int32_t k = 0; k < num_bodies; k++) {
-                    const Loc at = w->bodyLoc[k];
-                    if (at.archetype == loc.archetype && at.row == loc.row) {
-                        index[e] = (uint16_t)k;
-                        break;
-                    }
+                    end_loc[e] = Loc { joint_slots[e].loc.archetype,
+                                       joint_slots[e].loc.row };
                 }
             }
-            w->joints[lane] = joint;
-            w->jointBodies[lane][0] = index[0];
-            w->jointBodies[lane][1] = index[1];
+        }
+        // body index of an end point = the lane (and chunk) whose row it is:
+        // joint j's lane asks, every lane answers for its bodies (no match:
+        // body 0, like the table walk of rounds 1-3)
+        uint32_t index[2] = { 0u, 0u };
+        for (int32_t j = 0; j < num_joints; j++) {
+#pragma unroll
+            for (int32_t e = 0; e < 2; e++) {
+                const uint32_t want_arch = __shfl(end_loc[e].archetype, j, LPW);
+                const int32_t want_row = __shfl(end_loc[e].row, j, LPW);
+                uint32_t found = 0;
+                bool any = false;
+#pragma unroll
+                for (int32_t c = chunks - 1; c >= 0; c--) {
+                    const uint64_t match = wave::groupBallot<LPW>(
+                        mine.loc[c].row >= 0 && mine.loc[c].archetype == want_arch &&
+                        mine.loc[c].row == want_row);
+                    if (match != 0) {
+                        found = (uint32_t)(c * LPW) +
+                            (uint32_t)__builtin_ctzll(match);
+                        any = true;
+                    }
+                }
+                if ((int32_t)lane == j && any) {
+                    index[e] = found;
+                }
+            }
+        }
+        if (my_joint) {
+            if ((int32_t)lane < Block::maxJoints) {
+                w->joints[lane] = joint;
+            }
+            w->jointBodies[lane][0] = (uint8_t)index[0];
+            w->jointBodies[lane][1] = (uint8_t)index[1];
         }
         wave::phaseFence();
     }
     return out;
 }
 
-// Two waves per SIMD: PMC shows the step parked on s_waitcnt 45 % of its wave
-// cycles at one wave per SIMD (SQ_WAIT_ANY / SQ_WAVE_CYCLES); capping the
-// kernel at 256 registers costs spills but lets a second world fill those
-// gaps (measured 1140 -> 868 us per step at 8192 worlds).
-#ifndef MADRONA_PHYS_LDS_WAVES_PER_EU
-#define MADRONA_PHYS_LDS_WAVES_PER_EU 2
-#endif
-// (two worlds per wavefront: one wavefront per SIMD with the whole register
-// file -- a pair of world blocks is 37.8 KB of LDS, four per CU; 2 = the
-// register cap a second wavefront per SIMD would need, measured by itself in
-// profiles/r04_phys_variants.jsonl)
-#ifndef MADRONA_PHYS_LDS32_WAVES_PER_EU
-#define MADRONA_PHYS_LDS32_WAVES_PER_EU 1
-#endif
+// Wavefronts per SIMD.  The step is bound by instruction issue and by the
+// latency of its LDS / HBM round trips (SQ counters, profiles/r06_phys_occupancy_
+// counters.jsonl: one wavefront per SIMD issues 59 % of its cycles and waits
+// 38 %), so what it wants is a second instruction stream per SIMD: 256
+// registers per wavefront and 20 KB of LDS per workgroup.
 //
-// LPW = lanes per world.  64: one world per wavefront.  32: TWO worlds per
-// wavefront, one per half (MAXB <= 32): a 28-body world with ~14 contacts and
-// ~40 candidates keeps 45 % of 64 lanes busy, and the kernel is bound by
-// instruction issue -- the same instruction stream then advances two worlds.
+// LPW = lanes per world.  64: one world per wavefront (MAXB <= 64: 19-26 KB
+// blocks, two wavefronts per SIMD).  32: TWO worlds per wavefront, one per half
+// (MAXB <= 32): a 28-body world with ~14 contacts and ~21 candidates keeps 45 %
+// of 64 lanes busy -- the same instruction stream then advances two worlds.
 // Every wave-level primitive works on the world's group of LPW lanes
 // (wave::groupBallot, shuffles of width LPW); loop trip counts, early exits and
 // the level loops of the solver are per group, the halves diverge where their
-// worlds differ.  Two 32-body blocks are 35 KB of LDS: four wavefronts per CU,
-// one per SIMD, with the whole register file (512) to themselves.
+// worlds differ.  Rounds 3-5 ran this layout at ONE wavefront per SIMD with the
+// whole register file (two 19 KB blocks = 37.9 KB per workgroup, four per CU);
+// since round 6 a pair of blocks and the workgroup's primitive image are 20 256
+// B -- eight workgroups per CU, two per SIMD (profiles/r06_diet*_variants.jsonl:
+// 680 -> 575 us at 8192 Escape-Room worlds, 301 dwords spilled under the
+// 256-register cap).  -DMADRONA_PHYS_LDS32_WAVES_PER_EU=1 keeps one (394
+// registers) for measurements.
+#ifndef MADRONA_PHYS_LDS_WAVES_PER_EU
+#define MADRONA_PHYS_LDS_WAVES_PER_EU 2
+#endif
+#ifndef MADRONA_PHYS_LDS32_WAVES_PER_EU
+#define MADRONA_PHYS_LDS32_WAVES_PER_EU 2
+#endif
 #ifdef MADRONA_PHYS_LDS_NUM_VGPR
 // (measurement builds: a register cap without the occupancy to go with it --
 // the compiler ignores amdgpu_waves_per_eu above what the LDS block admits)
@@ -740,8 +892,8 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
     using Block = WorldBlock<MAXB, LPW>;
     static_assert(LPW == 64 || (LPW == 32 && MAXB <= 32));
     constexpr int worlds_per_wave = 64 / LPW;
+    constexpr int32_t chunks = (MAXB + LPW - 1) / LPW;  // bodies per lane
 
-    StateManager *state_mgr = static_cast<StateManager *>(S);
     PhysicsScratch *ps = detail::scratch(S);
     const PhysicsStepParams params = *(const PhysicsStepParams *)node_data;
 
@@ -751,6 +903,7 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
     const int32_t num_worlds = S->numWorlds;
 
     __shared__ Block blocks[worlds_per_wave];
+    __shared__ PrimBlock prim_block;
     Block *w = &blocks[group];
     LdsBodyStore<MAXB, LPW> store { w };
 
@@ -822,11 +975,11 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
         const int32_t world = world_order[order_slot];
         const long long cost_t0 = (long long)wall_clock64();
         uint32_t cost_work = 1;    // (what the world asked of the wavefront, roughly)
-        Context ctx = TaskGraph::makeContext<Context>(
-            state_mgr, WorldID { world }, true);
 
         // ---- the world through the frame: HBM -> LDS in five rounds ---------
-        const FramedWorld framed = loadWorldFramed<MAXB, LPW>(lane, w, frame, world);
+        LaneBodies<chunks> mine;
+        const FramedWorld framed =
+            loadWorldFramed<MAXB, LPW>(lane, w, frame, world, mine);
         if (framed.numBodies < 0) {
             if (framed.numBodies == FramedWorld::tooManyBodies) {
                 toFallback(world);
@@ -843,16 +996,49 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
 
         // primitives referenced by this world's bodies
         uint32_t prim_end = 0;
-        for (int32_t k = (int32_t)lane; k < num_bodies; k += LPW) {
-            uint32_t end = (uint32_t)w->primOffset[k] + w->primCount[k];
-            prim_end = end > prim_end ? end : prim_end;
-            w->solverKey[k] =
-                (w->resp[k] == (uint32_t)ResponseType::Static &&
-                 staticBodyIsInert(w->rot[k])) ? (uint16_t)0 : (uint16_t)(k + 1);
+        // ... and the bodies the solver can change, with their slots
+        uint32_t solver_bodies = 0;
+#pragma unroll
+        for (int32_t c = 0; c < chunks; c++) {
+            const int32_t k = c * LPW + (int32_t)lane;
+            bool solved = false;
+            if (k < num_bodies) {
+                uint32_t end = (uint32_t)w->primOffset[k] + w->primCount[k];
+                prim_end = end > prim_end ? end : prim_end;
+                solved = !((uint32_t)w->resp[k] == (uint32_t)ResponseType::Static &&
+                           staticBodyIsInert(w->poses[k].q));
+                w->solverKey[k] = solved ? (uint8_t)(k + 1) : (uint8_t)0;
+            }
+            const uint64_t solved_mask = wave::groupBallot<LPW>(solved);
+            if (k < num_bodies) {
+                w->solverSlot[k] = solved ? (uint8_t)(solver_bodies +
+                    wave::rankInGroup(solved_mask, lane)) : (uint8_t)Block::noSlot;
+            }
+            solver_bodies += (uint32_t)__builtin_popcountll(solved_mask);
+        }
+        if (solver_bodies > (uint32_t)Block::maxSolverBodies) {
+            // (nothing of the world has been changed yet)
+            toFallback(world);
+            continue;
         }
         prim_end = wave::maxReduce<LPW>(prim_end);
-        const ObjectManager obj_mgr =
-            stagePrimitives<MAXB, LPW>(lane, w, hbm_obj_mgr, prim_end);
+        // One primitive image per workgroup.  Two worlds share it: it then only
+        // ever holds the loader's image of the EXECUTOR's manager -- whichever
+        // world fills it, and whenever, the bytes are the same --, a world with
+        // a manager of its own (or a manager without an image) reads its
+        // primitives from HBM.  Worlds that are here together copy with all
+        // their lanes.
+        ObjectManager obj_mgr = hbm_obj_mgr;
+        if constexpr (worlds_per_wave == 1) {
+            obj_mgr = stagePrimitives(lane, (uint32_t)LPW, &prim_block, hbm_obj_mgr,
+                                      prim_end, false);
+        } else if (framed.objMgr == frame->objMgr) {
+            const uint64_t here = __builtin_amdgcn_ballot_w64(true);
+            const bool both = (uint32_t)here != 0u && (uint32_t)(here >> 32) != 0u;
+            obj_mgr = stagePrimitives(both ? wave::laneID() : lane,
+                                      both ? 64u : (uint32_t)LPW, &prim_block,
+                                      hbm_obj_mgr, prim_end, true);
+        }
         PHYS_PROF(9);
 
         // ---- broadphase: candidate pairs in (body, traversal) order -----------
@@ -868,7 +1054,12 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
             candidates_per_world *
                 (uint32_t)(sizeof(CandidateCollision) / sizeof(WaveCandidate));
         uint32_t num_candidates = 0;
-        for (int32_t chunk = 0; chunk < num_bodies; chunk += LPW) {
+#pragma unroll
+        for (int32_t cc = 0; cc < chunks; cc++) {
+            const int32_t chunk = cc * LPW;
+            if (chunk >= num_bodies) {
+                break;
+            }
             const int32_t k = chunk + (int32_t)lane;
             const bool active = k < num_bodies;
 
@@ -882,9 +1073,9 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
             uint32_t n = 0;
             if (active) {
                 const math::AABB query = w->queryBox()[k];
-                const int32_t my_id = w->entityID[k];
+                const int32_t my_id = mine.entityID[cc];
                 const bool my_static =
-                    w->resp[k] == (uint32_t)ResponseType::Static;
+                    (uint32_t)w->resp[k] == (uint32_t)ResponseType::Static;
                 const uint32_t a_prims = w->primCount[k];
 
 #pragma unroll
@@ -1008,35 +1199,29 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
         const JointConstraint *joints =
             mwhip::loadInvariant(&frame->joints) + framed.jointBegin;
 
-        // body index of a joint end point (the per-archetype row ranges are not
-        // kept alive through the substeps: look the row up among the staged
-        // bodies -- a handful of LDS reads, once per joint)
-        auto jointBodyLoc = [&](Entity e) {
-            Loc loc = ctx.loc(e);
-            for (int32_t k = 0; k < num_bodies; k++) {
-                Loc body = w->bodyLoc[k];
-                if (body.archetype == loc.archetype && body.row == loc.row) {
-                    return Loc { 0, k };
-                }
-            }
-            return Loc { 0, 0 };
-        };
-        // (staged by loadWorldFramed when they fit the block)
-        const bool joints_staged = framed.jointsStaged;
-
         PHYS_PROF(7);
         bool bailed = false;
         for (int32_t substep = 0; substep < params.numSubsteps; substep++) {
             // ---- integrate (xpbd.cpp substepRigidBodies) ------------------------
-            for (int32_t k = (int32_t)lane; k < num_bodies; k += LPW) {
-                Vector3 x = w->pos[k];
-                Quat q = w->rot[k];
+#pragma unroll
+            for (int32_t c = 0; c < chunks; c++) {
+                const int32_t k = c * LPW + (int32_t)lane;
+                if (k >= num_bodies) {
+                    continue;
+                }
+                if (w->solverKey[k] == 0) {
+                    continue;       // (inert static body: no records)
+                }
+                const uint32_t slot = w->solverSlot[k];
+                Vector3 x = w->poses[k].x;
+                Quat q = w->poses[k].q;
+                const uint32_t resp = (uint32_t)w->resp[k];
 
-                w->prev[k] = xpbd::SubstepPrevState { x, q };
+                w->poses[Block::prevBase + slot] = typename Block::Pose { x, q };
 
-                if (w->resp[k] == (uint32_t)ResponseType::Static) {
-                    w->prePos[k] = xpbd::PreSolvePositional { x, q };
-                    w->preVel[k] = xpbd::PreSolveVelocity {
+                if (resp == (uint32_t)ResponseType::Static) {
+                    w->poses[Block::prePosBase + slot] = typename Block::Pose { x, q };
+                    w->preVel[slot] = xpbd::PreSolveVelocity {
                         Vector3::zero(), Vector3::zero() };
                     continue;
                 }
@@ -1044,14 +1229,14 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                 xpbd::SubstepResult next = xpbd::integrateBody(
                     x, q, w->vel[k].linear, w->vel[k].angular,
                     w->constants[k].invMass, w->constants[k].invInertia,
-                    w->extForce[k],
-                    w->extTorque[k], w->sys.g, w->sys.h,
-                    w->resp[k] == (uint32_t)ResponseType::Dynamic);
+                    mine.extForce[c], mine.extTorque[c], w->sys.g, w->sys.h,
+                    resp == (uint32_t)ResponseType::Dynamic);
 
-                w->pos[k] = next.x;
-                w->rot[k] = next.q;
-                w->prePos[k] = xpbd::PreSolvePositional { next.x, next.q };
-                w->preVel[k] = xpbd::PreSolveVelocity { next.v, next.omega };
+                w->poses[k].x = next.x;
+                w->poses[k].q = next.q;
+                w->poses[Block::prePosBase + slot] =
+                    typename Block::Pose { next.x, next.q };
+                w->preVel[slot] = xpbd::PreSolveVelocity { next.v, next.omega };
             }
             wave::phaseFence();
             PHYS_PROF(2);
@@ -1074,7 +1259,7 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                 width = width < (uint32_t)LPW ? width : (uint32_t)LPW;
                 width = width < free_slots ? width : free_slots;
 
-                ContactConstraint *stage = w->contacts() + num_contacts;
+                PackedContact *stage = w->contacts() + num_contacts;
                 bool has_contact = false;
                 bool too_big = false;
                 bool unsupported = false;
@@ -1092,22 +1277,30 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                     }
                     PHYS_PROF(0);
 
-                    // lanes on their own, in rounds of lanePolyRows scratch rows
+                    // lanes on their own, in rounds of the block's scratch rows
+                    using Scratch = BlockScratch<LPW>;
                     uint64_t solo = wave::groupBallot<LPW>(kind == 1);
                     const uint32_t solo_rank = wave::rankInGroup(solo, lane);
                     const uint32_t solo_count =
                         (uint32_t)__builtin_popcountll(solo);
                     for (uint32_t first = 0; first < solo_count;
-                         first += lanePolyRows) {
+                         first += Scratch::polyRows) {
                         if (kind == 1 && solo_rank >= first &&
-                                solo_rank < first + lanePolyRows) {
+                                solo_rank < first + Scratch::polyRows) {
+                            ContactConstraint made;
                             has_contact = collidePairLane(pair,
-                                w->scratch.lanePoly +
-                                    (solo_rank - first) * lanePolyDwords,
-                                stage + lane, &too_big, &unsupported);
+                                w->scratch.lanePoly() +
+                                    (solo_rank - first) * Scratch::polyDwords,
+                                &made, &too_big, &unsupported,
+                                Scratch::polyVerts);
+                            if (has_contact) {
+                                stage[lane] = PackedContact::pack(made);
+                            }
                         }
                     }
                 }
+                // (the hull-hull scratch may be the rows' storage)
+                wave::phaseFence();
 
                 PHYS_PROF(3);
                 uint64_t hull_pairs = wave::groupBallot<LPW>(kind == 2);
@@ -1125,43 +1318,11 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                     }
                 }
 #endif
-                constexpr int hull_lanes = Block::hullLanes;
-                constexpr int hull_groups = Block::hullGroups;
+                constexpr int hull_lanes = BlockScratch<LPW>::hullLanes;
+                constexpr int hull_groups = LPW / hull_lanes;
                 static_assert(hull_groups == 1 || hull_groups == 2);
                 const uint32_t hull_group = lane / (uint32_t)hull_lanes;
                 const uint32_t hull_lane = lane % (uint32_t)hull_lanes;
-                HullScratch *hull_scratch = hull_group == 0 ?
-                    &w->scratch.hull : w->extraHull.at(0);
-                if constexpr (hull_groups == 2) {
-                    // Most chunks hold at most one hull-hull pair per world
-                    // (3.4 pairs per world and step on the Escape Room): then
-                    // all of the world's lanes take it instead of leaving one of
-                    // the two groups idle -- unless the other world of the
-                    // wavefront has more, whose path this one would have to sit
-                    // through anyway.
-                    const uint32_t mine =
-                        (uint32_t)__builtin_popcountll(hull_pairs);
-                    const uint32_t other = __shfl_xor(mine, LPW, 64);
-                    if (mine <= 1u && other <= 1u) {
-                        if (hull_pairs != 0) {
-                            const uint32_t src =
-                                (uint32_t)__builtin_ctzll(hull_pairs);
-                            hull_pairs = 0;
-                            bool pair_too_big = false;
-                            PairSetup shared_pair = ldsSetupPair(
-                                w, obj_mgr, candidateAt(chunk + src));
-                            const bool found = hullHullWave<LPW>(lane, shared_pair,
-                                &w->scratch.hull, stage + src, &pair_too_big,
-                                PHYS_HH_PROF());
-                            const uint32_t outcome = __shfl(
-                                (found ? 1u : 0u) | (pair_too_big ? 2u : 0u), 0, LPW);
-                            if (lane == src) {
-                                has_contact = (outcome & 1u) != 0u;
-                                too_big = (outcome & 2u) != 0u;
-                            }
-                        }
-                    }
-                }
                 while (hull_pairs != 0) {
                     // the next pairs of the world, one per group of hull_lanes
                     const uint32_t src0 = (uint32_t)__builtin_ctzll(hull_pairs);
@@ -1175,18 +1336,22 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
 
                     bool found = false;
                     bool pair_too_big = false;
+                    // (every lane of the group ends up with the same contact)
+                    ContactConstraint made;
                     if (src != 0xFFFFFFFFu) {
                         PairSetup shared_pair =
                             ldsSetupPair(w, obj_mgr, candidateAt(chunk + src));
-                        // every lane of the group writes the same contact to
-                        // src's slot
                         found = hullHullWave<hull_lanes>(hull_lane, shared_pair,
-                            hull_scratch, stage + src, &pair_too_big,
+                            w->scratch.hull(hull_group), &made, &pair_too_big,
                             PHYS_HH_PROF());
                     }
-                    // the lane that owns the candidate learns the outcome
+                    // the lane that owns the candidate keeps the outcome: the
+                    // first lane of its group hands it over
                     const uint32_t outcome =
                         (found ? 1u : 0u) | (pair_too_big ? 2u : 0u);
+                    if (found && hull_lane == 0u) {
+                        stage[src] = PackedContact::pack(made);
+                    }
                     const uint32_t outcome0 = __shfl(outcome, 0, LPW);
                     if (lane == src0) {
                         has_contact = (outcome0 & 1u) != 0u;
@@ -1195,9 +1360,6 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
 #ifdef MADRONA_PHYS_PROFILE
                     if (lane == 0) {
                         prof_acc[13] += outcome0 & 1u;
-                        if (hull_groups == 2 && src1 != 0xFFFFFFFFu) {
-                            prof_acc[13] += __shfl(outcome, hull_lanes, LPW) & 1u;
-                        }
                     }
 #endif
                     if (hull_groups == 2) {
@@ -1206,6 +1368,11 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                             has_contact = (outcome1 & 1u) != 0u;
                             too_big = (outcome1 & 2u) != 0u;
                         }
+#ifdef MADRONA_PHYS_PROFILE
+                        if (lane == 0 && src1 != 0xFFFFFFFFu) {
+                            prof_acc[13] += outcome1 & 1u;
+                        }
+#endif
                     }
                 }
 
@@ -1229,9 +1396,13 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                             tmp_faces + MADRONA_PHYS_MAX_HULL_ELEMS);
                         PairSetup pair = ldsSetupPair(w, obj_mgr,
                                                       candidateAt(chunk + lane));
+                        ContactConstraint made;
                         has_contact = collidePairStored(pair, tmp_vertices,
-                            tmp_faces, MADRONA_PHYS_MAX_HULL_ELEMS, stage + lane,
+                            tmp_faces, MADRONA_PHYS_MAX_HULL_ELEMS, &made,
                             &unsupported);
+                        if (has_contact) {
+                            stage[lane] = PackedContact::pack(made);
+                        }
                     }
                     wave::phaseFence();
                 }
@@ -1244,7 +1415,7 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                 uint64_t mask = wave::groupBallot<LPW>(has_contact);
                 const uint32_t rank = wave::rankInGroup(mask, lane);
                 const bool moves = has_contact && rank != lane;
-                ContactConstraint moved;
+                PackedContact moved;
                 if (moves) {
                     moved = stage[lane];
                 }
@@ -1277,8 +1448,8 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                 const uint32_t i = base + lane;
                 uint32_t key_a = 0, key_b = 0;
                 if (lane < n) {
-                    key_a = ldsBodyKey(w, w->contacts()[i].ref.row);
-                    key_b = ldsBodyKey(w, w->contacts()[i].alt.row);
+                    key_a = ldsBodyKey(w, w->contacts()[i].refBody());
+                    key_b = ldsBodyKey(w, w->contacts()[i].altBody());
                 }
                 uint32_t level = constraintLevels<LPW>(lane, n, key_a, key_b);
                 uint32_t max_level = wave::maxReduce<LPW>(lane < n ? level : 0);
@@ -1290,27 +1461,22 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                 for (uint32_t l = 0; l <= max_level; l++) {
                     if (lane < n && level == l) {
                         float lambda_n[4] { 0.f, 0.f, 0.f, 0.f };
-                        xpbd::handleContact(store, w->contacts()[i], lambda_n);
+                        xpbd::handleContact(store, w->contacts()[i].view(),
+                                            lambda_n);
                         w->lambdas[i] = lambda_n[0];
                     }
                     wave::phaseFence();
                 }
             }
 
-            for (int32_t base = 0; base < num_joints; base += LPW) {
-                const uint32_t n = num_joints - base < LPW ?
-                    (uint32_t)(num_joints - base) : (uint32_t)LPW;
-                const int32_t i = base + (int32_t)lane;
+            // (at most maxJointBodies of them: one window)
+            if (num_joints > 0) {
+                const uint32_t n = (uint32_t)num_joints;
                 Loc l1 { 0, 0 }, l2 { 0, 0 };
                 uint32_t key_a = 0, key_b = 0;
                 if (lane < n) {
-                    if (joints_staged) {
-                        l1 = Loc { 0, (int32_t)w->jointBodies[i][0] };
-                        l2 = Loc { 0, (int32_t)w->jointBodies[i][1] };
-                    } else {
-                        l1 = jointBodyLoc(joints[i].e1);
-                        l2 = jointBodyLoc(joints[i].e2);
-                    }
+                    l1 = Loc { 0, (int32_t)w->jointBodies[lane][0] };
+                    l2 = Loc { 0, (int32_t)w->jointBodies[lane][1] };
                     key_a = ldsBodyKey(w, l1.row);
                     key_b = ldsBodyKey(w, l2.row);
                 }
@@ -1319,8 +1485,10 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
 
                 for (uint32_t l = 0; l <= max_level; l++) {
                     if (lane < n && level == l) {
+                        // (rows beyond the block's: out of the sorted table)
                         xpbd::handleJointConstraint(store, l1, l2,
-                            joints_staged ? w->joints[i] : joints[i]);
+                            lane < (uint32_t)Block::maxJoints ? w->joints[lane] :
+                                                                joints[lane]);
                     }
                     wave::phaseFence();
                 }
@@ -1329,8 +1497,8 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
             PHYS_PROF(4);
             // ---- velocities -----------------------------------------------------
             for (int32_t k = (int32_t)lane; k < num_bodies; k += LPW) {
-                w->vel[k] = xpbd::deriveVelocity(w->pos[k], w->rot[k],
-                                                 w->prev[k], w->sys.h);
+                w->vel[k] = xpbd::deriveVelocity(w->poses[k].x, w->poses[k].q,
+                    store.prevState(Loc { 0, k }), w->sys.h);
             }
             wave::phaseFence();
             PHYS_PROF(4);
@@ -1344,8 +1512,8 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                 if (base != 0) {
                     uint32_t key_a = 0, key_b = 0;
                     if (lane < n) {
-                        key_a = ldsBodyKey(w, w->contacts()[i].ref.row);
-                        key_b = ldsBodyKey(w, w->contacts()[i].alt.row);
+                        key_a = ldsBodyKey(w, w->contacts()[i].refBody());
+                        key_b = ldsBodyKey(w, w->contacts()[i].altBody());
                     }
                     level = constraintLevels<LPW>(lane, n, key_a, key_b);
                     max_level = wave::maxReduce<LPW>(lane < n ? level : 0);
@@ -1354,7 +1522,8 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                 for (uint32_t l = 0; l <= max_level; l++) {
                     if (lane < n && level == l) {
                         float lambda_n[4] { w->lambdas[i], 0.f, 0.f, 0.f };
-                        xpbd::solveVelocitiesForContact(store, w->contacts()[i],
+                        xpbd::solveVelocitiesForContact(store,
+                            w->contacts()[i].view(),
                             lambda_n, w->sys.h,
                             w->sys.restitutionThreshold);
                     }
@@ -1374,8 +1543,13 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
         // column was: load the column address, wait -- for the stores before
         // it as well, they share the counter --, store: 14 us per pair of
         // worlds in the phase profile, now 3.)
-        for (int32_t k = (int32_t)lane; k < num_bodies; k += LPW) {
-            const Loc loc = w->bodyLoc[k];
+#pragma unroll
+        for (int32_t c = 0; c < chunks; c++) {
+            const int32_t k = c * LPW + (int32_t)lane;
+            if (k >= num_bodies) {
+                continue;
+            }
+            const Loc loc = mine.loc[c];
             const TableHdr &tbl = mwhip::tablesOf(S)[loc.archetype];
             base::Position *col_pos = (base::Position *)
                 mwhip::loadGlobal(&tbl.columns[RGDCols::Position]);
@@ -1390,12 +1564,14 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
             xpbd::PreSolveVelocity *col_pre_vel = (xpbd::PreSolveVelocity *)
                 mwhip::loadGlobal(&tbl.columns[xpbd::XPBDCols::PreSolveVelocity]);
             roundIssued();
-            const base::Position pos = w->pos[k];
-            const base::Rotation rot = w->rot[k];
+            const base::Position pos = w->poses[k].x;
+            const base::Rotation rot = w->poses[k].q;
             const Velocity vel = w->vel[k];
-            const xpbd::SubstepPrevState prev = w->prev[k];
-            const xpbd::PreSolvePositional pre_pos = w->prePos[k];
-            const xpbd::PreSolveVelocity pre_vel = w->preVel[k];
+            const xpbd::SubstepPrevState prev = store.prevState(Loc { 0, k });
+            const xpbd::PreSolvePositional pre_pos =
+                store.presolvePositional(Loc { 0, k });
+            const xpbd::PreSolveVelocity pre_vel =
+                store.presolveVelocity(Loc { 0, k });
             mwhip::storeGlobal(col_pos + loc.row, pos);
             mwhip::storeGlobal(col_rot + loc.row, rot);
             mwhip::storeGlobal(col_vel + loc.row, vel);

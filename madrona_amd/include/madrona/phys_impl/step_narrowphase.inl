@@ -18,11 +18,18 @@ inline constexpr uint32_t waveHullElems = 16;   // vertices, faces per hull
 
 // scratch of ONE cooperative hull-hull test (a world runs as many at a time as
 // it has lane groups for them: hullHullWave<G>)
-struct alignas(16) HullScratch {
-    math::Vector3 clip[2][wavePolyVerts];
-    math::Vector3 hullVerts[2][waveHullElems];
-    geo::Plane hullPlanes[2][waveHullElems];
+// (ELEMS: vertices / faces per hull it holds in world space -- a larger hull is
+// evaluated lazily; POLY: corners of the reference + the incident face it clips
+// -- more: the pair takes the per-lane HBM path)
+template <uint32_t ELEMS, uint32_t POLY>
+struct alignas(16) HullScratchT {
+    static constexpr uint32_t elems = ELEMS;
+    static constexpr uint32_t poly = POLY;
+    math::Vector3 clip[2][POLY];
+    math::Vector3 hullVerts[2][ELEMS];
+    geo::Plane hullPlanes[2][ELEMS];
 };
+using HullScratch = HullScratchT<waveHullElems, wavePolyVerts>;
 
 struct alignas(16) WaveScratch {
     float lanePoly[lanePolyRows * lanePolyDwords];
@@ -178,10 +185,10 @@ struct HullHullProf {
 #endif
 };
 
-template <int LPW = 64, typename HullA, typename HullB>
+template <int LPW = 64, typename ScratchT, typename HullA, typename HullB>
 __device__ inline bool hullHullWaveSAT(uint32_t lane, const PairSetup &pair,
                                        HullA &a, const HullB &b,
-                                       HullScratch *scratch,
+                                       ScratchT *scratch,
                                        ContactConstraint *out, bool *too_big,
                                        HullHullProf prof = HullHullProf {});
 
@@ -190,20 +197,20 @@ __device__ inline bool hullHullWaveSAT(uint32_t lane, const PairSetup &pair,
 // clipped polygon may not fit the LDS scratch.
 // (A template so that only the device pass instantiates it.  Keeping it out of
 // line to confine its register footprint was measured: 1166 -> 1637 us.)
-template <int LPW = 64>
+template <int LPW = 64, typename ScratchT = HullScratch>
 __device__ inline bool
 hullHullWave(uint32_t lane, const PairSetup &pair,
-                                    HullScratch *scratch,
+                                    ScratchT *scratch,
                                     ContactConstraint *out, bool *too_big,
                                     HullHullProf prof = HullHullProf {})
 {
     const HalfEdgeMesh &a_mesh = pair.aPrim->hull.halfEdgeMesh;
     const HalfEdgeMesh &b_mesh = pair.bPrim->hull.halfEdgeMesh;
 
-    if (a_mesh.numVertices <= waveHullElems &&
-        a_mesh.numFaces <= waveHullElems &&
-        b_mesh.numVertices <= waveHullElems &&
-        b_mesh.numFaces <= waveHullElems) {
+    if (a_mesh.numVertices <= ScratchT::elems &&
+        a_mesh.numFaces <= ScratchT::elems &&
+        b_mesh.numVertices <= ScratchT::elems &&
+        b_mesh.numFaces <= ScratchT::elems) {
         // small hulls: transform once into LDS
         HullState a = makeHullStateWave<LPW>(lane, a_mesh, pair.a,
             scratch->hullVerts[0], scratch->hullPlanes[0]);
@@ -444,22 +451,17 @@ __device__ inline Manifold createFaceContactWave(uint32_t lane, Plane ref_plane,
 }
 
 // (only hulls staged in LDS take the lane-parallel manifold)
-template <int LPW, typename HullA, typename HullB>
-__device__ inline bool faceContactWave(uint32_t, const SATResult &, const HullA &,
-                                       const HullB &, const PairSetup &,
-                                       HullScratch *, uint32_t, uint32_t,
-                                       ContactConstraint *, bool *)
-{
-    return false;
-}
-
-template <int LPW>
+template <int LPW, typename ScratchT, typename HullA, typename HullB>
 __device__ inline bool faceContactWave(uint32_t lane, const SATResult &sat,
-                                       const HullState &a, const HullState &b,
-                                       const PairSetup &pair, HullScratch *scratch,
+                                       const HullA &a, const HullB &b,
+                                       const PairSetup &pair, ScratchT *scratch,
                                        uint32_t n_ref, uint32_t n_inc,
                                        ContactConstraint *out, bool *found)
 {
+  if constexpr (!std::is_same_v<HullA, HullState> ||
+                !std::is_same_v<HullB, HullState>) {
+    return false;
+  } else {
 #ifdef MADRONA_PHYS_SEQUENTIAL_MANIFOLD
     return false;
 #else
@@ -486,12 +488,13 @@ __device__ inline bool faceContactWave(uint32_t lane, const SATResult &sat,
     }
     return true;
 #endif
+  }
 }
 
-template <int LPW, typename HullA, typename HullB>
+template <int LPW, typename ScratchT, typename HullA, typename HullB>
 __device__ inline bool hullHullWaveSAT(uint32_t lane, const PairSetup &pair,
                                        HullA &a, const HullB &b,
-                                       HullScratch *scratch,
+                                       ScratchT *scratch,
                                        ContactConstraint *out, bool *too_big,
                                        HullHullProf prof)
 {
@@ -533,7 +536,7 @@ __device__ inline bool hullHullWaveSAT(uint32_t lane, const PairSetup &pair,
                                     faceVertexCount(b, ref_face);
         uint32_t n_inc = a_is_ref ? faceVertexCount(b, inc_face) :
                                     faceVertexCount(a, inc_face);
-        if (n_ref + n_inc > wavePolyVerts) {
+        if (n_ref + n_inc > ScratchT::poly) {
             *too_big = true;
             return false;
         }
@@ -553,9 +556,12 @@ __device__ inline bool hullHullWaveSAT(uint32_t lane, const PairSetup &pair,
 
 // Every other primitive pair: one lane, hull evaluated lazily, clipping
 // scratch in the lane's LDS row.
+// row: poly_verts points + poly_verts depths of clipping scratch (a hull whose
+// face has more corners comes back with *too_big set)
 __device__ inline bool collidePairLane(const PairSetup &pair, float *row,
                                        ContactConstraint *out,
-                                       bool *too_big, bool *unsupported)
+                                       bool *too_big, bool *unsupported,
+                                       uint32_t poly_verts = lanePolyVerts)
 {
     switch (pair.test) {
     case NarrowphaseTest::SphereSphere:
@@ -569,8 +575,8 @@ __device__ inline bool collidePairLane(const PairSetup &pair, float *row,
         // the contact polygon is (part of) the face SAT picks: it must fit
         // the lane's LDS row
         return hullPlaneContact(a, pair.b, pair.aLoc, pair.bLoc,
-                                row, row + lanePolyVerts * 3, out,
-                                (CountT)lanePolyVerts, too_big);
+                                row, row + poly_verts * 3, out,
+                                (CountT)poly_verts, too_big);
     }
     case NarrowphaseTest::SphereHull: {
         // hull in the sphere's frame, evaluated lazily (no centroid needed)

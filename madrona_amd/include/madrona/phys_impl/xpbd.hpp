@@ -294,7 +294,10 @@ MADRONA_HD inline LocalContacts getLocalSpaceContacts(
 }
 
 // depth-weighted average of the manifold; true when all depths are zero
-MADRONA_HD inline bool getAvgContact(const ContactConstraint &contact,
+// (ContactT: a ContactConstraint, or anything with its ref / alt / points[] /
+// numPoints / normal -- the LDS step hands in a view of its packed contacts)
+template <typename ContactT>
+MADRONA_HD inline bool getAvgContact(const ContactT &contact,
                                      Vector3 *avg_out, float *penetration_out)
 {
     Vector3 avg_contact = Vector3::zero();
@@ -631,9 +634,9 @@ struct EcsBodyStore {
     }
 };
 
-template <typename StoreT>
+template <typename StoreT, typename ContactT>
 MADRONA_HD inline void handleContact(StoreT &store,
-                                     const ContactConstraint &contact,
+                                     const ContactT &contact,
                                      float *lambdas)
 {
     Vector3 *x1_ptr = &store.position(contact.ref);
@@ -709,9 +712,9 @@ MADRONA_HD inline void handleJointConstraint(StoreT &store, Loc l1, Loc l2,
     *q2_ptr = q2;
 }
 
-template <typename StoreT>
+template <typename StoreT, typename ContactT>
 MADRONA_HD inline void solveVelocitiesForContact(
-    StoreT &store, const ContactConstraint &contact, const float *lambda_n,
+    StoreT &store, const ContactT &contact, const float *lambda_n,
     float h, float restitution_threshold)
 {
     Velocity *v1_out = &store.velocity(contact.ref);

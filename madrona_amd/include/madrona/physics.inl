@@ -1534,7 +1534,7 @@ __device__ inline void rebuildTreeStaged(broadphase::BVH &bvh, uint32_t lane,
     }
 #endif
 
-    waveCopyDwords(lane, (uint32_t *)bvh.rawNodes(),
+    waveCopyDwords(lane, 64u, (uint32_t *)bvh.rawNodes(),
         (const uint32_t *)staging.nodes,
         (uint32_t)num_nodes * (broadphase::BVH::nodeBytes / 4));
     for (int32_t i = (int32_t)lane; i < num_leaves; i += 64) {
@@ -2495,25 +2495,41 @@ MADRONA_HOST_API inline TaskGraphNodeID setupPhysicsStepTasks(
     mwhip_exec *exec = builder.exec();
     int max_bodies = (int)phys::detail::capacityHint(
         "MADRONA_MWHIP_PHYS_MAX_BODIES", 0);
-    if (max_bodies == 0) {
+    // bodies per world that are not Static (what the two-worlds-per-wavefront
+    // layout keeps solver records for; world_step.inl, maxSolverBodies)
+    int bulk_movable = 0;
+    {
         // rows per world of every rigid-body archetype, as initialised
         const uint32_t num_worlds = mwhip_num_worlds(exec);
         std::vector<int32_t> per_world(num_worlds, 0);
+        std::vector<int32_t> movable(num_worlds, 0);
         std::vector<int32_t> counts(num_worlds);
-        std::vector<int32_t> world_ids;
+        std::vector<int32_t> resp;
         for (uint32_t i = 0; i < ps.numBodyArchetypes; i++) {
             int32_t rows = mwhip_num_rows(exec, ps.bodyArchetypes[i]);
-            world_ids.resize((size_t)(rows > 0 ? rows : 1));
+            resp.resize((size_t)(rows > 0 ? rows : 1));
+            static_assert(sizeof(ResponseType) == sizeof(int32_t));
             int64_t n = mwhip_dump_column(exec, ps.bodyArchetypes[i],
-                TypeTracker::typeID<WorldID>(), world_ids.data(),
-                world_ids.size() * sizeof(int32_t), counts.data());
+                TypeTracker::typeID<ResponseType>(), resp.data(),
+                resp.size() * sizeof(int32_t), counts.data());
             if (n < 0) {
                 FATAL("physics: cannot read the body tables");
             }
+            size_t row = 0;
             for (uint32_t w = 0; w < num_worlds; w++) {
                 per_world[w] += counts[w];
+                for (int32_t r = 0; r < counts[w]; r++, row++) {
+                    movable[w] += resp[row] != (int32_t)ResponseType::Static ? 1 : 0;
+                }
             }
         }
+        std::sort(movable.begin(), movable.end());
+        if (!movable.empty()) {
+            const size_t covered =
+                (movable.size() - 1) - (movable.size() - 1) / 50;
+            bulk_movable = movable[covered] + movable[covered] / 16;
+        }
+      if (max_bodies == 0) {
         // The instantiation is sized for the bulk of the worlds, not for the
         // largest one: what 98 % of them hold (+ 1/16); a world beyond it --
         // at build time or later -- is stepped by the HBM kernel in fallback
@@ -2524,6 +2540,7 @@ MADRONA_HOST_API inline TaskGraphNodeID setupPhysicsStepTasks(
         const int32_t bulk = per_world.empty() ? 1 :
             (per_world[covered] > 1 ? per_world[covered] : 1);
         max_bodies = bulk + bulk / 16;
+      }
     }
     max_bodies = max_bodies <= 32 ? 32 : max_bodies <= 64 ? 64 :
                  max_bodies <= 128 ? 128 : 0;
@@ -2532,7 +2549,9 @@ MADRONA_HOST_API inline TaskGraphNodeID setupPhysicsStepTasks(
     // (phys_impl/world_step.inl; measured on 8192 Escape-Room worlds: 830 ->
     // 712 us per step, profiles/r03_phys_variants.jsonl).
     // MADRONA_MWHIP_PHYS_LANES=64 keeps one world per wavefront.
-    const int lanes_per_world = max_bodies == 32 &&
+    // (that layout keeps solver records for 20 of a world's 32 bodies: worlds
+    // whose bulk has more bodies that move stay one to a wavefront)
+    const int lanes_per_world = max_bodies == 32 && bulk_movable <= 20 &&
         phys::detail::capacityHint("MADRONA_MWHIP_PHYS_LANES", 32) == 32 ? 32 : 64;
 
     // The LDS kernels take their worlds heaviest first (physicsOrderKernel:
