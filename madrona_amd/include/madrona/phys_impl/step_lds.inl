@@ -68,30 +68,52 @@ struct PackedContact {
 };
 static_assert(sizeof(PackedContact) == 80);
 
+// (what the narrowphase routines call to hand over their result, physics.inl:
+// straight into the packed record -- found through its namespace)
+__device__ inline void manifoldToContact(const narrowphase::Manifold &manifold,
+                                         Loc ref_loc, Loc other_loc,
+                                         PackedContact *out)
+{
+    for (int i = 0; i < 4; i++) {
+        out->points[i] = math::Vector4::fromVec3W(manifold.contactPoints[i],
+                                                  manifold.penetrationDepths[i]);
+    }
+    out->normal = manifold.normal;
+    out->meta = (uint32_t)ref_loc.row | ((uint32_t)other_loc.row << 8) |
+        ((uint32_t)manifold.numContactPoints << 16);
+}
+
+__device__ inline void sphereToContact(const narrowphase::SphereContact &sphere,
+                                       Loc a_loc, Loc b_loc, PackedContact *out)
+{
+    out->points[0] = math::Vector4::fromVec3W(sphere.pt, sphere.depth);
+    out->points[1] = math::Vector4::zero();
+    out->points[2] = math::Vector4::zero();
+    out->points[3] = math::Vector4::zero();
+    out->normal = sphere.normal;
+    out->meta = (uint32_t)b_loc.row | ((uint32_t)a_loc.row << 8) | (1u << 16);
+}
+
 // Narrowphase scratch of a world in the LDS step: clipping rows of the lanes that
-// test a pair on their own, and the scratch of its cooperative hull-hull tests.
-// One world per wavefront: rows and ONE hull-hull scratch side by side
-// (WaveScratch), a test takes all 64 lanes.  Two worlds per wavefront: the rows
-// are dead when the hull-hull tests of a chunk start, so they share their
-// storage with TWO small hull-hull scratch blocks -- a world's 32 lanes run two
-// tests at a time, 16 lanes each, when a chunk holds more than one (a cube pair
-// has 6 + 6 faces, 8 + 8 vertices and 144 edge pairs: the face queries, the
-// hull transforms and the clipping, which every lane repeats, take the same
-// instructions with 16 lanes as with 32).  Small: hulls of up to 8 vertices and
-// faces in world space (boxes, wedges; larger ones are evaluated lazily), 12
-// corners of clipping; rows of four corners (a hull with larger faces takes the
-// per-lane HBM path), 21 of them -- a chunk of the Escape Room holds ~13
-// hull-plane pairs.
+// test a pair on their own, and the scratch of ONE cooperative hull-hull test
+// (a world runs its hull-hull pairs one after the other, with all of its
+// lanes).  One world per wavefront: both side by side (WaveScratch).  Two
+// worlds per wavefront: the rows are dead when the hull-hull tests of a chunk
+// start, the two share their storage; rows of four corners (what the faces of
+// boxes and wedges need; a hull with larger faces takes the per-lane HBM path),
+// 21 of them -- a chunk of the Escape Room holds ~13 hull-plane pairs.
+// (Rounds 3-5 gave a 32-lane world two scratch blocks and ran two tests side by
+// side, 16 lanes each.  With two small blocks -- HullScratchT<8, 12> -- in the
+// same storage that is 372 spilled dwords instead of 301 under the 256-register
+// cap and 593 us against 576: profiles/r06_hull_variants.jsonl.)
 template <int LPW>
 struct BlockScratch {
     static constexpr uint32_t polyVerts = lanePolyVerts;
     static constexpr uint32_t polyDwords = lanePolyDwords;
     static constexpr uint32_t polyRows = lanePolyRows;
-    static constexpr int hullLanes = LPW;
-    using Hull = HullScratch;
     WaveScratch both;
     __device__ inline float *lanePoly() { return both.lanePoly; }
-    __device__ inline Hull *hull(uint32_t) { return &both.hull; }
+    __device__ inline HullScratch *hull() { return &both.hull; }
 };
 
 template <>
@@ -99,15 +121,13 @@ struct BlockScratch<32> {
     static constexpr uint32_t polyVerts = 4;
     static constexpr uint32_t polyDwords = polyVerts * 4 + 1;
     static constexpr uint32_t polyRows = 21;
-    static constexpr int hullLanes = 16;
-    using Hull = HullScratchT<8, 12>;
     union alignas(16) {
         float rows[polyRows * polyDwords];
-        Hull hullScratch[2];
+        HullScratch hullScratch;
     };
-    static_assert(sizeof(float) * polyRows * polyDwords <= 2 * sizeof(Hull));
+    static_assert(sizeof(float) * polyRows * polyDwords <= sizeof(HullScratch));
     __device__ inline float *lanePoly() { return rows; }
-    __device__ inline Hull *hull(uint32_t group) { return &hullScratch[group]; }
+    __device__ inline HullScratch *hull() { return &hullScratch; }
 };
 
 // The object manager's primitives (and as many hull meshes as fit) copied next
@@ -1287,15 +1307,11 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                          first += Scratch::polyRows) {
                         if (kind == 1 && solo_rank >= first &&
                                 solo_rank < first + Scratch::polyRows) {
-                            ContactConstraint made;
                             has_contact = collidePairLane(pair,
                                 w->scratch.lanePoly() +
                                     (solo_rank - first) * Scratch::polyDwords,
-                                &made, &too_big, &unsupported,
+                                stage + lane, &too_big, &unsupported,
                                 Scratch::polyVerts);
-                            if (has_contact) {
-                                stage[lane] = PackedContact::pack(made);
-                            }
                         }
                     }
                 }
@@ -1318,62 +1334,30 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                     }
                 }
 #endif
-                constexpr int hull_lanes = BlockScratch<LPW>::hullLanes;
-                constexpr int hull_groups = LPW / hull_lanes;
-                static_assert(hull_groups == 1 || hull_groups == 2);
-                const uint32_t hull_group = lane / (uint32_t)hull_lanes;
-                const uint32_t hull_lane = lane % (uint32_t)hull_lanes;
                 while (hull_pairs != 0) {
-                    // the next pairs of the world, one per group of hull_lanes
-                    const uint32_t src0 = (uint32_t)__builtin_ctzll(hull_pairs);
+                    // the next pair of the world, with all of its lanes
+                    const uint32_t src = (uint32_t)__builtin_ctzll(hull_pairs);
                     hull_pairs &= hull_pairs - 1;
-                    uint32_t src1 = 0xFFFFFFFFu;
-                    if (hull_groups == 2 && hull_pairs != 0) {
-                        src1 = (uint32_t)__builtin_ctzll(hull_pairs);
-                        hull_pairs &= hull_pairs - 1;
-                    }
-                    const uint32_t src = hull_group == 0 ? src0 : src1;
 
-                    bool found = false;
                     bool pair_too_big = false;
-                    // (every lane of the group ends up with the same contact)
-                    ContactConstraint made;
-                    if (src != 0xFFFFFFFFu) {
-                        PairSetup shared_pair =
-                            ldsSetupPair(w, obj_mgr, candidateAt(chunk + src));
-                        found = hullHullWave<hull_lanes>(hull_lane, shared_pair,
-                            w->scratch.hull(hull_group), &made, &pair_too_big,
-                            PHYS_HH_PROF());
-                    }
-                    // the lane that owns the candidate keeps the outcome: the
-                    // first lane of its group hands it over
-                    const uint32_t outcome =
-                        (found ? 1u : 0u) | (pair_too_big ? 2u : 0u);
-                    if (found && hull_lane == 0u) {
-                        stage[src] = PackedContact::pack(made);
-                    }
-                    const uint32_t outcome0 = __shfl(outcome, 0, LPW);
-                    if (lane == src0) {
-                        has_contact = (outcome0 & 1u) != 0u;
-                        too_big = (outcome0 & 2u) != 0u;
+                    PairSetup shared_pair =
+                        ldsSetupPair(w, obj_mgr, candidateAt(chunk + src));
+                    // every lane writes the same contact to src's slot
+                    const bool found = hullHullWave<LPW>(lane, shared_pair,
+                        w->scratch.hull(), stage + src, &pair_too_big,
+                        PHYS_HH_PROF());
+                    // the lane that owns the candidate learns the outcome
+                    const uint32_t outcome = __shfl(
+                        (found ? 1u : 0u) | (pair_too_big ? 2u : 0u), 0, LPW);
+                    if (lane == src) {
+                        has_contact = (outcome & 1u) != 0u;
+                        too_big = (outcome & 2u) != 0u;
                     }
 #ifdef MADRONA_PHYS_PROFILE
                     if (lane == 0) {
-                        prof_acc[13] += outcome0 & 1u;
+                        prof_acc[13] += outcome & 1u;
                     }
 #endif
-                    if (hull_groups == 2) {
-                        const uint32_t outcome1 = __shfl(outcome, hull_lanes, LPW);
-                        if (lane == src1) {
-                            has_contact = (outcome1 & 1u) != 0u;
-                            too_big = (outcome1 & 2u) != 0u;
-                        }
-#ifdef MADRONA_PHYS_PROFILE
-                        if (lane == 0 && src1 != 0xFFFFFFFFu) {
-                            prof_acc[13] += outcome1 & 1u;
-                        }
-#endif
-                    }
                 }
 
                 // Hulls whose faces outgrow the LDS scratch (rare: none in the
@@ -1396,13 +1380,9 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                             tmp_faces + MADRONA_PHYS_MAX_HULL_ELEMS);
                         PairSetup pair = ldsSetupPair(w, obj_mgr,
                                                       candidateAt(chunk + lane));
-                        ContactConstraint made;
                         has_contact = collidePairStored(pair, tmp_vertices,
-                            tmp_faces, MADRONA_PHYS_MAX_HULL_ELEMS, &made,
+                            tmp_faces, MADRONA_PHYS_MAX_HULL_ELEMS, stage + lane,
                             &unsupported);
-                        if (has_contact) {
-                            stage[lane] = PackedContact::pack(made);
-                        }
                     }
                     wave::phaseFence();
                 }

@@ -185,11 +185,12 @@ struct HullHullProf {
 #endif
 };
 
-template <int LPW = 64, typename ScratchT, typename HullA, typename HullB>
+template <int LPW = 64, typename ScratchT, typename HullA, typename HullB,
+          typename OutT>
 __device__ inline bool hullHullWaveSAT(uint32_t lane, const PairSetup &pair,
                                        HullA &a, const HullB &b,
                                        ScratchT *scratch,
-                                       ContactConstraint *out, bool *too_big,
+                                       OutT *out, bool *too_big,
                                        HullHullProf prof = HullHullProf {});
 
 // Hull-hull pair handled by a group of LPW lanes (`pair` is uniform across the
@@ -197,11 +198,12 @@ __device__ inline bool hullHullWaveSAT(uint32_t lane, const PairSetup &pair,
 // clipped polygon may not fit the LDS scratch.
 // (A template so that only the device pass instantiates it.  Keeping it out of
 // line to confine its register footprint was measured: 1166 -> 1637 us.)
-template <int LPW = 64, typename ScratchT = HullScratch>
+template <int LPW = 64, typename ScratchT = HullScratch,
+          typename OutT = ContactConstraint>
 __device__ inline bool
 hullHullWave(uint32_t lane, const PairSetup &pair,
                                     ScratchT *scratch,
-                                    ContactConstraint *out, bool *too_big,
+                                    OutT *out, bool *too_big,
                                     HullHullProf prof = HullHullProf {})
 {
     const HalfEdgeMesh &a_mesh = pair.aPrim->hull.halfEdgeMesh;
@@ -451,12 +453,13 @@ __device__ inline Manifold createFaceContactWave(uint32_t lane, Plane ref_plane,
 }
 
 // (only hulls staged in LDS take the lane-parallel manifold)
-template <int LPW, typename ScratchT, typename HullA, typename HullB>
+template <int LPW, typename ScratchT, typename HullA, typename HullB,
+          typename OutT>
 __device__ inline bool faceContactWave(uint32_t lane, const SATResult &sat,
                                        const HullA &a, const HullB &b,
                                        const PairSetup &pair, ScratchT *scratch,
                                        uint32_t n_ref, uint32_t n_inc,
-                                       ContactConstraint *out, bool *found)
+                                       OutT *out, bool *found)
 {
   if constexpr (!std::is_same_v<HullA, HullState> ||
                 !std::is_same_v<HullB, HullState>) {
@@ -491,11 +494,12 @@ __device__ inline bool faceContactWave(uint32_t lane, const SATResult &sat,
   }
 }
 
-template <int LPW, typename ScratchT, typename HullA, typename HullB>
+template <int LPW, typename ScratchT, typename HullA, typename HullB,
+          typename OutT>
 __device__ inline bool hullHullWaveSAT(uint32_t lane, const PairSetup &pair,
                                        HullA &a, const HullB &b,
                                        ScratchT *scratch,
-                                       ContactConstraint *out, bool *too_big,
+                                       OutT *out, bool *too_big,
                                        HullHullProf prof)
 {
     FaceQuery face_query_a = queryFaceDirectionsWave<LPW>(lane, a, b);
@@ -558,8 +562,9 @@ __device__ inline bool hullHullWaveSAT(uint32_t lane, const PairSetup &pair,
 // scratch in the lane's LDS row.
 // row: poly_verts points + poly_verts depths of clipping scratch (a hull whose
 // face has more corners comes back with *too_big set)
+template <typename OutT>
 __device__ inline bool collidePairLane(const PairSetup &pair, float *row,
-                                       ContactConstraint *out,
+                                       OutT *out,
                                        bool *too_big, bool *unsupported,
                                        uint32_t poly_verts = lanePolyVerts)
 {

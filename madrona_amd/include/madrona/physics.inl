@@ -850,12 +850,14 @@ MADRONA_HD inline void sphereToContact(const SphereContact &sphere,
 // SAT feature -> manifold -> constraint (reference generateContacts,
 // narrowphase.cpp:1516-1680).  tmp_a / tmp_b: clipping scratch, each large
 // enough for the clipped incident polygon (Vector3s).
-template <typename HullA, typename HullB>
+// (OutT, here and below: a ContactConstraint, or whatever manifoldToContact /
+// sphereToContact have an overload for -- the LDS step's packed contacts)
+template <typename HullA, typename HullB, typename OutT>
 MADRONA_HD inline bool satToContact(const SATResult &sat,
                                     const HullA &a, const HullB &b,
                                     Loc a_loc, Loc b_loc,
                                     void *tmp_a, void *tmp_b,
-                                    ContactConstraint *out)
+                                    OutT *out)
 {
     const Vector3 no_offset { 0, 0, 0 };
     const Quat no_rot { 1, 0, 0, 0 };
@@ -898,7 +900,7 @@ MADRONA_HD inline bool satToContact(const SATResult &sat,
     return false;
 }
 
-template <typename HullT>
+template <typename HullT, typename OutT>
 // tmp_a / tmp_b hold one entry per vertex of the incident face; a caller with
 // less room than the largest face passes its capacity and gets *too_big when
 // the face SAT picked does not fit.
@@ -906,7 +908,7 @@ MADRONA_HD inline bool hullPlaneContact(const HullT &a_hull,
                                         const PrimitiveTransform &plane_txfm,
                                         Loc a_loc, Loc b_loc,
                                         void *tmp_a, void *tmp_b,
-                                        ContactConstraint *out,
+                                        OutT *out,
                                         CountT tmp_capacity = -1,
                                         bool *too_big = nullptr)
 {
@@ -950,8 +952,9 @@ MADRONA_HD inline bool hullPlaneContact(const HullT &a_hull,
     return true;
 }
 
+template <typename OutT>
 MADRONA_HD inline bool sphereSphereContact(const PairSetup &pair,
-                                           ContactConstraint *out)
+                                           OutT *out)
 {
     float a_radius = pair.a.scale.d0 * pair.aPrim->sphere.radius;
     float b_radius = pair.b.scale.d0 * pair.bPrim->sphere.radius;
@@ -972,8 +975,9 @@ MADRONA_HD inline bool sphereSphereContact(const PairSetup &pair,
     return true;
 }
 
+template <typename OutT>
 MADRONA_HD inline bool spherePlaneContact(const PairSetup &pair,
-                                          ContactConstraint *out)
+                                          OutT *out)
 {
     float sphere_radius = pair.a.scale.d0 * pair.aPrim->sphere.radius;
 
@@ -997,10 +1001,10 @@ MADRONA_HD inline bool spherePlaneContact(const PairSetup &pair,
 // Sphere (a) against hull (b).  `b_hull` is the hull in the frame centred on
 // the sphere (translation b.pos - a.pos), so the sphere sits at the origin
 // (reference narrowphaseDispatch, SphereHull case, narrowphase.cpp:1325-1409).
-template <typename HullT>
+template <typename HullT, typename OutT>
 MADRONA_HD inline bool sphereHullContact(const PairSetup &pair,
                                          const HullT &b_hull,
-                                         ContactConstraint *out)
+                                         OutT *out)
 {
     float sphere_radius = pair.a.scale.d0 * pair.aPrim->sphere.radius;
 
@@ -1059,11 +1063,12 @@ MADRONA_HD inline bool sphereHullContact(const PairSetup &pair,
 // and the polygons written through Vector3 lvalues, so type-based alias
 // analysis lets the compiler sink a plane load below the polygon stores; the
 // device build did, for faces large enough to reach the plane it still needed.)
+template <typename OutT>
 MADRONA_HD inline bool collidePairStored(const PairSetup &pair,
                                          Vector3 *tmp_vertices,
                                          Plane *tmp_faces,
                                          CountT max_tmp_elems,
-                                         ContactConstraint *out,
+                                         OutT *out,
                                          bool *unsupported)
 {
     if (!pair.aabbOverlap) {

@@ -5,7 +5,7 @@
 
 the kernel then adds s_memtime deltas per phase to ecs_state::moduleData[1])."""
 import sys, os, ctypes as C
-os.environ['MADRONA_HIP_BUILD_DIR'] = '_build_prof'
+os.environ.setdefault('MADRONA_HIP_BUILD_DIR', '_build_prof')
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from madrona_amd.simlib import Simulator, hip_lib_path, runtime_lib
