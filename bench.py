@@ -623,10 +623,11 @@ def rooflines(stats, sim_name, worlds, ms_per_step):
         nodes["physics_step_issue"] = issue_roofline(
             "physics:worldStep (same kernel, instruction-issue yardstick)", sim_name,
             worlds, "physics:worldStep", sum(k["avg_us"] for k in phys_k),
-            1 if PHYS_BODIES.get(sim_name, 64) <= 32 else 2,
-            "two worlds per wavefront, one wavefront per SIMD (LDS: 2 x 17 KB per "
-            "wave): the kernel is bound by how fast one wave issues, not by HBM "
-            "(DESIGN.md §10)")
+            2,
+            "two worlds per wavefront, two wavefronts per SIMD since round 6 (LDS: "
+            "20 256 B per workgroup, 256 registers per wavefront): the kernel is "
+            "bound by instruction issue and LDS / scratch latency, not by HBM "
+            "(DESIGN.md §10, §16)")
     # ParallelFor nodes (north_star: "sort + ParallelFor nodes at >= 50 % of the
     # HBM roofline"): bytes = rows x (4 + declared reads + declared writes) where
     # the system declares its read / write set next to its definition

@@ -8,34 +8,17 @@
 // runtime compiler, no megakernel and no host<->device mailbox: registration
 // and graph construction are host code, every node is its own kernel, and a
 // step is one hipGraph replay on the executor's private stream.
-#include "runtime_internal.hpp"
-#include <madrona/tracing.hpp>
-#include <cstddef>
-#include "render_internal.hpp"
+#include "exec_internal.hpp"
 
-#include <hip/hip_ext.h>
+// ---- this translation unit: the C ABI (registry, queries, task-graph builder, create /
+// destroy, run, introspection, profiling) ----
 
-#include <atomic>
-#include <chrono>
-#include <cinttypes>
-#include <cstdarg>
-#include <mutex>
-#include <thread>
-#include <cstdio>
-#include <cstdlib>
-#include <map>
-#include <memory>
-#include <unordered_map>
-
-using namespace madrona;
-using namespace madrona::mwhip;
+static thread_local std::string g_lastError;
 
 // ---------------------------------------------------------------------------
 // errors
 // ---------------------------------------------------------------------------
-static thread_local std::string g_lastError;
-
-static int fail(int code, const char *fmt, ...)
+MWHIP_RT int fail(int code, const char *fmt, ...)
 {
     char buf[1024];
     va_list ap;
@@ -49,700 +32,11 @@ static int fail(int code, const char *fmt, ...)
     return code;
 }
 
-#define HIPCHK(expr) \
-    do { \
-        hipError_t hipchk_res_ = (expr); \
-        if (hipchk_res_ != hipSuccess) { \
-            return fail(-10, "%s -> %s (%s:%d)", #expr, \
-                hipGetErrorString(hipchk_res_), __FILE__, __LINE__); \
-        } \
-    } while (0)
-
-static uint32_t envU32(const char *name, uint32_t fallback)
+MWHIP_RT uint32_t envU32(const char *name, uint32_t fallback)
 {
     const char *v = getenv(name);
     if (v == nullptr || *v == '\0') return fallback;
     return (uint32_t)strtoul(v, nullptr, 10);
-}
-
-// ---------------------------------------------------------------------------
-// small device kernels owned by the runtime
-// ---------------------------------------------------------------------------
-namespace {
-
-// ClearTmpNode / ResetTmpAllocNode (reference taskgraph_utils.cpp:171-230):
-// a handful of scalar stores; consecutive ones share one launch -- or ride on
-// the last kernel of the sort chain they follow (sort_archetype.hip).
-__global__ void miscOpsKernel(EcsState *S, const MiscOp *ops, uint32_t num_ops)
-{
-    TraceScope trace_scope(S);
-    applyMiscOps(S, ops, num_ops, threadIdx.x);
-}
-
-// ---- exclusive scan over a few device arrays (MWHIP_NODE_EXCLUSIVE_SCAN) ----
-// Single pass, chained through 8-byte {epoch tag | status | value} granules
-// like the sort's look-back (relaxed agent-scope atomics, ticketed tiles).
-constexpr int kScanThreads = 256;
-constexpr int kScanItems = 8;
-constexpr int kScanTile = kScanThreads * kScanItems;
-
-struct ScanState {
-    uint32_t ticket;
-    uint32_t epoch;
-    uint32_t arrivals;
-    uint32_t pad;
-};
-
-struct ScanNode {
-    mwhip_scan_params params;
-    ScanState *state;
-    unsigned long long *granules;
-    uint32_t maxTiles;
-};
-
-__global__ void __launch_bounds__(kScanThreads)
-exclusiveScanKernel(EcsState *S, const ScanNode *node_ptr)
-{
-    TraceScope trace_scope(S);
-    const ScanNode &node = *node_ptr;
-    const mwhip_scan_params &p = node.params;
-
-    __shared__ uint32_t lds_tile;
-    __shared__ uint32_t lds_wave[kScanThreads / 64];
-    __shared__ uint32_t lds_prefix;
-
-    // segment layout: tiles never straddle segments
-    int32_t seg_len[MWHIP_SCAN_MAX_SEGMENTS];
-    uint32_t seg_tile_start[MWHIP_SCAN_MAX_SEGMENTS + 1];
-    uint32_t total_tiles = 0;
-    for (uint32_t s = 0; s < MWHIP_SCAN_MAX_SEGMENTS; s++) {
-        int32_t len = s < p.num_segments ? *p.lengths[s] : 0;
-        seg_len[s] = len > 0 ? len : 0;
-        seg_tile_start[s] = total_tiles;
-        total_tiles += (uint32_t)((seg_len[s] + kScanTile - 1) / kScanTile);
-    }
-    seg_tile_start[MWHIP_SCAN_MAX_SEGMENTS] = total_tiles;
-
-    if (threadIdx.x == 0) {
-        lds_tile = atomicAdd(&node.state->ticket, 1u);
-    }
-    __syncthreads();
-    const uint32_t tile = lds_tile;
-    const uint32_t epoch = node.state->epoch;
-    const uint32_t tag = epoch + 1u;
-
-    if (tile < total_tiles) {
-        uint32_t seg = 0;
-        while (seg + 1 < MWHIP_SCAN_MAX_SEGMENTS && tile >= seg_tile_start[seg + 1]) {
-            seg++;
-        }
-        const int32_t base = (int32_t)(tile - seg_tile_start[seg]) * kScanTile;
-        uint32_t *data = p.data[seg];
-        const int32_t len = seg_len[seg];
-
-        // blocked arrangement: thread t owns items [t*8, t*8+8) of the tile
-        uint32_t v[kScanItems];
-        uint32_t thread_sum = 0;
-#pragma unroll
-        for (int j = 0; j < kScanItems; j++) {
-            int32_t i = base + (int32_t)threadIdx.x * kScanItems + j;
-            v[j] = i < len ? data[i] : 0u;
-            thread_sum += v[j];
-        }
-
-        // block exclusive scan of thread sums
-        const uint32_t lane = threadIdx.x & 63u;
-        const uint32_t wave = threadIdx.x >> 6;
-        uint32_t incl = thread_sum;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            uint32_t up = __shfl_up(incl, d, 64);
-            if ((int)lane >= d) incl += up;
-        }
-        if (lane == 63) lds_wave[wave] = incl;
-        __syncthreads();
-        uint32_t wave_base = 0, tile_total = 0;
-#pragma unroll
-        for (int w = 0; w < kScanThreads / 64; w++) {
-            uint32_t ws = lds_wave[w];
-            if (w < (int)wave) wave_base += ws;
-            tile_total += ws;
-        }
-
-        // look back for the sum of all earlier tiles
-        if (threadIdx.x == 0) {
-            unsigned long long *g = node.granules;
-            uint32_t exclusive = 0;
-            if (tile == 0) {
-                __hip_atomic_store(&g[0], ((unsigned long long)tag << 32) |
-                    (2ull << 30) | tile_total, __ATOMIC_RELAXED,
-                    __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                __hip_atomic_store(&g[tile], ((unsigned long long)tag << 32) |
-                    (1ull << 30) | tile_total, __ATOMIC_RELAXED,
-                    __HIP_MEMORY_SCOPE_AGENT);
-                int32_t look = (int32_t)tile - 1;
-                uint32_t spins = 0;
-                while (true) {
-                    unsigned long long x = __hip_atomic_load(&g[look],
-                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((uint32_t)(x >> 32) != tag) {
-                        __builtin_amdgcn_s_sleep(1);
-                        if (++spins > (1u << 26)) {
-                            raiseError(S, kErrSortLookback);
-                            break;
-                        }
-                        continue;
-                    }
-                    exclusive += (uint32_t)(x & ((1ull << 30) - 1ull));
-                    if ((x >> 30) & 2ull) break;
-                    look -= 1;
-                }
-                __hip_atomic_store(&g[tile], ((unsigned long long)tag << 32) |
-                    (2ull << 30) | (unsigned long long)(exclusive + tile_total),
-                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            lds_prefix = exclusive;
-
-            if (tile == total_tiles - 1) {
-                uint32_t total = exclusive + tile_total;
-                if (total > p.capacity) {
-                    raiseError(S, kErrTableOverflow);
-                    total = p.capacity;
-                }
-                *p.total_out = (int32_t)total;
-                if (p.needs_sort_out != nullptr && total > 0) {
-                    *p.needs_sort_out = 1u;
-                }
-            }
-        }
-        __syncthreads();
-
-        uint32_t running = lds_prefix + wave_base + incl - thread_sum;
-#pragma unroll
-        for (int j = 0; j < kScanItems; j++) {
-            int32_t i = base + (int32_t)threadIdx.x * kScanItems + j;
-            if (i < len) {
-                data[i] = running;
-            }
-            running += v[j];
-        }
-    } else if (total_tiles == 0 && tile == 0 && threadIdx.x == 0) {
-        *p.total_out = 0;
-    }
-
-    // last block resets the ticket and advances the epoch for the next launch
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        uint32_t done = atomicAdd(&node.state->arrivals, 1u);
-        if (done == gridDim.x - 1) {
-            node.state->arrivals = 0;
-            node.state->ticket = 0;
-            node.state->epoch = epoch + 1u;
-        }
-    }
-}
-
-// Holds the stream until the host flips a flag in pinned memory, so that a
-// whole step's kernels + timing events can be queued behind it and then run
-// back to back on the device (per-kernel event deltas would otherwise mostly
-// measure the host's launch rate).
-__global__ void gateKernel(int32_t *host_flag)
-{
-    if (threadIdx.x != 0) return;
-    for (uint32_t spins = 0; spins < (1u << 22); spins++) {
-        if (__hip_atomic_load(host_flag, __ATOMIC_RELAXED,
-                              __HIP_MEMORY_SCOPE_SYSTEM) != 0) {
-            break;
-        }
-        __builtin_amdgcn_s_sleep(32);
-    }
-}
-
-// Brackets a measurement window in a kernel trace: profiles/summarize_rocprof.py
-// keeps the dispatches between the first and the last launch of this kernel
-// (mwhip_mark_window), so the committed rocprofv3 averages cover exactly the
-// steps bench.py timed.
-__global__ void benchWindowMarker(uint32_t *signal, uint32_t id)
-{
-    if (threadIdx.x == 0 && signal != nullptr && id == 0xFFFFFFFFu) {
-        *signal = id;   // never taken: keeps the arguments alive
-    }
-}
-
-// End-of-graph health record written straight into pinned host memory.
-struct PackArgs {
-    const uint32_t *src[MWHIP_PACK_MAX_COLUMNS];
-    uint32_t words[MWHIP_PACK_MAX_COLUMNS];     // per row, per column
-    uint32_t firstWord[MWHIP_PACK_MAX_COLUMNS]; // of the column inside a record
-    uint32_t numColumns;
-    uint32_t recordWords;
-    uint32_t numRows;
-};
-
-// One thread per output word (consecutive lanes -> consecutive words of a
-// record: coalesced stores; a column's words of one row are contiguous loads).
-__global__ void __launch_bounds__(256)
-packRowsKernel(PackArgs args, uint32_t *dst)
-{
-    const uint64_t total = (uint64_t)args.numRows * args.recordWords;
-    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-         i < total; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t row = (uint32_t)(i / args.recordWords);
-        const uint32_t w = (uint32_t)(i % args.recordWords);
-        uint32_t c = 0;
-#pragma unroll
-        for (uint32_t k = 1; k < MWHIP_PACK_MAX_COLUMNS; k++) {
-            if (k < args.numColumns && w >= args.firstWord[k]) {
-                c = k;
-            }
-        }
-        dst[i] = args.src[c][(uint64_t)row * args.words[c] +
-                             (w - args.firstWord[c])];
-    }
-}
-
-// layout of the pinned health record (int32 words)
-constexpr uint32_t kStatsRows = 2;                          // [kMaxArchetypes]
-constexpr uint32_t kStatsGate = 2 + kMaxArchetypes;         // profiling gate flag
-constexpr uint32_t kStatsPeaks = 3 + kMaxArchetypes;        // [kMaxArchetypes]
-constexpr uint32_t kStatsReplays = 3 + 2 * kMaxArchetypes;  // replays completed
-constexpr uint32_t kStatsTails = 4 + 2 * kMaxArchetypes;    // [kMaxArchetypes]
-constexpr uint32_t kStatsWords = 4 + 3 * kMaxArchetypes;
-
-// word of the replay-signal block that counts completed replays of STEP graphs
-// only (the ones that start with the input rings); word 0 counts every replay
-constexpr uint32_t kStepReplayWord = 16;
-
-// First kernel of a step graph with an input ring (mwhip_set_input_ring): slot
-// (step-graph replays since the ring was set) % num_slots of a device-resident
-// ring -> an exported column, i.e. a new set of actions every step without the
-// host touching the executor's stream between two graph launches.  Render
-// graphs neither read nor advance the rings (they bump word 0 only), so a
-// render replay between two steps does not skip a slot.
-__global__ void __launch_bounds__(256)
-inputRingKernel(EcsState *S, uint32_t *dst, const uint32_t *ring,
-                uint32_t slot_words, uint32_t num_slots, uint32_t first_replay)
-{
-    TraceScope trace_scope(S);
-    const uint32_t replay = __hip_atomic_load(S->replayCounter + kStepReplayWord,
-                                              __ATOMIC_RELAXED,
-                                              __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t *src =
-        ring + (size_t)((replay - first_replay) % num_slots) * slot_words;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < slot_words;
-         i += gridDim.x * blockDim.x) {
-        dst[i] = src[i];
-    }
-}
-
-#ifdef MADRONA_TRACING
-// One thread in front of every kernel of a traced graph (mw_gpu/tracing.hpp):
-// calibration starts a step's log, nodeStart names the kernel whose
-// workgroups log next, blockExit ends the step.
-__global__ void __launch_bounds__(256)
-traceMarkKernel(EcsState *S, uint32_t event, uint32_t node_id, uint32_t func_id,
-                uint32_t invocations, uint32_t workgroups)
-{
-    using mwGPU::DeviceEvent;
-    using mwGPU::DeviceTracing;
-    DeviceTracing *t = (DeviceTracing *)S->deviceTracing;
-    if (t == nullptr) return;
-    __shared__ uint32_t first_slot;
-    if (threadIdx.x == 0) {
-        first_slot = DeviceTracing::unusedSlot;
-        if ((DeviceEvent)event == DeviceEvent::calibration) {
-            __hip_atomic_store(&t->cur_index_, 0, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-        }
-        // this record + two per workgroup of the kernel that follows
-        const uint32_t want = 1u + 2u * workgroups;
-        int32_t base = __hip_atomic_load(&t->cur_index_, __ATOMIC_RELAXED,
-                                         __HIP_MEMORY_SCOPE_AGENT);
-        if (base >= 0) {
-            base = __hip_atomic_fetch_add(&t->cur_index_, (int32_t)want,
-                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((uint64_t)base + want > DeviceTracing::maxLogSize) {
-                // this step's trace is incomplete: dropped by the host
-                __hip_atomic_store(&t->cur_index_, -1, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-                base = -1;
-            }
-        }
-        DeviceTracing::Cursor cur { node_id, func_id, 0u, 0u };
-        if (base >= 0) {
-            t->device_logs_[base] = DeviceTracing::DeviceLog {
-                (DeviceEvent)event, func_id, invocations, node_id, 0u, 0u,
-                DeviceTracing::computeUnitID(), (uint32_t)base,
-                DeviceTracing::globalTimer(),
-            };
-            cur.firstSlot = (uint32_t)base + 1u;
-            cur.numWorkgroups = workgroups;
-            first_slot = cur.firstSlot;
-        }
-        *(DeviceTracing::Cursor *)S->traceCursor = cur;
-    }
-    __syncthreads();
-    // (a kernel without a TraceScope leaves its slots like this)
-    if (first_slot != DeviceTracing::unusedSlot) {
-        for (uint32_t i = threadIdx.x; i < 2u * workgroups; i += blockDim.x) {
-            t->device_logs_[first_slot + i].event = (DeviceEvent)DeviceTracing::unusedSlot;
-        }
-    }
-}
-#endif
-
-// report_rows == 0 (render pass): error flags and the replay counter only -- the
-// step's row statistics and high-water marks stay as its own health kernel
-// reported them
-__global__ void statsKernel(EcsState *S, int32_t *host_out,
-                            uint32_t *replay_signal, uint32_t report_rows)
-{
-    TraceScope trace_scope(S);
-    uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
-    if (a < S->numArchetypeSlots && report_rows != 0u) {
-        TableHdr &tbl = S->tables[a];
-        host_out[kStatsRows + a] = tbl.registered ? tbl.numRows : -1;
-        // the step's high-water mark (what growth is sized by), then reset
-        host_out[kStatsPeaks + a] = tbl.registered ?
-            (tbl.peakRows > tbl.numRows ? tbl.peakRows : tbl.numRows) : -1;
-        tbl.peakRows = 0;
-        // longest appended tail a compaction sort of the step met
-        host_out[kStatsTails + a] = tbl.registered ? tbl.tailRows : 0;
-        tbl.tailRows = 0;
-    }
-    if (a == 0) {
-        host_out[0] = (int32_t)S->errorFlags;
-        host_out[1] = S->numIds;
-        // this replay is complete (mwhip_stream_wait_replays polls this; the
-        // host reads the copy in pinned memory without waiting)
-        if (report_rows != 0u) {
-            // a step graph (not a render graph): the input rings move on
-            __hip_atomic_fetch_add(replay_signal + kStepReplayWord, 1u,
-                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        uint32_t done = __hip_atomic_fetch_add(replay_signal, 1u,
-            __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM) + 1u;
-        __hip_atomic_store((uint32_t *)&host_out[kStatsReplays], done,
-                           __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
-
-}
-
-// ---------------------------------------------------------------------------
-// executor
-// ---------------------------------------------------------------------------
-struct ComponentRec {
-    bool registered = false;
-    uint32_t alignment = 0;
-    uint32_t bytes = 0;
-};
-
-// Growable device memory: address space reserved up front
-// (hipMemAddressReserve), backed 2 MiB at a time (hipMemCreate / hipMemMap), so
-// a table can grow without any pointer into it changing -- the reference's GPU
-// backend does the same through its host allocator thread (memory.cpp:20-178,
-// cuda_exec.cpp:1603-1719).  One handle per 2 MiB chunk: the granule on which
-// map + set-access behaved on this ROCm (larger or mixed chunk sizes returned
-// hipErrorInvalidValue from hipMemSetAccess).
-struct VmRange {
-    char *base = nullptr;
-    size_t reserved = 0;
-    size_t mapped = 0;
-    std::vector<hipMemGenericAllocationHandle_t> chunks;
-};
-static constexpr size_t kVmChunk = (size_t)2 << 20;
-
-struct ArchetypeRec {
-    bool registered = false;
-    uint32_t id = 0;
-    std::vector<uint32_t> comps;        // flattened user components
-    uint32_t flags = 0;
-    uint32_t maxPerWorld = 0;
-    bool singleton = false;
-    bool bigSort = false;
-    uint32_t smallBusy = 0;     // consecutive reports of a busy one-launch sort           // outgrew the single-launch sort once
-    // world sorts of this table take the compaction chain unless something
-    // other than world sorts reorders / truncates it (a sort by another key,
-    // ClearTmp, a scan node writing its row count: scrambled), or its appended
-    // tails keep outgrowing what one workgroup sorts (noCompact)
-    bool scrambled = false;
-    bool noCompact = false;
-    uint32_t longTails = 0;         // steps whose tail exceeded the limit
-    int64_t peakSeen = 0;           // largest per-step peak reported so far
-    uint32_t fillingUntil = 0;      // replay count until which the queue is kept short
-    int32_t singletonOrdinal = -1;
-    uint32_t capacity = 0;              // rows backed by memory right now
-    uint32_t reservedCapacity = 0;      // rows the address space allows
-    uint32_t numColumns = 0;
-    uint32_t rowBytes = 0;
-    std::vector<void *> primary;
-    std::vector<void *> alt;
-    // growable archetypes: the ranges behind primary / alt / sort buffers
-    std::vector<VmRange *> primaryVm, altVm;
-    VmRange *sortVm[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
-    std::vector<uint32_t> colBytes;
-    std::vector<uint32_t> colFlags;
-    std::vector<uint32_t> colComponent;
-    int32_t *worldOffsets = nullptr;
-    int32_t *worldCounts = nullptr;
-    // sort scratch (allocated on first use)
-    SortState *sortState = nullptr;
-    uint32_t *keysA = nullptr, *keysB = nullptr;
-    int32_t *idxA = nullptr, *idxB = nullptr;
-    unsigned long long *lookback = nullptr;
-    int32_t *tileCounts = nullptr;      // compaction chain, per prefix tile
-    int32_t *tileTailStart = nullptr;
-    int32_t *tailLand = nullptr;        // [capacity] where each sorted tail row lands
-};
-
-struct QueryRec {
-    std::vector<uint32_t> comps;
-    uint32_t offset;
-    uint32_t numMatching;
-    uint32_t flags;
-};
-
-struct NodeRec {
-    mwhip_node_desc desc;
-    std::string name;
-    std::vector<int32_t> deps;
-};
-
-struct TaskGraphRec {
-    std::vector<NodeRec> nodes;
-    std::vector<void *> dataDev;
-    std::vector<int32_t> sorted;
-    bool built = false;
-};
-
-struct LaunchGraph {
-    // device memory that belongs to THIS graph (sort batches' site / column /
-    // slice tables, scan state, row-snapshot granules ...): released when the
-    // graph is rebuilt or freed, not at mwhip_destroy (every rebuild
-    // -- growth, a table outgrowing the one-launch sort, set_input_ring -- used
-    // to leave the previous graph's buffers allocated)
-    std::vector<void *> ownedAllocations;
-    std::vector<KernelLaunch> launches;
-    std::vector<std::unique_ptr<SortBatch>> sortBatches;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t graphExec = nullptr;
-    std::string statName;
-    std::vector<std::string> statNames;     // backing store for mwhip_kernel_stat::name
-    std::vector<uint32_t> taskGraphIds;     // to rebuild after a table grew
-    // optional last node: pack exported columns into a send buffer
-    bool hasPack = false;
-    PackArgs pack {};
-    void *packDst = nullptr;
-    // the batch ray caster's pass instead of task graphs
-    bool isRender = false;
-
-    LaunchGraph() = default;
-    LaunchGraph(const LaunchGraph &) = delete;
-    LaunchGraph &operator=(const LaunchGraph &) = delete;
-    // (a graph that dies on an error path of instantiateLaunchGraph or of a
-    // rebuild loop gives back what it had allocated so far; the caller has
-    // made sure nothing of it is in flight)
-    ~LaunchGraph()
-    {
-        if (graphExec) (void)hipGraphExecDestroy(graphExec);
-        if (graph) (void)hipGraphDestroy(graph);
-        for (void *p : ownedAllocations) {
-            (void)hipFree(p);
-        }
-    }
-};
-
-// Where devAlloc records what it hands out while THIS thread builds a launch
-// graph (the graph then owns the memory); another thread's allocations stay with
-// their executor.
-static thread_local std::vector<void *> *t_allocScope = nullptr;
-
-struct mwhip_exec {
-    mwhip_state_config cfg {};
-    mwhip_user_entry entry {};
-    hipStream_t stream = nullptr;
-
-    std::vector<ComponentRec> components;
-    std::vector<ArchetypeRec> archetypes;
-    std::unordered_map<uint32_t, std::vector<uint32_t>> bundles;
-    std::vector<QueryRec> queries;
-    std::vector<uint32_t> queryDataHost;
-    uint32_t queryCapacity = 1u << 16;      // reference state.hpp:207
-    uint32_t numSingletons = 0;
-    bool registrationOpen = false;
-    bool stateBuilt = false;
-
-    std::vector<void *> exported;
-
-    EcsState hostState {};
-    EcsState *stateDev = nullptr;
-    std::vector<TableHdr> tablesHost;
-    uint32_t singletonIdEnd = 0;            // rounded up to a block of 64
-
-    void *userCfgDev = nullptr;
-    void *worldInitsDev = nullptr;
-
-    std::vector<TaskGraphRec> taskGraphs;
-    std::unordered_map<uint64_t, std::unique_ptr<LaunchGraph>> launchGraphs;
-    // where devAlloc records what it hands out: the graph being built, or
-    // (nullptr) the executor's own list, freed at mwhip_destroy
-    uint64_t nextGraphHandle = 1;
-
-    // mwGPU::HostPrint: ring in pinned host memory + the thread that drains it
-    // while replays are in flight (replaces the reference's HostPrintCPU
-    // thread, src/mw/cuda_exec.cpp)
-    // device -> host requests for table memory (mwhip::GrowMailbox) and the
-    // lock that orders the service thread against growth between replays
-    hipStream_t serviceStream = nullptr;    // fills of freshly mapped memory
-    VmRange *entityVm = nullptr;            // entity slots (growable)
-    VmRange *tmpVm = nullptr;               // Context::tmpAlloc region (growable)
-    GrowMailbox *growMailbox = nullptr;
-    std::mutex growMutex;
-    bool headersStale = false;      // device headers / graphs lag the mapped rows
-    HostPrintRing *printRing = nullptr;
-    std::mutex printMutex;
-    std::thread printThread;
-    std::atomic<bool> printStop { false };
-    int32_t *statsHost = nullptr;           // pinned, device-visible
-    std::vector<void *> allocations;
-    std::vector<std::unique_ptr<VmRange>> vmRanges;
-    std::vector<uint32_t> rowsAtGraphBuild; // per archetype, see queryCapacityRows
-    uint32_t *replaySignal = nullptr;       // device: replays completed
-    uint32_t replaysLaunched = 0;           // host: replays queued
-    uint32_t tableGrowth = 1;               // reserved / initial rows
-    uint32_t numGrowths = 0;
-    bool checkAfterRun = true;
-    bool sortCarriesMisc = true;    // MADRONA_MWHIP_SORT_CARRIES_MISC
-
-    // mwhip_set_input_ring
-    struct InputRing {
-        uint32_t *dst;
-        const uint32_t *ring;
-        uint32_t slotWords;
-        uint32_t numSlots;
-        uint32_t firstReplay;   // replays completed when the ring was set
-    };
-    std::vector<InputRing> inputRings;
-
-    // MADRONA_TRACING builds: the device event log (mw_gpu/tracing.hpp), the
-    // records of the first steps, the names funcID indexes
-    void *deviceTracing = nullptr;
-    void *traceCursor = nullptr;
-    std::vector<mwGPU::DeviceTracing::DeviceLog> traceLogs;
-    std::vector<std::string> traceNames;
-    uint32_t traceSteps = 0;
-    // MADRONA_MWHIP_SORT_COMPACT: 0 never, 1 world sorts of tables nothing else
-    // reorders, 2 every world sort (tests: the chain is correct on any table,
-    // its one-workgroup tail sort is just slow when the whole table is "tail")
-    uint32_t sortCompaction = 1;
-    bool eagerReplay = false;       // MADRONA_MWHIP_EAGER (measurement, replayGraph)
-    const void *pforGroupKernel = nullptr;  // mwhip_set_pfor_group_kernel
-    void *pforBodyScratch = nullptr;        // 8 bytes: where report mode writes
-    // MADRONA_MWHIP_EXEC_CONFIG_FILE (the reference's
-    // MADRONA_MWGPU_EXEC_CONFIG_FILE, cuda_exec.cpp:2115-2172): per task-graph
-    // node (index in execution order) the workgroups per CU its kernel may
-    // occupy -- the reference's "blocks per SM" of the megakernel that runs the
-    // node --, written by madrona_amd/scripts/profile.py.  0 / absent: default.
-    std::vector<uint32_t> nodeWorkgroupsPerCU;
-    uint32_t numCUs = 256;
-
-    // batch ray caster: geometry (bottom-level BVHs) + where the ECS keeps what
-    // it reads and writes
-    bool haveRenderGeometry = false;
-    bool haveRenderLayout = false;
-    RenderGeometryHost renderGeometry;
-    RenderGeometryDev renderGeometryDev {};
-    mwhip_render_layout renderLayout {};
-    BvhNode *tlasNodes = nullptr;
-    PreparedInstance *preparedInstances = nullptr;
-};
-
-static int devAlloc(mwhip_exec *exec, void **out, size_t bytes, bool zero = true)
-{
-    bytes = (bytes + 255) & ~(size_t)255;
-    if (bytes == 0) bytes = 256;
-    HIPCHK(hipMalloc(out, bytes));
-    (t_allocScope != nullptr ? *t_allocScope : exec->allocations).push_back(*out);
-    if (zero) {
-        HIPCHK(hipMemset(*out, 0, bytes));
-    }
-    return 0;
-}
-
-template <typename T>
-static int devAllocT(mwhip_exec *exec, T **out, size_t count, bool zero = true)
-{
-    return devAlloc(exec, (void **)out, count * sizeof(T), zero);
-}
-
-static int vmEnsure(mwhip_exec *exec, VmRange &r, size_t bytes, bool zero)
-{
-    bytes = (bytes + kVmChunk - 1) / kVmChunk * kVmChunk;
-    if (bytes > r.reserved) {
-        return fail(-4, "growable range: %zu bytes requested, %zu reserved",
-                    bytes, r.reserved);
-    }
-
-    hipMemAllocationProp prop {};
-    prop.type = hipMemAllocationTypePinned;
-    prop.location.type = hipMemLocationTypeDevice;
-    prop.location.id = exec->cfg.gpu_id;
-    hipMemAccessDesc access {};
-    access.location = prop.location;
-    access.flags = hipMemAccessFlagsProtReadWrite;
-
-    while (r.mapped < bytes) {
-        hipMemGenericAllocationHandle_t chunk;
-        HIPCHK(hipMemCreate(&chunk, kVmChunk, &prop, 0));
-        HIPCHK(hipMemMap(r.base + r.mapped, kVmChunk, 0, chunk, 0));
-        HIPCHK(hipMemSetAccess(r.base + r.mapped, kVmChunk, &access, 1));
-        if (zero) {
-            // on the executor's side stream: a synchronous hipMemset waits for
-            // the device to drain, and the service thread maps memory for
-            // kernels that are waiting for exactly that
-            HIPCHK(hipMemsetAsync(r.base + r.mapped, 0, kVmChunk,
-                                  exec->serviceStream));
-        }
-        r.chunks.push_back(chunk);
-        r.mapped += kVmChunk;
-    }
-    if (zero) {
-        HIPCHK(hipStreamSynchronize(exec->serviceStream));
-    }
-    return 0;
-}
-
-static int vmAlloc(mwhip_exec *exec, void **out, VmRange **range_out,
-                   size_t reserve_bytes, size_t map_bytes, bool zero)
-{
-    std::unique_ptr<VmRange> r(new VmRange {});
-    r->reserved = (reserve_bytes + kVmChunk - 1) / kVmChunk * kVmChunk;
-    void *base = nullptr;
-    HIPCHK(hipMemAddressReserve(&base, r->reserved, kVmChunk, nullptr, 0));
-    r->base = (char *)base;
-    exec->vmRanges.push_back(std::move(r));
-    VmRange *range = exec->vmRanges.back().get();
-
-    int rc = vmEnsure(exec, *range, map_bytes, zero);
-    if (rc != 0) return rc;
-    *out = range->base;
-    *range_out = range;
-    return 0;
-}
-
-static void vmFreeAll(mwhip_exec *exec)
-{
-    for (auto &r : exec->vmRanges) {
-        for (size_t i = 0; i < r->chunks.size(); i++) {
-            (void)hipMemUnmap(r->base + i * kVmChunk, kVmChunk);
-            (void)hipMemRelease(r->chunks[i]);
-        }
-        (void)hipMemAddressFree(r->base, r->reserved);
-    }
-    exec->vmRanges.clear();
 }
 
 // ---------------------------------------------------------------------------
@@ -940,7 +234,7 @@ extern "C" int mwhip_register_singleton(mwhip_exec *exec, uint32_t archetype_id,
     return 0;
 }
 
-static int findColumn(const ArchetypeRec &arch, uint32_t component_id)
+MWHIP_RT int findColumn(const ArchetypeRec &arch, uint32_t component_id)
 {
     if (component_id == 0) return 0;
     if (component_id == 1) return 1;
@@ -1207,1523 +501,6 @@ extern "C" void *mwhip_get_exported(const mwhip_exec *exec, uint32_t slot)
     return slot < exec->exported.size() ? exec->exported[slot] : nullptr;
 }
 
-// ---------------------------------------------------------------------------
-// state construction
-// ---------------------------------------------------------------------------
-// Bottom-level BVHs, triangles and materials of the ray caster -> device.
-static int uploadRenderGeometry(mwhip_exec *exec)
-{
-    const RenderGeometryHost &g = exec->renderGeometry;
-    RenderGeometryDev &d = exec->renderGeometryDev;
-    d.numObjects = g.numObjects;
-    d.numMaterials = g.numMaterials;
-
-    auto upload = [exec](const void *src, size_t bytes, const void **out) -> int {
-        void *dev = nullptr;
-        int rc = devAlloc(exec, &dev, bytes, false);
-        if (rc != 0) return rc;
-        if (bytes != 0) {
-            HIPCHK(hipMemcpy(dev, src, bytes, hipMemcpyHostToDevice));
-        }
-        *out = dev;
-        return 0;
-    };
-    int rc = upload(g.nodes.data(), g.nodes.size() * sizeof(BvhNode),
-                    (const void **)&d.nodes);
-    if (rc != 0) return rc;
-    rc = upload(g.triangleVertices.data(), g.triangleVertices.size() * 4,
-                (const void **)&d.triangleVertices);
-    if (rc != 0) return rc;
-    rc = upload(g.objectNodeOffset.data(), g.objectNodeOffset.size() * 4,
-                (const void **)&d.objectNodeOffset);
-    if (rc != 0) return rc;
-    rc = upload(g.objectTriangleOffset.data(), g.objectTriangleOffset.size() * 4,
-                (const void **)&d.objectTriangleOffset);
-    if (rc != 0) return rc;
-    rc = upload(g.objectMaterial.data(), g.objectMaterial.size() * 4,
-                (const void **)&d.objectMaterial);
-    if (rc != 0) return rc;
-    rc = upload(g.objectRootBox.data(), g.objectRootBox.size() * 4,
-                (const void **)&d.objectBounds);
-    if (rc != 0) return rc;
-    rc = upload(g.objectIsBox.data(), g.objectIsBox.size() * 4,
-                (const void **)&d.objectIsBox);
-    if (rc != 0) return rc;
-    rc = upload(g.objectBoxFaces.data(), g.objectBoxFaces.size() * 4,
-                (const void **)&d.objectBoxFaces);
-    if (rc != 0) return rc;
-    rc = upload(g.materialColor.data(), g.materialColor.size() * 4,
-                (const void **)&d.materialColor);
-    if (rc != 0) return rc;
-    d.triangleUV = nullptr;
-    d.triangleMaterial = nullptr;
-    d.materialTexture = nullptr;
-    d.textureInfo = nullptr;
-    d.texels = nullptr;
-    d.numTextures = (uint32_t)(g.textureInfo.size() / 4);
-    if (!g.triangleUV.empty()) {
-        rc = upload(g.triangleUV.data(), g.triangleUV.size() * 4,
-                    (const void **)&d.triangleUV);
-        if (rc != 0) return rc;
-    }
-    // (only what the shading can reach is uploaded -- the ray cast kernel is
-    // compiled without the per-hit material / texture lookup when neither
-    // pointer is set: per-triangle materials are consulted for objects without
-    // a material of their own, textures through a material that has one)
-    bool some_object_without_material = false;
-    for (int32_t m : g.objectMaterial) {
-        some_object_without_material = some_object_without_material || m < 0;
-    }
-    bool some_textured_material = false;
-    for (int32_t t : g.materialTexture) {
-        some_textured_material = some_textured_material || t >= 0;
-    }
-    if (!g.triangleMaterial.empty() && some_object_without_material) {
-        rc = upload(g.triangleMaterial.data(), g.triangleMaterial.size() * 4,
-                    (const void **)&d.triangleMaterial);
-        if (rc != 0) return rc;
-    }
-    if (!g.materialTexture.empty() && some_textured_material) {
-        rc = upload(g.materialTexture.data(), g.materialTexture.size() * 4,
-                    (const void **)&d.materialTexture);
-        if (rc != 0) return rc;
-        rc = upload(g.textureInfo.data(), g.textureInfo.size() * 4,
-                    (const void **)&d.textureInfo);
-        if (rc != 0) return rc;
-        rc = upload(g.texels.data(), g.texels.size() * 4, (const void **)&d.texels);
-        if (rc != 0) return rc;
-    }
-    return 0;
-}
-
-static int buildDeviceState(mwhip_exec *exec)
-{
-    const uint32_t W = exec->cfg.num_worlds;
-    EcsState &hs = exec->hostState;
-
-    hs.numArchetypeSlots = (uint32_t)exec->archetypes.size();
-    hs.numComponentSlots = (uint32_t)exec->components.size();
-    hs.numWorlds = (int32_t)W;
-
-    // ---- table headers + dense (archetype, component) -> column lookup -----
-    exec->tablesHost.assign(std::max<uint32_t>(hs.numArchetypeSlots, 1u),
-                            TableHdr {});
-    std::vector<uint16_t> lookup(
-        (size_t)std::max<uint32_t>(hs.numArchetypeSlots, 1u) *
-            std::max<uint32_t>(hs.numComponentSlots, 1u), kNoColumn);
-    std::vector<void *> col_ptrs(lookup.size(), nullptr);
-
-    for (uint32_t a = 0; a < hs.numArchetypeSlots; a++) {
-        const ArchetypeRec &arch = exec->archetypes[a];
-        TableHdr &hdr = exec->tablesHost[a];
-        if (!arch.registered) continue;
-
-        for (uint32_t c = 0; c < arch.numColumns; c++) {
-            hdr.columns[c] = arch.primary[c];
-            hdr.columnsAlt[c] = arch.alt[c];
-            hdr.columnBytes[c] = arch.colBytes[c];
-            hdr.columnFlags[c] = arch.colFlags[c];
-            hdr.columnComponent[c] = (uint16_t)arch.colComponent[c];
-            lookup[(size_t)a * hs.numComponentSlots + arch.colComponent[c]] =
-                (uint16_t)c;
-            col_ptrs[(size_t)a * hs.numComponentSlots + arch.colComponent[c]] =
-                arch.primary[c];
-        }
-        hdr.numColumns = (int32_t)arch.numColumns;
-        hdr.numRows = arch.singleton ? (int32_t)W : 0;
-        hdr.capacity = (int32_t)arch.capacity;
-        hdr.needsSort = 0;
-        hdr.worldOffsets = arch.worldOffsets;
-        hdr.worldCounts = arch.worldCounts;
-        hdr.maxPerWorld = arch.maxPerWorld;
-        hdr.registered = 1;
-        hdr.rowBytes = arch.rowBytes;
-    }
-
-    int rc = devAllocT(exec, &hs.tables, exec->tablesHost.size());
-    if (rc != 0) return rc;
-    rc = devAllocT(exec, &hs.colLookup, lookup.size());
-    if (rc != 0) return rc;
-    HIPCHK(hipMemcpy(hs.colLookup, lookup.data(),
-        lookup.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-    rc = devAllocT(exec, &hs.colPtr, col_ptrs.size());
-    if (rc != 0) return rc;
-    HIPCHK(hipMemcpy(hs.colPtr, col_ptrs.data(),
-        col_ptrs.size() * sizeof(void *), hipMemcpyHostToDevice));
-
-    rc = devAllocT(exec, &hs.queryData, exec->queryCapacity);
-    if (rc != 0) return rc;
-
-    // ---- entity store ---------------------------------------------------------
-    const uint64_t singleton_ids = (uint64_t)exec->numSingletons * W;
-    exec->singletonIdEnd =
-        (uint32_t)((singleton_ids + kIdsPerBlock - 1) / kIdsPerBlock *
-                   kIdsPerBlock);
-    const uint32_t blocks_per_world =
-        envU32("MADRONA_MWHIP_ID_BLOCKS_PER_WORLD", 4);
-    uint64_t entity_capacity = (uint64_t)exec->singletonIdEnd +
-        (uint64_t)W * blocks_per_world * kIdsPerBlock + kIdsPerBlock;
-    if (entity_capacity > 0x7FFFFFF0ull) {
-        return fail(-2, "entity store overflow");
-    }
-    const uint64_t default_entity_capacity = entity_capacity;
-    // (test hook) start with a fraction of the ids the defaults provide
-    if (const char *div = getenv("MADRONA_MWHIP_INITIAL_ID_CAPACITY_DIV")) {
-        uint64_t d = strtoull(div, nullptr, 10);
-        if (d > 1) {
-            entity_capacity = std::max<uint64_t>(
-                exec->singletonIdEnd + ((entity_capacity - exec->singletonIdEnd) / d +
-                    kIdsPerBlock - 1) / kIdsPerBlock * kIdsPerBlock,
-                exec->singletonIdEnd + kIdsPerBlock);
-        }
-    }
-    hs.entityCapacity = (int32_t)entity_capacity;
-    if (exec->tableGrowth > 1) {
-        // growable like the tables: address space for 16 x the ids
-        const uint64_t reserve_ids =
-            std::min<uint64_t>(default_entity_capacity * 16, 0x7FFFFFF0ull);
-        rc = vmAlloc(exec, (void **)&hs.entities, &exec->entityVm,
-                     reserve_ids * sizeof(EntitySlot),
-                     entity_capacity * sizeof(EntitySlot), true);
-        if (rc != 0) return rc;
-    } else {
-        rc = devAllocT(exec, &hs.entities, entity_capacity);
-        if (rc != 0) return rc;
-    }
-    rc = devAllocT(exec, &hs.worldCaches, W);
-    if (rc != 0) return rc;
-    rc = devAllocT(exec, &hs.initBlockBase, W);
-    if (rc != 0) return rc;
-
-    // ---- per-world user data + scratch allocator --------------------------------
-    uint32_t align = std::max<uint32_t>(exec->cfg.world_data_alignment, 16u);
-    hs.worldDataStride =
-        (exec->cfg.num_world_data_bytes + align - 1) / align * align;
-    rc = devAlloc(exec, (void **)&hs.worldData,
-                  (size_t)hs.worldDataStride * W);
-    if (rc != 0) return rc;
-
-    hs.tmpCapacity =
-        (unsigned long long)envU32("MADRONA_MWHIP_TMP_MB", 64) << 20;
-    if (exec->tableGrowth > 1) {
-        rc = vmAlloc(exec, (void **)&hs.tmpBase, &exec->tmpVm,
-                     hs.tmpCapacity * 16, hs.tmpCapacity, false);
-        if (rc != 0) return rc;
-    } else {
-        rc = devAlloc(exec, (void **)&hs.tmpBase, hs.tmpCapacity, false);
-        if (rc != 0) return rc;
-    }
-    hs.tmpOffset = 0;
-
-    hs.persistCapacity = (unsigned long long)W *
-        envU32("MADRONA_MWHIP_PERSIST_KB_PER_WORLD", 16) * 1024ull + (1ull << 20);
-    rc = devAlloc(exec, (void **)&hs.persistBase, hs.persistCapacity, false);
-    if (rc != 0) return rc;
-    hs.persistOffset = 0;
-
-    hs.idFreeHead = 0xFFFFFFFFull;      // {gen 0, head sentinel}
-    hs.numIds = (int32_t)exec->singletonIdEnd;
-    hs.initMode = 0;
-    hs.errorFlags = 0;
-    hs.hostExec = nullptr;
-
-    // ---- singletons: one row per world, ids in (singleton, world) order -------
-    // (reference CPU state.inl:163-179: k-th created singleton entity gets id k)
-    std::vector<Entity> ents(W);
-    std::vector<int32_t> iota(W), ones(W, 1);
-    std::vector<EntitySlot> slots(W);
-    for (uint32_t a = 0; a < hs.numArchetypeSlots; a++) {
-        const ArchetypeRec &arch = exec->archetypes[a];
-        if (!arch.registered || !arch.singleton) continue;
-
-        const uint32_t base = (uint32_t)arch.singletonOrdinal * W;
-        for (uint32_t w = 0; w < W; w++) {
-            ents[w] = Entity { 0, (int32_t)(base + w) };
-            iota[w] = (int32_t)w;
-            slots[w].loc.archetype = a;
-            slots[w].loc.row = (int32_t)w;
-            slots[w].gen = 0;
-        }
-        HIPCHK(hipMemcpy(arch.primary[0], ents.data(), W * sizeof(Entity),
-                         hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(arch.primary[1], iota.data(), W * sizeof(int32_t),
-                         hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(arch.worldOffsets, iota.data(), W * sizeof(int32_t),
-                         hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(arch.worldCounts, ones.data(), W * sizeof(int32_t),
-                         hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(hs.entities + base, slots.data(),
-                         W * sizeof(EntitySlot), hipMemcpyHostToDevice));
-    }
-
-    HIPCHK(hipMemcpy(hs.tables, exec->tablesHost.data(),
-        exec->tablesHost.size() * sizeof(TableHdr), hipMemcpyHostToDevice));
-    if (!exec->queryDataHost.empty()) {
-        HIPCHK(hipMemcpy(hs.queryData, exec->queryDataHost.data(),
-            exec->queryDataHost.size() * sizeof(uint32_t),
-            hipMemcpyHostToDevice));
-    }
-
-    // replay counter in signal memory (hipStreamWaitValue32 polls it; ParallelFor
-    // nodes derive their per-launch tag from it)
-    if (hipExtMallocWithFlags((void **)&exec->replaySignal, 256,
-                              hipMallocSignalMemory) != hipSuccess) {
-        (void)hipGetLastError();
-        HIPCHK(hipMalloc((void **)&exec->replaySignal, 256));
-    }
-    exec->allocations.push_back(exec->replaySignal);
-    HIPCHK(hipMemset(exec->replaySignal, 0, 256));
-    hs.replayCounter = exec->replaySignal;
-#ifdef MADRONA_TRACING
-    {
-        // (only the index needs clearing; -1 until a traced graph starts a step)
-        HIPCHK(hipMalloc(&exec->deviceTracing, sizeof(mwGPU::DeviceTracing)));
-        exec->allocations.push_back(exec->deviceTracing);
-        const int32_t off = -1;
-        HIPCHK(hipMemcpy(exec->deviceTracing, &off, sizeof(off), hipMemcpyHostToDevice));
-        HIPCHK(hipMalloc(&exec->traceCursor, 256));
-        exec->allocations.push_back(exec->traceCursor);
-        HIPCHK(hipMemset(exec->traceCursor, 0, 256));
-        hs.deviceTracing = exec->deviceTracing;
-        hs.traceCursor = exec->traceCursor;
-    }
-#endif
-
-    // batch ray caster configuration (render-prep systems read it on the device)
-    hs.raycastOutputResolution = exec->cfg.raycast_output_resolution;
-    hs.raycastRGBD = exec->cfg.raycast_rgbd;
-    {
-        // object-space root boxes (TLBVH leaves are made from them): as given,
-        // else those of the geometry handed over for the ray caster
-        const float *boxes = exec->cfg.object_root_aabbs;
-        uint32_t num_boxes = exec->cfg.num_object_root_aabbs;
-        if ((boxes == nullptr || num_boxes == 0) && exec->haveRenderGeometry) {
-            boxes = exec->renderGeometry.objectRootBox.data();
-            num_boxes = exec->renderGeometry.numObjects;
-        }
-        if (boxes != nullptr && num_boxes != 0) {
-            void *aabbs_dev = nullptr;
-            const size_t bytes = (size_t)num_boxes * 24;
-            rc = devAlloc(exec, &aabbs_dev, bytes, false);
-            if (rc != 0) return rc;
-            HIPCHK(hipMemcpy(aabbs_dev, boxes, bytes, hipMemcpyHostToDevice));
-            hs.moduleData[2] = aabbs_dev;
-        }
-    }
-    if (exec->haveRenderGeometry) {
-        rc = uploadRenderGeometry(exec);
-        if (rc != 0) return rc;
-    }
-    // (caller's memory: not valid after mwhip_create returns)
-    exec->cfg.object_root_aabbs = nullptr;
-    exec->cfg.render_geometry = nullptr;
-
-    // device -> host requests for table memory
-    HIPCHK(hipHostMalloc((void **)&exec->growMailbox, sizeof(GrowMailbox),
-                         hipHostMallocMapped));
-    memset((void *)exec->growMailbox, 0, sizeof(GrowMailbox));
-    for (uint32_t a = 0; a < exec->archetypes.size() && a < kMaxArchetypes; a++) {
-        if (exec->archetypes[a].registered) {
-            exec->growMailbox->capacity[a] = (int32_t)exec->archetypes[a].capacity;
-        }
-    }
-    exec->growMailbox->capacity[kGrowSlotEntities] = hs.entityCapacity;
-    exec->growMailbox->capacity[kGrowSlotTmp] = (int32_t)(hs.tmpCapacity >> 10);
-    HIPCHK(hipHostGetDevicePointer((void **)&hs.growMailbox,
-                                   exec->growMailbox, 0));
-
-    // device -> host message ring of mwGPU::HostPrint
-    HIPCHK(hipHostMalloc((void **)&exec->printRing, sizeof(HostPrintRing),
-                         hipHostMallocMapped));
-    memset((void *)exec->printRing, 0, sizeof(HostPrintRing));
-    HIPCHK(hipHostGetDevicePointer((void **)&hs.hostPrintRing,
-                                   exec->printRing, 0));
-
-    rc = devAllocT(exec, &exec->stateDev, 1);
-    if (rc != 0) return rc;
-    HIPCHK(hipMemcpy(exec->stateDev, &hs, sizeof(EcsState),
-                     hipMemcpyHostToDevice));
-
-    // [0] error flags, [1] id high-water mark, rows / per-step peak rows per
-    // archetype, profiling gate flag, replays completed (kStats* above)
-    HIPCHK(hipHostMalloc((void **)&exec->statsHost,
-        kStatsWords * sizeof(int32_t), hipHostMallocMapped));
-    memset(exec->statsHost, 0, kStatsWords * sizeof(int32_t));
-
-    exec->stateBuilt = true;
-    return 0;
-}
-
-// ---------------------------------------------------------------------------
-// mwGPU::HostPrint, host side: "{}" placeholders, one line per record
-// (reference HostPrintCPU, src/mw/cuda_exec.cpp: same placeholder syntax)
-// ---------------------------------------------------------------------------
-static void printRecord(const HostPrintRecord &rec)
-{
-    std::string out;
-    uint32_t next_arg = 0;
-    char num[64];
-    for (const char *p = rec.fmt; *p != '\0' &&
-             p < rec.fmt + HostPrintRecord::maxChars; p++) {
-        if (p[0] == '{' && p[1] == '}' && next_arg < rec.numArgs &&
-                next_arg < (uint32_t)HostPrintRecord::maxArgs) {
-            const uint64_t v = rec.args[next_arg];
-            switch (rec.types[next_arg]) {
-            case HostPrintRecord::I32:
-                snprintf(num, sizeof(num), "%d", (int32_t)(int64_t)v); break;
-            case HostPrintRecord::U32:
-                snprintf(num, sizeof(num), "%u", (uint32_t)v); break;
-            case HostPrintRecord::I64:
-                snprintf(num, sizeof(num), "%" PRId64, (int64_t)v); break;
-            case HostPrintRecord::U64:
-                snprintf(num, sizeof(num), "%" PRIu64, v); break;
-            case HostPrintRecord::Float: {
-                uint32_t bits = (uint32_t)v;
-                float f;
-                memcpy(&f, &bits, sizeof(f));
-                snprintf(num, sizeof(num), "%f", f);
-            } break;
-            default:
-                snprintf(num, sizeof(num), "%p", (void *)(uintptr_t)v); break;
-            }
-            out += num;
-            next_arg++;
-            p++;
-        } else {
-            out += *p;
-        }
-    }
-    printf("%s\n", out.c_str());
-}
-
-// Prints completed records in ticket order and stops at the first incomplete
-// one (its writer is still running).  in_flight: called between replays by the
-// service thread; otherwise the stream has been waited for, every record below
-// head is complete, and the drop count is reported.
-static void drainHostPrints(mwhip_exec *exec, bool in_flight)
-{
-    HostPrintRing *ring = exec->printRing;
-    if (ring == nullptr) return;
-    std::lock_guard<std::mutex> guard(exec->printMutex);
-
-    const uint64_t head = __atomic_load_n(&ring->head, __ATOMIC_ACQUIRE);
-    uint64_t tail = ring->tail;
-    bool printed = false;
-    while (tail < head) {
-        HostPrintRecord &rec = ring->records[tail % HostPrintRing::numRecords];
-        const uint64_t seq = __atomic_load_n(&rec.seq, __ATOMIC_ACQUIRE);
-        if (seq == tail + 1) {
-            printRecord(rec);
-            printed = true;
-        } else {
-            // Not there yet: its writer is still filling it in (tickets are
-            // only taken when the ring has room, host_print.hpp: there are no
-            // holes to skip).  After a replay the host waited for, every
-            // writer has finished and this does not happen.
-            (void)in_flight;
-            break;
-        }
-        tail += 1;
-        __atomic_store_n(&ring->tail, tail, __ATOMIC_RELEASE);
-    }
-    if (!in_flight) {
-        const uint64_t dropped =
-            __atomic_exchange_n(&ring->dropped, 0ull, __ATOMIC_RELAXED);
-        if (dropped != 0) {
-            printf("madrona_amd: HostPrint ring overflow, %" PRIu64
-                   " message(s) dropped\n", dropped);
-            printed = true;
-        }
-    }
-    if (printed) fflush(stdout);
-}
-
-template <typename T>
-static int pokeState(mwhip_exec *exec, T EcsState::*field, const T &value)
-{
-    exec->hostState.*field = value;
-    char *dst = (char *)exec->stateDev +
-        ((char *)&(exec->hostState.*field) - (char *)&exec->hostState);
-    HIPCHK(hipMemcpy(dst, &value, sizeof(T), hipMemcpyHostToDevice));
-    return 0;
-}
-
-static int fetchError(mwhip_exec *exec, uint32_t *flags)
-{
-    HIPCHK(hipMemcpy(flags, (char *)exec->stateDev +
-        offsetof(EcsState, errorFlags), sizeof(uint32_t),
-        hipMemcpyDeviceToHost));
-    return 0;
-}
-
-static const char *describeError(uint32_t flags)
-{
-    if (flags & kErrTableOverflow) {
-        return "an archetype table ran out of rows (raise "
-               "max_num_entities_per_world or MADRONA_MWHIP_ROWS_PER_WORLD)";
-    }
-    if (flags & kErrEntityOverflow) {
-        return "the entity id store is full (raise "
-               "MADRONA_MWHIP_ID_BLOCKS_PER_WORLD)";
-    }
-    if (flags & kErrTmpOverflow) {
-        return "Context::tmpAlloc scratch exhausted (raise MADRONA_MWHIP_TMP_MB)";
-    }
-    if (flags & kErrSortLookback) {
-        return "sort look-back timed out";
-    }
-    if (flags & kErrPersistOverflow) {
-        return "persistent world-constructor allocations exhausted (raise "
-               "MADRONA_MWHIP_PERSIST_KB_PER_WORLD)";
-    }
-    if (flags & kErrPhysics) {
-        return "physics capacity exceeded (BVH leaves / traversal stack / "
-               "hull scratch)";
-    }
-    if (flags & kErrInitBlocks) {
-        return "world constructors are not deterministic";
-    }
-    if (flags & kErrRender) {
-        return "ray caster: a world holds more than 1024 instances, the "
-               "instance table was not world-sorted, or a traversal stack "
-               "overflowed";
-    }
-    return "unknown device error";
-}
-
-// ---------------------------------------------------------------------------
-// launches
-// ---------------------------------------------------------------------------
-static int launchOne(mwhip_exec *exec, KernelLaunch &k, hipStream_t stream)
-{
-    void *args[8];
-    k.argPointers(args);
-    HIPCHK(hipLaunchKernel(k.fn, k.grid, k.block, args, k.dynamicLds, stream));
-    (void)exec;
-    return 0;
-}
-
-static int ensureSortScratch(mwhip_exec *exec, ArchetypeRec &arch)
-{
-    if (arch.sortState != nullptr) return 0;
-    // (shared by every graph that sorts this table: not the building graph's)
-    struct ScopeOff {
-        mwhip_exec *e; std::vector<void *> *saved;
-        explicit ScopeOff(mwhip_exec *x) : e(x), saved(t_allocScope) { t_allocScope = nullptr; }
-        ~ScopeOff() { (void)e; t_allocScope = saved; }
-    } scope_off(exec);
-
-    int rc = devAllocT(exec, &arch.sortState, 1);
-    if (rc != 0) return rc;
-    if (arch.reservedCapacity > arch.capacity) {
-        void **bufs[5] = { (void **)&arch.keysA, (void **)&arch.keysB,
-                           (void **)&arch.idxA, (void **)&arch.idxB,
-                           (void **)&arch.tailLand };
-        for (int i = 0; i < 5; i++) {
-            rc = vmAlloc(exec, bufs[i], &arch.sortVm[i],
-                         (size_t)arch.reservedCapacity * 4,
-                         (size_t)arch.capacity * 4, false);
-            if (rc != 0) return rc;
-        }
-    } else {
-        rc = devAllocT(exec, &arch.keysA, arch.capacity, false);
-        if (rc != 0) return rc;
-        rc = devAllocT(exec, &arch.keysB, arch.capacity, false);
-        if (rc != 0) return rc;
-        rc = devAllocT(exec, &arch.idxA, arch.capacity, false);
-        if (rc != 0) return rc;
-        rc = devAllocT(exec, &arch.idxB, arch.capacity, false);
-        if (rc != 0) return rc;
-        rc = devAllocT(exec, &arch.tailLand, arch.capacity, false);
-        if (rc != 0) return rc;
-    }
-    // (look-back slots for every tile the table can ever have)
-    size_t tiles =
-        (arch.reservedCapacity + sortTileSize() - 1) / sortTileSize();
-    rc = devAllocT(exec, &arch.lookback, tiles * 256);
-    if (rc != 0) return rc;
-    rc = devAllocT(exec, &arch.tileCounts, tiles + 2);
-    if (rc != 0) return rc;
-    rc = devAllocT(exec, &arch.tileTailStart, tiles + 2);
-    return rc;
-}
-
-// Can the world sort of this archetype start from what the last one left?
-static bool compactionEligible(const mwhip_exec *exec, uint32_t archetype_id,
-                               uint32_t component_id)
-{
-    const ArchetypeRec &arch = exec->archetypes[archetype_id];
-    if (component_id != 1 || exec->sortCompaction == 0) return false;
-    return exec->sortCompaction == 2 || (!arch.scrambled && !arch.noCompact);
-}
-
-// batches that move at least this much take the gather's blocked assignment
-static constexpr double kGatherBlockedBytes = 256.0 * 1024.0 * 1024.0;
-
-static int makeSortBatch(mwhip_exec *exec,
-                         const std::vector<std::pair<uint32_t, uint32_t>> &specs,
-                         std::unique_ptr<SortBatch> &out, bool compact = false)
-{
-    out.reset(new SortBatch {});
-    out->stateDev = exec->stateDev;
-    out->compact = compact;
-
-    std::vector<SortSite> sites;
-    std::vector<GatherColumn> cols;
-    bool all_small = envU32("MADRONA_MWHIP_SORT_SMALL", 1) != 0;
-
-    for (auto [archetype_id, component_id] : specs) {
-        if (archetype_id >= exec->archetypes.size() ||
-                !exec->archetypes[archetype_id].registered) {
-            return fail(-3, "sort node on unregistered archetype %u",
-                        archetype_id);
-        }
-        ArchetypeRec &arch = exec->archetypes[archetype_id];
-        int key_col = findColumn(arch, component_id);
-        if (key_col < 0) {
-            return fail(-3, "sort node: archetype %u has no component %u",
-                        archetype_id, component_id);
-        }
-        if (arch.colBytes[key_col] != 4) {
-            return fail(-3, "sort key component %u is not 4 bytes",
-                        component_id);
-        }
-
-        int rc = ensureSortScratch(exec, arch);
-        if (rc != 0) return rc;
-
-        const bool world_sort = component_id == 1;
-
-        SortSiteHost host_site {};
-        host_site.archetype = archetype_id;
-        host_site.keyColumn = (uint32_t)key_col;
-        host_site.worldSort = world_sort;
-        host_site.numPasses = sortNumPasses(world_sort, exec->cfg.num_worlds);
-        host_site.capacity = arch.capacity;
-        host_site.rowBytes = arch.rowBytes;
-        host_site.stateDev = arch.sortState;
-        out->sites.push_back(host_site);
-
-        SortSite site {};
-        site.archetype = archetype_id;
-        site.keyColumn = (uint32_t)key_col;
-        site.numPasses = host_site.numPasses;
-        site.worldSort = world_sort ? 1u : 0u;
-        site.keysA = arch.keysA;
-        site.keysB = arch.keysB;
-        site.idxA = arch.idxA;
-        site.idxB = arch.idxB;
-        site.lookback = arch.lookback;
-        site.state = arch.sortState;
-        site.tileCounts = arch.tileCounts;
-        site.tileTailStart = arch.tileTailStart;
-        site.tailLand = arch.tailLand;
-        sites.push_back(site);
-
-        out->maxCapacity = std::max(out->maxCapacity, arch.capacity);
-        {
-            // small-table path while the table holds at most a quarter of the
-            // limit (checked again after every replay, sortsOutgrown())
-            uint64_t rows_now = archetype_id < exec->rowsAtGraphBuild.size() ?
-                exec->rowsAtGraphBuild[archetype_id] : arch.capacity;
-            // (a table that can never hold more than that quarter stays small)
-            if ((uint64_t)arch.capacity * 4 <= sortSmallRowLimit()) rows_now = 0;
-            if (arch.bigSort || rows_now * 4 > sortSmallRowLimit()) {
-                all_small = false;
-            }
-        }
-        uint32_t site_columns = 0;
-        sites.back().firstGatherColumn = (uint32_t)cols.size();
-        if (world_sort) {
-            // first in the list: its two binary-search chains per world overlap
-            // with the column traffic of the workgroups scheduled after it
-            GatherColumn ranges {};
-            ranges.site = (uint32_t)sites.size() - 1;
-            ranges.column = kWorldRangesColumn;
-            cols.push_back(ranges);
-            site_columns++;
-        }
-        for (uint32_t c = 0; c < arch.numColumns; c++) {
-            if ((arch.colFlags[c] & kColumnPinned) != 0u) {
-                out->hasPinned = true;
-                sites.back().hasPinned = 1u;
-            }
-            site_columns++;
-            uint32_t bytes = arch.colBytes[c];
-            GatherColumn gc {};
-            gc.site = (uint32_t)sites.size() - 1;
-            gc.column = c;
-            gc.wordBytes = bytes % 16 == 0 ? 16 : (bytes % 8 == 0 ? 8 :
-                (bytes % 4 == 0 ? 4 : 1));
-            gc.wordsPerRow = bytes / gc.wordBytes;
-            gc.invMagic = gc.wordsPerRow <= 1 ? 0ull :
-                (~0ull / gc.wordsPerRow) + 1ull;
-            // MADRONA_MWHIP_GATHER_WIDE=1: rows of whole dwords in 16-byte chunks
-            // of the destination (round 3's default).  Re-measured in round 4
-            // next to the blocked assignment (profiles/r04_sort_variants.jsonl):
-            // word by word is as fast or faster at every size -- 15.0 against
-            // 15.6 us at 4096 Escape-Room worlds, 28.1 against 30.7 at 8192 with
-            // physics, 168 against 204 at 65536 -- so that is the default again.
-            const bool wide = envU32("MADRONA_MWHIP_GATHER_WIDE", 0) != 0;
-            if (wide && bytes % 4 == 0 && bytes != 0) {
-                gc.rowDwords = bytes / 4;
-                out->gatherWide = true;
-                gc.invMagicDwords = gc.rowDwords <= 1 ? 0ull :
-                    (~0ull / gc.rowDwords) + 1ull;
-            }
-            cols.push_back(gc);
-        }
-        sites.back().numGatherColumns = site_columns;
-    }
-    out->small = all_small;
-
-    int rc = devAllocT(exec, &out->sitesDev, sites.size());
-    if (rc != 0) return rc;
-    HIPCHK(hipMemcpy(out->sitesDev, sites.data(),
-        sites.size() * sizeof(SortSite), hipMemcpyHostToDevice));
-    rc = devAllocT(exec, &out->gatherColumnsDev, cols.size());
-    if (rc != 0) return rc;
-    HIPCHK(hipMemcpy(out->gatherColumnsDev, cols.data(),
-        cols.size() * sizeof(GatherColumn), hipMemcpyHostToDevice));
-    out->numGatherColumns = (uint32_t)cols.size();
-
-    // ---- the gather's workgroups, shared out by bytes to move ----
-    {
-        // about one workgroup per 32 KB, between one and four resident rounds of
-        // the chip (measured, profiles/r03_sort_variants.jsonl: 2048 is best at
-        // 38 MB, 4096 at 94 MB, 8192 at 610 MB)
-        std::vector<double> weight(cols.size(), 0.0);
-        double total = 0.0;
-        for (size_t c = 0; c < cols.size(); c++) {
-            const SortSiteHost &site = out->sites[cols[c].site];
-            const ArchetypeRec &arch = exec->archetypes[site.archetype];
-            uint64_t rows = site.archetype < exec->rowsAtGraphBuild.size() ?
-                exec->rowsAtGraphBuild[site.archetype] : 0;
-            if (rows == 0) rows = arch.capacity;
-            if (cols[c].column == kWorldRangesColumn) {
-                // two binary searches per world: latency, not bytes
-                weight[c] = 64.0 * exec->cfg.num_worlds;
-            } else {
-                // (+ the 4-byte permutation entry every row of a column reads)
-                weight[c] = (double)rows * (arch.colBytes[cols[c].column] + 4.0);
-            }
-            total += weight[c];
-        }
-        const uint32_t target =
-            (uint32_t)std::min(std::max(total / 32768.0, 2048.0), 8192.0);
-        std::vector<GatherSlice> slices;
-        // big batches: a contiguous run of rows per workgroup instead of a
-        // stride over the whole column (measured at 65536 / 16384 Escape-Room
-        // worlds on one box, profiles/r04_sort_variants.jsonl: strided 300 /
-        // 53 us, contiguous 252 / 52 us)
-        const uint32_t blocked = total >= kGatherBlockedBytes ? 1u : 0u;
-        for (size_t c = 0; c < cols.size(); c++) {
-            uint32_t n = (uint32_t)(target * weight[c] / std::max(total, 1.0) + 0.5);
-            // at least 4 KB of work per workgroup, at least one workgroup
-            n = std::min<uint32_t>(n, (uint32_t)(weight[c] / 4096.0) + 1u);
-            n = std::max<uint32_t>(n, 1u);
-            for (uint32_t i = 0; i < n; i++) {
-                slices.push_back(GatherSlice { (uint32_t)c, i, n, blocked });
-            }
-        }
-        rc = devAllocT(exec, &out->gatherSlicesDev, slices.size());
-        if (rc != 0) return rc;
-        HIPCHK(hipMemcpy(out->gatherSlicesDev, slices.data(),
-            slices.size() * sizeof(GatherSlice), hipMemcpyHostToDevice));
-        out->numGatherSlices = (uint32_t)slices.size();
-    }
-    return 0;
-}
-
-static void pickGrid(mwhip_exec *exec, KernelLaunch &k, uint64_t max_invocations,
-                     uint32_t threads_per_invocation)
-{
-    (void)exec;
-    if (threads_per_invocation >= 64) {
-        // wave- (or workgroup-) per-invocation kernels: one workgroup of that
-        // size per invocation, the hardware scheduler balances the rest
-        k.block = dim3(threads_per_invocation, 1, 1);
-        k.grid = dim3((uint32_t)std::min<uint64_t>(
-            std::max<uint64_t>(max_invocations, 1), 1u << 20), 1, 1);
-        return;
-    }
-    uint64_t threads = max_invocations * std::max(threads_per_invocation, 1u);
-    // small tables: 64-thread workgroups so the work spreads over more CUs;
-    // big tables: 256-thread workgroups, capped, with grid-stride loops
-    uint32_t block = threads >= 256ull * 512ull ? 256u : 64u;
-    uint64_t blocks = (threads + block - 1) / block;
-    blocks = std::min<uint64_t>(std::max<uint64_t>(blocks, 1), 2048);
-    k.block = dim3(block, 1, 1);
-    k.grid = dim3((uint32_t)blocks, 1, 1);
-}
-
-static uint64_t queryCapacityRows(mwhip_exec *exec, uint32_t offset,
-                                  uint32_t num_matching, uint32_t num_components_hint)
-{
-    (void)num_components_hint;
-    // find the query record to learn its component count
-    for (const QueryRec &q : exec->queries) {
-        if (q.offset == offset) {
-            uint64_t rows = 0;
-            const uint32_t *p = exec->queryDataHost.data() + offset;
-            for (uint32_t i = 0; i < num_matching; i++) {
-                // Grids follow what the tables hold when the graph is built
-                // (x2 head room, at least 4096), not their capacity: the
-                // kernels stride over the device-resident row count, so a
-                // fuller table is still covered, and a table declared with 64
-                // rows per world but holding 4 does not launch 16x the
-                // workgroups it needs (a trivial system: 4.3 -> ~3 us).  Graphs
-                // are rebuilt when a table grows.
-                const ArchetypeRec &arch = exec->archetypes[p[0]];
-                uint64_t live = p[0] < exec->rowsAtGraphBuild.size() ?
-                    exec->rowsAtGraphBuild[p[0]] : arch.capacity;
-                // (tables that are empty at build time -- temporaries, joints
-                // -- say nothing about their steady state: capacity)
-                rows += live == 0 ? arch.capacity :
-                    std::min<uint64_t>(arch.capacity,
-                                       std::max<uint64_t>(2 * live, 4096));
-                p += 1 + q.comps.size();
-            }
-            return rows;
-        }
-    }
-    return 0;
-}
-
-// Which tables does something other than a world sort reorder or truncate?
-// (every task graph of the executor counts, not only the ones being built: a
-// launch graph over another task graph may run in between)
-static int findScrambledTables(mwhip_exec *exec)
-{
-    for (ArchetypeRec &arch : exec->archetypes) {
-        arch.scrambled = false;
-    }
-    for (TaskGraphRec &tg : exec->taskGraphs) {
-        for (const NodeRec &node : tg.nodes) {
-            const mwhip_node_desc &d = node.desc;
-            if (d.kind == MWHIP_NODE_CLEAR_TMP ||
-                    (d.kind == MWHIP_NODE_SORT_ARCHETYPE && d.component_id != 1)) {
-                if (d.archetype_id < exec->archetypes.size()) {
-                    exec->archetypes[d.archetype_id].scrambled = true;
-                }
-            } else if (d.kind == MWHIP_NODE_EXCLUSIVE_SCAN && d.node_data_id >= 0) {
-                // a scan that writes its total into a table's row count
-                mwhip_scan_params params;
-                HIPCHK(hipMemcpy(&params, tg.dataDev[d.node_data_id],
-                                 sizeof(params), hipMemcpyDeviceToHost));
-                const char *first = (const char *)exec->hostState.tables;
-                const char *at = (const char *)params.total_out;
-                if (at >= first && at < first + exec->tablesHost.size() *
-                                                 sizeof(TableHdr)) {
-                    exec->archetypes[(size_t)(at - first) / sizeof(TableHdr)]
-                        .scrambled = true;
-                }
-            }
-        }
-    }
-    return 0;
-}
-
-static int buildLaunchList(mwhip_exec *exec, const std::vector<uint32_t> &tg_ids,
-                           LaunchGraph &lg)
-{
-    {
-        int rc = findScrambledTables(exec);
-        if (rc != 0) return rc;
-    }
-    if (!lg.isRender) {
-        for (const mwhip_exec::InputRing &ring : exec->inputRings) {
-            KernelLaunch k;
-            k.fn = (const void *)&inputRingKernel;
-            k.grid = dim3(std::min<uint32_t>((ring.slotWords + 255u) / 256u, 1024u), 1, 1);
-            k.block = dim3(256, 1, 1);
-            k.setArgs(exec->stateDev, ring.dst, ring.ring, ring.slotWords, ring.numSlots,
-                      ring.firstReplay);
-            k.name = "input";
-            k.role = "ring";
-            k.kind = MWHIP_NODE_RECYCLE;
-            lg.launches.push_back(k);
-        }
-    }
-    for (uint32_t tg_id : tg_ids) {
-        if (tg_id >= exec->taskGraphs.size()) {
-            return fail(-3, "task graph %u does not exist", tg_id);
-        }
-        TaskGraphRec &tg = exec->taskGraphs[tg_id];
-        const std::vector<int32_t> &order = tg.sorted;
-
-        std::vector<MiscOp> pending_misc;
-        auto flushMisc = [&]() -> int {
-            if (pending_misc.empty()) return 0;
-            MiscOp *ops_dev;
-            int rc = devAllocT(exec, &ops_dev, pending_misc.size());
-            if (rc != 0) return rc;
-            HIPCHK(hipMemcpy(ops_dev, pending_misc.data(),
-                pending_misc.size() * sizeof(MiscOp), hipMemcpyHostToDevice));
-            KernelLaunch k;
-            k.fn = (const void *)&miscOpsKernel;
-            k.grid = dim3(1, 1, 1);
-            k.block = dim3(64, 1, 1);
-            k.setArgs(exec->stateDev, (const MiscOp *)ops_dev,
-                      (uint32_t)pending_misc.size());
-            k.name = "misc";
-            k.role = "clear/reset";
-            k.kind = MWHIP_NODE_CLEAR_TMP;
-            lg.launches.push_back(k);
-            pending_misc.clear();
-            return 0;
-        };
-
-        for (size_t oi = 0; oi < order.size(); oi++) {
-            NodeRec &node = tg.nodes[order[oi]];
-            const mwhip_node_desc &d = node.desc;
-
-            switch (d.kind) {
-            case MWHIP_NODE_KERNEL: {
-                int rc = flushMisc();
-                if (rc != 0) return rc;
-
-                KernelLaunch k;
-                k.fn = d.kernel;
-                void *data_dev = d.node_data_id >= 0 ?
-                    tg.dataDev[d.node_data_id] : nullptr;
-                k.setArgs(exec->stateDev, data_dev, d.arg0, d.arg1);
-                if (d.wants_pfor_args != 0 &&
-                        d.count_mode == MWHIP_COUNT_QUERY_ROWS) {
-                    mwhip_pfor_args pa {};
-                    pa.num_matching = d.num_matching;
-                    pa.num_inline = 0;
-                    for (const QueryRec &q : exec->queries) {
-                        if (q.offset != d.query_offset) continue;
-                        if (q.numMatching <= MWHIP_PFOR_MAX_INLINE &&
-                                q.comps.size() <= MWHIP_PFOR_MAX_COMPONENTS) {
-                            const uint32_t *p =
-                                exec->queryDataHost.data() + q.offset;
-                            for (uint32_t m = 0; m < q.numMatching; m++) {
-                                pa.tables[m] = exec->hostState.tables + p[0];
-                                for (size_t c = 0; c < q.comps.size(); c++) {
-                                    pa.columns[m][c] = (uint16_t)p[1 + c];
-                                }
-                                p += 1 + q.comps.size();
-                            }
-                            pa.num_inline = q.numMatching;
-                        }
-                        break;
-                    }
-                    // A system that can append rows (its kernel carries the
-                    // static LDS marker of appendRowIssue; any other static
-                    // LDS errs on the safe side) must not visit rows created
-                    // during its own node: such nodes fix their row counts
-                    // once per launch.
-                    hipFuncAttributes attr {};
-                    HIPCHK(hipFuncGetAttributes(&attr, d.kernel));
-                    if (d.num_matching > 0 && attr.sharedSizeBytes != 0) {
-                        void *sync_dev = nullptr;
-                        int src = devAlloc(exec, &sync_dev,
-                            sizeof(PforRowSync) + 8ull * d.num_matching);
-                        if (src != 0) return src;
-                        pa.row_sync = sync_dev;
-                        k.dynamicLds = 4u * d.num_matching;
-                    }
-                    k.pushArg(pa);
-                    k.pforArgs = pa;
-                    k.rowSnapshot = pa.row_sync != nullptr;
-                    k.pforBody = d.pfor_body;
-                    k.pforArg1 = d.arg1;
-                    k.pforVgprs = (uint32_t)std::max(attr.numRegs, 0);
-                    k.pforWriteMask = d.write_mask;
-                }
-                k.name = node.name;
-                k.role = "";
-                k.kind = d.kind;
-                k.bytesPerRow = d.bytes_per_row;
-                k.ioDeclared = d.io_declared;
-                k.countMode = d.count_mode;
-                k.fixedCount = d.fixed_count;
-                k.queryOffset = d.query_offset;
-                k.numMatching = d.num_matching;
-
-                uint64_t max_inv = 0;
-                if (d.count_mode == MWHIP_COUNT_QUERY_ROWS) {
-                    max_inv = queryCapacityRows(exec, d.query_offset,
-                                                d.num_matching, 0);
-                    if (d.num_matching == 0) max_inv = 1;
-                } else if (d.count_mode == MWHIP_COUNT_PER_WORLD) {
-                    max_inv = exec->cfg.num_worlds;
-                } else {
-                    max_inv = d.fixed_count == 0xFFFFFFFFu ?
-                        (256ull * 1024ull) : std::max(d.fixed_count, 1u);
-                }
-                pickGrid(exec, k, max_inv, d.threads_per_invocation);
-                // exec config: workgroups per CU of this node's kernel (only
-                // ParallelFor kernels: they stride over their rows with the grid)
-                if (d.count_mode == MWHIP_COUNT_QUERY_ROWS &&
-                        oi < exec->nodeWorkgroupsPerCU.size() &&
-                        exec->nodeWorkgroupsPerCU[oi] != 0u) {
-                    k.grid.x = std::min<uint32_t>(k.grid.x,
-                        exec->nodeWorkgroupsPerCU[oi] * exec->numCUs);
-                }
-                k.nodeIndex = (uint32_t)oi;
-                k.dagKernel = true;
-                k.tgId = tg_id;
-                k.tgNode = order[oi];
-                lg.launches.push_back(k);
-            } break;
-            case MWHIP_NODE_SORT_ARCHETYPE: {
-                int rc = flushMisc();
-                if (rc != 0) return rc;
-
-                // Batch this sort with the sort nodes that directly follow it.
-                // ResetTmpAlloc / Recycle nodes in between commute with the
-                // sort (it uses neither) and are replayed after the batch.
-                std::vector<std::pair<uint32_t, uint32_t>> specs;
-                specs.emplace_back(d.archetype_id, d.component_id);
-                std::string name = node.name;
-                size_t oj = oi + 1;
-                {
-                    for (; oj < order.size(); oj++) {
-                        const mwhip_node_desc &nd = tg.nodes[order[oj]].desc;
-                        if (nd.kind == MWHIP_NODE_RESET_TMP_ALLOC) {
-                            pending_misc.push_back({ kOpResetTmpAlloc, 0 });
-                            continue;
-                        }
-                        if (nd.kind == MWHIP_NODE_RECYCLE) {
-                            continue;
-                        }
-                        if (nd.kind != MWHIP_NODE_SORT_ARCHETYPE) {
-                            break;
-                        }
-                        bool dup = false;
-                        for (auto &s : specs) {
-                            if (s.first == nd.archetype_id) dup = true;
-                        }
-                        if (dup) break;
-                        specs.emplace_back(nd.archetype_id, nd.component_id);
-                    }
-                    // collapse duplicate deferred resets
-                    if (pending_misc.size() > 1) pending_misc.resize(1);
-                }
-
-                // World sorts of tables that nothing else reorders start from
-                // what the last sort left (compaction chain); the rest of the
-                // batch takes the radix chain.  Sites of one batch sort
-                // different tables, so the two chains commute.
-                // (Batches of small tables stay whole: one launch either way.)
-                std::vector<std::pair<uint32_t, uint32_t>> by_chain[2];
-                bool any_compact = false;
-                for (auto &spec : specs) {
-                    any_compact = any_compact ||
-                        compactionEligible(exec, spec.first, spec.second);
-                }
-                std::unique_ptr<SortBatch> whole;
-                rc = makeSortBatch(exec, specs, whole, false);
-                if (rc != 0) return rc;
-                const bool split = any_compact && !whole->small;
-                for (auto &spec : specs) {
-                    by_chain[split && compactionEligible(exec, spec.first,
-                                                         spec.second) ?
-                             1 : 0].push_back(spec);
-                }
-                for (int chain = 0; chain < 2; chain++) {
-                    if (by_chain[chain].empty()) continue;
-                    std::unique_ptr<SortBatch> batch;
-                    if (!split) {
-                        batch = std::move(whole);
-                    } else {
-                        rc = makeSortBatch(exec, by_chain[chain], batch, chain == 1);
-                        if (rc != 0) return rc;
-                    }
-
-                    size_t first = lg.launches.size();
-                    buildSortLaunches(*batch, lg.launches);
-                    for (size_t i = first; i < lg.launches.size(); i++) {
-                        lg.launches[i].name = name;
-                        lg.launches[i].archetype = by_chain[chain][0].first;
-                    }
-                    lg.sortBatches.push_back(std::move(batch));
-                }
-                // The ResetTmpAlloc nodes deferred behind the batch ride on its
-                // last kernel instead of taking a launch of their own (~4 us):
-                // the sort uses neither the scratch allocator nor their result.
-                if (!pending_misc.empty() && exec->sortCarriesMisc) {
-                    MiscOp *ops_dev;
-                    rc = devAllocT(exec, &ops_dev, pending_misc.size());
-                    if (rc != 0) return rc;
-                    HIPCHK(hipMemcpy(ops_dev, pending_misc.data(),
-                        pending_misc.size() * sizeof(MiscOp), hipMemcpyHostToDevice));
-                    // (the last kernel of a chain is sortSmall, sortGather or
-                    // sortFinalize: each ends in (ops, count), empty by default)
-                    KernelLaunch &last = lg.launches.back();
-                    last.numArgs -= 2;
-                    last.pushArg((const MiscOp *)ops_dev);
-                    last.pushArg((uint32_t)pending_misc.size());
-                    last.carriesMisc = true;
-                    pending_misc.clear();
-                }
-                oi = oj - 1;
-            } break;
-            case MWHIP_NODE_EXCLUSIVE_SCAN: {
-                int rc = flushMisc();
-                if (rc != 0) return rc;
-                if (d.node_data_id < 0) {
-                    return fail(-3, "scan node '%s' without parameters",
-                                node.name.c_str());
-                }
-
-                // node data holds mwhip_scan_params; wrap it with the scan's
-                // own state (ticket / epoch / granules)
-                mwhip_scan_params params;
-                HIPCHK(hipMemcpy(&params, tg.dataDev[d.node_data_id],
-                                 sizeof(params), hipMemcpyDeviceToHost));
-                uint32_t max_tiles = d.fixed_count == 0 ? 1u :
-                    (d.fixed_count + kScanTile - 1) / kScanTile +
-                    MWHIP_SCAN_MAX_SEGMENTS;
-
-                ScanNode host_node {};
-                host_node.params = params;
-                host_node.maxTiles = max_tiles;
-                rc = devAllocT(exec, &host_node.state, 1);
-                if (rc != 0) return rc;
-                rc = devAllocT(exec, &host_node.granules, max_tiles);
-                if (rc != 0) return rc;
-                ScanNode *node_dev;
-                rc = devAllocT(exec, &node_dev, 1);
-                if (rc != 0) return rc;
-                HIPCHK(hipMemcpy(node_dev, &host_node, sizeof(ScanNode),
-                                 hipMemcpyHostToDevice));
-
-                KernelLaunch k;
-                k.fn = (const void *)&exclusiveScanKernel;
-                k.grid = dim3(max_tiles, 1, 1);
-                k.block = dim3(kScanThreads, 1, 1);
-                k.setArgs(exec->stateDev, (const ScanNode *)node_dev);
-                k.name = node.name;
-                k.role = "scan";
-                k.kind = d.kind;
-                lg.launches.push_back(k);
-            } break;
-            case MWHIP_NODE_CLEAR_TMP:
-                pending_misc.push_back({ kOpClearTmp, d.archetype_id });
-                break;
-            case MWHIP_NODE_RESET_TMP_ALLOC:
-                pending_misc.push_back({ kOpResetTmpAlloc, 0 });
-                break;
-            case MWHIP_NODE_RECYCLE:
-                break;
-            default:
-                return fail(-3, "unknown node kind %u", d.kind);
-            }
-
-            if (pending_misc.size() >= 64) {
-                int rc = flushMisc();
-                if (rc != 0) return rc;
-            }
-        }
-
-        int rc = flushMisc();
-        if (rc != 0) return rc;
-    }
-
-    // every replay ends with the health kernel: error flags and row counts to
-    // pinned host memory (table growth reads them), replay counter bumped
-    {
-        KernelLaunch k;
-        k.fn = (const void *)&statsKernel;
-        k.grid = dim3(1, 1, 1);
-        k.block = dim3(256, 1, 1);
-        int32_t *host_out = nullptr;
-        HIPCHK(hipHostGetDevicePointer((void **)&host_out, exec->statsHost, 0));
-        k.setArgs(exec->stateDev, host_out, exec->replaySignal,
-                  lg.isRender ? 0u : 1u);
-        k.name = "stats";
-        k.role = "health";
-        k.kind = MWHIP_NODE_RECYCLE;
-        lg.launches.push_back(k);
-    }
-
-    return 0;
-}
-
-static int sortAllArchetypes(mwhip_exec *exec)
-{
-    // World-sort every non-singleton table once after world construction so
-    // rows are world-major (world constructors run in parallel and append in
-    // arrival order; the stable sort keeps each world's creation order).
-    std::vector<std::pair<uint32_t, uint32_t>> specs;
-    for (uint32_t a = 0; a < exec->archetypes.size(); a++) {
-        const ArchetypeRec &arch = exec->archetypes[a];
-        if (arch.registered && !arch.singleton) {
-            specs.emplace_back(a, 1u);
-        }
-    }
-    if (specs.empty()) return 0;
-
-    std::unique_ptr<SortBatch> batch;
-    int rc = makeSortBatch(exec, specs, batch);
-    if (rc != 0) return rc;
-
-    std::vector<KernelLaunch> launches;
-    buildSortLaunches(*batch, launches);
-    for (KernelLaunch &k : launches) {
-        rc = launchOne(exec, k, exec->stream);
-        if (rc != 0) return rc;
-    }
-    HIPCHK(hipStreamSynchronize(exec->stream));
-    return 0;
-}
-
-// ---------------------------------------------------------------------------
-// world construction (two passes, deterministic id blocks)
-// ---------------------------------------------------------------------------
-static int launchInitWorlds(mwhip_exec *exec)
-{
-    const int32_t W = (int32_t)exec->cfg.num_worlds;
-    EcsState *state = exec->stateDev;
-    const void *cfg = exec->userCfgDev;
-    const void *inits = exec->worldInitsDev;
-    void *args[] = { &state, &cfg, &inits, (void *)&W };
-    HIPCHK(hipLaunchKernel(exec->entry.init_worlds_kernel,
-        dim3((uint32_t)((W + 63) / 64), 1, 1), dim3(64, 1, 1), args, 0,
-        exec->stream));
-    HIPCHK(hipStreamSynchronize(exec->stream));
-    return 0;
-}
-
-static int resetForInitPass(mwhip_exec *exec)
-{
-    const uint32_t W = exec->cfg.num_worlds;
-    EcsState &hs = exec->hostState;
-
-    HIPCHK(hipMemcpy(hs.tables, exec->tablesHost.data(),
-        exec->tablesHost.size() * sizeof(TableHdr), hipMemcpyHostToDevice));
-    HIPCHK(hipMemset(hs.worldCaches, 0, W * sizeof(IdCache)));
-    std::vector<IdCache> caches(W);
-    for (IdCache &c : caches) {
-        c.freeHead = kIdSentinel;
-        c.numFree = 0;
-        c.overflowHead = kIdSentinel;
-        c.numOverflow = 0;
-        c.lock = 0;
-        c.initBlocksUsed = 0;
-        c.runtimeBlocksUsed = 0;
-    }
-    HIPCHK(hipMemcpy(hs.worldCaches, caches.data(), W * sizeof(IdCache),
-                     hipMemcpyHostToDevice));
-
-    HIPCHK(hipMemset(hs.entities + exec->singletonIdEnd, 0,
-        (size_t)(hs.entityCapacity - (int32_t)exec->singletonIdEnd) *
-            sizeof(EntitySlot)));
-    HIPCHK(hipMemset(hs.worldData, 0, (size_t)hs.worldDataStride * W));
-
-    // singleton user data back to zero
-    for (const ArchetypeRec &arch : exec->archetypes) {
-        if (arch.registered && arch.singleton) {
-            HIPCHK(hipMemset(arch.primary[2], 0,
-                             (size_t)arch.capacity * arch.colBytes[2]));
-        }
-    }
-
-    int rc = pokeState(exec, &EcsState::numIds, (int32_t)exec->singletonIdEnd);
-    if (rc != 0) return rc;
-    rc = pokeState(exec, &EcsState::tmpOffset, 0ull);
-    if (rc != 0) return rc;
-    rc = pokeState(exec, &EcsState::persistOffset, 0ull);
-    if (rc != 0) return rc;
-    rc = pokeState(exec, &EcsState::idFreeHead, 0xFFFFFFFFull);
-    if (rc != 0) return rc;
-    return pokeState(exec, &EcsState::errorFlags, 0u);
-}
-
-static int growTablesFromDevice(mwhip_exec *exec);
-// Entity store / scratch region: more memory mapped behind them (addresses do
-// not change), the mailbox told; the device header follows at the next replay
-// boundary (growTables).  Caller holds growMutex (or runs before the service
-// thread exists).
-static int growEntityStore(mwhip_exec *exec, uint64_t new_ids)
-{
-    EcsState &hs = exec->hostState;
-    if (exec->entityVm == nullptr) {
-        return fail(-4, "the entity store is a fixed allocation "
-                    "(MADRONA_MWHIP_TABLE_GROWTH=1)");
-    }
-    new_ids = (new_ids + kIdsPerBlock - 1) / kIdsPerBlock * kIdsPerBlock;
-    new_ids = std::min<uint64_t>(new_ids,
-                                 exec->entityVm->reserved / sizeof(EntitySlot));
-    if (new_ids <= (uint64_t)hs.entityCapacity) {
-        return fail(-4, "the entity store's reserved address space is used up "
-                    "(%d ids)", hs.entityCapacity);
-    }
-    int rc = vmEnsure(exec, *exec->entityVm, new_ids * sizeof(EntitySlot), true);
-    if (rc != 0) return rc;
-    hs.entityCapacity = (int32_t)new_ids;
-    if (exec->growMailbox != nullptr) {
-        __atomic_store_n(&exec->growMailbox->capacity[kGrowSlotEntities],
-                         (int32_t)new_ids, __ATOMIC_RELEASE);
-    }
-    exec->numGrowths++;
-    exec->headersStale = true;
-    if (getenv("MADRONA_MWHIP_DEBUG_GROWTH") != nullptr) {
-        fprintf(stderr, "madrona_amd: entity store now holds %llu ids\n",
-                (unsigned long long)new_ids);
-    }
-    return 0;
-}
-
-static int growTmpRegion(mwhip_exec *exec, uint64_t new_bytes)
-{
-    EcsState &hs = exec->hostState;
-    if (exec->tmpVm == nullptr) {
-        return fail(-4, "the scratch region is a fixed allocation "
-                    "(MADRONA_MWHIP_TABLE_GROWTH=1)");
-    }
-    new_bytes = std::min<uint64_t>((new_bytes + kVmChunk - 1) / kVmChunk * kVmChunk,
-                                   exec->tmpVm->reserved);
-    if (new_bytes <= hs.tmpCapacity) {
-        return fail(-4, "the scratch region's reserved address space is used up "
-                    "(%llu bytes)", (unsigned long long)hs.tmpCapacity);
-    }
-    int rc = vmEnsure(exec, *exec->tmpVm, new_bytes, false);
-    if (rc != 0) return rc;
-    hs.tmpCapacity = new_bytes;
-    if (exec->growMailbox != nullptr) {
-        __atomic_store_n(&exec->growMailbox->capacity[kGrowSlotTmp],
-                         (int32_t)(new_bytes >> 10), __ATOMIC_RELEASE);
-    }
-    exec->numGrowths++;
-    exec->headersStale = true;
-    if (getenv("MADRONA_MWHIP_DEBUG_GROWTH") != nullptr) {
-        fprintf(stderr, "madrona_amd: scratch region now %llu MiB\n",
-                (unsigned long long)(new_bytes >> 20));
-    }
-    return 0;
-}
-
-static void serviceGrowRequests(mwhip_exec *exec);
-
-static int constructWorlds(mwhip_exec *exec)
-{
-    const uint32_t W = exec->cfg.num_worlds;
-    EcsState &hs = exec->hostState;
-
-    // pass 1: run the constructors to learn how many id blocks each world
-    // takes from the global store
-    int rc = resetForInitPass(exec);
-    if (rc != 0) return rc;
-    rc = pokeState(exec, &EcsState::initMode, 1u);
-    if (rc != 0) return rc;
-    rc = launchInitWorlds(exec);
-    if (rc != 0) return rc;
-
-    uint32_t err = 0;
-    rc = fetchError(exec, &err);
-    if (rc != 0) return rc;
-    // (both recoverable conditions may be raised by one pass: test bits, handle
-    // the persistent region first -- after its overflow every world aliases
-    // persistBase, which can produce secondary flags that the rerun clears)
-    if ((err & kErrPersistOverflow) != 0u) {
-        // The constructors asked for more persistent memory (BVH arrays, ...)
-        // than MADRONA_MWHIP_PERSIST_KB_PER_WORLD provides.  persistAlloc kept
-        // counting, so the offset is what they need: size the region for it
-        // and run pass 1 again.
-        unsigned long long needed = 0;
-        HIPCHK(hipMemcpy(&needed, (char *)exec->stateDev +
-            offsetof(EcsState, persistOffset), sizeof(needed),
-            hipMemcpyDeviceToHost));
-        unsigned long long capacity = needed + needed / 8 + (1ull << 20);
-        char *region = nullptr;
-        rc = devAlloc(exec, (void **)&region, capacity, false);
-        if (rc != 0) return rc;
-        rc = pokeState(exec, &EcsState::persistBase, region);
-        if (rc != 0) return rc;
-        rc = pokeState(exec, &EcsState::persistCapacity, capacity);
-        if (rc != 0) return rc;
-
-        rc = resetForInitPass(exec);
-        if (rc != 0) return rc;
-        rc = pokeState(exec, &EcsState::initMode, 1u);
-        if (rc != 0) return rc;
-        rc = launchInitWorlds(exec);
-        if (rc != 0) return rc;
-        rc = fetchError(exec, &err);
-        if (rc != 0) return rc;
-    }
-    // Constructors that create more rows than a table was given at
-    // registration: full tables grow (they live in reserved address space,
-    // growTables) and pass 1 runs again, until everything fits or the
-    // reservations are exhausted.
-    // Likewise the entity store when the constructors take more id blocks than
-    // it was sized for.
-    constexpr uint32_t kGrowable = kErrTableOverflow | kErrEntityOverflow;
-    for (int attempt = 0; (err & kGrowable) != 0u &&
-             (err & ~kGrowable) == 0u && attempt < 8; attempt++) {
-        const uint32_t before = exec->numGrowths;
-        if ((err & kErrEntityOverflow) != 0u && exec->entityVm != nullptr) {
-            int32_t wanted = 0;     // (pass 1 keeps counting past the end)
-            HIPCHK(hipMemcpy(&wanted, (char *)exec->stateDev +
-                offsetof(EcsState, numIds), sizeof(wanted),
-                hipMemcpyDeviceToHost));
-            rc = growEntityStore(exec, std::max<uint64_t>(
-                (uint64_t)wanted + (uint64_t)wanted / 4,
-                2ull * (uint64_t)hs.entityCapacity));
-            if (rc != 0) return rc;
-            rc = pokeState(exec, &EcsState::entityCapacity, hs.entityCapacity);
-            if (rc != 0) return rc;
-        }
-        if ((err & kErrTableOverflow) != 0u) {
-            rc = growTablesFromDevice(exec);
-            if (rc != 0) return rc;
-        }
-        if (exec->numGrowths == before) {
-            break;      // nothing left to grow: report the overflow
-        }
-
-        rc = resetForInitPass(exec);
-        if (rc != 0) return rc;
-        rc = pokeState(exec, &EcsState::initMode, 1u);
-        if (rc != 0) return rc;
-        rc = launchInitWorlds(exec);
-        if (rc != 0) return rc;
-        rc = fetchError(exec, &err);
-        if (rc != 0) return rc;
-    }
-    if (err != 0) {
-        return fail(-4, "world construction failed: %s", describeError(err));
-    }
-
-    std::vector<IdCache> caches(W);
-    HIPCHK(hipMemcpy(caches.data(), hs.worldCaches, W * sizeof(IdCache),
-                     hipMemcpyDeviceToHost));
-
-    // pass 2: replay with world-major block bases, i.e. the order in which the
-    // reference CPU backend's sequential constructor loop
-    // (include/madrona/mw_cpu.inl:42-46) would have grabbed them
-    std::vector<int32_t> bases(W);
-    int64_t next = exec->singletonIdEnd;
-    for (uint32_t w = 0; w < W; w++) {
-        bases[w] = (int32_t)next;
-        next += (int64_t)caches[w].initBlocksUsed * kIdsPerBlock;
-    }
-    if (next + (int64_t)kIdsPerBlock > hs.entityCapacity) {
-        if (exec->entityVm == nullptr) {
-            return fail(-4, "world construction failed: %s",
-                        describeError(kErrEntityOverflow));
-        }
-        rc = growEntityStore(exec, (uint64_t)next + (uint64_t)next / 4 +
-                                   kIdsPerBlock);
-        if (rc != 0) return rc;
-        rc = pokeState(exec, &EcsState::entityCapacity, hs.entityCapacity);
-        if (rc != 0) return rc;
-    }
-
-    rc = resetForInitPass(exec);
-    if (rc != 0) return rc;
-    HIPCHK(hipMemcpy(hs.initBlockBase, bases.data(), W * sizeof(int32_t),
-                     hipMemcpyHostToDevice));
-    rc = pokeState(exec, &EcsState::numIds, (int32_t)next);
-    if (rc != 0) return rc;
-    rc = pokeState(exec, &EcsState::initMode, 2u);
-    if (rc != 0) return rc;
-    rc = launchInitWorlds(exec);
-    if (rc != 0) return rc;
-
-    std::vector<IdCache> caches2(W);
-    HIPCHK(hipMemcpy(caches2.data(), hs.worldCaches, W * sizeof(IdCache),
-                     hipMemcpyDeviceToHost));
-    for (uint32_t w = 0; w < W; w++) {
-        if (caches2[w].initBlocksUsed != caches[w].initBlocksUsed) {
-            return fail(-4, "world %u constructor is not deterministic "
-                "(%d id blocks, then %d)", w, caches[w].initBlocksUsed,
-                caches2[w].initBlocksUsed);
-        }
-    }
-
-    rc = fetchError(exec, &err);
-    if (rc != 0) return rc;
-    if (err != 0) {
-        return fail(-4, "world construction failed: %s", describeError(err));
-    }
-
-    rc = pokeState(exec, &EcsState::runtimeIdBase, (int32_t)next);
-    if (rc != 0) return rc;
-    return pokeState(exec, &EcsState::initMode, 0u);
-}
-
-// MADRONA_MWHIP_EXEC_CONFIG_FILE: { "<node index>": <workgroups per CU>, ... } --
-// the format of the reference's exec-config file (cuda_exec.cpp:2115-2172:
-// node index -> blocks per SM).  Written by madrona_amd/scripts/profile.py.
-static int loadExecConfigFile(mwhip_exec *exec)
-{
-    const char *path = getenv("MADRONA_MWHIP_EXEC_CONFIG_FILE");
-    if (path == nullptr || path[0] == '\0') {
-        return 0;
-    }
-    FILE *f = fopen(path, "rb");
-    if (f == nullptr) {
-        return fail(-2, "MADRONA_MWHIP_EXEC_CONFIG_FILE: cannot open %s", path);
-    }
-    std::string text;
-    char buf[4096];
-    size_t got;
-    while ((got = fread(buf, 1, sizeof(buf), f)) > 0) {
-        text.append(buf, got);
-    }
-    fclose(f);
-
-    // a flat object of "digits": digits pairs
-    size_t at = 0;
-    auto skip = [&]() {
-        while (at < text.size() && (isspace((unsigned char)text[at]) ||
-                                    text[at] == ',')) at++;
-    };
-    skip();
-    if (at >= text.size() || text[at] != '{') {
-        return fail(-2, "MADRONA_MWHIP_EXEC_CONFIG_FILE points to invalid file");
-    }
-    at++;
-    for (;;) {
-        skip();
-        if (at < text.size() && text[at] == '}') break;
-        if (at >= text.size() || text[at] != '"') {
-            return fail(-2, "MADRONA_MWHIP_EXEC_CONFIG_FILE points to invalid file");
-        }
-        at++;
-        unsigned long long node = 0, value = 0;
-        size_t digits = 0;
-        while (at < text.size() && isdigit((unsigned char)text[at])) {
-            node = node * 10 + (unsigned)(text[at++] - '0');
-            digits++;
-        }
-        if (digits == 0 || at >= text.size() || text[at] != '"' || node > 16384) {
-            return fail(-2, "MADRONA_MWHIP_EXEC_CONFIG_FILE points to invalid file");
-        }
-        at++;
-        skip();
-        if (at >= text.size() || text[at] != ':') {
-            return fail(-2, "MADRONA_MWHIP_EXEC_CONFIG_FILE points to invalid file");
-        }
-        at++;
-        skip();
-        digits = 0;
-        while (at < text.size() && isdigit((unsigned char)text[at])) {
-            value = value * 10 + (unsigned)(text[at++] - '0');
-            digits++;
-        }
-        if (digits == 0 || value > 64) {
-            return fail(-2, "MADRONA_MWHIP_EXEC_CONFIG_FILE points to invalid file");
-        }
-        if (node >= exec->nodeWorkgroupsPerCU.size()) {
-            exec->nodeWorkgroupsPerCU.resize(node + 1, 0u);
-        }
-        exec->nodeWorkgroupsPerCU[node] = (uint32_t)value;
-    }
-    return 0;
-}
-
-// ---------------------------------------------------------------------------
-// create / destroy
-// ---------------------------------------------------------------------------
-static void releaseLaunchGraph(LaunchGraph &lg);
-
 extern "C" int mwhip_create(const mwhip_state_config *cfg,
                             const mwhip_user_entry *entry, mwhip_exec **out)
 {
@@ -2828,10 +605,6 @@ extern "C" int mwhip_create(const mwhip_state_config *cfg,
     *out = raw;
     return 0;
 }
-
-#ifdef MADRONA_TRACING
-static void writeDeviceTrace(mwhip_exec *exec);
-#endif
 
 extern "C" void mwhip_destroy(mwhip_exec *exec)
 {
@@ -3007,713 +780,6 @@ static int topoSort(TaskGraphRec &tg)
     return 0;
 }
 
-// ---------------------------------------------------------------------------
-// launch graphs
-// ---------------------------------------------------------------------------
-// Launch list (grids sized from the tables' current capacities) + hipGraph.
-// The ray caster's launches for the tables as they are now (grids follow the
-// camera table's capacity: the kernels loop over the views that exist).
-static int renderLaunches(mwhip_exec *exec, std::vector<KernelLaunch> &out)
-{
-    const mwhip_render_layout &lay = exec->renderLayout;
-    auto column_of = [exec](uint32_t archetype, uint32_t component,
-                            uint32_t *out_col) -> int {
-        if (archetype >= exec->archetypes.size() ||
-                !exec->archetypes[archetype].registered) {
-            return fail(-3, "render layout: archetype %u is not registered",
-                        archetype);
-        }
-        const ArchetypeRec &arch = exec->archetypes[archetype];
-        for (uint32_t c = 2; c < arch.numColumns; c++) {
-            if (arch.colComponent[c] == component) {
-                *out_col = c;
-                return 0;
-            }
-        }
-        return fail(-3, "render layout: archetype %u has no component %u",
-                    archetype, component);
-    };
-
-    RenderParams params {};
-    params.layout = lay;
-    int rc = column_of(lay.renderable_archetype, lay.instance_component,
-                       &params.instanceColumn);
-    if (rc != 0) return rc;
-    rc = column_of(lay.renderable_archetype, lay.morton_component,
-                   &params.mortonColumn);
-    if (rc != 0) return rc;
-    rc = column_of(lay.renderable_archetype, lay.tlbvh_component,
-                   &params.tlbvhColumn);
-    if (rc != 0) return rc;
-    rc = column_of(lay.camera_archetype, lay.camera_component,
-                   &params.cameraColumn);
-    if (rc != 0) return rc;
-    rc = column_of(lay.light_archetype, lay.light_component, &params.lightColumn);
-    if (rc != 0) return rc;
-    rc = column_of(lay.output_archetype, lay.rgb_component, &params.rgbColumn);
-    if (rc != 0) return rc;
-    rc = column_of(lay.output_archetype, lay.depth_component,
-                   &params.depthColumn);
-    if (rc != 0) return rc;
-
-    const ArchetypeRec &inst = exec->archetypes[lay.renderable_archetype];
-    const ArchetypeRec &cams = exec->archetypes[lay.camera_archetype];
-    const ArchetypeRec &outs = exec->archetypes[lay.output_archetype];
-    const uint32_t res = exec->cfg.raycast_output_resolution;
-    if (inst.colBytes[params.instanceColumn] != 64 ||
-            inst.colBytes[params.tlbvhColumn] != 32 ||
-            cams.colBytes[params.cameraColumn] != 48 ||
-            exec->archetypes[lay.light_archetype].colBytes[params.lightColumn] != 40 ||
-            outs.colBytes[params.depthColumn] != res * res * 4u) {
-        return fail(-3, "render layout: component sizes are not those of "
-                    "madrona/render/ecs.hpp");
-    }
-
-    if (exec->tlasNodes == nullptr) {
-        // one node slot per instance row the table can ever hold (a world of n
-        // instances uses n - 1 of its n slots).  (The executor's, not the
-        // building graph's: every later render graph reuses them.)
-        std::vector<void *> *const saved_scope = t_allocScope;
-        t_allocScope = nullptr;
-        struct Restore {
-            mwhip_exec *e; std::vector<void *> *s;
-            ~Restore() { (void)e; t_allocScope = s; }
-        } restore { exec, saved_scope };
-        rc = devAllocT(exec, &exec->tlasNodes, inst.reservedCapacity, false);
-        if (rc != 0) return rc;
-        rc = devAllocT(exec, &exec->preparedInstances, inst.reservedCapacity,
-                       false);
-        if (rc != 0) return rc;
-    }
-
-    params.resolution = res;
-    params.rgbd = exec->cfg.raycast_rgbd;
-    params.tlasNodes = exec->tlasNodes;
-    params.prepared = exec->preparedInstances;
-    params.geometry = exec->renderGeometryDev;
-    // (any grid is correct: workgroups stride over the tiles of the views that
-    // exist; sized for the views the table held when the graph was built)
-    uint32_t views = cams.capacity;
-    if (lay.camera_archetype < exec->rowsAtGraphBuild.size()) {
-        views = std::max(exec->rowsAtGraphBuild[lay.camera_archetype], 16u);
-    }
-    // (the grid: one workgroup per view, at least six per CU -- see
-    // buildRenderLaunches)
-    int num_cus = 256;
-    (void)hipDeviceGetAttribute(&num_cus, hipDeviceAttributeMultiprocessorCount,
-                                exec->cfg.gpu_id);
-    // (per executor: its own device's CU count)
-    const uint32_t max_wgs = (uint32_t)std::max(num_cus, 1) * 6u;
-    buildRenderLaunches(exec->stateDev, params, exec->cfg.num_worlds, views,
-                        std::max(max_wgs, 1u), out);
-    return 0;
-}
-
-#ifdef MADRONA_TRACING
-// Marker launches (traceMarkKernel) around the kernels of a graph: called last,
-// when render / pack kernels have been spliced in.
-static int addTraceMarkers(mwhip_exec *exec, LaunchGraph &lg)
-{
-    {
-        using mwGPU::DeviceEvent;
-        auto mark = [&](DeviceEvent event, uint32_t node_id, uint32_t func_id,
-                        uint32_t invocations, uint32_t workgroups) {
-            KernelLaunch k;
-            k.fn = (const void *)&traceMarkKernel;
-            k.grid = dim3(1, 1, 1);
-            k.block = dim3(256, 1, 1);
-            k.setArgs(exec->stateDev, (uint32_t)event, node_id, func_id, invocations,
-                      workgroups);
-            k.name = "trace";
-            k.role = "mark";
-            k.kind = MWHIP_NODE_RECYCLE;
-            return k;
-        };
-        hipDeviceProp_t prop;
-        HIPCHK(hipGetDeviceProperties(&prop, exec->cfg.gpu_id));
-        std::vector<KernelLaunch> traced;
-        traced.push_back(mark(DeviceEvent::calibration,
-                              (uint32_t)prop.multiProcessorCount, 4u, 0u, 0u));
-        uint32_t node_id = 0;
-        for (const KernelLaunch &k : lg.launches) {
-            const std::string label =
-                k.role[0] != '\0' ? k.name + ":" + k.role : k.name;
-            uint32_t func_id = 0;
-            while (func_id < exec->traceNames.size() &&
-                   exec->traceNames[func_id] != label) {
-                func_id++;
-            }
-            if (func_id == exec->traceNames.size()) {
-                exec->traceNames.push_back(label);
-            }
-            const uint32_t workgroups = k.grid.x * k.grid.y * k.grid.z;
-            traced.push_back(mark(DeviceEvent::nodeStart, node_id, func_id,
-                workgroups * k.block.x * k.block.y * k.block.z, workgroups));
-            traced.push_back(k);
-            node_id++;
-        }
-        traced.push_back(mark(DeviceEvent::blockExit, node_id, 0u, 0u, 0u));
-        lg.launches = std::move(traced);
-    }
-    return 0;
-}
-#endif
-
-// the graph objects and the device memory the graph owns (the stream has been
-// waited for, or nothing of this graph is in flight)
-static void releaseLaunchGraph(LaunchGraph &lg)
-{
-    if (lg.graphExec) (void)hipGraphExecDestroy(lg.graphExec);
-    if (lg.graph) (void)hipGraphDestroy(lg.graph);
-    lg.graphExec = nullptr;
-    lg.graph = nullptr;
-    for (void *p : lg.ownedAllocations) {
-        (void)hipFree(p);
-    }
-    lg.ownedAllocations.clear();
-}
-
-// ParallelFor nodes that named the same dependencies -- the simulator's statement
-// that they do not depend on one another -- become ONE launch of the simulator's
-// group kernel (taskgraph.inl pforGroupKernel: blockIdx.y = the node): a launch
-// is ~4 us on this stack whatever it does, a group of k nodes saves k - 1 of
-// them.  Only nodes that cannot append rows (no row snapshot) and carry a body;
-// consecutive in the builder's order.  MADRONA_MWHIP_GROUP=0: every node its own
-// launch (rounds 1-4).
-static int groupLaunches(mwhip_exec *exec, LaunchGraph &lg)
-{
-    if (envU32("MADRONA_MWHIP_GROUP", 1) == 0 || exec->pforGroupKernel == nullptr ||
-            exec->eagerReplay) {
-        return 0;
-    }
-    // A member is reached through a function pointer: the shared kernel is
-    // compiled for the registers of the heaviest body in the module and a body
-    // runs out of line.  Row functions of a few loads and stores do not notice;
-    // a long one does (the portable lidar system, 121 VGPRs, next to
-    // collectObservations: step + 38 us, profiles/r05_group_variants.jsonl), so
-    // a node whose own kernel needs more than this many VGPRs keeps its launch.
-    const uint32_t max_vgprs = envU32("MADRONA_MWHIP_GROUP_MAX_VGPRS", 96);
-    auto groupable = [&](const KernelLaunch &k) {
-        return k.dagKernel && k.pforBody != nullptr && !k.rowSnapshot &&
-            k.pforVgprs <= max_vgprs &&
-            k.countMode == MWHIP_COUNT_QUERY_ROWS && k.tgNode >= 0 &&
-            k.tgId < exec->taskGraphs.size();
-    };
-    auto depsOf = [&](const KernelLaunch &k) {
-        std::vector<int32_t> d = exec->taskGraphs[k.tgId].nodes[(size_t)k.tgNode].deps;
-        std::sort(d.begin(), d.end());
-        d.erase(std::unique(d.begin(), d.end()), d.end());
-        return d;
-    };
-    // The reference runs same-dependency siblings one after the other, so a
-    // simulator may lean on registration order without saying so.  What the
-    // signatures show is checked here: two nodes do not share a launch when one
-    // may write (non-const reference) a component the other names, on a table
-    // both queries match.  (What a system reaches through ctx.get() is not in
-    // its signature: INTEGRATION.md section 3, MADRONA_MWHIP_GROUP=0.)
-    auto queryOf = [&](const KernelLaunch &k) -> const QueryRec * {
-        for (const QueryRec &q : exec->queries) {
-            if (q.offset == k.queryOffset) return &q;
-        }
-        return nullptr;
-    };
-    auto tablesOfQuery = [&](const QueryRec &q) {
-        std::vector<uint32_t> tables;
-        const uint32_t *p = exec->queryDataHost.data() + q.offset;
-        for (uint32_t m = 0; m < q.numMatching; m++) {
-            tables.push_back(p[0]);
-            p += 1 + q.comps.size();
-        }
-        return tables;
-    };
-    auto conflicts = [&](const KernelLaunch &a, const KernelLaunch &b) {
-        const QueryRec *qa = queryOf(a), *qb = queryOf(b);
-        if (qa == nullptr || qb == nullptr) return true;
-        bool shared_table = false;
-        const std::vector<uint32_t> tb = tablesOfQuery(*qb);
-        for (uint32_t t : tablesOfQuery(*qa)) {
-            shared_table = shared_table ||
-                std::find(tb.begin(), tb.end(), t) != tb.end();
-        }
-        if (!shared_table) return false;
-        for (size_t ia = 0; ia < qa->comps.size(); ia++) {
-            for (size_t ib = 0; ib < qb->comps.size(); ib++) {
-                if (qa->comps[ia] != qb->comps[ib]) continue;
-                const bool wa = ia >= 32 || ((a.pforWriteMask >> ia) & 1u) != 0u;
-                const bool wb = ib >= 32 || ((b.pforWriteMask >> ib) & 1u) != 0u;
-                if (wa || wb) return true;
-            }
-        }
-        return false;
-    };
-    std::vector<KernelLaunch> out;
-    for (size_t i = 0; i < lg.launches.size(); ) {
-        size_t j = i + 1;
-        if (groupable(lg.launches[i])) {
-            const std::vector<int32_t> deps = depsOf(lg.launches[i]);
-            while (j < lg.launches.size() && j - i < MWHIP_PFOR_GROUP_MAX &&
-                   groupable(lg.launches[j]) &&
-                   lg.launches[j].tgId == lg.launches[i].tgId &&
-                   depsOf(lg.launches[j]) == deps) {
-                bool clash = false;
-                for (size_t m = i; m < j; m++) {
-                    clash = clash || conflicts(lg.launches[m], lg.launches[j]);
-                }
-                if (clash) break;
-                j++;
-            }
-        }
-        if (j - i < 2) {
-            out.push_back(lg.launches[i]);
-            i = j;
-            continue;
-        }
-        mwhip_pfor_group group {};
-        group.count = (uint32_t)(j - i);
-        KernelLaunch g;
-        g.fn = exec->pforGroupKernel;
-        uint32_t threads = 0;
-        std::string name = "group[";
-        for (size_t m = i; m < j; m++) {
-            const KernelLaunch &k = lg.launches[m];
-            group.body[m - i] = k.pforBody;
-            group.query_offset[m - i] = k.queryOffset;
-            group.num_matching_and_flags[m - i] = k.pforArg1;
-            group.query[m - i] = k.pforArgs;
-            threads = std::max(threads, k.grid.x * k.block.x);
-            name += (m == i ? "" : " | ") + k.name;
-            g.members.push_back({ k.name, k.queryOffset, k.bytesPerRow, k.ioDeclared });
-        }
-        name += "]";
-        mwhip_pfor_group *group_dev = nullptr;
-        int rc = devAllocT(exec, &group_dev, 1);
-        if (rc != 0) return rc;
-        HIPCHK(hipMemcpy(group_dev, &group, sizeof(group), hipMemcpyHostToDevice));
-        g.grid = dim3(std::max((threads + 255u) / 256u, 1u), group.count, 1);
-        g.block = dim3(256, 1, 1);
-        g.setArgs(exec->stateDev, (const mwhip_pfor_group *)group_dev);
-        g.name = name;
-        g.role = "";
-        g.kind = MWHIP_NODE_KERNEL;
-        g.countMode = MWHIP_COUNT_QUERY_ROWS;
-        g.ioDeclared = 1;
-        for (const auto &mem : g.members) {
-            g.ioDeclared = g.ioDeclared && mem.ioDeclared != 0u ? 1u : 0u;
-        }
-        g.nodeIndex = lg.launches[i].nodeIndex;
-        // (waits for what its members named; everything that named a member
-        // waits for it: the group stands in the chain where its first member
-        // stood, the others were right behind it)
-        g.dagKernel = false;
-        out.push_back(g);
-        i = j;
-    }
-    lg.launches.swap(out);
-    return 0;
-}
-
-// Edges of the step's graph (KernelLaunch::deps): a chain in the builder's
-// topological order.  (Round 5 also built the task graph's real edges as
-// branches of the hipGraph and measured them slower than the chain on this
-// runtime -- configs[1] 141 -> 170 us per step, configs[2] 1.110 -> 1.190 ms,
-// profiles/r05_dag_variants.jsonl: a fork / join costs more than the launch
-// floors it overlaps.  Nodes that may run side by side share ONE launch instead,
-// groupLaunches.  The switch is gone since round 6.)
-static void buildLaunchDeps(LaunchGraph &lg)
-{
-    for (size_t i = 0; i < lg.launches.size(); i++) {
-        KernelLaunch &k = lg.launches[i];
-        k.deps.clear();
-        if (i > 0) {
-            k.deps.push_back((int32_t)i - 1);
-        }
-    }
-}
-
-static int instantiateLaunchGraph(mwhip_exec *exec,
-                                  const std::vector<uint32_t> &ids,
-                                  const std::string &stat_name,
-                                  std::unique_ptr<LaunchGraph> &out,
-                                  const LaunchGraph *pack_from = nullptr)
-{
-    std::unique_ptr<LaunchGraph> lg(new LaunchGraph {});
-    lg->statName = stat_name;
-    lg->taskGraphIds = ids;
-    struct ScopeOn {
-        mwhip_exec *e;
-        ScopeOn(mwhip_exec *x, std::vector<void *> *v) : e(x) { t_allocScope = v; }
-        ~ScopeOn() { (void)e; t_allocScope = nullptr; }
-    } scope_on(exec, &lg->ownedAllocations);
-
-    // (ParallelFor grids are sized from the rows the tables hold now, not from
-    // their capacities)
-    {
-        HIPCHK(hipStreamSynchronize(exec->stream));
-        std::vector<TableHdr> hdrs(exec->tablesHost.size());
-        HIPCHK(hipMemcpy(hdrs.data(), exec->hostState.tables,
-                         hdrs.size() * sizeof(TableHdr), hipMemcpyDeviceToHost));
-        exec->rowsAtGraphBuild.assign(hdrs.size(), 0);
-        for (size_t a = 0; a < hdrs.size(); a++) {
-            exec->rowsAtGraphBuild[a] =
-                (uint32_t)std::max(hdrs[a].numRows, 0);
-        }
-    }
-
-    lg->isRender = pack_from != nullptr && pack_from->isRender;
-    int rc = buildLaunchList(exec, ids, *lg);
-    if (rc != 0) return rc;
-
-    if (lg->isRender) {
-        // TLAS build + ray caster, before the health kernel
-        std::vector<KernelLaunch> render;
-        rc = renderLaunches(exec, render);
-        if (rc != 0) return rc;
-        lg->launches.insert(lg->launches.end() - 1, render.begin(), render.end());
-    }
-
-    if (pack_from != nullptr && pack_from->hasPack) {
-        lg->hasPack = true;
-        lg->pack = pack_from->pack;
-        lg->packDst = pack_from->packDst;
-
-        KernelLaunch k;
-        k.fn = (const void *)&packRowsKernel;
-        const uint64_t total =
-            (uint64_t)lg->pack.numRows * lg->pack.recordWords;
-        k.grid = dim3((uint32_t)std::min<uint64_t>(
-            std::max<uint64_t>((total + 255) / 256, 1), 4096), 1, 1);
-        k.block = dim3(256, 1, 1);
-        k.setArgs(lg->pack, (uint32_t *)lg->packDst);
-        k.name = "pack";
-        k.role = "pack.rows";
-        k.kind = MWHIP_NODE_RECYCLE;
-        // before the health kernel that closes every replay
-        lg->launches.insert(lg->launches.end() - 1, k);
-    }
-
-#ifdef MADRONA_TRACING
-    rc = addTraceMarkers(exec, *lg);
-    if (rc != 0) return rc;
-    // (a traced step logs kernel after kernel: no side-by-side launches)
-    for (KernelLaunch &k : lg->launches) {
-        k.dagKernel = false;
-    }
-#endif
-
-    rc = groupLaunches(exec, *lg);
-    if (rc != 0) return rc;
-    buildLaunchDeps(*lg);
-
-    // The step as an explicit hipGraph: one kernel node per launch, edges from
-    // buildLaunchDeps.  (Rounds 1-4 captured the launches from the stream: a
-    // chain, whatever the task graph said.)
-    HIPCHK(hipGraphCreate(&lg->graph, 0));
-    std::vector<hipGraphNode_t> nodes(lg->launches.size(), nullptr);
-    for (size_t i = 0; i < lg->launches.size(); i++) {
-        KernelLaunch &k = lg->launches[i];
-        void *args[8];
-        k.argPointers(args);
-        hipKernelNodeParams params {};
-        params.func = const_cast<void *>(k.fn);
-        params.gridDim = k.grid;
-        params.blockDim = k.block;
-        params.sharedMemBytes = k.dynamicLds;
-        params.kernelParams = args;
-        params.extra = nullptr;
-        std::vector<hipGraphNode_t> deps;
-        for (int32_t d : k.deps) {
-            deps.push_back(nodes[(size_t)d]);
-        }
-        HIPCHK(hipGraphAddKernelNode(&nodes[i], lg->graph, deps.data(),
-                                     deps.size(), &params));
-    }
-    HIPCHK(hipGraphInstantiate(&lg->graphExec, lg->graph, nullptr, nullptr, 0));
-    out = std::move(lg);
-    return 0;
-}
-
-// Table growth, between replays (the stream is idle).  A table whose live rows
-// fill more than half of its backed capacity gets more memory mapped behind
-// every column (primary and ping-pong twin) and behind its sort buffers --
-// addresses do not change --, the capacity in its device header is raised, and
-// the launch graphs are rebuilt so that grids follow the new size.  Half,
-// because rows destroyed and re-created in one step coexist until the step's
-// compaction; a single step that outruns the head room still raises
-// kErrTableOverflow, as a fixed-capacity table does.
-// rows_of(a) = live rows of archetype a, or -1.
-// Maps memory for `new_capacity` rows behind every column, twin and sort buffer
-// of archetype a (addresses do not change) and tells the device through the
-// mailbox.  The table's device header and the launch graphs are brought up to
-// date by refreshAfterGrowth(), with the stream idle.  Caller holds growMutex.
-static int mapTableRows(mwhip_exec *exec, uint32_t a, uint64_t new_capacity)
-{
-    ArchetypeRec &arch = exec->archetypes[a];
-    for (uint32_t c = 0; c < arch.numColumns; c++) {
-        size_t bytes = (size_t)new_capacity * arch.colBytes[c] + 16;
-        int rc = vmEnsure(exec, *arch.primaryVm[c], bytes, true);
-        if (rc != 0) return rc;
-        rc = vmEnsure(exec, *arch.altVm[c], bytes, true);
-        if (rc != 0) return rc;
-    }
-    for (VmRange *r : arch.sortVm) {
-        if (r != nullptr) {
-            int rc = vmEnsure(exec, *r, (size_t)new_capacity * 4, false);
-            if (rc != 0) return rc;
-        }
-    }
-    arch.capacity = (uint32_t)new_capacity;
-    exec->tablesHost[a].capacity = (int32_t)new_capacity;
-    if (exec->growMailbox != nullptr && a < kMaxArchetypes) {
-        __atomic_store_n(&exec->growMailbox->capacity[a], (int32_t)new_capacity,
-                         __ATOMIC_RELEASE);
-    }
-    exec->numGrowths++;
-    exec->headersStale = true;
-    if (getenv("MADRONA_MWHIP_DEBUG_GROWTH") != nullptr) {
-        fprintf(stderr, "madrona_amd: archetype %u now has %llu rows mapped\n",
-                a, (unsigned long long)new_capacity);
-    }
-    return 0;
-}
-
-// Service thread: answers the device's requests while a replay is running.
-static void serviceGrowRequests(mwhip_exec *exec)
-{
-    GrowMailbox *mb = exec->growMailbox;
-    if (mb == nullptr) return;
-    bool pending = false;
-    for (uint32_t a = 0; a < exec->archetypes.size() && a < kMaxArchetypes; a++) {
-        if (__atomic_load_n(&mb->requested[a], __ATOMIC_RELAXED) >
-                mb->capacity[a]) {
-            pending = true;
-            break;
-        }
-    }
-    for (uint32_t slot : { kGrowSlotEntities, kGrowSlotTmp }) {
-        if (__atomic_load_n(&mb->requested[slot], __ATOMIC_RELAXED) >
-                mb->capacity[slot]) {
-            pending = true;
-        }
-    }
-    if (!pending) return;
-
-    std::lock_guard<std::mutex> guard(exec->growMutex);
-    (void)hipSetDevice(exec->cfg.gpu_id);
-    {
-        const int64_t ids = __atomic_load_n(&mb->requested[kGrowSlotEntities],
-                                            __ATOMIC_RELAXED);
-        if (ids > mb->capacity[kGrowSlotEntities] && exec->entityVm != nullptr) {
-            // a layer of run-time blocks (one per world) at least
-            (void)growEntityStore(exec, std::max<uint64_t>(
-                2ull * (uint64_t)ids, 2ull * (uint64_t)exec->hostState.entityCapacity));
-        }
-        const int64_t kib = __atomic_load_n(&mb->requested[kGrowSlotTmp],
-                                            __ATOMIC_RELAXED);
-        if (kib > mb->capacity[kGrowSlotTmp] && exec->tmpVm != nullptr) {
-            (void)growTmpRegion(exec, std::max<uint64_t>(
-                2ull * ((uint64_t)kib << 10), 2ull * exec->hostState.tmpCapacity));
-        }
-    }
-    for (uint32_t a = 0; a < exec->archetypes.size() && a < kMaxArchetypes; a++) {
-        ArchetypeRec &arch = exec->archetypes[a];
-        const int64_t wanted = __atomic_load_n(&mb->requested[a], __ATOMIC_RELAXED);
-        if (!arch.registered || wanted <= (int64_t)arch.capacity ||
-                arch.reservedCapacity <= arch.capacity) {
-            continue;
-        }
-        uint64_t new_capacity = std::max<uint64_t>(2ull * arch.capacity,
-                                                   2ull * (uint64_t)wanted);
-        new_capacity = std::min<uint64_t>(new_capacity, arch.reservedCapacity);
-        if (getenv("MADRONA_MWHIP_DEBUG_GROWTH") != nullptr) {
-            fprintf(stderr, "madrona_amd: on-demand growth of archetype %u: "
-                    "%u -> %llu rows (wanted %lld)\n", a, arch.capacity,
-                    (unsigned long long)new_capacity, (long long)wanted);
-        }
-        if (mapTableRows(exec, a, new_capacity) != 0) {
-            if (getenv("MADRONA_MWHIP_DEBUG_GROWTH") != nullptr) {
-                fprintf(stderr, "madrona_amd: mapping failed: %s\n",
-                        g_lastError.c_str());
-            }
-            // the waiting threads time out and raise the overflow flag
-            return;
-        }
-    }
-}
-
-template <typename RowsFn>
-static int growTables(mwhip_exec *exec, RowsFn &&rows_of)
-{
-    // Anything to do?  If so the stream is drained BEFORE the lock is taken for
-    // the work: a replay in flight may be waiting for the service thread, which
-    // needs the same lock.
-    auto wants_growth = [&](uint32_t a) {
-        const ArchetypeRec &arch = exec->archetypes[a];
-        if (!arch.registered || arch.reservedCapacity <= arch.capacity) {
-            return false;
-        }
-        int64_t rows = rows_of(a);
-        return rows >= 0 && 2 * rows > (int64_t)arch.capacity;
-    };
-    {
-        std::lock_guard<std::mutex> peek(exec->growMutex);
-        bool needed = exec->headersStale;
-        for (uint32_t a = 0; a < exec->archetypes.size() && !needed; a++) {
-            needed = wants_growth(a);
-        }
-        if (!needed) {
-            return 0;
-        }
-    }
-    HIPCHK(hipStreamSynchronize(exec->stream));
-
-    std::lock_guard<std::mutex> guard(exec->growMutex);
-    bool grew = exec->headersStale;
-    for (uint32_t a = 0; a < exec->archetypes.size(); a++) {
-        ArchetypeRec &arch = exec->archetypes[a];
-        if (!arch.registered || arch.reservedCapacity <= arch.capacity) {
-            continue;
-        }
-        int64_t rows = rows_of(a);
-        if (rows < 0 || 2 * rows <= (int64_t)arch.capacity) {
-            continue;
-        }
-
-        uint64_t new_capacity = std::max<uint64_t>(2ull * arch.capacity,
-                                                   3ull * (uint64_t)rows);
-        new_capacity = std::min<uint64_t>(new_capacity, arch.reservedCapacity);
-        int rc = mapTableRows(exec, a, new_capacity);
-        if (rc != 0) return rc;
-        grew = true;
-    }
-
-    if (!grew) {
-        return 0;
-    }
-
-    // device headers follow what is mapped (also after on-demand growth by the
-    // service thread), then the graphs are rebuilt for the new sizes
-    for (uint32_t a = 0; a < exec->archetypes.size(); a++) {
-        const ArchetypeRec &arch = exec->archetypes[a];
-        if (!arch.registered) continue;
-        int32_t cap = (int32_t)arch.capacity;
-        HIPCHK(hipMemcpy((char *)(exec->hostState.tables + a) +
-                             offsetof(TableHdr, capacity),
-                         &cap, sizeof(cap), hipMemcpyHostToDevice));
-    }
-    {
-        int rc = pokeState(exec, &EcsState::entityCapacity,
-                           exec->hostState.entityCapacity);
-        if (rc != 0) return rc;
-        rc = pokeState(exec, &EcsState::tmpCapacity, exec->hostState.tmpCapacity);
-        if (rc != 0) return rc;
-    }
-    exec->headersStale = false;
-
-    for (auto &kv : exec->launchGraphs) {
-        std::unique_ptr<LaunchGraph> fresh;
-        int rc = instantiateLaunchGraph(exec, kv.second->taskGraphIds,
-                                        kv.second->statName, fresh,
-                                        kv.second.get());
-        if (rc != 0) return rc;
-        releaseLaunchGraph(*kv.second);
-        kv.second = std::move(fresh);
-    }
-    return 0;
-}
-
-// row counts read back from the device's table headers
-static int growTablesFromDevice(mwhip_exec *exec)
-{
-    HIPCHK(hipStreamSynchronize(exec->stream));
-    std::vector<TableHdr> hdrs(exec->tablesHost.size());
-    HIPCHK(hipMemcpy(hdrs.data(), exec->hostState.tables,
-                     hdrs.size() * sizeof(TableHdr), hipMemcpyDeviceToHost));
-    return growTables(exec, [&hdrs](uint32_t a) -> int64_t {
-        return a < hdrs.size() ? hdrs[a].numRows : -1;
-    });
-}
-
-// A table sorted by the single-launch path has grown past half of what that
-// path is meant for: its graphs are rebuilt with the chain (the single launch
-// stays correct at any size, it is just one workgroup).
-static int sortsOutgrown(mwhip_exec *exec)
-{
-    bool rebuild = false;
-    // a table whose appended tails keep exceeding what the compaction chain's
-    // one workgroup sorts quickly goes back to the radix chain
-    for (uint32_t a = 0; a < exec->archetypes.size() && a < kMaxArchetypes; a++) {
-        ArchetypeRec &arch = exec->archetypes[a];
-        if (!arch.registered || arch.noCompact || exec->sortCompaction != 1) continue;
-        if ((uint32_t)std::max(exec->statsHost[kStatsTails + a], 0) >
-                sortCompactTailLimit()) {
-            exec->statsHost[kStatsTails + a] = 0;   // (counted once per report)
-            if (++arch.longTails >= 3u) {
-                arch.noCompact = true;
-                rebuild = true;
-            }
-        }
-    }
-    for (auto &kv : exec->launchGraphs) {
-        for (const auto &batch : kv.second->sortBatches) {
-            if (!batch->small) continue;
-            for (const SortSiteHost &site : batch->sites) {
-                int64_t rows = site.archetype < kMaxArchetypes ?
-                    exec->statsHost[kStatsRows + site.archetype] : 0;
-                ArchetypeRec &arch = exec->archetypes[site.archetype];
-                if (rows * 2 > (int64_t)sortSmallRowLimit() && !arch.bigSort) {
-                    arch.bigSort = true;
-                    rebuild = true;
-                }
-                // One workgroup moving a few thousand rows is slower than the
-                // compaction chain's three launches (8192 Escape-Room worlds,
-                // ~2 K joints re-sorted every step: 50 us against 27); the one
-                // launch wins while the table is tiny or mostly idle (4 us
-                // against 3 x 4 when nothing changed).  Three reports in a
-                // row above the mark move a world-sorted table to the chain.
-                // (One launch on 16-32 workgroups -- every workgroup ordering
-                // all keys in LDS, then moving its share -- was built in round 4
-                // and measured at 29 us: the device-scope hand-off between the
-                // workgroups costs more than the launches it saves.  Removed in
-                // round 5; profiles/r04_sort_variants.jsonl.)
-                if (!arch.bigSort && site.worldSort &&
-                        compactionEligible(exec, site.archetype, 1u) &&
-                        rows >= (int64_t)sortSmallBusyRows()) {
-                    if (++arch.smallBusy >= 3u) {
-                        arch.bigSort = true;
-                        rebuild = true;
-                    }
-                } else {
-                    arch.smallBusy = 0;
-                }
-            }
-        }
-    }
-    if (!rebuild) {
-        return 0;
-    }
-    HIPCHK(hipStreamSynchronize(exec->stream));
-    for (auto &kv : exec->launchGraphs) {
-        std::unique_ptr<LaunchGraph> fresh;
-        int rc = instantiateLaunchGraph(exec, kv.second->taskGraphIds,
-                                        kv.second->statName, fresh,
-                                        kv.second.get());
-        if (rc != 0) return rc;
-        releaseLaunchGraph(*kv.second);
-        kv.second = std::move(fresh);
-    }
-    return 0;
-}
-
-// row counts the last completed replay reported (statsKernel)
-static int growTablesAfterReplay(mwhip_exec *exec)
-{
-    int rc = growTables(exec, [exec](uint32_t a) -> int64_t {
-        return a < kMaxArchetypes ? exec->statsHost[kStatsPeaks + a] : -1;
-    });
-    if (rc != 0) return rc;
-    return sortsOutgrown(exec);
-}
-
 extern "C" int mwhip_build_launch_graph(mwhip_exec *exec,
                                         const uint32_t *taskgraph_ids,
                                         uint32_t num_taskgraphs,
@@ -3800,81 +866,6 @@ extern "C" void mwhip_free_launch_graph(mwhip_exec *exec, uint64_t graph)
     releaseLaunchGraph(*it->second);
     exec->launchGraphs.erase(it);
 }
-
-#ifdef MADRONA_TRACING
-// The step that just completed -> exec->traceLogs (the first 100 steps, like the
-// reference's DeviceTracingManager, cuda_exec.cpp:204-257), with a nodeFinish
-// record per kernel: its latest blockWait.
-static int collectDeviceTrace(mwhip_exec *exec)
-{
-    using mwGPU::DeviceEvent;
-    using Log = mwGPU::DeviceTracing::DeviceLog;
-    if (exec->deviceTracing == nullptr || exec->traceSteps >= 100u) return 0;
-    int32_t count = 0;
-    HIPCHK(hipMemcpy(&count, exec->deviceTracing, sizeof(count), hipMemcpyDeviceToHost));
-    if (count <= 0) return 0;       // nothing logged, or the step overflowed
-    count = std::min<int32_t>(count, (int32_t)mwGPU::DeviceTracing::maxLogSize);
-    std::vector<Log> step((size_t)count);
-    HIPCHK(hipMemcpy(step.data(),
-        (const char *)exec->deviceTracing + offsetof(mwGPU::DeviceTracing, device_logs_),
-        step.size() * sizeof(Log), hipMemcpyDeviceToHost));
-    // (slots reserved for a kernel whose workgroups log nothing)
-    step.erase(std::remove_if(step.begin(), step.end(), [](const Log &l) {
-        return (uint32_t)l.event == mwGPU::DeviceTracing::unusedSlot;
-    }), step.end());
-    // a step begins with the calibration record: slot 0 of the log
-    for (size_t i = 0; i < step.size(); i++) {
-        step[i].padding = (uint32_t)i;
-    }
-    std::vector<Log> finish;
-    for (const Log &l : step) {
-        if (l.event == DeviceEvent::nodeStart) {
-            if (finish.size() <= l.nodeID) finish.resize(l.nodeID + 1, Log {});
-            Log f = l;      // (a kernel whose workgroups log nothing: zero length)
-            f.event = DeviceEvent::nodeFinish;
-            finish[l.nodeID] = f;
-        }
-    }
-    for (const Log &l : step) {
-        if (l.event == DeviceEvent::blockWait && l.nodeID < finish.size() &&
-                l.cycleCount >= finish[l.nodeID].cycleCount) {
-            Log &f = finish[l.nodeID];
-            f.cycleCount = l.cycleCount;
-            f.smID = l.smID;
-            f.warpID = l.warpID;
-            f.blockID = l.blockID;
-        }
-    }
-    uint32_t next = (uint32_t)step.size();
-    for (Log &f : finish) {
-        if (f.event != DeviceEvent::nodeFinish) continue;
-        f.padding = next++;
-        step.push_back(f);
-    }
-    exec->traceLogs.insert(exec->traceLogs.end(), step.begin(), step.end());
-    exec->traceSteps++;
-    // (until the next traced graph starts its step)
-    const int32_t off = -1;
-    HIPCHK(hipMemcpy(exec->deviceTracing, &off, sizeof(off), hipMemcpyHostToDevice));
-    return 0;
-}
-
-static void writeDeviceTrace(mwhip_exec *exec)
-{
-    if (exec->traceLogs.empty()) return;
-    const char *dir = getenv("MADRONA_MWHIP_TRACE_DIR");
-    const std::string path = dir != nullptr ? std::string(dir) + "/" : "/tmp/";
-    ::madrona::WriteToFile<mwGPU::DeviceTracing::DeviceLog>(
-        exec->traceLogs.data(), exec->traceLogs.size(), path,
-        "_madrona_device_tracing");
-    std::string names;
-    for (const std::string &n : exec->traceNames) {
-        names += n + "\n";
-    }
-    ::madrona::WriteToFile((void *)names.data(), names.size(), path,
-                           "_madrona_device_tracing_nodes");
-}
-#endif
 
 static int checkHealth(mwhip_exec *exec)
 {
@@ -4151,8 +1142,10 @@ extern "C" int mwhip_pack_rows(mwhip_exec *exec, uint32_t num_columns,
     const uint32_t blocks =
         (uint32_t)std::min<uint64_t>((total + 255) / 256, 4096);
     HIPCHK(hipSetDevice(exec->cfg.gpu_id));
-    hipLaunchKernelGGL(packRowsKernel, dim3(blocks), dim3(256), 0, exec->stream,
-                       args, (uint32_t *)dst);
+    uint32_t *dst_words = (uint32_t *)dst;
+    void *pack_args[] = { &args, &dst_words };
+    HIPCHK(hipLaunchKernel(packRowsKernelFn(), dim3(blocks), dim3(256), pack_args,
+                           0, exec->stream));
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -4160,8 +1153,10 @@ extern "C" int mwhip_pack_rows(mwhip_exec *exec, uint32_t num_columns,
 extern "C" int mwhip_mark_window(mwhip_exec *exec, uint32_t id)
 {
     HIPCHK(hipSetDevice(exec->cfg.gpu_id));
-    hipLaunchKernelGGL(benchWindowMarker, dim3(1), dim3(64), 0, exec->stream,
-                       (uint32_t *)nullptr, id);
+    uint32_t *no_signal = nullptr;
+    void *mark_args[] = { &no_signal, &id };
+    HIPCHK(hipLaunchKernel(benchWindowMarkerFn(), dim3(1), dim3(64), mark_args, 0,
+                           exec->stream));
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -4405,7 +1400,7 @@ extern "C" int32_t mwhip_profile(mwhip_exec *exec, uint64_t graph, uint32_t reps
             HIPCHK(hipHostGetDevicePointer((void **)&gate_dev,
                 (void *)(exec->statsHost + kStatsGate), 0));
             void *gargs[] = { &gate_dev };
-            HIPCHK(hipLaunchKernel((const void *)&gateKernel, dim3(1), dim3(64),
+            HIPCHK(hipLaunchKernel(gateKernelFn(), dim3(1), dim3(64),
                                    gargs, 0, exec->stream));
         }
         for (size_t i = 0; i < n; i++) {
@@ -4564,3 +1559,4 @@ extern "C" int32_t mwhip_profile(mwhip_exec *exec, uint64_t graph, uint32_t reps
     }
     return (int32_t)n;
 }
+
