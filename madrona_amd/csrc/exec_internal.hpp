@@ -229,7 +229,9 @@ struct LaunchGraph {
 // Where devAlloc records what it hands out while THIS thread builds a launch
 // graph (the graph then owns the memory); another thread's allocations stay with
 // their executor.
-extern MWHIP_RT thread_local std::vector<void *> *t_allocScope;   // (runtime_state.hip)
+// (__thread: no dynamic initialisation, so no TLS init function to call from the
+// other translation units)
+extern MWHIP_RT __thread std::vector<void *> *t_allocScope;   // (runtime_state.hip)
 
 struct mwhip_exec {
     mwhip_state_config cfg {};

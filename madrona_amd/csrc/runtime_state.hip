@@ -13,7 +13,7 @@
 // ---- this translation unit: device memory and state, world construction, table / entity
 // store / scratch growth and its service thread, host prints, device traces ----
 
-thread_local std::vector<void *> *t_allocScope = nullptr;
+__thread std::vector<void *> *t_allocScope = nullptr;
 
 MWHIP_RT int devAlloc(mwhip_exec *exec, void **out, size_t bytes, bool zero)
 {

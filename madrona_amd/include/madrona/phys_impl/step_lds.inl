@@ -987,6 +987,10 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
 
     for (int32_t job = (int32_t)blockIdx.x; job < num_jobs;
          job += (int32_t)gridDim.x) {
+    // (raising the priority of the wavefronts at the head of the order -- the
+    // heaviest worlds -- over the wavefront they share a SIMD with moves nothing:
+    // 522-529 us for the heaviest half / quarter / eighth against 522-527,
+    // profiles/r06_prio_variants.jsonl)
     do {
         const int32_t order_slot = job * worlds_per_wave + group;
         if (order_slot >= num_worlds) {
