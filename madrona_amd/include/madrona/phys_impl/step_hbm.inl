@@ -103,6 +103,10 @@ __device__ inline uint32_t constraintLevels(uint32_t lane, uint32_t n,
 }
 
 // (32-bit keys: body indices inside an LDS-resident world)
+// (Round 6 also built the levels without this chain of dependent shuffles --
+// conflict masks in n independent rounds, then one ballot per level -- and
+// measured no difference at two wavefronts per SIMD: 525-530 us against
+// 524-526, profiles/r06_levels_variants.jsonl.  Not kept.)
 template <int LPW = 64>
 __device__ inline uint32_t constraintLevels(uint32_t lane, uint32_t n,
                                             uint32_t key_a, uint32_t key_b)

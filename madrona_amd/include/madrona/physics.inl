@@ -1579,6 +1579,10 @@ __device__ inline void rebuildTreeStaged(broadphase::BVH &bvh, uint32_t lane,
 // instead of in a launch of its own with the chip idle.  The staging costs
 // 14 KB of LDS (11 wavefronts per CU instead of 32); setupPostIntegrationTasks
 // has no rebuild behind it and takes the plain variant (no LDS).
+// (86 registers: five wavefronts per SIMD.  Capped at 64 for eight -- every world
+// resident at once -- it spills 26 dwords and takes 32.6 us instead of 21.4:
+// profiles/r06_refresh_variants.jsonl.  The node is bound by its scattered
+// bytes, not by wavefronts in flight.)
 template <bool WithRebuild>
 __global__ void __launch_bounds__(64)
 bvhRefreshKernel(EcsState *S, void *, uint32_t, uint32_t)
