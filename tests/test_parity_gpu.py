@@ -146,6 +146,32 @@ def test_one_crowded_world_falls_back_to_the_hbm_step(built, monkeypatch, worlds
         assert counts[crowded] == 14 + 150 and counts.sum() == 14 * worlds + 150
 
 
+def test_a_world_with_more_movable_bodies_than_solver_slots_falls_back(built):
+    """Round 6: the two-worlds-per-wavefront block keeps solver records for 20 of
+    a world's 32 bodies (an inert static body's records are its pose).  ball_pit
+    with ONE world of 14 + 12 movable bodies (30 rigid bodies: it fits the
+    32-body block) among worlds of 14: the world is listed and stepped by the
+    HBM kernel in the same step, its partner in the wavefront stays.  Lock step
+    with the reference."""
+    _need_ref("ball_pit")
+    worlds, crowded, extra = 128, 5, 12
+    flags = (1 << 26) | (crowded << 27) | (extra << 16)
+    probs, step = run_pair("ball_pit", worlds, 60, flags=flags, check_every=5,
+                           check_init=False, ref_workers=0)
+    assert not probs, (step, probs[:3])
+    with Simulator(hip_lib_path("ball_pit"), worlds, flags=flags) as s:
+        s.step(10)
+        counts = s.dump_all()["MovableObject.Position"][1]
+        assert counts[crowded] == 14 + extra and counts.max() == 14 + extra
+        stats = {k["name"]: k for k in s.profile(2)}
+        assert "physics:worldStep(LDS)" in stats and \
+            "physics:worldStep(fallback)" in stats, list(stats)
+        # (an empty fallback list costs the launch its floor, ~4 us: this one
+        # steps a 30-body world out of HBM)
+        assert stats["physics:worldStep(fallback)"]["avg_us"] > 20.0, \
+            stats["physics:worldStep(fallback)"]
+
+
 @pytest.mark.parametrize("cap,lanes", [("20", ""), ("1", ""), ("20", "64")])
 def test_contacts_beyond_the_lds_block_fall_back(built, monkeypatch, cap, lanes):
     """The other capacity of the LDS block: more contacts in a substep than it
