@@ -901,6 +901,9 @@ __device__ __attribute__((always_inline)) inline FramedWorld loadWorldFramed(
 #else
 #define MADRONA_PHYS_VGPR_CAP
 #endif
+#ifndef MADRONA_PHYS_LDS_MESH
+#define MADRONA_PHYS_LDS_MESH false
+#endif
 template <int MAXB, int LPW = 64>
 __global__ void __launch_bounds__(64) MADRONA_PHYS_VGPR_CAP
 __attribute__((amdgpu_waves_per_eu(
@@ -927,6 +930,17 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
     Block *w = &blocks[group];
     LdsBodyStore<MAXB, LPW> store { w };
 
+#ifdef MADRONA_PHYS_PROFILE_LDS
+    // (the phase profile of a build that keeps its registers: the accumulators
+    // sit in what the block leaves of the workgroup's LDS, one ds_add per mark)
+    __shared__ uint32_t prof_lds[worlds_per_wave][16];
+    if (lane < 16u) prof_lds[group][lane] = 0u;
+    unsigned long long prof_t = __builtin_readcyclecounter();
+#undef PHYS_PROF
+#define PHYS_PROF(slot) do { unsigned long long now_ = __builtin_readcyclecounter(); \
+        if (lane == 0u) atomicAdd(&prof_lds[group][slot], (uint32_t)(now_ - prof_t)); \
+        prof_t = now_; } while (0)
+#endif
 #ifdef MADRONA_PHYS_PROFILE
     unsigned long long prof_t = __builtin_readcyclecounter();
     unsigned long long prof_acc[32] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
@@ -999,6 +1013,13 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
         const int32_t world = world_order[order_slot];
         const long long cost_t0 = (long long)wall_clock64();
         uint32_t cost_work = 1;    // (what the world asked of the wavefront, roughly)
+#ifdef MADRONA_PHYS_WAVELOG
+        // (measurement builds, profiles/tools/phys_wave_log.py: what the order
+        // kernel believed of this world against what it took)
+        const uint32_t wavelog_predicted = params.worldCost[world];
+        uint32_t wavelog_hull_pairs = 0, wavelog_contacts = 0;
+        uint32_t wavelog_iters_max = 0, wavelog_iters_shared = 0;
+#endif
 
         // ---- the world through the frame: HBM -> LDS in five rounds ---------
         LaneBodies<chunks> mine;
@@ -1311,7 +1332,7 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                          first += Scratch::polyRows) {
                         if (kind == 1 && solo_rank >= first &&
                                 solo_rank < first + Scratch::polyRows) {
-                            has_contact = collidePairLane(pair,
+                            has_contact = collidePairLane<MADRONA_PHYS_LDS_MESH>(pair,
                                 w->scratch.lanePoly() +
                                     (solo_rank - first) * Scratch::polyDwords,
                                 stage + lane, &too_big, &unsupported,
@@ -1325,6 +1346,30 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                 PHYS_PROF(3);
                 uint64_t hull_pairs = wave::groupBallot<LPW>(kind == 2);
                 cost_work += 24u * (uint32_t)__builtin_popcountll(hull_pairs);
+#ifdef MADRONA_PHYS_WAVELOG
+                wavelog_hull_pairs += (uint32_t)__builtin_popcountll(hull_pairs);
+                {
+                    // (hull-hull rounds of the wavefront: each half its own pairs,
+                    // against the halves sharing them out)
+                    const uint64_t all = __builtin_amdgcn_ballot_w64(kind == 2);
+                    const uint32_t na = (uint32_t)__builtin_popcountll(all & 0xFFFFFFFFull);
+                    const uint32_t nb = (uint32_t)__builtin_popcountll(all >> 32);
+                    wavelog_iters_max += na > nb ? na : nb;
+                    wavelog_iters_shared += (na + nb + 1u) / 2u;
+                }
+#endif
+#ifdef MADRONA_PHYS_PROFILE_LDS
+                {
+                    const uint64_t solo_pairs = wave::groupBallot<LPW>(kind == 1);
+                    if (lane == 0u) {
+                        atomicAdd(&prof_lds[group][12],
+                                  (uint32_t)__builtin_popcountll(hull_pairs));
+                        atomicAdd(&prof_lds[group][14],
+                                  (uint32_t)__builtin_popcountll(solo_pairs));
+                        atomicAdd(&prof_lds[group][15], width);
+                    }
+                }
+#endif
 #ifdef MADRONA_PHYS_PROFILE
                 // (event counts next to the cycle counters: lane 0 of a world)
                 {
@@ -1347,7 +1392,8 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                     PairSetup shared_pair =
                         ldsSetupPair(w, obj_mgr, candidateAt(chunk + src));
                     // every lane writes the same contact to src's slot
-                    const bool found = hullHullWave<LPW>(lane, shared_pair,
+                    const bool found = hullHullWave<LPW, HullScratch, PackedContact,
+                                                    MADRONA_PHYS_LDS_MESH>(lane, shared_pair,
                         w->scratch.hull(), stage + src, &pair_too_big,
                         PHYS_HH_PROF());
                     // the lane that owns the candidate learns the outcome
@@ -1360,6 +1406,11 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
 #ifdef MADRONA_PHYS_PROFILE
                     if (lane == 0) {
                         prof_acc[13] += outcome & 1u;
+                    }
+#endif
+#ifdef MADRONA_PHYS_PROFILE_LDS
+                    if (lane == 0u) {
+                        atomicAdd(&prof_lds[group][13], outcome & 1u);
                     }
 #endif
                 }
@@ -1418,6 +1469,9 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                 break;
             }
             cost_work += 8u * num_contacts;
+#ifdef MADRONA_PHYS_WAVELOG
+            wavelog_contacts += num_contacts;
+#endif
             wave::phaseFence();
             PHYS_PROF(5);
 
@@ -1581,10 +1635,32 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
             if (lane == 0) {
                 params.worldCost[world] = cost;
             }
+#ifdef MADRONA_PHYS_WAVELOG
+            if (lane == 0 && S->moduleData[1] != nullptr) {
+                uint32_t *rec = (uint32_t *)S->moduleData[1] + 8 * (size_t)world;
+                rec[0] = (uint32_t)job;
+                rec[1] = wavelog_predicted;
+                rec[2] = wavelog_iters_max | (wavelog_iters_shared << 16);
+                rec[3] = (uint32_t)((long long)wall_clock64() - cost_t0);
+                rec[4] = (uint32_t)((unsigned long long)cost_t0 & 0xFFFFFFFFull);
+                rec[5] = num_candidates | ((uint32_t)num_bodies << 16);
+                rec[6] = wavelog_hull_pairs | (wavelog_contacts << 16);
+                rec[7] = cost;
+            }
+#endif
         }
     } while (false);
     }
 
+#ifdef MADRONA_PHYS_PROFILE_LDS
+    wave::phaseFence();
+    if (lane < 16u && S->moduleData[1] != nullptr) {
+        atomicAdd(&((unsigned long long *)S->moduleData[1])[lane],
+                  (unsigned long long)prof_lds[group][lane]);
+    }
+#undef PHYS_PROF
+#define PHYS_PROF(slot) do {} while (0)
+#endif
 #ifdef MADRONA_PHYS_PROFILE
     if (lane == 0 && S->moduleData[1] != nullptr) {
         unsigned long long *dst = (unsigned long long *)S->moduleData[1];

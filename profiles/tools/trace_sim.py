@@ -4,7 +4,7 @@ for N steps with a fresh action set every step, so that the executor writes its
 device event log on exit:  trace_sim.py SIM WORLDS AGENTS STEPS"""
 import sys
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))))
 import torch
 from madrona_amd.simlib import Simulator, hip_lib_path
 
