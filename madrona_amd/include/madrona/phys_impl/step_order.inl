@@ -24,10 +24,27 @@ physicsOrderKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
     __shared__ uint32_t wave_max[16];
     __shared__ uint32_t most_shared;
 
+    // (up to 8192 worlds: a thread's costs stay in its registers -- the two
+    // later passes would each wait for the same loads again)
+    constexpr int32_t kept_costs = 8;
+    const bool costs_kept = num_worlds <= kept_costs * 1024;
+    uint32_t kept[kept_costs];
     uint32_t most = 0;
-    for (int32_t w = (int32_t)tid; w < num_worlds; w += 1024) {
-        const uint32_t c = params.worldCost[w];
-        most = c > most ? c : most;
+    if (costs_kept) {
+#pragma unroll
+        for (int32_t i = 0; i < kept_costs; i++) {
+            const int32_t w = i * 1024 + (int32_t)tid;
+            kept[i] = w < num_worlds ? params.worldCost[w] : 0u;
+        }
+#pragma unroll
+        for (int32_t i = 0; i < kept_costs; i++) {
+            most = kept[i] > most ? kept[i] : most;
+        }
+    } else {
+        for (int32_t w = (int32_t)tid; w < num_worlds; w += 1024) {
+            const uint32_t c = params.worldCost[w];
+            most = c > most ? c : most;
+        }
     }
     most = wave::maxReduce<64>(most);
     if (tid < 256) hist[tid] = 0;
@@ -41,11 +58,29 @@ physicsOrderKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
     __syncthreads();
     most = most_shared;
 
-    auto bucket_of = [most](uint32_t cost) {
-        return 255u - (uint32_t)(((uint64_t)cost * 255ull) / most);
+    // 256 buckets, heaviest first: any function of the cost that never
+    // decreases will do (the order only decides when a world is stepped), so
+    // no 64-bit division per world -- costs shifted down to 24 bits, one
+    // multiplication by 255 / most
+    const uint32_t cost_shift = most >= (1u << 24) ?
+        8u - (uint32_t)__builtin_clz(most) : 0u;
+    const float to_bucket = 255.f / (float)(most >> cost_shift);
+    auto bucket_of = [cost_shift, to_bucket](uint32_t cost) {
+        const uint32_t b = (uint32_t)((float)(cost >> cost_shift) * to_bucket);
+        return 255u - (b < 255u ? b : 255u);
     };
-    for (int32_t w = (int32_t)tid; w < num_worlds; w += 1024) {
-        atomicAdd(&hist[bucket_of(params.worldCost[w])], 1u);
+    if (costs_kept) {
+#pragma unroll
+        for (int32_t i = 0; i < kept_costs; i++) {
+            kept[i] = bucket_of(kept[i]);       // (from here on: its bucket)
+            if (i * 1024 + (int32_t)tid < num_worlds) {
+                atomicAdd(&hist[kept[i]], 1u);
+            }
+        }
+    } else {
+        for (int32_t w = (int32_t)tid; w < num_worlds; w += 1024) {
+            atomicAdd(&hist[bucket_of(params.worldCost[w])], 1u);
+        }
     }
     __syncthreads();
     // exclusive scan of the 256 buckets by the first four wavefronts (one thread
@@ -68,9 +103,20 @@ physicsOrderKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
         }
     }
     __syncthreads();
-    for (int32_t w = (int32_t)tid; w < num_worlds; w += 1024) {
-        const uint32_t at = atomicAdd(&hist[bucket_of(params.worldCost[w])], 1u);
-        params.worldOrder[at] = w;
+    if (costs_kept) {
+#pragma unroll
+        for (int32_t i = 0; i < kept_costs; i++) {
+            const int32_t w = i * 1024 + (int32_t)tid;
+            if (w < num_worlds) {
+                const uint32_t at = atomicAdd(&hist[kept[i]], 1u);
+                params.worldOrder[at] = w;
+            }
+        }
+    } else {
+        for (int32_t w = (int32_t)tid; w < num_worlds; w += 1024) {
+            const uint32_t at = atomicAdd(&hist[bucket_of(params.worldCost[w])], 1u);
+            params.worldOrder[at] = w;
+        }
     }
 }
 
