@@ -901,9 +901,6 @@ __device__ __attribute__((always_inline)) inline FramedWorld loadWorldFramed(
 #else
 #define MADRONA_PHYS_VGPR_CAP
 #endif
-#ifndef MADRONA_PHYS_LDS_MESH
-#define MADRONA_PHYS_LDS_MESH false
-#endif
 template <int MAXB, int LPW = 64>
 __global__ void __launch_bounds__(64) MADRONA_PHYS_VGPR_CAP
 __attribute__((amdgpu_waves_per_eu(
@@ -967,7 +964,12 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
     // wavefronts taking jobs from a counter with the next world's header
     // fetched ahead, +- 0; world images packed by a kernel of their own,
     // + 21 us net; the leaf refit folded into the epilogue, + 6 us net; the
-    // order blended over several steps, +- 0.)
+    // order blended over several steps, +- 0.  Round 6, profiles/r06_cost*_
+    // variants.jsonl, r06_phys_wave_log.txt: the order from hull pairs and
+    // contacts alone instead of the clock, +- 0; a cost that decays instead of
+    // being replaced, - 1 % of the kernel, the step unchanged; with the times
+    // the wavefronts took known beforehand the kernel would end 50-60 us
+    // earlier -- last step's cost predicts this step's with r = 0.64.)
     const int32_t *world_order = params.worldOrder;
     const int32_t num_jobs = (num_worlds + worlds_per_wave - 1) / worlds_per_wave;
 
@@ -1332,7 +1334,7 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                          first += Scratch::polyRows) {
                         if (kind == 1 && solo_rank >= first &&
                                 solo_rank < first + Scratch::polyRows) {
-                            has_contact = collidePairLane<MADRONA_PHYS_LDS_MESH>(pair,
+                            has_contact = collidePairLane(pair,
                                 w->scratch.lanePoly() +
                                     (solo_rank - first) * Scratch::polyDwords,
                                 stage + lane, &too_big, &unsupported,
@@ -1392,8 +1394,7 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                     PairSetup shared_pair =
                         ldsSetupPair(w, obj_mgr, candidateAt(chunk + src));
                     // every lane writes the same contact to src's slot
-                    const bool found = hullHullWave<LPW, HullScratch, PackedContact,
-                                                    MADRONA_PHYS_LDS_MESH>(lane, shared_pair,
+                    const bool found = hullHullWave<LPW>(lane, shared_pair,
                         w->scratch.hull(), stage + src, &pair_too_big,
                         PHYS_HH_PROF());
                     // the lane that owns the candidate learns the outcome

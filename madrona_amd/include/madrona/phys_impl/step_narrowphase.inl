@@ -36,40 +36,6 @@ struct alignas(16) WaveScratch {
     HullScratch hull;
 };
 
-// A hull mesh whose arrays are KNOWN to sit in LDS (the workgroup's primitive
-// image): the same mesh with pointers the compiler may turn into ds_read.  A
-// pointer loaded from memory is generic, and a flat load of a 12- or 16-byte
-// record that lands in LDS takes 4 x a ds_read with eight wavefronts per CU
-// doing the same (profiles/tools/lds_flat_latency.hip: 512 against 126 cycles).
-template <typename T>
-__device__ inline T *knownLds(T *p)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    __builtin_assume(__builtin_amdgcn_is_shared((const void *)p));
-#endif
-    return p;
-}
-
-__device__ inline HalfEdgeMesh knownLdsMesh(const HalfEdgeMesh &mesh)
-{
-    HalfEdgeMesh r = mesh;
-    r.halfEdges = knownLds(r.halfEdges);
-    r.faceBaseHalfEdges = knownLds(r.faceBaseHalfEdges);
-    r.facePlanes = knownLds(r.facePlanes);
-    r.vertices = knownLds(r.vertices);
-    return r;
-}
-
-__device__ inline bool meshInLds(const HalfEdgeMesh &mesh)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_amdgcn_is_shared((const void *)mesh.vertices);
-#else
-    (void)mesh;
-    return false;
-#endif
-}
-
 // number of vertices of face `face_idx`
 template <typename HullT>
 __device__ inline uint32_t faceVertexCount(const HullT &h, uint32_t face_idx)
@@ -232,19 +198,16 @@ __device__ inline bool hullHullWaveSAT(uint32_t lane, const PairSetup &pair,
 // clipped polygon may not fit the LDS scratch.
 // (A template so that only the device pass instantiates it.  Keeping it out of
 // line to confine its register footprint was measured: 1166 -> 1637 us.)
-// MeshesInLds: the caller has checked meshInLds() of both hulls.
 template <int LPW = 64, typename ScratchT = HullScratch,
-          typename OutT = ContactConstraint, bool MeshesInLds = false>
+          typename OutT = ContactConstraint>
 __device__ inline bool
 hullHullWave(uint32_t lane, const PairSetup &pair,
                                     ScratchT *scratch,
                                     OutT *out, bool *too_big,
                                     HullHullProf prof = HullHullProf {})
 {
-    const HalfEdgeMesh a_mesh = MeshesInLds ?
-        knownLdsMesh(pair.aPrim->hull.halfEdgeMesh) : pair.aPrim->hull.halfEdgeMesh;
-    const HalfEdgeMesh b_mesh = MeshesInLds ?
-        knownLdsMesh(pair.bPrim->hull.halfEdgeMesh) : pair.bPrim->hull.halfEdgeMesh;
+    const HalfEdgeMesh &a_mesh = pair.aPrim->hull.halfEdgeMesh;
+    const HalfEdgeMesh &b_mesh = pair.bPrim->hull.halfEdgeMesh;
 
     if (a_mesh.numVertices <= ScratchT::elems &&
         a_mesh.numFaces <= ScratchT::elems &&
@@ -599,8 +562,7 @@ __device__ inline bool hullHullWaveSAT(uint32_t lane, const PairSetup &pair,
 // scratch in the lane's LDS row.
 // row: poly_verts points + poly_verts depths of clipping scratch (a hull whose
 // face has more corners comes back with *too_big set)
-// MeshesInLds: the caller has checked meshInLds() of the pair's hull.
-template <bool MeshesInLds = false, typename OutT>
+template <typename OutT>
 __device__ inline bool collidePairLane(const PairSetup &pair, float *row,
                                        OutT *out,
                                        bool *too_big, bool *unsupported,
@@ -612,10 +574,7 @@ __device__ inline bool collidePairLane(const PairSetup &pair, float *row,
     case NarrowphaseTest::SpherePlane:
         return spherePlaneContact(pair, out);
     case NarrowphaseTest::HullPlane: {
-        const HalfEdgeMesh a_mesh = MeshesInLds ?
-            knownLdsMesh(pair.aPrim->hull.halfEdgeMesh) :
-            pair.aPrim->hull.halfEdgeMesh;
-        LazyHull a(a_mesh, pair.a.pos, pair.a.rot,
+        LazyHull a(pair.aPrim->hull.halfEdgeMesh, pair.a.pos, pair.a.rot,
                    pair.a.scale, false);
 
         // the contact polygon is (part of) the face SAT picks: it must fit
@@ -626,10 +585,7 @@ __device__ inline bool collidePairLane(const PairSetup &pair, float *row,
     }
     case NarrowphaseTest::SphereHull: {
         // hull in the sphere's frame, evaluated lazily (no centroid needed)
-        const HalfEdgeMesh b_mesh = MeshesInLds ?
-            knownLdsMesh(pair.bPrim->hull.halfEdgeMesh) :
-            pair.bPrim->hull.halfEdgeMesh;
-        LazyHull b(b_mesh, pair.b.pos - pair.a.pos,
+        LazyHull b(pair.bPrim->hull.halfEdgeMesh, pair.b.pos - pair.a.pos,
                    pair.b.rot, pair.b.scale, false);
         return sphereHullContact(pair, b, out);
     }
