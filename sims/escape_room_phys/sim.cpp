@@ -1278,12 +1278,18 @@ ESCPHYS_SYSTEM_IO(lidarSystem,
 // (131 registers with the leaf tests' loads batched -- one too many for the
 // four wavefronts per SIMD the ray systems want:
 // profiles/r03_lidar_occupancy_variants.jsonl)
+#ifndef ESCPHYS_GRABQ_WAVES
+#define ESCPHYS_GRABQ_WAVES 4
+#endif
+#ifndef ESCPHYS_LIDAR_WAVES
+#define ESCPHYS_LIDAR_WAVES 4
+#endif
 template <> inline constexpr unsigned
-    madrona::mwhip::systemWavesPerSIMD<escphys::lidarSystem> = 4;
+    madrona::mwhip::systemWavesPerSIMD<escphys::lidarSystem> = ESCPHYS_LIDAR_WAVES;
 #ifdef SIM_WAVE_API
 // (131 registers as well; a wavefront per world of dependent loads: 50 -> 44 us)
 template <> inline constexpr unsigned
-    madrona::mwhip::systemWavesPerSIMD<escphys::grabQuerySystem> = 4;
+    madrona::mwhip::systemWavesPerSIMD<escphys::grabQuerySystem> = ESCPHYS_GRABQ_WAVES;
 #endif
 namespace escphys {
 #endif
