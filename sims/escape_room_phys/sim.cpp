@@ -1278,18 +1278,14 @@ ESCPHYS_SYSTEM_IO(lidarSystem,
 // (131 registers with the leaf tests' loads batched -- one too many for the
 // four wavefronts per SIMD the ray systems want:
 // profiles/r03_lidar_occupancy_variants.jsonl)
-#ifndef ESCPHYS_GRABQ_WAVES
-#define ESCPHYS_GRABQ_WAVES 4
-#endif
-#ifndef ESCPHYS_LIDAR_WAVES
-#define ESCPHYS_LIDAR_WAVES 4
-#endif
 template <> inline constexpr unsigned
-    madrona::mwhip::systemWavesPerSIMD<escphys::lidarSystem> = ESCPHYS_LIDAR_WAVES;
+    madrona::mwhip::systemWavesPerSIMD<escphys::lidarSystem> = 4;
 #ifdef SIM_WAVE_API
-// (131 registers as well; a wavefront per world of dependent loads: 50 -> 44 us)
+// (131 registers as well; a wavefront per world of dependent loads: 50 -> 44 us;
+// five / six / eight wavefronts per SIMD: 44.0 / 45.5 / 50.4 us with 27 / 109 /
+// 439 spilled dwords, profiles/r06_grabq_variants.jsonl)
 template <> inline constexpr unsigned
-    madrona::mwhip::systemWavesPerSIMD<escphys::grabQuerySystem> = ESCPHYS_GRABQ_WAVES;
+    madrona::mwhip::systemWavesPerSIMD<escphys::grabQuerySystem> = 4;
 #endif
 namespace escphys {
 #endif
