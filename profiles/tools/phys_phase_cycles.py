@@ -37,8 +37,8 @@ with Simulator(hip_lib_path('escape_room_phys'), W, seed=5, flags=200) as hip:
     names = ['np.setup', 'candidates', 'integrate', 'np.solo', 'solvePos+jnt+setVel', 'np.hull+compact', '(end of substeps)', 'joints / store (+ refit)', 'load bodies (rows -> block)', 'stage prims', 'world lookup (singletons, row ranges)', 'solveVel']
     tot = out.sum()
     for n, v in zip(names, out):
-        print(f'{n:42s} {v / N / W:10.0f} ticks/world/step  {100 * v / tot:5.1f}%')
-    print('total ticks/world/step', tot / N / W, '(s_memtime @100MHz => us =', tot / N / W / 100, ')')
+        print(f'{n:42s} {v / N / W:10.0f} cycles per wavefront and step  {100 * v / tot:5.1f}%')
+    print('total cycles per wavefront and step (shader clock)', tot / N / W)
     # event counts of the same steps (lane 0 of every world)
     hull, hull_hit, solo, cands = (float(v) / N / W for v in events)
     print(f'per world and step (4 substeps): {cands:.1f} candidate tests, {solo:.1f} per-lane '
@@ -51,4 +51,4 @@ with Simulator(hip_lib_path('escape_room_phys'), W, seed=5, flags=200) as hip:
           f'overlapping {hh[8]:.2f}')
     for n, v in zip(['hulls -> LDS', 'face query A', 'face query B', 'edge query',
                      'manifold'], hh[:5]):
-        print(f'  hull-hull {n:14s} {v:10.0f} ticks/world/step')
+        print(f'  hull-hull {n:14s} {v:10.0f} cycles per wavefront and step')
