@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MWHIP_ABI_VERSION 6u   /* 6: mwhip_node_desc::write_mask (same-dependency nodes whose signatures clash keep their own launches); 5: mwhip_node_desc::pfor_body, mwhip_pfor_body(), mwhip_set_pfor_group_kernel() (side-by-side ParallelFor nodes in one launch); 4: io_declared */
+#define MWHIP_ABI_VERSION 7u   /* 7: mwhip_node_desc::pfor_group_kernel (a node's body is only called from the group kernel of the code object that defines it); 6: mwhip_node_desc::write_mask (same-dependency nodes whose signatures clash keep their own launches); 5: mwhip_node_desc::pfor_body, mwhip_pfor_body(), mwhip_set_pfor_group_kernel() (side-by-side ParallelFor nodes in one launch); 4: io_declared */
 
 typedef struct mwhip_exec mwhip_exec; /* opaque; == MWCudaExecutor::Impl */
 
@@ -332,6 +332,12 @@ typedef struct mwhip_node_desc {
      * siblings may still rely on registration order).  0 with pfor_body set
      * means "writes nothing"; nodes built without a signature pass ~0u. */
     uint32_t write_mask;
+    /* ParallelFor nodes with a pfor_body: the group kernel of the code object
+     * that defines the body (its registers, scratch and LDS were sized with this
+     * body in it).  Only nodes that name the SAME group kernel share a launch,
+     * and that kernel is the one launched.  NULL: the executor's default,
+     * mwhip_set_pfor_group_kernel(). */
+    const void *pfor_group_kernel;
 } mwhip_node_desc;
 
 /* Members of a grouped launch, in device memory (the group kernel's argument). */

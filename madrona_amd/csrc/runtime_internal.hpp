@@ -214,6 +214,7 @@ struct KernelLaunch {
 
     // ---- side-by-side ParallelFor nodes in one launch (groupLaunches) ----
     const void *pforBody = nullptr;         // mwhip_node_desc::pfor_body
+    const void *pforGroupKernel = nullptr;  // ... ::pfor_group_kernel (or the executor's)
     uint32_t pforArg1 = 0;                  // num_matching | exclusive-world flag
     bool rowSnapshot = false;               // the node can append rows: never grouped
     uint32_t pforVgprs = 0;                 // of the node's own kernel (groupLaunches)

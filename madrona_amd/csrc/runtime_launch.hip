@@ -450,6 +450,8 @@ static int buildLaunchList(mwhip_exec *exec, const std::vector<uint32_t> &tg_ids
                     k.pforArgs = pa;
                     k.rowSnapshot = pa.row_sync != nullptr;
                     k.pforBody = d.pfor_body;
+                    k.pforGroupKernel = d.pfor_group_kernel != nullptr ?
+                        d.pfor_group_kernel : exec->pforGroupKernel;
                     k.pforArg1 = d.arg1;
                     k.pforVgprs = (uint32_t)std::max(attr.numRegs, 0);
                     k.pforWriteMask = d.write_mask;
@@ -868,8 +870,7 @@ MWHIP_RT void releaseLaunchGraph(LaunchGraph &lg)
 // launch (rounds 1-4).
 static int groupLaunches(mwhip_exec *exec, LaunchGraph &lg)
 {
-    if (envU32("MADRONA_MWHIP_GROUP", 1) == 0 || exec->pforGroupKernel == nullptr ||
-            exec->eagerReplay) {
+    if (envU32("MADRONA_MWHIP_GROUP", 1) == 0 || exec->eagerReplay) {
         return 0;
     }
     // A member is reached through a function pointer: the shared kernel is
@@ -880,7 +881,8 @@ static int groupLaunches(mwhip_exec *exec, LaunchGraph &lg)
     // a node whose own kernel needs more than this many VGPRs keeps its launch.
     const uint32_t max_vgprs = envU32("MADRONA_MWHIP_GROUP_MAX_VGPRS", 96);
     auto groupable = [&](const KernelLaunch &k) {
-        return k.dagKernel && k.pforBody != nullptr && !k.rowSnapshot &&
+        return k.dagKernel && k.pforBody != nullptr &&
+            k.pforGroupKernel != nullptr && !k.rowSnapshot &&
             k.pforVgprs <= max_vgprs &&
             k.countMode == MWHIP_COUNT_QUERY_ROWS && k.tgNode >= 0 &&
             k.tgId < exec->taskGraphs.size();
@@ -940,6 +942,9 @@ static int groupLaunches(mwhip_exec *exec, LaunchGraph &lg)
             while (j < lg.launches.size() && j - i < MWHIP_PFOR_GROUP_MAX &&
                    groupable(lg.launches[j]) &&
                    lg.launches[j].tgId == lg.launches[i].tgId &&
+                   // (a body is only called from the group kernel of the code
+                   // object that defines it)
+                   lg.launches[j].pforGroupKernel == lg.launches[i].pforGroupKernel &&
                    depsOf(lg.launches[j]) == deps) {
                 bool clash = false;
                 for (size_t m = i; m < j; m++) {
@@ -957,7 +962,7 @@ static int groupLaunches(mwhip_exec *exec, LaunchGraph &lg)
         mwhip_pfor_group group {};
         group.count = (uint32_t)(j - i);
         KernelLaunch g;
-        g.fn = exec->pforGroupKernel;
+        g.fn = lg.launches[i].pforGroupKernel;
         uint32_t threads = 0;
         std::string name = "group[";
         for (size_t m = i; m < j; m++) {

@@ -813,6 +813,7 @@ CustomParallelForNode<ContextT, Fn, threads_per_invocation,
     if constexpr (items_per_invocation == 1) {
         // the node's body for grouped launches, and this module's group kernel
         desc.pfor_body = mwhip_pfor_body(builder.exec(), desc.kernel);
+        desc.pfor_group_kernel = group_stub();
         (void)mwhip_set_pfor_group_kernel(builder.exec(), group_stub());
     }
 #endif
