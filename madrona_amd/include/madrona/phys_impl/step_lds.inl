@@ -1498,12 +1498,34 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                 }
 
                 for (uint32_t l = 0; l <= max_level; l++) {
+#ifdef MADRONA_PHYS_ONE_LANE_SOLVE
                     if (lane < n && level == l) {
                         float lambda_n[4] { 0.f, 0.f, 0.f, 0.f };
                         xpbd::handleContact(store, w->contacts()[i].view(),
                                             lambda_n);
                         w->lambdas[i] = lambda_n[0];
                     }
+#else
+                    // two lanes per contact, a body each (xpbd::paired): the
+                    // level's contacts in index order over the world's teams
+                    const uint64_t members =
+                        wave::groupBallot<LPW>(lane < n && level == l);
+                    const uint32_t count = (uint32_t)__builtin_popcountll(members);
+                    for (uint32_t first = 0; first < count; first += LPW / 2) {
+                        const uint32_t team = first + (lane >> 1);
+                        if (team < count) {
+                            const uint32_t ci =
+                                base + wave::nthSetBit<LPW>(members, team);
+                            const bool second = (lane & 1u) != 0u;
+                            float lambda_n[4] { 0.f, 0.f, 0.f, 0.f };
+                            xpbd::paired::handleContact(second, store,
+                                w->contacts()[ci].view(), lambda_n);
+                            if (!second) {
+                                w->lambdas[ci] = lambda_n[0];
+                            }
+                        }
+                    }
+#endif
                     wave::phaseFence();
                 }
             }
@@ -1559,6 +1581,7 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                 }
 
                 for (uint32_t l = 0; l <= max_level; l++) {
+#ifdef MADRONA_PHYS_ONE_LANE_SOLVE
                     if (lane < n && level == l) {
                         float lambda_n[4] { w->lambdas[i], 0.f, 0.f, 0.f };
                         xpbd::solveVelocitiesForContact(store,
@@ -1566,6 +1589,23 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                             lambda_n, w->sys.h,
                             w->sys.restitutionThreshold);
                     }
+#else
+                    const uint64_t members =
+                        wave::groupBallot<LPW>(lane < n && level == l);
+                    const uint32_t count = (uint32_t)__builtin_popcountll(members);
+                    for (uint32_t first = 0; first < count; first += LPW / 2) {
+                        const uint32_t team = first + (lane >> 1);
+                        if (team < count) {
+                            const uint32_t ci =
+                                base + wave::nthSetBit<LPW>(members, team);
+                            float lambda_n[4] { w->lambdas[ci], 0.f, 0.f, 0.f };
+                            xpbd::paired::solveVelocitiesForContact(
+                                (lane & 1u) != 0u, store,
+                                w->contacts()[ci].view(), lambda_n, w->sys.h,
+                                w->sys.restitutionThreshold);
+                        }
+                    }
+#endif
                     wave::phaseFence();
                 }
             }

@@ -66,6 +66,30 @@ __device__ inline uint32_t rankInGroup(uint64_t mask, uint32_t lane)
     return (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
 }
 
+// position of the n-th set bit of a group ballot (n < its population count)
+template <int LPW = 64>
+__device__ inline uint32_t nthSetBit(uint64_t mask, uint32_t n)
+{
+    uint32_t pos = 0;
+    if constexpr (LPW == 64) {
+        const uint32_t low = (uint32_t)__builtin_popcount((uint32_t)mask);
+        const bool high = n >= low;
+        n = high ? n - low : n;
+        pos = high ? 32u : 0u;
+        mask = high ? mask >> 32 : mask;
+    }
+    uint32_t m = (uint32_t)mask;
+#pragma unroll
+    for (uint32_t width = 16; width != 0; width >>= 1) {
+        const uint32_t below = (uint32_t)__builtin_popcount(m & ((1u << width) - 1u));
+        const bool up = n >= below;
+        n = up ? n - below : n;
+        pos += up ? width : 0u;
+        m = up ? m >> width : m;
+    }
+    return pos;
+}
+
 // arg-max over the wave where the LOWEST index wins among equal values -- the
 // result of a sequential "if (v > best)" scan in index order.  Every lane
 // returns the winner.  (Lane-local values are never NaN: they start at

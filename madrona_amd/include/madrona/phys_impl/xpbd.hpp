@@ -801,6 +801,353 @@ MADRONA_HD inline void solveVelocitiesForContact(
     *v2_out = Velocity { v2, omega2 };
 }
 
+#if defined(__HIPCC__)
+// ---------------------------------------------------------------------------
+// The same solves by TWO lanes per constraint (this backend, device only).
+// A contact's position solve and velocity solve are symmetric in its two
+// bodies: each body's anchor, torque axis, generalised inverse mass and its
+// own update are computed from that body's state alone, and the bodies meet in
+// a handful of scalars (the gap along the normal, w1 + w2, the relative
+// velocity).  One lane per constraint does both bodies one after the other --
+// about a thousand instructions a level, and the step kernel is bound by the
+// instructions it issues.  Here lane `2t` of a team
+// holds the constraint's first body (`second` = false) and lane `2t + 1` its
+// second; what the other body contributed arrives by a lane exchange, and what
+// involves both is evaluated by both lanes with the operands in the order of
+// the one-lane routines above: same expressions on the same operands, the same
+// bits.  The second body's updates are subtractions there (x2 -= ..., q2 -= ...);
+// a - b and a + (-b) are the same IEEE operation.
+// Both lanes of a team must be in the call together (the level loops of
+// phys_impl/step_lds.inl see to it).
+// ---------------------------------------------------------------------------
+namespace paired {
+
+// the other lane of the team: lanes 2t and 2t + 1 swap inside their quad (a DPP
+// move: no LDS round trip)
+__device__ inline float partner(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(
+        __builtin_bit_cast(int, v), 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF,
+        true));
+}
+
+__device__ inline Vector3 partner(Vector3 v)
+{
+    return Vector3 { partner(v.x), partner(v.y), partner(v.z) };
+}
+
+// (what body 1 has) - (what body 2 has), from this lane's value
+__device__ inline Vector3 firstMinusSecond(bool second, Vector3 mine)
+{
+    const Vector3 theirs = partner(mine);
+    return (second ? theirs : mine) - (second ? mine : theirs);
+}
+
+// w1 + w2 (+ alpha_tilde: computePositionalLambda adds it even when it is 0)
+__device__ inline float bothInverseMasses(bool second, float w_mine)
+{
+    const float w_theirs = partner(w_mine);
+    return (second ? w_theirs : w_mine) + (second ? w_mine : w_theirs);
+}
+
+__device__ inline Vector3 signedFor(bool second, Vector3 v)
+{
+    return Vector3 { second ? -v.x : v.x, second ? -v.y : v.y, second ? -v.z : v.z };
+}
+
+// applyPositionalImpulse, this lane's body
+__device__ inline void applyPositionalImpulse(bool second, Vector3 &x, Quat &q,
+                                              Vector3 rot_axis_local, float inv_m,
+                                              Vector3 n, float delta_lambda)
+{
+    x += signedFor(second, delta_lambda * inv_m * n);
+
+    float half_lambda = 0.5f * delta_lambda;
+    Vector3 q_update_angular = q.rotateVec(half_lambda * rot_axis_local);
+    Quat dq = Quat::fromAngularVec(q_update_angular) * q;
+    q += Quat { second ? -dq.w : dq.w, second ? -dq.x : dq.x,
+                second ? -dq.y : dq.y, second ? -dq.z : dq.z };
+    q = q.normalize();
+}
+
+// applyPositionalUpdate
+__device__ inline float applyPositionalUpdate(bool second, Vector3 &x, Quat &q,
+                                             Vector3 r, float inv_m, Vector3 inv_I,
+                                             Vector3 n_world, float c,
+                                             float alpha_tilde)
+{
+    Vector3 n_local = q.inv().rotateVec(n_world);
+    Vector3 torque_axis_local = cross(r, n_local);
+    Vector3 rot_axis_local = multDiag(inv_I, torque_axis_local);
+
+    float w = generalizedInverseMass(torque_axis_local, rot_axis_local, inv_m);
+    float lambda = -c / (bothInverseMasses(second, w) + alpha_tilde);
+
+    applyPositionalImpulse(second, x, q, rot_axis_local, inv_m, n_world, lambda);
+    return lambda;
+}
+
+// solveContactPoint
+__device__ inline void solveContactPoint(bool second, Vector3 &x, Quat &q,
+                                         SubstepPrevState prev, float inv_m,
+                                         Vector3 inv_I, Vector3 r, Vector3 n_world,
+                                         float avg_mu_s, float *lambda_n_out,
+                                         float *lambda_t_out)
+{
+    Vector3 p = q.rotateVec(r) + x;
+
+    float d = dot(firstMinusSecond(second, p), n_world);
+    if (d <= 0) {
+        return;
+    }
+
+    float lambda_n = applyPositionalUpdate(second, x, q, r, inv_m, inv_I,
+                                           n_world, d, 0);
+    *lambda_n_out = lambda_n;
+
+    Vector3 p_hat = prev.prevRotation.rotateVec(r) + prev.prevPosition;
+
+    p = q.rotateVec(r) + x;
+
+    Vector3 delta_p = firstMinusSecond(second, p - p_hat);
+    Vector3 delta_p_t = delta_p - dot(delta_p, n_world) * n_world;
+
+    float tangential_magnitude = delta_p_t.length();
+    if (tangential_magnitude > 0.f) {
+        Vector3 t_world = delta_p_t / tangential_magnitude;
+        Vector3 t_local = q.inv().rotateVec(t_world);
+
+        Vector3 friction_torque_axis_local = cross(r, t_local);
+        Vector3 friction_rot_axis_local =
+            multDiag(inv_I, friction_torque_axis_local);
+
+        float w = generalizedInverseMass(friction_torque_axis_local,
+                                         friction_rot_axis_local, inv_m);
+        float lambda_t =
+            -tangential_magnitude / (bothInverseMasses(second, w) + 0);
+        float lambda_threshold = lambda_n * avg_mu_s;
+
+        if (lambda_t > lambda_threshold) {
+            *lambda_t_out = lambda_t;
+
+            applyPositionalImpulse(second, x, q, friction_rot_axis_local, inv_m,
+                                   t_world, lambda_t);
+        }
+    }
+}
+
+// getLocalSpaceContacts, this lane's body
+__device__ inline Vector3 localSpaceContact(bool second,
+                                            const PreSolvePositional &presolve_pos,
+                                            Vector3 contact1,
+                                            float penetration_depth,
+                                            Vector3 contact_normal)
+{
+    Vector3 contact2 = contact1 - contact_normal * penetration_depth;
+    return presolve_pos.q.inv().rotateVec(
+        (second ? contact2 : contact1) - presolve_pos.x);
+}
+
+// handleContact; lambdas[0] is the first lane's to keep
+template <typename StoreT, typename ContactT>
+__device__ inline void handleContact(bool second, StoreT &store,
+                                     const ContactT &contact, float *lambdas)
+{
+    const Loc me = second ? contact.alt : contact.ref;
+    Vector3 *x_ptr = &store.position(me);
+    Quat *q_ptr = &store.rotation(me);
+
+    SubstepPrevState prev = store.prevState(me);
+    PreSolvePositional presolve_pos = store.presolvePositional(me);
+    BodyConstants c = store.constants(me);
+
+    Vector3 x = *x_ptr;
+    Quat q = *q_ptr;
+
+    const float mu_theirs = partner(c.friction.muS);
+    float avg_mu_s = 0.5f * ((second ? mu_theirs : c.friction.muS) +
+                             (second ? c.friction.muS : mu_theirs));
+
+    Vector3 avg_contact_pos;
+    float contact_pos_penetration;
+    if (getAvgContact(contact, &avg_contact_pos, &contact_pos_penetration)) {
+        return;
+    }
+
+    Vector3 r = localSpaceContact(second, presolve_pos, avg_contact_pos,
+                                  contact_pos_penetration, contact.normal);
+
+    float lambda_n = 0.f;
+    float lambda_t = 0.f;
+
+    solveContactPoint(second, x, q, prev, c.invMass, c.invInertia, r,
+                      contact.normal, avg_mu_s, &lambda_n, &lambda_t);
+
+    lambdas[0] = lambda_n;
+
+    *x_ptr = x;
+    *q_ptr = q;
+}
+
+// (v1 + omega1 x dir1) - (v2 + omega2 x dir2): computeRelativeVelocity
+__device__ inline Vector3 relativeVelocity(bool second, Vector3 v, Vector3 omega,
+                                           Vector3 dir)
+{
+    return firstMinusSecond(second, v + cross(omega, dir));
+}
+
+__device__ inline void applyRestitutionVelocityUpdate(
+    bool second, Vector3 &v, Vector3 &omega, Quat q, float inv_m, Vector3 inv_I,
+    Vector3 n, float restitution_threshold, Vector3 r_world,
+    Vector3 restitution_torque_axis_local, float vn_bar)
+{
+    Vector3 v_rel = relativeVelocity(second, v, omega, r_world);
+
+    float vn = dot(n, v_rel);
+
+    float e = 0.3f;
+    if (fabsf(vn_bar) <= restitution_threshold) {
+        e = 0.f;
+    }
+
+    float restitution_magnitude = fminf(-e * vn_bar, 0) - vn;
+
+    Vector3 restitution_rot_axis_local =
+        multDiag(inv_I, restitution_torque_axis_local);
+
+    float w = generalizedInverseMass(restitution_torque_axis_local,
+                                     restitution_rot_axis_local, inv_m);
+
+    float inv_mass_scale = 1.f / bothInverseMasses(second, w);
+
+    float impulse_magnitude = restitution_magnitude * inv_mass_scale;
+    if (impulse_magnitude == 0.f) {
+        return;
+    }
+
+    v += signedFor(second, n * impulse_magnitude * inv_m);
+    omega += signedFor(second,
+        q.rotateVec(impulse_magnitude * restitution_rot_axis_local));
+}
+
+__device__ inline void applyFrictionVelocityUpdate(
+    bool second, Vector3 &v, Vector3 &omega, Quat q, float inv_m, Vector3 inv_I,
+    Vector3 n, float mu_d, float h, Vector3 r_local, Vector3 r_world,
+    float lambda)
+{
+    Vector3 v_rel = relativeVelocity(second, v, omega, r_world);
+
+    float vn = dot(n, v_rel);
+    Vector3 vt = v_rel - n * vn;
+
+    float vt_len = vt.length();
+    if (vt_len == 0.f) {
+        return;
+    }
+
+    Vector3 delta_world = vt / vt_len;
+
+    Vector3 delta_local = q.inv().rotateVec(delta_world);
+
+    Vector3 friction_torque_axis_local = cross(r_local, delta_local);
+    Vector3 friction_rot_axis_local =
+        multDiag(inv_I, friction_torque_axis_local);
+
+    float w = generalizedInverseMass(friction_torque_axis_local,
+                                     friction_rot_axis_local, inv_m);
+
+    float inv_mass_scale = 1.f / bothInverseMasses(second, w);
+
+    float dynamic_friction_magnitude =
+        mu_d * fabsf(lambda) * inv_mass_scale / h;
+
+    float corrected_magnitude = -fminf(dynamic_friction_magnitude, vt_len);
+
+    float impulse_magnitude = corrected_magnitude * inv_mass_scale;
+    if (impulse_magnitude == 0.f) {
+        return;
+    }
+
+    v += signedFor(second, delta_world * impulse_magnitude * inv_m);
+    omega += signedFor(second,
+        q.rotateVec(impulse_magnitude * friction_rot_axis_local));
+}
+
+// solveVelocitiesForContact
+template <typename StoreT, typename ContactT>
+__device__ inline void solveVelocitiesForContact(
+    bool second, StoreT &store, const ContactT &contact, const float *lambda_n,
+    float h, float restitution_threshold)
+{
+    const Loc me = second ? contact.alt : contact.ref;
+    Velocity *v_out = &store.velocity(me);
+
+    Quat q = store.rotation(me);
+
+    PreSolvePositional presolve_pos = store.presolvePositional(me);
+    PreSolveVelocity presolve_vel = store.presolveVelocity(me);
+    BodyConstants c = store.constants(me);
+
+    Vector3 v = v_out->linear;
+    Vector3 omega = v_out->angular;
+
+    const float mu_theirs = partner(c.friction.muD);
+    float mu_d = 0.5f * ((second ? mu_theirs : c.friction.muD) +
+                         (second ? c.friction.muD : mu_theirs));
+
+    {
+        Vector3 avg_contact_pos;
+        float contact_pos_penetration;
+        if (getAvgContact(contact, &avg_contact_pos,
+                          &contact_pos_penetration)) {
+            return;
+        }
+
+        Vector3 r = localSpaceContact(second, presolve_pos, avg_contact_pos,
+                                      contact_pos_penetration, contact.normal);
+
+        Vector3 r_presolve = presolve_pos.q.rotateVec(r);
+
+        Vector3 v_bar = relativeVelocity(second, presolve_vel.v,
+                                         presolve_vel.omega, r_presolve);
+
+        float vn_bar = dot(contact.normal, v_bar);
+
+        Vector3 r_world = q.rotateVec(r);
+
+        Vector3 restitution_torque_axis_local =
+            cross(r, q.inv().rotateVec(contact.normal));
+
+        applyRestitutionVelocityUpdate(
+            second, v, omega, q, c.invMass, c.invInertia, contact.normal,
+            restitution_threshold, r_world, restitution_torque_axis_local,
+            vn_bar);
+    }
+
+    float penetration_sum = 0.f;
+    for (CountT i = 0; i < contact.numPoints; i++) {
+        penetration_sum += contact.points[i].w;
+    }
+
+    for (CountT i = 0; i < contact.numPoints; i++) {
+        Vector3 r = localSpaceContact(second, presolve_pos,
+                                      contact.points[i].xyz(),
+                                      contact.points[i].w, contact.normal);
+
+        Vector3 r_world = q.rotateVec(r);
+
+        applyFrictionVelocityUpdate(
+            second, v, omega, q, c.invMass, c.invInertia, contact.normal, mu_d,
+            h, r, r_world,
+            lambda_n[0] * (contact.points[i].w / penetration_sum));
+    }
+
+    *v_out = Velocity { v, omega };
+}
+
+}
+#endif
+
 // ECS-backed conveniences
 MADRONA_HD inline void handleContact(Context &ctx,
                                      const ObjectManager &obj_mgr,
