@@ -1545,12 +1545,28 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                 uint32_t max_level = wave::maxReduce<LPW>(lane < n ? level : 0);
 
                 for (uint32_t l = 0; l <= max_level; l++) {
+#if defined(MADRONA_PHYS_ONE_LANE_SOLVE) || defined(MADRONA_PHYS_ONE_LANE_JOINTS)
                     if (lane < n && level == l) {
                         // (rows beyond the block's: out of the sorted table)
                         xpbd::handleJointConstraint(store, l1, l2,
                             lane < (uint32_t)Block::maxJoints ? w->joints[lane] :
                                                                 joints[lane]);
                     }
+#else
+                    // (two lanes per joint, an end each; at most maxJointBodies
+                    // joints: one round of teams)
+                    const uint64_t members =
+                        wave::groupBallot<LPW>(lane < n && level == l);
+                    const uint32_t team = lane >> 1;
+                    if (team < (uint32_t)__builtin_popcountll(members)) {
+                        const uint32_t j = wave::nthSetBit<LPW>(members, team);
+                        const bool second = (lane & 1u) != 0u;
+                        const Loc me { 0, (int32_t)w->jointBodies[j][second ? 1 : 0] };
+                        // (rows beyond the block's: out of the sorted table)
+                        xpbd::paired::handleJointConstraint(second, store, me,
+                            j < (uint32_t)Block::maxJoints ? w->joints[j] : joints[j]);
+                    }
+#endif
                     wave::phaseFence();
                 }
             }

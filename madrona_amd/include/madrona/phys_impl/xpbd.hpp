@@ -843,6 +843,14 @@ __device__ inline Vector3 firstMinusSecond(bool second, Vector3 mine)
     return (second ? theirs : mine) - (second ? mine : theirs);
 }
 
+// (what body 2 has) - (what body 1 has): not the negation of the above when
+// the two are equal (+0 either way)
+__device__ inline Vector3 secondMinusFirst(bool second, Vector3 mine)
+{
+    const Vector3 theirs = partner(mine);
+    return (second ? mine : theirs) - (second ? theirs : mine);
+}
+
 // w1 + w2 (+ alpha_tilde: computePositionalLambda adds it even when it is 0)
 __device__ inline float bothInverseMasses(bool second, float w_mine)
 {
@@ -984,6 +992,130 @@ __device__ inline void handleContact(bool second, StoreT &store,
                       contact.normal, avg_mu_s, &lambda_n, &lambda_t);
 
     lambdas[0] = lambda_n;
+
+    *x_ptr = x;
+    *q_ptr = q;
+}
+
+__device__ inline Quat partner(Quat v)
+{
+    return Quat { partner(v.w), partner(v.x), partner(v.y), partner(v.z) };
+}
+
+// computeAngularUpdate + applyAngularUpdate, this lane's body (n: delta_q in its
+// frame)
+__device__ inline void applyAngularUpdate(bool second, Quat &q, Vector3 inv_I,
+                                          Vector3 n, float theta, float alpha_tilde)
+{
+    Vector3 local_rot_axis = multDiag(inv_I, n);
+    float w = dot(n, local_rot_axis);
+
+    float delta_lambda = -theta / (bothInverseMasses(second, w) + alpha_tilde);
+    float half_lambda = 0.5f * delta_lambda;
+
+    Quat u = Quat::fromAngularVec(q.rotateVec(half_lambda * local_rot_axis));
+    Quat dq = u * q;
+    q = (q + Quat { second ? -dq.w : dq.w, second ? -dq.x : dq.x,
+                    second ? -dq.y : dq.y, second ? -dq.z : dq.z }).normalize();
+}
+
+// solveJoint
+__device__ inline void solveJoint(bool second, const JointConstraint &joint,
+                                  Vector3 &x, Quat &q, float inv_m, Vector3 inv_I)
+{
+    const Vector3 r = second ? joint.r2 : joint.r1;
+
+    Vector3 pos_correction;
+    if (joint.type == JointConstraint::Type::Fixed) {
+        JointConstraint::Fixed fixed_data = joint.fixed;
+        const Quat attach_q = second ? fixed_data.attachRot2 : fixed_data.attachRot1;
+
+        // applyJointOrientationConstraint
+        {
+            Quat orientation = (q * attach_q).normalize();
+            Quat theirs = partner(orientation);
+            Quat diff = (second ? theirs : orientation) *
+                (second ? orientation : theirs).inv();
+
+            Vector3 delta_q = 2.f * Vector3 { diff.x, diff.y, diff.z };
+            float delta_q_magnitude = delta_q.length();
+
+            if (delta_q_magnitude > 0) {
+                delta_q /= delta_q_magnitude;
+                Vector3 delta_q_local = q.inv().rotateVec(delta_q);
+
+                applyAngularUpdate(second, q, inv_I, delta_q_local,
+                                   delta_q_magnitude, 0);
+            }
+        }
+
+        Vector3 r_world = q.rotateVec(r) + x;
+        // (r2_world - r1_world)
+        Vector3 delta_r = secondMinusFirst(second, r_world);
+
+        // (the first body's, after its update)
+        Quat axes_mine = (q * fixed_data.attachRot1).normalize();
+        Quat axes_theirs = partner(axes_mine);
+        Quat axes_rot = second ? axes_theirs : axes_mine;
+
+        Vector3 a1 = axes_rot.rotateVec(math::fwd);
+        Vector3 b1 = axes_rot.rotateVec(math::right);
+        Vector3 c1 = cross(a1, b1);
+
+        pos_correction = Vector3::zero();
+        float a_separation = dot(delta_r, a1);
+        pos_correction -= (a_separation - fixed_data.separation) * a1;
+        float b_separation = dot(delta_r, b1);
+        pos_correction -= b_separation * b1;
+        float c_separation = dot(delta_r, c1);
+        pos_correction -= c_separation * c1;
+    } else {
+        JointConstraint::Hinge hinge_data = joint.hinge;
+
+        // applyJointAxisConstraint
+        {
+            Vector3 axis = q.rotateVec(second ? hinge_data.a2Local :
+                                                hinge_data.a1Local);
+            Vector3 theirs = partner(axis);
+            Vector3 delta_q = cross(second ? theirs : axis, second ? axis : theirs);
+            float delta_q_magnitude = delta_q.length();
+
+            if (delta_q_magnitude > 0) {
+                delta_q /= delta_q_magnitude;
+                Vector3 delta_q_local = q.inv().rotateVec(delta_q);
+
+                applyAngularUpdate(second, q, inv_I, delta_q_local,
+                                   delta_q_magnitude, 0);
+            }
+        }
+
+        Vector3 r_world = q.rotateVec(r) + x;
+        pos_correction = secondMinusFirst(second, r_world);
+    }
+
+    float pos_correction_magnitude = pos_correction.length();
+    if (pos_correction_magnitude > 0.f) {
+        pos_correction /= pos_correction_magnitude;
+
+        applyPositionalUpdate(second, x, q, r, inv_m, inv_I, pos_correction,
+                              pos_correction_magnitude, 0);
+    }
+}
+
+// handleJointConstraint: `me` is this lane's end of the joint
+template <typename StoreT>
+__device__ inline void handleJointConstraint(bool second, StoreT &store, Loc me,
+                                             const JointConstraint &joint)
+{
+    Vector3 *x_ptr = &store.position(me);
+    Quat *q_ptr = &store.rotation(me);
+
+    Vector3 x = *x_ptr;
+    Quat q = *q_ptr;
+
+    BodyConstants c = store.constants(me);
+
+    solveJoint(second, joint, x, q, c.invMass, c.invInertia);
 
     *x_ptr = x;
     *q_ptr = q;
