@@ -1324,6 +1324,73 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                     }
                     PHYS_PROF(0);
 
+#ifndef MADRONA_PHYS_ONE_LANE_HULL_PLANE
+                    // hull against plane: two lanes a pair (hullPlaneContactTeam),
+                    // the pairs in lane order over the world's teams.  The team
+                    // reads the pair out of the registers of the lane that set it
+                    // up and hands the outcome back to it.
+                    if constexpr (LPW == 32) {
+                        const bool plane_pair = kind == 1 &&
+                            pair.test == NarrowphaseTest::HullPlane;
+                        const uint64_t plane_pairs =
+                            wave::groupBallot<LPW>(plane_pair);
+                        const uint32_t num_plane_pairs =
+                            (uint32_t)__builtin_popcountll(plane_pairs);
+                        const uint32_t my_rank = wave::rankInGroup(plane_pairs, lane);
+                        if (plane_pair) {
+                            kind = 3;       // (not one of the lanes on their own)
+                        }
+                        for (uint32_t first = 0; first < num_plane_pairs;
+                             first += LPW / 2) {
+                            const uint32_t team = first + (lane >> 1);
+                            const bool in_team = team < num_plane_pairs;
+                            const int src = (int)wave::nthSetBit<LPW>(plane_pairs,
+                                in_team ? team : 0u);
+                            auto from = [&](float v) { return __shfl(v, src, LPW); };
+                            const PrimitiveTransform a_txfm {
+                                { from(pair.a.pos.x), from(pair.a.pos.y),
+                                  from(pair.a.pos.z) },
+                                { from(pair.a.rot.w), from(pair.a.rot.x),
+                                  from(pair.a.rot.y), from(pair.a.rot.z) },
+                                { from(pair.a.scale.d0), from(pair.a.scale.d1),
+                                  from(pair.a.scale.d2) },
+                            };
+                            PrimitiveTransform plane_txfm = a_txfm;
+                            plane_txfm.pos = { from(pair.b.pos.x), from(pair.b.pos.y),
+                                               from(pair.b.pos.z) };
+                            plane_txfm.rot = { from(pair.b.rot.w), from(pair.b.rot.x),
+                                               from(pair.b.rot.y), from(pair.b.rot.z) };
+                            const unsigned long long prim_bits =
+                                (unsigned long long)(uintptr_t)pair.aPrim;
+                            const CollisionPrimitive *a_prim =
+                                (const CollisionPrimitive *)(uintptr_t)(
+                                    ((unsigned long long)(uint32_t)__shfl(
+                                        (int32_t)(prim_bits >> 32), src, LPW) << 32) |
+                                    (unsigned long long)(uint32_t)__shfl(
+                                        (int32_t)prim_bits, src, LPW));
+                            const int32_t a_row = __shfl(pair.aLoc.row, src, LPW);
+                            const int32_t b_row = __shfl(pair.bLoc.row, src, LPW);
+
+                            uint32_t outcome = 0;
+                            if (in_team) {
+                                LazyHull a(a_prim->hull.halfEdgeMesh, a_txfm.pos,
+                                           a_txfm.rot, a_txfm.scale, false);
+                                outcome = hullPlaneContactTeam<BlockScratch<LPW>::polyVerts>(
+                                    (lane & 1u) != 0u, a, plane_txfm,
+                                    Loc { 0, a_row }, Loc { 0, b_row }, stage + src);
+                            }
+                            // (the lane whose pair it is learns the outcome)
+                            const uint32_t mine = (uint32_t)__shfl((int32_t)outcome,
+                                (int)((my_rank - first) * 2u) & (LPW - 1), LPW);
+                            if (plane_pair && my_rank >= first &&
+                                    my_rank < first + LPW / 2) {
+                                has_contact = (mine & 1u) != 0u;
+                                too_big = (mine & 2u) != 0u;
+                            }
+                        }
+                    }
+#endif
+
                     // lanes on their own, in rounds of the block's scratch rows
                     using Scratch = BlockScratch<LPW>;
                     uint64_t solo = wave::groupBallot<LPW>(kind == 1);
@@ -1362,7 +1429,8 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
 #endif
 #ifdef MADRONA_PHYS_PROFILE_LDS
                 {
-                    const uint64_t solo_pairs = wave::groupBallot<LPW>(kind == 1);
+                    const uint64_t solo_pairs =
+                        wave::groupBallot<LPW>(kind == 1 || kind == 3);
                     if (lane == 0u) {
                         atomicAdd(&prof_lds[group][12],
                                   (uint32_t)__builtin_popcountll(hull_pairs));

@@ -558,6 +558,165 @@ __device__ inline bool hullHullWaveSAT(uint32_t lane, const PairSetup &pair,
     return found;
 }
 
+// ---------------------------------------------------------------------------
+// Hull against plane by a TEAM of two lanes (the two-worlds-per-wavefront
+// kernel; sequential reference: hullPlaneContact = doSATPlane +
+// createFacePlaneContact + buildFaceContactManifold, physics.inl /
+// narrowphase.hpp).  One lane per pair spends most of its ~1.2 K instructions
+// on loops over the hull's vertices and faces -- every vertex against the plane,
+// every face's normal for the incident face, the incident face's corners -- and
+// the kernel is bound by the instructions it issues.  Here
+// lane `second` = false takes the first half of every such range and its
+// partner the second half; the halves meet in a minimum, an arg-min (the lower
+// index wins ties: the first half's) and a corner count, exchanged inside the
+// quad.  Faces of up to MaxCorners corners (more: *too big*, like a face that
+// does not fit a lane's LDS row): the surviving corners stay in registers and go
+// straight into the packed contact, in ring order -- no clipping scratch.
+// Returns bit 0: a contact was written, bit 1: the face is too big.
+// ---------------------------------------------------------------------------
+__device__ inline float teamPartner(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(
+        __builtin_bit_cast(int, v), 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF,
+        true));
+}
+
+__device__ inline int32_t teamPartner(int32_t v)
+{
+    return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);
+}
+
+// (OutT: the LDS step's PackedContact)
+template <int MaxCorners = 4, typename OutT>
+__device__ inline uint32_t hullPlaneContactTeam(bool second, const LazyHull &a_hull,
+                                                const PrimitiveTransform &plane_txfm,
+                                                Loc a_loc, Loc b_loc,
+                                                OutT *out)
+{
+    static_assert(MaxCorners % 2 == 0);
+    constexpr Vector3 base_normal = { 0, 0, 1 };
+    Vector3 plane_normal = plane_txfm.rot.rotateVec(base_normal);
+
+    Plane plane { plane_normal, dot(plane_normal, plane_txfm.pos) };
+
+    // ---- doSATPlane: getHullDistanceFromPlane ----
+    {
+        const CountT num_verts = a_hull.numVertices();
+        const CountT half = (num_verts + 1) / 2;
+        const CountT end = second ? num_verts : half;
+        float min_dot_n = FLT_MAX;
+        for (CountT i = second ? half : 0; i < end; i++) {
+            float cur_dot = dot(a_hull.vertex(i), plane.normal);
+            if (cur_dot < min_dot_n) {
+                min_dot_n = cur_dot;
+            }
+        }
+        const float theirs = teamPartner(min_dot_n);
+        const float of_first = second ? theirs : min_dot_n;
+        const float of_second = second ? min_dot_n : theirs;
+        min_dot_n = of_second < of_first ? of_second : of_first;
+
+        float separation = min_dot_n - plane.d;
+        if (separation > 0.0f) {
+            return 0u;
+        }
+    }
+
+    // ---- findIncidentFace ----
+    int32_t incident_face_idx;
+    {
+        const CountT num_faces = a_hull.numFaces();
+        const CountT half = (num_faces + 1) / 2;
+        const CountT end = second ? num_faces : half;
+        float min_dot = FLT_MAX;
+        int32_t minimizing_face = -1;
+        for (CountT face_idx = second ? half : 0; face_idx < end; face_idx++) {
+            float face_dot_ref = dot(a_hull.plane(face_idx).normal, plane.normal);
+            if (face_dot_ref < min_dot) {
+                min_dot = face_dot_ref;
+                minimizing_face = (int32_t)face_idx;
+            }
+        }
+        const float their_dot = teamPartner(min_dot);
+        const int32_t their_face = teamPartner(minimizing_face);
+        const float first_dot = second ? their_dot : min_dot;
+        const float second_dot = second ? min_dot : their_dot;
+        const int32_t first_face = second ? their_face : minimizing_face;
+        const int32_t second_face = second ? minimizing_face : their_face;
+        incident_face_idx = second_dot < first_dot ? second_face : first_face;
+    }
+
+    // ---- the incident face's corners (every lane walks the ring, keeps the
+    // roots of its half) ----
+    constexpr int32_t mine_max = MaxCorners / 2;
+    uint32_t roots[mine_max];
+    int32_t num_corners = 0;
+    {
+#pragma unroll
+        for (int32_t j = 0; j < mine_max; j++) roots[j] = 0;
+        uint32_t hedge_idx = a_hull.faceBaseHedge(incident_face_idx);
+        const uint32_t start_hedge_idx = hedge_idx;
+        do {
+            const HalfEdge cur_hedge = a_hull.hedge(hedge_idx);
+            hedge_idx = cur_hedge.next;
+            const int32_t slot = num_corners - (second ? mine_max : 0);
+#pragma unroll
+            for (int32_t j = 0; j < mine_max; j++) {
+                if (slot == j) roots[j] = cur_hedge.rootVertex;
+            }
+            num_corners++;
+        } while (hedge_idx != start_hedge_idx);
+    }
+    if (num_corners > MaxCorners) {
+        return 2u;
+    }
+
+    // ---- createFacePlaneContact: the first lane holds corners [0, MaxCorners / 2),
+    // its partner the rest; what lies on or below the plane, projected onto it ----
+    Vector3 points[mine_max];
+    float depths[mine_max];
+    bool below[mine_max];
+    int32_t my_count = 0;
+#pragma unroll
+    for (int32_t j = 0; j < mine_max; j++) {
+        const int32_t corner = j + (second ? mine_max : 0);
+        Vector3 vertex = a_hull.vertex(roots[j]);
+        float d = getDistanceFromPlane(plane, vertex);
+        below[j] = corner < num_corners && d <= 0.0f;
+        points[j] = vertex - d * plane.normal;
+        depths[j] = -d;
+        my_count += below[j] ? 1 : 0;
+    }
+    const int32_t their_count = teamPartner(my_count);
+    const int32_t num_contacts = my_count + their_count;
+
+    // ---- buildFaceContactManifold (at most four points: all of them) +
+    // manifoldToContact: the plane is always b and always the reference ----
+    if (num_contacts == 0) {
+        return 0u;
+    }
+    const Vector3 world_offset { 0, 0, 0 };
+    const Quat to_world_frame { 1, 0, 0, 0 };
+    int32_t at = second ? their_count : 0;
+#pragma unroll
+    for (int32_t j = 0; j < mine_max; j++) {
+        if (below[j]) {
+            out->points[at] = math::Vector4::fromVec3W(
+                to_world_frame.rotateVec(points[j]) + world_offset, depths[j]);
+            at++;
+        }
+    }
+    if (!second) {
+        for (int32_t i = num_contacts; i < 4; i++) {
+            out->points[i] = math::Vector4::zero();
+        }
+        out->normal = to_world_frame.rotateVec(plane.normal);
+        out->meta = (uint32_t)b_loc.row | ((uint32_t)a_loc.row << 8) |
+            ((uint32_t)num_contacts << 16);
+    }
+    return 1u;
+}
+
 // Every other primitive pair: one lane, hull evaluated lazily, clipping
 // scratch in the lane's LDS row.
 // row: poly_verts points + poly_verts depths of clipping scratch (a hull whose
