@@ -1088,6 +1088,31 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
         }
         PHYS_PROF(9);
 
+        // ---- the other world of the wavefront (LPW = 32): a half whose world has
+        // no hull-hull pair left takes one of the other world's (the narrowphase
+        // below) -- only between worlds that read the same primitives ----------
+        [[maybe_unused]] bool may_share = false;
+        [[maybe_unused]] Block *const partner_w = &blocks[group ^ (worlds_per_wave - 1)];
+        auto fromPartner64 = [](unsigned long long v) {
+            return ((unsigned long long)(uint32_t)__shfl_xor((int32_t)(v >> 32), 32, 64)
+                        << 32) |
+                (unsigned long long)(uint32_t)__shfl_xor((int32_t)v, 32, 64);
+        };
+#ifndef MADRONA_PHYS_OWN_HULL_PAIRS
+        if constexpr (worlds_per_wave == 2) {
+            const uint64_t here = __builtin_amdgcn_ballot_w64(true);
+            if ((uint32_t)here != 0u && (uint32_t)(here >> 32) != 0u) {
+                may_share =
+                    fromPartner64((unsigned long long)(uintptr_t)
+                        obj_mgr.collisionPrimitives) ==
+                        (unsigned long long)(uintptr_t)obj_mgr.collisionPrimitives &&
+                    fromPartner64((unsigned long long)(uintptr_t)
+                        obj_mgr.primitiveAABBs) ==
+                        (unsigned long long)(uintptr_t)obj_mgr.primitiveAABBs;
+            }
+        }
+#endif
+
         // ---- broadphase: candidate pairs in (body, traversal) order -----------
         // lane = body; one pass over the slot boxes in traversal order leaves a
         // bit mask of hits, the pairs are written from the mask.  Slot boxes
@@ -1453,24 +1478,95 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                     }
                 }
 #endif
-                while (hull_pairs != 0) {
-                    // the next pair of the world, with all of its lanes
-                    const uint32_t src = (uint32_t)__builtin_ctzll(hull_pairs);
-                    hull_pairs &= hull_pairs - 1;
+                // Two worlds per wavefront: the halves share their pairs out.  A
+                // half with pairs of its own takes the first of them; one that has
+                // none left takes the LAST of the other world's while that world
+                // still has two or more (it takes its first itself) -- both halves
+                // derive who takes what from the same two masks, so nothing is
+                // agreed on at run time.  The test runs on the taker's lanes and
+                // in its scratch; the contact lands in the slot of the lane that
+                // owns the candidate, which also learns the outcome.
+                [[maybe_unused]] uint32_t other_pairs = 0;
+                [[maybe_unused]] bool partner_takes = false;
+                [[maybe_unused]] uint32_t partner_chunk = 0, partner_contacts = 0;
+                [[maybe_unused]] WaveCandidate *partner_spilled = nullptr;
+                if constexpr (worlds_per_wave == 2) {
+                    const uint64_t all = __builtin_amdgcn_ballot_w64(kind == 2);
+                    const uint64_t here = __builtin_amdgcn_ballot_w64(true);
+                    const uint32_t partner_shift = group != 0 ? 0u : 32u;
+                    partner_takes = may_share &&
+                        (uint32_t)(here >> partner_shift) != 0u;
+                    if (partner_takes) {
+                        other_pairs = (uint32_t)(all >> partner_shift);
+                    }
+                    partner_chunk = (uint32_t)__shfl_xor((int32_t)chunk, 32, 64);
+                    partner_contacts =
+                        (uint32_t)__shfl_xor((int32_t)num_contacts, 32, 64);
+                    partner_spilled = (WaveCandidate *)(uintptr_t)fromPartner64(
+                        (unsigned long long)(uintptr_t)spilled_candidates);
+                }
+                while (hull_pairs != 0 ||
+                       (worlds_per_wave == 2 &&
+                        __builtin_popcount(other_pairs) >= 2)) {
+                    // the next pair of the world, with all of its lanes -- or the
+                    // other world's last
+                    const bool steal = hull_pairs == 0;
+                    uint32_t src;
+                    if (!steal) {
+                        src = (uint32_t)__builtin_ctzll(hull_pairs);
+                    } else {
+                        src = 31u - (uint32_t)__builtin_clz(other_pairs);
+                    }
+                    // (what the other half does in this round, from the same masks)
+                    int32_t taken_from_me = -1;
+                    if constexpr (worlds_per_wave == 2) {
+                        if (partner_takes && other_pairs == 0 &&
+                                __builtin_popcountll(hull_pairs) >= 2) {
+                            taken_from_me = 63 - __builtin_clzll(hull_pairs);
+                        }
+                        if (steal) {
+                            // (the other half takes its first, this one its last)
+                            other_pairs &= other_pairs - 1;
+                            other_pairs &= ~(1u << src);
+                        } else if (other_pairs != 0) {
+                            other_pairs &= other_pairs - 1;
+                        }
+                    }
+                    if (!steal) {
+                        hull_pairs &= hull_pairs - 1;
+                    }
+                    if (taken_from_me >= 0) {
+                        hull_pairs &= ~(1ull << taken_from_me);
+                    }
 
                     bool pair_too_big = false;
-                    PairSetup shared_pair =
-                        ldsSetupPair(w, obj_mgr, candidateAt(chunk + src));
-                    // every lane writes the same contact to src's slot
+                    const Block *pair_world = steal ? partner_w : w;
+                    const uint32_t c = (steal ? partner_chunk : chunk) + src;
+                    const WaveCandidate candidate =
+                        c < (uint32_t)Block::maxCandidates ? pair_world->candidates[c] :
+                            (steal ? partner_spilled : spilled_candidates)[
+                                c - (uint32_t)Block::maxCandidates];
+                    PairSetup shared_pair = ldsSetupPair(pair_world, obj_mgr, candidate);
+                    PackedContact *pair_out = steal ?
+                        partner_w->contacts() + partner_contacts + src : stage + src;
+                    // every lane writes the same contact to the owner's slot
                     const bool found = hullHullWave<LPW>(lane, shared_pair,
-                        w->scratch.hull(), stage + src, &pair_too_big,
+                        w->scratch.hull(), pair_out, &pair_too_big,
                         PHYS_HH_PROF());
                     // the lane that owns the candidate learns the outcome
                     const uint32_t outcome = __shfl(
                         (found ? 1u : 0u) | (pair_too_big ? 2u : 0u), 0, LPW);
-                    if (lane == src) {
+                    if (!steal && lane == src) {
                         has_contact = (outcome & 1u) != 0u;
                         too_big = (outcome & 2u) != 0u;
+                    }
+                    if constexpr (worlds_per_wave == 2) {
+                        const uint32_t theirs =
+                            (uint32_t)__shfl_xor((int32_t)outcome, 32, 64);
+                        if (taken_from_me >= 0 && (int32_t)lane == taken_from_me) {
+                            has_contact = (theirs & 1u) != 0u;
+                            too_big = (theirs & 2u) != 0u;
+                        }
                     }
 #ifdef MADRONA_PHYS_PROFILE
                     if (lane == 0) {

@@ -50,6 +50,9 @@ __device__ inline uint32_t faceVertexCount(const HullT &h, uint32_t face_idx)
     return n;
 }
 
+template <int LPW>
+__device__ inline Vector3 shflVec3(Vector3 v, int src);
+
 // SAT face query with the faces of `a` spread over the lanes (sequential
 // reference: narrowphase.hpp queryFaceDirections)
 template <int LPW = 64, typename HullA, typename HullB>
@@ -91,6 +94,7 @@ __device__ inline EdgeQuery queryEdgeDirectionsWave(uint32_t lane,
 {
     float best_sep = -FLT_MAX;
     uint32_t best_pair = 0xFFFFFFFFu;
+    Vector3 best_normal = Vector3::zero();
 
     const uint32_t b_num_edges = (uint32_t)b.numEdges();
     const uint32_t num_pairs = (uint32_t)a.numEdges() * b_num_edges;
@@ -101,6 +105,7 @@ __device__ inline EdgeQuery queryEdgeDirectionsWave(uint32_t lane,
         if (r.separation > best_sep) {
             best_sep = r.separation;
             best_pair = p;
+            best_normal = r.normal;
         }
     }
     wave::argMaxFirst<LPW>(best_sep, best_pair);
@@ -114,8 +119,9 @@ __device__ inline EdgeQuery queryEdgeDirectionsWave(uint32_t lane,
     } else {
         best.edgeIdxA = (int32_t)((best_pair / b_num_edges) * 2);
         best.edgeIdxB = (int32_t)((best_pair % b_num_edges) * 2);
-        best.normal =
-            testEdgePair(a, b, best.edgeIdxA, best.edgeIdxB).normal;
+        // (the lane that tested the winning pair -- pair p went to lane p % LPW --
+        // still holds its normal: no second test of the pair)
+        best.normal = shflVec3<LPW>(best_normal, (int)(best_pair % (uint32_t)LPW));
     }
     return best;
 }
