@@ -969,7 +969,9 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
     // contacts alone instead of the clock, +- 0; a cost that decays instead of
     // being replaced, - 1 % of the kernel, the step unchanged; with the times
     // the wavefronts took known beforehand the kernel would end 50-60 us
-    // earlier -- last step's cost predicts this step's with r = 0.64.)
+    // earlier -- last step's cost predicts this step's with r = 0.64; the k-th
+    // heaviest with the k-th lightest again, now that the halves share their
+    // hull-hull pairs out: + 12-15 us, r06_pairing_variants.jsonl.)
     const int32_t *world_order = params.worldOrder;
     const int32_t num_jobs = (num_worlds + worlds_per_wave - 1) / worlds_per_wave;
 
