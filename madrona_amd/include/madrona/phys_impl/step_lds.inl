@@ -1100,7 +1100,6 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                         << 32) |
                 (unsigned long long)(uint32_t)__shfl_xor((int32_t)v, 32, 64);
         };
-#ifndef MADRONA_PHYS_OWN_HULL_PAIRS
         if constexpr (worlds_per_wave == 2) {
             const uint64_t here = __builtin_amdgcn_ballot_w64(true);
             if ((uint32_t)here != 0u && (uint32_t)(here >> 32) != 0u) {
@@ -1113,7 +1112,6 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                         (unsigned long long)(uintptr_t)obj_mgr.primitiveAABBs;
             }
         }
-#endif
 
         // ---- broadphase: candidate pairs in (body, traversal) order -----------
         // lane = body; one pass over the slot boxes in traversal order leaves a
@@ -1351,7 +1349,6 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                     }
                     PHYS_PROF(0);
 
-#ifndef MADRONA_PHYS_ONE_LANE_HULL_PLANE
                     // hull against plane: two lanes a pair (hullPlaneContactTeam),
                     // the pairs in lane order over the world's teams.  The team
                     // reads the pair out of the registers of the lane that set it
@@ -1416,7 +1413,6 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                             }
                         }
                     }
-#endif
 
                     // lanes on their own, in rounds of the block's scratch rows
                     using Scratch = BlockScratch<LPW>;
@@ -1664,14 +1660,6 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                 }
 
                 for (uint32_t l = 0; l <= max_level; l++) {
-#ifdef MADRONA_PHYS_ONE_LANE_SOLVE
-                    if (lane < n && level == l) {
-                        float lambda_n[4] { 0.f, 0.f, 0.f, 0.f };
-                        xpbd::handleContact(store, w->contacts()[i].view(),
-                                            lambda_n);
-                        w->lambdas[i] = lambda_n[0];
-                    }
-#else
                     // two lanes per contact, a body each (xpbd::paired): the
                     // level's contacts in index order over the world's teams
                     const uint64_t members =
@@ -1691,7 +1679,6 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                             }
                         }
                     }
-#endif
                     wave::phaseFence();
                 }
             }
@@ -1711,14 +1698,6 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                 uint32_t max_level = wave::maxReduce<LPW>(lane < n ? level : 0);
 
                 for (uint32_t l = 0; l <= max_level; l++) {
-#if defined(MADRONA_PHYS_ONE_LANE_SOLVE) || defined(MADRONA_PHYS_ONE_LANE_JOINTS)
-                    if (lane < n && level == l) {
-                        // (rows beyond the block's: out of the sorted table)
-                        xpbd::handleJointConstraint(store, l1, l2,
-                            lane < (uint32_t)Block::maxJoints ? w->joints[lane] :
-                                                                joints[lane]);
-                    }
-#else
                     // (two lanes per joint, an end each; at most maxJointBodies
                     // joints: one round of teams)
                     const uint64_t members =
@@ -1732,7 +1711,6 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                         xpbd::paired::handleJointConstraint(second, store, me,
                             j < (uint32_t)Block::maxJoints ? w->joints[j] : joints[j]);
                     }
-#endif
                     wave::phaseFence();
                 }
             }
@@ -1763,15 +1741,6 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                 }
 
                 for (uint32_t l = 0; l <= max_level; l++) {
-#ifdef MADRONA_PHYS_ONE_LANE_SOLVE
-                    if (lane < n && level == l) {
-                        float lambda_n[4] { w->lambdas[i], 0.f, 0.f, 0.f };
-                        xpbd::solveVelocitiesForContact(store,
-                            w->contacts()[i].view(),
-                            lambda_n, w->sys.h,
-                            w->sys.restitutionThreshold);
-                    }
-#else
                     const uint64_t members =
                         wave::groupBallot<LPW>(lane < n && level == l);
                     const uint32_t count = (uint32_t)__builtin_popcountll(members);
@@ -1787,7 +1756,6 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
                                 w->sys.restitutionThreshold);
                         }
                     }
-#endif
                     wave::phaseFence();
                 }
             }

@@ -591,7 +591,7 @@ static inline void resetWorldWave(Engine &ctx)
     // order, which is the order ids are handed out in
     const bool is_button = in_level && k < consts::numButtonsPerRoom;
     const bool is_door = in_level && k == consts::numButtonsPerRoom;
-    const bool is_cube = in_level && k > consts::numButtonsPerRoom;
+    [[maybe_unused]] const bool is_cube = in_level && k > consts::numButtonsPerRoom;
     const uint32_t archetype = is_button ? TypeTracker::typeID<ButtonEntity>() :
         (is_door ? TypeTracker::typeID<DoorEntity>() :
                    TypeTracker::typeID<PhysicsEntity>());
