@@ -927,6 +927,9 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
     Block *w = &blocks[group];
     LdsBodyStore<MAXB, LPW> store { w };
 
+#ifdef MADRONA_PHYS_PROFILE_LDS_HH
+#define MADRONA_PHYS_PROFILE_LDS 1
+#endif
 #ifdef MADRONA_PHYS_PROFILE_LDS
     // (the phase profile of a build that keeps its registers: the accumulators
     // sit in what the block leaves of the workgroup's LDS, one ds_add per mark)
@@ -934,9 +937,17 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
     if (lane < 16u) prof_lds[group][lane] = 0u;
     unsigned long long prof_t = __builtin_readcyclecounter();
 #undef PHYS_PROF
+#ifdef MADRONA_PHYS_PROFILE_LDS_HH
+    // (the stages of the hull-hull tests instead of the phases: same slots)
+#define PHYS_PROF(slot) do { (void)prof_t; } while (0)
+#undef PHYS_HH_PROF
+#define PHYS_HH_PROF() HullHullProf { &prof_lds[group][0], \
+        (unsigned long long)__builtin_readcyclecounter() }
+#else
 #define PHYS_PROF(slot) do { unsigned long long now_ = __builtin_readcyclecounter(); \
         if (lane == 0u) atomicAdd(&prof_lds[group][slot], (uint32_t)(now_ - prof_t)); \
         prof_t = now_; } while (0)
+#endif
 #endif
 #ifdef MADRONA_PHYS_PROFILE
     unsigned long long prof_t = __builtin_readcyclecounter();
@@ -949,7 +960,7 @@ physicsStepLdsKernel(EcsState *S, void *node_data, uint32_t, uint32_t)
 #else
 #define PHYS_HH_PROF() HullHullProf {}
 #endif
-#else
+#elif !defined(MADRONA_PHYS_PROFILE_LDS_HH)
 #define PHYS_HH_PROF() HullHullProf {}
 #endif
 

@@ -172,7 +172,22 @@ __device__ inline void hullCentroid(LazyHull &) {}     // (has it already)
 // extra accumulators push the kernel into spilling, which inflates the phase
 // figures of the same build; use it for the stage split and exit counts only.
 struct HullHullProf {
-#ifdef MADRONA_PHYS_PROFILE_HH
+#ifdef MADRONA_PHYS_PROFILE_LDS_HH
+    // (accumulators in LDS, slots 0 .. 8 of the step kernel's prof_lds row: a
+    // build that keeps its registers, profiles/tools/phys_phase_cycles.py HH)
+    uint32_t *acc;
+    unsigned long long t;
+    __device__ inline void mark(uint32_t lane, int slot)
+    {
+        unsigned long long now = __builtin_readcyclecounter();
+        if (lane == 0u) atomicAdd(&acc[slot], (uint32_t)(now - t));
+        t = now;
+    }
+    __device__ inline void count(uint32_t lane, int slot)
+    {
+        if (lane == 0u) atomicAdd(&acc[slot], 1u);
+    }
+#elif defined(MADRONA_PHYS_PROFILE_HH)
     unsigned long long *acc;
     unsigned long long t;
     __device__ inline void mark(uint32_t, int slot)

@@ -36,13 +36,41 @@ __device__ inline uint32_t exclusiveScan(uint32_t v, uint32_t lane,
     return incl - v;
 }
 
+// A lane's partner in the four steps that reduce a row of 16 lanes: the other
+// lane of its pair, the other pair of its quad, the mirror lane of its eight,
+// the mirror lane of its row -- DPP moves (a VALU operand modifier: no LDS
+// crossbar round trip, where __shfl_xor is a ds_bpermute of ~100 cycles a step).
+// After the four every lane holds the row's result; groups wider than a row
+// finish with __shfl_xor.  The reductions below are commutative and associative
+// (ties included), so the order of the steps does not show in the result.
+template <int Ctrl>
+__device__ inline uint32_t dppMove(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, Ctrl, 0xF, 0xF, true);
+}
+template <int Ctrl>
+__device__ inline float dppMove(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(
+        __builtin_bit_cast(int, v), Ctrl, 0xF, 0xF, true));
+}
+inline constexpr int dppSwapPairs = 0xB1;       // quad_perm:[1,0,3,2]
+inline constexpr int dppSwapHalfQuads = 0x4E;   // quad_perm:[2,3,0,1]
+inline constexpr int dppHalfMirror = 0x141;     // row_half_mirror
+inline constexpr int dppMirror = 0x140;         // row_mirror
+
 template <int LPW = 64>
 __device__ inline uint32_t maxReduce(uint32_t v)
 {
+    static_assert(LPW >= 16);
+    auto with = [&](uint32_t o) { v = o > v ? o : v; };
+    with(dppMove<dppSwapPairs>(v));
+    with(dppMove<dppSwapHalfQuads>(v));
+    with(dppMove<dppHalfMirror>(v));
+    with(dppMove<dppMirror>(v));
 #pragma unroll
-    for (uint32_t d = LPW / 2; d > 0; d >>= 1) {
-        uint32_t o = __shfl_xor(v, d, LPW);
-        v = o > v ? o : v;
+    for (uint32_t d = 16; d < (uint32_t)LPW; d <<= 1) {
+        with((uint32_t)__shfl_xor(v, d, LPW));
     }
     return v;
 }
@@ -97,14 +125,20 @@ __device__ inline uint32_t nthSetBit(uint64_t mask, uint32_t n)
 template <int LPW = 64>
 __device__ inline void argMaxFirst(float &v, uint32_t &idx)
 {
-#pragma unroll
-    for (uint32_t d = LPW / 2; d > 0; d >>= 1) {
-        float ov = __shfl_xor(v, d, LPW);
-        uint32_t oi = __shfl_xor(idx, d, LPW);
+    static_assert(LPW >= 16);
+    auto with = [&](float ov, uint32_t oi) {
         if (ov > v || (ov == v && oi < idx)) {
             v = ov;
             idx = oi;
         }
+    };
+    with(dppMove<dppSwapPairs>(v), dppMove<dppSwapPairs>(idx));
+    with(dppMove<dppSwapHalfQuads>(v), dppMove<dppSwapHalfQuads>(idx));
+    with(dppMove<dppHalfMirror>(v), dppMove<dppHalfMirror>(idx));
+    with(dppMove<dppMirror>(v), dppMove<dppMirror>(idx));
+#pragma unroll
+    for (uint32_t d = 16; d < (uint32_t)LPW; d <<= 1) {
+        with(__shfl_xor(v, d, LPW), (uint32_t)__shfl_xor(idx, d, LPW));
     }
 }
 

@@ -31,7 +31,12 @@ with Simulator(hip_lib_path('escape_room_phys'), W, seed=5, flags=200) as hip:
     hip.step(N)
     out = np.zeros(32, np.uint64)
     rt.mwhip_memcpy_d2h(out.ctypes.data, buf, 256)
-    hh, events, out = out[16:], out[12:16], out[:12]
+    if os.environ.get('PHYS_PROFILE_HH_IN_LDS'):
+        # (-DMADRONA_PHYS_PROFILE_LDS_HH: the hull-hull stages sit in slots 0..8)
+        hh, events, out = np.concatenate([out[:9], np.zeros(7, np.uint64)]), out[12:16], np.zeros(12, np.uint64)
+        out[0] = 1
+    else:
+        hh, events, out = out[16:], out[12:16], out[:12]
     # (slot 2 also collects the velocity solve of the substep before it, slot 6
     # only that of the last substep: see the PHYS_PROF marks in world_step.inl)
     names = ['np.setup', 'candidates', 'integrate', 'np.solo', 'solvePos+jnt+setVel', 'np.hull+compact', '(end of substeps)', 'joints / store (+ refit)', 'load bodies (rows -> block)', 'stage prims', 'world lookup (singletons, row ranges)', 'solveVel']
