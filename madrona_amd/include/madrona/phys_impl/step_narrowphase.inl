@@ -53,9 +53,6 @@ __device__ inline uint32_t faceVertexCount(const HullT &h, uint32_t face_idx)
 template <int LPW>
 __device__ inline Vector3 shflVec3(Vector3 v, int src);
 
-#ifndef MADRONA_PHYS_EDGE_UNROLL
-#define MADRONA_PHYS_EDGE_UNROLL 1
-#endif
 // SAT face query with the faces of `a` spread over the lanes (sequential
 // reference: narrowphase.hpp queryFaceDirections)
 template <int LPW = 64, typename HullA, typename HullB>
@@ -101,9 +98,8 @@ __device__ inline EdgeQuery queryEdgeDirectionsWave(uint32_t lane,
 
     const uint32_t b_num_edges = (uint32_t)b.numEdges();
     const uint32_t num_pairs = (uint32_t)a.numEdges() * b_num_edges;
-    // (two rounds' worth of loads in flight: a round is a chain of four dependent
-    // reads -- half edge, its neighbour, their faces and vertices)
-#pragma unroll MADRONA_PHYS_EDGE_UNROLL
+    // (two or three rounds per iteration -- #pragma unroll -- to have their loads
+    // in flight together: no difference, profiles/r06_edge_unroll_variants.jsonl)
     for (uint32_t p = lane; p < num_pairs; p += LPW) {
         int32_t he_idx_a = (int32_t)((p / b_num_edges) * 2);
         int32_t he_idx_b = (int32_t)((p % b_num_edges) * 2);
