@@ -106,7 +106,9 @@ __device__ inline uint32_t constraintLevels(uint32_t lane, uint32_t n,
 // (Round 6 also built the levels without this chain of dependent shuffles --
 // conflict masks in n independent rounds, then one ballot per level -- and
 // measured no difference at two wavefronts per SIMD: 525-530 us against
-// 524-526, profiles/r06_levels_variants.jsonl.  Not kept.)
+// 524-526, profiles/r06_levels_variants.jsonl.  Not kept.  Constraint j's words
+// through v_readlane instead of __shfl: step 0.802 -> 0.812 ms, ten more
+// spilled SGPRs.  Not kept either.)
 template <int LPW = 64>
 __device__ inline uint32_t constraintLevels(uint32_t lane, uint32_t n,
                                             uint32_t key_a, uint32_t key_b)
